@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY.  Fixture generator; run in the build container only
+(`python oracle/make_golden.py`): it reads DATA the reference holds under /root/reference and writes
+small fixtures into tests/golden/.  Nothing here runs on the GPU box.
+
+What it extracts (data only — inputs and expected outputs, never source text):
+
+ 1. ultranest_points.npz — the reference's OWN stored nested-sampling run
+    (docs/src/data/inference/results/points.hdf5 + info/results.json): ~6e3 parameter points with the
+    log-likelihood the reference (Julia) computed for each, on the time series
+    docs/src/data/subset_simu_single_subset_time_series.txt (N=242, irregular).  The model is the one
+    of docs/src/ultranest.md:197-219 / examples/ultranest/single_pl.jl with the shift `c`:
+        sigma2 = nu * yerr^2 / (y - c)^2 ; yn = log(y - c)
+        R = approx(SingleBendingPowerLaw(a1, f1, a2), f_min, f_max, 20, variance, basis "SHO")
+        logpdf(ScalableGP(mu, R)(t, sigma2), yn)
+    The stored values are reproduced by v1.2.0's code with `is_integrated_power=false` (variance
+    normalisation — the normalisation in force when the run was made; cf. docs/src/diagnostics.md:80).
+    HDF5 is parsed by hand (no h5py in the image): one chunked, unfiltered float64 dataset
+    "points" of 17 columns [Lmin, logl, quality, u(7), params(7)], 256x5 chunks, v1 B-tree.
+
+ 2. reference_literals.json — numeric literals of the reference's tests that pin the path:
+    test/test_psd.jl:30-39 (20 SHO amplitudes), test/test_acvf.jl:19-33, test/test_covariancefunctions.jl,
+    test/test_carma.jl:55-69, test/test_scalablegp.jl:110-118 (N=6 series x 10 parameter sets),
+    test/test_likelihood.jl:9-18 (parameters for data/simu_log.txt).
+
+ 3. simu_log.txt, simu.txt — the reference's test data files (test/data/), verbatim data.
+
+ 4. relation_cases.json — for the inputs of (2)/(3), log-likelihood values of THIS oracle, stored only
+    after they satisfy the reference's own relation celerite == -dense (rtol 1.49e-8,
+    test/test_likelihood.jl:58-59) by a wide margin and agree with an mpmath (50-digit) evaluation of
+    the dense Gaussian log-density on the N=6 cases.  These are restatement values, flagged as such.
+"""
+from __future__ import annotations
+
+import json
+import re
+import shutil
+import struct
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+REF = Path("/root/reference")
+OUT = ROOT / "tests" / "golden"
+sys.path.insert(0, str(ROOT))
+from oracle import oracle as O  # noqa: E402
+
+
+def parse_points_hdf5(path: Path, ncols: int = 17) -> np.ndarray:
+    raw = path.read_bytes()
+    assert raw[:8] == b"\x89HDF\r\n\x1a\n"
+    ndims = 3  # rank-2 dataset + element-size dimension
+
+    def walk(addr, out):
+        assert raw[addr:addr + 4] == b"TREE"
+        ntype, level, nent = struct.unpack("<BBH", raw[addr + 4:addr + 8])
+        assert ntype == 1
+        p = addr + 24
+        for _ in range(nent):
+            csz, fmask = struct.unpack("<II", raw[p:p + 8])
+            offs = struct.unpack("<%dQ" % ndims, raw[p + 8:p + 8 + 8 * ndims])
+            p += 8 + 8 * ndims
+            (child,) = struct.unpack("<Q", raw[p:p + 8])
+            p += 8
+            if level == 0:
+                assert fmask == 0, "filtered chunks not supported"
+                out.append((offs, child, csz))
+            else:
+                walk(child, out)
+
+    roots = []
+    for m in re.finditer(rb"TREE", raw):
+        a = m.start()
+        ntype, level, nent = struct.unpack("<BBH", raw[a + 4:a + 8])
+        if ntype == 1:
+            roots.append((level, a))
+    top = max(roots)[1]
+    chunks = []
+    walk(top, chunks)
+    crow = 256
+    ccol = 5
+    assert all(c[2] == crow * ccol * 8 for c in chunks)
+    nrow = max(c[0][0] for c in chunks) + crow
+    arr = np.full((nrow, 4 * ccol), np.nan)
+    for offs, addr, csz in chunks:
+        blk = np.frombuffer(raw[addr:addr + csz], dtype="<f8").reshape(crow, ccol)
+        arr[offs[0]:offs[0] + crow, offs[1]:offs[1] + ccol] = blk
+    arr = arr[:, :ncols]
+    valid = np.isfinite(arr).all(axis=1) & (arr[:, 1] != 0.0)
+    return arr[valid]
+
+
+def make_ultranest_fixture():
+    series = np.loadtxt(REF / "docs/src/data/subset_simu_single_subset_time_series.txt")
+    t, y, yerr = series[:, 0], series[:, 1], series[:, 2]
+    pts = parse_points_hdf5(REF / "docs/src/data/inference/results/points.hdf5")
+    info = json.loads((REF / "docs/src/data/inference/info/results.json").read_text())
+    ml = info["maximum_likelihood"]
+    params = pts[:, 10:17].copy()
+    logl = pts[:, 1].copy()
+    # the stored maximum-likelihood point must be among them
+    k = int(np.argmax(logl))
+    assert logl[k] == ml["logl"] and np.allclose(params[k], ml["point"], rtol=0, atol=0)
+    # sanity: this oracle reproduces a sample of the reference's values
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for i in rng.choice(len(logl), 64, replace=False):
+        a1, f1, a2, var, nu, mu, cs = params[i]
+        a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, a1, f1, a2), f_min, f_max, 20, var,
+                              is_integrated_power=False)
+        v = O.logl(a, b, c, d, t, np.log(y - cs) - mu, nu * yerr ** 2 / (y - cs) ** 2)
+        worst = max(worst, abs(v - logl[i]) / abs(logl[i]))
+    print(f"ultranest fixture: {len(logl)} points, oracle-vs-reference worst rel err on 64 = {worst:.2e}")
+    assert worst < 1e-11
+    np.savez_compressed(
+        OUT / "ultranest_points.npz", t=t, y=y, yerr=yerr, params=params, logl=logl,
+        paramnames=np.array(info["paramnames"]), n_components=20, basis_function="SHO",
+        is_integrated_power=False,
+        note="logl = values computed by the reference (Julia) itself; see oracle/make_golden.py")
+
+
+def make_literals():
+    lit = {
+        "psd_amplitudes": {  # test/test_psd.jl:30-39
+            "cite": "test/test_psd.jl:30-39",
+            "model": "SingleBendingPowerLaw", "params": [0.3, 0.02, 2.93],
+            "f0": 0.02, "fM": 1.52e2, "J": 20,
+            "expected": [1.3749158408973243, 0.26031747510091013, 0.06961116778917277,
+                         0.013679642568525807, 0.0037949128465199307, 0.0008858780578830132,
+                         0.00023278915565955668, 5.714159750636342e-5, 1.463191298808472e-5,
+                         3.6532013241322788e-6, 9.262211884550235e-7, 2.3267166983266322e-7,
+                         5.877072005450016e-8, 1.4801031386988674e-8, 3.728877337268077e-9,
+                         9.44575715327315e-10, 2.3313738171903584e-10, 6.377629826311069e-11,
+                         1.119218106083312e-11, 6.962520986945091e-12],
+        },
+        "acvf_sum_scaled_exp": {  # test/test_acvf.jl:19-24: 12.5 * (Exp(1.0,0.34) + Exp(2.4,0.21))
+            "cite": "test/test_acvf.jl:19-24",
+            "terms": [["Exp", 1.0, 0.34], ["Exp", 2.4, 0.21]], "scale": 12.5,
+            "expected": [[12.5 / 2, 30.0 / 2], [0.0, 0.0], [0.34, 0.21], [0.0, 0.0]],
+        },
+        "acvf_large_sum": {  # test/test_acvf.jl:26-33
+            "cite": "test/test_acvf.jl:26-33",
+            "terms": [["Exp", 1.0, 0.34], ["Celerite", 1.3, 4.2, 1.3, 5.2], ["Exp", 2.4, 0.21],
+                      ["Celerite", 3.3, 1.2, 3.3, 2.13]],
+            "expected": [[1.0 / 2, 1.3, 2.4 / 2, 3.3], [0.0, 4.2, 0.0, 1.2], [0.34, 1.3, 0.21, 3.3],
+                         [0.0, 5.2, 0.0, 2.13]],
+        },
+        "coefs_celerite": {"cite": "test/test_covariancefunctions.jl:18-22", "args": [1.3, 4.0, 0.5, 3.2],
+                           "expected": [1.3, 4.0, 0.5, 3.2]},
+        "coefs_sho": {"cite": "test/test_covariancefunctions.jl:38-42", "A": 1.5, "w0_over_2pi": 0.23},
+        "coefs_sho_throws": {"cite": "test/test_covariancefunctions.jl:32-36", "A": 1.5, "w0_over_2pi": 0.23,
+                             "Q": 0.5, "message": "SHO with Q≠1/√2 not implemented yet"},
+        "coefs_exp": {"cite": "test/test_covariancefunctions.jl:44-47", "args": [2.3, 0.2],
+                      "expected": [2.3 / 2, 0.0, 0.2, 0.0]},
+        "carma32": {  # test/test_carma.jl:55-69
+            "cite": "test/test_carma.jl:55-69", "p": 3, "q": 2,
+            "r_alpha": [[-0.042163209825323775, 1.1115603157767922],
+                        [-0.042163209825323775, -1.1115603157767922], [-0.7599101571312047, 0.0]],
+            "beta": [3.9413022090550216, 11.38193903188344, 1], "norm": 1.3,
+            "expected": [[1.332733901854476, -0.03273390185447589], [-0.026820976815752837, 0.0],
+                         [0.042163209825323775, 0.7599101571312047], [-1.1115603157767922, 0.0]],
+        },
+        "scalablegp_n6": {  # test/test_scalablegp.jl:109-132
+            "cite": "test/test_scalablegp.jl:109-132",
+            "t": [0.0, 3.0, 3.2, 3.4, 45.5, 101.2], "y": [1.3, 2.2, 4.21, 2.5, 3.3, 5.2],
+            "yerr": [0.1, 0.2, 0.1, 0.1, 0.2, 0.1],
+            "alpha1": [0.2, 0.03, 0.1, 0.46, 0.1, 0.21, 0.74, 0.1, 0.03, 0.92],
+            "f1": [1.3e-2, 1.32e-1, 5.53e-2, 3.3, 0.342, 3.2e1, 1.3, 4.0e1, 1.0e-2, 0.5],
+            "alpha2": [3.2, 3.1, 2.3, 2.57, 3.6, 2.3, 2.1, 2.79, 3.3, 3.8],
+            "variance": [1.32, 35.3, 242.2, 46.6, 0.3, 0.244, 9.64, 0.75, 0.193, 0.21],
+            "mu": [1.2, 0.3, 0.1, 0.46, 0.1, 0.21, 0.74, 0.1, 0.03, 0.92],
+            "f_min": 1.0e-4, "f_max": 1.0e1, "n_components": 30, "basis_function": "SHO",
+        },
+        "likelihood_simu_log": {  # test/test_likelihood.jl:7-18
+            "cite": "test/test_likelihood.jl:7-59", "data": "simu_log.txt",
+            "alpha1": 0.82, "f1": 0.01, "alpha2": 3.3, "nu": 1.0, "mu": 0.0, "n_components": 20,
+            "f0_rule": "1/(t[end]-t[1])/100", "fM_rule": "1/minimum(diff(t))/2*20",
+            "variance_rule": "var(y, corrected=true)",
+        },
+    }
+    (OUT / "reference_literals.json").write_text(json.dumps(lit, indent=1))
+    return lit
+
+
+def make_relation_cases(lit):
+    import mpmath as mp
+    mp.mp.dps = 50
+    cases = []
+
+    def mp_dense_logpdf(a, b, c, d, t, y, s2):
+        N = len(t)
+        K = mp.matrix(N, N)
+        for i in range(N):
+            for j in range(N):
+                tau = abs(mp.mpf(t[i]) - mp.mpf(t[j]))
+                k = mp.mpf(0)
+                for aa, bb, cc, dd in zip(a, b, c, d):
+                    k += mp.e ** (-mp.mpf(cc) * tau) * (mp.mpf(aa) * mp.cos(mp.mpf(dd) * tau)
+                                                          + mp.mpf(bb) * mp.sin(mp.mpf(dd) * tau))
+                K[i, j] = k + (mp.mpf(s2[i]) if i == j else 0)
+        yv = mp.matrix([mp.mpf(v) for v in y])
+        z = mp.lu_solve(K, yv)
+        quad = sum(yv[i] * z[i] for i in range(N))
+        return float(-mp.log(mp.det(K)) / 2 - quad / 2 - N * mp.log(2 * mp.pi) / 2)
+
+    g = lit["scalablegp_n6"]
+    t = np.array(g["t"]); y = np.array(g["y"]); yerr = np.array(g["yerr"])
+    for i in range(10):
+        a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, g["alpha1"][i], g["f1"][i], g["alpha2"][i]),
+                              g["f_min"], g["f_max"], g["n_components"], g["variance"][i])
+        yc = y - g["mu"][i]
+        cel = O.logl(a, b, c, d, t, yc, yerr ** 2)
+        den = -O.dense_nll(a, b, c, d, t, yc, yerr ** 2)
+        hp = mp_dense_logpdf(a, b, c, d, t, yc, yerr ** 2)
+        assert abs(cel - den) <= 1e-11 * abs(den), (i, cel, den)
+        assert abs(cel - hp) <= 1e-11 * abs(hp), (i, cel, hp)
+        cases.append({"name": f"scalablegp_n6[{i}]", "logl_celerite": cel, "logl_dense": den, "logl_mpmath50": hp})
+
+    L = lit["likelihood_simu_log"]
+    A = np.loadtxt(REF / "test/data/simu_log.txt")
+    t, y, yerr = A[:, 0], A[:, 1], A[:, 2]
+    f0 = 1 / (t[-1] - t[0]) / 100
+    fM = 1 / np.min(np.diff(t)) / 2 * 20
+    var = np.var(y, ddof=1)
+    for basis in ("SHO", "DRWCelerite"):
+        a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, L["alpha1"], L["f1"], L["alpha2"]),
+                              f0, fM, 20, var, basis_function=basis)
+        cel = O.logl(a, b, c, d, t, y - L["mu"], L["nu"] * yerr ** 2)
+        den = -O.dense_nll(a, b, c, d, t, y - L["mu"], L["nu"] * yerr ** 2)
+        twin = O.logl_numpy(a, b, c, d, t, y - L["mu"], L["nu"] * yerr ** 2)
+        assert abs(cel - den) <= 1e-11 * abs(den), (basis, cel, den)
+        assert abs(cel - twin) <= 1e-11 * abs(cel)
+        cases.append({"name": f"simu_log[{basis}]", "logl_celerite": cel, "logl_dense": den, "J": len(a)})
+    (OUT / "relation_cases.json").write_text(json.dumps(
+        {"note": "values of the oracle restatement (NOT reference outputs); stored after passing the "
+                 "reference's relation celerite == -dense and, for N=6, a 50-digit mpmath evaluation",
+         "cases": cases}, indent=1))
+    for c in cases:
+        print(c)
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    for f in ("simu_log.txt", "simu.txt"):
+        shutil.copyfile(REF / "test/data" / f, OUT / f)
+        (OUT / f).chmod(0o644)
+    make_ultranest_fixture()
+    lit = make_literals()
+    make_relation_cases(lit)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+"""CPU tests (-m "not gpu"): pin the oracle (oracle/) against the reference's own outputs and literals.
+
+The oracle is test infrastructure; these tests are what makes it trustworthy as the parity checker
+for the HIP path (tests/test_gpu_parity.py).
+"""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+@pytest.fixture(scope="module")
+def lit(golden_dir):
+    return json.loads((golden_dir / "reference_literals.json").read_text())
+
+
+@pytest.fixture(scope="module")
+def un(golden_dir):
+    return np.load(golden_dir / "ultranest_points.npz")
+
+
+def _un_inputs(un, i):
+    t, y, yerr = un["t"], un["y"], un["yerr"]
+    a1, f1, a2, var, nu, mu, cs = un["params"][i]
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, a1, f1, a2), f_min, f_max, 20, var,
+                          is_integrated_power=False)
+    return a, b, c, d, t, np.log(y - cs) - mu, nu * yerr ** 2 / (y - cs) ** 2
+
+
+def test_reference_outputs_all_points(un):
+    """Every log-likelihood the reference itself computed in its stored ultranest run
+    (docs/src/data/inference, N=242, SHO-20 => J=20 terms) is reproduced by the C oracle."""
+    logl = un["logl"]
+    got = np.empty_like(logl)
+    for i in range(len(logl)):
+        got[i] = O.logl(*_un_inputs(un, i))
+    rel = np.abs(got - logl) / np.abs(logl)
+    assert len(logl) > 5000
+    assert rel.max() < 1e-11, rel.max()
+
+
+def test_numpy_twin_agrees(un):
+    for i in (0, 17, 4242):
+        args = _un_inputs(un, i)
+        assert O.logl_numpy(*args) == pytest.approx(O.logl(*args), rel=1e-12)
+
+
+def test_psd_amplitude_golden(lit):
+    g = lit["psd_amplitudes"]
+    amp = O.get_approx_coefficients(lambda f: O.single_bending_power_law(f, *g["params"]), g["f0"], g["fM"],
+                                    n_components=g["J"])
+    # reference uses isapprox (rtol sqrt(eps)); we hold 1e-9 elementwise (cond(B) ~ 2.6e3)
+    np.testing.assert_allclose(amp, g["expected"], rtol=1e-9)
+
+
+def test_coefficient_literals(lit):
+    assert O.celerite_coefs_celerite(*lit["coefs_celerite"]["args"]) == lit["coefs_celerite"]["expected"]
+    assert O.celerite_coefs_exp(*lit["coefs_exp"]["args"]) == lit["coefs_exp"]["expected"]
+    s = lit["coefs_sho"]
+    w0 = 2 * np.pi * s["w0_over_2pi"]
+    assert O.celerite_coefs_sho(s["A"], w0, 1 / np.sqrt(2)) == [s["A"], s["A"], np.sqrt(2) / 2 * w0, np.sqrt(2) / 2 * w0]
+    with pytest.raises(ValueError, match="not implemented yet"):
+        O.celerite_coefs_sho(s["A"], w0, 0.5)
+    g = lit["carma32"]
+    r = [complex(*x) for x in g["r_alpha"]]
+    a, b, c, d = O.carma_celerite_coefs(g["p"], r, g["beta"], g["norm"])
+    for got, exp in zip((a, b, c, d), g["expected"]):
+        np.testing.assert_allclose(got, exp, rtol=1.5e-8, atol=1e-15)
+
+
+def test_relation_celerite_equals_dense(lit, golden_dir):
+    """The reference's own known-answer relation (test/test_scalablegp.jl:128, test/test_likelihood.jl:58-59)."""
+    rel = {c["name"]: c for c in json.loads((golden_dir / "relation_cases.json").read_text())["cases"]}
+    g = lit["scalablegp_n6"]
+    t = np.array(g["t"]); y = np.array(g["y"]); yerr = np.array(g["yerr"])
+    for i in range(10):
+        a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, g["alpha1"][i], g["f1"][i], g["alpha2"][i]),
+                              g["f_min"], g["f_max"], g["n_components"], g["variance"][i])
+        cel = O.logl(a, b, c, d, t, y - g["mu"][i], yerr ** 2)
+        den = -O.dense_nll(a, b, c, d, t, y - g["mu"][i], yerr ** 2)
+        assert np.isfinite(cel)
+        assert cel == pytest.approx(den, rel=1e-11)
+        assert cel == pytest.approx(rel[f"scalablegp_n6[{i}]"]["logl_mpmath50"], rel=1e-11)
+    A = np.loadtxt(golden_dir / "simu_log.txt")
+    t, y, yerr = A[:, 0], A[:, 1], A[:, 2]
+    f0 = 1 / (t[-1] - t[0]) / 100
+    fM = 1 / np.min(np.diff(t)) / 2 * 20
+    for basis, J in (("SHO", 20), ("DRWCelerite", 40)):
+        a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, 0.82, 0.01, 3.3), f0, fM, 20,
+                              np.var(y, ddof=1), basis_function=basis)
+        assert len(a) == J
+        cel = O.logl(a, b, c, d, t, y, yerr ** 2)
+        den = -O.dense_nll(a, b, c, d, t, y, yerr ** 2)
+        assert cel == pytest.approx(den, rel=1e-11)
+        assert cel == pytest.approx(O.dense_nll_numpy(a, b, c, d, t, y, yerr ** 2) * -1, rel=1e-11)
+        assert cel == pytest.approx(rel[f"simu_log[{basis}]"]["logl_celerite"], rel=1e-13)
+
+
+def test_kernel_closed_forms():
+    """test/test_covariancefunctions.jl:3-30: k(tau) closed forms via the (a,b,c,d) representation."""
+    tt = np.linspace(0, 10, 50)
+    a, b, c, d = O.celerite_coefs_exp(1.0, 2.4)
+    np.testing.assert_allclose([O.kappa([a], [b], [c], [d], x) for x in tt], np.exp(-tt * 2.4) / 2, rtol=1e-14)
+    a, b, c, d = 1.3, 4.0, 0.5, 3.2
+    np.testing.assert_allclose([O.kappa([a], [b], [c], [d], x) for x in tt],
+                               np.exp(-c * tt) * (a * np.cos(d * tt) + b * np.sin(d * tt)), rtol=1e-13, atol=1e-15)
+
+
+def test_r0_equals_variance():
+    """test/test_psd.jl:100-153: with is_integrated_power=false, R(0) = sum(a) = variance."""
+    for basis in ("SHO", "DRWCelerite"):
+        a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, 0.2, 1.3e-2, 3.2), 2e-3, 3.52e2, 25, 1.32,
+                              is_integrated_power=False, basis_function=basis)
+        assert a.sum() == pytest.approx(1.32, rel=1e-12)
+        assert len(a) == (25 if basis == "SHO" else 50)
+
+
+def test_qpo_term_counts():
+    """test/test_psd.jl:206-285: each QPO feature appends one celerite term."""
+    a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, 0.2, 1.3e-2, 3.2), 2e-3, 3.52e2, 25, 1.32,
+                          is_integrated_power=False, qpo_features=[(2.0, 1e-2, 14.2), (4.0, 1e-1, 4.2)])
+    assert len(a) == 27
+    a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, 0.2, 1.3e-2, 4.2), 2e-3, 3.52e2, 25, 1.32,
+                          is_integrated_power=False, basis_function="DRWCelerite", qpo_features=[(1.4, 1e-2, 10.2)])
+    assert len(a) == 51
+
+
+def test_status_and_batch():
+    rng = np.random.default_rng(1)
+    t = np.cumsum(rng.uniform(0.1, 2, 50)); y = rng.standard_normal(50); s2 = np.full(50, 0.01)
+    A = rng.uniform(0.1, 1, (5, 3)); Bc = rng.uniform(0, 0.1, (5, 3))
+    C = rng.uniform(0.1, 1, 3); Dd = rng.uniform(0.1, 2, 3)
+    mu = rng.standard_normal(5); nu = rng.uniform(0.5, 2, 5)
+    out, st = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=2, return_status=True)
+    for i in range(5):
+        assert out[i] == O.logl(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2)
+    assert (st == 0).all()
+    # non positive-definite: negative amplitude with tiny noise -> status 1 (D_n <= 0)
+    v, s = O.logl([-5.0], [0.0], [0.1], [0.0], t, y, s2 * 1e-6, return_status=True)
+    assert s != 0
+
+
+def test_sim_matches_covariance():
+    """sim (src/celerite_solver.jl:515-549) draws have covariance K: check L-factor identity y = L q."""
+    rng = np.random.default_rng(3)
+    t = np.cumsum(rng.uniform(0.1, 1, 12)); s2 = np.full(12, 0.05)
+    a, b, c, d = [1.0, 0.4], [0.2, 0.0], [0.3, 1.0], [1.1, 0.0]
+    # columns of the implied factor: y(q = e_k)
+    Lf = np.stack([O.sim(a, b, c, d, t, s2, np.eye(12)[k]) for k in range(12)], axis=1)
+    K = np.array([[O.kappa(a, b, c, d, abs(ti - tj)) for tj in t] for ti in t]) + np.diag(s2)
+    np.testing.assert_allclose(Lf @ Lf.T, K, rtol=1e-11, atol=1e-13)
