@@ -1,0 +1,129 @@
+/*
+ * pioran_hip.h — C ABI of libpioran_hip.so: the MI355X (gfx950) implementation of the ScalableGP
+ * log-likelihood hot path of mlefkir/Pioran.jl (v1.2.0).
+ *
+ * This is the drop-in boundary.  The reference is pure Julia and has no FFI on this path; the seam
+ * it would bind with `ccall` is the narrow waist
+ *     logl(a, b, c, d, τ, y, σ2)                      src/celerite_solver.jl:312-334
+ * reached from
+ *     Distributions.logpdf(f::FiniteScalableGP, Y)    src/scalable_GP.jl:162-166
+ *       -> log_likelihood(cov, τ, y, σ2; solver)      src/celerite_solver.jl:262-294
+ * and, for the dense solver,
+ *     log_likelihood_direct(cov, t, y, σ²)            src/direct_solver.jl:6-21.
+ * INTEGRATION.md shows the Julia-side binding (julia/PioranHIP.jl in the package directory).
+ *
+ * Conventions
+ *   - plain C, all floating point is IEEE fp64, all sizes int64_t, no torch / C++ types;
+ *   - "host" pointers are ordinary process memory, "device" pointers are HBM of the ctx's GPU;
+ *   - matrices over the batch are "J x B column-major" = Julia `Matrix{Float64}(J, B)` = C `[B][J]`:
+ *     draw b's coefficients are contiguous at  A + b*J ;  series over the batch likewise `[B][N]`;
+ *   - every entry point returns 0 (PIORAN_OK) or a negative error code; nothing unwinds across the
+ *     ABI.  Numerical failures of single draws are reported per draw in `status` (below);
+ *   - calls on one ctx must not overlap in time (one ctx per host thread / Julia task); different
+ *     ctx objects are independent.  No global mutable state, no HIP call at library load.
+ *
+ * status[b]:  0 ok;  1 some D_n <= 0 (matrix not positive definite — the reference silently uses
+ *             log(abs(D_n)) for n >= 2, src/celerite_solver.jl:140, and so does out[b]);
+ *             2 non-finite result (the reference would throw DomainError from log(D_1 < 0), :126).
+ */
+#ifndef PIORAN_HIP_H
+#define PIORAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIORAN_OK 0
+#define PIORAN_ERR_ARG (-1)         /* null pointer, non-positive size, inconsistent arguments */
+#define PIORAN_ERR_HIP (-2)         /* a HIP runtime call failed; see pioran_last_hip_error */
+#define PIORAN_ERR_ALLOC (-3)       /* device or host allocation failed */
+#define PIORAN_ERR_UNSUPPORTED (-4) /* rank / size outside what the kernels handle */
+
+typedef struct pioran_ctx pioran_ctx; /* one GPU + one stream + scratch; not thread-safe */
+typedef struct pioran_ds pioran_ds;   /* a time series resident in HBM + its cached shared table */
+
+const char* pioran_strerror(int code);
+const char* pioran_last_hip_error(const pioran_ctx* ctx);
+/* ABI version of this header (bumped on any signature change). */
+int pioran_abi_version(void);
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* Creates a context on GPU `device` with its own non-blocking stream. */
+int pioran_ctx_create(int device, pioran_ctx** out);
+/* Same, but work is enqueued on the caller's hipStream_t (e.g. torch's current stream). */
+int pioran_ctx_create_on_stream(int device, void* hip_stream, pioran_ctx** out);
+int pioran_ctx_destroy(pioran_ctx* ctx);
+int pioran_ctx_synchronize(pioran_ctx* ctx);
+/* hipEvent-based timing on the ctx stream: record slot i (0..15), elapsed between two slots. */
+int pioran_ctx_event_record(pioran_ctx* ctx, int slot);
+int pioran_ctx_event_elapsed_ms(pioran_ctx* ctx, int slot_start, int slot_stop, float* ms);
+
+/* ---- data set ------------------------------------------------------------------------------ */
+/* Uploads (t, y, sigma2), each of length N (host pointers), once.  y is the raw series: the mean
+ * is subtracted per draw (mu), as logpdf does (src/scalable_GP.jl:164). */
+int pioran_dataset_create(pioran_ctx* ctx, int64_t N, const double* t, const double* y,
+                          const double* sigma2, pioran_ds** out);
+int pioran_dataset_destroy(pioran_ds* ds);
+/* Declares the (c_j, d_j) shared by every draw of the following *_dev batches and builds the
+ * cos/sin/exp table for them (src/celerite_solver.jl:52-54, once instead of per draw).
+ * c, d: host, length J.  real_term (host, length J, may be NULL): non-zero marks a term whose
+ * b_j = 0 and d_j = 0 for EVERY draw (Exp / DRW terms, src/Exp.jl:29-33, src/psd.jl:270-273); its
+ * identically-zero sin row is dropped, which leaves results bit-identical. */
+int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const double* d,
+                           const int32_t* real_term);
+
+/* ---- celerite solver ------------------------------------------------------------------------ */
+/* Scalar drop-in for logl(a,b,c,d,τ,y,σ2) (src/celerite_solver.jl:312-334): host vectors in, one
+ * double out.  y has the mean already subtracted, as in the reference.  status may be NULL. */
+int pioran_celerite_logl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,
+                         const double* c, const double* d, const double* t, const double* y,
+                         const double* sigma2, double* out, int32_t* status);
+
+/* B independent log-likelihoods on one data set; host pointers; blocks until `out` is filled.
+ *   A, Bc      : [B][J]
+ *   C, Dd      : [J] when cd_shared != 0, else [B][J] (per-draw decay/frequency: QPO, CARMA, ...)
+ *   mu         : [B] or NULL (0):   y_n - mu_b                      (ConstMean, scalable_GP.jl:164)
+ *   nu         : [B] or NULL (1):   sigma2_n * nu_b                 (the models' ν, README.md:44)
+ *   Y, S2      : [B][N] or NULL: per-draw series / variances that REPLACE the data set's y / sigma2
+ *                (models with a sampled shift, docs/src/ultranest.md:199-205); mu, nu still apply
+ *   out        : [B]     status: [B] or NULL */
+int pioran_celerite_logl_batch(pioran_ds* ds, int64_t B, int64_t J, const double* A,
+                               const double* Bc, const double* C, const double* Dd, int cd_shared,
+                               const double* mu, const double* nu, const double* Y,
+                               const double* S2, double* out, int32_t* status);
+
+/* Same computation with every array already in HBM (device pointers) and (c, d) declared by
+ * pioran_dataset_prepare.  Asynchronous: enqueues on the ctx stream and returns; use
+ * pioran_ctx_synchronize (or the stream) before reading out/status.  dmu, dnu, dY, dS2, dstatus
+ * may be NULL. */
+int pioran_celerite_logl_batch_dev(pioran_ds* ds, int64_t B, const double* dA, const double* dBc,
+                                   const double* dmu, const double* dnu, const double* dY,
+                                   const double* dS2, double* dout, int32_t* dstatus);
+/* Per-draw (c, d) variant of the above: dC, dDd are [B][J] device arrays, no shared table. */
+int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const double* dA,
+                                      const double* dBc, const double* dC, const double* dDd,
+                                      const double* dmu, const double* dnu, const double* dY,
+                                      const double* dS2, double* dout, int32_t* dstatus);
+/* Name of the kernel configuration a batch with R active rows runs on (diagnostics). */
+const char* pioran_celerite_config_name(int64_t R);
+
+/* ---- dense solver ---------------------------------------------------------------------------- */
+/* log_likelihood_direct (src/direct_solver.jl:6-21): builds K_ik = sum_j k_j(|t_i - t_k|) +
+ * diag(sigma2) in HBM, Cholesky-factorises it and returns the POSITIVE negative-log-likelihood,
+ * like the reference (callers negate, test/test_likelihood.jl:54).  info (may be NULL): 0, or the
+ * 1-based index of the first non-positive pivot (LAPACK convention; out is NaN then — the reference
+ * throws PosDefException). */
+int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,
+                     const double* c, const double* d, const double* t, const double* y,
+                     const double* sigma2, double* out, int32_t* info);
+/* Covariance build alone (K as N x N column-major host array) — kappa of src/acvf.jl:138-140. */
+int pioran_dense_covariance(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,
+                            const double* c, const double* d, const double* t, const double* sigma2,
+                            double* K_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIORAN_HIP_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of libpioran_hip.so (the C ABI of include/pioran_hip.h).
+
+The library is the product: if it is missing or fails to load, importing this module's `lib()` raises —
+there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libpioran_hip.so"
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+c_void_p = ctypes.c_void_p
+i64 = ctypes.c_int64
+
+# name -> (restype, argtypes); every symbol declared in include/pioran_hip.h
+SIGNATURES = {
+    "pioran_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "pioran_last_hip_error": (ctypes.c_char_p, [c_void_p]),
+    "pioran_abi_version": (ctypes.c_int, []),
+    "pioran_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_void_p)]),
+    "pioran_ctx_create_on_stream": (ctypes.c_int, [ctypes.c_int, c_void_p, ctypes.POINTER(c_void_p)]),
+    "pioran_ctx_destroy": (ctypes.c_int, [c_void_p]),
+    "pioran_ctx_synchronize": (ctypes.c_int, [c_void_p]),
+    "pioran_ctx_event_record": (ctypes.c_int, [c_void_p, ctypes.c_int]),
+    "pioran_ctx_event_elapsed_ms": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
+    "pioran_dataset_create": (ctypes.c_int, [c_void_p, i64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),
+    "pioran_dataset_destroy": (ctypes.c_int, [c_void_p]),
+    "pioran_dataset_prepare": (ctypes.c_int, [c_void_p, i64, c_void_p, c_void_p, c_void_p]),
+    "pioran_celerite_logl": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [c_void_p, c_void_p]),
+    "pioran_celerite_logl_batch": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                  ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                  c_void_p]),
+    "pioran_celerite_logl_batch_dev": (ctypes.c_int, [c_void_p, i64] + [c_void_p] * 8),
+    "pioran_celerite_logl_batch_dev_cd": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 10),
+    "pioran_celerite_config_name": (ctypes.c_char_p, [i64]),
+    "pioran_dense_nll": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [c_void_p, c_void_p]),
+    "pioran_dense_covariance": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 6 + [c_void_p]),
+}
+
+_lib = None
+
+
+class PioranHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libpioran_hip.so; raises if it has not been built (python pioran.jl_amd/build.py)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise PioranHipError(
+                f"{LIB_PATH} not found: build the HIP library first (python pioran.jl_amd/build.py or "
+                f"__graft_entry__.build()). There is no CPU fallback.")
+        L = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, ctx=None):
+    if rc != 0:
+        msg = lib().pioran_strerror(rc).decode()
+        if ctx is not None:
+            detail = lib().pioran_last_hip_error(ctx).decode()
+            if detail:
+                msg += f" ({detail})"
+        raise PioranHipError(f"pioran_hip error {rc}: {msg}")

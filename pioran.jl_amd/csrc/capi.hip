@@ -1,0 +1,418 @@
+// C ABI of libpioran_hip.so — see include/pioran_hip.h for the contract and the reference lines
+// each entry point replaces.
+#include "../../include/pioran_hip.h"
+#include "common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+struct pioran_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[16] = {};
+    std::string last_err;
+    // growable device staging for the host-pointer entry points
+    struct Buf {
+        void* p = nullptr;
+        size_t cap = 0;
+    };
+    Buf bA, bB, bC, bD, bmu, bnu, bY, bS2, bout, bst, bscratch, bK, bwork;
+};
+
+struct pioran_ds {
+    pioran_ctx* ctx = nullptr;
+    int64_t N = 0;
+    double *t = nullptr, *y = nullptr, *s2 = nullptr;  // device
+    // prepared shared (c, d)
+    int32_t J = 0, R = 0;
+    std::vector<double> c_host, d_host;
+    std::vector<int32_t> real_host;
+    double* tab = nullptr;
+    size_t tab_cap = 0;
+    int32_t* rowmap = nullptr;
+    size_t rowmap_cap = 0;
+    double *dc = nullptr, *dd = nullptr;
+    size_t dcd_cap = 0;
+    bool prepared = false;
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            (ctx)->last_err = std::string(#expr) + ": " + hipGetErrorString(e_);            \
+            return PIORAN_ERR_HIP;                                                          \
+        }                                                                                   \
+    } while (0)
+
+int ensure(pioran_ctx* ctx, pioran_ctx::Buf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return PIORAN_OK;
+    if (b.p) HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        b.p = nullptr;
+        ctx->last_err = "hipMalloc failed";
+        return PIORAN_ERR_ALLOC;
+    }
+    b.cap = want;
+    return PIORAN_OK;
+}
+
+int upload(pioran_ctx* ctx, pioran_ctx::Buf& b, const void* host, size_t bytes)
+{
+    int rc = ensure(ctx, b, bytes);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return PIORAN_OK;
+}
+
+// rows kept for a term list: cos row always, sin row unless the term is marked real (b = d = 0)
+std::vector<int32_t> build_rowmap(int64_t J, const int32_t* real_term)
+{
+    std::vector<int32_t> rm;
+    rm.reserve(2 * J);
+    for (int64_t j = 0; j < J; ++j) {
+        rm.push_back((int32_t)j);
+        if (!(real_term && real_term[j])) rm.push_back((int32_t)j | (1 << 30));
+    }
+    return rm;
+}
+
+int set_rowmap(pioran_ds* ds, const std::vector<int32_t>& rm)
+{
+    pioran_ctx* ctx = ds->ctx;
+    if (rm.size() > ds->rowmap_cap) {
+        if (ds->rowmap) HIPCHK(ctx, hipFree(ds->rowmap));
+        ds->rowmap = nullptr;
+        if (hipMalloc((void**)&ds->rowmap, rm.size() * sizeof(int32_t)) != hipSuccess) return PIORAN_ERR_ALLOC;
+        ds->rowmap_cap = rm.size();
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ds->rowmap, rm.data(), rm.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                               ctx->stream));
+    // the host vector is about to go out of scope in the callers: finish the copy first
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ds->R = (int32_t)rm.size();
+    return PIORAN_OK;
+}
+
+int launch(pioran_ds* ds, ScanParams& p)
+{
+    pioran_ctx* ctx = ds->ctx;
+    if (p.R <= pioran_scan_supported_rows() && !std::getenv("PIORAN_FORCE_FALLBACK")) {
+        int rc = pioran_launch_scan(p, ctx->stream);
+        if (rc != PIORAN_ERR_UNSUPPORTED) {
+            if (rc == PIORAN_ERR_HIP) ctx->last_err = "scan kernel launch failed";
+            return rc;
+        }
+    }
+    const int64_t chunk = p.B < 1024 ? p.B : 1024;
+    int rc = ensure(ctx, ctx->bscratch, (size_t)chunk * pioran_fallback_scratch_doubles(p.R) * sizeof(double));
+    if (rc) return rc;
+    p.scratch = (double*)ctx->bscratch.p;
+    rc = pioran_launch_scan_fallback(p, ctx->stream);
+    if (rc == PIORAN_ERR_HIP) ctx->last_err = "fallback kernel launch failed";
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pioran_strerror(int code)
+{
+    switch (code) {
+        case PIORAN_OK: return "ok";
+        case PIORAN_ERR_ARG: return "invalid argument";
+        case PIORAN_ERR_HIP: return "HIP runtime error";
+        case PIORAN_ERR_ALLOC: return "allocation failed";
+        case PIORAN_ERR_UNSUPPORTED: return "unsupported size";
+        default: return "unknown error";
+    }
+}
+
+const char* pioran_last_hip_error(const pioran_ctx* ctx) { return ctx ? ctx->last_err.c_str() : ""; }
+
+int pioran_abi_version(void) { return 1; }
+
+static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
+{
+    if (!out) return PIORAN_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return PIORAN_ERR_HIP;
+    pioran_ctx* ctx = new (std::nothrow) pioran_ctx;
+    if (!ctx) return PIORAN_ERR_ALLOC;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
+    if (own) {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
+        ctx->own_stream = true;
+    } else {
+        ctx->stream = (hipStream_t)stream;
+    }
+    for (auto& e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
+    *out = ctx;
+    return PIORAN_OK;
+}
+
+int pioran_ctx_create(int device, pioran_ctx** out) { return ctx_create_impl(device, nullptr, true, out); }
+
+int pioran_ctx_create_on_stream(int device, void* hip_stream, pioran_ctx** out)
+{
+    return ctx_create_impl(device, hip_stream, false, out);
+}
+
+int pioran_ctx_destroy(pioran_ctx* ctx)
+{
+    if (!ctx) return PIORAN_ERR_ARG;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
+                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork};
+    for (auto* b : bufs)
+        if (b->p) hipFree(b->p);
+    for (auto& e : ctx->ev)
+        if (e) hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PIORAN_OK;
+}
+
+int pioran_ctx_synchronize(pioran_ctx* ctx)
+{
+    if (!ctx) return PIORAN_ERR_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PIORAN_OK;
+}
+
+int pioran_ctx_event_record(pioran_ctx* ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot >= 16) return PIORAN_ERR_ARG;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[slot], ctx->stream));
+    return PIORAN_OK;
+}
+
+int pioran_ctx_event_elapsed_ms(pioran_ctx* ctx, int a, int b, float* ms)
+{
+    if (!ctx || !ms || a < 0 || a >= 16 || b < 0 || b >= 16) return PIORAN_ERR_ARG;
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[b]));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev[a], ctx->ev[b]));
+    return PIORAN_OK;
+}
+
+int pioran_dataset_create(pioran_ctx* ctx, int64_t N, const double* t, const double* y, const double* sigma2,
+                          pioran_ds** out)
+{
+    if (!ctx || !out || N < 1 || !t || !y || !sigma2) return PIORAN_ERR_ARG;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pioran_ds* ds = new (std::nothrow) pioran_ds;
+    if (!ds) return PIORAN_ERR_ALLOC;
+    ds->ctx = ctx;
+    ds->N = N;
+    const size_t bytes = (size_t)N * sizeof(double);
+    double* base = nullptr;
+    if (hipMalloc((void**)&base, 3 * bytes) != hipSuccess) { delete ds; return PIORAN_ERR_ALLOC; }
+    ds->t = base;
+    ds->y = base + N;
+    ds->s2 = base + 2 * N;
+    hipError_t e = hipMemcpyAsync(ds->t, t, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ds->y, y, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ds->s2, sigma2, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        ctx->last_err = hipGetErrorString(e);
+        hipFree(base);
+        delete ds;
+        return PIORAN_ERR_HIP;
+    }
+    *out = ds;
+    return PIORAN_OK;
+}
+
+int pioran_dataset_destroy(pioran_ds* ds)
+{
+    if (!ds) return PIORAN_ERR_ARG;
+    hipSetDevice(ds->ctx->device);
+    hipStreamSynchronize(ds->ctx->stream);
+    if (ds->t) hipFree(ds->t);
+    if (ds->tab) hipFree(ds->tab);
+    if (ds->rowmap) hipFree(ds->rowmap);
+    if (ds->dc) hipFree(ds->dc);
+    delete ds;
+    return PIORAN_OK;
+}
+
+int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const double* d, const int32_t* real_term)
+{
+    if (!ds || J < 1 || J > (1 << 20) || !c || !d) return PIORAN_ERR_ARG;
+    pioran_ctx* ctx = ds->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> real(J, 0);
+    for (int64_t j = 0; j < J; ++j) {
+        real[j] = (real_term && real_term[j]) ? 1 : 0;
+        if (real[j] && d[j] != 0.0) return PIORAN_ERR_ARG;  // a real term must have d = 0
+    }
+    const bool same_cd = ds->prepared && ds->J == J && !std::memcmp(ds->c_host.data(), c, J * sizeof(double)) &&
+                         !std::memcmp(ds->d_host.data(), d, J * sizeof(double));
+    const bool same_rows = same_cd && ds->real_host == real;
+    if (same_rows) return PIORAN_OK;
+    if (!same_cd) {
+        ds->prepared = false;
+        const size_t need = (size_t)ds->N * 3 * (size_t)(J + 1);
+        if (need > ds->tab_cap) {
+            if (ds->tab) HIPCHK(ctx, hipFree(ds->tab));
+            ds->tab = nullptr;
+            ds->tab_cap = 0;
+            if (hipMalloc((void**)&ds->tab, need * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
+            ds->tab_cap = need;
+        }
+        if ((size_t)J > ds->dcd_cap) {
+            if (ds->dc) HIPCHK(ctx, hipFree(ds->dc));
+            ds->dc = nullptr;
+            if (hipMalloc((void**)&ds->dc, 2 * (size_t)J * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
+            ds->dcd_cap = (size_t)J;
+        }
+        ds->dd = ds->dc + J;
+        ds->c_host.assign(c, c + J);
+        ds->d_host.assign(d, d + J);
+        HIPCHK(ctx, hipMemcpyAsync(ds->dc, ds->c_host.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ds->dd, ds->d_host.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        int rc = pioran_launch_table(ds->N, (int32_t)J, ds->t, ds->dc, ds->dd, ds->tab, ctx->stream);
+        if (rc) return rc;
+        ds->J = (int32_t)J;
+    }
+    int rc = set_rowmap(ds, build_rowmap(J, real.data()));
+    if (rc) return rc;
+    ds->real_host = real;
+    ds->prepared = true;
+    return PIORAN_OK;
+}
+
+int pioran_celerite_logl_batch_dev(pioran_ds* ds, int64_t B, const double* dA, const double* dBc, const double* dmu,
+                                   const double* dnu, const double* dY, const double* dS2, double* dout,
+                                   int32_t* dstatus)
+{
+    if (!ds || B < 1 || !dA || !dBc || !dout) return PIORAN_ERR_ARG;
+    if (!ds->prepared) return PIORAN_ERR_ARG;
+    if ((dY == nullptr) != (dS2 == nullptr)) return PIORAN_ERR_ARG;
+    pioran_ctx* ctx = ds->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ScanParams p{};
+    p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = B;
+    p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+    p.Y = dY; p.S2 = dS2; p.A = dA; p.Bc = dBc; p.C = ds->dc; p.D = ds->dd;
+    p.mu = dmu; p.nu = dnu; p.out = dout; p.status = dstatus;
+    return launch(ds, p);
+}
+
+int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const double* dA, const double* dBc,
+                                      const double* dC, const double* dDd, const double* dmu, const double* dnu,
+                                      const double* dY, const double* dS2, double* dout, int32_t* dstatus)
+{
+    if (!ds || B < 1 || J < 1 || !dA || !dBc || !dC || !dDd || !dout) return PIORAN_ERR_ARG;
+    if ((dY == nullptr) != (dS2 == nullptr)) return PIORAN_ERR_ARG;
+    pioran_ctx* ctx = ds->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // per-draw (c, d): full 2J rows, no table; the prepared shared state is left untouched
+    std::vector<int32_t> rm = build_rowmap(J, nullptr);
+    int32_t* drm = nullptr;
+    int rc = ensure(ctx, ctx->bwork, rm.size() * sizeof(int32_t));
+    if (rc) return rc;
+    drm = (int32_t*)ctx->bwork.p;
+    HIPCHK(ctx, hipMemcpyAsync(drm, rm.data(), rm.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ScanParams p{};
+    p.N = ds->N; p.J = (int32_t)J; p.R = (int32_t)rm.size(); p.B = B;
+    p.tab = nullptr; p.rowmap = drm; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+    p.Y = dY; p.S2 = dS2; p.A = dA; p.Bc = dBc; p.C = dC; p.D = dDd;
+    p.mu = dmu; p.nu = dnu; p.out = dout; p.status = dstatus;
+    return launch(ds, p);
+}
+
+int pioran_celerite_logl_batch(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc,
+                               const double* C, const double* Dd, int cd_shared, const double* mu, const double* nu,
+                               const double* Y, const double* S2, double* out, int32_t* status)
+{
+    if (!ds || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !out) return PIORAN_ERR_ARG;
+    if ((Y == nullptr) != (S2 == nullptr)) return PIORAN_ERR_ARG;
+    pioran_ctx* ctx = ds->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t bj = (size_t)B * (size_t)J * sizeof(double);
+    const size_t bn = (size_t)B * (size_t)ds->N * sizeof(double);
+    int rc;
+    if (cd_shared) {
+        // terms whose sin row is identically zero for the whole batch: d_j = 0 and b_j = 0 for all draws
+        std::vector<int32_t> real(J, 0);
+        for (int64_t j = 0; j < J; ++j) {
+            if (Dd[j] != 0.0) continue;
+            bool allzero = true;
+            for (int64_t b = 0; b < B && allzero; ++b) allzero = (Bc[b * J + j] == 0.0);
+            real[j] = allzero;
+        }
+        if ((rc = pioran_dataset_prepare(ds, J, C, Dd, real.data()))) return rc;
+    }
+    if ((rc = upload(ctx, ctx->bA, A, bj))) return rc;
+    if ((rc = upload(ctx, ctx->bB, Bc, bj))) return rc;
+    if (!cd_shared) {
+        if ((rc = upload(ctx, ctx->bC, C, bj))) return rc;
+        if ((rc = upload(ctx, ctx->bD, Dd, bj))) return rc;
+    }
+    if (mu && (rc = upload(ctx, ctx->bmu, mu, B * sizeof(double)))) return rc;
+    if (nu && (rc = upload(ctx, ctx->bnu, nu, B * sizeof(double)))) return rc;
+    if (Y) {
+        if ((rc = upload(ctx, ctx->bY, Y, bn))) return rc;
+        if ((rc = upload(ctx, ctx->bS2, S2, bn))) return rc;
+    }
+    if ((rc = ensure(ctx, ctx->bout, B * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->bst, B * sizeof(int32_t)))) return rc;
+    const double* dmu = mu ? (const double*)ctx->bmu.p : nullptr;
+    const double* dnu = nu ? (const double*)ctx->bnu.p : nullptr;
+    const double* dY = Y ? (const double*)ctx->bY.p : nullptr;
+    const double* dS2 = Y ? (const double*)ctx->bS2.p : nullptr;
+    if (cd_shared)
+        rc = pioran_celerite_logl_batch_dev(ds, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu, dY,
+                                            dS2, (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
+    else
+        rc = pioran_celerite_logl_batch_dev_cd(ds, B, J, (const double*)ctx->bA.p, (const double*)ctx->bB.p,
+                                               (const double*)ctx->bC.p, (const double*)ctx->bD.p, dmu, dnu, dY, dS2,
+                                               (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->bout.p, B * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (status)
+        HIPCHK(ctx, hipMemcpyAsync(status, ctx->bst.p, B * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PIORAN_OK;
+}
+
+int pioran_celerite_logl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
+                         const double* d, const double* t, const double* y, const double* sigma2, double* out,
+                         int32_t* status)
+{
+    if (!ctx || N < 1 || J < 1 || !a || !b || !c || !d || !t || !y || !sigma2 || !out) return PIORAN_ERR_ARG;
+    pioran_ds* ds = nullptr;
+    int rc = pioran_dataset_create(ctx, N, t, y, sigma2, &ds);
+    if (rc) return rc;
+    rc = pioran_celerite_logl_batch(ds, 1, J, a, b, c, d, 1, nullptr, nullptr, nullptr, nullptr, out, status);
+    pioran_dataset_destroy(ds);
+    return rc;
+}
+
+const char* pioran_celerite_config_name(int64_t R)
+{
+    if (R < 1 || R > pioran_scan_supported_rows()) return "fallback";
+    return pioran_scan_config_name((int)R);
+}
+
+}  // extern "C"

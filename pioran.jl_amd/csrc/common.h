@@ -1,0 +1,53 @@
+// Shared declarations of the pioran-hip native library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PIORAN_OK 0
+#define PIORAN_ERR_ARG (-1)
+#define PIORAN_ERR_HIP (-2)
+#define PIORAN_ERR_ALLOC (-3)
+#define PIORAN_ERR_UNSUPPORTED (-4)
+
+// layout of the shared per-step table ("trig/phi table"):
+//   tab[n][q][jp], q in {0: cos(d_j t_n), 1: sin(d_j t_n), 2: exp(-c_j (t_n - t_{n-1}))},
+//   jp in [0, J] — column J is the inert padding term (co=1, si=0, phi=0).
+struct ScanParams {
+    int64_t N;            // time stamps
+    int32_t J;            // celerite terms
+    int32_t R;            // active rows (<= 2J; structurally-zero sin rows of d=b=0 terms dropped)
+    int64_t B;            // batch (independent draws)
+    const double* tab;    // shared table [N][3][J+1], or nullptr when (c,d) are per draw
+    const int32_t* rowmap;  // [R]: term | kind<<30 (kind 1 = sin row)
+    const double* t;      // [N]   (used only when tab == nullptr)
+    const double* y;      // [N]   shared series (mean NOT subtracted), or nullptr if Y given
+    const double* s2;     // [N]   shared measurement variances
+    const double* Y;      // [B][N] per-draw series or nullptr
+    const double* S2;     // [B][N] per-draw variances or nullptr
+    const double* A;      // [B][J]
+    const double* Bc;     // [B][J]
+    const double* C;      // [J] or [B][J] (per-draw path)
+    const double* D;      // [J] or [B][J]
+    const double* mu;     // [B] or nullptr
+    const double* nu;     // [B] or nullptr
+    double* out;          // [B]
+    int32_t* status;      // [B] or nullptr
+    double* scratch;      // fallback kernel: [B][R*R + 4R]
+};
+
+// celerite_scan.hip
+int pioran_launch_scan(const ScanParams& p, hipStream_t stream);
+int pioran_scan_supported_rows();
+const char* pioran_scan_config_name(int R);
+// celerite_fallback.hip
+int pioran_launch_scan_fallback(const ScanParams& p, hipStream_t stream);
+size_t pioran_fallback_scratch_doubles(int R);
+// table.hip
+int pioran_launch_table(int64_t N, int32_t J, const double* t, const double* c, const double* d,
+                        double* tab, hipStream_t stream);
+// dense.hip
+struct DenseWork;
+int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,
+                            const double* d, const double* t, const double* y, const double* s2,
+                            double* K /*N*N*/, double* work /*>= 4N*/, double* out, int32_t* info,
+                            hipStream_t stream);

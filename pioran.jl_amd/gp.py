@@ -1,0 +1,256 @@
+"""GP facade + solver entry points of the hot path, host side (Python over the C ABI).
+
+Mirrors, with the same names and argument meaning:
+  ScalableGP(mu, kernel[, solver]) / f(t, sigma2) / logpdf(fx, y)   src/scalable_GP.jl:24-42,162-166
+  log_likelihood(cov, tau, y, sigma2; solver)                       src/celerite_solver.jl:262-294
+  logl(a, b, c, d, tau, y, sigma2)                                  src/celerite_solver.jl:312-334
+  log_likelihood_direct(cov, t, y, sigma2)  (returns +NLL)          src/direct_solver.jl:6-21
+plus the batched entry the reference lacks: logpdf_batch / Dataset.logl_batch.
+
+Everything numerical happens in libpioran_hip.so on the GPU.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .kernels import SemiSeparable, SumOfCelerite
+
+_SOLVERS = ("celerite", "celerite_matrix")
+
+
+def _f64(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def _ptr(x):
+    return None if x is None else ctypes.c_void_p(x.ctypes.data)
+
+
+class Context:
+    """One GPU + one HIP stream (pioran_ctx).  One per host thread / rank."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        L = _lib.lib()
+        h = ctypes.c_void_p()
+        if stream is None:
+            _lib.check(L.pioran_ctx_create(int(device), ctypes.byref(h)))
+        else:
+            _lib.check(L.pioran_ctx_create_on_stream(int(device), ctypes.c_void_p(stream), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            _lib.lib().pioran_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _lib.check(_lib.lib().pioran_ctx_synchronize(self._h), self._h)
+
+    def event_record(self, slot: int):
+        _lib.check(_lib.lib().pioran_ctx_event_record(self._h, slot), self._h)
+
+    def event_elapsed_ms(self, a: int, b: int) -> float:
+        ms = ctypes.c_float()
+        _lib.check(_lib.lib().pioran_ctx_event_elapsed_ms(self._h, a, b, ctypes.byref(ms)), self._h)
+        return ms.value
+
+    # -- scalar drop-ins ---------------------------------------------------------------------
+    def logl(self, a, b, c, d, tau, y, sigma2, return_status=False):
+        a, b, c, d, tau, y, sigma2 = map(_f64, (a, b, c, d, tau, y, sigma2))
+        if not (len(a) == len(b) == len(c) == len(d)) or not (len(tau) == len(y) == len(sigma2)):
+            raise ValueError("inconsistent lengths")
+        out = ctypes.c_double()
+        st = ctypes.c_int32()
+        _lib.check(_lib.lib().pioran_celerite_logl(self._h, len(tau), len(a), _ptr(a), _ptr(b), _ptr(c), _ptr(d),
+                                                   _ptr(tau), _ptr(y), _ptr(sigma2), ctypes.byref(out),
+                                                   ctypes.byref(st)), self._h)
+        return (out.value, st.value) if return_status else out.value
+
+    def dense_nll(self, a, b, c, d, t, y, sigma2, return_info=False):
+        a, b, c, d, t, y, sigma2 = map(_f64, (a, b, c, d, t, y, sigma2))
+        out = ctypes.c_double()
+        info = ctypes.c_int32()
+        _lib.check(_lib.lib().pioran_dense_nll(self._h, len(t), len(a), _ptr(a), _ptr(b), _ptr(c), _ptr(d), _ptr(t),
+                                               _ptr(y), _ptr(sigma2), ctypes.byref(out), ctypes.byref(info)), self._h)
+        return (out.value, info.value) if return_info else out.value
+
+    def dense_covariance(self, a, b, c, d, t, sigma2):
+        a, b, c, d, t, sigma2 = map(_f64, (a, b, c, d, t, sigma2))
+        K = np.empty((len(t), len(t)), dtype=np.float64)
+        _lib.check(_lib.lib().pioran_dense_covariance(self._h, len(t), len(a), _ptr(a), _ptr(b), _ptr(c), _ptr(d),
+                                                      _ptr(t), _ptr(sigma2), _ptr(K)), self._h)
+        return K  # symmetric, so row/column-major does not matter
+
+
+_default_ctx: Context | None = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class Dataset:
+    """A time series resident in HBM (pioran_ds): upload (t, y, sigma2) once, evaluate many batches."""
+
+    def __init__(self, t, y, sigma2, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        t, y, sigma2 = map(_f64, (t, y, sigma2))
+        if not (len(t) == len(y) == len(sigma2)) or len(t) < 1:
+            raise ValueError("t, y, sigma2 must be non-empty and of equal length")
+        self.N = len(t)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().pioran_dataset_create(self.ctx._h, self.N, _ptr(t), _ptr(y), _ptr(sigma2),
+                                                    ctypes.byref(h)), self.ctx._h)
+        self._h = h
+        self.J = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self.ctx._h:
+            _lib.lib().pioran_dataset_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prepare(self, c, d, real_term=None):
+        """Declare the (c, d) shared by the following device-pointer batches; builds the table."""
+        c, d = _f64(c), _f64(d)
+        rt = None if real_term is None else np.ascontiguousarray(real_term, dtype=np.int32)
+        _lib.check(_lib.lib().pioran_dataset_prepare(self._h, len(c), _ptr(c), _ptr(d), _ptr(rt)), self.ctx._h)
+        self.J = len(c)
+
+    def logl_batch(self, A, Bc, C, Dd, mu=None, nu=None, Y=None, S2=None, return_status=False):
+        """B log-likelihoods, host arrays.  A, Bc: (B, J); C, Dd: (J,) shared or (B, J) per draw."""
+        A, Bc, C, Dd = map(_f64, (A, Bc, C, Dd))
+        if A.ndim != 2 or A.shape != Bc.shape:
+            raise ValueError("A and Bc must be (B, J) arrays of equal shape")
+        B, J = A.shape
+        cd_shared = C.ndim == 1
+        if C.shape != Dd.shape or C.shape != ((J,) if cd_shared else (B, J)):
+            raise ValueError("C, Dd must be (J,) or (B, J)")
+        mu = None if mu is None else _f64(np.broadcast_to(mu, (B,)))
+        nu = None if nu is None else _f64(np.broadcast_to(nu, (B,)))
+        if (Y is None) != (S2 is None):
+            raise ValueError("Y and S2 must be given together")
+        if Y is not None:
+            Y, S2 = _f64(Y), _f64(S2)
+            if Y.shape != (B, self.N) or S2.shape != (B, self.N):
+                raise ValueError("Y, S2 must be (B, N)")
+        out = np.empty(B)
+        st = np.zeros(B, dtype=np.int32)
+        _lib.check(_lib.lib().pioran_celerite_logl_batch(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd),
+                                                         int(cd_shared), _ptr(mu), _ptr(nu), _ptr(Y), _ptr(S2),
+                                                         _ptr(out), _ptr(st)), self.ctx._h)
+        return (out, st) if return_status else out
+
+    def logl_batch_dev(self, B, dA, dBc, dmu=0, dnu=0, dY=0, dS2=0, dout=0, dstatus=0):
+        """Device-pointer (int addresses) asynchronous variant; (c, d) from prepare()."""
+        v = ctypes.c_void_p
+        _lib.check(_lib.lib().pioran_celerite_logl_batch_dev(self._h, int(B), v(dA), v(dBc), v(dmu or None),
+                                                             v(dnu or None), v(dY or None), v(dS2 or None), v(dout),
+                                                             v(dstatus or None)), self.ctx._h)
+
+
+# ---------------------------------------------------------------------------------------------
+# mean functions (AbstractGPs ConstMean / ZeroMean / CustomMean as used at scalable_GP.jl:164)
+# ---------------------------------------------------------------------------------------------
+class CustomMean:
+    def __init__(self, f):
+        self.f = f
+
+    def __call__(self, x):
+        return np.asarray(self.f(np.asarray(x, float)), float)
+
+
+def _mean_vector(mean, x):
+    if isinstance(mean, CustomMean):
+        return mean(x)
+    return np.full(len(x), float(mean))
+
+
+class ScalableGP:
+    """ScalableGP(kernel) | ScalableGP(mu, kernel) | ScalableGP(mu, kernel, solver)   scalable_GP.jl:24-40."""
+
+    def __init__(self, *args):
+        if len(args) == 1:
+            mean, kernel, solver = 0.0, args[0], "celerite"
+        elif len(args) == 2:
+            mean, kernel, solver = args[0], args[1], "celerite"
+        elif len(args) == 3:
+            mean, kernel, solver = args
+        else:
+            raise TypeError("ScalableGP(kernel) | ScalableGP(mean, kernel[, solver])")
+        if not isinstance(kernel, SemiSeparable):
+            raise TypeError("kernel must be a SemiSeparable covariance")
+        self.mean, self.kernel, self.solver = mean, kernel, str(solver).lstrip(":")
+
+    def __call__(self, t, sigma2=None):
+        t = _f64(t)
+        s2 = np.zeros(len(t)) if sigma2 is None else _f64(np.broadcast_to(sigma2, t.shape))
+        return FiniteScalableGP(self, t, s2)
+
+
+class FiniteScalableGP:
+    """f(t, sigma2): AbstractGPs.FiniteGP{<:ScalableGP} (scalable_GP.jl:42)."""
+
+    def __init__(self, f: ScalableGP, x, sigma2):
+        self.f, self.x, self.sigma2 = f, x, sigma2
+
+
+def logpdf(fx: FiniteScalableGP, Y, ctx: Context | None = None):
+    """Distributions.logpdf(f::FiniteScalableGP, Y)   src/scalable_GP.jl:162-166."""
+    Y = _f64(Y).reshape(-1)
+    y = Y - _mean_vector(fx.f.mean, fx.x)
+    return log_likelihood(fx.f.kernel, fx.x, y, fx.sigma2, solver=fx.f.solver, ctx=ctx)
+
+
+def log_likelihood(cov: SemiSeparable, tau, y, sigma2, solver="celerite", ctx: Context | None = None):
+    """log_likelihood(cov, tau, y, sigma2; solver)   src/celerite_solver.jl:262-294.
+    Both solver symbols the reference accepts run the same HIP kernel (the reference's
+    :celerite_matrix variant is experimental and untested, src/celerite_solver.jl:160-248)."""
+    solver = str(solver).lstrip(":")
+    if solver not in _SOLVERS:
+        raise ValueError(f"solver {solver} not recognised, use either :celerite or :celerite_matrix")
+    a, b, c, d = cov.celerite_coefs()
+    a, b, c, d = (np.real(np.atleast_1d(v)) for v in (a, b, c, d))
+    return logl(a, b, c, d, tau, y, sigma2, ctx=ctx)
+
+
+def logl(a, b, c, d, tau, y, sigma2, ctx: Context | None = None):
+    """logl(a, b, c, d, tau, y, sigma2)   src/celerite_solver.jl:312-334."""
+    val, st = (ctx or default_context()).logl(a, b, c, d, tau, y, sigma2, return_status=True)
+    if st == 2 and not np.isfinite(val):
+        # the reference throws DomainError from log(D[1] < 0) (celerite_solver.jl:126)
+        raise ValueError("log-likelihood is not finite: the covariance matrix is not positive definite")
+    return val
+
+
+def log_likelihood_direct(cov: SemiSeparable, t, y, sigma2, ctx: Context | None = None):
+    """log_likelihood_direct(cov, t, y, sigma2): dense solver, returns the POSITIVE NLL like the
+    reference (src/direct_solver.jl:19).  Raises like PosDefException when K is not PD."""
+    a, b, c, d = (np.real(np.atleast_1d(v)) for v in cov.celerite_coefs())
+    val, info = (ctx or default_context()).dense_nll(a, b, c, d, t, y, sigma2, return_info=True)
+    if info != 0:
+        raise np.linalg.LinAlgError(f"matrix is not positive definite; Cholesky factorization failed at pivot {info}")
+    return val
+
+
+def logpdf_batch(ds: Dataset, A, Bc, C, Dd, mu=None, nu=None, Y=None, S2=None, return_status=False):
+    """B independent logpdf evaluations on one data set (nested-sampling live points / MCMC walkers)."""
+    return ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2, return_status=return_status)
