@@ -115,8 +115,9 @@ def main():
     ctx = pj.Context(local_rank, stream=stream.cuda_stream)
     ds = pj.Dataset(t, y, yerr ** 2, ctx)
     ds.prepare(C, Dd, real_term.astype(np.int32))
-    dA = torch.from_numpy(A).to(dev); dB = torch.from_numpy(Bc).to(dev)
-    dmu = torch.from_numpy(mu).to(dev); dnu = torch.from_numpy(nu).to(dev)
+    A, Bc, mu, nu = (np.ascontiguousarray(v, dtype=np.float64) for v in (A, Bc, mu, nu))
+    dA = torch.from_numpy(A).to(dev).contiguous(); dB = torch.from_numpy(Bc).to(dev).contiguous()
+    dmu = torch.from_numpy(mu).to(dev).contiguous(); dnu = torch.from_numpy(nu).to(dev).contiguous()
     dout = torch.empty(B, dtype=torch.float64, device=dev)
     dst = torch.zeros(B, dtype=torch.int32, device=dev)
     gathered = torch.empty(B * world, dtype=torch.float64, device=dev) if world > 1 else None

@@ -200,7 +200,7 @@ def approx_batch(model, theta, f_min, f_max, n_components=20, norm=1.0, S_low=20
     sp, Bm = build_approx(n_components, f0, fM, basis_function)
     psd = np.stack([model(*row)(sp) for row in theta]) if B < 64 else _eval_model_batch(model, theta, sp)
     psd = psd / psd[:, :1]
-    amplitudes = np.linalg.solve(Bm, psd.T).T  # one LU, B right-hand sides
+    amplitudes = np.ascontiguousarray(np.linalg.solve(Bm, psd.T).T)  # one LU, B right-hand sides; C order (B, J)
     integ = get_norm_psd(amplitudes, sp, f_min, f_max, basis_function, is_integrated_power)
     amplitudes = amplitudes * (np.broadcast_to(np.asarray(norm, float), (B,)) / integ)[:, None]
     if basis_function == "SHO":

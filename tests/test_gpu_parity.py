@@ -210,21 +210,24 @@ def test_full_size_properties(ctx, full_size):
     ds = pj.Dataset(t, y, yerr ** 2, ctx)
     base, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
     ok = st == 0
-    assert ok.mean() > 0.5
+    assert ok.mean() > 0.9
     # (1) scale covariance: y -> s y, K -> s^2 K  =>  logL -> logL - N log s
     s = 3.0
     ds2 = pj.Dataset(t, s * y, s * s * yerr ** 2, ctx)
     sc = ds2.logl_batch(s * s * A, s * s * Bc, C, Dd, mu=s * mu, nu=nu)
-    assert relerr(sc[ok], (base - N * np.log(s))[ok]) < 1e-9
+    assert relerr(sc[ok], (base - N * np.log(s))[ok]) < 1e-8   # s = 3 changes every rounding; north-star bar
+    ds4 = pj.Dataset(t, 2.0 * y, 4.0 * yerr ** 2, ctx)   # power-of-two scaling is exact in fp64
+    sc4 = ds4.logl_batch(4.0 * A, 4.0 * Bc, C, Dd, mu=2.0 * mu, nu=nu)
+    assert relerr(sc4[ok], (base - N * np.log(2.0))[ok]) < 1e-13
     # (2) permutation of terms leaves the kernel unchanged
     perm = np.random.default_rng(0).permutation(20)
     pm = ds.logl_batch(A[:, perm], Bc[:, perm], C[perm], Dd[perm], mu=mu, nu=nu)
-    assert relerr(pm[ok], base[ok]) < 1e-9
+    assert relerr(pm[ok], base[ok]) < 1e-8
     # (3) splitting a term in two halves (J = 21) leaves the kernel unchanged
     A2 = np.concatenate([A, A[:, :1] / 2], axis=1); A2[:, 0] /= 2
     B2 = np.concatenate([Bc, Bc[:, :1] / 2], axis=1); B2[:, 0] /= 2
     sp = ds.logl_batch(A2, B2, np.append(C, C[0]), np.append(Dd, Dd[0]), mu=mu, nu=nu)
-    assert relerr(sp[ok], base[ok]) < 1e-9
+    assert relerr(sp[ok], base[ok]) < 1e-8
     # (4) batch consistency: the same draw evaluated in a different batch position / batch size is bit-identical
     sub = ds.logl_batch(A[100:103], Bc[100:103], C, Dd, mu=mu[100:103], nu=nu[100:103])
     assert (sub == base[100:103]).all() or np.array_equal(np.isnan(sub), np.isnan(base[100:103]))
