@@ -176,15 +176,15 @@ int pioran_ctx_create_on_stream(int device, void* hip_stream, pioran_ctx** out)
 int pioran_ctx_destroy(pioran_ctx* ctx)
 {
     if (!ctx) return PIORAN_ERR_ARG;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
     pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
                                &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork};
     for (auto* b : bufs)
-        if (b->p) hipFree(b->p);
+        if (b->p) (void)hipFree(b->p);
     for (auto& e : ctx->ev)
-        if (e) hipEventDestroy(e);
-    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PIORAN_OK;
 }
@@ -233,7 +233,7 @@ int pioran_dataset_create(pioran_ctx* ctx, int64_t N, const double* t, const dou
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         ctx->last_err = hipGetErrorString(e);
-        hipFree(base);
+        (void)hipFree(base);
         delete ds;
         return PIORAN_ERR_HIP;
     }
@@ -244,12 +244,12 @@ int pioran_dataset_create(pioran_ctx* ctx, int64_t N, const double* t, const dou
 int pioran_dataset_destroy(pioran_ds* ds)
 {
     if (!ds) return PIORAN_ERR_ARG;
-    hipSetDevice(ds->ctx->device);
-    hipStreamSynchronize(ds->ctx->stream);
-    if (ds->t) hipFree(ds->t);
-    if (ds->tab) hipFree(ds->tab);
-    if (ds->rowmap) hipFree(ds->rowmap);
-    if (ds->dc) hipFree(ds->dc);
+    (void)hipSetDevice(ds->ctx->device);
+    (void)hipStreamSynchronize(ds->ctx->stream);
+    if (ds->t) (void)hipFree(ds->t);
+    if (ds->tab) (void)hipFree(ds->tab);
+    if (ds->rowmap) (void)hipFree(ds->rowmap);
+    if (ds->dc) (void)hipFree(ds->dc);
     delete ds;
     return PIORAN_OK;
 }
@@ -270,7 +270,7 @@ int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const doub
     if (same_rows) return PIORAN_OK;
     if (!same_cd) {
         ds->prepared = false;
-        const size_t need = (size_t)ds->N * 3 * (size_t)(J + 1);
+        const size_t need = (size_t)ds->N * 3 * (size_t)(J + 2);
         if (need > ds->tab_cap) {
             if (ds->tab) HIPCHK(ctx, hipFree(ds->tab));
             ds->tab = nullptr;

@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(64) celerite_fallback_kernel(const ScanParams 
     __shared__ int term_s[RMAX];
     const int lane = threadIdx.x;
     const int64_t b = b0 + blockIdx.x;
-    const int J = p.J, Jp = J + 1, R = p.R;
+    const int J = p.J, Jp = J + 2, R = p.R;
     const int64_t N = p.N;
     double* S = p.scratch + (int64_t)blockIdx.x * ((int64_t)R * R);
 

@@ -7,6 +7,9 @@
 //   q    = S u ;  D_n = sum(a) + sigma2_n - u'q ;  w <- (v - q) / D_n      (:80-97)
 //   f   <- phi o (f + w_prev z_{n-1}) ;  z_n = y_n - u'f                    (:136-141)
 //   logdet += log|D_n| ;  quad += z_n^2 / D_n        (forward-only form of :145-155,:333)
+// The forward substitution is not a separate recurrence here: y is carried as ONE EXTRA ROW of S
+// (row index R, with u = 0, v = y_n - mu, phi = 1).  By symmetry that row of S is f', so its
+// (S u) entry is u'f, its "w" is z_n / D_n, and no cross-lane reduction is needed for z_n.
 // Nothing per-step is written to HBM: U, V(W), phi, D, z of the reference are never materialised.
 //
 // Mapping to the hardware:
@@ -44,7 +47,8 @@ __device__ __forceinline__ void static_for(F&& f)
 template <int N>
 __device__ __forceinline__ double row_bcast(double x)
 {
-    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + N, 0xf, 0xf, false);
+    // `old` undefined: every lane is written (row_newbcast has no invalid lanes), so no init mov
+    return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true);
 }
 
 template <int CTRL>
@@ -79,9 +83,11 @@ template <int RPL, int CBR, int NSRC, bool SHARED_TAB>
 __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
 {
     static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
-    constexpr int G = 16 * CBR;      // lanes per draw
-    constexpr int EPW = 64 / G;      // draws per wavefront
-    constexpr int NC = NSRC * RPL;   // columns held per lane
+    constexpr int G = 16 * CBR;          // lanes per draw
+    constexpr int EPW = 64 / G;          // draws per wavefront
+    constexpr int NC = NSRC * RPL;       // columns held per lane
+    constexpr int YLAM = NSRC * CBR - 1; // the y row is the LAST row slot: logical lane YLAM, slot RPL-1
+    constexpr int YS = RPL - 1;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -89,12 +95,13 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
     const int r = (lane % G) >> 4;           // DPP row inside the draw = column block
     const int l = lane & 15;
     const int lam = (l + NSRC * r) & 15;     // logical lane: which rows this lane owns
-    const bool contributes = l < NSRC;       // each row is counted once in u'q and u'f
+    const bool contributes = l < NSRC;       // each row is counted once in u'q
+    const bool isy = lam == YLAM;            // this lane's slot YS is the y row
     const int64_t b_raw = ((int64_t)blockIdx.x * 4 + wave) * EPW + e;
     const bool active = b_raw < p.B;
     const int64_t b = active ? b_raw : p.B - 1;
 
-    const int J = p.J, Jp = J + 1, R = p.R;
+    const int J = p.J, Jp = J + 2, R = p.R;  // table columns J (inert pad) and J+1 (y row)
     const int64_t N = p.N;
 
     int term[RPL];
@@ -116,8 +123,9 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
                 cc[i] = p.C[b * J + term[i]];
                 dd[i] = p.D[b * J + term[i]];
             }
-        } else {  // inert padding row: u = 0, v = 1, phi = 0
-            term[i] = J;
+        } else {
+            // inert padding row (u = 0, v = 1, phi = 0), or the y row (u = 0, v = y_n - mu, phi = 1)
+            term[i] = (isy && i == YS) ? J + 1 : J;
             ksin[i] = false;
             al[i] = 0.0;
             be[i] = 0.0;
@@ -158,7 +166,9 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
                     si_[i] = s_;
                     ph_[i] = exp(-cc[i] * dt);     // :54
                 } else {
-                    co_[i] = 1.0; si_[i] = 0.0; ph_[i] = 0.0;
+                    co_[i] = term[i] == J ? 1.0 : 0.0;
+                    si_[i] = 0.0;
+                    ph_[i] = term[i] == J ? 0.0 : 1.0;
                 }
             }
         }
@@ -175,15 +185,14 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
     for (int i = 0; i < RPL; ++i)
 #pragma unroll
         for (int c = 0; c < NC; ++c) S[i][c] = 0.0;
-    double w[RPL], f[RPL];
+    double w[RPL], v[RPL];
     double Dn = suma + (has_nu ? nu * s2n : s2n);
     double rD = 1.0 / Dn;
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) {
-        w[i] = (ksin[i] ? si[i] : co[i]) * rD;
-        f[i] = 0.0;
-    }
-    double z = yn - mu;
+    for (int i = 0; i < RPL; ++i) v[i] = ksin[i] ? si[i] : co[i];
+    if (isy) v[YS] = yn - mu;                // z_1 = y_1      :128
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) w[i] = v[i] * rD;
     double Pm = Dn;      // running product of |D| (sign of D_1 kept: log of a negative D_1 is NaN, :126)
     int Pe = 0;
     {
@@ -191,7 +200,7 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
         Pm = frexp(Pm, &ex);
         Pe += ex;
     }
-    double quad = z * z * rD;
+    double quad = v[YS] * v[YS] * rD;        // meaningful in the y-row lanes only
     bool nonpd = !(Dn > 0.0);
 
     double co2[RPL], si2[RPL], ph2[RPL], yn2, s2n2;
@@ -206,16 +215,14 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
         load_step(n + 1 < N ? n + 1 : n, co2, si2, ph2, yn2, s2n2);
 
         double u[RPL], g[RPL], qt[RPL];
-        double zzp = 0.0;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             u[i] = al[i] * co[i] + be[i] * si[i];
             g[i] = Dn * w[i];                       // dn = D[n-1] * V[j,n-1]   :73
-            f[i] = (f[i] + w[i] * z) * ph[i];       // :136
-            zzp += u[i] * f[i];                     // :137
             qt[i] = 0.0;
+            v[i] = ksin[i] ? si[i] : co[i];
         }
-        if (!contributes) zzp = 0.0;
+        if (isy) v[YS] = yn - mu;
 
         // ---- S update + q = S u over this DPP row's column block ----
         static_for<0, NSRC>([&](auto Nc) {
@@ -248,13 +255,12 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
         for (int i = 0; i < RPL; ++i) sp += u[i] * qt[i];        // u'Su                       :83,88
         if (!contributes) sp = 0.0;
         const double s = group_sum<CBR>(sp);
-        const double zz = group_sum<CBR>(zzp);
 
         Dn = suma + (has_nu ? nu * s2n : s2n) - s;               // :92
         rD = 1.0 / Dn;
+        const double z = v[YS] - qt[YS];                         // y row: z_n = y_n - u'f      :141
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) w[i] = ((ksin[i] ? si[i] : co[i]) - qt[i]) * rD;   // :89,96
-        z = (yn - mu) - zz;                                      // :141
+        for (int i = 0; i < RPL; ++i) w[i] = (v[i] - qt[i]) * rD;                        // :89,96
         nonpd |= !(Dn > 0.0);
         Pm *= fabs(Dn);                                          // log(abs(D[n]))  :140
         int ex;
@@ -263,7 +269,7 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
         quad = fma(z * z, rD, quad);                             // z_n^2 / D_n  (== y'K^-1 y, :333)
     }
 
-    if (active && (lane % G) == 0) {
+    if (active && isy && r == 0) {
         const double logdet = log(Pm) + (double)Pe * 0.6931471805599453094;
         const double res = -0.5 * logdet - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * quad;
         p.out[b] = res;
@@ -286,22 +292,22 @@ struct ScanConfig {
     const char* name;
     int rpl, cbr, nsrc;
     LaunchFn fn;
-    int capacity() const { return rpl * cbr * nsrc; }
+    int capacity() const { return rpl * cbr * nsrc - 1; }  // one row slot carries y
 };
 
 #define CFG(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC, RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC>}
 // preference order: first entry whose capacity >= R wins (unless PIORAN_SCAN_CONFIG names another)
 const ScanConfig kConfigs[] = {
-    CFG(1, 1, 4),  CFG(1, 1, 8),  CFG(1, 1, 12), CFG(1, 1, 16),           // R <= 16
-    CFG(2, 1, 10), CFG(2, 1, 12), CFG(2, 1, 14), CFG(2, 1, 16),           // R <= 32
-    CFG(3, 2, 6),  CFG(3, 2, 7),  CFG(3, 2, 8),                           // R <= 48
-    CFG(4, 4, 4),                                                         // R <= 64
-    CFG(5, 4, 4),                                                         // R <= 80
+    CFG(1, 1, 5),  CFG(1, 1, 9),  CFG(1, 1, 13), CFG(1, 1, 16),           // R <= 15
+    CFG(2, 1, 9),  CFG(2, 1, 11), CFG(2, 1, 13), CFG(2, 1, 15), CFG(2, 1, 16),  // R <= 31
+    CFG(3, 2, 6),  CFG(3, 2, 7),  CFG(3, 2, 8),                           // R <= 47
+    CFG(4, 4, 4),                                                         // R <= 63
+    CFG(5, 4, 4),                                                         // R <= 79
     // alternatives kept for tuning runs (selected by name)
     CFG(3, 1, 14), CFG(3, 4, 4), CFG(2, 2, 8),
 };
 #undef CFG
-constexpr int kNumPreferred = 13;
+constexpr int kNumPreferred = 14;
 
 const ScanConfig* pick_config(int R)
 {
@@ -316,7 +322,7 @@ const ScanConfig* pick_config(int R)
 
 }  // namespace
 
-int pioran_scan_supported_rows() { return 80; }
+int pioran_scan_supported_rows() { return 79; }
 
 const char* pioran_scan_config_name(int R)
 {

@@ -11,13 +11,13 @@
 
 // layout of the shared per-step table ("trig/phi table"):
 //   tab[n][q][jp], q in {0: cos(d_j t_n), 1: sin(d_j t_n), 2: exp(-c_j (t_n - t_{n-1}))},
-//   jp in [0, J] — column J is the inert padding term (co=1, si=0, phi=0).
+//   jp in [0, J+1] — column J is the inert padding term (1, 0, 0), column J+1 the y row (0, 0, 1).
 struct ScanParams {
     int64_t N;            // time stamps
     int32_t J;            // celerite terms
     int32_t R;            // active rows (<= 2J; structurally-zero sin rows of d=b=0 terms dropped)
     int64_t B;            // batch (independent draws)
-    const double* tab;    // shared table [N][3][J+1], or nullptr when (c,d) are per draw
+    const double* tab;    // shared table [N][3][J+2], or nullptr when (c,d) are per draw
     const int32_t* rowmap;  // [R]: term | kind<<30 (kind 1 = sin row)
     const double* t;      // [N]   (used only when tab == nullptr)
     const double* y;      // [N]   shared series (mean NOT subtracted), or nullptr if Y given

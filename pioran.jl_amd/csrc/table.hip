@@ -12,12 +12,13 @@ __global__ void __launch_bounds__(256) table_kernel(int64_t N, int32_t J, const 
                                                     const double* __restrict__ c,
                                                     const double* __restrict__ d, double* __restrict__ tab)
 {
-    const int32_t Jp = J + 1;
+    const int32_t Jp = J + 2;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * Jp) return;
     const int64_t n = idx / Jp;
     const int32_t jp = (int32_t)(idx - n * Jp);
-    double co = 1.0, si = 0.0, ph = 0.0;  // column J: inert padding term
+    // column J: inert padding term (1, 0, 0); column J+1: the y row of the scan (0, 0, 1)
+    double co = jp == J ? 1.0 : 0.0, si = 0.0, ph = jp == J ? 0.0 : 1.0;
     if (jp < J) {
         const double tn = t[n];
         sincos(d[jp] * tn, &si, &co);
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(256) table_kernel(int64_t N, int32_t J, const 
 int pioran_launch_table(int64_t N, int32_t J, const double* t, const double* c, const double* d,
                         double* tab, hipStream_t stream)
 {
-    const int64_t total = N * (int64_t)(J + 1);
+    const int64_t total = N * (int64_t)(J + 2);
     const int64_t blocks = (total + 255) / 256;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return PIORAN_ERR_ARG;
     hipLaunchKernelGGL(table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, N, J, t, c, d, tab);
