@@ -120,13 +120,12 @@ def main():
     dmu = torch.from_numpy(mu).to(dev).contiguous(); dnu = torch.from_numpy(nu).to(dev).contiguous()
     dout = torch.empty(B, dtype=torch.float64, device=dev)
     dst = torch.zeros(B, dtype=torch.int32, device=dev)
-    gathered = torch.empty(B * world, dtype=torch.float64, device=dev) if world > 1 else None
 
     def step():
         ds.logl_batch_dev(B, dA.data_ptr(), dB.data_ptr(), dmu.data_ptr(), dnu.data_ptr(), 0, 0, dout.data_ptr(),
                           dst.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, dout)  # the only collective: B fp64 per rank
+            pj.farm.gather_logl(dout, B * world)  # the only collective: all-gather of B fp64 per rank (RCCL)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -145,7 +144,7 @@ def main():
                           dst.data_ptr())
         ev1.record(stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, dout)
+            gathered = pj.farm.gather_logl(dout, B * world)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs)

@@ -2,7 +2,7 @@
 
 Directory name has a dot, so import it through the repo-root shim: `import pioran_jl_amd as pj`.
 """
-from . import _lib  # noqa: F401
+from . import _lib, farm  # noqa: F401
 from .gp import (Context, CustomMean, Dataset, FiniteScalableGP, ScalableGP, default_context, log_likelihood,
                  log_likelihood_direct, logl, logpdf, logpdf_batch)
 from .kernels import (Celerite, Exp, ScaledKernel, SemiSeparable, SHO, SumOfCelerite, SumOfSemiSeparable,

@@ -1,0 +1,68 @@
+"""CPU tests (-m "not gpu"): the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/pioran_hip.h declares; entry points reject bad arguments without a GPU; the product fails
+loudly (no CPU fallback) when no GPU is present."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+import pioran_jl_amd as pj
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _declared_symbols():
+    text = (ROOT / "include" / "pioran_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pioran_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported():
+    names = _declared_symbols()
+    assert len(names) >= 18
+    L = ctypes.CDLL(str(pj._lib.LIB_PATH))
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/pioran_hip.h but not exported"
+    assert sorted(pj._lib.SIGNATURES) == names          # the ctypes binding covers exactly the header
+
+
+def test_library_is_gfx950_code_object():
+    data = pj._lib.LIB_PATH.read_bytes()
+    assert b"gfx950" in data and b"celerite_scan_kernel" in data
+
+
+def test_version_and_strerror():
+    L = pj._lib.lib()
+    assert L.pioran_abi_version() == 1
+    assert L.pioran_strerror(0) == b"ok"
+    assert L.pioran_strerror(-4) == b"unsupported size"
+    assert L.pioran_celerite_config_name(40) == b"rpl3_cbr2_nsrc7"
+    assert L.pioran_celerite_config_name(60).startswith(b"rpl4_cbr4")
+    assert L.pioran_celerite_config_name(128) == b"fallback"
+
+
+def test_argument_validation_without_gpu():
+    L = pj._lib.lib()
+    assert L.pioran_ctx_create(0, None) == -1
+    assert L.pioran_ctx_destroy(None) == -1
+    assert L.pioran_dataset_create(None, 10, None, None, None, None) == -1
+    assert L.pioran_celerite_logl_batch(None, 1, 1, None, None, None, None, 1, None, None, None, None, None, None) == -1
+    assert L.pioran_celerite_logl_batch_dev(None, 1, None, None, None, None, None, None, None, None) == -1
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pj._lib.PioranHipError):
+        pj.Context(0)
+    with pytest.raises(pj._lib.PioranHipError):
+        pj.logl([1.0], [0.0], [0.5], [0.0], [0.0, 1.0], [0.1, 0.2], [0.01, 0.01])
+
+
+def test_product_never_imports_oracle():
+    pkg = ROOT / "pioran.jl_amd"
+    for f in list(pkg.glob("*.py")) + list((pkg / "csrc").glob("*")):
+        txt = f.read_text(errors="ignore")
+        assert "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt, f

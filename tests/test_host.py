@@ -1,0 +1,157 @@
+"""CPU tests (-m "not gpu") of the host-side mirror of the reference interface (pioran.jl_amd/*.py):
+kernel containers, `+`/scaling algebra, approx / approx_batch — against the reference's literals and the
+pinned oracle.  Nothing here touches the GPU."""
+import json
+import math
+
+import numpy as np
+import pytest
+
+import pioran_jl_amd as pj
+from oracle import oracle as O
+
+
+@pytest.fixture(scope="module")
+def lit(golden_dir):
+    return json.loads((golden_dir / "reference_literals.json").read_text())
+
+
+def test_term_kernels_closed_forms():
+    """test/test_covariancefunctions.jl:3-30."""
+    t = np.linspace(0, 10, 500)
+    e = pj.Exp(1.0, 2.4)
+    np.testing.assert_allclose(e(t, 0.0), np.exp(-t * 2.4) / 2, rtol=1e-15)
+    a, b, c, d = 1.3, 4.0, 0.5, 3.2
+    t = np.linspace(0, 25, 500)
+    np.testing.assert_allclose(pj.Celerite(a, b, c, d)(t, 0.0), np.exp(-c * t) * (a * np.cos(d * t) + b * np.sin(d * t)),
+                               rtol=1e-14, atol=1e-15)
+    A, w0, Q = 1.5, 2 * math.pi * 0.23, 1 / math.sqrt(2)
+    t = np.linspace(0, 15, 500)
+    eta = math.sqrt(abs(1 - 1 / (4 * Q ** 2)))
+    np.testing.assert_allclose(pj.SHO(A, w0, Q)(t, 0.0),
+                               A * np.exp(-w0 * t / 2 / Q) * (np.cos(eta * w0 * t) + np.sin(eta * w0 * t) / (2 * eta * Q)),
+                               rtol=1e-14, atol=1e-15)
+
+
+def test_celerite_coefs_literals(lit):
+    assert pj.celerite_coefs(pj.Celerite(*lit["coefs_celerite"]["args"])) == lit["coefs_celerite"]["expected"]
+    assert pj.celerite_coefs(pj.Exp(*lit["coefs_exp"]["args"])) == lit["coefs_exp"]["expected"]
+    s = lit["coefs_sho"]
+    w0 = 2 * math.pi * s["w0_over_2pi"]
+    assert pj.celerite_coefs(pj.SHO(s["A"], w0, 1 / math.sqrt(2))) == [s["A"], s["A"], math.sqrt(2) / 2 * w0,
+                                                                        math.sqrt(2) / 2 * w0]
+    with pytest.raises(ValueError, match="SHO with Q≠1/√2 not implemented yet"):
+        pj.celerite_coefs(pj.SHO(s["A"], w0, 0.5))
+
+
+def _mk(term):
+    return {"Exp": pj.Exp, "Celerite": pj.Celerite}[term[0]](*term[1:])
+
+
+def test_sum_and_scale_algebra(lit):
+    """test/test_acvf.jl:3-33: `+` concatenation order and scaling of the amplitudes only."""
+    g = lit["acvf_sum_scaled_exp"]
+    e = g["scale"] * (_mk(g["terms"][0]) + _mk(g["terms"][1]))
+    got = [list(v) for v in pj.celerite_coefs(e)]
+    assert got == g["expected"]
+    g = lit["acvf_large_sum"]
+    k = _mk(g["terms"][0]) + _mk(g["terms"][1]) + _mk(g["terms"][2]) + _mk(g["terms"][3])
+    assert [list(v) for v in pj.celerite_coefs(k)] == g["expected"]
+    assert isinstance(k, pj.SumOfSemiSeparable) and isinstance(k, pj.SumOfTerms)
+    t = np.linspace(0, 10, 500)
+    e1, e2 = pj.Exp(1.0, 0.34), pj.Exp(2.4, 0.21)
+    np.testing.assert_allclose((e1 + e2)(t, 0.0), e1(t, 0.0) + e2(t, 0.0), rtol=1e-15)
+    np.testing.assert_allclose((12.5 * (e1 + e2))(t, 0.0), 12.5 * (e1(t, 0.0) + e2(t, 0.0)), rtol=1e-15)
+
+
+def test_sum_of_celerite_container():
+    """test/test_acvf.jl:35-64."""
+    rng = np.random.default_rng(1234)
+    a, b, c, d = 2 * rng.random(10), rng.random(10), rng.random(10), rng.random(10)
+    C = pj.SumOfCelerite(a, b, c, d)
+    assert isinstance(C, pj.SumOfTerms)
+    for got, exp in zip(pj.celerite_coefs(C), (a, b, c, d)):
+        assert (got == exp).all()
+    assert C.cov == [pj.Celerite(*x) for x in zip(a, b, c, d)]
+    S = pj.ScaledKernel(C, 3.0)
+    assert (S.a == 3.0 * a).all() and (S.b == 3.0 * b).all() and (S.c == c).all() and (S.d == d).all()
+    tau = np.linspace(0, 5, 40)
+    np.testing.assert_allclose(C.kappa(tau), [O.kappa(a, b, c, d, x) for x in tau], rtol=1e-13)
+
+
+def test_psd_models_and_amplitude_golden(lit):
+    f = 10 ** np.linspace(-3, 2, 1000)
+    P = pj.SingleBendingPowerLaw(0.3, 0.02, 2.93)
+    assert (P(f) == (f / 0.02) ** (-0.3) / (1 + (f / 0.02) ** (2.93 - 0.3))).all()      # test/test_psd.jl:3-7
+    Dm = pj.DoubleBendingPowerLaw(0.3, 0.02, 1.4, 10.2, 2.93)
+    assert (Dm(f) == (f / 0.02) ** (-0.3) / (1 + (f / 0.02) ** (1.4 - 0.3)) / (1 + (f / 10.2) ** (2.93 - 1.4))).all()
+    g = lit["psd_amplitudes"]
+    sp, _ = pj.build_approx(g["J"], g["f0"], g["fM"])
+    np.testing.assert_allclose(sp, g["f0"] * (g["fM"] / g["f0"]) ** (np.arange(g["J"]) / (g["J"] - 1)), rtol=1e-15)
+    amp = pj.get_approx_coefficients(pj.SingleBendingPowerLaw(*g["params"]), g["f0"], g["fM"], n_components=g["J"])
+    np.testing.assert_allclose(amp, g["expected"], rtol=1e-9)                              # test/test_psd.jl:32-39
+
+
+@pytest.mark.parametrize("basis", ["SHO", "DRWCelerite"])
+@pytest.mark.parametrize("integ", [True, False])
+def test_approx_matches_oracle(basis, integ):
+    for a1, f1, a2, var in [(0.2, 1.3e-2, 3.2, 1.32), (0.92, 0.5, 3.8, 0.21), (-0.2, 3.0, 1.6, 5.0)]:
+        R = pj.approx(pj.SingleBendingPowerLaw(a1, f1, a2), 2e-3, 3.52e2, 25, var, is_integrated_power=integ,
+                      basis_function=basis)
+        ref = O.approx(lambda f: O.single_bending_power_law(f, a1, f1, a2), 2e-3, 3.52e2, 25, var,
+                       is_integrated_power=integ, basis_function=basis)
+        assert isinstance(R, pj.SumOfCelerite)
+        for got, exp in zip(pj.celerite_coefs(R), ref):   # cond(spectral matrix) ~ 1e3-1e4 amplifies ulp-level
+            np.testing.assert_allclose(got, exp, rtol=1e-9, atol=1e-14 * np.abs(exp).max())  # differences in the grid
+        if not integ:
+            assert R.a.sum() == pytest.approx(var, rel=1e-12)                              # test/test_psd.jl:100-153
+        assert len(R.a) == (25 if basis == "SHO" else 50)
+
+
+def test_approx_with_qpo_features():
+    """test/test_psd.jl:206-285: one extra celerite term per QPO, continuum required."""
+    PS = pj.SingleBendingPowerLaw(0.2, 1.3e-2, 3.2) + pj.QPO(2.0, 1e-2, 14.2) + pj.QPO(4.0, 1e-1, 4.2)
+    R = pj.approx(PS, 2e-3, 3.52e2, 25, 1.32, is_integrated_power=False)
+    ref = O.approx(lambda f: O.single_bending_power_law(f, 0.2, 1.3e-2, 3.2), 2e-3, 3.52e2, 25, 1.32,
+                   is_integrated_power=False, qpo_features=[(2.0, 1e-2, 14.2), (4.0, 1e-1, 4.2)])
+    assert len(R.a) == 27
+    for got, exp in zip(pj.celerite_coefs(R), ref):
+        np.testing.assert_allclose(got, exp, rtol=1e-9)
+    R = pj.approx(pj.SingleBendingPowerLaw(0.2, 1.3e-2, 4.2) + pj.QPO(1.4, 1e-2, 10.2), 2e-3, 3.52e2, 25, 1.32,
+                  is_integrated_power=True, basis_function="DRWCelerite")
+    assert len(R.a) == 51
+    with pytest.raises(AssertionError, match="ContinuumPowerSpectrum"):
+        pj.approx(pj.QPO(1.4, 1e-2, 10.2), 2e-3, 3.52e2, 25, 1.0)
+    with pytest.raises(ValueError, match="not implemented"):
+        pj.approx(pj.SingleBendingPowerLaw(0.2, 1.3e-2, 4.2), 2e-3, 3.52e2, 25, 1.0, basis_function="foo")
+
+
+@pytest.mark.parametrize("basis", ["SHO", "DRWCelerite"])
+def test_approx_batch_equals_scalar(basis):
+    rng = np.random.default_rng(3)
+    B = 70
+    th = np.column_stack([rng.uniform(-0.25, 2, B), np.exp(rng.uniform(np.log(1e-3), np.log(5), B)), rng.uniform(1.5, 4, B)])
+    var = np.exp(rng.standard_normal(B))
+    A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, th, 1e-3, 5.0, 20, var, basis_function=basis)
+    assert A.flags["C_CONTIGUOUS"] and Bc.flags["C_CONTIGUOUS"] and A.shape == (B, 20 if basis == "SHO" else 40)
+    for i in (0, 13, 69):
+        R = pj.approx(pj.SingleBendingPowerLaw(*th[i]), 1e-3, 5.0, 20, var[i], basis_function=basis)
+        np.testing.assert_allclose(A[i], R.a, rtol=1e-9, atol=1e-14 * np.abs(R.a).max())
+        np.testing.assert_allclose(Bc[i], R.b, rtol=1e-9, atol=1e-14 * np.abs(R.a).max())
+        np.testing.assert_allclose(C, R.c, rtol=1e-15)
+        np.testing.assert_allclose(Dd, R.d, rtol=1e-15)
+    A2, _, _, _ = pj.approx_batch(pj.SingleBendingPowerLaw, th[:5], 1e-3, 5.0, 20, var[:5], basis_function=basis)
+    np.testing.assert_allclose(A2, A[:5], rtol=1e-9, atol=1e-14)   # small-batch (loop) and vectorised PSD evaluation agree
+
+
+def test_scalable_gp_construction():
+    """test/test_scalablegp.jl:85-107."""
+    R = pj.approx(pj.SingleBendingPowerLaw(0.2, 0.02, 3.1), 1e-4, 1e1, 30, 2.31, basis_function="SHO")
+    f = pj.ScalableGP(R)
+    fm = pj.ScalableGP(1.2, R)
+    assert f.mean == 0.0 and fm.mean == 1.2 and f.solver == "celerite"
+    assert isinstance(f.kernel, pj.SumOfCelerite)
+    fx = fm(np.array([0.0, 1.0, 2.5]), np.array([0.1, 0.2, 0.1]))
+    assert isinstance(fx, pj.FiniteScalableGP) and fx.sigma2.shape == (3,)
+    with pytest.raises(TypeError):
+        pj.ScalableGP(1.0, "not a kernel")
