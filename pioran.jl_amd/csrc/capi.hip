@@ -409,6 +409,77 @@ int pioran_celerite_logl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a,
     return rc;
 }
 
+// ---- dense solver -------------------------------------------------------------------------------
+static int dense_stage(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
+                       const double* d, const double* t, const double* y, const double* sigma2, double** dv)
+{
+    // one staging buffer: a b c d (J each) | t y s2 (N each) | out (1) | info
+    const size_t nd = 4 * (size_t)J + 3 * (size_t)N + 2;
+    int rc = ensure(ctx, ctx->bwork, nd * sizeof(double));
+    if (rc) return rc;
+    double* base = (double*)ctx->bwork.p;
+    const double* src[7] = {a, b, c, d, t, y, sigma2};
+    size_t off = 0;
+    for (int i = 0; i < 7; ++i) {
+        const size_t n = i < 4 ? (size_t)J : (size_t)N;
+        dv[i] = base + off;
+        if (src[i])
+            HIPCHK(ctx, hipMemcpyAsync(dv[i], src[i], n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        else
+            HIPCHK(ctx, hipMemsetAsync(dv[i], 0, n * sizeof(double), ctx->stream));
+        off += n;
+    }
+    dv[7] = base + off;      // out
+    dv[8] = base + off + 1;  // info (int32 in the first 4 bytes)
+    int64_t Mp, ld;
+    pioran_dense_dims(N, &Mp, &ld);
+    return ensure(ctx, ctx->bK, (size_t)Mp * (size_t)ld * sizeof(double));
+}
+
+int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
+                     const double* d, const double* t, const double* y, const double* sigma2, double* out,
+                     int32_t* info)
+{
+    if (!ctx || N < 1 || J < 1 || !a || !b || !c || !d || !t || !y || !sigma2 || !out) return PIORAN_ERR_ARG;
+    if (N > 46000) return PIORAN_ERR_UNSUPPORTED;  // slab would exceed ~17 GB
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double* dv[9];
+    int rc = dense_stage(ctx, N, J, a, b, c, d, t, y, sigma2, dv);
+    if (rc) return rc;
+    rc = pioran_dense_nll_device(N, (int32_t)J, dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], (double*)ctx->bK.p,
+                                 nullptr, dv[7], (int32_t*)dv[8], ctx->stream);
+    if (rc) { ctx->last_err = "dense kernel launch failed"; return rc; }
+    int32_t hinfo = 0;
+    HIPCHK(ctx, hipMemcpyAsync(out, dv[7], sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&hinfo, dv[8], sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (info) *info = hinfo;
+    return PIORAN_OK;
+}
+
+int pioran_dense_covariance(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
+                            const double* d, const double* t, const double* sigma2, double* K_out)
+{
+    if (!ctx || N < 1 || J < 1 || !a || !b || !c || !d || !t || !K_out) return PIORAN_ERR_ARG;
+    if (N > 46000) return PIORAN_ERR_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double* dv[9];
+    int rc = dense_stage(ctx, N, J, a, b, c, d, t, nullptr, sigma2, dv);
+    if (rc) return rc;
+    rc = pioran_dense_build_device(N, (int32_t)J, dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], (double*)ctx->bK.p,
+                                   ctx->stream);
+    if (rc) { ctx->last_err = "dense build launch failed"; return rc; }
+    int64_t Mp, ld;
+    pioran_dense_dims(N, &Mp, &ld);
+    HIPCHK(ctx, hipMemcpy2DAsync(K_out, (size_t)N * sizeof(double), ctx->bK.p, (size_t)ld * sizeof(double),
+                                 (size_t)N * sizeof(double), (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // the slab holds the lower triangle (column-major): mirror it, K is symmetric (src/direct_solver.jl:9-14 fills both)
+    for (int64_t k = 0; k < N; ++k)
+        for (int64_t i = k + 1; i < N; ++i) K_out[k + i * N] = K_out[i + k * N];
+    return PIORAN_OK;
+}
+
 const char* pioran_celerite_config_name(int64_t R)
 {
     if (R < 1 || R > pioran_scan_supported_rows()) return "fallback";

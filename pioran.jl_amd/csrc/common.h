@@ -46,8 +46,11 @@ size_t pioran_fallback_scratch_doubles(int R);
 int pioran_launch_table(int64_t N, int32_t J, const double* t, const double* c, const double* d,
                         double* tab, hipStream_t stream);
 // dense.hip
-struct DenseWork;
+void pioran_dense_dims(int64_t N, int64_t* Mp, int64_t* ld);
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,
                             const double* d, const double* t, const double* y, const double* s2,
-                            double* K /*N*N*/, double* work /*>= 4N*/, double* out, int32_t* info,
+                            double* K /*ld*Mp*/, double* work, double* out, int32_t* info,
                             hipStream_t stream);
+int pioran_dense_build_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,
+                              const double* d, const double* t, const double* y, const double* s2,
+                              double* K, hipStream_t stream);

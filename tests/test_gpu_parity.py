@@ -231,3 +231,75 @@ def test_full_size_properties(ctx, full_size):
     # (4) batch consistency: the same draw evaluated in a different batch position / batch size is bit-identical
     sub = ds.logl_batch(A[100:103], Bc[100:103], C, Dd, mu=mu[100:103], nu=nu[100:103])
     assert (sub == base[100:103]).all() or np.array_equal(np.isnan(sub), np.isnan(base[100:103]))
+
+
+# ---------------------------------------------------------------------------------------------
+# dense solver: log_likelihood_direct (src/direct_solver.jl:6-21)
+# ---------------------------------------------------------------------------------------------
+def test_dense_covariance_build(ctx):
+    rng = np.random.default_rng(31)
+    for N, J in ((5, 1), (70, 3), (130, 6)):
+        t = rng.uniform(0, 50, N)          # unsorted on purpose: tau = |t_i - t_k|
+        a = rng.uniform(0.1, 2, J); b = rng.uniform(-0.2, 0.2, J); c = rng.uniform(0.05, 1, J); d = rng.uniform(0, 3, J)
+        s2 = rng.uniform(0.01, 0.1, N)
+        K = ctx.dense_covariance(a, b, c, d, t, s2)
+        ref = np.array([[O.kappa(a, b, c, d, abs(ti - tk)) for tk in t] for ti in t]) + np.diag(s2)
+        np.testing.assert_allclose(K, ref, rtol=1e-13, atol=1e-15)
+        assert (K == K.T).all()
+
+
+@pytest.mark.parametrize("N,J", [(1, 1), (6, 2), (63, 3), (64, 3), (65, 3), (200, 5), (257, 20), (1000, 8)])
+def test_dense_nll_vs_oracle(ctx, N, J):
+    rng = np.random.default_rng(400 + N)
+    t = np.cumsum(rng.uniform(0.05, 2.0, N)); y = rng.standard_normal(N); s2 = rng.uniform(0.01, 0.1, N)
+    a = rng.uniform(0.1, 2, J); b = rng.uniform(-0.05, 0.05, J) * a; c = rng.uniform(0.05, 2, J); d = rng.uniform(0, 3, J)
+    got, info = ctx.dense_nll(a, b, c, d, t, y, s2, return_info=True)
+    ref = O.dense_nll(a, b, c, d, t, y, s2)
+    assert info == 0
+    assert abs(got - ref) <= 1e-11 * abs(ref)
+
+
+def test_dense_reference_relation(ctx, golden_dir):
+    """The reference's own test relation: logpdf (celerite) == -log_likelihood_direct, isapprox rtol 1.49e-8
+    (test/test_likelihood.jl:58-59, test/test_scalablegp.jl:128) — here both sides on the GPU, bar 1e-10."""
+    lit = json.loads((golden_dir / "reference_literals.json").read_text())
+    g = lit["scalablegp_n6"]
+    t = np.array(g["t"]); y = np.array(g["y"]); yerr = np.array(g["yerr"])
+    for i in range(10):
+        R = pj.approx(pj.SingleBendingPowerLaw(g["alpha1"][i], g["f1"][i], g["alpha2"][i]), g["f_min"], g["f_max"],
+                      g["n_components"], g["variance"][i], basis_function="SHO")
+        f = pj.ScalableGP(g["mu"][i], R)
+        cel = pj.logpdf(f(t, yerr ** 2), y, ctx=ctx)
+        den = -pj.log_likelihood_direct(f.kernel, t, y - g["mu"][i], yerr ** 2, ctx=ctx)
+        assert abs(cel - den) <= 1e-10 * abs(den)
+    A = np.loadtxt(golden_dir / "simu_log.txt")
+    t, y, yerr = A[:, 0], A[:, 1], A[:, 2]
+    f0 = 1 / (t[-1] - t[0]) / 100
+    fM = 1 / np.min(np.diff(t)) / 2 * 20
+    rel = {c["name"]: c for c in json.loads((golden_dir / "relation_cases.json").read_text())["cases"]}
+    for basis in ("SHO", "DRWCelerite"):
+        R = pj.approx(pj.SingleBendingPowerLaw(0.82, 0.01, 3.3), f0, fM, 20, np.var(y, ddof=1), basis_function=basis)
+        cel = pj.log_likelihood(R, t, y, yerr ** 2, ctx=ctx)
+        den = -pj.log_likelihood_direct(R, t, y, yerr ** 2, ctx=ctx)
+        assert abs(cel - den) <= 1e-10 * abs(den)
+        assert abs(den - rel[f"simu_log[{basis}]"]["logl_dense"]) <= 1e-10 * abs(den)
+
+
+def test_dense_not_positive_definite(ctx):
+    t = np.linspace(0, 10, 40); y = np.ones(40); s2 = np.full(40, 1e-9)
+    val, info = ctx.dense_nll([-1.0], [0.0], [0.3], [0.0], t, y, s2, return_info=True)
+    assert info == 1 and np.isnan(val)          # first pivot K_11 = -1 + 1e-9 <= 0
+    with pytest.raises(np.linalg.LinAlgError):
+        pj.log_likelihood_direct(pj.Celerite(-1.0, 0.0, 0.3, 0.0), t, y, s2, ctx=ctx)
+
+
+def test_dense_full_size_relation(ctx, full_size):
+    """BASELINE config 5: N = 4096 prefix, SHO-40 (J = 40): dense (MFMA Cholesky) vs celerite scan, bar 1e-8."""
+    t, y, yerr = (v[:4096] for v in full_size)
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    R = pj.approx(pj.SingleBendingPowerLaw(0.82, 0.01, 3.3), f_min, f_max, 40, 1.0, basis_function="SHO")
+    mu = float(np.mean(y))
+    den, info = ctx.dense_nll(R.a, R.b, R.c, R.d, t, y - mu, yerr ** 2, return_info=True)
+    cel = pj.log_likelihood(R, t, y - mu, yerr ** 2, ctx=ctx)
+    assert info == 0
+    assert abs(cel + den) <= 1e-8 * abs(den)
