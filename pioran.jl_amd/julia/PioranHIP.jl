@@ -1,0 +1,120 @@
+# PioranHIP.jl — the Julia side of the drop-in boundary (ccall only; no CUDA.jl / AMDGPU.jl).
+#
+# This is the binding a Pioran.jl maintainer adds to route the ScalableGP log-likelihood to
+# libpioran_hip.so.  It overrides nothing for non-Float64 element types, so ForwardDiff Duals
+# (Turing/NUTS, test/test_likelihood.jl:55) keep flowing through the original Julia `logl`.
+#
+# NOTE: the build image has no `julia`, so this file is exercised only through the identical C ABI
+# from Python (pioran.jl_amd/_lib.py) and the GPU parity tests; see INTEGRATION.md.
+module PioranHIP
+
+using Pioran
+import Pioran: log_likelihood, SumOfCelerite, SemiSeparable, celerite_coefs
+
+const LIB = get(ENV, "PIORAN_HIP_LIB", "libpioran_hip")
+
+struct PioranHIPError <: Exception
+    code::Cint
+    msg::String
+end
+
+function check(rc::Cint)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:pioran_strerror, LIB), Cstring, (Cint,), rc))
+    throw(PioranHIPError(rc, msg))
+end
+
+# ---- context: one per Julia process / MPI rank / Distributed worker (device = rank % ngpu) ---------
+mutable struct Context
+    h::Ptr{Cvoid}
+    function Context(device::Integer = 0)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pioran_ctx_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), device, r))
+        ctx = new(r[])
+        finalizer(c -> ccall((:pioran_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), c.h), ctx)
+        return ctx
+    end
+end
+
+const DEFAULT_CTX = Ref{Union{Nothing, Context}}(nothing)
+default_context() = (DEFAULT_CTX[] === nothing && (DEFAULT_CTX[] = Context(parse(Int, get(ENV, "PIORAN_HIP_DEVICE", "0")))); DEFAULT_CTX[])
+
+# ---- scalar drop-in: logl(a, b, c, d, τ, y, σ2)  (src/celerite_solver.jl:312-334) -------------------
+function logl_hip(a::Vector{Float64}, b::Vector{Float64}, c::Vector{Float64}, d::Vector{Float64},
+                  τ::Vector{Float64}, y::Vector{Float64}, σ2::Vector{Float64}; ctx = default_context())
+    out = Ref{Cdouble}(NaN)
+    status = Ref{Int32}(0)
+    GC.@preserve a b c d τ y σ2 begin
+        check(ccall((:pioran_celerite_logl, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                     Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ref{Int32}),
+                    ctx.h, length(τ), length(a), a, b, c, d, τ, y, σ2, out, status))
+    end
+    # status 2: the reference throws DomainError from log(D[1] < 0) (src/celerite_solver.jl:126)
+    status[] == 2 && throw(DomainError(out[], "log-likelihood is not finite: covariance not positive definite"))
+    return out[]
+end
+
+# Float64-only methods: everything else (Duals, BigFloat, views ...) falls through to Pioran's own code.
+function log_likelihood(cov::SumOfCelerite, τ::Vector{Float64}, y::Vector{Float64}, σ2::Vector{Float64}; solver = :celerite)
+    (solver == :celerite || solver == :celerite_matrix) ||
+        error("solver $solver not recognised, use either :celerite or :celerite_matrix")
+    if eltype(cov.a) === Float64
+        return logl_hip(collect(cov.a), collect(cov.b), collect(cov.c), collect(cov.d), τ, y, σ2)
+    end
+    return Pioran.logl(cov.a, cov.b, cov.c, cov.d, τ, y, σ2)
+end
+
+# ---- data set handle + batched entry (the reference has no batch dimension) ---------------------------
+mutable struct Dataset
+    h::Ptr{Cvoid}
+    N::Int
+    ctx::Context
+    function Dataset(t::Vector{Float64}, y::Vector{Float64}, σ2::Vector{Float64}; ctx = default_context())
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve t y σ2 check(ccall((:pioran_dataset_create, LIB), Cint,
+            (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Ptr{Cvoid}}), ctx.h, length(t), t, y, σ2, r))
+        ds = new(r[], length(t), ctx)
+        finalizer(d -> ccall((:pioran_dataset_destroy, LIB), Cint, (Ptr{Cvoid},), d.h), ds)
+        return ds
+    end
+end
+
+"""
+    logpdf_batch(ds, A, B, c, d; μ, ν, Y, S2)
+
+`A`, `B`: `J × nbatch` matrices (one column per draw, Julia column-major = the ABI's `[B][J]`);
+`c`, `d`: length-`J` vectors shared by all draws (as produced by `approx`, src/psd.jl:250,266-267) or
+`J × nbatch` matrices.  Returns `(logl::Vector{Float64}, status::Vector{Int32})`.
+This is what an ultranest `vectorized=true` callback calls once per batch of live points.
+"""
+function logpdf_batch(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::VecOrMat{Float64}, d::VecOrMat{Float64};
+                      μ::Union{Nothing, Vector{Float64}} = nothing, ν::Union{Nothing, Vector{Float64}} = nothing,
+                      Y::Union{Nothing, Matrix{Float64}} = nothing, S2::Union{Nothing, Matrix{Float64}} = nothing)
+    J, nb = size(A)
+    out = Vector{Float64}(undef, nb)
+    status = zeros(Int32, nb)
+    p(x) = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
+    GC.@preserve A B c d μ ν Y S2 out status begin
+        check(ccall((:pioran_celerite_logl_batch, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint,
+                     Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}),
+                    ds.h, nb, J, A, B, c, d, c isa Vector ? 1 : 0, p(μ), p(ν), p(Y), p(S2), out, status))
+    end
+    return out, status
+end
+
+# ---- dense solver: log_likelihood_direct (src/direct_solver.jl:6-21), returns +NLL -------------------------
+function log_likelihood_direct_hip(cov::SemiSeparable, t::Vector{Float64}, y::Vector{Float64}, σ²::Vector{Float64};
+                                   ctx = default_context())
+    a, b, c, d = map(v -> collect(Float64, real.(v)), celerite_coefs(cov))
+    out = Ref{Cdouble}(NaN)
+    info = Ref{Int32}(0)
+    GC.@preserve a b c d t y σ² check(ccall((:pioran_dense_nll, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+         Ptr{Cdouble}, Ref{Cdouble}, Ref{Int32}), ctx.h, length(t), length(a), a, b, c, d, t, y, σ², out, info))
+    info[] != 0 && throw(LinearAlgebra.PosDefException(info[]))
+    return out[]
+end
+
+end # module

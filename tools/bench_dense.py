@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Dense path timing (BASELINE.json configs[4]): N=4096, SHO-40 (J=40), one log_likelihood_direct on one GPU.
+Prints one JSON line: wall time per call (host vectors in, scalar out), achieved MFMA TFLOP/s on the
+N^3/3 + 2N^2 Cholesky flop count, and the oracle's CPU time for the same call (optional)."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench, pioran_jl_amd as pj
+
+N = int(os.environ.get("N", 4096)); J = int(os.environ.get("J", 40)); reps = int(os.environ.get("REPS", 10))
+t, y, yerr = bench.synth_series(10_000)
+t, y, yerr = t[:N], y[:N], yerr[:N]
+f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+R = pj.approx(pj.SingleBendingPowerLaw(0.82, 0.01, 3.3), f_min, f_max, J, 1.0, basis_function="SHO")
+mu = float(np.mean(y))
+ctx = pj.Context(0)
+vals = []
+ctx.dense_nll(R.a, R.b, R.c, R.d, t, y - mu, yerr ** 2)
+times = []
+for _ in range(reps):
+    t0 = time.perf_counter()
+    v, info = ctx.dense_nll(R.a, R.b, R.c, R.d, t, y - mu, yerr ** 2, return_info=True)
+    times.append(time.perf_counter() - t0)
+ms = 1e3 * float(np.median(times))
+flop = N ** 3 / 3 + 2 * N ** 2
+cel = pj.log_likelihood(R, t, y - mu, yerr ** 2, ctx=ctx)
+res = {"workload": f"dense log_likelihood_direct N={N} SHO-{J} (J={J})", "ms_per_call": ms, "nll": v, "info": info,
+       "rel_diff_vs_celerite_gpu": abs(cel + v) / abs(v), "cholesky_flop": flop,
+       "tflops_on_cholesky_flop_whole_call": flop / (ms * 1e-3) / 1e12}
+if os.environ.get("CPU", "1") == "1":
+    from oracle import oracle as O
+    t0 = time.perf_counter(); ref = O.dense_nll(R.a, R.b, R.c, R.d, t, y - mu, yerr ** 2); cpu_s = time.perf_counter() - t0
+    res["oracle_cpu_s"] = cpu_s; res["rel_err_vs_oracle"] = abs(v - ref) / abs(ref); res["cpu_threads"] = os.cpu_count()
+print(json.dumps(res))
