@@ -264,37 +264,35 @@ int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const doub
         real[j] = (real_term && real_term[j]) ? 1 : 0;
         if (real[j] && d[j] != 0.0) return PIORAN_ERR_ARG;  // a real term must have d = 0
     }
-    const bool same_cd = ds->prepared && ds->J == J && !std::memcmp(ds->c_host.data(), c, J * sizeof(double)) &&
-                         !std::memcmp(ds->d_host.data(), d, J * sizeof(double));
-    const bool same_rows = same_cd && ds->real_host == real;
-    if (same_rows) return PIORAN_OK;
-    if (!same_cd) {
-        ds->prepared = false;
-        const size_t need = (size_t)ds->N * 3 * (size_t)(J + 2);
-        if (need > ds->tab_cap) {
-            if (ds->tab) HIPCHK(ctx, hipFree(ds->tab));
-            ds->tab = nullptr;
-            ds->tab_cap = 0;
-            if (hipMalloc((void**)&ds->tab, need * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
-            ds->tab_cap = need;
-        }
-        if ((size_t)J > ds->dcd_cap) {
-            if (ds->dc) HIPCHK(ctx, hipFree(ds->dc));
-            ds->dc = nullptr;
-            if (hipMalloc((void**)&ds->dc, 2 * (size_t)J * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
-            ds->dcd_cap = (size_t)J;
-        }
-        ds->dd = ds->dc + J;
-        ds->c_host.assign(c, c + J);
-        ds->d_host.assign(d, d + J);
-        HIPCHK(ctx, hipMemcpyAsync(ds->dc, ds->c_host.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ds->dd, ds->d_host.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        int rc = pioran_launch_table(ds->N, (int32_t)J, ds->t, ds->dc, ds->dd, ds->tab, ctx->stream);
-        if (rc) return rc;
-        ds->J = (int32_t)J;
+    const bool same = ds->prepared && ds->J == J && !std::memcmp(ds->c_host.data(), c, J * sizeof(double)) &&
+                      !std::memcmp(ds->d_host.data(), d, J * sizeof(double)) && ds->real_host == real;
+    if (same) return PIORAN_OK;
+    ds->prepared = false;
+    if ((size_t)J > ds->dcd_cap) {
+        if (ds->dc) HIPCHK(ctx, hipFree(ds->dc));
+        ds->dc = nullptr;
+        if (hipMalloc((void**)&ds->dc, 2 * (size_t)J * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
+        ds->dcd_cap = (size_t)J;
     }
-    int rc = set_rowmap(ds, build_rowmap(J, real.data()));
+    ds->dd = ds->dc + J;
+    ds->c_host.assign(c, c + J);
+    ds->d_host.assign(d, d + J);
+    HIPCHK(ctx, hipMemcpyAsync(ds->dc, ds->c_host.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ds->dd, ds->d_host.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int rc = set_rowmap(ds, build_rowmap(J, real.data()));   // sets ds->R
     if (rc) return rc;
+    // the table is per ROW (v, x, phi) + (y_n, sigma2_n) per step, see table.hip
+    const size_t need = pioran_table_doubles(ds->N, ds->R);
+    if (need > ds->tab_cap) {
+        if (ds->tab) HIPCHK(ctx, hipFree(ds->tab));
+        ds->tab = nullptr;
+        ds->tab_cap = 0;
+        if (hipMalloc((void**)&ds->tab, need * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
+        ds->tab_cap = need;
+    }
+    rc = pioran_launch_table(ds->N, ds->R, ds->rowmap, ds->t, ds->dc, ds->dd, ds->y, ds->s2, ds->tab, ctx->stream);
+    if (rc) return rc;
+    ds->J = (int32_t)J;
     ds->real_host = real;
     ds->prepared = true;
     return PIORAN_OK;

@@ -23,7 +23,8 @@ __global__ void __launch_bounds__(64) celerite_fallback_kernel(const ScanParams 
     __shared__ int term_s[RMAX];
     const int lane = threadIdx.x;
     const int64_t b = b0 + blockIdx.x;
-    const int J = p.J, Jp = J + 2, R = p.R;
+    const int J = p.J, R = p.R, Rp = R + 2;
+    const int64_t RS = 3 * (int64_t)Rp + 2;  // shared table record, see table.hip
     const int64_t N = p.N;
     double* S = p.scratch + (int64_t)blockIdx.x * ((int64_t)R * R);
 
@@ -33,8 +34,8 @@ __global__ void __launch_bounds__(64) celerite_fallback_kernel(const ScanParams 
         const bool ks = (rm >> 30) & 1;
         const double a = p.A[b * J + tj], bb = p.Bc[b * J + tj];
         term_s[j] = rm;
-        al_s[j] = ks ? -bb : a;
-        be_s[j] = ks ? a : bb;
+        al_s[j] = a;              // u = a v + (+-b) x  with (v, x) = (cos, sin) | (sin, cos)
+        be_s[j] = ks ? -bb : bb;
         if (!p.tab) { cc_s[j] = p.C[b * J + tj]; dd_s[j] = p.D[b * J + tj]; }
         f_s[j] = 0.0;
         for (int k = 0; k < R; ++k) S[(int64_t)k * R + j] = 0.0;
@@ -46,14 +47,18 @@ __global__ void __launch_bounds__(64) celerite_fallback_kernel(const ScanParams 
     const double* yv = p.Y ? p.Y + b * N : p.y;
     const double* sv = p.S2 ? p.S2 + b * N : p.s2;
 
-    auto trig = [&](int j, int64_t n, double& co, double& si, double& ph) {
-        const int tj = term_s[j] & 0x3fffffff;
+    // (v, x, phi) of row j at step n: v is the row's own trig value, x the other one
+    auto trig = [&](int j, int64_t n, double& v, double& x, double& ph) {
         if (p.tab) {
-            const double* rec = p.tab + n * 3 * Jp;
-            co = rec[tj]; si = rec[Jp + tj]; ph = rec[2 * Jp + tj];
+            const double* rec = p.tab + n * RS;
+            v = rec[j]; x = rec[Rp + j]; ph = rec[2 * Rp + j];
         } else {
             const double tn = p.t[n];
+            double si, co;
             sincos(dd_s[j] * tn, &si, &co);
+            const bool ks = (term_s[j] >> 30) & 1;
+            v = ks ? si : co;
+            x = ks ? co : si;
             ph = n > 0 ? exp(-cc_s[j] * (tn - p.t[n - 1])) : 0.0;
         }
     };
@@ -61,9 +66,9 @@ __global__ void __launch_bounds__(64) celerite_fallback_kernel(const ScanParams 
     double Dn = suma + (p.nu ? nu * sv[0] : sv[0]);
     double rD = 1.0 / Dn;
     for (int j = lane; j < R; j += 64) {
-        double co, si, ph;
-        trig(j, 0, co, si, ph);
-        w_s[j] = (((term_s[j] >> 30) & 1) ? si : co) * rD;
+        double v, x, ph;
+        trig(j, 0, v, x, ph);
+        w_s[j] = v * rD;
     }
     double z = yv[0] - mu;
     int Pe = 0;
@@ -75,11 +80,11 @@ __global__ void __launch_bounds__(64) celerite_fallback_kernel(const ScanParams 
     for (int64_t n = 1; n < N; ++n) {
         double zzp = 0.0;
         for (int j = lane; j < R; j += 64) {
-            double co, si, ph;
-            trig(j, n, co, si, ph);
-            const double u = al_s[j] * co + be_s[j] * si;
+            double v, x, ph;
+            trig(j, n, v, x, ph);
+            const double u = al_s[j] * v + be_s[j] * x;
             u_s[j] = u;
-            v_s[j] = ((term_s[j] >> 30) & 1) ? si : co;
+            v_s[j] = v;
             ph_s[j] = ph;
             g_s[j] = Dn * w_s[j];
             const double f = (f_s[j] + w_s[j] * z) * ph;

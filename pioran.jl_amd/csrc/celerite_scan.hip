@@ -60,6 +60,116 @@ __device__ __forceinline__ double dpp_perm(double x)
     return __hiloint2double(hi, lo);
 }
 
+
+// One column of the S update for RPL rows with the broadcasts FOLDED into the FMAs:
+//   pk = bcast(phi_k);  S_i = (phi_i pk) * (S_i + g_i bcast(w_k));  q_i += S_i bcast(u_k)
+// v_fmac_f64_dpp ... row_newbcast:N takes its src0 from lane N of the DPP row (DP-ALU DPP supports exactly this
+// control on gfx950), so w_k and u_k never occupy a register or an instruction of their own.
+// Hazard (VALU write of a VGPR -> DPP read of it needs 2 wait states; nothing is padded inside asm): the
+// leading s_nop 1 covers a producer scheduled directly in front of the block; inside the block no DPP source
+// (w, u, phi of the row-owning lane) is written.
+#define PIORAN_DPP_STR2(N) #N
+#define PIORAN_DPP_CTRL(N) " row_newbcast:" PIORAN_DPP_STR2(N) " row_mask:0xf bank_mask:0xf"
+#define PD_FMAC(d, s0, s1) "v_fmac_f64_dpp %[" #d "], %[" #s0 "], %[" #s1 "]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+#define PD_MUL(d, s0, s1) "v_mul_f64 %[" #d "], %[" #s0 "], %[" #s1 "]\n\t"
+
+template <int RPL, int N>
+struct ColBlock;
+
+template <int N>
+struct ColBlock<1, N> {
+    static __device__ __forceinline__ void run(double (&S)[1], double (&q)[1], const double (&g)[1],
+                                               const double (&ph)[1], double ws, double us, double phs)
+    {
+        double pk, p0;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_FMAC(s0, ws, g0) PD_MUL(p0, h0, pk) PD_MUL(s0, p0, s0) PD_FMAC(q0, us, s0)
+                     : [s0] "+v"(S[0]), [q0] "+v"(q[0]), [pk] "=&v"(pk), [p0] "=&v"(p0)
+                     : [g0] "v"(g[0]), [h0] "v"(ph[0]), [ws] "v"(ws), [us] "v"(us), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+
+template <int N>
+struct ColBlock<2, N> {
+    static __device__ __forceinline__ void run(double (&S)[2], double (&q)[2], const double (&g)[2],
+                                               const double (&ph)[2], double ws, double us, double phs)
+    {
+        double pk, p0, p1;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk)
+                     PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1)
+                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [pk] "=&v"(pk),
+                       [p0] "=&v"(p0), [p1] "=&v"(p1)
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [ws] "v"(ws), [us] "v"(us),
+                       [phs] "v"(phs), [n] "i"(N));
+    }
+};
+
+template <int N>
+struct ColBlock<3, N> {
+    static __device__ __forceinline__ void run(double (&S)[3], double (&q)[3], const double (&g)[3],
+                                               const double (&ph)[3], double ws, double us, double phs)
+    {
+        double pk, p0, p1, p2;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2)
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk)
+                     PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2)
+                     PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1) PD_FMAC(q2, us, s2)
+                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [q0] "+v"(q[0]), [q1] "+v"(q[1]),
+                       [q2] "+v"(q[2]), [pk] "=&v"(pk), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2)
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [h0] "v"(ph[0]), [h1] "v"(ph[1]),
+                       [h2] "v"(ph[2]), [ws] "v"(ws), [us] "v"(us), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+
+template <int N>
+struct ColBlock<4, N> {
+    static __device__ __forceinline__ void run(double (&S)[4], double (&q)[4], const double (&g)[4],
+                                               const double (&ph)[4], double ws, double us, double phs)
+    {
+        double pk, p0, p1, p2, p3;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3)
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk)
+                     PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2) PD_MUL(s3, p3, s3)
+                     PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1) PD_FMAC(q2, us, s2) PD_FMAC(q3, us, s3)
+                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [q0] "+v"(q[0]),
+                       [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [pk] "=&v"(pk), [p0] "=&v"(p0),
+                       [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3)
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [h0] "v"(ph[0]),
+                       [h1] "v"(ph[1]), [h2] "v"(ph[2]), [h3] "v"(ph[3]), [ws] "v"(ws), [us] "v"(us), [phs] "v"(phs),
+                       [n] "i"(N));
+    }
+};
+
+template <int N>
+struct ColBlock<5, N> {
+    static __device__ __forceinline__ void run(double (&S)[5], double (&q)[5], const double (&g)[5],
+                                               const double (&ph)[5], double ws, double us, double phs)
+    {
+        double pk, p0, p1, p2, p3, p4;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3) PD_FMAC(s4, ws, g4)
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk) PD_MUL(p4, h4, pk)
+                     PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2) PD_MUL(s3, p3, s3) PD_MUL(s4, p4, s4)
+                     PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1) PD_FMAC(q2, us, s2) PD_FMAC(q3, us, s3) PD_FMAC(q4, us, s4)
+                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]),
+                       [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [q4] "+v"(q[4]),
+                       [pk] "=&v"(pk), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3), [p4] "=&v"(p4)
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [h0] "v"(ph[0]),
+                       [h1] "v"(ph[1]), [h2] "v"(ph[2]), [h3] "v"(ph[3]), [h4] "v"(ph[4]), [ws] "v"(ws), [us] "v"(us),
+                       [phs] "v"(phs), [n] "i"(N));
+    }
+};
+#undef PD_FMAC
+#undef PD_MUL
+
 // sum over the 16 lanes of a DPP row; every lane gets the bit-identical total
 __device__ __forceinline__ double row16_sum(double x)
 {
@@ -79,7 +189,20 @@ __device__ __forceinline__ double group_sum(double x)
     return x;
 }
 
-template <int RPL, int CBR, int NSRC, bool SHARED_TAB>
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+
+template <int RPL>
+struct StepIn {           // what one time step reads: per own row (v, x, phi) + the shared y_n, sigma2_n
+    double v[RPL], x[RPL], ph[RPL], y, s2;
+};
+
+template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false>
 __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
 {
     static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
@@ -101,34 +224,36 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
     const bool active = b_raw < p.B;
     const int64_t b = active ? b_raw : p.B - 1;
 
-    const int J = p.J, Jp = J + 2, R = p.R;  // table columns J (inert pad) and J+1 (y row)
+    const int J = p.J, R = p.R, Rp = R + 2;  // table rows R (inert pad) and R+1 (y row)
     const int64_t N = p.N;
 
-    int term[RPL];
-    bool ksin[RPL];
-    double al[RPL], be[RPL];
+    int trow[RPL];                           // row of the shared table this slot reads
+    double al[RPL], be[RPL];                 // u = al * v + be * x
     [[maybe_unused]] double cc[RPL], dd[RPL];
+    [[maybe_unused]] bool ksin[RPL];
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
         const int j = lam * RPL + i;
         if (j < R) {
             const int rm = p.rowmap[j];
-            term[i] = rm & 0x3fffffff;
-            ksin[i] = (rm >> 30) & 1;
-            const double a = p.A[b * J + term[i]], bb = p.Bc[b * J + term[i]];
-            // u = a co + b si (cos row) | a si - b co (sin row)      celerite_solver.jl:59-60
-            al[i] = ksin[i] ? -bb : a;
-            be[i] = ksin[i] ? a : bb;
+            const int term = rm & 0x3fffffff;
+            const bool ks = (rm >> 30) & 1;
+            const double a = p.A[b * J + term], bb = p.Bc[b * J + term];
+            // cos row: v = co, x = si, u = a co + b si ; sin row: v = si, x = co, u = a si - b co   (:59-63)
+            trow[i] = j;
+            al[i] = a;
+            be[i] = ks ? -bb : bb;
+            ksin[i] = ks;
             if constexpr (!SHARED_TAB) {
-                cc[i] = p.C[b * J + term[i]];
-                dd[i] = p.D[b * J + term[i]];
+                cc[i] = p.C[b * J + term];
+                dd[i] = p.D[b * J + term];
             }
         } else {
             // inert padding row (u = 0, v = 1, phi = 0), or the y row (u = 0, v = y_n - mu, phi = 1)
-            term[i] = (isy && i == YS) ? J + 1 : J;
-            ksin[i] = false;
+            trow[i] = (isy && i == YS) ? R + 1 : R;
             al[i] = 0.0;
             be[i] = 0.0;
+            ksin[i] = false;
             if constexpr (!SHARED_TAB) { cc[i] = 0.0; dd[i] = 0.0; }
         }
     }
@@ -137,62 +262,81 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
     const double mu = p.mu ? p.mu[b] : 0.0;
     const double nu = p.nu ? p.nu[b] : 1.0;
     const bool has_nu = p.nu != nullptr;
-    const double* yv = p.Y ? p.Y + b * N : p.y;
-    const double* sv = p.S2 ? p.S2 + b * N : p.s2;
+    const bool own_series = p.Y != nullptr;   // per-draw y / sigma2 (wave-uniform)
+    const double* yv = own_series ? p.Y + b * N : p.y;
+    const double* sv = own_series ? p.S2 + b * N : p.s2;
 
     int p1 = 0, p2 = 0;  // lanes holding the same rows in the other column blocks
     if constexpr (CBR >= 2) p1 = e * G + (r ^ 1) * 16 + ((lam - NSRC * (r ^ 1)) & 15);
     if constexpr (CBR >= 4) p2 = e * G + (r ^ 2) * 16 + ((lam - NSRC * (r ^ 2)) & 15);
 
-    double co[RPL], si[RPL], ph[RPL];
-    auto load_step = [&](int64_t n, double (&co_)[RPL], double (&si_)[RPL], double (&ph_)[RPL], double& y_, double& s2_) {
+    // shared table record of step n: [v x Rp | x x Rp | phi x Rp | y_n, sigma2_n]; N + 1 records (the last
+    // one is a readable dummy so the prefetch of step n + 1 needs no bounds test).  Read with buffer loads:
+    // per-lane byte offset in a VGPR (constant), step offset in an SGPR -> no vector address arithmetic.
+    const int RS = 3 * Rp + 2;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(SHARED_TAB ? p.tab : p.t), 0, 0x7ffffffc, 0x00020000);
+    [[maybe_unused]] int voff[RPL];
+    if constexpr (SHARED_TAB) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) voff[i] = trow[i] * 8;
+    }
+
+    auto load_step = [&](int64_t n, StepIn<RPL>& in) {
         if constexpr (SHARED_TAB) {
-            const double* rec = p.tab + n * 3 * Jp;
+            const int soff = (int)n * RS * 8;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
-                co_[i] = rec[term[i]];
-                si_[i] = rec[Jp + term[i]];
-                ph_[i] = rec[2 * Jp + term[i]];
+                in.v[i] = buf_load_f64(rs, voff[i], soff);
+                in.x[i] = buf_load_f64(rs, voff[i], soff + Rp * 8);
+                in.ph[i] = buf_load_f64(rs, voff[i], soff + 2 * Rp * 8);
+            }
+            if (own_series) {
+                const int64_t nn = n < N ? n : N - 1;
+                in.y = yv[nn];
+                in.s2 = sv[nn];
+            } else {
+                in.y = buf_load_f64(rs, 0, soff + 3 * Rp * 8);
+                in.s2 = buf_load_f64(rs, 0, soff + 3 * Rp * 8 + 8);
             }
         } else {
-            const double tn = p.t[n];
-            const double dt = n > 0 ? tn - p.t[n - 1] : 0.0;
+            const int64_t nn = n < N ? n : N - 1;
+            const double tn = p.t[nn];
+            const double dt = nn > 0 ? tn - p.t[nn - 1] : 0.0;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
-                if (term[i] < J) {
+                if (trow[i] < R) {
                     double s_, c_;
                     sincos(dd[i] * tn, &s_, &c_);  // :52-53
-                    co_[i] = c_;
-                    si_[i] = s_;
-                    ph_[i] = exp(-cc[i] * dt);     // :54
+                    in.v[i] = ksin[i] ? s_ : c_;
+                    in.x[i] = ksin[i] ? c_ : s_;
+                    in.ph[i] = exp(-cc[i] * dt);   // :54
                 } else {
-                    co_[i] = term[i] == J ? 1.0 : 0.0;
-                    si_[i] = 0.0;
-                    ph_[i] = term[i] == J ? 0.0 : 1.0;
+                    in.v[i] = trow[i] == R ? 1.0 : 0.0;
+                    in.x[i] = 0.0;
+                    in.ph[i] = trow[i] == R ? 0.0 : 1.0;
                 }
             }
+            in.y = yv[nn];
+            in.s2 = sv[nn];
         }
-        y_ = yv[n];
-        s2_ = sv[n];
     };
 
-    double yn, s2n;
-    load_step(0, co, si, ph, yn, s2n);
+    StepIn<RPL> bufA, bufB;
+    load_step(0, bufA);
 
     // ---- first row, :27-42 and :126-128 ----
-    double S[RPL][NC];
+    double S[NC][RPL];   // [column][own row]
 #pragma unroll
-    for (int i = 0; i < RPL; ++i)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) S[i][c] = 0.0;
-    double w[RPL], v[RPL];
-    double Dn = suma + (has_nu ? nu * s2n : s2n);
+        for (int i = 0; i < RPL; ++i) S[c][i] = 0.0;
+    double w[RPL];
+    double Dn = suma + (has_nu ? nu * bufA.s2 : bufA.s2);
     double rD = 1.0 / Dn;
+    if (isy) bufA.v[YS] = bufA.y - mu;       // z_1 = y_1      :128
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) v[i] = ksin[i] ? si[i] : co[i];
-    if (isy) v[YS] = yn - mu;                // z_1 = y_1      :128
-#pragma unroll
-    for (int i = 0; i < RPL; ++i) w[i] = v[i] * rD;
+    for (int i = 0; i < RPL; ++i) w[i] = bufA.v[i] * rD;
     double Pm = Dn;      // running product of |D| (sign of D_1 kept: log of a negative D_1 is NaN, :126)
     int Pe = 0;
     {
@@ -200,29 +344,20 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
         Pm = frexp(Pm, &ex);
         Pe += ex;
     }
-    double quad = v[YS] * v[YS] * rD;        // meaningful in the y-row lanes only
+    double quad = bufA.v[YS] * bufA.v[YS] * rD;   // meaningful in the y-row lanes only
     bool nonpd = !(Dn > 0.0);
 
-    double co2[RPL], si2[RPL], ph2[RPL], yn2, s2n2;
-    if (N > 1) load_step(1, co2, si2, ph2, yn2, s2n2);
-
-    for (int64_t n = 1; n < N; ++n) {
-#pragma unroll
-        for (int i = 0; i < RPL; ++i) { co[i] = co2[i]; si[i] = si2[i]; ph[i] = ph2[i]; }
-        yn = yn2;
-        s2n = s2n2;
-        // prefetch the next step's table row; independent of the recurrence
-        load_step(n + 1 < N ? n + 1 : n, co2, si2, ph2, yn2, s2n2);
-
+    // one time step: consumes `in` (loaded one step earlier), prefetches step n + 1 into `nxt`
+    auto do_step = [&](int64_t n, StepIn<RPL>& in, StepIn<RPL>& nxt) {
+        load_step(n + 1, nxt);   // independent of the recurrence
         double u[RPL], g[RPL], qt[RPL];
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            u[i] = al[i] * co[i] + be[i] * si[i];
+            u[i] = al[i] * in.v[i] + be[i] * in.x[i];
             g[i] = Dn * w[i];                       // dn = D[n-1] * V[j,n-1]   :73
             qt[i] = 0.0;
-            v[i] = ksin[i] ? si[i] : co[i];
         }
-        if (isy) v[YS] = yn - mu;
+        if (isy) in.v[YS] = in.y - mu;
 
         // ---- S update + q = S u over this DPP row's column block ----
         static_for<0, NSRC>([&](auto Nc) {
@@ -230,14 +365,18 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
             static_for<0, RPL>([&](auto Mc) {
                 constexpr int MM = decltype(Mc)::value;
                 constexpr int c = NN * RPL + MM;
+                if constexpr (ASM_DPP) {
+                    ColBlock<RPL, NN>::run(S[c], qt, g, in.ph, w[MM], u[MM], in.ph[MM]);
+                    return;
+                }
                 const double wk = row_bcast<NN>(w[MM]);
                 const double uk = row_bcast<NN>(u[MM]);
-                const double pk = row_bcast<NN>(ph[MM]);
+                const double pk = row_bcast<NN>(in.ph[MM]);
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) {
-                    const double m = fma(g[i], wk, S[i][c]);   // S + dn * V[k,n-1]          :78
-                    const double sn = (ph[i] * pk) * m;        // phi_j phi_k ( ... )        :78,85
-                    S[i][c] = sn;
+                    const double m = fma(g[i], wk, S[c][i]);   // S + dn * V[k,n-1]          :78
+                    const double sn = (in.ph[i] * pk) * m;     // phi_j phi_k ( ... )        :78,85
+                    S[c][i] = sn;
                     qt[i] = fma(sn, uk, qt[i]);                // (S u)_j                    :80-82,86-89
                 }
             });
@@ -256,18 +395,26 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
         if (!contributes) sp = 0.0;
         const double s = group_sum<CBR>(sp);
 
-        Dn = suma + (has_nu ? nu * s2n : s2n) - s;               // :92
+        Dn = suma + (has_nu ? nu * in.s2 : in.s2) - s;           // :92
         rD = 1.0 / Dn;
-        const double z = v[YS] - qt[YS];                         // y row: z_n = y_n - u'f      :141
+        const double z = in.v[YS] - qt[YS];                      // y row: z_n = y_n - u'f      :141
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) w[i] = (v[i] - qt[i]) * rD;                        // :89,96
+        for (int i = 0; i < RPL; ++i) w[i] = (in.v[i] - qt[i]) * rD;                     // :89,96
         nonpd |= !(Dn > 0.0);
         Pm *= fabs(Dn);                                          // log(abs(D[n]))  :140
         int ex;
         Pm = frexp(Pm, &ex);
         Pe += ex;
         quad = fma(z * z, rD, quad);                             // z_n^2 / D_n  (== y'K^-1 y, :333)
+    };
+
+    if (N > 1) load_step(1, bufB);
+    int64_t n = 1;
+    for (; n + 1 < N; n += 2) {      // ping-pong: no register rotation between steps
+        do_step(n, bufB, bufA);
+        do_step(n + 1, bufA, bufB);
     }
+    if (n < N) do_step(n, bufB, bufA);
 
     if (active && isy && r == 0) {
         const double logdet = log(Pm) + (double)Pe * 0.6931471805599453094;
@@ -279,13 +426,13 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
 
 using LaunchFn = void (*)(const ScanParams&, dim3, hipStream_t);
 
-template <int RPL, int CBR, int NSRC>
+template <int RPL, int CBR, int NSRC, bool ASM_DPP = false>
 void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 {
     if (p.tab)
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, ASM_DPP>), grid, dim3(256), 0, st, p);
     else
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false, ASM_DPP>), grid, dim3(256), 0, st, p);
 }
 
 struct ScanConfig {
@@ -295,8 +442,10 @@ struct ScanConfig {
     int capacity() const { return rpl * cbr * nsrc - 1; }  // one row slot carries y
 };
 
-#define CFG(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC, RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC>}
-// preference order: first entry whose capacity >= R wins (unless PIORAN_SCAN_CONFIG names another)
+#define CFG(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC, RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC, true>}
+#define CFG_C(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC "_c", RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC, false>}
+// preference order: first entry whose capacity >= R wins (unless PIORAN_SCAN_CONFIG names another).
+// Default entries use the DPP-folded column block (ColBlock); "_c" = same mapping, compiler-scheduled builtins.
 const ScanConfig kConfigs[] = {
     CFG(1, 1, 5),  CFG(1, 1, 9),  CFG(1, 1, 13), CFG(1, 1, 16),           // R <= 15
     CFG(2, 1, 9),  CFG(2, 1, 11), CFG(2, 1, 13), CFG(2, 1, 15), CFG(2, 1, 16),  // R <= 31
@@ -304,9 +453,10 @@ const ScanConfig kConfigs[] = {
     CFG(4, 4, 4),                                                         // R <= 63
     CFG(5, 4, 4),                                                         // R <= 79
     // alternatives kept for tuning runs (selected by name)
-    CFG(3, 1, 14), CFG(3, 4, 4), CFG(2, 2, 8),
+    CFG(3, 4, 4), CFG(2, 2, 8), CFG_C(3, 2, 7), CFG_C(4, 4, 4), CFG_C(2, 1, 16), CFG_C(1, 1, 16), CFG_C(5, 4, 4),
 };
 #undef CFG
+#undef CFG_C
 constexpr int kNumPreferred = 14;
 
 const ScanConfig* pick_config(int R)

@@ -10,14 +10,15 @@
 #define PIORAN_ERR_UNSUPPORTED (-4)
 
 // layout of the shared per-step table ("trig/phi table"):
-//   tab[n][q][jp], q in {0: cos(d_j t_n), 1: sin(d_j t_n), 2: exp(-c_j (t_n - t_{n-1}))},
-//   jp in [0, J+1] — column J is the inert padding term (1, 0, 0), column J+1 the y row (0, 0, 1).
+//   record n (n <= N, the last one a readable copy of N-1) = [ v_r | x_r | phi_r | y_n sigma2_n ], r < R + 2:
+//   cos row (v, x) = (cos, sin)(d_j t_n), sin row (sin, cos); phi = exp(-c_j (t_n - t_{n-1}));
+//   row R is the inert padding row (1, 0, 0), row R+1 the y row (0, 0, 1).
 struct ScanParams {
     int64_t N;            // time stamps
     int32_t J;            // celerite terms
     int32_t R;            // active rows (<= 2J; structurally-zero sin rows of d=b=0 terms dropped)
     int64_t B;            // batch (independent draws)
-    const double* tab;    // shared table [N][3][J+2], or nullptr when (c,d) are per draw
+    const double* tab;    // shared table [N+1][3(R+2)+2], or nullptr when (c,d) are per draw
     const int32_t* rowmap;  // [R]: term | kind<<30 (kind 1 = sin row)
     const double* t;      // [N]   (used only when tab == nullptr)
     const double* y;      // [N]   shared series (mean NOT subtracted), or nullptr if Y given
@@ -43,8 +44,9 @@ const char* pioran_scan_config_name(int R);
 int pioran_launch_scan_fallback(const ScanParams& p, hipStream_t stream);
 size_t pioran_fallback_scratch_doubles(int R);
 // table.hip
-int pioran_launch_table(int64_t N, int32_t J, const double* t, const double* c, const double* d,
-                        double* tab, hipStream_t stream);
+size_t pioran_table_doubles(int64_t N, int32_t R);
+int pioran_launch_table(int64_t N, int32_t R, const int32_t* rowmap, const double* t, const double* c,
+                        const double* d, const double* y, const double* s2, double* tab, hipStream_t stream);
 // dense.hip
 void pioran_dense_dims(int64_t N, int64_t* Mp, int64_t* ld);
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,

@@ -8,35 +8,54 @@
 #include "common.h"
 
 namespace {
-__global__ void __launch_bounds__(256) table_kernel(int64_t N, int32_t J, const double* __restrict__ t,
-                                                    const double* __restrict__ c,
-                                                    const double* __restrict__ d, double* __restrict__ tab)
+// record of step n (RS = 3 Rp + 2 doubles, Rp = R + 2):
+//   [ v_r (r < Rp) | x_r | phi_r | y_n  sigma2_n ],  cos row: (v, x) = (cos, sin)(d t_n), sin row: (sin, cos);
+//   row R = inert padding (1, 0, 0), row R+1 = the y row of the scan (0, 0, 1).  N + 1 records: the last one
+//   repeats step N-1 so that the scan's prefetch of "step N" stays in bounds.
+__global__ void __launch_bounds__(256) table_kernel(int64_t N, int32_t R, const int32_t* __restrict__ rowmap,
+                                                    const double* __restrict__ t, const double* __restrict__ c,
+                                                    const double* __restrict__ d, const double* __restrict__ y,
+                                                    const double* __restrict__ s2, double* __restrict__ tab)
 {
-    const int32_t Jp = J + 2;
+    const int32_t Rp = R + 2;
+    const int64_t RS = 3 * (int64_t)Rp + 2;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * Jp) return;
-    const int64_t n = idx / Jp;
-    const int32_t jp = (int32_t)(idx - n * Jp);
-    // column J: inert padding term (1, 0, 0); column J+1: the y row of the scan (0, 0, 1)
-    double co = jp == J ? 1.0 : 0.0, si = 0.0, ph = jp == J ? 0.0 : 1.0;
-    if (jp < J) {
+    if (idx >= (N + 1) * Rp) return;
+    const int64_t nrec = idx / Rp;
+    const int32_t row = (int32_t)(idx - nrec * Rp);
+    const int64_t n = nrec < N ? nrec : N - 1;
+    double v = row == R ? 1.0 : 0.0, x = 0.0, ph = row == R ? 0.0 : 1.0;
+    if (row < R) {
+        const int32_t rm = rowmap[row];
+        const int32_t term = rm & 0x3fffffff;
         const double tn = t[n];
-        sincos(d[jp] * tn, &si, &co);
-        ph = n > 0 ? exp(-c[jp] * (tn - t[n - 1])) : 0.0;
+        double si, co;
+        sincos(d[term] * tn, &si, &co);
+        const bool ks = (rm >> 30) & 1;
+        v = ks ? si : co;
+        x = ks ? co : si;
+        ph = n > 0 ? exp(-c[term] * (tn - t[n - 1])) : 0.0;
     }
-    double* rec = tab + n * 3 * Jp;
-    rec[jp] = co;
-    rec[Jp + jp] = si;
-    rec[2 * Jp + jp] = ph;
+    double* rec = tab + nrec * RS;
+    rec[row] = v;
+    rec[Rp + row] = x;
+    rec[2 * Rp + row] = ph;
+    if (row == 0) {
+        rec[3 * Rp] = y[n];
+        rec[3 * Rp + 1] = s2[n];
+    }
 }
 }  // namespace
 
-int pioran_launch_table(int64_t N, int32_t J, const double* t, const double* c, const double* d,
-                        double* tab, hipStream_t stream)
+size_t pioran_table_doubles(int64_t N, int32_t R) { return (size_t)(N + 1) * (size_t)(3 * (R + 2) + 2); }
+
+int pioran_launch_table(int64_t N, int32_t R, const int32_t* rowmap, const double* t, const double* c,
+                        const double* d, const double* y, const double* s2, double* tab, hipStream_t stream)
 {
-    const int64_t total = N * (int64_t)(J + 2);
+    const int64_t total = (N + 1) * (int64_t)(R + 2);
     const int64_t blocks = (total + 255) / 256;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return PIORAN_ERR_ARG;
-    hipLaunchKernelGGL(table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, N, J, t, c, d, tab);
+    if (pioran_table_doubles(N, R) * 8 > 0x7ffffff0ull) return PIORAN_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+    hipLaunchKernelGGL(table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, N, R, rowmap, t, c, d, y, s2, tab);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }

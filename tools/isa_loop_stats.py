@@ -5,7 +5,7 @@ import re, sys
 from collections import Counter
 s = open(sys.argv[1]).read()
 flt = sys.argv[2] if len(sys.argv) > 2 else "Lb1E"
-for m in re.finditer(r'^(_ZN12_GLOBAL__N_120celerite_scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)EEEv10ScanParams):', s, re.M):
+for m in re.finditer(r'^(_ZN12_GLOBAL__N_120celerite_scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E(?:Lb(\d)E)?EEv10ScanParams):', s, re.M):
     name = m.group(1)
     if flt not in name: continue
     i = m.start(); j = s.index('.Lfunc_end', i)
@@ -16,7 +16,7 @@ for m in re.finditer(r'^(_ZN12_GLOBAL__N_120celerite_scan_kernelILi(\d+)ELi(\d+)
         if mm: labels[mm.group(1)] = idx
     loops = []
     for idx, l in enumerate(body):
-        mm = re.search(r's_cbranch_\w+ (\.LBB\d+_\d+)', l)
+        mm = re.search(r's_c?branch\w* (\.LBB\d+_\d+)', l)
         if mm and mm.group(1) in labels and labels[mm.group(1)] < idx:
             loops.append((idx - labels[mm.group(1)], labels[mm.group(1)], idx))
     loops.sort(reverse=True)
@@ -29,5 +29,5 @@ for m in re.finditer(r'^(_ZN12_GLOBAL__N_120celerite_scan_kernelILi(\d+)ELi(\d+)
     k = s.find('.name:           ' + name)
     meta = s[k - 1500:k + 800] if k > 0 else ''
     vg = re.search(r'\.vgpr_count:\s+(\d+)', meta); ag = re.search(r'\.agpr_count:\s+(\d+)', meta)
-    print(f"rpl{m.group(2)} cbr{m.group(3)} nsrc{m.group(4)} tab{m.group(5)}: loop={sum(c.values())} vgpr={vg.group(1) if vg else '?'} agpr={ag.group(1) if ag else '?'} | " +
+    print(f"rpl{m.group(2)} cbr{m.group(3)} nsrc{m.group(4)} tab{m.group(5)} asm{m.group(6)}: loop={sum(c.values())} vgpr={vg.group(1) if vg else '?'} agpr={ag.group(1) if ag else '?'} | " +
           " ".join(f"{k}:{v}" for k, v in c.most_common(12)))
