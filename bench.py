@@ -161,6 +161,14 @@ def main():
     flops_launch = algorithmic_flops(N, 2 * Jt) * B   # algorithmic count uses the reference's R = 2J
     achieved = flops_launch / (kern_ms * 1e-3) / 1e12
 
+    # HBM bytes per launch come from a separate rocprofv3 --pmc pass of this same command (bench.py cannot
+    # collect PMCs on itself); the summary is committed under profiles/ and quoted here when the workload matches.
+    traffic, traffic_src = None, None
+    pmc = ROOT / "profiles" / "r01_pmc_sho20_b4096.json"
+    if pmc.exists() and (N, B, Jt, args.basis) == (10_000, 4096, 20, "SHO"):
+        traffic = json.loads(pmc.read_text())["derived"]["hbm_traffic_bytes"]
+        traffic_src = "profiles/r01_pmc_sho20_b4096.json (2*FETCH_SIZE + WRITE_SIZE, KB->B, separate --pmc passes)"
+
     result = {
         "metric": "logpdf evals/sec (batched) at N=1e4, J=20; max |Δlogℒ| vs reference",
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,7 +180,7 @@ def main():
                    "kernel_config": pj._lib.lib().pioran_celerite_config_name(R).decode(),
                    "parallelism": f"batch-sharded x{world}, all-gather of logL"},
         "roofline": {"bound": "valu-fp64", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "celerite_scan_kernel", "kernel_ms": kern_ms,
                      "algorithmic_flop_per_eval": algorithmic_flops(N, 2 * Jt),
                      "note": "FP64 vector-ALU bound (rank-1 update + matvec per draw; not HBM, not MFMA). peak = "
@@ -183,7 +191,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O  # checker + CPU baseline only
         cores = os.cpu_count() or 1
-        S = args.cpu_sample or max(cores, min(B, 4 * cores))
+        S = args.cpu_sample or max(cores, min(B, 8 * cores))   # ~8 draws per core: tens of core-seconds
         S = min(S, B)
         O.lib()
         tc = time.perf_counter()

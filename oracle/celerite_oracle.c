@@ -127,33 +127,59 @@ static double solve_prec(int64_t N, int64_t R, double *z, const double *y, const
     return logdetD;
 }
 
+/* workspace of one logl call: what the reference allocates per call (:322-330) */
+typedef struct {
+    double *S, *phi, *U, *V, *D, *z, *fg;
+} logl_ws;
+
+static int ws_alloc(logl_ws *w, int64_t N, int64_t R)
+{
+    w->S = malloc(sizeof(double) * (size_t)(R * R));
+    w->phi = malloc(sizeof(double) * (size_t)(R * (N > 1 ? N - 1 : 1)));
+    w->U = malloc(sizeof(double) * (size_t)(R * N));
+    w->V = malloc(sizeof(double) * (size_t)(R * N));
+    w->D = malloc(sizeof(double) * (size_t)N);
+    w->z = malloc(sizeof(double) * (size_t)N);
+    w->fg = malloc(sizeof(double) * (size_t)(2 * R));
+    return w->S && w->phi && w->U && w->V && w->D && w->z && w->fg;
+}
+
+static void ws_free(logl_ws *w)
+{
+    free(w->S); free(w->phi); free(w->U); free(w->V); free(w->D); free(w->z); free(w->fg);
+}
+
+static double logl_ws_run(logl_ws *w, int64_t N, int64_t J, const double *a, const double *b, const double *c,
+                          const double *d, const double *tau, const double *y, const double *sigma2,
+                          int32_t *status)
+{
+    const int64_t R = 2 * J;
+    memset(w->S, 0, sizeof(double) * (size_t)(R * R)); /* S_n = zeros(T, R, R)  :322 */
+    init_semi_separable(J, N, a, b, c, d, tau, sigma2, w->V, w->D, w->U, w->phi, w->S);
+    double logdetD = solve_prec(N, R, w->z, y, w->U, w->V, w->D, w->phi, w->fg, w->fg + R);
+    double ytz = 0.0; /* :333 y'z */
+    for (int64_t n = 0; n < N; ++n) ytz += y[n] * w->z[n];
+    double res = -logdetD / 2 - (double)N * log(2 * M_PI) / 2 - ytz / 2;
+    if (status) {
+        int32_t st = 0;
+        for (int64_t n = 0; n < N; ++n)
+            if (!(w->D[n] > 0.0)) st = 1;
+        if (!isfinite(res)) st = 2;
+        *status = st;
+    }
+    return res;
+}
+
 /* src/celerite_solver.jl:312-334  logl.
  * status (optional): 0 ok, 1 some D_n <= 0, 2 non-finite result. */
 double oracle_logl(int64_t N, int64_t J, const double *a, const double *b, const double *c,
                    const double *d, const double *tau, const double *y, const double *sigma2,
                    int32_t *status)
 {
-    const int64_t R = 2 * J;
-    double *S = calloc((size_t)(R * R), sizeof(double));
-    double *phi = malloc(sizeof(double) * (size_t)(R * (N > 1 ? N - 1 : 1)));
-    double *U = malloc(sizeof(double) * (size_t)(R * N));
-    double *V = malloc(sizeof(double) * (size_t)(R * N));
-    double *D = malloc(sizeof(double) * (size_t)N);
-    double *z = malloc(sizeof(double) * (size_t)N);
-    double *fg = malloc(sizeof(double) * (size_t)(2 * R));
-    init_semi_separable(J, N, a, b, c, d, tau, sigma2, V, D, U, phi, S);
-    double logdetD = solve_prec(N, R, z, y, U, V, D, phi, fg, fg + R);
-    double ytz = 0.0; /* :333 y'z */
-    for (int64_t n = 0; n < N; ++n) ytz += y[n] * z[n];
-    double res = -logdetD / 2 - (double)N * log(2 * M_PI) / 2 - ytz / 2;
-    if (status) {
-        int32_t st = 0;
-        for (int64_t n = 0; n < N; ++n)
-            if (!(D[n] > 0.0)) st = 1;
-        if (!isfinite(res)) st = 2;
-        *status = st;
-    }
-    free(S); free(phi); free(U); free(V); free(D); free(z); free(fg);
+    logl_ws w;
+    double res = NAN;
+    if (ws_alloc(&w, N, 2 * J)) res = logl_ws_run(&w, N, J, a, b, c, d, tau, y, sigma2, status);
+    ws_free(&w);
     return res;
 }
 
@@ -189,22 +215,33 @@ void oracle_logl_batch(int64_t N, int64_t J, int64_t B, const double *A, const d
                        const double *nu, const double *tau, const double *y, const double *sigma2,
                        double *out, int32_t *status, int nthreads)
 {
+    /* each thread keeps ONE workspace for all its draws (a process-farm worker would let its allocator
+     * reuse the same pages; per-call malloc of ~10 MB from 100+ threads measures the kernel's mmap lock) */
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
 #endif
-    for (int64_t bi = 0; bi < B; ++bi) {
+    {
+        logl_ws w;
         double *yb = malloc(sizeof(double) * (size_t)N);
         double *sb = malloc(sizeof(double) * (size_t)N);
-        double m = mu ? mu[bi] : 0.0, v = nu ? nu[bi] : 1.0;
-        for (int64_t n = 0; n < N; ++n) {
-            yb[n] = mu ? y[n] - m : y[n];
-            sb[n] = nu ? v * sigma2[n] : sigma2[n];
+        const int okws = ws_alloc(&w, N, 2 * J) && yb && sb;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int64_t bi = 0; bi < B; ++bi) {
+            if (!okws) { out[bi] = NAN; if (status) status[bi] = 2; continue; }
+            double m = mu ? mu[bi] : 0.0, v = nu ? nu[bi] : 1.0;
+            for (int64_t n = 0; n < N; ++n) {
+                yb[n] = mu ? y[n] - m : y[n];
+                sb[n] = nu ? v * sigma2[n] : sigma2[n];
+            }
+            const double *cb = cd_shared ? C : C + bi * J;
+            const double *db = cd_shared ? Dd : Dd + bi * J;
+            int32_t st = 0;
+            out[bi] = logl_ws_run(&w, N, J, A + bi * J, Bc + bi * J, cb, db, tau, yb, sb, &st);
+            if (status) status[bi] = st;
         }
-        const double *cb = cd_shared ? C : C + bi * J;
-        const double *db = cd_shared ? Dd : Dd + bi * J;
-        int32_t st = 0;
-        out[bi] = oracle_logl(N, J, A + bi * J, Bc + bi * J, cb, db, tau, yb, sb, &st);
-        if (status) status[bi] = st;
+        ws_free(&w);
         free(yb); free(sb);
     }
 }
