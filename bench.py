@@ -96,9 +96,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ   # under torch.distributed.run always take the RCCL path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # communicator set-up (RCCL builds rings / loads kernels lazily on the first collectives): part of
+        # process start-up, not of a step, so it must not depend on --warmup
+        _w = torch.zeros(8, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            pj.farm.gather_logl(_w, 8 * world)
+            dist.barrier()
+        torch.cuda.synchronize(dev)
 
     N, B, J = args.n, args.batch, args.components
     t, y, yerr = synth_series(N)
@@ -124,12 +133,12 @@ def main():
     def step():
         ds.logl_batch_dev(B, dA.data_ptr(), dB.data_ptr(), dmu.data_ptr(), dnu.data_ptr(), 0, 0, dout.data_ptr(),
                           dst.data_ptr())
-        if world > 1:
+        if use_dist:
             pj.farm.gather_logl(dout, B * world)  # the only collective: all-gather of B fp64 per rank (RCCL)
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -143,12 +152,12 @@ def main():
         ds.logl_batch_dev(B, dA.data_ptr(), dB.data_ptr(), dmu.data_ptr(), dnu.data_ptr(), 0, 0, dout.data_ptr(),
                           dst.data_ptr())
         ev1.record(stream)
-        if world > 1:
+        if use_dist:
             gathered = pj.farm.gather_logl(dout, B * world)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -207,7 +216,8 @@ def main():
         result["max_rel_dlogl_vs_oracle"] = float((err / np.abs(ref[ok])).max()) if ok.any() else None
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
+        assert gathered.numel() == B * world and torch.equal(gathered[rank * B:(rank + 1) * B], dout)
         dist.destroy_process_group()
 
 
