@@ -408,6 +408,14 @@ int pioran_celerite_logl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a,
 }
 
 // ---- dense solver -------------------------------------------------------------------------------
+// ascending time stamps enable the factorised covariance build (dense.hip); anything else takes the direct one
+static int is_sorted(const double* t, int64_t N)
+{
+    for (int64_t i = 1; i < N; ++i)
+        if (!(t[i] >= t[i - 1])) return 0;
+    return 1;
+}
+
 static int dense_stage(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
                        const double* d, const double* t, const double* y, const double* sigma2, double** dv)
 {
@@ -431,7 +439,7 @@ static int dense_stage(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, c
     dv[8] = base + off + 1;  // info (int32 in the first 4 bytes)
     int64_t Mp, ld;
     pioran_dense_dims(N, &Mp, &ld);
-    return ensure(ctx, ctx->bK, (size_t)Mp * (size_t)ld * sizeof(double));
+    return ensure(ctx, ctx->bK, ((size_t)Mp * (size_t)ld + 1024) * sizeof(double));
 }
 
 int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
@@ -445,7 +453,7 @@ int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, con
     int rc = dense_stage(ctx, N, J, a, b, c, d, t, y, sigma2, dv);
     if (rc) return rc;
     rc = pioran_dense_nll_device(N, (int32_t)J, dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], (double*)ctx->bK.p,
-                                 nullptr, dv[7], (int32_t*)dv[8], ctx->stream);
+                                 nullptr, dv[7], (int32_t*)dv[8], is_sorted(t, N), ctx->stream);
     if (rc) { ctx->last_err = "dense kernel launch failed"; return rc; }
     int32_t hinfo = 0;
     HIPCHK(ctx, hipMemcpyAsync(out, dv[7], sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -465,7 +473,7 @@ int pioran_dense_covariance(pioran_ctx* ctx, int64_t N, int64_t J, const double*
     int rc = dense_stage(ctx, N, J, a, b, c, d, t, nullptr, sigma2, dv);
     if (rc) return rc;
     rc = pioran_dense_build_device(N, (int32_t)J, dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], (double*)ctx->bK.p,
-                                   ctx->stream);
+                                   is_sorted(t, N), ctx->stream);
     if (rc) { ctx->last_err = "dense build launch failed"; return rc; }
     int64_t Mp, ld;
     pioran_dense_dims(N, &Mp, &ld);

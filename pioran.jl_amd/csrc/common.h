@@ -51,8 +51,8 @@ int pioran_launch_table(int64_t N, int32_t R, const int32_t* rowmap, const doubl
 void pioran_dense_dims(int64_t N, int64_t* Mp, int64_t* ld);
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,
                             const double* d, const double* t, const double* y, const double* s2,
-                            double* K /*ld*Mp*/, double* work, double* out, int32_t* info,
-                            hipStream_t stream);
+                            double* K /*ld*Mp + 1024*/, double* work, double* out, int32_t* info,
+                            int sorted, hipStream_t stream);
 int pioran_dense_build_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,
                               const double* d, const double* t, const double* y, const double* s2,
-                              double* K, hipStream_t stream);
+                              double* K, int sorted, hipStream_t stream);
