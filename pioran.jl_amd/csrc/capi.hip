@@ -22,6 +22,9 @@ struct pioran_ctx {
         size_t cap = 0;
     };
     Buf bA, bB, bC, bD, bmu, bnu, bY, bS2, bout, bst, bscratch, bK, bwork;
+    // scalar entry point: the last series' time stamps stay resident (samplers call logl with the same t)
+    pioran_ds* scalar_ds = nullptr;
+    std::vector<double> scalar_t;
 };
 
 struct pioran_ds {
@@ -178,6 +181,8 @@ int pioran_ctx_destroy(pioran_ctx* ctx)
     if (!ctx) return PIORAN_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scalar_ds) pioran_dataset_destroy(ctx->scalar_ds);
+    ctx->scalar_ds = nullptr;
     pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
                                &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork};
     for (auto* b : bufs)
@@ -399,12 +404,26 @@ int pioran_celerite_logl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a,
                          int32_t* status)
 {
     if (!ctx || N < 1 || J < 1 || !a || !b || !c || !d || !t || !y || !sigma2 || !out) return PIORAN_ERR_ARG;
-    pioran_ds* ds = nullptr;
-    int rc = pioran_dataset_create(ctx, N, t, y, sigma2, &ds);
-    if (rc) return rc;
-    rc = pioran_celerite_logl_batch(ds, 1, J, a, b, c, d, 1, nullptr, nullptr, nullptr, nullptr, out, status);
-    pioran_dataset_destroy(ds);
-    return rc;
+    // A sampler calls logl thousands of times with the same t (and usually the same c, d) and a fresh y - mu,
+    // sigma2 * nu: keep the series handle (and through it the cos/sin/exp table) while t is unchanged, and pass
+    // y, sigma2 as this call's per-draw series.
+    int rc;
+    const bool same_t = ctx->scalar_ds && (int64_t)ctx->scalar_t.size() == N &&
+                        !std::memcmp(ctx->scalar_t.data(), t, (size_t)N * sizeof(double));
+    if (!same_t) {
+        if (ctx->scalar_ds) pioran_dataset_destroy(ctx->scalar_ds);
+        ctx->scalar_ds = nullptr;
+        ctx->scalar_t.clear();
+        if ((rc = pioran_dataset_create(ctx, N, t, y, sigma2, &ctx->scalar_ds))) return rc;
+        ctx->scalar_t.assign(t, t + N);
+    }
+    return pioran_celerite_logl_batch(ctx->scalar_ds, 1, J, a, b, c, d, 1, nullptr, nullptr, y, sigma2, out, status);
+}
+
+const char* pioran_celerite_config_name(int64_t R)
+{
+    if (R < 1 || R > pioran_scan_supported_rows()) return "fallback";
+    return pioran_scan_config_name((int)R);
 }
 
 // ---- dense solver -------------------------------------------------------------------------------
@@ -486,10 +505,5 @@ int pioran_dense_covariance(pioran_ctx* ctx, int64_t N, int64_t J, const double*
     return PIORAN_OK;
 }
 
-const char* pioran_celerite_config_name(int64_t R)
-{
-    if (R < 1 || R > pioran_scan_supported_rows()) return "fallback";
-    return pioran_scan_config_name((int)R);
-}
 
 }  // extern "C"

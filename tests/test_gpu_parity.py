@@ -318,3 +318,72 @@ def test_dense_full_size_relation(ctx, full_size):
     cel = pj.log_likelihood(R, t, y - mu, yerr ** 2, ctx=ctx)
     assert info == 0
     assert abs(cel + den) <= 1e-8 * abs(den)
+
+
+# ---------------------------------------------------------------------------------------------
+# C-ABI behaviour: caching, re-preparation, several handles, argument errors
+# ---------------------------------------------------------------------------------------------
+def test_scalar_entry_caches_series_and_table(ctx):
+    """Repeated logl calls with the same t (sampler pattern) reuse the resident series; changing y, sigma2,
+    (a, b), (c, d), J or t between calls must still give the right answer every time."""
+    rng = np.random.default_rng(77)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 300, 5, 4)
+    for k in range(4):   # same t, same (c, d); fresh y - mu, nu * s2, (a, b)
+        v = ctx.logl(A[k], Bc[k], C, Dd, t, y - mu[k], nu[k] * s2)
+        assert abs(v - O.logl(A[k], Bc[k], C, Dd, t, y - mu[k], nu[k] * s2)) <= 1e-11 * abs(v)
+    C2 = C * 1.3
+    assert abs(ctx.logl(A[0], Bc[0], C2, Dd, t, y, s2) - O.logl(A[0], Bc[0], C2, Dd, t, y, s2)) <= 1e-9   # new (c, d)
+    assert abs(ctx.logl(A[0, :3], Bc[0, :3], C[:3], Dd[:3], t, y, s2) - O.logl(A[0, :3], Bc[0, :3], C[:3], Dd[:3], t, y, s2)) <= 1e-9
+    t2 = t * 1.01                                                                                              # new t
+    assert abs(ctx.logl(A[0], Bc[0], C, Dd, t2, y, s2) - O.logl(A[0], Bc[0], C, Dd, t2, y, s2)) <= 1e-9
+    t3 = t[:200]                                                                                               # new N
+    assert abs(ctx.logl(A[0], Bc[0], C, Dd, t3, y[:200], s2[:200]) - O.logl(A[0], Bc[0], C, Dd, t3, y[:200], s2[:200])) <= 1e-9
+
+
+def test_two_datasets_and_two_contexts(ctx):
+    rng = np.random.default_rng(78)
+    c1 = _random_case(rng, 150, 6, 9)
+    c2 = _random_case(rng, 90, 11, 5)
+    ctx2 = pj.Context(0)
+    ds1 = pj.Dataset(c1[0], c1[1], c1[2], ctx)
+    ds2 = pj.Dataset(c2[0], c2[1], c2[2], ctx2)
+    ds3 = pj.Dataset(c2[0], c2[1], c2[2], ctx)      # second data set on the first context
+    for _ in range(2):                               # interleaved use must not cross-contaminate cached tables
+        for ds, cs in ((ds1, c1), (ds2, c2), (ds3, c2)):
+            t, y, s2, A, Bc, C, Dd, mu, nu = cs
+            got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+            assert relerr(got, O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu)) < 1e-11
+    ds2.close(); ctx2.close()
+
+
+def test_abi_argument_errors_on_gpu(ctx):
+    L = pj._lib.lib()
+    rng = np.random.default_rng(79)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 50, 3, 2)
+    ds = pj.Dataset(t, y, s2, ctx)
+    # device-pointer batch before pioran_dataset_prepare -> invalid argument, not a crash
+    assert L.pioran_celerite_logl_batch_dev(ds._h, 2, 1, 1, None, None, None, None, 1, None) == -1
+    with pytest.raises(ValueError):
+        ds.logl_batch(A, Bc[:, :2], C, Dd)
+    with pytest.raises(ValueError):
+        ds.logl_batch(A, Bc, C, Dd, Y=np.zeros((2, 50)))
+    with pytest.raises(pj._lib.PioranHipError):     # a "real" term must have d = 0
+        ds.prepare(C, np.ones(3), real_term=[1, 0, 0])
+    with pytest.raises(ValueError):
+        pj.Dataset(t, y[:10], s2, ctx)
+    assert L.pioran_ctx_event_record(ctx._h, 99) == -1
+    ctx.event_record(0); ctx.event_record(1)
+    assert ctx.event_elapsed_ms(0, 1) >= 0.0
+
+
+def test_large_batch_and_long_series(ctx):
+    """B = 20000 draws (ragged vs workgroup size) at small N, and N = 65536 (the reference benchmark's longest
+    series, benchmark/benchmarks.jl:16) at small B, J = 16 terms."""
+    rng = np.random.default_rng(80)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 40, 4, 20001)
+    got = pj.Dataset(t, y, s2, ctx).logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    sel = rng.choice(20001, 300, replace=False)
+    assert relerr(got[sel], O.logl_batch(A[sel], Bc[sel], C, Dd, t, y, s2, mu[sel], nu[sel], nthreads=8)) < 1e-11
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 65536, 16, 3)
+    got = pj.Dataset(t, y, s2, ctx).logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    assert relerr(got, O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=3)) < 1e-9

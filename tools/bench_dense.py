@@ -28,7 +28,14 @@ res = {"workload": f"dense log_likelihood_direct N={N} SHO-{J} (J={J})", "ms_per
        "rel_diff_vs_celerite_gpu": abs(cel + v) / abs(v), "cholesky_flop": flop,
        "tflops_on_cholesky_flop_whole_call": flop / (ms * 1e-3) / 1e12}
 if os.environ.get("CPU", "1") == "1":
+    # CPU baseline the way the reference does it (src/direct_solver.jl:6-21): build K entry by entry, then LAPACK
+    # dpotrf/dtrtrs (numpy/scipy -> OpenBLAS, all host threads).  oracle.dense_nll_numpy vectorises the build over
+    # (i, k) per term; the reference's own build is a scalar double loop and is slower still.
     from oracle import oracle as O
-    t0 = time.perf_counter(); ref = O.dense_nll(R.a, R.b, R.c, R.d, t, y - mu, yerr ** 2); cpu_s = time.perf_counter() - t0
-    res["oracle_cpu_s"] = cpu_s; res["rel_err_vs_oracle"] = abs(v - ref) / abs(ref); res["cpu_threads"] = os.cpu_count()
+    t0 = time.perf_counter(); ref = O.dense_nll_numpy(R.a, R.b, R.c, R.d, t, y - mu, yerr ** 2); cpu_s = time.perf_counter() - t0
+    res["cpu_baseline"] = {"value": cpu_s * 1e3, "unit": "ms_per_call", "cores": os.cpu_count(), "kind": "port",
+                           "sample": "same single call; numpy build + LAPACK Cholesky/solve (oracle.dense_nll_numpy)"}
+    res["rel_err_vs_cpu_lapack"] = abs(v - ref) / abs(ref)
+res["roofline"] = {"bound": "mfma", "kernel": "dense_syrk_kernel", "peak": 78.6, "unit": "TFLOP/s",
+                   "note": "achieved = N^3/3 flop / summed SYRK time from the rocprofv3 summary in profiles/ (this script times the whole call)"}
 print(json.dumps(res))
