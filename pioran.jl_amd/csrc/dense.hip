@@ -190,81 +190,151 @@ constexpr int LP = NB + 1;
 //   ws[0 .. 1023]   inv(L_ss), s = 0..3, row-major 16 x 16 each
 [[maybe_unused]] constexpr int WS_DOUBLES = 4 * 16 * 16;
 
+// Diagnostic hooks: compiled out in the product; tools/factor_probe.hip defines PIORAN_STAMP to s_memtime stamps.
+#ifndef PIORAN_STAMP
+#define PIORAN_STAMP(i)
+#endif
+
+// lane N of each 16-lane DPP row -> all lanes of that row
+template <int N>
+__device__ __forceinline__ double bcast16(double x)
+{
+    return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true);
+}
+
 // Factor the 64 x 64 block held row-major (padded) in LDS `Ls`, in place, by ONE wavefront; writes the four
 // 16 x 16 inverses to `ws` (global).  Returns the 1-based index of the first non-positive pivot (0 = none).
-__device__ __forceinline__ int factor_block64(double* __restrict__ Ls, double* __restrict__ rdiag,
-                                              double* __restrict__ ws, int lane)
+//
+// Per 16-column sub-panel s only the 16 x 16 diagonal tile is scalar work: every DPP row of the wave holds the
+// tile (lane l&15 = tile row), the right-looking Cholesky and the triangular inverse take their cross-lane
+// operands from v_mov_b64_dpp row_newbcast, and the per-column critical path is bcast -> rsqrt -> mul -> fma.
+// Everything below the tile is matrix-core work through LDS: X_t = A_ts inv(L_ss)' for the tiles t > s
+// (transposed C/D layout, the inverse as A operand), then the in-block update A_rc -= X_r X_c'.
+__device__ __forceinline__ int factor_block64(double* __restrict__ Ls, double* __restrict__ ws, int lane)
 {
     const int lr = lane & 15, lk = lane >> 4;
     int bad = 0;
-#pragma unroll
+    // runtime loop over the four 16-column sub-panels: one copy of the code (instruction cache stays warm after
+    // the first pass), the tile loops inside are static with wave-uniform guards.
+#pragma unroll 1
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
-        // ---- scalar sub-panel: rows >= c0, 16 columns, right-looking ------------------------------------
-        // lane = row.  Column p: the pivot and the multipliers l_{c0+q,p} (q > p) live in other lanes'
-        // registers; they are fetched with v_readlane (compile-time lane -> SGPR pair), so the per-column
-        // critical path is readlane -> rsqrt -> mul -> readlane -> fma, with no LDS round trip.
+        const int ir0 = s == 3 ? 16 : 0, ic0 = s == 3 ? 32 : 16 * (s + 1);   // where inv(L_ss) is parked
+        PIORAN_STAMP(8 * s + 0);
+        // ---- 16 x 16 diagonal tile: right-looking Cholesky, lane lr = row (replicated in the 4 DPP rows) -----
         double r[16];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) r[p] = Ls[lane * LP + c0 + p];
+        for (int p = 0; p < 16; ++p) r[p] = Ls[(c0 + lr) * LP + c0 + p];
+        double rinv_own = 0.0;   // 1 / l_pp of this lane's row
         static_for16([&](auto Pc) {
             constexpr int p = decltype(Pc)::value;
-            const int src = c0 + p;
-            const double piv = readlane_f64(r[p], src);
-            if (!(piv > 0.0) && !bad) bad = src + 1;
+            const double piv = bcast16<p>(r[p]);
+            if (!(piv > 0.0) && !bad) bad = c0 + p + 1;
             const double rinv = rsqrt_f64(piv);           // 1 / l_pp
-            r[p] = lane == src ? piv * rinv : r[p] * rinv;
-            if (lane == src) rdiag[src] = rinv;
+            r[p] = lr == p ? piv * rinv : r[p] * rinv;    // rows above p hold junk in column p (never used)
+            if (lr == p) rinv_own = rinv;
+            const double nrp = -r[p];
             static_for16([&](auto Qc) {
                 constexpr int q = decltype(Qc)::value;
-                if constexpr (q > p) {
-                    const double lqp = readlane_f64(r[p], c0 + q);   // l_{c0+q, p}
-                    r[q] = fma(-r[p], lqp, r[q]);
-                }
+                if constexpr (q > p) r[q] = fma(bcast16<q>(r[p]), nrp, r[q]);   // a_iq -= l_ip l_qp
             });
         });
+        PIORAN_STAMP(8 * s + 1);
+        // ---- inverse of the tile, column-owner layout: lane j computes column j of X = inv(L) -------------------
+        //   X[i][j] = (delta_ij - sum_{k<i} L[i][k] X[k][j]) / l_ii ; L[i][k] and 1/l_ii come from lane i by DPP broadcast
+        double x[16];
+        static_for16([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            double acc0 = lr == i ? 1.0 : 0.0, acc1 = 0.0;
+            static_for16([&](auto Kc) {
+                constexpr int k = decltype(Kc)::value;
+                if constexpr (k < i) {
+                    if constexpr (k & 1) acc1 = fma(-bcast16<i>(r[k]), x[k], acc1);
+                    else acc0 = fma(-bcast16<i>(r[k]), x[k], acc0);
+                }
+            });
+            x[i] = (acc0 + acc1) * bcast16<i>(rinv_own);
+        });
+        PIORAN_STAMP(8 * s + 2);
+        // publish to LDS only: L rows in place (lane = row; junk above the diagonal is never read) and the inverse
+        // (lane = column) into a 16 x 16 tile of the block's strictly-upper part, which the algorithm never touches
+        if (lk == 0) {
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
-            if (lane >= c0 + p) Ls[lane * LP + c0 + p] = r[p];
+            for (int p = 0; p < 16; ++p) {
+                Ls[(c0 + lr) * LP + c0 + p] = r[p];
+                Ls[(ir0 + p) * LP + ic0 + lr] = x[p];     // X[p][lr]
+            }
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        // ---- in-block trailing update on the matrix cores: tiles (rt, ct), s < ct <= rt ----------------------
-        if (s < 3) {
-            double xop[4][4];   // [tile t][k-step]: X_t as MFMA A/B operand (same access pattern for both)
+        PIORAN_STAMP(8 * s + 3);
+        // ---- rows below the tile on the matrix cores: Y_t = inv(L_ss) A_ts'  (D[row = c][col = r]) ---------------
+        double iop[4];   // A operand of k-step ks: inv(L)[row lr][k = 4ks + lk]
 #pragma unroll
-            for (int t = s + 1; t < 4; ++t)
+        for (int ks = 0; ks < 4; ++ks) iop[ks] = Ls[(ir0 + lr) * LP + ic0 + 4 * ks + lk];
+        f64x4 Yt[4];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) xop[t][ks] = Ls[(16 * t + lr) * LP + c0 + 4 * ks + lk];
+        for (int t = 1; t < 4; ++t) {
+            Yt[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+            if (t > s) {   // wave-uniform
+                f64x4 a;
 #pragma unroll
-            for (int rt = s + 1; rt < 4; ++rt)
+                for (int g = 0; g < 4; ++g) a[g] = Ls[(16 * t + lr) * LP + c0 + lk + 4 * g];   // A_ts' in C/D layout
+                f64x4 z = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int ct = s + 1; ct <= rt; ++ct) {
+                for (int ks = 0; ks < 4; ++ks) z = mfma4(iop[ks], a[ks], z);                    // reg ks IS the B operand
+                Yt[t] = z;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Ls[(16 * t + lr) * LP + c0 + lk + 4 * g] = z[g];
+            }
+        }
+        PIORAN_STAMP(8 * s + 4);
+        // ---- in-block trailing update: A_rc -= X_r X_c', operands straight from the result registers ---------------
+        // X_t as A operand: M[row = c][k] = Y_t[k][c] -> C/D register ks of Y_t; as B operand: B[k][col = r] -> the same.
+#pragma unroll
+        for (int rt = 1; rt < 4; ++rt)
+#pragma unroll
+            for (int ct = 1; ct <= rt; ++ct)
+                if (ct > s) {   // wave-uniform (then rt > s too)
                     f64x4 c;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) c[g] = Ls[(16 * rt + lr) * LP + 16 * ct + lk + 4 * g];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) c = mfma4(-xop[ct][ks], xop[rt][ks], c);
+                    for (int ks = 0; ks < 4; ++ks) c = mfma4(-Yt[ct][ks], Yt[rt][ks], c);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) Ls[(16 * rt + lr) * LP + 16 * ct + lk + 4 * g] = c[g];
                 }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        PIORAN_STAMP(8 * s + 5);
     }
-    // ---- inverses of the four diagonal 16 x 16 blocks: lane = (block, column) ---------------------------------
+    // the four inverses -> workspace (row-major 16 x 16 each), 16 entries per lane, coalesced
     {
-        const int bk = lane >> 4, j = lane & 15, c0 = 16 * bk;
-        double x[16];
+        double v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double acc = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < i; ++k) acc = fma(-Ls[(c0 + i) * LP + c0 + k], x[k], acc);   // x[k] = 0 for k < j
-            x[i] = (i < j) ? 0.0 : acc * rdiag[c0 + i];
-            ws[(bk * 16 + i) * 16 + j] = x[i];
+        for (int e = 0; e < 16; ++e) {
+            const int idx = e * 64 + lane, sb = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
+            v[e] = Ls[((sb == 3 ? 16 : 0) + i) * LP + (sb == 3 ? 32 : 16 * (sb + 1)) + j];
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ws[e * 64 + lane] = v[e];
     }
+    PIORAN_STAMP(40);
     return bad;
+}
+
+// factored block: LDS -> global, lane = row, rows contiguous across lanes.  The strictly-upper part of the slab is
+// scratch (never read as data), so the whole 64 x 64 block is stored without masking.
+__device__ __forceinline__ void store_block_lower(const double* __restrict__ Ls, double* __restrict__ blk, int64_t ld, int lane)
+{
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = Ls[lane * LP + 16 * h + q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) blk[lane + (int64_t)(16 * h + q) * ld] = v[q];
+    }
 }
 
 // First diagonal block (no trailing update precedes it): load, factor, write back.
@@ -272,14 +342,19 @@ __global__ void __launch_bounds__(64) dense_diag0_kernel(double* __restrict__ A,
                                                          int32_t* __restrict__ info)
 {
     __shared__ double Ls[NB * LP];
-    __shared__ double rdiag[NB];
     const int lane = threadIdx.x;
-    for (int q = 0; q < NB; ++q) Ls[lane * LP + q] = A[lane + (int64_t)q * ld];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = A[lane + (int64_t)(16 * h + q) * ld];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Ls[lane * LP + 16 * h + q] = v[q];
+    }
     __syncthreads();
-    const int bad = factor_block64(Ls, rdiag, ws, lane);
+    const int bad = factor_block64(Ls, ws, lane);
     __syncthreads();
-    for (int q = 0; q < NB; ++q)
-        if (q <= lane) A[lane + (int64_t)q * ld] = Ls[lane * LP + q];
+    store_block_lower(Ls, A, ld, lane);
     if (lane == 0 && bad && *info == 0) *info = bad;
 }
 
@@ -357,7 +432,6 @@ __global__ void __launch_bounds__(64) dense_syrk_kernel(double* __restrict__ A, 
     // it right away (factor_block64), while the other tiles are still being updated; the next panel kernel then
     // starts from a finished diagonal block.  33.8 KB of LDS per workgroup still allows 4 workgroups per CU.
     __shared__ double Ls[NB * LP];
-    __shared__ double rdiag[NB];
     const int64_t j0 = kb + NB;
     // i tiles 0..nt (the last one holds the y row Mp and 63 scratch rows of the slab), j tiles 0..nt-1, i >= j
     const int nt = (int)((Mp - j0) / NB) + 1;
@@ -440,11 +514,9 @@ __global__ void __launch_bounds__(64) dense_syrk_kernel(double* __restrict__ A, 
     }
     if (diag_next) {
         __syncthreads();
-        const int bad = factor_block64(Ls, rdiag, ws, lane);
+        const int bad = factor_block64(Ls, ws, lane);
         __syncthreads();
-        double* blk = A + j0 + j0 * ld;
-        for (int q = 0; q < NB; ++q)
-            if (q <= lane) blk[lane + (int64_t)q * ld] = Ls[lane * LP + q];
+        store_block_lower(Ls, A + j0 + j0 * ld, ld, lane);
         if (lane == 0 && bad && *info == 0) *info = (int32_t)(j0 + bad);
     }
 }
