@@ -202,8 +202,8 @@ struct StepIn {           // what one time step reads: per own row (v, x, phi) +
     double v[RPL], x[RPL], ph[RPL], y, s2;
 };
 
-template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false>
-__global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
+template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false, int MINW = 1>
+__global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanParams p)
 {
     static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
     constexpr int G = 16 * CBR;          // lanes per draw
@@ -426,13 +426,13 @@ __global__ void __launch_bounds__(256) celerite_scan_kernel(const ScanParams p)
 
 using LaunchFn = void (*)(const ScanParams&, dim3, hipStream_t);
 
-template <int RPL, int CBR, int NSRC, bool ASM_DPP = false>
+template <int RPL, int CBR, int NSRC, bool ASM_DPP = false, int MINW = 1>
 void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 {
     if (p.tab)
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, ASM_DPP>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, ASM_DPP, MINW>), grid, dim3(256), 0, st, p);
     else
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false, ASM_DPP>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false, ASM_DPP, MINW>), grid, dim3(256), 0, st, p);
 }
 
 struct ScanConfig {
@@ -450,10 +450,13 @@ const ScanConfig kConfigs[] = {
     CFG(1, 1, 5),  CFG(1, 1, 9),  CFG(1, 1, 13), CFG(1, 1, 16),           // R <= 15
     CFG(2, 1, 9),  CFG(2, 1, 11), CFG(2, 1, 13), CFG(2, 1, 15), CFG(2, 1, 16),  // R <= 31
     CFG(3, 2, 6),  CFG(3, 2, 7),  CFG(3, 2, 8),                           // R <= 47
-    CFG(4, 4, 4),                                                         // R <= 63
+    // R <= 63: 256 registers/lane (2 waves per SIMD) beats the AGPR-spilling 1-wave build; compiler-scheduled
+    {"rpl4_cbr4_nsrc4", 4, 4, 4, &launch_cfg<4, 4, 4, false, 2>},
     CFG(5, 4, 4),                                                         // R <= 79
     // alternatives kept for tuning runs (selected by name)
     CFG(3, 4, 4), CFG(2, 2, 8), CFG_C(3, 2, 7), CFG_C(4, 4, 4), CFG_C(2, 1, 16), CFG_C(1, 1, 16), CFG_C(5, 4, 4),
+    {"rpl4_cbr4_nsrc4_asm", 4, 4, 4, &launch_cfg<4, 4, 4, true, 1>},
+    {"rpl4_cbr4_nsrc4_asm_w2", 4, 4, 4, &launch_cfg<4, 4, 4, true, 2>},
 };
 #undef CFG
 #undef CFG_C
