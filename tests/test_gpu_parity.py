@@ -388,3 +388,29 @@ def test_large_batch_and_long_series(ctx):
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 65536, 16, 3)
     got = pj.Dataset(t, y, s2, ctx).logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
     assert relerr(got, O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=3)) < 1e-9
+
+
+def test_nonpd_value_follows_reference_abs_semantics(ctx):
+    """D_n <= 0 for some n >= 2 but D_1 > 0: the reference silently uses log(abs(D[n])) (celerite_solver.jl:140);
+    the value must match the oracle's (which restates that), with status 1."""
+    rng = np.random.default_rng(91)
+    t = np.cumsum(rng.uniform(0.2, 1.0, 60)); y = rng.standard_normal(60); s2 = np.full(60, 1e-3)
+    # two terms, the second with a negative amplitude: sum(a) + s2 > 0 but K is indefinite
+    a = np.array([1.0, -0.9]); b = np.zeros(2); c = np.array([0.05, 2.0]); d = np.array([0.0, 0.0])
+    ref, rst = O.logl(a, b, c, d, t, y, s2, return_status=True)
+    got, st = ctx.logl(a, b, c, d, t, y, s2, return_status=True)
+    assert rst == 1 and st == 1 and np.isfinite(ref)
+    assert abs(got - ref) <= 1e-9 * abs(ref)
+
+
+def test_custom_mean_logpdf(ctx):
+    """test/test_mean.jl:64-74: CustomMean, zero measurement variance, N = 100 on a regular grid: finite logpdf,
+    equal to the oracle with the mean subtracted."""
+    t = np.linspace(0, 1000, 100)
+    mfun = lambda x: 1.3 * np.sin(2 * np.pi * x / 53.4) + 0.84
+    R = pj.approx(pj.SingleBendingPowerLaw(0.4, 1e-2, 3.1), 1e-3, 1e3, 20, 0.3, basis_function="SHO")
+    fx = pj.ScalableGP(pj.CustomMean(mfun), R)(t, np.zeros(100))
+    y = np.random.default_rng(12).standard_normal(100)
+    val = pj.logpdf(fx, y, ctx=ctx)
+    assert np.isfinite(val)
+    assert abs(val - O.logl(R.a, R.b, R.c, R.d, t, y - mfun(t), np.zeros(100))) <= 1e-9 * abs(val)
