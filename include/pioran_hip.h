@@ -106,6 +106,19 @@ int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const
                                       const double* dBc, const double* dC, const double* dDd,
                                       const double* dmu, const double* dnu, const double* dY,
                                       const double* dS2, double* dout, int32_t* dstatus);
+/* Per-draw data transform on the device — the reference's production models sample a shift c_b and fit the
+ * log-flux (docs/src/ultranest.md:199-205, examples/ultranest/single_pl.jl:65-86, benchmark/benchmarks.jl:58-59):
+ *     y_b      = log(y - shift_b)
+ *     sigma2_b = sigma2 / (y - shift_b)^2            (then mu_b, nu_b exactly as above)
+ * The data set holds the RAW flux y and sigma2 = yerr^2.  Only shift[B] crosses the boundary; the [B][N]
+ * transformed series are built in HBM by a transform kernel.  y - shift_b <= 0 gives status 2 (NaN), where the
+ * reference throws DomainError from log.  Host-pointer (blocking) and device-pointer (asynchronous) forms. */
+int pioran_celerite_logl_batch_shift(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc,
+                                     const double* C, const double* Dd, int cd_shared, const double* mu,
+                                     const double* nu, const double* shift, double* out, int32_t* status);
+int pioran_celerite_logl_batch_shift_dev(pioran_ds* ds, int64_t B, const double* dA, const double* dBc,
+                                         const double* dmu, const double* dnu, const double* dshift,
+                                         double* dout, int32_t* dstatus);
 /* Name of the kernel configuration a batch with R active rows runs on (diagnostics). */
 const char* pioran_celerite_config_name(int64_t R);
 

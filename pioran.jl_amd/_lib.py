@@ -36,6 +36,9 @@ SIGNATURES = {
                                                   c_void_p]),
     "pioran_celerite_logl_batch_dev": (ctypes.c_int, [c_void_p, i64] + [c_void_p] * 8),
     "pioran_celerite_logl_batch_dev_cd": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 10),
+    "pioran_celerite_logl_batch_shift": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                        ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pioran_celerite_logl_batch_shift_dev": (ctypes.c_int, [c_void_p, i64] + [c_void_p] * 7),
     "pioran_celerite_config_name": (ctypes.c_char_p, [i64]),
     "pioran_dense_nll": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [c_void_p, c_void_p]),
     "pioran_dense_covariance": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 6 + [c_void_p]),

@@ -344,9 +344,10 @@ int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const
     return launch(ds, p);
 }
 
-int pioran_celerite_logl_batch(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc,
-                               const double* C, const double* Dd, int cd_shared, const double* mu, const double* nu,
-                               const double* Y, const double* S2, double* out, int32_t* status)
+// host-pointer batch; series_on_device: ctx->bY / ctx->bS2 already hold the per-draw series (shift transform)
+static int batch_host_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                           const double* Dd, int cd_shared, const double* mu, const double* nu, const double* Y,
+                           const double* S2, bool series_on_device, double* out, int32_t* status)
 {
     if (!ds || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !out) return PIORAN_ERR_ARG;
     if ((Y == nullptr) != (S2 == nullptr)) return PIORAN_ERR_ARG;
@@ -382,8 +383,8 @@ int pioran_celerite_logl_batch(pioran_ds* ds, int64_t B, int64_t J, const double
     if ((rc = ensure(ctx, ctx->bst, B * sizeof(int32_t)))) return rc;
     const double* dmu = mu ? (const double*)ctx->bmu.p : nullptr;
     const double* dnu = nu ? (const double*)ctx->bnu.p : nullptr;
-    const double* dY = Y ? (const double*)ctx->bY.p : nullptr;
-    const double* dS2 = Y ? (const double*)ctx->bS2.p : nullptr;
+    const double* dY = (Y || series_on_device) ? (const double*)ctx->bY.p : nullptr;
+    const double* dS2 = (Y || series_on_device) ? (const double*)ctx->bS2.p : nullptr;
     if (cd_shared)
         rc = pioran_celerite_logl_batch_dev(ds, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu, dY,
                                             dS2, (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
@@ -397,6 +398,49 @@ int pioran_celerite_logl_batch(pioran_ds* ds, int64_t B, int64_t J, const double
         HIPCHK(ctx, hipMemcpyAsync(status, ctx->bst.p, B * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PIORAN_OK;
+}
+
+int pioran_celerite_logl_batch(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc,
+                               const double* C, const double* Dd, int cd_shared, const double* mu, const double* nu,
+                               const double* Y, const double* S2, double* out, int32_t* status)
+{
+    return batch_host_impl(ds, B, J, A, Bc, C, Dd, cd_shared, mu, nu, Y, S2, false, out, status);
+}
+
+int pioran_celerite_logl_batch_shift_dev(pioran_ds* ds, int64_t B, const double* dA, const double* dBc, const double* dmu,
+                                         const double* dnu, const double* dshift, double* dout, int32_t* dstatus)
+{
+    if (!ds || B < 1 || !dA || !dBc || !dshift || !dout) return PIORAN_ERR_ARG;
+    if (!ds->prepared) return PIORAN_ERR_ARG;
+    pioran_ctx* ctx = ds->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t bn = (size_t)B * (size_t)ds->N * sizeof(double);
+    int rc;
+    if ((rc = ensure(ctx, ctx->bY, bn))) return rc;
+    if ((rc = ensure(ctx, ctx->bS2, bn))) return rc;
+    rc = pioran_launch_shift_transform(ds->N, B, ds->y, ds->s2, dshift, (double*)ctx->bY.p, (double*)ctx->bS2.p, ctx->stream);
+    if (rc) return rc;
+    return pioran_celerite_logl_batch_dev(ds, B, dA, dBc, dmu, dnu, (const double*)ctx->bY.p, (const double*)ctx->bS2.p,
+                                          dout, dstatus);
+}
+
+int pioran_celerite_logl_batch_shift(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc,
+                                     const double* C, const double* Dd, int cd_shared, const double* mu, const double* nu,
+                                     const double* shift, double* out, int32_t* status)
+{
+    if (!ds || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !shift || !out) return PIORAN_ERR_ARG;
+    pioran_ctx* ctx = ds->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t bn = (size_t)B * (size_t)ds->N * sizeof(double);
+    if ((rc = ensure(ctx, ctx->bY, bn))) return rc;
+    if ((rc = ensure(ctx, ctx->bS2, bn))) return rc;
+    if ((rc = upload(ctx, ctx->bwork, shift, B * sizeof(double)))) return rc;
+    rc = pioran_launch_shift_transform(ds->N, B, ds->y, ds->s2, (const double*)ctx->bwork.p, (double*)ctx->bY.p,
+                                       (double*)ctx->bS2.p, ctx->stream);
+    if (rc) return rc;
+    return batch_host_impl(ds, B, J, A, Bc, C, Dd, cd_shared, mu, nu, nullptr, nullptr, /*series_on_device=*/true, out,
+                           status);
 }
 
 int pioran_celerite_logl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,

@@ -47,6 +47,8 @@ size_t pioran_fallback_scratch_doubles(int R);
 size_t pioran_table_doubles(int64_t N, int32_t R);
 int pioran_launch_table(int64_t N, int32_t R, const int32_t* rowmap, const double* t, const double* c,
                         const double* d, const double* y, const double* s2, double* tab, hipStream_t stream);
+int pioran_launch_shift_transform(int64_t N, int64_t B, const double* y, const double* s2, const double* shift,
+                                  double* Y, double* S2, hipStream_t stream);
 // dense.hip
 void pioran_dense_dims(int64_t N, int64_t* Mp, int64_t* ld);
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,

@@ -45,7 +45,32 @@ __global__ void __launch_bounds__(256) table_kernel(int64_t N, int32_t R, const 
         rec[3 * Rp + 1] = s2[n];
     }
 }
+// Per-draw series of the shifted log-flux models: Y[b][n] = log(y_n - shift_b), S2[b][n] = sigma2_n / (y_n - shift_b)^2
+// (docs/src/ultranest.md:199-205).  Pure streaming kernel: 16 B written per (draw, step), coalesced along n.
+__global__ void __launch_bounds__(256) shift_transform_kernel(int64_t N, int64_t B, const double* __restrict__ y,
+                                                              const double* __restrict__ s2, const double* __restrict__ shift,
+                                                              double* __restrict__ Y, double* __restrict__ S2)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = blockIdx.y;
+    if (n >= N || b >= B) return;
+    const double v = y[n] - shift[b];
+    Y[b * N + n] = log(v);
+    S2[b * N + n] = s2[n] / (v * v);
+}
 }  // namespace
+
+int pioran_launch_shift_transform(int64_t N, int64_t B, const double* y, const double* s2, const double* shift,
+                                  double* Y, double* S2, hipStream_t stream)
+{
+    if (B > 65535 * 1024LL) return PIORAN_ERR_ARG;
+    for (int64_t b0 = 0; b0 < B; b0 += 65535) {   // gridDim.y limit
+        const int64_t nb = B - b0 < 65535 ? B - b0 : 65535;
+        hipLaunchKernelGGL(shift_transform_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)nb), dim3(256), 0, stream, N,
+                           nb, y, s2, shift + b0, Y + b0 * N, S2 + b0 * N);
+    }
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
 
 size_t pioran_table_doubles(int64_t N, int32_t R) { return (size_t)(N + 1) * (size_t)(3 * (R + 2) + 2); }
 

@@ -135,8 +135,10 @@ class Dataset:
         _lib.check(_lib.lib().pioran_dataset_prepare(self._h, len(c), _ptr(c), _ptr(d), _ptr(rt)), self.ctx._h)
         self.J = len(c)
 
-    def logl_batch(self, A, Bc, C, Dd, mu=None, nu=None, Y=None, S2=None, return_status=False):
-        """B log-likelihoods, host arrays.  A, Bc: (B, J); C, Dd: (J,) shared or (B, J) per draw."""
+    def logl_batch(self, A, Bc, C, Dd, mu=None, nu=None, Y=None, S2=None, shift=None, return_status=False):
+        """B log-likelihoods, host arrays.  A, Bc: (B, J); C, Dd: (J,) shared or (B, J) per draw.
+        shift (B,): the data set holds raw flux and yerr**2; draw b is evaluated on log(y - shift_b) with
+        variances sigma2 / (y - shift_b)**2, transformed on the device (docs/src/ultranest.md:199-205)."""
         A, Bc, C, Dd = map(_f64, (A, Bc, C, Dd))
         if A.ndim != 2 or A.shape != Bc.shape:
             raise ValueError("A and Bc must be (B, J) arrays of equal shape")
@@ -148,6 +150,16 @@ class Dataset:
         nu = None if nu is None else _f64(np.broadcast_to(nu, (B,)))
         if (Y is None) != (S2 is None):
             raise ValueError("Y and S2 must be given together")
+        if shift is not None:
+            if Y is not None:
+                raise ValueError("give either shift or (Y, S2)")
+            shift = _f64(np.broadcast_to(shift, (B,)))
+            out = np.empty(B)
+            st = np.zeros(B, dtype=np.int32)
+            _lib.check(_lib.lib().pioran_celerite_logl_batch_shift(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd),
+                                                                   int(cd_shared), _ptr(mu), _ptr(nu), _ptr(shift),
+                                                                   _ptr(out), _ptr(st)), self.ctx._h)
+            return (out, st) if return_status else out
         if Y is not None:
             Y, S2 = _f64(Y), _f64(S2)
             if Y.shape != (B, self.N) or S2.shape != (B, self.N):
@@ -165,6 +177,14 @@ class Dataset:
         _lib.check(_lib.lib().pioran_celerite_logl_batch_dev(self._h, int(B), v(dA), v(dBc), v(dmu or None),
                                                              v(dnu or None), v(dY or None), v(dS2 or None), v(dout),
                                                              v(dstatus or None)), self.ctx._h)
+
+
+    def logl_batch_shift_dev(self, B, dA, dBc, dmu=0, dnu=0, dshift=0, dout=0, dstatus=0):
+        """Device-pointer asynchronous variant of the shifted-log-flux batch; (c, d) from prepare()."""
+        v = ctypes.c_void_p
+        _lib.check(_lib.lib().pioran_celerite_logl_batch_shift_dev(self._h, int(B), v(dA), v(dBc), v(dmu or None),
+                                                                   v(dnu or None), v(dshift), v(dout),
+                                                                   v(dstatus or None)), self.ctx._h)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -251,6 +271,6 @@ def log_likelihood_direct(cov: SemiSeparable, t, y, sigma2, ctx: Context | None 
     return val
 
 
-def logpdf_batch(ds: Dataset, A, Bc, C, Dd, mu=None, nu=None, Y=None, S2=None, return_status=False):
+def logpdf_batch(ds: Dataset, A, Bc, C, Dd, mu=None, nu=None, Y=None, S2=None, shift=None, return_status=False):
     """B independent logpdf evaluations on one data set (nested-sampling live points / MCMC walkers)."""
-    return ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2, return_status=return_status)
+    return ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2, shift=shift, return_status=return_status)

@@ -104,6 +104,28 @@ function logpdf_batch(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::Ve
     return out, status
 end
 
+"""
+    logpdf_batch_shift(ds, A, B, c, d, shift; μ, ν)
+
+The shifted log-flux models (docs/src/ultranest.md:199-205): `ds` holds the raw flux `y` and `yerr.^2`; draw `b` is
+evaluated on `log.(y .- shift[b])` with variances `ν[b] .* yerr.^2 ./ (y .- shift[b]).^2`, transformed on the GPU.
+"""
+function logpdf_batch_shift(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::VecOrMat{Float64}, d::VecOrMat{Float64},
+                            shift::Vector{Float64}; μ::Union{Nothing, Vector{Float64}} = nothing,
+                            ν::Union{Nothing, Vector{Float64}} = nothing)
+    J, nb = size(A)
+    out = Vector{Float64}(undef, nb)
+    status = zeros(Int32, nb)
+    p(x) = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
+    GC.@preserve A B c d μ ν shift out status begin
+        check(ccall((:pioran_celerite_logl_batch_shift, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint,
+                     Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}),
+                    ds.h, nb, J, A, B, c, d, c isa Vector ? 1 : 0, p(μ), p(ν), shift, out, status))
+    end
+    return out, status
+end
+
 # ---- dense solver: log_likelihood_direct (src/direct_solver.jl:6-21), returns +NLL -------------------------
 function log_likelihood_direct_hip(cov::SemiSeparable, t::Vector{Float64}, y::Vector{Float64}, σ²::Vector{Float64};
                                    ctx = default_context())

@@ -43,6 +43,25 @@ def test_reference_outputs_ultranest(ctx, golden_dir):
     assert relerr(got, ref) < 1e-10
 
 
+def test_reference_outputs_ultranest_device_transform(ctx, golden_dir):
+    """Same 5791 reference values, but the data set holds the RAW flux and yerr**2 and the per-draw transform
+    log(y - c_b), yerr**2 / (y - c_b)**2 runs on the device (pioran_celerite_logl_batch_shift): the reference's
+    production model end to end (docs/src/ultranest.md:197-219), only theta-derived arrays cross the boundary."""
+    un = np.load(golden_dir / "ultranest_points.npz")
+    t, y, yerr, P, ref = un["t"], un["y"], un["yerr"], un["params"], un["logl"]
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, P[:, :3], f_min, f_max, 20, P[:, 3],
+                                   is_integrated_power=False)
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    got, st = ds.logl_batch(A, Bc, C, Dd, mu=P[:, 5], nu=P[:, 4], shift=P[:, 6], return_status=True)
+    assert (st == 0).all()
+    assert relerr(got, ref) < 1e-10
+    # a shift above min(y) makes log(y - c) undefined: status 2 / NaN where the reference throws DomainError
+    bad, st = ds.logl_batch(A[:2], Bc[:2], C, Dd, mu=P[:2, 5], nu=P[:2, 4], shift=[y.min() + 1.0, P[1, 6]],
+                            return_status=True)
+    assert st[0] == 2 and np.isnan(bad[0]) and st[1] == 0 and abs(bad[1] - ref[1]) <= 1e-10 * abs(ref[1])
+
+
 def test_reference_literal_cases(ctx, golden_dir):
     lit = json.loads((golden_dir / "reference_literals.json").read_text())
     rel = {c["name"]: c for c in json.loads((golden_dir / "relation_cases.json").read_text())["cases"]}
