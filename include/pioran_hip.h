@@ -119,6 +119,18 @@ int pioran_celerite_logl_batch_shift(pioran_ds* ds, int64_t B, int64_t J, const 
 int pioran_celerite_logl_batch_shift_dev(pioran_ds* ds, int64_t B, const double* dA, const double* dBc,
                                          const double* dmu, const double* dnu, const double* dshift,
                                          double* dout, int32_t* dstatus);
+/* theta -> log L in one call: `approx` (src/psd.jl:214-289) runs on the device in front of the scan, so only the
+ * sampled parameters cross the boundary.  Continuum-only PSD models:
+ *   model 0  SingleBendingPowerLaw(alpha1, f1, alpha2)                  P = 3 parameters per draw
+ *   model 1  DoubleBendingPowerLaw(alpha1, f1, alpha2, f2, alpha3)      P = 5
+ * basis 0 "SHO" (J = n_components terms), 1 "DRWCelerite" (J = 2 n_components terms);
+ * theta [B][P], norm [B] (the `norm` argument of approx), is_integrated_power / S_low / S_high as in approx;
+ * mu, nu, shift: [B] or NULL, as in pioran_celerite_logl_batch[_shift].  Host pointers, blocking.
+ * Also returns, when A_out / Bc_out are non-NULL ([B][J] host), the coefficients approx produced. */
+int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_components, int basis,
+                              int is_integrated_power, double f_min, double f_max, double S_low, double S_high,
+                              const double* theta, const double* norm, const double* mu, const double* nu,
+                              const double* shift, double* out, int32_t* status, double* A_out, double* Bc_out);
 /* Name of the kernel configuration a batch with R active rows runs on (diagnostics). */
 const char* pioran_celerite_config_name(int64_t R);
 

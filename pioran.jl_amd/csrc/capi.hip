@@ -21,7 +21,7 @@ struct pioran_ctx {
         void* p = nullptr;
         size_t cap = 0;
     };
-    Buf bA, bB, bC, bD, bmu, bnu, bY, bS2, bout, bst, bscratch, bK, bwork;
+    Buf bA, bB, bC, bD, bmu, bnu, bY, bS2, bout, bst, bscratch, bK, bwork, bshift;
     // scalar entry point: the last series' time stamps stay resident (samplers call logl with the same t)
     pioran_ds* scalar_ds = nullptr;
     std::vector<double> scalar_t;
@@ -184,7 +184,7 @@ int pioran_ctx_destroy(pioran_ctx* ctx)
     if (ctx->scalar_ds) pioran_dataset_destroy(ctx->scalar_ds);
     ctx->scalar_ds = nullptr;
     pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
-                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork};
+                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift};
     for (auto* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : ctx->ev)
@@ -435,12 +435,69 @@ int pioran_celerite_logl_batch_shift(pioran_ds* ds, int64_t B, int64_t J, const 
     const size_t bn = (size_t)B * (size_t)ds->N * sizeof(double);
     if ((rc = ensure(ctx, ctx->bY, bn))) return rc;
     if ((rc = ensure(ctx, ctx->bS2, bn))) return rc;
-    if ((rc = upload(ctx, ctx->bwork, shift, B * sizeof(double)))) return rc;
-    rc = pioran_launch_shift_transform(ds->N, B, ds->y, ds->s2, (const double*)ctx->bwork.p, (double*)ctx->bY.p,
+    if ((rc = upload(ctx, ctx->bshift, shift, B * sizeof(double)))) return rc;
+    rc = pioran_launch_shift_transform(ds->N, B, ds->y, ds->s2, (const double*)ctx->bshift.p, (double*)ctx->bY.p,
                                        (double*)ctx->bS2.p, ctx->stream);
     if (rc) return rc;
     return batch_host_impl(ds, B, J, A, Bc, C, Dd, cd_shared, mu, nu, nullptr, nullptr, /*series_on_device=*/true, out,
                            status);
+}
+
+int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_components, int basis, int is_integrated_power,
+                              double f_min, double f_max, double S_low, double S_high, const double* theta,
+                              const double* norm, const double* mu, const double* nu, const double* shift, double* out,
+                              int32_t* status, double* A_out, double* Bc_out)
+{
+    if (!ds || B < 1 || !theta || !norm || !out || model < 0 || model > 1 || basis < 0 || basis > 1) return PIORAN_ERR_ARG;
+    pioran_ctx* ctx = ds->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int P = model == 0 ? 3 : 5;
+    const int64_t J = n_components, Jt = basis == 0 ? J : 2 * J;
+    std::vector<double> sp, LU, c, d;
+    std::vector<int32_t> piv, real;
+    int rc = pioran_approx_setup_host(J, basis, f_min, f_max, S_low, S_high, sp, LU, piv, c, d, real);
+    if (rc) return rc;
+    if ((rc = pioran_dataset_prepare(ds, Jt, c.data(), d.data(), real.data()))) return rc;
+    // staging: [sp J | LU J*J | piv (as int32, J)] in bwork; theta in bC, norm in bD (free when (c,d) are shared)
+    const size_t nd = (size_t)J + (size_t)J * J + (size_t)J;
+    if ((rc = ensure(ctx, ctx->bwork, nd * sizeof(double)))) return rc;
+    double* dsp = (double*)ctx->bwork.p;
+    double* dLU = dsp + J;
+    int32_t* dpiv = (int32_t*)(dLU + J * J);
+    HIPCHK(ctx, hipMemcpyAsync(dsp, sp.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dLU, LU.data(), J * J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dpiv, piv.data(), J * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = upload(ctx, ctx->bC, theta, (size_t)B * P * sizeof(double)))) return rc;
+    if ((rc = upload(ctx, ctx->bD, norm, (size_t)B * sizeof(double)))) return rc;
+    const size_t bj = (size_t)B * (size_t)Jt * sizeof(double);
+    if ((rc = ensure(ctx, ctx->bA, bj))) return rc;
+    if ((rc = ensure(ctx, ctx->bB, bj))) return rc;
+    rc = pioran_launch_approx(B, model, P, (int)J, basis, is_integrated_power, f_min, f_max, dsp, dLU, dpiv,
+                              (const double*)ctx->bC.p, (const double*)ctx->bD.p, (double*)ctx->bA.p, (double*)ctx->bB.p,
+                              ctx->stream);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // sp/LU/piv host vectors go out of scope below
+    if (mu && (rc = upload(ctx, ctx->bmu, mu, B * sizeof(double)))) return rc;
+    if (nu && (rc = upload(ctx, ctx->bnu, nu, B * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->bout, B * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->bst, B * sizeof(int32_t)))) return rc;
+    const double* dmu = mu ? (const double*)ctx->bmu.p : nullptr;
+    const double* dnu = nu ? (const double*)ctx->bnu.p : nullptr;
+    if (shift) {
+        if ((rc = upload(ctx, ctx->bshift, shift, B * sizeof(double)))) return rc;
+        rc = pioran_celerite_logl_batch_shift_dev(ds, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu,
+                                                  (const double*)ctx->bshift.p, (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
+    } else {
+        rc = pioran_celerite_logl_batch_dev(ds, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu, nullptr,
+                                            nullptr, (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
+    }
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->bout.p, B * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (status) HIPCHK(ctx, hipMemcpyAsync(status, ctx->bst.p, B * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (A_out) HIPCHK(ctx, hipMemcpyAsync(A_out, ctx->bA.p, bj, hipMemcpyDeviceToHost, ctx->stream));
+    if (Bc_out) HIPCHK(ctx, hipMemcpyAsync(Bc_out, ctx->bB.p, bj, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PIORAN_OK;
 }
 
 int pioran_celerite_logl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,

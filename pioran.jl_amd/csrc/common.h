@@ -49,6 +49,16 @@ int pioran_launch_table(int64_t N, int32_t R, const int32_t* rowmap, const doubl
                         const double* d, const double* y, const double* s2, double* tab, hipStream_t stream);
 int pioran_launch_shift_transform(int64_t N, int64_t B, const double* y, const double* s2, const double* shift,
                                   double* Y, double* S2, hipStream_t stream);
+// approx.hip
+#ifdef __cplusplus
+#include <vector>
+int pioran_approx_setup_host(int64_t J, int basis, double f_min, double f_max, double S_low, double S_high,
+                             std::vector<double>& sp, std::vector<double>& LU, std::vector<int32_t>& piv,
+                             std::vector<double>& c, std::vector<double>& d, std::vector<int32_t>& real_term);
+#endif
+int pioran_launch_approx(int64_t B, int model, int P, int J, int basis, int integrated, double f_min, double f_max,
+                         const double* sp, const double* LU, const int32_t* piv, const double* theta, const double* norm,
+                         double* A, double* Bc, hipStream_t stream);
 // dense.hip
 void pioran_dense_dims(int64_t N, int64_t* Mp, int64_t* ld);
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,

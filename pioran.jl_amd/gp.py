@@ -179,6 +179,41 @@ class Dataset:
                                                              v(dstatus or None)), self.ctx._h)
 
 
+    def logpdf_theta(self, model, theta, norm, f_min, f_max, n_components=20, S_low=20.0, S_high=20.0, *,
+                     is_integrated_power=True, basis_function="SHO", mu=None, nu=None, shift=None,
+                     return_status=False, return_coefs=False):
+        """theta -> log L in one call, `approx` running on the device (pioran_logpdf_batch_theta).
+        model: SingleBendingPowerLaw / DoubleBendingPowerLaw (the class); theta: (B, 3 | 5); norm: scalar or (B,)
+        — same meaning as the arguments of approx (src/psd.jl:214-289); mu, nu, shift as in logl_batch."""
+        from .psd import DoubleBendingPowerLaw, SingleBendingPowerLaw
+        mid = {SingleBendingPowerLaw: 0, DoubleBendingPowerLaw: 1}.get(model)
+        if mid is None:
+            raise ValueError("model must be SingleBendingPowerLaw or DoubleBendingPowerLaw")
+        if basis_function not in ("SHO", "DRWCelerite"):
+            raise ValueError("Basis function" + basis_function + "not implemented")
+        theta = _f64(np.atleast_2d(theta))
+        B, P = theta.shape
+        if P != (3 if mid == 0 else 5):
+            raise ValueError("theta has the wrong number of columns for this model")
+        norm = _f64(np.broadcast_to(norm, (B,)))
+        mu = None if mu is None else _f64(np.broadcast_to(mu, (B,)))
+        nu = None if nu is None else _f64(np.broadcast_to(nu, (B,)))
+        shift = None if shift is None else _f64(np.broadcast_to(shift, (B,)))
+        basis = 0 if basis_function == "SHO" else 1
+        Jt = n_components * (1 if basis == 0 else 2)
+        out = np.empty(B)
+        st = np.zeros(B, dtype=np.int32)
+        Ao = np.empty((B, Jt)) if return_coefs else None
+        Bo = np.empty((B, Jt)) if return_coefs else None
+        _lib.check(_lib.lib().pioran_logpdf_batch_theta(self._h, B, mid, int(n_components), basis, int(bool(is_integrated_power)),
+                                                        float(f_min), float(f_max), float(S_low), float(S_high), _ptr(theta),
+                                                        _ptr(norm), _ptr(mu), _ptr(nu), _ptr(shift), _ptr(out), _ptr(st),
+                                                        _ptr(Ao), _ptr(Bo)), self.ctx._h)
+        res = (out, st) if return_status else (out,)
+        if return_coefs:
+            res = res + (Ao, Bo)
+        return res if len(res) > 1 else res[0]
+
     def logl_batch_shift_dev(self, B, dA, dBc, dmu=0, dnu=0, dshift=0, dout=0, dstatus=0):
         """Device-pointer asynchronous variant of the shifted-log-flux batch; (c, d) from prepare()."""
         v = ctypes.c_void_p

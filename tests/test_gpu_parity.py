@@ -433,3 +433,49 @@ def test_custom_mean_logpdf(ctx):
     val = pj.logpdf(fx, y, ctx=ctx)
     assert np.isfinite(val)
     assert abs(val - O.logl(R.a, R.b, R.c, R.d, t, y - mfun(t), np.zeros(100))) <= 1e-9 * abs(val)
+
+
+# ---------------------------------------------------------------------------------------------
+# approx on the device: theta -> log L in one call
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("basis", ["SHO", "DRWCelerite"])
+@pytest.mark.parametrize("integ", [True, False])
+def test_device_approx_matches_host_approx(ctx, basis, integ):
+    """Coefficients produced by the device approx kernel vs the host approx_batch (itself pinned to the reference's
+    amplitude golden, test/test_psd.jl:38) — same 1e-9 bar as the host tests (cond of the spectral matrix ~1e3-1e4)."""
+    rng = np.random.default_rng(55)
+    B = 200
+    t = np.cumsum(rng.uniform(0.05, 2.0, 120)); y = rng.standard_normal(120); s2 = rng.uniform(0.01, 0.1, 120)
+    th = np.column_stack([rng.uniform(-0.25, 2, B), np.exp(rng.uniform(np.log(1e-3), np.log(5), B)), rng.uniform(1.5, 4, B)])
+    var = np.exp(rng.standard_normal(B))
+    ds = pj.Dataset(t, y, s2, ctx)
+    out, st, A, Bc = ds.logpdf_theta(pj.SingleBendingPowerLaw, th, var, 1e-3, 5.0, 20, is_integrated_power=integ,
+                                     basis_function=basis, return_status=True, return_coefs=True)
+    Ah, Bh, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, th, 1e-3, 5.0, 20, var, is_integrated_power=integ,
+                                    basis_function=basis)
+    scale = np.abs(Ah).max(axis=1, keepdims=True)
+    assert np.max(np.abs(A - Ah) / scale) < 1e-9 and np.max(np.abs(Bc - Bh) / scale) < 1e-9
+    ref = ds.logl_batch(Ah, Bh, C, Dd)
+    ok = st == 0
+    assert ok.mean() > 0.8
+    assert relerr(out[ok], ref[ok]) < 1e-8        # log L through either coefficient source
+    # double-bending model
+    th5 = np.column_stack([th[:, 0], th[:, 1], th[:, 2] * 0.6 + 0.4, th[:, 1] * 30, th[:, 2] + 0.5])
+    out5, A5, B5 = ds.logpdf_theta(pj.DoubleBendingPowerLaw, th5, var, 1e-3, 5.0, 20, is_integrated_power=integ,
+                                   basis_function=basis, return_coefs=True)
+    A5h, _, _, _ = pj.approx_batch(pj.DoubleBendingPowerLaw, th5, 1e-3, 5.0, 20, var, is_integrated_power=integ,
+                                   basis_function=basis)
+    assert np.max(np.abs(A5 - A5h) / np.abs(A5h).max(axis=1, keepdims=True)) < 1e-9
+
+
+def test_reference_outputs_ultranest_theta_only(ctx, golden_dir):
+    """The reference's stored run once more, now with NOTHING but the sampled parameters crossing the boundary:
+    approx, the shift transform and the scan all on the device; 5791 reference log-likelihoods, bar 1e-10."""
+    un = np.load(golden_dir / "ultranest_points.npz")
+    t, y, yerr, P, ref = un["t"], un["y"], un["yerr"], un["params"], un["logl"]
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    got, st = ds.logpdf_theta(pj.SingleBendingPowerLaw, P[:, :3], P[:, 3], f_min, f_max, 20, is_integrated_power=False,
+                              mu=P[:, 5], nu=P[:, 4], shift=P[:, 6], return_status=True)
+    assert (st == 0).all()
+    assert relerr(got, ref) < 1e-10
