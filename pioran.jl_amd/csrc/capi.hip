@@ -314,6 +314,7 @@ int pioran_celerite_logl_batch_dev(pioran_ds* ds, int64_t B, const double* dA, c
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ScanParams p{};
     p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = B;
+    p.standard_rows = ds->R == 2 * ds->J;
     p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
     p.Y = dY; p.S2 = dS2; p.A = dA; p.Bc = dBc; p.C = ds->dc; p.D = ds->dd;
     p.mu = dmu; p.nu = dnu; p.out = dout; p.status = dstatus;
@@ -338,6 +339,7 @@ int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ScanParams p{};
     p.N = ds->N; p.J = (int32_t)J; p.R = (int32_t)rm.size(); p.B = B;
+    p.standard_rows = 1;
     p.tab = nullptr; p.rowmap = drm; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
     p.Y = dY; p.S2 = dS2; p.A = dA; p.Bc = dBc; p.C = dC; p.D = dDd;
     p.mu = dmu; p.nu = dnu; p.out = dout; p.status = dstatus;

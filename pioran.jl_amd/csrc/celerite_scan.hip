@@ -167,6 +167,162 @@ struct ColBlock<5, N> {
                        [phs] "v"(phs), [n] "i"(N));
     }
 };
+// Column PAIRS: the cos and the sin row of one celerite term have the same phi, so two consecutive columns share
+// phi_k and the products phi_i * phi_k.  PairFirst = ColBlock that also returns pp[]; PairSecond reuses them
+// (no v_mov_b64_dpp, no pp multiplies).
+template <int RPL, int N>
+struct PairFirst;
+template <int RPL, int N>
+struct PairSecond;
+
+template <int N>
+struct PairFirst<3, N> {
+    static __device__ __forceinline__ void run(double (&S)[3], double (&q)[3], const double (&g)[3],
+                                               const double (&ph)[3], double ws, double us, double phs, double (&pp)[3])
+    {
+        double pk;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2)
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk)
+                     PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2)
+                     PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1) PD_FMAC(q2, us, s2)
+                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [q0] "+v"(q[0]), [q1] "+v"(q[1]),
+                       [q2] "+v"(q[2]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2])
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [h0] "v"(ph[0]), [h1] "v"(ph[1]),
+                       [h2] "v"(ph[2]), [ws] "v"(ws), [us] "v"(us), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct PairSecond<3, N> {
+    static __device__ __forceinline__ void run(double (&S)[3], double (&q)[3], const double (&g)[3], double ws, double us,
+                                               const double (&pp)[3])
+    {
+        asm volatile("s_nop 1\n\t"
+                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2)
+                     PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2)
+                     PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1) PD_FMAC(q2, us, s2)
+                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2])
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]),
+                       [ws] "v"(ws), [us] "v"(us), [n] "i"(N));
+    }
+};
+template <int N>
+struct PairFirst<1, N> {
+    static __device__ __forceinline__ void run(double (&S)[1], double (&q)[1], const double (&g)[1],
+                                               const double (&ph)[1], double ws, double us, double phs, double (&pp)[1])
+    {
+        double pk;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_FMAC(s0, ws, g0)
+                     PD_MUL(p0, h0, pk)
+                     PD_MUL(s0, p0, s0)
+                     PD_FMAC(q0, us, s0)
+                     : [s0] "+v"(S[0]), [q0] "+v"(q[0]), [pk] "=&v"(pk), [p0] "=&v"(pp[0])
+                     : [g0] "v"(g[0]), [h0] "v"(ph[0]), [ws] "v"(ws), [us] "v"(us), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct PairSecond<1, N> {
+    static __device__ __forceinline__ void run(double (&S)[1], double (&q)[1], const double (&g)[1], double ws, double us,
+                                               const double (&pp)[1])
+    {
+        asm volatile("s_nop 1\n\t"
+                     PD_FMAC(s0, ws, g0)
+                     PD_MUL(s0, p0, s0)
+                     PD_FMAC(q0, us, s0)
+                     : [s0] "+v"(S[0]), [q0] "+v"(q[0])
+                     : [g0] "v"(g[0]), [p0] "v"(pp[0]), [ws] "v"(ws), [us] "v"(us), [n] "i"(N));
+    }
+};
+template <int N>
+struct PairFirst<2, N> {
+    static __device__ __forceinline__ void run(double (&S)[2], double (&q)[2], const double (&g)[2],
+                                               const double (&ph)[2], double ws, double us, double phs, double (&pp)[2])
+    {
+        double pk;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1)
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk)
+                     PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1)
+                     PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1)
+                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1])
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [ws] "v"(ws), [us] "v"(us), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct PairSecond<2, N> {
+    static __device__ __forceinline__ void run(double (&S)[2], double (&q)[2], const double (&g)[2], double ws, double us,
+                                               const double (&pp)[2])
+    {
+        asm volatile("s_nop 1\n\t"
+                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1)
+                     PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1)
+                     PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1)
+                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [q0] "+v"(q[0]), [q1] "+v"(q[1])
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [ws] "v"(ws), [us] "v"(us), [n] "i"(N));
+    }
+};
+template <int N>
+struct PairFirst<4, N> {
+    static __device__ __forceinline__ void run(double (&S)[4], double (&q)[4], const double (&g)[4],
+                                               const double (&ph)[4], double ws, double us, double phs, double (&pp)[4])
+    {
+        double pk;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3)
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk)
+                     PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2) PD_MUL(s3, p3, s3)
+                     PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1) PD_FMAC(q2, us, s2) PD_FMAC(q3, us, s3)
+                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2]), [p3] "=&v"(pp[3])
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [h3] "v"(ph[3]), [ws] "v"(ws), [us] "v"(us), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct PairSecond<4, N> {
+    static __device__ __forceinline__ void run(double (&S)[4], double (&q)[4], const double (&g)[4], double ws, double us,
+                                               const double (&pp)[4])
+    {
+        asm volatile("s_nop 1\n\t"
+                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3)
+                     PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2) PD_MUL(s3, p3, s3)
+                     PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1) PD_FMAC(q2, us, s2) PD_FMAC(q3, us, s3)
+                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3])
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]), [p3] "v"(pp[3]), [ws] "v"(ws), [us] "v"(us), [n] "i"(N));
+    }
+};
+template <int N>
+struct PairFirst<5, N> {
+    static __device__ __forceinline__ void run(double (&S)[5], double (&q)[5], const double (&g)[5],
+                                               const double (&ph)[5], double ws, double us, double phs, double (&pp)[5])
+    {
+        double pk;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3) PD_FMAC(s4, ws, g4)
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk) PD_MUL(p4, h4, pk)
+                     PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2) PD_MUL(s3, p3, s3) PD_MUL(s4, p4, s4)
+                     PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1) PD_FMAC(q2, us, s2) PD_FMAC(q3, us, s3) PD_FMAC(q4, us, s4)
+                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [q4] "+v"(q[4]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2]), [p3] "=&v"(pp[3]), [p4] "=&v"(pp[4])
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [h3] "v"(ph[3]), [h4] "v"(ph[4]), [ws] "v"(ws), [us] "v"(us), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct PairSecond<5, N> {
+    static __device__ __forceinline__ void run(double (&S)[5], double (&q)[5], const double (&g)[5], double ws, double us,
+                                               const double (&pp)[5])
+    {
+        asm volatile("s_nop 1\n\t"
+                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3) PD_FMAC(s4, ws, g4)
+                     PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2) PD_MUL(s3, p3, s3) PD_MUL(s4, p4, s4)
+                     PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1) PD_FMAC(q2, us, s2) PD_FMAC(q3, us, s3) PD_FMAC(q4, us, s4)
+                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [q4] "+v"(q[4])
+                     : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]), [p3] "v"(pp[3]), [p4] "v"(pp[4]), [ws] "v"(ws), [us] "v"(us), [n] "i"(N));
+    }
+};
 #undef PD_FMAC
 #undef PD_MUL
 
@@ -202,7 +358,7 @@ struct StepIn {           // what one time step reads: per own row (v, x, phi) +
     double v[RPL], x[RPL], ph[RPL], y, s2;
 };
 
-template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false, int MINW = 1>
+template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false, int MINW = 1, bool PAIRED = false>
 __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanParams p)
 {
     static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
@@ -227,13 +383,26 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     const int J = p.J, R = p.R, Rp = R + 2;  // table rows R (inert pad) and R+1 (y row)
     const int64_t N = p.N;
 
+    // slot -> row.  Unpaired: slot index = row index, the slots after the last real row are padding and the very
+    // last slot is the y row.  PAIRED (every term has both rows; R = 2J): the columns of each DPP row's block are
+    // processed two at a time, so real rows must sit pair-aligned inside a block: with RB = NSRC*RPL slots per
+    // block, an odd RB leaves one "single" slot at the end of each block (padding, or the y row in the last block).
+    constexpr int RB = NSRC * RPL;
+    constexpr int RBR = PAIRED ? (RB & ~1) : RB;   // real-row slots per block
     int trow[RPL];                           // row of the shared table this slot reads
     double al[RPL], be[RPL];                 // u = al * v + be * x
     [[maybe_unused]] double cc[RPL], dd[RPL];
     [[maybe_unused]] bool ksin[RPL];
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
-        const int j = lam * RPL + i;
+        const int slot = lam * RPL + i;
+        int j;   // real row index, or >= R for a special slot
+        if constexpr (PAIRED) {
+            const int blk = slot / RB, c = slot - blk * RB;
+            j = c < RBR ? blk * RBR + c : R;   // the single slot of an odd block is never a real row
+        } else {
+            j = slot;
+        }
         if (j < R) {
             const int rm = p.rowmap[j];
             const int term = rm & 0x3fffffff;
@@ -249,7 +418,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 dd[i] = p.D[b * J + term];
             }
         } else {
-            // inert padding row (u = 0, v = 1, phi = 0), or the y row (u = 0, v = y_n - mu, phi = 1)
+            // inert padding row (u = 0, v = 1, phi = 1), or the y row (u = 0, v = y_n - mu, phi = 1)
             trow[i] = (isy && i == YS) ? R + 1 : R;
             al[i] = 0.0;
             be[i] = 0.0;
@@ -314,7 +483,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 } else {
                     in.v[i] = trow[i] == R ? 1.0 : 0.0;
                     in.x[i] = 0.0;
-                    in.ph[i] = trow[i] == R ? 0.0 : 1.0;
+                    in.ph[i] = 1.0;
                 }
             }
             in.y = yv[nn];
@@ -360,6 +529,18 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         if (isy) in.v[YS] = in.y - mu;
 
         // ---- S update + q = S u over this DPP row's column block ----
+        if constexpr (PAIRED && ASM_DPP) {
+            // column pairs (c, c+1), c even: same phi_k, so phi_i * phi_k is formed once per pair
+            static_for<0, NC / 2>([&](auto Pc) {
+                constexpr int c = 2 * decltype(Pc)::value;
+                double pp[RPL];
+                PairFirst<RPL, c / RPL>::run(S[c], qt, g, in.ph, w[c % RPL], u[c % RPL], in.ph[c % RPL], pp);
+                PairSecond<RPL, (c + 1) / RPL>::run(S[c + 1], qt, g, w[(c + 1) % RPL], u[(c + 1) % RPL], pp);
+            });
+            if constexpr (NC & 1)   // the single slot at the end of an odd block: padding or the y row
+                ColBlock<RPL, (NC - 1) / RPL>::run(S[NC - 1], qt, g, in.ph, w[(NC - 1) % RPL], u[(NC - 1) % RPL],
+                                                   in.ph[(NC - 1) % RPL]);
+        } else {
         static_for<0, NSRC>([&](auto Nc) {
             constexpr int NN = decltype(Nc)::value;
             static_for<0, RPL>([&](auto Mc) {
@@ -381,6 +562,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 }
             });
         });
+        }
         if constexpr (CBR >= 2) {
 #pragma unroll
             for (int i = 0; i < RPL; ++i) qt[i] += __shfl(qt[i], p1);
@@ -426,20 +608,27 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 
 using LaunchFn = void (*)(const ScanParams&, dim3, hipStream_t);
 
-template <int RPL, int CBR, int NSRC, bool ASM_DPP = false, int MINW = 1>
+template <int RPL, int CBR, int NSRC, bool ASM_DPP = false, int MINW = 1, bool PAIRED = false>
 void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 {
     if (p.tab)
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, ASM_DPP, MINW>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, ASM_DPP, MINW, PAIRED>), grid, dim3(256), 0, st, p);
     else
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false, ASM_DPP, MINW>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false, ASM_DPP, MINW, PAIRED>), grid, dim3(256), 0, st, p);
 }
 
 struct ScanConfig {
     const char* name;
     int rpl, cbr, nsrc;
     LaunchFn fn;
-    int capacity() const { return rpl * cbr * nsrc - 1; }  // one row slot carries y
+    bool paired = false;   // needs the standard row map (every term has both rows)
+    bool autopick = true;  // false: only selectable by name (measured slower than the default of its row range)
+    // real rows it holds: one slot carries y; a paired config with an odd block keeps one single slot per block
+    int capacity() const
+    {
+        const int rb = rpl * nsrc;
+        return paired ? cbr * (rb & ~1) - ((rb & 1) ? 0 : 1) : rpl * cbr * nsrc - 1;
+    }
 };
 
 #define CFG(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC, RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC, true>}
@@ -453,6 +642,20 @@ const ScanConfig kConfigs[] = {
     // R <= 63: 256 registers/lane (2 waves per SIMD) beats the AGPR-spilling 1-wave build; compiler-scheduled
     {"rpl4_cbr4_nsrc4", 4, 4, 4, &launch_cfg<4, 4, 4, false, 2>},
     CFG(5, 4, 4),                                                         // R <= 79
+    // column-paired variants (standard row map only; picked automatically by pick_config when applicable)
+    {"rpl3_cbr2_nsrc7_p", 3, 2, 7, &launch_cfg<3, 2, 7, true, 1, true>, true},
+    {"rpl3_cbr2_nsrc8_p", 3, 2, 8, &launch_cfg<3, 2, 8, true, 1, true>, true},
+    {"rpl3_cbr2_nsrc6_p", 3, 2, 6, &launch_cfg<3, 2, 6, true, 1, true>, true},
+    {"rpl1_cbr1_nsrc5_p", 1, 1, 5, &launch_cfg<1, 1, 5, true, 1, true>, true},
+    {"rpl1_cbr1_nsrc9_p", 1, 1, 9, &launch_cfg<1, 1, 9, true, 1, true>, true},
+    {"rpl1_cbr1_nsrc13_p", 1, 1, 13, &launch_cfg<1, 1, 13, true, 1, true>, true},
+    {"rpl1_cbr1_nsrc16_p", 1, 1, 16, &launch_cfg<1, 1, 16, true, 1, true>, true},
+    {"rpl2_cbr1_nsrc9_p", 2, 1, 9, &launch_cfg<2, 1, 9, true, 1, true>, true},
+    {"rpl2_cbr1_nsrc11_p", 2, 1, 11, &launch_cfg<2, 1, 11, true, 1, true>, true},
+    {"rpl2_cbr1_nsrc13_p", 2, 1, 13, &launch_cfg<2, 1, 13, true, 1, true>, true},
+    {"rpl2_cbr1_nsrc15_p", 2, 1, 15, &launch_cfg<2, 1, 15, true, 1, true>, true},
+    {"rpl2_cbr1_nsrc16_p", 2, 1, 16, &launch_cfg<2, 1, 16, true, 1, true>, true},
+    {"rpl4_cbr4_nsrc4_p", 4, 4, 4, &launch_cfg<4, 4, 4, true, 2, true>, true, false},   // 104k vs 116k evals/s (SHO-30)
     // alternatives kept for tuning runs (selected by name)
     CFG(3, 4, 4), CFG(2, 2, 8), CFG_C(3, 2, 7), CFG_C(4, 4, 4), CFG_C(2, 1, 16), CFG_C(1, 1, 16), CFG_C(5, 4, 4),
     {"rpl4_cbr4_nsrc4_asm", 4, 4, 4, &launch_cfg<4, 4, 4, true, 1>},
@@ -462,15 +665,22 @@ const ScanConfig kConfigs[] = {
 #undef CFG_C
 constexpr int kNumPreferred = 14;
 
-const ScanConfig* pick_config(int R)
+const ScanConfig* pick_config(int R, bool standard_rows)
 {
     if (const char* env = std::getenv("PIORAN_SCAN_CONFIG")) {
         for (const auto& c : kConfigs)
-            if (!std::strcmp(env, c.name) && c.capacity() >= R) return &c;
+            if (!std::strcmp(env, c.name) && c.capacity() >= R && (!c.paired || standard_rows)) return &c;
     }
+    const ScanConfig* best = nullptr;
     for (int i = 0; i < kNumPreferred; ++i)
-        if (kConfigs[i].capacity() >= R) return &kConfigs[i];
-    return nullptr;
+        if (kConfigs[i].capacity() >= R) { best = &kConfigs[i]; break; }
+    if (standard_rows && !std::getenv("PIORAN_NO_PAIRED")) {
+        // a paired variant of the same shape (or the smallest paired one that fits) wins when the row map allows it
+        for (const auto& c : kConfigs)
+            if (c.paired && c.autopick && c.capacity() >= R && (!best || c.rpl * c.cbr * c.nsrc <= best->rpl * best->cbr * best->nsrc))
+                return &c;
+    }
+    return best;
 }
 
 }  // namespace
@@ -479,13 +689,13 @@ int pioran_scan_supported_rows() { return 79; }
 
 const char* pioran_scan_config_name(int R)
 {
-    const ScanConfig* c = pick_config(R);
+    const ScanConfig* c = pick_config(R, (R & 1) == 0);   // diagnostics: assumes the standard row map for even R
     return c ? c->name : "fallback";
 }
 
 int pioran_launch_scan(const ScanParams& p, hipStream_t stream)
 {
-    const ScanConfig* c = pick_config(p.R);
+    const ScanConfig* c = pick_config(p.R, p.standard_rows != 0);
     if (!c) return PIORAN_ERR_UNSUPPORTED;
     const int epw = 64 / (16 * c->cbr);
     const int64_t per_block = 4 * epw;

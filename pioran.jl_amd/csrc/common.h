@@ -17,6 +17,7 @@ struct ScanParams {
     int64_t N;            // time stamps
     int32_t J;            // celerite terms
     int32_t R;            // active rows (<= 2J; structurally-zero sin rows of d=b=0 terms dropped)
+    int32_t standard_rows;  // 1: R = 2J and row 2j / 2j+1 are the cos / sin rows of term j (no dropped rows)
     int64_t B;            // batch (independent draws)
     const double* tab;    // shared table [N+1][3(R+2)+2], or nullptr when (c,d) are per draw
     const int32_t* rowmap;  // [R]: term | kind<<30 (kind 1 = sin row)

@@ -10,7 +10,7 @@
 namespace {
 // record of step n (RS = 3 Rp + 2 doubles, Rp = R + 2):
 //   [ v_r (r < Rp) | x_r | phi_r | y_n  sigma2_n ],  cos row: (v, x) = (cos, sin)(d t_n), sin row: (sin, cos);
-//   row R = inert padding (1, 0, 0), row R+1 = the y row of the scan (0, 0, 1).  N + 1 records: the last one
+//   row R = inert padding (1, 0, 1) (u = 0: never feeds a real row), row R+1 = the y row of the scan (0, 0, 1).  N + 1 records: the last one
 //   repeats step N-1 so that the scan's prefetch of "step N" stays in bounds.
 __global__ void __launch_bounds__(256) table_kernel(int64_t N, int32_t R, const int32_t* __restrict__ rowmap,
                                                     const double* __restrict__ t, const double* __restrict__ c,
@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) table_kernel(int64_t N, int32_t R, const 
     const int64_t nrec = idx / Rp;
     const int32_t row = (int32_t)(idx - nrec * Rp);
     const int64_t n = nrec < N ? nrec : N - 1;
-    double v = row == R ? 1.0 : 0.0, x = 0.0, ph = row == R ? 0.0 : 1.0;
+    double v = row == R ? 1.0 : 0.0, x = 0.0, ph = 1.0;   // padding (1, 0, 1) and y row (0, 0, 1)
     if (row < R) {
         const int32_t rm = rowmap[row];
         const int32_t term = rm & 0x3fffffff;

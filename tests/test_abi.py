@@ -37,7 +37,7 @@ def test_version_and_strerror():
     assert L.pioran_abi_version() == 1
     assert L.pioran_strerror(0) == b"ok"
     assert L.pioran_strerror(-4) == b"unsupported size"
-    assert L.pioran_celerite_config_name(40) == b"rpl3_cbr2_nsrc7"
+    assert L.pioran_celerite_config_name(40) == b"rpl3_cbr2_nsrc7_p"   # column-paired variant for the standard row map
     assert L.pioran_celerite_config_name(60).startswith(b"rpl4_cbr4")
     assert L.pioran_celerite_config_name(128) == b"fallback"
 

@@ -185,7 +185,7 @@ def test_all_kernel_configs_agree(ctx):
     ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
     ds = pj.Dataset(t, y, s2, ctx)
     try:
-        for name in ("rpl3_cbr2_nsrc7", "rpl3_cbr2_nsrc8", "rpl3_cbr2_nsrc7_c", "rpl3_cbr4_nsrc4", "rpl4_cbr4_nsrc4",
+        for name in ("rpl3_cbr2_nsrc7_p", "rpl3_cbr2_nsrc8_p", "rpl3_cbr2_nsrc7", "rpl3_cbr2_nsrc8", "rpl3_cbr2_nsrc7_c", "rpl3_cbr4_nsrc4", "rpl4_cbr4_nsrc4",
                      "rpl4_cbr4_nsrc4_c", "rpl4_cbr4_nsrc4_asm", "rpl4_cbr4_nsrc4_asm_w2", "rpl5_cbr4_nsrc4",
                      "rpl5_cbr4_nsrc4_c"):
             os.environ["PIORAN_SCAN_CONFIG"] = name
