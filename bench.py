@@ -199,19 +199,27 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O  # checker + CPU baseline only
-        cores = os.cpu_count() or 1
-        S = args.cpu_sample or max(cores, min(B, 8 * cores))   # ~8 draws per core: tens of core-seconds
-        S = min(S, B)
+        ncpu = os.cpu_count() or 1
         O.lib()
-        tc = time.perf_counter()
-        ref, rst = O.logl_batch(A[:S], Bc[:S], C, Dd, t, y, yerr ** 2, mu[:S], nu[:S], nthreads=cores, return_status=True)
-        cpu_s = time.perf_counter() - tc
+        # The oracle is one independent logl per draw, OpenMP over draws.  More threads than the job really gets
+        # (cgroup quota, SMT, memory bandwidth) makes it SLOWER, so sweep a few thread counts on bounded samples
+        # (8 draws per thread) and report the best one — the most favourable baseline this host gives.
+        best = None
+        for nthr in sorted({max(1, ncpu // 8), max(1, ncpu // 4), max(1, ncpu // 2), ncpu}):
+            Sn = min(B, max(16, 8 * nthr))
+            tc = time.perf_counter()
+            r_, s_ = O.logl_batch(A[:Sn], Bc[:Sn], C, Dd, t, y, yerr ** 2, mu[:Sn], nu[:Sn], nthreads=nthr, return_status=True)
+            dt = time.perf_counter() - tc
+            if best is None or Sn / dt > best[0]:
+                best = (Sn / dt, nthr, Sn, dt, r_, s_)
+        cpu_rate, cores, S, cpu_s, ref, rst = best
         ok = (rst == 0) & (st_host[:S] == 0)
         err = np.abs(out_host[:S][ok] - ref[ok])
         result["cpu_baseline"] = {
-            "value": S / cpu_s, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": f"first {S} draws of the same batch (N={N}, J={Jt}), oracle/celerite_oracle.c "
-                      f"(reference algorithm and memory layout), OpenMP over draws, {cpu_s:.1f} s"}
+            "value": cpu_rate, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"first {S} draws of the same batch (N={N}, J={Jt}), oracle/celerite_oracle.c (reference "
+                      f"algorithm and memory layout), OpenMP over draws, {cpu_s:.1f} s; best of a thread-count sweep "
+                      f"over {{1/8, 1/4, 1/2, 1}} x {ncpu} logical CPUs"}
         result["max_abs_dlogl_vs_oracle"] = float(err.max()) if ok.any() else None
         result["max_rel_dlogl_vs_oracle"] = float((err / np.abs(ref[ok])).max()) if ok.any() else None
     if rank == 0:
