@@ -353,6 +353,16 @@ __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, int vo
     return __hiloint2double((int)v.y, (int)v.x);
 }
 
+// 1/x to fp64 accuracy without the IEEE division sequence (no denormal scaling needed: D_n is O(1e-6..1e6)):
+// v_rcp_f64 seed + two Newton steps; 0 -> inf, NaN -> NaN, so failures still surface in `status`.
+__device__ __forceinline__ double recip_f64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 template <int RPL>
 struct StepIn {           // what one time step reads: per own row (v, x, phi) + the shared y_n, sigma2_n
     double v[RPL], x[RPL], ph[RPL], y, s2;
@@ -502,10 +512,14 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         for (int i = 0; i < RPL; ++i) S[c][i] = 0.0;
     double w[RPL];
     double Dn = suma + (has_nu ? nu * bufA.s2 : bufA.s2);
-    double rD = 1.0 / Dn;
+    double rD = recip_f64(Dn);
     if (isy) bufA.v[YS] = bufA.y - mu;       // z_1 = y_1      :128
+    double num[RPL];                          // (v - q) of the last step = D_n W_n, the `dn` of :73 up to one rounding
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) w[i] = bufA.v[i] * rD;
+    for (int i = 0; i < RPL; ++i) {
+        num[i] = bufA.v[i];
+        w[i] = bufA.v[i] * rD;
+    }
     double Pm = Dn;      // running product of |D| (sign of D_1 kept: log of a negative D_1 is NaN, :126)
     int Pe = 0;
     {
@@ -517,13 +531,13 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     bool nonpd = !(Dn > 0.0);
 
     // one time step: consumes `in` (loaded one step earlier), prefetches step n + 1 into `nxt`
-    auto do_step = [&](int64_t n, StepIn<RPL>& in, StepIn<RPL>& nxt) {
+    auto do_step = [&](int64_t n, StepIn<RPL>& in, StepIn<RPL>& nxt, auto renorm) {
         load_step(n + 1, nxt);   // independent of the recurrence
         double u[RPL], g[RPL], qt[RPL];
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             u[i] = al[i] * in.v[i] + be[i] * in.x[i];
-            g[i] = Dn * w[i];                       // dn = D[n-1] * V[j,n-1]   :73
+            g[i] = num[i];                          // dn = D[n-1] * V[j,n-1]   :73
             qt[i] = 0.0;
         }
         if (isy) in.v[YS] = in.y - mu;
@@ -578,25 +592,30 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         const double s = group_sum<CBR>(sp);
 
         Dn = suma + (has_nu ? nu * in.s2 : in.s2) - s;           // :92
-        rD = 1.0 / Dn;
-        const double z = in.v[YS] - qt[YS];                      // y row: z_n = y_n - u'f      :141
+        rD = recip_f64(Dn);
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) w[i] = (in.v[i] - qt[i]) * rD;                     // :89,96
+        for (int i = 0; i < RPL; ++i) {
+            num[i] = in.v[i] - qt[i];                            // :89
+            w[i] = num[i] * rD;                                  // :96
+        }
+        const double z = num[YS];                                // y row: z_n = y_n - u'f      :141
         nonpd |= !(Dn > 0.0);
         Pm *= fabs(Dn);                                          // log(abs(D[n]))  :140
-        int ex;
-        Pm = frexp(Pm, &ex);
-        Pe += ex;
+        if constexpr (decltype(renorm)::value) {                 // mantissa/exponent split every second step
+            int ex;
+            Pm = frexp(Pm, &ex);
+            Pe += ex;
+        }
         quad = fma(z * z, rD, quad);                             // z_n^2 / D_n  (== y'K^-1 y, :333)
     };
 
     if (N > 1) load_step(1, bufB);
     int64_t n = 1;
     for (; n + 1 < N; n += 2) {      // ping-pong: no register rotation between steps
-        do_step(n, bufB, bufA);
-        do_step(n + 1, bufA, bufB);
+        do_step(n, bufB, bufA, std::false_type{});
+        do_step(n + 1, bufA, bufB, std::true_type{});
     }
-    if (n < N) do_step(n, bufB, bufA);
+    if (n < N) do_step(n, bufB, bufA, std::true_type{});
 
     if (active && isy && r == 0) {
         const double logdet = log(Pm) + (double)Pe * 0.6931471805599453094;
