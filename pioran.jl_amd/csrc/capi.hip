@@ -42,6 +42,9 @@ struct pioran_ds {
     double *dc = nullptr, *dd = nullptr;
     size_t dcd_cap = 0;
     bool prepared = false;
+    // mixed mode (term kind 2): indices of the per-draw terms, on the device
+    int32_t npd_terms = 0;
+    int32_t* dpd_terms = nullptr;
 };
 
 namespace {
@@ -79,14 +82,24 @@ int upload(pioran_ctx* ctx, pioran_ctx::Buf& b, const void* host, size_t bytes)
     return PIORAN_OK;
 }
 
-// rows kept for a term list: cos row always, sin row unless the term is marked real (b = d = 0)
-std::vector<int32_t> build_rowmap(int64_t J, const int32_t* real_term)
+// rows kept for a term list.  kind[j]: 0 = shared (c, d): cos + sin row from the shared table;
+//   1 = "real" term (b = d = 0 for every draw): cos row only; 2 = per-draw (c, d): cos + sin row from the per-draw table.
+// Encoding: term (bits 0-19) | per-draw row index (20-28) | per-draw flag (29) | sin row (30).
+std::vector<int32_t> build_rowmap(int64_t J, const int32_t* kind)
 {
     std::vector<int32_t> rm;
     rm.reserve(2 * J);
+    int32_t npd = 0;
     for (int64_t j = 0; j < J; ++j) {
-        rm.push_back((int32_t)j);
-        if (!(real_term && real_term[j])) rm.push_back((int32_t)j | (1 << 30));
+        const int32_t k = kind ? kind[j] : 0;
+        if (k == 2) {
+            rm.push_back((int32_t)j | ((2 * npd) << 20) | (1 << 29));
+            rm.push_back((int32_t)j | ((2 * npd + 1) << 20) | (1 << 29) | (1 << 30));
+            ++npd;
+        } else {
+            rm.push_back((int32_t)j);
+            if (k != 1) rm.push_back((int32_t)j | (1 << 30));
+        }
     }
     return rm;
 }
@@ -255,6 +268,7 @@ int pioran_dataset_destroy(pioran_ds* ds)
     if (ds->tab) (void)hipFree(ds->tab);
     if (ds->rowmap) (void)hipFree(ds->rowmap);
     if (ds->dc) (void)hipFree(ds->dc);
+    if (ds->dpd_terms) (void)hipFree(ds->dpd_terms);
     delete ds;
     return PIORAN_OK;
 }
@@ -265,10 +279,16 @@ int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const doub
     pioran_ctx* ctx = ds->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::vector<int32_t> real(J, 0);
+    std::vector<double> cc(c, c + J), dv(d, d + J);
+    std::vector<int32_t> pdlist;
     for (int64_t j = 0; j < J; ++j) {
-        real[j] = (real_term && real_term[j]) ? 1 : 0;
-        if (real[j] && d[j] != 0.0) return PIORAN_ERR_ARG;  // a real term must have d = 0
+        real[j] = real_term ? (real_term[j] == 2 ? 2 : (real_term[j] ? 1 : 0)) : 0;
+        if (real[j] == 1 && d[j] != 0.0) return PIORAN_ERR_ARG;  // a real term must have d = 0
+        if (real[j] == 2) { cc[j] = 0.0; dv[j] = 0.0; pdlist.push_back((int32_t)j); }   // (c, d) come per draw
     }
+    if (pdlist.size() > 255 || J > 0xfffff) return PIORAN_ERR_UNSUPPORTED;
+    c = cc.data();
+    d = dv.data();
     const bool same = ds->prepared && ds->J == J && !std::memcmp(ds->c_host.data(), c, J * sizeof(double)) &&
                       !std::memcmp(ds->d_host.data(), d, J * sizeof(double)) && ds->real_host == real;
     if (same) return PIORAN_OK;
@@ -286,6 +306,12 @@ int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const doub
     HIPCHK(ctx, hipMemcpyAsync(ds->dd, ds->d_host.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     int rc = set_rowmap(ds, build_rowmap(J, real.data()));   // sets ds->R
     if (rc) return rc;
+    ds->npd_terms = (int32_t)pdlist.size();
+    if (!pdlist.empty()) {
+        if (!ds->dpd_terms && hipMalloc((void**)&ds->dpd_terms, 256 * sizeof(int32_t)) != hipSuccess) return PIORAN_ERR_ALLOC;
+        HIPCHK(ctx, hipMemcpyAsync(ds->dpd_terms, pdlist.data(), pdlist.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     // the table is per ROW (v, x, phi) + (y_n, sigma2_n) per step, see table.hip
     const size_t need = pioran_table_doubles(ds->N, ds->R);
     if (need > ds->tab_cap) {
@@ -295,7 +321,8 @@ int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const doub
         if (hipMalloc((void**)&ds->tab, need * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
         ds->tab_cap = need;
     }
-    rc = pioran_launch_table(ds->N, ds->R, ds->rowmap, ds->t, ds->dc, ds->dd, ds->y, ds->s2, ds->tab, ctx->stream);
+    rc = pioran_launch_table(ds->N, ds->R, ds->rowmap, ds->t, ds->dc, ds->dd, ds->y, ds->s2, ds->tab,
+                             3 * (int64_t)(ds->R + 2) + 2, ctx->stream);
     if (rc) return rc;
     ds->J = (int32_t)J;
     ds->real_host = real;
@@ -315,6 +342,7 @@ int pioran_celerite_logl_batch_dev(pioran_ds* ds, int64_t B, const double* dA, c
     ScanParams p{};
     p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = B;
     p.standard_rows = ds->R == 2 * ds->J;
+    p.rec_stride = 3 * (int64_t)(ds->R + 2) + 2;
     p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
     p.Y = dY; p.S2 = dS2; p.A = dA; p.Bc = dBc; p.C = ds->dc; p.D = ds->dd;
     p.mu = dmu; p.nu = dnu; p.out = dout; p.status = dstatus;
@@ -340,10 +368,91 @@ int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const
     ScanParams p{};
     p.N = ds->N; p.J = (int32_t)J; p.R = (int32_t)rm.size(); p.B = B;
     p.standard_rows = 1;
+    p.rec_stride = 0;
     p.tab = nullptr; p.rowmap = drm; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
     p.Y = dY; p.S2 = dS2; p.A = dA; p.Bc = dBc; p.C = dC; p.D = dDd;
     p.mu = dmu; p.nu = dnu; p.out = dout; p.status = dstatus;
     return launch(ds, p);
+}
+
+// Mixed mode (host-pointer entry, cd_shared == 0): when only a few terms really differ between draws (QPO features on
+// top of an approx continuum, src/psd.jl:254-261), the shared terms keep using the shared table and only the per-draw
+// terms get a per-draw table, built by a pre-pass kernel for chunks of draws (32-bit buffer offsets).
+// Returns 1 if it handled the batch, 0 if the caller should take the generic per-draw path, < 0 on error.
+static int batch_host_mixed(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                            const double* Dd, const double* mu, const double* nu, const double* Y, const double* S2,
+                            bool series_on_device, double* out, int32_t* status)
+{
+    pioran_ctx* ctx = ds->ctx;
+    if (std::getenv("PIORAN_NO_MIXED")) return 0;
+    std::vector<int32_t> kind(J, 0);
+    int64_t npd = 0;
+    for (int64_t j = 0; j < J; ++j) {
+        bool shared = true;
+        for (int64_t b = 1; b < B && shared; ++b) shared = C[b * J + j] == C[j] && Dd[b * J + j] == Dd[j];
+        if (!shared) { kind[j] = 2; ++npd; continue; }
+        if (Dd[j] == 0.0) {
+            bool allzero = true;
+            for (int64_t b = 0; b < B && allzero; ++b) allzero = Bc[b * J + j] == 0.0;
+            kind[j] = allzero ? 1 : 0;
+        }
+    }
+    if (npd == 0 || npd > 8 || npd * 2 > J) return 0;   // all shared is handled by the caller; many per-draw terms: generic
+    int64_t rows = 0;
+    for (int64_t j = 0; j < J; ++j) rows += kind[j] == 1 ? 1 : 2;
+    if (rows > pioran_scan_supported_rows()) return 0;
+    const int64_t rs_shared = 3 * (rows + 2) + 2;               // shared part of a step record (doubles)
+    // combined table: (N+1) records of rs_shared + chunk * 2 npd * 3 doubles, addressed with 32-bit byte offsets
+    int64_t chunk = ((int64_t)0x7fff0000 / ((ds->N + 1) * 8) - rs_shared) / (6 * npd);
+    chunk = chunk > B ? B : chunk & ~(int64_t)15;
+    if (chunk < 16) return 0;
+    int rc;
+    if ((rc = pioran_dataset_prepare(ds, J, C, Dd, kind.data()))) return rc;   // row 0 of C, Dd: the shared values
+    const int64_t rec_stride = rs_shared + chunk * 6 * npd;
+    if ((rc = ensure(ctx, ctx->bscratch, (size_t)(ds->N + 1) * (size_t)rec_stride * sizeof(double)))) return rc;
+    double* ctab = (double*)ctx->bscratch.p;
+    // shared rows into the combined layout (same kernel as the plain table, wider record stride)
+    if ((rc = pioran_launch_table(ds->N, ds->R, ds->rowmap, ds->t, ds->dc, ds->dd, ds->y, ds->s2, ctab, rec_stride, ctx->stream)))
+        return rc;
+    if ((rc = ensure(ctx, ctx->bout, chunk * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t)))) return rc;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+        const size_t bj = (size_t)nb * (size_t)J * sizeof(double);
+        if ((rc = upload(ctx, ctx->bA, A + b0 * J, bj))) return rc;
+        if ((rc = upload(ctx, ctx->bB, Bc + b0 * J, bj))) return rc;
+        if ((rc = upload(ctx, ctx->bC, C + b0 * J, bj))) return rc;
+        if ((rc = upload(ctx, ctx->bD, Dd + b0 * J, bj))) return rc;
+        if (mu && (rc = upload(ctx, ctx->bmu, mu + b0, nb * sizeof(double)))) return rc;
+        if (nu && (rc = upload(ctx, ctx->bnu, nu + b0, nb * sizeof(double)))) return rc;
+        const double *dY = nullptr, *dS2 = nullptr;
+        if (Y) {
+            const size_t bn = (size_t)nb * (size_t)ds->N * sizeof(double);
+            if ((rc = upload(ctx, ctx->bY, Y + b0 * ds->N, bn))) return rc;
+            if ((rc = upload(ctx, ctx->bS2, S2 + b0 * ds->N, bn))) return rc;
+            dY = (const double*)ctx->bY.p; dS2 = (const double*)ctx->bS2.p;
+        } else if (series_on_device) {
+            dY = (const double*)ctx->bY.p + b0 * ds->N; dS2 = (const double*)ctx->bS2.p + b0 * ds->N;
+        }
+        rc = pioran_launch_pd_table(ds->N, nb, (int32_t)J, ds->npd_terms, ds->dpd_terms, ds->t, (const double*)ctx->bC.p,
+                                    (const double*)ctx->bD.p, ctab, rec_stride, rs_shared, ctx->stream);
+        if (rc) return rc;
+        ScanParams p{};
+        p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = nb;
+        p.standard_rows = ds->R == 2 * ds->J;
+        p.rec_stride = rec_stride;
+        p.tab = ctab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+        p.Y = dY; p.S2 = dS2; p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
+        p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
+        p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
+        p.npd_rows = 2 * ds->npd_terms;
+        rc = pioran_launch_scan(p, ctx->stream);
+        if (rc) { ctx->last_err = "mixed-mode scan launch failed"; return rc; }
+        HIPCHK(ctx, hipMemcpyAsync(out + b0, ctx->bout.p, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (status) HIPCHK(ctx, hipMemcpyAsync(status + b0, ctx->bst.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return 1;
 }
 
 // host-pointer batch; series_on_device: ctx->bY / ctx->bS2 already hold the per-draw series (shift transform)
@@ -358,6 +467,11 @@ static int batch_host_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A,
     const size_t bj = (size_t)B * (size_t)J * sizeof(double);
     const size_t bn = (size_t)B * (size_t)ds->N * sizeof(double);
     int rc;
+    if (!cd_shared && B > 1) {
+        rc = batch_host_mixed(ds, B, J, A, Bc, C, Dd, mu, nu, Y, S2, series_on_device, out, status);
+        if (rc < 0) return rc;
+        if (rc == 1) return PIORAN_OK;
+    }
     if (cd_shared) {
         // terms whose sin row is identically zero for the whole batch: d_j = 0 and b_j = 0 for all draws
         std::vector<int32_t> real(J, 0);

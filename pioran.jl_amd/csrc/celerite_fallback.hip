@@ -24,13 +24,13 @@ __global__ void __launch_bounds__(64) celerite_fallback_kernel(const ScanParams 
     const int lane = threadIdx.x;
     const int64_t b = b0 + blockIdx.x;
     const int J = p.J, R = p.R, Rp = R + 2;
-    const int64_t RS = 3 * (int64_t)Rp + 2;  // shared table record, see table.hip
+    const int64_t RS = p.rec_stride;  // shared table record stride, see table.hip
     const int64_t N = p.N;
     double* S = p.scratch + (int64_t)blockIdx.x * ((int64_t)R * R);
 
     for (int j = lane; j < R; j += 64) {
         const int rm = p.rowmap[j];
-        const int tj = rm & 0x3fffffff;
+        const int tj = rm & 0xfffff;
         const bool ks = (rm >> 30) & 1;
         const double a = p.A[b * J + tj], bb = p.Bc[b * J + tj];
         term_s[j] = rm;

@@ -403,8 +403,10 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     double al[RPL], be[RPL];                 // u = al * v + be * x
     [[maybe_unused]] double cc[RPL], dd[RPL];
     [[maybe_unused]] bool ksin[RPL];
+    [[maybe_unused]] int pdoff[RPL];         // >= 0: this slot's row is a per-draw row (mixed mode): its index in the per-draw block
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
+        pdoff[i] = -1;
         const int slot = lam * RPL + i;
         int j;   // real row index, or >= R for a special slot
         if constexpr (PAIRED) {
@@ -415,8 +417,9 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         }
         if (j < R) {
             const int rm = p.rowmap[j];
-            const int term = rm & 0x3fffffff;
+            const int term = rm & 0xfffff;
             const bool ks = (rm >> 30) & 1;
+            if ((rm >> 29) & 1) pdoff[i] = (int)(b * p.npd_rows) + ((rm >> 20) & 0x1ff);   // b: draw within this launch
             const double a = p.A[b * J + term], bb = p.Bc[b * J + term];
             // cos row: v = co, x = si, u = a co + b si ; sin row: v = si, x = co, u = a si - b co   (:59-63)
             trow[i] = j;
@@ -449,26 +452,39 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     if constexpr (CBR >= 2) p1 = e * G + (r ^ 1) * 16 + ((lam - NSRC * (r ^ 1)) & 15);
     if constexpr (CBR >= 4) p2 = e * G + (r ^ 2) * 16 + ((lam - NSRC * (r ^ 2)) & 15);
 
-    // shared table record of step n: [v x Rp | x x Rp | phi x Rp | y_n, sigma2_n]; N + 1 records (the last
-    // one is a readable dummy so the prefetch of step n + 1 needs no bounds test).  Read with buffer loads:
-    // per-lane byte offset in a VGPR (constant), step offset in an SGPR -> no vector address arithmetic.
+    // Table record of step n: [v x Rp | x x Rp | phi x Rp | y_n, sigma2_n | per-draw block]; N + 1 records (the last
+    // one is a readable dummy so the prefetch of step n + 1 needs no bounds test).  The per-draw block (mixed mode:
+    // rows of the few terms whose (c, d) differ per draw) is [draw][row][v, x, phi] and sits INSIDE the step record,
+    // so every row has the same step stride.  Read with buffer loads: per-lane byte offsets in VGPRs (constant),
+    // step offset in an SGPR -> no vector address arithmetic and no branches.
     const int RS = 3 * Rp + 2;
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double*>(SHARED_TAB ? p.tab : p.t), 0, 0x7ffffffc, 0x00020000);
-    [[maybe_unused]] int voff[RPL];
+    [[maybe_unused]] int vo_v[RPL], vo_x[RPL], vo_p[RPL];
+    [[maybe_unused]] const int step_bytes = (int)p.rec_stride * 8;
     if constexpr (SHARED_TAB) {
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) voff[i] = trow[i] * 8;
+        for (int i = 0; i < RPL; ++i) {
+            if (pdoff[i] >= 0) {
+                vo_v[i] = (RS + pdoff[i] * 3) * 8;
+                vo_x[i] = vo_v[i] + 8;
+                vo_p[i] = vo_v[i] + 16;
+            } else {
+                vo_v[i] = trow[i] * 8;
+                vo_x[i] = vo_v[i] + Rp * 8;
+                vo_p[i] = vo_v[i] + 2 * Rp * 8;
+            }
+        }
     }
 
     auto load_step = [&](int64_t n, StepIn<RPL>& in) {
         if constexpr (SHARED_TAB) {
-            const int soff = (int)n * RS * 8;
+            const int soff = (int)n * step_bytes;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
-                in.v[i] = buf_load_f64(rs, voff[i], soff);
-                in.x[i] = buf_load_f64(rs, voff[i], soff + Rp * 8);
-                in.ph[i] = buf_load_f64(rs, voff[i], soff + 2 * Rp * 8);
+                in.v[i] = buf_load_f64(rs, vo_v[i], soff);
+                in.x[i] = buf_load_f64(rs, vo_x[i], soff);
+                in.ph[i] = buf_load_f64(rs, vo_p[i], soff);
             }
             if (own_series) {
                 const int64_t nn = n < N ? n : N - 1;

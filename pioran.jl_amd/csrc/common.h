@@ -20,7 +20,7 @@ struct ScanParams {
     int32_t standard_rows;  // 1: R = 2J and row 2j / 2j+1 are the cos / sin rows of term j (no dropped rows)
     int64_t B;            // batch (independent draws)
     const double* tab;    // shared table [N+1][3(R+2)+2], or nullptr when (c,d) are per draw
-    const int32_t* rowmap;  // [R]: term | kind<<30 (kind 1 = sin row)
+    const int32_t* rowmap;  // [R]: term (bits 0-19) | per-draw row index (20-28) | per-draw flag (29) | sin row (30)
     const double* t;      // [N]   (used only when tab == nullptr)
     const double* y;      // [N]   shared series (mean NOT subtracted), or nullptr if Y given
     const double* s2;     // [N]   shared measurement variances
@@ -35,6 +35,10 @@ struct ScanParams {
     double* out;          // [B]
     int32_t* status;      // [B] or nullptr
     double* scratch;      // fallback kernel: [B][R*R + 4R]
+    // step record stride of `tab` in doubles: 3(R+2)+2, plus B*npd_rows*3 in mixed mode, where the rows of the few
+    // terms with per-draw (c, d) read (v, x, phi) from a per-draw block appended to every step record
+    int64_t rec_stride;
+    int32_t npd_rows;     // per-draw rows (2 per per-draw term), 0 if none
 };
 
 // celerite_scan.hip
@@ -47,7 +51,11 @@ size_t pioran_fallback_scratch_doubles(int R);
 // table.hip
 size_t pioran_table_doubles(int64_t N, int32_t R);
 int pioran_launch_table(int64_t N, int32_t R, const int32_t* rowmap, const double* t, const double* c,
-                        const double* d, const double* y, const double* s2, double* tab, hipStream_t stream);
+                        const double* d, const double* y, const double* s2, double* tab, int64_t rec_stride,
+                        hipStream_t stream);
+int pioran_launch_pd_table(int64_t N, int64_t B, int32_t J, int32_t npd_terms, const int32_t* pd_terms /*device*/,
+                           const double* t, const double* C /*[B][J]*/, const double* D, double* tab, int64_t rec_stride,
+                           int64_t rs_shared, hipStream_t stream);
 int pioran_launch_shift_transform(int64_t N, int64_t B, const double* y, const double* s2, const double* shift,
                                   double* Y, double* S2, hipStream_t stream);
 // approx.hip

@@ -15,19 +15,18 @@ namespace {
 __global__ void __launch_bounds__(256) table_kernel(int64_t N, int32_t R, const int32_t* __restrict__ rowmap,
                                                     const double* __restrict__ t, const double* __restrict__ c,
                                                     const double* __restrict__ d, const double* __restrict__ y,
-                                                    const double* __restrict__ s2, double* __restrict__ tab)
+                                                    const double* __restrict__ s2, double* __restrict__ tab, int64_t RS /*record stride*/)
 {
     const int32_t Rp = R + 2;
-    const int64_t RS = 3 * (int64_t)Rp + 2;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (N + 1) * Rp) return;
     const int64_t nrec = idx / Rp;
     const int32_t row = (int32_t)(idx - nrec * Rp);
     const int64_t n = nrec < N ? nrec : N - 1;
     double v = row == R ? 1.0 : 0.0, x = 0.0, ph = 1.0;   // padding (1, 0, 1) and y row (0, 0, 1)
-    if (row < R) {
+    if (row < R && !((rowmap[row] >> 29) & 1)) {   // per-draw rows live in the per-draw table (mixed mode)
         const int32_t rm = rowmap[row];
-        const int32_t term = rm & 0x3fffffff;
+        const int32_t term = rm & 0xfffff;
         const double tn = t[n];
         double si, co;
         sincos(d[term] * tn, &si, &co);
@@ -45,6 +44,30 @@ __global__ void __launch_bounds__(256) table_kernel(int64_t N, int32_t R, const 
         rec[3 * Rp + 1] = s2[n];
     }
 }
+// Mixed mode: (v, x, phi) of the rows of the few terms whose (c, d) differ per draw (QPO features, src/psd.jl:15-27),
+// appended to every step record of the table so that all rows share one step stride:
+//   tab[n * rec_stride + rs_shared + (b * 2 npd + 2k + kind) * 3 + {v, x, phi}].
+__global__ void __launch_bounds__(256) pd_table_kernel(int64_t N, int64_t B, int32_t J, int32_t npd, const int32_t* __restrict__ pd_terms,
+                                                       const double* __restrict__ t, const double* __restrict__ C,
+                                                       const double* __restrict__ D, double* __restrict__ tab,
+                                                       int64_t rec_stride, int64_t rs_shared)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (n, b, k), k fastest
+    if (idx >= (N + 1) * B * npd) return;
+    const int32_t k = (int32_t)(idx % npd);
+    const int64_t nb = idx / npd;
+    const int64_t b = nb % B, nrec = nb / B;
+    const int64_t n = nrec < N ? nrec : N - 1;
+    const int32_t term = pd_terms[k];
+    const double tn = t[n];
+    double si, co;
+    sincos(D[b * J + term] * tn, &si, &co);                                   // :52-53
+    const double ph = n > 0 ? exp(-C[b * J + term] * (tn - t[n - 1])) : 0.0;  // :54
+    double* rec = tab + nrec * rec_stride + rs_shared + (b * (2 * npd) + 2 * k) * 3;   // inside the step record
+    rec[0] = co; rec[1] = si; rec[2] = ph;   // cos row: v = co, x = si
+    rec[3] = si; rec[4] = co; rec[5] = ph;   // sin row: v = si, x = co
+}
+
 // Per-draw series of the shifted log-flux models: Y[b][n] = log(y_n - shift_b), S2[b][n] = sigma2_n / (y_n - shift_b)^2
 // (docs/src/ultranest.md:199-205).  Pure streaming kernel: 16 B written per (draw, step), coalesced along n.
 __global__ void __launch_bounds__(256) shift_transform_kernel(int64_t N, int64_t B, const double* __restrict__ y,
@@ -59,6 +82,18 @@ __global__ void __launch_bounds__(256) shift_transform_kernel(int64_t N, int64_t
     S2[b * N + n] = s2[n] / (v * v);
 }
 }  // namespace
+
+int pioran_launch_pd_table(int64_t N, int64_t B, int32_t J, int32_t npd_terms, const int32_t* pd_terms, const double* t,
+                           const double* C, const double* D, double* tab, int64_t rec_stride, int64_t rs_shared,
+                           hipStream_t stream)
+{
+    const int64_t total = (N + 1) * B * npd_terms;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return PIORAN_ERR_ARG;
+    hipLaunchKernelGGL(pd_table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, N, B, J, npd_terms, pd_terms, t, C, D, tab,
+                       rec_stride, rs_shared);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
 
 int pioran_launch_shift_transform(int64_t N, int64_t B, const double* y, const double* s2, const double* shift,
                                   double* Y, double* S2, hipStream_t stream)
@@ -75,12 +110,13 @@ int pioran_launch_shift_transform(int64_t N, int64_t B, const double* y, const d
 size_t pioran_table_doubles(int64_t N, int32_t R) { return (size_t)(N + 1) * (size_t)(3 * (R + 2) + 2); }
 
 int pioran_launch_table(int64_t N, int32_t R, const int32_t* rowmap, const double* t, const double* c,
-                        const double* d, const double* y, const double* s2, double* tab, hipStream_t stream)
+                        const double* d, const double* y, const double* s2, double* tab, int64_t rec_stride,
+                        hipStream_t stream)
 {
     const int64_t total = (N + 1) * (int64_t)(R + 2);
     const int64_t blocks = (total + 255) / 256;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return PIORAN_ERR_ARG;
-    if (pioran_table_doubles(N, R) * 8 > 0x7ffffff0ull) return PIORAN_ERR_UNSUPPORTED;  // 32-bit buffer offsets
-    hipLaunchKernelGGL(table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, N, R, rowmap, t, c, d, y, s2, tab);
+    if ((uint64_t)(N + 1) * (uint64_t)rec_stride * 8 > 0x7ffffff0ull) return PIORAN_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+    hipLaunchKernelGGL(table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, N, R, rowmap, t, c, d, y, s2, tab, rec_stride);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }

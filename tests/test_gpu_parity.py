@@ -479,3 +479,59 @@ def test_reference_outputs_ultranest_theta_only(ctx, golden_dir):
                               mu=P[:, 5], nu=P[:, 4], shift=P[:, 6], return_status=True)
     assert (st == 0).all()
     assert relerr(got, ref) < 1e-10
+
+
+# ---------------------------------------------------------------------------------------------
+# mixed mode: a few per-draw terms (QPO features) on top of shared terms
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("J,npd,with_real", [(21, 1, False), (12, 2, False), (9, 1, True), (5, 2, True)])
+def test_mixed_shared_and_per_draw_terms(ctx, J, npd, with_real):
+    """C, Dd given per draw, but only `npd` columns actually differ between draws (src/psd.jl:254-261: QPO terms
+    appended to an approx continuum).  The host entry detects that, keeps the shared table for the common terms and
+    builds a per-draw table for the rest; result must equal the oracle and the generic per-draw path."""
+    rng = np.random.default_rng(600 + J)
+    N, B = 140, 37
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    C2 = np.broadcast_to(C, (B, J)).copy(); D2 = np.broadcast_to(Dd, (B, J)).copy()
+    cols = rng.choice(J, npd, replace=False)
+    C2[:, cols] = rng.uniform(0.05, 2.0, (B, npd)); D2[:, cols] = rng.uniform(0.1, 3.0, (B, npd))
+    if with_real:   # some shared Exp-like terms (b = d = 0): their sin rows are dropped
+        real_cols = [j for j in range(J) if j not in cols][:2]
+        Bc[:, real_cols] = 0.0; D2[:, real_cols] = 0.0
+    ds = pj.Dataset(t, y, s2, ctx)
+    ref = O.logl_batch(A, Bc, C2, D2, t, y, s2, mu, nu, nthreads=8)
+    got = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu)
+    assert relerr(got, ref) < 1e-11
+    try:
+        os.environ["PIORAN_NO_MIXED"] = "1"
+        gen = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu)
+    finally:
+        os.environ.pop("PIORAN_NO_MIXED", None)
+    assert relerr(gen, ref) < 1e-11
+    # per-draw series on top (Y, S2) and the shift transform go through the same path
+    Y = y[None, :] + 0.01 * rng.standard_normal((B, N)); S2 = np.broadcast_to(s2, (B, N)) * rng.uniform(0.5, 2, (B, 1))
+    got2 = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu, Y=Y, S2=S2)
+    ref2 = np.array([O.logl(A[i], Bc[i], C2[i], D2[i], t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(B)])
+    assert relerr(got2, ref2) < 1e-11
+
+
+def test_mixed_mode_qpo_model_full_size(ctx, full_size):
+    """approx(SingleBendingPowerLaw + QPO) at N = 1e4: 20 shared SHO terms + 1 sampled QPO term (J = 21)."""
+    t, y, yerr = full_size
+    rng = np.random.default_rng(9)
+    B = 24
+    th = O.synthetic_theta(B, t, y, seed=3)
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    rows = []
+    for i in range(B):
+        PS = pj.SingleBendingPowerLaw(*th[i, :3]) + pj.QPO(rng.uniform(0.01, 0.1), np.exp(rng.uniform(np.log(1e-2), 0.0)), rng.uniform(2, 20))
+        R = pj.approx(PS, f_min, f_max, 20, th[i, 3])
+        rows.append((R.a, R.b, R.c, R.d))
+    A, Bc, C2, D2 = (np.array([r[k] for r in rows]) for k in range(4))
+    assert A.shape == (B, 21) and (C2[:, :20] == C2[0, :20]).all() and not (C2[:, 20] == C2[0, 20]).all()
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    got, st = ds.logl_batch(A, Bc, C2, D2, mu=th[:, 5], nu=th[:, 4], return_status=True)
+    ref, rst = O.logl_batch(A, Bc, C2, D2, t, y, yerr ** 2, th[:, 5].copy(), th[:, 4].copy(), nthreads=8, return_status=True)
+    ok = rst == 0
+    assert ok.sum() >= B // 2 and (st[ok] == 0).all()
+    assert relerr(got[ok], ref[ok]) < 1e-8
