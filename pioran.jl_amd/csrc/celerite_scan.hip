@@ -368,7 +368,7 @@ struct StepIn {           // what one time step reads: per own row (v, x, phi) +
     double v[RPL], x[RPL], ph[RPL], y, s2;
 };
 
-template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false, int MINW = 1, bool PAIRED = false>
+template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false, int MINW = 1, bool PAIRED = false, bool MIXED = false>
 __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanParams p)
 {
     static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             const int rm = p.rowmap[j];
             const int term = rm & 0xfffff;
             const bool ks = (rm >> 30) & 1;
-            if ((rm >> 29) & 1) pdoff[i] = (int)(b * p.npd_rows) + ((rm >> 20) & 0x1ff);   // b: draw within this launch
+            if (MIXED && ((rm >> 29) & 1)) pdoff[i] = (int)(b * p.npd_rows) + ((rm >> 20) & 0x1ff);   // b: draw within this launch
             const double a = p.A[b * J + term], bb = p.Bc[b * J + term];
             // cos row: v = co, x = si, u = a co + b si ; sin row: v = si, x = co, u = a si - b co   (:59-63)
             trow[i] = j;
@@ -460,19 +460,21 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     const int RS = 3 * Rp + 2;
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double*>(SHARED_TAB ? p.tab : p.t), 0, 0x7ffffffc, 0x00020000);
-    [[maybe_unused]] int vo_v[RPL], vo_x[RPL], vo_p[RPL];
+    // Per-lane byte offsets of v, x, phi.  MIXED launches (some rows are per-draw) need all three per lane; otherwise
+    // x and phi are the v offset plus a wave-uniform constant, which can either live in two more VGPRs per row (no
+    // scalar adds per load: faster where registers allow, RPL <= 3) or be added to the scalar step offset.
+    constexpr bool LANE_OFFS = MIXED || RPL <= 3;
+    [[maybe_unused]] int vo_v[RPL], vo_x[LANE_OFFS ? RPL : 1], vo_p[LANE_OFFS ? RPL : 1];
     [[maybe_unused]] const int step_bytes = (int)p.rec_stride * 8;
     if constexpr (SHARED_TAB) {
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            if (pdoff[i] >= 0) {
+            if (MIXED && pdoff[i] >= 0) {
                 vo_v[i] = (RS + pdoff[i] * 3) * 8;
-                vo_x[i] = vo_v[i] + 8;
-                vo_p[i] = vo_v[i] + 16;
+                if constexpr (LANE_OFFS) { vo_x[i] = vo_v[i] + 8; vo_p[i] = vo_v[i] + 16; }
             } else {
                 vo_v[i] = trow[i] * 8;
-                vo_x[i] = vo_v[i] + Rp * 8;
-                vo_p[i] = vo_v[i] + 2 * Rp * 8;
+                if constexpr (LANE_OFFS) { vo_x[i] = vo_v[i] + Rp * 8; vo_p[i] = vo_v[i] + 2 * Rp * 8; }
             }
         }
     }
@@ -483,8 +485,13 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
                 in.v[i] = buf_load_f64(rs, vo_v[i], soff);
-                in.x[i] = buf_load_f64(rs, vo_x[i], soff);
-                in.ph[i] = buf_load_f64(rs, vo_p[i], soff);
+                if constexpr (LANE_OFFS) {
+                    in.x[i] = buf_load_f64(rs, vo_x[i], soff);
+                    in.ph[i] = buf_load_f64(rs, vo_p[i], soff);
+                } else {
+                    in.x[i] = buf_load_f64(rs, vo_v[i], soff + Rp * 8);
+                    in.ph[i] = buf_load_f64(rs, vo_v[i], soff + 2 * Rp * 8);
+                }
             }
             if (own_series) {
                 const int64_t nn = n < N ? n : N - 1;
@@ -646,7 +653,9 @@ using LaunchFn = void (*)(const ScanParams&, dim3, hipStream_t);
 template <int RPL, int CBR, int NSRC, bool ASM_DPP = false, int MINW = 1, bool PAIRED = false>
 void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 {
-    if (p.tab)
+    if (p.tab && p.npd_rows > 0)
+        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, ASM_DPP, MINW, PAIRED, true>), grid, dim3(256), 0, st, p);
+    else if (p.tab)
         hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, ASM_DPP, MINW, PAIRED>), grid, dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false, ASM_DPP, MINW, PAIRED>), grid, dim3(256), 0, st, p);
