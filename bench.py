@@ -81,7 +81,6 @@ def main():
     ap.add_argument("--components", type=int, default=20)
     ap.add_argument("--basis", default="SHO", choices=["SHO", "DRWCelerite"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="draws in the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
     import torch

@@ -47,7 +47,7 @@ typedef struct pioran_ds pioran_ds;   /* a time series resident in HBM + its cac
 const char* pioran_strerror(int code);
 const char* pioran_last_hip_error(const pioran_ctx* ctx);
 /* ABI version of this header (bumped on any signature change). */
-int pioran_abi_version(void);
+int pioran_abi_version(void);   /* currently 2 */
 
 /* ---- context ------------------------------------------------------------------------------- */
 /* Creates a context on GPU `device` with its own non-blocking stream. */
@@ -133,6 +133,22 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
                               const double* shift, double* out, int32_t* status, double* A_out, double* Bc_out);
 /* Name of the kernel configuration a batch with R active rows runs on (diagnostics). */
 const char* pioran_celerite_config_name(int64_t R);
+
+/* ---- in-process farm over several GPUs ---------------------------------------------------------------------------
+ * For hosts without a process-per-GPU launcher (a single Julia process driving the 8 GPUs of a node): one context and
+ * one resident copy of the data set per listed device, one host thread per device per call.  Draws are independent, so
+ * the batch is cut into contiguous shards (the first B % ngpu devices get one more draw) and every device writes its
+ * slice of out/status directly — there is no collective.  `devices` may list a device more than once.
+ * Arguments of pioran_farm_logl_batch are those of pioran_celerite_logl_batch[_shift] (shift may be NULL; Y/S2 per-draw
+ * series are not supported here). */
+typedef struct pioran_farm pioran_farm;
+int pioran_farm_create(int ngpu, const int* devices, int64_t N, const double* t, const double* y,
+                       const double* sigma2, pioran_farm** out);
+int pioran_farm_destroy(pioran_farm* farm);
+int pioran_farm_size(const pioran_farm* farm);
+int pioran_farm_logl_batch(pioran_farm* farm, int64_t B, int64_t J, const double* A, const double* Bc,
+                           const double* C, const double* Dd, int cd_shared, const double* mu, const double* nu,
+                           const double* shift, double* out, int32_t* status);
 
 /* ---- dense solver ---------------------------------------------------------------------------- */
 /* log_likelihood_direct (src/direct_solver.jl:6-21): builds K_ik = sum_j k_j(|t_i - t_k|) +

@@ -44,6 +44,11 @@ SIGNATURES = {
                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_void_p, c_void_p]),
     "pioran_celerite_config_name": (ctypes.c_char_p, [i64]),
+    "pioran_farm_create": (ctypes.c_int, [ctypes.c_int, c_void_p, i64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),
+    "pioran_farm_destroy": (ctypes.c_int, [c_void_p]),
+    "pioran_farm_size": (ctypes.c_int, [c_void_p]),
+    "pioran_farm_logl_batch": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pioran_dense_nll": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [c_void_p, c_void_p]),
     "pioran_dense_covariance": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 6 + [c_void_p]),
 }

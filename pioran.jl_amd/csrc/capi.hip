@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 struct pioran_ctx {
@@ -158,7 +159,7 @@ const char* pioran_strerror(int code)
 
 const char* pioran_last_hip_error(const pioran_ctx* ctx) { return ctx ? ctx->last_err.c_str() : ""; }
 
-int pioran_abi_version(void) { return 1; }
+int pioran_abi_version(void) { return 2; }
 
 static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
 {
@@ -641,6 +642,76 @@ const char* pioran_celerite_config_name(int64_t R)
 {
     if (R < 1 || R > pioran_scan_supported_rows()) return "fallback";
     return pioran_scan_config_name((int)R);
+}
+
+// ---- in-process farm ----------------------------------------------------------------------------
+struct pioran_farm {
+    std::vector<pioran_ctx*> ctx;
+    std::vector<pioran_ds*> ds;
+};
+
+int pioran_farm_create(int ngpu, const int* devices, int64_t N, const double* t, const double* y, const double* sigma2,
+                       pioran_farm** out)
+{
+    if (!out || ngpu < 1 || ngpu > 64 || !devices || N < 1 || !t || !y || !sigma2) return PIORAN_ERR_ARG;
+    *out = nullptr;
+    pioran_farm* f = new (std::nothrow) pioran_farm;
+    if (!f) return PIORAN_ERR_ALLOC;
+    int rc = PIORAN_OK;
+    for (int g = 0; g < ngpu && rc == PIORAN_OK; ++g) {
+        pioran_ctx* c = nullptr;
+        pioran_ds* d = nullptr;
+        rc = pioran_ctx_create(devices[g], &c);
+        if (rc == PIORAN_OK) {
+            f->ctx.push_back(c);
+            rc = pioran_dataset_create(c, N, t, y, sigma2, &d);
+            if (rc == PIORAN_OK) f->ds.push_back(d);
+        }
+    }
+    if (rc != PIORAN_OK) { pioran_farm_destroy(f); return rc; }
+    *out = f;
+    return PIORAN_OK;
+}
+
+int pioran_farm_destroy(pioran_farm* f)
+{
+    if (!f) return PIORAN_ERR_ARG;
+    for (auto* d : f->ds) pioran_dataset_destroy(d);
+    for (auto* c : f->ctx) pioran_ctx_destroy(c);
+    delete f;
+    return PIORAN_OK;
+}
+
+int pioran_farm_size(const pioran_farm* f) { return f ? (int)f->ds.size() : PIORAN_ERR_ARG; }
+
+int pioran_farm_logl_batch(pioran_farm* f, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                           const double* Dd, int cd_shared, const double* mu, const double* nu, const double* shift,
+                           double* out, int32_t* status)
+{
+    if (!f || f->ds.empty() || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !out) return PIORAN_ERR_ARG;
+    const int64_t G = (int64_t)f->ds.size();
+    const int64_t base = B / G, extra = B % G;
+    std::vector<int> rcs(G, PIORAN_OK);
+    std::vector<std::thread> th;
+    for (int64_t g = 0; g < G; ++g) {
+        const int64_t lo = g * base + (g < extra ? g : extra), nb = base + (g < extra ? 1 : 0);
+        if (nb == 0) continue;
+        th.emplace_back([=, &rcs]() {
+            const double* Cg = cd_shared ? C : C + lo * J;
+            const double* Dg = cd_shared ? Dd : Dd + lo * J;
+            const double* mug = mu ? mu + lo : nullptr;
+            const double* nug = nu ? nu + lo : nullptr;
+            int32_t* stg = status ? status + lo : nullptr;
+            rcs[g] = shift ? pioran_celerite_logl_batch_shift(f->ds[g], nb, J, A + lo * J, Bc + lo * J, Cg, Dg, cd_shared, mug,
+                                                              nug, shift + lo, out + lo, stg)
+                           : pioran_celerite_logl_batch(f->ds[g], nb, J, A + lo * J, Bc + lo * J, Cg, Dg, cd_shared, mug, nug,
+                                                        nullptr, nullptr, out + lo, stg);
+        });
+    }
+    for (auto& t_ : th) t_.join();
+    for (int rc : rcs)
+        if (rc != PIORAN_OK) return rc;
+    return PIORAN_OK;
 }
 
 // ---- dense solver -------------------------------------------------------------------------------

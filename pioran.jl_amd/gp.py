@@ -222,6 +222,47 @@ class Dataset:
                                                                    v(dstatus or None)), self.ctx._h)
 
 
+class Farm:
+    """In-process farm over several GPUs (pioran_farm): one context + resident data set per listed device, one host
+    thread per device per call, contiguous shards of the draws.  For launcher-less hosts (a single Julia / Python
+    process driving a node); the process-per-GPU route is pioran.jl_amd/farm.py."""
+
+    def __init__(self, devices, t, y, sigma2):
+        t, y, sigma2 = map(_f64, (t, y, sigma2))
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().pioran_farm_create(len(dev), _ptr(dev), len(t), _ptr(t), _ptr(y), _ptr(sigma2), ctypes.byref(h)))
+        self._h = h
+        self.N = len(t)
+
+    def __len__(self):
+        return _lib.lib().pioran_farm_size(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().pioran_farm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def logl_batch(self, A, Bc, C, Dd, mu=None, nu=None, shift=None, return_status=False):
+        A, Bc, C, Dd = map(_f64, (A, Bc, C, Dd))
+        B, J = A.shape
+        cd_shared = C.ndim == 1
+        mu = None if mu is None else _f64(np.broadcast_to(mu, (B,)))
+        nu = None if nu is None else _f64(np.broadcast_to(nu, (B,)))
+        shift = None if shift is None else _f64(np.broadcast_to(shift, (B,)))
+        out = np.empty(B)
+        st = np.zeros(B, dtype=np.int32)
+        _lib.check(_lib.lib().pioran_farm_logl_batch(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), int(cd_shared),
+                                                     _ptr(mu), _ptr(nu), _ptr(shift), _ptr(out), _ptr(st)))
+        return (out, st) if return_status else out
+
+
 # ---------------------------------------------------------------------------------------------
 # mean functions (AbstractGPs ConstMean / ZeroMean / CustomMean as used at scalable_GP.jl:164)
 # ---------------------------------------------------------------------------------------------

@@ -535,3 +535,19 @@ def test_mixed_mode_qpo_model_full_size(ctx, full_size):
     ok = rst == 0
     assert ok.sum() >= B // 2 and (st[ok] == 0).all()
     assert relerr(got[ok], ref[ok]) < 1e-8
+
+
+def test_in_process_farm_sharding(golden_dir):
+    """pioran_farm: several contexts in one process, one thread per device, contiguous ragged shards.  The 1-GPU box
+    lists device 0 three times — same code path as three GPUs; checked against reference-computed values."""
+    un = np.load(golden_dir / "ultranest_points.npz")
+    t, y, yerr, P, ref = un["t"], un["y"], un["yerr"], un["params"][:1000], un["logl"][:1000]
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, P[:, :3], f_min, f_max, 20, P[:, 3], is_integrated_power=False)
+    farm = pj.Farm([0, 0, 0], t, y, yerr ** 2)
+    assert len(farm) == 3
+    got, st = farm.logl_batch(A, Bc, C, Dd, mu=P[:, 5], nu=P[:, 4], shift=P[:, 6], return_status=True)
+    assert (st == 0).all() and relerr(got, ref) < 1e-10
+    got2 = farm.logl_batch(A[:2], Bc[:2], C, Dd, mu=P[:2, 5], nu=P[:2, 4], shift=P[:2, 6])    # fewer draws than devices
+    assert relerr(got2, ref[:2]) < 1e-10
+    farm.close()
