@@ -185,7 +185,7 @@ __device__ __forceinline__ f64x4 mfma4(double a, double b, f64x4 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-[[maybe_unused]] constexpr int LP = NB + 1;
+constexpr int LP = NB + 1;
 // workspace written by whoever factors a diagonal block, read by the following panel kernel:
 //   ws[0 .. 1023]   inv(L_ss), s = 0..3, row-major 16 x 16 each
 [[maybe_unused]] constexpr int WS_DOUBLES = 4 * 16 * 16;
@@ -202,41 +202,29 @@ __device__ __forceinline__ double bcast16(double x)
     return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true);
 }
 
-// Factor a 64 x 64 diagonal block held as register-resident MFMA tiles, by ONE wavefront.
+// Factor the 64 x 64 block held row-major (padded) in LDS `Ls`, in place, by ONE wavefront; writes the four
+// 16 x 16 inverses to `ws` (global).  Returns the 1-based index of the first non-positive pivot (0 = none).
 //
-// T[rt][ct] (ct <= rt) are the ten lower 16 x 16 tiles in the f64 C/D layout, TRANSPOSED storage:
-//   T[rt][ct][g] of lane l = A[16 rt + (l & 15)][16 ct + (l >> 4) + 4 g]
-// (exactly what the trailing-update accumulators of tile (0,0) hold).  Per 16-column sub-panel:
-//   1. the diagonal tile goes through a 16 x 17 LDS patch into row-per-lane form (every DPP row gets a copy);
-//   2. scalar right-looking Cholesky of the tile and its triangular inverse, cross-lane operands by
-//      v_mov_b64_dpp row_newbcast (pivot chain: bcast -> v_rsq_f64 + 2 Newton steps -> mul -> fma);
-//   3. rows below: Y_t = inv(L_ss) T[t][0] on the matrix cores — C/D register ks of a tile IS the B operand of
-//      k-step ks, so tiles never leave the registers;
-//   4. in-block update T[r][c] -= X_r X_c', both operands again straight from the result registers;
-//   5. the finished column of tiles is stored (coalesced along rows), the remaining tiles are renamed one step
-//      up-left, and the same code runs again (runtime loop: one copy of the code).
-// Writes L (lower part of the block) to `blk` and the four inverses to `ws`; returns the 1-based index of the
-// first non-positive pivot (0 = none).
-__device__ __forceinline__ int factor_block64_tiles(f64x4 (&T)[4][4], double* __restrict__ Ld /*16*17*/,
-                                                    double* __restrict__ Li /*16*17*/, double* __restrict__ blk, int64_t ld,
-                                                    double* __restrict__ ws, int lane)
+// Per 16-column sub-panel s only the 16 x 16 diagonal tile is scalar work: every DPP row of the wave holds the
+// tile (lane l&15 = tile row), the right-looking Cholesky and the triangular inverse take their cross-lane
+// operands from v_mov_b64_dpp row_newbcast, and the per-column critical path is bcast -> rsqrt -> mul -> fma.
+// Everything below the tile is matrix-core work through LDS: X_t = A_ts inv(L_ss)' for the tiles t > s
+// (transposed C/D layout, the inverse as A operand), then the in-block update A_rc -= X_r X_c'.
+__device__ __forceinline__ int factor_block64(double* __restrict__ Ls, double* __restrict__ ws, int lane)
 {
     const int lr = lane & 15, lk = lane >> 4;
     int bad = 0;
+    // runtime loop over the four 16-column sub-panels: one copy of the code (instruction cache stays warm after
+    // the first pass), the tile loops inside are static with wave-uniform guards.
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
-        const int m = 4 - s;   // tiles per side still alive; the current panel is always tile column 0
+        const int ir0 = s == 3 ? 16 : 0, ic0 = s == 3 ? 32 : 16 * (s + 1);   // where inv(L_ss) is parked
         PIORAN_STAMP(8 * s + 0);
-        // ---- 1. diagonal tile -> row-per-lane ------------------------------------------------------------------
-#pragma unroll
-        for (int g = 0; g < 4; ++g) Ld[lr * 17 + lk + 4 * g] = T[0][0][g];
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
+        // ---- 16 x 16 diagonal tile: right-looking Cholesky, lane lr = row (replicated in the 4 DPP rows) -----
         double r[16];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) r[p] = Ld[lr * 17 + p];
-        // ---- 2a. right-looking Cholesky of the tile, lane lr = row (replicated in the 4 DPP rows) ----------------
+        for (int p = 0; p < 16; ++p) r[p] = Ls[(c0 + lr) * LP + c0 + p];
         double rinv_own = 0.0;   // 1 / l_pp of this lane's row
         static_for16([&](auto Pc) {
             constexpr int p = decltype(Pc)::value;
@@ -252,7 +240,7 @@ __device__ __forceinline__ int factor_block64_tiles(f64x4 (&T)[4][4], double* __
             });
         });
         PIORAN_STAMP(8 * s + 1);
-        // ---- 2b. inverse of the tile, column-owner layout: lane j computes column j of X = inv(L) ----------------
+        // ---- inverse of the tile, column-owner layout: lane j computes column j of X = inv(L) -------------------
         //   X[i][j] = (delta_ij - sum_{k<i} L[i][k] X[k][j]) / l_ii ; L[i][k] and 1/l_ii come from lane i by DPP broadcast
         double x[16];
         static_for16([&](auto Ic) {
@@ -268,87 +256,105 @@ __device__ __forceinline__ int factor_block64_tiles(f64x4 (&T)[4][4], double* __
             x[i] = (acc0 + acc1) * bcast16<i>(rinv_own);
         });
         PIORAN_STAMP(8 * s + 2);
-        // publish: inverse -> LDS (A-operand loads) and workspace; L_ss rows -> global (lane = row, DPP row 0 only)
+        // publish to LDS only: L rows in place (lane = row; junk above the diagonal is never read) and the inverse
+        // (lane = column) into a 16 x 16 tile of the block's strictly-upper part, which the algorithm never touches
         if (lk == 0) {
-            double* wsp = ws + s * 256 + lr;                       // X[p][lr], p-major
-            double* lp = blk + (c0 + lr) + (int64_t)c0 * ld;       // L[c0+lr][c0+p]: one column further per p
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                Li[p * 17 + lr] = x[p];
-                wsp[p * 16] = x[p];
-                *lp = r[p];                                        // junk above the diagonal lands in the scratch triangle
-                lp += ld;
+                Ls[(c0 + lr) * LP + c0 + p] = r[p];
+                Ls[(ir0 + p) * LP + ic0 + lr] = x[p];     // X[p][lr]
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         PIORAN_STAMP(8 * s + 3);
-        // ---- 3. rows below the tile: Y_t = inv(L_ss) T[t][0] -------------------------------------------------------
-        // k-step outermost: consecutive MFMAs belong to different tiles, so none waits on its predecessor's result.
+        // ---- rows below the tile on the matrix cores: Y_t = inv(L_ss) A_ts'  (D[row = c][col = r]) ---------------
         double iop[4];   // A operand of k-step ks: inv(L)[row lr][k = 4ks + lk]
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) iop[ks] = Li[lr * 17 + 4 * ks + lk];
-        f64x4 Z[4];
+        for (int ks = 0; ks < 4; ++ks) iop[ks] = Ls[(ir0 + lr) * LP + ic0 + 4 * ks + lk];
+        f64x4 Yt[4];
 #pragma unroll
-        for (int t = 1; t < 4; ++t) Z[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int t = 1; t < 4; ++t) {
+            Yt[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+            if (t > s) {   // wave-uniform
+                f64x4 a;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+                for (int g = 0; g < 4; ++g) a[g] = Ls[(16 * t + lr) * LP + c0 + lk + 4 * g];   // A_ts' in C/D layout
+                f64x4 z = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int t = 1; t < 4; ++t)
-                if (t < m) Z[t] = mfma4(iop[ks], T[t][0][ks], Z[t]);   // reg ks IS the B operand (wave-uniform guard)
+                for (int ks = 0; ks < 4; ++ks) z = mfma4(iop[ks], a[ks], z);                    // reg ks IS the B operand
+                Yt[t] = z;
 #pragma unroll
-        for (int t = 1; t < 4; ++t) T[t][0] = Z[t];
-        PIORAN_STAMP(8 * s + 4);
-        // ---- 4. in-block trailing update: T[r][c] -= X_r X_c' ------------------------------------------------------
-        // each f64 16x16x4 MFMA issues for 64 cycles, so dead tiles are skipped (wave-uniform guards); X_c negated once
-        double nX[4][4];
-#pragma unroll
-        for (int ct = 1; ct < 4; ++ct)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) nX[ct][ks] = -T[ct][0][ks];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int rt = 1; rt < 4; ++rt)
-#pragma unroll
-                for (int ct = 1; ct <= rt; ++ct)
-                    if (rt < m) T[rt][ct] = mfma4(nX[ct][ks], T[rt][0][ks], T[rt][ct]);
-        // ---- 5. store the finished tile column, rename the rest ----------------------------------------------------
-        {
-            double* cp = blk + (c0 + lr) + (int64_t)(c0 + lk) * ld;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int t = 1; t < 4; ++t)
-                    if (t < m) cp[16 * t] = T[t][0][g];
-                cp += 4 * ld;
+                for (int g = 0; g < 4; ++g) Ls[(16 * t + lr) * LP + c0 + lk + 4 * g] = z[g];
             }
         }
+        PIORAN_STAMP(8 * s + 4);
+        // ---- in-block trailing update: A_rc -= X_r X_c', operands straight from the result registers ---------------
+        // X_t as A operand: M[row = c][k] = Y_t[k][c] -> C/D register ks of Y_t; as B operand: B[k][col = r] -> the same.
 #pragma unroll
-        for (int rt = 0; rt < 3; ++rt)
+        for (int rt = 1; rt < 4; ++rt)
 #pragma unroll
-            for (int ct = 0; ct <= rt; ++ct) T[rt][ct] = T[rt + 1][ct + 1];
+            for (int ct = 1; ct <= rt; ++ct)
+                if (ct > s) {   // wave-uniform (then rt > s too)
+                    f64x4 c;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) c[g] = Ls[(16 * rt + lr) * LP + 16 * ct + lk + 4 * g];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) c = mfma4(-Yt[ct][ks], Yt[rt][ks], c);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) Ls[(16 * rt + lr) * LP + 16 * ct + lk + 4 * g] = c[g];
+                }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
         PIORAN_STAMP(8 * s + 5);
+    }
+    // the four inverses -> workspace (row-major 16 x 16 each), 16 entries per lane, coalesced
+    {
+        double v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int idx = e * 64 + lane, sb = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
+            v[e] = Ls[((sb == 3 ? 16 : 0) + i) * LP + (sb == 3 ? 32 : 16 * (sb + 1)) + j];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ws[e * 64 + lane] = v[e];
     }
     PIORAN_STAMP(40);
     return bad;
 }
 
-// First diagonal block (no trailing update precedes it): load as tiles, factor, (factor_block64_tiles stores L).
+// factored block: LDS -> global, lane = row, rows contiguous across lanes.  The strictly-upper part of the slab is
+// scratch (never read as data), so the whole 64 x 64 block is stored without masking.
+__device__ __forceinline__ void store_block_lower(const double* __restrict__ Ls, double* __restrict__ blk, int64_t ld, int lane)
+{
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = Ls[lane * LP + 16 * h + q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) blk[lane + (int64_t)(16 * h + q) * ld] = v[q];
+    }
+}
+
+// First diagonal block (no trailing update precedes it): load, factor, write back.
 __global__ void __launch_bounds__(64) dense_diag0_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ ws,
                                                          int32_t* __restrict__ info)
 {
-    __shared__ double Ld[16 * 17], Li[16 * 17];
-    const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
-    f64x4 T[4][4];
+    __shared__ double Ls[NB * LP];
+    const int lane = threadIdx.x;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int h = 0; h < 4; ++h) {
+        double v[16];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int q = 0; q < 16; ++q) v[q] = A[lane + (int64_t)(16 * h + q) * ld];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                T[rt][ct][g] = ct <= rt ? A[(16 * rt + lr) + (int64_t)(16 * ct + lk + 4 * g) * ld] : 0.0;
-    const int bad = factor_block64_tiles(T, Ld, Li, A, ld, ws, lane);
+        for (int q = 0; q < 16; ++q) Ls[lane * LP + 16 * h + q] = v[q];
+    }
+    __syncthreads();
+    const int bad = factor_block64(Ls, ws, lane);
+    __syncthreads();
+    store_block_lower(Ls, A, ld, lane);
     if (lane == 0 && bad && *info == 0) *info = bad;
 }
 
@@ -424,9 +430,8 @@ __global__ void __launch_bounds__(64) dense_syrk_kernel(double* __restrict__ A, 
 {
     // Lookahead: the workgroup of tile (0,0) — the NEXT diagonal block — keeps its updated tile in LDS and factors
     // it right away (factor_block64), while the other tiles are still being updated; the next panel kernel then
-    // starts from a finished diagonal block.  The block never leaves the registers: the accumulators of this tile
-    // are already the MFMA tiles factor_block64_tiles works on (4.4 KB of LDS for the 16 x 16 patches).
-    __shared__ double Ld[16 * 17], Li[16 * 17];   // diagonal-tile patch and its inverse (factor_block64_tiles)
+    // starts from a finished diagonal block.  33.8 KB of LDS per workgroup still allows 4 workgroups per CU.
+    __shared__ double Ls[NB * LP];
     const int64_t j0 = kb + NB;
     // i tiles 0..nt (the last one holds the y row Mp and 63 scratch rows of the slab), j tiles 0..nt-1, i >= j
     const int nt = (int)((Mp - j0) / NB) + 1;
@@ -502,18 +507,16 @@ __global__ void __launch_bounds__(64) dense_syrk_kernel(double* __restrict__ A, 
                     const int jb = 2 * half + jq;
                     const double v = cv[jq][ib][g] - acc[jb][ib][g];
                     if (diag_next)
-                        acc[jb][ib][g] = v;   // keep the updated tile in place: acc[jb][ib] becomes T[rt = ib][ct = jb]
+                        Ls[(ib * 16 + lr) * LP + jb * 16 + lk + 4 * g] = v;   // row i, column j
                     else
                         C[ib * 16 + (int64_t)(jb * 16 + 4 * g) * ld] = v;
                 }
     }
     if (diag_next) {
-        f64x4 T[4][4];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) T[rt][ct] = acc[ct][rt];
-        const int bad = factor_block64_tiles(T, Ld, Li, A + j0 + j0 * ld, ld, ws, lane);
+        __syncthreads();
+        const int bad = factor_block64(Ls, ws, lane);
+        __syncthreads();
+        store_block_lower(Ls, A + j0 + j0 * ld, ld, lane);
         if (lane == 0 && bad && *info == 0) *info = (int32_t)(j0 + bad);
     }
 }

@@ -16,19 +16,23 @@ __device__ unsigned long long g_st[64];
 
 __global__ void __launch_bounds__(64) probe_kernel(double* A, int64_t ld, double* ws, unsigned long long* out)
 {
-    __shared__ double Ld[16 * 17], Li[16 * 17];
-    const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
+    __shared__ double Ls[NB * LP];
+    const int lane = threadIdx.x;
     PIORAN_STAMP(50);
-    f64x4 T[4][4];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int h = 0; h < 4; ++h) {
+        double v[16];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int q = 0; q < 16; ++q) v[q] = A[lane + (int64_t)(16 * h + q) * ld];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) T[rt][ct][g] = ct <= rt ? A[(16 * rt + lr) + (int64_t)(16 * ct + lk + 4 * g) * ld] : 0.0;
+        for (int q = 0; q < 16; ++q) Ls[lane * LP + 16 * h + q] = v[q];
+    }
+    __syncthreads();
     PIORAN_STAMP(51);
-    const int bad = factor_block64_tiles(T, Ld, Li, A, ld, ws, lane);
+    const int bad = factor_block64(Ls, ws, lane);
+    __syncthreads();
     PIORAN_STAMP(52);
+    store_block_lower(Ls, A, ld, lane);
     PIORAN_STAMP(53);
     if (lane == 0) { for (int i = 0; i < 64; ++i) out[i] = g_st[i]; out[63] = bad; }
 }
