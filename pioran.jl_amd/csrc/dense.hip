@@ -12,14 +12,16 @@
 // Kernels (all fp64):
 //   dense_build      one thread per lower-triangle entry: J x (exp + sincos); transcendental/VALU bound;
 //                    coalesced 8-byte stores along i (algorithmic bytes: 4 N^2 written once).
-//   dense_panel      per 64-column step: every workgroup factors the 64 x 64 diagonal block in LDS (scalar
-//                    16-column sub-panels + MFMA updates inside the block; reports the first non-positive pivot)
-//                    and then solves X L^T = A for its rows entirely on the matrix cores (blocked, with the
-//                    16 x 16 inverses), results staying in accumulator registers between sub-steps.
+//   dense_panel      per 64-column step: the rows below the (already factored) diagonal block, solved
+//                    X L^T = A entirely on the matrix cores (blocked, with the 16 x 16 inverses the factor
+//                    left in the workspace), results staying in accumulator registers between sub-steps.
 //   dense_syrk       trailing update A22 -= P P^T on the matrix cores: v_mfma_f64_16x16x4_f64, one
 //                    64 x 64 output tile per wavefront (16 accumulators), operands straight from L2
 //                    in the MFMA A/B fragment layout; the product is oriented so that the C/D
 //                    fragment's lane index runs along the memory-contiguous row index.
+//                    Workgroup 0 is the critical path: four waves share the tile that is the NEXT diagonal
+//                    block and factor it in LDS right away (factor_block64: DPP column sweeps for the
+//                    16-column sub-panels, MFMA for the in-block update; reports the first non-positive pivot).
 //                    MFMA bound: N^3/3 flop at N = 4096 => 2.3e10 flop (the only dense contraction here).
 //   dense_finish     logdet + z'z reduction -> +NLL.
 #include "../../include/pioran_hip.h"
@@ -170,14 +172,14 @@ __device__ __forceinline__ double readlane_f64(double x, int src)
     return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(x) to fp64 accuracy: v_rsq_f64 + two Newton steps (off the division/sqrt latency chains)
+// 1/sqrt(x) to fp64 accuracy: v_rsq_f64 + ONE third-order step, y (1 + e/2 + 3e^2/8) with e = 1 - x y^2.
+// Four dependent operations instead of the six of two Newton steps: this sits on the per-column critical path of
+// the diagonal-tile factorisation.  (|e| <= 2^-22 after v_rsq_f64 leaves a relative error ~ e^3 < 2^-66.)
 __device__ __forceinline__ double rsqrt_f64(double x)
 {
-    double y = __builtin_amdgcn_rsq(x);
-    const double hx = 0.5 * x;
-    y = fma(y, fma(-hx * y, y, 0.5), y);
-    y = fma(y, fma(-hx * y, y, 0.5), y);
-    return y;
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
 __device__ __forceinline__ f64x4 mfma4(double a, double b, f64x4 c)
@@ -202,149 +204,156 @@ __device__ __forceinline__ double bcast16(double x)
     return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true);
 }
 
-// Factor the 64 x 64 block held row-major (padded) in LDS `Ls`, in place, by ONE wavefront; writes the four
-// 16 x 16 inverses to `ws` (global).  Returns the 1-based index of the first non-positive pivot (0 = none).
+// Factor the 64 x 64 block held row-major (padded) in LDS `Ls`, in place, by a FOUR-wave workgroup (tid 0..255);
+// writes the four 16 x 16 inverses to `ws` (global).  Returns the 1-based index of the first non-positive pivot
+// (0 = none) to every thread.  `flag` is one int of LDS.
 //
-// Per 16-column sub-panel s only the 16 x 16 diagonal tile is scalar work: every DPP row of the wave holds the
-// tile (lane l&15 = tile row), the right-looking Cholesky and the triangular inverse take their cross-lane
-// operands from v_mov_b64_dpp row_newbcast, and the per-column critical path is bcast -> rsqrt -> mul -> fma.
-// Everything below the tile is matrix-core work through LDS: X_t = A_ts inv(L_ss)' for the tiles t > s
-// (transposed C/D layout, the inverse as A operand), then the in-block update A_rc -= X_r X_c'.
-__device__ __forceinline__ int factor_block64(double* __restrict__ Ls, double* __restrict__ ws, int lane)
+// Per 16-column sub-panel s:
+//   wave 0      the whole 64 x 16 sub-panel as ONE right-looking column sweep.  Every DPP row of the wave carries the
+//               16 x 16 diagonal tile (lane l&15 = tile row; r) and, beside it, one more 16-row strip m that goes
+//               through the same column steps: DPP row 0 the identity (Cholesky of [[A, I], [I, *]] leaves
+//               inv(L_ss)' there — lane j ends with column j of the inverse), DPP rows 1..3 the tiles BELOW the
+//               diagonal one, which come out as X_t = A_ts inv(L_ss)' with no triangular solve of their own.
+//               Cross-lane operands come from v_mov_b64_dpp row_newbcast, each shared by the r and the m update;
+//               per-column critical path bcast -> rsqrt -> mul -> fma.  The sweep is issue-bound (about 640
+//               DP instructions); folding the broadcast into v_fmac_f64_dpp was measured slower (DP DPP operands
+//               cost more issue cycles than the shared v_mov_b64_dpp they replace).
+//   waves 1..3  update of the next sub-panel's tiles A_r,s+1 -= X_r X_s+1' on the matrix cores (4 MFMAs per tile)
+//               while wave 0 stores its L rows; then wave 0 goes straight on to the next sweep while waves 1..3
+//               finish the remaining tiles of the in-block update (lookahead).
+__device__ __forceinline__ int factor_block64(double* __restrict__ Ls, double* __restrict__ ws, int* __restrict__ flag,
+                                              int tid)
 {
+    const int lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     int bad = 0;
-    // runtime loop over the four 16-column sub-panels: one copy of the code (instruction cache stays warm after
-    // the first pass), the tile loops inside are static with wave-uniform guards.
+    auto update_tile = [&](int rt, int ct, int c0) {
+        f64x4 c;
+        double ya[4], yb[4];   // X_t as A operand: M[row = c][k] -> X_t[c][k]; as B operand: B[k][col = r] -> the same
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            c[g] = Ls[(16 * rt + lr) * LP + 16 * ct + lk + 4 * g];
+            ya[g] = Ls[(16 * ct + lr) * LP + c0 + lk + 4 * g];
+            yb[g] = Ls[(16 * rt + lr) * LP + c0 + lk + 4 * g];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) c = mfma4(-ya[ks], yb[ks], c);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Ls[(16 * rt + lr) * LP + 16 * ct + lk + 4 * g] = c[g];
+    };
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
         const int c0 = 16 * s;
-        const int ir0 = s == 3 ? 16 : 0, ic0 = s == 3 ? 32 : 16 * (s + 1);   // where inv(L_ss) is parked
         PIORAN_STAMP(8 * s + 0);
-        // ---- 16 x 16 diagonal tile: right-looking Cholesky, lane lr = row (replicated in the 4 DPP rows) -----
-        double r[16];
+        if (wave == 0) {
+            const int ir0 = s == 3 ? 16 : 0, ic0 = s == 3 ? 32 : 16 * (s + 1);   // where inv(L_ss) is parked
+            const int t = s + lk;                 // tile carried in m by this DPP row (lk >= 1); t > 3: nothing
+            const bool has_m = lk == 0 || t < 4;
+            double r[16], m[16];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) r[p] = Ls[(c0 + lr) * LP + c0 + p];
-        double rinv_own = 0.0;   // 1 / l_pp of this lane's row
-        static_for16([&](auto Pc) {
-            constexpr int p = decltype(Pc)::value;
-            const double piv = bcast16<p>(r[p]);
-            if (!(piv > 0.0) && !bad) bad = c0 + p + 1;
-            const double rinv = rsqrt_f64(piv);           // 1 / l_pp
-            r[p] = lr == p ? piv * rinv : r[p] * rinv;    // rows above p hold junk in column p (never used)
-            if (lr == p) rinv_own = rinv;
-            const double nrp = -r[p];
-            static_for16([&](auto Qc) {
-                constexpr int q = decltype(Qc)::value;
-                if constexpr (q > p) r[q] = fma(bcast16<q>(r[p]), nrp, r[q]);   // a_iq -= l_ip l_qp
-            });
-        });
-        PIORAN_STAMP(8 * s + 1);
-        // ---- inverse of the tile, column-owner layout: lane j computes column j of X = inv(L) -------------------
-        //   X[i][j] = (delta_ij - sum_{k<i} L[i][k] X[k][j]) / l_ii ; L[i][k] and 1/l_ii come from lane i by DPP broadcast
-        double x[16];
-        static_for16([&](auto Ic) {
-            constexpr int i = decltype(Ic)::value;
-            double acc0 = lr == i ? 1.0 : 0.0, acc1 = 0.0;
-            static_for16([&](auto Kc) {
-                constexpr int k = decltype(Kc)::value;
-                if constexpr (k < i) {
-                    if constexpr (k & 1) acc1 = fma(-bcast16<i>(r[k]), x[k], acc1);
-                    else acc0 = fma(-bcast16<i>(r[k]), x[k], acc0);
-                }
-            });
-            x[i] = (acc0 + acc1) * bcast16<i>(rinv_own);
-        });
-        PIORAN_STAMP(8 * s + 2);
-        // publish to LDS only: L rows in place (lane = row; junk above the diagonal is never read) and the inverse
-        // (lane = column) into a 16 x 16 tile of the block's strictly-upper part, which the algorithm never touches
-        if (lk == 0) {
+            for (int p = 0; p < 16; ++p) r[p] = Ls[(c0 + lr) * LP + c0 + p];
+            const int mrow = (t < 4 ? 16 * t : c0) + lr;   // (rows past the block: re-read the diagonal tile, result unused)
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                Ls[(c0 + lr) * LP + c0 + p] = r[p];
-                Ls[(ir0 + p) * LP + ic0 + lr] = x[p];     // X[p][lr]
+                const double v = Ls[mrow * LP + c0 + p];
+                m[p] = lk == 0 ? (lr == p ? 1.0 : 0.0) : v;
             }
+            static_for16([&](auto Pc) {
+                constexpr int p = decltype(Pc)::value;
+                const double piv = bcast16<p>(r[p]);
+                if (!(piv > 0.0) && !bad) bad = c0 + p + 1;
+                const double rinv = rsqrt_f64(piv);     // 1 / l_pp
+                r[p] *= rinv;                           // lane p: piv * rinv = l_pp; rows above p: junk, never used
+                m[p] *= rinv;
+                const double nrp = -r[p], nmp = -m[p];
+                static_for16([&](auto Qc) {
+                    constexpr int q = decltype(Qc)::value;
+                    if constexpr (q > p) {
+                        const double lqp = bcast16<q>(r[p]);
+                        r[q] = fma(lqp, nrp, r[q]);     // a_iq -= l_ip l_qp
+                        m[q] = fma(lqp, nmp, m[q]);
+                    }
+                });
+            });
+            // keep the compiler from sinking the m updates into the publish branches below
+#pragma unroll
+            for (int p = 0; p < 16; ++p) asm volatile("" : "+v"(m[p]));
+            PIORAN_STAMP(8 * s + 1);
+            // publish what the other waves wait for: the inverse (lane = column) into a 16 x 16 tile of the block's
+            // strictly-upper part, which the algorithm never touches, and X_t in place
+            if (has_m) {
+                const int base = lk == 0 ? ir0 * LP + ic0 + lr : (16 * t + lr) * LP + c0;
+                const int stride = lk == 0 ? LP : 1;   // X[p][lr] down a column of the parked tile | row lr of X_t
+#pragma unroll
+                for (int p = 0; p < 16; ++p) Ls[base + p * stride] = m[p];
+            }
+            __syncthreads();   // sub-panel s finished and visible; every update tile of the previous sub-panel finished
+            PIORAN_STAMP(8 * s + 2);
+            // the L rows are read by nobody inside the block (only by the final write-back): store them while waves
+            // 1..3 update the next sub-panel's tiles (junk above the diagonal is never read)
+            if (lk == 0) {
+#pragma unroll
+                for (int p = 0; p < 16; ++p) Ls[(c0 + lr) * LP + c0 + p] = r[p];
+            }
+        } else {
+            __syncthreads();
+            // ---- in-block trailing update, first the tiles of the next sub-panel: (rt, s+1), rt = s+1 .. 3 -> wave rt-s
+            const int rt = s + wave;
+            if (s < 3 && rt < 4) update_tile(rt, s + 1, c0);
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         PIORAN_STAMP(8 * s + 3);
-        // ---- rows below the tile on the matrix cores: Y_t = inv(L_ss) A_ts'  (D[row = c][col = r]) ---------------
-        double iop[4];   // A operand of k-step ks: inv(L)[row lr][k = 4ks + lk]
+        // ---- the rest, (rt, ct) with ct >= s+2, on waves 1..3 while wave 0 starts the next sweep ---------------------
+        if (wave > 0) {
+            int idx = 0;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) iop[ks] = Ls[(ir0 + lr) * LP + ic0 + 4 * ks + lk];
-        f64x4 Yt[4];
+            for (int rt = 2; rt < 4; ++rt)
 #pragma unroll
-        for (int t = 1; t < 4; ++t) {
-            Yt[t] = f64x4{0.0, 0.0, 0.0, 0.0};
-            if (t > s) {   // wave-uniform
-                f64x4 a;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) a[g] = Ls[(16 * t + lr) * LP + c0 + lk + 4 * g];   // A_ts' in C/D layout
-                f64x4 z = f64x4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) z = mfma4(iop[ks], a[ks], z);                    // reg ks IS the B operand
-                Yt[t] = z;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) Ls[(16 * t + lr) * LP + c0 + lk + 4 * g] = z[g];
-            }
+                for (int ct = 2; ct <= rt; ++ct)
+                    if (ct >= s + 2) {   // wave-uniform
+                        if (wave == 1 + idx % 3) update_tile(rt, ct, c0);
+                        ++idx;
+                    }
         }
-        PIORAN_STAMP(8 * s + 4);
-        // ---- in-block trailing update: A_rc -= X_r X_c', operands straight from the result registers ---------------
-        // X_t as A operand: M[row = c][k] = Y_t[k][c] -> C/D register ks of Y_t; as B operand: B[k][col = r] -> the same.
-#pragma unroll
-        for (int rt = 1; rt < 4; ++rt)
-#pragma unroll
-            for (int ct = 1; ct <= rt; ++ct)
-                if (ct > s) {   // wave-uniform (then rt > s too)
-                    f64x4 c;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) c[g] = Ls[(16 * rt + lr) * LP + 16 * ct + lk + 4 * g];
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) c = mfma4(-Yt[ct][ks], Yt[rt][ks], c);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) Ls[(16 * rt + lr) * LP + 16 * ct + lk + 4 * g] = c[g];
-                }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        PIORAN_STAMP(8 * s + 5);
     }
-    // the four inverses -> workspace (row-major 16 x 16 each), 16 entries per lane, coalesced
+    if (tid == 0) *flag = bad;
+    __syncthreads();
+    bad = *flag;
+    // the four inverses -> workspace (row-major 16 x 16 each), 4 entries per thread, coalesced
     {
-        double v[16];
+        double v[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int idx = e * 64 + lane, sb = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
+        for (int e = 0; e < 4; ++e) {
+            const int idx = e * 256 + tid, sb = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
             v[e] = Ls[((sb == 3 ? 16 : 0) + i) * LP + (sb == 3 ? 32 : 16 * (sb + 1)) + j];
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) ws[e * 64 + lane] = v[e];
+        for (int e = 0; e < 4; ++e) ws[e * 256 + tid] = v[e];
     }
     PIORAN_STAMP(40);
     return bad;
 }
 
-// factored block: LDS -> global, lane = row, rows contiguous across lanes.  The strictly-upper part of the slab is
-// scratch (never read as data), so the whole 64 x 64 block is stored without masking.
-__device__ __forceinline__ void store_block_lower(const double* __restrict__ Ls, double* __restrict__ blk, int64_t ld, int lane)
+// factored block: LDS -> global by 256 threads: lane = row (rows contiguous across lanes), wave = 16-column strip.
+// The strictly-upper part of the slab is scratch (never read as data), so the block is stored without masking.
+__device__ __forceinline__ void store_block_lower(const double* __restrict__ Ls, double* __restrict__ blk, int64_t ld, int tid)
 {
+    const int lane = tid & 63, h = tid >> 6;
+    double v[16];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        double v[16];
+    for (int q = 0; q < 16; ++q) v[q] = Ls[lane * LP + 16 * h + q];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = Ls[lane * LP + 16 * h + q];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) blk[lane + (int64_t)(16 * h + q) * ld] = v[q];
-    }
+    for (int q = 0; q < 16; ++q) blk[lane + (int64_t)(16 * h + q) * ld] = v[q];
 }
 
 // First diagonal block (no trailing update precedes it): load, factor, write back.
-__global__ void __launch_bounds__(64) dense_diag0_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ ws,
-                                                         int32_t* __restrict__ info)
+__global__ void __launch_bounds__(256) dense_diag0_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ ws,
+                                                          int32_t* __restrict__ info)
 {
     __shared__ double Ls[NB * LP];
-    const int lane = threadIdx.x;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
+    __shared__ int flag;
+    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+    {
         double v[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = A[lane + (int64_t)(16 * h + q) * ld];
@@ -352,24 +361,24 @@ __global__ void __launch_bounds__(64) dense_diag0_kernel(double* __restrict__ A,
         for (int q = 0; q < 16; ++q) Ls[lane * LP + 16 * h + q] = v[q];
     }
     __syncthreads();
-    const int bad = factor_block64(Ls, ws, lane);
+    const int bad = factor_block64(Ls, ws, &flag, tid);
     __syncthreads();
-    store_block_lower(Ls, A, ld, lane);
-    if (lane == 0 && bad && *info == 0) *info = bad;
+    store_block_lower(Ls, A, ld, tid);
+    if (tid == 0 && bad && *info == 0) *info = bad;
 }
 
 // ---- panel solve, all on the matrix cores --------------------------------------------------------------------
-// Rows below the (already factored) diagonal block, 32 rows per wave, kept TRANSPOSED in MFMA C/D layout
+// Rows below the (already factored) diagonal block, 16 RT rows per wave, kept TRANSPOSED in MFMA C/D layout
 // (D[row = column-in-subpanel c][col = row r], so the lane index runs along memory-contiguous rows):
 //   Y_s = inv(L_ss) (A_s' - sum_{s' < s} L[s][s'] Y_s')
 // A operands (blocks of L, the inverses from `ws`) come straight from L2.  Key identity of the f64 layouts:
 // C/D register g of lane l holds D[k = (l>>4) + 4g][col = l&15] and the B operand of k-step ks wants
 // B[k = 4ks + (l>>4)][col = l&15]: with g = ks these are the same element, so a result tile is fed back as the
 // next B operand with no data movement.
+template <int RT>   // 16-row tiles per wave
 __global__ void __launch_bounds__(256) dense_panel_kernel(double* __restrict__ A, int64_t ld, int64_t kb,
                                                           const double* __restrict__ ws)
 {
-    constexpr int RT = 2;   // 16-row tiles per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     const int64_t row0 = kb + NB + ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
@@ -425,25 +434,64 @@ __global__ void __launch_bounds__(256) dense_panel_kernel(double* __restrict__ A
 // result reg g of lane l is D[row (l>>4) + 4g][col l&15]  (f64 layout, cdna_hip_programming.md section 3).
 // With X[row][k] = P[j][k] and Y[k][col] = P[i][k], D[row][col] = (P P^T)[i][j]: col = l&15 runs along i,
 // the memory-contiguous index of the column-major slab, so C loads/stores are 128-byte segments.
-__global__ void __launch_bounds__(64) dense_syrk_kernel(double* __restrict__ A, int64_t ld, int64_t kb, int64_t Mp,
-                                                        double* __restrict__ ws, int32_t* __restrict__ info)
+__global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__ A, int64_t ld, int64_t kb, int64_t Mp,
+                                                         double* __restrict__ ws, int32_t* __restrict__ info)
 {
-    // Lookahead: the workgroup of tile (0,0) — the NEXT diagonal block — keeps its updated tile in LDS and factors
-    // it right away (factor_block64), while the other tiles are still being updated; the next panel kernel then
-    // starts from a finished diagonal block.  33.8 KB of LDS per workgroup still allows 4 workgroups per CU.
+    // Workgroups of four wavefronts.  Workgroup 0 is the critical path: its four waves share tile (0,0) — the NEXT
+    // diagonal block — one 16-column strip each, keep the updated tile in LDS and factor it right away
+    // (factor_block64) while the other tiles are still being updated; the next panel kernel then starts from a
+    // finished diagonal block.  Every other workgroup takes four tiles, one per wavefront.
     __shared__ double Ls[NB * LP];
+    __shared__ int flag;
     const int64_t j0 = kb + NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+
+    if (blockIdx.x == 0) {
+        const double* P0 = A + j0 + kb * ld + lr + (int64_t)lk * ld;   // rows of diagonal block k+1, panel columns
+        f64x4 acc[4];   // [ib], column strip jb = wave
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) acc[ib] = f64x4{0.0, 0.0, 0.0, 0.0};
+        double xa[16], yb[16][4];
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4) {
+            xa[k4] = P0[wave * 16 + (int64_t)(4 * k4) * ld];
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) yb[k4][ib] = P0[ib * 16 + (int64_t)(4 * k4) * ld];
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4)
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+                acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k4], yb[k4][ib], acc[ib], 0, 0, 0);
+        double* C = A + j0 + j0 * ld + lr + (int64_t)lk * ld;
+        double cv[4][4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cv[ib][g] = C[ib * 16 + (int64_t)(wave * 16 + 4 * g) * ld];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                Ls[(ib * 16 + lr) * LP + wave * 16 + lk + 4 * g] = cv[ib][g] - acc[ib][g];   // row i, column j
+        __syncthreads();
+        const int bad = factor_block64(Ls, ws, &flag, tid);
+        __syncthreads();
+        store_block_lower(Ls, A + j0 + j0 * ld, ld, tid);
+        if (tid == 0 && bad && *info == 0) *info = (int32_t)(j0 + bad);
+        return;
+    }
+
     // i tiles 0..nt (the last one holds the y row Mp and 63 scratch rows of the slab), j tiles 0..nt-1, i >= j
     const int nt = (int)((Mp - j0) / NB) + 1;
-    // linear block id -> (ti, tj) with ti >= tj
-    int bid = blockIdx.x;
+    // linear tile id -> (ti, tj) with ti >= tj; tile 0 belongs to workgroup 0
+    const int bid = ((int)blockIdx.x - 1) * 4 + wave + 1;
     int ti = (int)((sqrt(8.0 * bid + 1.0) - 1.0) * 0.5);
     while ((int64_t)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
     while ((int64_t)ti * (ti + 1) / 2 > bid) --ti;
     const int tj = bid - (int)((int64_t)ti * (ti + 1) / 2);
-    if (ti >= nt || tj >= nt - 1) return;
-    const int lane = threadIdx.x;
-    const int lr = lane & 15, lk = lane >> 4;
+    if (ti >= nt || tj >= nt - 1) return;   // wave-uniform; no workgroup barrier below
     const double* Pi = A + (j0 + (int64_t)ti * NB) + kb * ld + lr + (int64_t)lk * ld;  // rows of the i tile
     const double* Pj = A + (j0 + (int64_t)tj * NB) + kb * ld + lr + (int64_t)lk * ld;  // rows of the j tile
     f64x4 acc[4][4];  // [jb][ib]
@@ -452,72 +500,44 @@ __global__ void __launch_bounds__(64) dense_syrk_kernel(double* __restrict__ A, 
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) acc[jb][ib] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-    // operand fragments of 4 k-steps (K = 16 columns of the panel) at a time, double-buffered in registers:
-    // the loads of group g+1 are in flight while the 64 MFMAs of group g issue.
-    double xa[2][4][4], yb[2][4][4];   // [buffer][k-step][16-row strip]
-    auto load_group = [&](int g, int buf) {
+    // operand fragments one k-step (4 panel columns: 4 + 4 doubles per lane) at a time, three buffers deep: the
+    // loads of k-step ks+2 are issued before the 16 MFMAs (1024 issue cycles) of k-step ks.  With the 128
+    // accumulator registers this stays under 256 registers per lane, so two wavefronts share a SIMD and the
+    // second one hides whatever latency is left (launch bounds below).
+    double xa[3][4], yb[3][4];   // [buffer][16-row strip]
+    auto load_kstep = [&](int ks, int buf) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx) {
-                const int64_t off = sidx * 16 + (int64_t)(16 * g + 4 * ks) * ld;
-                xa[buf][ks][sidx] = Pj[off];  // X[row][k] = P[j][k]
-                yb[buf][ks][sidx] = Pi[off];  // Y[k][col] = P[i][k]
-            }
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int64_t off = sidx * 16 + (int64_t)(4 * ks) * ld;
+            xa[buf][sidx] = Pj[off];  // X[row][k] = P[j][k]
+            yb[buf][sidx] = Pi[off];  // Y[k][col] = P[i][k]
+        }
     };
-    auto mma_group = [&](int buf) {
+    load_kstep(0, 0);
+    load_kstep(1, 1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < 16; ++ks) {
+        if (ks + 2 < 16) load_kstep(ks + 2, (ks + 2) % 3);
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-                for (int ib = 0; ib < 4; ++ib)
-                    acc[jb][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[buf][ks][jb], yb[buf][ks][ib], acc[jb][ib], 0, 0, 0);
-    };
-    load_group(0, 0);
-    load_group(1, 1);
-    mma_group(0);
-    load_group(2, 0);
-    mma_group(1);
-    load_group(3, 1);
-    mma_group(0);
-    mma_group(1);
-
-    // C -= acc, in two halves of 32 entries per lane: all loads of a half in flight before the first store
-    double* C = A + (j0 + (int64_t)ti * NB) + (j0 + (int64_t)tj * NB) * ld + lr + (int64_t)lk * ld;
-    const bool diag_next = bid == 0;   // tile (0,0)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        double cv[2][4][4];
-#pragma unroll
-        for (int jq = 0; jq < 2; ++jq)
+        for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int jb = 2 * half + jq;
-                    cv[jq][ib][g] = C[ib * 16 + (int64_t)(jb * 16 + 4 * g) * ld];   // D row (l>>4)+4g -> j, col l&15 -> i
-                }
-#pragma unroll
-        for (int jq = 0; jq < 2; ++jq)
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int jb = 2 * half + jq;
-                    const double v = cv[jq][ib][g] - acc[jb][ib][g];
-                    if (diag_next)
-                        Ls[(ib * 16 + lr) * LP + jb * 16 + lk + 4 * g] = v;   // row i, column j
-                    else
-                        C[ib * 16 + (int64_t)(jb * 16 + 4 * g) * ld] = v;
-                }
+                acc[jb][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks % 3][jb], yb[ks % 3][ib], acc[jb][ib], 0, 0, 0);
     }
-    if (diag_next) {
-        __syncthreads();
-        const int bad = factor_block64(Ls, ws, lane);
-        __syncthreads();
-        store_block_lower(Ls, A + j0 + j0 * ld, ld, lane);
-        if (lane == 0 && bad && *info == 0) *info = (int32_t)(j0 + bad);
+
+    // C -= acc, one 16-column strip (16 entries per lane) at a time: its loads are all in flight before the first store
+    double* C = A + (j0 + (int64_t)ti * NB) + (j0 + (int64_t)tj * NB) * ld + lr + (int64_t)lk * ld;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        double cv[4][4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cv[ib][g] = C[ib * 16 + (int64_t)(jb * 16 + 4 * g) * ld];   // D row (l>>4)+4g -> j, col l&15 -> i
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) C[ib * 16 + (int64_t)(jb * 16 + 4 * g) * ld] = cv[ib][g] - acc[jb][ib][g];
     }
 }
 
@@ -573,14 +593,20 @@ int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double*
     launch_build(N, Mp, ld, J, a, b, c, d, t, y, s2, K, sorted, stream);
     if (hipMemsetAsync(info, 0, sizeof(int32_t), stream) != hipSuccess) return PIORAN_ERR_HIP;
     double* ws = K + (size_t)ld * (size_t)Mp;   // WS_DOUBLES doubles right behind the slab
-    hipLaunchKernelGGL(dense_diag0_kernel, dim3(1), dim3(64), 0, stream, K, ld, ws, info);
+    hipLaunchKernelGGL(dense_diag0_kernel, dim3(1), dim3(256), 0, stream, K, ld, ws, info);
     for (int64_t kb = 0; kb < Mp; kb += NB) {
         // rows below the block: kb+NB .. Mp+63 (the y row Mp and the scratch rows of its 64-row tile)
         const int64_t below = Mp - kb;
-        hipLaunchKernelGGL(dense_panel_kernel, dim3((unsigned)((below + 127) / 128)), dim3(256), 0, stream, K, ld, kb, ws);
+        // one 16-row strip per wave while that still fills the chip's 1024 SIMDs at most a few times over (the step
+        // is latency-bound: 40 dependent-ish MFMAs per strip); two strips per wave beyond
+        if (below <= 65536)
+            hipLaunchKernelGGL(dense_panel_kernel<1>, dim3((unsigned)((below + 63) / 64)), dim3(256), 0, stream, K, ld, kb, ws);
+        else
+            hipLaunchKernelGGL(dense_panel_kernel<2>, dim3((unsigned)((below + 127) / 128)), dim3(256), 0, stream, K, ld, kb, ws);
         const int64_t nt = (Mp - kb - NB) / NB + 1;
         if (nt > 1)
-            hipLaunchKernelGGL(dense_syrk_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(64), 0, stream, K, ld, kb, Mp, ws, info);
+            hipLaunchKernelGGL(dense_syrk_kernel, dim3((unsigned)(1 + (nt * (nt + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
+                               kb, Mp, ws, info);
     }
     hipLaunchKernelGGL(dense_finish_kernel, dim3(1), dim3(256), 0, stream, K, ld, N, Mp, out, info);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;

@@ -14,13 +14,13 @@ __device__ unsigned long long g_st[64];
 #include <cstdio>
 #include <vector>
 
-__global__ void __launch_bounds__(64) probe_kernel(double* A, int64_t ld, double* ws, unsigned long long* out)
+__global__ void __launch_bounds__(256) probe_kernel(double* A, int64_t ld, double* ws, unsigned long long* out)
 {
     __shared__ double Ls[NB * LP];
-    const int lane = threadIdx.x;
+    __shared__ int flag;
+    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
     PIORAN_STAMP(50);
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
+    {
         double v[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = A[lane + (int64_t)(16 * h + q) * ld];
@@ -29,12 +29,12 @@ __global__ void __launch_bounds__(64) probe_kernel(double* A, int64_t ld, double
     }
     __syncthreads();
     PIORAN_STAMP(51);
-    const int bad = factor_block64(Ls, ws, lane);
+    const int bad = factor_block64(Ls, ws, &flag, tid);
     __syncthreads();
     PIORAN_STAMP(52);
-    store_block_lower(Ls, A, ld, lane);
+    store_block_lower(Ls, A, ld, tid);
     PIORAN_STAMP(53);
-    if (lane == 0) { for (int i = 0; i < 64; ++i) out[i] = g_st[i]; out[63] = bad; }
+    if (tid == 0) { for (int i = 0; i < 64; ++i) out[i] = g_st[i]; out[63] = bad; }
 }
 
 int main()
@@ -46,17 +46,26 @@ int main()
     double *dA, *dws; unsigned long long* dout;
     hipMalloc(&dA, sizeof(double) * ld * n); hipMalloc(&dws, sizeof(double) * 2048); hipMalloc(&dout, 64 * 8);
     unsigned long long st[64];
+    std::vector<double> L(ld * n);
     for (int rep = 0; rep < 3; ++rep) {
         hipMemcpy(dA, h.data(), sizeof(double) * ld * n, hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, 0, dA, (int64_t)ld, dws, dout);
+        hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(256), 0, 0, dA, (int64_t)ld, dws, dout);
         hipMemcpy(st, dout, sizeof(st), hipMemcpyDeviceToHost);
     }
+    hipMemcpy(L.data(), dA, sizeof(double) * ld * n, hipMemcpyDeviceToHost);
+    // residual of L L' against the input (lower triangle)
+    double err = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k <= j; ++k) acc += L[i + k * ld] * L[j + k * ld];
+            err = fmax(err, fabs(acc - h[i + j * ld]));
+        }
     auto d = [&](int a, int b) { return (long long)(st[b] - st[a]); };
-    printf("load->LDS %lld | factor %lld | writeback %lld  (cycles, 100 MHz ticks? see clock) bad=%llu\n", d(50, 51), d(51, 52), d(52, 53), st[63]);
+    printf("load->LDS %lld | factor %lld | writeback %lld  (shader clock cycles) bad=%llu  max|LL'-A|=%.3e\n", d(50, 51),
+           d(51, 52), d(52, 53), st[63], err);
     for (int s = 0; s < 4; ++s)
-        printf(" s=%d: load tile %lld | chol16 ... | inverse %lld | publish %lld | trsm-mfma %lld | update-mfma %lld\n", s,
-               d(8 * s + 0, 8 * s + 1), d(8 * s + 1, 8 * s + 2), d(8 * s + 2, 8 * s + 3), s < 3 ? d(8 * s + 3, 8 * s + 4) : 0,
-               s < 3 ? d(8 * s + 4, 8 * s + 5) : 0);
-    printf(" (first column = tile load + 16x16 cholesky)\n");
+        printf(" s=%d: sub-panel sweep (wave 0) %lld | publish + barrier %lld | next-sub-panel tiles + barrier %lld\n", s,
+               d(8 * s + 0, 8 * s + 1), d(8 * s + 1, 8 * s + 2), d(8 * s + 2, 8 * s + 3));
     return 0;
 }
