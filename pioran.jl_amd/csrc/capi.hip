@@ -122,11 +122,24 @@ int set_rowmap(pioran_ds* ds, const std::vector<int32_t>& rm)
     return PIORAN_OK;
 }
 
+// Register-resident scan: small shared-table batches take the latency layout (celerite_wide.hip, one draw per
+// workgroup), everything else the throughput layouts (celerite_scan.hip).  PIORAN_SCAN_CONFIG=wide forces the former
+// for any batch size, any other value names a throughput configuration; PIORAN_NO_WIDE=1 disables the former.
+int scan_dispatch(const ScanParams& p, hipStream_t stream)
+{
+    const char* cfg = std::getenv("PIORAN_SCAN_CONFIG");
+    const bool force_wide = cfg && !std::strcmp(cfg, "wide");
+    // (below 16 rows the per-step exchange of the latency layout costs more than the whole step of a throughput layout)
+    const bool auto_wide = !cfg && p.B <= pioran_wide_max_batch() && p.R >= 16 && !std::getenv("PIORAN_NO_WIDE");
+    if (p.tab && p.R <= pioran_wide_supported_rows() && (force_wide || auto_wide)) return pioran_launch_scan_wide(p, stream);
+    return pioran_launch_scan(p, stream);
+}
+
 int launch(pioran_ds* ds, ScanParams& p)
 {
     pioran_ctx* ctx = ds->ctx;
     if (p.R <= pioran_scan_supported_rows() && !std::getenv("PIORAN_FORCE_FALLBACK")) {
-        int rc = pioran_launch_scan(p, ctx->stream);
+        int rc = scan_dispatch(p, ctx->stream);
         if (rc != PIORAN_ERR_UNSUPPORTED) {
             if (rc == PIORAN_ERR_HIP) ctx->last_err = "scan kernel launch failed";
             return rc;
@@ -447,7 +460,7 @@ static int batch_host_mixed(pioran_ds* ds, int64_t B, int64_t J, const double* A
         p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
         p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
         p.npd_rows = 2 * ds->npd_terms;
-        rc = pioran_launch_scan(p, ctx->stream);
+        rc = scan_dispatch(p, ctx->stream);
         if (rc) { ctx->last_err = "mixed-mode scan launch failed"; return rc; }
         HIPCHK(ctx, hipMemcpyAsync(out + b0, ctx->bout.p, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (status) HIPCHK(ctx, hipMemcpyAsync(status + b0, ctx->bst.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -1,0 +1,362 @@
+// Latency layout of the celerite scan for SMALL batches (gfx950): one draw per workgroup of four wavefronts.
+//
+// Same recurrence as celerite_scan.hip (init_semi_separable! + the forward half of solve_prec!,
+// src/celerite_solver.jl:12-100,115-142, logl :312-334):
+//   S <- (phi phi') o (S + D w w') ;  q = S u ;  D_n = sum(a) + sigma2_n - u'q ;  w = (v - q) / D_n
+// with y carried as one more row (u = 0, v = y_n - mu, phi = 1), so z_n = v_y - q_y needs no recurrence of its own.
+//
+// celerite_scan.hip is built for throughput: 16..64 lanes per draw, 36..75 entries of S per lane, thousands of
+// draws in flight to hide every latency.  With a handful of draws (the scalar `logl` drop-in, MCMC walkers) a time
+// step is one long dependent chain on a single wavefront.  Here a draw gets 256 lanes arranged as 16 x 16:
+//   DPP row g (16 of them over 4 waves) = ROW block g of S;  lane l inside the row = COLUMN block l;
+//   RPL x RPL entries of S per lane (RPL <= 5: up to 79 rows + the y row).
+// Consequences:
+//   * q = S u is a sum over the 16 lanes of a DPP row: four DPP butterfly stages, no LDS, no ds_bpermute;
+//   * u and phi of the lane's column block are table data: the lane loads them itself (no broadcast);
+//   * the only exchange per step is through LDS, ONE barrier: each DPP row publishes (v - q) of its RPL rows and its
+//     share of u'q; every lane then reads the 16 shares (fixed summation order: all waves get the same bits),
+//     forms D_n and its reciprocal, and the RPL values w_k = (v - q)_k / D_n of its column block.
+//     Buffers alternate with the step parity, which makes the single barrier sufficient.
+//   * the table records are prefetched several steps ahead (a ring of register buffers): a lone workgroup keeps
+//     nothing else in flight, and at small B the 10 MB table is not L2 resident, so every record is an HBM-latency
+//     miss that only depth can hide.
+// Shared-table launches only ((c, d) common to the batch, possibly with a few per-draw rows: mixed mode); launches
+// with fully per-draw (c, d) stay on celerite_scan.hip.
+#include "common.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+// Diagnostic hooks: compiled out in the product; tools/wide_probe.hip defines them to s_memtime accumulators.
+#ifndef PIORAN_WSTAMP
+#define PIORAN_WSTAMP(i)
+#define PIORAN_WSTAMP_DECL
+#define PIORAN_WSTAMP_FLUSH
+#endif
+
+namespace {
+
+template <int I>
+using ic = std::integral_constant<int, I>;
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (B < E) {
+        f(ic<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the 16 lanes of a DPP row; every lane gets the bit-identical total
+__device__ __forceinline__ double row16_sum(double x)
+{
+    x += dpp_perm<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_perm<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_perm<0x141>(x);  // row_half_mirror
+    x += dpp_perm<0x140>(x);  // row_mirror
+    return x;
+}
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+
+// 1/x to fp64 accuracy: v_rcp_f64 seed + two Newton steps (same sequence as celerite_scan.hip)
+__device__ __forceinline__ double recip_f64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+template <int RPL>
+struct WideIn {   // what one time step reads: (v, x, phi) of the lane's row block and of its column block, y_n, sigma2_n
+    double rv[RPL], rx[RPL], rp[RPL], cv[RPL], cx[RPL], cp[RPL], y, s2;
+};
+
+template <int RPL>
+struct Slots {    // per-lane description of RPL consecutive row slots
+    int ov[RPL], ox[RPL], op[RPL];   // positions (in doubles) of v, x, phi inside the staged step record
+    double al[RPL], be[RPL];         // u = al v + be x
+};
+
+// Staged record of one time step (LDS), L = RS + 3 npd_rows doubles: the shared part of the table record
+// [v x Rp | x x Rp | phi x Rp | y_n, sigma2_n] (RS = 3 Rp + 2) followed by THIS draw's per-draw rows
+// [row][v, x, phi] (mixed mode), which sit at RS + 3 (b npd_rows + row) in the table record.
+template <int RPL>
+__device__ __forceinline__ void describe_slots(const ScanParams& p, int64_t b, int block, Slots<RPL>& s)
+{
+    const int R = p.R, Rp = R + 2, J = p.J, RS = 3 * Rp + 2;
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const int slot = block * RPL + i;
+        int trow;
+        s.al[i] = 0.0;
+        s.be[i] = 0.0;
+        int pdrow = -1;
+        if (slot < R) {
+            const int rm = p.rowmap[slot];
+            const int term = rm & 0xfffff;
+            const bool ks = (rm >> 30) & 1;
+            if ((rm >> 29) & 1) pdrow = (rm >> 20) & 0x1ff;
+            const double a = p.A[b * J + term], bb = p.Bc[b * J + term];
+            // cos row: v = co, x = si, u = a co + b si ; sin row: v = si, x = co, u = a si - b co   (:59-63)
+            trow = slot;
+            s.al[i] = a;
+            s.be[i] = ks ? -bb : bb;
+        } else if (slot == 16 * RPL - 1) {
+            trow = R + 1;   // the y row: u = 0, v = y_n - mu, phi = 1
+        } else {
+            trow = R;       // inert padding row: u = 0, v = 1, phi = 1
+        }
+        if (pdrow >= 0) {
+            s.ov[i] = RS + pdrow * 3;
+            s.ox[i] = s.ov[i] + 1;
+            s.op[i] = s.ov[i] + 2;
+        } else {
+            s.ov[i] = trow;
+            s.ox[i] = trow + Rp;
+            s.op[i] = trow + 2 * Rp;
+        }
+    }
+}
+
+constexpr int kWideMaxRecord = 512;   // staged doubles per step: two per thread
+
+template <int RPL>
+__global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams p)
+{
+    constexpr int YS = RPL - 1;                       // slot of the y row inside row / column block 15
+    constexpr int DG = 4;                             // records in flight from HBM per thread
+    const int tid = threadIdx.x;
+    const int g = tid >> 4;                           // row block (DPP row of the draw)
+    const int l = tid & 15;                           // column block
+    const int64_t b = blockIdx.x;                     // grid = batch
+    const int64_t N = p.N;
+    const int J = p.J, Rp = p.R + 2, RS = 3 * Rp + 2;
+    const int L = RS + 3 * p.npd_rows;                // staged doubles per step (<= kWideMaxRecord, checked on the host)
+
+    __shared__ double sh_rec[2][kWideMaxRecord];      // staged records, by step parity
+    __shared__ double sh_num[2][16 * RPL];            // (v - q) of every row = D_n w
+    __shared__ double sh_uq[2][16];                   // u'q share of every row block
+
+    Slots<RPL> rs_, cs_;
+    describe_slots<RPL>(p, b, g, rs_);
+    describe_slots<RPL>(p, b, l, cs_);
+    double suma = 0.0;  // :21
+    for (int j = 0; j < J; ++j) suma += p.A[b * J + j];
+    const double mu = p.mu ? p.mu[b] : 0.0;
+    const double nu = p.nu ? p.nu[b] : 1.0;
+    const bool has_nu = p.nu != nullptr;
+    const bool yrow = g == 15;                        // this lane's row slot YS is the y row
+    const bool ycol = l == 15;                        // ... column slot YS
+
+    // ---- HBM -> registers -> LDS staging: thread `tid` owns elements tid and tid + 256 of every staged record -------
+    // element e < RS comes from table element e, e >= RS from this draw's per-draw rows; with a per-draw series
+    // (Y, S2) the two elements y_n, sigma2_n come from there instead.  One 8-byte load per thread and step (two when
+    // L > 256) instead of 6 RPL + 2 broadcast-heavy loads per lane: the texture path, not HBM, was the bottleneck.
+    const bool two = L > 256;                         // uniform
+    const double* src[2];
+    int64_t stride[2], last[2];                       // address = src + min(n, last) * stride
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = tid + 256 * h;
+        src[h] = p.tab + (e < RS ? e : e + (int64_t)b * p.npd_rows * 3);
+        stride[h] = p.rec_stride;
+        last[h] = N;                                  // the table holds N + 1 records
+        if (p.Y && (e == 3 * Rp || e == 3 * Rp + 1)) {
+            src[h] = (e == 3 * Rp ? p.Y : p.S2) + b * N;
+            stride[h] = 1;
+            last[h] = N - 1;
+        }
+        if (e >= L) { src[h] = p.tab; stride[h] = 0; }   // idle thread: harmless re-read of element 0
+    }
+    double gv[DG][2];                                 // record m is (or will be) in gv[m % DG]
+    auto fetch = [&](int64_t m, double (&dst)[2]) __attribute__((always_inline)) {
+        dst[0] = src[0][(m < last[0] ? m : last[0]) * stride[0]];
+        if (two) dst[1] = src[1][(m < last[1] ? m : last[1]) * stride[1]];
+    };
+    auto stage = [&](int par, const double (&v)[2]) __attribute__((always_inline)) {
+        sh_rec[par][tid] = v[0];
+        if (two) sh_rec[par][tid + 256] = v[1];
+    };
+    auto unstage = [&](int par, WideIn<RPL>& in) __attribute__((always_inline)) {
+        const double* r = sh_rec[par];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            in.rv[i] = r[rs_.ov[i]];
+            in.rx[i] = r[rs_.ox[i]];
+            in.rp[i] = r[rs_.op[i]];
+            in.cv[i] = r[cs_.ov[i]];
+            in.cx[i] = r[cs_.ox[i]];
+            in.cp[i] = r[cs_.op[i]];
+        }
+        in.y = r[3 * Rp];
+        in.s2 = r[3 * Rp + 1];
+    };
+
+#pragma unroll
+    for (int m = 0; m < DG; ++m) fetch(m, gv[m]);
+    WideIn<RPL> cur[2];                               // record m is consumed from cur[m & 1]
+    stage(0, gv[0]);
+    fetch(DG, gv[0]);
+    __syncthreads();
+    unstage(0, cur[0]);
+
+    // ---- first row, :27-42 and :126-128 ----
+    double S[RPL][RPL];   // [own row][own column]
+#pragma unroll
+    for (int i = 0; i < RPL; ++i)
+#pragma unroll
+        for (int c = 0; c < RPL; ++c) S[i][c] = 0.0;
+    double num[RPL];      // (v - q) of this lane's rows at the last step = D_n W_n, the `dn` of :73
+    double wc[RPL];       // W_n of this lane's columns
+    double Dn = suma + (has_nu ? nu * cur[0].s2 : cur[0].s2);
+    double rD = recip_f64(Dn);
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const double v0r = (yrow && i == YS) ? cur[0].y - mu : cur[0].rv[i];   // z_1 = y_1      :128
+        const double v0c = (ycol && i == YS) ? cur[0].y - mu : cur[0].cv[i];
+        num[i] = v0r;
+        wc[i] = v0c * rD;
+    }
+    double Pm = Dn;       // running product of |D| (sign of D_1 kept: log of a negative D_1 is NaN, :126)
+    int Pe = 0;
+    {
+        int ex;
+        Pm = frexp(Pm, &ex);
+        Pe += ex;
+    }
+    double quad = num[YS] * num[YS] * rD;             // meaningful in the y-row lanes only
+    bool nonpd = !(Dn > 0.0);
+    // record 1 for the first step of the loop
+    stage(1, gv[1 % DG]);
+    fetch(DG + 1, gv[1 % DG]);
+    __syncthreads();
+    unstage(1, cur[1]);
+
+    PIORAN_WSTAMP_DECL
+    // one time step n: consumes `in` (record n); stages record n + 1 (fetched DG - 1 steps ago) for the next step
+    // and refills its register slot with record n + 1 + DG
+    auto do_step = [&](int64_t n, WideIn<RPL>& in, WideIn<RPL>& nxt, double (&gslot)[2]) __attribute__((always_inline)) {
+        PIORAN_WSTAMP(0);
+        double ur[RPL], uc[RPL], qt[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            ur[i] = rs_.al[i] * in.rv[i] + rs_.be[i] * in.rx[i];
+            uc[i] = cs_.al[i] * in.cv[i] + cs_.be[i] * in.cx[i];
+            qt[i] = 0.0;
+        }
+        if (yrow) in.rv[YS] = in.y - mu;
+        // ---- S update + this lane's share of q = S u ----
+#pragma unroll
+        for (int c = 0; c < RPL; ++c)
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const double m = fma(num[i], wc[c], S[i][c]);     // S + dn * V[k,n-1]          :78
+                const double sn = (in.rp[i] * in.cp[c]) * m;      // phi_j phi_k ( ... )        :78,85
+                S[i][c] = sn;
+                qt[i] = fma(sn, uc[c], qt[i]);                    // (S u)_j                    :80-82,86-89
+            }
+        PIORAN_WSTAMP(1);
+        double sp = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            qt[i] = row16_sum(qt[i]);                             // over the 16 column blocks
+            num[i] = in.rv[i] - qt[i];                            // :89
+            sp = fma(ur[i], qt[i], sp);                           // this row block's share of u'Su   :83,88
+        }
+        PIORAN_WSTAMP(2);
+        // ---- the one exchange of the step (+ the next record on its way through LDS) ----
+        const int par = (int)(n & 1);
+        if (l == 0) {
+            sh_uq[par][g] = sp;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) sh_num[par][g * RPL + i] = num[i];
+        }
+        stage(par ^ 1, gslot);
+        fetch(n + 1 + DG, gslot);
+        __syncthreads();
+        PIORAN_WSTAMP(3);
+        double sh[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sh[k] = sh_uq[par][k];
+        double nc[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) nc[i] = sh_num[par][l * RPL + i];
+        unstage(par ^ 1, nxt);
+        const double s = (((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]))) +
+                         (((sh[8] + sh[9]) + (sh[10] + sh[11])) + ((sh[12] + sh[13]) + (sh[14] + sh[15])));
+        PIORAN_WSTAMP(4);
+        Dn = suma + (has_nu ? nu * in.s2 : in.s2) - s;           // :92
+        rD = recip_f64(Dn);
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) wc[i] = nc[i] * rD;        // :96
+        PIORAN_WSTAMP(5);
+        const double z = num[YS];                                // y row: z_n = y_n - u'f      :141
+        nonpd |= !(Dn > 0.0);
+        Pm *= fabs(Dn);                                          // log(abs(D[n]))  :140
+        {                                                        // mantissa/exponent split
+            int ex;
+            Pm = frexp(Pm, &ex);
+            Pe += ex;
+        }
+        quad = fma(z * z, rD, quad);                             // z_n^2 / D_n  (== y'K^-1 y, :333)
+        PIORAN_WSTAMP(6);
+    };
+
+    int64_t n = 1;
+    // unrolled by DG (even) so that the register slots are compile-time constants: at the loop top n = 1 (mod DG);
+    // step n + k consumes cur[(1 + k) & 1] and stages record n + k + 1 out of gv[(2 + k) % DG]
+    for (; n + DG - 1 < N; n += DG)
+        static_for<0, DG>([&](auto Kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(Kc)::value;
+            do_step(n + k, cur[(1 + k) & 1], cur[k & 1], gv[(2 + k) % DG]);
+        });
+    static_for<0, DG - 1>([&](auto Kc) __attribute__((always_inline)) {   // the last N - n < DG steps
+        constexpr int k = decltype(Kc)::value;
+        if (n + k < N) do_step(n + k, cur[(1 + k) & 1], cur[k & 1], gv[(2 + k) % DG]);
+    });
+
+    PIORAN_WSTAMP_FLUSH
+    if (yrow && l == 0) {
+        const double logdet = log(Pm) + (double)Pe * 0.6931471805599453094;
+        const double res = -0.5 * logdet - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * quad;
+        p.out[b] = res;
+        if (p.status) p.status[b] = !isfinite(res) ? 2 : (nonpd ? 1 : 0);
+    }
+}
+
+}  // namespace
+
+int pioran_wide_supported_rows() { return 79; }
+
+// Batches up to this size take the latency layout (at most one workgroup per CU on the chip's 256 CUs).
+int64_t pioran_wide_max_batch() { return 256; }
+
+int pioran_launch_scan_wide(const ScanParams& p, hipStream_t stream)
+{
+    if (!p.tab || p.R > 79 || p.B <= 0 || p.B > 0x7fffffffLL) return PIORAN_ERR_UNSUPPORTED;
+    if (3 * (p.R + 2) + 2 + 3 * p.npd_rows > kWideMaxRecord) return PIORAN_ERR_UNSUPPORTED;   // staged record too long
+    const dim3 grid((unsigned)p.B), block(256);
+    if (p.R <= 15) hipLaunchKernelGGL(celerite_wide_kernel<1>, grid, block, 0, stream, p);
+    else if (p.R <= 31) hipLaunchKernelGGL(celerite_wide_kernel<2>, grid, block, 0, stream, p);
+    else if (p.R <= 47) hipLaunchKernelGGL(celerite_wide_kernel<3>, grid, block, 0, stream, p);
+    else if (p.R <= 63) hipLaunchKernelGGL(celerite_wide_kernel<4>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(celerite_wide_kernel<5>, grid, block, 0, stream, p);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}

@@ -12,7 +12,7 @@
 // layout of the shared per-step table ("trig/phi table"):
 //   record n (n <= N, the last one a readable copy of N-1) = [ v_r | x_r | phi_r | y_n sigma2_n ], r < R + 2:
 //   cos row (v, x) = (cos, sin)(d_j t_n), sin row (sin, cos); phi = exp(-c_j (t_n - t_{n-1}));
-//   row R is the inert padding row (1, 0, 0), row R+1 the y row (0, 0, 1).
+//   row R is the inert padding row (v, x, phi) = (1, 0, 1), row R+1 the y row (0, 0, 1).
 struct ScanParams {
     int64_t N;            // time stamps
     int32_t J;            // celerite terms
@@ -45,6 +45,10 @@ struct ScanParams {
 int pioran_launch_scan(const ScanParams& p, hipStream_t stream);
 int pioran_scan_supported_rows();
 const char* pioran_scan_config_name(int R);
+// celerite_wide.hip: latency layout for small batches (one draw per workgroup); shared-table launches only
+int pioran_launch_scan_wide(const ScanParams& p, hipStream_t stream);
+int pioran_wide_supported_rows();
+int64_t pioran_wide_max_batch();
 // celerite_fallback.hip
 int pioran_launch_scan_fallback(const ScanParams& p, hipStream_t stream);
 size_t pioran_fallback_scratch_doubles(int R);

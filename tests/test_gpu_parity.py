@@ -102,8 +102,18 @@ def _random_case(rng, N, J, B, per_draw_cd=False):
     return t, y, s2, A, Bc, C, Dd, mu, nu
 
 
+@pytest.fixture(params=["throughput", "latency"])
+def layout(request):
+    """Small batches (B <= 256) take the one-draw-per-workgroup latency layout by default; PIORAN_NO_WIDE=1 sends
+    them through the throughput layouts (the ones large batches use), so both are checked on the same inputs."""
+    if request.param == "throughput":
+        os.environ["PIORAN_NO_WIDE"] = "1"
+    yield request.param
+    os.environ.pop("PIORAN_NO_WIDE", None)
+
+
 @pytest.mark.parametrize("J", [1, 2, 3, 5, 8, 10, 13, 16, 20, 21, 24, 27, 32, 40])
-def test_random_batches_shared_cd(ctx, J):
+def test_random_batches_shared_cd(ctx, J, layout):
     """Every register-resident kernel configuration (R = 2J = 2..80) + ragged batch sizes."""
     rng = np.random.default_rng(100 + J)
     N, B = 257, 37
@@ -116,7 +126,7 @@ def test_random_batches_shared_cd(ctx, J):
 
 
 @pytest.mark.parametrize("J", [2, 7, 20, 30])
-def test_random_batches_per_draw_cd(ctx, J):
+def test_random_batches_per_draw_cd(ctx, J, layout):
     rng = np.random.default_rng(200 + J)
     N, B = 130, 19
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B, per_draw_cd=True)
@@ -138,7 +148,7 @@ def test_fallback_any_rank(ctx, J):
     assert relerr(got, ref) < 1e-11
 
 
-def test_real_terms_row_compaction(ctx):
+def test_real_terms_row_compaction(ctx, layout):
     """Exp / DRW terms (b = d = 0): their zero sin rows are dropped; result must equal the full-rank oracle."""
     rng = np.random.default_rng(7)
     N, B, J = 200, 9, 12
@@ -151,7 +161,7 @@ def test_real_terms_row_compaction(ctx):
     assert relerr(got, ref) < 1e-11
 
 
-def test_edge_sizes(ctx):
+def test_edge_sizes(ctx, layout):
     rng = np.random.default_rng(11)
     for N in (1, 2, 3):
         t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, 4, 3)
@@ -187,9 +197,10 @@ def test_all_kernel_configs_agree(ctx):
     try:
         for name in ("rpl3_cbr2_nsrc7_p", "rpl3_cbr2_nsrc8_p", "rpl3_cbr2_nsrc7", "rpl3_cbr2_nsrc8", "rpl3_cbr2_nsrc7_c", "rpl3_cbr4_nsrc4", "rpl4_cbr4_nsrc4",
                      "rpl4_cbr4_nsrc4_c", "rpl4_cbr4_nsrc4_asm", "rpl4_cbr4_nsrc4_asm_w2", "rpl5_cbr4_nsrc4",
-                     "rpl5_cbr4_nsrc4_c"):
+                     "rpl5_cbr4_nsrc4_c", "wide"):
             os.environ["PIORAN_SCAN_CONFIG"] = name
-            assert pj._lib.lib().pioran_celerite_config_name(40).decode() == name
+            if name != "wide":   # ("wide" = the latency layout of celerite_wide.hip, not an entry of the scan table)
+                assert pj._lib.lib().pioran_celerite_config_name(40).decode() == name
             got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
             assert relerr(got, ref) < 1e-11, name
         os.environ["PIORAN_FORCE_FALLBACK"] = "1"
@@ -206,7 +217,7 @@ def full_size():
     return t, y, yerr
 
 
-def test_full_size_vs_oracle(ctx, full_size):
+def test_full_size_vs_oracle(ctx, full_size, layout):
     """BASELINE config 2/3 shape: N = 1e4, J = 20 (SHO-20) and J = 40 (DRWCelerite-20); bar 1e-8 (north star)."""
     t, y, yerr = full_size
     th = O.synthetic_theta(48, t, y)
@@ -485,7 +496,7 @@ def test_reference_outputs_ultranest_theta_only(ctx, golden_dir):
 # mixed mode: a few per-draw terms (QPO features) on top of shared terms
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("J,npd,with_real", [(21, 1, False), (12, 2, False), (9, 1, True), (5, 2, True)])
-def test_mixed_shared_and_per_draw_terms(ctx, J, npd, with_real):
+def test_mixed_shared_and_per_draw_terms(ctx, J, npd, with_real, layout):
     """C, Dd given per draw, but only `npd` columns actually differ between draws (src/psd.jl:254-261: QPO terms
     appended to an approx continuum).  The host entry detects that, keeps the shared table for the common terms and
     builds a per-draw table for the rest; result must equal the oracle and the generic per-draw path."""
