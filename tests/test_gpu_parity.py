@@ -175,6 +175,41 @@ def test_edge_sizes(ctx, layout):
     assert abs(v - O.logl(A[0], Bc[0], C, Dd, t, y, np.zeros_like(s2))) <= 1e-10 * abs(v)
 
 
+def test_latency_layout_edges(ctx):
+    """celerite_wide.hip on its own: every prologue / tail length of the 4-deep record pipeline (N = 1..9), every
+    RPL (R = 2J = 2..78), with and without mu / nu, per-draw series, and the not-positive-definite status."""
+    rng = np.random.default_rng(12)
+    os.environ["PIORAN_SCAN_CONFIG"] = "wide"
+    try:
+        for N in range(1, 10):
+            t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, 9, 3)
+            ds = pj.Dataset(t, y, s2, ctx)
+            assert relerr(ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu), O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu)) < 1e-12
+        for J in (1, 7, 8, 15, 16, 23, 24, 31, 32, 39):
+            t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 203, J, 5)
+            ds = pj.Dataset(t, y, s2, ctx)
+            ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+            assert relerr(ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu), ref) < 1e-11, J
+        t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 150, 12, 4)
+        ds = pj.Dataset(t, y, s2, ctx)
+        zero, one = np.zeros(4), np.ones(4)
+        assert relerr(ds.logl_batch(A, Bc, C, Dd), O.logl_batch(A, Bc, C, Dd, t, y, s2, zero, one)) < 1e-11
+        Y = y[None, :] + 0.01 * rng.standard_normal((4, 150)); S2 = np.broadcast_to(s2, (4, 150)) * rng.uniform(0.5, 2, (4, 1))
+        got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+        ref = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(4)])
+        assert relerr(got, ref) < 1e-11
+        # not positive definite: same status and |D| semantics as the throughput layouts
+        A2 = A.copy(); A2[1] = -5.0
+        out, st = ds.logl_batch(A2, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        os.environ["PIORAN_SCAN_CONFIG"] = "rpl2_cbr1_nsrc13"
+        out_t, st_t = ds.logl_batch(A2, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        assert (st == st_t).all() and st[1] != 0 and st[0] == 0
+        ok = np.isfinite(out_t)
+        assert (np.isfinite(out) == ok).all() and relerr(out[ok], out_t[ok]) < 1e-9
+    finally:
+        os.environ.pop("PIORAN_SCAN_CONFIG", None)
+
+
 def test_status_not_positive_definite(ctx):
     rng = np.random.default_rng(5)
     t = np.cumsum(rng.uniform(0.1, 2, 50)); y = rng.standard_normal(50); s2 = np.full(50, 1e-8)
