@@ -8,6 +8,7 @@
 # from Python (pioran.jl_amd/_lib.py) and the GPU parity tests; see INTEGRATION.md.
 module PioranHIP
 
+using LinearAlgebra
 using Pioran
 import Pioran: log_likelihood, SumOfCelerite, SemiSeparable, celerite_coefs
 
@@ -122,6 +123,71 @@ function logpdf_batch_shift(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64},
                     (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint,
                      Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}),
                     ds.h, nb, J, A, B, c, d, c isa Vector ? 1 : 0, p(μ), p(ν), shift, out, status))
+    end
+    return out, status
+end
+
+"""
+    logpdf_batch_theta(ds, model, θ, norm, f_min, f_max, n_components; basis, μ, ν, shift, ...)
+
+θ → log L in one call: `approx` (src/psd.jl:214-289) runs on the GPU in front of the scan, so only the sampled parameters
+cross the boundary.  `model`: `:SingleBendingPowerLaw` (`θ` is `3 × nbatch`: α₁, f₁, α₂) or `:DoubleBendingPowerLaw`
+(`5 × nbatch`); `norm`: the `norm` argument of `approx` per draw; `basis`: `"SHO"` or `"DRWCelerite"`.
+This is the whole body of an ultranest `vectorized=true` likelihood for the models of docs/src/ultranest.md.
+"""
+function logpdf_batch_theta(ds::Dataset, model::Symbol, θ::Matrix{Float64}, norm::Vector{Float64}, f_min::Real, f_max::Real,
+                            n_components::Integer; basis::String = "SHO", is_integrated_power::Bool = true,
+                            S_low::Real = 20.0, S_high::Real = 20.0, μ::Union{Nothing, Vector{Float64}} = nothing,
+                            ν::Union{Nothing, Vector{Float64}} = nothing, shift::Union{Nothing, Vector{Float64}} = nothing)
+    m = model === :SingleBendingPowerLaw ? 0 : model === :DoubleBendingPowerLaw ? 1 : error("model $model not supported on the device")
+    bs = basis == "SHO" ? 0 : basis == "DRWCelerite" ? 1 : error("basis $basis not supported on the device")
+    size(θ, 1) == (m == 0 ? 3 : 5) || error("θ must be $(m == 0 ? 3 : 5) × nbatch")
+    nb = size(θ, 2)
+    out = Vector{Float64}(undef, nb)
+    status = zeros(Int32, nb)
+    p(x) = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
+    GC.@preserve θ norm μ ν shift out status begin
+        check(ccall((:pioran_logpdf_batch_theta, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Cint, Int64, Cint, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble},
+                     Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}),
+                    ds.h, nb, m, n_components, bs, is_integrated_power ? 1 : 0, f_min, f_max, S_low, S_high, θ, norm,
+                    p(μ), p(ν), p(shift), out, status, C_NULL, C_NULL))
+    end
+    return out, status
+end
+
+# ---- in-process farm: ONE Julia process driving several GPUs (no Distributed/MPI launcher needed) ----------------------
+mutable struct Farm
+    h::Ptr{Cvoid}
+    function Farm(devices::Vector{<:Integer}, t::Vector{Float64}, y::Vector{Float64}, σ2::Vector{Float64})
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        dev = Vector{Cint}(devices)
+        GC.@preserve dev t y σ2 check(ccall((:pioran_farm_create, LIB), Cint,
+            (Cint, Ptr{Cint}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Ptr{Cvoid}}), length(dev), dev, length(t), t, y, σ2, r))
+        f = new(r[])
+        finalizer(x -> ccall((:pioran_farm_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), f)
+        return f
+    end
+end
+
+"""
+    logpdf_batch(farm, A, B, c, d; μ, ν, shift)
+
+Same arguments as the single-GPU `logpdf_batch`; the draws are cut into contiguous shards, one per listed device, every
+device writes its slice of the result directly (draws are independent: no collective).
+"""
+function logpdf_batch(farm::Farm, A::Matrix{Float64}, B::Matrix{Float64}, c::VecOrMat{Float64}, d::VecOrMat{Float64};
+                      μ::Union{Nothing, Vector{Float64}} = nothing, ν::Union{Nothing, Vector{Float64}} = nothing,
+                      shift::Union{Nothing, Vector{Float64}} = nothing)
+    J, nb = size(A)
+    out = Vector{Float64}(undef, nb)
+    status = zeros(Int32, nb)
+    p(x) = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
+    GC.@preserve A B c d μ ν shift out status begin
+        check(ccall((:pioran_farm_logl_batch, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint,
+                     Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}),
+                    farm.h, nb, J, A, B, c, d, c isa Vector ? 1 : 0, p(μ), p(ν), p(shift), out, status))
     end
     return out, status
 end
