@@ -47,7 +47,7 @@ typedef struct pioran_ds pioran_ds;   /* a time series resident in HBM + its cac
 const char* pioran_strerror(int code);
 const char* pioran_last_hip_error(const pioran_ctx* ctx);
 /* ABI version of this header (bumped on any signature change). */
-int pioran_abi_version(void);   /* currently 2 */
+int pioran_abi_version(void);   /* currently 3 */
 
 /* ---- context ------------------------------------------------------------------------------- */
 /* Creates a context on GPU `device` with its own non-blocking stream. */
@@ -131,6 +131,20 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
                               int is_integrated_power, double f_min, double f_max, double S_low, double S_high,
                               const double* theta, const double* norm, const double* mu, const double* nu,
                               const double* shift, double* out, int32_t* status, double* A_out, double* Bc_out);
+/* ---- posterior mean and simulation (the callers either side of the likelihood) -----------
+ * predict (src/celerite_solver.jl:348-361 -> pred :363-483; mean(::PosteriorGP, tau) of src/scalable_GP.jl:64-72,90-91):
+ *     mean_out[b][m] = mu_b + sum_n z_n k_b(|tau_m - t_n|),   z = K_b^-1 (y - mu_b),  K_b = kernel_b + diag(nu_b sigma2)
+ * for B draws of (a, b) with shared (c, d) [J].  tau: M evaluation times, any order (the reference wants them sorted).
+ * status (may be NULL) as in pioran_celerite_logl_batch.  Host pointers, blocking. */
+int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                            const double* Dd, const double* mu, const double* nu, int64_t M, const double* tau,
+                            double* mean_out, int32_t* status);
+/* simulate (src/celerite_solver.jl:497-513 -> sim :515-549; rand(f(t, sigma2)) of src/scalable_GP.jl:137-146):
+ * realisations y_b = L_b D_b^(1/2) q_b of the GP with kernel (a_b, b_b, c, d) + diag(sigma2) at the times t, from
+ * caller-supplied standard-normal draws q [B][N] (the reference draws them with its rng, :528).  y_out [B][N]. */
+int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc,
+                             const double* C, const double* Dd, const double* t, const double* sigma2, const double* q,
+                             double* y_out);
 /* Name of the kernel configuration a batch with R active rows runs on (diagnostics). */
 const char* pioran_celerite_config_name(int64_t R);
 

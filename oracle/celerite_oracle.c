@@ -347,3 +347,86 @@ void oracle_sim(int64_t N, int64_t J, const double *a, const double *b, const do
     }
     free(S); free(phi); free(U); free(V); free(D); free(f);
 }
+
+/* src/celerite_solver.jl:363-483  pred: posterior mean at the (ascending) times tq[M] of the zero-mean GP given (t, y).
+ * z = K^-1 y by init_semi_separable! + solve_prec! (:375-384), then the two walks over the merged sequence:
+ *   forward pass (:392-428): Q <- (Q + z_n V_n) e^{-c (t_{n+1} - t_n)} for the data points left of tau (:397-404),
+ *                            mu_m = sum_rows (Q + z_{n0} V_{n0}) e^{-c (tau - t_{n0})} U~(tau)       (:412-413,427)
+ *   backward pass (:433-479): Q <- (Q + z_n U_n) e^{-c (t_n - t_{n-1})} from the right (:445-446),
+ *                            mu_m += sum_rows (Q + z_{n0+1} U_{n0+1}) e^{-c (t_{n0+1} - tau)} V(tau)  (:457-458,475)
+ * with n0 = searchsortedfirst(t, tau) - 1 = the number of t_n < tau (:388).  The reference's bookkeeping of which data
+ * points Q has absorbed (`start`, `stop`, :395-424,:440-472) is restated as "Q has absorbed exactly the points it must
+ * for this tau", which is what that bookkeeping maintains for ascending tau. */
+void oracle_predict(int64_t N, int64_t J, const double *a, const double *b, const double *c, const double *d,
+                    const double *t, const double *y, const double *sigma2, int64_t M, const double *tq, double *mu_out)
+{
+    const int64_t R = 2 * J;
+    double *S = calloc((size_t)(R * R), sizeof(double));
+    double *phi = malloc(sizeof(double) * (size_t)(R * (N > 1 ? N - 1 : 1)));
+    double *U = malloc(sizeof(double) * (size_t)(R * N));
+    double *V = malloc(sizeof(double) * (size_t)(R * N));
+    double *D = malloc(sizeof(double) * (size_t)N);
+    double *z = malloc(sizeof(double) * (size_t)N);
+    double *fg = malloc(sizeof(double) * (size_t)(2 * R));
+    double *Q = calloc((size_t)R, sizeof(double));
+    int64_t *n0 = malloc(sizeof(int64_t) * (size_t)(M > 0 ? M : 1));
+    init_semi_separable(J, N, a, b, c, d, t, sigma2, V, D, U, phi, S);
+    (void)solve_prec(N, R, z, y, U, V, D, phi, fg, fg + R);
+    for (int64_t m = 0; m < M; ++m) {   /* :388 */
+        int64_t k = 0;
+        while (k < N && t[k] < tq[m]) ++k;
+        n0[m] = k;                      /* 1-based index of the last t_n < tau, 0 if none */
+        mu_out[m] = 0.0;
+    }
+    /* forward pass: `done` = data points (1-based 1..done) already folded into Q, Q referred to t_{done+1} */
+    int64_t done = 0;
+    for (int64_t m = 0; m < M; ++m) {
+        const int64_t k0 = n0[m];
+        if (k0 == 0) continue;          /* nothing to the left: S stays zero (:407) */
+        while (done < k0 - 1) {         /* :397-404 */
+            const int64_t n = done;     /* 0-based data index */
+            for (int64_t j = 0; j < J; ++j) {
+                const double e = exp(-c[j] * (t[n + 1] - t[n]));
+                Q[2 * j] = (Q[2 * j] + z[n] * cos(d[j] * t[n])) * e;
+                Q[2 * j + 1] = (Q[2 * j + 1] + z[n] * sin(d[j] * t[n])) * e;
+            }
+            ++done;
+        }
+        const int64_t n = k0 - 1;
+        double acc = 0.0;
+        for (int64_t j = 0; j < J; ++j) {   /* :412-413, summed in row order like sum(S) (:427) */
+            const double e = exp(-c[j] * (tq[m] - t[n]));
+            const double ct = cos(d[j] * tq[m]), st = sin(d[j] * tq[m]);
+            acc += (Q[2 * j] + z[n] * cos(d[j] * t[n])) * e * (a[j] * ct + b[j] * st);
+            acc += (Q[2 * j + 1] + z[n] * sin(d[j] * t[n])) * e * (a[j] * st - b[j] * ct);
+        }
+        mu_out[m] = acc;
+    }
+    /* backward pass: `left` = data points (0-based left..N-1) already folded into Q, Q referred to t_{left-1} */
+    memset(Q, 0, sizeof(double) * (size_t)R);   /* :430 */
+    int64_t left = N;
+    for (int64_t m = M - 1; m >= 0; --m) {
+        const int64_t k0 = n0[m];
+        if (k0 == N) continue;          /* nothing to the right (:436) */
+        while (left > k0 + 1) {         /* :440-448: fold n = left-1 (0-based), decay to t_{n-1} */
+            const int64_t n = left - 1;
+            for (int64_t j = 0; j < J; ++j) {
+                const double e = exp(-c[j] * (t[n] - t[n - 1]));
+                const double ct = cos(d[j] * t[n]), st = sin(d[j] * t[n]);
+                Q[2 * j] = (Q[2 * j] + z[n] * (a[j] * ct + b[j] * st)) * e;
+                Q[2 * j + 1] = (Q[2 * j + 1] + z[n] * (a[j] * st - b[j] * ct)) * e;
+            }
+            --left;
+        }
+        const int64_t n = k0;           /* 0-based index of the first t_n >= tau */
+        double acc = 0.0;
+        for (int64_t j = 0; j < J; ++j) {   /* :457-458 */
+            const double e = exp(-c[j] * (t[n] - tq[m]));
+            const double ct = cos(d[j] * t[n]), st = sin(d[j] * t[n]);
+            acc += (Q[2 * j] + z[n] * (a[j] * ct + b[j] * st)) * e * cos(d[j] * tq[m]);
+            acc += (Q[2 * j + 1] + z[n] * (a[j] * st - b[j] * ct)) * e * sin(d[j] * tq[m]);
+        }
+        mu_out[m] += acc;               /* :475 */
+    }
+    free(S); free(phi); free(U); free(V); free(D); free(z); free(fg); free(Q); free(n0);
+}

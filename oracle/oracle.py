@@ -67,6 +67,8 @@ def lib():
         L.oracle_dense_nll.argtypes = [i64, i64, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.oracle_kappa.restype = ctypes.c_double
         L.oracle_kappa.argtypes = [i64, _dp, _dp, _dp, _dp, ctypes.c_double]
+        L.oracle_predict.restype = None
+        L.oracle_predict.argtypes = [i64, i64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, i64, _dp, _dp]
         L.oracle_sim.restype = None
         L.oracle_sim.argtypes = [i64, i64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib = L
@@ -172,6 +174,28 @@ def logl_numpy(a, b, c, d, t, y, sigma2):
         ld += np.log(abs(D))
         q2 += z * z / D
     return -0.5 * ld - 0.5 * N * np.log(2 * np.pi) - 0.5 * q2
+
+
+def predict(a, b, c, d, tau, t, y, sigma2):
+    """pred(a, b, c, d, tau, t, y, sigma2)   src/celerite_solver.jl:363-483 (tau ascending); C restatement."""
+    a, b, c, d, tau, t, y, sigma2 = (np.ascontiguousarray(v, dtype=np.float64) for v in (a, b, c, d, tau, t, y, sigma2))
+    out = np.empty(len(tau))
+    P = lambda v: v.ctypes.data_as(_dp)
+    lib().oracle_predict(len(t), len(a), P(a), P(b), P(c), P(d), P(t), P(y), P(sigma2), len(tau), P(tau), P(out))
+    return out
+
+
+def predict_direct_numpy(a, b, c, d, tau, t, y, sigma2):
+    """predict_direct (src/direct_solver.jl:75-119): K_tau0 K0^-1 y with dense matrices and a Cholesky solve."""
+    a, b, c, d, tau, t, y, sigma2 = (np.asarray(v, dtype=np.float64) for v in (a, b, c, d, tau, t, y, sigma2))
+    def kern(dt):
+        dt = np.abs(dt)[..., None]
+        return (np.exp(-c * dt) * (a * np.cos(d * dt) + b * np.sin(d * dt))).sum(-1)
+    K0 = kern(t[:, None] - t[None, :]) + np.diag(sigma2)
+    Kt0 = kern(tau[:, None] - t[None, :])
+    L = np.linalg.cholesky(K0)
+    z = np.linalg.solve(L.T, np.linalg.solve(L, y))
+    return Kt0 @ z
 
 
 def dense_nll_numpy(a, b, c, d, t, y, sigma2):

@@ -172,7 +172,7 @@ const char* pioran_strerror(int code)
 
 const char* pioran_last_hip_error(const pioran_ctx* ctx) { return ctx ? ctx->last_err.c_str() : ""; }
 
-int pioran_abi_version(void) { return 2; }
+int pioran_abi_version(void) { return 3; }
 
 static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
 {
@@ -649,6 +649,102 @@ int pioran_celerite_logl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a,
         ctx->scalar_t.assign(t, t + N);
     }
     return pioran_celerite_logl_batch(ctx->scalar_ds, 1, J, a, b, c, d, 1, nullptr, nullptr, y, sigma2, out, status);
+}
+
+// ---- posterior mean / simulation --------------------------------------------------------------------
+// shared (c, d) only; draws are processed in chunks of at most 256 (one workgroup per draw, factor kept in HBM)
+static int prepare_shared(pioran_ds* ds, int64_t B, int64_t J, const double* Bc, const double* C, const double* Dd)
+{
+    std::vector<int32_t> real(J, 0);
+    for (int64_t j = 0; j < J; ++j) {
+        if (Dd[j] != 0.0) continue;
+        bool allzero = true;
+        for (int64_t b = 0; b < B && allzero; ++b) allzero = (Bc[b * J + j] == 0.0);
+        real[j] = allzero;
+    }
+    return pioran_dataset_prepare(ds, J, C, Dd, real.data());
+}
+
+int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                            const double* Dd, const double* mu, const double* nu, int64_t M, const double* tau,
+                            double* mean_out, int32_t* status)
+{
+    if (!ds || B < 1 || J < 1 || M < 1 || !A || !Bc || !C || !Dd || !tau || !mean_out) return PIORAN_ERR_ARG;
+    pioran_ctx* ctx = ds->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
+    if (ds->R > 79 || ds->npd_terms) return PIORAN_ERR_UNSUPPORTED;
+    const int64_t chunk = B < 256 ? B : 256;
+    if ((rc = ensure(ctx, ctx->bwork, pioran_predict_workspace_doubles(chunk, ds->N, ds->R) * sizeof(double)))) return rc;
+    if ((rc = upload(ctx, ctx->bshift, tau, (size_t)M * sizeof(double)))) return rc;          // tau
+    if ((rc = ensure(ctx, ctx->bY, (size_t)chunk * (size_t)M * sizeof(double)))) return rc;   // mean [chunk][M]
+    if ((rc = ensure(ctx, ctx->bout, chunk * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t)))) return rc;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+        if ((rc = upload(ctx, ctx->bA, A + b0 * J, (size_t)nb * J * sizeof(double)))) return rc;
+        if ((rc = upload(ctx, ctx->bB, Bc + b0 * J, (size_t)nb * J * sizeof(double)))) return rc;
+        if (mu && (rc = upload(ctx, ctx->bmu, mu + b0, nb * sizeof(double)))) return rc;
+        if (nu && (rc = upload(ctx, ctx->bnu, nu + b0, nb * sizeof(double)))) return rc;
+        ScanParams p{};
+        p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = nb;
+        p.standard_rows = ds->R == 2 * ds->J;
+        p.rec_stride = 3 * (int64_t)(ds->R + 2) + 2;
+        p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+        p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
+        p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
+        p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
+        rc = pioran_launch_predict(p, (double*)ctx->bwork.p, ds->t, M, (const double*)ctx->bshift.p, (double*)ctx->bY.p,
+                                   ctx->stream);
+        if (rc) { ctx->last_err = "prediction launch failed"; return rc; }
+        HIPCHK(ctx, hipMemcpyAsync(mean_out + b0 * M, ctx->bY.p, (size_t)nb * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (status) HIPCHK(ctx, hipMemcpyAsync(status + b0, ctx->bst.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PIORAN_OK;
+}
+
+int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc,
+                             const double* C, const double* Dd, const double* t, const double* sigma2, const double* q,
+                             double* y_out)
+{
+    if (!ctx || N < 1 || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !t || !sigma2 || !q || !y_out) return PIORAN_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pioran_ds* ds = nullptr;
+    std::vector<double> zeros((size_t)N, 0.0);
+    int rc = pioran_dataset_create(ctx, N, t, zeros.data(), sigma2, &ds);
+    if (rc) return rc;
+    auto done = [&](int code) { pioran_dataset_destroy(ds); return code; };
+    if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return done(rc);
+    if (ds->R > 79 || ds->npd_terms) return done(PIORAN_ERR_UNSUPPORTED);
+    const int64_t chunk = B < 256 ? B : 256;
+    const size_t cn = (size_t)chunk * (size_t)N * sizeof(double);
+    if ((rc = ensure(ctx, ctx->bY, cn))) return done(rc);     // noise
+    if ((rc = ensure(ctx, ctx->bS2, cn))) return done(rc);    // realisations
+    if ((rc = ensure(ctx, ctx->bout, chunk * sizeof(double)))) return done(rc);
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+        if ((rc = upload(ctx, ctx->bA, A + b0 * J, (size_t)nb * J * sizeof(double)))) return done(rc);
+        if ((rc = upload(ctx, ctx->bB, Bc + b0 * J, (size_t)nb * J * sizeof(double)))) return done(rc);
+        if ((rc = upload(ctx, ctx->bY, q + b0 * N, (size_t)nb * N * sizeof(double)))) return done(rc);
+        ScanParams p{};
+        p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = nb;
+        p.standard_rows = ds->R == 2 * ds->J;
+        p.rec_stride = 3 * (int64_t)(ds->R + 2) + 2;
+        p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+        p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
+        p.out = (double*)ctx->bout.p;
+        p.noise = (const double*)ctx->bY.p; p.ysim = (double*)ctx->bS2.p;
+        rc = pioran_launch_scan_wide_sim(p, ctx->stream);
+        if (rc) { ctx->last_err = "simulation launch failed"; return done(rc); }
+        if (hipMemcpyAsync(y_out + b0 * N, ctx->bS2.p, (size_t)nb * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            ctx->last_err = "simulation copy-back failed";
+            return done(PIORAN_ERR_HIP);
+        }
+    }
+    return done(PIORAN_OK);
 }
 
 const char* pioran_celerite_config_name(int64_t R)

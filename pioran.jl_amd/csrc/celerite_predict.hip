@@ -1,0 +1,220 @@
+// Posterior mean of the GP at new times (gfx950): `pred` of the reference (src/celerite_solver.jl:363-483) behind
+// `predict` (:348-361) and `mean(::PosteriorGP, tau)` (src/scalable_GP.jl:64-72, 90-91).
+//
+//   z = K^-1 (y - mu)                      init_semi_separable! + solve_prec! (forward AND backward sweep)   :375-384
+//   mu(tau) = sum_n z_n k(|tau - t_n|)     evaluated through the semi-separable structure                    :386-479
+//
+// The reference walks the merged (t, tau) sequence twice with running vectors Q.  Here the two recurrences are
+// decoupled from the evaluation points so that the evaluation is embarrassingly parallel over tau:
+//   1. celerite_wide_kernel<MODE 1> (celerite_wide.hip) factors and forward-solves, leaving W_n, D_n, z'_n in HBM;
+//   2. predict_sweep_kernel, one wavefront per draw, lane = row: the backward sweep of solve_prec! (:145-155)
+//        g <- phi_{n+1} o (g + U_{n+1} z_{n+1}) ;  z_n = z'_n / D_n - W_n' g          (one wave reduction per step)
+//      which also gives  Qb_n = g + U_n z_n = sum_{k >= n} z_k U_k e^{-c (t_k - t_n)}  (the backward-pass Q of :437-470),
+//      followed by the forward recurrence  Qf_n = phi_n o Qf_{n-1} + z_n V_n = sum_{k <= n} z_k V_k e^{-c (t_n - t_k)}
+//      (the forward-pass Q of :397-424); both [N][R] per draw in HBM;
+//   3. predict_eval_kernel, one thread per (draw, tau_m): n0 = #{t_n < tau} (searchsortedfirst - 1, :388),
+//        mu_m = sum_r Qf[n0-1][r] e^{-c_r (tau - t_{n0-1})} U~_r(tau)   +   sum_r Qb[n0][r] e^{-c_r (t_{n0} - tau)} V_r(tau)
+//      with U~_r(tau) = (a cos + b sin | a sin - b cos)(d tau), V_r(tau) = (cos | sin)(d tau)             (:412-413, :457-458).
+// tau must be ascending for the reference; here any order works (each tau is independent).
+#include "common.h"
+
+#include <cmath>
+
+namespace {
+
+// sum over the 64 lanes of a wavefront, result in every lane
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+struct RowDesc {
+    double al, be;   // u = al v + be x
+    int row;         // table row, < 0: lane idle
+};
+
+// Lane j of the wavefront owns rows j and j + 64 (R <= 128 here; the scan path allows R <= 79).
+__global__ void __launch_bounds__(64) predict_sweep_kernel(const ScanParams p, double* __restrict__ z, double* __restrict__ Qf,
+                                                           double* __restrict__ Qb)
+{
+    const int64_t b = blockIdx.x, N = p.N;
+    const int lane = threadIdx.x, R = p.R, Rp = R + 2, J = p.J;
+    const int64_t rec = p.rec_stride;
+    RowDesc rd[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = lane + 64 * h;
+        rd[h].row = r < R ? r : -1;
+        rd[h].al = rd[h].be = 0.0;
+        if (r < R) {
+            const int rm = p.rowmap[r];
+            const int term = rm & 0xfffff;
+            const bool ks = (rm >> 30) & 1;
+            const double a = p.A[b * J + term], bb = p.Bc[b * J + term];
+            rd[h].al = a;
+            rd[h].be = ks ? -bb : bb;
+        }
+    }
+    const double* W = p.st_w + b * N * R;
+    const double* Dd = p.st_d + b * N;
+    const double* zf = p.st_z + b * N;
+    double* zb = z + b * N;
+    double* qf = Qf + b * N * R;
+    double* qb = Qb + b * N * R;
+
+    // What step n reads that does not depend on the recurrence (table record n, W_n, z'_n, D_n), fetched one step ahead
+    // of its use: a lone wavefront per draw has nothing else to hide the latency behind.
+    struct StepData {
+        double v[2], x[2], ph[2], w[2], zf, Dn;
+    };
+    auto fetch = [&](int64_t n, StepData& sd) __attribute__((always_inline)) {
+        const int64_t nn = n < 0 ? 0 : (n >= N ? N - 1 : n);
+        const double* recn = p.tab + nn * rec;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = rd[h].row >= 0 ? rd[h].row : 0;
+            sd.v[h] = recn[r];
+            sd.x[h] = recn[Rp + r];
+            sd.ph[h] = recn[2 * Rp + r];
+            sd.w[h] = W[nn * R + r];
+        }
+        sd.zf = zf[nn];
+        sd.Dn = Dd[nn];
+    };
+
+    // ---- backward sweep, :145-155 ----
+    double g[2] = {0.0, 0.0};
+    double znext = 0.0;
+    double unext[2] = {0.0, 0.0}, phnext[2] = {1.0, 1.0};   // U_{n+1}, phi between t_n and t_{n+1} (record n+1)
+    StepData cur, nxt;
+    fetch(N - 1, cur);
+    for (int64_t n = N - 1; n >= 0; --n) {
+        fetch(n - 1, nxt);
+        double u[2];
+        double dot = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u[h] = 0.0;
+            if (rd[h].row >= 0) {
+                u[h] = rd[h].al * cur.v[h] + rd[h].be * cur.x[h];
+                if (n < N - 1) g[h] = phnext[h] * (g[h] + unext[h] * znext);   // :149-150
+                dot = fma(cur.w[h], g[h], dot);
+            }
+        }
+        dot = wave_sum(dot);
+        const double zn = cur.zf / cur.Dn - dot;                                // :146,151
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (rd[h].row >= 0) {
+                qb[n * R + rd[h].row] = g[h] + u[h] * zn;
+                unext[h] = u[h];
+                phnext[h] = cur.ph[h];
+            }
+        if (lane == 0) zb[n] = zn;
+        znext = zn;
+        cur = nxt;
+    }
+    // ---- forward recurrence of the prediction, :397-404 (lane 0 wrote z: make it visible to the wavefront) ----
+    __threadfence_block();
+    double q[2] = {0.0, 0.0};
+    constexpr int FD = 4;   // z and the table record four steps ahead (no dependence on q)
+    double zr[FD], vr[FD][2], pr[FD][2];
+    auto fetch_f = [&](int64_t n, int slot) __attribute__((always_inline)) {
+        const int64_t nn = n >= N ? N - 1 : n;
+        const double* recn = p.tab + nn * rec;
+        zr[slot] = zb[nn];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = rd[h].row >= 0 ? rd[h].row : 0;
+            vr[slot][h] = recn[r];
+            pr[slot][h] = recn[2 * Rp + r];
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < FD; ++k) fetch_f(k, k);
+    for (int64_t n0 = 0; n0 < N; n0 += FD) {
+#pragma unroll
+        for (int k = 0; k < FD; ++k) {
+            const int64_t n = n0 + k;
+            if (n < N) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (rd[h].row >= 0) {
+                        q[h] = fma(zr[k], vr[k][h], n > 0 ? pr[k][h] * q[h] : 0.0);
+                        qf[n * R + rd[h].row] = q[h];
+                    }
+            }
+            fetch_f(n + FD, k);
+        }
+    }
+}
+
+// one thread per (draw, tau_m)
+__global__ void __launch_bounds__(256) predict_eval_kernel(const ScanParams p, const double* __restrict__ t,
+                                                           const double* __restrict__ Qf, const double* __restrict__ Qb,
+                                                           int64_t M, const double* __restrict__ tau, double* __restrict__ out)
+{
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t b = blockIdx.y, N = p.N;
+    if (m >= M) return;
+    const int R = p.R, J = p.J;
+    const double tm = tau[m];
+    // n0 = number of t_n < tau  (searchsortedfirst(t, tau) - 1 in 1-based terms, :388)
+    int64_t lo = 0, hi = N;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (t[mid] < tm) lo = mid + 1; else hi = mid;
+    }
+    const int64_t n0 = lo;
+    const double* qf = n0 > 0 ? Qf + (b * N + (n0 - 1)) * R : nullptr;
+    const double* qb = n0 < N ? Qb + (b * N + n0) * R : nullptr;
+    const double dtf = n0 > 0 ? tm - t[n0 - 1] : 0.0;
+    const double dtb = n0 < N ? t[n0] - tm : 0.0;
+    double acc = 0.0;
+    for (int r = 0; r < R; ++r) {
+        const int rm = p.rowmap[r];
+        const int term = rm & 0xfffff;
+        const bool ks = (rm >> 30) & 1;
+        const double a = p.A[b * J + term], bb = p.Bc[b * J + term], c = p.C[term], d = p.D[term];
+        double s_, c_;
+        sincos(d * tm, &s_, &c_);
+        const double v = ks ? s_ : c_;                               // V_r(tau)
+        const double u = ks ? a * s_ - bb * c_ : a * c_ + bb * s_;   // U~_r(tau)
+        if (qf) acc = fma(qf[r] * exp(-c * dtf), u, acc);            // :412-413
+        if (qb) acc = fma(qb[r] * exp(-c * dtb), v, acc);            // :457-458
+    }
+    out[b * M + m] = acc + (p.mu ? p.mu[b] : 0.0);
+}
+
+}  // namespace
+
+size_t pioran_predict_workspace_doubles(int64_t B, int64_t N, int32_t R)
+{
+    // W, Qf, Qb: [B][N][R]; D, z', z: [B][N]
+    return (size_t)B * (size_t)N * (3 * (size_t)R + 3);
+}
+
+// p: a shared-table launch description (tab, rowmap, A, Bc, C, D (shared, [J]), mu, nu, y/s2 or Y/S2, out, status).
+// work: pioran_predict_workspace_doubles(B, N, R) doubles.  t: device [N].  tau: device [M].  mean_out: device [B][M].
+int pioran_launch_predict(ScanParams p, double* work, const double* t, int64_t M, const double* tau, double* mean_out,
+                          hipStream_t stream)
+{
+    if (!p.tab || p.npd_rows != 0 || p.R > 128 || M < 0) return PIORAN_ERR_UNSUPPORTED;
+    const size_t BN = (size_t)p.B * (size_t)p.N;
+    double* W = work;
+    double* Qf = W + BN * p.R;
+    double* Qb = Qf + BN * p.R;
+    double* Dd = Qb + BN * p.R;
+    double* zf = Dd + BN;
+    double* z = zf + BN;
+    p.st_w = W; p.st_d = Dd; p.st_z = zf;
+    int rc = pioran_launch_scan_wide_store(p, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(predict_sweep_kernel, dim3((unsigned)p.B), dim3(64), 0, stream, p, z, Qf, Qb);
+    if (M > 0)
+        hipLaunchKernelGGL(predict_eval_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)p.B), dim3(256), 0, stream, p, t, Qf,
+                           Qb, M, tau, mean_out);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}

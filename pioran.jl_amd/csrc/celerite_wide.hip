@@ -137,7 +137,11 @@ __device__ __forceinline__ void describe_slots(const ScanParams& p, int64_t b, i
 
 constexpr int kWideMaxRecord = 512;   // staged doubles per step: two per thread
 
-template <int RPL>
+// MODE 0: log-likelihood.  MODE 1: the same, and the factor goes to HBM (W_n, D_n, forward-solved z_n per step) for the
+// backward sweep of the prediction path (celerite_predict.hip).  MODE 2: simulation — the extra row carries
+// f <- phi o (f + W_{n-1} x_{n-1}) instead of the forward solve and emits y_n = x_n + u_n'f, x_n = sqrt(D_n) q_n
+// (sim, src/celerite_solver.jl:515-549); the noise q takes the place of y in the staged record.
+template <int RPL, int MODE = 0>
 __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams p)
 {
     constexpr int YS = RPL - 1;                       // slot of the y row inside row / column block 15
@@ -180,6 +184,11 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
         last[h] = N;                                  // the table holds N + 1 records
         if (p.Y && (e == 3 * Rp || e == 3 * Rp + 1)) {
             src[h] = (e == 3 * Rp ? p.Y : p.S2) + b * N;
+            stride[h] = 1;
+            last[h] = N - 1;
+        }
+        if (MODE == 2 && e == 3 * Rp) {   // the noise rides where y would
+            src[h] = p.noise + b * N;
             stride[h] = 1;
             last[h] = N - 1;
         }
@@ -243,6 +252,28 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
     }
     double quad = num[YS] * num[YS] * rD;             // meaningful in the y-row lanes only
     bool nonpd = !(Dn > 0.0);
+    // per-step outputs of MODE 1 / MODE 2 (one lane per DPP row stores)
+    auto emit = [&](int64_t n, double yn) __attribute__((always_inline)) {
+        if constexpr (MODE == 1) {
+            if (l == 0) {
+#pragma unroll
+                for (int i = 0; i < RPL; ++i)
+                    if (g * RPL + i < p.R) p.st_w[(b * N + n) * p.R + g * RPL + i] = num[i] * rD;
+                if (yrow) {
+                    p.st_d[b * N + n] = Dn;
+                    p.st_z[b * N + n] = num[YS];
+                }
+            }
+        }
+        if constexpr (MODE == 2) {
+            const double x = sqrt(Dn) * yn;            // x_n = sqrt(D_n) q_n      :539,546
+            if (yrow) {
+                if (l == 0) p.ysim[b * N + n] = x + ((yn - mu) - num[YS]);   // x_n + u_n'f  (this row's v is q_n - mu, num = v - u'f)
+                num[YS] = x;                           // what the extra row adds next step: W_{n} x_n   :543
+            }
+        }
+    };
+    emit(0, cur[0].y);
     // record 1 for the first step of the loop
     stage(1, gv[1 % DG]);
     fetch(DG + 1, gv[1 % DG]);
@@ -316,6 +347,7 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
             Pe += ex;
         }
         quad = fma(z * z, rD, quad);                             // z_n^2 / D_n  (== y'K^-1 y, :333)
+        emit(n, in.y);
         PIORAN_WSTAMP(6);
     };
 
@@ -348,15 +380,30 @@ int pioran_wide_supported_rows() { return 79; }
 // Batches up to this size take the latency layout (at most one workgroup per CU on the chip's 256 CUs).
 int64_t pioran_wide_max_batch() { return 256; }
 
-int pioran_launch_scan_wide(const ScanParams& p, hipStream_t stream)
+template <int MODE>
+static int launch_wide_mode(const ScanParams& p, hipStream_t stream)
 {
     if (!p.tab || p.R > 79 || p.B <= 0 || p.B > 0x7fffffffLL) return PIORAN_ERR_UNSUPPORTED;
     if (3 * (p.R + 2) + 2 + 3 * p.npd_rows > kWideMaxRecord) return PIORAN_ERR_UNSUPPORTED;   // staged record too long
     const dim3 grid((unsigned)p.B), block(256);
-    if (p.R <= 15) hipLaunchKernelGGL(celerite_wide_kernel<1>, grid, block, 0, stream, p);
-    else if (p.R <= 31) hipLaunchKernelGGL(celerite_wide_kernel<2>, grid, block, 0, stream, p);
-    else if (p.R <= 47) hipLaunchKernelGGL(celerite_wide_kernel<3>, grid, block, 0, stream, p);
-    else if (p.R <= 63) hipLaunchKernelGGL(celerite_wide_kernel<4>, grid, block, 0, stream, p);
-    else hipLaunchKernelGGL(celerite_wide_kernel<5>, grid, block, 0, stream, p);
+    if (p.R <= 15) hipLaunchKernelGGL((celerite_wide_kernel<1, MODE>), grid, block, 0, stream, p);
+    else if (p.R <= 31) hipLaunchKernelGGL((celerite_wide_kernel<2, MODE>), grid, block, 0, stream, p);
+    else if (p.R <= 47) hipLaunchKernelGGL((celerite_wide_kernel<3, MODE>), grid, block, 0, stream, p);
+    else if (p.R <= 63) hipLaunchKernelGGL((celerite_wide_kernel<4, MODE>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((celerite_wide_kernel<5, MODE>), grid, block, 0, stream, p);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
+int pioran_launch_scan_wide(const ScanParams& p, hipStream_t stream) { return launch_wide_mode<0>(p, stream); }
+
+int pioran_launch_scan_wide_store(const ScanParams& p, hipStream_t stream)
+{
+    if (!p.st_w || !p.st_d || !p.st_z) return PIORAN_ERR_ARG;
+    return launch_wide_mode<1>(p, stream);
+}
+
+int pioran_launch_scan_wide_sim(const ScanParams& p, hipStream_t stream)
+{
+    if (!p.noise || !p.ysim || p.Y) return PIORAN_ERR_ARG;
+    return launch_wide_mode<2>(p, stream);
 }

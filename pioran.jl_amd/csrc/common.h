@@ -39,6 +39,15 @@ struct ScanParams {
     // terms with per-draw (c, d) read (v, x, phi) from a per-draw block appended to every step record
     int64_t rec_stride;
     int32_t npd_rows;     // per-draw rows (2 per per-draw term), 0 if none
+    // celerite_wide.hip only.  Factor store (pioran_launch_scan_wide_store): W [B][N][R] (the reference's V after
+    // init_semi_separable!, src/celerite_solver.jl:95-97), D [B][N], forward-solved z [B][N] (:141).
+    double* st_w;
+    double* st_d;
+    double* st_z;
+    // Simulation (pioran_launch_scan_wide_sim): standard-normal draws q [B][N] in, GP realisations [B][N] out
+    // (sim, src/celerite_solver.jl:515-549); y / Y are not read.
+    const double* noise;
+    double* ysim;
 };
 
 // celerite_scan.hip
@@ -47,8 +56,14 @@ int pioran_scan_supported_rows();
 const char* pioran_scan_config_name(int R);
 // celerite_wide.hip: latency layout for small batches (one draw per workgroup); shared-table launches only
 int pioran_launch_scan_wide(const ScanParams& p, hipStream_t stream);
+int pioran_launch_scan_wide_store(const ScanParams& p, hipStream_t stream);   // log L + (W, D, z) to HBM
+int pioran_launch_scan_wide_sim(const ScanParams& p, hipStream_t stream);     // y = L D^(1/2) q
 int pioran_wide_supported_rows();
 int64_t pioran_wide_max_batch();
+// celerite_predict.hip: posterior mean at new times (pred, src/celerite_solver.jl:363-483)
+size_t pioran_predict_workspace_doubles(int64_t B, int64_t N, int32_t R);
+int pioran_launch_predict(ScanParams p, double* work, const double* t, int64_t M, const double* tau, double* mean_out,
+                          hipStream_t stream);
 // celerite_fallback.hip
 int pioran_launch_scan_fallback(const ScanParams& p, hipStream_t stream);
 size_t pioran_fallback_scratch_doubles(int R);

@@ -76,6 +76,21 @@ class Context:
                                                    ctypes.byref(st)), self._h)
         return (out.value, st.value) if return_status else out.value
 
+    def simulate(self, A, Bc, C, Dd, t, sigma2, q):
+        """GP realisations from standard-normal draws q (B, N): sim of src/celerite_solver.jl:515-549 for B coefficient
+        sets (A, Bc: (B, J)) sharing (C, Dd: (J,)).  Returns (B, N)."""
+        A, Bc, C, Dd, t, sigma2, q = map(_f64, (A, Bc, C, Dd, t, sigma2, q))
+        if A.ndim != 2 or A.shape != Bc.shape or C.shape != (A.shape[1],) or Dd.shape != C.shape:
+            raise ValueError("A, Bc must be (B, J) and C, Dd (J,)")
+        B, J = A.shape
+        N = len(t)
+        if sigma2.shape != (N,) or q.shape != (B, N):
+            raise ValueError("sigma2 must be (N,) and q (B, N)")
+        out = np.empty((B, N))
+        _lib.check(_lib.lib().pioran_celerite_simulate(self._h, N, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), _ptr(t),
+                                                       _ptr(sigma2), _ptr(q), _ptr(out)), self._h)
+        return out
+
     def dense_nll(self, a, b, c, d, t, y, sigma2, return_info=False):
         a, b, c, d, t, y, sigma2 = map(_f64, (a, b, c, d, t, y, sigma2))
         out = ctypes.c_double()
@@ -169,6 +184,21 @@ class Dataset:
         _lib.check(_lib.lib().pioran_celerite_logl_batch(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd),
                                                          int(cd_shared), _ptr(mu), _ptr(nu), _ptr(Y), _ptr(S2),
                                                          _ptr(out), _ptr(st)), self.ctx._h)
+        return (out, st) if return_status else out
+
+    def predict(self, A, Bc, C, Dd, tau, mu=None, nu=None, return_status=False):
+        """Posterior mean at the times tau (M,) for B coefficient sets sharing (C, Dd): pred of
+        src/celerite_solver.jl:363-483 (+ the constant mean mu_b).  Returns (B, M)."""
+        A, Bc, C, Dd, tau = map(_f64, (A, Bc, C, Dd, tau))
+        if A.ndim != 2 or A.shape != Bc.shape or C.shape != (A.shape[1],) or Dd.shape != C.shape or tau.ndim != 1:
+            raise ValueError("A, Bc must be (B, J), C, Dd (J,) and tau (M,)")
+        B, J = A.shape
+        mu = None if mu is None else _f64(np.broadcast_to(mu, (B,)))
+        nu = None if nu is None else _f64(np.broadcast_to(nu, (B,)))
+        out = np.empty((B, len(tau)))
+        st = np.zeros(B, dtype=np.int32)
+        _lib.check(_lib.lib().pioran_celerite_predict(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), _ptr(mu),
+                                                      _ptr(nu), len(tau), _ptr(tau), _ptr(out), _ptr(st)), self.ctx._h)
         return (out, st) if return_status else out
 
     def logl_batch_dev(self, B, dA, dBc, dmu=0, dnu=0, dY=0, dS2=0, dout=0, dstatus=0):
@@ -307,6 +337,55 @@ class FiniteScalableGP:
 
     def __init__(self, f: ScalableGP, x, sigma2):
         self.f, self.x, self.sigma2 = f, x, sigma2
+
+
+class PosteriorGP:
+    """posterior(f(t, sigma2), y)   src/scalable_GP.jl:44-55."""
+
+    def __init__(self, fx: "FiniteScalableGP", y):
+        self.f, self.y = fx, _f64(y).reshape(-1)
+        if len(self.y) != len(fx.x):
+            raise ValueError("y must have one value per time stamp")
+
+
+def posterior(fx: "FiniteScalableGP", y) -> PosteriorGP:
+    return PosteriorGP(fx, y)
+
+
+def predict(cov: SemiSeparable, tau, t, y, sigma2, ctx: Context | None = None):
+    """predict(cov, tau, t, y, sigma2): posterior mean of the zero-mean GP   src/celerite_solver.jl:348-361."""
+    a, b, c, d = (np.real(np.atleast_1d(v)) for v in cov.celerite_coefs())
+    ds = Dataset(t, y, sigma2, ctx)
+    try:
+        return ds.predict(a[None, :], b[None, :], c, d, tau)[0]
+    finally:
+        ds.close()
+
+
+def mean(fp: PosteriorGP, tau=None, ctx: Context | None = None):
+    """mean(fp[, tau])   src/scalable_GP.jl:64-72, 90-91: predict on y - mean(t), plus mean(tau)."""
+    x = fp.f.x
+    tau = x if tau is None else _f64(tau).reshape(-1)
+    y0 = fp.y - _mean_vector(fp.f.f.mean, x)
+    return predict(fp.f.f.kernel, tau, x, y0, fp.f.sigma2, ctx=ctx) + _mean_vector(fp.f.f.mean, tau)
+
+
+def simulate(rng, cov: SemiSeparable, tau, sigma2, ctx: Context | None = None):
+    """simulate(rng, cov, tau, sigma2)   src/celerite_solver.jl:497-513: one realisation; `rng` is a numpy Generator
+    supplying the standard normals (the reference's randn(rng, N), :528)."""
+    a, b, c, d = (np.real(np.atleast_1d(v)) for v in cov.celerite_coefs())
+    tau = _f64(tau).reshape(-1)
+    q = rng.standard_normal(len(tau))
+    s2 = _f64(np.broadcast_to(sigma2, tau.shape))
+    return (ctx or default_context()).simulate(a[None, :], b[None, :], c, d, tau, s2, q[None, :])[0]
+
+
+def rand(rng, fx: "FiniteScalableGP", t=None, ctx: Context | None = None):
+    """rand(rng, f(t, sigma2)) / rand(rng, f(t, sigma2), t')   src/scalable_GP.jl:137-158 (zero variance at new times)."""
+    if t is None:
+        return simulate(rng, fx.f.kernel, fx.x, fx.sigma2, ctx=ctx) + _mean_vector(fx.f.mean, fx.x)
+    t = _f64(t).reshape(-1)
+    return simulate(rng, fx.f.kernel, t, np.zeros(len(t)), ctx=ctx) + _mean_vector(fx.f.mean, t)
 
 
 def logpdf(fx: FiniteScalableGP, Y, ctx: Context | None = None):

@@ -597,3 +597,104 @@ def test_in_process_farm_sharding(golden_dir):
     got2 = farm.logl_batch(A[:2], Bc[:2], C, Dd, mu=P[:2, 5], nu=P[:2, 4], shift=P[:2, 6])    # fewer draws than devices
     assert relerr(got2, ref[:2]) < 1e-10
     farm.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# posterior mean and simulation (the callers either side of the likelihood)
+# ---------------------------------------------------------------------------------------------
+def test_predict_reference_cases(ctx, golden_dir):
+    """mean(posterior(f(t, s2), y)[, tau]) on the inputs of test/test_scalablegp.jl:134-157 and
+    test/test_prediction.jl:49-58 / test_predict_celerite.jl: equal to the oracle's `pred` (1e-10) and, like the
+    reference asserts, to the dense prediction."""
+    t = np.array([0.0, 3.0, 3.2, 3.4, 45.5, 101.2])
+    tx = np.array([0.0, 1.4, 2.3, 3.0, 3.1, 3.2, 3.3, 3.4, 45.5, 101.2, 202.32])
+    y = np.array([1.3, 2.2, 4.21, 2.5, 3.3, 5.2]); yerr = np.array([0.1, 0.2, 0.1, 0.1, 0.2, 0.1])
+    R = pj.approx(pj.SingleBendingPowerLaw(0.2, 0.02, 3.1), 1e-4, 1e1, 30, 2.31, basis_function="SHO")
+    fp = pj.posterior(pj.ScalableGP(1.2, R)(t, yerr ** 2), y)
+    for tau in (None, tx):
+        tt = t if tau is None else tau
+        m = pj.mean(fp, tau, ctx=ctx)
+        assert np.isfinite(m).all()
+        np.testing.assert_allclose(m, O.predict(R.a, R.b, R.c, R.d, tt, t, y - 1.2, yerr ** 2) + 1.2, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(m, O.predict_direct_numpy(R.a, R.b, R.c, R.d, tt, t, y - 1.2, yerr ** 2) + 1.2, rtol=1e-9)
+    A = np.loadtxt(golden_dir / "simu.txt")
+    t, y, yerr = A[:, 0], A[:, 1], A[:, 2]
+    f0, fM = 1 / (t[-1] - t[0]) / 100, 1 / np.min(np.diff(t)) / 2 * 20
+    rng = np.random.default_rng(0)
+    grids = (t, np.linspace(t.min(), t.max(), 1000), np.linspace(t.min() - 30, t.max() + 30, 1000),
+             np.sort(rng.random(1000)) * (t[-1] - t[0]) * 2 + (t[0] - t[-1] / 2))
+    kernels = [pj.approx(pj.SingleBendingPowerLaw(0.82, 0.01, 3.3), f0, fM, 20, np.var(y, ddof=1)),
+               pj.approx(pj.SingleBendingPowerLaw(0.82, 0.01, 3.3), f0, fM, 20, np.var(y, ddof=1), basis_function="DRWCelerite"),
+               pj.Exp(1.0, 2.4), pj.Celerite(3.2, 0.2, 3.0, 0.2)]
+    for k in kernels:
+        a, b, c, d = (np.real(np.atleast_1d(v)) for v in k.celerite_coefs())
+        for tau in grids:
+            m = pj.predict(k, tau, t, y, yerr ** 2, ctx=ctx)
+            np.testing.assert_allclose(m, O.predict(a, b, c, d, tau, t, y, yerr ** 2), rtol=1e-10, atol=1e-11)
+    # unsorted tau: every evaluation time is independent here (the reference requires ascending tau)
+    tau = grids[3]; perm = rng.permutation(len(tau))
+    k = kernels[0]
+    np.testing.assert_allclose(pj.predict(k, tau[perm], t, y, yerr ** 2, ctx=ctx), pj.predict(k, tau, t, y, yerr ** 2, ctx=ctx)[perm],
+                               rtol=1e-13, atol=1e-14)
+
+
+@pytest.mark.parametrize("J,N,B", [(3, 50, 4), (10, 257, 7), (20, 1000, 300), (39, 300, 3)])
+def test_predict_random_batches(ctx, J, N, B):
+    """B draws at once (more than one 256-draw chunk), mu / nu per draw, every RPL of the factor-storing scan."""
+    rng = np.random.default_rng(700 + J)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    tau = np.sort(rng.uniform(t[0] - 5, t[-1] + 5, 123))
+    tau[:3] = t[[0, N // 2, N - 1]]          # exactly on data points
+    tau = np.sort(tau)
+    ds = pj.Dataset(t, y, s2, ctx)
+    got, st = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu, return_status=True)
+    assert (st == 0).all()
+    for i in list(range(min(B, 5))) + [B - 1]:
+        ref = O.predict(A[i], Bc[i], C, Dd, tau, t, y - mu[i], nu[i] * s2) + mu[i]
+        np.testing.assert_allclose(got[i], ref, rtol=1e-10, atol=1e-11)
+    # the log-likelihood the same launch computes is still the batch log-likelihood
+    ll = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    assert np.isfinite(ll).all()
+
+
+def test_predict_full_size(ctx, full_size):
+    """N = 1e4 (BASELINE config shape), M = 2000: against the oracle to 1e-8 and self-consistency at the data."""
+    t, y, yerr = full_size
+    th = O.synthetic_theta(6, t, y)
+    A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, 20, "SHO")
+    tau = np.sort(np.random.default_rng(1).uniform(t[0], t[-1], 2000))
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    got = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu)
+    for i in range(2):
+        ref = O.predict(A[i], Bc[i], C, Dd, tau, t, y - mu[i], nu[i] * yerr ** 2) + mu[i]
+        assert np.max(np.abs(got[i] - ref)) <= 1e-8 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_simulate_matches_oracle(ctx, golden_dir):
+    """simulate / rand: y = L D^(1/2) q for the same normals q as the oracle's `sim` (src/celerite_solver.jl:515-549)."""
+    A = np.loadtxt(golden_dir / "simu.txt")
+    t, yerr = A[:, 0], A[:, 2]
+    f0, fM = 1 / (t[-1] - t[0]) / 100, 1 / np.min(np.diff(t)) / 2 * 20
+    rng = np.random.default_rng(3)
+    for basis in ("SHO", "DRWCelerite"):
+        R = pj.approx(pj.SingleBendingPowerLaw(0.82, 0.01, 3.3), f0, fM, 20, 1.0, basis_function=basis)
+        q = rng.standard_normal((5, len(t)))
+        scale = np.array([1.0, 2.0, 0.5, 1.5, 0.1])[:, None]
+        ys = ctx.simulate(scale * R.a, scale * R.b, R.c, R.d, t, yerr ** 2, q)
+        for i in range(5):
+            ref = O.sim(scale[i] * R.a, scale[i] * R.b, R.c, R.d, t, yerr ** 2, q[i])
+            assert np.max(np.abs(ys[i] - ref)) <= 1e-10 * np.max(np.abs(ref)), basis
+    # reference-shaped entry: rand(rng, f(t, s2)) adds the mean; same generator state -> same normals
+    R = pj.approx(pj.SingleBendingPowerLaw(0.82, 0.01, 3.3), f0, fM, 20, 1.0)
+    y1 = pj.rand(np.random.default_rng(9), pj.ScalableGP(0.7, R)(t, yerr ** 2), ctx=ctx)
+    ref = O.sim(R.a, R.b, R.c, R.d, t, yerr ** 2, np.random.default_rng(9).standard_normal(len(t))) + 0.7
+    assert np.max(np.abs(y1 - ref)) <= 1e-10 * np.max(np.abs(ref))
+    # more draws than one chunk, and the sample covariance of many draws approaches K
+    tt = np.cumsum(np.random.default_rng(4).uniform(0.2, 1.0, 24)); s2 = np.full(24, 0.05)
+    a, b, c, d = np.array([1.0, 0.4]), np.array([0.2, 0.0]), np.array([0.3, 1.0]), np.array([1.1, 0.0])
+    B = 4000
+    q = np.random.default_rng(5).standard_normal((B, 24))
+    ys = ctx.simulate(np.tile(a, (B, 1)), np.tile(b, (B, 1)), c, d, tt, s2, q)
+    K = np.array([[O.kappa(a, b, c, d, abs(ti - tj)) for tj in tt] for ti in tt]) + np.diag(s2)
+    assert np.max(np.abs(ys.T @ ys / B - K)) < 0.15 * np.max(np.abs(K))
+    assert np.max(np.abs(ys[7] - O.sim(a, b, c, d, tt, s2, q[7]))) < 1e-12

@@ -152,3 +152,29 @@ def test_sim_matches_covariance():
     Lf = np.stack([O.sim(a, b, c, d, t, s2, np.eye(12)[k]) for k in range(12)], axis=1)
     K = np.array([[O.kappa(a, b, c, d, abs(ti - tj)) for tj in t] for ti in t]) + np.diag(s2)
     np.testing.assert_allclose(Lf @ Lf.T, K, rtol=1e-11, atol=1e-13)
+
+
+def test_predict_equals_dense_prediction(golden_dir):
+    """The reference pins its celerite `predict` against the dense `predict_direct` (isapprox, rtol 1.5e-8):
+    test/test_scalablegp.jl:134-157 (N = 6 literals, tau on / between / outside the data),
+    test/test_prediction.jl:49-58 and test/test_predict_celerite.jl:3-28 (test/data/simu.txt, N = 489)."""
+    t = np.array([0.0, 3.0, 3.2, 3.4, 45.5, 101.2])
+    tx = np.array([0.0, 1.4, 2.3, 3.0, 3.1, 3.2, 3.3, 3.4, 45.5, 101.2, 202.32])
+    y = np.array([1.3, 2.2, 4.21, 2.5, 3.3, 5.2]); yerr = np.array([0.1, 0.2, 0.1, 0.1, 0.2, 0.1])
+    a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, 0.2, 0.02, 3.1), 1e-4, 1e1, 30, 2.31)
+    for tau in (t, tx):
+        np.testing.assert_allclose(O.predict(a, b, c, d, tau, t, y - 1.2, yerr ** 2),
+                                   O.predict_direct_numpy(a, b, c, d, tau, t, y - 1.2, yerr ** 2), rtol=1e-10, atol=1e-12)
+    A = np.loadtxt(golden_dir / "simu.txt")
+    t, y, yerr = A[:, 0], A[:, 1], A[:, 2]
+    f0, fM = 1 / (t[-1] - t[0]) / 100, 1 / np.min(np.diff(t)) / 2 * 20
+    rng = np.random.default_rng(0)
+    grids = (t, np.linspace(t.min(), t.max(), 1000), np.linspace(t.min() - 30, t.max() + 30, 1000),
+             np.sort(rng.random(1000)) * (t[-1] - t[0]) * 2 + (t[0] - t[-1] / 2))
+    coefs = [O.approx(lambda f: O.single_bending_power_law(f, 0.82, 0.01, 3.3), f0, fM, 20, np.var(y, ddof=1)),
+             ([0.5], [0.0], [2.4], [0.0]),          # Exp(1.0, 2.4): a = A / 2 (src/Exp.jl:29-33)
+             ([3.2], [0.2], [3.0], [0.2])]          # Celerite(3.2, 0.2, 3.0, 0.2)
+    for a, b, c, d in coefs:
+        for tau in grids:
+            np.testing.assert_allclose(O.predict(a, b, c, d, tau, t, y, yerr ** 2),
+                                       O.predict_direct_numpy(a, b, c, d, tau, t, y, yerr ** 2), rtol=1e-9, atol=1e-11)
