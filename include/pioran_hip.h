@@ -173,6 +173,13 @@ int pioran_farm_logl_batch(pioran_farm* farm, int64_t B, int64_t J, const double
 int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,
                      const double* c, const double* d, const double* t, const double* y,
                      const double* sigma2, double* out, int32_t* info);
+/* predict_cov (src/direct_solver.jl:28-69; cov / std / rand of a PosteriorGP, src/scalable_GP.jl:73-104):
+ *     cov_out = K(tau,tau) - K(tau,t) (K(t,t) + diag(sigma2))^-1 K(t,tau),   M x M, symmetric,
+ * computed as the Schur complement the blocked MFMA Cholesky of the augmented (N+M) x (N+M) matrix leaves when it stops
+ * after the data columns.  info as in pioran_dense_nll (cov_out is NaN when K(t,t) + diag(sigma2) is not PD). */
+int pioran_dense_predict_cov(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,
+                             const double* c, const double* d, const double* t, const double* sigma2, int64_t M,
+                             const double* tau, double* cov_out, int32_t* info);
 /* Covariance build alone (K as N x N column-major host array) — kappa of src/acvf.jl:138-140. */
 int pioran_dense_covariance(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,
                             const double* c, const double* d, const double* t, const double* sigma2,

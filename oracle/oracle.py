@@ -198,6 +198,20 @@ def predict_direct_numpy(a, b, c, d, tau, t, y, sigma2):
     return Kt0 @ z
 
 
+def predict_cov_numpy(a, b, c, d, tau, t, sigma2):
+    """predict_cov (src/direct_solver.jl:28-69): K_tau - w'w, w = L \\ K_tau0' with L the Cholesky factor of K0 + diag(sigma2)."""
+    a, b, c, d, tau, t, sigma2 = (np.asarray(v, dtype=np.float64) for v in (a, b, c, d, tau, t, sigma2))
+    def kern(dt):
+        dt = np.abs(dt)[..., None]
+        return (np.exp(-c * dt) * (a * np.cos(d * dt) + b * np.sin(d * dt))).sum(-1)
+    K0 = kern(t[:, None] - t[None, :]) + np.diag(sigma2)
+    Kt0 = kern(tau[:, None] - t[None, :])
+    Kt = kern(tau[:, None] - tau[None, :])
+    L = np.linalg.cholesky(K0)
+    w = np.linalg.solve(L, Kt0.T)
+    return Kt - w.T @ w
+
+
 def dense_nll_numpy(a, b, c, d, t, y, sigma2):
     """src/direct_solver.jl:6-21 with numpy's LAPACK Cholesky (second implementation)."""
     a = np.asarray(a, float); b = np.asarray(b, float)

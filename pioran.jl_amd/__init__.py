@@ -3,9 +3,9 @@
 Directory name has a dot, so import it through the repo-root shim: `import pioran_jl_amd as pj`.
 """
 from . import _lib, farm  # noqa: F401
-from .gp import (Context, CustomMean, Dataset, Farm, FiniteScalableGP, PosteriorGP, ScalableGP, default_context,
-                 log_likelihood, log_likelihood_direct, logl, logpdf, logpdf_batch, mean, posterior, predict, rand,
-                 simulate)
+from .gp import (Context, CustomMean, Dataset, Farm, FiniteScalableGP, PosteriorGP, ScalableGP, cov, default_context,
+                 log_likelihood, log_likelihood_direct, logl, logpdf, logpdf_batch, mean, posterior, predict, predict_cov,
+                 rand, rand_posterior, simulate, std)
 from .kernels import (Celerite, Exp, ScaledKernel, SemiSeparable, SHO, SumOfCelerite, SumOfSemiSeparable,
                       SumOfTerms, celerite_coefs)
 from .psd import (QPO, DoubleBendingPowerLaw, SingleBendingPowerLaw, approx, approx_batch, build_approx,

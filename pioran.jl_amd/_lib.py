@@ -53,6 +53,7 @@ SIGNATURES = {
     "pioran_farm_logl_batch": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pioran_dense_nll": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [c_void_p, c_void_p]),
+    "pioran_dense_predict_cov": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 6 + [i64, c_void_p, c_void_p, c_void_p]),
     "pioran_dense_covariance": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 6 + [c_void_p]),
 }
 

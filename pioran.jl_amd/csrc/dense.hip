@@ -69,6 +69,34 @@ __global__ void __launch_bounds__(256) dense_build_kernel(int64_t N, int64_t Mp,
     if (i == k) A[Mp + k * ld] = k < N ? y[k] : 0.0;            // the y row
 }
 
+// Covariance of an arbitrary list of times, a NaN time marking an identity (padding) row/column; no y row.
+// Used for the augmented matrix [[K(t,t) + diag(s2), K(t,tau)], [K(tau,t), K(tau,tau)]] of predict_cov.
+__global__ void __launch_bounds__(256) dense_build_aug_kernel(int64_t Mtot, int64_t ld, int32_t J, const double* __restrict__ a,
+                                                              const double* __restrict__ b, const double* __restrict__ c,
+                                                              const double* __restrict__ d, const double* __restrict__ te,
+                                                              const double* __restrict__ s2e, double* __restrict__ A)
+{
+    if ((int64_t)blockIdx.x < (int64_t)blockIdx.y) return;  // tile strictly above the diagonal
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const int64_t k = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= Mtot || k >= Mtot || i < k) return;
+    const double ti = te[i], tk = te[k];
+    double v;
+    if (isnan(ti) || isnan(tk)) {
+        v = (i == k) ? 1.0 : 0.0;
+    } else {
+        const double tau = fabs(ti - tk);
+        v = 0.0;
+        for (int j = 0; j < J; ++j) {
+            double sn, cs;
+            sincos(d[j] * tau, &sn, &cs);
+            v += exp(-c[j] * tau) * (a[j] * cs + b[j] * sn);   // src/Celerite.jl:42-44, summed as acvf.jl:138-140
+        }
+        if (i == k) v += s2e[i];
+    }
+    A[i + k * ld] = v;
+}
+
 // ---- fast covariance build for sorted time stamps -------------------------------------------------------------
 // Off-diagonal 64 x 64 tile (rows i0.., columns k0.., i0 >= k0 + 64, t ascending => tau = t_i - t_k >= 0).
 // With t_ref = t[i0] both factors of exp(-c tau) = exp(-c (t_i - t_ref)) exp(-c (t_ref - t_k)) are <= 1 (no
@@ -435,7 +463,7 @@ __global__ void __launch_bounds__(256) dense_panel_kernel(double* __restrict__ A
 // With X[row][k] = P[j][k] and Y[k][col] = P[i][k], D[row][col] = (P P^T)[i][j]: col = l&15 runs along i,
 // the memory-contiguous index of the column-major slab, so C loads/stores are 128-byte segments.
 __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__ A, int64_t ld, int64_t kb, int64_t Mp,
-                                                         double* __restrict__ ws, int32_t* __restrict__ info)
+                                                         double* __restrict__ ws, int32_t* __restrict__ info, int factor_next)
 {
     // Workgroups of four wavefronts.  Workgroup 0 is the critical path: its four waves share tile (0,0) — the NEXT
     // diagonal block — one 16-column strip each, keep the updated tile in LDS and factor it right away
@@ -476,7 +504,8 @@ __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__
             for (int g = 0; g < 4; ++g)
                 Ls[(ib * 16 + lr) * LP + wave * 16 + lk + 4 * g] = cv[ib][g] - acc[ib][g];   // row i, column j
         __syncthreads();
-        const int bad = factor_block64(Ls, ws, &flag, tid);
+        // (partial factorisation, predict_cov: the last step leaves its Schur complement unfactored)
+        const int bad = factor_next ? factor_block64(Ls, ws, &flag, tid) : 0;
         __syncthreads();
         store_block_lower(Ls, A + j0 + j0 * ld, ld, tid);
         if (tid == 0 && bad && *info == 0) *info = (int32_t)(j0 + bad);
@@ -606,9 +635,37 @@ int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double*
         const int64_t nt = (Mp - kb - NB) / NB + 1;
         if (nt > 1)
             hipLaunchKernelGGL(dense_syrk_kernel, dim3((unsigned)(1 + (nt * (nt + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
-                               kb, Mp, ws, info);
+                               kb, Mp, ws, info, 1);
     }
     hipLaunchKernelGGL(dense_finish_kernel, dim3(1), dim3(256), 0, stream, K, ld, N, Mp, out, info);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
+// predict_cov (src/direct_solver.jl:28-69): K(tau,tau) - K(tau,t) (K(t,t) + diag(s2))^-1 K(t,tau) as the Schur complement
+// the blocked Cholesky leaves behind when it stops after the data columns.  te / s2e: device, Mtot = Mp + Mq entries,
+// [t (N) | NaN x (Mp - N) | tau (M) | NaN x (Mq - M)] with Mp, Mq = N, M rounded up to 64.  K: slab with
+// ld = Mtot + 64, ld * Mtot + 1024 doubles; afterwards the lower triangle of K[Mp.., Mp..] holds the M x M result.
+int pioran_dense_predict_cov_device(int64_t N, int64_t M, int32_t J, const double* a, const double* b, const double* c,
+                                    const double* d, const double* te, const double* s2e, double* K, int32_t* info,
+                                    hipStream_t stream)
+{
+    const int64_t Mp = (N + NB - 1) / NB * NB, Mq = (M + NB - 1) / NB * NB, Mtot = Mp + Mq, ld = Mtot + NB;
+    if (hipMemsetAsync(K, 0, (size_t)ld * (size_t)Mtot * sizeof(double), stream) != hipSuccess) return PIORAN_ERR_HIP;
+    if (hipMemsetAsync(info, 0, sizeof(int32_t), stream) != hipSuccess) return PIORAN_ERR_HIP;
+    const unsigned tiles = (unsigned)(Mtot / 16);
+    hipLaunchKernelGGL(dense_build_aug_kernel, dim3(tiles, tiles), dim3(256), 0, stream, Mtot, ld, J, a, b, c, d, te, s2e, K);
+    double* ws = K + (size_t)ld * (size_t)Mtot;
+    hipLaunchKernelGGL(dense_diag0_kernel, dim3(1), dim3(256), 0, stream, K, ld, ws, info);
+    for (int64_t kb = 0; kb < Mp; kb += NB) {
+        const int64_t below = Mtot - kb;
+        if (below <= 65536)
+            hipLaunchKernelGGL(dense_panel_kernel<1>, dim3((unsigned)((below + 63) / 64)), dim3(256), 0, stream, K, ld, kb, ws);
+        else
+            hipLaunchKernelGGL(dense_panel_kernel<2>, dim3((unsigned)((below + 127) / 128)), dim3(256), 0, stream, K, ld, kb, ws);
+        const int64_t nt = (Mtot - kb - NB) / NB + 1;   // >= 2: the tau block is never empty
+        hipLaunchKernelGGL(dense_syrk_kernel, dim3((unsigned)(1 + (nt * (nt + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
+                           kb, Mtot, ws, info, kb + NB < Mp ? 1 : 0);
+    }
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 

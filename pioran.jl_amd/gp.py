@@ -99,6 +99,16 @@ class Context:
                                                _ptr(y), _ptr(sigma2), ctypes.byref(out), ctypes.byref(info)), self._h)
         return (out.value, info.value) if return_info else out.value
 
+    def dense_predict_cov(self, a, b, c, d, tau, t, sigma2, return_info=False):
+        """predict_cov(cov, tau, t, sigma2): posterior covariance at tau, (M, M)   src/direct_solver.jl:28-69."""
+        a, b, c, d, tau, t, sigma2 = map(_f64, (a, b, c, d, tau, t, sigma2))
+        out = np.empty((len(tau), len(tau)))
+        info = ctypes.c_int32()
+        _lib.check(_lib.lib().pioran_dense_predict_cov(self._h, len(t), len(a), _ptr(a), _ptr(b), _ptr(c), _ptr(d), _ptr(t),
+                                                       _ptr(sigma2), len(tau), _ptr(tau), _ptr(out), ctypes.byref(info)),
+                   self._h)
+        return (out, info.value) if return_info else out
+
     def dense_covariance(self, a, b, c, d, t, sigma2):
         a, b, c, d, t, sigma2 = map(_f64, (a, b, c, d, t, sigma2))
         K = np.empty((len(t), len(t)), dtype=np.float64)
@@ -368,6 +378,34 @@ def mean(fp: PosteriorGP, tau=None, ctx: Context | None = None):
     tau = x if tau is None else _f64(tau).reshape(-1)
     y0 = fp.y - _mean_vector(fp.f.f.mean, x)
     return predict(fp.f.f.kernel, tau, x, y0, fp.f.sigma2, ctx=ctx) + _mean_vector(fp.f.f.mean, tau)
+
+
+def predict_cov(cov_fn: SemiSeparable, tau, t, sigma2, ctx: Context | None = None):
+    """predict_cov(cov, tau, t, sigma2)   src/direct_solver.jl:28-69 (dense, MFMA Cholesky of the augmented matrix)."""
+    a, b, c, d = (np.real(np.atleast_1d(v)) for v in cov_fn.celerite_coefs())
+    K, info = (ctx or default_context()).dense_predict_cov(a, b, c, d, tau, t, sigma2, return_info=True)
+    if info != 0:
+        raise np.linalg.LinAlgError(f"matrix is not positive definite; Cholesky factorization failed at pivot {info}")
+    return K
+
+
+def cov(fp: PosteriorGP, tau=None, ctx: Context | None = None):
+    """cov(fp[, tau])   src/scalable_GP.jl:73-78, 95-96."""
+    tau = fp.f.x if tau is None else _f64(tau).reshape(-1)
+    return predict_cov(fp.f.f.kernel, tau, fp.f.x, fp.f.sigma2, ctx=ctx)
+
+
+def std(fp: PosteriorGP, tau=None, ctx: Context | None = None):
+    """std(fp[, tau]) = sqrt.(diag(cov))   src/scalable_GP.jl:103-104."""
+    return np.sqrt(np.diag(cov(fp, tau, ctx=ctx)))
+
+
+def rand_posterior(rng, fp: PosteriorGP, tau=None, n: int = 1, ctx: Context | None = None):
+    """rand(rng, fp[, tau], N): draws from MvNormal(mean, cov)   src/scalable_GP.jl:106-129.  Returns (len(tau), n)."""
+    tau = fp.f.x if tau is None else _f64(tau).reshape(-1)
+    m, K = mean(fp, tau, ctx=ctx), cov(fp, tau, ctx=ctx)
+    L = np.linalg.cholesky(K + 1e-14 * np.trace(K) / len(tau) * np.eye(len(tau)))
+    return m[:, None] + L @ rng.standard_normal((len(tau), n))
 
 
 def simulate(rng, cov: SemiSeparable, tau, sigma2, ctx: Context | None = None):

@@ -255,4 +255,17 @@ function log_likelihood_direct_hip(cov::SemiSeparable, t::Vector{Float64}, y::Ve
     return out[]
 end
 
+# predict_cov (src/direct_solver.jl:28-69): posterior covariance at τ, the matrix behind cov / std / rand of a PosteriorGP
+function predict_cov_hip(cov::SemiSeparable, τ::Vector{Float64}, t::Vector{Float64}, σ²::Vector{Float64}; ctx = default_context())
+    a, b, c, d = map(v -> collect(Float64, real.(v)), celerite_coefs(cov))
+    M = length(τ)
+    out = Matrix{Float64}(undef, M, M)
+    info = Ref{Int32}(0)
+    GC.@preserve a b c d τ t σ² out check(ccall((:pioran_dense_predict_cov, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64,
+         Ptr{Cdouble}, Ptr{Cdouble}, Ref{Int32}), ctx.h, length(t), length(a), a, b, c, d, t, σ², M, τ, out, info))
+    info[] != 0 && throw(LinearAlgebra.PosDefException(info[]))
+    return out
+end
+
 end # module

@@ -698,3 +698,40 @@ def test_simulate_matches_oracle(ctx, golden_dir):
     K = np.array([[O.kappa(a, b, c, d, abs(ti - tj)) for tj in tt] for ti in tt]) + np.diag(s2)
     assert np.max(np.abs(ys.T @ ys / B - K)) < 0.15 * np.max(np.abs(K))
     assert np.max(np.abs(ys[7] - O.sim(a, b, c, d, tt, s2, q[7]))) < 1e-12
+
+
+def test_predict_cov_reference_cases(ctx, golden_dir):
+    """cov / std of the posterior (src/direct_solver.jl:28-69 through src/scalable_GP.jl:73-104) on the inputs of
+    test/test_scalablegp.jl:134-175: finite, positive definite, equal to the numpy restatement of predict_cov."""
+    t = np.array([0.0, 3.0, 3.2, 3.4, 45.5, 101.2])
+    tx = np.array([0.0, 1.4, 2.3, 3.0, 3.1, 3.2, 3.3, 3.4, 45.5, 101.2, 202.32])
+    y = np.array([1.3, 2.2, 4.21, 2.5, 3.3, 5.2]); yerr = np.array([0.1, 0.2, 0.1, 0.1, 0.2, 0.1])
+    R = pj.approx(pj.SingleBendingPowerLaw(0.2, 0.02, 3.1), 1e-4, 1e1, 30, 2.31, basis_function="SHO")
+    fp = pj.posterior(pj.ScalableGP(1.2, R)(t, yerr ** 2), y)
+    for tau in (None, tx):
+        tt = t if tau is None else tau
+        K = pj.cov(fp, tau, ctx=ctx)
+        ref = O.predict_cov_numpy(R.a, R.b, R.c, R.d, tt, t, yerr ** 2)
+        assert np.isfinite(K).all() and np.allclose(K, K.T, rtol=0, atol=0)
+        scale = np.max(np.abs(ref))
+        assert np.max(np.abs(K - ref)) <= 1e-9 * scale
+        assert np.linalg.eigvalsh(K).min() > -1e-9 * scale                      # isposdef up to rounding, like the reference's checks
+        np.testing.assert_allclose(pj.std(fp, tau, ctx=ctx), np.sqrt(np.diag(ref)), rtol=1e-6, atol=1e-7)
+    # a larger case crossing several 64-blocks on both sides: N = 489 data points, M = 300 new times
+    A = np.loadtxt(golden_dir / "simu.txt")
+    t, y, yerr = A[:, 0], A[:, 1], A[:, 2]
+    f0, fM = 1 / (t[-1] - t[0]) / 100, 1 / np.min(np.diff(t)) / 2 * 20
+    R = pj.approx(pj.SingleBendingPowerLaw(0.82, 0.01, 3.3), f0, fM, 20, np.var(y, ddof=1))
+    tau = np.linspace(t.min() - 30, t.max() + 30, 300)
+    K = pj.predict_cov(R, tau, t, yerr ** 2, ctx=ctx)
+    ref = O.predict_cov_numpy(R.a, R.b, R.c, R.d, tau, t, yerr ** 2)
+    assert np.max(np.abs(K - ref)) <= 1e-9 * np.max(np.abs(ref))
+    # posterior draws: right shape, centred on the posterior mean
+    fp = pj.posterior(pj.ScalableGP(0.0, R)(t, yerr ** 2), y)
+    draws = pj.rand_posterior(np.random.default_rng(2), fp, tau, 200, ctx=ctx)
+    assert draws.shape == (300, 200)
+    m = pj.mean(fp, tau, ctx=ctx)
+    assert np.max(np.abs(draws.mean(axis=1) - m)) < 6 * np.sqrt(np.max(np.diag(K)) / 200) + 1e-6
+    # K(t,t) + diag(sigma2) not positive definite -> LinAlgError like the reference's PosDefException
+    with pytest.raises(np.linalg.LinAlgError):
+        pj.predict_cov(pj.Celerite(-1.0, 0.0, 0.5, 0.0), tau[:5], t[:70], np.zeros(70), ctx=ctx)
