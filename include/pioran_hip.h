@@ -139,6 +139,16 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
 int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
                             const double* Dd, const double* mu, const double* nu, int64_t M, const double* tau,
                             double* mean_out, int32_t* status);
+/* log L and its gradient (what ForwardDiff obtains through the generic `logl`,
+ * src/celerite_solver.jl:316, test/test_likelihood.jl:55-60) by reverse mode through the recurrence, for B draws with
+ * shared (c, d):  grad_a, grad_b [B][J] = dlogL/da_j, dlogL/db_j;  grad_nu, grad_mu [B] (may be NULL);
+ * grad_y, grad_sigma2 [B][N] (may be NULL) = dlogL/dy_n and dlogL/dsigma2_n of the series in the data set — what a
+ * model that transforms the data per draw (the sampled shift of docs/src/ultranest.md:199-205) chains through.
+ * (c, d) are not differentiated: with `approx` they depend on (f_min, f_max) only. */
+int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                              const double* Dd, const double* mu, const double* nu, double* out, int32_t* status,
+                              double* grad_a, double* grad_b, double* grad_nu, double* grad_mu, double* grad_y,
+                              double* grad_sigma2);
 /* simulate (src/celerite_solver.jl:497-513 -> sim :515-549; rand(f(t, sigma2)) of src/scalable_GP.jl:137-146):
  * realisations y_b = L_b D_b^(1/2) q_b of the GP with kernel (a_b, b_b, c, d) + diag(sigma2) at the times t, from
  * caller-supplied standard-normal draws q [B][N] (the reference draws them with its rng, :528).  y_out [B][N]. */

@@ -37,11 +37,12 @@ _ip = ctypes.POINTER(ctypes.c_int32)
 
 def build(force: bool = False) -> Path:
     """Compile the C restatement with gcc (seconds)."""
-    if not force and _LIB.exists() and _LIB.stat().st_mtime >= _SRC.stat().st_mtime:
+    srcs = [_SRC, _SRC.with_name("celerite_oracle_cstep.c")]
+    if not force and _LIB.exists() and all(_LIB.stat().st_mtime >= f.stat().st_mtime for f in srcs):
         return _LIB
     _BUILD.mkdir(exist_ok=True)
     tmp = _BUILD / f"liboracle.{os.getpid()}.so"
-    subprocess.run(["gcc", *_CFLAGS, str(_SRC), "-o", str(tmp), "-lm"], check=True)
+    subprocess.run(["gcc", *_CFLAGS, *map(str, srcs), "-o", str(tmp), "-lm"], check=True)
     os.replace(tmp, _LIB)
     return _LIB
 
@@ -67,6 +68,8 @@ def lib():
         L.oracle_dense_nll.argtypes = [i64, i64, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.oracle_kappa.restype = ctypes.c_double
         L.oracle_kappa.argtypes = [i64, _dp, _dp, _dp, _dp, ctypes.c_double]
+        L.oracle_logl_complex.restype = ctypes.c_double
+        L.oracle_logl_complex.argtypes = [i64, i64] + [_dp] * 11 + [_dp]
         L.oracle_predict.restype = None
         L.oracle_predict.argtypes = [i64, i64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, i64, _dp, _dp]
         L.oracle_sim.restype = None
@@ -174,6 +177,41 @@ def logl_numpy(a, b, c, d, t, y, sigma2):
         ld += np.log(abs(D))
         q2 += z * z / D
     return -0.5 * ld - 0.5 * N * np.log(2 * np.pi) - 0.5 * q2
+
+
+def logl_grad(a, b, c, d, t, y, sigma2, series=False, h=1e-30):
+    """Exact derivatives of logl (src/celerite_solver.jl:312-334) by the complex step on the complex twin of the C
+    restatement: d/da_j, d/db_j (J each) and, with series=True, d/dy_n, d/dsigma2_n (N each; 2N more evaluations)."""
+    a, b, c, d, t, y, sigma2 = (np.ascontiguousarray(v, dtype=np.float64) for v in (a, b, c, d, t, y, sigma2))
+    J, N = len(a), len(t)
+    P = lambda v: None if v is None else v.ctypes.data_as(_dp)
+    im = ctypes.c_double()
+    def run(a_im=None, b_im=None, y_im=None, s_im=None):
+        lib().oracle_logl_complex(N, J, P(a), P(a_im), P(b), P(b_im), P(c), P(d), P(t), P(y), P(y_im), P(sigma2), P(s_im),
+                                  ctypes.byref(im))
+        return im.value / h
+    def sweep(n, key):
+        out = np.empty(n)
+        for k in range(n):
+            e = np.zeros(n); e[k] = h
+            out[k] = run(**{key: e})
+        return out
+    res = {"grad_a": sweep(J, "a_im"), "grad_b": sweep(J, "b_im")}
+    if series:
+        res["grad_y"] = sweep(N, "y_im"); res["grad_sigma2"] = sweep(N, "s_im")
+    return res
+
+
+def logl_dir(a, b, c, d, t, y, sigma2, da=None, db=None, dy=None, ds2=None, h=1e-30):
+    """Directional derivative of logl along (da, db, dy, ds2) by one complex step (exact to rounding)."""
+    a, b, c, d, t, y, sigma2 = (np.ascontiguousarray(v, dtype=np.float64) for v in (a, b, c, d, t, y, sigma2))
+    P = lambda v: None if v is None else np.ascontiguousarray(h * np.asarray(v, dtype=np.float64))
+    parts = [P(da), P(db), P(dy), P(ds2)]
+    Q = lambda v: None if v is None else v.ctypes.data_as(_dp)
+    im = ctypes.c_double()
+    lib().oracle_logl_complex(len(t), len(a), Q(a), Q(parts[0]), Q(b), Q(parts[1]), Q(c), Q(d), Q(t), Q(y), Q(parts[2]),
+                              Q(sigma2), Q(parts[3]), ctypes.byref(im))
+    return im.value / h
 
 
 def predict(a, b, c, d, tau, t, y, sigma2):

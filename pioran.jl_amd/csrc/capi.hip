@@ -705,6 +705,61 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
     return PIORAN_OK;
 }
 
+int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                              const double* Dd, const double* mu, const double* nu, double* out, int32_t* status,
+                              double* grad_a, double* grad_b, double* grad_nu, double* grad_mu, double* grad_y,
+                              double* grad_sigma2)
+{
+    if (!ds || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !out || !grad_a || !grad_b) return PIORAN_ERR_ARG;
+    pioran_ctx* ctx = ds->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
+    if (ds->R > 79 || ds->npd_terms) return PIORAN_ERR_UNSUPPORTED;
+    // the forward pass keeps S_n of every step: bound the chunk by ~48 GB of workspace
+    int64_t chunk = B < 256 ? B : 256;
+    while (chunk > 1 && pioran_grad_workspace_doubles(chunk, ds->N, ds->R) * sizeof(double) > (48ull << 30)) chunk /= 2;
+    if ((rc = ensure(ctx, ctx->bwork, pioran_grad_workspace_doubles(chunk, ds->N, ds->R) * sizeof(double)))) return rc;
+    const size_t cj = (size_t)chunk * (size_t)J * sizeof(double), cn = (size_t)chunk * (size_t)ds->N * sizeof(double);
+    if ((rc = ensure(ctx, ctx->bC, 2 * cj))) return rc;              // grad_a | grad_b
+    if ((rc = ensure(ctx, ctx->bD, 2 * chunk * sizeof(double)))) return rc;   // grad_nu | grad_mu
+    if (grad_y && (rc = ensure(ctx, ctx->bY, cn))) return rc;
+    if (grad_sigma2 && (rc = ensure(ctx, ctx->bS2, cn))) return rc;
+    if ((rc = ensure(ctx, ctx->bout, chunk * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t)))) return rc;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+        if ((rc = upload(ctx, ctx->bA, A + b0 * J, (size_t)nb * J * sizeof(double)))) return rc;
+        if ((rc = upload(ctx, ctx->bB, Bc + b0 * J, (size_t)nb * J * sizeof(double)))) return rc;
+        if (mu && (rc = upload(ctx, ctx->bmu, mu + b0, nb * sizeof(double)))) return rc;
+        if (nu && (rc = upload(ctx, ctx->bnu, nu + b0, nb * sizeof(double)))) return rc;
+        ScanParams p{};
+        p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = nb;
+        p.standard_rows = ds->R == 2 * ds->J;
+        p.rec_stride = 3 * (int64_t)(ds->R + 2) + 2;
+        p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+        p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
+        p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
+        p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
+        p.g_y = grad_y ? (double*)ctx->bY.p : nullptr;
+        p.g_s2 = grad_sigma2 ? (double*)ctx->bS2.p : nullptr;
+        double* dga = (double*)ctx->bC.p; double* dgb = dga + (size_t)chunk * J;
+        double* dgn = (double*)ctx->bD.p; double* dgm = dgn + chunk;
+        rc = pioran_launch_scan_wide_grad(p, (double*)ctx->bwork.p, dga, dgb, dgn, dgm, ctx->stream);
+        if (rc) { ctx->last_err = "gradient launch failed"; return rc; }
+        HIPCHK(ctx, hipMemcpyAsync(out + b0, ctx->bout.p, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (status) HIPCHK(ctx, hipMemcpyAsync(status + b0, ctx->bst.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(grad_a + b0 * J, dga, (size_t)nb * J * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(grad_b + b0 * J, dgb, (size_t)nb * J * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (grad_nu) HIPCHK(ctx, hipMemcpyAsync(grad_nu + b0, dgn, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (grad_mu) HIPCHK(ctx, hipMemcpyAsync(grad_mu + b0, dgm, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (grad_y) HIPCHK(ctx, hipMemcpyAsync(grad_y + b0 * ds->N, ctx->bY.p, (size_t)nb * ds->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (grad_sigma2) HIPCHK(ctx, hipMemcpyAsync(grad_sigma2 + b0 * ds->N, ctx->bS2.p, (size_t)nb * ds->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PIORAN_OK;
+}
+
 int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc,
                              const double* C, const double* Dd, const double* t, const double* sigma2, const double* q,
                              double* y_out)

@@ -140,7 +140,8 @@ constexpr int kWideMaxRecord = 512;   // staged doubles per step: two per thread
 // MODE 0: log-likelihood.  MODE 1: the same, and the factor goes to HBM (W_n, D_n, forward-solved z_n per step) for the
 // backward sweep of the prediction path (celerite_predict.hip).  MODE 2: simulation — the extra row carries
 // f <- phi o (f + W_{n-1} x_{n-1}) instead of the forward solve and emits y_n = x_n + u_n'f, x_n = sqrt(D_n) q_n
-// (sim, src/celerite_solver.jl:515-549); the noise q takes the place of y in the staged record.
+// (sim, src/celerite_solver.jl:515-549); the noise q takes the place of y in the staged record.  MODE 3: log-likelihood,
+// and S_n (lane layout), v - q of all 16 RPL slots and D_n go to HBM for the reverse pass (celerite_adjoint_kernel below).
 template <int RPL, int MODE = 0>
 __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams p)
 {
@@ -265,6 +266,13 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
                 }
             }
         }
+        if constexpr (MODE == 3) {
+            if (l == 0) {
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) p.st_w[(b * N + n) * (16 * RPL) + g * RPL + i] = num[i];
+                if (yrow) p.st_d[b * N + n] = Dn;
+            }
+        }
         if constexpr (MODE == 2) {
             const double x = sqrt(Dn) * yn;            // x_n = sqrt(D_n) q_n      :539,546
             if (yrow) {
@@ -303,6 +311,13 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
                 S[i][c] = sn;
                 qt[i] = fma(sn, uc[c], qt[i]);                    // (S u)_j                    :80-82,86-89
             }
+        if constexpr (MODE == 3) {   // S_n for the adjoint pass, lane layout (each lane's block contiguous)
+            double* dst = p.st_s + (((size_t)b * (size_t)N + (size_t)n) * 256 + tid) * (RPL * RPL);
+#pragma unroll
+            for (int i = 0; i < RPL; ++i)
+#pragma unroll
+                for (int c = 0; c < RPL; ++c) dst[i * RPL + c] = S[i][c];
+        }
         PIORAN_WSTAMP(1);
         double sp = 0.0;
 #pragma unroll
@@ -373,6 +388,277 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
     }
 }
 
+// ---- reverse mode through the recurrence ----------------------------------------------------------------------------
+// log L = -1/2 sum_n (log D_n + z_n^2 / D_n) - N/2 log(2 pi), with per step (rows incl. the y row, u_y = 0, v_y = y_n - mu)
+//   T = S_{n-1} + m_{n-1} m_{n-1}' / D_{n-1}   (m = v - q = D w) ;  S_n = (phi phi') o T ;  q = S_n u_n
+//   D_n = sum(a) + nu sigma2_n - u_n'q ;  m_n = v_n - q ;  z_n = (m_n)_y
+// Walking n = N-1 .. 0 with the adjoints (Sb, mb, Db) of (S_n, m_n, D_n) that the later steps left:
+//   Db += -1/(2 D_n) + z_n^2 / (2 D_n^2) ;  (mb)_y -= z_n / D_n
+//   qb = -mb - Db u ;  ub = -Db q + S_n qb ;  d/d(al_r) += ub_r v_r ;  d/d(be_r) += ub_r x_r        (u_r = al_r v_r + be_r x_r)
+//   d/dsum(a) += Db ;  d/dnu += Db sigma2_n ;  d/dmu -= (mb)_y ;  d/dy_n = (mb)_y ;  d/dsigma2_n = nu Db
+//   Sb <- (phi phi') o (Sb + (qb u' + u qb') / 2)      (S is symmetric: only the symmetric part of its adjoint matters)
+//   mb <- 2 Sb m_{n-1} / D_{n-1} ;  Db <- -(m_{n-1}' mb) / (2 D_{n-1})
+// Same 16 x 16 lane layout and the same single LDS exchange per step as the forward kernel (here: mb of the rows and
+// the shares of m'mb); the two mat-vecs (S_n qb, Sb m) are DPP butterflies.  S_n comes back from HBM in the lane
+// layout the forward pass (MODE 3) wrote, m_{n-1} and D_{n-1} ride through the staged record.
+template <int RPL>
+__global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanParams p)
+{
+    constexpr int YS = RPL - 1;
+    constexpr int DG = 4;
+    constexpr int NS = 16 * RPL;                      // row slots
+    const int tid = threadIdx.x;
+    const int g = tid >> 4, l = tid & 15;
+    const int64_t b = blockIdx.x, N = p.N;
+    const int Rp = p.R + 2, RS = 3 * Rp + 2;
+    const int L = RS + 3 * p.npd_rows;                // table part of the staged record
+    const int LT = L + NS + 1;                        // + m_{n-1} of every slot + D_{n-1}
+
+    __shared__ double sh_rec[2][kWideMaxRecord];
+    __shared__ double sh_num[2][NS];
+    __shared__ double sh_uq[2][16];
+
+    Slots<RPL> rs_, cs_;
+    describe_slots<RPL>(p, b, g, rs_);
+    describe_slots<RPL>(p, b, l, cs_);
+    const double mu = p.mu ? p.mu[b] : 0.0;
+    const double nu = p.nu ? p.nu[b] : 1.0;
+    const bool yrow = g == 15, ycol = l == 15;
+    const double* numst = p.st_w + (size_t)b * (size_t)N * NS;
+    const double* dst_ = p.st_d + (size_t)b * (size_t)N;
+
+    // staged element e of step n: e < L table record n (as in the forward kernel); L <= e < L + NS: m_{n-1}[e - L];
+    // e == L + NS: D_{n-1}.  address = src + clamp(n + shift, 0, last) * stride
+    const double* src[2];
+    int64_t stride[2], last[2], shift[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = tid + 256 * h;
+        src[h] = p.tab + (e < RS ? e : e + (int64_t)b * p.npd_rows * 3);
+        stride[h] = p.rec_stride; last[h] = N; shift[h] = 0;
+        if (p.Y && (e == 3 * Rp || e == 3 * Rp + 1)) {
+            src[h] = (e == 3 * Rp ? p.Y : p.S2) + b * N;
+            stride[h] = 1; last[h] = N - 1;
+        }
+        if (e >= L && e < L + NS) { src[h] = numst + (e - L); stride[h] = NS; last[h] = N - 1; shift[h] = -1; }
+        if (e == L + NS) { src[h] = dst_; stride[h] = 1; last[h] = N - 1; shift[h] = -1; }
+        if (e >= LT) { src[h] = p.tab; stride[h] = 0; }
+    }
+    const bool two = LT > 256;
+    auto fetch = [&](int64_t n, double (&dstv)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) break;
+            int64_t k = n + shift[h];
+            k = k < 0 ? 0 : (k > last[h] ? last[h] : k);
+            dstv[h] = src[h][k * stride[h]];
+        }
+    };
+    auto stage = [&](int par, const double (&v)[2]) __attribute__((always_inline)) {
+        sh_rec[par][tid] = v[0];
+        if (two) sh_rec[par][tid + 256] = v[1];
+    };
+    struct AdjIn {
+        double rv[RPL], rx[RPL], rp[RPL], cv[RPL], cx[RPL], cp[RPL], y, s2;
+        double pr[RPL], pc[RPL], Dp, zp;              // m_{n-1} of the row / column block, D_{n-1}, z_{n-1}
+    };
+    auto unstage = [&](int par, AdjIn& in) __attribute__((always_inline)) {
+        const double* r = sh_rec[par];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            in.rv[i] = r[rs_.ov[i]]; in.rx[i] = r[rs_.ox[i]]; in.rp[i] = r[rs_.op[i]];
+            in.cv[i] = r[cs_.ov[i]]; in.cx[i] = r[cs_.ox[i]]; in.cp[i] = r[cs_.op[i]];
+            in.pr[i] = r[L + g * RPL + i];
+            in.pc[i] = r[L + l * RPL + i];
+        }
+        in.y = r[3 * Rp];
+        in.s2 = r[3 * Rp + 1];
+        in.Dp = r[L + NS];
+        in.zp = r[L + NS - 1];                        // the y slot is the last one
+    };
+    // S_n of this lane, two steps ahead in registers
+    const double* sbase = p.st_s + ((size_t)b * (size_t)N * 256 + tid) * (RPL * RPL);
+    auto fetch_s = [&](int64_t n, double (&dsts)[RPL * RPL]) __attribute__((always_inline)) {
+        const int64_t k = n < 1 ? 1 : n;              // S_0 is never used (and was never written)
+        const double* q_ = sbase + (size_t)(N > 1 ? k : 0) * 256 * (RPL * RPL);
+#pragma unroll
+        for (int e = 0; e < RPL * RPL; ++e) dsts[e] = N > 1 ? q_[e] : 0.0;
+    };
+
+    // steps are visited in DEscending n; "position" s = N - 1 - n plays the role n plays in the forward kernel
+    double gv[DG][2];
+#pragma unroll
+    for (int m = 0; m < DG; ++m) fetch(N - 1 - m, gv[m]);
+    double sv[2][RPL * RPL];
+    fetch_s(N - 1, sv[0]);
+    fetch_s(N - 2, sv[1]);
+    AdjIn cur[2];
+    const int par0 = (int)((N - 1) & 1);              // record n is staged in sh_rec[n & 1]
+    stage(par0, gv[0]);
+    fetch(N - 1 - DG, gv[0]);
+    __syncthreads();
+    unstage(par0, cur[0]);
+
+    // m_{N-1}, D_{N-1}, z_{N-1}: straight from HBM, once
+    double mr[RPL], mc[RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        mr[i] = numst[(size_t)(N - 1) * NS + g * RPL + i];
+        mc[i] = numst[(size_t)(N - 1) * NS + l * RPL + i];
+    }
+    double Dn = dst_[N - 1];
+    double zn = numst[(size_t)(N - 1) * NS + NS - 1];
+
+    double Sb[RPL][RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i)
+#pragma unroll
+        for (int c = 0; c < RPL; ++c) Sb[i][c] = 0.0;
+    double mbr[RPL], mbc[RPL], galr[RPL], gber[RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) { mbr[i] = 0.0; mbc[i] = 0.0; galr[i] = 0.0; gber[i] = 0.0; }
+    double Db = 0.0, gA = 0.0, gnu = 0.0, gmu = 0.0;
+
+    auto do_step = [&](int64_t n, AdjIn& in, AdjIn& nxt, double (&gslot)[2], double (&sn)[RPL * RPL]) __attribute__((always_inline)) {
+        double ur[RPL], uc[RPL], qr[RPL], qbr[RPL], qbc[RPL], ub[RPL];
+        const double rDn = recip_f64(Dn);
+        Db += -0.5 * rDn + 0.5 * zn * zn * rDn * rDn;
+        if (yrow) mbr[YS] -= zn * rDn;
+        if (ycol) mbc[YS] -= zn * rDn;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            ur[i] = rs_.al[i] * in.rv[i] + rs_.be[i] * in.rx[i];
+            uc[i] = cs_.al[i] * in.cv[i] + cs_.be[i] * in.cx[i];
+            const double vr = (yrow && i == YS) ? in.y - mu : in.rv[i];
+            qr[i] = vr - mr[i];
+            qbr[i] = -mbr[i] - Db * ur[i];
+            qbc[i] = -mbc[i] - Db * uc[i];
+            ub[i] = 0.0;
+        }
+        if (n > 0) {
+#pragma unroll
+            for (int i = 0; i < RPL; ++i)
+#pragma unroll
+                for (int c = 0; c < RPL; ++c) ub[i] = fma(sn[i * RPL + c], qbc[c], ub[i]);
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) ub[i] = row16_sum(ub[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            ub[i] = fma(-Db, qr[i], ub[i]);
+            galr[i] = fma(ub[i], in.rv[i], galr[i]);
+            gber[i] = fma(ub[i], in.rx[i], gber[i]);
+        }
+        gA += Db;
+        gnu = fma(Db, in.s2, gnu);
+        if (yrow) {
+            gmu -= mbr[YS];
+            if (l == 0) {
+                if (p.g_y) p.g_y[b * N + n] = mbr[YS];
+                if (p.g_s2) p.g_s2[b * N + n] = nu * Db;
+            }
+        }
+        fetch_s(n - 2, sn);                            // this register buffer is free again
+        if (n == 0) return;
+        // ---- adjoints of (S_{n-1}, m_{n-1}, D_{n-1}) ----
+        double nb[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) nb[i] = 0.0;
+#pragma unroll
+        for (int c = 0; c < RPL; ++c)
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const double t_ = fma(0.5 * qbr[i], uc[c], fma(0.5 * ur[i], qbc[c], Sb[i][c]));
+                const double sbn = (in.rp[i] * in.cp[c]) * t_;
+                Sb[i][c] = sbn;
+                nb[i] = fma(sbn, in.pc[c], nb[i]);
+            }
+        const double rDp = recip_f64(in.Dp);
+        double share = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            nb[i] = 2.0 * row16_sum(nb[i]) * rDp;
+            share = fma(in.pr[i], nb[i], share);
+            mbr[i] = nb[i];
+        }
+        const int par = (int)(n & 1);
+        if (l == 0) {
+            sh_uq[par][g] = share;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) sh_num[par][g * RPL + i] = nb[i];
+        }
+        stage(par ^ 1, gslot);                         // record n - 1 -> sh_rec[(n-1) & 1]
+        fetch(n - 1 - DG, gslot);
+        __syncthreads();
+        double sh[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sh[k] = sh_uq[par][k];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) mbc[i] = sh_num[par][l * RPL + i];
+        unstage(par ^ 1, nxt);
+        const double tot = (((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]))) +
+                           (((sh[8] + sh[9]) + (sh[10] + sh[11])) + ((sh[12] + sh[13]) + (sh[14] + sh[15])));
+        Db = -0.5 * tot * rDp;
+        // what was "previous" becomes "current"
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) { mr[i] = in.pr[i]; mc[i] = in.pc[i]; }
+        Dn = in.Dp;
+        zn = in.zp;
+    };
+
+    // positions: step at position s = N-1-n uses cur[s & 1], the global ring slot (s + 1) % DG holds record n - 1,
+    // the S buffer s & 1 holds S_n.  Unrolled by DG so that all of these are compile-time constants.
+    int64_t s0 = 0;
+    for (; s0 + DG <= N; s0 += DG)
+        static_for<0, DG>([&](auto Kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(Kc)::value;
+            do_step(N - 1 - (s0 + k), cur[k & 1], cur[(k + 1) & 1], gv[(k + 1) % DG], sv[k & 1]);
+        });
+    static_for<0, DG - 1>([&](auto Kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(Kc)::value;
+        if (s0 + k < N) do_step(N - 1 - (s0 + k), cur[k & 1], cur[(k + 1) & 1], gv[(k + 1) % DG], sv[k & 1]);
+    });
+
+    if (l == 0) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            p.g_al[b * NS + g * RPL + i] = galr[i];
+            p.g_be[b * NS + g * RPL + i] = gber[i];
+        }
+        if (yrow) {
+            p.g_scal[b * 4 + 0] = gA;
+            p.g_scal[b * 4 + 1] = gnu;
+            p.g_scal[b * 4 + 2] = gmu;
+            p.g_scal[b * 4 + 3] = 0.0;
+        }
+    }
+}
+
+// row adjoints -> term gradients: a_j enters al of both rows and sum(a); b_j enters be of the cos row and -be of the sin row
+__global__ void __launch_bounds__(256) grad_finish_kernel(const ScanParams p, int NS, double* __restrict__ grad_a,
+                                                          double* __restrict__ grad_b, double* __restrict__ grad_nu,
+                                                          double* __restrict__ grad_mu)
+{
+    const int64_t b = blockIdx.x;
+    const int J = p.J;
+    for (int j = threadIdx.x; j < J; j += 256) {
+        double ga = p.g_scal[b * 4 + 0], gb = 0.0;
+        for (int r = 0; r < p.R; ++r) {
+            const int rm = p.rowmap[r];
+            if ((rm & 0xfffff) != j) continue;
+            const bool ks = (rm >> 30) & 1;
+            ga += p.g_al[b * NS + r];
+            gb += ks ? -p.g_be[b * NS + r] : p.g_be[b * NS + r];
+        }
+        grad_a[b * J + j] = ga;
+        grad_b[b * J + j] = gb;
+    }
+    if (threadIdx.x == 0) {
+        if (grad_nu) grad_nu[b] = p.g_scal[b * 4 + 1];
+        if (grad_mu) grad_mu[b] = p.g_scal[b * 4 + 2];
+    }
+}
+
 }  // namespace
 
 int pioran_wide_supported_rows() { return 79; }
@@ -406,4 +692,40 @@ int pioran_launch_scan_wide_sim(const ScanParams& p, hipStream_t stream)
 {
     if (!p.noise || !p.ysim || p.Y) return PIORAN_ERR_ARG;
     return launch_wide_mode<2>(p, stream);
+}
+
+static int rpl_of(int R) { return R <= 15 ? 1 : R <= 31 ? 2 : R <= 47 ? 3 : R <= 63 ? 4 : 5; }
+
+size_t pioran_grad_workspace_doubles(int64_t B, int64_t N, int32_t R)
+{
+    const size_t rpl = (size_t)rpl_of(R), ns = 16 * rpl;
+    // S [B][N][256][rpl^2] | m [B][N][ns] | D [B][N] | row adjoints 2 x [B][ns] | scalars [B][4]
+    return (size_t)B * (size_t)N * (256 * rpl * rpl + ns + 1) + (size_t)B * (2 * ns + 4);
+}
+
+// p: shared-table launch description with out / status set; work: pioran_grad_workspace_doubles doubles;
+// grad_a, grad_b: device [B][J]; grad_nu, grad_mu: device [B] or nullptr; p.g_y / p.g_s2: device [B][N] or nullptr.
+int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, double* grad_b, double* grad_nu,
+                                 double* grad_mu, hipStream_t stream)
+{
+    if (!p.tab || p.R > 79 || p.B <= 0 || p.B > 0x7fffffffLL || !grad_a || !grad_b) return PIORAN_ERR_UNSUPPORTED;
+    const int rpl = rpl_of(p.R), ns = 16 * rpl;
+    if (3 * (p.R + 2) + 2 + 3 * p.npd_rows + ns + 1 > kWideMaxRecord) return PIORAN_ERR_UNSUPPORTED;
+    const size_t BN = (size_t)p.B * (size_t)p.N;
+    p.st_s = work;
+    p.st_w = p.st_s + BN * 256 * rpl * rpl;
+    p.st_d = p.st_w + BN * ns;
+    p.g_al = p.st_d + BN;
+    p.g_be = p.g_al + (size_t)p.B * ns;
+    p.g_scal = p.g_be + (size_t)p.B * ns;
+    const dim3 grid((unsigned)p.B), block(256);
+    switch (rpl) {
+    case 1: hipLaunchKernelGGL((celerite_wide_kernel<1, 3>), grid, block, 0, stream, p); hipLaunchKernelGGL(celerite_adjoint_kernel<1>, grid, block, 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((celerite_wide_kernel<2, 3>), grid, block, 0, stream, p); hipLaunchKernelGGL(celerite_adjoint_kernel<2>, grid, block, 0, stream, p); break;
+    case 3: hipLaunchKernelGGL((celerite_wide_kernel<3, 3>), grid, block, 0, stream, p); hipLaunchKernelGGL(celerite_adjoint_kernel<3>, grid, block, 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((celerite_wide_kernel<4, 3>), grid, block, 0, stream, p); hipLaunchKernelGGL(celerite_adjoint_kernel<4>, grid, block, 0, stream, p); break;
+    default: hipLaunchKernelGGL((celerite_wide_kernel<5, 3>), grid, block, 0, stream, p); hipLaunchKernelGGL(celerite_adjoint_kernel<5>, grid, block, 0, stream, p); break;
+    }
+    hipLaunchKernelGGL(grad_finish_kernel, grid, block, 0, stream, p, ns, grad_a, grad_b, grad_nu, grad_mu);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }

@@ -48,6 +48,16 @@ struct ScanParams {
     // (sim, src/celerite_solver.jl:515-549); y / Y are not read.
     const double* noise;
     double* ysim;
+    // Gradient (pioran_launch_scan_wide_grad): the forward pass (MODE 3) stores S_n in the lane layout
+    // [B][N][256][RPL*RPL], v - q of ALL 16 RPL row slots in st_w [B][N][16 RPL] and D_n in st_d; the adjoint pass
+    // returns the row adjoints of (al, be) [B][16 RPL] each, the scalars (dL/dsum(a), dL/dnu, dL/dmu) [B][4] and,
+    // optionally, dL/dy_n and dL/dsigma2_n [B][N].
+    double* st_s;
+    double* g_al;
+    double* g_be;
+    double* g_scal;
+    double* g_y;
+    double* g_s2;
 };
 
 // celerite_scan.hip
@@ -58,6 +68,10 @@ const char* pioran_scan_config_name(int R);
 int pioran_launch_scan_wide(const ScanParams& p, hipStream_t stream);
 int pioran_launch_scan_wide_store(const ScanParams& p, hipStream_t stream);   // log L + (W, D, z) to HBM
 int pioran_launch_scan_wide_sim(const ScanParams& p, hipStream_t stream);     // y = L D^(1/2) q
+// log L and its gradient with respect to (a_j, b_j) [B][J], nu, mu (reverse mode through the recurrence)
+size_t pioran_grad_workspace_doubles(int64_t B, int64_t N, int32_t R);
+int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, double* grad_b, double* grad_nu,
+                                 double* grad_mu, hipStream_t stream);
 int pioran_wide_supported_rows();
 int64_t pioran_wide_max_batch();
 // celerite_predict.hip: posterior mean at new times (pred, src/celerite_solver.jl:363-483)

@@ -211,6 +211,26 @@ class Dataset:
                                                       _ptr(nu), len(tau), _ptr(tau), _ptr(out), _ptr(st)), self.ctx._h)
         return (out, st) if return_status else out
 
+    def logl_grad(self, A, Bc, C, Dd, mu=None, nu=None, series_grad=False):
+        """log L and its gradient for B draws sharing (C, Dd): returns a dict with logl (B,), status, grad_a, grad_b (B, J),
+        grad_mu, grad_nu (B,) (None where mu / nu were not given) and, with series_grad, grad_y, grad_sigma2 (B, N)."""
+        A, Bc, C, Dd = map(_f64, (A, Bc, C, Dd))
+        if A.ndim != 2 or A.shape != Bc.shape or C.shape != (A.shape[1],) or Dd.shape != C.shape:
+            raise ValueError("A, Bc must be (B, J) and C, Dd (J,)")
+        B, J = A.shape
+        mu_ = None if mu is None else _f64(np.broadcast_to(mu, (B,)))
+        nu_ = None if nu is None else _f64(np.broadcast_to(nu, (B,)))
+        out = np.empty(B); st = np.zeros(B, dtype=np.int32)
+        ga, gb = np.empty((B, J)), np.empty((B, J))
+        gnu, gmu = np.empty(B), np.empty(B)
+        gy = np.empty((B, self.N)) if series_grad else None
+        gs = np.empty((B, self.N)) if series_grad else None
+        _lib.check(_lib.lib().pioran_celerite_logl_grad(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), _ptr(mu_), _ptr(nu_),
+                                                        _ptr(out), _ptr(st), _ptr(ga), _ptr(gb), _ptr(gnu), _ptr(gmu),
+                                                        _ptr(gy), _ptr(gs)), self.ctx._h)
+        return {"logl": out, "status": st, "grad_a": ga, "grad_b": gb, "grad_nu": gnu, "grad_mu": gmu,
+                "grad_y": gy, "grad_sigma2": gs}
+
     def logl_batch_dev(self, B, dA, dBc, dmu=0, dnu=0, dY=0, dS2=0, dout=0, dstatus=0):
         """Device-pointer (int addresses) asynchronous variant; (c, d) from prepare()."""
         v = ctypes.c_void_p

@@ -242,6 +242,34 @@ function simulate_batch(A::Matrix{Float64}, B::Matrix{Float64}, c::Vector{Float6
     return out
 end
 
+# ---- value and gradient (reverse mode through the recurrence on the GPU) --------------------------------------------------
+"""
+    logpdf_grad_batch(ds, A, B, c, d; μ, ν, series = false)
+
+log L and ∂log L/∂(a_j, b_j) (`J × nbatch` each), ∂/∂ν, ∂/∂μ for every draw; with `series = true` also ∂/∂y_n and ∂/∂σ²_n
+(`N × nbatch`).  This is what a `ChainRulesCore.rrule` / `LogDensityProblems.logdensity_and_gradient` for the GP
+likelihood returns instead of pushing ForwardDiff Duals through `Pioran.logl` (test/test_likelihood.jl:55-60); the chain
+rule from (a, b) to the PSD parameters goes through `approx`, which stays in Julia.
+"""
+function logpdf_grad_batch(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::Vector{Float64}, d::Vector{Float64};
+                           μ::Union{Nothing, Vector{Float64}} = nothing, ν::Union{Nothing, Vector{Float64}} = nothing,
+                           series::Bool = false)
+    J, nb = size(A)
+    out = Vector{Float64}(undef, nb); status = zeros(Int32, nb)
+    ga = Matrix{Float64}(undef, J, nb); gb = Matrix{Float64}(undef, J, nb)
+    gν = Vector{Float64}(undef, nb); gμ = Vector{Float64}(undef, nb)
+    gy = series ? Matrix{Float64}(undef, ds.N, nb) : nothing
+    gs = series ? Matrix{Float64}(undef, ds.N, nb) : nothing
+    p(x) = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
+    GC.@preserve A B c d μ ν out status ga gb gν gμ gy gs begin
+        check(ccall((:pioran_celerite_logl_grad, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                     Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                    ds.h, nb, J, A, B, c, d, p(μ), p(ν), out, status, ga, gb, gν, gμ, p(gy), p(gs)))
+    end
+    return (logl = out, status = status, grad_a = ga, grad_b = gb, grad_ν = gν, grad_μ = gμ, grad_y = gy, grad_σ² = gs)
+end
+
 # ---- dense solver: log_likelihood_direct (src/direct_solver.jl:6-21), returns +NLL -------------------------
 function log_likelihood_direct_hip(cov::SemiSeparable, t::Vector{Float64}, y::Vector{Float64}, σ²::Vector{Float64};
                                    ctx = default_context())

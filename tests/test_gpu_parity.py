@@ -735,3 +735,58 @@ def test_predict_cov_reference_cases(ctx, golden_dir):
     # K(t,t) + diag(sigma2) not positive definite -> LinAlgError like the reference's PosDefException
     with pytest.raises(np.linalg.LinAlgError):
         pj.predict_cov(pj.Celerite(-1.0, 0.0, 0.5, 0.0), tau[:5], t[:70], np.zeros(70), ctx=ctx)
+
+
+# ---------------------------------------------------------------------------------------------
+# gradient of log L by reverse mode through the recurrence
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("J,N,B", [(3, 40, 2), (7, 64, 3), (10, 257, 3), (20, 500, 2), (30, 129, 2), (39, 100, 2), (4, 1, 1), (9, 2, 2),
+                                   (9, 3, 2), (9, 6, 2)])
+def test_gradient_matches_complex_step(ctx, J, N, B):
+    """dlogL/d(a_j, b_j, mu, nu, y_n, sigma2_n) against the complex-step derivatives of the oracle (exact to rounding):
+    every RPL of the adjoint kernel, every prologue / tail length of its pipelines."""
+    rng = np.random.default_rng(800 + J + N)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    ds = pj.Dataset(t, y, s2, ctx)
+    g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, series_grad=True)
+    ref_l = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu)
+    assert relerr(g["logl"], ref_l) < 1e-11 and (g["status"] == 0).all()
+    assert (g["logl"] == ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)).all() or relerr(g["logl"], ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)) < 1e-12
+    for i in range(B):
+        ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, series=N <= 129)
+        sa = 1e-9 * (1 + np.max(np.abs(ref["grad_a"]))); sb = 1e-9 * (1 + np.max(np.abs(ref["grad_b"])))
+        assert np.max(np.abs(g["grad_a"][i] - ref["grad_a"])) <= sa
+        assert np.max(np.abs(g["grad_b"][i] - ref["grad_b"])) <= sb
+        gm = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, dy=-np.ones(N))
+        gn = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, ds2=s2)
+        assert abs(g["grad_mu"][i] - gm) <= 1e-9 * (1 + abs(gm)) and abs(g["grad_nu"][i] - gn) <= 1e-9 * (1 + abs(gn))
+        if N <= 129:
+            # the data set holds (y, s2): dL/dy_n is the oracle's derivative w.r.t. (y - mu)_n, dL/ds2_n carries nu
+            assert np.max(np.abs(g["grad_y"][i] - ref["grad_y"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_y"])))
+            assert np.max(np.abs(g["grad_sigma2"][i] - nu[i] * ref["grad_sigma2"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_sigma2"])))
+
+
+def test_gradient_full_size_and_real_terms(ctx, full_size):
+    """N = 1e4 (BASELINE shape), SHO-20 and DRWCelerite-20 (terms with b = d = 0: one row each), against one complex
+    step per direction for a few directions, bar 1e-7 relative to the gradient scale."""
+    t, y, yerr = full_size
+    th = O.synthetic_theta(3, t, y)
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    rng = np.random.default_rng(5)
+    for basis in ("SHO", "DRWCelerite"):
+        A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, 20, basis)
+        g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+        ref_l, rst = O.logl_batch(A, Bc, C, Dd, t, y, yerr ** 2, mu, nu, nthreads=4, return_status=True)
+        for i in np.flatnonzero(rst == 0)[:2]:
+            assert abs(g["logl"][i] - ref_l[i]) <= 1e-8 * abs(ref_l[i])
+            J = A.shape[1]
+            scale = 1 + max(np.max(np.abs(g["grad_a"][i])), np.max(np.abs(g["grad_b"][i])))
+            for _ in range(3):
+                da, db = rng.standard_normal(J), rng.standard_normal(J)
+                if basis == "DRWCelerite":
+                    db[Dd == 0.0] = 0.0        # b of a real term is structurally zero (its sin row is dropped)
+                ref = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * yerr ** 2, da=da, db=db)
+                got = g["grad_a"][i] @ da + g["grad_b"][i] @ db
+                assert abs(got - ref) <= 1e-7 * scale * np.sqrt(J), basis
+            gm = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * yerr ** 2, dy=-np.ones(len(t)))
+            assert abs(g["grad_mu"][i] - gm) <= 1e-7 * (1 + abs(gm))

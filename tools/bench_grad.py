@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Gradient of log L at BASELINE size: N = 1e4, SHO-20 / DRWCelerite-20, B = 1 (one NUTS chain) and a
+batch of chains; host-pointer entry (staging included), next to the value-only call and to one complex-step derivative of
+the oracle (= the cost unit of one ForwardDiff partial on the CPU)."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench, pioran_jl_amd as pj
+from oracle import oracle as O
+N, J = 10_000, 20
+basis = os.environ.get("BASIS", "SHO")
+t, y, yerr = bench.synth_series(N)
+th, f_min, f_max = bench.synth_theta(64, t, y, seed=4321)
+A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, th[:, :3], f_min, f_max, J, th[:, 3], basis_function=basis)
+mu, nu = th[:, 5].copy(), th[:, 4].copy()
+ctx = pj.Context(0); ds = pj.Dataset(t, y, yerr ** 2, ctx)
+def timed(f, reps=3):
+    f(); ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); r = f(); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e3, r
+res = {"workload": f"N={N}, {basis}-{J}, gradient w.r.t. (a, b) [J each], mu, nu"}
+for B in (1, 16, 64):
+    tg, g = timed(lambda: ds.logl_grad(A[:B], Bc[:B], C, Dd, mu=mu[:B], nu=nu[:B]))
+    tv, v = timed(lambda: ds.logl_batch(A[:B], Bc[:B], C, Dd, mu=mu[:B], nu=nu[:B]))
+    res[f"B{B}"] = {"value_and_gradient_ms": round(tg, 2), "value_only_ms": round(tv, 2)}
+t0 = time.perf_counter(); ref = O.logl_dir(A[0], Bc[0], C, Dd, t, y - mu[0], nu[0] * yerr ** 2, da=np.ones(A.shape[1])); tc = time.perf_counter() - t0
+res["cpu_one_complex_step_ms"] = round(tc * 1e3, 1)
+res["directional_check_rel"] = float(abs(g["grad_a"][0].sum() - ref) / (1 + abs(ref)))
+print(json.dumps(res))
