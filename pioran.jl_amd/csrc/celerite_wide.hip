@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
         in.Dp = r[L + NS];
         in.zp = r[L + NS - 1];                        // the y slot is the last one
     };
-    // S_n of this lane, two steps ahead in registers
+    // S_n of this lane, SD steps ahead in registers
     const double* sbase = p.st_s + ((size_t)b * (size_t)N * 256 + tid) * (RPL * RPL);
     auto fetch_s = [&](int64_t n, double (&dsts)[RPL * RPL]) __attribute__((always_inline)) {
         const int64_t k = n < 1 ? 1 : n;              // S_0 is never used (and was never written)
@@ -489,15 +489,17 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
     double gv[DG][2];
 #pragma unroll
     for (int m = 0; m < DG; ++m) fetch(N - 1 - m, gv[m]);
-    double sv[2][RPL * RPL];
+    constexpr int SD = RPL <= 3 ? 2 : 1;              // S_n buffers (steps ahead); one where registers are short
+    double sv[SD][RPL * RPL];
     fetch_s(N - 1, sv[0]);
-    fetch_s(N - 2, sv[1]);
-    AdjIn cur[2];
+    if constexpr (SD == 2) fetch_s(N - 2, sv[1]);
+    AdjIn cur;                                        // ONE register copy of the staged record (register budget):
+                                                      // refilled at the end of a step, after its last field is consumed
     const int par0 = (int)((N - 1) & 1);              // record n is staged in sh_rec[n & 1]
     stage(par0, gv[0]);
     fetch(N - 1 - DG, gv[0]);
     __syncthreads();
-    unstage(par0, cur[0]);
+    unstage(par0, cur);
 
     // m_{N-1}, D_{N-1}, z_{N-1}: straight from HBM, once
     double mr[RPL], mc[RPL];
@@ -519,7 +521,7 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
     for (int i = 0; i < RPL; ++i) { mbr[i] = 0.0; mbc[i] = 0.0; galr[i] = 0.0; gber[i] = 0.0; }
     double Db = 0.0, gA = 0.0, gnu = 0.0, gmu = 0.0;
 
-    auto do_step = [&](int64_t n, AdjIn& in, AdjIn& nxt, double (&gslot)[2], double (&sn)[RPL * RPL]) __attribute__((always_inline)) {
+    auto do_step = [&](int64_t n, AdjIn& in, double (&gslot)[2], double (&sn)[RPL * RPL]) __attribute__((always_inline)) {
         double ur[RPL], uc[RPL], qr[RPL], qbr[RPL], qbc[RPL], ub[RPL];
         const double rDn = recip_f64(Dn);
         Db += -0.5 * rDn + 0.5 * zn * zn * rDn * rDn;
@@ -558,7 +560,7 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
                 if (p.g_s2) p.g_s2[b * N + n] = nu * Db;
             }
         }
-        fetch_s(n - 2, sn);                            // this register buffer is free again
+        fetch_s(n - SD, sn);                           // this register buffer is free again
         if (n == 0) return;
         // ---- adjoints of (S_{n-1}, m_{n-1}, D_{n-1}) ----
         double nb[RPL];
@@ -595,7 +597,6 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
         for (int k = 0; k < 16; ++k) sh[k] = sh_uq[par][k];
 #pragma unroll
         for (int i = 0; i < RPL; ++i) mbc[i] = sh_num[par][l * RPL + i];
-        unstage(par ^ 1, nxt);
         const double tot = (((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]))) +
                            (((sh[8] + sh[9]) + (sh[10] + sh[11])) + ((sh[12] + sh[13]) + (sh[14] + sh[15])));
         Db = -0.5 * tot * rDp;
@@ -604,19 +605,20 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
         for (int i = 0; i < RPL; ++i) { mr[i] = in.pr[i]; mc[i] = in.pc[i]; }
         Dn = in.Dp;
         zn = in.zp;
+        unstage(par ^ 1, in);                          // record n - 1 for the next step
     };
 
-    // positions: step at position s = N-1-n uses cur[s & 1], the global ring slot (s + 1) % DG holds record n - 1,
+    // positions: at position s = N-1-n the global ring slot (s + 1) % DG holds record n - 1,
     // the S buffer s & 1 holds S_n.  Unrolled by DG so that all of these are compile-time constants.
     int64_t s0 = 0;
     for (; s0 + DG <= N; s0 += DG)
         static_for<0, DG>([&](auto Kc) __attribute__((always_inline)) {
             constexpr int k = decltype(Kc)::value;
-            do_step(N - 1 - (s0 + k), cur[k & 1], cur[(k + 1) & 1], gv[(k + 1) % DG], sv[k & 1]);
+            do_step(N - 1 - (s0 + k), cur, gv[(k + 1) % DG], sv[k % SD]);
         });
     static_for<0, DG - 1>([&](auto Kc) __attribute__((always_inline)) {
         constexpr int k = decltype(Kc)::value;
-        if (s0 + k < N) do_step(N - 1 - (s0 + k), cur[k & 1], cur[(k + 1) & 1], gv[(k + 1) % DG], sv[k & 1]);
+        if (s0 + k < N) do_step(N - 1 - (s0 + k), cur, gv[(k + 1) % DG], sv[k % SD]);
     });
 
     if (l == 0) {
