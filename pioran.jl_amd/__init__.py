@@ -8,7 +8,7 @@ from .gp import (Context, CustomMean, Dataset, Farm, FiniteScalableGP, Posterior
                  rand, rand_posterior, simulate, std)
 from .kernels import (Celerite, Exp, ScaledKernel, SemiSeparable, SHO, SumOfCelerite, SumOfSemiSeparable,
                       SumOfTerms, celerite_coefs)
-from .psd import (QPO, DoubleBendingPowerLaw, SingleBendingPowerLaw, approx, approx_batch, build_approx,
+from .psd import (QPO, DoubleBendingPowerLaw, SingleBendingPowerLaw, approx, approx_batch, approx_batch_vjp, build_approx,
                   convert_feature, get_approx_coefficients, get_norm_psd, psd_decomp, separate_psd)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -231,6 +231,22 @@ class Dataset:
         return {"logl": out, "status": st, "grad_a": ga, "grad_b": gb, "grad_nu": gnu, "grad_mu": gmu,
                 "grad_y": gy, "grad_sigma2": gs}
 
+    def logpdf_theta_grad(self, model, theta, norm, f_min, f_max, n_components=20, S_low=20.0, S_high=20.0, *,
+                          is_integrated_power=True, basis_function="SHO", mu=None, nu=None):
+        """log L and its gradient with respect to the SAMPLED parameters of the reference's models
+        (README.md:38-71: theta = PSD parameters, norm = variance, nu, mu): the device gradient w.r.t. (a, b, nu, mu)
+        chained through `approx` on the host (approx_batch_vjp).  Returns a dict: logl, status, grad_theta (B, P),
+        grad_norm, grad_nu, grad_mu (B,)."""
+        from .psd import approx_batch, approx_batch_vjp
+        theta = np.atleast_2d(_f64(theta))
+        A, Bc, C, Dd = approx_batch(model, theta, f_min, f_max, n_components, norm, S_low, S_high,
+                                    is_integrated_power=is_integrated_power, basis_function=basis_function)
+        g = self.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+        gth, gnorm = approx_batch_vjp(model, theta, f_min, f_max, n_components, norm, g["grad_a"], g["grad_b"], S_low, S_high,
+                                      is_integrated_power=is_integrated_power, basis_function=basis_function)
+        return {"logl": g["logl"], "status": g["status"], "grad_theta": gth, "grad_norm": gnorm,
+                "grad_nu": g["grad_nu"] if nu is not None else None, "grad_mu": g["grad_mu"] if mu is not None else None}
+
     def logl_batch_dev(self, B, dA, dBc, dmu=0, dnu=0, dY=0, dS2=0, dout=0, dstatus=0):
         """Device-pointer (int addresses) asynchronous variant; (c, d) from prepare()."""
         v = ctypes.c_void_p

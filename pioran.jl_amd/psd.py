@@ -193,16 +193,19 @@ def approx_batch(model, theta, f_min, f_max, n_components=20, norm=1.0, S_low=20
     model: SingleBendingPowerLaw or DoubleBendingPowerLaw (the class); theta: (B, n_psd_params);
     norm: scalar or (B,).  Returns A, Bc of shape (B, J) and the shared c, d of shape (J,)
     (c_j, d_j depend only on the spectral grid, src/psd.jl:250,266-267)."""
-    theta = np.atleast_2d(np.asarray(theta, float))
+    theta = np.atleast_2d(np.asarray(theta))
+    # complex parameters are allowed (every operation below is analytic): approx_batch_vjp differentiates by the complex step
+    cplx = np.iscomplexobj(theta) or np.iscomplexobj(norm)
+    theta = theta.astype(complex if cplx else float)
     B = theta.shape[0]
     f0 = f_min / S_low
     fM = f_max * S_high
     sp, Bm = build_approx(n_components, f0, fM, basis_function)
-    psd = np.stack([model(*row)(sp) for row in theta]) if B < 64 else _eval_model_batch(model, theta, sp)
+    psd = np.stack([model(*row)(sp) for row in theta]) if (B < 64 and not cplx) else _eval_model_batch(model, theta, sp)
     psd = psd / psd[:, :1]
     amplitudes = np.ascontiguousarray(np.linalg.solve(Bm, psd.T).T)  # one LU, B right-hand sides; C order (B, J)
     integ = get_norm_psd(amplitudes, sp, f_min, f_max, basis_function, is_integrated_power)
-    amplitudes = amplitudes * (np.broadcast_to(np.asarray(norm, float), (B,)) / integ)[:, None]
+    amplitudes = amplitudes * (np.broadcast_to(np.asarray(norm, complex if cplx else float), (B,)) / integ)[:, None]
     if basis_function == "SHO":
         a = amplitudes * sp * math.pi / math.sqrt(2)
         c = math.sqrt(2) * math.pi * sp
@@ -212,6 +215,29 @@ def approx_batch(model, theta, f_min, f_max, n_components=20, norm=1.0, S_low=20
     A = np.concatenate([a, a], axis=1)
     Bc = np.concatenate([math.sqrt(3) * a, np.zeros_like(a)], axis=1)
     return A, Bc, np.concatenate([c, 2 * c]), np.concatenate([math.sqrt(3) * c, np.zeros(n_components)])
+
+
+def approx_batch_vjp(model, theta, f_min, f_max, n_components, norm, grad_a, grad_b, S_low=20.0, S_high=20.0, *,
+                     is_integrated_power=True, basis_function="SHO", h=1e-30):
+    """Chain rule through `approx`: given dL/da, dL/db (B, J) returns dL/dtheta (B, P) and dL/dnorm (B,).
+    The Jacobian-vector products come from one complex step per parameter (exact to rounding; `approx` is a chain of
+    analytic operations: power laws, one linear solve, a normalising ratio)."""
+    theta = np.atleast_2d(np.asarray(theta, float))
+    B, P = theta.shape
+    norm = np.broadcast_to(np.asarray(norm, float), (B,))
+    if model not in (SingleBendingPowerLaw, DoubleBendingPowerLaw):
+        raise ValueError("approx_batch_vjp supports SingleBendingPowerLaw and DoubleBendingPowerLaw")
+    gth = np.empty((B, P))
+    for k in range(P):
+        th = theta.astype(complex)
+        th[:, k] += 1j * h
+        Ak, Bk, _, _ = approx_batch(model, th, f_min, f_max, n_components, norm, S_low, S_high,
+                                    is_integrated_power=is_integrated_power, basis_function=basis_function)
+        gth[:, k] = (grad_a * Ak.imag + grad_b * Bk.imag).sum(axis=1) / h
+    A, Bc, _, _ = approx_batch(model, theta, f_min, f_max, n_components, norm, S_low, S_high,
+                               is_integrated_power=is_integrated_power, basis_function=basis_function)
+    gnorm = (grad_a * A + grad_b * Bc).sum(axis=1) / norm      # (a, b) are proportional to norm
+    return gth, gnorm
 
 
 def _eval_model_batch(model, theta, sp):

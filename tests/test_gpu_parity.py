@@ -790,3 +790,32 @@ def test_gradient_full_size_and_real_terms(ctx, full_size):
                 assert abs(got - ref) <= 1e-7 * scale * np.sqrt(J), basis
             gm = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * yerr ** 2, dy=-np.ones(len(t)))
             assert abs(g["grad_mu"][i] - gm) <= 1e-7 * (1 + abs(gm))
+
+
+def test_gradient_wrt_sampled_parameters(ctx, golden_dir):
+    """d log L / d(alpha1, f1, alpha2, variance, nu, mu) — the parameters a sampler moves (README.md:38-71) — on the
+    reference's simu_log series: device gradient chained through approx vs central differences of the oracle's value
+    through the oracle's own approx (a fully independent path), bar 1e-5 (finite-difference accuracy)."""
+    A_ = np.loadtxt(golden_dir / "simu_log.txt")
+    t, y, yerr = A_[:, 0], A_[:, 1], A_[:, 2]
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    th = np.array([[0.82, 0.01, 3.3], [0.3, 0.05, 2.5], [0.6, 0.02, 3.0]])
+    var = np.array([np.var(y, ddof=1), 0.5, 2.0]); nu = np.array([1.0, 1.4, 0.8]); mu = np.array([0.0, 0.1, -0.2])
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    for basis in ("SHO", "DRWCelerite"):
+        g = ds.logpdf_theta_grad(pj.SingleBendingPowerLaw, th, var, f_min, f_max, 20, basis_function=basis, mu=mu, nu=nu)
+        def val(i, p):
+            a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, p[0], p[1], p[2]), f_min, f_max, 20, p[3],
+                                  basis_function=basis)
+            return O.logl(a, b, c, d, t, y - p[5], p[4] * yerr ** 2)
+        for i in range(3):
+            p0 = np.array([th[i, 0], th[i, 1], th[i, 2], var[i], nu[i], mu[i]])
+            assert abs(g["logl"][i] - val(i, p0)) <= 1e-10 * abs(val(i, p0))
+            got = np.array([*g["grad_theta"][i], g["grad_norm"][i], g["grad_nu"][i], g["grad_mu"][i]])
+            for k in range(6):
+                # five-point stencil with a step large enough to keep the rounding of the ill-conditioned spectral
+                # solve inside approx (amplified by 1/h) below the bar
+                h = 1e-4 * max(1.0, abs(p0[k])) if k != 1 else 1e-4 * p0[1]
+                e = np.zeros(6); e[k] = h
+                fd = (8 * (val(i, p0 + e) - val(i, p0 - e)) - (val(i, p0 + 2 * e) - val(i, p0 - 2 * e))) / (12 * h)
+                assert abs(got[k] - fd) <= 1e-5 * (1 + abs(fd)), (basis, i, k, got[k], fd)
