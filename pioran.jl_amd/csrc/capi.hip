@@ -65,7 +65,7 @@ int ensure(pioran_ctx* ctx, pioran_ctx::Buf& b, size_t bytes)
     if (b.p) HIPCHK(ctx, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
-    size_t want = bytes + bytes / 4 + 256;
+    size_t want = bytes + (bytes < (size_t(1) << 28) ? bytes / 4 : 0) + 256;   // growth slack for small buffers only
     if (hipMalloc(&b.p, want) != hipSuccess) {
         b.p = nullptr;
         ctx->last_err = "hipMalloc failed";

@@ -68,6 +68,7 @@ __device__ __forceinline__ double row16_sum(double x)
 }
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
 {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
@@ -311,12 +312,18 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
                 S[i][c] = sn;
                 qt[i] = fma(sn, uc[c], qt[i]);                    // (S u)_j                    :80-82,86-89
             }
-        if constexpr (MODE == 3) {   // S_n for the adjoint pass, lane layout (each lane's block contiguous)
-            double* dst = p.st_s + (((size_t)b * (size_t)N + (size_t)n) * 256 + tid) * (RPL * RPL);
+        if constexpr (MODE == 3) {   // S_n for the adjoint pass, lane layout: each lane's block contiguous, padded to
+                                     // an even number of doubles so that it moves as 16-byte pairs
+            constexpr int SP = (RPL * RPL + 1) & ~1;
+            d2* dst = reinterpret_cast<d2*>(p.st_s + (((size_t)b * (size_t)N + (size_t)n) * 256 + tid) * SP);
 #pragma unroll
-            for (int i = 0; i < RPL; ++i)
-#pragma unroll
-                for (int c = 0; c < RPL; ++c) dst[i * RPL + c] = S[i][c];
+            for (int e = 0; e < SP / 2; ++e) {
+                const int e0 = 2 * e, e1 = 2 * e + 1;
+                d2 v;
+                v.x = S[e0 / RPL][e0 % RPL];
+                v.y = e1 < RPL * RPL ? S[e1 / RPL][e1 % RPL] : 0.0;
+                dst[e] = v;
+            }
         }
         PIORAN_WSTAMP(1);
         double sp = 0.0;
@@ -477,12 +484,19 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
         in.zp = r[L + NS - 1];                        // the y slot is the last one
     };
     // S_n of this lane, SD steps ahead in registers
-    const double* sbase = p.st_s + ((size_t)b * (size_t)N * 256 + tid) * (RPL * RPL);
+    constexpr int SP = (RPL * RPL + 1) & ~1;          // padded block (16-byte pairs), as the forward pass wrote it
+    const double* sbase = p.st_s + ((size_t)b * (size_t)N * 256 + tid) * SP;
     auto fetch_s = [&](int64_t n, double (&dsts)[RPL * RPL]) __attribute__((always_inline)) {
         const int64_t k = n < 1 ? 1 : n;              // S_0 is never used (and was never written)
-        const double* q_ = sbase + (size_t)(N > 1 ? k : 0) * 256 * (RPL * RPL);
+        const d2* q_ = reinterpret_cast<const d2*>(sbase + (size_t)(N > 1 ? k : 0) * 256 * SP);
 #pragma unroll
-        for (int e = 0; e < RPL * RPL; ++e) dsts[e] = N > 1 ? q_[e] : 0.0;
+        for (int e = 0; e < SP / 2; ++e) {
+            d2 v;
+            v.x = 0.0; v.y = 0.0;
+            if (N > 1) v = q_[e];
+            dsts[2 * e] = v.x;
+            if (2 * e + 1 < RPL * RPL) dsts[2 * e + 1] = v.y;
+        }
     };
 
     // steps are visited in DEscending n; "position" s = N - 1 - n plays the role n plays in the forward kernel
@@ -701,8 +715,9 @@ static int rpl_of(int R) { return R <= 15 ? 1 : R <= 31 ? 2 : R <= 47 ? 3 : R <=
 size_t pioran_grad_workspace_doubles(int64_t B, int64_t N, int32_t R)
 {
     const size_t rpl = (size_t)rpl_of(R), ns = 16 * rpl;
-    // S [B][N][256][rpl^2] | m [B][N][ns] | D [B][N] | row adjoints 2 x [B][ns] | scalars [B][4]
-    return (size_t)B * (size_t)N * (256 * rpl * rpl + ns + 1) + (size_t)B * (2 * ns + 4);
+    const size_t sp = (rpl * rpl + 1) & ~(size_t)1;
+    // S [B][N][256][sp] | m [B][N][ns] | D [B][N] | row adjoints 2 x [B][ns] | scalars [B][4]
+    return (size_t)B * (size_t)N * (256 * sp + ns + 1) + (size_t)B * (2 * ns + 4) + 2;
 }
 
 // p: shared-table launch description with out / status set; work: pioran_grad_workspace_doubles doubles;
@@ -714,8 +729,8 @@ int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, dou
     const int rpl = rpl_of(p.R), ns = 16 * rpl;
     if (3 * (p.R + 2) + 2 + 3 * p.npd_rows + ns + 1 > kWideMaxRecord) return PIORAN_ERR_UNSUPPORTED;
     const size_t BN = (size_t)p.B * (size_t)p.N;
-    p.st_s = work;
-    p.st_w = p.st_s + BN * 256 * rpl * rpl;
+    p.st_s = work;                                     // hipMalloc'ed: 256-byte aligned, blocks of an even number of doubles
+    p.st_w = p.st_s + BN * 256 * (size_t)((rpl * rpl + 1) & ~1);
     p.st_d = p.st_w + BN * ns;
     p.g_al = p.st_d + BN;
     p.g_be = p.g_al + (size_t)p.B * ns;

@@ -49,7 +49,7 @@ struct ScanParams {
     const double* noise;
     double* ysim;
     // Gradient (pioran_launch_scan_wide_grad): the forward pass (MODE 3) stores S_n in the lane layout
-    // [B][N][256][RPL*RPL], v - q of ALL 16 RPL row slots in st_w [B][N][16 RPL] and D_n in st_d; the adjoint pass
+    // [B][N][256][RPL*RPL rounded up to even], v - q of ALL 16 RPL row slots in st_w [B][N][16 RPL] and D_n in st_d; the adjoint pass
     // returns the row adjoints of (al, be) [B][16 RPL] each, the scalars (dL/dsum(a), dL/dnu, dL/dmu) [B][4] and,
     // optionally, dL/dy_n and dL/dsigma2_n [B][N].
     double* st_s;
