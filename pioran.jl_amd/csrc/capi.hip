@@ -389,6 +389,20 @@ int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const
     return launch(ds, p);
 }
 
+// Shared (c, d): terms whose sin row is identically zero for the whole batch (d_j = 0 and b_j = 0 for all draws) keep
+// only their cos row; builds (or reuses) the shared table.
+static int prepare_shared(pioran_ds* ds, int64_t B, int64_t J, const double* Bc, const double* C, const double* Dd)
+{
+    std::vector<int32_t> real(J, 0);
+    for (int64_t j = 0; j < J; ++j) {
+        if (Dd[j] != 0.0) continue;
+        bool allzero = true;
+        for (int64_t b = 0; b < B && allzero; ++b) allzero = (Bc[b * J + j] == 0.0);
+        real[j] = allzero;
+    }
+    return pioran_dataset_prepare(ds, J, C, Dd, real.data());
+}
+
 // Mixed mode (host-pointer entry, cd_shared == 0): when only a few terms really differ between draws (QPO features on
 // top of an approx continuum, src/psd.jl:254-261), the shared terms keep using the shared table and only the per-draw
 // terms get a per-draw table, built by a pre-pass kernel for chunks of draws (32-bit buffer offsets).
@@ -486,17 +500,7 @@ static int batch_host_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A,
         if (rc < 0) return rc;
         if (rc == 1) return PIORAN_OK;
     }
-    if (cd_shared) {
-        // terms whose sin row is identically zero for the whole batch: d_j = 0 and b_j = 0 for all draws
-        std::vector<int32_t> real(J, 0);
-        for (int64_t j = 0; j < J; ++j) {
-            if (Dd[j] != 0.0) continue;
-            bool allzero = true;
-            for (int64_t b = 0; b < B && allzero; ++b) allzero = (Bc[b * J + j] == 0.0);
-            real[j] = allzero;
-        }
-        if ((rc = pioran_dataset_prepare(ds, J, C, Dd, real.data()))) return rc;
-    }
+    if (cd_shared && (rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
     if ((rc = upload(ctx, ctx->bA, A, bj))) return rc;
     if ((rc = upload(ctx, ctx->bB, Bc, bj))) return rc;
     if (!cd_shared) {
@@ -653,18 +657,6 @@ int pioran_celerite_logl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a,
 
 // ---- posterior mean / simulation --------------------------------------------------------------------
 // shared (c, d) only; draws are processed in chunks of at most 256 (one workgroup per draw, factor kept in HBM)
-static int prepare_shared(pioran_ds* ds, int64_t B, int64_t J, const double* Bc, const double* C, const double* Dd)
-{
-    std::vector<int32_t> real(J, 0);
-    for (int64_t j = 0; j < J; ++j) {
-        if (Dd[j] != 0.0) continue;
-        bool allzero = true;
-        for (int64_t b = 0; b < B && allzero; ++b) allzero = (Bc[b * J + j] == 0.0);
-        real[j] = allzero;
-    }
-    return pioran_dataset_prepare(ds, J, C, Dd, real.data());
-}
-
 int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
                             const double* Dd, const double* mu, const double* nu, int64_t M, const double* tau,
                             double* mean_out, int32_t* status)
