@@ -521,8 +521,15 @@ __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__
     while ((int64_t)ti * (ti + 1) / 2 > bid) --ti;
     const int tj = bid - (int)((int64_t)ti * (ti + 1) / 2);
     if (ti >= nt || tj >= nt - 1) return;   // wave-uniform; no workgroup barrier below
-    const double* Pi = A + (j0 + (int64_t)ti * NB) + kb * ld + lr + (int64_t)lk * ld;  // rows of the i tile
-    const double* Pj = A + (j0 + (int64_t)tj * NB) + kb * ld + lr + (int64_t)lk * ld;  // rows of the j tile
+    // Row permutation inside the tile: MFMA strip s (s = 0..3) takes the rows 32 (s >> 1) + 2 r + (s & 1), r = 0..15,
+    // instead of 16 s + r.  Lane (lr, lk) then needs rows 2 lr and 2 lr + 1 of each half of the tile — ADJACENT in the
+    // column-major slab — for strips 2h and 2h + 1: one 16-byte load feeds two operand fragments, and the C entries of
+    // the strip pair (2h, 2h + 1) are adjacent too.  128 vector-memory instructions per tile instead of 256: with eight
+    // waves per CU the texture path was as busy as the matrix pipe.  (All addresses are even multiples of 8 bytes:
+    // j0, NB and ld are multiples of 64.)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double* Pi = A + (j0 + (int64_t)ti * NB) + kb * ld + 2 * lr + (int64_t)lk * ld;  // rows of the i tile
+    const double* Pj = A + (j0 + (int64_t)tj * NB) + kb * ld + 2 * lr + (int64_t)lk * ld;  // rows of the j tile
     f64x4 acc[4][4];  // [jb][ib]
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
@@ -533,13 +540,15 @@ __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__
     // loads of k-step ks+2 are issued before the 16 MFMAs (1024 issue cycles) of k-step ks.  With the 128
     // accumulator registers this stays under 256 registers per lane, so two wavefronts share a SIMD and the
     // second one hides whatever latency is left (launch bounds below).
-    double xa[3][4], yb[3][4];   // [buffer][16-row strip]
+    double xa[3][4], yb[3][4];   // [buffer][strip]
     auto load_kstep = [&](int ks, int buf) {
 #pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-            const int64_t off = sidx * 16 + (int64_t)(4 * ks) * ld;
-            xa[buf][sidx] = Pj[off];  // X[row][k] = P[j][k]
-            yb[buf][sidx] = Pi[off];  // Y[k][col] = P[i][k]
+        for (int h = 0; h < 2; ++h) {
+            const int64_t off = 32 * h + (int64_t)(4 * ks) * ld;
+            const d2 x = *reinterpret_cast<const d2*>(Pj + off);   // X[row][k] = P[j][k], rows 32h + 2lr + {0, 1}
+            const d2 y = *reinterpret_cast<const d2*>(Pi + off);   // Y[k][col] = P[i][k]
+            xa[buf][2 * h] = x.x; xa[buf][2 * h + 1] = x.y;
+            yb[buf][2 * h] = y.x; yb[buf][2 * h + 1] = y.y;
         }
     };
     load_kstep(0, 0);
@@ -554,19 +563,27 @@ __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__
                 acc[jb][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks % 3][jb], yb[ks % 3][ib], acc[jb][ib], 0, 0, 0);
     }
 
-    // C -= acc, one 16-column strip (16 entries per lane) at a time: its loads are all in flight before the first store
-    double* C = A + (j0 + (int64_t)ti * NB) + (j0 + (int64_t)tj * NB) * ld + lr + (int64_t)lk * ld;
+    // C -= acc.  D row (l>>4) + 4g of strip jb is the j-row 32 (jb >> 1) + 2 (lk + 4g) + (jb & 1); D column l&15 of strip
+    // ib is the i-row 32 (ib >> 1) + 2 lr + (ib & 1): the strip pair (2h, 2h + 1) is one 16-byte access.  One j strip
+    // (8 accesses per lane) at a time: its loads are all in flight before the first store.
+    double* C = A + (j0 + (int64_t)ti * NB) + (j0 + (int64_t)tj * NB) * ld + 2 * lr;
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
-        double cv[4][4];
+        d2 cv[2][4];
 #pragma unroll
-        for (int ib = 0; ib < 4; ++ib)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) cv[ib][g] = C[ib * 16 + (int64_t)(jb * 16 + 4 * g) * ld];   // D row (l>>4)+4g -> j, col l&15 -> i
+            for (int g = 0; g < 4; ++g)
+                cv[h][g] = *reinterpret_cast<const d2*>(C + 32 * h + (int64_t)(32 * (jb >> 1) + 2 * (lk + 4 * g) + (jb & 1)) * ld);
 #pragma unroll
-        for (int ib = 0; ib < 4; ++ib)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) C[ib * 16 + (int64_t)(jb * 16 + 4 * g) * ld] = cv[ib][g] - acc[jb][ib][g];
+            for (int g = 0; g < 4; ++g) {
+                d2 v = cv[h][g];
+                v.x -= acc[jb][2 * h][g];
+                v.y -= acc[jb][2 * h + 1][g];
+                *reinterpret_cast<d2*>(C + 32 * h + (int64_t)(32 * (jb >> 1) + 2 * (lk + 4 * g) + (jb & 1)) * ld) = v;
+            }
     }
 }
 
