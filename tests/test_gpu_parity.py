@@ -819,3 +819,18 @@ def test_gradient_wrt_sampled_parameters(ctx, golden_dir):
                 e = np.zeros(6); e[k] = h
                 fd = (8 * (val(i, p0 + e) - val(i, p0 - e)) - (val(i, p0 + 2 * e) - val(i, p0 - 2 * e))) / (12 * h)
                 assert abs(got[k] - fd) <= 1e-5 * (1 + abs(fd)), (basis, i, k, got[k], fd)
+
+
+def test_gradient_chunking_and_optional_arguments(ctx):
+    """More draws than one 256-draw chunk; mu / nu omitted; gradient rows of every draw consistent with a one-draw call."""
+    rng = np.random.default_rng(31)
+    N, J, B = 60, 6, 260
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    ds = pj.Dataset(t, y, s2, ctx)
+    g = ds.logl_grad(A, Bc, C, Dd)
+    assert relerr(g["logl"], O.logl_batch(A, Bc, C, Dd, t, y, s2, np.zeros(B), np.ones(B), nthreads=8)) < 1e-11
+    for i in (0, 255, 256, 259):
+        one = ds.logl_grad(A[i:i + 1], Bc[i:i + 1], C, Dd)
+        assert np.array_equal(one["grad_a"][0], g["grad_a"][i]) and np.array_equal(one["grad_b"][0], g["grad_b"][i])
+        ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y, s2)
+        assert np.max(np.abs(g["grad_a"][i] - ref["grad_a"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_a"])))
