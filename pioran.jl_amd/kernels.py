@@ -146,6 +146,63 @@ class SumOfCelerite(SumOfTerms):
         return SumOfCelerite(number * self.a, number * self.b, self.c, self.d)
 
 
+class CARMA(SemiSeparable):
+    """CARMA(p, q, r_alpha, beta[, norm[, is_integrated_power]])   src/CARMA.jl:20-43.
+
+    r_alpha: the p roots of the autoregressive polynomial, complex-conjugate pairs first (for odd p the last root is
+    real); beta: the q + 1 moving-average coefficients.  On the likelihood path a CARMA kernel is only its celerite
+    coefficients (`log_likelihood(::CARMA, ...)`, src/celerite_solver.jl:272-282)."""
+
+    def __init__(self, p, q, r_alpha, beta, norm=1.0, is_integrated_power=True):
+        if isinstance(norm, bool):   # CARMA(p, q, r_alpha, beta, is_integrated_power)   src/CARMA.jl:42
+            norm, is_integrated_power = 1.0, norm
+        p, q = int(p), int(q)
+        r_alpha = np.atleast_1d(np.asarray(r_alpha, dtype=complex))
+        beta = np.atleast_1d(np.asarray(beta, dtype=float))
+        if p < 1 or q < 0:
+            raise ValueError("The order of the autoregressive and moving average polynomials must be positive")
+        if q > p:
+            raise ValueError("The order of the moving average polynomial must be less than or equal to the order of the "
+                             "autoregressive polynomial")
+        if len(r_alpha) != p:
+            raise ValueError("The length of the roots of the autoregressive polynomial must be equal to the order of the "
+                             "autoregressive polynomial")
+        if len(beta) != q + 1:
+            raise ValueError("The length of the moving average coefficients must be equal to q + 1")
+        self.p, self.q, self.r_alpha, self.beta = p, q, r_alpha, beta
+        self.norm, self.is_integrated_power = float(norm), bool(is_integrated_power)
+
+    def celerite_coefs(self):
+        """CARMA_celerite_coefs (src/CARMA.jl:98-143): one celerite term per conjugate pair of roots (every second
+        root), a real term for the unpaired last root of an odd p."""
+        r_all, beta, p = self.r_alpha, self.beta, self.p
+        rk = r_all[0::2]                                   # one root of each pair (+ the real one)
+        J = len(rk)
+        powers = np.arange(len(beta))
+        num = (beta * rk[:, None] ** powers).sum(axis=1) * (beta * (-rk[:, None]) ** powers).sum(axis=1)
+        frac = -num / rk.real
+        for k in range(J):
+            others = r_all[r_all != rk[k]]
+            frac[k] /= np.prod((others - rk[k]) * (np.conj(others) + rk[k]))
+        a, b, c, d = 2 * frac.real, 2 * frac.imag, -rk.real, -rk.imag
+        if p % 2 == 1:                                     # the last root is real: a single exponential term
+            a[-1], b[-1], d[-1] = frac[-1].real, 0.0, 0.0
+        scale = self.norm / a.sum() if self.is_integrated_power else self.norm
+        return a * scale, b * scale, c, d
+
+    def celerite_repr(self):
+        """celerite_repr(cov::CARMA)   src/CARMA.jl:57-72."""
+        return SumOfCelerite(*self.celerite_coefs())
+
+    def kappa(self, tau):
+        a, b, c, d = self.celerite_coefs()
+        tau = np.abs(np.asarray(tau, float))[..., None]
+        return (np.exp(-c * tau) * (a * np.cos(d * tau) + b * np.sin(d * tau))).sum(-1)
+
+    def scaled(self, number):
+        return CARMA(self.p, self.q, self.r_alpha, self.beta, self.norm * number, self.is_integrated_power)
+
+
 def celerite_coefs(cov: SemiSeparable):
     return cov.celerite_coefs()
 

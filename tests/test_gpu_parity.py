@@ -834,3 +834,17 @@ def test_gradient_chunking_and_optional_arguments(ctx):
         assert np.array_equal(one["grad_a"][0], g["grad_a"][i]) and np.array_equal(one["grad_b"][0], g["grad_b"][i])
         ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y, s2)
         assert np.max(np.abs(g["grad_a"][i] - ref["grad_a"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_a"])))
+
+
+def test_carma_kernel_on_the_likelihood_path(ctx, golden_dir):
+    """log_likelihood(::CARMA, ...) (src/celerite_solver.jl:272-282): the kernel enters as its celerite coefficients;
+    celerite path == oracle == -dense path, as the reference's relation tests do for the other kernels."""
+    g = json.loads((golden_dir / "reference_literals.json").read_text())["carma32"]
+    k = pj.CARMA(g["p"], g["q"], np.array([complex(*z) for z in g["r_alpha"]]), g["beta"], g["norm"])
+    A = np.loadtxt(golden_dir / "simu.txt")
+    t, y, yerr = A[:200, 0], A[:200, 1], A[:200, 2]
+    v = pj.log_likelihood(k, t, y, yerr ** 2, ctx=ctx)
+    a, b, c, d = k.celerite_coefs()
+    assert abs(v - O.logl(a, b, c, d, t, y, yerr ** 2)) <= 1e-10 * abs(v)
+    assert abs(v + pj.log_likelihood_direct(k, t, y, yerr ** 2, ctx=ctx)) <= 1e-9 * abs(v)
+    assert abs(pj.logpdf(pj.ScalableGP(0.3, k)(t, yerr ** 2), y, ctx=ctx) - O.logl(a, b, c, d, t, y - 0.3, yerr ** 2)) <= 1e-10 * abs(v)

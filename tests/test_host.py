@@ -177,3 +177,29 @@ def test_approx_batch_vjp_matches_finite_differences():
         Ap, Bp, _, _ = pj.approx_batch(pj.SingleBendingPowerLaw, th, 1e-3, 5.0, 20, norm * (1 + h), basis_function=basis)
         fdn = (ga * (Ap - A) + gb * (Bp - Bc)).sum(1) / (norm * h)
         assert np.max(np.abs(fdn - gn) / (1 + np.abs(gn))) < 1e-6
+
+
+def test_carma_kernel_coefficients(golden_dir):
+    """CARMA(3, 2) -> (a, b, c, d): the reference's literal (test/test_carma.jl:55-69), the oracle, argument checks."""
+    from oracle import oracle as O
+    g = json.loads((golden_dir / "reference_literals.json").read_text())["carma32"]
+    r = np.array([complex(*z) for z in g["r_alpha"]])
+    k = pj.CARMA(g["p"], g["q"], r, g["beta"], g["norm"])
+    got = k.celerite_coefs()
+    for x, e in zip(got, g["expected"]):
+        np.testing.assert_allclose(x, e, rtol=1e-12, atol=1e-14)
+    for x, e in zip(got, O.carma_celerite_coefs(g["p"], r, g["beta"], g["norm"])):
+        np.testing.assert_allclose(x, e, rtol=1e-13, atol=1e-15)
+    # even order, variance normalisation, scaling, kappa(0) = sum(a)
+    r4 = np.array([-0.1 + 0.7j, -0.1 - 0.7j, -0.4 + 0.2j, -0.4 - 0.2j])
+    k4 = pj.CARMA(4, 1, r4, [1.0, 0.3], 2.0, False)
+    a, b, c, d = k4.celerite_coefs()
+    assert len(a) == 2 and abs(k4.kappa(0.0) - a.sum()) < 1e-14
+    for x, e in zip(k4.celerite_coefs(), O.carma_celerite_coefs(4, r4, [1.0, 0.3], 2.0, False)):
+        np.testing.assert_allclose(x, e, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose((3.0 * k4).celerite_coefs()[0], 3.0 * a, rtol=1e-14)
+    assert isinstance(k.celerite_repr(), pj.SumOfCelerite)
+    for bad in (dict(p=0, q=0, r=[], beta=[1.0]), dict(p=2, q=3, r=r4[:2], beta=[1, 2, 3, 4]),
+                dict(p=3, q=1, r=r4[:2], beta=[1, 2]), dict(p=2, q=1, r=r4[:2], beta=[1.0])):
+        with pytest.raises(ValueError):
+            pj.CARMA(bad["p"], bad["q"], bad["r"], bad["beta"])
