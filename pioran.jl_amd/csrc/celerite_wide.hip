@@ -67,13 +67,7 @@ __device__ __forceinline__ double row16_sum(double x)
     return x;
 }
 
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef double d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
-{
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
-    return __hiloint2double((int)v.y, (int)v.x);
-}
 
 // 1/x to fp64 accuracy: v_rcp_f64 seed + two Newton steps (same sequence as celerite_scan.hip)
 __device__ __forceinline__ double recip_f64(double x)

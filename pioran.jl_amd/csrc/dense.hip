@@ -192,14 +192,6 @@ __device__ __forceinline__ void static_for16(F&& f)
     static_for16_impl(f, std::make_integer_sequence<int, 16>{});
 }
 
-// value of lane `src` (wave-uniform) as a scalar: two v_readlane_b32
-__device__ __forceinline__ double readlane_f64(double x, int src)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
-    return __hiloint2double(hi, lo);
-}
-
 // 1/sqrt(x) to fp64 accuracy: v_rsq_f64 + ONE third-order step, y (1 + e/2 + 3e^2/8) with e = 1 - x y^2.
 // Four dependent operations instead of the six of two Newton steps: this sits on the per-column critical path of
 // the diagonal-tile factorisation.  (|e| <= 2^-22 after v_rsq_f64 leaves a relative error ~ e^3 < 2^-66.)
@@ -601,7 +593,7 @@ __global__ void __launch_bounds__(256) dense_finish_kernel(const double* __restr
     s1[threadIdx.x] = ld_;
     s2[threadIdx.x] = zz;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (unsigned s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
             s1[threadIdx.x] += s1[threadIdx.x + s];
             s2[threadIdx.x] += s2[threadIdx.x + s];
