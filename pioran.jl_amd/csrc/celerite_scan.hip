@@ -372,6 +372,7 @@ template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false, int
 __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanParams p)
 {
     static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
+    static_assert(!PAIRED || ASM_DPP || ((NSRC * RPL) % 2 == 0), "compiler-scheduled column pairs need an even block");
     constexpr int G = 16 * CBR;          // lanes per draw
     constexpr int EPW = 64 / G;          // draws per wavefront
     constexpr int NC = NSRC * RPL;       // columns held per lane
@@ -578,6 +579,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 ColBlock<RPL, (NC - 1) / RPL>::run(S[NC - 1], qt, g, in.ph, w[(NC - 1) % RPL], u[(NC - 1) % RPL],
                                                    in.ph[(NC - 1) % RPL]);
         } else {
+        [[maybe_unused]] double ppair[RPL];   // compiler-scheduled PAIRED: phi_i phi_k of the even column, reused by the odd one
         static_for<0, NSRC>([&](auto Nc) {
             constexpr int NN = decltype(Nc)::value;
             static_for<0, RPL>([&](auto Mc) {
@@ -589,11 +591,16 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 }
                 const double wk = row_bcast<NN>(w[MM]);
                 const double uk = row_bcast<NN>(u[MM]);
-                const double pk = row_bcast<NN>(in.ph[MM]);
+                constexpr bool reuse = PAIRED && (c & 1);     // (RB even: columns c, c + 1 with c even are one term's rows)
+                if constexpr (!reuse) {
+                    const double pk = row_bcast<NN>(in.ph[MM]);
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i) ppair[i] = in.ph[i] * pk;   // phi_j phi_k   :78,85
+                }
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) {
                     const double m = fma(g[i], wk, S[c][i]);   // S + dn * V[k,n-1]          :78
-                    const double sn = (in.ph[i] * pk) * m;     // phi_j phi_k ( ... )        :78,85
+                    const double sn = ppair[i] * m;            // phi_j phi_k ( ... )        :78,85
                     S[c][i] = sn;
                     qt[i] = fma(sn, uk, qt[i]);                // (S u)_j                    :80-82,86-89
                 }
@@ -699,7 +706,8 @@ const ScanConfig kConfigs[] = {
     {"rpl2_cbr1_nsrc13_p", 2, 1, 13, &launch_cfg<2, 1, 13, true, 1, true>, true},
     {"rpl2_cbr1_nsrc15_p", 2, 1, 15, &launch_cfg<2, 1, 15, true, 1, true>, true},
     {"rpl2_cbr1_nsrc16_p", 2, 1, 16, &launch_cfg<2, 1, 16, true, 1, true>, true},
-    {"rpl4_cbr4_nsrc4_p", 4, 4, 4, &launch_cfg<4, 4, 4, true, 2, true>, true, false},   // 104k vs 116k evals/s (SHO-30)
+    {"rpl4_cbr4_nsrc4_p", 4, 4, 4, &launch_cfg<4, 4, 4, true, 2, true>, true, false},   // asm pairs: 113k evals/s (SHO-30)
+    {"rpl4_cbr4_nsrc4_pc", 4, 4, 4, &launch_cfg<4, 4, 4, false, 2, true>, true},  // compiler-scheduled, phi products shared per pair: 116k vs 106k (SHO-30)
     // alternatives kept for tuning runs (selected by name)
     CFG(3, 4, 4), CFG(2, 2, 8), CFG_C(3, 2, 7), CFG_C(4, 4, 4), CFG_C(2, 1, 16), CFG_C(1, 1, 16), CFG_C(5, 4, 4),
     {"rpl4_cbr4_nsrc4_asm", 4, 4, 4, &launch_cfg<4, 4, 4, true, 1>},

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench, pioran_jl_amd as pj
 
-N, J = int(os.environ.get("N", 10000)), 20
+N, J = int(os.environ.get("N", 10000)), int(os.environ.get("J", 20))
 basis = os.environ.get("BASIS", "SHO")
 Bs = [int(x) for x in sys.argv[1:]] or [4096]
 cfgs = os.environ.get("CFGS", "rpl3_cbr2_nsrc7,rpl3_cbr2_nsrc8,rpl3_cbr1_nsrc14,rpl3_cbr4_nsrc4,rpl4_cbr4_nsrc4").split(",")
