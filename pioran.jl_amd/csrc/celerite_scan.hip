@@ -372,7 +372,6 @@ template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false, int
 __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanParams p)
 {
     static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
-    static_assert(!PAIRED || ASM_DPP || ((NSRC * RPL) % 2 == 0), "compiler-scheduled column pairs need an even block");
     constexpr int G = 16 * CBR;          // lanes per draw
     constexpr int EPW = 64 / G;          // draws per wavefront
     constexpr int NC = NSRC * RPL;       // columns held per lane
@@ -591,7 +590,8 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 }
                 const double wk = row_bcast<NN>(w[MM]);
                 const double uk = row_bcast<NN>(u[MM]);
-                constexpr bool reuse = PAIRED && (c & 1);     // (RB even: columns c, c + 1 with c even are one term's rows)
+                constexpr bool reuse = PAIRED && (c & 1);     // columns c, c + 1 with c even are one term's rows (an odd block
+                                                              // ends with a single slot at an even index, which is not reused)
                 if constexpr (!reuse) {
                     const double pk = row_bcast<NN>(in.ph[MM]);
 #pragma unroll
@@ -707,6 +707,8 @@ const ScanConfig kConfigs[] = {
     {"rpl2_cbr1_nsrc15_p", 2, 1, 15, &launch_cfg<2, 1, 15, true, 1, true>, true},
     {"rpl2_cbr1_nsrc16_p", 2, 1, 16, &launch_cfg<2, 1, 16, true, 1, true>, true},
     {"rpl4_cbr4_nsrc4_p", 4, 4, 4, &launch_cfg<4, 4, 4, true, 2, true>, true, false},   // asm pairs: 113k evals/s (SHO-30)
+    {"rpl3_cbr2_nsrc7_pc", 3, 2, 7, &launch_cfg<3, 2, 7, false, 1, true>, true, false},   // tuning alternative of the headline config
+    {"rpl5_cbr4_nsrc4_pc", 5, 4, 4, &launch_cfg<5, 4, 4, false, 1, true>, true},   // 52.2k vs 49.4k evals/s (SHO-39)
     {"rpl4_cbr4_nsrc4_pc", 4, 4, 4, &launch_cfg<4, 4, 4, false, 2, true>, true},  // compiler-scheduled, phi products shared per pair: 116k vs 106k (SHO-30)
     // alternatives kept for tuning runs (selected by name)
     CFG(3, 4, 4), CFG(2, 2, 8), CFG_C(3, 2, 7), CFG_C(4, 4, 4), CFG_C(2, 1, 16), CFG_C(1, 1, 16), CFG_C(5, 4, 4),

@@ -232,7 +232,7 @@ def test_all_kernel_configs_agree(ctx):
     try:
         for name in ("rpl3_cbr2_nsrc7_p", "rpl3_cbr2_nsrc8_p", "rpl3_cbr2_nsrc7", "rpl3_cbr2_nsrc8", "rpl3_cbr2_nsrc7_c", "rpl3_cbr4_nsrc4", "rpl4_cbr4_nsrc4",
                      "rpl4_cbr4_nsrc4_c", "rpl4_cbr4_nsrc4_asm", "rpl4_cbr4_nsrc4_asm_w2", "rpl5_cbr4_nsrc4",
-                     "rpl5_cbr4_nsrc4_c", "rpl4_cbr4_nsrc4_p", "rpl4_cbr4_nsrc4_pc", "wide"):
+                     "rpl5_cbr4_nsrc4_c", "rpl4_cbr4_nsrc4_p", "rpl4_cbr4_nsrc4_pc", "rpl3_cbr2_nsrc7_pc", "rpl5_cbr4_nsrc4_pc", "wide"):
             os.environ["PIORAN_SCAN_CONFIG"] = name
             if name != "wide":   # ("wide" = the latency layout of celerite_wide.hip, not an entry of the scan table)
                 assert pj._lib.lib().pioran_celerite_config_name(40).decode() == name
