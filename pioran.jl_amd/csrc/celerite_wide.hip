@@ -17,11 +17,18 @@
 //     share of u'q; every lane then reads the 16 shares (fixed summation order: all waves get the same bits),
 //     forms D_n and its reciprocal, and the RPL values w_k = (v - q)_k / D_n of its column block.
 //     Buffers alternate with the step parity, which makes the single barrier sufficient.
-//   * the table records are prefetched several steps ahead (a ring of register buffers): a lone workgroup keeps
-//     nothing else in flight, and at small B the 10 MB table is not L2 resident, so every record is an HBM-latency
-//     miss that only depth can hide.
+//   * the table records go HBM -> registers -> LDS: each thread fetches ONE double of the step record (two when it is
+//     longer than 256 doubles), four records ahead, and the lanes read their 6 RPL + 2 values from LDS.  A lone
+//     workgroup keeps nothing else in flight and the 10 MB table is not L2 resident at small B, so every record is
+//     an HBM-latency miss that only depth can hide; and 6 RPL + 2 broadcast-heavy buffer loads per lane and step
+//     (the first version) saturated the texture path instead.
 // Shared-table launches only ((c, d) common to the batch, possibly with a few per-draw rows: mixed mode); launches
 // with fully per-draw (c, d) stay on celerite_scan.hip.
+//
+// The same kernel carries three more modes (template MODE) for the callers either side of the likelihood
+// (SURVEY.md 8(f)): 1 = also store the factor (W_n, D_n, forward-solved z_n) for the posterior mean
+// (celerite_predict.hip); 2 = simulate (the extra row applies L instead of L^-1); 3 = also store S_n, v - q and D_n for
+// celerite_adjoint_kernel below, which walks the recurrence backwards and returns the gradient of log L.
 #include "common.h"
 
 #include <cmath>
