@@ -185,7 +185,7 @@ def main():
         "config": {"workload": f"N={N} irregular series, {args.basis}-{J} (J={Jt} celerite terms, R={R} active rows), "
                                f"batch={B} draws per GPU, shared (c,d) table, per-draw mu/nu",
                    "N": N, "J": Jt, "R_active": R, "batch_per_gpu": B, "global_batch": B * world,
-                   "kernel_config": pj._lib.lib().pioran_celerite_config_name(R).decode(),
+                   "kernel_config": pj._lib.lib().pioran_celerite_config_name(0).decode(),   # what the last launch ran on
                    "parallelism": f"batch-sharded x{world}, all-gather of logL"},
         "roofline": {"bound": "valu-fp64", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -155,7 +155,8 @@ int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double*
 int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc,
                              const double* C, const double* Dd, const double* t, const double* sigma2, const double* q,
                              double* y_out);
-/* Name of the kernel configuration a batch with R active rows runs on (diagnostics). */
+/* Name of the kernel configuration a large batch with R active rows (all terms with both rows when R is even) runs on;
+ * R <= 0: the configuration the calling thread's last throughput-layout launch actually ran on (diagnostics). */
 const char* pioran_celerite_config_name(int64_t R);
 
 /* ---- in-process farm over several GPUs ---------------------------------------------------------------------------

@@ -46,6 +46,8 @@ struct pioran_ds {
     // mixed mode (term kind 2): indices of the per-draw terms, on the device
     int32_t npd_terms = 0;
     int32_t* dpd_terms = nullptr;
+    // row layout class for the scan's configuration choice (ScanParams::standard_rows / n_complex)
+    int32_t row_layout = 0, n_complex = 0;
 };
 
 namespace {
@@ -340,6 +342,14 @@ int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const doub
     if (rc) return rc;
     ds->J = (int32_t)J;
     ds->real_host = real;
+    {   // 1: every term has both rows; 2: two-row terms first, then one-row terms only; 0: anything else
+        int64_t nc = 0;
+        while (nc < J && real[nc] == 0) ++nc;
+        bool rest_real = true;
+        for (int64_t j = nc; j < J; ++j) rest_real = rest_real && real[j] == 1;
+        ds->row_layout = nc == J ? 1 : ((rest_real && pdlist.empty()) ? 2 : 0);
+        ds->n_complex = (int32_t)nc;
+    }
     ds->prepared = true;
     return PIORAN_OK;
 }
@@ -355,7 +365,7 @@ int pioran_celerite_logl_batch_dev(pioran_ds* ds, int64_t B, const double* dA, c
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ScanParams p{};
     p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = B;
-    p.standard_rows = ds->R == 2 * ds->J;
+    p.standard_rows = ds->row_layout; p.n_complex = ds->n_complex;
     p.rec_stride = 3 * (int64_t)(ds->R + 2) + 2;
     p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
     p.Y = dY; p.S2 = dS2; p.A = dA; p.Bc = dBc; p.C = ds->dc; p.D = ds->dd;
@@ -467,7 +477,7 @@ static int batch_host_mixed(pioran_ds* ds, int64_t B, int64_t J, const double* A
         if (rc) return rc;
         ScanParams p{};
         p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = nb;
-        p.standard_rows = ds->R == 2 * ds->J;
+        p.standard_rows = ds->row_layout; p.n_complex = ds->n_complex;
         p.rec_stride = rec_stride;
         p.tab = ctab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
         p.Y = dY; p.S2 = dS2; p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
@@ -681,7 +691,7 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
         if (nu && (rc = upload(ctx, ctx->bnu, nu + b0, nb * sizeof(double)))) return rc;
         ScanParams p{};
         p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = nb;
-        p.standard_rows = ds->R == 2 * ds->J;
+        p.standard_rows = ds->row_layout; p.n_complex = ds->n_complex;
         p.rec_stride = 3 * (int64_t)(ds->R + 2) + 2;
         p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
         p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
@@ -727,7 +737,7 @@ int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double*
         if (nu && (rc = upload(ctx, ctx->bnu, nu + b0, nb * sizeof(double)))) return rc;
         ScanParams p{};
         p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = nb;
-        p.standard_rows = ds->R == 2 * ds->J;
+        p.standard_rows = ds->row_layout; p.n_complex = ds->n_complex;
         p.rec_stride = 3 * (int64_t)(ds->R + 2) + 2;
         p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
         p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
@@ -777,7 +787,7 @@ int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, c
         if ((rc = upload(ctx, ctx->bY, q + b0 * N, (size_t)nb * N * sizeof(double)))) return done(rc);
         ScanParams p{};
         p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = nb;
-        p.standard_rows = ds->R == 2 * ds->J;
+        p.standard_rows = ds->row_layout; p.n_complex = ds->n_complex;
         p.rec_stride = 3 * (int64_t)(ds->R + 2) + 2;
         p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
         p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
@@ -796,7 +806,8 @@ int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, c
 
 const char* pioran_celerite_config_name(int64_t R)
 {
-    if (R < 1 || R > pioran_scan_supported_rows()) return "fallback";
+    if (R <= 0) return pioran_scan_config_name(0);   // what the calling thread's last throughput-layout launch ran on
+    if (R > pioran_scan_supported_rows()) return "fallback";
     return pioran_scan_config_name((int)R);
 }
 

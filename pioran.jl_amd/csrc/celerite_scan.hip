@@ -368,9 +368,15 @@ struct StepIn {           // what one time step reads: per own row (v, x, phi) +
     double v[RPL], x[RPL], ph[RPL], y, s2;
 };
 
-template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false, int MINW = 1, bool PAIRED = false, bool MIXED = false>
+// NPB > 0 selects the "two-row terms first, one-row terms after" slot layout (DRWCelerite: n complex terms and n real
+// ones, src/psd.jl:264-275): every DPP row's block of RB slots holds NPB column PAIRS (rows of NPB complex terms), then
+// RB - 1 - 2 NPB single rows (real terms), then one spare slot (padding; the y row in the last block).  All blocks
+// look alike, so the phi_i phi_k product of a pair is formed once per pair in every DPP row of the wavefront.
+template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false, int MINW = 1, bool PAIRED = false, bool MIXED = false,
+          int NPB = 0>
 __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanParams p)
 {
+    static_assert(NPB == 0 || (!PAIRED && !ASM_DPP && 2 * NPB < NSRC * RPL), "block layout: compiler-scheduled, unpaired base");
     static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
     constexpr int G = 16 * CBR;          // lanes per draw
     constexpr int EPW = 64 / G;          // draws per wavefront
@@ -409,7 +415,15 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         pdoff[i] = -1;
         const int slot = lam * RPL + i;
         int j;   // real row index, or >= R for a special slot
-        if constexpr (PAIRED) {
+        if constexpr (NPB > 0) {
+            constexpr int NSB = RB - 1 - 2 * NPB;      // single rows per block
+            constexpr int NCR = 2 * NPB * CBR;         // rows of the two-row terms (n_complex = NPB * CBR, checked on the host)
+            const int blk = slot / RB, c = slot - blk * RB;
+            if (c < 2 * NPB) j = blk * 2 * NPB + c;
+            else if (c < RB - 1) j = NCR + blk * NSB + (c - 2 * NPB);
+            else j = R;                                // spare slot: padding (the y row in the last block)
+            if (j > R) j = R;
+        } else if constexpr (PAIRED) {
             const int blk = slot / RB, c = slot - blk * RB;
             j = c < RBR ? blk * RBR + c : R;   // the single slot of an odd block is never a real row
         } else {
@@ -590,8 +604,9 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 }
                 const double wk = row_bcast<NN>(w[MM]);
                 const double uk = row_bcast<NN>(u[MM]);
-                constexpr bool reuse = PAIRED && (c & 1);     // columns c, c + 1 with c even are one term's rows (an odd block
-                                                              // ends with a single slot at an even index, which is not reused)
+                // columns c, c + 1 with c even are one term's rows (an odd block ends with a single slot at an even index,
+                // which is not reused); block layout: only the first 2 NPB columns of a block are pairs
+                constexpr bool reuse = (c & 1) && (PAIRED || (NPB > 0 && c < 2 * NPB));
                 if constexpr (!reuse) {
                     const double pk = row_bcast<NN>(in.ph[MM]);
 #pragma unroll
@@ -668,12 +683,20 @@ void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
         hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false, ASM_DPP, MINW, PAIRED>), grid, dim3(256), 0, st, p);
 }
 
+// block layout (NPB pairs per block): shared-table launches without per-draw rows only
+template <int RPL, int CBR, int NSRC, int MINW, int NPB>
+void launch_blocked(const ScanParams& p, dim3 grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, false, MINW, false, false, NPB>), grid, dim3(256), 0, st, p);
+}
+
 struct ScanConfig {
     const char* name;
     int rpl, cbr, nsrc;
     LaunchFn fn;
     bool paired = false;   // needs the standard row map (every term has both rows)
     bool autopick = true;  // false: only selectable by name (measured slower than the default of its row range)
+    int npb = 0;           // > 0: block layout for "n_complex = npb * cbr two-row terms, then one-row terms" (standard_rows == 2)
     // real rows it holds: one slot carries y; a paired config with an odd block keeps one single slot per block
     int capacity() const
     {
@@ -709,6 +732,8 @@ const ScanConfig kConfigs[] = {
     {"rpl4_cbr4_nsrc4_p", 4, 4, 4, &launch_cfg<4, 4, 4, true, 2, true>, true, false},   // asm pairs: 113k evals/s (SHO-30)
     {"rpl3_cbr2_nsrc7_pc", 3, 2, 7, &launch_cfg<3, 2, 7, false, 1, true>, true, false},   // tuning alternative of the headline config
     {"rpl5_cbr4_nsrc4_pc", 5, 4, 4, &launch_cfg<5, 4, 4, false, 1, true>, true},   // 52.2k vs 49.4k evals/s (SHO-39)
+    // DRWCelerite with 20 components: 20 complex + 20 real terms = 5 pairs + 5 singles + 1 spare in each of the 4 blocks
+    {"rpl4_cbr4_nsrc4_b5", 4, 4, 4, &launch_blocked<4, 4, 4, 2, 5>, false, true, 5},
     {"rpl4_cbr4_nsrc4_pc", 4, 4, 4, &launch_cfg<4, 4, 4, false, 2, true>, true},  // compiler-scheduled, phi products shared per pair: 116k vs 106k (SHO-30)
     // alternatives kept for tuning runs (selected by name)
     CFG(3, 4, 4), CFG(2, 2, 8), CFG_C(3, 2, 7), CFG_C(4, 4, 4), CFG_C(2, 1, 16), CFG_C(1, 1, 16), CFG_C(5, 4, 4),
@@ -719,11 +744,25 @@ const ScanConfig kConfigs[] = {
 #undef CFG_C
 constexpr int kNumPreferred = 14;
 
-const ScanConfig* pick_config(int R, bool standard_rows)
+// does the block layout of `c` hold this row structure?  (shared table, no per-draw rows)
+bool blocked_fits(const ScanConfig& c, const ScanParams& p)
+{
+    if (c.npb == 0) return true;
+    const int rb = c.rpl * c.nsrc, nsb = rb - 1 - 2 * c.npb;
+    return p.standard_rows == 2 && p.tab && p.npd_rows == 0 && p.n_complex == c.npb * c.cbr &&
+           p.R - 2 * p.n_complex <= nsb * c.cbr;
+}
+
+const ScanConfig* pick_config(int R, bool standard_rows, const ScanParams* p = nullptr)
 {
     if (const char* env = std::getenv("PIORAN_SCAN_CONFIG")) {
         for (const auto& c : kConfigs)
-            if (!std::strcmp(env, c.name) && c.capacity() >= R && (!c.paired || standard_rows)) return &c;
+            if (!std::strcmp(env, c.name) && c.capacity() >= R && (!c.paired || standard_rows) && (c.npb == 0 || (p && blocked_fits(c, *p))))
+                return &c;
+    }
+    if (p && !std::getenv("PIORAN_NO_PAIRED")) {
+        for (const auto& c : kConfigs)
+            if (c.npb > 0 && c.autopick && blocked_fits(c, *p)) return &c;
     }
     const ScanConfig* best = nullptr;
     for (int i = 0; i < kNumPreferred; ++i)
@@ -731,7 +770,7 @@ const ScanConfig* pick_config(int R, bool standard_rows)
     if (standard_rows && !std::getenv("PIORAN_NO_PAIRED")) {
         // a paired variant of the same shape (or the smallest paired one that fits) wins when the row map allows it
         for (const auto& c : kConfigs)
-            if (c.paired && c.autopick && c.capacity() >= R && (!best || c.rpl * c.cbr * c.nsrc <= best->rpl * best->cbr * best->nsrc))
+            if (c.paired && c.npb == 0 && c.autopick && c.capacity() >= R && (!best || c.rpl * c.cbr * c.nsrc <= best->rpl * best->cbr * best->nsrc))
                 return &c;
     }
     return best;
@@ -741,20 +780,24 @@ const ScanConfig* pick_config(int R, bool standard_rows)
 
 int pioran_scan_supported_rows() { return 79; }
 
+static thread_local const char* g_last_config = "none";
+
 const char* pioran_scan_config_name(int R)
 {
+    if (R <= 0) return g_last_config;                      // the configuration the last launch of this thread ran on
     const ScanConfig* c = pick_config(R, (R & 1) == 0);   // diagnostics: assumes the standard row map for even R
     return c ? c->name : "fallback";
 }
 
 int pioran_launch_scan(const ScanParams& p, hipStream_t stream)
 {
-    const ScanConfig* c = pick_config(p.R, p.standard_rows != 0);
+    const ScanConfig* c = pick_config(p.R, p.standard_rows == 1, &p);
     if (!c) return PIORAN_ERR_UNSUPPORTED;
     const int epw = 64 / (16 * c->cbr);
     const int64_t per_block = 4 * epw;
     const int64_t blocks = (p.B + per_block - 1) / per_block;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return PIORAN_ERR_ARG;
+    g_last_config = c->name;
     c->fn(p, dim3((unsigned)blocks), stream);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }

@@ -17,7 +17,9 @@ struct ScanParams {
     int64_t N;            // time stamps
     int32_t J;            // celerite terms
     int32_t R;            // active rows (<= 2J; structurally-zero sin rows of d=b=0 terms dropped)
-    int32_t standard_rows;  // 1: R = 2J and row 2j / 2j+1 are the cos / sin rows of term j (no dropped rows)
+    int32_t standard_rows;  // 1: R = 2J and row 2j / 2j+1 are the cos / sin rows of term j (no dropped rows);
+                            // 2: n_complex two-row terms first, then one-row (real) terms only — DRWCelerite (src/psd.jl:264-275)
+    int32_t n_complex;      // leading two-row terms when standard_rows == 2
     int64_t B;            // batch (independent draws)
     const double* tab;    // shared table [N+1][3(R+2)+2], or nullptr when (c,d) are per draw
     const int32_t* rowmap;  // [R]: term (bits 0-19) | per-draw row index (20-28) | per-draw flag (29) | sin row (30)

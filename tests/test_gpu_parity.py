@@ -210,6 +210,30 @@ def test_latency_layout_edges(ctx):
         os.environ.pop("PIORAN_SCAN_CONFIG", None)
 
 
+def test_drwcelerite_block_layout(ctx):
+    """DRWCelerite with 20 components (20 two-row + 20 one-row terms) runs on the block-layout configuration; same
+    values as the plain configuration and as the oracle; 12 components (no matching block layout) stay on the plain one."""
+    rng = np.random.default_rng(41)
+    t = np.cumsum(rng.uniform(0.05, 2.0, 300)); y = rng.standard_normal(300); yerr = rng.uniform(0.01, 0.05, 300)
+    th = O.synthetic_theta(300, t, y)
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(0).decode()
+    for ncomp, expect in ((20, "rpl4_cbr4_nsrc4_b5"), (12, "rpl3_cbr2_nsrc7")):
+        A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, ncomp, "DRWCelerite")
+        got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert name() == expect, name()
+        ref, rst = O.logl_batch(A, Bc, C, Dd, t, y, yerr ** 2, mu, nu, nthreads=8, return_status=True)
+        ok = rst == 0
+        assert ok.sum() > 100 and relerr(got[ok], ref[ok]) < 1e-9
+        try:
+            os.environ["PIORAN_NO_PAIRED"] = "1"
+            plain = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+            assert name() != "rpl4_cbr4_nsrc4_b5"
+        finally:
+            os.environ.pop("PIORAN_NO_PAIRED", None)
+        assert relerr(got[ok], plain[ok]) < 1e-9   # different row order => different summation order of q
+
+
 def test_status_not_positive_definite(ctx):
     rng = np.random.default_rng(5)
     t = np.cumsum(rng.uniform(0.1, 2, 50)); y = rng.standard_normal(50); s2 = np.full(50, 1e-8)
