@@ -191,6 +191,12 @@ int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, con
 int pioran_dense_predict_cov(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,
                              const double* c, const double* d, const double* t, const double* sigma2, int64_t M,
                              const double* tau, double* cov_out, int32_t* info);
+/* predict_direct(cov, tau, t, y, sigma2[, with_covariance]) (src/direct_solver.jl:75-119): the dense posterior mean
+ * K(tau,t) (K(t,t) + diag(sigma2))^-1 y from the same partial factorisation (y rides as one more row, as in
+ * pioran_dense_nll), and optionally (cov_out != NULL) the covariance of pioran_dense_predict_cov. */
+int pioran_dense_predict(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,
+                         const double* c, const double* d, const double* t, const double* y, const double* sigma2,
+                         int64_t M, const double* tau, double* mean_out, double* cov_out, int32_t* info);
 /* Covariance build alone (K as N x N column-major host array) — kappa of src/acvf.jl:138-140. */
 int pioran_dense_covariance(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,
                             const double* c, const double* d, const double* t, const double* sigma2,

@@ -4,7 +4,7 @@ Directory name has a dot, so import it through the repo-root shim: `import piora
 """
 from . import _lib, farm  # noqa: F401
 from .gp import (Context, CustomMean, Dataset, Farm, FiniteScalableGP, PosteriorGP, ScalableGP, cov, default_context,
-                 log_likelihood, log_likelihood_direct, logl, logpdf, logpdf_batch, mean, posterior, predict, predict_cov,
+                 log_likelihood, log_likelihood_direct, logl, logpdf, logpdf_batch, mean, posterior, predict, predict_cov, predict_direct,
                  rand, rand_posterior, simulate, std)
 from .kernels import (CARMA, Celerite, Exp, ScaledKernel, SemiSeparable, SHO, SumOfCelerite, SumOfSemiSeparable,
                       SumOfTerms, celerite_coefs)

@@ -55,6 +55,7 @@ SIGNATURES = {
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pioran_dense_nll": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [c_void_p, c_void_p]),
     "pioran_dense_predict_cov": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 6 + [i64, c_void_p, c_void_p, c_void_p]),
+    "pioran_dense_predict": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pioran_dense_covariance": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 6 + [c_void_p]),
 }
 

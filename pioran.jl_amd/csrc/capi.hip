@@ -937,41 +937,65 @@ int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, con
     return PIORAN_OK;
 }
 
-int pioran_dense_predict_cov(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
-                             const double* d, const double* t, const double* sigma2, int64_t M, const double* tau,
-                             double* cov_out, int32_t* info)
+// predict_direct / predict_cov (src/direct_solver.jl:28-119): y == nullptr: covariance only; cov_out == nullptr: mean only
+static int dense_predict_impl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
+                              const double* d, const double* t, const double* y, const double* sigma2, int64_t M,
+                              const double* tau, double* mean_out, double* cov_out, int32_t* info)
 {
-    if (!ctx || N < 1 || J < 1 || M < 1 || !a || !b || !c || !d || !t || !sigma2 || !tau || !cov_out) return PIORAN_ERR_ARG;
+    if (!ctx || N < 1 || J < 1 || M < 1 || !a || !b || !c || !d || !t || !sigma2 || !tau) return PIORAN_ERR_ARG;
+    if ((y == nullptr) != (mean_out == nullptr) || (!mean_out && !cov_out)) return PIORAN_ERR_ARG;
     const int64_t Mp = (N + 63) / 64 * 64, Mq = (M + 63) / 64 * 64, Mtot = Mp + Mq;
     if (Mtot > 46000) return PIORAN_ERR_UNSUPPORTED;  // slab would exceed ~17 GB
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // [t | NaN padding | tau | NaN padding]: a NaN time is an identity row/column of the augmented matrix
-    std::vector<double> te((size_t)Mtot, std::nan("")), s2e((size_t)Mtot, 0.0);
+    std::vector<double> te((size_t)Mtot, std::nan("")), s2e((size_t)Mtot, 0.0), ye((size_t)Mtot, 0.0);
     std::memcpy(te.data(), t, (size_t)N * sizeof(double));
     std::memcpy(s2e.data(), sigma2, (size_t)N * sizeof(double));
     std::memcpy(te.data() + Mp, tau, (size_t)M * sizeof(double));
+    if (y) std::memcpy(ye.data(), y, (size_t)N * sizeof(double));
     double* dv[9];
-    int rc = dense_stage(ctx, Mtot, J, a, b, c, d, te.data(), nullptr, s2e.data(), dv);
+    int rc = dense_stage(ctx, Mtot, J, a, b, c, d, te.data(), ye.data(), s2e.data(), dv);
     if (rc) return rc;
-    // dense_stage copies asynchronously from te / s2e: they must outlive the copies
+    // dense_stage copies asynchronously from the vectors above: they must outlive the copies
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = ensure(ctx, ctx->bout, (size_t)M * sizeof(double)))) return rc;
     rc = pioran_dense_predict_cov_device(N, M, (int32_t)J, dv[0], dv[1], dv[2], dv[3], dv[4], dv[6], (double*)ctx->bK.p,
-                                         (int32_t*)dv[8], ctx->stream);
-    if (rc) { ctx->last_err = "dense predict_cov launch failed"; return rc; }
+                                         (int32_t*)dv[8], y ? dv[5] : nullptr, y ? (double*)ctx->bout.p : nullptr, ctx->stream);
+    if (rc) { ctx->last_err = "dense prediction launch failed"; return rc; }
     const int64_t ld = Mtot + 64;
     int32_t hinfo = 0;
-    HIPCHK(ctx, hipMemcpy2DAsync(cov_out, (size_t)M * sizeof(double), (const double*)ctx->bK.p + Mp + Mp * ld,
-                                 (size_t)ld * sizeof(double), (size_t)M * sizeof(double), (size_t)M, hipMemcpyDeviceToHost,
-                                 ctx->stream));
+    if (cov_out)
+        HIPCHK(ctx, hipMemcpy2DAsync(cov_out, (size_t)M * sizeof(double), (const double*)ctx->bK.p + Mp + Mp * ld,
+                                     (size_t)ld * sizeof(double), (size_t)M * sizeof(double), (size_t)M, hipMemcpyDeviceToHost,
+                                     ctx->stream));
+    if (mean_out) HIPCHK(ctx, hipMemcpyAsync(mean_out, ctx->bout.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&hinfo, dv[8], sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    // the slab holds the lower triangle (column k, rows i >= k): mirror it
-    for (int64_t k = 0; k < M; ++k)
-        for (int64_t i = k + 1; i < M; ++i) cov_out[i * M + k] = cov_out[k * M + i];
+    if (cov_out) {
+        // the slab holds the lower triangle (column k, rows i >= k): mirror it
+        for (int64_t k = 0; k < M; ++k)
+            for (int64_t i = k + 1; i < M; ++i) cov_out[i * M + k] = cov_out[k * M + i];
+        if (hinfo != 0)
+            for (int64_t e = 0; e < M * M; ++e) cov_out[e] = std::nan("");
+    }
     if (info) *info = hinfo;
-    if (hinfo != 0)
-        for (int64_t e = 0; e < M * M; ++e) cov_out[e] = std::nan("");
     return PIORAN_OK;
+}
+
+int pioran_dense_predict_cov(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
+                             const double* d, const double* t, const double* sigma2, int64_t M, const double* tau,
+                             double* cov_out, int32_t* info)
+{
+    if (!cov_out) return PIORAN_ERR_ARG;
+    return dense_predict_impl(ctx, N, J, a, b, c, d, t, nullptr, sigma2, M, tau, nullptr, cov_out, info);
+}
+
+int pioran_dense_predict(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
+                         const double* d, const double* t, const double* y, const double* sigma2, int64_t M,
+                         const double* tau, double* mean_out, double* cov_out, int32_t* info)
+{
+    if (!y || !mean_out) return PIORAN_ERR_ARG;
+    return dense_predict_impl(ctx, N, J, a, b, c, d, t, y, sigma2, M, tau, mean_out, cov_out, info);
 }
 
 int pioran_dense_covariance(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,

@@ -111,7 +111,7 @@ int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double*
                             int sorted, hipStream_t stream);
 int pioran_dense_predict_cov_device(int64_t N, int64_t M, int32_t J, const double* a, const double* b, const double* c,
                                     const double* d, const double* te, const double* s2e, double* K, int32_t* info,
-                                    hipStream_t stream);
+                                    const double* y, double* mean, hipStream_t stream);
 int pioran_dense_build_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,
                               const double* d, const double* t, const double* y, const double* s2,
                               double* K, int sorted, hipStream_t stream);

@@ -606,6 +606,33 @@ __global__ void __launch_bounds__(256) dense_finish_kernel(const double* __restr
     }
 }
 
+// predict_direct (src/direct_solver.jl:75-119): the data y as row Mtot of the augmented slab (the panel steps turn it into
+// z = L^-1 y, as in the likelihood path), and afterwards mean_m = sum_k X[m][k] z[k] with X = K(tau,t) L^-T left in the
+// tau rows by the same panel steps.
+__global__ void __launch_bounds__(256) dense_set_yrow_kernel(double* __restrict__ A, int64_t ld, int64_t Mtot, int64_t N,
+                                                             const double* __restrict__ y)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < N) A[Mtot + k * ld] = y[k];
+}
+
+__global__ void __launch_bounds__(256) dense_predict_mean_kernel(const double* __restrict__ A, int64_t ld, int64_t Mtot,
+                                                                 int64_t Mp, int64_t M, double* __restrict__ mean,
+                                                                 const int32_t* __restrict__ info)
+{
+    __shared__ double red[256];
+    const int64_t m = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t k = threadIdx.x; k < Mp; k += 256) acc = fma(A[(Mp + m) + k * ld], A[Mtot + k * ld], acc);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (unsigned s_ = 128; s_ > 0; s_ >>= 1) {
+        if (threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && m < M) mean[m] = *info ? (double)NAN : red[0];
+}
+
 }  // namespace
 
 // K must hold ld * Mp + 1024 doubles with Mp = roundup(N, 64), ld = Mp + 64 (slab + inverse workspace).
@@ -654,15 +681,17 @@ int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double*
 // the blocked Cholesky leaves behind when it stops after the data columns.  te / s2e: device, Mtot = Mp + Mq entries,
 // [t (N) | NaN x (Mp - N) | tau (M) | NaN x (Mq - M)] with Mp, Mq = N, M rounded up to 64.  K: slab with
 // ld = Mtot + 64, ld * Mtot + 1024 doubles; afterwards the lower triangle of K[Mp.., Mp..] holds the M x M result.
+// y (device [N]) and mean (device [M]) may be nullptr: covariance only.
 int pioran_dense_predict_cov_device(int64_t N, int64_t M, int32_t J, const double* a, const double* b, const double* c,
                                     const double* d, const double* te, const double* s2e, double* K, int32_t* info,
-                                    hipStream_t stream)
+                                    const double* y, double* mean, hipStream_t stream)
 {
     const int64_t Mp = (N + NB - 1) / NB * NB, Mq = (M + NB - 1) / NB * NB, Mtot = Mp + Mq, ld = Mtot + NB;
     if (hipMemsetAsync(K, 0, (size_t)ld * (size_t)Mtot * sizeof(double), stream) != hipSuccess) return PIORAN_ERR_HIP;
     if (hipMemsetAsync(info, 0, sizeof(int32_t), stream) != hipSuccess) return PIORAN_ERR_HIP;
     const unsigned tiles = (unsigned)(Mtot / 16);
     hipLaunchKernelGGL(dense_build_aug_kernel, dim3(tiles, tiles), dim3(256), 0, stream, Mtot, ld, J, a, b, c, d, te, s2e, K);
+    if (y) hipLaunchKernelGGL(dense_set_yrow_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, K, ld, Mtot, N, y);
     double* ws = K + (size_t)ld * (size_t)Mtot;
     hipLaunchKernelGGL(dense_diag0_kernel, dim3(1), dim3(256), 0, stream, K, ld, ws, info);
     for (int64_t kb = 0; kb < Mp; kb += NB) {
@@ -675,6 +704,8 @@ int pioran_dense_predict_cov_device(int64_t N, int64_t M, int32_t J, const doubl
         hipLaunchKernelGGL(dense_syrk_kernel, dim3((unsigned)(1 + (nt * (nt + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
                            kb, Mtot, ws, info, kb + NB < Mp ? 1 : 0);
     }
+    if (y && mean)
+        hipLaunchKernelGGL(dense_predict_mean_kernel, dim3((unsigned)M), dim3(256), 0, stream, K, ld, Mtot, Mp, M, mean, info);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 

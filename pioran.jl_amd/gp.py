@@ -109,6 +109,18 @@ class Context:
                    self._h)
         return (out, info.value) if return_info else out
 
+    def dense_predict(self, a, b, c, d, tau, t, y, sigma2, with_covariance=False, return_info=False):
+        """predict_direct(cov, tau, t, y, sigma2[, with_covariance])   src/direct_solver.jl:75-119 (dense solver)."""
+        a, b, c, d, tau, t, y, sigma2 = map(_f64, (a, b, c, d, tau, t, y, sigma2))
+        mean_ = np.empty(len(tau))
+        cov_ = np.empty((len(tau), len(tau))) if with_covariance else None
+        info = ctypes.c_int32()
+        _lib.check(_lib.lib().pioran_dense_predict(self._h, len(t), len(a), _ptr(a), _ptr(b), _ptr(c), _ptr(d), _ptr(t), _ptr(y),
+                                                   _ptr(sigma2), len(tau), _ptr(tau), _ptr(mean_), _ptr(cov_),
+                                                   ctypes.byref(info)), self._h)
+        res = (mean_, cov_) if with_covariance else mean_
+        return (res, info.value) if return_info else res
+
     def dense_covariance(self, a, b, c, d, t, sigma2):
         a, b, c, d, t, sigma2 = map(_f64, (a, b, c, d, t, sigma2))
         K = np.empty((len(t), len(t)), dtype=np.float64)
@@ -423,6 +435,15 @@ def predict_cov(cov_fn: SemiSeparable, tau, t, sigma2, ctx: Context | None = Non
     if info != 0:
         raise np.linalg.LinAlgError(f"matrix is not positive definite; Cholesky factorization failed at pivot {info}")
     return K
+
+
+def predict_direct(cov_fn: SemiSeparable, tau, t, y, sigma2, with_covariance=False, ctx: Context | None = None):
+    """predict_direct(cov, tau, t, y, sigma2[, with_covariance])   src/direct_solver.jl:75-119."""
+    a, b, c, d = (np.real(np.atleast_1d(v)) for v in cov_fn.celerite_coefs())
+    res, info = (ctx or default_context()).dense_predict(a, b, c, d, tau, t, y, sigma2, with_covariance, return_info=True)
+    if info != 0:
+        raise np.linalg.LinAlgError(f"matrix is not positive definite; Cholesky factorization failed at pivot {info}")
+    return res
 
 
 def cov(fp: PosteriorGP, tau=None, ctx: Context | None = None):

@@ -296,4 +296,20 @@ function predict_cov_hip(cov::SemiSeparable, τ::Vector{Float64}, t::Vector{Floa
     return out
 end
 
+# predict_direct (src/direct_solver.jl:75-119): dense posterior mean (and covariance) — the reference's ground truth for `predict`
+function predict_direct_hip(cov::SemiSeparable, τ::Vector{Float64}, t::Vector{Float64}, y::Vector{Float64}, σ²::Vector{Float64},
+                            with_covariance::Bool = false; ctx = default_context())
+    a, b, c, d = map(v -> collect(Float64, real.(v)), celerite_coefs(cov))
+    M = length(τ)
+    μ = Vector{Float64}(undef, M)
+    K = with_covariance ? Matrix{Float64}(undef, M, M) : nothing
+    info = Ref{Int32}(0)
+    GC.@preserve a b c d τ t y σ² μ K check(ccall((:pioran_dense_predict, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+         Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Int32}), ctx.h, length(t), length(a), a, b, c, d, t, y, σ², M, τ, μ,
+        K === nothing ? Ptr{Cdouble}(C_NULL) : pointer(K), info))
+    info[] != 0 && throw(LinearAlgebra.PosDefException(info[]))
+    return with_covariance ? (μ, K) : μ
+end
+
 end # module

@@ -872,3 +872,20 @@ def test_carma_kernel_on_the_likelihood_path(ctx, golden_dir):
     assert abs(v - O.logl(a, b, c, d, t, y, yerr ** 2)) <= 1e-10 * abs(v)
     assert abs(v + pj.log_likelihood_direct(k, t, y, yerr ** 2, ctx=ctx)) <= 1e-9 * abs(v)
     assert abs(pj.logpdf(pj.ScalableGP(0.3, k)(t, yerr ** 2), y, ctx=ctx) - O.logl(a, b, c, d, t, y - 0.3, yerr ** 2)) <= 1e-10 * abs(v)
+
+
+def test_dense_predict_direct(ctx, golden_dir):
+    """predict_direct (src/direct_solver.jl:75-119) on the device's dense solver: equal to the numpy restatement and — the
+    relation the reference's prediction tests assert (test/test_prediction.jl:49-58) — to the celerite `predict`."""
+    A = np.loadtxt(golden_dir / "simu.txt")
+    t, y, yerr = A[:, 0], A[:, 1], A[:, 2]
+    f0, fM = 1 / (t[-1] - t[0]) / 100, 1 / np.min(np.diff(t)) / 2 * 20
+    R = pj.approx(pj.SingleBendingPowerLaw(0.82, 0.01, 3.3), f0, fM, 20, np.var(y, ddof=1))
+    for tau in (t, np.linspace(t.min() - 30, t.max() + 30, 333)):
+        m, K = pj.predict_direct(R, tau, t, y, yerr ** 2, with_covariance=True, ctx=ctx)
+        ref = O.predict_direct_numpy(R.a, R.b, R.c, R.d, tau, t, y, yerr ** 2)
+        assert np.max(np.abs(m - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
+        assert np.max(np.abs(m - pj.predict(R, tau, t, y, yerr ** 2, ctx=ctx))) <= 1e-8 * max(1.0, np.max(np.abs(ref)))
+        Kref = O.predict_cov_numpy(R.a, R.b, R.c, R.d, tau, t, yerr ** 2)
+        assert np.max(np.abs(K - Kref)) <= 1e-9 * np.max(np.abs(Kref))
+        assert np.array_equal(pj.predict_direct(R, tau, t, y, yerr ** 2, ctx=ctx), m)
