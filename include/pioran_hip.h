@@ -47,7 +47,7 @@ typedef struct pioran_ds pioran_ds;   /* a time series resident in HBM + its cac
 const char* pioran_strerror(int code);
 const char* pioran_last_hip_error(const pioran_ctx* ctx);
 /* ABI version of this header (bumped on any signature change). */
-int pioran_abi_version(void);   /* currently 3 */
+int pioran_abi_version(void);   /* currently 4 */
 
 /* ---- context ------------------------------------------------------------------------------- */
 /* Creates a context on GPU `device` with its own non-blocking stream. */

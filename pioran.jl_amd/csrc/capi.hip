@@ -174,7 +174,7 @@ const char* pioran_strerror(int code)
 
 const char* pioran_last_hip_error(const pioran_ctx* ctx) { return ctx ? ctx->last_err.c_str() : ""; }
 
-int pioran_abi_version(void) { return 3; }
+int pioran_abi_version(void) { return 4; }
 
 static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
 {
