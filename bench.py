@@ -74,8 +74,8 @@ def algorithmic_flops(N: int, R: int) -> float:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="draws per GPU")
     ap.add_argument("--n", type=int, default=10_000)
     ap.add_argument("--components", type=int, default=20)
