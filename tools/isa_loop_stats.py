@@ -4,8 +4,8 @@ usage: hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o scan.
 import re, sys
 from collections import Counter
 s = open(sys.argv[1]).read()
-flt = sys.argv[2] if len(sys.argv) > 2 else "Lb1E"
-for m in re.finditer(r'^(_ZN12_GLOBAL__N_120celerite_scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E(?:Lb(\d)E)?EEv10ScanParams):', s, re.M):
+flt = sys.argv[2] if len(sys.argv) > 2 else "Lb1ELb1E"   # substring of the mangled name, e.g. Li3ELi2ELi7ELb1ELb1ELi1ELb1E
+for m in re.finditer(r'^(_ZN12_GLOBAL__N_120celerite_scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)E\w*EEv10ScanParams):', s, re.M):
     name = m.group(1)
     if flt not in name: continue
     i = m.start(); j = s.index('.Lfunc_end', i)
