@@ -889,3 +889,20 @@ def test_dense_predict_direct(ctx, golden_dir):
         Kref = O.predict_cov_numpy(R.a, R.b, R.c, R.d, tau, t, yerr ** 2)
         assert np.max(np.abs(K - Kref)) <= 1e-9 * np.max(np.abs(Kref))
         assert np.array_equal(pj.predict_direct(R, tau, t, y, yerr ** 2, ctx=ctx), m)
+
+
+def test_reference_sample_tests(ctx):
+    """test/test_scalablegp.jl:179-237: rand of the posterior (shapes, finiteness) and of the prior GP, same literals."""
+    t = np.array([0.0, 3.0, 3.2, 3.4, 45.5, 101.2])
+    tx = np.array([0.0, 1.4, 2.3, 3.0, 3.1, 3.2, 3.3, 3.4, 45.5, 101.2, 202.32])
+    y = np.array([1.3, 2.2, 4.21, 2.5, 3.3, 5.2]); yerr = np.array([0.1, 0.2, 0.1, 0.1, 0.2, 0.1])
+    R = pj.approx(pj.SingleBendingPowerLaw(0.2, 0.02, 3.1), 1e-4, 1e1, 30, 2.31, basis_function="SHO")
+    fx = pj.ScalableGP(1.2, R)(t, yerr ** 2)
+    fp = pj.posterior(fx, y)
+    rng = np.random.default_rng(1234)
+    s, s10 = pj.rand_posterior(rng, fp, ctx=ctx), pj.rand_posterior(rng, fp, None, 10, ctx=ctx)
+    sx, sx10 = pj.rand_posterior(rng, fp, tx, ctx=ctx), pj.rand_posterior(rng, fp, tx, 10, ctx=ctx)
+    assert np.isfinite(s).all() and np.isfinite(s10).all()
+    assert s10.shape == (len(t), 10) and sx.shape == (len(tx), 1) and sx10.shape == (len(tx), 10)
+    assert np.isfinite(pj.rand(rng, fx, ctx=ctx)).all() and np.isfinite(pj.rand(rng, fx, tx, ctx=ctx)).all()
+    assert len(pj.rand(rng, fx, tx, ctx=ctx)) == len(tx)
