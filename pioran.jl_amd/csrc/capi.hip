@@ -133,14 +133,17 @@ int scan_dispatch(const ScanParams& p, hipStream_t stream)
     const bool force_wide = cfg && !std::strcmp(cfg, "wide");
     // (below 16 rows the per-step exchange of the latency layout costs more than the whole step of a throughput layout)
     const bool auto_wide = !cfg && p.B <= pioran_wide_max_batch() && p.R >= 16 && !std::getenv("PIORAN_NO_WIDE");
-    if (p.tab && p.R <= pioran_wide_supported_rows() && (force_wide || auto_wide)) return pioran_launch_scan_wide(p, stream);
+    // 80..95 rows: the throughput layouts do not hold S in registers any more, the latency layout still does
+    const bool only_wide = p.R > pioran_scan_supported_rows() && !std::getenv("PIORAN_NO_WIDE");
+    if (p.tab && p.R <= pioran_wide_supported_rows() && (force_wide || auto_wide || only_wide)) return pioran_launch_scan_wide(p, stream);
+    if (p.R > pioran_scan_supported_rows()) return PIORAN_ERR_UNSUPPORTED;
     return pioran_launch_scan(p, stream);
 }
 
 int launch(pioran_ds* ds, ScanParams& p)
 {
     pioran_ctx* ctx = ds->ctx;
-    if (p.R <= pioran_scan_supported_rows() && !std::getenv("PIORAN_FORCE_FALLBACK")) {
+    if (p.R <= pioran_wide_supported_rows() && !std::getenv("PIORAN_FORCE_FALLBACK")) {
         int rc = scan_dispatch(p, ctx->stream);
         if (rc != PIORAN_ERR_UNSUPPORTED) {
             if (rc == PIORAN_ERR_HIP) ctx->last_err = "scan kernel launch failed";
@@ -676,7 +679,7 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
-    if (ds->R > 79 || ds->npd_terms) return PIORAN_ERR_UNSUPPORTED;
+    if (ds->R > pioran_wide_supported_rows() || ds->npd_terms) return PIORAN_ERR_UNSUPPORTED;
     const int64_t chunk = B < 256 ? B : 256;
     if ((rc = ensure(ctx, ctx->bwork, pioran_predict_workspace_doubles(chunk, ds->N, ds->R) * sizeof(double)))) return rc;
     if ((rc = upload(ctx, ctx->bshift, tau, (size_t)M * sizeof(double)))) return rc;          // tau
@@ -774,7 +777,7 @@ int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, c
     if (rc) return rc;
     auto done = [&](int code) { pioran_dataset_destroy(ds); return code; };
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return done(rc);
-    if (ds->R > 79 || ds->npd_terms) return done(PIORAN_ERR_UNSUPPORTED);
+    if (ds->R > pioran_wide_supported_rows() || ds->npd_terms) return done(PIORAN_ERR_UNSUPPORTED);
     const int64_t chunk = B < 256 ? B : 256;
     const size_t cn = (size_t)chunk * (size_t)N * sizeof(double);
     if ((rc = ensure(ctx, ctx->bY, cn))) return done(rc);     // noise

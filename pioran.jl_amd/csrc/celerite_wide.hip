@@ -9,7 +9,7 @@
 // draws in flight to hide every latency.  With a handful of draws (the scalar `logl` drop-in, MCMC walkers) a time
 // step is one long dependent chain on a single wavefront.  Here a draw gets 256 lanes arranged as 16 x 16:
 //   DPP row g (16 of them over 4 waves) = ROW block g of S;  lane l inside the row = COLUMN block l;
-//   RPL x RPL entries of S per lane (RPL <= 5: up to 79 rows + the y row).
+//   RPL x RPL entries of S per lane (RPL <= 6: up to 95 rows + the y row; the throughput layouts stop at 79).
 // Consequences:
 //   * q = S u is a sum over the 16 lanes of a DPP row: four DPP butterfly stages, no LDS, no ds_bpermute;
 //   * u and phi of the lane's column block are table data: the lane loads them itself (no broadcast);
@@ -678,7 +678,7 @@ __global__ void __launch_bounds__(256) grad_finish_kernel(const ScanParams p, in
 
 }  // namespace
 
-int pioran_wide_supported_rows() { return 79; }
+int pioran_wide_supported_rows() { return 95; }
 
 // Batches up to this size take the latency layout (at most one workgroup per CU on the chip's 256 CUs).
 int64_t pioran_wide_max_batch() { return 256; }
@@ -686,14 +686,18 @@ int64_t pioran_wide_max_batch() { return 256; }
 template <int MODE>
 static int launch_wide_mode(const ScanParams& p, hipStream_t stream)
 {
-    if (!p.tab || p.R > 79 || p.B <= 0 || p.B > 0x7fffffffLL) return PIORAN_ERR_UNSUPPORTED;
+    if (!p.tab || p.R > 95 || p.B <= 0 || p.B > 0x7fffffffLL) return PIORAN_ERR_UNSUPPORTED;
     if (3 * (p.R + 2) + 2 + 3 * p.npd_rows > kWideMaxRecord) return PIORAN_ERR_UNSUPPORTED;   // staged record too long
     const dim3 grid((unsigned)p.B), block(256);
     if (p.R <= 15) hipLaunchKernelGGL((celerite_wide_kernel<1, MODE>), grid, block, 0, stream, p);
     else if (p.R <= 31) hipLaunchKernelGGL((celerite_wide_kernel<2, MODE>), grid, block, 0, stream, p);
     else if (p.R <= 47) hipLaunchKernelGGL((celerite_wide_kernel<3, MODE>), grid, block, 0, stream, p);
     else if (p.R <= 63) hipLaunchKernelGGL((celerite_wide_kernel<4, MODE>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((celerite_wide_kernel<5, MODE>), grid, block, 0, stream, p);
+    else if (p.R <= 79) hipLaunchKernelGGL((celerite_wide_kernel<5, MODE>), grid, block, 0, stream, p);
+    else {
+        if constexpr (MODE == 3) return PIORAN_ERR_UNSUPPORTED;   // (the adjoint pass stops at 79 rows)
+        else hipLaunchKernelGGL((celerite_wide_kernel<6, MODE>), grid, block, 0, stream, p);
+    }
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 

@@ -136,9 +136,30 @@ def test_random_batches_per_draw_cd(ctx, J, layout):
     assert relerr(got, ref) < 1e-11
 
 
-@pytest.mark.parametrize("J", [44, 64])
+@pytest.mark.parametrize("J,B", [(40, 5), (44, 5), (47, 300), (40, 300)])
+def test_rows_80_to_95_stay_register_resident(ctx, J, B):
+    """R = 80 .. 95 rows (SHO-40, the dense configuration's model, is R = 80): past the throughput layouts' 79 rows the
+    latency layout still holds S in registers, for any batch size; same values as the oracle and as the HBM fallback."""
+    rng = np.random.default_rng(350 + J)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 90, J, B)
+    ds = pj.Dataset(t, y, s2, ctx)
+    got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+    assert relerr(got, ref) < 1e-11
+    try:
+        os.environ["PIORAN_FORCE_FALLBACK"] = "1"
+        fb = ds.logl_batch(A[:7], Bc[:7], C, Dd, mu=mu[:7], nu=nu[:7])
+    finally:
+        os.environ.pop("PIORAN_FORCE_FALLBACK", None)
+    assert relerr(fb, ref[:7]) < 1e-11
+    tau = np.linspace(t[0] - 1, t[-1] + 1, 33)
+    pm = ds.predict(A[:2], Bc[:2], C, Dd, tau, mu=mu[:2], nu=nu[:2])
+    np.testing.assert_allclose(pm[0], O.predict(A[0], Bc[0], C, Dd, tau, t, y - mu[0], nu[0] * s2) + mu[0], rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("J", [48, 64])
 def test_fallback_any_rank(ctx, J):
-    """R > 80 rows (the reference benchmark's j = 64, benchmark/benchmarks.jl:17) runs on the HBM-resident fallback."""
+    """R > 95 rows (the reference benchmark's j = 64, benchmark/benchmarks.jl:17) runs on the HBM-resident fallback."""
     rng = np.random.default_rng(300 + J)
     N, B = 60, 5
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
