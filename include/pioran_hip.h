@@ -149,6 +149,13 @@ int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double*
                               const double* Dd, const double* mu, const double* nu, double* out, int32_t* status,
                               double* grad_a, double* grad_b, double* grad_nu, double* grad_mu, double* grad_y,
                               double* grad_sigma2);
+/* The same for the shifted log-flux models (docs/src/turing.md:205-230: c ~ LogUniform(...), y = log.(y .- c),
+ * sigma2 = nu sigma.^2 ./ (y .- c).^2): the data set holds the raw flux and yerr^2, the transform runs on the device as in
+ * pioran_celerite_logl_batch_shift, and grad_shift [B] = dlogL/dc_b comes out of the series gradients by the chain rule. */
+int pioran_celerite_logl_grad_shift(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                                    const double* Dd, const double* mu, const double* nu, const double* shift, double* out,
+                                    int32_t* status, double* grad_a, double* grad_b, double* grad_nu, double* grad_mu,
+                                    double* grad_shift);
 /* simulate (src/celerite_solver.jl:497-513 -> sim :515-549; rand(f(t, sigma2)) of src/scalable_GP.jl:137-146):
  * realisations y_b = L_b D_b^(1/2) q_b of the GP with kernel (a_b, b_b, c, d) + diag(sigma2) at the times t, from
  * caller-supplied standard-normal draws q [B][N] (the reference draws them with its rng, :528).  y_out [B][N]. */

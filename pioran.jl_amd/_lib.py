@@ -46,6 +46,7 @@ SIGNATURES = {
     "pioran_celerite_predict": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, i64, c_void_p, c_void_p, c_void_p]),
     "pioran_celerite_logl_grad": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 14),
+    "pioran_celerite_logl_grad_shift": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 14),
     "pioran_celerite_simulate": (ctypes.c_int, [c_void_p, i64, i64, i64] + [c_void_p] * 8),
     "pioran_celerite_config_name": (ctypes.c_char_p, [i64]),
     "pioran_farm_create": (ctypes.c_int, [ctypes.c_int, c_void_p, i64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),

@@ -710,12 +710,15 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
     return PIORAN_OK;
 }
 
-int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
-                              const double* Dd, const double* mu, const double* nu, double* out, int32_t* status,
-                              double* grad_a, double* grad_b, double* grad_nu, double* grad_mu, double* grad_y,
-                              double* grad_sigma2)
+// shift / grad_shift != nullptr: the shifted log-flux models (the data set holds raw flux and yerr^2); grad_y / grad_sigma2
+// then refer to the TRANSFORMED series of each draw
+static int logl_grad_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                          const double* Dd, const double* mu, const double* nu, const double* shift, double* out,
+                          int32_t* status, double* grad_a, double* grad_b, double* grad_nu, double* grad_mu, double* grad_y,
+                          double* grad_sigma2, double* grad_shift)
 {
     if (!ds || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !out || !grad_a || !grad_b) return PIORAN_ERR_ARG;
+    if ((shift == nullptr) != (grad_shift == nullptr)) return PIORAN_ERR_ARG;
     pioran_ctx* ctx = ds->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
@@ -728,8 +731,11 @@ int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double*
     const size_t cj = (size_t)chunk * (size_t)J * sizeof(double), cn = (size_t)chunk * (size_t)ds->N * sizeof(double);
     if ((rc = ensure(ctx, ctx->bC, 2 * cj))) return rc;              // grad_a | grad_b
     if ((rc = ensure(ctx, ctx->bD, 2 * chunk * sizeof(double)))) return rc;   // grad_nu | grad_mu
-    if (grad_y && (rc = ensure(ctx, ctx->bY, cn))) return rc;
-    if (grad_sigma2 && (rc = ensure(ctx, ctx->bS2, cn))) return rc;
+    const bool want_series = grad_y || grad_sigma2 || shift;   // the shift's chain rule needs both series gradients
+    if (want_series && (rc = ensure(ctx, ctx->bY, cn))) return rc;
+    if (want_series && (rc = ensure(ctx, ctx->bS2, cn))) return rc;
+    if (shift && (rc = ensure(ctx, ctx->bscratch, 2 * cn))) return rc;           // transformed Y | S2 of the chunk
+    if (shift && (rc = ensure(ctx, ctx->bshift, 2 * chunk * sizeof(double)))) return rc;   // shift | grad_shift
     if ((rc = ensure(ctx, ctx->bout, chunk * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t)))) return rc;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
@@ -746,12 +752,24 @@ int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double*
         p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
         p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
         p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
-        p.g_y = grad_y ? (double*)ctx->bY.p : nullptr;
-        p.g_s2 = grad_sigma2 ? (double*)ctx->bS2.p : nullptr;
+        p.g_y = want_series ? (double*)ctx->bY.p : nullptr;
+        p.g_s2 = want_series ? (double*)ctx->bS2.p : nullptr;
+        double* dshift = (double*)ctx->bshift.p;
+        if (shift) {
+            HIPCHK(ctx, hipMemcpyAsync(dshift, shift + b0, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            double* dYt = (double*)ctx->bscratch.p; double* dSt = dYt + (size_t)chunk * (size_t)ds->N;
+            if ((rc = pioran_launch_shift_transform(ds->N, nb, ds->y, ds->s2, dshift, dYt, dSt, ctx->stream))) return rc;
+            p.Y = dYt; p.S2 = dSt;
+        }
         double* dga = (double*)ctx->bC.p; double* dgb = dga + (size_t)chunk * J;
         double* dgn = (double*)ctx->bD.p; double* dgm = dgn + chunk;
         rc = pioran_launch_scan_wide_grad(p, (double*)ctx->bwork.p, dga, dgb, dgn, dgm, ctx->stream);
         if (rc) { ctx->last_err = "gradient launch failed"; return rc; }
+        if (shift) {
+            rc = pioran_launch_shift_grad(ds->N, nb, ds->y, ds->s2, dshift, p.g_y, p.g_s2, dshift + chunk, ctx->stream);
+            if (rc) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(grad_shift + b0, dshift + chunk, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        }
         HIPCHK(ctx, hipMemcpyAsync(out + b0, ctx->bout.p, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (status) HIPCHK(ctx, hipMemcpyAsync(status + b0, ctx->bst.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(grad_a + b0 * J, dga, (size_t)nb * J * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -763,6 +781,25 @@ int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double*
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return PIORAN_OK;
+}
+
+int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                              const double* Dd, const double* mu, const double* nu, double* out, int32_t* status,
+                              double* grad_a, double* grad_b, double* grad_nu, double* grad_mu, double* grad_y,
+                              double* grad_sigma2)
+{
+    return logl_grad_impl(ds, B, J, A, Bc, C, Dd, mu, nu, nullptr, out, status, grad_a, grad_b, grad_nu, grad_mu, grad_y,
+                          grad_sigma2, nullptr);
+}
+
+int pioran_celerite_logl_grad_shift(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                                    const double* Dd, const double* mu, const double* nu, const double* shift, double* out,
+                                    int32_t* status, double* grad_a, double* grad_b, double* grad_nu, double* grad_mu,
+                                    double* grad_shift)
+{
+    if (!shift || !grad_shift) return PIORAN_ERR_ARG;
+    return logl_grad_impl(ds, B, J, A, Bc, C, Dd, mu, nu, shift, out, status, grad_a, grad_b, grad_nu, grad_mu, nullptr, nullptr,
+                          grad_shift);
 }
 
 int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc,

@@ -93,6 +93,8 @@ int pioran_launch_pd_table(int64_t N, int64_t B, int32_t J, int32_t npd_terms, c
                            int64_t rs_shared, hipStream_t stream);
 int pioran_launch_shift_transform(int64_t N, int64_t B, const double* y, const double* s2, const double* shift,
                                   double* Y, double* S2, hipStream_t stream);
+int pioran_launch_shift_grad(int64_t N, int64_t B, const double* y, const double* s2, const double* shift, const double* gY,
+                             const double* gS, double* gshift, hipStream_t stream);
 // approx.hip
 #ifdef __cplusplus
 #include <vector>

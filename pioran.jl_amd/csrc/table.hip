@@ -81,7 +81,37 @@ __global__ void __launch_bounds__(256) shift_transform_kernel(int64_t N, int64_t
     Y[b * N + n] = log(v);
     S2[b * N + n] = s2[n] / (v * v);
 }
+// Chain rule of the transform above: with g_Y = dL/dY_n and g_S = dL/dS2_n of draw b,
+//   dL/dshift_b = sum_n ( -g_Y / (y_n - shift_b) + 2 g_S sigma2_n / (y_n - shift_b)^3 ).    One workgroup per draw.
+__global__ void __launch_bounds__(256) shift_grad_kernel(int64_t N, const double* __restrict__ y, const double* __restrict__ s2,
+                                                         const double* __restrict__ shift, const double* __restrict__ gY,
+                                                         const double* __restrict__ gS, double* __restrict__ gshift)
+{
+    __shared__ double red[256];
+    const int64_t b = blockIdx.x;
+    const double c = shift[b];
+    double acc = 0.0;
+    for (int64_t n = threadIdx.x; n < N; n += 256) {
+        const double v = y[n] - c, rv = 1.0 / v;
+        acc += -gY[b * N + n] * rv + 2.0 * gS[b * N + n] * s2[n] * rv * rv * rv;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (unsigned s_ = 128; s_ > 0; s_ >>= 1) {
+        if (threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gshift[b] = red[0];
+}
 }  // namespace
+
+int pioran_launch_shift_grad(int64_t N, int64_t B, const double* y, const double* s2, const double* shift, const double* gY,
+                             const double* gS, double* gshift, hipStream_t stream)
+{
+    if (B < 1 || B > 0x7fffffffLL) return PIORAN_ERR_ARG;
+    hipLaunchKernelGGL(shift_grad_kernel, dim3((unsigned)B), dim3(256), 0, stream, N, y, s2, shift, gY, gS, gshift);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
 
 int pioran_launch_pd_table(int64_t N, int64_t B, int32_t J, int32_t npd_terms, const int32_t* pd_terms, const double* t,
                            const double* C, const double* D, double* tab, int64_t rec_stride, int64_t rs_shared,

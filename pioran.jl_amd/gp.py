@@ -223,9 +223,12 @@ class Dataset:
                                                       _ptr(nu), len(tau), _ptr(tau), _ptr(out), _ptr(st)), self.ctx._h)
         return (out, st) if return_status else out
 
-    def logl_grad(self, A, Bc, C, Dd, mu=None, nu=None, series_grad=False):
+    def logl_grad(self, A, Bc, C, Dd, mu=None, nu=None, series_grad=False, shift=None):
         """log L and its gradient for B draws sharing (C, Dd): returns a dict with logl (B,), status, grad_a, grad_b (B, J),
-        grad_mu, grad_nu (B,) (None where mu / nu were not given) and, with series_grad, grad_y, grad_sigma2 (B, N)."""
+        grad_mu, grad_nu (B,) (None where mu / nu were not given) and, with series_grad, grad_y, grad_sigma2 (B, N).
+        shift (B,): the shifted log-flux models (the data set holds raw flux and yerr**2); adds grad_shift (B,)."""
+        if shift is not None:
+            return self._logl_grad_shift(A, Bc, C, Dd, mu, nu, shift)
         A, Bc, C, Dd = map(_f64, (A, Bc, C, Dd))
         if A.ndim != 2 or A.shape != Bc.shape or C.shape != (A.shape[1],) or Dd.shape != C.shape:
             raise ValueError("A, Bc must be (B, J) and C, Dd (J,)")
@@ -243,8 +246,25 @@ class Dataset:
         return {"logl": out, "status": st, "grad_a": ga, "grad_b": gb, "grad_nu": gnu, "grad_mu": gmu,
                 "grad_y": gy, "grad_sigma2": gs}
 
+    def _logl_grad_shift(self, A, Bc, C, Dd, mu, nu, shift):
+        A, Bc, C, Dd = map(_f64, (A, Bc, C, Dd))
+        if A.ndim != 2 or A.shape != Bc.shape or C.shape != (A.shape[1],) or Dd.shape != C.shape:
+            raise ValueError("A, Bc must be (B, J) and C, Dd (J,)")
+        B, J = A.shape
+        mu_ = None if mu is None else _f64(np.broadcast_to(mu, (B,)))
+        nu_ = None if nu is None else _f64(np.broadcast_to(nu, (B,)))
+        shift = _f64(np.broadcast_to(shift, (B,)))
+        out = np.empty(B); st = np.zeros(B, dtype=np.int32)
+        ga, gb = np.empty((B, J)), np.empty((B, J))
+        gnu, gmu, gsh = np.empty(B), np.empty(B), np.empty(B)
+        _lib.check(_lib.lib().pioran_celerite_logl_grad_shift(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), _ptr(mu_),
+                                                              _ptr(nu_), _ptr(shift), _ptr(out), _ptr(st), _ptr(ga), _ptr(gb),
+                                                              _ptr(gnu), _ptr(gmu), _ptr(gsh)), self.ctx._h)
+        return {"logl": out, "status": st, "grad_a": ga, "grad_b": gb, "grad_nu": gnu, "grad_mu": gmu, "grad_shift": gsh,
+                "grad_y": None, "grad_sigma2": None}
+
     def logpdf_theta_grad(self, model, theta, norm, f_min, f_max, n_components=20, S_low=20.0, S_high=20.0, *,
-                          is_integrated_power=True, basis_function="SHO", mu=None, nu=None):
+                          is_integrated_power=True, basis_function="SHO", mu=None, nu=None, shift=None):
         """log L and its gradient with respect to the SAMPLED parameters of the reference's models
         (README.md:38-71: theta = PSD parameters, norm = variance, nu, mu): the device gradient w.r.t. (a, b, nu, mu)
         chained through `approx` on the host (approx_batch_vjp).  Returns a dict: logl, status, grad_theta (B, P),
@@ -253,11 +273,12 @@ class Dataset:
         theta = np.atleast_2d(_f64(theta))
         A, Bc, C, Dd = approx_batch(model, theta, f_min, f_max, n_components, norm, S_low, S_high,
                                     is_integrated_power=is_integrated_power, basis_function=basis_function)
-        g = self.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+        g = self.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, shift=shift)
         gth, gnorm = approx_batch_vjp(model, theta, f_min, f_max, n_components, norm, g["grad_a"], g["grad_b"], S_low, S_high,
                                       is_integrated_power=is_integrated_power, basis_function=basis_function)
         return {"logl": g["logl"], "status": g["status"], "grad_theta": gth, "grad_norm": gnorm,
-                "grad_nu": g["grad_nu"] if nu is not None else None, "grad_mu": g["grad_mu"] if mu is not None else None}
+                "grad_nu": g["grad_nu"] if nu is not None else None, "grad_mu": g["grad_mu"] if mu is not None else None,
+                "grad_shift": g.get("grad_shift")}
 
     def logl_batch_dev(self, B, dA, dBc, dmu=0, dnu=0, dY=0, dS2=0, dout=0, dstatus=0):
         """Device-pointer (int addresses) asynchronous variant; (c, d) from prepare()."""

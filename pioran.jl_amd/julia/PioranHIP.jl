@@ -270,6 +270,29 @@ function logpdf_grad_batch(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, 
     return (logl = out, status = status, grad_a = ga, grad_b = gb, grad_ν = gν, grad_μ = gμ, grad_y = gy, grad_σ² = gs)
 end
 
+"""
+    logpdf_grad_batch_shift(ds, A, B, c, d, shift; μ, ν)
+
+Value and gradient for the shifted log-flux models (docs/src/turing.md:205-230): `ds` holds the raw flux and `yerr.^2`;
+returns in addition `grad_shift` = ∂log L/∂c per draw.
+"""
+function logpdf_grad_batch_shift(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::Vector{Float64}, d::Vector{Float64},
+                                 shift::Vector{Float64}; μ::Union{Nothing, Vector{Float64}} = nothing,
+                                 ν::Union{Nothing, Vector{Float64}} = nothing)
+    J, nb = size(A)
+    out = Vector{Float64}(undef, nb); status = zeros(Int32, nb)
+    ga = Matrix{Float64}(undef, J, nb); gb = Matrix{Float64}(undef, J, nb)
+    gν = Vector{Float64}(undef, nb); gμ = Vector{Float64}(undef, nb); gs = Vector{Float64}(undef, nb)
+    p(x) = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
+    GC.@preserve A B c d μ ν shift out status ga gb gν gμ gs begin
+        check(ccall((:pioran_celerite_logl_grad_shift, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                     Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                    ds.h, nb, J, A, B, c, d, p(μ), p(ν), shift, out, status, ga, gb, gν, gμ, gs))
+    end
+    return (logl = out, status = status, grad_a = ga, grad_b = gb, grad_ν = gν, grad_μ = gμ, grad_shift = gs)
+end
+
 # ---- dense solver: log_likelihood_direct (src/direct_solver.jl:6-21), returns +NLL -------------------------
 function log_likelihood_direct_hip(cov::SemiSeparable, t::Vector{Float64}, y::Vector{Float64}, σ²::Vector{Float64};
                                    ctx = default_context())

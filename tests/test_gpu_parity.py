@@ -927,3 +927,30 @@ def test_reference_sample_tests(ctx):
     assert s10.shape == (len(t), 10) and sx.shape == (len(tx), 1) and sx10.shape == (len(tx), 10)
     assert np.isfinite(pj.rand(rng, fx, ctx=ctx)).all() and np.isfinite(pj.rand(rng, fx, tx, ctx=ctx)).all()
     assert len(pj.rand(rng, fx, tx, ctx=ctx)) == len(tx)
+
+
+def test_gradient_shifted_log_flux_model(ctx, golden_dir):
+    """The documented Turing model with a sampled shift (docs/src/turing.md:205-230): d log L / dc through the device
+    transform, against the complex step of the oracle along the induced direction in (y, sigma2) space; the other
+    gradients equal those of a data set that holds the transformed series."""
+    un = np.load(golden_dir / "ultranest_points.npz")
+    t, y, yerr = un["t"], un["y"], un["yerr"]
+    P = un["params"][:5]
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, P[:, :3], f_min, f_max, 20, P[:, 3], is_integrated_power=False)
+    nu, mu, cs = P[:, 4].copy(), P[:, 5].copy(), P[:, 6].copy()
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, shift=cs)
+    assert relerr(g["logl"], ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, shift=cs)) < 1e-12
+    assert relerr(g["logl"], un["logl"][:5]) < 1e-9          # the reference's own values for these points
+    for i in range(5):
+        v = y - cs[i]
+        Yt, St = np.log(v), yerr ** 2 / v ** 2
+        ref = O.logl_dir(A[i], Bc[i], C, Dd, t, Yt - mu[i], nu[i] * St, dy=-1 / v, ds2=nu[i] * 2 * yerr ** 2 / v ** 3)
+        assert abs(g["grad_shift"][i] - ref) <= 1e-8 * (1 + abs(ref)), (g["grad_shift"][i], ref)
+        gi = pj.Dataset(t, Yt, St, ctx).logl_grad(A[i:i + 1], Bc[i:i + 1], C, Dd, mu=mu[i:i + 1], nu=nu[i:i + 1])
+        for k in ("grad_a", "grad_b", "grad_mu", "grad_nu"):
+            assert np.max(np.abs(g[k][i] - gi[k][0])) <= 1e-9 * (1 + np.max(np.abs(gi[k][0]))), k
+    # y - c <= 0: status 2, as in the value-only entry
+    bad = ds.logl_grad(A[:1], Bc[:1], C, Dd, mu=mu[:1], nu=nu[:1], shift=[y.min() + 1.0])
+    assert bad["status"][0] == 2 and np.isnan(bad["logl"][0])
