@@ -126,14 +126,25 @@ def main():
     A, Bc, mu, nu = (np.ascontiguousarray(v, dtype=np.float64) for v in (A, Bc, mu, nu))
     dA = torch.from_numpy(A).to(dev).contiguous(); dB = torch.from_numpy(Bc).to(dev).contiguous()
     dmu = torch.from_numpy(mu).to(dev).contiguous(); dnu = torch.from_numpy(nu).to(dev).contiguous()
-    dout = torch.empty(B, dtype=torch.float64, device=dev)
+    # two output buffers: the all-gather of batch k (RCCL, on its own stream) overlaps the scan of batch k + 1
+    douts = [torch.empty(B, dtype=torch.float64, device=dev) for _ in range(2)]
+    gathered_bufs = [torch.empty(B * world, dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
+    works = [None, None]
+    dout = douts[0]
     dst = torch.zeros(B, dtype=torch.int32, device=dev)
+    counter = [0]
 
     def step():
-        ds.logl_batch_dev(B, dA.data_ptr(), dB.data_ptr(), dmu.data_ptr(), dnu.data_ptr(), 0, 0, dout.data_ptr(),
+        k = counter[0] & 1
+        counter[0] += 1
+        if works[k] is not None:
+            works[k].wait()      # buffer k is about to be rewritten: its gather (two batches ago) must be done
+        ds.logl_batch_dev(B, dA.data_ptr(), dB.data_ptr(), dmu.data_ptr(), dnu.data_ptr(), 0, 0, douts[k].data_ptr(),
                           dst.data_ptr())
         if use_dist:
-            pj.farm.gather_logl(dout, B * world)  # the only collective: all-gather of B fp64 per rank (RCCL)
+            # the only collective: all-gather of B fp64 per rank (RCCL)
+            works[k] = pj.farm.gather_logl_async(douts[k], gathered_bufs[k])
+        return k
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -146,14 +157,25 @@ def main():
     fence()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
+    last = 0
     for ev0, ev1 in evs:
+        k = counter[0] & 1
+        counter[0] += 1
+        if works[k] is not None:
+            works[k].wait()
         ev0.record(stream)      # same stream the scan kernel is launched on (ctx was created on it)
-        ds.logl_batch_dev(B, dA.data_ptr(), dB.data_ptr(), dmu.data_ptr(), dnu.data_ptr(), 0, 0, dout.data_ptr(),
+        ds.logl_batch_dev(B, dA.data_ptr(), dB.data_ptr(), dmu.data_ptr(), dnu.data_ptr(), 0, 0, douts[k].data_ptr(),
                           dst.data_ptr())
         ev1.record(stream)
         if use_dist:
-            gathered = pj.farm.gather_logl(dout, B * world)
+            works[k] = pj.farm.gather_logl_async(douts[k], gathered_bufs[k])
+        last = k
+    for w in works:              # every gather finished inside the timed region
+        if w is not None:
+            w.wait()
     fence()
+    dout = douts[last]
+    gathered = gathered_bufs[last] if use_dist else None
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs)
     if use_dist:

@@ -56,6 +56,18 @@ def gather_logl(local, B: int, group=None, device=None):
     return torch.cat(parts)
 
 
+def gather_logl_async(local, out, group=None):
+    """Non-blocking form for equal shards: starts the all-gather of the torch tensor `local` into the preallocated
+    `out` (world * local.numel() values) on the collective's own stream and returns the work handle; `work.wait()` makes
+    the CURRENT stream wait for it.  Lets the gather of batch k overlap the scan of batch k + 1 (both buffers must stay
+    untouched until then: double-buffer them)."""
+    import torch.distributed as dist
+
+    if out.numel() != local.numel() * dist.get_world_size(group):
+        raise ValueError("out must hold world * local.numel() values")
+    return dist.all_gather_into_tensor(out, local, group=group, async_op=True)
+
+
 def farm_logl(evaluate: Callable[[int, int], "np.ndarray"], B: int, group=None, device=None):
     """Evaluate draws [lo, hi) of this rank with `evaluate(lo, hi)` (e.g. a Dataset.logl_batch closure on
     this rank's GPU) and return the full (B,) log-L vector on every rank."""
