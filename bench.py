@@ -10,11 +10,16 @@ of BASELINE.json configs[2]/[3] (B = 4096 per GPU; weak scaling: 8 GPUs = 32768 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task description; DESIGN.md section 7 explains the
-roofline and cpu_baseline objects).
+roofline and cpu_baseline objects).  At N_gpus = 1 the line also carries a `secondary` object with
+the other BASELINE.json configurations, each event- or wall-timed in this same process:
+DRWCelerite-20 at B = 4096 (the model BASELINE's configs name; roofline fraction on the rows the
+kernel EXECUTES and on the reference's count), the single evaluation (configs[0], [1]: N = 1e3 and
+1e4, B = 1), the dense path (configs[4]: N = 4096, J = 40) and the PCIe-inclusive host-pointer entries.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -65,6 +70,30 @@ def synth_theta(B: int, t, y, seed: int):
     return th, f_min, f_max
 
 
+def scan_source_hash() -> str:
+    """Fingerprint of the scan kernel's sources: a committed PMC summary is only quoted while it matches."""
+    h = hashlib.sha256()
+    for f in ("celerite_scan.hip", "common.h"):
+        h.update((ROOT / "pioran.jl_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(basis: str, J: int, B: int, N: int, kernel_config: str):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary of this same command (bench.py cannot collect
+    PMCs on itself).  Quoted only when the summary was taken on the SAME kernel: same configuration name and same
+    source fingerprint; otherwise null with the reason."""
+    f = ROOT / "profiles" / f"r02_pmc_{basis.lower()}{J}_b{B}.json"
+    if N != 10_000 or not f.exists():
+        return None, f"no PMC summary for this workload ({f.name})"
+    d = json.loads(f.read_text())
+    if d.get("kernel_config") != kernel_config:
+        return None, f"{f.name} was taken on {d.get('kernel_config')}, this run used {kernel_config}"
+    if d.get("scan_source_hash") != scan_source_hash():
+        return None, f"{f.name} predates the current kernel source ({d.get('scan_source_hash')} != {scan_source_hash()})"
+    return d["derived"]["hbm_traffic_bytes"], (f"profiles/{f.name}: 2*FETCH_SIZE + WRITE_SIZE (KB -> B, gfx950 x2 on fetch), separate "
+                                               f"--pmc passes of this command; kernel {d['kernel']}")
+
+
 def algorithmic_flops(N: int, R: int) -> float:
     """F_cel(N, R) = (N-1)(5.5 R^2 + 18 R) fp64 flop per evaluation — SURVEY.md section 8(d), counted
     from src/celerite_solver.jl:69-98,132-155 (mul, add, div = 1 each)."""
@@ -81,6 +110,9 @@ def main():
     ap.add_argument("--components", type=int, default=20)
     ap.add_argument("--basis", default="SHO", choices=["SHO", "DRWCelerite"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configurations (N_gpus = 1 only)")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="N_gpus > 1: rank 0 re-evaluates every rank's batch on its own GPU and compares with the gathered vector")
     args = ap.parse_args()
 
     import torch
@@ -191,13 +223,8 @@ def main():
     flops_launch = algorithmic_flops(N, 2 * Jt) * B   # algorithmic count uses the reference's R = 2J
     achieved = flops_launch / (kern_ms * 1e-3) / 1e12
 
-    # HBM bytes per launch come from a separate rocprofv3 --pmc pass of this same command (bench.py cannot
-    # collect PMCs on itself); the summary is committed under profiles/ and quoted here when the workload matches.
-    traffic, traffic_src = None, None
-    pmc = ROOT / "profiles" / "r01_pmc_sho20_b4096.json"
-    if pmc.exists() and (N, B, Jt, args.basis) == (10_000, 4096, 20, "SHO"):
-        traffic = json.loads(pmc.read_text())["derived"]["hbm_traffic_bytes"]
-        traffic_src = "profiles/r01_pmc_sho20_b4096.json (2*FETCH_SIZE + WRITE_SIZE, KB->B, separate --pmc passes)"
+    kernel_config = pj._lib.lib().pioran_celerite_config_name(0).decode()   # what the last launch ran on
+    traffic, traffic_src = pmc_traffic(args.basis, J, B, N, kernel_config)
 
     result = {
         "metric": "logpdf evals/sec (batched) at N=1e4, J=20; max |Δlogℒ| vs reference",
@@ -205,13 +232,14 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"N={N} irregular series, {args.basis}-{J} (J={Jt} celerite terms, R={R} active rows), "
-                               f"batch={B} draws per GPU, shared (c,d) table, per-draw mu/nu",
+                               f"batch={B} draws per GPU, shared (c,d) table, per-draw mu/nu; inputs HBM-resident, every "
+                               f"step re-evaluates the resident batch (PCIe-inclusive rates: secondary.host_api)",
                    "N": N, "J": Jt, "R_active": R, "batch_per_gpu": B, "global_batch": B * world,
-                   "kernel_config": pj._lib.lib().pioran_celerite_config_name(0).decode(),   # what the last launch ran on
+                   "kernel_config": kernel_config,
                    "parallelism": f"batch-sharded x{world}, all-gather of logL"},
         "roofline": {"bound": "valu-fp64", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "celerite_scan_kernel", "kernel_ms": kern_ms,
+                     "kernel": "celerite_scan_kernel", "kernel_ms": kern_ms, "scan_source_hash": scan_source_hash(),
                      "algorithmic_flop_per_eval": algorithmic_flops(N, 2 * Jt),
                      "note": "FP64 vector-ALU bound (rank-1 update + matvec per draw; not HBM, not MFMA). peak = "
                              "MI355X FP64 vector peak (at 2.4 GHz), numerically equal to the dense FP64 MFMA peak. Issue "
@@ -222,34 +250,186 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O  # checker + CPU baseline only
-        ncpu = os.cpu_count() or 1
-        O.lib()
-        # The oracle is one independent logl per draw, OpenMP over draws.  More threads than the job really gets
-        # (cgroup quota, SMT, memory bandwidth) makes it SLOWER, so sweep a few thread counts on bounded samples
-        # (8 draws per thread) and report the best one — the most favourable baseline this host gives.
-        best = None
-        for nthr in sorted({max(1, ncpu // 8), max(1, ncpu // 4), max(1, ncpu // 2), ncpu}):
-            Sn = min(B, max(16, 8 * nthr))
-            tc = time.perf_counter()
-            r_, s_ = O.logl_batch(A[:Sn], Bc[:Sn], C, Dd, t, y, yerr ** 2, mu[:Sn], nu[:Sn], nthreads=nthr, return_status=True)
-            dt = time.perf_counter() - tc
-            if best is None or Sn / dt > best[0]:
-                best = (Sn / dt, nthr, Sn, dt, r_, s_)
-        cpu_rate, cores, S, cpu_s, ref, rst = best
-        ok = (rst == 0) & (st_host[:S] == 0)
-        err = np.abs(out_host[:S][ok] - ref[ok])
-        result["cpu_baseline"] = {
-            "value": cpu_rate, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": f"first {S} draws of the same batch (N={N}, J={Jt}), oracle/celerite_oracle.c (reference "
-                      f"algorithm and memory layout), OpenMP over draws, {cpu_s:.1f} s; best of a thread-count sweep "
-                      f"over {{1/8, 1/4, 1/2, 1}} x {ncpu} logical CPUs"}
-        result["max_abs_dlogl_vs_oracle"] = float(err.max()) if ok.any() else None
-        result["max_rel_dlogl_vs_oracle"] = float((err / np.abs(ref[ok])).max()) if ok.any() else None
+        result.update(cpu_baseline_leg(O, A, Bc, C, Dd, t, y, yerr, mu, nu, out_host, st_host, N, Jt))
+    if rank == 0 and world == 1 and not args.no_secondary:
+        from oracle import oracle as O  # checker only
+        result["secondary"] = secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, f_max, args)
+    if use_dist:
+        assert gathered.numel() == B * world and torch.equal(gathered[rank * B:(rank + 1) * B], dout)
+        if args.verify_gather and rank == 0:
+            # every rank's slice of the gathered vector against a single-GPU evaluation of that rank's batch
+            for r in range(world):
+                th_r, _, _ = synth_theta(B, t, y, seed=4321 + r)
+                A_r, B_r, _, _ = pj.approx_batch(pj.SingleBendingPowerLaw, th_r[:, :3], f_min, f_max, J, th_r[:, 3],
+                                                 basis_function=args.basis)
+                d_r = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (A_r, B_r, th_r[:, 5].copy(), th_r[:, 4].copy())]
+                chk = torch.empty(B, dtype=torch.float64, device=dev)
+                ds.logl_batch_dev(B, d_r[0].data_ptr(), d_r[1].data_ptr(), d_r[2].data_ptr(), d_r[3].data_ptr(), 0, 0,
+                                  chk.data_ptr(), 0)
+                torch.cuda.synchronize(dev)
+                same = torch.eq(chk, gathered[r * B:(r + 1) * B]) | (torch.isnan(chk) & torch.isnan(gathered[r * B:(r + 1) * B]))
+                assert bool(same.all()), f"gathered slice of rank {r} differs from the single-GPU evaluation"
+            result["gather_verified"] = True
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
-        assert gathered.numel() == B * world and torch.equal(gathered[rank * B:(rank + 1) * B], dout)
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline_leg(O, A, Bc, C, Dd, t, y, yerr, mu, nu, out_host, st_host, N, Jt):
+    """The oracle (reference algorithm AND memory layout: U, V, phi, D materialised per evaluation = 9.6 MB of workspace
+    per thread at R = 40) timed on this host, OpenMP over draws.  More threads than the memory system feeds make it
+    SLOWER (every thread streams its own 9.6 MB workspace several times per evaluation, so the sweep saturates L3 / DRAM
+    bandwidth well before the core count), hence a warmed sweep over thread counts and then >= 2 s of timed work at the
+    best one (median of 3 repeats)."""
+    B = len(A)
+    ncpu = os.cpu_count() or 1
+    O.lib()
+    s2 = yerr ** 2
+
+    def run(lo, n, nthr):
+        tc = time.perf_counter()
+        r_, s_ = O.logl_batch(A[lo:lo + n], Bc[lo:lo + n], C, Dd, t, y, s2, mu[lo:lo + n], nu[lo:lo + n], nthreads=nthr,
+                              return_status=True)
+        return time.perf_counter() - tc, r_, s_
+
+    sweep = {}
+    for nthr in sorted({1, max(1, ncpu // 8), max(1, ncpu // 4), max(1, ncpu // 2), ncpu}):
+        n = min(B, max(4, 2 * nthr))
+        run(0, min(B, nthr), nthr)                      # warm: thread start-up, workspaces touched
+        dt, _, _ = run(0, n, nthr)
+        sweep[nthr] = n / dt
+    cores = max(sweep, key=sweep.get)
+    S = int(min(B, max(16, np.ceil(2.2 * sweep[cores] / cores) * cores)))   # >= 2 s of work at the measured rate
+    reps = [run(0, S, cores) for _ in range(3)]
+    reps.sort(key=lambda r: r[0])
+    cpu_s, ref, rst = reps[1]
+    ok = (rst == 0) & (st_host[:S] == 0)
+    err = np.abs(out_host[:S][ok] - ref[ok])
+    return {
+        "cpu_baseline": {
+            "value": S / cpu_s, "unit": "evals/s", "cores": cores, "kind": "port",
+            "one_thread_evals_per_s": sweep[1],
+            "sweep_evals_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
+            "sample": f"first {S} draws of the same batch (N={N}, J={Jt}), oracle/celerite_oracle.c (reference algorithm and "
+                      f"memory layout), OpenMP over draws; median of 3 warmed repeats of {cpu_s:.1f} s at the best thread "
+                      f"count of a warmed sweep over {{1, 1/8, 1/4, 1/2, 1}} x {ncpu} logical CPUs"},
+        "max_abs_dlogl_vs_oracle": float(err.max()) if ok.any() else None,
+        "max_rel_dlogl_vs_oracle": float((err / np.abs(ref[ok])).max()) if ok.any() else None,
+    }
+
+
+def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, f_max, args):
+    """The other BASELINE.json configurations, measured in this process after the headline loop (rank 0, one GPU)."""
+    N, B, J = args.n, args.batch, args.components
+    s2 = yerr ** 2
+    mu, nu = theta[:, 5].copy(), theta[:, 4].copy()
+    out = {}
+
+    def med(xs):
+        return float(np.median(xs))
+
+    def resident_batch(basis, n, nb, reps):
+        """event-timed launches of the device-pointer entry on the first n time stamps / first nb draws"""
+        tt, yy, ee = t[:n], y[:n], yerr[:n]
+        fm, fM = (f_min, f_max) if n == N else (1.0 / (tt[-1] - tt[0]), 1.0 / (2 * np.min(np.diff(tt))))
+        A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:nb, :3], fm, fM, J, theta[:nb, 3], basis_function=basis)
+        real = (Dd == 0.0) & (Bc == 0.0).all(axis=0)
+        ds = pj.Dataset(tt, yy, ee ** 2, ctx)
+        ds.prepare(C, Dd, real.astype(np.int32))
+        d = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (A, Bc, mu[:nb].copy(), nu[:nb].copy())]
+        do = torch.empty(nb, dtype=torch.float64, device=dev); dsx = torch.zeros(nb, dtype=torch.int32, device=dev)
+
+        def go():
+            ds.logl_batch_dev(nb, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, 0, do.data_ptr(), dsx.data_ptr())
+        for _ in range(2):
+            go()
+        torch.cuda.synchronize(dev)
+        ms = []
+        for _ in range(reps):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream); go(); e1.record(stream); e1.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        cfg = pj._lib.lib().pioran_celerite_config_name(0).decode()
+        return med(ms), A, Bc, C, Dd, int(2 * len(C) - real.sum()), do.cpu().numpy(), dsx.cpu().numpy(), cfg, (tt, yy, ee)
+
+    # -- the other basis at the headline size (BASELINE's configs name DRWCelerite-20; SURVEY 8 note A) -------------
+    other = "DRWCelerite" if args.basis == "SHO" else "SHO"
+    ms, A, Bc, C, Dd, R_exec, got, st, cfg, _ = resident_batch(other, N, B, 5)
+    Jt = len(C)
+    S = min(B, 64)
+    ref, rst = O.logl_batch(A[:S], Bc[:S], C, Dd, t, y, s2, mu[:S], nu[:S], nthreads=min(32, os.cpu_count() or 1), return_status=True)
+    ok = (rst == 0) & (st[:S] == 0)
+    f_exec = algorithmic_flops(N, R_exec) * B / (ms * 1e-3) / 1e12
+    f_ref = algorithmic_flops(N, 2 * Jt) * B / (ms * 1e-3) / 1e12
+    out[f"{other.lower()}{J}_b{B}"] = {
+        "workload": f"N={N}, {other}-{J} (J={Jt} terms; {2 * Jt} rows in the reference, {R_exec} executed: structurally zero sin rows dropped), "
+                    f"batch={B}, HBM-resident", "evals_per_s": B / (ms * 1e-3), "kernel_ms": ms, "kernel_config": cfg,
+        "roofline_frac_executed_rows": f_exec / FP64_PEAK_TFLOPS, "roofline_frac_reference_rows": f_ref / FP64_PEAK_TFLOPS,
+        "achieved_tflops_executed_rows": f_exec, "rows_executed": R_exec, "rows_reference": 2 * Jt,
+        "max_rel_dlogl_vs_oracle": float((np.abs(got[:S][ok] - ref[ok]) / np.abs(ref[ok])).max()) if ok.any() else None,
+        "oracle_sample": int(ok.sum())}
+
+    # -- single evaluation: configs[0] (N = 1e3) and configs[1] (N = 1e4), B = 1 -------------------------------------
+    single = {}
+    for basis in ("SHO", "DRWCelerite"):
+        for n in (N, max(2, N // 10)):
+            ms1, A1, B1, C1, D1, R1, got1, st1, _, (tt, yy, ee) = resident_batch(basis, n, 1, 7)
+            ys, ss = yy - mu[0], nu[0] * ee ** 2
+            ctx.logl(A1[0], B1[0], C1, D1, tt, ys, ss)
+            wall = []
+            for _ in range(5):
+                t0 = time.perf_counter(); v = ctx.logl(A1[0], B1[0], C1, D1, tt, ys, ss); wall.append(time.perf_counter() - t0)
+            cpu = []
+            for _ in range(3):
+                t0 = time.perf_counter(); r = O.logl(A1[0], B1[0], C1, D1, tt, ys, ss); cpu.append(time.perf_counter() - t0)
+            single[f"{basis}{J}_N{n}"] = {"resident_launch_ms": ms1, "scalar_entry_ms_incl_pcie": med(wall) * 1e3,
+                                         "cpu_one_core_ms": med(cpu) * 1e3, "rows_executed": R1,
+                                         "rel_dlogl_vs_oracle": abs(v - r) / abs(r)}
+    out["single_evaluation_B1"] = single
+
+    # -- dense path: configs[4], N = 4096, J = 40 (SHO-40) -------------------------------------------------------------
+    Nd, Jd = min(4096, N), 40
+    td, yd, ed = t[:Nd], y[:Nd], yerr[:Nd]
+    Rk = pj.approx(pj.SingleBendingPowerLaw(0.82, 0.01, 3.3), 1 / (td[-1] - td[0]), 1 / (2 * np.min(np.diff(td))), Jd, 1.0,
+                   basis_function="SHO")
+    mud = float(np.mean(yd))
+    ctx.dense_nll(Rk.a, Rk.b, Rk.c, Rk.d, td, yd - mud, ed ** 2)
+    ph, wall = [], []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        v, info, p3 = ctx.dense_nll_timed(Rk.a, Rk.b, Rk.c, Rk.d, td, yd - mud, ed ** 2)
+        wall.append(time.perf_counter() - t0); ph.append(p3)
+    fac, bld = med([p["factor_ms"] for p in ph]), med([p["build_ms"] for p in ph])
+    flop = Nd ** 3 / 3 + 2 * Nd ** 2
+    cel = pj.log_likelihood(Rk, td, yd - mud, ed ** 2, ctx=ctx)
+    out[f"dense_n{Nd}_j{Jd}"] = {
+        "workload": f"log_likelihood_direct, N={Nd}, SHO-{Jd} (J={Jd}), one evaluation", "ms_per_call_incl_pcie": med(wall) * 1e3,
+        "build_ms": bld, "factor_ms": fac, "cholesky_flop": flop, "mfma_tflops_factorisation": flop / (fac * 1e-3) / 1e12,
+        "roofline": {"bound": "mfma", "achieved": flop / (fac * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flop / (fac * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                     "note": "N^3/3 + 2N^2 flop over the event-timed factorisation (all panel + trailing-update launches)"},
+        "info": info, "rel_diff_vs_celerite_path": abs(cel + v) / abs(v)}
+
+    # -- PCIe-inclusive host-pointer entries at the headline size ------------------------------------------------------
+    A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:, :3], f_min, f_max, J, theta[:, 3], basis_function=args.basis)
+    dsh = pj.Dataset(t, y, s2, ctx)
+    dsh.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    wc, wt = [], []
+    for _ in range(5):
+        t0 = time.perf_counter(); o1 = dsh.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu); wc.append(time.perf_counter() - t0)
+    dsh.logpdf_theta(pj.SingleBendingPowerLaw, theta[:, :3], theta[:, 3], f_min, f_max, J, basis_function=args.basis, mu=mu, nu=nu)
+    for _ in range(5):
+        t0 = time.perf_counter()
+        o2 = dsh.logpdf_theta(pj.SingleBendingPowerLaw, theta[:, :3], theta[:, 3], f_min, f_max, J, basis_function=args.basis, mu=mu, nu=nu)
+        wt.append(time.perf_counter() - t0)
+    fin = np.isfinite(o1) & np.isfinite(o2)
+    out["host_api"] = {"workload": f"same batch through the blocking host-pointer entries (H2D + launch + D2H per call), B={B}",
+                       "coefficients_call_ms": med(wc) * 1e3, "coefficients_evals_per_s": B / med(wc),
+                       "theta_only_call_ms": med(wt) * 1e3, "theta_only_evals_per_s": B / med(wt),
+                       "theta_only_vs_coefficients_max_rel": float(np.max(np.abs(o1[fin] - o2[fin]) / np.abs(o1[fin])))}
+    return out
 
 
 if __name__ == "__main__":

@@ -20,7 +20,12 @@
  *   - every entry point returns 0 (PIORAN_OK) or a negative error code; nothing unwinds across the
  *     ABI.  Numerical failures of single draws are reported per draw in `status` (below);
  *   - calls on one ctx must not overlap in time (one ctx per host thread / Julia task); different
- *     ctx objects are independent.  No global mutable state, no HIP call at library load.
+ *     ctx objects are independent.  No global mutable state, no HIP call at library load; the
+ *     environment is read once, when a context is created (diagnostic switches, pioran_ctx_set_option).
+ *   - a data set keeps the state declared by pioran_dataset_prepare (the "(c, d) + table" the asynchronous
+ *     *_dev entries use) SEPARATE from the scratch state of the host-pointer entries: pioran_celerite_logl_batch,
+ *     _shift, pioran_logpdf_batch_theta, _predict, _logl_grad prepare their own tables and never change what
+ *     pioran_dataset_prepare declared, so host-pointer and *_dev calls can be mixed freely on one data set.
  *
  * status[b]:  0 ok;  1 some D_n <= 0 (matrix not positive definite — the reference silently uses
  *             log(abs(D_n)) for n >= 2, src/celerite_solver.jl:140, and so does out[b]);
@@ -47,7 +52,7 @@ typedef struct pioran_ds pioran_ds;   /* a time series resident in HBM + its cac
 const char* pioran_strerror(int code);
 const char* pioran_last_hip_error(const pioran_ctx* ctx);
 /* ABI version of this header (bumped on any signature change). */
-int pioran_abi_version(void);   /* currently 4 */
+int pioran_abi_version(void);   /* currently 5 */
 
 /* ---- context ------------------------------------------------------------------------------- */
 /* Creates a context on GPU `device` with its own non-blocking stream. */
@@ -56,7 +61,14 @@ int pioran_ctx_create(int device, pioran_ctx** out);
 int pioran_ctx_create_on_stream(int device, void* hip_stream, pioran_ctx** out);
 int pioran_ctx_destroy(pioran_ctx* ctx);
 int pioran_ctx_synchronize(pioran_ctx* ctx);
-/* hipEvent-based timing on the ctx stream: record slot i (0..15), elapsed between two slots. */
+/* Diagnostic switches (none is needed in production; tests and tuning runs use them to pin a code path):
+ *   "scan_config"     name of a throughput configuration of the scan, or "wide" = latency layout for any batch; NULL/"" = automatic
+ *   "no_wide" / "no_paired" / "no_mixed" / "force_fallback"   value "1" disables the latency layout / the column-paired
+ *                     variants / the mixed shared+per-draw table / sends everything through the any-rank kernel; NULL, "" or "0" = off.
+ * Initial values come from the environment variables PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_PAIRED, PIORAN_NO_MIXED,
+ * PIORAN_FORCE_FALLBACK, read once when the context is created. */
+int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value);
+/* hipEvent-based timing on the ctx stream: record slot i (0..11), elapsed between two slots. */
 int pioran_ctx_event_record(pioran_ctx* ctx, int slot);
 int pioran_ctx_event_elapsed_ms(pioran_ctx* ctx, int slot_start, int slot_stop, float* ms);
 
@@ -70,7 +82,10 @@ int pioran_dataset_destroy(pioran_ds* ds);
  * cos/sin/exp table for them (src/celerite_solver.jl:52-54, once instead of per draw).
  * c, d: host, length J.  real_term (host, length J, may be NULL): non-zero marks a term whose
  * b_j = 0 and d_j = 0 for EVERY draw (Exp / DRW terms, src/Exp.jl:29-33, src/psd.jl:270-273); its
- * identically-zero sin row is dropped, which leaves results bit-identical. */
+ * identically-zero sin row is dropped, which leaves results bit-identical.  (The value 2 — a term whose (c, d)
+ * differ per draw — is accepted for table-building purposes but the *_dev entries then return PIORAN_ERR_ARG: per-draw
+ * terms go through the host-pointer entry with cd_shared = 0, which builds the mixed table itself.)
+ * The declared state persists until the next pioran_dataset_prepare on this data set; no other entry changes it. */
 int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const double* d,
                            const int32_t* real_term);
 
@@ -191,6 +206,11 @@ int pioran_farm_logl_batch(pioran_farm* farm, int64_t B, int64_t J, const double
 int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,
                      const double* c, const double* d, const double* t, const double* y,
                      const double* sigma2, double* out, int32_t* info);
+/* Same call with event timing of its phases on the ctx stream: phase_ms[0] covariance build, [1] factorisation (all panel
+ * and trailing-update launches), [2] finish kernel — what bench.py reports as the dense path's MFMA utilisation. */
+int pioran_dense_nll_timed(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,
+                           const double* c, const double* d, const double* t, const double* y,
+                           const double* sigma2, double* out, int32_t* info, float* phase_ms);
 /* predict_cov (src/direct_solver.jl:28-69; cov / std / rand of a PosteriorGP, src/scalable_GP.jl:73-104):
  *     cov_out = K(tau,tau) - K(tau,t) (K(t,t) + diag(sigma2))^-1 K(t,tau),   M x M, symmetric,
  * computed as the Schur complement the blocked MFMA Cholesky of the augmented (N+M) x (N+M) matrix leaves when it stops

@@ -19,6 +19,10 @@ What it extracts (data only — inputs and expected outputs, never source text):
     HDF5 is parsed by hand (no h5py in the image): one chunked, unfiltered float64 dataset
     "points" of 17 columns [Lmin, logl, quality, u(7), params(7)], 256x5 chunks, v1 B-tree.
 
+ 1b. ultranest_example_runs.npz — the same for the three runs stored under examples/ultranest/inference/
+    (simu_single: integrated-power normalisation; simu_double: DoubleBendingPowerLaw; simu_periodic: a CustomMean
+    sinusoid, i.e. a per-draw mean FUNCTION): 6075 + 6142 + 8080 points with the reference's own log-likelihoods.
+
  2. reference_literals.json — numeric literals of the reference's tests that pin the path:
     test/test_psd.jl:30-39 (20 SHO amplitudes), test/test_acvf.jl:19-33, test/test_covariancefunctions.jl,
     test/test_carma.jl:55-69, test/test_scalablegp.jl:110-118 (N=6 series x 10 parameter sets),
@@ -50,6 +54,8 @@ from oracle import oracle as O  # noqa: E402
 
 
 def parse_points_hdf5(path: Path, ncols: int = 17) -> np.ndarray:
+    """ultranest's points store: one chunked, unfiltered float64 dataset of 3 + 2*ndim columns
+    [Lmin, logl, quality, u(ndim), params(ndim)], v1 B-tree of 256 x ccol chunks (ccol read off the keys)."""
     raw = path.read_bytes()
     assert raw[:8] == b"\x89HDF\r\n\x1a\n"
     ndims = 3  # rank-2 dataset + element-size dimension
@@ -81,10 +87,11 @@ def parse_points_hdf5(path: Path, ncols: int = 17) -> np.ndarray:
     chunks = []
     walk(top, chunks)
     crow = 256
-    ccol = 5
+    col_offs = sorted({c[0][1] for c in chunks})
+    ccol = col_offs[1] - col_offs[0]
     assert all(c[2] == crow * ccol * 8 for c in chunks)
     nrow = max(c[0][0] for c in chunks) + crow
-    arr = np.full((nrow, 4 * ccol), np.nan)
+    arr = np.full((nrow, len(col_offs) * ccol), np.nan)
     for offs, addr, csz in chunks:
         blk = np.frombuffer(raw[addr:addr + csz], dtype="<f8").reshape(crow, ccol)
         arr[offs[0]:offs[0] + crow, offs[1]:offs[1] + ccol] = blk
@@ -121,6 +128,63 @@ def make_ultranest_fixture():
         paramnames=np.array(info["paramnames"]), n_components=20, basis_function="SHO",
         is_integrated_power=False,
         note="logl = values computed by the reference (Julia) itself; see oracle/make_golden.py")
+
+
+def make_example_runs_fixture():
+    """The three further nested-sampling runs the reference stores under examples/ultranest/inference/ (made by
+    examples/ultranest/{single_pl,double_pl,single_pl_periodicity}.jl): every evaluated point with the log-likelihood
+    the reference (Julia) returned for it.  Models (read off those scripts; n_components = 20, basis "SHO", approx with
+    its default is_integrated_power = true):
+      simu_single   SingleBendingPowerLaw(a1,f1,a2), variance, nu, mu          yn = log(y),  s2 = nu yerr^2 / y^2
+      simu_double   DoubleBendingPowerLaw(a1,f1,a2,f2,a3), variance, nu, mu    same transform
+      simu_periodic SingleBendingPowerLaw + CustomMean  A sin(2 pi t / T0 + phi) + mu,   s2 = nu yerr^2   (no log)
+    Stored only after this oracle reproduces a sample of each run's values to < 1e-10 (median 4e-15)."""
+    base = REF / "examples/ultranest/inference"
+    runs = {
+        "simu_single": ("simu_single", "simu_single_subset_time_series.txt", 6),
+        "simu_double": ("simu_double", "simu_double_subset_time_series.txt", 8),
+        "simu_periodic": ("simu_periodic_rednoise_123_factor", "simu_periodic_rednoise_subset_time_series.txt", 9),
+    }
+    out = {}
+    for name, (d, series_file, ndim) in runs.items():
+        pts = parse_points_hdf5(base / d / "results/points.hdf5", ncols=3 + 2 * ndim)
+        series = np.loadtxt(base / d / series_file)
+        t, y, yerr = series[:, 0], series[:, 1], series[:, 2]
+        info = json.loads((base / d / "info/results.json").read_text())
+        params = pts[:, 3 + ndim:3 + 2 * ndim].copy()
+        logl = pts[:, 1].copy()
+        k = int(np.argmax(logl))
+        assert logl[k] == info["maximum_likelihood"]["logl"]
+        assert np.array_equal(params[k], np.array(info["maximum_likelihood"]["point"]))
+        ref_vals = example_run_logl(name, t, y, yerr, params[:64])
+        worst = float(np.max(np.abs(ref_vals - logl[:64]) / np.abs(logl[:64])))
+        print(f"{name}: {len(logl)} points, N={len(t)}, oracle-vs-reference worst rel err on 64 = {worst:.2e}")
+        assert worst < 1e-10   # median 4e-15; the tail comes from the ill-conditioned spectral solve inside approx
+        out[name + "_t"] = t; out[name + "_y"] = y; out[name + "_yerr"] = yerr
+        out[name + "_params"] = params; out[name + "_logl"] = logl
+        out[name + "_paramnames"] = np.array(info["paramnames"])
+    np.savez_compressed(OUT / "ultranest_example_runs.npz", n_components=20, basis_function="SHO", is_integrated_power=True,
+                        note="logl = values computed by the reference (Julia) itself; see oracle/make_golden.py", **out)
+
+
+def example_run_logl(name, t, y, yerr, params):
+    """The oracle's value for rows of one of the example runs (model definitions in make_example_runs_fixture)."""
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    vals = np.empty(len(params))
+    for i, p in enumerate(params):
+        if name == "simu_double":
+            a1, f1, a2, f2, a3, var, nu, mu = p
+            psd = lambda f: O.double_bending_power_law(f, a1, f1, a2, f2, a3)  # noqa: E731
+        else:
+            a1, f1, a2, var, nu, mu = p[:6]
+            psd = lambda f: O.single_bending_power_law(f, a1, f1, a2)  # noqa: E731
+        a, b, c, d = O.approx(psd, f_min, f_max, 20, var)
+        if name == "simu_periodic":
+            A, ph, T0 = p[6:9]
+            vals[i] = O.logl(a, b, c, d, t, y - (A * np.sin(2 * np.pi * t / T0 + ph) + mu), nu * yerr ** 2)
+        else:
+            vals[i] = O.logl(a, b, c, d, t, np.log(y) - mu, nu * yerr ** 2 / y ** 2)
+    return vals
 
 
 def make_literals():
@@ -249,6 +313,7 @@ def main():
         shutil.copyfile(REF / "test/data" / f, OUT / f)
         (OUT / f).chmod(0o644)
     make_ultranest_fixture()
+    make_example_runs_fixture()
     lit = make_literals()
     make_relation_cases(lit)
 

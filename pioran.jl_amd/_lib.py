@@ -25,6 +25,7 @@ SIGNATURES = {
     "pioran_ctx_create_on_stream": (ctypes.c_int, [ctypes.c_int, c_void_p, ctypes.POINTER(c_void_p)]),
     "pioran_ctx_destroy": (ctypes.c_int, [c_void_p]),
     "pioran_ctx_synchronize": (ctypes.c_int, [c_void_p]),
+    "pioran_ctx_set_option": (ctypes.c_int, [c_void_p, ctypes.c_char_p, ctypes.c_char_p]),
     "pioran_ctx_event_record": (ctypes.c_int, [c_void_p, ctypes.c_int]),
     "pioran_ctx_event_elapsed_ms": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
     "pioran_dataset_create": (ctypes.c_int, [c_void_p, i64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),
@@ -55,6 +56,7 @@ SIGNATURES = {
     "pioran_farm_logl_batch": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pioran_dense_nll": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [c_void_p, c_void_p]),
+    "pioran_dense_nll_timed": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [c_void_p, c_void_p, c_void_p]),
     "pioran_dense_predict_cov": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 6 + [i64, c_void_p, c_void_p, c_void_p]),
     "pioran_dense_predict": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pioran_dense_covariance": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 6 + [c_void_p]),

@@ -17,6 +17,7 @@ struct pioran_ctx {
     bool own_stream = false;
     hipEvent_t ev[16] = {};
     std::string last_err;
+    ScanOptions opt{};   // diagnostic switches: environment at creation, then pioran_ctx_set_option
     // growable device staging for the host-pointer entry points
     struct Buf {
         void* p = nullptr;
@@ -28,11 +29,10 @@ struct pioran_ctx {
     std::vector<double> scalar_t;
 };
 
-struct pioran_ds {
-    pioran_ctx* ctx = nullptr;
-    int64_t N = 0;
-    double *t = nullptr, *y = nullptr, *s2 = nullptr;  // device
-    // prepared shared (c, d)
+// Prepared shared-(c, d) state: table, row map, device copies of (c, d).  A data set holds TWO of them: `user` is what
+// pioran_dataset_prepare declared for the asynchronous *_dev entries and is changed by nothing else; `host` is the
+// scratch state of the host-pointer entries (logl_batch, mixed mode, theta, predict, grad), which prepare on their own.
+struct PrepState {
     int32_t J = 0, R = 0;
     std::vector<double> c_host, d_host;
     std::vector<int32_t> real_host;
@@ -48,6 +48,13 @@ struct pioran_ds {
     int32_t* dpd_terms = nullptr;
     // row layout class for the scan's configuration choice (ScanParams::standard_rows / n_complex)
     int32_t row_layout = 0, n_complex = 0;
+};
+
+struct pioran_ds {
+    pioran_ctx* ctx = nullptr;
+    int64_t N = 0;
+    double *t = nullptr, *y = nullptr, *s2 = nullptr;  // device
+    PrepState user, host;
 };
 
 namespace {
@@ -107,20 +114,20 @@ std::vector<int32_t> build_rowmap(int64_t J, const int32_t* kind)
     return rm;
 }
 
-int set_rowmap(pioran_ds* ds, const std::vector<int32_t>& rm)
+int set_rowmap(pioran_ds* ds, PrepState& s, const std::vector<int32_t>& rm)
 {
     pioran_ctx* ctx = ds->ctx;
-    if (rm.size() > ds->rowmap_cap) {
-        if (ds->rowmap) HIPCHK(ctx, hipFree(ds->rowmap));
-        ds->rowmap = nullptr;
-        if (hipMalloc((void**)&ds->rowmap, rm.size() * sizeof(int32_t)) != hipSuccess) return PIORAN_ERR_ALLOC;
-        ds->rowmap_cap = rm.size();
+    if (rm.size() > s.rowmap_cap) {
+        if (s.rowmap) HIPCHK(ctx, hipFree(s.rowmap));
+        s.rowmap = nullptr;
+        if (hipMalloc((void**)&s.rowmap, rm.size() * sizeof(int32_t)) != hipSuccess) return PIORAN_ERR_ALLOC;
+        s.rowmap_cap = rm.size();
     }
-    HIPCHK(ctx, hipMemcpyAsync(ds->rowmap, rm.data(), rm.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+    HIPCHK(ctx, hipMemcpyAsync(s.rowmap, rm.data(), rm.size() * sizeof(int32_t), hipMemcpyHostToDevice,
                                ctx->stream));
     // the host vector is about to go out of scope in the callers: finish the copy first
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ds->R = (int32_t)rm.size();
+    s.R = (int32_t)rm.size();
     return PIORAN_OK;
 }
 
@@ -129,12 +136,14 @@ int set_rowmap(pioran_ds* ds, const std::vector<int32_t>& rm)
 // for any batch size, any other value names a throughput configuration; PIORAN_NO_WIDE=1 disables the former.
 int scan_dispatch(const ScanParams& p, hipStream_t stream)
 {
-    const char* cfg = std::getenv("PIORAN_SCAN_CONFIG");
+    static const ScanOptions kDefaults{};
+    const ScanOptions& o = p.opt ? *p.opt : kDefaults;
+    const char* cfg = o.scan_config[0] ? o.scan_config : nullptr;
     const bool force_wide = cfg && !std::strcmp(cfg, "wide");
     // (below 16 rows the per-step exchange of the latency layout costs more than the whole step of a throughput layout)
-    const bool auto_wide = !cfg && p.B <= pioran_wide_max_batch() && p.R >= 16 && !std::getenv("PIORAN_NO_WIDE");
+    const bool auto_wide = !cfg && p.B <= pioran_wide_max_batch() && p.R >= 16 && !o.no_wide;
     // 80..95 rows: the throughput layouts do not hold S in registers any more, the latency layout still does
-    const bool only_wide = p.R > pioran_scan_supported_rows() && !std::getenv("PIORAN_NO_WIDE");
+    const bool only_wide = p.R > pioran_scan_supported_rows() && !o.no_wide;
     if (p.tab && p.R <= pioran_wide_supported_rows() && (force_wide || auto_wide || only_wide)) return pioran_launch_scan_wide(p, stream);
     if (p.R > pioran_scan_supported_rows()) return PIORAN_ERR_UNSUPPORTED;
     return pioran_launch_scan(p, stream);
@@ -143,7 +152,8 @@ int scan_dispatch(const ScanParams& p, hipStream_t stream)
 int launch(pioran_ds* ds, ScanParams& p)
 {
     pioran_ctx* ctx = ds->ctx;
-    if (p.R <= pioran_wide_supported_rows() && !std::getenv("PIORAN_FORCE_FALLBACK")) {
+    p.opt = &ctx->opt;
+    if (p.R <= pioran_wide_supported_rows() && !ctx->opt.force_fallback) {
         int rc = scan_dispatch(p, ctx->stream);
         if (rc != PIORAN_ERR_UNSUPPORTED) {
             if (rc == PIORAN_ERR_HIP) ctx->last_err = "scan kernel launch failed";
@@ -177,7 +187,24 @@ const char* pioran_strerror(int code)
 
 const char* pioran_last_hip_error(const pioran_ctx* ctx) { return ctx ? ctx->last_err.c_str() : ""; }
 
-int pioran_abi_version(void) { return 4; }
+int pioran_abi_version(void) { return 5; }
+
+int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
+{
+    if (!ctx || !key) return PIORAN_ERR_ARG;
+    const bool on = value && value[0] && std::strcmp(value, "0") != 0;
+    ScanOptions& o = ctx->opt;
+    if (!std::strcmp(key, "scan_config")) {
+        if (value && std::strlen(value) >= sizeof(o.scan_config)) return PIORAN_ERR_ARG;
+        std::memset(o.scan_config, 0, sizeof(o.scan_config));
+        if (value) std::strcpy(o.scan_config, value);
+    } else if (!std::strcmp(key, "no_wide")) o.no_wide = on;
+    else if (!std::strcmp(key, "no_paired")) o.no_paired = on;
+    else if (!std::strcmp(key, "no_mixed")) o.no_mixed = on;
+    else if (!std::strcmp(key, "force_fallback")) o.force_fallback = on;
+    else return PIORAN_ERR_ARG;
+    return PIORAN_OK;
+}
 
 static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
 {
@@ -188,6 +215,12 @@ static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
     pioran_ctx* ctx = new (std::nothrow) pioran_ctx;
     if (!ctx) return PIORAN_ERR_ALLOC;
     ctx->device = device;
+    // the only place the environment is read
+    pioran_ctx_set_option(ctx, "scan_config", std::getenv("PIORAN_SCAN_CONFIG"));
+    pioran_ctx_set_option(ctx, "no_wide", std::getenv("PIORAN_NO_WIDE"));
+    pioran_ctx_set_option(ctx, "no_paired", std::getenv("PIORAN_NO_PAIRED"));
+    pioran_ctx_set_option(ctx, "no_mixed", std::getenv("PIORAN_NO_MIXED"));
+    pioran_ctx_set_option(ctx, "force_fallback", std::getenv("PIORAN_FORCE_FALLBACK"));
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
     if (own) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
@@ -235,14 +268,14 @@ int pioran_ctx_synchronize(pioran_ctx* ctx)
 
 int pioran_ctx_event_record(pioran_ctx* ctx, int slot)
 {
-    if (!ctx || slot < 0 || slot >= 16) return PIORAN_ERR_ARG;
+    if (!ctx || slot < 0 || slot >= 12) return PIORAN_ERR_ARG;   // 12..15: internal
     HIPCHK(ctx, hipEventRecord(ctx->ev[slot], ctx->stream));
     return PIORAN_OK;
 }
 
 int pioran_ctx_event_elapsed_ms(pioran_ctx* ctx, int a, int b, float* ms)
 {
-    if (!ctx || !ms || a < 0 || a >= 16 || b < 0 || b >= 16) return PIORAN_ERR_ARG;
+    if (!ctx || !ms || a < 0 || a >= 12 || b < 0 || b >= 12) return PIORAN_ERR_ARG;
     HIPCHK(ctx, hipEventSynchronize(ctx->ev[b]));
     HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev[a], ctx->ev[b]));
     return PIORAN_OK;
@@ -284,15 +317,17 @@ int pioran_dataset_destroy(pioran_ds* ds)
     (void)hipSetDevice(ds->ctx->device);
     (void)hipStreamSynchronize(ds->ctx->stream);
     if (ds->t) (void)hipFree(ds->t);
-    if (ds->tab) (void)hipFree(ds->tab);
-    if (ds->rowmap) (void)hipFree(ds->rowmap);
-    if (ds->dc) (void)hipFree(ds->dc);
-    if (ds->dpd_terms) (void)hipFree(ds->dpd_terms);
+    for (PrepState* s : {&ds->user, &ds->host}) {
+        if (s->tab) (void)hipFree(s->tab);
+        if (s->rowmap) (void)hipFree(s->rowmap);
+        if (s->dc) (void)hipFree(s->dc);
+        if (s->dpd_terms) (void)hipFree(s->dpd_terms);
+    }
     delete ds;
     return PIORAN_OK;
 }
 
-int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const double* d, const int32_t* real_term)
+static int prepare_state(pioran_ds* ds, PrepState& s, int64_t J, const double* c, const double* d, const int32_t* real_term)
 {
     if (!ds || J < 1 || J > (1 << 20) || !c || !d) return PIORAN_ERR_ARG;
     pioran_ctx* ctx = ds->ctx;
@@ -308,72 +343,85 @@ int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const doub
     if (pdlist.size() > 255 || J > 0xfffff) return PIORAN_ERR_UNSUPPORTED;
     c = cc.data();
     d = dv.data();
-    const bool same = ds->prepared && ds->J == J && !std::memcmp(ds->c_host.data(), c, J * sizeof(double)) &&
-                      !std::memcmp(ds->d_host.data(), d, J * sizeof(double)) && ds->real_host == real;
+    const bool same = s.prepared && s.J == J && !std::memcmp(s.c_host.data(), c, J * sizeof(double)) &&
+                      !std::memcmp(s.d_host.data(), d, J * sizeof(double)) && s.real_host == real;
     if (same) return PIORAN_OK;
-    ds->prepared = false;
-    if ((size_t)J > ds->dcd_cap) {
-        if (ds->dc) HIPCHK(ctx, hipFree(ds->dc));
-        ds->dc = nullptr;
-        if (hipMalloc((void**)&ds->dc, 2 * (size_t)J * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
-        ds->dcd_cap = (size_t)J;
+    s.prepared = false;
+    if ((size_t)J > s.dcd_cap) {
+        if (s.dc) HIPCHK(ctx, hipFree(s.dc));
+        s.dc = nullptr;
+        if (hipMalloc((void**)&s.dc, 2 * (size_t)J * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
+        s.dcd_cap = (size_t)J;
     }
-    ds->dd = ds->dc + J;
-    ds->c_host.assign(c, c + J);
-    ds->d_host.assign(d, d + J);
-    HIPCHK(ctx, hipMemcpyAsync(ds->dc, ds->c_host.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ds->dd, ds->d_host.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    int rc = set_rowmap(ds, build_rowmap(J, real.data()));   // sets ds->R
+    s.dd = s.dc + J;
+    s.c_host.assign(c, c + J);
+    s.d_host.assign(d, d + J);
+    HIPCHK(ctx, hipMemcpyAsync(s.dc, s.c_host.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(s.dd, s.d_host.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int rc = set_rowmap(ds, s, build_rowmap(J, real.data()));   // sets s.R
     if (rc) return rc;
-    ds->npd_terms = (int32_t)pdlist.size();
+    s.npd_terms = (int32_t)pdlist.size();
     if (!pdlist.empty()) {
-        if (!ds->dpd_terms && hipMalloc((void**)&ds->dpd_terms, 256 * sizeof(int32_t)) != hipSuccess) return PIORAN_ERR_ALLOC;
-        HIPCHK(ctx, hipMemcpyAsync(ds->dpd_terms, pdlist.data(), pdlist.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (!s.dpd_terms && hipMalloc((void**)&s.dpd_terms, 256 * sizeof(int32_t)) != hipSuccess) return PIORAN_ERR_ALLOC;
+        HIPCHK(ctx, hipMemcpyAsync(s.dpd_terms, pdlist.data(), pdlist.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     // the table is per ROW (v, x, phi) + (y_n, sigma2_n) per step, see table.hip
-    const size_t need = pioran_table_doubles(ds->N, ds->R);
-    if (need > ds->tab_cap) {
-        if (ds->tab) HIPCHK(ctx, hipFree(ds->tab));
-        ds->tab = nullptr;
-        ds->tab_cap = 0;
-        if (hipMalloc((void**)&ds->tab, need * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
-        ds->tab_cap = need;
+    const size_t need = pioran_table_doubles(ds->N, s.R);
+    if (need > s.tab_cap) {
+        if (s.tab) HIPCHK(ctx, hipFree(s.tab));
+        s.tab = nullptr;
+        s.tab_cap = 0;
+        if (hipMalloc((void**)&s.tab, need * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
+        s.tab_cap = need;
     }
-    rc = pioran_launch_table(ds->N, ds->R, ds->rowmap, ds->t, ds->dc, ds->dd, ds->y, ds->s2, ds->tab,
-                             3 * (int64_t)(ds->R + 2) + 2, ctx->stream);
+    rc = pioran_launch_table(ds->N, s.R, s.rowmap, ds->t, s.dc, s.dd, ds->y, ds->s2, s.tab,
+                             3 * (int64_t)(s.R + 2) + 2, ctx->stream);
     if (rc) return rc;
-    ds->J = (int32_t)J;
-    ds->real_host = real;
+    s.J = (int32_t)J;
+    s.real_host = real;
     {   // 1: every term has both rows; 2: two-row terms first, then one-row terms only; 0: anything else
         int64_t nc = 0;
         while (nc < J && real[nc] == 0) ++nc;
         bool rest_real = true;
         for (int64_t j = nc; j < J; ++j) rest_real = rest_real && real[j] == 1;
-        ds->row_layout = nc == J ? 1 : ((rest_real && pdlist.empty()) ? 2 : 0);
-        ds->n_complex = (int32_t)nc;
+        s.row_layout = nc == J ? 1 : ((rest_real && pdlist.empty()) ? 2 : 0);
+        s.n_complex = (int32_t)nc;
     }
-    ds->prepared = true;
+    s.prepared = true;
     return PIORAN_OK;
+}
+
+int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const double* d, const int32_t* real_term)
+{
+    if (!ds) return PIORAN_ERR_ARG;
+    return prepare_state(ds, ds->user, J, c, d, real_term);
+}
+
+static int batch_dev_impl(pioran_ds* ds, const PrepState& s, int64_t B, const double* dA, const double* dBc, const double* dmu,
+                          const double* dnu, const double* dY, const double* dS2, double* dout, int32_t* dstatus)
+{
+    if (!ds || B < 1 || !dA || !dBc || !dout) return PIORAN_ERR_ARG;
+    if (!s.prepared || s.npd_terms > 0) return PIORAN_ERR_ARG;   // per-draw terms need the mixed-mode host entry
+    if ((dY == nullptr) != (dS2 == nullptr)) return PIORAN_ERR_ARG;
+    pioran_ctx* ctx = ds->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ScanParams p{};
+    p.N = ds->N; p.J = s.J; p.R = s.R; p.B = B;
+    p.standard_rows = s.row_layout; p.n_complex = s.n_complex;
+    p.rec_stride = 3 * (int64_t)(s.R + 2) + 2;
+    p.tab = s.tab; p.rowmap = s.rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+    p.Y = dY; p.S2 = dS2; p.A = dA; p.Bc = dBc; p.C = s.dc; p.D = s.dd;
+    p.mu = dmu; p.nu = dnu; p.out = dout; p.status = dstatus;
+    return launch(ds, p);
 }
 
 int pioran_celerite_logl_batch_dev(pioran_ds* ds, int64_t B, const double* dA, const double* dBc, const double* dmu,
                                    const double* dnu, const double* dY, const double* dS2, double* dout,
                                    int32_t* dstatus)
 {
-    if (!ds || B < 1 || !dA || !dBc || !dout) return PIORAN_ERR_ARG;
-    if (!ds->prepared) return PIORAN_ERR_ARG;
-    if ((dY == nullptr) != (dS2 == nullptr)) return PIORAN_ERR_ARG;
-    pioran_ctx* ctx = ds->ctx;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    ScanParams p{};
-    p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = B;
-    p.standard_rows = ds->row_layout; p.n_complex = ds->n_complex;
-    p.rec_stride = 3 * (int64_t)(ds->R + 2) + 2;
-    p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
-    p.Y = dY; p.S2 = dS2; p.A = dA; p.Bc = dBc; p.C = ds->dc; p.D = ds->dd;
-    p.mu = dmu; p.nu = dnu; p.out = dout; p.status = dstatus;
-    return launch(ds, p);
+    if (!ds) return PIORAN_ERR_ARG;
+    return batch_dev_impl(ds, ds->user, B, dA, dBc, dmu, dnu, dY, dS2, dout, dstatus);
 }
 
 int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const double* dA, const double* dBc,
@@ -413,7 +461,7 @@ static int prepare_shared(pioran_ds* ds, int64_t B, int64_t J, const double* Bc,
         for (int64_t b = 0; b < B && allzero; ++b) allzero = (Bc[b * J + j] == 0.0);
         real[j] = allzero;
     }
-    return pioran_dataset_prepare(ds, J, C, Dd, real.data());
+    return prepare_state(ds, ds->host, J, C, Dd, real.data());
 }
 
 // Mixed mode (host-pointer entry, cd_shared == 0): when only a few terms really differ between draws (QPO features on
@@ -425,7 +473,8 @@ static int batch_host_mixed(pioran_ds* ds, int64_t B, int64_t J, const double* A
                             bool series_on_device, double* out, int32_t* status)
 {
     pioran_ctx* ctx = ds->ctx;
-    if (std::getenv("PIORAN_NO_MIXED")) return 0;
+    PrepState& s = ds->host;
+    if (ctx->opt.no_mixed) return 0;
     std::vector<int32_t> kind(J, 0);
     int64_t npd = 0;
     for (int64_t j = 0; j < J; ++j) {
@@ -448,12 +497,12 @@ static int batch_host_mixed(pioran_ds* ds, int64_t B, int64_t J, const double* A
     chunk = chunk > B ? B : chunk & ~(int64_t)15;
     if (chunk < 16) return 0;
     int rc;
-    if ((rc = pioran_dataset_prepare(ds, J, C, Dd, kind.data()))) return rc;   // row 0 of C, Dd: the shared values
+    if ((rc = prepare_state(ds, s, J, C, Dd, kind.data()))) return rc;   // row 0 of C, Dd: the shared values
     const int64_t rec_stride = rs_shared + chunk * 6 * npd;
     if ((rc = ensure(ctx, ctx->bscratch, (size_t)(ds->N + 1) * (size_t)rec_stride * sizeof(double)))) return rc;
     double* ctab = (double*)ctx->bscratch.p;
     // shared rows into the combined layout (same kernel as the plain table, wider record stride)
-    if ((rc = pioran_launch_table(ds->N, ds->R, ds->rowmap, ds->t, ds->dc, ds->dd, ds->y, ds->s2, ctab, rec_stride, ctx->stream)))
+    if ((rc = pioran_launch_table(ds->N, s.R, s.rowmap, ds->t, s.dc, s.dd, ds->y, ds->s2, ctab, rec_stride, ctx->stream)))
         return rc;
     if ((rc = ensure(ctx, ctx->bout, chunk * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t)))) return rc;
@@ -475,18 +524,19 @@ static int batch_host_mixed(pioran_ds* ds, int64_t B, int64_t J, const double* A
         } else if (series_on_device) {
             dY = (const double*)ctx->bY.p + b0 * ds->N; dS2 = (const double*)ctx->bS2.p + b0 * ds->N;
         }
-        rc = pioran_launch_pd_table(ds->N, nb, (int32_t)J, ds->npd_terms, ds->dpd_terms, ds->t, (const double*)ctx->bC.p,
+        rc = pioran_launch_pd_table(ds->N, nb, (int32_t)J, s.npd_terms, s.dpd_terms, ds->t, (const double*)ctx->bC.p,
                                     (const double*)ctx->bD.p, ctab, rec_stride, rs_shared, ctx->stream);
         if (rc) return rc;
         ScanParams p{};
-        p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = nb;
-        p.standard_rows = ds->row_layout; p.n_complex = ds->n_complex;
+        p.N = ds->N; p.J = s.J; p.R = s.R; p.B = nb;
+        p.standard_rows = s.row_layout; p.n_complex = s.n_complex;
         p.rec_stride = rec_stride;
-        p.tab = ctab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
-        p.Y = dY; p.S2 = dS2; p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
+        p.tab = ctab; p.rowmap = s.rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+        p.Y = dY; p.S2 = dS2; p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = s.dc; p.D = s.dd;
         p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
         p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
-        p.npd_rows = 2 * ds->npd_terms;
+        p.npd_rows = 2 * s.npd_terms;
+        p.opt = &ctx->opt;
         rc = scan_dispatch(p, ctx->stream);
         if (rc) { ctx->last_err = "mixed-mode scan launch failed"; return rc; }
         HIPCHK(ctx, hipMemcpyAsync(out + b0, ctx->bout.p, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -533,7 +583,7 @@ static int batch_host_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A,
     const double* dY = (Y || series_on_device) ? (const double*)ctx->bY.p : nullptr;
     const double* dS2 = (Y || series_on_device) ? (const double*)ctx->bS2.p : nullptr;
     if (cd_shared)
-        rc = pioran_celerite_logl_batch_dev(ds, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu, dY,
+        rc = batch_dev_impl(ds, ds->host, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu, dY,
                                             dS2, (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
     else
         rc = pioran_celerite_logl_batch_dev_cd(ds, B, J, (const double*)ctx->bA.p, (const double*)ctx->bB.p,
@@ -554,11 +604,11 @@ int pioran_celerite_logl_batch(pioran_ds* ds, int64_t B, int64_t J, const double
     return batch_host_impl(ds, B, J, A, Bc, C, Dd, cd_shared, mu, nu, Y, S2, false, out, status);
 }
 
-int pioran_celerite_logl_batch_shift_dev(pioran_ds* ds, int64_t B, const double* dA, const double* dBc, const double* dmu,
-                                         const double* dnu, const double* dshift, double* dout, int32_t* dstatus)
+static int batch_shift_dev_impl(pioran_ds* ds, const PrepState& s, int64_t B, const double* dA, const double* dBc, const double* dmu,
+                                const double* dnu, const double* dshift, double* dout, int32_t* dstatus)
 {
     if (!ds || B < 1 || !dA || !dBc || !dshift || !dout) return PIORAN_ERR_ARG;
-    if (!ds->prepared) return PIORAN_ERR_ARG;
+    if (!s.prepared) return PIORAN_ERR_ARG;
     pioran_ctx* ctx = ds->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t bn = (size_t)B * (size_t)ds->N * sizeof(double);
@@ -567,8 +617,15 @@ int pioran_celerite_logl_batch_shift_dev(pioran_ds* ds, int64_t B, const double*
     if ((rc = ensure(ctx, ctx->bS2, bn))) return rc;
     rc = pioran_launch_shift_transform(ds->N, B, ds->y, ds->s2, dshift, (double*)ctx->bY.p, (double*)ctx->bS2.p, ctx->stream);
     if (rc) return rc;
-    return pioran_celerite_logl_batch_dev(ds, B, dA, dBc, dmu, dnu, (const double*)ctx->bY.p, (const double*)ctx->bS2.p,
+    return batch_dev_impl(ds, s, B, dA, dBc, dmu, dnu, (const double*)ctx->bY.p, (const double*)ctx->bS2.p,
                                           dout, dstatus);
+}
+
+int pioran_celerite_logl_batch_shift_dev(pioran_ds* ds, int64_t B, const double* dA, const double* dBc, const double* dmu,
+                                         const double* dnu, const double* dshift, double* dout, int32_t* dstatus)
+{
+    if (!ds) return PIORAN_ERR_ARG;
+    return batch_shift_dev_impl(ds, ds->user, B, dA, dBc, dmu, dnu, dshift, dout, dstatus);
 }
 
 int pioran_celerite_logl_batch_shift(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc,
@@ -604,7 +661,7 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
     std::vector<int32_t> piv, real;
     int rc = pioran_approx_setup_host(J, basis, f_min, f_max, S_low, S_high, sp, LU, piv, c, d, real);
     if (rc) return rc;
-    if ((rc = pioran_dataset_prepare(ds, Jt, c.data(), d.data(), real.data()))) return rc;
+    if ((rc = prepare_state(ds, ds->host, Jt, c.data(), d.data(), real.data()))) return rc;
     // staging: [sp J | LU J*J | piv (as int32, J)] in bwork; theta in bC, norm in bD (free when (c,d) are shared)
     const size_t nd = (size_t)J + (size_t)J * J + (size_t)J;
     if ((rc = ensure(ctx, ctx->bwork, nd * sizeof(double)))) return rc;
@@ -632,10 +689,10 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
     const double* dnu = nu ? (const double*)ctx->bnu.p : nullptr;
     if (shift) {
         if ((rc = upload(ctx, ctx->bshift, shift, B * sizeof(double)))) return rc;
-        rc = pioran_celerite_logl_batch_shift_dev(ds, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu,
+        rc = batch_shift_dev_impl(ds, ds->host, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu,
                                                   (const double*)ctx->bshift.p, (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
     } else {
-        rc = pioran_celerite_logl_batch_dev(ds, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu, nullptr,
+        rc = batch_dev_impl(ds, ds->host, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu, nullptr,
                                             nullptr, (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
     }
     if (rc) return rc;
@@ -676,12 +733,13 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
 {
     if (!ds || B < 1 || J < 1 || M < 1 || !A || !Bc || !C || !Dd || !tau || !mean_out) return PIORAN_ERR_ARG;
     pioran_ctx* ctx = ds->ctx;
+    PrepState& s = ds->host;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
-    if (ds->R > pioran_wide_supported_rows() || ds->npd_terms) return PIORAN_ERR_UNSUPPORTED;
+    if (s.R > pioran_wide_supported_rows() || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
     const int64_t chunk = B < 256 ? B : 256;
-    if ((rc = ensure(ctx, ctx->bwork, pioran_predict_workspace_doubles(chunk, ds->N, ds->R) * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->bwork, pioran_predict_workspace_doubles(chunk, ds->N, s.R) * sizeof(double)))) return rc;
     if ((rc = upload(ctx, ctx->bshift, tau, (size_t)M * sizeof(double)))) return rc;          // tau
     if ((rc = ensure(ctx, ctx->bY, (size_t)chunk * (size_t)M * sizeof(double)))) return rc;   // mean [chunk][M]
     if ((rc = ensure(ctx, ctx->bout, chunk * sizeof(double)))) return rc;
@@ -693,11 +751,11 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
         if (mu && (rc = upload(ctx, ctx->bmu, mu + b0, nb * sizeof(double)))) return rc;
         if (nu && (rc = upload(ctx, ctx->bnu, nu + b0, nb * sizeof(double)))) return rc;
         ScanParams p{};
-        p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = nb;
-        p.standard_rows = ds->row_layout; p.n_complex = ds->n_complex;
-        p.rec_stride = 3 * (int64_t)(ds->R + 2) + 2;
-        p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
-        p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
+        p.N = ds->N; p.J = s.J; p.R = s.R; p.B = nb;
+        p.standard_rows = s.row_layout; p.n_complex = s.n_complex;
+        p.rec_stride = 3 * (int64_t)(s.R + 2) + 2;
+        p.tab = s.tab; p.rowmap = s.rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+        p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = s.dc; p.D = s.dd;
         p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
         p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
         rc = pioran_launch_predict(p, (double*)ctx->bwork.p, ds->t, M, (const double*)ctx->bshift.p, (double*)ctx->bY.p,
@@ -720,14 +778,15 @@ static int logl_grad_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
     if (!ds || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !out || !grad_a || !grad_b) return PIORAN_ERR_ARG;
     if ((shift == nullptr) != (grad_shift == nullptr)) return PIORAN_ERR_ARG;
     pioran_ctx* ctx = ds->ctx;
+    PrepState& s = ds->host;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
-    if (ds->R > 79 || ds->npd_terms) return PIORAN_ERR_UNSUPPORTED;
+    if (s.R > 79 || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
     // the forward pass keeps S_n of every step: bound the chunk by ~48 GB of workspace
     int64_t chunk = B < 256 ? B : 256;
-    while (chunk > 1 && pioran_grad_workspace_doubles(chunk, ds->N, ds->R) * sizeof(double) > (48ull << 30)) chunk /= 2;
-    if ((rc = ensure(ctx, ctx->bwork, pioran_grad_workspace_doubles(chunk, ds->N, ds->R) * sizeof(double)))) return rc;
+    while (chunk > 1 && pioran_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double) > (48ull << 30)) chunk /= 2;
+    if ((rc = ensure(ctx, ctx->bwork, pioran_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double)))) return rc;
     const size_t cj = (size_t)chunk * (size_t)J * sizeof(double), cn = (size_t)chunk * (size_t)ds->N * sizeof(double);
     if ((rc = ensure(ctx, ctx->bC, 2 * cj))) return rc;              // grad_a | grad_b
     if ((rc = ensure(ctx, ctx->bD, 2 * chunk * sizeof(double)))) return rc;   // grad_nu | grad_mu
@@ -745,11 +804,11 @@ static int logl_grad_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
         if (mu && (rc = upload(ctx, ctx->bmu, mu + b0, nb * sizeof(double)))) return rc;
         if (nu && (rc = upload(ctx, ctx->bnu, nu + b0, nb * sizeof(double)))) return rc;
         ScanParams p{};
-        p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = nb;
-        p.standard_rows = ds->row_layout; p.n_complex = ds->n_complex;
-        p.rec_stride = 3 * (int64_t)(ds->R + 2) + 2;
-        p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
-        p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
+        p.N = ds->N; p.J = s.J; p.R = s.R; p.B = nb;
+        p.standard_rows = s.row_layout; p.n_complex = s.n_complex;
+        p.rec_stride = 3 * (int64_t)(s.R + 2) + 2;
+        p.tab = s.tab; p.rowmap = s.rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+        p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = s.dc; p.D = s.dd;
         p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
         p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
         p.g_y = want_series ? (double*)ctx->bY.p : nullptr;
@@ -814,7 +873,8 @@ int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, c
     if (rc) return rc;
     auto done = [&](int code) { pioran_dataset_destroy(ds); return code; };
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return done(rc);
-    if (ds->R > pioran_wide_supported_rows() || ds->npd_terms) return done(PIORAN_ERR_UNSUPPORTED);
+    PrepState& s = ds->host;
+    if (s.R > pioran_wide_supported_rows() || s.npd_terms) return done(PIORAN_ERR_UNSUPPORTED);
     const int64_t chunk = B < 256 ? B : 256;
     const size_t cn = (size_t)chunk * (size_t)N * sizeof(double);
     if ((rc = ensure(ctx, ctx->bY, cn))) return done(rc);     // noise
@@ -826,11 +886,11 @@ int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, c
         if ((rc = upload(ctx, ctx->bB, Bc + b0 * J, (size_t)nb * J * sizeof(double)))) return done(rc);
         if ((rc = upload(ctx, ctx->bY, q + b0 * N, (size_t)nb * N * sizeof(double)))) return done(rc);
         ScanParams p{};
-        p.N = ds->N; p.J = ds->J; p.R = ds->R; p.B = nb;
-        p.standard_rows = ds->row_layout; p.n_complex = ds->n_complex;
-        p.rec_stride = 3 * (int64_t)(ds->R + 2) + 2;
-        p.tab = ds->tab; p.rowmap = ds->rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
-        p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = ds->dc; p.D = ds->dd;
+        p.N = ds->N; p.J = s.J; p.R = s.R; p.B = nb;
+        p.standard_rows = s.row_layout; p.n_complex = s.n_complex;
+        p.rec_stride = 3 * (int64_t)(s.R + 2) + 2;
+        p.tab = s.tab; p.rowmap = s.rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+        p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = s.dc; p.D = s.dd;
         p.out = (double*)ctx->bout.p;
         p.noise = (const double*)ctx->bY.p; p.ysim = (double*)ctx->bS2.p;
         rc = pioran_launch_scan_wide_sim(p, ctx->stream);
@@ -956,9 +1016,9 @@ static int dense_stage(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, c
     return ensure(ctx, ctx->bK, ((size_t)Mp * (size_t)ld + 1024) * sizeof(double));
 }
 
-int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
-                     const double* d, const double* t, const double* y, const double* sigma2, double* out,
-                     int32_t* info)
+static int dense_nll_impl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
+                          const double* d, const double* t, const double* y, const double* sigma2, double* out,
+                          int32_t* info, float* phase_ms)
 {
     if (!ctx || N < 1 || J < 1 || !a || !b || !c || !d || !t || !y || !sigma2 || !out) return PIORAN_ERR_ARG;
     if (N > 46000) return PIORAN_ERR_UNSUPPORTED;  // slab would exceed ~17 GB
@@ -966,15 +1026,33 @@ int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, con
     double* dv[9];
     int rc = dense_stage(ctx, N, J, a, b, c, d, t, y, sigma2, dv);
     if (rc) return rc;
+    if (phase_ms) HIPCHK(ctx, hipEventRecord(ctx->ev[12], ctx->stream));
     rc = pioran_dense_nll_device(N, (int32_t)J, dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], (double*)ctx->bK.p,
-                                 nullptr, dv[7], (int32_t*)dv[8], is_sorted(t, N), ctx->stream);
+                                 phase_ms ? &ctx->ev[13] : nullptr, dv[7], (int32_t*)dv[8], is_sorted(t, N), ctx->stream);
     if (rc) { ctx->last_err = "dense kernel launch failed"; return rc; }
     int32_t hinfo = 0;
     HIPCHK(ctx, hipMemcpyAsync(out, dv[7], sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&hinfo, dv[8], sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (info) *info = hinfo;
+    if (phase_ms)
+        for (int i = 0; i < 3; ++i) HIPCHK(ctx, hipEventElapsedTime(&phase_ms[i], ctx->ev[12 + i], ctx->ev[13 + i]));
     return PIORAN_OK;
+}
+
+int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
+                     const double* d, const double* t, const double* y, const double* sigma2, double* out,
+                     int32_t* info)
+{
+    return dense_nll_impl(ctx, N, J, a, b, c, d, t, y, sigma2, out, info, nullptr);
+}
+
+int pioran_dense_nll_timed(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
+                           const double* d, const double* t, const double* y, const double* sigma2, double* out,
+                           int32_t* info, float* phase_ms)
+{
+    if (!phase_ms) return PIORAN_ERR_ARG;
+    return dense_nll_impl(ctx, N, J, a, b, c, d, t, y, sigma2, out, info, phase_ms);
 }
 
 // predict_direct / predict_cov (src/direct_solver.jl:28-119): y == nullptr: covariance only; cov_out == nullptr: mean only

@@ -755,19 +755,21 @@ bool blocked_fits(const ScanConfig& c, const ScanParams& p)
 
 const ScanConfig* pick_config(int R, bool standard_rows, const ScanParams* p = nullptr)
 {
-    if (const char* env = std::getenv("PIORAN_SCAN_CONFIG")) {
+    const ScanOptions* opt = p ? p->opt : nullptr;
+    const bool no_paired = opt && opt->no_paired;
+    if (const char* env = (opt && opt->scan_config[0]) ? opt->scan_config : nullptr) {
         for (const auto& c : kConfigs)
             if (!std::strcmp(env, c.name) && c.capacity() >= R && (!c.paired || standard_rows) && (c.npb == 0 || (p && blocked_fits(c, *p))))
                 return &c;
     }
-    if (p && !std::getenv("PIORAN_NO_PAIRED")) {
+    if (p && !no_paired) {
         for (const auto& c : kConfigs)
             if (c.npb > 0 && c.autopick && blocked_fits(c, *p)) return &c;
     }
     const ScanConfig* best = nullptr;
     for (int i = 0; i < kNumPreferred; ++i)
         if (kConfigs[i].capacity() >= R) { best = &kConfigs[i]; break; }
-    if (standard_rows && !std::getenv("PIORAN_NO_PAIRED")) {
+    if (standard_rows && !no_paired) {
         // a paired variant of the same shape (or the smallest paired one that fits) wins when the row map allows it
         for (const auto& c : kConfigs)
             if (c.paired && c.npb == 0 && c.autopick && c.capacity() >= R && (!best || c.rpl * c.cbr * c.nsrc <= best->rpl * best->cbr * best->nsrc))

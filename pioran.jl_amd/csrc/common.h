@@ -13,7 +13,16 @@
 //   record n (n <= N, the last one a readable copy of N-1) = [ v_r | x_r | phi_r | y_n sigma2_n ], r < R + 2:
 //   cos row (v, x) = (cos, sin)(d_j t_n), sin row (sin, cos); phi = exp(-c_j (t_n - t_{n-1}));
 //   row R is the inert padding row (v, x, phi) = (1, 0, 1), row R+1 the y row (0, 0, 1).
+// Diagnostic switches of a context (none is needed in production).  Read ONCE from the environment when the context is
+// created (PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_PAIRED, PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK) and changed
+// afterwards only through pioran_ctx_set_option — the launch path never calls getenv.
+struct ScanOptions {
+    char scan_config[48];   // "" automatic; "wide": latency layout for any batch size; else a throughput configuration's name
+    bool no_wide, no_paired, no_mixed, force_fallback;
+};
+
 struct ScanParams {
+    const ScanOptions* opt;   // host-side only (the launch dispatch); nullptr = defaults
     int64_t N;            // time stamps
     int32_t J;            // celerite terms
     int32_t R;            // active rows (<= 2J; structurally-zero sin rows of d=b=0 terms dropped)
@@ -109,7 +118,7 @@ int pioran_launch_approx(int64_t B, int model, int P, int J, int basis, int inte
 void pioran_dense_dims(int64_t N, int64_t* Mp, int64_t* ld);
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,
                             const double* d, const double* t, const double* y, const double* s2,
-                            double* K /*ld*Mp + 1024*/, double* work, double* out, int32_t* info,
+                            double* K /*ld*Mp + 1024*/, hipEvent_t* phase_ev /*nullptr or [3]*/, double* out, int32_t* info,
                             int sorted, hipStream_t stream);
 int pioran_dense_predict_cov_device(int64_t N, int64_t M, int32_t J, const double* a, const double* b, const double* c,
                                     const double* d, const double* te, const double* s2e, double* K, int32_t* info,

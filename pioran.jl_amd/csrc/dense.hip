@@ -651,11 +651,13 @@ static void launch_build(int64_t N, int64_t Mp, int64_t ld, int32_t J, const dou
 }
 
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c, const double* d,
-                            const double* t, const double* y, const double* s2, double* K, double* /*work*/,
+                            const double* t, const double* y, const double* s2, double* K, hipEvent_t* phase_ev,
                             double* out, int32_t* info, int sorted, hipStream_t stream)
 {
+    // phase_ev (nullptr or 3 events): recorded after the covariance build, after the factorisation loop, after the finish
     const int64_t Mp = (N + NB - 1) / NB * NB, ld = Mp + NB;
     launch_build(N, Mp, ld, J, a, b, c, d, t, y, s2, K, sorted, stream);
+    if (phase_ev) (void)hipEventRecord(phase_ev[0], stream);
     if (hipMemsetAsync(info, 0, sizeof(int32_t), stream) != hipSuccess) return PIORAN_ERR_HIP;
     double* ws = K + (size_t)ld * (size_t)Mp;   // WS_DOUBLES doubles right behind the slab
     hipLaunchKernelGGL(dense_diag0_kernel, dim3(1), dim3(256), 0, stream, K, ld, ws, info);
@@ -673,7 +675,9 @@ int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double*
             hipLaunchKernelGGL(dense_syrk_kernel, dim3((unsigned)(1 + (nt * (nt + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
                                kb, Mp, ws, info, 1);
     }
+    if (phase_ev) (void)hipEventRecord(phase_ev[1], stream);
     hipLaunchKernelGGL(dense_finish_kernel, dim3(1), dim3(256), 0, stream, K, ld, N, Mp, out, info);
+    if (phase_ev) (void)hipEventRecord(phase_ev[2], stream);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 

@@ -56,6 +56,17 @@ class Context:
     def synchronize(self):
         _lib.check(_lib.lib().pioran_ctx_synchronize(self._h), self._h)
 
+    def set_option(self, key: str, value=None):
+        """Diagnostic switch of this context (pioran_ctx_set_option): "scan_config" (a configuration name, "wide", or
+        None), "no_wide" / "no_paired" / "no_mixed" / "force_fallback" (truthy = on).  Tests and tuning tools only."""
+        if value is None or value is False:
+            v = None
+        elif value is True:
+            v = b"1"
+        else:
+            v = str(value).encode()
+        _lib.check(_lib.lib().pioran_ctx_set_option(self._h, key.encode(), v), self._h)
+
     def event_record(self, slot: int):
         _lib.check(_lib.lib().pioran_ctx_event_record(self._h, slot), self._h)
 
@@ -98,6 +109,16 @@ class Context:
         _lib.check(_lib.lib().pioran_dense_nll(self._h, len(t), len(a), _ptr(a), _ptr(b), _ptr(c), _ptr(d), _ptr(t),
                                                _ptr(y), _ptr(sigma2), ctypes.byref(out), ctypes.byref(info)), self._h)
         return (out.value, info.value) if return_info else out.value
+
+    def dense_nll_timed(self, a, b, c, d, t, y, sigma2):
+        """dense_nll plus the event-timed phases of the call: (nll, info, {"build_ms", "factor_ms", "finish_ms"})."""
+        a, b, c, d, t, y, sigma2 = map(_f64, (a, b, c, d, t, y, sigma2))
+        out = ctypes.c_double()
+        info = ctypes.c_int32()
+        ms = (ctypes.c_float * 3)()
+        _lib.check(_lib.lib().pioran_dense_nll_timed(self._h, len(t), len(a), _ptr(a), _ptr(b), _ptr(c), _ptr(d), _ptr(t),
+                                                     _ptr(y), _ptr(sigma2), ctypes.byref(out), ctypes.byref(info), ms), self._h)
+        return out.value, info.value, {"build_ms": ms[0], "factor_ms": ms[1], "finish_ms": ms[2]}
 
     def dense_predict_cov(self, a, b, c, d, tau, t, sigma2, return_info=False):
         """predict_cov(cov, tau, t, sigma2): posterior covariance at tau, (M, M)   src/direct_solver.jl:28-69."""

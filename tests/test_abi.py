@@ -34,7 +34,7 @@ def test_library_is_gfx950_code_object():
 
 def test_version_and_strerror():
     L = pj._lib.lib()
-    assert L.pioran_abi_version() == 4
+    assert L.pioran_abi_version() == 5
     assert L.pioran_strerror(0) == b"ok"
     assert L.pioran_strerror(-4) == b"unsupported size"
     assert L.pioran_celerite_config_name(40) == b"rpl3_cbr2_nsrc7_p"   # column-paired variant for the standard row map
@@ -49,6 +49,18 @@ def test_argument_validation_without_gpu():
     assert L.pioran_dataset_create(None, 10, None, None, None, None) == -1
     assert L.pioran_celerite_logl_batch(None, 1, 1, None, None, None, None, 1, None, None, None, None, None, None) == -1
     assert L.pioran_celerite_logl_batch_dev(None, 1, None, None, None, None, None, None, None, None) == -1
+    assert L.pioran_ctx_set_option(None, b"no_wide", b"1") == -1
+    assert L.pioran_dense_nll_timed(None, 4, 1, None, None, None, None, None, None, None, None, None, None) == -1
+
+
+def test_launch_path_never_reads_the_environment():
+    """Diagnostic switches are context state (read from the environment once, at context creation)."""
+    csrc = ROOT / "pioran.jl_amd" / "csrc"
+    hits = [(f.name, i + 1) for f in csrc.glob("*") for i, line in enumerate(f.read_text().splitlines()) if "getenv(" in line]
+    assert hits and all(name == "capi.hip" for name, _ in hits)
+    capi = (csrc / "capi.hip").read_text()
+    body = capi[capi.index("static int ctx_create_impl"):capi.index("int pioran_ctx_create(int device")]
+    assert capi.count("getenv(") == body.count("getenv(")     # every read sits inside context creation
 
 
 def test_fails_loudly_without_gpu():

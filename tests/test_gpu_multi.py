@@ -1,0 +1,75 @@
+"""GPU test (-m gpu) of the process-per-GPU farm on REAL devices: bench.py under torch.distributed.run with one rank per
+GPU over RCCL — BASELINE.json configs[3] (N = 1e4, J = 20, 4096 draws per GPU, all-gather of log L).  Skipped on boxes
+with fewer than two GPUs; tests/test_farm.py covers the same sharding / gather logic with gloo on CPU, and
+tests/test_gpu_configs.py::test_config4_global_batch_on_one_gpu the 8-way cut at full size on one device.
+
+The launcher runs as a fresh CHILD process (subprocess): the pytest process itself is never replaced.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parents[1]
+NGPU = torch.cuda.device_count()          # counting devices does not initialise the GPU
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _bench(n, extra=()):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    base = [sys.executable]
+    if n > 1:
+        base += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                 "--master-port", str(_free_port())]
+    cmd = base + [str(ROOT / "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                  "--no-secondary", *extra]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.skipif(NGPU < 2, reason="needs at least two GPUs (RCCL ranks)")
+def test_bench_over_rccl_ranks():
+    n = min(8, NGPU)
+    one = _bench(1)
+    many = _bench(n, ["--verify-gather"])
+    assert many["n_gpus"] == n and many["config"]["global_batch"] == n * one["config"]["batch_per_gpu"]
+    # rank 0 re-evaluated every rank's batch on its own GPU: the gathered slices are the single-GPU values, bit for bit
+    assert many["gather_verified"] is True
+    assert many["status_ok_frac"] > 0.9
+    # weak scaling: the only exchange is a 32 KiB-per-rank all-gather overlapped with the next scan
+    assert many["value"] >= 0.75 * n * one["value"], (many["value"], one["value"])
+
+
+@pytest.mark.skipif(NGPU < 2, reason="needs at least two GPUs")
+def test_in_process_farm_over_real_devices():
+    """pioran_farm_* (one host thread + context per device inside ONE process) across distinct GPUs."""
+    import numpy as np
+
+    import pioran_jl_amd as pj
+    from oracle import oracle as O
+    t, y, yerr = O.synthetic_series(2000, seed=5)
+    B = 1000 * NGPU + 3
+    th = O.synthetic_theta(B, t, y, seed=6)
+    A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, 20, "SHO")
+    farm = pj.Farm(list(range(NGPU)), t, y, yerr ** 2)
+    got, st = farm.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+    farm.close()
+    one = pj.Dataset(t, y, yerr ** 2, pj.Context(0)).logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    ok = st == 0
+    assert ok.mean() > 0.9 and np.array_equal(got[ok], one[ok])

@@ -4,6 +4,7 @@
   (3) size-independent properties at BASELINE.json's full size (N = 1e4, J = 20).
 Tolerances are relative errors on log L, written next to each assert; north-star bar is 1e-8.
 """
+import ctypes
 import json
 import os
 
@@ -103,13 +104,13 @@ def _random_case(rng, N, J, B, per_draw_cd=False):
 
 
 @pytest.fixture(params=["throughput", "latency"])
-def layout(request):
-    """Small batches (B <= 256) take the one-draw-per-workgroup latency layout by default; PIORAN_NO_WIDE=1 sends
-    them through the throughput layouts (the ones large batches use), so both are checked on the same inputs."""
+def layout(request, ctx):
+    """Small batches (B <= 256) take the one-draw-per-workgroup latency layout by default; the context option "no_wide"
+    sends them through the throughput layouts (the ones large batches use), so both are checked on the same inputs."""
     if request.param == "throughput":
-        os.environ["PIORAN_NO_WIDE"] = "1"
+        ctx.set_option("no_wide", True)
     yield request.param
-    os.environ.pop("PIORAN_NO_WIDE", None)
+    ctx.set_option("no_wide", False)
 
 
 @pytest.mark.parametrize("J", [1, 2, 3, 5, 8, 10, 13, 16, 20, 21, 24, 27, 32, 40])
@@ -147,10 +148,10 @@ def test_rows_80_to_95_stay_register_resident(ctx, J, B):
     ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
     assert relerr(got, ref) < 1e-11
     try:
-        os.environ["PIORAN_FORCE_FALLBACK"] = "1"
+        ctx.set_option("force_fallback", True)
         fb = ds.logl_batch(A[:7], Bc[:7], C, Dd, mu=mu[:7], nu=nu[:7])
     finally:
-        os.environ.pop("PIORAN_FORCE_FALLBACK", None)
+        ctx.set_option("force_fallback", False)
     assert relerr(fb, ref[:7]) < 1e-11
     tau = np.linspace(t[0] - 1, t[-1] + 1, 33)
     pm = ds.predict(A[:2], Bc[:2], C, Dd, tau, mu=mu[:2], nu=nu[:2])
@@ -200,7 +201,7 @@ def test_latency_layout_edges(ctx):
     """celerite_wide.hip on its own: every prologue / tail length of the 4-deep record pipeline (N = 1..9), every
     RPL (R = 2J = 2..78), with and without mu / nu, per-draw series, and the not-positive-definite status."""
     rng = np.random.default_rng(12)
-    os.environ["PIORAN_SCAN_CONFIG"] = "wide"
+    ctx.set_option("scan_config", "wide")
     try:
         for N in range(1, 10):
             t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, 9, 3)
@@ -222,13 +223,13 @@ def test_latency_layout_edges(ctx):
         # not positive definite: same status and |D| semantics as the throughput layouts
         A2 = A.copy(); A2[1] = -5.0
         out, st = ds.logl_batch(A2, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
-        os.environ["PIORAN_SCAN_CONFIG"] = "rpl2_cbr1_nsrc13"
+        ctx.set_option("scan_config", "rpl2_cbr1_nsrc13")
         out_t, st_t = ds.logl_batch(A2, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
         assert (st == st_t).all() and st[1] != 0 and st[0] == 0
         ok = np.isfinite(out_t)
         assert (np.isfinite(out) == ok).all() and relerr(out[ok], out_t[ok]) < 1e-9
     finally:
-        os.environ.pop("PIORAN_SCAN_CONFIG", None)
+        ctx.set_option("scan_config", None)
 
 
 def test_drwcelerite_block_layout(ctx):
@@ -247,11 +248,11 @@ def test_drwcelerite_block_layout(ctx):
         ok = rst == 0
         assert ok.sum() > 100 and relerr(got[ok], ref[ok]) < 1e-9
         try:
-            os.environ["PIORAN_NO_PAIRED"] = "1"
+            ctx.set_option("no_paired", True)
             plain = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
             assert name() != "rpl4_cbr4_nsrc4_b5"
         finally:
-            os.environ.pop("PIORAN_NO_PAIRED", None)
+            ctx.set_option("no_paired", False)
         assert relerr(got[ok], plain[ok]) < 1e-9   # different row order => different summation order of q
 
 
@@ -269,7 +270,7 @@ def test_status_not_positive_definite(ctx):
 
 
 def test_all_kernel_configs_agree(ctx):
-    """Tuning alternatives (PIORAN_SCAN_CONFIG) compute the same thing."""
+    """Tuning alternatives (context option "scan_config") compute the same thing."""
     rng = np.random.default_rng(21)
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 300, 20, 21)
     ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
@@ -278,16 +279,16 @@ def test_all_kernel_configs_agree(ctx):
         for name in ("rpl3_cbr2_nsrc7_p", "rpl3_cbr2_nsrc8_p", "rpl3_cbr2_nsrc7", "rpl3_cbr2_nsrc8", "rpl3_cbr2_nsrc7_c", "rpl3_cbr4_nsrc4", "rpl4_cbr4_nsrc4",
                      "rpl4_cbr4_nsrc4_c", "rpl4_cbr4_nsrc4_asm", "rpl4_cbr4_nsrc4_asm_w2", "rpl5_cbr4_nsrc4",
                      "rpl5_cbr4_nsrc4_c", "rpl4_cbr4_nsrc4_p", "rpl4_cbr4_nsrc4_pc", "rpl3_cbr2_nsrc7_pc", "rpl5_cbr4_nsrc4_pc", "wide"):
-            os.environ["PIORAN_SCAN_CONFIG"] = name
-            if name != "wide":   # ("wide" = the latency layout of celerite_wide.hip, not an entry of the scan table)
-                assert pj._lib.lib().pioran_celerite_config_name(40).decode() == name
+            ctx.set_option("scan_config", name)
             got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+            if name != "wide":   # ("wide" = the latency layout of celerite_wide.hip, not an entry of the scan table)
+                assert pj._lib.lib().pioran_celerite_config_name(0).decode() == name   # what the launch actually ran on
             assert relerr(got, ref) < 1e-11, name
-        os.environ["PIORAN_FORCE_FALLBACK"] = "1"
+        ctx.set_option("force_fallback", True)
         assert relerr(ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu), ref) < 1e-11
     finally:
-        os.environ.pop("PIORAN_SCAN_CONFIG", None)
-        os.environ.pop("PIORAN_FORCE_FALLBACK", None)
+        ctx.set_option("scan_config", None)
+        ctx.set_option("force_fallback", False)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -467,6 +468,51 @@ def test_two_datasets_and_two_contexts(ctx):
     ds2.close(); ctx2.close()
 
 
+def test_prepared_state_survives_host_pointer_calls(ctx):
+    """The (c, d) declared by pioran_dataset_prepare belong to the *_dev entries and nothing else touches them: a mixed-mode
+    host call (per-draw rows), a theta-only call with another n_components / f-range, a plain host batch with other (c, d)
+    and a gradient call in between must leave a following *_dev launch on the caller's [B][J] arrays correct."""
+    import torch
+    rng = np.random.default_rng(81)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 200, 20, 300)
+    ds = pj.Dataset(t, y, s2, ctx)
+    ds.prepare(C, Dd)
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (A, Bc, mu, nu)]
+    dout = torch.empty(300, dtype=torch.float64, device=dev); dst = torch.zeros(300, dtype=torch.int32, device=dev)
+    ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+
+    def dev_call(B):
+        dout.fill_(float("nan")); torch.cuda.synchronize()
+        ds.logl_batch_dev(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, 0, dout.data_ptr(), dst.data_ptr())
+        ctx.synchronize()
+        assert relerr(dout[:B].cpu().numpy(), ref[:B]) < 1e-11 and (dst[:B].cpu().numpy() == 0).all()
+
+    dev_call(300)
+    # (1) mixed mode: 21 terms, one of them with per-draw (c, d)
+    C2 = np.tile(np.append(C, 0.3), (40, 1)); D2 = np.tile(np.append(Dd, 1.0), (40, 1))
+    C2[:, 20] = rng.uniform(0.1, 1.0, 40); D2[:, 20] = rng.uniform(0.5, 2.0, 40)
+    A2 = np.concatenate([A[:40], rng.uniform(0.1, 1, (40, 1))], axis=1); B2 = np.concatenate([Bc[:40], np.zeros((40, 1))], axis=1)
+    mixed = ds.logl_batch(A2, B2, C2, D2, mu=mu[:40], nu=nu[:40])
+    assert relerr(mixed, O.logl_batch(A2, B2, C2, D2, t, y, s2, mu[:40], nu[:40], nthreads=8)) < 1e-11
+    dev_call(300); dev_call(7)          # both layouts
+    # (2) theta-only entry: J = 12 DRWCelerite terms (24 celerite terms, another row map), another frequency range
+    th = np.column_stack([rng.uniform(0, 1.5, 16), np.exp(rng.uniform(-4, 0, 16)), rng.uniform(2, 4, 16)])
+    ds.logpdf_theta(pj.SingleBendingPowerLaw, th, 1.0, 1e-3, 3.0, 12, basis_function="DRWCelerite")
+    dev_call(300)
+    # (3) host batch with other shared (c, d) and (4) a gradient call
+    ds.logl_batch(A[:5, :7], Bc[:5, :7], C[:7] * 1.5, Dd[:7])
+    ds.logl_grad(A[:2, :9], Bc[:2, :9], C[:9] * 0.7, Dd[:9], mu=mu[:2], nu=nu[:2])
+    assert ds.J == 20
+    dev_call(300); dev_call(1)
+    # a per-draw term declared through prepare() is refused by the *_dev entry instead of reading a (0, 0, 1) table row
+    ds.prepare(C, Dd, real_term=[2] + [0] * 19)
+    L = pj._lib.lib()
+    v = ctypes.c_void_p
+    assert L.pioran_celerite_logl_batch_dev(ds._h, 4, v(d[0].data_ptr()), v(d[1].data_ptr()), None, None, None, None,
+                                            v(dout.data_ptr()), None) == -1
+
+
 def test_abi_argument_errors_on_gpu(ctx):
     L = pj._lib.lib()
     rng = np.random.default_rng(79)
@@ -594,10 +640,10 @@ def test_mixed_shared_and_per_draw_terms(ctx, J, npd, with_real, layout):
     got = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu)
     assert relerr(got, ref) < 1e-11
     try:
-        os.environ["PIORAN_NO_MIXED"] = "1"
+        ctx.set_option("no_mixed", True)
         gen = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu)
     finally:
-        os.environ.pop("PIORAN_NO_MIXED", None)
+        ctx.set_option("no_mixed", False)
     assert relerr(gen, ref) < 1e-11
     # per-draw series on top (Y, S2) and the shift transform go through the same path
     Y = y[None, :] + 0.01 * rng.standard_normal((B, N)); S2 = np.broadcast_to(s2, (B, N)) * rng.uniform(0.5, 2, (B, 1))

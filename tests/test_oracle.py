@@ -200,3 +200,52 @@ def test_complex_step_twin_matches_logl_and_finite_differences():
     # directional form: d/dmu = -sum_n d/dy_n, d/dnu = sum_n sigma2_n d/d(sigma2_n)
     assert abs(O.logl_dir(a, b, c, d, t, y, s2, dy=-np.ones(N)) + g["grad_y"].sum()) < 1e-9 * N
     assert abs(O.logl_dir(a, b, c, d, t, y, s2, ds2=s2) - g["grad_sigma2"] @ s2) < 1e-9 * N
+
+
+# ---- the three further stored runs of the reference (examples/ultranest/inference/*) ---------------------------------
+@pytest.fixture(scope="module")
+def runs(golden_dir):
+    return np.load(golden_dir / "ultranest_example_runs.npz")
+
+
+def example_run_inputs(runs, name, rows):
+    """(A, Bc, C, Dd, t, y, s2, mu, nu, Y) of the model each run was made with (oracle/make_golden.py:
+    make_example_runs_fixture): Y is None except for the CustomMean run, where it is the per-draw y - mean(t)."""
+    t, y, yerr, P = (runs[f"{name}_{k}"] for k in ("t", "y", "yerr", "params"))
+    P = P[rows]
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    A, Bc = np.empty((len(P), 20)), np.empty((len(P), 20))
+    for i, p in enumerate(P):
+        if name == "simu_double":
+            psd = lambda f, p=p: O.double_bending_power_law(f, *p[:5])  # noqa: E731
+            var = p[5]
+        else:
+            psd = lambda f, p=p: O.single_bending_power_law(f, *p[:3])  # noqa: E731
+            var = p[3]
+        A[i], Bc[i], C, Dd = O.approx(psd, f_min, f_max, 20, var)
+    if name == "simu_periodic":
+        amp, ph, T0 = P[:, 6:7], P[:, 7:8], P[:, 8:9]
+        Y = y[None, :] - amp * np.sin(2 * np.pi * t[None, :] / T0 + ph)   # CustomMean minus its constant part mu
+        return A, Bc, C, Dd, t, y, yerr ** 2, P[:, 5], P[:, 4], Y
+    k = 6 if name == "simu_double" else 4
+    return A, Bc, C, Dd, t, np.log(y), yerr ** 2 / y ** 2, P[:, k + 1], P[:, k], None
+
+
+@pytest.mark.parametrize("name", ["simu_single", "simu_double", "simu_periodic"])
+def test_reference_outputs_example_runs(runs, name):
+    """Every log-likelihood the reference computed in its three other stored runs — integrated-power normalisation,
+    DoubleBendingPowerLaw, a CustomMean sinusoid (examples/ultranest/*.jl) — is reproduced by the C oracle.
+    Median error 4e-15, 99.9 % of the points < 3e-11; the tail (8 of 20 297 points between 1e-10 and 4.4e-10) are prior
+    draws with alpha_2 -> 4, the SHO basis' limit, where approx's spectral solve is ill-conditioned and Julia's LU and
+    LAPACK's round differently — still 20x inside the 1e-8 north-star bar."""
+    logl = runs[f"{name}_logl"]
+    assert len(logl) > 6000
+    A, Bc, C, Dd, t, y, s2, mu, nu, Y = example_run_inputs(runs, name, slice(None))
+    if Y is None:
+        got = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+    else:
+        got = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * s2) for i in range(len(logl))])
+    rel = np.abs(got - logl) / np.abs(logl)
+    assert np.median(rel) < 1e-13
+    assert np.quantile(rel, 0.999) < 1e-10
+    assert rel.max() < 1e-9, rel.max()

@@ -42,14 +42,14 @@ def run(B, reps=5):
 
 res = {"workload": f"N={N}, {basis}-{J}, shared (c,d) table, HBM-resident inputs", "ms_per_call": {}}
 for mode in ("default", "throughput_only"):
-    if mode == "throughput_only": os.environ["PIORAN_NO_WIDE"] = "1"
+    ctx.set_option("no_wide", mode == "throughput_only")
     row = {}
     for B in (1, 4, 16, 64, 128, 256, 512, 1024):
         ms, err = run(B)
         row[str(B)] = round(ms, 3)
         assert err < 1e-8, (mode, B, err)
     res["ms_per_call"][mode] = row
-    os.environ.pop("PIORAN_NO_WIDE", None)
+    ctx.set_option("no_wide", False)
 R = pj.approx(pj.SingleBendingPowerLaw(0.82, 0.01, 3.3), f_min, f_max, J, 1.0, basis_function=basis)
 for n in (10_000, 1000):
     pj.logl(R.a, R.b, R.c, R.d, t[:n], y[:n], yerr[:n] ** 2, ctx=ctx)

@@ -27,7 +27,7 @@ for B in Bs:
     outs = {}
     for rnd in range(4):
         for c in cfgs:
-            os.environ["PIORAN_SCAN_CONFIG"] = c
+            ctx.set_option("scan_config", c)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             ds.logl_batch_dev(B, dA.data_ptr(), dB.data_ptr(), dmu.data_ptr(), dnu.data_ptr(), 0, 0, dout.data_ptr(), 0)
