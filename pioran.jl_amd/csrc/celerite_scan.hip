@@ -336,12 +336,52 @@ __device__ __forceinline__ double row16_sum(double x)
     return x;
 }
 
-template <int CBR>
-__device__ __forceinline__ double group_sum(double x)
+// sum over lanes 0 .. NSRC-1 of each DPP row, delivered to all 16 lanes: acc += bcast_N(x) * 1.0 as v_fmac_f64_dpp
+// row_newbcast:N — ONE 4-cycle DP instruction per contributing lane (two interleaved chains), where the butterfly above
+// costs four stages of two 32-bit DPP moves (the DP ALU has no other DPP control than row_newbcast; tools/valu_probe.hip:
+// 6.3 cycles per v_mov_b32_dpp) plus an add.  Lanes >= NSRC are never read, so no "contributes" mask is needed.
+template <int N>
+__device__ __forceinline__ void bcast_acc(double& acc, double x, double one)
 {
-    x = row16_sum(x);
-    if constexpr (CBR >= 2) x += __shfl_xor(x, 16);
-    if constexpr (CBR >= 4) x += __shfl_xor(x, 32);
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%c3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(one), "i"(N));
+}
+
+template <int NSRC>
+__device__ __forceinline__ double row_sum_sources(double x, double one)
+{
+    double a0, a1 = 0.0;
+    // s_nop 1: x was just written by a VALU instruction and is read through DPP (2 wait states)
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(a0) : "v"(x));
+    static_for<1, NSRC>([&](auto Nc) {
+        constexpr int N = decltype(Nc)::value;
+        if constexpr (N & 1) bcast_acc<N>(a1, x, one);
+        else bcast_acc<N>(a0, x, one);
+    });
+    return NSRC > 1 ? a0 + a1 : a0;
+}
+
+// u'q over one draw: every row is counted once (physical lanes l < NSRC of each of the CBR DPP rows)
+// value of x in the lane at byte address `addr4` (= 4 * lane) of this wavefront: two ds_bpermute_b32 (LDS crossbar, no VALU issue)
+__device__ __forceinline__ double lane_fetch(double x, int addr4)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(addr4, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr4, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
+// p1, p2: any lane of the DPP row across (r ^ 1, r ^ 2) — after the row sum all 16 lanes of a row hold its total
+// (the inline-asm row sum only in the DPP-folded kernels: volatile asm pins the compiler-scheduled variants' loads)
+template <int CBR, int NSRC, bool ASM_DPP>
+__device__ __forceinline__ double group_sum(double x, bool contributes, double one, int p1, int p2)
+{
+    if constexpr (ASM_DPP && NSRC <= 10) {
+        x = row_sum_sources<NSRC>(x, one);
+    } else {
+        if (!contributes) x = 0.0;
+        x = row16_sum(x);
+    }
+    if constexpr (CBR >= 2) x += lane_fetch(x, p1);
+    if constexpr (CBR >= 4) x += lane_fetch(x, p2);
     return x;
 }
 
@@ -376,7 +416,8 @@ template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false, int
           int NPB = 0>
 __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanParams p)
 {
-    static_assert(NPB == 0 || (!PAIRED && !ASM_DPP && 2 * NPB < NSRC * RPL), "block layout: compiler-scheduled, unpaired base");
+    static_assert(NPB == 0 || (!PAIRED && 2 * NPB < NSRC * RPL && (!ASM_DPP || RPL % 2 == 0)),
+                  "block layout: unpaired base; the DPP-folded form needs both columns of a pair in one source lane");
     static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
     constexpr int G = 16 * CBR;          // lanes per draw
     constexpr int EPW = 64 / G;          // draws per wavefront
@@ -457,14 +498,13 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     for (int j = 0; j < J; ++j) suma += p.A[b * J + j];
     const double mu = p.mu ? p.mu[b] : 0.0;
     const double nu = p.nu ? p.nu[b] : 1.0;
-    const bool has_nu = p.nu != nullptr;
     const bool own_series = p.Y != nullptr;   // per-draw y / sigma2 (wave-uniform)
-    const double* yv = own_series ? p.Y + b * N : p.y;
-    const double* sv = own_series ? p.S2 + b * N : p.s2;
+    [[maybe_unused]] const double* yv = own_series ? p.Y + b * N : p.y;     // per-draw (c, d) path only
+    [[maybe_unused]] const double* sv = own_series ? p.S2 + b * N : p.s2;
 
-    int p1 = 0, p2 = 0;  // lanes holding the same rows in the other column blocks
-    if constexpr (CBR >= 2) p1 = e * G + (r ^ 1) * 16 + ((lam - NSRC * (r ^ 1)) & 15);
-    if constexpr (CBR >= 4) p2 = e * G + (r ^ 2) * 16 + ((lam - NSRC * (r ^ 2)) & 15);
+    [[maybe_unused]] int p1 = 0, p2 = 0;  // byte addresses (ds_bpermute) of the lanes holding the same rows in the other column blocks
+    if constexpr (CBR >= 2) p1 = 4 * (e * G + (r ^ 1) * 16 + ((lam - NSRC * (r ^ 1)) & 15));
+    if constexpr (CBR >= 4) p2 = 4 * (e * G + (r ^ 2) * 16 + ((lam - NSRC * (r ^ 2)) & 15));
 
     // Table record of step n: [v x Rp | x x Rp | phi x Rp | y_n, sigma2_n | per-draw block]; N + 1 records (the last
     // one is a readable dummy so the prefetch of step n + 1 needs no bounds test).  The per-draw block (mixed mode:
@@ -480,6 +520,27 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     constexpr bool LANE_OFFS = MIXED || RPL <= 3;
     [[maybe_unused]] int vo_v[RPL], vo_x[LANE_OFFS ? RPL : 1], vo_p[LANE_OFFS ? RPL : 1];
     [[maybe_unused]] const int step_bytes = (int)p.rec_stride * 8;
+    // y_n, sigma2_n of the step: the shared series sit in the step record (columns 3 Rp, 3 Rp + 1); per-draw series are
+    // [B][N] arrays read through a buffer resource based at the wavefront's FIRST draw (wave-uniform base in SGPRs,
+    // per-lane draw offset in one VGPR, step offset in an SGPR): the same two loads either way, no 64-bit per-lane
+    // pointers and no branch in the loop.  The prefetch of step N reads one element past a draw's series: the next draw's
+    // first element, or zero from the bounds check of the resource at the very end of the array — never used.
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_y = rs, rs_s = rs;
+    [[maybe_unused]] int vo_y = 3 * Rp * 8, vo_s = 3 * Rp * 8 + 8, y_step = step_bytes;
+    if constexpr (SHARED_TAB) {
+        if (own_series) {
+            int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * EPW;
+            b0 = b0 < p.B ? b0 : p.B - 1;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b0), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b0 >> 32));
+            const int64_t b0u = (int64_t)(((uint64_t)hi << 32) | lo);
+            const int64_t rem = (p.B - b0u) * N * 8;
+            const int recs = rem > 0x7ffffff0LL ? 0x7ffffff0 : (int)rem;
+            rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.Y + b0u * N), 0, recs, 0x00020000);
+            rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.S2 + b0u * N), 0, recs, 0x00020000);
+            vo_y = vo_s = (int)((b - b0u) * N * 8);
+            y_step = 8;
+        }
+    }
     if constexpr (SHARED_TAB) {
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
@@ -507,14 +568,9 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                     in.ph[i] = buf_load_f64(rs, vo_v[i], soff + 2 * Rp * 8);
                 }
             }
-            if (own_series) {
-                const int64_t nn = n < N ? n : N - 1;
-                in.y = yv[nn];
-                in.s2 = sv[nn];
-            } else {
-                in.y = buf_load_f64(rs, 0, soff + 3 * Rp * 8);
-                in.s2 = buf_load_f64(rs, 0, soff + 3 * Rp * 8 + 8);
-            }
+            const int ysoff = (int)n * y_step;
+            in.y = buf_load_f64(rs_y, vo_y, ysoff);
+            in.s2 = buf_load_f64(rs_s, vo_s, ysoff);
         } else {
             const int64_t nn = n < N ? n : N - 1;
             const double tn = p.t[nn];
@@ -548,9 +604,12 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 #pragma unroll
         for (int i = 0; i < RPL; ++i) S[c][i] = 0.0;
     double w[RPL];
-    double Dn = suma + (has_nu ? nu * bufA.s2 : bufA.s2);
+    double Dn = fma(nu, bufA.s2, suma);
+    double one = 1.0;
+    asm volatile("" : "+v"(one));   // keep 1.0 in a VGPR pair (DPP multiplier operand of the row sums)
     double rD = recip_f64(Dn);
-    if (isy) bufA.v[YS] = bufA.y - mu;       // z_1 = y_1      :128
+    const double ysel = isy ? 1.0 : 0.0;     // the y row's table entry is v = 0: v_y = ysel (y_n - mu) + v, no selects
+    bufA.v[YS] = fma(ysel, bufA.y - mu, bufA.v[YS]);   // z_1 = y_1      :128
     double num[RPL];                          // (v - q) of the last step = D_n W_n, the `dn` of :73 up to one rounding
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
@@ -577,10 +636,23 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             g[i] = num[i];                          // dn = D[n-1] * V[j,n-1]   :73
             qt[i] = 0.0;
         }
-        if (isy) in.v[YS] = in.y - mu;
+        in.v[YS] = fma(ysel, in.y - mu, in.v[YS]);
 
         // ---- S update + q = S u over this DPP row's column block ----
-        if constexpr (PAIRED && ASM_DPP) {
+        if constexpr (NPB > 0 && ASM_DPP) {
+            // block layout, DPP-folded: the first 2 NPB columns of the block are the (cos, sin) pairs of NPB two-row terms
+            // (phi_i phi_k formed once per pair), the rest single rows of one-row terms and the spare slot
+            static_for<0, NPB>([&](auto Pc) {
+                constexpr int c = 2 * decltype(Pc)::value;
+                double pp[RPL];
+                PairFirst<RPL, c / RPL>::run(S[c], qt, g, in.ph, w[c % RPL], u[c % RPL], in.ph[c % RPL], pp);
+                PairSecond<RPL, (c + 1) / RPL>::run(S[c + 1], qt, g, w[(c + 1) % RPL], u[(c + 1) % RPL], pp);
+            });
+            static_for<2 * NPB, NC>([&](auto Cc) {
+                constexpr int c = decltype(Cc)::value;
+                ColBlock<RPL, c / RPL>::run(S[c], qt, g, in.ph, w[c % RPL], u[c % RPL], in.ph[c % RPL]);
+            });
+        } else if constexpr (PAIRED && ASM_DPP) {
             // column pairs (c, c+1), c even: same phi_k, so phi_i * phi_k is formed once per pair
             static_for<0, NC / 2>([&](auto Pc) {
                 constexpr int c = 2 * decltype(Pc)::value;
@@ -624,19 +696,18 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         }
         if constexpr (CBR >= 2) {
 #pragma unroll
-            for (int i = 0; i < RPL; ++i) qt[i] += __shfl(qt[i], p1);
+            for (int i = 0; i < RPL; ++i) qt[i] += lane_fetch(qt[i], p1);
         }
         if constexpr (CBR >= 4) {
 #pragma unroll
-            for (int i = 0; i < RPL; ++i) qt[i] += __shfl(qt[i], p2);
+            for (int i = 0; i < RPL; ++i) qt[i] += lane_fetch(qt[i], p2);
         }
         double sp = 0.0;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) sp += u[i] * qt[i];        // u'Su                       :83,88
-        if (!contributes) sp = 0.0;
-        const double s = group_sum<CBR>(sp);
+        const double s = group_sum<CBR, NSRC, ASM_DPP>(sp, contributes, one, p1, p2);
 
-        Dn = suma + (has_nu ? nu * in.s2 : in.s2) - s;           // :92
+        Dn = fma(nu, in.s2, suma) - s;                           // :92  (nu = 1 without a per-draw scale: exact)
         rD = recip_f64(Dn);
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
@@ -684,10 +755,10 @@ void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 }
 
 // block layout (NPB pairs per block): shared-table launches without per-draw rows only
-template <int RPL, int CBR, int NSRC, int MINW, int NPB>
+template <int RPL, int CBR, int NSRC, int MINW, int NPB, bool ASM_DPP = false>
 void launch_blocked(const ScanParams& p, dim3 grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, false, MINW, false, false, NPB>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, ASM_DPP, MINW, false, false, NPB>), grid, dim3(256), 0, st, p);
 }
 
 struct ScanConfig {
@@ -706,42 +777,31 @@ struct ScanConfig {
 };
 
 #define CFG(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC, RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC, true>}
-#define CFG_C(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC "_c", RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC, false>}
-// preference order: first entry whose capacity >= R wins (unless PIORAN_SCAN_CONFIG names another).
-// Default entries use the DPP-folded column block (ColBlock); "_c" = same mapping, compiler-scheduled builtins.
+#define CFG_P(RPL, CBR, NSRC, MINW) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC "_p", RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC, true, MINW, true>, true}
+// preference order: first entry whose capacity >= R wins (unless the context option "scan_config" names another).
+// Every entry uses the DPP-folded column blocks (ColBlock / PairFirst / PairSecond); the compiler-scheduled builtin
+// variants of round 1 were dropped when the DPP-folded ones became the faster choice in every row range
+// (SHO-30: 140 k vs 116 k evals/s, SHO-39: 60 k vs 52 k; profiles/r02_scan_variants.txt).
 const ScanConfig kConfigs[] = {
     CFG(1, 1, 5),  CFG(1, 1, 9),  CFG(1, 1, 13), CFG(1, 1, 16),           // R <= 15
     CFG(2, 1, 9),  CFG(2, 1, 11), CFG(2, 1, 13), CFG(2, 1, 15), CFG(2, 1, 16),  // R <= 31
     CFG(3, 2, 6),  CFG(3, 2, 7),  CFG(3, 2, 8),                           // R <= 47
-    // R <= 63: 256 registers/lane (2 waves per SIMD) beats the AGPR-spilling 1-wave build; compiler-scheduled
-    {"rpl4_cbr4_nsrc4", 4, 4, 4, &launch_cfg<4, 4, 4, false, 2>},
+    {"rpl4_cbr4_nsrc4", 4, 4, 4, &launch_cfg<4, 4, 4, true, 2>},          // R <= 63: 256 registers/lane, 2 waves per SIMD
     CFG(5, 4, 4),                                                         // R <= 79
     // column-paired variants (standard row map only; picked automatically by pick_config when applicable)
-    {"rpl3_cbr2_nsrc7_p", 3, 2, 7, &launch_cfg<3, 2, 7, true, 1, true>, true},
-    {"rpl3_cbr2_nsrc8_p", 3, 2, 8, &launch_cfg<3, 2, 8, true, 1, true>, true},
-    {"rpl3_cbr2_nsrc6_p", 3, 2, 6, &launch_cfg<3, 2, 6, true, 1, true>, true},
-    {"rpl1_cbr1_nsrc5_p", 1, 1, 5, &launch_cfg<1, 1, 5, true, 1, true>, true},
-    {"rpl1_cbr1_nsrc9_p", 1, 1, 9, &launch_cfg<1, 1, 9, true, 1, true>, true},
-    {"rpl1_cbr1_nsrc13_p", 1, 1, 13, &launch_cfg<1, 1, 13, true, 1, true>, true},
-    {"rpl1_cbr1_nsrc16_p", 1, 1, 16, &launch_cfg<1, 1, 16, true, 1, true>, true},
-    {"rpl2_cbr1_nsrc9_p", 2, 1, 9, &launch_cfg<2, 1, 9, true, 1, true>, true},
-    {"rpl2_cbr1_nsrc11_p", 2, 1, 11, &launch_cfg<2, 1, 11, true, 1, true>, true},
-    {"rpl2_cbr1_nsrc13_p", 2, 1, 13, &launch_cfg<2, 1, 13, true, 1, true>, true},
-    {"rpl2_cbr1_nsrc15_p", 2, 1, 15, &launch_cfg<2, 1, 15, true, 1, true>, true},
-    {"rpl2_cbr1_nsrc16_p", 2, 1, 16, &launch_cfg<2, 1, 16, true, 1, true>, true},
-    {"rpl4_cbr4_nsrc4_p", 4, 4, 4, &launch_cfg<4, 4, 4, true, 2, true>, true, false},   // asm pairs: 113k evals/s (SHO-30)
-    {"rpl3_cbr2_nsrc7_pc", 3, 2, 7, &launch_cfg<3, 2, 7, false, 1, true>, true, false},   // tuning alternative of the headline config
-    {"rpl5_cbr4_nsrc4_pc", 5, 4, 4, &launch_cfg<5, 4, 4, false, 1, true>, true},   // 52.2k vs 49.4k evals/s (SHO-39)
+    CFG_P(3, 2, 7, 1), CFG_P(3, 2, 8, 1), CFG_P(3, 2, 6, 1),
+    CFG_P(1, 1, 5, 1), CFG_P(1, 1, 9, 1), CFG_P(1, 1, 13, 1), CFG_P(1, 1, 16, 1),
+    CFG_P(2, 1, 9, 1), CFG_P(2, 1, 11, 1), CFG_P(2, 1, 13, 1), CFG_P(2, 1, 15, 1), CFG_P(2, 1, 16, 1),
+    CFG_P(4, 4, 4, 2), CFG_P(5, 4, 4, 1),
     // DRWCelerite with 20 components: 20 complex + 20 real terms = 5 pairs + 5 singles + 1 spare in each of the 4 blocks
-    {"rpl4_cbr4_nsrc4_b5", 4, 4, 4, &launch_blocked<4, 4, 4, 2, 5>, false, true, 5},
-    {"rpl4_cbr4_nsrc4_pc", 4, 4, 4, &launch_cfg<4, 4, 4, false, 2, true>, true},  // compiler-scheduled, phi products shared per pair: 116k vs 106k (SHO-30)
+    {"rpl4_cbr4_nsrc4_b5a", 4, 4, 4, &launch_blocked<4, 4, 4, 2, 5, true>, false, true, 5},
     // alternatives kept for tuning runs (selected by name)
-    CFG(3, 4, 4), CFG(2, 2, 8), CFG_C(3, 2, 7), CFG_C(4, 4, 4), CFG_C(2, 1, 16), CFG_C(1, 1, 16), CFG_C(5, 4, 4),
-    {"rpl4_cbr4_nsrc4_asm", 4, 4, 4, &launch_cfg<4, 4, 4, true, 1>},
-    {"rpl4_cbr4_nsrc4_asm_w2", 4, 4, 4, &launch_cfg<4, 4, 4, true, 2>},
+    CFG(3, 4, 4), CFG(2, 2, 8),
+    {"rpl4_cbr4_nsrc4_w1", 4, 4, 4, &launch_cfg<4, 4, 4, true, 1>},
+    {"rpl4_cbr4_nsrc4_p_w1", 4, 4, 4, &launch_cfg<4, 4, 4, true, 1, true>, true, false},
 };
 #undef CFG
-#undef CFG_C
+#undef CFG_P
 constexpr int kNumPreferred = 14;
 
 // does the block layout of `c` hold this row structure?  (shared table, no per-draw rows)

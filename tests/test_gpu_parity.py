@@ -240,7 +240,7 @@ def test_drwcelerite_block_layout(ctx):
     th = O.synthetic_theta(300, t, y)
     ds = pj.Dataset(t, y, yerr ** 2, ctx)
     name = lambda: pj._lib.lib().pioran_celerite_config_name(0).decode()
-    for ncomp, expect in ((20, "rpl4_cbr4_nsrc4_b5"), (12, "rpl3_cbr2_nsrc7")):
+    for ncomp, expect in ((20, "rpl4_cbr4_nsrc4_b5a"), (12, "rpl3_cbr2_nsrc7")):
         A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, ncomp, "DRWCelerite")
         got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
         assert name() == expect, name()
@@ -250,7 +250,7 @@ def test_drwcelerite_block_layout(ctx):
         try:
             ctx.set_option("no_paired", True)
             plain = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
-            assert name() != "rpl4_cbr4_nsrc4_b5"
+            assert not name().startswith("rpl4_cbr4_nsrc4_b5")
         finally:
             ctx.set_option("no_paired", False)
         assert relerr(got[ok], plain[ok]) < 1e-9   # different row order => different summation order of q
@@ -276,9 +276,8 @@ def test_all_kernel_configs_agree(ctx):
     ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
     ds = pj.Dataset(t, y, s2, ctx)
     try:
-        for name in ("rpl3_cbr2_nsrc7_p", "rpl3_cbr2_nsrc8_p", "rpl3_cbr2_nsrc7", "rpl3_cbr2_nsrc8", "rpl3_cbr2_nsrc7_c", "rpl3_cbr4_nsrc4", "rpl4_cbr4_nsrc4",
-                     "rpl4_cbr4_nsrc4_c", "rpl4_cbr4_nsrc4_asm", "rpl4_cbr4_nsrc4_asm_w2", "rpl5_cbr4_nsrc4",
-                     "rpl5_cbr4_nsrc4_c", "rpl4_cbr4_nsrc4_p", "rpl4_cbr4_nsrc4_pc", "rpl3_cbr2_nsrc7_pc", "rpl5_cbr4_nsrc4_pc", "wide"):
+        for name in ("rpl3_cbr2_nsrc7_p", "rpl3_cbr2_nsrc8_p", "rpl3_cbr2_nsrc7", "rpl3_cbr2_nsrc8", "rpl3_cbr4_nsrc4", "rpl4_cbr4_nsrc4",
+                     "rpl4_cbr4_nsrc4_w1", "rpl5_cbr4_nsrc4", "rpl4_cbr4_nsrc4_p", "rpl4_cbr4_nsrc4_p_w1", "rpl5_cbr4_nsrc4_p", "wide"):
             ctx.set_option("scan_config", name)
             got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
             if name != "wide":   # ("wide" = the latency layout of celerite_wide.hip, not an entry of the scan table)
