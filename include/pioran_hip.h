@@ -61,6 +61,9 @@ int pioran_ctx_create(int device, pioran_ctx** out);
 int pioran_ctx_create_on_stream(int device, void* hip_stream, pioran_ctx** out);
 int pioran_ctx_destroy(pioran_ctx* ctx);
 int pioran_ctx_synchronize(pioran_ctx* ctx);
+/* Releases every scratch buffer the context has grown (staging, gradient / prediction workspaces, the dense slab); they are
+ * re-allocated on demand.  Data sets and their tables are not touched. */
+int pioran_ctx_trim(pioran_ctx* ctx);
 /* Diagnostic switches (none is needed in production; tests and tuning runs use them to pin a code path):
  *   "scan_config"     name of a throughput configuration of the scan, or "wide" = latency layout for any batch; NULL/"" = automatic
  *   "no_wide" / "no_paired" / "no_mixed" / "force_fallback"   value "1" disables the latency layout / the column-paired
@@ -155,22 +158,28 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
                             const double* Dd, const double* mu, const double* nu, int64_t M, const double* tau,
                             double* mean_out, int32_t* status);
 /* log L and its gradient (what ForwardDiff obtains through the generic `logl`,
- * src/celerite_solver.jl:316, test/test_likelihood.jl:55-60) by reverse mode through the recurrence, for B draws with
- * shared (c, d):  grad_a, grad_b [B][J] = dlogL/da_j, dlogL/db_j;  grad_nu, grad_mu [B] (may be NULL);
- * grad_y, grad_sigma2 [B][N] (may be NULL) = dlogL/dy_n and dlogL/dsigma2_n of the series in the data set — what a
- * model that transforms the data per draw (the sampled shift of docs/src/ultranest.md:199-205) chains through.
- * (c, d) are not differentiated: with `approx` they depend on (f_min, f_max) only. */
+ * src/celerite_solver.jl:316, test/test_likelihood.jl:55-60) by reverse mode through the recurrence, for B draws:
+ *   grad_a, grad_b [B][J] = dlogL/da_j, dlogL/db_j;
+ *   grad_c, grad_d [B][J] (may be NULL) = dlogL/dc_j, dlogL/dd_j — what QPO features (src/psd.jl:15-27), CARMA kernels
+ *       (src/CARMA.jl:98-143) and free Celerite terms need; per draw also when (c, d) are shared (sum over b for a common parameter);
+ *   grad_nu, grad_mu [B] (may be NULL);
+ *   grad_y, grad_sigma2 [B][N] (may be NULL) = dlogL/dy_n and dlogL/dsigma2_n of the series in the data set — what a
+ *       model that transforms the data per draw (the sampled shift of docs/src/ultranest.md:199-205) chains through.
+ * C, Dd: [J] when cd_shared != 0, else [B][J] (each draw is then evaluated as its own one-draw batch).
+ * Memory: the forward pass keeps the R x R state only at checkpoints (every ~2 sqrt(N) steps) and the reverse pass replays one
+ * segment at a time: ~8 MB of workspace per draw at N = 1e4, J = 20; draws are processed in chunks sized to the free memory.
+ * The workspace stays in the context for the next call; pioran_ctx_trim releases it. */
 int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
-                              const double* Dd, const double* mu, const double* nu, double* out, int32_t* status,
-                              double* grad_a, double* grad_b, double* grad_nu, double* grad_mu, double* grad_y,
-                              double* grad_sigma2);
+                              const double* Dd, int cd_shared, const double* mu, const double* nu, double* out,
+                              int32_t* status, double* grad_a, double* grad_b, double* grad_c, double* grad_d,
+                              double* grad_nu, double* grad_mu, double* grad_y, double* grad_sigma2);
 /* The same for the shifted log-flux models (docs/src/turing.md:205-230: c ~ LogUniform(...), y = log.(y .- c),
  * sigma2 = nu sigma.^2 ./ (y .- c).^2): the data set holds the raw flux and yerr^2, the transform runs on the device as in
  * pioran_celerite_logl_batch_shift, and grad_shift [B] = dlogL/dc_b comes out of the series gradients by the chain rule. */
 int pioran_celerite_logl_grad_shift(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
-                                    const double* Dd, const double* mu, const double* nu, const double* shift, double* out,
-                                    int32_t* status, double* grad_a, double* grad_b, double* grad_nu, double* grad_mu,
-                                    double* grad_shift);
+                                    const double* Dd, int cd_shared, const double* mu, const double* nu, const double* shift,
+                                    double* out, int32_t* status, double* grad_a, double* grad_b, double* grad_c,
+                                    double* grad_d, double* grad_nu, double* grad_mu, double* grad_shift);
 /* simulate (src/celerite_solver.jl:497-513 -> sim :515-549; rand(f(t, sigma2)) of src/scalable_GP.jl:137-146):
  * realisations y_b = L_b D_b^(1/2) q_b of the GP with kernel (a_b, b_b, c, d) + diag(sigma2) at the times t, from
  * caller-supplied standard-normal draws q [B][N] (the reference draws them with its rng, :528).  y_out [B][N]. */

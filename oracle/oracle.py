@@ -70,6 +70,8 @@ def lib():
         L.oracle_kappa.argtypes = [i64, _dp, _dp, _dp, _dp, ctypes.c_double]
         L.oracle_logl_complex.restype = ctypes.c_double
         L.oracle_logl_complex.argtypes = [i64, i64] + [_dp] * 11 + [_dp]
+        L.oracle_logl_complex_cd.restype = ctypes.c_double
+        L.oracle_logl_complex_cd.argtypes = [i64, i64] + [_dp] * 13 + [_dp]
         L.oracle_predict.restype = None
         L.oracle_predict.argtypes = [i64, i64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, i64, _dp, _dp]
         L.oracle_sim.restype = None
@@ -179,16 +181,17 @@ def logl_numpy(a, b, c, d, t, y, sigma2):
     return -0.5 * ld - 0.5 * N * np.log(2 * np.pi) - 0.5 * q2
 
 
-def logl_grad(a, b, c, d, t, y, sigma2, series=False, h=1e-30):
+def logl_grad(a, b, c, d, t, y, sigma2, series=False, h=1e-30, cd=False):
     """Exact derivatives of logl (src/celerite_solver.jl:312-334) by the complex step on the complex twin of the C
-    restatement: d/da_j, d/db_j (J each) and, with series=True, d/dy_n, d/dsigma2_n (N each; 2N more evaluations)."""
+    restatement: d/da_j, d/db_j (J each), with cd=True d/dc_j, d/dd_j and, with series=True, d/dy_n, d/dsigma2_n (N each;
+    2N more evaluations)."""
     a, b, c, d, t, y, sigma2 = (np.ascontiguousarray(v, dtype=np.float64) for v in (a, b, c, d, t, y, sigma2))
     J, N = len(a), len(t)
     P = lambda v: None if v is None else v.ctypes.data_as(_dp)
     im = ctypes.c_double()
-    def run(a_im=None, b_im=None, y_im=None, s_im=None):
-        lib().oracle_logl_complex(N, J, P(a), P(a_im), P(b), P(b_im), P(c), P(d), P(t), P(y), P(y_im), P(sigma2), P(s_im),
-                                  ctypes.byref(im))
+    def run(a_im=None, b_im=None, y_im=None, s_im=None, c_im=None, d_im=None):
+        lib().oracle_logl_complex_cd(N, J, P(a), P(a_im), P(b), P(b_im), P(c), P(c_im), P(d), P(d_im), P(t), P(y), P(y_im),
+                                     P(sigma2), P(s_im), ctypes.byref(im))
         return im.value / h
     def sweep(n, key):
         out = np.empty(n)
@@ -197,6 +200,8 @@ def logl_grad(a, b, c, d, t, y, sigma2, series=False, h=1e-30):
             out[k] = run(**{key: e})
         return out
     res = {"grad_a": sweep(J, "a_im"), "grad_b": sweep(J, "b_im")}
+    if cd:
+        res["grad_c"] = sweep(J, "c_im"); res["grad_d"] = sweep(J, "d_im")
     if series:
         res["grad_y"] = sweep(N, "y_im"); res["grad_sigma2"] = sweep(N, "s_im")
     return res

@@ -25,6 +25,7 @@ SIGNATURES = {
     "pioran_ctx_create_on_stream": (ctypes.c_int, [ctypes.c_int, c_void_p, ctypes.POINTER(c_void_p)]),
     "pioran_ctx_destroy": (ctypes.c_int, [c_void_p]),
     "pioran_ctx_synchronize": (ctypes.c_int, [c_void_p]),
+    "pioran_ctx_trim": (ctypes.c_int, [c_void_p]),
     "pioran_ctx_set_option": (ctypes.c_int, [c_void_p, ctypes.c_char_p, ctypes.c_char_p]),
     "pioran_ctx_event_record": (ctypes.c_int, [c_void_p, ctypes.c_int]),
     "pioran_ctx_event_elapsed_ms": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
@@ -46,8 +47,8 @@ SIGNATURES = {
                                                  c_void_p, c_void_p]),
     "pioran_celerite_predict": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, i64, c_void_p, c_void_p, c_void_p]),
-    "pioran_celerite_logl_grad": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 14),
-    "pioran_celerite_logl_grad_shift": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 14),
+    "pioran_celerite_logl_grad": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 4 + [ctypes.c_int] + [c_void_p] * 12),
+    "pioran_celerite_logl_grad_shift": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 4 + [ctypes.c_int] + [c_void_p] * 12),
     "pioran_celerite_simulate": (ctypes.c_int, [c_void_p, i64, i64, i64] + [c_void_p] * 8),
     "pioran_celerite_config_name": (ctypes.c_char_p, [i64]),
     "pioran_farm_create": (ctypes.c_int, [ctypes.c_int, c_void_p, i64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),
@@ -69,6 +70,31 @@ class PioranHipError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's): whichever
+    copy is loaded first serves every later user, and torch finds no GPU when it ends up on the other one.  If torch is
+    installed but not imported yet, load ITS copy now, so that `import torch` after the first pioran call still works
+    (bench.py, farm.py and the tests use torch for device buffers and torch.distributed).  Without torch: nothing to do."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for d in spec.submodule_search_locations:
+        cand = Path(d) / "lib" / "libamdhip64.so"
+        if cand.exists():
+            try:
+                ctypes.CDLL(str(cand), mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def lib():
     """Loads libpioran_hip.so; raises if it has not been built (python pioran.jl_amd/build.py)."""
     global _lib
@@ -77,6 +103,7 @@ def lib():
             raise PioranHipError(
                 f"{LIB_PATH} not found: build the HIP library first (python pioran.jl_amd/build.py or "
                 f"__graft_entry__.build()). There is no CPU fallback.")
+        _share_hip_runtime_with_torch()
         L = ctypes.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the ABI is incomplete

@@ -18,6 +18,9 @@ struct pioran_ctx {
     hipEvent_t ev[16] = {};
     std::string last_err;
     ScanOptions opt{};   // diagnostic switches: environment at creation, then pioran_ctx_set_option
+    // second stream + events of the gradient's reverse pass (replay of one segment overlaps the adjoint of the next); lazy
+    hipStream_t aux = nullptr;
+    hipEvent_t gev[5] = {};
     // growable device staging for the host-pointer entry points
     struct Buf {
         void* p = nullptr;
@@ -254,8 +257,26 @@ int pioran_ctx_destroy(pioran_ctx* ctx)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->gev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return PIORAN_OK;
+}
+
+int pioran_ctx_trim(pioran_ctx* ctx)
+{
+    if (!ctx) return PIORAN_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
+                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift};
+    for (auto* b : bufs) {
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+    }
     return PIORAN_OK;
 }
 
@@ -769,26 +790,34 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
 }
 
 // shift / grad_shift != nullptr: the shifted log-flux models (the data set holds raw flux and yerr^2); grad_y / grad_sigma2
-// then refer to the TRANSFORMED series of each draw
-static int logl_grad_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
-                          const double* Dd, const double* mu, const double* nu, const double* shift, double* out,
-                          int32_t* status, double* grad_a, double* grad_b, double* grad_nu, double* grad_mu, double* grad_y,
-                          double* grad_sigma2, double* grad_shift)
+// then refer to the TRANSFORMED series of each draw.  Shared (c, d) [J] only; per-draw (c, d) are looped over by the callers below.
+static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                            const double* Dd, const double* mu, const double* nu, const double* shift, double* out,
+                            int32_t* status, double* grad_a, double* grad_b, double* grad_c, double* grad_d, double* grad_nu,
+                            double* grad_mu, double* grad_y, double* grad_sigma2, double* grad_shift)
 {
-    if (!ds || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !out || !grad_a || !grad_b) return PIORAN_ERR_ARG;
-    if ((shift == nullptr) != (grad_shift == nullptr)) return PIORAN_ERR_ARG;
     pioran_ctx* ctx = ds->ctx;
     PrepState& s = ds->host;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
     if (s.R > 79 || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
-    // the forward pass keeps S_n of every step: bound the chunk by ~48 GB of workspace
-    int64_t chunk = B < 256 ? B : 256;
-    while (chunk > 1 && pioran_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double) > (48ull << 30)) chunk /= 2;
-    if ((rc = ensure(ctx, ctx->bwork, pioran_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double)))) return rc;
+    // Workspace per draw: (m, D) of every step + S at the checkpoints + one replayed segment (celerite_wide.hip): ~8 MB at
+    // N = 1e4, R = 40.  The chunk is bounded by half of the memory that is free right now (plus what this buffer already
+    // holds) and halved again if the allocation still fails.
+    int64_t chunk = B < 1024 ? B : 1024;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t allowed = free_b / 2 + ctx->bwork.cap;
+            while (chunk > 1 && pioran_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double) > allowed) chunk /= 2;
+        }
+    }
+    while ((rc = ensure(ctx, ctx->bwork, pioran_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double))) == PIORAN_ERR_ALLOC && chunk > 1)
+        chunk /= 2;
+    if (rc) return rc;
     const size_t cj = (size_t)chunk * (size_t)J * sizeof(double), cn = (size_t)chunk * (size_t)ds->N * sizeof(double);
-    if ((rc = ensure(ctx, ctx->bC, 2 * cj))) return rc;              // grad_a | grad_b
+    if ((rc = ensure(ctx, ctx->bC, 4 * cj))) return rc;              // grad_a | grad_b | grad_c | grad_d
     if ((rc = ensure(ctx, ctx->bD, 2 * chunk * sizeof(double)))) return rc;   // grad_nu | grad_mu
     const bool want_series = grad_y || grad_sigma2 || shift;   // the shift's chain rule needs both series gradients
     if (want_series && (rc = ensure(ctx, ctx->bY, cn))) return rc;
@@ -821,18 +850,27 @@ static int logl_grad_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
             p.Y = dYt; p.S2 = dSt;
         }
         double* dga = (double*)ctx->bC.p; double* dgb = dga + (size_t)chunk * J;
+        double* dgc = dgb + (size_t)chunk * J; double* dgd = dgc + (size_t)chunk * J;
         double* dgn = (double*)ctx->bD.p; double* dgm = dgn + chunk;
-        rc = pioran_launch_scan_wide_grad(p, (double*)ctx->bwork.p, dga, dgb, dgn, dgm, ctx->stream);
+        if (!ctx->aux) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+            for (auto& e : ctx->gev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        rc = pioran_launch_scan_wide_grad(p, (double*)ctx->bwork.p, dga, dgb, grad_c ? dgc : nullptr, grad_d ? dgd : nullptr, dgn, dgm,
+                                          ctx->stream, ctx->aux, ctx->gev);
         if (rc) { ctx->last_err = "gradient launch failed"; return rc; }
         if (shift) {
             rc = pioran_launch_shift_grad(ds->N, nb, ds->y, ds->s2, dshift, p.g_y, p.g_s2, dshift + chunk, ctx->stream);
             if (rc) return rc;
             HIPCHK(ctx, hipMemcpyAsync(grad_shift + b0, dshift + chunk, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         }
+        const size_t nbj = (size_t)nb * J * sizeof(double);
         HIPCHK(ctx, hipMemcpyAsync(out + b0, ctx->bout.p, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (status) HIPCHK(ctx, hipMemcpyAsync(status + b0, ctx->bst.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(grad_a + b0 * J, dga, (size_t)nb * J * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(grad_b + b0 * J, dgb, (size_t)nb * J * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(grad_a + b0 * J, dga, nbj, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(grad_b + b0 * J, dgb, nbj, hipMemcpyDeviceToHost, ctx->stream));
+        if (grad_c) HIPCHK(ctx, hipMemcpyAsync(grad_c + b0 * J, dgc, nbj, hipMemcpyDeviceToHost, ctx->stream));
+        if (grad_d) HIPCHK(ctx, hipMemcpyAsync(grad_d + b0 * J, dgd, nbj, hipMemcpyDeviceToHost, ctx->stream));
         if (grad_nu) HIPCHK(ctx, hipMemcpyAsync(grad_nu + b0, dgn, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (grad_mu) HIPCHK(ctx, hipMemcpyAsync(grad_mu + b0, dgm, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (grad_y) HIPCHK(ctx, hipMemcpyAsync(grad_y + b0 * ds->N, ctx->bY.p, (size_t)nb * ds->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -842,23 +880,48 @@ static int logl_grad_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
     return PIORAN_OK;
 }
 
-int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
-                              const double* Dd, const double* mu, const double* nu, double* out, int32_t* status,
-                              double* grad_a, double* grad_b, double* grad_nu, double* grad_mu, double* grad_y,
-                              double* grad_sigma2)
+static int logl_grad_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                          const double* Dd, int cd_shared, const double* mu, const double* nu, const double* shift, double* out,
+                          int32_t* status, double* grad_a, double* grad_b, double* grad_c, double* grad_d, double* grad_nu,
+                          double* grad_mu, double* grad_y, double* grad_sigma2, double* grad_shift)
 {
-    return logl_grad_impl(ds, B, J, A, Bc, C, Dd, mu, nu, nullptr, out, status, grad_a, grad_b, grad_nu, grad_mu, grad_y,
-                          grad_sigma2, nullptr);
+    if (!ds || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !out || !grad_a || !grad_b) return PIORAN_ERR_ARG;
+    if ((shift == nullptr) != (grad_shift == nullptr)) return PIORAN_ERR_ARG;
+    if (cd_shared || B == 1)
+        return logl_grad_shared(ds, B, J, A, Bc, C, Dd, mu, nu, shift, out, status, grad_a, grad_b, grad_c, grad_d, grad_nu, grad_mu,
+                                grad_y, grad_sigma2, grad_shift);
+    // per-draw (c, d) — CARMA, QPO features, free Celerite sums under NUTS (a handful of chains): every draw is its own
+    // one-draw batch with its own table
+    const int64_t N = ds->N;
+    for (int64_t b = 0; b < B; ++b) {
+        const int rc = logl_grad_shared(ds, 1, J, A + b * J, Bc + b * J, C + b * J, Dd + b * J, mu ? mu + b : nullptr,
+                                        nu ? nu + b : nullptr, shift ? shift + b : nullptr, out + b, status ? status + b : nullptr,
+                                        grad_a + b * J, grad_b + b * J, grad_c ? grad_c + b * J : nullptr,
+                                        grad_d ? grad_d + b * J : nullptr, grad_nu ? grad_nu + b : nullptr,
+                                        grad_mu ? grad_mu + b : nullptr, grad_y ? grad_y + b * N : nullptr,
+                                        grad_sigma2 ? grad_sigma2 + b * N : nullptr, grad_shift ? grad_shift + b : nullptr);
+        if (rc) return rc;
+    }
+    return PIORAN_OK;
+}
+
+int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                              const double* Dd, int cd_shared, const double* mu, const double* nu, double* out, int32_t* status,
+                              double* grad_a, double* grad_b, double* grad_c, double* grad_d, double* grad_nu, double* grad_mu,
+                              double* grad_y, double* grad_sigma2)
+{
+    return logl_grad_impl(ds, B, J, A, Bc, C, Dd, cd_shared, mu, nu, nullptr, out, status, grad_a, grad_b, grad_c, grad_d, grad_nu,
+                          grad_mu, grad_y, grad_sigma2, nullptr);
 }
 
 int pioran_celerite_logl_grad_shift(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
-                                    const double* Dd, const double* mu, const double* nu, const double* shift, double* out,
-                                    int32_t* status, double* grad_a, double* grad_b, double* grad_nu, double* grad_mu,
-                                    double* grad_shift)
+                                    const double* Dd, int cd_shared, const double* mu, const double* nu, const double* shift,
+                                    double* out, int32_t* status, double* grad_a, double* grad_b, double* grad_c, double* grad_d,
+                                    double* grad_nu, double* grad_mu, double* grad_shift)
 {
     if (!shift || !grad_shift) return PIORAN_ERR_ARG;
-    return logl_grad_impl(ds, B, J, A, Bc, C, Dd, mu, nu, shift, out, status, grad_a, grad_b, grad_nu, grad_mu, nullptr, nullptr,
-                          grad_shift);
+    return logl_grad_impl(ds, B, J, A, Bc, C, Dd, cd_shared, mu, nu, shift, out, status, grad_a, grad_b, grad_c, grad_d, grad_nu,
+                          grad_mu, nullptr, nullptr, grad_shift);
 }
 
 int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc,

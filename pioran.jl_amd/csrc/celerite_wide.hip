@@ -143,7 +143,8 @@ constexpr int kWideMaxRecord = 512;   // staged doubles per step: two per thread
 // backward sweep of the prediction path (celerite_predict.hip).  MODE 2: simulation — the extra row carries
 // f <- phi o (f + W_{n-1} x_{n-1}) instead of the forward solve and emits y_n = x_n + u_n'f, x_n = sqrt(D_n) q_n
 // (sim, src/celerite_solver.jl:515-549); the noise q takes the place of y in the staged record.  MODE 3: log-likelihood,
-// and S_n (lane layout), v - q of all 16 RPL slots and D_n go to HBM for the reverse pass (celerite_adjoint_kernel below).
+// and v - q of all 16 RPL slots and D_n of every step plus S_n (lane layout) at the checkpoints n = k * ckpt_every go to HBM
+// for the reverse pass below.
 template <int RPL, int MODE = 0>
 __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams p)
 {
@@ -313,17 +314,20 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
                 S[i][c] = sn;
                 qt[i] = fma(sn, uc[c], qt[i]);                    // (S u)_j                    :80-82,86-89
             }
-        if constexpr (MODE == 3) {   // S_n for the adjoint pass, lane layout: each lane's block contiguous, padded to
-                                     // an even number of doubles so that it moves as 16-byte pairs
-            constexpr int SP = (RPL * RPL + 1) & ~1;
-            d2* dst = reinterpret_cast<d2*>(p.st_s + (((size_t)b * (size_t)N + (size_t)n) * 256 + tid) * SP);
+        if constexpr (MODE == 3) {   // checkpoint of S_n, lane layout: each lane's block contiguous, padded to an even
+                                     // number of doubles so that it moves as 16-byte pairs
+            if (n % p.ckpt_every == 0) {   // uniform
+                constexpr int SP = (RPL * RPL + 1) & ~1;
+                const size_t nck = (size_t)((N - 1) / p.ckpt_every + 1);
+                d2* dst = reinterpret_cast<d2*>(p.st_ck + (((size_t)b * nck + (size_t)(n / p.ckpt_every)) * 256 + tid) * SP);
 #pragma unroll
-            for (int e = 0; e < SP / 2; ++e) {
-                const int e0 = 2 * e, e1 = 2 * e + 1;
-                d2 v;
-                v.x = S[e0 / RPL][e0 % RPL];
-                v.y = e1 < RPL * RPL ? S[e1 / RPL][e1 % RPL] : 0.0;
-                dst[e] = v;
+                for (int e = 0; e < SP / 2; ++e) {
+                    const int e0 = 2 * e, e1 = 2 * e + 1;
+                    d2 v;
+                    v.x = S[e0 / RPL][e0 % RPL];
+                    v.y = e1 < RPL * RPL ? S[e1 / RPL][e1 % RPL] : 0.0;
+                    dst[e] = v;
+                }
             }
         }
         PIORAN_WSTAMP(1);
@@ -404,20 +408,137 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
 //   Db += -1/(2 D_n) + z_n^2 / (2 D_n^2) ;  (mb)_y -= z_n / D_n
 //   qb = -mb - Db u ;  ub = -Db q + S_n qb ;  d/d(al_r) += ub_r v_r ;  d/d(be_r) += ub_r x_r        (u_r = al_r v_r + be_r x_r)
 //   d/dsum(a) += Db ;  d/dnu += Db sigma2_n ;  d/dmu -= (mb)_y ;  d/dy_n = (mb)_y ;  d/dsigma2_n = nu Db
-//   Sb <- (phi phi') o (Sb + (qb u' + u qb') / 2)      (S is symmetric: only the symmetric part of its adjoint matters)
-//   mb <- 2 Sb m_{n-1} / D_{n-1} ;  Db <- -(m_{n-1}' mb) / (2 D_{n-1})
+//   vb_r = ub_r al_r + mb_r ;  xb_r = ub_r be_r ;  with (v, x) = (cos, sin)(d t_n) for a cos row, (sin, cos) for a sin row:
+//   d/dd_j += t_n s_r (vb_r x_r - xb_r v_r),  s_r = -1 (cos row), +1 (sin row)                       (src/celerite_solver.jl:52-53)
+//   Sb <- Sb + (qb u' + u qb') / 2   (total adjoint of S_n; S is symmetric: only the symmetric part matters)
+//   phi enters only through S_n = (phi phi') o T:  phi_i (dL/dphi_i) = 2 sum_k Sb_ik S_n,ik, and dphi_i/dc_j = -(t_n - t_{n-1}) phi_i, so
+//   d/dc_j -= 2 (t_n - t_{n-1}) sum_{i in rows(j)} sum_k Sb_ik S_n,ik     — no division by phi               (:54)
+//   Sb <- (phi phi') o Sb ;  mb <- 2 Sb m_{n-1} / D_{n-1} ;  Db <- -(m_{n-1}' mb) / (2 D_{n-1})
 // Same 16 x 16 lane layout and the same single LDS exchange per step as the forward kernel (here: mb of the rows and
-// the shares of m'mb); the two mat-vecs (S_n qb, Sb m) are DPP butterflies.  S_n comes back from HBM in the lane
-// layout the forward pass (MODE 3) wrote, m_{n-1} and D_{n-1} ride through the staged record.
+// the shares of m'mb); the two mat-vecs (S_n qb, Sb m) are DPP butterflies.  m_{n-1} and D_{n-1} ride through the staged
+// record.
+//
+// Memory: the forward pass keeps S_n only at checkpoints (every K steps).  The reverse pass handles one segment between
+// checkpoints per launch pair: celerite_replay_kernel rebuilds S_n of the segment — S_n = (phi phi') o (S_{n-1} + m m'/D) from
+// the STORED (m, D): purely lane-local, no reduction, no barrier — and celerite_adjoint_kernel consumes it backwards.
+// N = 1e4, R = 41: 20 KB per step and draw -> 180 MB per draw when every S_n was kept; now K x 20 KB for the segment plus
+// N/K x 20 KB of checkpoints (K = 128: 4 MB) next to the 3.9 MB of (m, D).
+
+// S_n, n = seg_n0 + 1 .. seg_hi, into st_s slots 0 .. seg_hi - seg_n0 - 1, from the checkpoint S_{seg_n0} (zero for seg_n0 = 0).
+// Bit-identical to what the forward kernel held: same operations on the same stored operands.  The operands of a step —
+// phi_n of every row (table), m_{n-1} of every slot and D_{n-1} (stored by the forward pass) — are contiguous runs: the 256
+// threads fetch them coalesced for SB steps at a time into LDS (double-buffered, one barrier per SB steps) and every lane
+// picks its 4 RPL + 1 values from there; per-lane global loads of those broadcast-heavy values ran at the texture path's
+// pace (1 us per step for a lone workgroup).
+template <int RPL>
+__global__ void __launch_bounds__(256) celerite_replay_kernel(const ScanParams p)
+{
+    constexpr int NS = 16 * RPL, SP = (RPL * RPL + 1) & ~1;
+    constexpr int SB = 8;                              // steps per staged block
+    constexpr int EMAX = 96 + 2 + NS + 1;              // phi of <= 95 rows + padding + y | m | D
+    constexpr int PT = (SB * EMAX + 255) / 256;        // staged elements per thread and block
+    const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
+    const int64_t b = blockIdx.x, N = p.N;
+    const int Rp = p.R + 2;
+    const int E = Rp + NS + 1;                         // staged doubles per step
+    __shared__ double sh[2][SB * EMAX];
+    int opr[RPL], opc[RPL];                            // positions of phi of this lane's row / column slots inside the staged step
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        auto pos = [&](int slot) { return slot < p.R ? slot : (slot == NS - 1 ? p.R + 1 : p.R); };
+        opr[i] = pos(g * RPL + i);
+        opc[i] = pos(l * RPL + i);
+    }
+    const double* numst = p.st_w + (size_t)b * (size_t)N * NS;
+    const double* dst_ = p.st_d + (size_t)b * (size_t)N;
+    const int64_t n_first = p.seg_n0 + 1, n_end = p.seg_hi;
+    if (n_end < n_first) return;
+    double S[RPL][RPL];
+    if (p.seg_n0 == 0) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i)
+#pragma unroll
+            for (int c = 0; c < RPL; ++c) S[i][c] = 0.0;
+    } else {
+        const size_t nck = (size_t)((N - 1) / p.ckpt_every + 1);
+        const d2* src = reinterpret_cast<const d2*>(p.st_ck + (((size_t)b * nck + (size_t)(p.seg_n0 / p.ckpt_every)) * 256 + tid) * SP);
+#pragma unroll
+        for (int e = 0; e < SP / 2; ++e) {
+            const d2 v = src[e];
+            S[(2 * e) / RPL][(2 * e) % RPL] = v.x;
+            if (2 * e + 1 < RPL * RPL) S[(2 * e + 1) / RPL][(2 * e + 1) % RPL] = v.y;
+        }
+    }
+    d2* out = reinterpret_cast<d2*>(p.st_s + ((size_t)b * (size_t)p.ckpt_every * 256 + tid) * SP);
+    double regs[PT];
+    auto fetch_block = [&](int64_t blk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const int idx = tid + 256 * k;
+            const int j = idx / E, e = idx - j * E;
+            double v = 0.0;
+            if (j < SB) {
+                int64_t n = n_first + blk * SB + j;
+                n = n > n_end ? n_end : n;             // past the segment: re-read its last step (never used)
+                v = e < Rp ? p.tab[n * p.rec_stride + 2 * Rp + e] : (e < Rp + NS ? numst[(size_t)(n - 1) * NS + (e - Rp)] : dst_[n - 1]);
+            }
+            regs[k] = v;
+        }
+    };
+    auto put_block = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const int idx = tid + 256 * k;
+            if (idx < SB * E) sh[buf][idx] = regs[k];
+        }
+    };
+    const int64_t nblk = (n_end - n_first + SB) / SB;
+    fetch_block(0);
+    put_block(0);
+    __syncthreads();
+    for (int64_t blk = 0; blk < nblk; ++blk) {
+        if (blk + 1 < nblk) fetch_block(blk + 1);      // in flight while this block is computed
+        const double* base = sh[blk & 1];
+#pragma unroll 2
+        for (int j = 0; j < SB; ++j) {
+            const int64_t n = n_first + blk * SB + j;
+            if (n > n_end) break;                      // uniform
+            const double* r = base + j * E;
+            const double rD = recip_f64(r[Rp + NS]);
+            double rp[RPL], mr[RPL];
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) { rp[i] = r[opr[i]]; mr[i] = r[Rp + g * RPL + i]; }
+#pragma unroll
+            for (int c = 0; c < RPL; ++c) {
+                const double cp = r[opc[c]], wc = r[Rp + l * RPL + c] * rD;
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) S[i][c] = (rp[i] * cp) * fma(mr[i], wc, S[i][c]);
+            }
+            d2* dst = out + (size_t)(n - n_first) * 256 * (SP / 2);
+#pragma unroll
+            for (int e = 0; e < SP / 2; ++e) {
+                d2 v;
+                v.x = S[(2 * e) / RPL][(2 * e) % RPL];
+                v.y = 2 * e + 1 < RPL * RPL ? S[(2 * e + 1) / RPL][(2 * e + 1) % RPL] : 0.0;
+                dst[e] = v;
+            }
+        }
+        if (blk + 1 < nblk) put_block((int)((blk + 1) & 1));
+        __syncthreads();
+    }
+}
+
 template <int RPL>
 __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanParams p)
 {
     constexpr int YS = RPL - 1;
     constexpr int DG = 4;
     constexpr int NS = 16 * RPL;                      // row slots
+    constexpr int NSTATE = RPL * RPL + 3 * RPL + 4;   // per lane: Sb | mbr mbc gphr | Db gA gnu gmu
     const int tid = threadIdx.x;
     const int g = tid >> 4, l = tid & 15;
     const int64_t b = blockIdx.x, N = p.N;
+    const int64_t n_hi = p.seg_hi, n_lo = p.seg_lo, NP = n_hi - n_lo + 1;   // steps of this launch
     const int Rp = p.R + 2, RS = 3 * Rp + 2;
     const int L = RS + 3 * p.npd_rows;                // table part of the staged record
     const int LT = L + NS + 1;                        // + m_{n-1} of every slot + D_{n-1}
@@ -425,6 +546,9 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
     __shared__ double sh_rec[2][kWideMaxRecord];
     __shared__ double sh_num[2][NS];
     __shared__ double sh_uq[2][16];
+    // row accumulators of d/d(al), d/d(be), d/dd: identical in the 16 lanes of a DPP row, so they live here (updated by
+    // the lane l = 0 of each row, off the critical path) instead of in 3 RPL registers of every lane
+    __shared__ double sh_acc[3][NS];
 
     Slots<RPL> rs_, cs_;
     describe_slots<RPL>(p, b, g, rs_);
@@ -432,6 +556,15 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
     const double mu = p.mu ? p.mu[b] : 0.0;
     const double nu = p.nu ? p.nu[b] : 1.0;
     const bool yrow = g == 15, ycol = l == 15;
+    int sinmask = 0, realmask = 0;                    // bit i: row slot i of this lane is a sin row / a real row at all
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const int slot = g * RPL + i;
+        if (slot < p.R) {
+            realmask |= 1 << i;
+            if ((p.rowmap[slot] >> 30) & 1) sinmask |= 1 << i;
+        }
+    }
     const double* numst = p.st_w + (size_t)b * (size_t)N * NS;
     const double* dst_ = p.st_d + (size_t)b * (size_t)N;
 
@@ -466,88 +599,89 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
         sh_rec[par][tid] = v[0];
         if (two) sh_rec[par][tid + 256] = v[1];
     };
-    struct AdjIn {
-        double rv[RPL], rx[RPL], rp[RPL], cv[RPL], cx[RPL], cp[RPL], y, s2;
-        double pr[RPL], pc[RPL], Dp, zp;              // m_{n-1} of the row / column block, D_{n-1}, z_{n-1}
-    };
-    auto unstage = [&](int par, AdjIn& in) __attribute__((always_inline)) {
-        const double* r = sh_rec[par];
-#pragma unroll
-        for (int i = 0; i < RPL; ++i) {
-            in.rv[i] = r[rs_.ov[i]]; in.rx[i] = r[rs_.ox[i]]; in.rp[i] = r[rs_.op[i]];
-            in.cv[i] = r[cs_.ov[i]]; in.cx[i] = r[cs_.ox[i]]; in.cp[i] = r[cs_.op[i]];
-            in.pr[i] = r[L + g * RPL + i];
-            in.pc[i] = r[L + l * RPL + i];
-        }
-        in.y = r[3 * Rp];
-        in.s2 = r[3 * Rp + 1];
-        in.Dp = r[L + NS];
-        in.zp = r[L + NS - 1];                        // the y slot is the last one
-    };
-    // S_n of this lane, SD steps ahead in registers
-    constexpr int SP = (RPL * RPL + 1) & ~1;          // padded block (16-byte pairs), as the forward pass wrote it
-    const double* sbase = p.st_s + ((size_t)b * (size_t)N * 256 + tid) * SP;
+    // S_n of this lane from the replayed segment (slot n - seg_n0 - 1), SD steps ahead in registers
+    constexpr int SP = (RPL * RPL + 1) & ~1;          // padded block (16-byte pairs)
+    const double* sbase = p.st_s + ((size_t)b * (size_t)p.ckpt_every * 256 + tid) * SP;
+    const int64_t s_first = p.seg_n0 + 1;             // lowest step present in the segment buffer
     auto fetch_s = [&](int64_t n, double (&dsts)[RPL * RPL]) __attribute__((always_inline)) {
-        const int64_t k = n < 1 ? 1 : n;              // S_0 is never used (and was never written)
-        const d2* q_ = reinterpret_cast<const d2*>(sbase + (size_t)(N > 1 ? k : 0) * 256 * SP);
+        int64_t k = n < s_first ? s_first : n;        // below the segment (or S_0): never used, any readable slot will do
+        k = k > n_hi ? n_hi : k;
+        const bool have = n_hi >= s_first;            // N = 1: nothing was replayed
+        const d2* q_ = reinterpret_cast<const d2*>(sbase + (size_t)(have ? k - s_first : 0) * 256 * SP);
 #pragma unroll
         for (int e = 0; e < SP / 2; ++e) {
             d2 v;
             v.x = 0.0; v.y = 0.0;
-            if (N > 1) v = q_[e];
+            if (have) v = q_[e];
             dsts[2 * e] = v.x;
             if (2 * e + 1 < RPL * RPL) dsts[2 * e + 1] = v.y;
         }
     };
 
-    // steps are visited in DEscending n; "position" s = N - 1 - n plays the role n plays in the forward kernel
+    // steps are visited in DEscending n; "position" s = n_hi - n plays the role n plays in the forward kernel
     double gv[DG][2];
 #pragma unroll
-    for (int m = 0; m < DG; ++m) fetch(N - 1 - m, gv[m]);
+    for (int m = 0; m < DG; ++m) fetch(n_hi - m, gv[m]);
     constexpr int SD = RPL <= 3 ? 2 : 1;              // S_n buffers (steps ahead); one where registers are short
     double sv[SD][RPL * RPL];
-    fetch_s(N - 1, sv[0]);
-    if constexpr (SD == 2) fetch_s(N - 2, sv[1]);
-    AdjIn cur;                                        // ONE register copy of the staged record (register budget):
-                                                      // refilled at the end of a step, after its last field is consumed
-    const int par0 = (int)((N - 1) & 1);              // record n is staged in sh_rec[n & 1]
-    stage(par0, gv[0]);
-    fetch(N - 1 - DG, gv[0]);
-    __syncthreads();
-    unstage(par0, cur);
+    fetch_s(n_hi, sv[0]);
+    if constexpr (SD == 2) fetch_s(n_hi - 1, sv[1]);
+    stage((int)(n_hi & 1), gv[0]);                    // record n is staged in sh_rec[n & 1] and READ FROM THERE at its
+    fetch(n_hi - DG, gv[0]);                          // points of use (no register copy: the register budget goes to S)
 
-    // m_{N-1}, D_{N-1}, z_{N-1}: straight from HBM, once
+    // m_n, D_n, z_n of the first step of this launch: straight from HBM, once
     double mr[RPL], mc[RPL];
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
-        mr[i] = numst[(size_t)(N - 1) * NS + g * RPL + i];
-        mc[i] = numst[(size_t)(N - 1) * NS + l * RPL + i];
+        mr[i] = numst[(size_t)n_hi * NS + g * RPL + i];
+        mc[i] = numst[(size_t)n_hi * NS + l * RPL + i];
     }
-    double Dn = dst_[N - 1];
-    double zn = numst[(size_t)(N - 1) * NS + NS - 1];
+    double Dn = dst_[n_hi];
+    double zn = numst[(size_t)n_hi * NS + NS - 1];
 
+    // adjoint state: zero at the first launch of the reverse pass, else what the previous launch (the later segment) parked
     double Sb[RPL][RPL];
-#pragma unroll
-    for (int i = 0; i < RPL; ++i)
-#pragma unroll
-        for (int c = 0; c < RPL; ++c) Sb[i][c] = 0.0;
-    double mbr[RPL], mbc[RPL], galr[RPL], gber[RPL];
-#pragma unroll
-    for (int i = 0; i < RPL; ++i) { mbr[i] = 0.0; mbc[i] = 0.0; galr[i] = 0.0; gber[i] = 0.0; }
+    double mbr[RPL], mbc[RPL], gphr[RPL];
     double Db = 0.0, gA = 0.0, gnu = 0.0, gmu = 0.0;
+    double* state = p.st_state + (size_t)b * (NSTATE * 256 + 3 * NS) + tid;      // [e][tid]: coalesced; then the 3 NS row accumulators
+    double* state_acc = p.st_state + (size_t)b * (NSTATE * 256 + 3 * NS) + NSTATE * 256;
+    if (p.seg_first) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+#pragma unroll
+            for (int c = 0; c < RPL; ++c) Sb[i][c] = 0.0;
+            mbr[i] = 0.0; mbc[i] = 0.0; gphr[i] = 0.0;
+        }
+        for (int e = tid; e < 3 * NS; e += 256) (&sh_acc[0][0])[e] = 0.0;
+    } else {
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i)
+#pragma unroll
+            for (int c = 0; c < RPL; ++c) Sb[i][c] = state[256 * e++];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            mbr[i] = state[256 * (e + 0 * RPL + i)]; mbc[i] = state[256 * (e + 1 * RPL + i)]; gphr[i] = state[256 * (e + 2 * RPL + i)];
+        }
+        e += 3 * RPL;
+        Db = state[256 * e]; gA = state[256 * (e + 1)]; gnu = state[256 * (e + 2)]; gmu = state[256 * (e + 3)];
+        for (int k = tid; k < 3 * NS; k += 256) (&sh_acc[0][0])[k] = state_acc[k];
+    }
+    __syncthreads();
 
-    auto do_step = [&](int64_t n, AdjIn& in, double (&gslot)[2], double (&sn)[RPL * RPL]) __attribute__((always_inline)) {
-        double ur[RPL], uc[RPL], qr[RPL], qbr[RPL], qbc[RPL], ub[RPL];
+    auto do_step = [&](int64_t n, double (&gslot)[2], double (&sn)[RPL * RPL]) __attribute__((always_inline)) {
+        const double* r = sh_rec[n & 1];               // record n: table part, then m_{n-1} of every slot, D_{n-1}
+        double ur[RPL], uc[RPL], qbr[RPL], qbc[RPL], ub[RPL];
         const double rDn = recip_f64(Dn);
+        const double tn = p.t[n];                      // uniform (scalar load)
+        const double dtn = n > 0 ? tn - p.t[n - 1] : 0.0;
         Db += -0.5 * rDn + 0.5 * zn * zn * rDn * rDn;
         if (yrow) mbr[YS] -= zn * rDn;
         if (ycol) mbc[YS] -= zn * rDn;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            ur[i] = rs_.al[i] * in.rv[i] + rs_.be[i] * in.rx[i];
-            uc[i] = cs_.al[i] * in.cv[i] + cs_.be[i] * in.cx[i];
-            const double vr = (yrow && i == YS) ? in.y - mu : in.rv[i];
-            qr[i] = vr - mr[i];
+            ur[i] = rs_.al[i] * r[rs_.ov[i]] + rs_.be[i] * r[rs_.ox[i]];
+            uc[i] = cs_.al[i] * r[cs_.ov[i]] + cs_.be[i] * r[cs_.ox[i]];
             qbr[i] = -mbr[i] - Db * ur[i];
             qbc[i] = -mbc[i] - Db * uc[i];
             ub[i] = 0.0;
@@ -562,12 +696,20 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
         }
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            ub[i] = fma(-Db, qr[i], ub[i]);
-            galr[i] = fma(ub[i], in.rv[i], galr[i]);
-            gber[i] = fma(ub[i], in.rx[i], gber[i]);
+            const double rv = r[rs_.ov[i]], rx = r[rs_.ox[i]];
+            const double vr = (yrow && i == YS) ? r[3 * Rp] - mu : rv;
+            ub[i] = fma(-Db, vr - mr[i], ub[i]);       // q = v - m
+            if (l == 0) {
+                // d/dd: through v (in u and in m = v - q) and x (in u); s = -1 for a cos row, +1 for a sin row
+                const double vb = fma(ub[i], rs_.al[i], mbr[i]), xb = ub[i] * rs_.be[i];
+                const double sg = ((realmask >> i) & 1) ? (((sinmask >> i) & 1) ? tn : -tn) : 0.0;
+                sh_acc[0][g * RPL + i] = fma(ub[i], rv, sh_acc[0][g * RPL + i]);
+                sh_acc[1][g * RPL + i] = fma(ub[i], rx, sh_acc[1][g * RPL + i]);
+                sh_acc[2][g * RPL + i] = fma(sg, fma(vb, rx, -xb * rv), sh_acc[2][g * RPL + i]);
+            }
         }
         gA += Db;
-        gnu = fma(Db, in.s2, gnu);
+        gnu = fma(Db, r[3 * Rp + 1], gnu);
         if (yrow) {
             gmu -= mbr[YS];
             if (l == 0) {
@@ -575,27 +717,32 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
                 if (p.g_s2) p.g_s2[b * N + n] = nu * Db;
             }
         }
-        fetch_s(n - SD, sn);                           // this register buffer is free again
         if (n == 0) return;
-        // ---- adjoints of (S_{n-1}, m_{n-1}, D_{n-1}) ----
-        double nb[RPL];
+        // ---- adjoints of (S_{n-1}, m_{n-1}, D_{n-1}); d/dc through phi_n ----
+        double nb[RPL], rp[RPL];
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) nb[i] = 0.0;
+        for (int i = 0; i < RPL; ++i) { nb[i] = 0.0; rp[i] = r[rs_.op[i]]; }
 #pragma unroll
-        for (int c = 0; c < RPL; ++c)
+        for (int c = 0; c < RPL; ++c) {
+            const double cp = r[cs_.op[c]], pc = r[L + l * RPL + c];
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
-                const double t_ = fma(0.5 * qbr[i], uc[c], fma(0.5 * ur[i], qbc[c], Sb[i][c]));
-                const double sbn = (in.rp[i] * in.cp[c]) * t_;
+                const double t_ = fma(0.5 * qbr[i], uc[c], fma(0.5 * ur[i], qbc[c], Sb[i][c]));   // total adjoint of S_n[i][c]
+                gphr[i] = fma(dtn * t_, sn[i * RPL + c], gphr[i]);                                 // this lane's share of sum_k Sb_ik S_ik
+                const double sbn = (rp[i] * cp) * t_;
                 Sb[i][c] = sbn;
-                nb[i] = fma(sbn, in.pc[c], nb[i]);
+                nb[i] = fma(sbn, pc, nb[i]);
             }
-        const double rDp = recip_f64(in.Dp);
+        }
+        fetch_s(n - SD, sn);                           // this register buffer is free again
+        const double Dp = r[L + NS];
+        const double rDp = recip_f64(Dp);
         double share = 0.0;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             nb[i] = 2.0 * row16_sum(nb[i]) * rDp;
-            share = fma(in.pr[i], nb[i], share);
+            mr[i] = r[L + g * RPL + i];                // m_{n-1}: "previous" becomes "current"
+            share = fma(mr[i], nb[i], share);
             mbr[i] = nb[i];
         }
         const int par = (int)(n & 1);
@@ -604,6 +751,10 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
 #pragma unroll
             for (int i = 0; i < RPL; ++i) sh_num[par][g * RPL + i] = nb[i];
         }
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) mc[i] = r[L + l * RPL + i];
+        Dn = Dp;
+        zn = r[L + NS - 1];                            // the y slot is the last one
         stage(par ^ 1, gslot);                         // record n - 1 -> sh_rec[(n-1) & 1]
         fetch(n - 1 - DG, gslot);
         __syncthreads();
@@ -615,32 +766,46 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
         const double tot = (((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]))) +
                            (((sh[8] + sh[9]) + (sh[10] + sh[11])) + ((sh[12] + sh[13]) + (sh[14] + sh[15])));
         Db = -0.5 * tot * rDp;
-        // what was "previous" becomes "current"
-#pragma unroll
-        for (int i = 0; i < RPL; ++i) { mr[i] = in.pr[i]; mc[i] = in.pc[i]; }
-        Dn = in.Dp;
-        zn = in.zp;
-        unstage(par ^ 1, in);                          // record n - 1 for the next step
     };
 
-    // positions: at position s = N-1-n the global ring slot (s + 1) % DG holds record n - 1,
-    // the S buffer s & 1 holds S_n.  Unrolled by DG so that all of these are compile-time constants.
+    // positions: at position s = n_hi - n the global ring slot (s + 1) % DG holds record n - 1,
+    // the S buffer s % SD holds S_n.  Unrolled by DG so that all of these are compile-time constants.
     int64_t s0 = 0;
-    for (; s0 + DG <= N; s0 += DG)
+    for (; s0 + DG <= NP; s0 += DG)
         static_for<0, DG>([&](auto Kc) __attribute__((always_inline)) {
             constexpr int k = decltype(Kc)::value;
-            do_step(N - 1 - (s0 + k), cur, gv[(k + 1) % DG], sv[k % SD]);
+            do_step(n_hi - (s0 + k), gv[(k + 1) % DG], sv[k % SD]);
         });
     static_for<0, DG - 1>([&](auto Kc) __attribute__((always_inline)) {
         constexpr int k = decltype(Kc)::value;
-        if (s0 + k < N) do_step(N - 1 - (s0 + k), cur, gv[(k + 1) % DG], sv[k % SD]);
+        if (s0 + k < NP) do_step(n_hi - (s0 + k), gv[(k + 1) % DG], sv[k % SD]);
     });
 
+    __syncthreads();
+    if (n_lo > 0) {   // park the adjoint state for the launch that continues with the earlier segment
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i)
+#pragma unroll
+            for (int c = 0; c < RPL; ++c) state[256 * e++] = Sb[i][c];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            state[256 * (e + 0 * RPL + i)] = mbr[i]; state[256 * (e + 1 * RPL + i)] = mbc[i]; state[256 * (e + 2 * RPL + i)] = gphr[i];
+        }
+        e += 3 * RPL;
+        state[256 * e] = Db; state[256 * (e + 1)] = gA; state[256 * (e + 2)] = gnu; state[256 * (e + 3)] = gmu;
+        for (int k = tid; k < 3 * NS; k += 256) state_acc[k] = (&sh_acc[0][0])[k];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) gphr[i] = row16_sum(gphr[i]);   // over the 16 column blocks
     if (l == 0) {
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            p.g_al[b * NS + g * RPL + i] = galr[i];
-            p.g_be[b * NS + g * RPL + i] = gber[i];
+            p.g_al[b * NS + g * RPL + i] = sh_acc[0][g * RPL + i];
+            p.g_be[b * NS + g * RPL + i] = sh_acc[1][g * RPL + i];
+            p.g_d[b * NS + g * RPL + i] = sh_acc[2][g * RPL + i];
+            p.g_c[b * NS + g * RPL + i] = -2.0 * gphr[i];
         }
         if (yrow) {
             p.g_scal[b * 4 + 0] = gA;
@@ -651,24 +816,30 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
     }
 }
 
-// row adjoints -> term gradients: a_j enters al of both rows and sum(a); b_j enters be of the cos row and -be of the sin row
+// row adjoints -> term gradients: a_j enters al of both rows and sum(a); b_j enters be of the cos row and -be of the sin row;
+// c_j and d_j collect the accumulators of their rows
 __global__ void __launch_bounds__(256) grad_finish_kernel(const ScanParams p, int NS, double* __restrict__ grad_a,
-                                                          double* __restrict__ grad_b, double* __restrict__ grad_nu,
+                                                          double* __restrict__ grad_b, double* __restrict__ grad_c,
+                                                          double* __restrict__ grad_d, double* __restrict__ grad_nu,
                                                           double* __restrict__ grad_mu)
 {
     const int64_t b = blockIdx.x;
     const int J = p.J;
     for (int j = threadIdx.x; j < J; j += 256) {
-        double ga = p.g_scal[b * 4 + 0], gb = 0.0;
+        double ga = p.g_scal[b * 4 + 0], gb = 0.0, gc = 0.0, gd = 0.0;
         for (int r = 0; r < p.R; ++r) {
             const int rm = p.rowmap[r];
             if ((rm & 0xfffff) != j) continue;
             const bool ks = (rm >> 30) & 1;
             ga += p.g_al[b * NS + r];
             gb += ks ? -p.g_be[b * NS + r] : p.g_be[b * NS + r];
+            gc += p.g_c[b * NS + r];
+            gd += p.g_d[b * NS + r];
         }
         grad_a[b * J + j] = ga;
         grad_b[b * J + j] = gb;
+        if (grad_c) grad_c[b * J + j] = gc;
+        if (grad_d) grad_d[b * J + j] = gd;
     }
     if (threadIdx.x == 0) {
         if (grad_nu) grad_nu[b] = p.g_scal[b * 4 + 1];
@@ -717,37 +888,92 @@ int pioran_launch_scan_wide_sim(const ScanParams& p, hipStream_t stream)
 
 static int rpl_of(int R) { return R <= 15 ? 1 : R <= 31 ? 2 : R <= 47 ? 3 : R <= 63 ? 4 : 5; }
 
+// checkpoint interval of the gradient's forward pass: ~2 sqrt(N), between 16 and 256 (memory K + N/K blocks of S per draw)
+static int grad_ckpt_every(int64_t N)
+{
+    int k = 16;
+    while (k < 256 && (int64_t)k * k < 4 * N) k *= 2;
+    return k;
+}
+
 size_t pioran_grad_workspace_doubles(int64_t B, int64_t N, int32_t R)
 {
     const size_t rpl = (size_t)rpl_of(R), ns = 16 * rpl;
     const size_t sp = (rpl * rpl + 1) & ~(size_t)1;
-    // S [B][N][256][sp] | m [B][N][ns] | D [B][N] | row adjoints 2 x [B][ns] | scalars [B][4]
-    return (size_t)B * (size_t)N * (256 * sp + ns + 1) + (size_t)B * (2 * ns + 4) + 2;
+    const size_t K = (size_t)grad_ckpt_every(N), nck = (size_t)((N - 1) / (int64_t)K + 1);
+    const size_t nstate = rpl * rpl + 3 * rpl + 4;   // per lane; + 3 ns row accumulators per draw
+    // two S segment buffers 2 x [B][K][256][sp] | S checkpoints [B][nck][256][sp] | m [B][N][ns] | D [B][N] |
+    // state [B][nstate][256] + [B][3 ns] | row accumulators 4 x [B][ns] | scalars [B][4]
+    return (size_t)B * ((2 * K + nck) * 256 * sp + (size_t)N * (ns + 1) + nstate * 256 + 3 * ns + 4 * ns + 4) + 2;
 }
 
 // p: shared-table launch description with out / status set; work: pioran_grad_workspace_doubles doubles;
-// grad_a, grad_b: device [B][J]; grad_nu, grad_mu: device [B] or nullptr; p.g_y / p.g_s2: device [B][N] or nullptr.
-int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, double* grad_b, double* grad_nu,
-                                 double* grad_mu, hipStream_t stream)
+// grad_a, grad_b: device [B][J]; grad_c, grad_d: device [B][J] or nullptr; grad_nu, grad_mu: device [B] or nullptr;
+// p.g_y / p.g_s2: device [B][N] or nullptr.  aux / ev (5 events): a second stream on which the replay of segment k - 1 runs
+// while the adjoint kernel works through segment k (two segment buffers); aux == nullptr: everything on `stream`.
+int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, double* grad_b, double* grad_c, double* grad_d,
+                                 double* grad_nu, double* grad_mu, hipStream_t stream, hipStream_t aux, hipEvent_t* ev)
 {
-    if (!p.tab || p.R > 79 || p.B <= 0 || p.B > 0x7fffffffLL || !grad_a || !grad_b) return PIORAN_ERR_UNSUPPORTED;
+    if (!p.tab || p.R > 79 || p.npd_rows || p.B <= 0 || p.B > 0x7fffffffLL || !grad_a || !grad_b) return PIORAN_ERR_UNSUPPORTED;
     const int rpl = rpl_of(p.R), ns = 16 * rpl;
     if (3 * (p.R + 2) + 2 + 3 * p.npd_rows + ns + 1 > kWideMaxRecord) return PIORAN_ERR_UNSUPPORTED;
-    const size_t BN = (size_t)p.B * (size_t)p.N;
+    const size_t sp = (size_t)((rpl * rpl + 1) & ~1), nstate = (size_t)(rpl * rpl + 3 * rpl + 4);
+    const int K = grad_ckpt_every(p.N);
+    const size_t nck = (size_t)((p.N - 1) / K + 1), B = (size_t)p.B, BN = B * (size_t)p.N;
+    p.ckpt_every = K;
     p.st_s = work;                                     // hipMalloc'ed: 256-byte aligned, blocks of an even number of doubles
-    p.st_w = p.st_s + BN * 256 * (size_t)((rpl * rpl + 1) & ~1);
+    const size_t seg_doubles = B * (size_t)K * 256 * sp;
+    p.st_ck = p.st_s + 2 * seg_doubles;
+    p.st_w = p.st_ck + B * nck * 256 * sp;
     p.st_d = p.st_w + BN * ns;
-    p.g_al = p.st_d + BN;
-    p.g_be = p.g_al + (size_t)p.B * ns;
-    p.g_scal = p.g_be + (size_t)p.B * ns;
+    p.st_state = p.st_d + BN;
+    p.g_al = p.st_state + B * (nstate * 256 + 3 * (size_t)ns);
+    p.g_be = p.g_al + B * ns;
+    p.g_d = p.g_be + B * ns;
+    p.g_c = p.g_d + B * ns;
+    p.g_scal = p.g_c + B * ns;
     const dim3 grid((unsigned)p.B), block(256);
+    auto run = [&](auto Rc) {
+        constexpr int RPL = decltype(Rc)::value;
+        hipLaunchKernelGGL((celerite_wide_kernel<RPL, 3>), grid, block, 0, stream, p);
+        // reverse pass, last segment first; segment k holds steps k K + 1 .. min((k + 1) K, N - 1); the first segment's
+        // adjoint launch also takes step 0
+        const int64_t nseg = (p.N - 1 + K - 1) / K;
+        ScanParams q = p;
+        q.seg_first = 1;
+        if (nseg == 0) {                               // N = 1
+            q.seg_n0 = 0; q.seg_hi = 0; q.seg_lo = 0;
+            hipLaunchKernelGGL(celerite_adjoint_kernel<RPL>, grid, block, 0, stream, q);
+        }
+        // events: ev[0] forward done; ev[1 + (k & 1)] replay of segment k done; ev[3 + (k & 1)] adjoint of segment k done
+        hipStream_t rs = aux ? aux : stream;
+        if (aux) {
+            (void)hipEventRecord(ev[0], stream);
+            (void)hipStreamWaitEvent(aux, ev[0], 0);
+        }
+        for (int64_t k = nseg - 1; k >= 0; --k) {
+            q.seg_n0 = k * K;
+            q.seg_hi = (k + 1) * K < p.N - 1 ? (k + 1) * K : p.N - 1;
+            q.seg_lo = k == 0 ? 0 : q.seg_n0 + 1;
+            q.st_s = p.st_s + (size_t)(k & 1) * seg_doubles;
+            if (aux && k + 2 <= nseg - 1) (void)hipStreamWaitEvent(aux, ev[3 + (k & 1)], 0);   // its buffer was read by segment k + 2
+            hipLaunchKernelGGL(celerite_replay_kernel<RPL>, grid, block, 0, rs, q);
+            if (aux) {
+                (void)hipEventRecord(ev[1 + (k & 1)], aux);
+                (void)hipStreamWaitEvent(stream, ev[1 + (k & 1)], 0);
+            }
+            hipLaunchKernelGGL(celerite_adjoint_kernel<RPL>, grid, block, 0, stream, q);
+            if (aux) (void)hipEventRecord(ev[3 + (k & 1)], stream);
+            q.seg_first = 0;
+        }
+    };
     switch (rpl) {
-    case 1: hipLaunchKernelGGL((celerite_wide_kernel<1, 3>), grid, block, 0, stream, p); hipLaunchKernelGGL(celerite_adjoint_kernel<1>, grid, block, 0, stream, p); break;
-    case 2: hipLaunchKernelGGL((celerite_wide_kernel<2, 3>), grid, block, 0, stream, p); hipLaunchKernelGGL(celerite_adjoint_kernel<2>, grid, block, 0, stream, p); break;
-    case 3: hipLaunchKernelGGL((celerite_wide_kernel<3, 3>), grid, block, 0, stream, p); hipLaunchKernelGGL(celerite_adjoint_kernel<3>, grid, block, 0, stream, p); break;
-    case 4: hipLaunchKernelGGL((celerite_wide_kernel<4, 3>), grid, block, 0, stream, p); hipLaunchKernelGGL(celerite_adjoint_kernel<4>, grid, block, 0, stream, p); break;
-    default: hipLaunchKernelGGL((celerite_wide_kernel<5, 3>), grid, block, 0, stream, p); hipLaunchKernelGGL(celerite_adjoint_kernel<5>, grid, block, 0, stream, p); break;
+    case 1: run(ic<1>{}); break;
+    case 2: run(ic<2>{}); break;
+    case 3: run(ic<3>{}); break;
+    case 4: run(ic<4>{}); break;
+    default: run(ic<5>{}); break;
     }
-    hipLaunchKernelGGL(grad_finish_kernel, grid, block, 0, stream, p, ns, grad_a, grad_b, grad_nu, grad_mu);
+    hipLaunchKernelGGL(grad_finish_kernel, grid, block, 0, stream, p, ns, grad_a, grad_b, grad_c, grad_d, grad_nu, grad_mu);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }

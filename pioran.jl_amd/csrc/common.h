@@ -59,13 +59,25 @@ struct ScanParams {
     // (sim, src/celerite_solver.jl:515-549); y / Y are not read.
     const double* noise;
     double* ysim;
-    // Gradient (pioran_launch_scan_wide_grad): the forward pass (MODE 3) stores S_n in the lane layout
-    // [B][N][256][RPL*RPL rounded up to even], v - q of ALL 16 RPL row slots in st_w [B][N][16 RPL] and D_n in st_d; the adjoint pass
-    // returns the row adjoints of (al, be) [B][16 RPL] each, the scalars (dL/dsum(a), dL/dnu, dL/dmu) [B][4] and,
-    // optionally, dL/dy_n and dL/dsigma2_n [B][N].
+    // Gradient (pioran_launch_scan_wide_grad).  The forward pass (MODE 3) stores v - q of ALL 16 RPL row slots in st_w
+    // [B][N][16 RPL], D_n in st_d [B][N] and S_n — lane layout [256][RPL*RPL rounded up to even] — only at the CHECKPOINTS
+    // n = k * ckpt_every (st_ck [B][nck][256][SP]).  The reverse pass walks the segments between checkpoints from the last to
+    // the first: celerite_replay_kernel rebuilds S_n of one segment from its checkpoint and the stored (v - q, D) into
+    // st_s [B][ckpt_every][256][SP], celerite_adjoint_kernel then runs steps seg_hi .. seg_lo backwards, its adjoint state
+    // parked in st_state [B][NSTATE][256] between launches.  Outputs: row adjoints of (al, be) and the row accumulators of
+    // dL/dd and dL/dc [B][16 RPL] each, the scalars (dL/dsum(a), dL/dnu, dL/dmu) [B][4] and, optionally, dL/dy_n, dL/dsigma2_n.
     double* st_s;
+    double* st_ck;
+    double* st_state;
+    int32_t ckpt_every;   // K
+    int32_t seg_first;    // 1: the first launch of the reverse pass (adjoint state starts at zero)
+    int64_t seg_n0;       // checkpoint step of the segment: st_s slot j holds S_{seg_n0 + 1 + j}
+    int64_t seg_hi;       // steps seg_hi, seg_hi - 1, ..., seg_lo are processed by this adjoint launch
+    int64_t seg_lo;
     double* g_al;
     double* g_be;
+    double* g_d;
+    double* g_c;
     double* g_scal;
     double* g_y;
     double* g_s2;
@@ -81,8 +93,8 @@ int pioran_launch_scan_wide_store(const ScanParams& p, hipStream_t stream);   //
 int pioran_launch_scan_wide_sim(const ScanParams& p, hipStream_t stream);     // y = L D^(1/2) q
 // log L and its gradient with respect to (a_j, b_j) [B][J], nu, mu (reverse mode through the recurrence)
 size_t pioran_grad_workspace_doubles(int64_t B, int64_t N, int32_t R);
-int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, double* grad_b, double* grad_nu,
-                                 double* grad_mu, hipStream_t stream);
+int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, double* grad_b, double* grad_c, double* grad_d,
+                                 double* grad_nu, double* grad_mu, hipStream_t stream, hipStream_t aux, hipEvent_t* ev /*[5]*/);
 int pioran_wide_supported_rows();
 int64_t pioran_wide_max_batch();
 // celerite_predict.hip: posterior mean at new times (pred, src/celerite_solver.jl:363-483)

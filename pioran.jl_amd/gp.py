@@ -56,6 +56,10 @@ class Context:
     def synchronize(self):
         _lib.check(_lib.lib().pioran_ctx_synchronize(self._h), self._h)
 
+    def trim(self):
+        """Release the context's scratch buffers (gradient / prediction workspaces, staging, the dense slab)."""
+        _lib.check(_lib.lib().pioran_ctx_trim(self._h), self._h)
+
     def set_option(self, key: str, value=None):
         """Diagnostic switch of this context (pioran_ctx_set_option): "scan_config" (a configuration name, "wide", or
         None), "no_wide" / "no_paired" / "no_mixed" / "force_fallback" (truthy = on).  Tests and tuning tools only."""
@@ -244,45 +248,41 @@ class Dataset:
                                                       _ptr(nu), len(tau), _ptr(tau), _ptr(out), _ptr(st)), self.ctx._h)
         return (out, st) if return_status else out
 
-    def logl_grad(self, A, Bc, C, Dd, mu=None, nu=None, series_grad=False, shift=None):
-        """log L and its gradient for B draws sharing (C, Dd): returns a dict with logl (B,), status, grad_a, grad_b (B, J),
-        grad_mu, grad_nu (B,) (None where mu / nu were not given) and, with series_grad, grad_y, grad_sigma2 (B, N).
+    def logl_grad(self, A, Bc, C, Dd, mu=None, nu=None, series_grad=False, shift=None, cd_grad=True):
+        """log L and its gradient for B draws: returns a dict with logl (B,), status, grad_a, grad_b, grad_c, grad_d (B, J),
+        grad_mu, grad_nu (B,) and, with series_grad, grad_y, grad_sigma2 (B, N).  C, Dd: (J,) shared by the draws or
+        (B, J) per draw (QPO / CARMA / free Celerite terms).  grad_c / grad_d are per draw also when (C, Dd) are shared.
         shift (B,): the shifted log-flux models (the data set holds raw flux and yerr**2); adds grad_shift (B,)."""
-        if shift is not None:
-            return self._logl_grad_shift(A, Bc, C, Dd, mu, nu, shift)
         A, Bc, C, Dd = map(_f64, (A, Bc, C, Dd))
-        if A.ndim != 2 or A.shape != Bc.shape or C.shape != (A.shape[1],) or Dd.shape != C.shape:
-            raise ValueError("A, Bc must be (B, J) and C, Dd (J,)")
+        if A.ndim != 2 or A.shape != Bc.shape:
+            raise ValueError("A, Bc must be (B, J)")
         B, J = A.shape
+        cd_shared = C.ndim == 1
+        if C.shape != Dd.shape or C.shape != ((J,) if cd_shared else (B, J)):
+            raise ValueError("C, Dd must be (J,) or (B, J)")
         mu_ = None if mu is None else _f64(np.broadcast_to(mu, (B,)))
         nu_ = None if nu is None else _f64(np.broadcast_to(nu, (B,)))
         out = np.empty(B); st = np.zeros(B, dtype=np.int32)
         ga, gb = np.empty((B, J)), np.empty((B, J))
+        gc = np.empty((B, J)) if cd_grad else None
+        gd = np.empty((B, J)) if cd_grad else None
         gnu, gmu = np.empty(B), np.empty(B)
+        L = _lib.lib()
+        if shift is not None:
+            shift = _f64(np.broadcast_to(shift, (B,)))
+            gsh = np.empty(B)
+            _lib.check(L.pioran_celerite_logl_grad_shift(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), int(cd_shared), _ptr(mu_),
+                                                         _ptr(nu_), _ptr(shift), _ptr(out), _ptr(st), _ptr(ga), _ptr(gb), _ptr(gc),
+                                                         _ptr(gd), _ptr(gnu), _ptr(gmu), _ptr(gsh)), self.ctx._h)
+            return {"logl": out, "status": st, "grad_a": ga, "grad_b": gb, "grad_c": gc, "grad_d": gd, "grad_nu": gnu,
+                    "grad_mu": gmu, "grad_shift": gsh, "grad_y": None, "grad_sigma2": None}
         gy = np.empty((B, self.N)) if series_grad else None
         gs = np.empty((B, self.N)) if series_grad else None
-        _lib.check(_lib.lib().pioran_celerite_logl_grad(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), _ptr(mu_), _ptr(nu_),
-                                                        _ptr(out), _ptr(st), _ptr(ga), _ptr(gb), _ptr(gnu), _ptr(gmu),
-                                                        _ptr(gy), _ptr(gs)), self.ctx._h)
-        return {"logl": out, "status": st, "grad_a": ga, "grad_b": gb, "grad_nu": gnu, "grad_mu": gmu,
+        _lib.check(L.pioran_celerite_logl_grad(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), int(cd_shared), _ptr(mu_), _ptr(nu_),
+                                               _ptr(out), _ptr(st), _ptr(ga), _ptr(gb), _ptr(gc), _ptr(gd), _ptr(gnu), _ptr(gmu),
+                                               _ptr(gy), _ptr(gs)), self.ctx._h)
+        return {"logl": out, "status": st, "grad_a": ga, "grad_b": gb, "grad_c": gc, "grad_d": gd, "grad_nu": gnu, "grad_mu": gmu,
                 "grad_y": gy, "grad_sigma2": gs}
-
-    def _logl_grad_shift(self, A, Bc, C, Dd, mu, nu, shift):
-        A, Bc, C, Dd = map(_f64, (A, Bc, C, Dd))
-        if A.ndim != 2 or A.shape != Bc.shape or C.shape != (A.shape[1],) or Dd.shape != C.shape:
-            raise ValueError("A, Bc must be (B, J) and C, Dd (J,)")
-        B, J = A.shape
-        mu_ = None if mu is None else _f64(np.broadcast_to(mu, (B,)))
-        nu_ = None if nu is None else _f64(np.broadcast_to(nu, (B,)))
-        shift = _f64(np.broadcast_to(shift, (B,)))
-        out = np.empty(B); st = np.zeros(B, dtype=np.int32)
-        ga, gb = np.empty((B, J)), np.empty((B, J))
-        gnu, gmu, gsh = np.empty(B), np.empty(B), np.empty(B)
-        _lib.check(_lib.lib().pioran_celerite_logl_grad_shift(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), _ptr(mu_),
-                                                              _ptr(nu_), _ptr(shift), _ptr(out), _ptr(st), _ptr(ga), _ptr(gb),
-                                                              _ptr(gnu), _ptr(gmu), _ptr(gsh)), self.ctx._h)
-        return {"logl": out, "status": st, "grad_a": ga, "grad_b": gb, "grad_nu": gnu, "grad_mu": gmu, "grad_shift": gsh,
-                "grad_y": None, "grad_sigma2": None}
 
     def logpdf_theta_grad(self, model, theta, norm, f_min, f_max, n_components=20, S_low=20.0, S_high=20.0, *,
                           is_integrated_power=True, basis_function="SHO", mu=None, nu=None, shift=None):

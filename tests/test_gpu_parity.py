@@ -833,8 +833,9 @@ def test_predict_cov_reference_cases(ctx, golden_dir):
 @pytest.mark.parametrize("J,N,B", [(3, 40, 2), (7, 64, 3), (10, 257, 3), (20, 500, 2), (30, 129, 2), (39, 100, 2), (4, 1, 1), (9, 2, 2),
                                    (9, 3, 2), (9, 6, 2)])
 def test_gradient_matches_complex_step(ctx, J, N, B):
-    """dlogL/d(a_j, b_j, mu, nu, y_n, sigma2_n) against the complex-step derivatives of the oracle (exact to rounding):
-    every RPL of the adjoint kernel, every prologue / tail length of its pipelines."""
+    """dlogL/d(a_j, b_j, c_j, d_j, mu, nu, y_n, sigma2_n) against the complex-step derivatives of the oracle (exact to
+    rounding): every RPL of the adjoint kernel, every prologue / tail length of its pipelines, series shorter and longer
+    than one checkpoint segment (16 steps at these N)."""
     rng = np.random.default_rng(800 + J + N)
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
     ds = pj.Dataset(t, y, s2, ctx)
@@ -843,10 +844,12 @@ def test_gradient_matches_complex_step(ctx, J, N, B):
     assert relerr(g["logl"], ref_l) < 1e-11 and (g["status"] == 0).all()
     assert (g["logl"] == ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)).all() or relerr(g["logl"], ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)) < 1e-12
     for i in range(B):
-        ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, series=N <= 129)
+        ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, series=N <= 129, cd=True)
         sa = 1e-9 * (1 + np.max(np.abs(ref["grad_a"]))); sb = 1e-9 * (1 + np.max(np.abs(ref["grad_b"])))
         assert np.max(np.abs(g["grad_a"][i] - ref["grad_a"])) <= sa
         assert np.max(np.abs(g["grad_b"][i] - ref["grad_b"])) <= sb
+        assert np.max(np.abs(g["grad_c"][i] - ref["grad_c"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_c"])))
+        assert np.max(np.abs(g["grad_d"][i] - ref["grad_d"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_d"])))
         gm = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, dy=-np.ones(N))
         gn = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, ds2=s2)
         assert abs(g["grad_mu"][i] - gm) <= 1e-9 * (1 + abs(gm)) and abs(g["grad_nu"][i] - gn) <= 1e-9 * (1 + abs(gn))
@@ -882,6 +885,99 @@ def test_gradient_full_size_and_real_terms(ctx, full_size):
             assert abs(g["grad_mu"][i] - gm) <= 1e-7 * (1 + abs(gm))
 
 
+def test_gradient_wrt_c_and_d_qpo_and_carma(ctx, golden_dir, full_size):
+    """dlogL/d(c_j, d_j) — what ForwardDiff gets through the generic logl for kernels whose decay rates and frequencies are
+    sampled: a QPO feature on top of an approx continuum (src/psd.jl:15-27, 254-261), a CARMA(3,2) kernel
+    (src/CARMA.jl:98-143, coefficients of test/test_carma.jl:55-69), per-draw (c, d) [B][J], and N = 1e4 with 78 checkpoint
+    segments.  Against the complex step of the oracle, 1e-8 of the gradient scale (1e-6 at N = 1e4: the gradient of a
+    10^4-step recurrence carries ~1e-9 relative rounding per component of a vector whose entries span 6 decades)."""
+    def check(ds, t, y, s2, A, Bc, C, Dd, mu, nu, tol, dirs=None):
+        g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+        shared = np.ndim(C) == 1
+        for i in range(len(A)):
+            c_i, d_i = (C, Dd) if shared else (C[i], Dd[i])
+            yy, ss = y - (mu[i] if mu is not None else 0.0), (nu[i] if nu is not None else 1.0) * s2
+            assert abs(g["logl"][i] - O.logl(A[i], Bc[i], c_i, d_i, t, yy, ss)) <= 1e-8 * abs(g["logl"][i])
+            if dirs is None:
+                ref = O.logl_grad(A[i], Bc[i], c_i, d_i, t, yy, ss, cd=True)
+                for k in ("grad_a", "grad_b", "grad_c", "grad_d"):
+                    assert np.max(np.abs(g[k][i] - ref[k])) <= tol * (1 + np.max(np.abs(ref[k]))), (k, i)
+            else:   # a few random directions in (c, d) space: one complex step each
+                J = A.shape[1]
+                im = ctypes.c_double()
+                P = lambda v: np.ascontiguousarray(v, dtype=np.float64).ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+                for dc, dd in dirs:
+                    h = 1e-30
+                    O.lib().oracle_logl_complex_cd(len(t), J, P(A[i]), None, P(Bc[i]), None, P(c_i), P(h * dc), P(d_i), P(h * dd), P(t),
+                                                   P(yy), None, P(ss), None, ctypes.byref(im))
+                    got = g["grad_c"][i] @ dc + g["grad_d"][i] @ dd
+                    scale = np.abs(g["grad_c"][i]) @ np.abs(dc) + np.abs(g["grad_d"][i]) @ np.abs(dd)
+                    assert abs(got - im.value / h) <= tol * (1 + scale), (got, im.value / h)
+        return g
+
+    rng = np.random.default_rng(4)
+    A_ = np.loadtxt(golden_dir / "simu.txt")
+    t, y, yerr = A_[:300, 0], A_[:300, 1], A_[:300, 2]
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    # (1) continuum (SHO-10) + one QPO term (a, b = a / (2Q) ... : Celerite term with d >> c), shared by 3 draws
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    th = np.array([[0.5, 0.02, 3.0], [0.8, 0.05, 2.5], [0.2, 0.01, 3.5]])
+    A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, th, f_min, f_max, 10, np.array([1.0, 0.5, 2.0]))
+    qa = rng.uniform(0.1, 0.5, (3, 1))
+    C2 = np.append(C, 0.02); D2 = np.append(Dd, 2 * np.pi * 0.1)
+    # (a celerite term is a valid covariance only for |b d| <= a c: half of that bound)
+    A2 = np.concatenate([A, qa], axis=1); B2 = np.concatenate([Bc, 0.5 * qa * C2[-1] / D2[-1]], axis=1)
+    check(ds, t, y, yerr ** 2, A2, B2, C2, D2, np.array([0.1, 0.0, -0.1]), np.array([1.0, 1.2, 0.9]), 1e-8)
+    # (2) the same with per-draw (c, d) of the QPO term: [B][J] arrays, every draw its own table
+    C3 = np.tile(C2, (3, 1)); D3 = np.tile(D2, (3, 1))
+    C3[:, -1] = [0.02, 0.05, 0.01]; D3[:, -1] = 2 * np.pi * np.array([0.1, 0.13, 0.07])
+    B3 = B2.copy(); B3[:, -1] = 0.5 * A2[:, -1] * C3[:, -1] / D3[:, -1]
+    g3 = check(ds, t, y, yerr ** 2, A2, B3, C3, D3, np.array([0.1, 0.0, -0.1]), np.array([1.0, 1.2, 0.9]), 1e-8)
+    assert g3["grad_c"].shape == (3, 11)
+    # (3) CARMA(3,2): one real term (b = d = 0: single row) and one complex term with NEGATIVE d
+    lit = json.loads((golden_dir / "reference_literals.json").read_text())["carma32"]
+    k = pj.CARMA(lit["p"], lit["q"], np.array([complex(*z) for z in lit["r_alpha"]]), lit["beta"], lit["norm"])
+    a, b, c, d = (np.atleast_2d(v) for v in k.celerite_coefs())
+    gk = ds.logl_grad(a, b, c[0], d[0], mu=[0.3], nu=[1.1])
+    ref = O.logl_grad(a[0], b[0], c[0], d[0], t, y - 0.3, 1.1 * yerr ** 2, cd=True)
+    real = d[0] == 0.0
+    for key in ("grad_a", "grad_c"):
+        assert np.max(np.abs(gk[key][0] - ref[key])) <= 1e-8 * (1 + np.max(np.abs(ref[key]))), key
+    # a real term keeps only its cos row: b and d are structurally absent there, their derivatives are reported as 0
+    for key in ("grad_b", "grad_d"):
+        assert np.max(np.abs(gk[key][0][~real] - ref[key][~real])) <= 1e-8 * (1 + np.max(np.abs(ref[key]))), key
+        assert (gk[key][0][real] == 0.0).all()
+    # (4) N = 1e4, SHO-20: 78 segments of 128 steps (+ the tail); random directions in (c, d)
+    tL, yL, eL = full_size
+    thL = O.synthetic_theta(2, tL, yL)
+    AL, BL, CL, DL, muL, nuL = O.theta_to_coefs(thL, tL, 20, "SHO")
+    dsL = pj.Dataset(tL, yL, eL ** 2, ctx)
+    dirs = [(rng.standard_normal(20) * CL, rng.standard_normal(20) * DL) for _ in range(3)]
+    check(dsL, tL, yL, eL ** 2, AL, BL, CL, DL, muL, nuL, 1e-6, dirs=dirs)
+
+
+def test_gradient_workspace_is_small(ctx, full_size):
+    """64 chains at N = 1e4, J = 20: the reverse pass keeps checkpoints + one replayed segment, not every S_n
+    (180 MB per draw before): the context's memory grows by well under 1 GB, and pioran_ctx_trim gives it back."""
+    import torch
+    t, y, yerr = full_size
+    th = O.synthetic_theta(64, t, y, seed=3)
+    A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, 20, "SHO")
+    c2 = pj.Context(0)
+    ds = pj.Dataset(t, y, yerr ** 2, c2)
+    ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+    used = free0 - torch.cuda.mem_get_info()[0]
+    assert used < 1.0e9, used
+    ok = g["status"] == 0
+    assert ok.sum() > 32 and relerr(g["logl"][ok], ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)[ok]) < 1e-10
+    c2.trim()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+    ds.close(); c2.close()
+
+
 def test_gradient_wrt_sampled_parameters(ctx, golden_dir):
     """d log L / d(alpha1, f1, alpha2, variance, nu, mu) — the parameters a sampler moves (README.md:38-71) — on the
     reference's simu_log series: device gradient chained through approx vs central differences of the oracle's value
@@ -912,14 +1008,14 @@ def test_gradient_wrt_sampled_parameters(ctx, golden_dir):
 
 
 def test_gradient_chunking_and_optional_arguments(ctx):
-    """More draws than one 256-draw chunk; mu / nu omitted; gradient rows of every draw consistent with a one-draw call."""
+    """More draws than one 1024-draw chunk; mu / nu omitted; gradient rows of every draw consistent with a one-draw call."""
     rng = np.random.default_rng(31)
-    N, J, B = 60, 6, 260
+    N, J, B = 60, 6, 1030
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
     ds = pj.Dataset(t, y, s2, ctx)
     g = ds.logl_grad(A, Bc, C, Dd)
     assert relerr(g["logl"], O.logl_batch(A, Bc, C, Dd, t, y, s2, np.zeros(B), np.ones(B), nthreads=8)) < 1e-11
-    for i in (0, 255, 256, 259):
+    for i in (0, 255, 1023, 1024, 1029):
         one = ds.logl_grad(A[i:i + 1], Bc[i:i + 1], C, Dd)
         assert np.array_equal(one["grad_a"][0], g["grad_a"][i]) and np.array_equal(one["grad_b"][0], g["grad_b"][i])
         ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y, s2)
