@@ -4,15 +4,29 @@
 # libpioran_hip.so.  It overrides nothing for non-Float64 element types, so ForwardDiff Duals
 # (Turing/NUTS, test/test_likelihood.jl:55) keep flowing through the original Julia `logl`.
 #
-# NOTE: the build image has no `julia`, so this file is exercised only through the identical C ABI
-# from Python (pioran.jl_amd/_lib.py) and the GPU parity tests; see INTEGRATION.md.
+# NOTE: the build image has no `julia`, so this file has never been parsed by a Julia front-end; the identical C ABI is
+# exercised from Python (pioran.jl_amd/_lib.py), from plain C (tests/cabi_driver.c) and by the GPU parity tests, and
+# tests/test_host.py::test_julia_shim_matches_header checks every ccall here against include/pioran_hip.h (symbol,
+# argument count, integer / pointer kinds).  See INTEGRATION.md.
 module PioranHIP
 
 using LinearAlgebra
 using Pioran
-import Pioran: log_likelihood, SumOfCelerite, SemiSeparable, celerite_coefs
+import Pioran: log_likelihood, SumOfCelerite, SemiSeparable, CARMA, celerite_coefs
+import ChainRulesCore
 
 const LIB = get(ENV, "PIORAN_HIP_LIB", "libpioran_hip")
+const ABI_VERSION = 5
+
+# PIORAN_BACKEND=julia keeps every call on Pioran's own Julia code (the escape hatch a deployment wants when no GPU is
+# visible or for A/B comparisons); anything else (default "hip") routes Float64 calls to libpioran_hip.so.
+const USE_HIP = Ref(lowercase(get(ENV, "PIORAN_BACKEND", "hip")) != "julia")
+
+function __init__()
+    USE_HIP[] || return
+    v = ccall((:pioran_abi_version, LIB), Cint, ())
+    v == ABI_VERSION || error("libpioran_hip.so has ABI version $v, PioranHIP.jl was written for $ABI_VERSION")
+end
 
 struct PioranHIPError <: Exception
     code::Cint
@@ -26,15 +40,30 @@ function check(rc::Cint)
 end
 
 # ---- context: one per Julia process / MPI rank / Distributed worker (device = rank % ngpu) ---------
+# Julia does not order finalizers: a Dataset may be finalized after its Context.  pioran_dataset_destroy dereferences the
+# context, so the Context keeps the handles of its live data sets and destroys THEM first; a Dataset whose context is
+# already gone only forgets its handle.
 mutable struct Context
     h::Ptr{Cvoid}
+    datasets::Set{Ptr{Cvoid}}
     function Context(device::Integer = 0)
         r = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:pioran_ctx_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), device, r))
-        ctx = new(r[])
-        finalizer(c -> ccall((:pioran_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), c.h), ctx)
+        ctx = new(r[], Set{Ptr{Cvoid}}())
+        finalizer(close!, ctx)
         return ctx
     end
+end
+
+function close!(ctx::Context)
+    ctx.h == C_NULL && return
+    for d in ctx.datasets
+        ccall((:pioran_dataset_destroy, LIB), Cint, (Ptr{Cvoid},), d)
+    end
+    empty!(ctx.datasets)
+    ccall((:pioran_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), ctx.h)
+    ctx.h = C_NULL
+    return
 end
 
 const DEFAULT_CTX = Ref{Union{Nothing, Context}}(nothing)
@@ -57,13 +86,47 @@ function logl_hip(a::Vector{Float64}, b::Vector{Float64}, c::Vector{Float64}, d:
 end
 
 # Float64-only methods: everything else (Duals, BigFloat, views ...) falls through to Pioran's own code.
+# The three methods of src/celerite_solver.jl:262-294, same solver switch and error text.
 function log_likelihood(cov::SumOfCelerite, τ::Vector{Float64}, y::Vector{Float64}, σ2::Vector{Float64}; solver = :celerite)
     (solver == :celerite || solver == :celerite_matrix) ||
         error("solver $solver not recognised, use either :celerite or :celerite_matrix")
-    if eltype(cov.a) === Float64
+    if USE_HIP[] && eltype(cov.a) === Float64
         return logl_hip(collect(cov.a), collect(cov.b), collect(cov.c), collect(cov.d), τ, y, σ2)
     end
     return Pioran.logl(cov.a, cov.b, cov.c, cov.d, τ, y, σ2)
+end
+
+# CARMA (:272-282) and any other SemiSeparable kernel (:284-294): celerite_coefs, then real(logl(...))
+function _log_likelihood_coefs(cov, τ::Vector{Float64}, y::Vector{Float64}, σ2::Vector{Float64}, solver)
+    (solver == :celerite || solver == :celerite_matrix) ||
+        error("solver $solver not recognised, use either :celerite or :celerite_matrix")
+    a, b, c, d = celerite_coefs(cov)
+    if USE_HIP[] && all(v -> eltype(v) <: Union{Float64, ComplexF64}, (a, b, c, d)) && all(v -> all(iszero, imag.(v)), (a, b, c, d))
+        return logl_hip(collect(Float64, real.(a)), collect(Float64, real.(b)), collect(Float64, real.(c)), collect(Float64, real.(d)), τ, y, σ2)
+    end
+    return real(Pioran.logl(a, b, c, d, τ, y, σ2))
+end
+log_likelihood(cov::CARMA, τ::Vector{Float64}, y::Vector{Float64}, σ2::Vector{Float64}; solver = :celerite) =
+    _log_likelihood_coefs(cov, τ, y, σ2, solver)
+log_likelihood(cov::SemiSeparable, τ::Vector{Float64}, y::Vector{Float64}, σ2::Vector{Float64}; solver = :celerite) =
+    _log_likelihood_coefs(cov, τ, y, σ2, solver)
+
+# Reverse rule for the scalar likelihood: Zygote / ReverseDiff-based samplers (and Turing with an rrule-aware backend) get
+# the GPU gradient instead of pushing Duals through Pioran.logl.  Cotangents for (a, b, c, d, y, σ2); τ is data.
+function ChainRulesCore.rrule(::typeof(logl_hip), a::Vector{Float64}, b::Vector{Float64}, c::Vector{Float64}, d::Vector{Float64},
+                              τ::Vector{Float64}, y::Vector{Float64}, σ2::Vector{Float64}; ctx = default_context())
+    ds = Dataset(τ, y, σ2; ctx = ctx)
+    g = try
+        logpdf_grad_batch(ds, reshape(a, :, 1), reshape(b, :, 1), c, d; series = true)
+    finally
+        close!(ds)
+    end
+    g.status[1] == 2 && throw(DomainError(g.logl[1], "log-likelihood is not finite: covariance not positive definite"))
+    function logl_pullback(Δ)
+        NT = ChainRulesCore.NoTangent()
+        return (NT, Δ .* vec(g.grad_a), Δ .* vec(g.grad_b), Δ .* vec(g.grad_c), Δ .* vec(g.grad_d), NT, Δ .* vec(g.grad_y), Δ .* vec(g.grad_σ²))
+    end
+    return g.logl[1], logl_pullback
 end
 
 # ---- data set handle + batched entry (the reference has no batch dimension) ---------------------------
@@ -76,9 +139,20 @@ mutable struct Dataset
         GC.@preserve t y σ2 check(ccall((:pioran_dataset_create, LIB), Cint,
             (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Ptr{Cvoid}}), ctx.h, length(t), t, y, σ2, r))
         ds = new(r[], length(t), ctx)
-        finalizer(d -> ccall((:pioran_dataset_destroy, LIB), Cint, (Ptr{Cvoid},), d.h), ds)
+        push!(ctx.datasets, ds.h)
+        finalizer(close!, ds)
         return ds
     end
+end
+
+function close!(ds::Dataset)
+    ds.h == C_NULL && return
+    if ds.ctx.h != C_NULL && ds.h in ds.ctx.datasets      # context still alive: it has not destroyed this handle yet
+        delete!(ds.ctx.datasets, ds.h)
+        ccall((:pioran_dataset_destroy, LIB), Cint, (Ptr{Cvoid},), ds.h)
+    end
+    ds.h = C_NULL
+    return
 end
 
 """
@@ -218,8 +292,12 @@ end
 function pred_hip(a::Vector{Float64}, b::Vector{Float64}, c::Vector{Float64}, d::Vector{Float64}, τ::Vector{Float64},
                   t::Vector{Float64}, y::Vector{Float64}, σ²::Vector{Float64}; ctx = default_context())
     ds = Dataset(t, y, σ²; ctx = ctx)
-    out, _ = predict_batch(ds, reshape(a, :, 1), reshape(b, :, 1), c, d, τ)
-    return vec(out)
+    try
+        out, _ = predict_batch(ds, reshape(a, :, 1), reshape(b, :, 1), c, d, τ)
+        return vec(out)
+    finally
+        close!(ds)          # release the device copy now, not at the next GC
+    end
 end
 
 """
@@ -246,28 +324,32 @@ end
 """
     logpdf_grad_batch(ds, A, B, c, d; μ, ν, series = false)
 
-log L and ∂log L/∂(a_j, b_j) (`J × nbatch` each), ∂/∂ν, ∂/∂μ for every draw; with `series = true` also ∂/∂y_n and ∂/∂σ²_n
-(`N × nbatch`).  This is what a `ChainRulesCore.rrule` / `LogDensityProblems.logdensity_and_gradient` for the GP
+log L and ∂log L/∂(a_j, b_j, c_j, d_j) (`J × nbatch` each), ∂/∂ν, ∂/∂μ for every draw; with `series = true` also ∂/∂y_n and
+∂/∂σ²_n (`N × nbatch`).  `c`, `d`: length-`J` vectors shared by the draws or `J × nbatch` matrices (QPO features, CARMA,
+free Celerite terms).  This is what a `ChainRulesCore.rrule` / `LogDensityProblems.logdensity_and_gradient` for the GP
 likelihood returns instead of pushing ForwardDiff Duals through `Pioran.logl` (test/test_likelihood.jl:55-60); the chain
-rule from (a, b) to the PSD parameters goes through `approx`, which stays in Julia.
+rule from (a, b, c, d) to the PSD parameters goes through `approx`, which stays in Julia.
 """
-function logpdf_grad_batch(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::Vector{Float64}, d::Vector{Float64};
+function logpdf_grad_batch(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::VecOrMat{Float64}, d::VecOrMat{Float64};
                            μ::Union{Nothing, Vector{Float64}} = nothing, ν::Union{Nothing, Vector{Float64}} = nothing,
                            series::Bool = false)
     J, nb = size(A)
     out = Vector{Float64}(undef, nb); status = zeros(Int32, nb)
     ga = Matrix{Float64}(undef, J, nb); gb = Matrix{Float64}(undef, J, nb)
+    gc = Matrix{Float64}(undef, J, nb); gd = Matrix{Float64}(undef, J, nb)
     gν = Vector{Float64}(undef, nb); gμ = Vector{Float64}(undef, nb)
     gy = series ? Matrix{Float64}(undef, ds.N, nb) : nothing
     gs = series ? Matrix{Float64}(undef, ds.N, nb) : nothing
     p(x) = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
-    GC.@preserve A B c d μ ν out status ga gb gν gμ gy gs begin
+    GC.@preserve A B c d μ ν out status ga gb gc gd gν gμ gy gs begin
         check(ccall((:pioran_celerite_logl_grad, LIB), Cint,
-                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
-                     Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
-                    ds.h, nb, J, A, B, c, d, p(μ), p(ν), out, status, ga, gb, gν, gμ, p(gy), p(gs)))
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble},
+                     Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                     Ptr{Cdouble}, Ptr{Cdouble}),
+                    ds.h, nb, J, A, B, c, d, c isa Vector ? 1 : 0, p(μ), p(ν), out, status, ga, gb, gc, gd, gν, gμ, p(gy), p(gs)))
     end
-    return (logl = out, status = status, grad_a = ga, grad_b = gb, grad_ν = gν, grad_μ = gμ, grad_y = gy, grad_σ² = gs)
+    return (logl = out, status = status, grad_a = ga, grad_b = gb, grad_c = gc, grad_d = gd, grad_ν = gν, grad_μ = gμ,
+            grad_y = gy, grad_σ² = gs)
 end
 
 """
@@ -276,21 +358,23 @@ end
 Value and gradient for the shifted log-flux models (docs/src/turing.md:205-230): `ds` holds the raw flux and `yerr.^2`;
 returns in addition `grad_shift` = ∂log L/∂c per draw.
 """
-function logpdf_grad_batch_shift(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::Vector{Float64}, d::Vector{Float64},
+function logpdf_grad_batch_shift(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::VecOrMat{Float64}, d::VecOrMat{Float64},
                                  shift::Vector{Float64}; μ::Union{Nothing, Vector{Float64}} = nothing,
                                  ν::Union{Nothing, Vector{Float64}} = nothing)
     J, nb = size(A)
     out = Vector{Float64}(undef, nb); status = zeros(Int32, nb)
     ga = Matrix{Float64}(undef, J, nb); gb = Matrix{Float64}(undef, J, nb)
+    gc = Matrix{Float64}(undef, J, nb); gd = Matrix{Float64}(undef, J, nb)
     gν = Vector{Float64}(undef, nb); gμ = Vector{Float64}(undef, nb); gs = Vector{Float64}(undef, nb)
     p(x) = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
-    GC.@preserve A B c d μ ν shift out status ga gb gν gμ gs begin
+    GC.@preserve A B c d μ ν shift out status ga gb gc gd gν gμ gs begin
         check(ccall((:pioran_celerite_logl_grad_shift, LIB), Cint,
-                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
-                     Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
-                    ds.h, nb, J, A, B, c, d, p(μ), p(ν), shift, out, status, ga, gb, gν, gμ, gs))
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble},
+                     Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                     Ptr{Cdouble}, Ptr{Cdouble}),
+                    ds.h, nb, J, A, B, c, d, c isa Vector ? 1 : 0, p(μ), p(ν), shift, out, status, ga, gb, gc, gd, gν, gμ, gs))
     end
-    return (logl = out, status = status, grad_a = ga, grad_b = gb, grad_ν = gν, grad_μ = gμ, grad_shift = gs)
+    return (logl = out, status = status, grad_a = ga, grad_b = gb, grad_c = gc, grad_d = gd, grad_ν = gν, grad_μ = gμ, grad_shift = gs)
 end
 
 # ---- dense solver: log_likelihood_direct (src/direct_solver.jl:6-21), returns +NLL -------------------------

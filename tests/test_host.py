@@ -203,3 +203,48 @@ def test_carma_kernel_coefficients(golden_dir):
                 dict(p=3, q=1, r=r4[:2], beta=[1, 2]), dict(p=2, q=1, r=r4[:2], beta=[1.0])):
         with pytest.raises(ValueError):
             pj.CARMA(bad["p"], bad["q"], bad["r"], bad["beta"])
+
+
+def test_julia_shim_matches_header():
+    """pioran.jl_amd/julia/PioranHIP.jl cannot be executed here (no julia in the image): check every ccall statically
+    against the prototypes of include/pioran_hip.h — symbol exists, same number of arguments, and each position has the
+    same kind (32-bit int / 64-bit int / double / pointer), return type included."""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    hdr = re.sub(r"/\*.*?\*/", "", (root / "include" / "pioran_hip.h").read_text(), flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"([\w \*]+?)\s*\b(pioran_\w+)\s*\(([^)]*)\)\s*;", hdr):
+        def kind(a):
+            a = a.strip()
+            if "*" in a:
+                return "ptr"
+            if a.startswith("int64_t"):
+                return "i64"
+            if a.startswith("double"):
+                return "f64"
+            if a.startswith("int") or a.startswith("int32_t"):
+                return "i32"
+            if a == "void" or a == "":
+                return None
+            raise AssertionError(f"unknown C type {a!r} in {name}")
+        ks = [kind(a) for a in args.split(",")]
+        protos[name] = ([k for k in ks if k], "ptr" if "*" in ret else ("i32" if "int" in ret else ret.strip()))
+    jl = (root / "pioran.jl_amd" / "julia" / "PioranHIP.jl").read_text()
+    jkind = {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Cdouble": "f64", "Cstring": "ptr"}
+    calls = re.findall(r"ccall\(\(:(\w+), LIB\),\s*(\w+),\s*\(([^)]*)\)", jl, flags=re.S)
+    assert len(calls) >= 20
+    seen = set()
+    for name, ret, args in calls:
+        assert name in protos, f"{name} is not declared in include/pioran_hip.h"
+        seen.add(name)
+        want, wret = protos[name]
+        toks = [a.strip() for a in args.split(",") if a.strip()]
+        got = [("ptr" if a.startswith(("Ptr{", "Ref{")) else jkind[a]) for a in toks]
+        assert got == want, f"{name}: Julia passes {got}, the header declares {want}"
+        assert ("ptr" if ret == "Cstring" else jkind[ret]) == wret, name
+    # the entries a Pioran.jl maintainer needs are all bound
+    for must in ("pioran_abi_version", "pioran_celerite_logl", "pioran_celerite_logl_batch", "pioran_celerite_logl_grad",
+                 "pioran_logpdf_batch_theta", "pioran_dense_nll", "pioran_celerite_predict", "pioran_farm_logl_batch"):
+        assert must in seen, must
+    assert "pioran_abi_version" in jl and "ABI_VERSION = 5" in jl
