@@ -18,6 +18,13 @@ struct pioran_ctx {
     hipEvent_t ev[16] = {};
     std::string last_err;
     ScanOptions opt{};   // diagnostic switches: environment at creation, then pioran_ctx_set_option
+    // pinned staging of the host-pointer entries: pageable hipMemcpyAsync is staged by the runtime with a hidden
+    // synchronisation per call (~0.4 ms each); copies out of / into this buffer are true asynchronous DMA.  A bump
+    // allocator, reset at every stream synchronisation; results land here and are handed to the caller after the sync.
+    char* pin = nullptr;
+    size_t pin_cap = 0, pin_off = 0;
+    struct Pending { void* host; const void* pinned; size_t bytes; };
+    std::vector<Pending> pending;
     // second stream + events of the gradient's reverse pass (replay of one segment overlaps the adjoint of the next); lazy
     hipStream_t aux = nullptr;
     hipEvent_t gev[5] = {};
@@ -87,11 +94,66 @@ int ensure(pioran_ctx* ctx, pioran_ctx::Buf& b, size_t bytes)
     return PIORAN_OK;
 }
 
+// stream synchronisation + delivery of the results staged in pinned memory + reset of the staging allocator
+int ctx_sync(pioran_ctx* ctx)
+{
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (const auto& q : ctx->pending) std::memcpy(q.host, q.pinned, q.bytes);
+    ctx->pending.clear();
+    ctx->pin_off = 0;
+    return PIORAN_OK;
+}
+#define SYNC(ctx)                      \
+    do {                               \
+        int rc_sync_ = ctx_sync(ctx);  \
+        if (rc_sync_) return rc_sync_; \
+    } while (0)
+
+constexpr size_t kPinMaxRequest = size_t(32) << 20;   // larger transfers go straight from / to the caller's memory
+
+// bytes of pinned staging, 256-byte aligned; nullptr when the request is too large for staging (or pinning fails)
+void* pin_reserve(pioran_ctx* ctx, size_t bytes)
+{
+    if (bytes > kPinMaxRequest) return nullptr;
+    const size_t need = (bytes + 255) & ~size_t(255);
+    if (ctx->pin_off + need > ctx->pin_cap) {
+        if (ctx_sync(ctx) != PIORAN_OK) return nullptr;           // nothing in flight uses the old buffer any more
+        if (need > ctx->pin_cap) {
+            if (ctx->pin) (void)hipHostFree(ctx->pin);
+            ctx->pin = nullptr;
+            ctx->pin_cap = 0;
+            size_t want = need * 4 < (size_t(8) << 20) ? (size_t(8) << 20) : need * 4;
+            if (hipHostMalloc((void**)&ctx->pin, want, hipHostMallocDefault) != hipSuccess) { ctx->pin = nullptr; return nullptr; }
+            ctx->pin_cap = want;
+        }
+    }
+    void* p = ctx->pin + ctx->pin_off;
+    ctx->pin_off += need;
+    return p;
+}
+
 int upload(pioran_ctx* ctx, pioran_ctx::Buf& b, const void* host, size_t bytes)
 {
     int rc = ensure(ctx, b, bytes);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const void* src = host;
+    if (void* st = pin_reserve(ctx, bytes)) {
+        std::memcpy(st, host, bytes);
+        src = st;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return PIORAN_OK;
+}
+
+// device -> caller: through pinned staging (delivered by the next ctx_sync) where it fits, else directly
+int download(pioran_ctx* ctx, void* host, const void* dev, size_t bytes)
+{
+    if (void* st = pin_reserve(ctx, bytes)) {
+        HIPCHK(ctx, hipMemcpyAsync(st, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->pending.push_back({host, st, bytes});
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
     return PIORAN_OK;
 }
 
@@ -129,7 +191,7 @@ int set_rowmap(pioran_ds* ds, PrepState& s, const std::vector<int32_t>& rm)
     HIPCHK(ctx, hipMemcpyAsync(s.rowmap, rm.data(), rm.size() * sizeof(int32_t), hipMemcpyHostToDevice,
                                ctx->stream));
     // the host vector is about to go out of scope in the callers: finish the copy first
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNC(ctx);
     s.R = (int32_t)rm.size();
     return PIORAN_OK;
 }
@@ -259,6 +321,7 @@ int pioran_ctx_destroy(pioran_ctx* ctx)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->gev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -269,7 +332,7 @@ int pioran_ctx_trim(pioran_ctx* ctx)
 {
     if (!ctx) return PIORAN_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNC(ctx);
     pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
                                &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift};
     for (auto* b : bufs) {
@@ -277,13 +340,16 @@ int pioran_ctx_trim(pioran_ctx* ctx)
         b->p = nullptr;
         b->cap = 0;
     }
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    ctx->pin = nullptr;
+    ctx->pin_cap = ctx->pin_off = 0;
     return PIORAN_OK;
 }
 
 int pioran_ctx_synchronize(pioran_ctx* ctx)
 {
     if (!ctx) return PIORAN_ERR_ARG;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNC(ctx);
     return PIORAN_OK;
 }
 
@@ -385,7 +451,7 @@ static int prepare_state(pioran_ds* ds, PrepState& s, int64_t J, const double* c
     if (!pdlist.empty()) {
         if (!s.dpd_terms && hipMalloc((void**)&s.dpd_terms, 256 * sizeof(int32_t)) != hipSuccess) return PIORAN_ERR_ALLOC;
         HIPCHK(ctx, hipMemcpyAsync(s.dpd_terms, pdlist.data(), pdlist.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        SYNC(ctx);
     }
     // the table is per ROW (v, x, phi) + (y_n, sigma2_n) per step, see table.hip
     const size_t need = pioran_table_doubles(ds->N, s.R);
@@ -460,7 +526,7 @@ int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const
     if (rc) return rc;
     drm = (int32_t*)ctx->bwork.p;
     HIPCHK(ctx, hipMemcpyAsync(drm, rm.data(), rm.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNC(ctx);
     ScanParams p{};
     p.N = ds->N; p.J = (int32_t)J; p.R = (int32_t)rm.size(); p.B = B;
     p.standard_rows = 1;
@@ -560,9 +626,9 @@ static int batch_host_mixed(pioran_ds* ds, int64_t B, int64_t J, const double* A
         p.opt = &ctx->opt;
         rc = scan_dispatch(p, ctx->stream);
         if (rc) { ctx->last_err = "mixed-mode scan launch failed"; return rc; }
-        HIPCHK(ctx, hipMemcpyAsync(out + b0, ctx->bout.p, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (status) HIPCHK(ctx, hipMemcpyAsync(status + b0, ctx->bst.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = download(ctx, out + b0, ctx->bout.p, nb * sizeof(double)))) return rc;
+        if (status) if ((rc = download(ctx, status + b0, ctx->bst.p, nb * sizeof(int32_t)))) return rc;
+        SYNC(ctx);
     }
     return 1;
 }
@@ -611,10 +677,10 @@ static int batch_host_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A,
                                                (const double*)ctx->bC.p, (const double*)ctx->bD.p, dmu, dnu, dY, dS2,
                                                (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(out, ctx->bout.p, B * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = download(ctx, out, ctx->bout.p, B * sizeof(double)))) return rc;
     if (status)
-        HIPCHK(ctx, hipMemcpyAsync(status, ctx->bst.p, B * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = download(ctx, status, ctx->bst.p, B * sizeof(int32_t)))) return rc;
+    SYNC(ctx);
     return PIORAN_OK;
 }
 
@@ -701,7 +767,7 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
                               (const double*)ctx->bC.p, (const double*)ctx->bD.p, (double*)ctx->bA.p, (double*)ctx->bB.p,
                               ctx->stream);
     if (rc) return rc;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // sp/LU/piv host vectors go out of scope below
+    SYNC(ctx);   // sp/LU/piv host vectors go out of scope below
     if (mu && (rc = upload(ctx, ctx->bmu, mu, B * sizeof(double)))) return rc;
     if (nu && (rc = upload(ctx, ctx->bnu, nu, B * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->bout, B * sizeof(double)))) return rc;
@@ -717,11 +783,11 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
                                             nullptr, (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
     }
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(out, ctx->bout.p, B * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (status) HIPCHK(ctx, hipMemcpyAsync(status, ctx->bst.p, B * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (A_out) HIPCHK(ctx, hipMemcpyAsync(A_out, ctx->bA.p, bj, hipMemcpyDeviceToHost, ctx->stream));
-    if (Bc_out) HIPCHK(ctx, hipMemcpyAsync(Bc_out, ctx->bB.p, bj, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = download(ctx, out, ctx->bout.p, B * sizeof(double)))) return rc;
+    if (status) if ((rc = download(ctx, status, ctx->bst.p, B * sizeof(int32_t)))) return rc;
+    if (A_out) if ((rc = download(ctx, A_out, ctx->bA.p, bj))) return rc;
+    if (Bc_out) if ((rc = download(ctx, Bc_out, ctx->bB.p, bj))) return rc;
+    SYNC(ctx);
     return PIORAN_OK;
 }
 
@@ -782,9 +848,9 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
         rc = pioran_launch_predict(p, (double*)ctx->bwork.p, ds->t, M, (const double*)ctx->bshift.p, (double*)ctx->bY.p,
                                    ctx->stream);
         if (rc) { ctx->last_err = "prediction launch failed"; return rc; }
-        HIPCHK(ctx, hipMemcpyAsync(mean_out + b0 * M, ctx->bY.p, (size_t)nb * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (status) HIPCHK(ctx, hipMemcpyAsync(status + b0, ctx->bst.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = download(ctx, mean_out + b0 * M, ctx->bY.p, (size_t)nb * M * sizeof(double)))) return rc;
+        if (status) if ((rc = download(ctx, status + b0, ctx->bst.p, nb * sizeof(int32_t)))) return rc;
+        SYNC(ctx);
     }
     return PIORAN_OK;
 }
@@ -862,20 +928,20 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
         if (shift) {
             rc = pioran_launch_shift_grad(ds->N, nb, ds->y, ds->s2, dshift, p.g_y, p.g_s2, dshift + chunk, ctx->stream);
             if (rc) return rc;
-            HIPCHK(ctx, hipMemcpyAsync(grad_shift + b0, dshift + chunk, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            if ((rc = download(ctx, grad_shift + b0, dshift + chunk, nb * sizeof(double)))) return rc;
         }
         const size_t nbj = (size_t)nb * J * sizeof(double);
-        HIPCHK(ctx, hipMemcpyAsync(out + b0, ctx->bout.p, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (status) HIPCHK(ctx, hipMemcpyAsync(status + b0, ctx->bst.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(grad_a + b0 * J, dga, nbj, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(grad_b + b0 * J, dgb, nbj, hipMemcpyDeviceToHost, ctx->stream));
-        if (grad_c) HIPCHK(ctx, hipMemcpyAsync(grad_c + b0 * J, dgc, nbj, hipMemcpyDeviceToHost, ctx->stream));
-        if (grad_d) HIPCHK(ctx, hipMemcpyAsync(grad_d + b0 * J, dgd, nbj, hipMemcpyDeviceToHost, ctx->stream));
-        if (grad_nu) HIPCHK(ctx, hipMemcpyAsync(grad_nu + b0, dgn, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (grad_mu) HIPCHK(ctx, hipMemcpyAsync(grad_mu + b0, dgm, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (grad_y) HIPCHK(ctx, hipMemcpyAsync(grad_y + b0 * ds->N, ctx->bY.p, (size_t)nb * ds->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (grad_sigma2) HIPCHK(ctx, hipMemcpyAsync(grad_sigma2 + b0 * ds->N, ctx->bS2.p, (size_t)nb * ds->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = download(ctx, out + b0, ctx->bout.p, nb * sizeof(double)))) return rc;
+        if (status) if ((rc = download(ctx, status + b0, ctx->bst.p, nb * sizeof(int32_t)))) return rc;
+        if ((rc = download(ctx, grad_a + b0 * J, dga, nbj))) return rc;
+        if ((rc = download(ctx, grad_b + b0 * J, dgb, nbj))) return rc;
+        if (grad_c) if ((rc = download(ctx, grad_c + b0 * J, dgc, nbj))) return rc;
+        if (grad_d) if ((rc = download(ctx, grad_d + b0 * J, dgd, nbj))) return rc;
+        if (grad_nu) if ((rc = download(ctx, grad_nu + b0, dgn, nb * sizeof(double)))) return rc;
+        if (grad_mu) if ((rc = download(ctx, grad_mu + b0, dgm, nb * sizeof(double)))) return rc;
+        if (grad_y) if ((rc = download(ctx, grad_y + b0 * ds->N, ctx->bY.p, (size_t)nb * ds->N * sizeof(double)))) return rc;
+        if (grad_sigma2) if ((rc = download(ctx, grad_sigma2 + b0 * ds->N, ctx->bS2.p, (size_t)nb * ds->N * sizeof(double)))) return rc;
+        SYNC(ctx);
     }
     return PIORAN_OK;
 }
@@ -959,7 +1025,7 @@ int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, c
         rc = pioran_launch_scan_wide_sim(p, ctx->stream);
         if (rc) { ctx->last_err = "simulation launch failed"; return done(rc); }
         if (hipMemcpyAsync(y_out + b0 * N, ctx->bS2.p, (size_t)nb * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            ctx_sync(ctx) != PIORAN_OK) {
             ctx->last_err = "simulation copy-back failed";
             return done(PIORAN_ERR_HIP);
         }
@@ -1094,9 +1160,9 @@ static int dense_nll_impl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a
                                  phase_ms ? &ctx->ev[13] : nullptr, dv[7], (int32_t*)dv[8], is_sorted(t, N), ctx->stream);
     if (rc) { ctx->last_err = "dense kernel launch failed"; return rc; }
     int32_t hinfo = 0;
-    HIPCHK(ctx, hipMemcpyAsync(out, dv[7], sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = download(ctx, out, dv[7], sizeof(double)))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(&hinfo, dv[8], sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNC(ctx);
     if (info) *info = hinfo;
     if (phase_ms)
         for (int i = 0; i < 3; ++i) HIPCHK(ctx, hipEventElapsedTime(&phase_ms[i], ctx->ev[12 + i], ctx->ev[13 + i]));
@@ -1138,7 +1204,7 @@ static int dense_predict_impl(pioran_ctx* ctx, int64_t N, int64_t J, const doubl
     int rc = dense_stage(ctx, Mtot, J, a, b, c, d, te.data(), ye.data(), s2e.data(), dv);
     if (rc) return rc;
     // dense_stage copies asynchronously from the vectors above: they must outlive the copies
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNC(ctx);
     if ((rc = ensure(ctx, ctx->bout, (size_t)M * sizeof(double)))) return rc;
     rc = pioran_dense_predict_cov_device(N, M, (int32_t)J, dv[0], dv[1], dv[2], dv[3], dv[4], dv[6], (double*)ctx->bK.p,
                                          (int32_t*)dv[8], y ? dv[5] : nullptr, y ? (double*)ctx->bout.p : nullptr, ctx->stream);
@@ -1149,9 +1215,9 @@ static int dense_predict_impl(pioran_ctx* ctx, int64_t N, int64_t J, const doubl
         HIPCHK(ctx, hipMemcpy2DAsync(cov_out, (size_t)M * sizeof(double), (const double*)ctx->bK.p + Mp + Mp * ld,
                                      (size_t)ld * sizeof(double), (size_t)M * sizeof(double), (size_t)M, hipMemcpyDeviceToHost,
                                      ctx->stream));
-    if (mean_out) HIPCHK(ctx, hipMemcpyAsync(mean_out, ctx->bout.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (mean_out) if ((rc = download(ctx, mean_out, ctx->bout.p, (size_t)M * sizeof(double)))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(&hinfo, dv[8], sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNC(ctx);
     if (cov_out) {
         // the slab holds the lower triangle (column k, rows i >= k): mirror it
         for (int64_t k = 0; k < M; ++k)
@@ -1195,7 +1261,7 @@ int pioran_dense_covariance(pioran_ctx* ctx, int64_t N, int64_t J, const double*
     pioran_dense_dims(N, &Mp, &ld);
     HIPCHK(ctx, hipMemcpy2DAsync(K_out, (size_t)N * sizeof(double), ctx->bK.p, (size_t)ld * sizeof(double),
                                  (size_t)N * sizeof(double), (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNC(ctx);
     // the slab holds the lower triangle (column-major): mirror it, K is symmetric (src/direct_solver.jl:9-14 fills both)
     for (int64_t k = 0; k < N; ++k)
         for (int64_t i = k + 1; i < N; ++i) K_out[k + i * N] = K_out[i + k * N];
