@@ -34,6 +34,7 @@
 namespace {
 
 constexpr int NB = 64;
+constexpr int kPairThreshold = 24;   // trailing tiles per side above which steps are taken in pairs (128-deep updates)
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 __global__ void __launch_bounds__(256) dense_build_kernel(int64_t N, int64_t Mp, int64_t ld, int32_t J,
@@ -454,8 +455,15 @@ __global__ void __launch_bounds__(256) dense_panel_kernel(double* __restrict__ A
 // result reg g of lane l is D[row (l>>4) + 4g][col l&15]  (f64 layout, cdna_hip_programming.md section 3).
 // With X[row][k] = P[j][k] and Y[k][col] = P[i][k], D[row][col] = (P P^T)[i][j]: col = l&15 runs along i,
 // the memory-contiguous index of the column-major slab, so C loads/stores are 128-byte segments.
+// KP = 1: the trailing update of one 64-column step.  KP = 2: TWO adjacent, finished panels (columns kb .. kb + 127) applied
+// in one pass to the trailing matrix that starts at kb + 128 — the read-modify-write of C, which bounds the early steps
+// (each 64 x 64 x 64 tile moves 128 KB through L2 for 0.5 Mflop), happens once per 128 columns instead of once per 64.
+// col0_only (KP = 1): only block column 0 of the trailing matrix (the next panel) and its diagonal tile — the narrow
+// update between the two panel solves of a pair.
+template <int KP>
 __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__ A, int64_t ld, int64_t kb, int64_t Mp,
-                                                         double* __restrict__ ws, int32_t* __restrict__ info, int factor_next)
+                                                         double* __restrict__ ws, int32_t* __restrict__ info, int factor_next,
+                                                         int col0_only)
 {
     // Workgroups of four wavefronts.  Workgroup 0 is the critical path: its four waves share tile (0,0) — the NEXT
     // diagonal block — one 16-column strip each, keep the updated tile in LDS and factor it right away
@@ -463,27 +471,30 @@ __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__
     // finished diagonal block.  Every other workgroup takes four tiles, one per wavefront.
     __shared__ double Ls[NB * LP];
     __shared__ int flag;
-    const int64_t j0 = kb + NB;
+    const int64_t j0 = kb + NB * KP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
 
     if (blockIdx.x == 0) {
-        const double* P0 = A + j0 + kb * ld + lr + (int64_t)lk * ld;   // rows of diagonal block k+1, panel columns
         f64x4 acc[4];   // [ib], column strip jb = wave
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) acc[ib] = f64x4{0.0, 0.0, 0.0, 0.0};
-        double xa[16], yb[16][4];
 #pragma unroll
-        for (int k4 = 0; k4 < 16; ++k4) {
-            xa[k4] = P0[wave * 16 + (int64_t)(4 * k4) * ld];
+        for (int pp = 0; pp < KP; ++pp) {
+            const double* P0 = A + j0 + (kb + NB * pp) * ld + lr + (int64_t)lk * ld;   // rows of the next diagonal block, panel columns
+            double xa[16], yb[16][4];
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) yb[k4][ib] = P0[ib * 16 + (int64_t)(4 * k4) * ld];
+            for (int k4 = 0; k4 < 16; ++k4) {
+                xa[k4] = P0[wave * 16 + (int64_t)(4 * k4) * ld];
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) yb[k4][ib] = P0[ib * 16 + (int64_t)(4 * k4) * ld];
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 16; ++k4)
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib)
+                    acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k4], yb[k4][ib], acc[ib], 0, 0, 0);
         }
-#pragma unroll
-        for (int k4 = 0; k4 < 16; ++k4)
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib)
-                acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k4], yb[k4][ib], acc[ib], 0, 0, 0);
         double* C = A + j0 + j0 * ld + lr + (int64_t)lk * ld;
         double cv[4][4];
 #pragma unroll
@@ -508,10 +519,16 @@ __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__
     const int nt = (int)((Mp - j0) / NB) + 1;
     // linear tile id -> (ti, tj) with ti >= tj; tile 0 belongs to workgroup 0
     const int bid = ((int)blockIdx.x - 1) * 4 + wave + 1;
-    int ti = (int)((sqrt(8.0 * bid + 1.0) - 1.0) * 0.5);
-    while ((int64_t)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
-    while ((int64_t)ti * (ti + 1) / 2 > bid) --ti;
-    const int tj = bid - (int)((int64_t)ti * (ti + 1) / 2);
+    int ti, tj;
+    if (col0_only) {   // block column 0 only: tiles (1 .. nt-1, 0)
+        ti = bid;
+        tj = 0;
+    } else {
+        ti = (int)((sqrt(8.0 * bid + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+        while ((int64_t)ti * (ti + 1) / 2 > bid) --ti;
+        tj = bid - (int)((int64_t)ti * (ti + 1) / 2);
+    }
     if (ti >= nt || tj >= nt - 1) return;   // wave-uniform; no workgroup barrier below
     // Row permutation inside the tile: MFMA strip s (s = 0..3) takes the rows 32 (s >> 1) + 2 r + (s & 1), r = 0..15,
     // instead of 16 s + r.  Lane (lr, lk) then needs rows 2 lr and 2 lr + 1 of each half of the tile — ADJACENT in the
@@ -546,8 +563,8 @@ __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__
     load_kstep(0, 0);
     load_kstep(1, 1);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-        if (ks + 2 < 16) load_kstep(ks + 2, (ks + 2) % 3);
+    for (int ks = 0; ks < 16 * KP; ++ks) {
+        if (ks + 2 < 16 * KP) load_kstep(ks + 2, (ks + 2) % 3);
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
@@ -661,7 +678,7 @@ int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double*
     if (hipMemsetAsync(info, 0, sizeof(int32_t), stream) != hipSuccess) return PIORAN_ERR_HIP;
     double* ws = K + (size_t)ld * (size_t)Mp;   // WS_DOUBLES doubles right behind the slab
     hipLaunchKernelGGL(dense_diag0_kernel, dim3(1), dim3(256), 0, stream, K, ld, ws, info);
-    for (int64_t kb = 0; kb < Mp; kb += NB) {
+    auto panel = [&](int64_t kb) {
         // rows below the block: kb+NB .. Mp+63 (the y row Mp and the scratch rows of its 64-row tile)
         const int64_t below = Mp - kb;
         // one 16-row strip per wave while that still fills the chip's 1024 SIMDs at most a few times over (the step
@@ -670,10 +687,28 @@ int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double*
             hipLaunchKernelGGL(dense_panel_kernel<1>, dim3((unsigned)((below + 63) / 64)), dim3(256), 0, stream, K, ld, kb, ws);
         else
             hipLaunchKernelGGL(dense_panel_kernel<2>, dim3((unsigned)((below + 127) / 128)), dim3(256), 0, stream, K, ld, kb, ws);
-        const int64_t nt = (Mp - kb - NB) / NB + 1;
-        if (nt > 1)
-            hipLaunchKernelGGL(dense_syrk_kernel, dim3((unsigned)(1 + (nt * (nt + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
-                               kb, Mp, ws, info, 1);
+    };
+    // While the trailing update is bound by the traffic of C (more tile-waves than the chip holds at once), steps go in
+    // PAIRS: panel k, narrow update of block column k+1 (+ its diagonal factor), panel k+1, then ONE 128-deep update of the
+    // rest; afterwards (latency-bound steps) one 64-deep update per step as before.
+    int64_t kb = 0;
+    while (kb < Mp) {
+        const int64_t nt = (Mp - kb - NB) / NB + 1;           // i tiles of the trailing matrix of step kb (incl. the y-row tile)
+        if (nt > kPairThreshold && kb + 2 * NB < Mp) {
+            panel(kb);
+            hipLaunchKernelGGL(dense_syrk_kernel<1>, dim3((unsigned)(1 + (nt - 1 + 3) / 4)), dim3(256), 0, stream, K, ld, kb, Mp, ws, info, 1, 1);
+            panel(kb + NB);
+            const int64_t nt2 = nt - 1;                        // trailing matrix of the pair starts one block further
+            hipLaunchKernelGGL(dense_syrk_kernel<2>, dim3((unsigned)(1 + (nt2 * (nt2 + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
+                               kb, Mp, ws, info, 1, 0);
+            kb += 2 * NB;
+        } else {
+            panel(kb);
+            if (nt > 1)
+                hipLaunchKernelGGL(dense_syrk_kernel<1>, dim3((unsigned)(1 + (nt * (nt + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
+                                   kb, Mp, ws, info, 1, 0);
+            kb += NB;
+        }
     }
     if (phase_ev) (void)hipEventRecord(phase_ev[1], stream);
     hipLaunchKernelGGL(dense_finish_kernel, dim3(1), dim3(256), 0, stream, K, ld, N, Mp, out, info);
@@ -705,8 +740,8 @@ int pioran_dense_predict_cov_device(int64_t N, int64_t M, int32_t J, const doubl
         else
             hipLaunchKernelGGL(dense_panel_kernel<2>, dim3((unsigned)((below + 127) / 128)), dim3(256), 0, stream, K, ld, kb, ws);
         const int64_t nt = (Mtot - kb - NB) / NB + 1;   // >= 2: the tau block is never empty
-        hipLaunchKernelGGL(dense_syrk_kernel, dim3((unsigned)(1 + (nt * (nt + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
-                           kb, Mtot, ws, info, kb + NB < Mp ? 1 : 0);
+        hipLaunchKernelGGL(dense_syrk_kernel<1>, dim3((unsigned)(1 + (nt * (nt + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
+                           kb, Mtot, ws, info, kb + NB < Mp ? 1 : 0, 0);
     }
     if (y && mean)
         hipLaunchKernelGGL(dense_predict_mean_kernel, dim3((unsigned)M), dim3(256), 0, stream, K, ld, Mtot, Mp, M, mean, info);
