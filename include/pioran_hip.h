@@ -138,17 +138,22 @@ int pioran_celerite_logl_batch_shift_dev(pioran_ds* ds, int64_t B, const double*
                                          const double* dmu, const double* dnu, const double* dshift,
                                          double* dout, int32_t* dstatus);
 /* theta -> log L in one call: `approx` (src/psd.jl:214-289) runs on the device in front of the scan, so only the
- * sampled parameters cross the boundary.  Continuum-only PSD models:
+ * sampled parameters cross the boundary.  Continuum PSD models:
  *   model 0  SingleBendingPowerLaw(alpha1, f1, alpha2)                  P = 3 parameters per draw
  *   model 1  DoubleBendingPowerLaw(alpha1, f1, alpha2, f2, alpha3)      P = 5
  * basis 0 "SHO" (J = n_components terms), 1 "DRWCelerite" (J = 2 n_components terms);
  * theta [B][P], norm [B] (the `norm` argument of approx), is_integrated_power / S_low / S_high as in approx;
- * mu, nu, shift: [B] or NULL, as in pioran_celerite_logl_batch[_shift].  Host pointers, blocking.
- * Also returns, when A_out / Bc_out are non-NULL ([B][J] host), the coefficients approx produced. */
+ * mu, nu, shift: [B] or NULL, as in pioran_celerite_logl_batch[_shift].
+ * PSD features (`continuum + QPO(S0, f0, Q) + ...`, src/psd.jl:15-27, 228-241, 254-261): n_qpo (0..8) Lorentzians per draw,
+ * qpo [B][n_qpo][3] = (S0, f0, Q) (NULL when n_qpo = 0); each becomes one more celerite term whose (c, d) differ per draw —
+ * the scan then runs in the mixed mode (shared table for the continuum, per-draw rows for the features).
+ * Host pointers, blocking.  Also returns, when A_out / Bc_out are non-NULL ([B][J + n_qpo] host), the coefficients
+ * approx produced (feature terms last, as the reference concatenates them). */
 int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_components, int basis,
                               int is_integrated_power, double f_min, double f_max, double S_low, double S_high,
                               const double* theta, const double* norm, const double* mu, const double* nu,
-                              const double* shift, double* out, int32_t* status, double* A_out, double* Bc_out);
+                              const double* shift, int64_t n_qpo, const double* qpo, double* out, int32_t* status,
+                              double* A_out, double* Bc_out);
 /* ---- posterior mean and simulation (the callers either side of the likelihood) -----------
  * predict (src/celerite_solver.jl:348-361 -> pred :363-483; mean(::PosteriorGP, tau) of src/scalable_GP.jl:64-72,90-91):
  *     mean_out[b][m] = mu_b + sum_n z_n k_b(|tau_m - t_n|),   z = K_b^-1 (y - mu_b),  K_b = kernel_b + diag(nu_b sigma2)

@@ -43,7 +43,7 @@ SIGNATURES = {
     "pioran_celerite_logl_batch_shift_dev": (ctypes.c_int, [c_void_p, i64] + [c_void_p] * 7),
     "pioran_logpdf_batch_theta": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
-                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, i64, c_void_p, c_void_p, c_void_p,
                                                  c_void_p, c_void_p]),
     "pioran_celerite_predict": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, i64, c_void_p, c_void_p, c_void_p]),

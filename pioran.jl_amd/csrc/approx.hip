@@ -8,7 +8,11 @@
 //           the variance form                              get_norm_psd                   :301-324,375-395
 //   SHO:          a = b = A_j f_j pi / sqrt2                                               :249-252
 //   DRWCelerite:  a = A_j f_j pi / 3, b = sqrt3 a  ++  (a, 0)                             :264-275
-// c_j, d_j depend only on the grid and stay on the host side of the ABI (pioran_dataset_prepare).
+// PSD features (QPO, src/psd.jl:15-27, 228-241, 254-261): n_qpo Lorentzians (S0, f0, Q) per draw become one celerite term each,
+//   a = S0 w0 Q / 4, b = a / Delta, c = w0 / (2 Q), d = c Delta (Delta = sqrt(4 Q^2 - 1), w0 = 2 pi f0), a and b divided by the
+// continuum's P(f_0) like the amplitudes, their integral (integrate_psd_feature :356-358) added to the normalisation when
+// is_integrated_power, and appended as (2a, 2b, c, d) after the continuum terms; their (c, d) differ per draw.
+// c_j, d_j of the continuum depend only on the grid and stay on the host side of the ABI (pioran_dataset_prepare).
 // PSD models are Tonari.jl's closed forms (test/test_psd.jl:3-13).  The J x J matrix B is LU-factorised once
 // on the host (partial pivoting, like Julia's `\`); each draw is one thread doing 2 J^2 flops of triangular
 // solves in its own output row.  Cost ~ J (2 pow + log + atan2) + 2 J^2 flop per draw: microseconds per batch.
@@ -32,11 +36,13 @@ __global__ void __launch_bounds__(64) approx_kernel(int64_t B, int model, int P,
                                                     double f_min, double f_max, const double* __restrict__ sp,
                                                     const double* __restrict__ LU, const int32_t* __restrict__ piv,
                                                     const double* __restrict__ theta, const double* __restrict__ norm,
-                                                    double* __restrict__ A, double* __restrict__ Bc)
+                                                    int n_qpo, const double* __restrict__ qpo, double* __restrict__ A,
+                                                    double* __restrict__ Bc, double* __restrict__ Cq, double* __restrict__ Dq)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const int Jt = basis == 0 ? J : 2 * J;       // celerite terms
+    const int Jc = basis == 0 ? J : 2 * J;       // celerite terms of the continuum
+    const int Jt = Jc + n_qpo;                   // + one per feature
     double* x = A + b * Jt;                      // work in place in the output row (first J entries)
     const double* th = theta + b * P;
     const double p0 = psd_model(model, th, sp[0]);
@@ -80,6 +86,18 @@ __global__ void __launch_bounds__(64) approx_kernel(int64_t B, int model, int P,
             }
         }
         integ = hi - lo;
+        // features: integral of the celerite power spectrum between f_min and f_max   (src/psd.jl:330-334, 356-358)
+        for (int q = 0; q < n_qpo; ++q) {
+            const double S0 = qpo[(b * n_qpo + q) * 3], f0q = qpo[(b * n_qpo + q) * 3 + 1], Q = qpo[(b * n_qpo + q) * 3 + 2];
+            const double De = sqrt(4.0 * Q * Q - 1.0), w0 = 2.0 * M_PI * f0q;
+            const double fa = S0 * w0 * Q / 4.0 / p0, fb = fa / De, fc = w0 / Q / 2.0, fd = fc * De;
+            auto icel = [&](double xx) {
+                const double num = fc * fc + (fd + 2.0 * M_PI * xx) * (fd + 2.0 * M_PI * xx);
+                const double den = fc * fc + (fd - 2.0 * M_PI * xx) * (fd - 2.0 * M_PI * xx);
+                return (2.0 * fa * (atan2(fc, fd - 2.0 * M_PI * xx) - atan2(fc, fd + 2.0 * M_PI * xx)) + fb * log(num / den)) / (2.0 * M_PI);
+            };
+            integ += icel(f_max) - icel(f_min);
+        }
     } else {
         double acc = 0.0;
         for (int j = 0; j < J; ++j) acc += x[j] * sp[j];
@@ -87,6 +105,15 @@ __global__ void __launch_bounds__(64) approx_kernel(int64_t B, int model, int P,
     }
     const double scale = norm[b] / integ;
     double* bb = Bc + b * Jt;
+    for (int q = 0; q < n_qpo; ++q) {            // (2a, 2b, c, d) of the feature terms   (:254-261, 276-283)
+        const double S0 = qpo[(b * n_qpo + q) * 3], f0q = qpo[(b * n_qpo + q) * 3 + 1], Q = qpo[(b * n_qpo + q) * 3 + 2];
+        const double De = sqrt(4.0 * Q * Q - 1.0), w0 = 2.0 * M_PI * f0q;
+        const double fa = S0 * w0 * Q / 4.0 / p0 * scale, fc = w0 / Q / 2.0;
+        x[Jc + q] = 2.0 * fa;
+        bb[Jc + q] = 2.0 * (fa / De);
+        Cq[b * Jt + Jc + q] = fc;
+        Dq[b * Jt + Jc + q] = fc * De;
+    }
     if (basis == 0) {
         for (int j = 0; j < J; ++j) {
             const double a = x[j] * scale * sp[j] * M_PI / 1.4142135623730951;
@@ -153,11 +180,12 @@ int pioran_approx_setup_host(int64_t J, int basis, double f_min, double f_max, d
 
 int pioran_launch_approx(int64_t B, int model, int P, int J, int basis, int integrated, double f_min, double f_max,
                          const double* sp, const double* LU, const int32_t* piv, const double* theta, const double* norm,
-                         double* A, double* Bc, hipStream_t stream)
+                         int n_qpo, const double* qpo, double* A, double* Bc, double* Cq, double* Dq, hipStream_t stream)
 {
     const int64_t blocks = (B + 63) / 64;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return PIORAN_ERR_ARG;
+    if (n_qpo > 0 && (!qpo || !Cq || !Dq)) return PIORAN_ERR_ARG;
     hipLaunchKernelGGL(approx_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, B, model, P, J, basis, integrated, f_min,
-                       f_max, sp, LU, piv, theta, norm, A, Bc);
+                       f_max, sp, LU, piv, theta, norm, n_qpo, qpo, A, Bc, Cq, Dq);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <thread>
@@ -555,28 +556,19 @@ static int prepare_shared(pioran_ds* ds, int64_t B, int64_t J, const double* Bc,
 // top of an approx continuum, src/psd.jl:254-261), the shared terms keep using the shared table and only the per-draw
 // terms get a per-draw table, built by a pre-pass kernel for chunks of draws (32-bit buffer offsets).
 // Returns 1 if it handled the batch, 0 if the caller should take the generic per-draw path, < 0 on error.
-static int batch_host_mixed(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
-                            const double* Dd, const double* mu, const double* nu, const double* Y, const double* S2,
-                            bool series_on_device, double* out, int32_t* status)
+// Mixed-mode core: kind[J] (0 shared two-row, 1 shared real, 2 per-draw) and the shared values (C0, D0: [J], entries of
+// per-draw terms ignored) declare the layout; `fetch(b0, nb, ptrs)` hands the DEVICE pointers of one chunk of draws
+// (A, Bc, C, D as [nb][J]; mu, nu [nb] or nullptr; Y, S2 [nb][N] or nullptr).  Results go to the caller's host arrays.
+// Returns 1 if it handled the batch, 0 if this layout is not worth / not able to run mixed (caller takes the generic path).
+struct MixedChunk { const double *A, *Bc, *C, *D, *mu, *nu, *Y, *S2; };
+static int mixed_core(pioran_ds* ds, int64_t B, int64_t J, const std::vector<int32_t>& kind, const double* C0, const double* D0,
+                      const std::function<int(int64_t, int64_t, MixedChunk&)>& fetch, double* out, int32_t* status)
 {
     pioran_ctx* ctx = ds->ctx;
     PrepState& s = ds->host;
-    if (ctx->opt.no_mixed) return 0;
-    std::vector<int32_t> kind(J, 0);
-    int64_t npd = 0;
-    for (int64_t j = 0; j < J; ++j) {
-        bool shared = true;
-        for (int64_t b = 1; b < B && shared; ++b) shared = C[b * J + j] == C[j] && Dd[b * J + j] == Dd[j];
-        if (!shared) { kind[j] = 2; ++npd; continue; }
-        if (Dd[j] == 0.0) {
-            bool allzero = true;
-            for (int64_t b = 0; b < B && allzero; ++b) allzero = Bc[b * J + j] == 0.0;
-            kind[j] = allzero ? 1 : 0;
-        }
-    }
+    int64_t npd = 0, rows = 0;
+    for (int64_t j = 0; j < J; ++j) { npd += kind[j] == 2; rows += kind[j] == 1 ? 1 : 2; }
     if (npd == 0 || npd > 8 || npd * 2 > J) return 0;   // all shared is handled by the caller; many per-draw terms: generic
-    int64_t rows = 0;
-    for (int64_t j = 0; j < J; ++j) rows += kind[j] == 1 ? 1 : 2;
     if (rows > pioran_scan_supported_rows()) return 0;
     const int64_t rs_shared = 3 * (rows + 2) + 2;               // shared part of a step record (doubles)
     // combined table: (N+1) records of rs_shared + chunk * 2 npd * 3 doubles, addressed with 32-bit byte offsets
@@ -584,7 +576,7 @@ static int batch_host_mixed(pioran_ds* ds, int64_t B, int64_t J, const double* A
     chunk = chunk > B ? B : chunk & ~(int64_t)15;
     if (chunk < 16) return 0;
     int rc;
-    if ((rc = prepare_state(ds, s, J, C, Dd, kind.data()))) return rc;   // row 0 of C, Dd: the shared values
+    if ((rc = prepare_state(ds, s, J, C0, D0, kind.data()))) return rc;
     const int64_t rec_stride = rs_shared + chunk * 6 * npd;
     if ((rc = ensure(ctx, ctx->bscratch, (size_t)(ds->N + 1) * (size_t)rec_stride * sizeof(double)))) return rc;
     double* ctab = (double*)ctx->bscratch.p;
@@ -595,32 +587,18 @@ static int batch_host_mixed(pioran_ds* ds, int64_t B, int64_t J, const double* A
     if ((rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t)))) return rc;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
-        const size_t bj = (size_t)nb * (size_t)J * sizeof(double);
-        if ((rc = upload(ctx, ctx->bA, A + b0 * J, bj))) return rc;
-        if ((rc = upload(ctx, ctx->bB, Bc + b0 * J, bj))) return rc;
-        if ((rc = upload(ctx, ctx->bC, C + b0 * J, bj))) return rc;
-        if ((rc = upload(ctx, ctx->bD, Dd + b0 * J, bj))) return rc;
-        if (mu && (rc = upload(ctx, ctx->bmu, mu + b0, nb * sizeof(double)))) return rc;
-        if (nu && (rc = upload(ctx, ctx->bnu, nu + b0, nb * sizeof(double)))) return rc;
-        const double *dY = nullptr, *dS2 = nullptr;
-        if (Y) {
-            const size_t bn = (size_t)nb * (size_t)ds->N * sizeof(double);
-            if ((rc = upload(ctx, ctx->bY, Y + b0 * ds->N, bn))) return rc;
-            if ((rc = upload(ctx, ctx->bS2, S2 + b0 * ds->N, bn))) return rc;
-            dY = (const double*)ctx->bY.p; dS2 = (const double*)ctx->bS2.p;
-        } else if (series_on_device) {
-            dY = (const double*)ctx->bY.p + b0 * ds->N; dS2 = (const double*)ctx->bS2.p + b0 * ds->N;
-        }
-        rc = pioran_launch_pd_table(ds->N, nb, (int32_t)J, s.npd_terms, s.dpd_terms, ds->t, (const double*)ctx->bC.p,
-                                    (const double*)ctx->bD.p, ctab, rec_stride, rs_shared, ctx->stream);
+        MixedChunk m{};
+        if ((rc = fetch(b0, nb, m))) return rc;
+        rc = pioran_launch_pd_table(ds->N, nb, (int32_t)J, s.npd_terms, s.dpd_terms, ds->t, m.C, m.D, ctab, rec_stride, rs_shared,
+                                    ctx->stream);
         if (rc) return rc;
         ScanParams p{};
         p.N = ds->N; p.J = s.J; p.R = s.R; p.B = nb;
         p.standard_rows = s.row_layout; p.n_complex = s.n_complex;
         p.rec_stride = rec_stride;
         p.tab = ctab; p.rowmap = s.rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
-        p.Y = dY; p.S2 = dS2; p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = s.dc; p.D = s.dd;
-        p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
+        p.Y = m.Y; p.S2 = m.S2; p.A = m.A; p.Bc = m.Bc; p.C = s.dc; p.D = s.dd;
+        p.mu = m.mu; p.nu = m.nu;
         p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
         p.npd_rows = 2 * s.npd_terms;
         p.opt = &ctx->opt;
@@ -631,6 +609,47 @@ static int batch_host_mixed(pioran_ds* ds, int64_t B, int64_t J, const double* A
         SYNC(ctx);
     }
     return 1;
+}
+
+static int batch_host_mixed(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                            const double* Dd, const double* mu, const double* nu, const double* Y, const double* S2,
+                            bool series_on_device, double* out, int32_t* status)
+{
+    pioran_ctx* ctx = ds->ctx;
+    if (ctx->opt.no_mixed) return 0;
+    std::vector<int32_t> kind(J, 0);
+    for (int64_t j = 0; j < J; ++j) {
+        bool shared = true;
+        for (int64_t b = 1; b < B && shared; ++b) shared = C[b * J + j] == C[j] && Dd[b * J + j] == Dd[j];
+        if (!shared) { kind[j] = 2; continue; }
+        if (Dd[j] == 0.0) {
+            bool allzero = true;
+            for (int64_t b = 0; b < B && allzero; ++b) allzero = Bc[b * J + j] == 0.0;
+            kind[j] = allzero ? 1 : 0;
+        }
+    }
+    auto fetch = [&](int64_t b0, int64_t nb, MixedChunk& m) -> int {
+        int rc;
+        const size_t bj = (size_t)nb * (size_t)J * sizeof(double);
+        if ((rc = upload(ctx, ctx->bA, A + b0 * J, bj))) return rc;
+        if ((rc = upload(ctx, ctx->bB, Bc + b0 * J, bj))) return rc;
+        if ((rc = upload(ctx, ctx->bC, C + b0 * J, bj))) return rc;
+        if ((rc = upload(ctx, ctx->bD, Dd + b0 * J, bj))) return rc;
+        if (mu && (rc = upload(ctx, ctx->bmu, mu + b0, nb * sizeof(double)))) return rc;
+        if (nu && (rc = upload(ctx, ctx->bnu, nu + b0, nb * sizeof(double)))) return rc;
+        m.A = (const double*)ctx->bA.p; m.Bc = (const double*)ctx->bB.p; m.C = (const double*)ctx->bC.p; m.D = (const double*)ctx->bD.p;
+        m.mu = mu ? (const double*)ctx->bmu.p : nullptr; m.nu = nu ? (const double*)ctx->bnu.p : nullptr;
+        if (Y) {
+            const size_t bn = (size_t)nb * (size_t)ds->N * sizeof(double);
+            if ((rc = upload(ctx, ctx->bY, Y + b0 * ds->N, bn))) return rc;
+            if ((rc = upload(ctx, ctx->bS2, S2 + b0 * ds->N, bn))) return rc;
+            m.Y = (const double*)ctx->bY.p; m.S2 = (const double*)ctx->bS2.p;
+        } else if (series_on_device) {
+            m.Y = (const double*)ctx->bY.p + b0 * ds->N; m.S2 = (const double*)ctx->bS2.p + b0 * ds->N;
+        }
+        return PIORAN_OK;
+    };
+    return mixed_core(ds, B, J, kind, C, Dd, fetch, out, status);   // row 0 of C, Dd: the shared values
 }
 
 // host-pointer batch; series_on_device: ctx->bY / ctx->bS2 already hold the per-draw series (shift transform)
@@ -736,55 +755,98 @@ int pioran_celerite_logl_batch_shift(pioran_ds* ds, int64_t B, int64_t J, const 
 
 int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_components, int basis, int is_integrated_power,
                               double f_min, double f_max, double S_low, double S_high, const double* theta,
-                              const double* norm, const double* mu, const double* nu, const double* shift, double* out,
-                              int32_t* status, double* A_out, double* Bc_out)
+                              const double* norm, const double* mu, const double* nu, const double* shift, int64_t n_qpo,
+                              const double* qpo, double* out, int32_t* status, double* A_out, double* Bc_out)
 {
     if (!ds || B < 1 || !theta || !norm || !out || model < 0 || model > 1 || basis < 0 || basis > 1) return PIORAN_ERR_ARG;
+    if (n_qpo < 0 || n_qpo > 8 || (n_qpo > 0 && !qpo)) return PIORAN_ERR_ARG;
     pioran_ctx* ctx = ds->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int P = model == 0 ? 3 : 5;
-    const int64_t J = n_components, Jt = basis == 0 ? J : 2 * J;
+    const int64_t J = n_components, Jc = basis == 0 ? J : 2 * J, Jt = Jc + n_qpo;
     std::vector<double> sp, LU, c, d;
     std::vector<int32_t> piv, real;
     int rc = pioran_approx_setup_host(J, basis, f_min, f_max, S_low, S_high, sp, LU, piv, c, d, real);
     if (rc) return rc;
-    if ((rc = prepare_state(ds, ds->host, Jt, c.data(), d.data(), real.data()))) return rc;
-    // staging: [sp J | LU J*J | piv (as int32, J)] in bwork; theta in bC, norm in bD (free when (c,d) are shared)
+    // staging: [sp J | LU J*J | piv (as int32, J)] in bwork; theta in bC / norm in bD without QPO features (both free when
+    // (c, d) are shared); with features bC / bD receive the per-draw (c, d) of the feature terms and theta, norm, qpo ride in bwork
     const size_t nd = (size_t)J + (size_t)J * J + (size_t)J;
-    if ((rc = ensure(ctx, ctx->bwork, nd * sizeof(double)))) return rc;
+    const size_t nextra = n_qpo ? (size_t)B * (P + 1 + 3 * n_qpo) : 0;
+    if ((rc = ensure(ctx, ctx->bwork, (nd + nextra) * sizeof(double)))) return rc;
     double* dsp = (double*)ctx->bwork.p;
     double* dLU = dsp + J;
     int32_t* dpiv = (int32_t*)(dLU + J * J);
     HIPCHK(ctx, hipMemcpyAsync(dsp, sp.data(), J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dLU, LU.data(), J * J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dpiv, piv.data(), J * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = upload(ctx, ctx->bC, theta, (size_t)B * P * sizeof(double)))) return rc;
-    if ((rc = upload(ctx, ctx->bD, norm, (size_t)B * sizeof(double)))) return rc;
     const size_t bj = (size_t)B * (size_t)Jt * sizeof(double);
     if ((rc = ensure(ctx, ctx->bA, bj))) return rc;
     if ((rc = ensure(ctx, ctx->bB, bj))) return rc;
-    rc = pioran_launch_approx(B, model, P, (int)J, basis, is_integrated_power, f_min, f_max, dsp, dLU, dpiv,
-                              (const double*)ctx->bC.p, (const double*)ctx->bD.p, (double*)ctx->bA.p, (double*)ctx->bB.p,
-                              ctx->stream);
+    const double *dtheta, *dnorm, *dqpo = nullptr;
+    double *dCq = nullptr, *dDq = nullptr;
+    if (n_qpo) {
+        double* ex = dsp + nd;
+        HIPCHK(ctx, hipMemcpyAsync(ex, theta, (size_t)B * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ex + (size_t)B * P, norm, (size_t)B * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ex + (size_t)B * (P + 1), qpo, (size_t)B * 3 * n_qpo * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        dtheta = ex; dnorm = ex + (size_t)B * P; dqpo = ex + (size_t)B * (P + 1);
+        if ((rc = ensure(ctx, ctx->bC, bj))) return rc;
+        if ((rc = ensure(ctx, ctx->bD, bj))) return rc;
+        dCq = (double*)ctx->bC.p; dDq = (double*)ctx->bD.p;
+    } else {
+        if ((rc = upload(ctx, ctx->bC, theta, (size_t)B * P * sizeof(double)))) return rc;
+        if ((rc = upload(ctx, ctx->bD, norm, (size_t)B * sizeof(double)))) return rc;
+        dtheta = (const double*)ctx->bC.p; dnorm = (const double*)ctx->bD.p;
+    }
+    rc = pioran_launch_approx(B, model, P, (int)J, basis, is_integrated_power, f_min, f_max, dsp, dLU, dpiv, dtheta, dnorm,
+                              (int)n_qpo, dqpo, (double*)ctx->bA.p, (double*)ctx->bB.p, dCq, dDq, ctx->stream);
     if (rc) return rc;
     SYNC(ctx);   // sp/LU/piv host vectors go out of scope below
     if (mu && (rc = upload(ctx, ctx->bmu, mu, B * sizeof(double)))) return rc;
     if (nu && (rc = upload(ctx, ctx->bnu, nu, B * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->bout, B * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->bst, B * sizeof(int32_t)))) return rc;
     const double* dmu = mu ? (const double*)ctx->bmu.p : nullptr;
     const double* dnu = nu ? (const double*)ctx->bnu.p : nullptr;
+    const size_t bn = (size_t)B * (size_t)ds->N * sizeof(double);
     if (shift) {
         if ((rc = upload(ctx, ctx->bshift, shift, B * sizeof(double)))) return rc;
-        rc = batch_shift_dev_impl(ds, ds->host, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu,
-                                                  (const double*)ctx->bshift.p, (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
-    } else {
-        rc = batch_dev_impl(ds, ds->host, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu, nullptr,
-                                            nullptr, (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
+        if (n_qpo) {   // transformed series of the whole batch, chunks of the mixed core read their slices
+            if ((rc = ensure(ctx, ctx->bY, bn))) return rc;
+            if ((rc = ensure(ctx, ctx->bS2, bn))) return rc;
+            if ((rc = pioran_launch_shift_transform(ds->N, B, ds->y, ds->s2, (const double*)ctx->bshift.p, (double*)ctx->bY.p,
+                                                    (double*)ctx->bS2.p, ctx->stream))) return rc;
+        }
     }
-    if (rc) return rc;
-    if ((rc = download(ctx, out, ctx->bout.p, B * sizeof(double)))) return rc;
-    if (status) if ((rc = download(ctx, status, ctx->bst.p, B * sizeof(int32_t)))) return rc;
+    if (n_qpo) {
+        // continuum terms from the shared table, the feature terms (per-draw c, d) from the per-draw block: mixed mode
+        std::vector<int32_t> kind((size_t)Jt, 0);
+        std::vector<double> c0((size_t)Jt, 0.0), d0((size_t)Jt, 0.0);
+        for (int64_t j = 0; j < Jc; ++j) { kind[j] = real[j] ? 1 : 0; c0[j] = c[j]; d0[j] = d[j]; }
+        for (int64_t q = 0; q < n_qpo; ++q) kind[Jc + q] = 2;
+        auto fetch = [&](int64_t b0, int64_t nb, MixedChunk& m) -> int {
+            (void)nb;
+            m.A = (const double*)ctx->bA.p + b0 * Jt; m.Bc = (const double*)ctx->bB.p + b0 * Jt;
+            m.C = dCq + b0 * Jt; m.D = dDq + b0 * Jt;
+            m.mu = dmu ? dmu + b0 : nullptr; m.nu = dnu ? dnu + b0 : nullptr;
+            if (shift) { m.Y = (const double*)ctx->bY.p + b0 * ds->N; m.S2 = (const double*)ctx->bS2.p + b0 * ds->N; }
+            return PIORAN_OK;
+        };
+        rc = mixed_core(ds, B, Jt, kind, c0.data(), d0.data(), fetch, out, status);
+        if (rc < 0) return rc;
+        if (rc == 0) return PIORAN_ERR_UNSUPPORTED;   // too many rows for the register-resident kernels
+    } else {
+        if ((rc = prepare_state(ds, ds->host, Jc, c.data(), d.data(), real.data()))) return rc;
+        if ((rc = ensure(ctx, ctx->bout, B * sizeof(double)))) return rc;
+        if ((rc = ensure(ctx, ctx->bst, B * sizeof(int32_t)))) return rc;
+        if (shift)
+            rc = batch_shift_dev_impl(ds, ds->host, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu,
+                                      (const double*)ctx->bshift.p, (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
+        else
+            rc = batch_dev_impl(ds, ds->host, B, (const double*)ctx->bA.p, (const double*)ctx->bB.p, dmu, dnu, nullptr,
+                                nullptr, (double*)ctx->bout.p, (int32_t*)ctx->bst.p);
+        if (rc) return rc;
+        if ((rc = download(ctx, out, ctx->bout.p, B * sizeof(double)))) return rc;
+        if (status) if ((rc = download(ctx, status, ctx->bst.p, B * sizeof(int32_t)))) return rc;
+    }
     if (A_out) if ((rc = download(ctx, A_out, ctx->bA.p, bj))) return rc;
     if (Bc_out) if ((rc = download(ctx, Bc_out, ctx->bB.p, bj))) return rc;
     SYNC(ctx);

@@ -125,7 +125,8 @@ int pioran_approx_setup_host(int64_t J, int basis, double f_min, double f_max, d
 #endif
 int pioran_launch_approx(int64_t B, int model, int P, int J, int basis, int integrated, double f_min, double f_max,
                          const double* sp, const double* LU, const int32_t* piv, const double* theta, const double* norm,
-                         double* A, double* Bc, hipStream_t stream);
+                         int n_qpo, const double* qpo /*[B][n_qpo][3]: S0, f0, Q*/, double* A, double* Bc,
+                         double* Cq /*[B][Jt]: per-draw c of the feature terms*/, double* Dq, hipStream_t stream);
 // dense.hip
 void pioran_dense_dims(int64_t N, int64_t* Mp, int64_t* ld);
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,

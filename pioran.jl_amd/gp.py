@@ -310,11 +310,12 @@ class Dataset:
 
 
     def logpdf_theta(self, model, theta, norm, f_min, f_max, n_components=20, S_low=20.0, S_high=20.0, *,
-                     is_integrated_power=True, basis_function="SHO", mu=None, nu=None, shift=None,
+                     is_integrated_power=True, basis_function="SHO", mu=None, nu=None, shift=None, qpo=None,
                      return_status=False, return_coefs=False):
         """theta -> log L in one call, `approx` running on the device (pioran_logpdf_batch_theta).
         model: SingleBendingPowerLaw / DoubleBendingPowerLaw (the class); theta: (B, 3 | 5); norm: scalar or (B,)
-        — same meaning as the arguments of approx (src/psd.jl:214-289); mu, nu, shift as in logl_batch."""
+        — same meaning as the arguments of approx (src/psd.jl:214-289); mu, nu, shift as in logl_batch.
+        qpo: (B, n_qpo, 3) or (B, 3) = (S0, f0, Q) of the QPO features added to the continuum (src/psd.jl:15-27, 228-241)."""
         from .psd import DoubleBendingPowerLaw, SingleBendingPowerLaw
         mid = {SingleBendingPowerLaw: 0, DoubleBendingPowerLaw: 1}.get(model)
         if mid is None:
@@ -330,14 +331,18 @@ class Dataset:
         nu = None if nu is None else _f64(np.broadcast_to(nu, (B,)))
         shift = None if shift is None else _f64(np.broadcast_to(shift, (B,)))
         basis = 0 if basis_function == "SHO" else 1
-        Jt = n_components * (1 if basis == 0 else 2)
+        n_qpo = 0
+        if qpo is not None:
+            qpo = _f64(np.asarray(qpo, dtype=np.float64).reshape(B, -1, 3))
+            n_qpo = qpo.shape[1]
+        Jt = n_components * (1 if basis == 0 else 2) + n_qpo
         out = np.empty(B)
         st = np.zeros(B, dtype=np.int32)
         Ao = np.empty((B, Jt)) if return_coefs else None
         Bo = np.empty((B, Jt)) if return_coefs else None
         _lib.check(_lib.lib().pioran_logpdf_batch_theta(self._h, B, mid, int(n_components), basis, int(bool(is_integrated_power)),
                                                         float(f_min), float(f_max), float(S_low), float(S_high), _ptr(theta),
-                                                        _ptr(norm), _ptr(mu), _ptr(nu), _ptr(shift), _ptr(out), _ptr(st),
+                                                        _ptr(norm), _ptr(mu), _ptr(nu), _ptr(shift), n_qpo, _ptr(qpo), _ptr(out), _ptr(st),
                                                         _ptr(Ao), _ptr(Bo)), self.ctx._h)
         res = (out, st) if return_status else (out,)
         if return_coefs:

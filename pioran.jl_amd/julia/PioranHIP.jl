@@ -212,20 +212,22 @@ This is the whole body of an ultranest `vectorized=true` likelihood for the mode
 function logpdf_batch_theta(ds::Dataset, model::Symbol, θ::Matrix{Float64}, norm::Vector{Float64}, f_min::Real, f_max::Real,
                             n_components::Integer; basis::String = "SHO", is_integrated_power::Bool = true,
                             S_low::Real = 20.0, S_high::Real = 20.0, μ::Union{Nothing, Vector{Float64}} = nothing,
-                            ν::Union{Nothing, Vector{Float64}} = nothing, shift::Union{Nothing, Vector{Float64}} = nothing)
+                            ν::Union{Nothing, Vector{Float64}} = nothing, shift::Union{Nothing, Vector{Float64}} = nothing,
+                            qpo::Union{Nothing, Array{Float64, 3}} = nothing)   # 3 × n_qpo × nbatch: (S₀, f₀, Q) of the QPO features
     m = model === :SingleBendingPowerLaw ? 0 : model === :DoubleBendingPowerLaw ? 1 : error("model $model not supported on the device")
     bs = basis == "SHO" ? 0 : basis == "DRWCelerite" ? 1 : error("basis $basis not supported on the device")
     size(θ, 1) == (m == 0 ? 3 : 5) || error("θ must be $(m == 0 ? 3 : 5) × nbatch")
     nb = size(θ, 2)
+    nq = qpo === nothing ? 0 : size(qpo, 2)
     out = Vector{Float64}(undef, nb)
     status = zeros(Int32, nb)
     p(x) = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
-    GC.@preserve θ norm μ ν shift out status begin
+    GC.@preserve θ norm μ ν shift qpo out status begin
         check(ccall((:pioran_logpdf_batch_theta, LIB), Cint,
                     (Ptr{Cvoid}, Int64, Cint, Int64, Cint, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble},
-                     Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}),
+                     Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}),
                     ds.h, nb, m, n_components, bs, is_integrated_power ? 1 : 0, f_min, f_max, S_low, S_high, θ, norm,
-                    p(μ), p(ν), p(shift), out, status, C_NULL, C_NULL))
+                    p(μ), p(ν), p(shift), nq, p(qpo), out, status, C_NULL, C_NULL))
     end
     return out, status
 end

@@ -604,6 +604,53 @@ def test_device_approx_matches_host_approx(ctx, basis, integ):
     assert np.max(np.abs(A5 - A5h) / np.abs(A5h).max(axis=1, keepdims=True)) < 1e-9
 
 
+@pytest.mark.parametrize("basis,integ,nq", [("SHO", True, 1), ("SHO", False, 2), ("DRWCelerite", True, 1)])
+def test_device_approx_with_qpo_features(ctx, golden_dir, basis, integ, nq):
+    """approx(continuum + QPO features) on the device (src/psd.jl:228-241, 254-261): only (theta, norm, S0, f0, Q, mu, nu)
+    cross the boundary; the feature terms have per-draw (c, d) and run in the mixed mode.  Against the oracle's approx +
+    logl per draw, and against the host mirror's approx through the coefficient-level entry."""
+    rng = np.random.default_rng(60 + nq)
+    A_ = np.loadtxt(golden_dir / "simu.txt")
+    t, y, yerr = A_[:, 0], A_[:, 1], A_[:, 2]
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    B = 37
+    th = np.column_stack([rng.uniform(0.0, 1.2, B), np.exp(rng.uniform(np.log(f_min * 4), np.log(f_max / 4), B)), rng.uniform(2.0, 3.8, B)])
+    var = np.exp(rng.normal(np.log(np.var(y)), 0.5, B)); nu = rng.uniform(0.7, 1.5, B); mu = np.mean(y) + 0.1 * rng.standard_normal(B)
+    qpo = np.stack([np.column_stack([rng.uniform(0.05, 2.0, B), np.exp(rng.uniform(np.log(f_min * 20), np.log(f_max / 5), B)),
+                                     rng.uniform(2.0, 30.0, B)]) for _ in range(nq)], axis=1)      # (B, nq, 3): S0, f0, Q
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    got, st, Ao, Bo = ds.logpdf_theta(pj.SingleBendingPowerLaw, th, var, f_min, f_max, 20, is_integrated_power=integ,
+                                      basis_function=basis, mu=mu, nu=nu, qpo=qpo, return_status=True, return_coefs=True)
+    J = (20 if basis == "SHO" else 40) + nq
+    assert Ao.shape == (B, J) and (st == 0).all()
+    ref = np.empty(B); C = np.empty((B, J)); D = np.empty((B, J)); Ah = np.empty((B, J)); Bh = np.empty((B, J))
+    for i in range(B):
+        a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, *th[i]), f_min, f_max, 20, var[i], is_integrated_power=integ,
+                              basis_function=basis, qpo_features=[tuple(q) for q in qpo[i]])
+        ref[i] = O.logl(a, b, c, d, t, y - mu[i], nu[i] * yerr ** 2)
+        Ah[i], Bh[i], C[i], D[i] = a, b, c, d
+        # the host mirror of approx (the reference-shaped API) gives the same kernel
+        psd = pj.SingleBendingPowerLaw(*th[i])
+        for q in qpo[i]:
+            psd = psd + pj.QPO(*q)
+        R = pj.approx(psd, f_min, f_max, 20, var[i], is_integrated_power=integ, basis_function=basis)
+        np.testing.assert_allclose(R.a, a, rtol=1e-11); np.testing.assert_allclose(R.d, d, rtol=1e-12)
+    assert np.max(np.abs(Ao - Ah) / np.abs(Ah).max(axis=1, keepdims=True)) < 1e-9
+    assert np.max(np.abs(Bo - Bh) / np.abs(Ah).max(axis=1, keepdims=True)) < 1e-9
+    assert relerr(got, ref) < 1e-9
+    host = ds.logl_batch(Ah, Bh, C, D, mu=mu, nu=nu)       # coefficient-level entry, mixed mode on its own detection
+    assert relerr(host, ref) < 1e-10
+    # shifted log-flux series on top
+    ys = y - y.min() + 1.0
+    ds2 = pj.Dataset(t, ys, yerr ** 2, ctx)
+    shift = rng.uniform(0.0, 0.5, B)
+    got2 = ds2.logpdf_theta(pj.SingleBendingPowerLaw, th, var, f_min, f_max, 20, is_integrated_power=integ, basis_function=basis,
+                            mu=mu, nu=nu, shift=shift, qpo=qpo)
+    ref2 = np.array([O.logl(Ah[i], Bh[i], C[i], D[i], t, np.log(ys - shift[i]) - mu[i], nu[i] * yerr ** 2 / (ys - shift[i]) ** 2)
+                     for i in range(B)])
+    assert relerr(got2, ref2) < 1e-9
+
+
 def test_reference_outputs_ultranest_theta_only(ctx, golden_dir):
     """The reference's stored run once more, now with NOTHING but the sampled parameters crossing the boundary:
     approx, the shift transform and the scan all on the device; 5791 reference log-likelihoods, bar 1e-10."""
