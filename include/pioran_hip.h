@@ -220,6 +220,14 @@ int pioran_farm_logl_batch(pioran_farm* farm, int64_t B, int64_t J, const double
 int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,
                      const double* c, const double* d, const double* t, const double* y,
                      const double* sigma2, double* out, int32_t* info);
+/* B dense evaluations on one data set (the reference has no batch dimension: one log_likelihood_direct per call).  A, Bc
+ * [B][J]; C, Dd [J] (cd_shared != 0) or [B][J]; mu, nu [B] or NULL as in pioran_celerite_logl_batch: y - mu_b, nu_b sigma2.
+ * out[b] = +NLL of draw b, info[b] (may be NULL) as above.  The factorisations are independent: up to eight run
+ * concurrently, each on its own stream and slab, which is what fills the matrix cores at N of a few thousand (one
+ * factorisation alone is a chain of N/64 latency-bound steps). */
+int pioran_dense_nll_batch(pioran_ctx* ctx, int64_t N, int64_t J, int64_t B, const double* A, const double* Bc,
+                           const double* C, const double* Dd, int cd_shared, const double* t, const double* y,
+                           const double* sigma2, const double* mu, const double* nu, double* out, int32_t* info);
 /* Same call with event timing of its phases on the ctx stream: phase_ms[0] covariance build, [1] factorisation (all panel
  * and trailing-update launches), [2] finish kernel — what bench.py reports as the dense path's MFMA utilisation. */
 int pioran_dense_nll_timed(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b,

@@ -57,6 +57,8 @@ SIGNATURES = {
     "pioran_farm_logl_batch": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pioran_dense_nll": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [c_void_p, c_void_p]),
+    "pioran_dense_nll_batch": (ctypes.c_int, [c_void_p, i64, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pioran_dense_nll_timed": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [c_void_p, c_void_p, c_void_p]),
     "pioran_dense_predict_cov": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 6 + [i64, c_void_p, c_void_p, c_void_p]),
     "pioran_dense_predict": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [i64, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -26,6 +26,9 @@ struct pioran_ctx {
     size_t pin_cap = 0, pin_off = 0;
     struct Pending { void* host; const void* pinned; size_t bytes; };
     std::vector<Pending> pending;
+    // batched dense solver: independent factorisations on their own streams, one slab each (lazy)
+    hipStream_t dstream[8] = {};
+    hipEvent_t dev_[9] = {};
     // second stream + events of the gradient's reverse pass (replay of one segment overlaps the adjoint of the next); lazy
     hipStream_t aux = nullptr;
     hipEvent_t gev[5] = {};
@@ -322,6 +325,10 @@ int pioran_ctx_destroy(pioran_ctx* ctx)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->gev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->dev_)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& st : ctx->dstream)
+        if (st) (void)hipStreamDestroy(st);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1236,6 +1243,64 @@ int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, con
                      int32_t* info)
 {
     return dense_nll_impl(ctx, N, J, a, b, c, d, t, y, sigma2, out, info, nullptr);
+}
+
+int pioran_dense_nll_batch(pioran_ctx* ctx, int64_t N, int64_t J, int64_t B, const double* A, const double* Bc, const double* C,
+                           const double* Dd, int cd_shared, const double* t, const double* y, const double* sigma2,
+                           const double* mu, const double* nu, double* out, int32_t* info)
+{
+    if (!ctx || N < 1 || J < 1 || B < 1 || !A || !Bc || !C || !Dd || !t || !y || !sigma2 || !out) return PIORAN_ERR_ARG;
+    if (N > 46000) return PIORAN_ERR_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    int64_t Mp, ld;
+    pioran_dense_dims(N, &Mp, &ld);
+    const size_t slab = (size_t)Mp * (size_t)ld + 1024;
+    // concurrent factorisations: as many slabs as fit in a third of the free memory, at most 8 (one stream each).  A single
+    // N = 4096 factorisation is a chain of 64 latency-bound steps that leaves most of the chip idle; independent matrices fill it.
+    int64_t ns = B < 8 ? B : 8;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            while (ns > 1 && (size_t)ns * slab * sizeof(double) > free_b / 3 + ctx->bK.cap) --ns;
+    }
+    while ((rc = ensure(ctx, ctx->bK, (size_t)ns * slab * sizeof(double))) == PIORAN_ERR_ALLOC && ns > 1) --ns;
+    if (rc) return rc;
+    for (int64_t i = 0; i < ns; ++i)
+        if (!ctx->dstream[i]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->dstream[i], hipStreamNonBlocking));
+    for (auto& e : ctx->dev_)
+        if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // staging: A Bc [B][J] | C D ([J] or [B][J]) | t y s2 [N] | out [B] | info [B] (int32)
+    const size_t ncd = cd_shared ? (size_t)J : (size_t)B * J;
+    const size_t nd = 2 * (size_t)B * J + 2 * ncd + 3 * (size_t)N + 2 * (size_t)B;
+    if ((rc = ensure(ctx, ctx->bwork, nd * sizeof(double)))) return rc;
+    double* dA = (double*)ctx->bwork.p; double* dB = dA + (size_t)B * J; double* dC = dB + (size_t)B * J; double* dD = dC + ncd;
+    double* dt = dD + ncd; double* dy = dt + N; double* ds2 = dy + N; double* dout = ds2 + N; int32_t* dinfo = (int32_t*)(dout + B);
+    HIPCHK(ctx, hipMemcpyAsync(dA, A, (size_t)B * J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dB, Bc, (size_t)B * J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dC, C, ncd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dD, Dd, ncd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dt, t, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dy, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ds2, sigma2, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->dev_[8], ctx->stream));
+    const int sorted = is_sorted(t, N);
+    for (int64_t i = 0; i < ns; ++i) HIPCHK(ctx, hipStreamWaitEvent(ctx->dstream[i], ctx->dev_[8], 0));
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t i = b % ns;
+        rc = pioran_dense_nll_device(N, (int32_t)J, dA + b * J, dB + b * J, cd_shared ? dC : dC + b * J, cd_shared ? dD : dD + b * J, dt, dy,
+                                     ds2, (double*)ctx->bK.p + (size_t)i * slab, nullptr, dout + b, dinfo + b, sorted, ctx->dstream[i],
+                                     mu ? mu[b] : 0.0, nu ? nu[b] : 1.0);
+        if (rc) { ctx->last_err = "dense kernel launch failed"; return rc; }
+    }
+    for (int64_t i = 0; i < ns; ++i) {
+        HIPCHK(ctx, hipEventRecord(ctx->dev_[i], ctx->dstream[i]));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->dev_[i], 0));
+    }
+    if ((rc = download(ctx, out, dout, (size_t)B * sizeof(double)))) return rc;
+    if (info) if ((rc = download(ctx, info, dinfo, (size_t)B * sizeof(int32_t)))) return rc;
+    SYNC(ctx);
+    return PIORAN_OK;
 }
 
 int pioran_dense_nll_timed(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,

@@ -132,7 +132,7 @@ void pioran_dense_dims(int64_t N, int64_t* Mp, int64_t* ld);
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,
                             const double* d, const double* t, const double* y, const double* s2,
                             double* K /*ld*Mp + 1024*/, hipEvent_t* phase_ev /*nullptr or [3]*/, double* out, int32_t* info,
-                            int sorted, hipStream_t stream);
+                            int sorted, hipStream_t stream, double mu = 0.0 /*subtracted from y*/, double nu = 1.0 /*scales s2*/);
 int pioran_dense_predict_cov_device(int64_t N, int64_t M, int32_t J, const double* a, const double* b, const double* c,
                                     const double* d, const double* te, const double* s2e, double* K, int32_t* info,
                                     const double* y, double* mean, hipStream_t stream);

@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256) dense_build_kernel(int64_t N, int64_t Mp,
                                                           const double* __restrict__ a, const double* __restrict__ b,
                                                           const double* __restrict__ c, const double* __restrict__ d,
                                                           const double* __restrict__ t, const double* __restrict__ s2,
-                                                          const double* __restrict__ y, double* __restrict__ A, int diag_only)
+                                                          const double* __restrict__ y, double* __restrict__ A, int diag_only,
+                                                          double mu, double nu)
 {
     if (diag_only && (blockIdx.x >> 2) != (blockIdx.y >> 2)) return;  // keep only the diagonal 64 x 64 tiles
     // 16 x 16 tile of (i, k); i is the fast index (threadIdx.x) = memory-contiguous
@@ -61,13 +62,13 @@ __global__ void __launch_bounds__(256) dense_build_kernel(int64_t N, int64_t Mp,
             sincos(d[j] * tau, &sn, &cs);
             v += exp(-c[j] * tau) * (a[j] * cs + b[j] * sn);   // src/Celerite.jl:42-44, summed as acvf.jl:138-140
         }
-        if (i == k) v += s2[i];                                 // src/direct_solver.jl:15
+        if (i == k) v = fma(nu, s2[i], v);                      // src/direct_solver.jl:15 (nu = 1: the data set's variances)
     } else {
         if (i < k) return;
         v = (i == k) ? 1.0 : 0.0;                               // identity padding
     }
     A[i + k * ld] = v;
-    if (i == k) A[Mp + k * ld] = k < N ? y[k] : 0.0;            // the y row
+    if (i == k) A[Mp + k * ld] = k < N ? y[k] - mu : 0.0;       // the y row (mean subtracted: src/scalable_GP.jl:164)
 }
 
 // Covariance of an arbitrary list of times, a NaN time marking an identity (padding) row/column; no y row.
@@ -655,13 +656,13 @@ __global__ void __launch_bounds__(256) dense_predict_mean_kernel(const double* _
 // K must hold ld * Mp + 1024 doubles with Mp = roundup(N, 64), ld = Mp + 64 (slab + inverse workspace).
 static void launch_build(int64_t N, int64_t Mp, int64_t ld, int32_t J, const double* a, const double* b, const double* c,
                          const double* d, const double* t, const double* y, const double* s2, double* K, int sorted,
-                         hipStream_t stream)
+                         hipStream_t stream, double mu = 0.0, double nu = 1.0)
 {
     const unsigned tiles = (unsigned)(Mp / 16);
     const int64_t nt = Mp / BT;
     const bool fast = sorted && nt > 1;
     hipLaunchKernelGGL(dense_build_kernel, dim3(tiles, tiles), dim3(256), 0, stream, N, Mp, ld, J, a, b, c, d, t, s2, y, K,
-                       fast ? 1 : 0);
+                       fast ? 1 : 0, mu, nu);
     if (fast)
         hipLaunchKernelGGL(dense_build_fast_kernel, dim3((unsigned)(nt * (nt - 1) / 2)), dim3(256), 0, stream, N, ld, J, a,
                            b, c, d, t, K);
@@ -669,11 +670,11 @@ static void launch_build(int64_t N, int64_t Mp, int64_t ld, int32_t J, const dou
 
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c, const double* d,
                             const double* t, const double* y, const double* s2, double* K, hipEvent_t* phase_ev,
-                            double* out, int32_t* info, int sorted, hipStream_t stream)
+                            double* out, int32_t* info, int sorted, hipStream_t stream, double mu, double nu)
 {
     // phase_ev (nullptr or 3 events): recorded after the covariance build, after the factorisation loop, after the finish
     const int64_t Mp = (N + NB - 1) / NB * NB, ld = Mp + NB;
-    launch_build(N, Mp, ld, J, a, b, c, d, t, y, s2, K, sorted, stream);
+    launch_build(N, Mp, ld, J, a, b, c, d, t, y, s2, K, sorted, stream, mu, nu);
     if (phase_ev) (void)hipEventRecord(phase_ev[0], stream);
     if (hipMemsetAsync(info, 0, sizeof(int32_t), stream) != hipSuccess) return PIORAN_ERR_HIP;
     double* ws = K + (size_t)ld * (size_t)Mp;   // WS_DOUBLES doubles right behind the slab

@@ -114,6 +114,23 @@ class Context:
                                                _ptr(y), _ptr(sigma2), ctypes.byref(out), ctypes.byref(info)), self._h)
         return (out.value, info.value) if return_info else out.value
 
+    def dense_nll_batch(self, A, Bc, C, Dd, t, y, sigma2, mu=None, nu=None, return_info=False):
+        """B dense +NLL values on one data set (pioran_dense_nll_batch): A, Bc (B, J); C, Dd (J,) or (B, J); mu, nu (B,) or
+        None.  Independent factorisations run concurrently on the device."""
+        A, Bc, C, Dd, t, y, sigma2 = map(_f64, (A, Bc, C, Dd, t, y, sigma2))
+        if A.ndim != 2 or A.shape != Bc.shape:
+            raise ValueError("A, Bc must be (B, J)")
+        B, J = A.shape
+        cd_shared = C.ndim == 1
+        if C.shape != Dd.shape or C.shape != ((J,) if cd_shared else (B, J)):
+            raise ValueError("C, Dd must be (J,) or (B, J)")
+        mu = None if mu is None else _f64(np.broadcast_to(mu, (B,)))
+        nu = None if nu is None else _f64(np.broadcast_to(nu, (B,)))
+        out = np.empty(B); info = np.zeros(B, dtype=np.int32)
+        _lib.check(_lib.lib().pioran_dense_nll_batch(self._h, len(t), J, B, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), int(cd_shared),
+                                                     _ptr(t), _ptr(y), _ptr(sigma2), _ptr(mu), _ptr(nu), _ptr(out), _ptr(info)), self._h)
+        return (out, info) if return_info else out
+
     def dense_nll_timed(self, a, b, c, d, t, y, sigma2):
         """dense_nll plus the event-timed phases of the call: (nll, info, {"build_ms", "factor_ms", "finish_ms"})."""
         a, b, c, d, t, y, sigma2 = map(_f64, (a, b, c, d, t, y, sigma2))

@@ -411,6 +411,28 @@ def test_dense_reference_relation(ctx, golden_dir):
         assert abs(den - rel[f"simu_log[{basis}]"]["logl_dense"]) <= 1e-10 * abs(den)
 
 
+def test_dense_batch(ctx, golden_dir):
+    """pioran_dense_nll_batch: B factorisations on concurrent streams == B single calls == -celerite path; per-draw mu / nu;
+    shared and per-draw (c, d); one non-PD draw in the middle only flags itself."""
+    rng = np.random.default_rng(17)
+    A_ = np.loadtxt(golden_dir / "simu.txt")
+    t, y, yerr = A_[:300, 0], A_[:300, 1], A_[:300, 2]
+    B, J = 19, 6
+    _, _, _, A, Bc, C, Dd, mu, nu = _random_case(rng, 300, J, B)
+    one = np.array([ctx.dense_nll(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * yerr ** 2) for i in range(B)])
+    got, info = ctx.dense_nll_batch(A, Bc, C, Dd, t, y, yerr ** 2, mu=mu, nu=nu, return_info=True)
+    assert (info == 0).all() and relerr(got, one) < 1e-13
+    cel = pj.Dataset(t, y, yerr ** 2, ctx).logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    assert relerr(-got, cel) < 1e-9
+    C2 = np.tile(C, (B, 1)) * rng.uniform(0.8, 1.2, (B, J)); D2 = np.tile(Dd, (B, 1)) * rng.uniform(0.8, 1.2, (B, J))
+    got2 = ctx.dense_nll_batch(A, Bc, C2, D2, t, y, yerr ** 2, mu=mu, nu=nu)
+    ref2 = np.array([O.dense_nll(A[i], Bc[i], C2[i], D2[i], t, y - mu[i], nu[i] * yerr ** 2) for i in range(B)])
+    assert relerr(got2, ref2) < 1e-10
+    Abad = A.copy(); Abad[7] = -3.0
+    got3, info3 = ctx.dense_nll_batch(Abad, Bc, C, Dd, t, y, yerr ** 2, mu=mu, nu=nu, return_info=True)
+    assert info3[7] != 0 and np.isnan(got3[7]) and (np.delete(info3, 7) == 0).all() and relerr(np.delete(got3, 7), np.delete(one, 7)) < 1e-13
+
+
 def test_dense_not_positive_definite(ctx):
     t = np.linspace(0, 10, 40); y = np.ones(40); s2 = np.full(40, 1e-9)
     val, info = ctx.dense_nll([-1.0], [0.0], [0.3], [0.0], t, y, s2, return_info=True)
