@@ -157,10 +157,11 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
 /* ---- posterior mean and simulation (the callers either side of the likelihood) -----------
  * predict (src/celerite_solver.jl:348-361 -> pred :363-483; mean(::PosteriorGP, tau) of src/scalable_GP.jl:64-72,90-91):
  *     mean_out[b][m] = mu_b + sum_n z_n k_b(|tau_m - t_n|),   z = K_b^-1 (y - mu_b),  K_b = kernel_b + diag(nu_b sigma2)
- * for B draws of (a, b) with shared (c, d) [J].  tau: M evaluation times, any order (the reference wants them sorted).
+ * for B draws of (a, b); (c, d) [J] shared (cd_shared != 0) or [B][J] per draw (each draw then runs as its own one-draw
+ * batch).  tau: M evaluation times, any order (the reference wants them sorted).
  * status (may be NULL) as in pioran_celerite_logl_batch.  Host pointers, blocking. */
 int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
-                            const double* Dd, const double* mu, const double* nu, int64_t M, const double* tau,
+                            const double* Dd, int cd_shared, const double* mu, const double* nu, int64_t M, const double* tau,
                             double* mean_out, int32_t* status);
 /* log L and its gradient (what ForwardDiff obtains through the generic `logl`,
  * src/celerite_solver.jl:316, test/test_likelihood.jl:55-60) by reverse mode through the recurrence, for B draws:
@@ -187,10 +188,11 @@ int pioran_celerite_logl_grad_shift(pioran_ds* ds, int64_t B, int64_t J, const d
                                     double* grad_d, double* grad_nu, double* grad_mu, double* grad_shift);
 /* simulate (src/celerite_solver.jl:497-513 -> sim :515-549; rand(f(t, sigma2)) of src/scalable_GP.jl:137-146):
  * realisations y_b = L_b D_b^(1/2) q_b of the GP with kernel (a_b, b_b, c, d) + diag(sigma2) at the times t, from
- * caller-supplied standard-normal draws q [B][N] (the reference draws them with its rng, :528).  y_out [B][N]. */
+ * caller-supplied standard-normal draws q [B][N] (the reference draws them with its rng, :528).  y_out [B][N].
+ * C, Dd: [J] (cd_shared != 0) or [B][J]. */
 int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc,
-                             const double* C, const double* Dd, const double* t, const double* sigma2, const double* q,
-                             double* y_out);
+                             const double* C, const double* Dd, int cd_shared, const double* t, const double* sigma2,
+                             const double* q, double* y_out);
 /* Name of the kernel configuration a large batch with R active rows (all terms with both rows when R is even) runs on;
  * R <= 0: the configuration the calling thread's last throughput-layout launch actually ran on (diagnostics). */
 const char* pioran_celerite_config_name(int64_t R);

@@ -883,9 +883,9 @@ int pioran_celerite_logl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a,
 
 // ---- posterior mean / simulation --------------------------------------------------------------------
 // shared (c, d) only; draws are processed in chunks of at most 256 (one workgroup per draw, factor kept in HBM)
-int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
-                            const double* Dd, const double* mu, const double* nu, int64_t M, const double* tau,
-                            double* mean_out, int32_t* status)
+static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                          const double* Dd, const double* mu, const double* nu, int64_t M, const double* tau,
+                          double* mean_out, int32_t* status)
 {
     if (!ds || B < 1 || J < 1 || M < 1 || !A || !Bc || !C || !Dd || !tau || !mean_out) return PIORAN_ERR_ARG;
     pioran_ctx* ctx = ds->ctx;
@@ -920,6 +920,20 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
         if ((rc = download(ctx, mean_out + b0 * M, ctx->bY.p, (size_t)nb * M * sizeof(double)))) return rc;
         if (status) if ((rc = download(ctx, status + b0, ctx->bst.p, nb * sizeof(int32_t)))) return rc;
         SYNC(ctx);
+    }
+    return PIORAN_OK;
+}
+
+int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                            const double* Dd, int cd_shared, const double* mu, const double* nu, int64_t M, const double* tau,
+                            double* mean_out, int32_t* status)
+{
+    if (!ds || B < 1 || J < 1 || M < 1 || !A || !Bc || !C || !Dd || !tau || !mean_out) return PIORAN_ERR_ARG;
+    if (cd_shared || B == 1) return predict_shared(ds, B, J, A, Bc, C, Dd, mu, nu, M, tau, mean_out, status);
+    for (int64_t b = 0; b < B; ++b) {   // per-draw (c, d): every draw is its own one-draw batch with its own table
+        const int rc = predict_shared(ds, 1, J, A + b * J, Bc + b * J, C + b * J, Dd + b * J, mu ? mu + b : nullptr, nu ? nu + b : nullptr,
+                                      M, tau, mean_out + b * M, status ? status + b : nullptr);
+        if (rc) return rc;
     }
     return PIORAN_OK;
 }
@@ -1059,9 +1073,9 @@ int pioran_celerite_logl_grad_shift(pioran_ds* ds, int64_t B, int64_t J, const d
                           grad_mu, nullptr, nullptr, grad_shift);
 }
 
-int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc,
-                             const double* C, const double* Dd, const double* t, const double* sigma2, const double* q,
-                             double* y_out)
+static int simulate_shared(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc,
+                           const double* C, const double* Dd, const double* t, const double* sigma2, const double* q,
+                           double* y_out)
 {
     if (!ctx || N < 1 || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !t || !sigma2 || !q || !y_out) return PIORAN_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1100,6 +1114,19 @@ int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, c
         }
     }
     return done(PIORAN_OK);
+}
+
+int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc,
+                             const double* C, const double* Dd, int cd_shared, const double* t, const double* sigma2,
+                             const double* q, double* y_out)
+{
+    if (!ctx || N < 1 || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !t || !sigma2 || !q || !y_out) return PIORAN_ERR_ARG;
+    if (cd_shared || B == 1) return simulate_shared(ctx, N, B, J, A, Bc, C, Dd, t, sigma2, q, y_out);
+    for (int64_t b = 0; b < B; ++b) {
+        const int rc = simulate_shared(ctx, N, 1, J, A + b * J, Bc + b * J, C + b * J, Dd + b * J, t, sigma2, q + b * N, y_out + b * N);
+        if (rc) return rc;
+    }
+    return PIORAN_OK;
 }
 
 const char* pioran_celerite_config_name(int64_t R)

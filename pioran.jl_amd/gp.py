@@ -95,14 +95,14 @@ class Context:
         """GP realisations from standard-normal draws q (B, N): sim of src/celerite_solver.jl:515-549 for B coefficient
         sets (A, Bc: (B, J)) sharing (C, Dd: (J,)).  Returns (B, N)."""
         A, Bc, C, Dd, t, sigma2, q = map(_f64, (A, Bc, C, Dd, t, sigma2, q))
-        if A.ndim != 2 or A.shape != Bc.shape or C.shape != (A.shape[1],) or Dd.shape != C.shape:
-            raise ValueError("A, Bc must be (B, J) and C, Dd (J,)")
+        if A.ndim != 2 or A.shape != Bc.shape or C.shape not in ((A.shape[1],), A.shape) or Dd.shape != C.shape:
+            raise ValueError("A, Bc must be (B, J) and C, Dd (J,) or (B, J)")
         B, J = A.shape
         N = len(t)
         if sigma2.shape != (N,) or q.shape != (B, N):
             raise ValueError("sigma2 must be (N,) and q (B, N)")
         out = np.empty((B, N))
-        _lib.check(_lib.lib().pioran_celerite_simulate(self._h, N, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), _ptr(t),
+        _lib.check(_lib.lib().pioran_celerite_simulate(self._h, N, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), int(C.ndim == 1), _ptr(t),
                                                        _ptr(sigma2), _ptr(q), _ptr(out)), self._h)
         return out
 
@@ -254,14 +254,14 @@ class Dataset:
         """Posterior mean at the times tau (M,) for B coefficient sets sharing (C, Dd): pred of
         src/celerite_solver.jl:363-483 (+ the constant mean mu_b).  Returns (B, M)."""
         A, Bc, C, Dd, tau = map(_f64, (A, Bc, C, Dd, tau))
-        if A.ndim != 2 or A.shape != Bc.shape or C.shape != (A.shape[1],) or Dd.shape != C.shape or tau.ndim != 1:
-            raise ValueError("A, Bc must be (B, J), C, Dd (J,) and tau (M,)")
+        if A.ndim != 2 or A.shape != Bc.shape or C.shape not in ((A.shape[1],), A.shape) or Dd.shape != C.shape or tau.ndim != 1:
+            raise ValueError("A, Bc must be (B, J), C, Dd (J,) or (B, J) and tau (M,)")
         B, J = A.shape
         mu = None if mu is None else _f64(np.broadcast_to(mu, (B,)))
         nu = None if nu is None else _f64(np.broadcast_to(nu, (B,)))
         out = np.empty((B, len(tau)))
         st = np.zeros(B, dtype=np.int32)
-        _lib.check(_lib.lib().pioran_celerite_predict(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), _ptr(mu),
+        _lib.check(_lib.lib().pioran_celerite_predict(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), int(C.ndim == 1), _ptr(mu),
                                                       _ptr(nu), len(tau), _ptr(tau), _ptr(out), _ptr(st)), self.ctx._h)
         return (out, st) if return_status else out
 

@@ -275,7 +275,7 @@ end
 Posterior mean at the times `τ` for every draw (column) of `A`, `B` with shared `c`, `d`: what `mean(posterior(f(t, σ²), y), τ)`
 (src/scalable_GP.jl:64-72) computes one draw at a time.  Returns an `length(τ) × nbatch` matrix and the status vector.
 """
-function predict_batch(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::Vector{Float64}, d::Vector{Float64},
+function predict_batch(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::VecOrMat{Float64}, d::VecOrMat{Float64},
                        τ::Vector{Float64}; μ::Union{Nothing, Vector{Float64}} = nothing, ν::Union{Nothing, Vector{Float64}} = nothing)
     J, nb = size(A)
     out = Matrix{Float64}(undef, length(τ), nb)      # column-major = the ABI's [B][M]
@@ -283,9 +283,9 @@ function predict_batch(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::V
     p(x) = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
     GC.@preserve A B c d μ ν τ out status begin
         check(ccall((:pioran_celerite_predict, LIB), Cint,
-                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble},
                      Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}),
-                    ds.h, nb, J, A, B, c, d, p(μ), p(ν), length(τ), τ, out, status))
+                    ds.h, nb, J, A, B, c, d, c isa Vector ? 1 : 0, p(μ), p(ν), length(τ), τ, out, status))
     end
     return out, status
 end
@@ -308,16 +308,16 @@ end
 GP realisations `y = L D^(1/2) q` for every column of `A`, `B` from the standard normals `q` (`length(t) × nbatch`);
 `simulate(rng, cov, t, σ²)` (src/celerite_solver.jl:497-513) is `simulate_batch(..., randn(rng, N, 1))`.
 """
-function simulate_batch(A::Matrix{Float64}, B::Matrix{Float64}, c::Vector{Float64}, d::Vector{Float64}, t::Vector{Float64},
+function simulate_batch(A::Matrix{Float64}, B::Matrix{Float64}, c::VecOrMat{Float64}, d::VecOrMat{Float64}, t::Vector{Float64},
                         σ²::Vector{Float64}, q::Matrix{Float64}; ctx = default_context())
     J, nb = size(A)
     size(q) == (length(t), nb) || error("q must be length(t) × nbatch")
     out = Matrix{Float64}(undef, length(t), nb)
     GC.@preserve A B c d t σ² q out begin
         check(ccall((:pioran_celerite_simulate, LIB), Cint,
-                    (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                    (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble},
                      Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
-                    ctx.h, length(t), nb, J, A, B, c, d, t, σ², q, out))
+                    ctx.h, length(t), nb, J, A, B, c, d, c isa Vector ? 1 : 0, t, σ², q, out))
     end
     return out
 end

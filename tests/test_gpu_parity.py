@@ -816,6 +816,22 @@ def test_predict_random_batches(ctx, J, N, B):
     assert np.isfinite(ll).all()
 
 
+def test_predict_and_simulate_per_draw_cd(ctx):
+    """predict / simulate with (c, d) given per draw [B][J] (QPO / CARMA posterior samples): every draw against the oracle."""
+    rng = np.random.default_rng(91)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 180, 5, 4, per_draw_cd=True)
+    ds = pj.Dataset(t, y, s2, ctx)
+    tau = np.sort(rng.uniform(t[0] - 2, t[-1] + 2, 41))
+    pm = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu)
+    for i in range(4):
+        ref = O.predict(A[i], Bc[i], C[i], Dd[i], tau, t, y - mu[i], nu[i] * s2) + mu[i]
+        np.testing.assert_allclose(pm[i], ref, rtol=1e-9, atol=1e-10)
+    q = rng.standard_normal((4, 180))
+    ys = ctx.simulate(A, Bc, C, Dd, t, s2, q)
+    for i in range(4):
+        np.testing.assert_allclose(ys[i], O.sim(A[i], Bc[i], C[i], Dd[i], t, s2, q[i]), rtol=1e-9, atol=1e-10)
+
+
 def test_predict_full_size(ctx, full_size):
     """N = 1e4 (BASELINE config shape), M = 2000: against the oracle to 1e-8 and self-consistency at the data."""
     t, y, yerr = full_size
