@@ -16,9 +16,9 @@
 //   * one draw occupies G = 16*CBR lanes = CBR DPP rows of a 64-wide wavefront;
 //   * inside a DPP row, logical lane `lam` owns the RPL rows  lam*RPL .. lam*RPL+RPL-1  of the FULL
 //     (not triangular) R x R state S, for the column block of its DPP row: S lives in VGPRs;
-//   * the column loop broadcasts w_k, u_k, phi_k of the row-owning lane to the 16 lanes of the DPP
-//     row with v_mov_b64_dpp row_newbcast (no LDS, no readlane), so q = S u needs no cross-lane
-//     reduction inside a DPP row; only u'q and u'f are 16-lane DPP butterflies;
+//   * the column loop takes w_k, u_k of the row-owning lane through the DPP operand of the FMAs themselves
+//     (v_fmac_f64_dpp row_newbcast; phi_k through one v_mov_b64_dpp): no LDS, no readlane, and q = S u needs no
+//     cross-lane reduction inside a DPP row; u'q is summed by broadcast-accumulating the contributing lanes;
 //   * with CBR > 1 every DPP row r holds the rows rotated by NSRC*r lanes, so the SAME instruction
 //     stream (broadcast source lane N, register slot m) walks a DIFFERENT column block in each DPP
 //     row; the partial q of the CBR column blocks are summed with ds_bpermute.
@@ -41,14 +41,6 @@ __device__ __forceinline__ void static_for(F&& f)
         f(ic<B>{});
         static_for<B + 1, E>(f);
     }
-}
-
-// lane N of each 16-lane DPP row -> all lanes of that row (one v_mov_b64_dpp)
-template <int N>
-__device__ __forceinline__ double row_bcast(double x)
-{
-    // `old` undefined: every lane is written (row_newbcast has no invalid lanes), so no init mov
-    return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true);
 }
 
 template <int CTRL>
@@ -370,11 +362,10 @@ __device__ __forceinline__ double lane_fetch(double x, int addr4)
 }
 
 // p1, p2: any lane of the DPP row across (r ^ 1, r ^ 2) — after the row sum all 16 lanes of a row hold its total
-// (the inline-asm row sum only in the DPP-folded kernels: volatile asm pins the compiler-scheduled variants' loads)
-template <int CBR, int NSRC, bool ASM_DPP>
+template <int CBR, int NSRC>
 __device__ __forceinline__ double group_sum(double x, bool contributes, double one, int p1, int p2)
 {
-    if constexpr (ASM_DPP && NSRC <= 10) {
+    if constexpr (NSRC <= 10) {
         x = row_sum_sources<NSRC>(x, one);
     } else {
         if (!contributes) x = 0.0;
@@ -412,12 +403,11 @@ struct StepIn {           // what one time step reads: per own row (v, x, phi) +
 // ones, src/psd.jl:264-275): every DPP row's block of RB slots holds NPB column PAIRS (rows of NPB complex terms), then
 // RB - 1 - 2 NPB single rows (real terms), then one spare slot (padding; the y row in the last block).  All blocks
 // look alike, so the phi_i phi_k product of a pair is formed once per pair in every DPP row of the wavefront.
-template <int RPL, int CBR, int NSRC, bool SHARED_TAB, bool ASM_DPP = false, int MINW = 1, bool PAIRED = false, bool MIXED = false,
-          int NPB = 0>
+template <int RPL, int CBR, int NSRC, bool SHARED_TAB, int MINW = 1, bool PAIRED = false, bool MIXED = false, int NPB = 0>
 __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanParams p)
 {
-    static_assert(NPB == 0 || (!PAIRED && 2 * NPB < NSRC * RPL && (!ASM_DPP || RPL % 2 == 0)),
-                  "block layout: unpaired base; the DPP-folded form needs both columns of a pair in one source lane");
+    static_assert(NPB == 0 || (!PAIRED && 2 * NPB < NSRC * RPL && RPL % 2 == 0),
+                  "block layout: unpaired base; both columns of a pair must sit in one source lane");
     static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
     constexpr int G = 16 * CBR;          // lanes per draw
     constexpr int EPW = 64 / G;          // draws per wavefront
@@ -639,8 +629,8 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         in.v[YS] = fma(ysel, in.y - mu, in.v[YS]);
 
         // ---- S update + q = S u over this DPP row's column block ----
-        if constexpr (NPB > 0 && ASM_DPP) {
-            // block layout, DPP-folded: the first 2 NPB columns of the block are the (cos, sin) pairs of NPB two-row terms
+        if constexpr (NPB > 0) {
+            // block layout: the first 2 NPB columns of the block are the (cos, sin) pairs of NPB two-row terms
             // (phi_i phi_k formed once per pair), the rest single rows of one-row terms and the spare slot
             static_for<0, NPB>([&](auto Pc) {
                 constexpr int c = 2 * decltype(Pc)::value;
@@ -652,7 +642,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 constexpr int c = decltype(Cc)::value;
                 ColBlock<RPL, c / RPL>::run(S[c], qt, g, in.ph, w[c % RPL], u[c % RPL], in.ph[c % RPL]);
             });
-        } else if constexpr (PAIRED && ASM_DPP) {
+        } else if constexpr (PAIRED) {
             // column pairs (c, c+1), c even: same phi_k, so phi_i * phi_k is formed once per pair
             static_for<0, NC / 2>([&](auto Pc) {
                 constexpr int c = 2 * decltype(Pc)::value;
@@ -664,35 +654,10 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 ColBlock<RPL, (NC - 1) / RPL>::run(S[NC - 1], qt, g, in.ph, w[(NC - 1) % RPL], u[(NC - 1) % RPL],
                                                    in.ph[(NC - 1) % RPL]);
         } else {
-        [[maybe_unused]] double ppair[RPL];   // compiler-scheduled PAIRED: phi_i phi_k of the even column, reused by the odd one
-        static_for<0, NSRC>([&](auto Nc) {
-            constexpr int NN = decltype(Nc)::value;
-            static_for<0, RPL>([&](auto Mc) {
-                constexpr int MM = decltype(Mc)::value;
-                constexpr int c = NN * RPL + MM;
-                if constexpr (ASM_DPP) {
-                    ColBlock<RPL, NN>::run(S[c], qt, g, in.ph, w[MM], u[MM], in.ph[MM]);
-                    return;
-                }
-                const double wk = row_bcast<NN>(w[MM]);
-                const double uk = row_bcast<NN>(u[MM]);
-                // columns c, c + 1 with c even are one term's rows (an odd block ends with a single slot at an even index,
-                // which is not reused); block layout: only the first 2 NPB columns of a block are pairs
-                constexpr bool reuse = (c & 1) && (PAIRED || (NPB > 0 && c < 2 * NPB));
-                if constexpr (!reuse) {
-                    const double pk = row_bcast<NN>(in.ph[MM]);
-#pragma unroll
-                    for (int i = 0; i < RPL; ++i) ppair[i] = in.ph[i] * pk;   // phi_j phi_k   :78,85
-                }
-#pragma unroll
-                for (int i = 0; i < RPL; ++i) {
-                    const double m = fma(g[i], wk, S[c][i]);   // S + dn * V[k,n-1]          :78
-                    const double sn = ppair[i] * m;            // phi_j phi_k ( ... )        :78,85
-                    S[c][i] = sn;
-                    qt[i] = fma(sn, uk, qt[i]);                // (S u)_j                    :80-82,86-89
-                }
+            static_for<0, NC>([&](auto Cc) {
+                constexpr int c = decltype(Cc)::value;
+                ColBlock<RPL, c / RPL>::run(S[c], qt, g, in.ph, w[c % RPL], u[c % RPL], in.ph[c % RPL]);
             });
-        });
         }
         if constexpr (CBR >= 2) {
 #pragma unroll
@@ -705,7 +670,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         double sp = 0.0;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) sp += u[i] * qt[i];        // u'Su                       :83,88
-        const double s = group_sum<CBR, NSRC, ASM_DPP>(sp, contributes, one, p1, p2);
+        const double s = group_sum<CBR, NSRC>(sp, contributes, one, p1, p2);
 
         Dn = fma(nu, in.s2, suma) - s;                           // :92  (nu = 1 without a per-draw scale: exact)
         rD = recip_f64(Dn);
@@ -743,22 +708,22 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 
 using LaunchFn = void (*)(const ScanParams&, dim3, hipStream_t);
 
-template <int RPL, int CBR, int NSRC, bool ASM_DPP = false, int MINW = 1, bool PAIRED = false>
+template <int RPL, int CBR, int NSRC, int MINW = 1, bool PAIRED = false>
 void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 {
     if (p.tab && p.npd_rows > 0)
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, ASM_DPP, MINW, PAIRED, true>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, true>), grid, dim3(256), 0, st, p);
     else if (p.tab)
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, ASM_DPP, MINW, PAIRED>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED>), grid, dim3(256), 0, st, p);
     else
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false, ASM_DPP, MINW, PAIRED>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false, MINW, PAIRED>), grid, dim3(256), 0, st, p);
 }
 
 // block layout (NPB pairs per block): shared-table launches without per-draw rows only
-template <int RPL, int CBR, int NSRC, int MINW, int NPB, bool ASM_DPP = false>
+template <int RPL, int CBR, int NSRC, int MINW, int NPB>
 void launch_blocked(const ScanParams& p, dim3 grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, ASM_DPP, MINW, false, false, NPB>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB>), grid, dim3(256), 0, st, p);
 }
 
 struct ScanConfig {
@@ -776,8 +741,8 @@ struct ScanConfig {
     }
 };
 
-#define CFG(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC, RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC, true>}
-#define CFG_P(RPL, CBR, NSRC, MINW) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC "_p", RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC, true, MINW, true>, true}
+#define CFG(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC, RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC>}
+#define CFG_P(RPL, CBR, NSRC, MINW) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC "_p", RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC, MINW, true>, true}
 // preference order: first entry whose capacity >= R wins (unless the context option "scan_config" names another).
 // Every entry uses the DPP-folded column blocks (ColBlock / PairFirst / PairSecond); the compiler-scheduled builtin
 // variants of round 1 were dropped when the DPP-folded ones became the faster choice in every row range
@@ -786,7 +751,7 @@ const ScanConfig kConfigs[] = {
     CFG(1, 1, 5),  CFG(1, 1, 9),  CFG(1, 1, 13), CFG(1, 1, 16),           // R <= 15
     CFG(2, 1, 9),  CFG(2, 1, 11), CFG(2, 1, 13), CFG(2, 1, 15), CFG(2, 1, 16),  // R <= 31
     CFG(3, 2, 6),  CFG(3, 2, 7),  CFG(3, 2, 8),                           // R <= 47
-    {"rpl4_cbr4_nsrc4", 4, 4, 4, &launch_cfg<4, 4, 4, true, 2>},          // R <= 63: 256 registers/lane, 2 waves per SIMD
+    {"rpl4_cbr4_nsrc4", 4, 4, 4, &launch_cfg<4, 4, 4, 2>},                // R <= 63: 256 registers/lane, 2 waves per SIMD
     CFG(5, 4, 4),                                                         // R <= 79
     // column-paired variants (standard row map only; picked automatically by pick_config when applicable)
     CFG_P(3, 2, 7, 1), CFG_P(3, 2, 8, 1), CFG_P(3, 2, 6, 1),
@@ -794,11 +759,9 @@ const ScanConfig kConfigs[] = {
     CFG_P(2, 1, 9, 1), CFG_P(2, 1, 11, 1), CFG_P(2, 1, 13, 1), CFG_P(2, 1, 15, 1), CFG_P(2, 1, 16, 1),
     CFG_P(4, 4, 4, 2), CFG_P(5, 4, 4, 1),
     // DRWCelerite with 20 components: 20 complex + 20 real terms = 5 pairs + 5 singles + 1 spare in each of the 4 blocks
-    {"rpl4_cbr4_nsrc4_b5a", 4, 4, 4, &launch_blocked<4, 4, 4, 2, 5, true>, false, true, 5},
+    {"rpl4_cbr4_nsrc4_b5a", 4, 4, 4, &launch_blocked<4, 4, 4, 2, 5>, false, true, 5},
     // alternatives kept for tuning runs (selected by name)
     CFG(3, 4, 4), CFG(2, 2, 8),
-    {"rpl4_cbr4_nsrc4_w1", 4, 4, 4, &launch_cfg<4, 4, 4, true, 1>},
-    {"rpl4_cbr4_nsrc4_p_w1", 4, 4, 4, &launch_cfg<4, 4, 4, true, 1, true>, true, false},
 };
 #undef CFG
 #undef CFG_P

@@ -277,7 +277,7 @@ def test_all_kernel_configs_agree(ctx):
     ds = pj.Dataset(t, y, s2, ctx)
     try:
         for name in ("rpl3_cbr2_nsrc7_p", "rpl3_cbr2_nsrc8_p", "rpl3_cbr2_nsrc7", "rpl3_cbr2_nsrc8", "rpl3_cbr4_nsrc4", "rpl4_cbr4_nsrc4",
-                     "rpl4_cbr4_nsrc4_w1", "rpl5_cbr4_nsrc4", "rpl4_cbr4_nsrc4_p", "rpl4_cbr4_nsrc4_p_w1", "rpl5_cbr4_nsrc4_p", "wide"):
+                     "rpl5_cbr4_nsrc4", "rpl4_cbr4_nsrc4_p", "rpl5_cbr4_nsrc4_p", "wide"):
             ctx.set_option("scan_config", name)
             got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
             if name != "wide":   # ("wide" = the latency layout of celerite_wide.hip, not an entry of the scan table)

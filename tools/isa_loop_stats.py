@@ -4,8 +4,8 @@ usage: hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o scan.
 import re, sys
 from collections import Counter
 s = open(sys.argv[1]).read()
-flt = sys.argv[2] if len(sys.argv) > 2 else "Lb1ELb1E"   # substring of the mangled name, e.g. Li3ELi2ELi7ELb1ELb1ELi1ELb1E
-for m in re.finditer(r'^(_ZN12_GLOBAL__N_120celerite_scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)E\w*EEv10ScanParams):', s, re.M):
+flt = sys.argv[2] if len(sys.argv) > 2 else "Lb1E"   # substring of the mangled name, e.g. Li3ELi2ELi7ELb1ELi1ELb1E (headline kernel)
+for m in re.finditer(r'^(_ZN12_GLOBAL__N_120celerite_scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d)E\w*EEv10ScanParams):', s, re.M):
     name = m.group(1)
     if flt not in name: continue
     i = m.start(); j = s.index('.Lfunc_end', i)
@@ -29,5 +29,5 @@ for m in re.finditer(r'^(_ZN12_GLOBAL__N_120celerite_scan_kernelILi(\d+)ELi(\d+)
     k = s.find('.name:           ' + name)
     meta = s[k - 1500:k + 800] if k > 0 else ''
     vg = re.search(r'\.vgpr_count:\s+(\d+)', meta); ag = re.search(r'\.agpr_count:\s+(\d+)', meta)
-    print(f"rpl{m.group(2)} cbr{m.group(3)} nsrc{m.group(4)} tab{m.group(5)} asm{m.group(6)}: loop={sum(c.values())} vgpr={vg.group(1) if vg else '?'} agpr={ag.group(1) if ag else '?'} | " +
+    print(f"rpl{m.group(2)} cbr{m.group(3)} nsrc{m.group(4)} tab{m.group(5)} minw{m.group(6)}: loop={sum(c.values())} vgpr={vg.group(1) if vg else '?'} agpr={ag.group(1) if ag else '?'} | " +
           " ".join(f"{k}:{v}" for k, v in c.most_common(12)))

@@ -12,7 +12,7 @@
 #define DPPC " row_newbcast:3 row_mask:0xf bank_mask:0xf"
 
 template <int KIND>
-__global__ void __launch_bounds__(512) probe(double* out, int iters, unsigned long long* cyc, unsigned long long* real)
+__global__ void __launch_bounds__(1024) probe(double* out, int iters, unsigned long long* cyc, unsigned long long* real)
 {
     double a0 = threadIdx.x * 1e-9 + 1.0, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     double b = 1.0000001, c = 1e-9, d = 0.9999999;
@@ -124,11 +124,11 @@ void run(const char* name, int per_iter)
 {
     const int iters = 20000;
     double* out; unsigned long long *cyc, *real;
-    hipMalloc(&out, 8 * 512 * 1024); hipMalloc(&cyc, 8 * 8192); hipMalloc(&real, 8 * 8192);
+    hipMalloc(&out, 8 * 1024 * 1024); hipMalloc(&cyc, 8 * 8192); hipMalloc(&real, 8 * 8192);
     std::vector<unsigned long long> hc(8192), hr(8192);
     printf("%-44s", name);
-    // (threads per block, blocks): 1 wave; 4 waves = 1 per SIMD; 8 waves = 2 per SIMD (one CU); whole chip 2/SIMD
-    const int cfgs[4][2] = {{64, 1}, {256, 1}, {512, 1}, {512, 256}};
+    // (threads per block, blocks): 1 wave; 4 waves = 1 per SIMD; 8 = 2 per SIMD; 16 = 4 per SIMD (one CU); whole chip at 2 and 4 per SIMD
+    const int cfgs[6][2] = {{64, 1}, {256, 1}, {512, 1}, {1024, 1}, {512, 256}, {1024, 256}};
     for (auto& c : cfgs) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipLaunchKernelGGL(probe<KIND>, dim3(c[1]), dim3(c[0]), 0, 0, out, 200, cyc, real);
@@ -143,7 +143,11 @@ void run(const char* name, int per_iter)
         sc /= nw; sr /= nw;
         const double ninst = (double)iters * per_iter;
         // s_memrealtime ticks at 100 MHz
-        printf(" | %5.2f cyc/inst  %4.2f GHz  %6.2f ms", sc / ninst, sc / sr * 0.1, ms);
+        // cycles per instruction per SIMD from the WALL time of the launch at the measured clock (waves of a block may be
+        // spread unevenly over the SIMDs, so the per-wave s_memtime average is not the SIMD's issue interval)
+        const double ghz = sc / sr * 0.1;
+        const double per_simd = ms * 1e-3 * ghz * 1e9 / (ninst * (c[0] / 256.0));
+        printf(" | %5.2f cyc/inst/SIMD %4.2f GHz %6.2f ms", c[0] >= 256 ? per_simd : sc / ninst, ghz, ms);
     }
     printf("\n");
     hipFree(out); hipFree(cyc); hipFree(real);
@@ -151,7 +155,7 @@ void run(const char* name, int per_iter)
 
 int main()
 {
-    printf("%-44s | 1 wave                       | 4 waves (1/SIMD)             | 8 waves (2/SIMD), one CU      | 2048 waves (2/SIMD), whole chip\n", "kind");
+    printf("%-44s | 1 wave | 4 waves (1/SIMD) | 8 waves (2/SIMD) | 16 waves (4/SIMD), one CU | whole chip 2/SIMD | whole chip 4/SIMD\n", "kind");
     run<0>("v_fma_f64", 64);
     run<9>("v_fma_f64 (three distinct registers)", 64);
     run<13>("v_fma_f64 (SGPR multiplier)", 64);
