@@ -62,6 +62,10 @@ struct PrepState {
     int32_t* dpd_terms = nullptr;
     // row layout class for the scan's configuration choice (ScanParams::standard_rows / n_complex)
     int32_t row_layout = 0, n_complex = 0;
+    // table of the windowed kernel (celerite_block.hip), built on first use for the prepared (c, d)
+    double* btab = nullptr;
+    size_t btab_cap = 0;
+    bool btab_ready = false;
 };
 
 struct pioran_ds {
@@ -218,10 +222,45 @@ int scan_dispatch(const ScanParams& p, hipStream_t stream)
     return pioran_launch_scan(p, stream);
 }
 
+// Small shared-table batches without per-draw rows: the windowed kernel (celerite_block.hip), which needs its own table.
+// Returns PIORAN_ERR_UNSUPPORTED when the launch is not one of those (the caller goes on to the other kernels).
+int block_dispatch(pioran_ds* ds, const ScanParams& p)
+{
+    pioran_ctx* ctx = ds->ctx;
+    const ScanOptions& o = ctx->opt;
+    const char* cfg = o.scan_config[0] ? o.scan_config : nullptr;
+    const bool force = cfg && !std::strcmp(cfg, "block");
+    const bool automatic = !cfg && !o.no_block && p.B <= pioran_wide_max_batch() && p.R >= 16;
+    if (!(force || automatic) || !p.tab || p.npd_rows != 0 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
+    if (!s || !s->prepared || s->npd_terms != 0 || p.rec_stride != 3 * (int64_t)(s->R + 2) + 2) return PIORAN_ERR_UNSUPPORTED;
+    if (!s->btab_ready) {
+        const size_t need = pioran_block_table_doubles(ds->N, s->R, s->J);
+        if (need > s->btab_cap) {
+            if (s->btab) HIPCHK(ctx, hipFree(s->btab));
+            s->btab = nullptr;
+            s->btab_cap = 0;
+            if (hipMalloc((void**)&s->btab, need * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
+            s->btab_cap = need;
+        }
+        int rc = pioran_launch_block_table(ds->N, s->R, s->J, s->rowmap, ds->t, s->dc, s->dd, ds->y, ds->s2, s->btab, ctx->stream);
+        if (rc) return rc;
+        s->btab_ready = true;
+    }
+    return pioran_launch_scan_block(p, s->btab, ctx->stream);
+}
+
 int launch(pioran_ds* ds, ScanParams& p)
 {
     pioran_ctx* ctx = ds->ctx;
     p.opt = &ctx->opt;
+    if (!ctx->opt.force_fallback) {
+        int rc = block_dispatch(ds, p);
+        if (rc != PIORAN_ERR_UNSUPPORTED) {
+            if (rc == PIORAN_ERR_HIP) ctx->last_err = "block kernel launch failed";
+            return rc;
+        }
+    }
     if (p.R <= pioran_wide_supported_rows() && !ctx->opt.force_fallback) {
         int rc = scan_dispatch(p, ctx->stream);
         if (rc != PIORAN_ERR_UNSUPPORTED) {
@@ -271,6 +310,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "no_paired")) o.no_paired = on;
     else if (!std::strcmp(key, "no_mixed")) o.no_mixed = on;
     else if (!std::strcmp(key, "force_fallback")) o.force_fallback = on;
+    else if (!std::strcmp(key, "no_block")) o.no_block = on;
     else return PIORAN_ERR_ARG;
     return PIORAN_OK;
 }
@@ -290,6 +330,7 @@ static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
     pioran_ctx_set_option(ctx, "no_paired", std::getenv("PIORAN_NO_PAIRED"));
     pioran_ctx_set_option(ctx, "no_mixed", std::getenv("PIORAN_NO_MIXED"));
     pioran_ctx_set_option(ctx, "force_fallback", std::getenv("PIORAN_FORCE_FALLBACK"));
+    pioran_ctx_set_option(ctx, "no_block", std::getenv("PIORAN_NO_BLOCK"));
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
     if (own) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
@@ -414,6 +455,7 @@ int pioran_dataset_destroy(pioran_ds* ds)
     if (ds->t) (void)hipFree(ds->t);
     for (PrepState* s : {&ds->user, &ds->host}) {
         if (s->tab) (void)hipFree(s->tab);
+        if (s->btab) (void)hipFree(s->btab);
         if (s->rowmap) (void)hipFree(s->rowmap);
         if (s->dc) (void)hipFree(s->dc);
         if (s->dpd_terms) (void)hipFree(s->dpd_terms);
@@ -442,6 +484,7 @@ static int prepare_state(pioran_ds* ds, PrepState& s, int64_t J, const double* c
                       !std::memcmp(s.d_host.data(), d, J * sizeof(double)) && s.real_host == real;
     if (same) return PIORAN_OK;
     s.prepared = false;
+    s.btab_ready = false;
     if ((size_t)J > s.dcd_cap) {
         if (s.dc) HIPCHK(ctx, hipFree(s.dc));
         s.dc = nullptr;

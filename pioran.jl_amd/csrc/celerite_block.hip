@@ -1,0 +1,573 @@
+// Windowed ("block") form of the celerite factorisation for SMALL batches (gfx950): one draw per workgroup of four
+// wavefronts, sixteen time steps per window, the O(R^2) work of a window on the matrix cores.
+//
+// Same mathematics as init_semi_separable! + the forward half of solve_prec! (src/celerite_solver.jl:12-100,115-142; logl
+// :312-334), re-associated.  The reference (and celerite_scan.hip / celerite_wide.hip) walk the time steps one by one:
+//   S_n = (phi phi') o (S_{n-1} + D_{n-1} w w') ;  q = S_n u_n ;  D_n = sum(a) + sigma2_n - u_n'q ;  w_n = (v_n - q) / D_n
+// (:69-98): a chain of N dependent steps, each with a reduction and a reciprocal — 1400 cycles per step in the latency layout.
+// Here the state is T_m = S_m + D_m w_m w_m' (time-m coordinates) and K = 16 steps m+1 .. m+K are eliminated together:
+//   C_n   = prod_{i=m+1..n} phi_i                       (cumulative decay from the window base; table)
+//   u~_n  = C_n o u_n ,  U~ = [u~_n]                    R x K
+//   M     = T U~                                        R x K     (MFMA)      the past, seen from every step of the window
+//   G     = U~' M                                       K x K     (MFMA)
+//   Sigma = A - G ,  A_jn = k(t_n - t_j), A_nn = sum(a) + sigma2_n            the window's own covariance block (kappa,
+//                                                                             src/acvf.jl:138-140) minus what the past explains
+//   Sigma = L D L'                                      16 x 16 dense LDL' — D holds exactly the reference's D_n (:92)
+//   X     = V^ - C_K o M ,  V^_n = (C_K / C_n) o v_n    R x K     (v scaled forward to the window end)
+//   Y^    = X L^-T                                      R x K     (MFMA)      = [ w_n D_n ] in window-end coordinates
+//   T    <- (C_K C_K') o T + Y^ D^-1 Y^'                R x R     (MFMA)
+// and, with y carried as one more row (u = 0, v = y_n - mu, phi = 1; as in the other kernels), z_n = Y^_{y,n}, so that
+//   log L = -1/2 sum log|D_n| - 1/2 sum Y^_{y,n}^2 / D_n - N/2 log(2 pi).
+// Every scaling factor is a product of phi's (<= 1): nothing is ever divided by a decay, so terms whose phi underflows inside a
+// window (c_j dt >> 700) are exact zeros, not NaNs.  The only place where a pairwise decay C_n / C_j (j < n) is needed is the
+// window's own block A, and that is the plain kernel function: a shared table holds e^{-c tau}(cos, sin)(d tau) per (pair, term),
+// each draw contracts it with its (a_j, b_j).
+//
+// Work split (R + 1 <= 16 NB rows, NB <= 5): wavefront w owns the block columns J = w, w + 4 of T (C/D register layout of
+// v_mfma_f64_16x16x4_f64: register g of block (I, J) = element (16 I + 4 g + (lane >> 4), 16 J + (lane & 15))).  Those registers
+// are the B operand of M' = U~' T and the accumulator of the update without any data movement; M' comes out in the layout in
+// which X, Y^ and the update's operands are needed.  Wavefront 3 also runs the chain: Gram, Sigma, the 16 x 16 LDL' with every
+// column replicated in the four DPP rows (pivot broadcasts and rank-1 updates are v_mov_b64_dpp / v_fmac_f64_dpp row_newbcast: no
+// LDS inside the factorisation), and L^-1 by carrying the identity through the same row operations.  Three workgroup barriers
+// per window; while the chain runs, the other wavefronts rescale T, form A and U~ of the NEXT window and prefetch its table
+// fragments.  The table is stored in fragment order (one 8-byte element per lane and register), so every load is coalesced and
+// nothing is staged through LDS except the exchanges between wavefronts.
+#include "common.h"
+
+#include <cmath>
+#include <type_traits>
+
+// Diagnostic hooks: compiled out in the product; tools/block_probe.hip defines them to s_memtime accumulators.
+#ifndef PIORAN_BSTAMP
+#define PIORAN_BSTAMP(i)
+#define PIORAN_BSTAMP_DECL
+#define PIORAN_BSTAMP_FLUSH
+#endif
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int I>
+using ic = std::integral_constant<int, I>;
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (B < E) {
+        f(ic<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+__device__ __forceinline__ double recip_f64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+constexpr int KW = 16;   // time steps per window
+
+// ---- table -----------------------------------------------------------------------------------------------------------
+// One record per window k (steps 16 k + s), in doubles:
+//   CVf [NB][4][64]   C_n o v_n,  A-operand fragment order: element (row 16 I + 4 ks + (lane >> 4), step lane & 15)
+//   CXf [NB][4][64]   C_n o x_n,  same order                       (u = al v + be x, cos row (v, x) = (cos, sin), sin row swapped)
+//   VHf [NB][4][64]   (C_K / C_n) o v_n, C/D fragment order: element (step 4 g + (lane >> 4), row 16 J + (lane & 15));
+//                     the y row (row R) holds y_n
+//   CK  [16 NB]       C_K (decay over the whole window; 1 for the y row, 0 for the padding rows)
+//   S2w [16]          sigma2_n (1 for the padded steps of the last window)
+//   E   [J][128][2]   e^{-c_t tau} (cos, sin)(d_t tau) for the pair p = n (n - 1) / 2 + j of steps j < n of the window, tau = t_n - t_j
+//   (the first five padded together to a multiple of 128 doubles: the record is copied to LDS in 1 KB pieces)
+__host__ __device__ inline int64_t block_rec_doubles(int NB, int J) { return ((3 * (int64_t)NB * 256 + 16 * NB + 16 + 127) & ~(int64_t)127) + (int64_t)J * 256; }
+
+__global__ void __launch_bounds__(256) block_table_kernel(int64_t N, int32_t R, int32_t J, int32_t NB, const int32_t* __restrict__ rowmap,
+                                                          const double* __restrict__ t, const double* __restrict__ c,
+                                                          const double* __restrict__ d, const double* __restrict__ y,
+                                                          const double* __restrict__ s2, double* __restrict__ tab)
+{
+    const int64_t RSB = block_rec_doubles(NB, J);
+    const int64_t NW = (N + KW - 1) / KW;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NW * RSB) return;
+    const int64_t k = idx / RSB;
+    int64_t e = idx - k * RSB;
+    const int64_t n0 = k * KW;
+    const int64_t nlast = n0 + KW - 1 < N ? n0 + KW - 1 : N - 1;
+    const double tb = k > 0 ? t[n0 - 1] : t[0];    // window base (irrelevant for k = 0: T = 0)
+    const double te = t[nlast];                    // window end
+    double val = 0.0;
+    const int64_t nfrag = (int64_t)NB * 256;
+    if (e < 3 * nfrag) {
+        const int sec = (int)(e / nfrag);
+        const int f = (int)(e - sec * nfrag);
+        const int blk = f >> 8, reg = (f >> 6) & 3, lane = f & 63;
+        int row, s;
+        if (sec < 2) { row = 16 * blk + 4 * reg + (lane >> 4); s = lane & 15; }
+        else { s = 4 * reg + (lane >> 4); row = 16 * blk + (lane & 15); }
+        const int64_t n = n0 + s;
+        if (n < N) {
+            if (row < R) {
+                const int32_t rm = rowmap[row];
+                const int32_t term = rm & 0xfffff;
+                const bool ks = (rm >> 30) & 1;
+                const double tn = t[n];
+                double si, co;
+                sincos(d[term] * tn, &si, &co);                                  // :52-53
+                if (sec == 2) val = (ks ? si : co) * exp(-c[term] * (te - tn));
+                else val = ((sec == 0) == ks ? si : co) * exp(-c[term] * (tn - tb));   // sec 0: v, sec 1: x
+            } else if (row == R && sec == 2) {
+                val = y[n];
+            }
+        }
+    } else if ((e -= 3 * nfrag) < 16 * NB) {
+        const int row = (int)e;
+        if (row < R) val = exp(-c[rowmap[row] & 0xfffff] * (te - tb));
+        else if (row == R) val = 1.0;
+    } else if ((e -= 16 * NB) < 16) {
+        const int64_t n = n0 + e;
+        val = n < N ? s2[n] : 1.0;
+    } else if ((e -= 16) < RSB - (int64_t)J * 256 - 3 * nfrag - 16 * NB - 16) {
+        val = 0.0;   // padding of the tile part
+    } else {
+        e -= RSB - (int64_t)J * 256 - 3 * nfrag - 16 * NB - 16;
+        const int term = (int)(e >> 8), p = (int)((e >> 1) & 127), h = (int)(e & 1);
+        if (p < 120) {
+            int nn = 1;
+            while ((nn + 1) * nn / 2 <= p) ++nn;       // p = nn (nn - 1) / 2 + jj, jj < nn
+            const int jj = p - nn * (nn - 1) / 2;
+            if (n0 + nn < N) {
+                const double tau = t[n0 + nn] - t[n0 + jj];
+                double si, co;
+                sincos(d[term] * tau, &si, &co);
+                val = exp(-c[term] * tau) * (h ? si : co);
+            }
+        }
+    }
+    tab[idx] = val;
+}
+
+// ---- the 16 x 16 LDL' of the chain wavefront -------------------------------------------------------------------------
+// Lane (q, n): col[j] = Sigma_{j n}, aug[j] = (row operations applied to the identity)_{j n}; the four DPP rows q hold copies.
+#define PIORAN_BLK_DPP " row_newbcast:%c[p] row_mask:0xf bank_mask:0xf"
+// rows j = J0 .. J0 + CNT - 1 of step P: aug[j] += bcast_P(col[j]) * nta ; col[j] += bcast_P(col[j]) * ntn
+template <int P, int J0, int CNT>
+__device__ __forceinline__ void ldl_rows(double (&col)[16], double (&aug)[16], double ntn, double nta)
+{
+    if constexpr (CNT >= 1) {
+        constexpr int A = J0, B = CNT >= 2 ? J0 + 1 : J0, C = CNT >= 3 ? J0 + 2 : J0, D = CNT >= 4 ? J0 + 3 : J0;
+        if constexpr (CNT >= 4) {
+            asm volatile("s_nop 1\n\t"
+                         "v_fmac_f64_dpp %[a0], %[c0], %[ta]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[a1], %[c1], %[ta]" PIORAN_BLK_DPP "\n\t"
+                         "v_fmac_f64_dpp %[a2], %[c2], %[ta]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[a3], %[c3], %[ta]" PIORAN_BLK_DPP "\n\t"
+                         "v_fmac_f64_dpp %[c0], %[c0], %[tn]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[c1], %[c1], %[tn]" PIORAN_BLK_DPP "\n\t"
+                         "v_fmac_f64_dpp %[c2], %[c2], %[tn]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[c3], %[c3], %[tn]" PIORAN_BLK_DPP
+                         : [a0] "+v"(aug[A]), [a1] "+v"(aug[B]), [a2] "+v"(aug[C]), [a3] "+v"(aug[D]), [c0] "+v"(col[A]), [c1] "+v"(col[B]),
+                           [c2] "+v"(col[C]), [c3] "+v"(col[D])
+                         : [tn] "v"(ntn), [ta] "v"(nta), [p] "i"(P));
+            ldl_rows<P, J0 + 4, CNT - 4>(col, aug, ntn, nta);
+        } else {
+            // (a DPP source must not have been written by one of the two preceding VALU instructions: aug first, then col)
+            asm volatile("s_nop 1\n\t"
+                         "v_fmac_f64_dpp %[a0], %[c0], %[ta]" PIORAN_BLK_DPP "\n\t"
+                         "v_fmac_f64_dpp %[c0], %[c0], %[tn]" PIORAN_BLK_DPP
+                         : [a0] "+v"(aug[A]), [c0] "+v"(col[A])
+                         : [tn] "v"(ntn), [ta] "v"(nta), [p] "i"(P));
+            ldl_rows<P, J0 + 1, CNT - 1>(col, aug, ntn, nta);
+        }
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void ldl_step(double (&col)[16], double (&aug)[16], double (&dv)[16], double (&rv)[16])
+{
+    double dp;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%c2 row_mask:0xf bank_mask:0xf" : "=v"(dp) : "v"(col[P]), "i"(P));
+    const double rp = recip_f64(dp);
+    dv[P] = dp;
+    rv[P] = rp;
+    const double ntn = -col[P] * rp, nta = -aug[P] * rp;
+    ldl_rows<P, P + 1, 15 - P>(col, aug, ntn, nta);
+}
+
+struct BlockShared {                // exchanges between the wavefronts of a workgroup
+    double Mt[16 * (16 * 4 + 2)];   // M' [step][row], row stride 16 NB + 2
+    double Sg[256];                 // Sigma [j][n]
+    double Ab[2][256];              // A of window k in Ab[k & 1]
+    double Li[256];                 // L^-1 [i][k]
+    double iD[16];                  // 1 / D_n of the window
+    double Yt[4 * 256];             // Y^' fragments [J][g][lane]
+    double fin[8];
+    double2 ab[64];                 // (a_t, b_t) of this draw
+};
+constexpr int kBlockMaxTerms = 64;
+
+// doubles of the (CV, CX, VH, CK, S2w) part of a record, rounded up to whole 1 KB pieces of the LDS DMA
+__host__ __device__ inline int block_tile_doubles(int NB) { return (3 * NB * 256 + 16 * NB + 16 + 127) & ~127; }
+
+// global -> LDS without registers: 1 KB per wavefront instruction (global_load_lds_dwordx4: LDS address = uniform base + 16 lane)
+__device__ __forceinline__ void dma_pieces(const double* gsrc, double* ldst, int npieces, int w, int lane)
+{
+    for (int c = w; c < npieces; c += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + c * 128 + lane * 2),
+                                         (__attribute__((address_space(3))) void*)(ldst + c * 128), 16, 0, 0);
+}
+// workgroup barrier that publishes LDS writes but leaves LDS DMAs / global loads in flight (__syncthreads() would drain them)
+#define PIORAN_BLK_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PIORAN_BLK_BARRIER_DMA() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// ---- the kernel --------------------------------------------------------------------------------------------------------
+// LDS: two tile buffers (records k, k + 1), one E buffer, the exchange block.  Record k + 2 is copied in (LDS DMA) while the chain
+// of window k runs and is first read after barrier 1 of window k + 1: a whole window of latency cover, no registers.
+template <int NB>
+__global__ void __launch_bounds__(256, 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
+{
+    constexpr int LDM = 16 * NB + 2;
+    constexpr int TS = 3 * NB * 256 + 16 * NB + 16, TSP = (TS + 127) & ~127;
+    extern __shared__ double lds_[];
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, lane = tid & 63, q = lane >> 4, c16 = lane & 15;
+    const int64_t b = blockIdx.x;
+    const int64_t N = p.N;
+    const int J = p.J, R = p.R;
+    const int64_t NW = (N + KW - 1) / KW;
+    const int64_t RSB = TSP + 256 * (int64_t)J;
+    double* const tileb = lds_;
+    double* const Eb = lds_ + 2 * TSP;
+    BlockShared& sh = *reinterpret_cast<BlockShared*>(lds_ + 2 * TSP + 256 * J);
+    const bool chain = w == 3;
+    const bool owner = w < NB;                                    // this wavefront owns block column w of T
+    const bool has_u = owner || chain;
+    const int Jy = R >> 4, ry = R & 15;                           // block column / lane column of the y row
+    const bool ycol = owner && w == Jy && c16 == ry;
+    const double mu = p.mu ? p.mu[b] : 0.0;
+    const double nu = p.nu ? p.nu[b] : 1.0;
+    const bool has_nu = p.nu != nullptr;
+    const double* __restrict__ Ab_ = p.A + b * J;
+    const double* __restrict__ Bb_ = p.Bc + b * J;
+    double suma = 0.0;  // :21
+    for (int j = 0; j < J; ++j) suma += Ab_[j];
+
+    dma_pieces(btab, tileb, TSP / 128, w, lane);
+    dma_pieces(btab + TSP, Eb, 2 * J, w, lane);
+    if (tid < J) sh.ab[tid] = double2{Ab_[tid], Bb_[tid]};
+
+    // u = al v + be x of the rows of this lane's A-operand fragments
+    double alf[NB][4], bef[NB][4];
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int row = 16 * I + 4 * ks + q;
+            double a = 0.0, bb = 0.0;
+            if (row < R) {
+                const int rm = p.rowmap[row];
+                const int term = rm & 0xfffff;
+                a = Ab_[term];
+                bb = ((rm >> 30) & 1) ? -Bb_[term] : Bb_[term];   // :59-63
+            }
+            alf[I][ks] = a;
+            bef[I][ks] = bb;
+        }
+
+    d4 T[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) T[I] = d4{0.0, 0.0, 0.0, 0.0};
+    double Uf[NB][4];
+    double vh[4], ckc = 0.0, ckr[NB][4];
+
+    auto load_u = [&](int64_t k) __attribute__((always_inline)) {
+        const double* tl = tileb + (k & 1) * TSP;
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int f = (I * 4 + ks) * 64 + lane;
+                Uf[I][ks] = fma(alf[I][ks], tl[f], bef[I][ks] * tl[NB * 256 + f]);
+            }
+    };
+    auto load_vh = [&](int64_t k) __attribute__((always_inline)) {
+        const double* tl = tileb + (k & 1) * TSP;
+        if (owner) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                double v = tl[2 * NB * 256 + (w * 4 + g) * 64 + lane];
+                if (ycol) {
+                    const int64_t n = k * KW + 4 * g + q;
+                    if (p.Y) v = n < N ? p.Y[b * N + n] : 0.0;
+                    v = n < N ? v - mu : 0.0;              // z_n = y_n - u'f   :141
+                }
+                vh[g] = v;
+            }
+            ckc = tl[3 * NB * 256 + 16 * w + c16];
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ckr[I][g] = tl[3 * NB * 256 + 16 * I + 4 * g + q];
+        }
+    };
+    // A of window k (kappa, src/acvf.jl:138-140, on the window's own pairs) -> sh.Ab[k & 1]; wavefronts 0 .. 2:
+    // thread pp < 120 owns the pair (jj < nn), threads 120 .. 135 the diagonal
+    const int pp = 64 * w + lane;
+    int nn = 1;
+    while ((nn + 1) * nn / 2 <= pp) ++nn;
+    const int jj = pp - nn * (nn - 1) / 2;
+    auto form_A = [&](int64_t k) __attribute__((always_inline)) {
+        if (w < 3) {
+            double* Ad = sh.Ab[k & 1];
+            if (pp < 120) {
+                const double2* E = reinterpret_cast<const double2*>(Eb) + pp;
+                double acc0 = 0.0, acc1 = 0.0;
+                int t = 0;
+                for (; t + 4 <= J; t += 4) {
+                    double2 e[4], cf[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { e[i] = E[(t + i) * 128]; cf[i] = sh.ab[t + i]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { acc0 = fma(cf[i].x, e[i].x, acc0); acc1 = fma(cf[i].y, e[i].y, acc1); }
+                }
+                for (; t < J; ++t) {
+                    const double2 e = E[t * 128], cf = sh.ab[t];
+                    acc0 = fma(cf.x, e.x, acc0);
+                    acc1 = fma(cf.y, e.y, acc1);
+                }
+                const double acc = acc0 + acc1;
+                Ad[jj * 16 + nn] = acc;
+                Ad[nn * 16 + jj] = acc;
+            } else if (pp < 136) {
+                const int s = pp - 120;
+                const int64_t n = k * KW + s;
+                double v = 1.0;
+                if (n < N) {
+                    const double s2n = p.S2 ? p.S2[b * N + n] : tileb[(k & 1) * TSP + 3 * NB * 256 + 16 * NB + s];
+                    v = suma + (has_nu ? nu * s2n : s2n);    // :92
+                }
+                Ad[s * 16 + s] = v;
+            }
+        }
+    };
+
+    PIORAN_BLK_BARRIER_DMA();          // record 0 has landed
+    if (has_u) load_u(0);
+    load_vh(0);
+    form_A(0);
+    double quad = 0.0;                 // meaningful in the y-row lanes of the wavefront that owns block column Jy
+    double Pm = 1.0;                   // running product of |D| (sign of D_1 kept: :126), chain wavefront
+    int Pe = 0;
+    bool nonpd = false;
+    PIORAN_BLK_BARRIER();              // every wavefront is done with E(0)
+    if (NW > 1) {
+        dma_pieces(btab + RSB, tileb + TSP, TSP / 128, w, lane);
+        dma_pieces(btab + RSB + TSP, Eb, 2 * J, w, lane);
+    }
+
+    PIORAN_BSTAMP_DECL
+    for (int64_t k = 0; k < NW; ++k) {
+        PIORAN_BSTAMP(0);
+        // ---- M' = U~' T, X' = V^' - C_K o M' ------------------------------------------------------------------------
+        double x[4];
+        if (owner) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[I][ks], T[I][ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                sh.Mt[(4 * g + q) * LDM + 16 * w + c16] = acc[g];
+                x[g] = fma(-ckc, acc[g], vh[g]);
+            }
+        }
+        PIORAN_BSTAMP(1);
+        PIORAN_BLK_BARRIER_DMA();   // B1: M' published; record k + 1 has landed
+        PIORAN_BSTAMP(2);
+        // ---- chain: Sigma = A - U~' M, LDL', L^-1 ---------------------------------------------------------------------
+        double dv[16];
+        if (chain) {
+            d4 G = {0.0, 0.0, 0.0, 0.0};
+            double mb[NB][4];
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) mb[I][ks] = sh.Mt[c16 * LDM + 16 * I + 4 * ks + q];   // M [row 16 I + 4 ks + q][step c16]
+            const double* Ad = sh.Ab[k & 1];
+            double av[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) av[g] = Ad[(4 * g + q) * 16 + c16];
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) G = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[I][ks], mb[I][ks], G, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sh.Sg[(4 * g + q) * 16 + c16] = av[g] - G[g];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PIORAN_BSTAMP(3);
+            double col[16], aug[16], rv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                col[j] = sh.Sg[j * 16 + c16];
+                aug[j] = j == c16 ? 1.0 : 0.0;
+            }
+            PIORAN_BSTAMP(4);
+            static_for<0, 16>([&](auto Pc) __attribute__((always_inline)) { ldl_step<decltype(Pc)::value>(col, aug, dv, rv); });
+            PIORAN_BSTAMP(5);
+            if (q == 0) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sh.Li[j * 16 + c16] = aug[j];
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sh.iD[j] = rv[j];
+            }
+        }
+        PIORAN_BSTAMP(6);
+        // ---- meanwhile: rescale T, A and U~ of the next window ---------------------------------------------------------
+        if (owner) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) T[I][g] *= ckr[I][g] * ckc;
+        }
+        if (k + 1 < NW) {
+            form_A(k + 1);
+            if (owner && !chain) load_u(k + 1);
+            load_vh(k + 1);
+        }
+        // record k + 2: tile k (buffer k & 1) has no reader left since barrier 1; the E pieces a wavefront refills are the ones
+        // only it reads (piece 2 t + h = term t, pairs 64 h .. 64 h + 63), just consumed by its own form_A above
+        if (k + 2 < NW) {
+            const double* src = btab + (k + 2) * RSB;
+            if (w < 2) {
+                for (int t = 0; t < J; ++t)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + TSP + (2 * t + w) * 128 + lane * 2),
+                                                     (__attribute__((address_space(3))) void*)(Eb + (2 * t + w) * 128), 16, 0, 0);
+            } else if (w == 2) {
+                for (int c = 0; c < TSP / 128; ++c)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c * 128 + lane * 2),
+                                                     (__attribute__((address_space(3))) void*)(tileb + (k & 1) * TSP + c * 128), 16, 0, 0);
+            }
+        }
+        PIORAN_BSTAMP(7);
+        PIORAN_BLK_BARRIER();   // B2: L^-1, 1/D published
+        PIORAN_BSTAMP(8);
+        // ---- Y^' = L^-1 X' --------------------------------------------------------------------------------------------
+        double ysc[4], yown[4];
+        if (owner) {
+            double li[4], idv[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                li[ks] = sh.Li[c16 * 16 + 4 * ks + q];
+                idv[ks] = sh.iD[4 * ks + q];
+            }
+            d4 yt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) yt = __builtin_amdgcn_mfma_f64_16x16x4f64(li[ks], x[ks], yt, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                sh.Yt[(w * 4 + g) * 64 + lane] = yt[g];
+                yown[g] = yt[g];
+                ysc[g] = yt[g] * idv[g];
+                if (w == Jy) quad = fma(yt[g], ysc[g], quad);     // z_n^2 / D_n (== y'K^-1 y, :333)
+            }
+        }
+        PIORAN_BSTAMP(9);
+        PIORAN_BLK_BARRIER();   // B3: Y^' published
+        PIORAN_BSTAMP(10);
+        // ---- T += Y^ D^-1 Y^' -----------------------------------------------------------------------------------------
+        if (owner) {
+            double ya[NB][4];
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) ya[I][ks] = I == w ? yown[ks] : sh.Yt[(I * 4 + ks) * 64 + lane];
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) T[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[I][ks], ysc[ks], T[I], 0, 0, 0);
+        }
+        if (chain) {   // off the critical path: log-determinant bookkeeping, U~ of the next window
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double dj = dv[j];
+                nonpd |= !(dj > 0.0);
+                Pm *= (k == 0 && j == 0) ? dj : fabs(dj);    // log(D[1]) :126, log(abs(D[n])) :140
+                if ((j & 3) == 3) {
+                    int ex;
+                    Pm = frexp(Pm, &ex);
+                    Pe += ex;
+                }
+            }
+            if (k + 1 < NW) load_u(k + 1);
+        }
+    }
+
+    PIORAN_BSTAMP(11);
+    PIORAN_BSTAMP_FLUSH
+    // ---- result ------------------------------------------------------------------------------------------------------------
+    if (ycol) sh.fin[q] = quad;
+    PIORAN_BLK_BARRIER();
+    if (chain && lane == 0) {
+        const double qs = (sh.fin[0] + sh.fin[1]) + (sh.fin[2] + sh.fin[3]);
+        const double logdet = log(Pm) + (double)Pe * 0.6931471805599453094;
+        const double res = -0.5 * logdet - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * qs;
+        p.out[b] = res;
+        if (p.status) p.status[b] = !isfinite(res) ? 2 : (nonpd ? 1 : 0);
+    }
+}
+
+template <int NB>
+int launch_block(const ScanParams& p, const double* btab, hipStream_t stream)
+{
+    const size_t lds = (size_t)(2 * block_tile_doubles(NB) + 256 * p.J) * sizeof(double) + sizeof(BlockShared);
+    if (lds > 160 * 1024) return PIORAN_ERR_UNSUPPORTED;
+    static size_t granted = 0;   // per template instance
+    if (lds > granted) {
+        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PIORAN_ERR_HIP;
+        granted = lds;
+    }
+    hipLaunchKernelGGL((celerite_block_kernel<NB>), dim3((unsigned)p.B), dim3(256), lds, stream, p, btab);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
+}  // namespace
+
+int pioran_block_supported_rows() { return 63; }
+
+// 0 when (R, J) does not fit the kernel's LDS budget
+size_t pioran_block_table_doubles(int64_t N, int32_t R, int32_t J)
+{
+    const int NB = (R + 1 + 15) / 16;
+    return (size_t)((N + KW - 1) / KW) * (size_t)block_rec_doubles(NB, J);
+}
+
+int pioran_block_fits(int32_t R, int32_t J)
+{
+    const int NB = (R + 1 + 15) / 16;
+    if (R < 1 || NB > 4 || J < 1 || J > kBlockMaxTerms) return 0;
+    return (size_t)(2 * block_tile_doubles(NB) + 256 * J) * sizeof(double) + sizeof(BlockShared) <= 160 * 1024;
+}
+
+int pioran_launch_block_table(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,
+                              const double* d, const double* y, const double* s2, double* btab, hipStream_t stream)
+{
+    const int NB = (R + 1 + 15) / 16;
+    const int64_t total = (int64_t)pioran_block_table_doubles(N, R, J);
+    hipLaunchKernelGGL(block_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, N, R, J, NB, rowmap, t, c, d, y,
+                       s2, btab);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
+// shared-(c, d) launches without per-draw rows; btab from pioran_launch_block_table for the same (N, R, J, rowmap)
+int pioran_launch_scan_block(const ScanParams& p, const double* btab, hipStream_t stream)
+{
+    if (!btab || p.npd_rows != 0 || p.B < 1 || p.N < 1 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    if ((p.Y == nullptr) != (p.S2 == nullptr)) return PIORAN_ERR_ARG;
+    switch ((p.R + 1 + 15) / 16) {
+        case 1: return launch_block<1>(p, btab, stream);
+        case 2: return launch_block<2>(p, btab, stream);
+        case 3: return launch_block<3>(p, btab, stream);
+        case 4: return launch_block<4>(p, btab, stream);
+    }
+    return PIORAN_ERR_UNSUPPORTED;
+}

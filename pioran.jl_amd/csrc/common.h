@@ -14,11 +14,11 @@
 //   cos row (v, x) = (cos, sin)(d_j t_n), sin row (sin, cos); phi = exp(-c_j (t_n - t_{n-1}));
 //   row R is the inert padding row (v, x, phi) = (1, 0, 1), row R+1 the y row (0, 0, 1).
 // Diagnostic switches of a context (none is needed in production).  Read ONCE from the environment when the context is
-// created (PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_PAIRED, PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK) and changed
+// created (PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_BLOCK, PIORAN_NO_PAIRED, PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK) and changed
 // afterwards only through pioran_ctx_set_option — the launch path never calls getenv.
 struct ScanOptions {
-    char scan_config[48];   // "" automatic; "wide": latency layout for any batch size; else a throughput configuration's name
-    bool no_wide, no_paired, no_mixed, force_fallback;
+    char scan_config[48];   // "" automatic; "wide" / "block": that small-batch kernel for any batch size; else a throughput configuration's name
+    bool no_wide, no_paired, no_mixed, force_fallback, no_block;
 };
 
 struct ScanParams {
@@ -97,6 +97,14 @@ int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, dou
                                  double* grad_nu, double* grad_mu, hipStream_t stream, hipStream_t aux, hipEvent_t* ev /*[5]*/);
 int pioran_wide_supported_rows();
 int64_t pioran_wide_max_batch();
+// celerite_block.hip: windowed form (16 steps per window on the matrix cores), one draw per workgroup; shared (c, d) without
+// per-draw rows; its own table (fragment order), built once per prepared (c, d)
+int pioran_block_supported_rows();
+int pioran_block_fits(int32_t R, int32_t J);   // rows and terms within the kernel's LDS budget
+size_t pioran_block_table_doubles(int64_t N, int32_t R, int32_t J);
+int pioran_launch_block_table(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,
+                              const double* d, const double* y, const double* s2, double* btab, hipStream_t stream);
+int pioran_launch_scan_block(const ScanParams& p, const double* btab, hipStream_t stream);
 // celerite_predict.hip: posterior mean at new times (pred, src/celerite_solver.jl:363-483)
 size_t pioran_predict_workspace_doubles(int64_t B, int64_t N, int32_t R);
 int pioran_launch_predict(ScanParams p, double* work, const double* t, int64_t M, const double* tau, double* mean_out,

@@ -103,14 +103,18 @@ def _random_case(rng, N, J, B, per_draw_cd=False):
     return t, y, s2, A, Bc, C, Dd, mu, nu
 
 
-@pytest.fixture(params=["throughput", "latency"])
+@pytest.fixture(params=["throughput", "latency", "block"])
 def layout(request, ctx):
-    """Small batches (B <= 256) take the one-draw-per-workgroup latency layout by default; the context option "no_wide"
-    sends them through the throughput layouts (the ones large batches use), so both are checked on the same inputs."""
+    """Small batches (B <= 256) with 16 <= R <= 63 rows take the windowed kernel (celerite_block.hip) by default; "no_block" sends
+    them to the one-draw-per-workgroup latency layout (celerite_wide.hip), "no_wide" as well to the throughput layouts (the ones
+    large batches use): all three are checked on the same inputs."""
+    if request.param != "block":
+        ctx.set_option("no_block", True)
     if request.param == "throughput":
         ctx.set_option("no_wide", True)
     yield request.param
     ctx.set_option("no_wide", False)
+    ctx.set_option("no_block", False)
 
 
 @pytest.mark.parametrize("J", [1, 2, 3, 5, 8, 10, 13, 16, 20, 21, 24, 27, 32, 40])
@@ -197,6 +201,49 @@ def test_edge_sizes(ctx, layout):
     assert abs(v - O.logl(A[0], Bc[0], C, Dd, t, y, np.zeros_like(s2))) <= 1e-10 * abs(v)
 
 
+def test_block_kernel_edges(ctx):
+    """Windowed kernel (celerite_block.hip): series shorter than, equal to and just past a window / two windows, every block
+    count NB = 1..4, batches above the automatic limit, per-draw series, the y row in the last lane of a block (R = 15, 31, 47)
+    and in the first lane of the next one (R = 16, 32, 48)."""
+    rng = np.random.default_rng(77)
+    ctx.set_option("scan_config", "block")
+    try:
+        for J, N, B in [(1, 1, 3), (2, 15, 4), (8, 16, 5), (8, 17, 5), (12, 31, 2), (16, 32, 3), (16, 33, 300), (20, 100, 7),
+                        (24, 64, 3), (30, 49, 2), (31, 130, 3)]:
+            t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+            ds = pj.Dataset(t, y, s2, ctx)
+            got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+            ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+            assert relerr(got, ref) < 1e-11, (J, N, B)
+            assert (st == 0).all()
+        # odd row counts through real (one-row) terms: R = 15, 16, 31, 47
+        for J, nreal in [(8, 1), (9, 2), (16, 1), (24, 1)]:
+            t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 70, J, 5)
+            Bc[:, :nreal] = 0.0
+            Dd[:nreal] = 0.0
+            ds = pj.Dataset(t, y, s2, ctx)
+            got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+            ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+            assert relerr(got, ref) < 1e-11, (J, nreal)
+        # per-draw series
+        t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 90, 20, 6)
+        Y = rng.standard_normal((6, 90)); S2 = rng.uniform(0.01, 0.1, (6, 90))
+        ds = pj.Dataset(t, y, s2, ctx)
+        got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+        ref = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(6)])
+        assert relerr(got, ref) < 1e-11
+        # non-positive-definite draws follow the reference's log(abs(D_n)) (src/celerite_solver.jl:140) and are flagged
+        t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 60, 20, 4)
+        A[1] *= -1.0
+        got, st = pj.Dataset(t, y, s2, ctx).logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        ref, rst = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=4, return_status=True)
+        assert (st == rst).all() and st[1] != 0
+        ok = np.isfinite(ref)
+        assert relerr(got[ok], ref[ok]) < 1e-9 and (np.isnan(got) == np.isnan(ref)).all()
+    finally:
+        ctx.set_option("scan_config", None)
+
+
 def test_latency_layout_edges(ctx):
     """celerite_wide.hip on its own: every prologue / tail length of the 4-deep record pipeline (N = 1..9), every
     RPL (R = 2J = 2..78), with and without mu / nu, per-draw series, and the not-positive-definite status."""
@@ -277,10 +324,10 @@ def test_all_kernel_configs_agree(ctx):
     ds = pj.Dataset(t, y, s2, ctx)
     try:
         for name in ("rpl3_cbr2_nsrc7_p", "rpl3_cbr2_nsrc8_p", "rpl3_cbr2_nsrc7", "rpl3_cbr2_nsrc8", "rpl3_cbr4_nsrc4", "rpl4_cbr4_nsrc4",
-                     "rpl5_cbr4_nsrc4", "rpl4_cbr4_nsrc4_p", "rpl5_cbr4_nsrc4_p", "wide"):
+                     "rpl5_cbr4_nsrc4", "rpl4_cbr4_nsrc4_p", "rpl5_cbr4_nsrc4_p", "wide", "block"):
             ctx.set_option("scan_config", name)
             got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
-            if name != "wide":   # ("wide" = the latency layout of celerite_wide.hip, not an entry of the scan table)
+            if name not in ("wide", "block"):   # (the small-batch kernels of celerite_wide.hip / celerite_block.hip are not entries of the scan table)
                 assert pj._lib.lib().pioran_celerite_config_name(0).decode() == name   # what the launch actually ran on
             assert relerr(got, ref) < 1e-11, name
         ctx.set_option("force_fallback", True)
