@@ -148,57 +148,84 @@ __global__ void __launch_bounds__(256) block_table_kernel(int64_t N, int32_t R, 
 }
 
 // ---- the 16 x 16 LDL' of the chain wavefront -------------------------------------------------------------------------
-// Lane (q, n): col[j] = Sigma_{j n}, aug[j] = (row operations applied to the identity)_{j n}; the four DPP rows q hold copies.
+// In-place Gauss-Jordan form.  Lane (q, n) holds column n in m[0..15]; the four DPP rows q hold copies.  Before step P, lanes
+// n >= P hold the reduced Sigma (column n, rows >= P matter), lanes n < P already hold column n of L^-1 (rows > n).  Step P:
+//   d_P = m[P] of lane P ;  mult_n = -m[P]_n / d_P  (lane P: -2) ;  m[j]_n += bcast_P(m[j]) * mult_n  for j > P
+// which is the rank-1 update of Sigma for n > P, the row operation on the identity for n < P, and turns lane P's own
+// Sigma_jP = L_jP d_P into -L_jP d_P: column P of L^-1 SCALED BY d_P (exactly: the factor -2 is exact, and every later row
+// operation is linear in the column; -1/d_P - 1 instead would leave the unscaled column but rounds 1/d_P to the grid of 1).
+// One v_fmac_f64_dpp per (P, j): 120 in all.  At the end lane n holds d_n in m[n] and d_n (L^-1)_jn in m[j], j > n; m[j]_n
+// with j < n is left-over Sigma (the readers mask it).
 #define PIORAN_BLK_DPP " row_newbcast:%c[p] row_mask:0xf bank_mask:0xf"
-// rows j = J0 .. J0 + CNT - 1 of step P: aug[j] += bcast_P(col[j]) * nta ; col[j] += bcast_P(col[j]) * ntn
 template <int P, int J0, int CNT>
-__device__ __forceinline__ void ldl_rows(double (&col)[16], double (&aug)[16], double ntn, double nta)
+__device__ __forceinline__ void ldl_rows(double (&m)[16], double mult)
 {
-    if constexpr (CNT >= 1) {
-        constexpr int A = J0, B = CNT >= 2 ? J0 + 1 : J0, C = CNT >= 3 ? J0 + 2 : J0, D = CNT >= 4 ? J0 + 3 : J0;
-        if constexpr (CNT >= 4) {
-            asm volatile("s_nop 1\n\t"
-                         "v_fmac_f64_dpp %[a0], %[c0], %[ta]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[a1], %[c1], %[ta]" PIORAN_BLK_DPP "\n\t"
-                         "v_fmac_f64_dpp %[a2], %[c2], %[ta]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[a3], %[c3], %[ta]" PIORAN_BLK_DPP "\n\t"
-                         "v_fmac_f64_dpp %[c0], %[c0], %[tn]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[c1], %[c1], %[tn]" PIORAN_BLK_DPP "\n\t"
-                         "v_fmac_f64_dpp %[c2], %[c2], %[tn]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[c3], %[c3], %[tn]" PIORAN_BLK_DPP
-                         : [a0] "+v"(aug[A]), [a1] "+v"(aug[B]), [a2] "+v"(aug[C]), [a3] "+v"(aug[D]), [c0] "+v"(col[A]), [c1] "+v"(col[B]),
-                           [c2] "+v"(col[C]), [c3] "+v"(col[D])
-                         : [tn] "v"(ntn), [ta] "v"(nta), [p] "i"(P));
-            ldl_rows<P, J0 + 4, CNT - 4>(col, aug, ntn, nta);
-        } else {
-            // (a DPP source must not have been written by one of the two preceding VALU instructions: aug first, then col)
-            asm volatile("s_nop 1\n\t"
-                         "v_fmac_f64_dpp %[a0], %[c0], %[ta]" PIORAN_BLK_DPP "\n\t"
-                         "v_fmac_f64_dpp %[c0], %[c0], %[tn]" PIORAN_BLK_DPP
-                         : [a0] "+v"(aug[A]), [c0] "+v"(col[A])
-                         : [tn] "v"(ntn), [ta] "v"(nta), [p] "i"(P));
-            ldl_rows<P, J0 + 1, CNT - 1>(col, aug, ntn, nta);
-        }
+    if constexpr (CNT >= 4) {
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f64_dpp %[c0], %[c0], %[t]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[c1], %[c1], %[t]" PIORAN_BLK_DPP "\n\t"
+                     "v_fmac_f64_dpp %[c2], %[c2], %[t]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[c3], %[c3], %[t]" PIORAN_BLK_DPP
+                     : [c0] "+v"(m[J0]), [c1] "+v"(m[J0 + 1]), [c2] "+v"(m[J0 + 2]), [c3] "+v"(m[J0 + 3])
+                     : [t] "v"(mult), [p] "i"(P));
+        ldl_rows<P, J0 + 4, CNT - 4>(m, mult);
+    } else if constexpr (CNT >= 1) {
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %[c0], %[c0], %[t]" PIORAN_BLK_DPP : [c0] "+v"(m[J0]) : [t] "v"(mult), [p] "i"(P));
+        ldl_rows<P, J0 + 1, CNT - 1>(m, mult);
     }
 }
 
-template <int P>
-__device__ __forceinline__ void ldl_step(double (&col)[16], double (&aug)[16], double (&dv)[16], double (&rv)[16])
+// One elimination step with the NEXT pivot's reciprocal chain (broadcast, v_rcp_f64, two Newton steps: ~10 dependent DP
+// operations) spread between the rank-1 updates of this step, which do not depend on it: the wavefront issues in order, so the
+// order below is the schedule (every piece is its own asm volatile statement).  `mult` is this step's multiplier, on return the
+// next step's; D_P stays in m[P] of lane P.
+__device__ __forceinline__ void blk_rcp(double& r, double d) { asm volatile("v_rcp_f64 %0, %1" : "=v"(r) : "v"(d)); }
+__device__ __forceinline__ void blk_newton(double& r, double d)
 {
-    double dp;
-    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%c2 row_mask:0xf bank_mask:0xf" : "=v"(dp) : "v"(col[P]), "i"(P));
-    const double rp = recip_f64(dp);
-    dv[P] = dp;
-    rv[P] = rp;
-    const double ntn = -col[P] * rp, nta = -aug[P] * rp;
-    ldl_rows<P, P + 1, 15 - P>(col, aug, ntn, nta);
+    double e;
+    asm volatile("s_nop 0\n\tv_fma_f64 %0, -%2, %1, 1.0\n\tv_fma_f64 %1, %0, %1, %1" : "=&v"(e), "+v"(r) : "v"(d));
+}
+template <int P>
+__device__ __forceinline__ void ldl_step(double (&m)[16], double& mult, int c16)
+{
+    constexpr int NR = 15 - P;                       // rows below the pivot
+    constexpr int NA = NR >= 1 ? 1 : 0;              // the next pivot's row first
+    constexpr int NBk = NR - NA >= 4 ? 4 : NR - NA;
+    constexpr int NCk = NR - NA - NBk >= 4 ? 4 : NR - NA - NBk;
+    constexpr int NDk = NR - NA - NBk - NCk;
+    ldl_rows<P, P + 1, NA>(m, mult);
+    if constexpr (P < 15) {
+        double dn, rn;
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%c2 row_mask:0xf bank_mask:0xf" : "=v"(dn) : "v"(m[P + 1]), "i"(P + 1));
+        if constexpr (NBk == 0) asm volatile("s_nop 0");
+        blk_rcp(rn, dn);
+        ldl_rows<P, P + 1 + NA, NBk>(m, mult);
+        blk_newton(rn, dn);
+        ldl_rows<P, P + 1 + NA + NBk, NCk>(m, mult);
+        blk_newton(rn, dn);
+        ldl_rows<P, P + 1 + NA + NBk + NCk, NDk>(m, mult);
+        mult = c16 == P + 1 ? -2.0 : -m[P + 1] * rn;
+    }
+}
+__device__ __forceinline__ double ldl_first_mult(double (&m)[16], int c16)
+{
+    double d0, r0;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(d0) : "v"(m[0]));
+    asm volatile("s_nop 0");
+    blk_rcp(r0, d0);
+    blk_newton(r0, d0);
+    blk_newton(r0, d0);
+    return c16 == 0 ? -2.0 : -m[0] * r0;
 }
 
 struct BlockShared {                // exchanges between the wavefronts of a workgroup
-    double Mt[16 * (16 * 4 + 2)];   // M' [step][row], row stride 16 NB + 2
+    double MG[4][16 * 18];          // per wavefront: its block of M' [step][row, stride 18] for the transposing read-back, then
+                                    // (same storage) its partial Gram U~_J' M_J as fragments [g][lane]
     double Sg[256];                 // Sigma [j][n]
     double Ab[2][256];              // A of window k in Ab[k & 1]
-    double Li[256];                 // L^-1 [i][k]
-    double iD[16];                  // 1 / D_n of the window
+    double Li[16 * 18];             // D_k (L^-1)_ik at [k * 18 + i], i > k; D_k at [k * 18 + k]; the rest is not L^-1 (readers mask)
     double Yt[4 * 256];             // Y^' fragments [J][g][lane]
     double fin[8];
     double2 ab[64];                 // (a_t, b_t) of this draw
+    double2 albe[64];               // per row: u = al v + be x
 };
 constexpr int kBlockMaxTerms = 64;
 
@@ -206,9 +233,9 @@ constexpr int kBlockMaxTerms = 64;
 __host__ __device__ inline int block_tile_doubles(int NB) { return (3 * NB * 256 + 16 * NB + 16 + 127) & ~127; }
 
 // global -> LDS without registers: 1 KB per wavefront instruction (global_load_lds_dwordx4: LDS address = uniform base + 16 lane)
-__device__ __forceinline__ void dma_pieces(const double* gsrc, double* ldst, int npieces, int w, int lane)
+__device__ __forceinline__ void dma_pieces(const double* gsrc, double* ldst, int npieces, int w, int nwaves, int lane)
 {
-    for (int c = w; c < npieces; c += 4)
+    for (int c = w; c < npieces; c += nwaves)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + c * 128 + lane * 2),
                                          (__attribute__((address_space(3))) void*)(ldst + c * 128), 16, 0, 0);
 }
@@ -219,23 +246,31 @@ __device__ __forceinline__ void dma_pieces(const double* gsrc, double* ldst, int
 // ---- the kernel --------------------------------------------------------------------------------------------------------
 // LDS: two tile buffers (records k, k + 1), one E buffer, the exchange block.  Record k + 2 is copied in (LDS DMA) while the chain
 // of window k runs and is first read after barrier 1 of window k + 1: a whole window of latency cover, no registers.
-template <int NB>
-__global__ void __launch_bounds__(256, 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
+// Wavefronts: NB owners of a block column of T + the chain wavefront (with NB = 4 a fifth wavefront, so that the chain never
+// queues behind an owner's MFMA work on the same instruction stream); never fewer than four (the pair contraction uses three).
+// EDBL: E has two LDS buffers as well (when it fits): then every piece of record k + 2 may be copied by any wavefront once barrier 1
+// of window k has passed, and the copies are spread over all wavefronts (a piece costs its issuer ~150 cycles); with a single E
+// buffer a wavefront refills exactly the E pieces that only it reads.
+template <int NB, bool EDBL>
+__global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
 {
-    constexpr int LDM = 16 * NB + 2;
+    constexpr int NWV = NB < 4 ? 4 : 5;     // wavefronts per workgroup
+    constexpr int CH = NWV - 1;             // the chain wavefront
     constexpr int TS = 3 * NB * 256 + 16 * NB + 16, TSP = (TS + 127) & ~127;
     extern __shared__ double lds_[];
     const int tid = threadIdx.x;
-    const int w = tid >> 6, lane = tid & 63, q = lane >> 4, c16 = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be
+    const int lane = tid & 63, q = lane >> 4, c16 = lane & 15;
     const int64_t b = blockIdx.x;
     const int64_t N = p.N;
     const int J = p.J, R = p.R;
     const int64_t NW = (N + KW - 1) / KW;
     const int64_t RSB = TSP + 256 * (int64_t)J;
     double* const tileb = lds_;
-    double* const Eb = lds_ + 2 * TSP;
-    BlockShared& sh = *reinterpret_cast<BlockShared*>(lds_ + 2 * TSP + 256 * J);
-    const bool chain = w == 3;
+    double* const Eb = lds_ + 2 * TSP;               // E(k) lives in Eb + (EDBL ? (k & 1) * 256 J : 0)
+    const int ebs = EDBL ? 256 * J : 0;
+    BlockShared& sh = *reinterpret_cast<BlockShared*>(lds_ + 2 * TSP + (EDBL ? 2 : 1) * 256 * J);
+    const bool chain = w == CH;
     const bool owner = w < NB;                                    // this wavefront owns block column w of T
     const bool has_u = owner || chain;
     const int Jy = R >> 4, ry = R & 15;                           // block column / lane column of the y row
@@ -248,27 +283,21 @@ __global__ void __launch_bounds__(256, 1) celerite_block_kernel(const ScanParams
     double suma = 0.0;  // :21
     for (int j = 0; j < J; ++j) suma += Ab_[j];
 
-    dma_pieces(btab, tileb, TSP / 128, w, lane);
-    dma_pieces(btab + TSP, Eb, 2 * J, w, lane);
+    dma_pieces(btab, tileb, TSP / 128, w, NWV, lane);
+    dma_pieces(btab + TSP, Eb, 2 * J, w, NWV, lane);
     if (tid < J) sh.ab[tid] = double2{Ab_[tid], Bb_[tid]};
 
-    // u = al v + be x of the rows of this lane's A-operand fragments
-    double alf[NB][4], bef[NB][4];
-#pragma unroll
-    for (int I = 0; I < NB; ++I)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int row = 16 * I + 4 * ks + q;
-            double a = 0.0, bb = 0.0;
-            if (row < R) {
-                const int rm = p.rowmap[row];
-                const int term = rm & 0xfffff;
-                a = Ab_[term];
-                bb = ((rm >> 30) & 1) ? -Bb_[term] : Bb_[term];   // :59-63
-            }
-            alf[I][ks] = a;
-            bef[I][ks] = bb;
+    // u = al v + be x per row (:59-63)
+    if (tid < 64) {
+        double a = 0.0, bb = 0.0;
+        if (tid < R) {
+            const int rm = p.rowmap[tid];
+            const int term = rm & 0xfffff;
+            a = Ab_[term];
+            bb = ((rm >> 30) & 1) ? -Bb_[term] : Bb_[term];
         }
+        sh.albe[tid] = double2{a, bb};
+    }
 
     d4 T[NB];
 #pragma unroll
@@ -283,7 +312,8 @@ __global__ void __launch_bounds__(256, 1) celerite_block_kernel(const ScanParams
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int f = (I * 4 + ks) * 64 + lane;
-                Uf[I][ks] = fma(alf[I][ks], tl[f], bef[I][ks] * tl[NB * 256 + f]);
+                const double2 cf = sh.albe[16 * I + 4 * ks + q];
+                Uf[I][ks] = fma(cf.x, tl[f], cf.y * tl[NB * 256 + f]);
             }
     };
     auto load_vh = [&](int64_t k) __attribute__((always_inline)) {
@@ -316,7 +346,7 @@ __global__ void __launch_bounds__(256, 1) celerite_block_kernel(const ScanParams
         if (w < 3) {
             double* Ad = sh.Ab[k & 1];
             if (pp < 120) {
-                const double2* E = reinterpret_cast<const double2*>(Eb) + pp;
+                const double2* E = reinterpret_cast<const double2*>(Eb + (k & 1) * ebs) + pp;
                 double acc0 = 0.0, acc1 = 0.0;
                 int t = 0;
                 for (; t + 4 <= J; t += 4) {
@@ -357,8 +387,8 @@ __global__ void __launch_bounds__(256, 1) celerite_block_kernel(const ScanParams
     bool nonpd = false;
     PIORAN_BLK_BARRIER();              // every wavefront is done with E(0)
     if (NW > 1) {
-        dma_pieces(btab + RSB, tileb + TSP, TSP / 128, w, lane);
-        dma_pieces(btab + RSB + TSP, Eb, 2 * J, w, lane);
+        dma_pieces(btab + RSB, tileb + TSP, TSP / 128, w, NWV, lane);
+        dma_pieces(btab + RSB + TSP, Eb + ebs, 2 * J, w, NWV, lane);
     }
 
     PIORAN_BSTAMP_DECL
@@ -372,52 +402,59 @@ __global__ void __launch_bounds__(256, 1) celerite_block_kernel(const ScanParams
             for (int I = 0; I < NB; ++I)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[I][ks], T[I][ks], acc, 0, 0, 0);
+            double* mg = sh.MG[w];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                sh.Mt[(4 * g + q) * LDM + 16 * w + c16] = acc[g];
-                x[g] = fma(-ckc, acc[g], vh[g]);
-            }
+            for (int g = 0; g < 4; ++g) mg[(4 * g + q) * 18 + c16] = acc[g];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double mb[4];   // the same block transposed: M [row 16 w + 4 ks + q][step c16], the B operand of U~_w' M_w
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) mb[ks] = mg[c16 * 18 + 4 * ks + q];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) x[g] = fma(-ckc, acc[g], vh[g]);
+            double uw[4];   // U~ fragments of this wavefront's own row block
+            static_for<0, NB>([&](auto Ic) __attribute__((always_inline)) {
+                constexpr int I = decltype(Ic)::value;
+                if (w == I) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) uw[ks] = Uf[I][ks];
+                }
+            });
+            d4 G = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) G = __builtin_amdgcn_mfma_f64_16x16x4f64(uw[ks], mb[ks], G, 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the read-back is complete: the block's storage is reused
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mg[g * 64 + lane] = G[g];
         }
         PIORAN_BSTAMP(1);
         PIORAN_BLK_BARRIER_DMA();   // B1: M' published; record k + 1 has landed
         PIORAN_BSTAMP(2);
         // ---- chain: Sigma = A - U~' M, LDL', L^-1 ---------------------------------------------------------------------
-        double dv[16];
         if (chain) {
-            d4 G = {0.0, 0.0, 0.0, 0.0};
-            double mb[NB][4];
-#pragma unroll
-            for (int I = 0; I < NB; ++I)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) mb[I][ks] = sh.Mt[c16 * LDM + 16 * I + 4 * ks + q];   // M [row 16 I + 4 ks + q][step c16]
             const double* Ad = sh.Ab[k & 1];
-            double av[4];
+            double sg[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) av[g] = Ad[(4 * g + q) * 16 + c16];
+            for (int g = 0; g < 4; ++g) {
+                double gs = sh.MG[0][g * 64 + lane];
 #pragma unroll
-            for (int I = 0; I < NB; ++I)
+                for (int I = 1; I < NB; ++I) gs += sh.MG[I][g * 64 + lane];
+                sg[g] = Ad[(4 * g + q) * 16 + c16] - gs;
+            }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) G = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[I][ks], mb[I][ks], G, 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) sh.Sg[(4 * g + q) * 16 + c16] = av[g] - G[g];
+            for (int g = 0; g < 4; ++g) sh.Sg[(4 * g + q) * 16 + c16] = sg[g];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PIORAN_BSTAMP(3);
-            double col[16], aug[16], rv[16];
+            double m[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                col[j] = sh.Sg[j * 16 + c16];
-                aug[j] = j == c16 ? 1.0 : 0.0;
-            }
+            for (int j = 0; j < 16; ++j) m[j] = sh.Sg[j * 16 + c16];
             PIORAN_BSTAMP(4);
-            static_for<0, 16>([&](auto Pc) __attribute__((always_inline)) { ldl_step<decltype(Pc)::value>(col, aug, dv, rv); });
+            double mult = ldl_first_mult(m, c16);
+            static_for<0, 16>([&](auto Pc) __attribute__((always_inline)) { ldl_step<decltype(Pc)::value>(m, mult, c16); });
             PIORAN_BSTAMP(5);
-            if (q == 0) {
+            if (q == 0) {   // lane n holds column n of L^-1 in m[j], j > n; the rest of m is left-over Sigma (the readers mask it)
+                double2* dst = reinterpret_cast<double2*>(sh.Li + c16 * 18);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) sh.Li[j * 16 + c16] = aug[j];
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) sh.iD[j] = rv[j];
+                for (int j = 0; j < 16; j += 2) dst[j / 2] = double2{m[j], m[j + 1]};
             }
         }
         PIORAN_BSTAMP(6);
@@ -433,31 +470,47 @@ __global__ void __launch_bounds__(256, 1) celerite_block_kernel(const ScanParams
             if (owner && !chain) load_u(k + 1);
             load_vh(k + 1);
         }
-        // record k + 2: tile k (buffer k & 1) has no reader left since barrier 1; the E pieces a wavefront refills are the ones
-        // only it reads (piece 2 t + h = term t, pairs 64 h .. 64 h + 63), just consumed by its own form_A above
-        if (k + 2 < NW) {
-            const double* src = btab + (k + 2) * RSB;
-            if (w < 2) {
-                for (int t = 0; t < J; ++t)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + TSP + (2 * t + w) * 128 + lane * 2),
-                                                     (__attribute__((address_space(3))) void*)(Eb + (2 * t + w) * 128), 16, 0, 0);
-            } else if (w == 2) {
-                for (int c = 0; c < TSP / 128; ++c)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c * 128 + lane * 2),
-                                                     (__attribute__((address_space(3))) void*)(tileb + (k & 1) * TSP + c * 128), 16, 0, 0);
+        // record k + 2: tile k (buffer k & 1) has no reader left since barrier 1.  One E buffer: the E pieces a wavefront refills
+        // are the ones only it reads (piece 2 t + h = term t, pairs 64 h .. 64 h + 63), just consumed by its own form_A above.
+        // Two E buffers: the target held E(k), last read before barrier 2 of window k - 1.
+        const int np_tile = TSP / 128, np_all = np_tile + 2 * J, np_chain = EDBL ? np_all / 4 : 0;
+        auto copy_piece = [&](int c) __attribute__((always_inline)) {
+            const double* src = btab + (k + 2) * RSB + c * 128 + lane * 2;
+            double* dst = c < np_tile ? tileb + (k & 1) * TSP + c * 128 : Eb + (k & 1) * ebs + (c - np_tile) * 128;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        };
+        if (k + 2 < NW && !chain) {
+            if constexpr (EDBL) {
+                // contiguous shares; wavefronts 0 and 1 carry the pair contraction, the others take twice as much
+                const int rest = np_all - np_chain, unit = rest / (NWV == 4 ? 4 : 6);
+                const int lo = np_chain + (w == 0 ? 0 : w == 1 ? unit : w == 2 ? 2 * unit : 4 * unit);
+                const int hi = w == 0 ? np_chain + unit : w == 1 ? np_chain + 2 * unit : (w == 2 && NWV == 5) ? np_chain + 4 * unit : np_all;
+                for (int c = lo; c < hi; ++c) copy_piece(c);
+            } else {
+                if (w < 2) {
+                    for (int t = 0; t < J; ++t) copy_piece(np_tile + 2 * t + w);
+                } else if (w == 2) {
+                    for (int c = 0; c < np_tile; ++c) copy_piece(c);
+                }
             }
         }
         PIORAN_BSTAMP(7);
         PIORAN_BLK_BARRIER();   // B2: L^-1, 1/D published
         PIORAN_BSTAMP(8);
+        if constexpr (EDBL) {
+            if (chain && k + 2 < NW)
+                for (int c = 0; c < np_chain; ++c) copy_piece(c);
+        }
         // ---- Y^' = L^-1 X' --------------------------------------------------------------------------------------------
-        double ysc[4], yown[4];
+        double ysc[4];
         if (owner) {
             double li[4], idv[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                li[ks] = sh.Li[c16 * 16 + 4 * ks + q];
-                idv[ks] = sh.iD[4 * ks + q];
+                const int kk = 4 * ks + q;                             // L^-1 [i = c16][k = kk]: unit lower triangular
+                const double lv = sh.Li[kk * 18 + c16];
+                idv[ks] = recip_f64(sh.Li[kk * 18 + kk]);             // D_n sits on the diagonal (same reciprocal as the chain's)
+                li[ks] = kk < c16 ? lv * idv[ks] : (kk == c16 ? 1.0 : 0.0);   // the column arrives scaled by D_kk
             }
             d4 yt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -465,7 +518,6 @@ __global__ void __launch_bounds__(256, 1) celerite_block_kernel(const ScanParams
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 sh.Yt[(w * 4 + g) * 64 + lane] = yt[g];
-                yown[g] = yt[g];
                 ysc[g] = yt[g] * idv[g];
                 if (w == Jy) quad = fma(yt[g], ysc[g], quad);     // z_n^2 / D_n (== y'K^-1 y, :333)
             }
@@ -479,7 +531,7 @@ __global__ void __launch_bounds__(256, 1) celerite_block_kernel(const ScanParams
 #pragma unroll
             for (int I = 0; I < NB; ++I)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) ya[I][ks] = I == w ? yown[ks] : sh.Yt[(I * 4 + ks) * 64 + lane];
+                for (int ks = 0; ks < 4; ++ks) ya[I][ks] = sh.Yt[(I * 4 + ks) * 64 + lane];
 #pragma unroll
             for (int I = 0; I < NB; ++I)
 #pragma unroll
@@ -488,7 +540,7 @@ __global__ void __launch_bounds__(256, 1) celerite_block_kernel(const ScanParams
         if (chain) {   // off the critical path: log-determinant bookkeeping, U~ of the next window
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const double dj = dv[j];
+                const double dj = sh.Li[j * 18 + j];
                 nonpd |= !(dj > 0.0);
                 Pm *= (k == 0 && j == 0) ? dj : fabs(dj);    // log(D[1]) :126, log(abs(D[n])) :140
                 if ((j & 3) == 3) {
@@ -515,19 +567,34 @@ __global__ void __launch_bounds__(256, 1) celerite_block_kernel(const ScanParams
     }
 }
 
-template <int NB>
-int launch_block(const ScanParams& p, const double* btab, hipStream_t stream)
+constexpr size_t kBlockLdsMax = 160 * 1024;
+__host__ inline size_t block_lds_bytes(int NB, int J, bool edbl)
 {
-    const size_t lds = (size_t)(2 * block_tile_doubles(NB) + 256 * p.J) * sizeof(double) + sizeof(BlockShared);
-    if (lds > 160 * 1024) return PIORAN_ERR_UNSUPPORTED;
+    return (size_t)(2 * block_tile_doubles(NB) + (edbl ? 2 : 1) * 256 * J) * sizeof(double) + sizeof(BlockShared);
+}
+
+template <int NB, bool EDBL>
+int launch_block2(const ScanParams& p, const double* btab, hipStream_t stream)
+{
+    const size_t lds = block_lds_bytes(NB, p.J, EDBL);
     static size_t granted = 0;   // per template instance
     if (lds > granted) {
-        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, EDBL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PIORAN_ERR_HIP;
         granted = lds;
     }
-    hipLaunchKernelGGL((celerite_block_kernel<NB>), dim3((unsigned)p.B), dim3(256), lds, stream, p, btab);
+    hipLaunchKernelGGL((celerite_block_kernel<NB, EDBL>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 320), lds, stream, p, btab);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
+template <int NB>
+int launch_block(const ScanParams& p, const double* btab, hipStream_t stream)
+{
+    // two E buffers only while one workgroup per CU is all there is to run: above 256 draws the smaller footprint lets several
+    // workgroups share a CU, which is worth more (tools/sweep_block.py)
+    if (p.B <= 256 && block_lds_bytes(NB, p.J, true) <= kBlockLdsMax) return launch_block2<NB, true>(p, btab, stream);
+    if (block_lds_bytes(NB, p.J, false) <= kBlockLdsMax) return launch_block2<NB, false>(p, btab, stream);
+    return PIORAN_ERR_UNSUPPORTED;
 }
 
 }  // namespace
@@ -545,7 +612,7 @@ int pioran_block_fits(int32_t R, int32_t J)
 {
     const int NB = (R + 1 + 15) / 16;
     if (R < 1 || NB > 4 || J < 1 || J > kBlockMaxTerms) return 0;
-    return (size_t)(2 * block_tile_doubles(NB) + 256 * J) * sizeof(double) + sizeof(BlockShared) <= 160 * 1024;
+    return block_lds_bytes(NB, J, false) <= kBlockLdsMax;
 }
 
 int pioran_launch_block_table(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,

@@ -289,6 +289,7 @@ def test_drwcelerite_block_layout(ctx):
     name = lambda: pj._lib.lib().pioran_celerite_config_name(0).decode()
     for ncomp, expect in ((20, "rpl4_cbr4_nsrc4_b5a"), (12, "rpl3_cbr2_nsrc7")):
         A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, ncomp, "DRWCelerite")
+        ctx.set_option("no_block", True)   # 300 draws would take the windowed kernel: this test is about the throughput layouts
         got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
         assert name() == expect, name()
         ref, rst = O.logl_batch(A, Bc, C, Dd, t, y, yerr ** 2, mu, nu, nthreads=8, return_status=True)
@@ -300,6 +301,7 @@ def test_drwcelerite_block_layout(ctx):
             assert not name().startswith("rpl4_cbr4_nsrc4_b5")
         finally:
             ctx.set_option("no_paired", False)
+            ctx.set_option("no_block", False)
         assert relerr(got[ok], plain[ok]) < 1e-9   # different row order => different summation order of q
 
 
