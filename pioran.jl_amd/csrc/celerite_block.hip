@@ -226,6 +226,7 @@ struct BlockShared {                // exchanges between the wavefronts of a wor
     double fin[8];
     double2 ab[64];                 // (a_t, b_t) of this draw
     double2 albe[64];               // per row: u = al v + be x
+    double ys[2][32];               // per-draw series: (y_n, sigma2_n) of window k in ys[k & 1][0..15 | 16..31]
 };
 constexpr int kBlockMaxTerms = 64;
 
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
                 double v = tl[2 * NB * 256 + (w * 4 + g) * 64 + lane];
                 if (ycol) {
                     const int64_t n = k * KW + 4 * g + q;
-                    if (p.Y) v = n < N ? p.Y[b * N + n] : 0.0;
+                    if (p.Y) v = sh.ys[k & 1][4 * g + q];
                     v = n < N ? v - mu : 0.0;              // z_n = y_n - u'f   :141
                 }
                 vh[g] = v;
@@ -369,7 +370,7 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
                 const int64_t n = k * KW + s;
                 double v = 1.0;
                 if (n < N) {
-                    const double s2n = p.S2 ? p.S2[b * N + n] : tileb[(k & 1) * TSP + 3 * NB * 256 + 16 * NB + s];
+                    const double s2n = p.S2 ? sh.ys[k & 1][16 + s] : tileb[(k & 1) * TSP + 3 * NB * 256 + 16 * NB + s];
                     v = suma + (has_nu ? nu * s2n : s2n);    // :92
                 }
                 Ad[s * 16 + s] = v;
@@ -377,6 +378,17 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
         }
     };
 
+    // per-draw series (y, sigma2) [B][N]: window k + 2 is fetched by wavefront 2 while the chain of window k runs and staged in
+    // LDS (a plain global load consumed on the critical path would wait for the LDS DMAs issued after it as well)
+    auto stage_series = [&](int64_t k) __attribute__((always_inline)) {
+        if (p.Y && w == 2 && lane < 32) {
+            const int64_t n = k * KW + (lane & 15);
+            const double* src = lane < 16 ? p.Y : p.S2;
+            sh.ys[k & 1][lane] = n < N ? src[b * N + n] : 0.0;
+        }
+    };
+    stage_series(0);
+    if (NW > 1) stage_series(1);
     PIORAN_BLK_BARRIER_DMA();          // record 0 has landed
     if (has_u) load_u(0);
     load_vh(0);
@@ -470,6 +482,7 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
             if (owner && !chain) load_u(k + 1);
             load_vh(k + 1);
         }
+        if (k + 2 < NW) stage_series(k + 2);   // slot k & 1: window k's values were consumed before barrier 2 of window k - 1
         // record k + 2: tile k (buffer k & 1) has no reader left since barrier 1.  One E buffer: the E pieces a wavefront refills
         // are the ones only it reads (piece 2 t + h = term t, pairs 64 h .. 64 h + 63), just consumed by its own form_A above.
         // Two E buffers: the target held E(k), last read before barrier 2 of window k - 1.
