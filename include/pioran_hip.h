@@ -65,11 +65,14 @@ int pioran_ctx_synchronize(pioran_ctx* ctx);
  * re-allocated on demand.  Data sets and their tables are not touched. */
 int pioran_ctx_trim(pioran_ctx* ctx);
 /* Diagnostic switches (none is needed in production; tests and tuning runs use them to pin a code path):
- *   "scan_config"     name of a throughput configuration of the scan, or "wide" = latency layout for any batch; NULL/"" = automatic
- *   "no_wide" / "no_paired" / "no_mixed" / "force_fallback"   value "1" disables the latency layout / the column-paired
- *                     variants / the mixed shared+per-draw table / sends everything through the any-rank kernel; NULL, "" or "0" = off.
- * Initial values come from the environment variables PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_PAIRED, PIORAN_NO_MIXED,
- * PIORAN_FORCE_FALLBACK, read once when the context is created. */
+ *   "scan_config"     name of a throughput configuration of the scan, "wide" = latency layout or "block" = windowed kernel for
+ *                     any batch; NULL/"" = automatic
+ *   "no_wide" / "no_block" / "no_paired" / "no_mixed" / "force_fallback"   value "1" disables the latency layout / the windowed
+ *                     small-batch kernel / the column-paired variants / the mixed shared+per-draw table / sends everything through
+ *                     the any-rank kernel; NULL, "" or "0" = off.
+ *   "win2" / "no_win2"  force / forbid the two-step form of the throughput layouts (default: on up to three rows per lane)
+ * Initial values come from the environment variables PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_BLOCK, PIORAN_NO_PAIRED,
+ * PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK, PIORAN_WIN2, PIORAN_NO_WIN2, read once when the context is created. */
 int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value);
 /* hipEvent-based timing on the ctx stream: record slot i (0..11), elapsed between two slots. */
 int pioran_ctx_event_record(pioran_ctx* ctx, int slot);

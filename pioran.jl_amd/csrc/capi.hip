@@ -312,6 +312,8 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "no_mixed")) o.no_mixed = on;
     else if (!std::strcmp(key, "force_fallback")) o.force_fallback = on;
     else if (!std::strcmp(key, "no_block")) o.no_block = on;
+    else if (!std::strcmp(key, "win2")) o.win2 = on;
+    else if (!std::strcmp(key, "no_win2")) o.no_win2 = on;
     else return PIORAN_ERR_ARG;
     return PIORAN_OK;
 }
@@ -332,6 +334,8 @@ static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
     pioran_ctx_set_option(ctx, "no_mixed", std::getenv("PIORAN_NO_MIXED"));
     pioran_ctx_set_option(ctx, "force_fallback", std::getenv("PIORAN_FORCE_FALLBACK"));
     pioran_ctx_set_option(ctx, "no_block", std::getenv("PIORAN_NO_BLOCK"));
+    pioran_ctx_set_option(ctx, "win2", std::getenv("PIORAN_WIN2"));
+    pioran_ctx_set_option(ctx, "no_win2", std::getenv("PIORAN_NO_WIN2"));
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
     if (own) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }

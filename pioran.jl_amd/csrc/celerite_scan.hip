@@ -315,6 +315,237 @@ struct PairSecond<5, N> {
                      : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]), [p3] "v"(pp[3]), [p4] "v"(pp[4]), [ws] "v"(ws), [us] "v"(us), [n] "i"(N));
     }
 };
+// ---- GENERATED by tools/gen_scan_win2.py: column blocks of the two-step form (do not edit by hand) ----
+template <int RPL, int N> struct MatVec2;
+template <int RPL, int N> struct Update2;
+template <int RPL, int N> struct Update2First;
+template <int RPL, int N> struct Update2Second;
+template <int N>
+struct MatVec2<1, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k) for one column k of this lane's rows
+    static __device__ __forceinline__ void run(const double (&T)[1], double (&rA)[1], double (&rB)[1], double ua, double ub)
+    {
+        asm volatile("s_nop 1\n\t" PD_FMAC(a0, ua, t0) PD_FMAC(b0, ub, t0)
+                     : [a0] "+v"(rA[0]), [b0] "+v"(rB[0])
+                     : [t0] "v"(T[0]), [ua] "v"(ua), [ub] "v"(ub), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2<1, N> {   // T = (phAB_i bcast(phAB_k)) T + hA_i bcast(wA_k) + mB_i bcast(wB_k)
+    static __device__ __forceinline__ void run(double (&T)[1], const double (&hA)[1], const double (&mB)[1], const double (&ph)[1],
+                                               double wa, double wb, double phs)
+    {
+        double pk, pp[1];
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(t0, p0, t0) PD_FMAC(t0, wa, g0) PD_FMAC(t0, wb, m0)
+                     : [t0] "+v"(T[0]), [pk] "=&v"(pk), [p0] "=&v"(pp[0])
+                     : [g0] "v"(hA[0]), [m0] "v"(mB[0]), [h0] "v"(ph[0]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2First<1, N> {   // first column of a (cos, sin) pair: also hands phAB_i phAB_k to the second
+    static __device__ __forceinline__ void run(double (&T)[1], const double (&hA)[1], const double (&mB)[1], const double (&ph)[1],
+                                               double wa, double wb, double phs, double (&pp)[1])
+    {
+        double pk;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(t0, p0, t0) PD_FMAC(t0, wa, g0) PD_FMAC(t0, wb, m0)
+                     : [t0] "+v"(T[0]), [pk] "=&v"(pk), [p0] "=&v"(pp[0])
+                     : [g0] "v"(hA[0]), [m0] "v"(mB[0]), [h0] "v"(ph[0]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2Second<1, N> {
+    static __device__ __forceinline__ void run(double (&T)[1], const double (&hA)[1], const double (&mB)[1], double wa, double wb,
+                                               const double (&pp)[1])
+    {
+        asm volatile("s_nop 1\n\t" PD_MUL(t0, p0, t0) PD_FMAC(t0, wa, g0) PD_FMAC(t0, wb, m0)
+                     : [t0] "+v"(T[0])
+                     : [g0] "v"(hA[0]), [m0] "v"(mB[0]), [p0] "v"(pp[0]), [wa] "v"(wa), [wb] "v"(wb), [n] "i"(N));
+    }
+};
+template <int N>
+struct MatVec2<2, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k) for one column k of this lane's rows
+    static __device__ __forceinline__ void run(const double (&T)[2], double (&rA)[2], double (&rB)[2], double ua, double ub)
+    {
+        asm volatile("s_nop 1\n\t" PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1)
+                     : [a0] "+v"(rA[0]), [a1] "+v"(rA[1]), [b0] "+v"(rB[0]), [b1] "+v"(rB[1])
+                     : [t0] "v"(T[0]), [t1] "v"(T[1]), [ua] "v"(ua), [ub] "v"(ub), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2<2, N> {   // T = (phAB_i bcast(phAB_k)) T + hA_i bcast(wA_k) + mB_i bcast(wB_k)
+    static __device__ __forceinline__ void run(double (&T)[2], const double (&hA)[2], const double (&mB)[2], const double (&ph)[2],
+                                               double wa, double wb, double phs)
+    {
+        double pk, pp[2];
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2First<2, N> {   // first column of a (cos, sin) pair: also hands phAB_i phAB_k to the second
+    static __device__ __forceinline__ void run(double (&T)[2], const double (&hA)[2], const double (&mB)[2], const double (&ph)[2],
+                                               double wa, double wb, double phs, double (&pp)[2])
+    {
+        double pk;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2Second<2, N> {
+    static __device__ __forceinline__ void run(double (&T)[2], const double (&hA)[2], const double (&mB)[2], double wa, double wb,
+                                               const double (&pp)[2])
+    {
+        asm volatile("s_nop 1\n\t" PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [wa] "v"(wa), [wb] "v"(wb), [n] "i"(N));
+    }
+};
+template <int N>
+struct MatVec2<3, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k) for one column k of this lane's rows
+    static __device__ __forceinline__ void run(const double (&T)[3], double (&rA)[3], double (&rB)[3], double ua, double ub)
+    {
+        asm volatile("s_nop 1\n\t" PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(a2, ua, t2) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1) PD_FMAC(b2, ub, t2)
+                     : [a0] "+v"(rA[0]), [a1] "+v"(rA[1]), [a2] "+v"(rA[2]), [b0] "+v"(rB[0]), [b1] "+v"(rB[1]), [b2] "+v"(rB[2])
+                     : [t0] "v"(T[0]), [t1] "v"(T[1]), [t2] "v"(T[2]), [ua] "v"(ua), [ub] "v"(ub), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2<3, N> {   // T = (phAB_i bcast(phAB_k)) T + hA_i bcast(wA_k) + mB_i bcast(wB_k)
+    static __device__ __forceinline__ void run(double (&T)[3], const double (&hA)[3], const double (&mB)[3], const double (&ph)[3],
+                                               double wa, double wb, double phs)
+    {
+        double pk, pp[3];
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2First<3, N> {   // first column of a (cos, sin) pair: also hands phAB_i phAB_k to the second
+    static __device__ __forceinline__ void run(double (&T)[3], const double (&hA)[3], const double (&mB)[3], const double (&ph)[3],
+                                               double wa, double wb, double phs, double (&pp)[3])
+    {
+        double pk;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2Second<3, N> {
+    static __device__ __forceinline__ void run(double (&T)[3], const double (&hA)[3], const double (&mB)[3], double wa, double wb,
+                                               const double (&pp)[3])
+    {
+        asm volatile("s_nop 1\n\t" PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]), [wa] "v"(wa), [wb] "v"(wb), [n] "i"(N));
+    }
+};
+template <int N>
+struct MatVec2<4, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k) for one column k of this lane's rows
+    static __device__ __forceinline__ void run(const double (&T)[4], double (&rA)[4], double (&rB)[4], double ua, double ub)
+    {
+        asm volatile("s_nop 1\n\t" PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(a2, ua, t2) PD_FMAC(a3, ua, t3) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1) PD_FMAC(b2, ub, t2) PD_FMAC(b3, ub, t3)
+                     : [a0] "+v"(rA[0]), [a1] "+v"(rA[1]), [a2] "+v"(rA[2]), [a3] "+v"(rA[3]), [b0] "+v"(rB[0]), [b1] "+v"(rB[1]), [b2] "+v"(rB[2]), [b3] "+v"(rB[3])
+                     : [t0] "v"(T[0]), [t1] "v"(T[1]), [t2] "v"(T[2]), [t3] "v"(T[3]), [ua] "v"(ua), [ub] "v"(ub), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2<4, N> {   // T = (phAB_i bcast(phAB_k)) T + hA_i bcast(wA_k) + mB_i bcast(wB_k)
+    static __device__ __forceinline__ void run(double (&T)[4], const double (&hA)[4], const double (&mB)[4], const double (&ph)[4],
+                                               double wa, double wb, double phs)
+    {
+        double pk, pp[4];
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2]), [p3] "=&v"(pp[3])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [h3] "v"(ph[3]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2First<4, N> {   // first column of a (cos, sin) pair: also hands phAB_i phAB_k to the second
+    static __device__ __forceinline__ void run(double (&T)[4], const double (&hA)[4], const double (&mB)[4], const double (&ph)[4],
+                                               double wa, double wb, double phs, double (&pp)[4])
+    {
+        double pk;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2]), [p3] "=&v"(pp[3])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [h3] "v"(ph[3]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2Second<4, N> {
+    static __device__ __forceinline__ void run(double (&T)[4], const double (&hA)[4], const double (&mB)[4], double wa, double wb,
+                                               const double (&pp)[4])
+    {
+        asm volatile("s_nop 1\n\t" PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]), [p3] "v"(pp[3]), [wa] "v"(wa), [wb] "v"(wb), [n] "i"(N));
+    }
+};
+template <int N>
+struct MatVec2<5, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k) for one column k of this lane's rows
+    static __device__ __forceinline__ void run(const double (&T)[5], double (&rA)[5], double (&rB)[5], double ua, double ub)
+    {
+        asm volatile("s_nop 1\n\t" PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(a2, ua, t2) PD_FMAC(a3, ua, t3) PD_FMAC(a4, ua, t4) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1) PD_FMAC(b2, ub, t2) PD_FMAC(b3, ub, t3) PD_FMAC(b4, ub, t4)
+                     : [a0] "+v"(rA[0]), [a1] "+v"(rA[1]), [a2] "+v"(rA[2]), [a3] "+v"(rA[3]), [a4] "+v"(rA[4]), [b0] "+v"(rB[0]), [b1] "+v"(rB[1]), [b2] "+v"(rB[2]), [b3] "+v"(rB[3]), [b4] "+v"(rB[4])
+                     : [t0] "v"(T[0]), [t1] "v"(T[1]), [t2] "v"(T[2]), [t3] "v"(T[3]), [t4] "v"(T[4]), [ua] "v"(ua), [ub] "v"(ub), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2<5, N> {   // T = (phAB_i bcast(phAB_k)) T + hA_i bcast(wA_k) + mB_i bcast(wB_k)
+    static __device__ __forceinline__ void run(double (&T)[5], const double (&hA)[5], const double (&mB)[5], const double (&ph)[5],
+                                               double wa, double wb, double phs)
+    {
+        double pk, pp[5];
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk) PD_MUL(p4, h4, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_MUL(t4, p4, t4) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t4, wa, g4) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3) PD_FMAC(t4, wb, m4)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2]), [p3] "=&v"(pp[3]), [p4] "=&v"(pp[4])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [g4] "v"(hA[4]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [m4] "v"(mB[4]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [h3] "v"(ph[3]), [h4] "v"(ph[4]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2First<5, N> {   // first column of a (cos, sin) pair: also hands phAB_i phAB_k to the second
+    static __device__ __forceinline__ void run(double (&T)[5], const double (&hA)[5], const double (&mB)[5], const double (&ph)[5],
+                                               double wa, double wb, double phs, double (&pp)[5])
+    {
+        double pk;
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk) PD_MUL(p4, h4, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_MUL(t4, p4, t4) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t4, wa, g4) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3) PD_FMAC(t4, wb, m4)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2]), [p3] "=&v"(pp[3]), [p4] "=&v"(pp[4])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [g4] "v"(hA[4]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [m4] "v"(mB[4]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [h3] "v"(ph[3]), [h4] "v"(ph[4]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update2Second<5, N> {
+    static __device__ __forceinline__ void run(double (&T)[5], const double (&hA)[5], const double (&mB)[5], double wa, double wb,
+                                               const double (&pp)[5])
+    {
+        asm volatile("s_nop 1\n\t" PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_MUL(t4, p4, t4) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t4, wa, g4) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3) PD_FMAC(t4, wb, m4)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [g4] "v"(hA[4]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [m4] "v"(mB[4]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]), [p3] "v"(pp[3]), [p4] "v"(pp[4]), [wa] "v"(wa), [wb] "v"(wb), [n] "i"(N));
+    }
+};
+// ---- END GENERATED ----
 #undef PD_FMAC
 #undef PD_MUL
 
@@ -403,7 +634,8 @@ struct StepIn {           // what one time step reads: per own row (v, x, phi) +
 // ones, src/psd.jl:264-275): every DPP row's block of RB slots holds NPB column PAIRS (rows of NPB complex terms), then
 // RB - 1 - 2 NPB single rows (real terms), then one spare slot (padding; the y row in the last block).  All blocks
 // look alike, so the phi_i phi_k product of a pair is formed once per pair in every DPP row of the wavefront.
-template <int RPL, int CBR, int NSRC, bool SHARED_TAB, int MINW = 1, bool PAIRED = false, bool MIXED = false, int NPB = 0>
+// WIN2: the two-step form (below, after the slot set-up) instead of the step-by-step recurrence.
+template <int RPL, int CBR, int NSRC, bool SHARED_TAB, int MINW = 1, bool PAIRED = false, bool MIXED = false, int NPB = 0, bool WIN2 = false>
 __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanParams p)
 {
     static_assert(NPB == 0 || (!PAIRED && 2 * NPB < NSRC * RPL && RPL % 2 == 0),
@@ -416,8 +648,9 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     constexpr int YS = RPL - 1;
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int e = lane / G;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // known to be wave-uniform: with one draw per wavefront
+                                                                         // (CBR = 4) mu, nu, sum(a) then live in SGPRs
+    const int e = EPW == 1 ? 0 : lane / G;
     const int r = (lane % G) >> 4;           // DPP row inside the draw = column block
     const int l = lane & 15;
     const int lam = (l + NSRC * r) & 15;     // logical lane: which rows this lane owns
@@ -546,6 +779,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 
     auto load_step = [&](int64_t n, StepIn<RPL>& in) {
         if constexpr (SHARED_TAB) {
+            if constexpr (WIN2) n = n < N ? n : N;   // the table holds N + 1 records
             const int soff = (int)n * step_bytes;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
@@ -558,9 +792,16 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                     in.ph[i] = buf_load_f64(rs, vo_v[i], soff + 2 * Rp * 8);
                 }
             }
-            const int ysoff = (int)n * y_step;
-            in.y = buf_load_f64(rs_y, vo_y, ysoff);
-            in.s2 = buf_load_f64(rs_s, vo_s, ysoff);
+            if constexpr (WIN2 && EPW == 1) {
+                // one draw per wavefront: y_n, sigma2_n are wave-uniform -> scalar loads, no vector registers
+                const int64_t ny = own_series ? (n < N ? n : N - 1) : n;
+                in.y = own_series ? p.Y[b * N + ny] : p.tab[ny * p.rec_stride + 3 * Rp];
+                in.s2 = own_series ? p.S2[b * N + ny] : p.tab[ny * p.rec_stride + 3 * Rp + 1];
+            } else {
+                const int ysoff = (int)n * y_step;
+                in.y = buf_load_f64(rs_y, vo_y, ysoff);
+                in.s2 = buf_load_f64(rs_s, vo_s, ysoff);
+            }
         } else {
             const int64_t nn = n < N ? n : N - 1;
             const double tn = p.t[nn];
@@ -583,6 +824,162 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             in.s2 = sv[nn];
         }
     };
+
+
+    // ---- two-step form --------------------------------------------------------------------------------------------------
+    // State T = S_m + D_m w_m w_m' (time-m coordinates).  Steps A = m + 1 and B = m + 2 are taken together:
+    //   u~A = phA o uA,  u~B = phA phB o uB;   rA = T u~A,  rB = T u~B            one pass over T, two FMAs per entry
+    //   D_A = dA - u~A'rA;   mA = vA - phA o rA;   hA = phB o mA;   g = hA'uB
+    //   D_B = dB - u~B'rB - g^2 / D_A;   mB = vB - phAB o rB - hA g / D_A
+    //   T  <- (phAB phAB') o T + hA hA' / D_A + mB mB' / D_B                       one scaling per entry and PAIR of steps
+    // i.e. 5.5 instead of 7 instructions per entry and two steps (the Hadamard scaling by phi phi', which the step-by-step
+    // form applies every step, :78-79,85, is applied once per pair), one more row reduction (g).  Same D_n, z_n as the
+    // reference up to rounding; T = 0 before the first step, so there is no special first row; a series of odd length
+    // starts with the pair (void, step 0).
+    if constexpr (WIN2) {
+        double T[NC][RPL];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) T[c][i] = 0.0;
+        // RPL >= 4: the row coefficients (al, be) wait in LDS (lane-private slots) instead of 4 RPL registers
+        constexpr bool COEF_LDS = RPL >= 4;
+        __shared__ double sh_coef[COEF_LDS ? 2 * RPL * 256 : 1];
+        if constexpr (COEF_LDS) {
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) { sh_coef[(2 * i) * 256 + threadIdx.x] = al[i]; sh_coef[(2 * i + 1) * 256 + threadIdx.x] = be[i]; }
+        }
+        double one = 1.0;
+        asm volatile("" : "+v"(one));
+        [[maybe_unused]] const double ysel = isy ? 1.0 : 0.0;
+        double Pm = 1.0, quad = 0.0;
+        int Pe = 0;
+        bool nonpd = false;
+        StepIn<RPL> sa, sb;
+        // VOIDA: step A does not exist (D = 1, m = 0, no contribution); FIRST: step A is the first of the series (log D_1, :126)
+        auto pair = [&](int64_t nA, auto voidc, auto firstc) __attribute__((always_inline)) {
+            constexpr bool VOIDA = decltype(voidc)::value, FIRST = decltype(firstc)::value;
+            double uB[RPL], tA[RPL], tB[RPL], pAB[RPL], rA[RPL], rB[RPL];
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                double ali = al[i], bei = be[i];
+                if constexpr (COEF_LDS) { ali = sh_coef[(2 * i) * 256 + threadIdx.x]; bei = sh_coef[(2 * i + 1) * 256 + threadIdx.x]; }
+                const double uA = ali * sa.v[i] + bei * sa.x[i];
+                uB[i] = ali * sb.v[i] + bei * sb.x[i];
+                pAB[i] = sa.ph[i] * sb.ph[i];
+                tA[i] = sa.ph[i] * uA;
+                tB[i] = pAB[i] * uB[i];
+                rA[i] = 0.0;
+                rB[i] = 0.0;
+            }
+            if constexpr (COEF_LDS) {   // (register-starved shapes: a select on the lane mask instead of the multiplier ysel)
+                sa.v[YS] = isy ? sa.y - mu : sa.v[YS];
+                sb.v[YS] = isy ? sb.y - mu : sb.v[YS];
+            } else {
+                sa.v[YS] = fma(ysel, sa.y - mu, sa.v[YS]);
+                sb.v[YS] = fma(ysel, sb.y - mu, sb.v[YS]);
+            }
+            static_for<0, NC>([&](auto Cc) {
+                constexpr int c = decltype(Cc)::value;
+                MatVec2<RPL, c / RPL>::run(T[c], rA, rB, tA[c % RPL], tB[c % RPL]);
+            });
+            if constexpr (CBR >= 2) {
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) { rA[i] += lane_fetch(rA[i], p1); rB[i] += lane_fetch(rB[i], p1); }
+            }
+            if constexpr (CBR >= 4) {
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) { rA[i] += lane_fetch(rA[i], p2); rB[i] += lane_fetch(rB[i], p2); }
+            }
+            double spA = 0.0, spB = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) { spA += tA[i] * rA[i]; spB += tB[i] * rB[i]; }
+            const double sA = group_sum<CBR, NSRC>(spA, contributes, one, p1, p2);
+            const double sB = group_sum<CBR, NSRC>(spB, contributes, one, p1, p2);
+            const double DA = VOIDA ? 1.0 : fma(nu, sa.s2, suma) - sA;                  // :92
+            const double rDA = recip_f64(DA);
+            double hA[RPL], mB[RPL], wA[RPL], wB[RPL], spg = 0.0;
+            double zA = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const double mA = VOIDA ? 0.0 : fma(-sa.ph[i], rA[i], sa.v[i]);        // v - q      :89
+                if (i == YS) zA = mA;
+                hA[i] = sb.ph[i] * mA;
+                spg = fma(hA[i], uB[i], spg);
+            }
+            load_step(nA + 2, sa);                                                       // step A's record is consumed
+            const double g = group_sum<CBR, NSRC>(spg, contributes, one, p1, p2);
+            const double gr = g * rDA;
+            const double DB = fma(nu, sb.s2, suma) - sB - g * gr;
+            const double rDB = recip_f64(DB);
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                mB[i] = fma(-hA[i], gr, fma(-pAB[i], rB[i], sb.v[i]));
+                wA[i] = hA[i] * rDA;
+                wB[i] = mB[i] * rDB;
+            }
+            load_step(nA + 3, sb);
+            const double zB = mB[YS];                                                    // y row: z_n = y_n - u'f      :141
+            nonpd |= !(DA > 0.0) | !(DB > 0.0);
+            Pm *= (FIRST ? DA : fabs(DA)) * ((VOIDA && FIRST) ? DB : fabs(DB));          // log(D[1]) :126, log(abs(D[n])) :140
+            {
+                int ex;
+                Pm = frexp(Pm, &ex);
+                Pe += ex;
+            }
+            quad = fma(zB * zB, rDB, fma(zA * zA, rDA, quad));                           // z_n^2 / D_n  (== y'K^-1 y, :333)
+            // ---- T <- (phAB phAB') o T + hA wA' + mB wB' ----
+            if constexpr (NPB > 0) {
+                static_for<0, NPB>([&](auto Pc) {
+                    constexpr int c = 2 * decltype(Pc)::value;
+                    double pp[RPL];
+                    Update2First<RPL, c / RPL>::run(T[c], hA, mB, pAB, wA[c % RPL], wB[c % RPL], pAB[c % RPL], pp);
+                    Update2Second<RPL, (c + 1) / RPL>::run(T[c + 1], hA, mB, wA[(c + 1) % RPL], wB[(c + 1) % RPL], pp);
+                });
+                static_for<2 * NPB, NC>([&](auto Cc) {
+                    constexpr int c = decltype(Cc)::value;
+                    Update2<RPL, c / RPL>::run(T[c], hA, mB, pAB, wA[c % RPL], wB[c % RPL], pAB[c % RPL]);
+                });
+            } else if constexpr (PAIRED) {
+                static_for<0, NC / 2>([&](auto Pc) {
+                    constexpr int c = 2 * decltype(Pc)::value;
+                    double pp[RPL];
+                    Update2First<RPL, c / RPL>::run(T[c], hA, mB, pAB, wA[c % RPL], wB[c % RPL], pAB[c % RPL], pp);
+                    Update2Second<RPL, (c + 1) / RPL>::run(T[c + 1], hA, mB, wA[(c + 1) % RPL], wB[(c + 1) % RPL], pp);
+                });
+                if constexpr (NC & 1)
+                    Update2<RPL, (NC - 1) / RPL>::run(T[NC - 1], hA, mB, pAB, wA[(NC - 1) % RPL], wB[(NC - 1) % RPL], pAB[(NC - 1) % RPL]);
+            } else {
+                static_for<0, NC>([&](auto Cc) {
+                    constexpr int c = decltype(Cc)::value;
+                    Update2<RPL, c / RPL>::run(T[c], hA, mB, pAB, wA[c % RPL], wB[c % RPL], pAB[c % RPL]);
+                });
+            }
+        };
+        int64_t n;
+        if (N & 1) {   // (void, step 0), then (1, 2), (3, 4), ...
+            load_step(0, sb);
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) { sa.v[i] = 0.0; sa.x[i] = 0.0; sa.ph[i] = 1.0; }
+            sa.y = mu;
+            sa.s2 = 0.0;
+            pair(-1, std::true_type{}, std::true_type{});
+            n = 1;
+        } else {       // (0, 1), (2, 3), ...
+            load_step(0, sa);
+            load_step(1, sb);
+            pair(0, std::false_type{}, std::true_type{});
+            n = 2;
+        }
+        for (; n + 1 < N; n += 2) pair(n, std::false_type{}, std::false_type{});
+        if (active && isy && r == 0) {
+            const double logdet = log(Pm) + (double)Pe * 0.6931471805599453094;
+            const double res = -0.5 * logdet - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * quad;
+            p.out[b] = res;
+            if (p.status) p.status[b] = !isfinite(res) ? 2 : (nonpd ? 1 : 0);
+        }
+        return;
+    }
 
     StepIn<RPL> bufA, bufB;
     load_step(0, bufA);
@@ -711,6 +1108,17 @@ using LaunchFn = void (*)(const ScanParams&, dim3, hipStream_t);
 template <int RPL, int CBR, int NSRC, int MINW = 1, bool PAIRED = false>
 void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 {
+    // two-step form: faster wherever its working set fits the register file (RPL <= 3: +10 .. 24 %, tools/sweep_win2.py); with
+    // RPL >= 4 it spills inside the loop and loses 10 %, so there it runs only when forced (context option "win2")
+    if ((RPL <= 3 && !(p.opt && p.opt->no_win2)) || (p.opt && p.opt->win2)) {
+        if (p.tab && p.npd_rows > 0)
+            hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, true, 0, true>), grid, dim3(256), 0, st, p);
+        else if (p.tab)
+            hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true>), grid, dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false, MINW, PAIRED, false, 0, true>), grid, dim3(256), 0, st, p);
+        return;
+    }
     if (p.tab && p.npd_rows > 0)
         hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, true>), grid, dim3(256), 0, st, p);
     else if (p.tab)
@@ -723,7 +1131,10 @@ void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 template <int RPL, int CBR, int NSRC, int MINW, int NPB>
 void launch_blocked(const ScanParams& p, dim3 grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB>), grid, dim3(256), 0, st, p);
+    if (p.opt && p.opt->win2)
+        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB, true>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB>), grid, dim3(256), 0, st, p);
 }
 
 struct ScanConfig {

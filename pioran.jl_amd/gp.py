@@ -61,8 +61,9 @@ class Context:
         _lib.check(_lib.lib().pioran_ctx_trim(self._h), self._h)
 
     def set_option(self, key: str, value=None):
-        """Diagnostic switch of this context (pioran_ctx_set_option): "scan_config" (a configuration name, "wide", or
-        None), "no_wide" / "no_paired" / "no_mixed" / "force_fallback" (truthy = on).  Tests and tuning tools only."""
+        """Diagnostic switch of this context (pioran_ctx_set_option): "scan_config" (a configuration name, "wide", "block" or
+        None), "no_wide" / "no_block" / "no_paired" / "no_mixed" / "force_fallback" / "win2" / "no_win2" (truthy = on).
+        Tests and tuning tools only."""
         if value is None or value is False:
             v = None
         elif value is True:

@@ -103,18 +103,23 @@ def _random_case(rng, N, J, B, per_draw_cd=False):
     return t, y, s2, A, Bc, C, Dd, mu, nu
 
 
-@pytest.fixture(params=["throughput", "latency", "block"])
+@pytest.fixture(params=["throughput", "throughput_steps", "throughput_pairs", "latency", "block"])
 def layout(request, ctx):
-    """Small batches (B <= 256) with 16 <= R <= 63 rows take the windowed kernel (celerite_block.hip) by default; "no_block" sends
+    """Small batches (B <= 512) with 6 <= R <= 63 rows take the windowed kernel (celerite_block.hip) by default; "no_block" sends
     them to the one-draw-per-workgroup latency layout (celerite_wide.hip), "no_wide" as well to the throughput layouts (the ones
-    large batches use): all three are checked on the same inputs."""
+    large batches use).  The throughput layouts run the two-step form up to three rows per lane and the step-by-step recurrence
+    above ("no_win2" / "win2" force either everywhere).  All are checked on the same inputs."""
     if request.param != "block":
         ctx.set_option("no_block", True)
-    if request.param == "throughput":
+    if request.param.startswith("throughput"):
         ctx.set_option("no_wide", True)
+    if request.param == "throughput_steps":
+        ctx.set_option("no_win2", True)
+    if request.param == "throughput_pairs":
+        ctx.set_option("win2", True)
     yield request.param
-    ctx.set_option("no_wide", False)
-    ctx.set_option("no_block", False)
+    for k in ("no_wide", "no_block", "no_win2", "win2"):
+        ctx.set_option(k, False)
 
 
 @pytest.mark.parametrize("J", [1, 2, 3, 5, 8, 10, 13, 16, 20, 21, 24, 27, 32, 40])
