@@ -244,11 +244,13 @@ def main():
                      "kernel": "celerite_scan_kernel", "kernel_ms": kern_ms, "scan_source_hash": scan_source_hash(),
                      "algorithmic_flop_per_eval": algorithmic_flops(N, R), "rows_executed": R, "rows_reference": 2 * Jt,
                      "frac_on_reference_rows": achieved_ref_rows / FP64_PEAK_TFLOPS,
-                     "note": "FP64 vector-ALU bound (rank-1 update + matvec per draw; not HBM, not MFMA). peak = "
-                             "MI355X FP64 vector peak (at 2.4 GHz), numerically equal to the dense FP64 MFMA peak. Budget "
-                             "(DESIGN.md 4.1; profiles/r02_pmc_*.json, profiles/r02_valu_probe.txt): the vector ALU issues one DP "
-                             "instruction per ~4.6 cycles at two wavefronts per SIMD, the clock sustains ~1.9 GHz of 2.4 under "
-                             "chip-wide FP64 issue, 1.40 flop per lane-instruction, full (not triangular) S."},
+                     "note": "FP64 vector-ALU bound (per draw: two matrix-vector products and a rank-2 update of the R x R state per "
+                             "pair of time steps; not HBM). peak = MI355X FP64 vector peak (at 2.4 GHz) = the dense FP64 MFMA peak: "
+                             "on gfx950 the fp64 matrix instructions run on the DP vector pipe (tools/mfma_probe.hip, "
+                             "profiles/r02_mfma_probe.txt), so there is no second pipe to overlap with. Budget (DESIGN.md 4.1; "
+                             "profiles/r02_pmc_*.json, profiles/r02_valu_probe.txt): one DP instruction per ~4.6 cycles at two "
+                             "wavefronts per SIMD, ~1.9 GHz of 2.4 under chip-wide FP64 issue, 1.53 flop per lane-instruction "
+                             "(two-step form: 242 instead of 280 instructions per wave-step), full (not triangular) state."},
         "status_ok_frac": float((st_host == 0).mean()),
     }
 
@@ -392,6 +394,14 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
                                          "cpu_one_core_ms": med(cpu) * 1e3, "rows_executed": R1,
                                          "rel_dlogl_vs_oracle": abs(v - r) / abs(r)}
     out["single_evaluation_B1"] = single
+    out["single_evaluation_B1"]["kernel"] = ("celerite_block_kernel (windowed form, 16 steps per window on the fp64 matrix cores; "
+                                             "celerite_block.hip) for B <= 512 and 6 <= rows <= 63")
+    # -- small batches (MCMC walkers / a few live points): one workgroup per draw, the same windowed kernel --------------
+    small = {}
+    for basis in ("SHO", "DRWCelerite"):
+        msb, *_ = resident_batch(basis, N, 256, 11)
+        small[f"{basis}{J}_N{N}_B256"] = {"resident_launch_ms": msb, "evals_per_s": 256 / (msb * 1e-3)}
+    out["small_batch_B256"] = small
 
     # -- dense path: configs[4], N = 4096, J = 40 (SHO-40) -------------------------------------------------------------
     Nd, Jd = min(4096, N), 40
