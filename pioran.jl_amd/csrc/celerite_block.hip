@@ -219,9 +219,10 @@ __device__ __forceinline__ double ldl_first_mult(double (&m)[16], int c16)
 struct BlockShared {                // exchanges between the wavefronts of a workgroup
     double MG[4][16 * 18];          // per wavefront: its block of M' [step][row, stride 18] for the transposing read-back, then
                                     // (same storage) its partial Gram U~_J' M_J as fragments [g][lane]
-    double Sg[256];                 // Sigma [j][n]
-    double Ab[2][256];              // A of window k in Ab[k & 1]
-    double Li[16 * 18];             // D_k (L^-1)_ik at [k * 18 + i], i > k; D_k at [k * 18 + k]; the rest is not L^-1 (readers mask)
+    double Ab[2][2][256];           // A of window k in Ab[k & 1][0] (four block columns: the two term-parity partial sums [0] + [1])
+    double Li[16 * 18];             // D_k (L^-1)_ik at [k * 18 + i], i > k; D_k at [k * 18 + k]; the rest is not L^-1 (readers mask).
+                                    // Before the elimination the chain wavefront uses the same storage for Sigma [j][n] (its own
+                                    // layout change; the readers of L^-1 of the previous window are two barriers behind)
     double Yt[4 * 256];             // Y^' fragments [J][g][lane]
     double fin[8];
     double2 ab[64];                 // (a_t, b_t) of this draw
@@ -337,27 +338,31 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
                 for (int g = 0; g < 4; ++g) ckr[I][g] = tl[3 * NB * 256 + 16 * I + 4 * g + q];
         }
     };
-    // A of window k (kappa, src/acvf.jl:138-140, on the window's own pairs) -> sh.Ab[k & 1]; wavefronts 0 .. 2:
-    // thread pp < 120 owns the pair (jj < nn), threads 120 .. 135 the diagonal
-    const int pp = 64 * w + lane;
+    // A of window k (kappa, src/acvf.jl:138-140, on the window's own pairs) -> sh.Ab[k & 1].  Thread pp < 120 of a pair half owns
+    // the pair (jj < nn), threads 120 .. 135 the diagonal.  NB <= 3: wavefronts 0 .. 2, all terms.  NB = 4 (SPLIT4; the E buffer
+    // is single and a wavefront refills what it alone reads): wavefronts 0 .. 3 = (pair half w & 1) x (terms of parity w >> 1),
+    // two partial sums that the chain adds; E piece 2 t + h then belongs to wavefront h + 2 (t & 1).
+    constexpr bool SPLIT4 = NB == 4;
+    const int pp = SPLIT4 ? 64 * (w & 1) + lane : 64 * w + lane;
+    const int tpar = SPLIT4 ? (w >> 1) : 0, tstep = SPLIT4 ? 2 : 1;
     int nn = 1;
     while ((nn + 1) * nn / 2 <= pp) ++nn;
     const int jj = pp - nn * (nn - 1) / 2;
     auto form_A = [&](int64_t k) __attribute__((always_inline)) {
-        if (w < 3) {
-            double* Ad = sh.Ab[k & 1];
+        if (w < (SPLIT4 ? 4 : 3)) {
+            double* Ad = sh.Ab[k & 1][tpar];
             if (pp < 120) {
                 const double2* E = reinterpret_cast<const double2*>(Eb + (k & 1) * ebs) + pp;
                 double acc0 = 0.0, acc1 = 0.0;
-                int t = 0;
-                for (; t + 4 <= J; t += 4) {
+                int t = tpar;
+                for (; t + 3 * tstep < J; t += 4 * tstep) {
                     double2 e[4], cf[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { e[i] = E[(t + i) * 128]; cf[i] = sh.ab[t + i]; }
+                    for (int i = 0; i < 4; ++i) { e[i] = E[(t + i * tstep) * 128]; cf[i] = sh.ab[t + i * tstep]; }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { acc0 = fma(cf[i].x, e[i].x, acc0); acc1 = fma(cf[i].y, e[i].y, acc1); }
                 }
-                for (; t < J; ++t) {
+                for (; t < J; t += tstep) {
                     const double2 e = E[t * 128], cf = sh.ab[t];
                     acc0 = fma(cf.x, e.x, acc0);
                     acc1 = fma(cf.y, e.y, acc1);
@@ -365,8 +370,10 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
                 const double acc = acc0 + acc1;
                 Ad[jj * 16 + nn] = acc;
                 Ad[nn * 16 + jj] = acc;
-            } else if (pp < 136) {
-                const int s = pp - 120;
+            } else if (pp < (SPLIT4 ? 128 : 136)) {
+                // diagonal: NB <= 3: s = pp - 120 (wavefronts 1 and 2); SPLIT4: wavefront 1 -> s = 0 .. 7, wavefront 3 -> s = 8 .. 15,
+                // each also zeroing the same entries of the other partial sum
+                const int s = SPLIT4 ? pp - 120 + 8 * tpar : pp - 120;
                 const int64_t n = k * KW + s;
                 double v = 1.0;
                 if (n < N) {
@@ -374,6 +381,7 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
                     v = suma + (has_nu ? nu * s2n : s2n);    // :92
                 }
                 Ad[s * 16 + s] = v;
+                if constexpr (SPLIT4) sh.Ab[k & 1][tpar ^ 1][s * 16 + s] = 0.0;
             }
         }
     };
@@ -443,22 +451,24 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
         PIORAN_BSTAMP(2);
         // ---- chain: Sigma = A - U~' M, LDL', L^-1 ---------------------------------------------------------------------
         if (chain) {
-            const double* Ad = sh.Ab[k & 1];
+            const double* Ad = sh.Ab[k & 1][0];
             double sg[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 double gs = sh.MG[0][g * 64 + lane];
 #pragma unroll
                 for (int I = 1; I < NB; ++I) gs += sh.MG[I][g * 64 + lane];
-                sg[g] = Ad[(4 * g + q) * 16 + c16] - gs;
+                double av = Ad[(4 * g + q) * 16 + c16];
+                if constexpr (SPLIT4) av += sh.Ab[k & 1][1][(4 * g + q) * 16 + c16];
+                sg[g] = av - gs;
             }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) sh.Sg[(4 * g + q) * 16 + c16] = sg[g];
+            for (int g = 0; g < 4; ++g) sh.Li[(4 * g + q) * 16 + c16] = sg[g];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PIORAN_BSTAMP(3);
             double m[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) m[j] = sh.Sg[j * 16 + c16];
+            for (int j = 0; j < 16; ++j) m[j] = sh.Li[j * 16 + c16];
             PIORAN_BSTAMP(4);
             double mult = ldl_first_mult(m, c16);
             static_for<0, 16>([&](auto Pc) __attribute__((always_inline)) { ldl_step<decltype(Pc)::value>(m, mult, c16); });
@@ -486,7 +496,7 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
         // record k + 2: tile k (buffer k & 1) has no reader left since barrier 1.  One E buffer: the E pieces a wavefront refills
         // are the ones only it reads (piece 2 t + h = term t, pairs 64 h .. 64 h + 63), just consumed by its own form_A above.
         // Two E buffers: the target held E(k), last read before barrier 2 of window k - 1.
-        const int np_tile = TSP / 128, np_all = np_tile + 2 * J, np_chain = EDBL ? np_all / 4 : 0;
+        const int np_tile = TSP / 128, np_all = np_tile + 2 * J, np_chain = np_all / 4;
         auto copy_piece = [&](int c) __attribute__((always_inline)) {
             const double* src = btab + (k + 2) * RSB + c * 128 + lane * 2;
             double* dst = c < np_tile ? tileb + (k & 1) * TSP + c * 128 : Eb + (k & 1) * ebs + (c - np_tile) * 128;
@@ -499,20 +509,19 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
                 const int lo = np_chain + (w == 0 ? 0 : w == 1 ? unit : w == 2 ? 2 * unit : 4 * unit);
                 const int hi = w == 0 ? np_chain + unit : w == 1 ? np_chain + 2 * unit : (w == 2 && NWV == 5) ? np_chain + 4 * unit : np_all;
                 for (int c = lo; c < hi; ++c) copy_piece(c);
+            } else if constexpr (SPLIT4) {
+                for (int t = tpar; t < J; t += 2) copy_piece(np_tile + 2 * t + (w & 1));
             } else {
-                if (w < 2) {
+                if (w < 2)
                     for (int t = 0; t < J; ++t) copy_piece(np_tile + 2 * t + w);
-                } else if (w == 2) {
-                    for (int c = 0; c < np_tile; ++c) copy_piece(c);
-                }
             }
         }
         PIORAN_BSTAMP(7);
         PIORAN_BLK_BARRIER();   // B2: L^-1, 1/D published
         PIORAN_BSTAMP(8);
-        if constexpr (EDBL) {
-            if (chain && k + 2 < NW)
-                for (int c = 0; c < np_chain; ++c) copy_piece(c);
+        if (chain && k + 2 < NW) {   // the chain wavefront idles until the next barrier 1: its share of record k + 2 (one E buffer:
+                                     // the tile, free since barrier 1; measured: better there than on the owners)
+            for (int c = 0; c < (EDBL ? np_chain : np_tile); ++c) copy_piece(c);
         }
         // ---- Y^' = L^-1 X' --------------------------------------------------------------------------------------------
         double ysc[4];
