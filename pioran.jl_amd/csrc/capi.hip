@@ -236,12 +236,17 @@ int block_dispatch(pioran_ds* ds, const ScanParams& p)
     PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
     if (!s || !s->prepared || s->npd_terms != 0 || p.rec_stride != 3 * (int64_t)(s->R + 2) + 2) return PIORAN_ERR_UNSUPPORTED;
     if (!s->btab_ready) {
+        // 60 KB per 16 time stamps at J = 20: very long series (or a device short of memory) stay on the other kernels
         const size_t need = pioran_block_table_doubles(ds->N, s->R, s->J);
+        if (need * sizeof(double) > (size_t(2) << 30)) return PIORAN_ERR_UNSUPPORTED;
         if (need > s->btab_cap) {
             if (s->btab) HIPCHK(ctx, hipFree(s->btab));
             s->btab = nullptr;
             s->btab_cap = 0;
-            if (hipMalloc((void**)&s->btab, need * sizeof(double)) != hipSuccess) return PIORAN_ERR_ALLOC;
+            if (hipMalloc((void**)&s->btab, need * sizeof(double)) != hipSuccess) {
+                (void)hipGetLastError();
+                return PIORAN_ERR_UNSUPPORTED;
+            }
             s->btab_cap = need;
         }
         int rc = pioran_launch_block_table(ds->N, s->R, s->J, s->rowmap, ds->t, s->dc, s->dd, ds->y, ds->s2, s->btab, ctx->stream);
