@@ -57,9 +57,10 @@ __device__ __forceinline__ double dpp_perm(double x)
 //   pk = bcast(phi_k);  S_i = (phi_i pk) * (S_i + g_i bcast(w_k));  q_i += S_i bcast(u_k)
 // v_fmac_f64_dpp ... row_newbcast:N takes its src0 from lane N of the DPP row (DP-ALU DPP supports exactly this
 // control on gfx950), so w_k and u_k never occupy a register or an instruction of their own.
-// Hazard (VALU write of a VGPR -> DPP read of it needs 2 wait states; nothing is padded inside asm): the
-// leading s_nop 1 covers a producer scheduled directly in front of the block; inside the block no DPP source
-// (w, u, phi of the row-owning lane) is written.
+// Hazard (VALU write of a VGPR -> DPP read of it needs 2 wait states; nothing is padded inside asm): the DPP sources of
+// a pass (w, u, phi of the row-owning lane) are written BEFORE the pass and never inside it; the caller pins them in
+// their registers and issues ONE s_nop 1 in front of the pass (a leading s_nop per block, as in round 1, cost 8 % of the
+// instruction slots); tools/check_dpp_hazards.py verifies the listing.
 #define PIORAN_DPP_STR2(N) #N
 #define PIORAN_DPP_CTRL(N) " row_newbcast:" PIORAN_DPP_STR2(N) " row_mask:0xf bank_mask:0xf"
 #define PD_FMAC(d, s0, s1) "v_fmac_f64_dpp %[" #d "], %[" #s0 "], %[" #s1 "]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
@@ -74,8 +75,7 @@ struct ColBlock<1, N> {
                                                const double (&ph)[1], double ws, double us, double phs)
     {
         double pk, p0;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_FMAC(s0, ws, g0) PD_MUL(p0, h0, pk) PD_MUL(s0, p0, s0) PD_FMAC(q0, us, s0)
                      : [s0] "+v"(S[0]), [q0] "+v"(q[0]), [pk] "=&v"(pk), [p0] "=&v"(p0)
                      : [g0] "v"(g[0]), [h0] "v"(ph[0]), [ws] "v"(ws), [us] "v"(us), [phs] "v"(phs), [n] "i"(N));
@@ -88,8 +88,7 @@ struct ColBlock<2, N> {
                                                const double (&ph)[2], double ws, double us, double phs)
     {
         double pk, p0, p1;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk)
                      PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1)
                      : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [pk] "=&v"(pk),
@@ -105,8 +104,7 @@ struct ColBlock<3, N> {
                                                const double (&ph)[3], double ws, double us, double phs)
     {
         double pk, p0, p1, p2;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2)
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk)
                      PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2)
@@ -124,8 +122,7 @@ struct ColBlock<4, N> {
                                                const double (&ph)[4], double ws, double us, double phs)
     {
         double pk, p0, p1, p2, p3;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3)
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk)
                      PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2) PD_MUL(s3, p3, s3)
@@ -145,8 +142,7 @@ struct ColBlock<5, N> {
                                                const double (&ph)[5], double ws, double us, double phs)
     {
         double pk, p0, p1, p2, p3, p4;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3) PD_FMAC(s4, ws, g4)
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk) PD_MUL(p4, h4, pk)
                      PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2) PD_MUL(s3, p3, s3) PD_MUL(s4, p4, s4)
@@ -173,8 +169,7 @@ struct PairFirst<3, N> {
                                                const double (&ph)[3], double ws, double us, double phs, double (&pp)[3])
     {
         double pk;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2)
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk)
                      PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2)
@@ -190,8 +185,7 @@ struct PairSecond<3, N> {
     static __device__ __forceinline__ void run(double (&S)[3], double (&q)[3], const double (&g)[3], double ws, double us,
                                                const double (&pp)[3])
     {
-        asm volatile("s_nop 1\n\t"
-                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2)
+        asm volatile(PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2)
                      PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2)
                      PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1) PD_FMAC(q2, us, s2)
                      : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2])
@@ -205,8 +199,7 @@ struct PairFirst<1, N> {
                                                const double (&ph)[1], double ws, double us, double phs, double (&pp)[1])
     {
         double pk;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_FMAC(s0, ws, g0)
                      PD_MUL(p0, h0, pk)
                      PD_MUL(s0, p0, s0)
@@ -220,8 +213,7 @@ struct PairSecond<1, N> {
     static __device__ __forceinline__ void run(double (&S)[1], double (&q)[1], const double (&g)[1], double ws, double us,
                                                const double (&pp)[1])
     {
-        asm volatile("s_nop 1\n\t"
-                     PD_FMAC(s0, ws, g0)
+        asm volatile(PD_FMAC(s0, ws, g0)
                      PD_MUL(s0, p0, s0)
                      PD_FMAC(q0, us, s0)
                      : [s0] "+v"(S[0]), [q0] "+v"(q[0])
@@ -234,8 +226,7 @@ struct PairFirst<2, N> {
                                                const double (&ph)[2], double ws, double us, double phs, double (&pp)[2])
     {
         double pk;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1)
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk)
                      PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1)
@@ -249,8 +240,7 @@ struct PairSecond<2, N> {
     static __device__ __forceinline__ void run(double (&S)[2], double (&q)[2], const double (&g)[2], double ws, double us,
                                                const double (&pp)[2])
     {
-        asm volatile("s_nop 1\n\t"
-                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1)
+        asm volatile(PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1)
                      PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1)
                      PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1)
                      : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [q0] "+v"(q[0]), [q1] "+v"(q[1])
@@ -263,8 +253,7 @@ struct PairFirst<4, N> {
                                                const double (&ph)[4], double ws, double us, double phs, double (&pp)[4])
     {
         double pk;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3)
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk)
                      PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2) PD_MUL(s3, p3, s3)
@@ -278,8 +267,7 @@ struct PairSecond<4, N> {
     static __device__ __forceinline__ void run(double (&S)[4], double (&q)[4], const double (&g)[4], double ws, double us,
                                                const double (&pp)[4])
     {
-        asm volatile("s_nop 1\n\t"
-                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3)
+        asm volatile(PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3)
                      PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2) PD_MUL(s3, p3, s3)
                      PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1) PD_FMAC(q2, us, s2) PD_FMAC(q3, us, s3)
                      : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3])
@@ -292,8 +280,7 @@ struct PairFirst<5, N> {
                                                const double (&ph)[5], double ws, double us, double phs, double (&pp)[5])
     {
         double pk;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3) PD_FMAC(s4, ws, g4)
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk) PD_MUL(p4, h4, pk)
                      PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2) PD_MUL(s3, p3, s3) PD_MUL(s4, p4, s4)
@@ -307,8 +294,7 @@ struct PairSecond<5, N> {
     static __device__ __forceinline__ void run(double (&S)[5], double (&q)[5], const double (&g)[5], double ws, double us,
                                                const double (&pp)[5])
     {
-        asm volatile("s_nop 1\n\t"
-                     PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3) PD_FMAC(s4, ws, g4)
+        asm volatile(PD_FMAC(s0, ws, g0) PD_FMAC(s1, ws, g1) PD_FMAC(s2, ws, g2) PD_FMAC(s3, ws, g3) PD_FMAC(s4, ws, g4)
                      PD_MUL(s0, p0, s0) PD_MUL(s1, p1, s1) PD_MUL(s2, p2, s2) PD_MUL(s3, p3, s3) PD_MUL(s4, p4, s4)
                      PD_FMAC(q0, us, s0) PD_FMAC(q1, us, s1) PD_FMAC(q2, us, s2) PD_FMAC(q3, us, s3) PD_FMAC(q4, us, s4)
                      : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [q4] "+v"(q[4])
@@ -324,7 +310,7 @@ template <int N>
 struct MatVec2<1, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k) for one column k of this lane's rows
     static __device__ __forceinline__ void run(const double (&T)[1], double (&rA)[1], double (&rB)[1], double ua, double ub)
     {
-        asm volatile("s_nop 1\n\t" PD_FMAC(a0, ua, t0) PD_FMAC(b0, ub, t0)
+        asm volatile(PD_FMAC(a0, ua, t0) PD_FMAC(b0, ub, t0)
                      : [a0] "+v"(rA[0]), [b0] "+v"(rB[0])
                      : [t0] "v"(T[0]), [ua] "v"(ua), [ub] "v"(ub), [n] "i"(N));
     }
@@ -335,8 +321,7 @@ struct Update2<1, N> {   // T = (phAB_i bcast(phAB_k)) T + hA_i bcast(wA_k) + mB
                                                double wa, double wb, double phs)
     {
         double pk, pp[1];
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_MUL(p0, h0, pk) PD_MUL(t0, p0, t0) PD_FMAC(t0, wa, g0) PD_FMAC(t0, wb, m0)
                      : [t0] "+v"(T[0]), [pk] "=&v"(pk), [p0] "=&v"(pp[0])
                      : [g0] "v"(hA[0]), [m0] "v"(mB[0]), [h0] "v"(ph[0]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
@@ -348,8 +333,7 @@ struct Update2First<1, N> {   // first column of a (cos, sin) pair: also hands p
                                                double wa, double wb, double phs, double (&pp)[1])
     {
         double pk;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_MUL(p0, h0, pk) PD_MUL(t0, p0, t0) PD_FMAC(t0, wa, g0) PD_FMAC(t0, wb, m0)
                      : [t0] "+v"(T[0]), [pk] "=&v"(pk), [p0] "=&v"(pp[0])
                      : [g0] "v"(hA[0]), [m0] "v"(mB[0]), [h0] "v"(ph[0]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
@@ -360,7 +344,7 @@ struct Update2Second<1, N> {
     static __device__ __forceinline__ void run(double (&T)[1], const double (&hA)[1], const double (&mB)[1], double wa, double wb,
                                                const double (&pp)[1])
     {
-        asm volatile("s_nop 1\n\t" PD_MUL(t0, p0, t0) PD_FMAC(t0, wa, g0) PD_FMAC(t0, wb, m0)
+        asm volatile(PD_MUL(t0, p0, t0) PD_FMAC(t0, wa, g0) PD_FMAC(t0, wb, m0)
                      : [t0] "+v"(T[0])
                      : [g0] "v"(hA[0]), [m0] "v"(mB[0]), [p0] "v"(pp[0]), [wa] "v"(wa), [wb] "v"(wb), [n] "i"(N));
     }
@@ -369,7 +353,7 @@ template <int N>
 struct MatVec2<2, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k) for one column k of this lane's rows
     static __device__ __forceinline__ void run(const double (&T)[2], double (&rA)[2], double (&rB)[2], double ua, double ub)
     {
-        asm volatile("s_nop 1\n\t" PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1)
+        asm volatile(PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1)
                      : [a0] "+v"(rA[0]), [a1] "+v"(rA[1]), [b0] "+v"(rB[0]), [b1] "+v"(rB[1])
                      : [t0] "v"(T[0]), [t1] "v"(T[1]), [ua] "v"(ua), [ub] "v"(ub), [n] "i"(N));
     }
@@ -380,8 +364,7 @@ struct Update2<2, N> {   // T = (phAB_i bcast(phAB_k)) T + hA_i bcast(wA_k) + mB
                                                double wa, double wb, double phs)
     {
         double pk, pp[2];
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1)
                      : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1])
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
@@ -393,8 +376,7 @@ struct Update2First<2, N> {   // first column of a (cos, sin) pair: also hands p
                                                double wa, double wb, double phs, double (&pp)[2])
     {
         double pk;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1)
                      : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1])
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
@@ -405,7 +387,7 @@ struct Update2Second<2, N> {
     static __device__ __forceinline__ void run(double (&T)[2], const double (&hA)[2], const double (&mB)[2], double wa, double wb,
                                                const double (&pp)[2])
     {
-        asm volatile("s_nop 1\n\t" PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1)
+        asm volatile(PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1)
                      : [t0] "+v"(T[0]), [t1] "+v"(T[1])
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [wa] "v"(wa), [wb] "v"(wb), [n] "i"(N));
     }
@@ -414,7 +396,7 @@ template <int N>
 struct MatVec2<3, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k) for one column k of this lane's rows
     static __device__ __forceinline__ void run(const double (&T)[3], double (&rA)[3], double (&rB)[3], double ua, double ub)
     {
-        asm volatile("s_nop 1\n\t" PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(a2, ua, t2) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1) PD_FMAC(b2, ub, t2)
+        asm volatile(PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(a2, ua, t2) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1) PD_FMAC(b2, ub, t2)
                      : [a0] "+v"(rA[0]), [a1] "+v"(rA[1]), [a2] "+v"(rA[2]), [b0] "+v"(rB[0]), [b1] "+v"(rB[1]), [b2] "+v"(rB[2])
                      : [t0] "v"(T[0]), [t1] "v"(T[1]), [t2] "v"(T[2]), [ua] "v"(ua), [ub] "v"(ub), [n] "i"(N));
     }
@@ -425,8 +407,7 @@ struct Update2<3, N> {   // T = (phAB_i bcast(phAB_k)) T + hA_i bcast(wA_k) + mB
                                                double wa, double wb, double phs)
     {
         double pk, pp[3];
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2)
                      : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2])
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
@@ -438,8 +419,7 @@ struct Update2First<3, N> {   // first column of a (cos, sin) pair: also hands p
                                                double wa, double wb, double phs, double (&pp)[3])
     {
         double pk;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2)
                      : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2])
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
@@ -450,7 +430,7 @@ struct Update2Second<3, N> {
     static __device__ __forceinline__ void run(double (&T)[3], const double (&hA)[3], const double (&mB)[3], double wa, double wb,
                                                const double (&pp)[3])
     {
-        asm volatile("s_nop 1\n\t" PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2)
+        asm volatile(PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2)
                      : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2])
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]), [wa] "v"(wa), [wb] "v"(wb), [n] "i"(N));
     }
@@ -459,7 +439,7 @@ template <int N>
 struct MatVec2<4, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k) for one column k of this lane's rows
     static __device__ __forceinline__ void run(const double (&T)[4], double (&rA)[4], double (&rB)[4], double ua, double ub)
     {
-        asm volatile("s_nop 1\n\t" PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(a2, ua, t2) PD_FMAC(a3, ua, t3) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1) PD_FMAC(b2, ub, t2) PD_FMAC(b3, ub, t3)
+        asm volatile(PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(a2, ua, t2) PD_FMAC(a3, ua, t3) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1) PD_FMAC(b2, ub, t2) PD_FMAC(b3, ub, t3)
                      : [a0] "+v"(rA[0]), [a1] "+v"(rA[1]), [a2] "+v"(rA[2]), [a3] "+v"(rA[3]), [b0] "+v"(rB[0]), [b1] "+v"(rB[1]), [b2] "+v"(rB[2]), [b3] "+v"(rB[3])
                      : [t0] "v"(T[0]), [t1] "v"(T[1]), [t2] "v"(T[2]), [t3] "v"(T[3]), [ua] "v"(ua), [ub] "v"(ub), [n] "i"(N));
     }
@@ -470,8 +450,7 @@ struct Update2<4, N> {   // T = (phAB_i bcast(phAB_k)) T + hA_i bcast(wA_k) + mB
                                                double wa, double wb, double phs)
     {
         double pk, pp[4];
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3)
                      : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2]), [p3] "=&v"(pp[3])
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [h3] "v"(ph[3]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
@@ -483,8 +462,7 @@ struct Update2First<4, N> {   // first column of a (cos, sin) pair: also hands p
                                                double wa, double wb, double phs, double (&pp)[4])
     {
         double pk;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3)
                      : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2]), [p3] "=&v"(pp[3])
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [h3] "v"(ph[3]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
@@ -495,7 +473,7 @@ struct Update2Second<4, N> {
     static __device__ __forceinline__ void run(double (&T)[4], const double (&hA)[4], const double (&mB)[4], double wa, double wb,
                                                const double (&pp)[4])
     {
-        asm volatile("s_nop 1\n\t" PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3)
+        asm volatile(PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3)
                      : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3])
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]), [p3] "v"(pp[3]), [wa] "v"(wa), [wb] "v"(wb), [n] "i"(N));
     }
@@ -504,7 +482,7 @@ template <int N>
 struct MatVec2<5, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k) for one column k of this lane's rows
     static __device__ __forceinline__ void run(const double (&T)[5], double (&rA)[5], double (&rB)[5], double ua, double ub)
     {
-        asm volatile("s_nop 1\n\t" PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(a2, ua, t2) PD_FMAC(a3, ua, t3) PD_FMAC(a4, ua, t4) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1) PD_FMAC(b2, ub, t2) PD_FMAC(b3, ub, t3) PD_FMAC(b4, ub, t4)
+        asm volatile(PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(a2, ua, t2) PD_FMAC(a3, ua, t3) PD_FMAC(a4, ua, t4) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1) PD_FMAC(b2, ub, t2) PD_FMAC(b3, ub, t3) PD_FMAC(b4, ub, t4)
                      : [a0] "+v"(rA[0]), [a1] "+v"(rA[1]), [a2] "+v"(rA[2]), [a3] "+v"(rA[3]), [a4] "+v"(rA[4]), [b0] "+v"(rB[0]), [b1] "+v"(rB[1]), [b2] "+v"(rB[2]), [b3] "+v"(rB[3]), [b4] "+v"(rB[4])
                      : [t0] "v"(T[0]), [t1] "v"(T[1]), [t2] "v"(T[2]), [t3] "v"(T[3]), [t4] "v"(T[4]), [ua] "v"(ua), [ub] "v"(ub), [n] "i"(N));
     }
@@ -515,8 +493,7 @@ struct Update2<5, N> {   // T = (phAB_i bcast(phAB_k)) T + hA_i bcast(wA_k) + mB
                                                double wa, double wb, double phs)
     {
         double pk, pp[5];
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk) PD_MUL(p4, h4, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_MUL(t4, p4, t4) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t4, wa, g4) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3) PD_FMAC(t4, wb, m4)
                      : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2]), [p3] "=&v"(pp[3]), [p4] "=&v"(pp[4])
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [g4] "v"(hA[4]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [m4] "v"(mB[4]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [h3] "v"(ph[3]), [h4] "v"(ph[4]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
@@ -528,8 +505,7 @@ struct Update2First<5, N> {   // first column of a (cos, sin) pair: also hands p
                                                double wa, double wb, double phs, double (&pp)[5])
     {
         double pk;
-        asm volatile("s_nop 1\n\t"
-                     "v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
                      PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(p3, h3, pk) PD_MUL(p4, h4, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_MUL(t4, p4, t4) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t4, wa, g4) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3) PD_FMAC(t4, wb, m4)
                      : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2]), [p3] "=&v"(pp[3]), [p4] "=&v"(pp[4])
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [g4] "v"(hA[4]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [m4] "v"(mB[4]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [h3] "v"(ph[3]), [h4] "v"(ph[4]), [wa] "v"(wa), [wb] "v"(wb), [phs] "v"(phs), [n] "i"(N));
@@ -540,7 +516,7 @@ struct Update2Second<5, N> {
     static __device__ __forceinline__ void run(double (&T)[5], const double (&hA)[5], const double (&mB)[5], double wa, double wb,
                                                const double (&pp)[5])
     {
-        asm volatile("s_nop 1\n\t" PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_MUL(t4, p4, t4) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t4, wa, g4) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3) PD_FMAC(t4, wb, m4)
+        asm volatile(PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_MUL(t3, p3, t3) PD_MUL(t4, p4, t4) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t3, wa, g3) PD_FMAC(t4, wa, g4) PD_FMAC(t0, wb, m0) PD_FMAC(t1, wb, m1) PD_FMAC(t2, wb, m2) PD_FMAC(t3, wb, m3) PD_FMAC(t4, wb, m4)
                      : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4])
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [g4] "v"(hA[4]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [m4] "v"(mB[4]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]), [p3] "v"(pp[3]), [p4] "v"(pp[4]), [wa] "v"(wa), [wb] "v"(wb), [n] "i"(N));
     }
@@ -879,6 +855,13 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 sa.v[YS] = fma(ysel, sa.y - mu, sa.v[YS]);
                 sb.v[YS] = fma(ysel, sb.y - mu, sb.v[YS]);
             }
+            // DPP hazard (a VALU write of a DPP source needs two wait states before the DPP read): the sources of a pass (u~A, u~B
+            // here; wA, wB, phAB below) are written BEFORE the pass and never inside it, so one s_nop in front of the pass covers
+            // a producer scheduled directly before it; the column blocks carry none (tools/check_dpp_hazards.py checks the listing)
+            // (the "+v" operands pin every source in its register before the pass: the compiler may not sink a producer between blocks)
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(tA[i]), "+v"(tB[i]));
+            asm volatile("s_nop 1");
             static_for<0, NC>([&](auto Cc) {
                 constexpr int c = decltype(Cc)::value;
                 MatVec2<RPL, c / RPL>::run(T[c], rA, rB, tA[c % RPL], tB[c % RPL]);
@@ -929,6 +912,9 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             }
             quad = fma(zB * zB, rDB, fma(zA * zA, rDA, quad));                           // z_n^2 / D_n  (== y'K^-1 y, :333)
             // ---- T <- (phAB phAB') o T + hA wA' + mB wB' ----
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(wA[i]), "+v"(wB[i]), "+v"(pAB[i]));
+            asm volatile("s_nop 1");
             if constexpr (NPB > 0) {
                 static_for<0, NPB>([&](auto Pc) {
                     constexpr int c = 2 * decltype(Pc)::value;
@@ -1026,6 +1012,9 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         in.v[YS] = fma(ysel, in.y - mu, in.v[YS]);
 
         // ---- S update + q = S u over this DPP row's column block ----
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(w[i]), "+v"(u[i]), "+v"(in.ph[i]));   // DPP sources: final before the pass
+        asm volatile("s_nop 1");
         if constexpr (NPB > 0) {
             // block layout: the first 2 NPB columns of the block are the (cos, sin) pairs of NPB two-row terms
             // (phi_i phi_k formed once per pair), the rest single rows of one-row terms and the spare slot
