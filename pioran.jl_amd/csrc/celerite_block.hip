@@ -599,11 +599,15 @@ template <int NB, bool EDBL>
 int launch_block2(const ScanParams& p, const double* btab, hipStream_t stream)
 {
     const size_t lds = block_lds_bytes(NB, p.J, EDBL);
-    static size_t granted = 0;   // per template instance
-    if (lds > granted) {
+    // the attribute belongs to (function, device): one process may drive several devices (pioran_farm_*).  Racing threads at
+    // worst set it twice.
+    static size_t granted[64] = {};   // per template instance
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
+    if (lds > granted[dev]) {
         if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, EDBL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PIORAN_ERR_HIP;
-        granted = lds;
+        granted[dev] = lds;
     }
     hipLaunchKernelGGL((celerite_block_kernel<NB, EDBL>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 320), lds, stream, p, btab);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
