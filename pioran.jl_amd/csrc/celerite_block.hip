@@ -23,15 +23,19 @@
 // window's own block A, and that is the plain kernel function: a shared table holds e^{-c tau}(cos, sin)(d tau) per (pair, term),
 // each draw contracts it with its (a_j, b_j).
 //
-// Work split (R + 1 <= 16 NB rows, NB <= 5): wavefront w owns the block columns J = w, w + 4 of T (C/D register layout of
+// Work split (R + 1 <= 16 NB rows, NB <= 4): wavefront w < NB owns block column w of T (C/D register layout of
 // v_mfma_f64_16x16x4_f64: register g of block (I, J) = element (16 I + 4 g + (lane >> 4), 16 J + (lane & 15))).  Those registers
 // are the B operand of M' = U~' T and the accumulator of the update without any data movement; M' comes out in the layout in
-// which X, Y^ and the update's operands are needed.  Wavefront 3 also runs the chain: Gram, Sigma, the 16 x 16 LDL' with every
-// column replicated in the four DPP rows (pivot broadcasts and rank-1 updates are v_mov_b64_dpp / v_fmac_f64_dpp row_newbcast: no
-// LDS inside the factorisation), and L^-1 by carrying the identity through the same row operations.  Three workgroup barriers
-// per window; while the chain runs, the other wavefronts rescale T, form A and U~ of the NEXT window and prefetch its table
-// fragments.  The table is stored in fragment order (one 8-byte element per lane and register), so every load is coalesced and
-// nothing is staged through LDS except the exchanges between wavefronts.
+// which X, Y^ and the update's operands are needed; each owner adds its own Gram partial U~_w' M_w (one transposing LDS round
+// trip inside the wavefront).  One more wavefront (the last: 3, or 4 when NB = 4) runs the chain: Sigma from the partials, the
+// 16 x 16 LDL' as an in-place Gauss-Jordan with every column replicated in the four DPP rows (pivot broadcasts and rank-1
+// updates are v_mov_b64_dpp / v_fmac_f64_dpp row_newbcast: no LDS inside the factorisation; L^-1 comes out of the same
+// instructions).  Three workgroup barriers per window.  While the chain runs, the owners rescale T, form A and U~ of the NEXT
+// window and copy record k + 2 of the table into LDS (global_load_lds_dwordx4: the table is stored in fragment order — one
+// 8-byte element per lane and MFMA register — so a record is a plain copy in 1 KB pieces, lands a whole window ahead, costs no
+// registers, and every operand read is a conflict-free ds_read_b64).
+// Numerical notes: the only division-like operation is 1 / D_n (v_rcp_f64 + two Newton steps, 1 ulp); a non-positive D_n is
+// carried on like the reference does (log|D_n|, :140; status 1), NaN / inf surface as status 2.
 #include "common.h"
 
 #include <cmath>
