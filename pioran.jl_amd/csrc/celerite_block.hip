@@ -390,17 +390,25 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
         }
     };
 
-    // per-draw series (y, sigma2) [B][N]: window k + 2 is fetched by wavefront 2 while the chain of window k runs and staged in
-    // LDS (a plain global load consumed on the critical path would wait for the LDS DMAs issued after it as well)
-    auto stage_series = [&](int64_t k) __attribute__((always_inline)) {
+    // per-draw series (y, sigma2) [B][N]: fetched by wavefront 2 into a register a whole window before it is staged in LDS (a
+    // plain global load consumed at once — or on the critical path — would expose its HBM latency, and wait for the LDS DMAs
+    // issued after it as well): window k + 3 is loaded and window k + 2 staged while the chain of window k runs
+    double series_reg = 0.0;
+    auto fetch_series = [&](int64_t k) __attribute__((always_inline)) {
         if (p.Y && w == 2 && lane < 32) {
             const int64_t n = k * KW + (lane & 15);
             const double* src = lane < 16 ? p.Y : p.S2;
-            sh.ys[k & 1][lane] = n < N ? src[b * N + n] : 0.0;
+            series_reg = n < N ? src[b * N + n] : 0.0;
         }
     };
+    auto stage_series = [&](int64_t k) __attribute__((always_inline)) {
+        if (p.Y && w == 2 && lane < 32) sh.ys[k & 1][lane] = series_reg;
+    };
+    fetch_series(0);
     stage_series(0);
-    if (NW > 1) stage_series(1);
+    fetch_series(1);
+    stage_series(1);
+    fetch_series(2);
     PIORAN_BLK_BARRIER_DMA();          // record 0 has landed
     if (has_u) load_u(0);
     load_vh(0);
@@ -496,7 +504,10 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
             if (owner && !chain) load_u(k + 1);
             load_vh(k + 1);
         }
-        if (k + 2 < NW) stage_series(k + 2);   // slot k & 1: window k's values were consumed before barrier 2 of window k - 1
+        if (k + 2 < NW) {   // slot k & 1: window k's values were consumed before barrier 2 of window k - 1
+            stage_series(k + 2);
+            fetch_series(k + 3);
+        }
         // record k + 2: tile k (buffer k & 1) has no reader left since barrier 1.  One E buffer: the E pieces a wavefront refills
         // are the ones only it reads (piece 2 t + h = term t, pairs 64 h .. 64 h + 63), just consumed by its own form_A above.
         // Two E buffers: the target held E(k), last read before barrier 2 of window k - 1.
