@@ -177,16 +177,19 @@ __device__ __forceinline__ void ldl_rows(double (&m)[16], double mult)
     }
 }
 
-// One elimination step with the NEXT pivot's reciprocal chain (broadcast, v_rcp_f64, two Newton steps: ~10 dependent DP
-// operations) spread between the rank-1 updates of this step, which do not depend on it: the wavefront issues in order, so the
-// order below is the schedule (every piece is its own asm volatile statement).  `mult` is this step's multiplier, on return the
-// next step's; D_P stays in m[P] of lane P.
+// One elimination step with the NEXT pivot's multiplier chain spread between the rank-1 updates of this step, which do not depend
+// on it: the wavefront issues in order, so the order below is the schedule (every piece is its own asm volatile statement).
+// The multiplier -m / d is formed without a finished reciprocal: r0 = v_rcp_f64(d) (24 bits), e = 1 - d r0, t0 = -m r0,
+// mult = t0 (1 + e + e^2) — third order, relative error e^3 < 1e-22 before rounding — four dependent DP operations after the
+// broadcast instead of the seven of "two Newton steps, then multiply".  `mult` is this step's multiplier, on return the next
+// step's; D_P stays in m[P] of lane P.
 __device__ __forceinline__ void blk_rcp(double& r, double d) { asm volatile("v_rcp_f64 %0, %1" : "=v"(r) : "v"(d)); }
-__device__ __forceinline__ void blk_newton(double& r, double d)
+__device__ __forceinline__ void blk_e_t0(double& e, double& t0, double r0, double d, double mrow)
 {
-    double e;
-    asm volatile("s_nop 0\n\tv_fma_f64 %0, -%2, %1, 1.0\n\tv_fma_f64 %1, %0, %1, %1" : "=&v"(e), "+v"(r) : "v"(d));
+    asm volatile("s_nop 0\n\tv_fma_f64 %0, -%2, %3, 1.0\n\tv_mul_f64 %1, -%4, %2" : "=&v"(e), "=&v"(t0) : "v"(r0), "v"(d), "v"(mrow));
 }
+__device__ __forceinline__ void blk_poly(double& pq, double e) { asm volatile("v_fma_f64 %0, %1, %1, %1" : "=v"(pq) : "v"(e)); }
+__device__ __forceinline__ void blk_mult(double& mu_, double t0, double pq) { asm volatile("v_fma_f64 %0, %1, %2, %1" : "=v"(mu_) : "v"(t0), "v"(pq)); }
 template <int P>
 __device__ __forceinline__ void ldl_step(double (&m)[16], double& mult, int c16)
 {
@@ -197,27 +200,29 @@ __device__ __forceinline__ void ldl_step(double (&m)[16], double& mult, int c16)
     constexpr int NDk = NR - NA - NBk - NCk;
     ldl_rows<P, P + 1, NA>(m, mult);
     if constexpr (P < 15) {
-        double dn, rn;
+        double dn, r0, e, t0, pq, mn;
         asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%c2 row_mask:0xf bank_mask:0xf" : "=v"(dn) : "v"(m[P + 1]), "i"(P + 1));
         if constexpr (NBk == 0) asm volatile("s_nop 0");
-        blk_rcp(rn, dn);
+        blk_rcp(r0, dn);
         ldl_rows<P, P + 1 + NA, NBk>(m, mult);
-        blk_newton(rn, dn);
+        blk_e_t0(e, t0, r0, dn, m[P + 1]);
         ldl_rows<P, P + 1 + NA + NBk, NCk>(m, mult);
-        blk_newton(rn, dn);
+        blk_poly(pq, e);
         ldl_rows<P, P + 1 + NA + NBk + NCk, NDk>(m, mult);
-        mult = c16 == P + 1 ? -2.0 : -m[P + 1] * rn;
+        blk_mult(mn, t0, pq);
+        mult = c16 == P + 1 ? -2.0 : mn;
     }
 }
 __device__ __forceinline__ double ldl_first_mult(double (&m)[16], int c16)
 {
-    double d0, r0;
+    double d0, r0, e, t0, pq, mn;
     asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(d0) : "v"(m[0]));
     asm volatile("s_nop 0");
     blk_rcp(r0, d0);
-    blk_newton(r0, d0);
-    blk_newton(r0, d0);
-    return c16 == 0 ? -2.0 : -m[0] * r0;
+    blk_e_t0(e, t0, r0, d0, m[0]);
+    blk_poly(pq, e);
+    blk_mult(mn, t0, pq);
+    return c16 == 0 ? -2.0 : mn;
 }
 
 struct BlockShared {                // exchanges between the wavefronts of a workgroup
@@ -359,12 +364,13 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
                 const double2* E = reinterpret_cast<const double2*>(Eb + (k & 1) * ebs) + pp;
                 double acc0 = 0.0, acc1 = 0.0;
                 int t = tpar;
-                for (; t + 3 * tstep < J; t += 4 * tstep) {
-                    double2 e[4], cf[4];
+                constexpr int UN = 10;   // LDS reads in flight per chunk (two chunks at J = 20)
+                for (; t + (UN - 1) * tstep < J; t += UN * tstep) {
+                    double2 e[UN], cf[UN];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { e[i] = E[(t + i * tstep) * 128]; cf[i] = sh.ab[t + i * tstep]; }
+                    for (int i = 0; i < UN; ++i) { e[i] = E[(t + i * tstep) * 128]; cf[i] = sh.ab[t + i * tstep]; }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { acc0 = fma(cf[i].x, e[i].x, acc0); acc1 = fma(cf[i].y, e[i].y, acc1); }
+                    for (int i = 0; i < UN; ++i) { acc0 = fma(cf[i].x, e[i].x, acc0); acc1 = fma(cf[i].y, e[i].y, acc1); }
                 }
                 for (; t < J; t += tstep) {
                     const double2 e = E[t * 128], cf = sh.ab[t];
@@ -499,10 +505,13 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
 #pragma unroll
                 for (int g = 0; g < 4; ++g) T[I][g] *= ckr[I][g] * ckc;
         }
+        PIORAN_BSTAMP(12);
         if (k + 1 < NW) {
             form_A(k + 1);
+            PIORAN_BSTAMP(13);
             if (owner && !chain) load_u(k + 1);
             load_vh(k + 1);
+            PIORAN_BSTAMP(14);
         }
         if (k + 2 < NW) {   // slot k & 1: window k's values were consumed before barrier 2 of window k - 1
             stage_series(k + 2);

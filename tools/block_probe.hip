@@ -2,8 +2,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/block_probe.hip -o tools/block_probe && tools/block_probe [J]
 // s_memtime stamps around the phases of a window, accumulated per phase by lane 0 of every wavefront of block 0.
 #include <hip/hip_runtime.h>
-__device__ unsigned long long g_acc[5][12];
-#define PIORAN_BSTAMP_DECL unsigned long long wacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long wprev_ = 0; \
+__device__ unsigned long long g_acc[5][16];
+#define PIORAN_BSTAMP_DECL unsigned long long wacc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long wprev_ = 0; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wprev_)::"memory");
 #define PIORAN_BSTAMP(i)                                                                 \
     do {                                                                                 \
@@ -14,7 +14,7 @@ __device__ unsigned long long g_acc[5][12];
         wacc_[i] += t_ - wprev_;                                                         \
         wprev_ = t_;                                                                     \
     } while (0)
-#define PIORAN_BSTAMP_FLUSH if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { for (int i_ = 0; i_ < 12; ++i_) g_acc[threadIdx.x >> 6][i_] = wacc_[i_]; }
+#define PIORAN_BSTAMP_FLUSH if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { for (int i_ = 0; i_ < 16; ++i_) g_acc[threadIdx.x >> 6][i_] = wacc_[i_]; }
 #include "../pioran.jl_amd/csrc/celerite_block.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -41,7 +41,7 @@ int main(int argc, char** argv)
     ScanParams p{}; p.N = N; p.J = J; p.R = R; p.standard_rows = 1; p.B = 1; p.rowmap = drm; p.A = dA; p.Bc = dB;
     p.out = dout; p.status = dst; p.npd_rows = 0;
     for (int rep = 0; rep < 2; ++rep) { pioran_launch_scan_block(p, btab, 0); hipDeviceSynchronize(); }
-    unsigned long long acc[5][12]; double out;
+    unsigned long long acc[5][16]; double out;
     hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_acc), sizeof(acc)); hipMemcpy(&out, dout, 8, hipMemcpyDeviceToHost);
     const char* nm[12] = {"P6 of the previous window (update)", "M' = U~'T, publish, X", "barrier 1", "chain: read M, Gram, Sigma", "chain: Sigma columns from LDS",
                           "chain: LDL' + inverse", "chain: publish L^-1, 1/D, logdet", "rescale T, A and U~ of the next window", "barrier 2",
@@ -51,7 +51,9 @@ int main(int argc, char** argv)
     for (int wv = 0; wv < (R + 1 > 48 ? 5 : 4); ++wv) {
         unsigned long long tot = 0; for (int i = 0; i < 11; ++i) tot += acc[wv][i];
         printf("wavefront %d: %.0f cycles per window (stamps included)\n", wv, (double)tot / nw);
-        for (int i = 0; i < 11; ++i) printf("  %-46s %8.1f\n", nm[i], (double)acc[wv][(i + 0) % 12] / nw);
+        for (int i = 0; i < 11; ++i) printf("  %-46s %8.1f\n", nm[i], (double)acc[wv][i] / nw);
+        printf("    of the rescale / A / U~ phase: rescale T %.1f, A %.1f, U~ and V^ %.1f (the rest: DMA issue)\n", (double)acc[wv][12] / nw,
+               (double)acc[wv][13] / nw, (double)acc[wv][14] / nw);
     }
     return 0;
 }
