@@ -1097,9 +1097,10 @@ using LaunchFn = void (*)(const ScanParams&, dim3, hipStream_t);
 template <int RPL, int CBR, int NSRC, int MINW = 1, bool PAIRED = false>
 void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 {
-    // two-step form: faster wherever its working set fits the register file (RPL <= 3: +10 .. 24 %, tools/sweep_win2.py); with
-    // RPL >= 4 it spills inside the loop and loses 10 %, so there it runs only when forced (context option "win2")
-    if ((RPL <= 3 && !(p.opt && p.opt->no_win2)) || (p.opt && p.opt->win2)) {
+    // two-step form: faster wherever its working set fits the register file (tools/sweep_win2.py: RPL <= 3: +10 .. 24 %;
+    // RPL = 4: +4 .. 6 % with a few spilled registers); with RPL = 5 it loses 7 %, so there it runs only when forced
+    // (context option "win2")
+    if ((RPL <= 4 && !(p.opt && p.opt->no_win2)) || (p.opt && p.opt->win2)) {
         if (p.tab && p.npd_rows > 0)
             hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, true, 0, true>), grid, dim3(256), 0, st, p);
         else if (p.tab)
@@ -1120,7 +1121,7 @@ void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 template <int RPL, int CBR, int NSRC, int MINW, int NPB>
 void launch_blocked(const ScanParams& p, dim3 grid, hipStream_t st)
 {
-    if (p.opt && p.opt->win2)
+    if ((RPL <= 4 && !(p.opt && p.opt->no_win2)) || (p.opt && p.opt->win2))
         hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB, true>), grid, dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB>), grid, dim3(256), 0, st, p);

@@ -14,7 +14,9 @@ import bench  # noqa: E402  (scan_source_hash)
 src = Path(sys.argv[1]) if len(sys.argv) > 1 else root / "gpurun_out" / "r02"
 prof = root / "profiles"
 for tag, basis in (("sho", "SHO"), ("drwcelerite", "DRWCelerite")):
-    ks = glob.glob(str(src / f"trace_{tag}" / "**" / "*kernel_stats.csv"), recursive=True)[0]
+    found = glob.glob(str(src / f"trace_{tag}" / "**" / "*kernel_stats.csv"), recursive=True)
+    assert len(found) == 1, f"{len(found)} kernel-trace summaries under {src}/trace_{tag}: remove gpurun_out/r02 before a new tools/run_profiles.sh run"
+    ks = found[0]
     shutil.copy(ks, prof / f"r02_bench_{tag}20_b4096_kernel_stats.csv")
     line = [ln for ln in (src / f"bench_plain_{tag}.json").read_text().splitlines() if ln.startswith("{")][-1]
     plain = json.loads(line)
