@@ -262,11 +262,16 @@ __device__ __forceinline__ void dma_pieces(const double* gsrc, double* ldst, int
 // EDBL: E has two LDS buffers as well (when it fits): then every piece of record k + 2 may be copied by any wavefront once barrier 1
 // of window k has passed, and the copies are spread over all wavefronts (a piece costs its issuer ~150 cycles); with a single E
 // buffer a wavefront refills exactly the E pieces that only it reads.
+// With four block columns (always a single E buffer) the workgroup is filled up to eight wavefronts with COPY wavefronts that do
+// nothing but issue the LDS DMA of record k + 2 between the barriers (a piece costs its issuer ~150 cycles, ~100 pieces per window: too
+// much for the computing wavefronts' slack).
 template <int NB, bool EDBL>
-__global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
+__global__ void __launch_bounds__(NB < 4 ? 256 : 512, NB < 4 ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
 {
-    constexpr int NWV = NB < 4 ? 4 : 5;     // wavefronts per workgroup
-    constexpr int CH = NWV - 1;             // the chain wavefront
+    constexpr int NCW = NB < 4 ? 4 : 5;     // computing wavefronts: owners + chain
+    constexpr bool COPYW = NB == 4;         // copy wavefronts (these shapes fill a CU's LDS with one workgroup anyway)
+    constexpr int NWV = COPYW ? 8 : NCW;    // wavefronts per workgroup
+    constexpr int CH = NCW - 1;             // the chain wavefront
     constexpr int TS = 3 * NB * 256 + 16 * NB + 16, TSP = (TS + 127) & ~127;
     extern __shared__ double lds_[];
     const int tid = threadIdx.x;
@@ -533,9 +538,7 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
                 const int lo = np_chain + (w == 0 ? 0 : w == 1 ? unit : w == 2 ? 2 * unit : 4 * unit);
                 const int hi = w == 0 ? np_chain + unit : w == 1 ? np_chain + 2 * unit : (w == 2 && NWV == 5) ? np_chain + 4 * unit : np_all;
                 for (int c = lo; c < hi; ++c) copy_piece(c);
-            } else if constexpr (SPLIT4) {
-                for (int t = tpar; t < J; t += 2) copy_piece(np_tile + 2 * t + (w & 1));
-            } else {
+            } else if constexpr (!COPYW) {
                 if (w < 2)
                     for (int t = 0; t < J; ++t) copy_piece(np_tile + 2 * t + w);
             }
@@ -543,9 +546,23 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
         PIORAN_BSTAMP(7);
         PIORAN_BLK_BARRIER();   // B2: L^-1, 1/D published
         PIORAN_BSTAMP(8);
-        if (chain && k + 2 < NW) {   // the chain wavefront idles until the next barrier 1: its share of record k + 2 (one E buffer:
-                                     // the tile, free since barrier 1; measured: better there than on the owners)
-            for (int c = 0; c < (EDBL ? np_chain : np_tile); ++c) copy_piece(c);
+        const int nt_chain = 0;   // with copy wavefronts the chain wavefront issues none (measured: 0, 6, 12 pieces: 2.61, 2.67, 2.64 ms)
+        // the chain wavefront idles until the next barrier 1: its share of record k + 2 (issued right away: the copies then have
+        // the whole Y^ / update / M' stretch to land; issued after its own LDS reads below they land too late for barrier 1)
+        if (chain && k + 2 < NW) {
+            for (int c = 0; c < (EDBL ? np_chain : (COPYW ? nt_chain : np_tile)); ++c) copy_piece(c);
+        }
+        // copy wavefronts (one E buffer): everything else, E(k + 1) and tile k being consumed since this barrier; a quarter of the
+        // share before barrier 3, which follows within ~1000 cycles, the rest after it
+        int c_copy = 0, c_step = 1, c_mid = 0;
+        if constexpr (COPYW) {
+            if (w >= NCW) {
+                c_step = NWV - NCW;
+                c_copy = nt_chain + (w - NCW);
+                c_mid = c_copy + ((np_all - c_copy) / c_step / 4) * c_step;
+                if (k + 2 < NW)
+                    for (; c_copy < c_mid; c_copy += c_step) copy_piece(c_copy);
+            }
         }
         // ---- Y^' = L^-1 X' --------------------------------------------------------------------------------------------
         double ysc[4];
@@ -571,6 +588,10 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 2) celerite_block_kernel(c
         PIORAN_BSTAMP(9);
         PIORAN_BLK_BARRIER();   // B3: Y^' published
         PIORAN_BSTAMP(10);
+        if constexpr (COPYW) {
+            if (w >= NCW && k + 2 < NW)
+                for (; c_copy < np_all; c_copy += c_step) copy_piece(c_copy);
+        }
         // ---- T += Y^ D^-1 Y^' -----------------------------------------------------------------------------------------
         if (owner) {
             double ya[NB][4];
@@ -633,7 +654,7 @@ int launch_block2(const ScanParams& p, const double* btab, hipStream_t stream)
             return PIORAN_ERR_HIP;
         granted[dev] = lds;
     }
-    hipLaunchKernelGGL((celerite_block_kernel<NB, EDBL>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 320), lds, stream, p, btab);
+    hipLaunchKernelGGL((celerite_block_kernel<NB, EDBL>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 

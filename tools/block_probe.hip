@@ -2,7 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/block_probe.hip -o tools/block_probe && tools/block_probe [J]
 // s_memtime stamps around the phases of a window, accumulated per phase by lane 0 of every wavefront of block 0.
 #include <hip/hip_runtime.h>
-__device__ unsigned long long g_acc[5][16];
+__device__ unsigned long long g_acc[8][16];
 #define PIORAN_BSTAMP_DECL unsigned long long wacc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long wprev_ = 0; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wprev_)::"memory");
 #define PIORAN_BSTAMP(i)                                                                 \
@@ -41,7 +41,7 @@ int main(int argc, char** argv)
     ScanParams p{}; p.N = N; p.J = J; p.R = R; p.standard_rows = 1; p.B = 1; p.rowmap = drm; p.A = dA; p.Bc = dB;
     p.out = dout; p.status = dst; p.npd_rows = 0;
     for (int rep = 0; rep < 2; ++rep) { pioran_launch_scan_block(p, btab, 0); hipDeviceSynchronize(); }
-    unsigned long long acc[5][16]; double out;
+    unsigned long long acc[8][16]; double out;
     hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_acc), sizeof(acc)); hipMemcpy(&out, dout, 8, hipMemcpyDeviceToHost);
     const char* nm[12] = {"P6 of the previous window (update)", "M' = U~'T, publish, X", "barrier 1", "chain: read M, Gram, Sigma", "chain: Sigma columns from LDS",
                           "chain: LDL' + inverse", "chain: publish L^-1, 1/D, logdet", "rescale T, A and U~ of the next window", "barrier 2",
