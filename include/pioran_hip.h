@@ -70,7 +70,7 @@ int pioran_ctx_trim(pioran_ctx* ctx);
  *   "no_wide" / "no_block" / "no_paired" / "no_mixed" / "force_fallback"   value "1" disables the latency layout / the windowed
  *                     small-batch kernel / the column-paired variants / the mixed shared+per-draw table / sends everything through
  *                     the any-rank kernel; NULL, "" or "0" = off.
- *   "win2" / "no_win2"  force / forbid the two-step form of the throughput layouts (default: on up to three rows per lane)
+ *   "win2" / "no_win2"  force / forbid the two-step form of the throughput layouts (default: on up to four rows per lane, i.e. R <= 63)
  * Initial values come from the environment variables PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_BLOCK, PIORAN_NO_PAIRED,
  * PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK, PIORAN_WIN2, PIORAN_NO_WIN2, read once when the context is created. */
 int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value);
@@ -179,7 +179,7 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
  *       model that transforms the data per draw (the sampled shift of docs/src/ultranest.md:199-205) chains through.
  * C, Dd: [J] when cd_shared != 0, else [B][J] (each draw is then evaluated as its own one-draw batch).
  * Memory: the forward pass keeps the R x R state only at checkpoints (every ~2 sqrt(N) steps) and the reverse pass replays one
- * segment at a time: ~8 MB of workspace per draw at N = 1e4, J = 20; draws are processed in chunks sized to the free memory.
+ * segment at a time: ~15 MB of workspace per draw at N = 1e4, J = 20 (two replayed segments + checkpoints 11 MB, stored m / D 4 MB: pioran_grad_workspace_doubles); draws are processed in chunks sized to the free memory.
  * The workspace stays in the context for the next call; pioran_ctx_trim releases it. */
 int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
                               const double* Dd, int cd_shared, const double* mu, const double* nu, double* out,

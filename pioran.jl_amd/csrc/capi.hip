@@ -94,6 +94,8 @@ int ensure(pioran_ctx* ctx, pioran_ctx::Buf& b, size_t bytes)
     b.cap = 0;
     size_t want = bytes + (bytes < (size_t(1) << 28) ? bytes / 4 : 0) + 256;   // growth slack for small buffers only
     if (hipMalloc(&b.p, want) != hipSuccess) {
+        (void)hipGetLastError();   // the failure is reported through the return code: do not leave it sticky for the callers'
+                                   // shrink-and-retry loops (a later launch wrapper would read it as its own error)
         b.p = nullptr;
         ctx->last_err = "hipMalloc failed";
         return PIORAN_ERR_ALLOC;
@@ -105,12 +107,37 @@ int ensure(pioran_ctx* ctx, pioran_ctx::Buf& b, size_t bytes)
 // stream synchronisation + delivery of the results staged in pinned memory + reset of the staging allocator
 int ctx_sync(pioran_ctx* ctx)
 {
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        // nothing is delivered after a failed synchronisation, and nothing may be delivered LATER either: the caller's
+        // buffers are only valid for the duration of the call that queued them
+        ctx->pending.clear();
+        ctx->pin_off = 0;
+        ctx->last_err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e);
+        return PIORAN_ERR_HIP;
+    }
     for (const auto& q : ctx->pending) std::memcpy(q.host, q.pinned, q.bytes);
     ctx->pending.clear();
     ctx->pin_off = 0;
     return PIORAN_OK;
 }
+
+// Every host-pointer entry opens with one of these: result deliveries queued by download() refer to memory the caller
+// owns only until the entry returns, so an entry that leaves early (any error between download() and the final SYNC)
+// must not leave them behind for the next successful ctx_sync of some later call.  On the normal path the queue is
+// already empty when the guard runs.
+struct PendingGuard {
+    pioran_ctx* ctx;
+    explicit PendingGuard(pioran_ctx* c) : ctx(c) {}
+    ~PendingGuard()
+    {
+        if (ctx && !ctx->pending.empty()) {
+            (void)hipStreamSynchronize(ctx->stream);   // the staged copies may still be in flight: the pinned slots are reused
+            ctx->pending.clear();
+            ctx->pin_off = 0;
+        }
+    }
+};
 #define SYNC(ctx)                      \
     do {                               \
         int rc_sync_ = ctx_sync(ctx);  \
@@ -622,19 +649,23 @@ static int prepare_shared(pioran_ds* ds, int64_t B, int64_t J, const double* Bc,
 // Returns 1 if it handled the batch, 0 if this layout is not worth / not able to run mixed (caller takes the generic path).
 struct MixedChunk { const double *A, *Bc, *C, *D, *mu, *nu, *Y, *S2; };
 static int mixed_core(pioran_ds* ds, int64_t B, int64_t J, const std::vector<int32_t>& kind, const double* C0, const double* D0,
-                      const std::function<int(int64_t, int64_t, MixedChunk&)>& fetch, double* out, int32_t* status)
+                      const std::function<int(int64_t, int64_t, MixedChunk&)>& fetch, double* out, int32_t* status,
+                      bool must_run = false)
 {
     pioran_ctx* ctx = ds->ctx;
     PrepState& s = ds->host;
     int64_t npd = 0, rows = 0;
     for (int64_t j = 0; j < J; ++j) { npd += kind[j] == 2; rows += kind[j] == 1 ? 1 : 2; }
-    if (npd == 0 || npd > 8 || npd * 2 > J) return 0;   // all shared is handled by the caller; many per-draw terms: generic
+    // all shared is handled by the caller; many per-draw terms: the generic per-draw path is as good.  must_run: the caller has
+    // no generic path to fall back to (theta entry: the continuum's (c, d) exist only as a shared table), so the two
+    // "not worth it" cuts — a performance heuristic, not a kernel constraint — are skipped
+    if (npd == 0 || npd > 8 || (!must_run && npd * 2 > J)) return 0;
     if (rows > pioran_scan_supported_rows()) return 0;
     const int64_t rs_shared = 3 * (rows + 2) + 2;               // shared part of a step record (doubles)
     // combined table: (N+1) records of rs_shared + chunk * 2 npd * 3 doubles, addressed with 32-bit byte offsets
     int64_t chunk = ((int64_t)0x7fff0000 / ((ds->N + 1) * 8) - rs_shared) / (6 * npd);
-    chunk = chunk > B ? B : chunk & ~(int64_t)15;
-    if (chunk < 16) return 0;
+    chunk = chunk > B ? B : (chunk >= 16 ? chunk & ~(int64_t)15 : chunk);
+    if (chunk < 1 || (!must_run && chunk < 16)) return 0;
     int rc;
     if ((rc = prepare_state(ds, s, J, C0, D0, kind.data()))) return rc;
     const int64_t rec_stride = rs_shared + chunk * 6 * npd;
@@ -721,6 +752,7 @@ static int batch_host_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A,
     if ((Y == nullptr) != (S2 == nullptr)) return PIORAN_ERR_ARG;
     pioran_ctx* ctx = ds->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    PendingGuard pending_guard(ctx);
     const size_t bj = (size_t)B * (size_t)J * sizeof(double);
     const size_t bn = (size_t)B * (size_t)ds->N * sizeof(double);
     int rc;
@@ -822,6 +854,7 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
     if (n_qpo < 0 || n_qpo > 8 || (n_qpo > 0 && !qpo)) return PIORAN_ERR_ARG;
     pioran_ctx* ctx = ds->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    PendingGuard pending_guard(ctx);
     const int P = model == 0 ? 3 : 5;
     const int64_t J = n_components, Jc = basis == 0 ? J : 2 * J, Jt = Jc + n_qpo;
     std::vector<double> sp, LU, c, d;
@@ -890,7 +923,7 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
             if (shift) { m.Y = (const double*)ctx->bY.p + b0 * ds->N; m.S2 = (const double*)ctx->bS2.p + b0 * ds->N; }
             return PIORAN_OK;
         };
-        rc = mixed_core(ds, B, Jt, kind, c0.data(), d0.data(), fetch, out, status);
+        rc = mixed_core(ds, B, Jt, kind, c0.data(), d0.data(), fetch, out, status, /*must_run=*/true);
         if (rc < 0) return rc;
         if (rc == 0) return PIORAN_ERR_UNSUPPORTED;   // too many rows for the register-resident kernels
     } else {
@@ -944,6 +977,7 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
     pioran_ctx* ctx = ds->ctx;
     PrepState& s = ds->host;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    PendingGuard pending_guard(ctx);
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
     if (s.R > pioran_wide_supported_rows() || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
@@ -1001,10 +1035,11 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
     pioran_ctx* ctx = ds->ctx;
     PrepState& s = ds->host;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    PendingGuard pending_guard(ctx);
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
     if (s.R > 79 || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
-    // Workspace per draw: (m, D) of every step + S at the checkpoints + one replayed segment (celerite_wide.hip): ~8 MB at
+    // Workspace per draw: (m, D) of every step + S at the checkpoints + two replayed segments (celerite_wide.hip): ~15 MB at
     // N = 1e4, R = 40.  The chunk is bounded by half of the memory that is free right now (plus what this buffer already
     // holds) and halved again if the allocation still fails.
     int64_t chunk = B < 1024 ? B : 1024;
@@ -1301,6 +1336,7 @@ static int dense_nll_impl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a
     if (!ctx || N < 1 || J < 1 || !a || !b || !c || !d || !t || !y || !sigma2 || !out) return PIORAN_ERR_ARG;
     if (N > 46000) return PIORAN_ERR_UNSUPPORTED;  // slab would exceed ~17 GB
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    PendingGuard pending_guard(ctx);
     double* dv[9];
     int rc = dense_stage(ctx, N, J, a, b, c, d, t, y, sigma2, dv);
     if (rc) return rc;
@@ -1332,6 +1368,7 @@ int pioran_dense_nll_batch(pioran_ctx* ctx, int64_t N, int64_t J, int64_t B, con
     if (!ctx || N < 1 || J < 1 || B < 1 || !A || !Bc || !C || !Dd || !t || !y || !sigma2 || !out) return PIORAN_ERR_ARG;
     if (N > 46000) return PIORAN_ERR_UNSUPPORTED;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    PendingGuard pending_guard(ctx);
     int rc;
     int64_t Mp, ld;
     pioran_dense_dims(N, &Mp, &ld);
@@ -1401,6 +1438,7 @@ static int dense_predict_impl(pioran_ctx* ctx, int64_t N, int64_t J, const doubl
     const int64_t Mp = (N + 63) / 64 * 64, Mq = (M + 63) / 64 * 64, Mtot = Mp + Mq;
     if (Mtot > 46000) return PIORAN_ERR_UNSUPPORTED;  // slab would exceed ~17 GB
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    PendingGuard pending_guard(ctx);
     // [t | NaN padding | tau | NaN padding]: a NaN time is an identity row/column of the augmented matrix
     std::vector<double> te((size_t)Mtot, std::nan("")), s2e((size_t)Mtot, 0.0), ye((size_t)Mtot, 0.0);
     std::memcpy(te.data(), t, (size_t)N * sizeof(double));

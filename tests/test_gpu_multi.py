@@ -29,18 +29,34 @@ def _free_port():
     return p
 
 
-def _bench(n, extra=()):
+def _bench(n, extra=(), steps=3):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     base = [sys.executable]
     if n > 1:
         base += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
                  "--master-port", str(_free_port())]
-    cmd = base + [str(ROOT / "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+    cmd = base + [str(ROOT / "bench.py"), "--gpus", str(n), "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline",
                   "--no-secondary", *extra]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     return json.loads(line)
+
+
+def test_bench_multi_rank_loop_two_ranks_on_one_gpu():
+    """bench.py's multi-rank loop (double-buffered scan / gather, slice check, --verify-gather, MAX-reduced timing) run for real
+    on ONE GPU: two ranks under torch.distributed.run, both on cuda:0, log-L gathered over gloo (RCCL refuses two ranks on
+    one device; the transport is the only difference from the 8-GPU run).  A fresh child process — pytest is never replaced."""
+    one = _bench(1, ["--batch", "1024"], steps=4)
+    two = _bench(2, ["--dist-backend", "gloo", "--device", "0", "--batch", "1024", "--verify-gather"], steps=4)
+    assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 2048 and two["steps"] == 4
+    assert two["gather_verified"] is True          # rank 1's slice == a single-process evaluation of rank 1's batch, bit for bit
+    assert two["status_ok_frac"] > 0.9
+    assert "gloo" in two["config"]["parallelism"]
+    # both ranks share one GPU, so whole-job throughput is about the one-rank figure (not twice it); the timed region must
+    # cover both ranks' work: value = global draws / MAX-over-ranks time
+    assert 0.4 * one["value"] < two["value"] < 2.5 * one["value"], (one["value"], two["value"])
+    assert two["ms_per_step"] >= 0.8 * one["ms_per_step"]
 
 
 @pytest.mark.skipif(NGPU < 2, reason="needs at least two GPUs (RCCL ranks)")

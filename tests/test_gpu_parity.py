@@ -107,7 +107,7 @@ def _random_case(rng, N, J, B, per_draw_cd=False):
 def layout(request, ctx):
     """Small batches (B <= 512) with 6 <= R <= 63 rows take the windowed kernel (celerite_block.hip) by default; "no_block" sends
     them to the one-draw-per-workgroup latency layout (celerite_wide.hip), "no_wide" as well to the throughput layouts (the ones
-    large batches use).  The throughput layouts run the two-step form up to three rows per lane and the step-by-step recurrence
+    large batches use).  The throughput layouts run the two-step form up to four rows per lane (R <= 63) and the step-by-step recurrence
     above ("no_win2" / "win2" force either everywhere).  All are checked on the same inputs."""
     if request.param != "block":
         ctx.set_option("no_block", True)
@@ -505,6 +505,14 @@ def test_dense_full_size_relation(ctx, full_size):
     cel = pj.log_likelihood(R, t, y - mu, yerr ** 2, ctx=ctx)
     assert info == 0
     assert abs(cel + den) <= 1e-8 * abs(den)
+    # ... and BOTH against the CPU oracle at this size (one evaluation, ~30 ms): anchors the 80-row celerite_wide_kernel<6> and
+    # the MFMA Cholesky at length, not only against each other
+    ref = O.logl(R.a, R.b, R.c, R.d, t, y - mu, yerr ** 2)
+    assert abs(cel - ref) <= 1e-8 * abs(ref), (cel, ref)
+    assert abs(-den - ref) <= 1e-8 * abs(ref), (den, ref)
+    # the throughput shape for 80 rows would be the any-rank kernel; the batch entry at B = 3 takes the same latency layout
+    got3 = pj.Dataset(t, y, yerr ** 2, ctx).logl_batch(np.tile(R.a, (3, 1)), np.tile(R.b, (3, 1)), R.c, R.d, mu=np.full(3, mu))
+    assert np.max(np.abs(got3 - ref)) <= 1e-8 * abs(ref)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -716,6 +724,13 @@ def test_device_approx_with_qpo_features(ctx, golden_dir, basis, integ, nq):
     assert relerr(got, ref) < 1e-9
     host = ds.logl_batch(Ah, Bh, C, D, mu=mu, nu=nu)       # coefficient-level entry, mixed mode on its own detection
     assert relerr(host, ref) < 1e-10
+    # a single evaluation and a handful of walkers: the theta entry has no generic per-draw path to fall back to, so the mixed
+    # core must run for ANY batch size (the reference evaluates such models one draw at a time; round 2 returned UNSUPPORTED
+    # below 16 draws)
+    for nb in (1, 8):
+        small, sst = ds.logpdf_theta(pj.SingleBendingPowerLaw, th[:nb], var[:nb], f_min, f_max, 20, is_integrated_power=integ,
+                                     basis_function=basis, mu=mu[:nb], nu=nu[:nb], qpo=qpo[:nb], return_status=True)
+        assert (sst == 0).all() and relerr(small, ref[:nb]) < 1e-9
     # shifted log-flux series on top
     ys = y - y.min() + 1.0
     ds2 = pj.Dataset(t, ys, yerr ** 2, ctx)

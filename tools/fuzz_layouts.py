@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """GPU: randomized comparison of the windowed kernel and the throughput scan (two-step form) against the CPU oracle — random
 term counts (1..31, some of them one-row terms), series lengths 1..700 with occasional long gaps, batch sizes, optional mu / nu /
-per-draw series.  usage: python tools/fuzz_layouts.py [seconds]   (round 2: 26 533 cases in 150 s, worst relative deviation
-2.6e-9, no status / NaN mismatch)"""
-import sys, time
-from pathlib import Path
-import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-import pioran_jl_amd as pj
-from oracle import oracle as O
+per-draw series.  Every case is generated from (seed, index) alone, so the worst ones can be regenerated anywhere (also on a
+box without a GPU, for an extended-precision look at them: tools/explain_outliers.py).
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 150.0
-ctx = pj.Context(0)
-rng = np.random.default_rng(20261003)
-worst = 0.0; n_bad = 0; t0 = time.time(); it = 0
-while time.time() - t0 < budget:
-    it += 1
+usage: python tools/fuzz_layouts.py [seconds] [--dump gpurun_out/fuzz_worst.json]
+  round 2: 26 533 cases in 150 s, worst relative deviation 2.6e-9, no status / NaN mismatch
+tests/test_gpu_fuzz.py runs a case-bounded slice of the same generator under -m gpu."""
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+
+SEED = 20261003
+LAYOUTS = (("block", "block"), ("scan", None))
+
+
+def make_case(seed: int, idx: int) -> dict:
+    rng = np.random.default_rng([seed, idx])
     J = int(rng.integers(1, 32)); N = int(rng.integers(1, 700)); B = int(rng.integers(1, 40))
     nreal = int(rng.integers(0, J + 1)) if rng.random() < 0.4 else 0
     t = np.cumsum(rng.uniform(0.01, 3.0, N) * (rng.random(N) < 0.9) + rng.uniform(0, 40, N) * (rng.random(N) < 0.05) + 1e-3)
@@ -25,25 +31,74 @@ while time.time() - t0 < budget:
     Bc[:, :nreal] = 0.0; Dd[:nreal] = 0.0
     mu = rng.standard_normal(B) * 0.1 if rng.random() < 0.7 else None
     nu = rng.uniform(0.5, 2.0, B) if rng.random() < 0.7 else None
-    useY = rng.random() < 0.3
+    useY = bool(rng.random() < 0.3)
     Y = rng.standard_normal((B, N)) if useY else None
     S2 = rng.uniform(1e-4, 0.1, (B, N)) if useY else None
-    ds = pj.Dataset(t, y, s2, ctx)
+    return dict(idx=idx, J=J, N=N, B=B, nreal=nreal, useY=useY, t=t, y=y, s2=s2, A=A, Bc=Bc, C=C, Dd=Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+
+
+def draw_series(c: dict, i: int):
+    """(y - mu, nu * sigma2) of draw i: what the reference's logl is called with (src/scalable_GP.jl:163-165)."""
+    m = c["mu"][i] if c["mu"] is not None else 0.0
+    v = c["nu"][i] if c["nu"] is not None else 1.0
+    return (c["Y"][i] if c["useY"] else c["y"]) - m, v * (c["S2"][i] if c["useY"] else c["s2"])
+
+
+def oracle_values(O, c: dict) -> np.ndarray:
+    out = np.empty(c["B"])
+    for i in range(c["B"]):
+        ys, ss = draw_series(c, i)
+        out[i] = O.logl(c["A"][i], c["Bc"][i], c["C"], c["Dd"], c["t"], ys, ss)
+    return out
+
+
+def gpu_values(pj, ctx, c: dict) -> dict:
+    ds = pj.Dataset(c["t"], c["y"], c["s2"], ctx)
     res = {}
-    for name, cfg in (("block", "block"), ("scan", None)):
-        ctx.set_option("scan_config", cfg); ctx.set_option("no_block", cfg is None); ctx.set_option("no_wide", cfg is None)
-        res[name] = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2, return_status=True)
-    ctx.set_option("scan_config", None); ctx.set_option("no_block", False); ctx.set_option("no_wide", False)
-    m = mu if mu is not None else np.zeros(B); v = nu if nu is not None else np.ones(B)
-    ref = np.array([O.logl(A[i], Bc[i], C, Dd, t, (Y[i] if useY else y) - m[i], v[i] * (S2[i] if useY else s2)) for i in range(B)])
-    for name, (got, st) in res.items():
-        ok = np.isfinite(ref) & (st == 0)
-        if ok.any():
-            e = np.max(np.abs(got[ok] - ref[ok]) / np.maximum(1.0, np.abs(ref[ok])))
-            worst = max(worst, e)
-            if e > 1e-8:
-                n_bad += 1; print("BAD", name, J, N, B, nreal, useY, e, flush=True)
-        if (np.isnan(got) != np.isnan(ref)).any():
-            n_bad += 1; print("NaN mismatch", name, J, N, B, nreal, flush=True)
-print("cases", it, "worst relative deviation", worst, "failures", n_bad)
-sys.exit(1 if n_bad else 0)
+    try:
+        for name, cfg in LAYOUTS:
+            ctx.set_option("scan_config", cfg); ctx.set_option("no_block", cfg is None); ctx.set_option("no_wide", cfg is None)
+            res[name] = ds.logl_batch(c["A"], c["Bc"], c["C"], c["Dd"], mu=c["mu"], nu=c["nu"], Y=c["Y"], S2=c["S2"], return_status=True)
+    finally:
+        ctx.set_option("scan_config", None); ctx.set_option("no_block", False); ctx.set_option("no_wide", False)
+    return res
+
+
+def fuzz(pj, O, ctx, seed=SEED, ncases=None, seconds=None, first=0, keep=8):
+    """Runs cases first, first + 1, ... until `ncases` are done or `seconds` have passed.  Returns a summary: the number of
+    cases, the worst deviation relative to max(1, |log L|), the `keep` worst (case, layout, draw) records, the failures."""
+    t0 = time.time(); it = 0; worst = []; failures = []
+    while (ncases is None or it < ncases) and (seconds is None or time.time() - t0 < seconds):
+        c = make_case(seed, first + it); it += 1
+        ref = oracle_values(O, c)
+        for name, (got, st) in gpu_values(pj, ctx, c).items():
+            ok = np.isfinite(ref) & (st == 0)
+            if (np.isnan(got) != np.isnan(ref)).any():
+                failures.append(dict(kind="nan-mismatch", layout=name, idx=c["idx"], J=c["J"], N=c["N"], B=c["B"], nreal=c["nreal"]))
+            if not ok.any():
+                continue
+            dev = np.where(ok, np.abs(got - ref) / np.maximum(1.0, np.abs(ref)), 0.0)
+            i = int(np.argmax(dev))
+            rec = dict(dev=float(dev[i]), layout=name, idx=c["idx"], draw=i, J=c["J"], N=c["N"], B=c["B"], nreal=c["nreal"], useY=c["useY"],
+                       got=float(got[i]), oracle=float(ref[i]))
+            worst.append(rec); worst.sort(key=lambda r: -r["dev"]); del worst[keep:]
+            if rec["dev"] > 1e-8:
+                failures.append(dict(kind="deviation", **rec))
+    return dict(seed=seed, first=first, cases=it, seconds=time.time() - t0, worst_dev=worst[0]["dev"] if worst else 0.0, worst=worst,
+                failures=failures)
+
+
+if __name__ == "__main__":
+    import pioran_jl_amd as pj
+    from oracle import oracle as O
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    budget = float(args[0]) if args else 150.0
+    s = fuzz(pj, O, pj.Context(0), seconds=budget)
+    for r in s["worst"]:
+        print("worst", r)
+    for f in s["failures"]:
+        print("BAD", f, flush=True)
+    print("cases", s["cases"], "worst relative deviation", s["worst_dev"], "failures", len(s["failures"]))
+    if "--dump" in sys.argv:
+        Path(sys.argv[sys.argv.index("--dump") + 1]).write_text(json.dumps(s, indent=1))
+    sys.exit(1 if s["failures"] else 0)
