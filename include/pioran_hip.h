@@ -52,7 +52,7 @@ typedef struct pioran_ds pioran_ds;   /* a time series resident in HBM + its cac
 const char* pioran_strerror(int code);
 const char* pioran_last_hip_error(const pioran_ctx* ctx);
 /* ABI version of this header (bumped on any signature change). */
-int pioran_abi_version(void);   /* currently 5 */
+int pioran_abi_version(void);   /* currently 6 */
 
 /* ---- context ------------------------------------------------------------------------------- */
 /* Creates a context on GPU `device` with its own non-blocking stream. */
@@ -71,6 +71,7 @@ int pioran_ctx_trim(pioran_ctx* ctx);
  *                     small-batch kernel / the column-paired variants / the mixed shared+per-draw table / sends everything through
  *                     the any-rank kernel; NULL, "" or "0" = off.
  *   "win2" / "no_win2"  force / forbid the two-step form of the throughput layouts (default: on up to four rows per lane, i.e. R <= 63)
+ *   "wide2" / "no_wide2"  force / forbid the lean form of the latency layout (default: from 64 rows on; the only form for 96 .. 143 rows)
  * Initial values come from the environment variables PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_BLOCK, PIORAN_NO_PAIRED,
  * PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK, PIORAN_WIN2, PIORAN_NO_WIN2, read once when the context is created. */
 int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value);
@@ -208,8 +209,10 @@ const char* pioran_celerite_config_name(int64_t R);
  * one resident copy of the data set per listed device, one host thread per device per call.  Draws are independent, so
  * the batch is cut into contiguous shards (the first B % ngpu devices get one more draw) and every device writes its
  * slice of out/status directly — there is no collective.  `devices` may list a device more than once.
- * Arguments of pioran_farm_logl_batch are those of pioran_celerite_logl_batch[_shift] (shift may be NULL; Y/S2 per-draw
- * series are not supported here). */
+ * Arguments of pioran_farm_logl_batch are those of pioran_celerite_logl_batch[_shift] (shift may be NULL);
+ * pioran_farm_logl_batch_series takes per-draw series Y, S2 [B][N] instead (the models with a sampled mean FUNCTION, e.g. the
+ * sinusoid of examples/ultranest/single_pl_periodicity.jl:115: CustomMean makes y - mean(t) a per-draw series): every device
+ * receives the rows of its shard. */
 typedef struct pioran_farm pioran_farm;
 int pioran_farm_create(int ngpu, const int* devices, int64_t N, const double* t, const double* y,
                        const double* sigma2, pioran_farm** out);
@@ -218,6 +221,9 @@ int pioran_farm_size(const pioran_farm* farm);
 int pioran_farm_logl_batch(pioran_farm* farm, int64_t B, int64_t J, const double* A, const double* Bc,
                            const double* C, const double* Dd, int cd_shared, const double* mu, const double* nu,
                            const double* shift, double* out, int32_t* status);
+int pioran_farm_logl_batch_series(pioran_farm* farm, int64_t B, int64_t J, const double* A, const double* Bc,
+                                  const double* C, const double* Dd, int cd_shared, const double* mu, const double* nu,
+                                  const double* Y, const double* S2, double* out, int32_t* status);
 
 /* ---- dense solver ---------------------------------------------------------------------------- */
 /* log_likelihood_direct (src/direct_solver.jl:6-21): builds K_ik = sum_j k_j(|t_i - t_k|) +

@@ -56,6 +56,8 @@ SIGNATURES = {
     "pioran_farm_size": (ctypes.c_int, [c_void_p]),
     "pioran_farm_logl_batch": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pioran_farm_logl_batch_series": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int,
+                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pioran_dense_nll": (ctypes.c_int, [c_void_p, i64, i64] + [c_void_p] * 7 + [c_void_p, c_void_p]),
     "pioran_dense_nll_batch": (ctypes.c_int, [c_void_p, i64, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -328,7 +328,7 @@ const char* pioran_strerror(int code)
 
 const char* pioran_last_hip_error(const pioran_ctx* ctx) { return ctx ? ctx->last_err.c_str() : ""; }
 
-int pioran_abi_version(void) { return 5; }
+int pioran_abi_version(void) { return 6; }
 
 int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
 {
@@ -346,6 +346,8 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "no_block")) o.no_block = on;
     else if (!std::strcmp(key, "win2")) o.win2 = on;
     else if (!std::strcmp(key, "no_win2")) o.no_win2 = on;
+    else if (!std::strcmp(key, "wide2")) o.wide2 = on;
+    else if (!std::strcmp(key, "no_wide2")) o.no_wide2 = on;
     else return PIORAN_ERR_ARG;
     return PIORAN_OK;
 }
@@ -368,6 +370,8 @@ static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
     pioran_ctx_set_option(ctx, "no_block", std::getenv("PIORAN_NO_BLOCK"));
     pioran_ctx_set_option(ctx, "win2", std::getenv("PIORAN_WIN2"));
     pioran_ctx_set_option(ctx, "no_win2", std::getenv("PIORAN_NO_WIN2"));
+    pioran_ctx_set_option(ctx, "wide2", std::getenv("PIORAN_WIDE2"));
+    pioran_ctx_set_option(ctx, "no_wide2", std::getenv("PIORAN_NO_WIDE2"));
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
     if (own) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
@@ -1264,11 +1268,13 @@ int pioran_farm_destroy(pioran_farm* f)
 
 int pioran_farm_size(const pioran_farm* f) { return f ? (int)f->ds.size() : PIORAN_ERR_ARG; }
 
-int pioran_farm_logl_batch(pioran_farm* f, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+static int farm_batch_impl(pioran_farm* f, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
                            const double* Dd, int cd_shared, const double* mu, const double* nu, const double* shift,
-                           double* out, int32_t* status)
+                           const double* Y, const double* S2, double* out, int32_t* status)
 {
     if (!f || f->ds.empty() || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !out) return PIORAN_ERR_ARG;
+    if ((Y == nullptr) != (S2 == nullptr) || (Y && shift)) return PIORAN_ERR_ARG;
+    const int64_t N = f->ds[0]->N;
     const int64_t G = (int64_t)f->ds.size();
     const int64_t base = B / G, extra = B % G;
     std::vector<int> rcs(G, PIORAN_OK);
@@ -1285,13 +1291,28 @@ int pioran_farm_logl_batch(pioran_farm* f, int64_t B, int64_t J, const double* A
             rcs[g] = shift ? pioran_celerite_logl_batch_shift(f->ds[g], nb, J, A + lo * J, Bc + lo * J, Cg, Dg, cd_shared, mug,
                                                               nug, shift + lo, out + lo, stg)
                            : pioran_celerite_logl_batch(f->ds[g], nb, J, A + lo * J, Bc + lo * J, Cg, Dg, cd_shared, mug, nug,
-                                                        nullptr, nullptr, out + lo, stg);
+                                                        Y ? Y + lo * N : nullptr, S2 ? S2 + lo * N : nullptr, out + lo, stg);
         });
     }
     for (auto& t_ : th) t_.join();
     for (int rc : rcs)
         if (rc != PIORAN_OK) return rc;
     return PIORAN_OK;
+}
+
+int pioran_farm_logl_batch(pioran_farm* f, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                           const double* Dd, int cd_shared, const double* mu, const double* nu, const double* shift,
+                           double* out, int32_t* status)
+{
+    return farm_batch_impl(f, B, J, A, Bc, C, Dd, cd_shared, mu, nu, shift, nullptr, nullptr, out, status);
+}
+
+int pioran_farm_logl_batch_series(pioran_farm* f, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                                  const double* Dd, int cd_shared, const double* mu, const double* nu, const double* Y,
+                                  const double* S2, double* out, int32_t* status)
+{
+    if (!Y || !S2) return PIORAN_ERR_ARG;
+    return farm_batch_impl(f, B, J, A, Bc, C, Dd, cd_shared, mu, nu, nullptr, Y, S2, out, status);
 }
 
 // ---- dense solver -------------------------------------------------------------------------------

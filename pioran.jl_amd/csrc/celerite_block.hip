@@ -141,10 +141,19 @@ __global__ void __launch_bounds__(256) block_table_kernel(int64_t N, int32_t R, 
             while ((nn + 1) * nn / 2 <= p) ++nn;       // p = nn (nn - 1) / 2 + jj, jj < nn
             const int jj = p - nn * (nn - 1) / 2;
             if (n0 + nn < N) {
-                const double tau = t[n0 + nn] - t[n0 + jj];
-                double si, co;
-                sincos(d[term] * tau, &si, &co);
-                val = exp(-c[term] * tau) * (h ? si : co);
+                // (cos, sin)(d tau) by angle addition from the SAME rounded (cos, sin)(d t) that the u / v fragments above are
+                // made of, not from d * tau directly: the window's own covariance block A must be consistent with the Gram
+                // block G = U~' T U~ it is subtracted from.  The phase d * t_n (up to 1e4 .. 1e7 rad) is rounded to ~1e-12 rad;
+                // the step-by-step recurrence (and the reference) use those rounded phases everywhere, which is a harmless
+                // perturbation of the time stamps — mixing them with the exactly-differenced d * tau left an O(1e-12 a)
+                // mismatch in A - G, i.e. 1e-8 relative in D_n where near-coincident time stamps make D_n ~ 1e-4 a
+                // (tools/explain_outliers.py).
+                const double tn = t[n0 + nn], tj = t[n0 + jj];
+                double sn, cn, sj, cj;
+                sincos(d[term] * tn, &sn, &cn);
+                sincos(d[term] * tj, &sj, &cj);
+                const double trig = h ? fma(sn, cj, -cn * sj) : fma(cn, cj, sn * sj);
+                val = exp(-c[term] * (tn - tj)) * trig;
             }
         }
     }

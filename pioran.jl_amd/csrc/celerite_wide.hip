@@ -400,6 +400,207 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
     }
 }
 
+// ---- lean form of the latency layout (round 3): 64 .. 143 rows ----------------------------------------------------------
+// Same 16 x 16 arrangement, same single LDS exchange per step and the same arithmetic as celerite_wide_kernel<RPL, 0>, but the
+// per-step inputs are prepared ONCE PER SLOT instead of once per lane: thread s < 16 RPL is the "slot thread" of row slot s — it
+// fetches (v, x, phi) of its table row (three coalesced loads per step, DG records ahead), forms u_s = al_s v_s + be_s x_s and
+// publishes (u, v, phi) of the slot; the y slot's thread publishes v = y_n - mu and sigma2_n.  The 256 lanes then read what
+// they need from LDS at the point of use: u, v, phi of their RPL rows and u, phi of their RPL columns (5 RPL values, no x) —
+// where celerite_wide_kernel keeps two register copies of 6 RPL + 2 inputs per lane (152 registers at RPL = 6) and recomputes
+// every u 16 times.  With RPL >= 5 that kernel's loop moves 140 .. 200 values per step between VGPRs and AGPRs; here the
+// registers hold S (RPL x RPL), the row / column vectors of the step and nothing else, which is what makes 7 .. 9 rows per
+// lane (the reference benchmark's j = 64: 128 rows + y, benchmark/benchmarks.jl:16-18) fit at all.
+template <int RPL>
+__global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams p)
+{
+    constexpr int NS = 16 * RPL;                      // row slots; the last one is the y row
+    constexpr int YS = RPL - 1;
+    constexpr int DG = 4;                             // records in flight from HBM per slot thread
+    const int tid = threadIdx.x;
+    const int g = tid >> 4;                           // row block (DPP row of the draw)
+    const int l = tid & 15;                           // column block
+    const int64_t b = blockIdx.x;                     // grid = batch
+    const int64_t N = p.N;
+    const int J = p.J, R = p.R, Rp = R + 2, RS = 3 * Rp + 2;
+
+    __shared__ double sh_rec[2][3 * NS + 2];          // [u x NS | v x NS | phi x NS | sigma2_n], by step parity
+    __shared__ double sh_num[2][NS];                  // (v - q) of every row = D_n w
+    __shared__ double sh_uq[2][16];                   // u'q share of every row block
+
+    double suma = 0.0;  // :21
+    for (int j = 0; j < J; ++j) suma += p.A[b * J + j];
+    const double mu = p.mu ? p.mu[b] : 0.0;
+    const double nu = p.nu ? p.nu[b] : 1.0;
+    const bool has_nu = p.nu != nullptr;
+    const bool yrow = g == 15;                        // this lane's row slot YS is the y row
+
+    // ---- slot threads: sources of (v, x, phi) of slot `tid`; address = src + min(n, last) * stride ----------------------
+    const bool slot_thread = tid < NS;
+    const bool yslot = tid == NS - 1;
+    const double* src[3] = {p.tab, p.tab, p.tab};
+    int64_t stride[3] = {0, 0, 0}, last[3] = {N, N, N};
+    double al = 0.0, be = 0.0;
+    if (slot_thread) {
+        if (yslot) {                                  // v <- y_n, x <- sigma2_n, phi <- the table's y row (1)
+            src[0] = p.Y ? p.Y + b * N : p.tab + 3 * Rp;
+            src[1] = p.S2 ? p.S2 + b * N : p.tab + 3 * Rp + 1;
+            stride[0] = stride[1] = p.Y ? 1 : p.rec_stride;
+            last[0] = last[1] = p.Y ? N - 1 : N;
+            src[2] = p.tab + 2 * Rp + (R + 1);
+            stride[2] = p.rec_stride;
+        } else if (tid < R) {
+            const int rm = p.rowmap[tid];
+            const int term = rm & 0xfffff;
+            const bool ks = (rm >> 30) & 1;
+            const double a = p.A[b * J + term], bb = p.Bc[b * J + term];
+            al = a;                                   // cos row: u = a co + b si ; sin row: u = a si - b co   (:59-63)
+            be = ks ? -bb : bb;
+            if ((rm >> 29) & 1) {                     // per-draw row (mixed mode): [draw][row][v, x, phi] inside the step record
+                const double* base = p.tab + RS + ((int64_t)b * p.npd_rows + ((rm >> 20) & 0x1ff)) * 3;
+                src[0] = base; src[1] = base + 1; src[2] = base + 2;
+            } else {
+                src[0] = p.tab + tid; src[1] = p.tab + tid + Rp; src[2] = p.tab + tid + 2 * Rp;
+            }
+            stride[0] = stride[1] = stride[2] = p.rec_stride;
+        } else {                                      // inert padding slot: the table's padding row (v, x, phi) = (1, 0, 1), u = 0
+            src[0] = p.tab + R; src[1] = p.tab + R + Rp; src[2] = p.tab + R + 2 * Rp;
+            stride[0] = stride[1] = stride[2] = p.rec_stride;
+        }
+    }
+    double gv[DG][3];                                 // record m is (or will be) in gv[m % DG]
+    auto fetch = [&](int64_t m, double (&dst)[3]) __attribute__((always_inline)) {
+        if (slot_thread) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h) dst[h] = src[h][(m < last[h] ? m : last[h]) * stride[h]];
+        }
+    };
+    auto stage = [&](int par, const double (&v)[3]) __attribute__((always_inline)) {
+        if (slot_thread) {
+            double* r = sh_rec[par];
+            r[tid] = yslot ? 0.0 : al * v[0] + be * v[1];
+            r[NS + tid] = yslot ? v[0] - mu : v[0];
+            r[2 * NS + tid] = v[2];
+            if (yslot) r[3 * NS] = has_nu ? nu * v[1] : v[1];
+        }
+    };
+
+#pragma unroll
+    for (int m = 0; m < DG; ++m) fetch(m, gv[m]);
+    stage(0, gv[0]);
+    fetch(DG, gv[0]);
+    __syncthreads();
+
+    // ---- first row, :27-42 and :126-128 ----
+    double S[RPL][RPL];   // [own row][own column]
+#pragma unroll
+    for (int i = 0; i < RPL; ++i)
+#pragma unroll
+        for (int c = 0; c < RPL; ++c) S[i][c] = 0.0;
+    double num[RPL];      // (v - q) of this lane's rows at the last step = D_n W_n, the `dn` of :73
+    double wc[RPL];       // W_n of this lane's columns
+    double Dn = suma + sh_rec[0][3 * NS];
+    double rD = recip_f64(Dn);
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        num[i] = sh_rec[0][NS + g * RPL + i];         // z_1 = y_1 in the y row      :128
+        wc[i] = sh_rec[0][NS + l * RPL + i] * rD;
+    }
+    double Pm = Dn;       // running product of |D| (sign of D_1 kept: log of a negative D_1 is NaN, :126)
+    int Pe = 0;
+    {
+        int ex;
+        Pm = frexp(Pm, &ex);
+        Pe += ex;
+    }
+    double quad = num[YS] * num[YS] * rD;             // meaningful in the y-row lanes only
+    bool nonpd = !(Dn > 0.0);
+    stage(1, gv[1 % DG]);
+    fetch(DG + 1, gv[1 % DG]);
+    __syncthreads();
+
+    // one time step n: consumes the staged record n (parity n & 1); stages record n + 1 and refills its register slot
+    auto do_step = [&](int64_t n, double (&gslot)[3]) __attribute__((always_inline)) {
+        const int par = (int)(n & 1);
+        const double* r = sh_rec[par];
+        double uc[RPL], cp[RPL], rp[RPL], qt[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            uc[i] = r[l * RPL + i];
+            cp[i] = r[2 * NS + l * RPL + i];
+            rp[i] = r[2 * NS + g * RPL + i];
+            qt[i] = 0.0;
+        }
+        // ---- S update + this lane's share of q = S u ----
+#pragma unroll
+        for (int c = 0; c < RPL; ++c)
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const double m = fma(num[i], wc[c], S[i][c]);     // S + dn * V[k,n-1]          :78
+                const double sn = (rp[i] * cp[c]) * m;            // phi_j phi_k ( ... )        :78,85
+                S[i][c] = sn;
+                qt[i] = fma(sn, uc[c], qt[i]);                    // (S u)_j                    :80-82,86-89
+            }
+        double sp = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            qt[i] = row16_sum(qt[i]);                             // over the 16 column blocks
+            num[i] = r[NS + g * RPL + i] - qt[i];                 // :89
+            sp = fma(r[g * RPL + i], qt[i], sp);                  // this row block's share of u'Su   :83,88
+        }
+        const double s2n = r[3 * NS];
+        // ---- the one exchange of the step (+ the next record on its way through LDS) ----
+        if (l == 0) {
+            sh_uq[par][g] = sp;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) sh_num[par][g * RPL + i] = num[i];
+        }
+        stage(par ^ 1, gslot);
+        fetch(n + 1 + DG, gslot);
+        __syncthreads();
+        double sh[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sh[k] = sh_uq[par][k];
+        double nc[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) nc[i] = sh_num[par][l * RPL + i];
+        const double s = (((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]))) +
+                         (((sh[8] + sh[9]) + (sh[10] + sh[11])) + ((sh[12] + sh[13]) + (sh[14] + sh[15])));
+        Dn = suma + s2n - s;                                     // :92
+        rD = recip_f64(Dn);
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) wc[i] = nc[i] * rD;        // :96
+        const double z = num[YS];                                // y row: z_n = y_n - u'f      :141
+        nonpd |= !(Dn > 0.0);
+        Pm *= fabs(Dn);                                          // log(abs(D[n]))  :140
+        {                                                        // mantissa/exponent split
+            int ex;
+            Pm = frexp(Pm, &ex);
+            Pe += ex;
+        }
+        quad = fma(z * z, rD, quad);                             // z_n^2 / D_n  (== y'K^-1 y, :333)
+    };
+
+    int64_t n = 1;
+    // unrolled by DG so that the register slots of the slot threads are compile-time constants: at the loop top n = 1 (mod DG);
+    // step n + k stages record n + k + 1 out of gv[(2 + k) % DG]
+    for (; n + DG - 1 < N; n += DG)
+        static_for<0, DG>([&](auto Kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(Kc)::value;
+            do_step(n + k, gv[(2 + k) % DG]);
+        });
+    static_for<0, DG - 1>([&](auto Kc) __attribute__((always_inline)) {   // the last N - n < DG steps
+        constexpr int k = decltype(Kc)::value;
+        if (n + k < N) do_step(n + k, gv[(2 + k) % DG]);
+    });
+
+    if (yrow && l == 0) {
+        const double logdet = log(Pm) + (double)Pe * 0.6931471805599453094;
+        const double res = -0.5 * logdet - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * quad;
+        p.out[b] = res;
+        if (p.status) p.status[b] = !isfinite(res) ? 2 : (nonpd ? 1 : 0);
+    }
+}
+
 // ---- reverse mode through the recurrence ----------------------------------------------------------------------------
 // log L = -1/2 sum_n (log D_n + z_n^2 / D_n) - N/2 log(2 pi), with per step (rows incl. the y row, u_y = 0, v_y = y_n - mu)
 //   T = S_{n-1} + m_{n-1} m_{n-1}' / D_{n-1}   (m = v - q = D w) ;  S_n = (phi phi') o T ;  q = S_n u_n
@@ -849,7 +1050,10 @@ __global__ void __launch_bounds__(256) grad_finish_kernel(const ScanParams p, in
 
 }  // namespace
 
-int pioran_wide_supported_rows() { return 95; }
+// RPL <= 6 (95 rows): the shapes of rounds 1-2.  RPL 7 .. 9 (up to 143 rows, round 3): 49 .. 81 entries of S per lane, one
+// wavefront per SIMD with the 512-register budget — the reference's own benchmark grid goes up to j = 64 terms = 128 rows
+// (benchmark/benchmarks.jl:16-18), which used to fall to the HBM-resident any-rank kernel.
+int pioran_wide_supported_rows() { return 143; }
 
 // Batches up to this size take the latency layout (at most one workgroup per CU on the chip's 256 CUs).
 int64_t pioran_wide_max_batch() { return 256; }
@@ -857,17 +1061,38 @@ int64_t pioran_wide_max_batch() { return 256; }
 template <int MODE>
 static int launch_wide_mode(const ScanParams& p, hipStream_t stream)
 {
-    if (!p.tab || p.R > 95 || p.B <= 0 || p.B > 0x7fffffffLL) return PIORAN_ERR_UNSUPPORTED;
-    if (3 * (p.R + 2) + 2 + 3 * p.npd_rows > kWideMaxRecord) return PIORAN_ERR_UNSUPPORTED;   // staged record too long
+    if (!p.tab || p.R > 143 || p.B <= 0 || p.B > 0x7fffffffLL) return PIORAN_ERR_UNSUPPORTED;
+    if (MODE != 0 && p.R > 95) return PIORAN_ERR_UNSUPPORTED;   // store / simulate / gradient modes: up to 95 rows
     const dim3 grid((unsigned)p.B), block(256);
+    if constexpr (MODE == 0) {
+        // the lean form: from 64 rows on (where celerite_wide_kernel starts moving its inputs through AGPRs), or on request
+        const bool lean = (p.opt && p.opt->wide2) || (p.R >= 64 && !(p.opt && p.opt->no_wide2));
+        if (lean || p.R > 95) {
+            switch ((p.R + 1 + 15) / 16) {
+            case 1: hipLaunchKernelGGL(celerite_wide2_kernel<1>, grid, block, 0, stream, p); break;
+            case 2: hipLaunchKernelGGL(celerite_wide2_kernel<2>, grid, block, 0, stream, p); break;
+            case 3: hipLaunchKernelGGL(celerite_wide2_kernel<3>, grid, block, 0, stream, p); break;
+            case 4: hipLaunchKernelGGL(celerite_wide2_kernel<4>, grid, block, 0, stream, p); break;
+            case 5: hipLaunchKernelGGL(celerite_wide2_kernel<5>, grid, block, 0, stream, p); break;
+            case 6: hipLaunchKernelGGL(celerite_wide2_kernel<6>, grid, block, 0, stream, p); break;
+            case 7: hipLaunchKernelGGL(celerite_wide2_kernel<7>, grid, block, 0, stream, p); break;
+            case 8: hipLaunchKernelGGL(celerite_wide2_kernel<8>, grid, block, 0, stream, p); break;
+            default: hipLaunchKernelGGL(celerite_wide2_kernel<9>, grid, block, 0, stream, p); break;
+            }
+            return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+        }
+    }
+    if (3 * (p.R + 2) + 2 + 3 * p.npd_rows > kWideMaxRecord) return PIORAN_ERR_UNSUPPORTED;   // staged record too long
     if (p.R <= 15) hipLaunchKernelGGL((celerite_wide_kernel<1, MODE>), grid, block, 0, stream, p);
     else if (p.R <= 31) hipLaunchKernelGGL((celerite_wide_kernel<2, MODE>), grid, block, 0, stream, p);
     else if (p.R <= 47) hipLaunchKernelGGL((celerite_wide_kernel<3, MODE>), grid, block, 0, stream, p);
     else if (p.R <= 63) hipLaunchKernelGGL((celerite_wide_kernel<4, MODE>), grid, block, 0, stream, p);
     else if (p.R <= 79) hipLaunchKernelGGL((celerite_wide_kernel<5, MODE>), grid, block, 0, stream, p);
-    else {
+    else if (p.R <= 95) {
         if constexpr (MODE == 3) return PIORAN_ERR_UNSUPPORTED;   // (the adjoint pass stops at 79 rows)
         else hipLaunchKernelGGL((celerite_wide_kernel<6, MODE>), grid, block, 0, stream, p);
+    } else {
+        return PIORAN_ERR_UNSUPPORTED;   // 96 .. 143 rows: celerite_wide2_kernel above (log-likelihood only)
     }
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }

@@ -402,7 +402,9 @@ class Farm:
         except Exception:
             pass
 
-    def logl_batch(self, A, Bc, C, Dd, mu=None, nu=None, shift=None, return_status=False):
+    def logl_batch(self, A, Bc, C, Dd, mu=None, nu=None, shift=None, Y=None, S2=None, return_status=False):
+        """Y, S2: per-draw series (B, N) — e.g. y - mean_b(t) for a CustomMean model
+        (examples/ultranest/single_pl_periodicity.jl:115); exclusive with shift."""
         A, Bc, C, Dd = map(_f64, (A, Bc, C, Dd))
         B, J = A.shape
         cd_shared = C.ndim == 1
@@ -411,8 +413,17 @@ class Farm:
         shift = None if shift is None else _f64(np.broadcast_to(shift, (B,)))
         out = np.empty(B)
         st = np.zeros(B, dtype=np.int32)
-        _lib.check(_lib.lib().pioran_farm_logl_batch(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), int(cd_shared),
-                                                     _ptr(mu), _ptr(nu), _ptr(shift), _ptr(out), _ptr(st)))
+        if (Y is None) != (S2 is None) or (Y is not None and shift is not None):
+            raise ValueError("Y and S2 come together, and not with shift")
+        if Y is not None:
+            Y, S2 = _f64(Y), _f64(S2)
+            if Y.shape != (B, self.N) or S2.shape != (B, self.N):
+                raise ValueError("Y, S2 must be (B, N)")
+            _lib.check(_lib.lib().pioran_farm_logl_batch_series(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), int(cd_shared),
+                                                                _ptr(mu), _ptr(nu), _ptr(Y), _ptr(S2), _ptr(out), _ptr(st)))
+        else:
+            _lib.check(_lib.lib().pioran_farm_logl_batch(self._h, B, J, _ptr(A), _ptr(Bc), _ptr(C), _ptr(Dd), int(cd_shared),
+                                                         _ptr(mu), _ptr(nu), _ptr(shift), _ptr(out), _ptr(st)))
         return (out, st) if return_status else out
 
 

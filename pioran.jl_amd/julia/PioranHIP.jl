@@ -16,7 +16,7 @@ import Pioran: log_likelihood, SumOfCelerite, SemiSeparable, CARMA, celerite_coe
 import ChainRulesCore
 
 const LIB = get(ENV, "PIORAN_HIP_LIB", "libpioran_hip")
-const ABI_VERSION = 5
+const ABI_VERSION = 6
 
 # PIORAN_BACKEND=julia keeps every call on Pioran's own Julia code (the escape hatch a deployment wants when no GPU is
 # visible or for A/B comparisons); anything else (default "hip") routes Float64 calls to libpioran_hip.so.
@@ -254,11 +254,22 @@ device writes its slice of the result directly (draws are independent: no collec
 """
 function logpdf_batch(farm::Farm, A::Matrix{Float64}, B::Matrix{Float64}, c::VecOrMat{Float64}, d::VecOrMat{Float64};
                       μ::Union{Nothing, Vector{Float64}} = nothing, ν::Union{Nothing, Vector{Float64}} = nothing,
-                      shift::Union{Nothing, Vector{Float64}} = nothing)
+                      shift::Union{Nothing, Vector{Float64}} = nothing,
+                      Y::Union{Nothing, Matrix{Float64}} = nothing, S2::Union{Nothing, Matrix{Float64}} = nothing)
     J, nb = size(A)
     out = Vector{Float64}(undef, nb)
     status = zeros(Int32, nb)
     p(x) = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
+    if Y !== nothing   # per-draw series, N x nb (a column per draw): CustomMean models, y .- mean_b.(t)
+        (S2 !== nothing && shift === nothing) || error("Y and S2 come together, and not with shift")
+        GC.@preserve A B c d μ ν Y S2 out status begin
+            check(ccall((:pioran_farm_logl_batch_series, LIB), Cint,
+                        (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint,
+                         Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}),
+                        farm.h, nb, J, A, B, c, d, c isa Vector ? 1 : 0, p(μ), p(ν), Y, S2, out, status))
+        end
+        return out, status
+    end
     GC.@preserve A B c d μ ν shift out status begin
         check(ccall((:pioran_farm_logl_batch, LIB), Cint,
                     (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint,

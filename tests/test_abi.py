@@ -34,7 +34,7 @@ def test_library_is_gfx950_code_object():
 
 def test_version_and_strerror():
     L = pj._lib.lib()
-    assert L.pioran_abi_version() == 5
+    assert L.pioran_abi_version() == 6
     assert L.pioran_strerror(0) == b"ok"
     assert L.pioran_strerror(-4) == b"unsupported size"
     assert L.pioran_celerite_config_name(40) == b"rpl3_cbr2_nsrc7_p"   # column-paired variant for the standard row map

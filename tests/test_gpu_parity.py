@@ -103,7 +103,7 @@ def _random_case(rng, N, J, B, per_draw_cd=False):
     return t, y, s2, A, Bc, C, Dd, mu, nu
 
 
-@pytest.fixture(params=["throughput", "throughput_steps", "throughput_pairs", "latency", "block"])
+@pytest.fixture(params=["throughput", "throughput_steps", "throughput_pairs", "latency", "latency_lean", "block"])
 def layout(request, ctx):
     """Small batches (B <= 512) with 6 <= R <= 63 rows take the windowed kernel (celerite_block.hip) by default; "no_block" sends
     them to the one-draw-per-workgroup latency layout (celerite_wide.hip), "no_wide" as well to the throughput layouts (the ones
@@ -113,13 +113,17 @@ def layout(request, ctx):
         ctx.set_option("no_block", True)
     if request.param.startswith("throughput"):
         ctx.set_option("no_wide", True)
+    if request.param == "latency_lean":     # celerite_wide2_kernel (default from 64 rows on) forced for every row count
+        ctx.set_option("wide2", True)
+        ctx.set_option("scan_config", "wide")   # ... and for every batch size
     if request.param == "throughput_steps":
         ctx.set_option("no_win2", True)
     if request.param == "throughput_pairs":
         ctx.set_option("win2", True)
     yield request.param
-    for k in ("no_wide", "no_block", "no_win2", "win2"):
+    for k in ("no_wide", "no_block", "no_win2", "win2", "wide2"):
         ctx.set_option(k, False)
+    ctx.set_option("scan_config", None)
 
 
 @pytest.mark.parametrize("J", [1, 2, 3, 5, 8, 10, 13, 16, 20, 21, 24, 27, 32, 40])
@@ -167,11 +171,58 @@ def test_rows_80_to_95_stay_register_resident(ctx, J, B):
     np.testing.assert_allclose(pm[0], O.predict(A[0], Bc[0], C, Dd, tau, t, y - mu[0], nu[0] * s2) + mu[0], rtol=1e-10, atol=1e-11)
 
 
-@pytest.mark.parametrize("J", [48, 64])
-def test_fallback_any_rank(ctx, J):
-    """R > 95 rows (the reference benchmark's j = 64, benchmark/benchmarks.jl:17) runs on the HBM-resident fallback."""
+@pytest.mark.parametrize("J,N,B", [(48, 60, 5), (52, 33, 2), (56, 130, 3), (60, 61, 1), (64, 60, 5), (64, 700, 2), (71, 45, 3), (32, 300, 4), (40, 77, 2)])
+def test_rows_64_to_143_lean_latency_layout(ctx, J, N, B):
+    """R = 64 .. 143 rows stay register-resident (round 3): celerite_wide2_kernel, 5 .. 9 rows per lane.  The reference's own
+    benchmark grid goes up to j = 64 terms = 128 rows (benchmark/benchmarks.jl:16-18), which used to run on the HBM-resident
+    any-rank kernel.  Against the oracle, and against that kernel (still the path for more than 143 rows)."""
     rng = np.random.default_rng(300 + J)
-    N, B = 60, 5
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    ds = pj.Dataset(t, y, s2, ctx)
+    got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+    ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+    assert relerr(got, ref) < 1e-11 and (st == 0).all()
+    Y = rng.standard_normal((B, N)); S2 = rng.uniform(0.01, 0.1, (B, N))       # per-draw series through the y slot's thread
+    got2 = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+    ref2 = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(B)])
+    assert relerr(got2, ref2) < 1e-11
+    try:
+        ctx.set_option("force_fallback", True)
+        fb = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    finally:
+        ctx.set_option("force_fallback", False)
+    assert relerr(fb, ref) < 1e-11
+
+
+def test_lean_latency_layout_mixed_rows_and_nonpd(ctx):
+    """celerite_wide2_kernel with per-draw rows (a QPO-like term with per-draw (c, d) on 33 shared terms: 68 rows) and with a
+    draw whose D_n goes negative (status 1, log|D_n| as the reference, src/celerite_solver.jl:140)."""
+    rng = np.random.default_rng(9)
+    N, B, J = 150, 6, 34
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B, per_draw_cd=True)
+    C[:, :33] = C[0, :33]; Dd[:, :33] = Dd[0, :33]
+    ds = pj.Dataset(t, y, s2, ctx)
+    try:
+        ctx.set_option("no_block", True)
+        got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+    finally:
+        ctx.set_option("no_block", False)
+    ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+    assert relerr(got, ref) < 1e-11 and (st == 0).all()
+    A2 = A.copy(); A2[2, :] *= -1.0      # indefinite "covariance": D_1 < 0 -> NaN like the reference's log(D[1]) DomainError
+    A2[4, 5] = -30.0
+    got3, st3 = ds.logl_batch(A2, Bc, C[0], Dd[0], mu=mu, nu=nu, return_status=True)
+    ref3, rst3 = O.logl_batch(A2, Bc, C[0], Dd[0], t, y, s2, mu, nu, nthreads=8, return_status=True)
+    assert (np.isnan(got3) == np.isnan(ref3)).all()
+    fin = np.isfinite(ref3)
+    assert relerr(got3[fin], ref3[fin]) < 1e-9 and ((st3 != 0) == (rst3 != 0)).all()
+
+
+@pytest.mark.parametrize("J", [80, 100])
+def test_fallback_any_rank(ctx, J):
+    """More than 143 rows run on the HBM-resident any-rank kernel (celerite_fallback.hip)."""
+    rng = np.random.default_rng(300 + J)
+    N, B = 40, 3
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
     ds = pj.Dataset(t, y, s2, ctx)
     got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
@@ -824,6 +875,14 @@ def test_in_process_farm_sharding(golden_dir):
     assert (st == 0).all() and relerr(got, ref) < 1e-10
     got2 = farm.logl_batch(A[:2], Bc[:2], C, Dd, mu=P[:2, 5], nu=P[:2, 4], shift=P[:2, 6])    # fewer draws than devices
     assert relerr(got2, ref[:2]) < 1e-10
+    # per-draw series through the farm (pioran_farm_logl_batch_series; round 3): the same reference values with the shifted
+    # log-flux transform done by the caller — what a CustomMean model hands over (examples/ultranest/single_pl_periodicity.jl:115)
+    cs = P[:, 6:7]
+    Y = np.log(y[None, :] - cs); S2 = yerr[None, :] ** 2 / (y[None, :] - cs) ** 2
+    got3, st3 = farm.logl_batch(A, Bc, C, Dd, mu=P[:, 5], nu=P[:, 4], Y=Y, S2=S2, return_status=True)
+    assert (st3 == 0).all() and relerr(got3, ref) < 1e-10
+    with pytest.raises(ValueError):
+        farm.logl_batch(A, Bc, C, Dd, Y=Y, S2=S2, shift=P[:, 6])
     farm.close()
 
 

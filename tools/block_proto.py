@@ -31,8 +31,14 @@ def block_logl(a, b, c, d, t, y, s2, K=16):
         G = M @ U.T                                                            # Gram
         tau = np.abs(tt[:, None] - tt[None, :])
         A = np.zeros((k, k))
+        # (cos, sin)(d tau) by angle addition from the same rounded (cos, sin)(d t) that U and v are made of — NOT np.cos(d * tau):
+        # A must be consistent with the Gram block it is subtracted from (round 3; tools/explain_outliers.py)
+        cj = np.cos(np.outer(tt, d)); sj = np.sin(np.outer(tt, d))
+        later = tt[:, None] >= tt[None, :]
         for j in range(J):
-            A += np.exp(-c[j] * tau) * (a[j] * np.cos(d[j] * tau) + b[j] * np.sin(d[j] * tau))
+            cd = np.outer(cj[:, j], cj[:, j]) + np.outer(sj[:, j], sj[:, j])
+            sd = np.outer(sj[:, j], cj[:, j]) - np.outer(cj[:, j], sj[:, j])
+            A += np.exp(-c[j] * tau) * (a[j] * cd + b[j] * np.where(later, sd, -sd))
         A[np.diag_indices(k)] = suma + s2[m:n1]
         S = A - G
         X = v * Cend - M * C[-1]                                               # [k][R]
