@@ -346,6 +346,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "no_block")) o.no_block = on;
     else if (!std::strcmp(key, "win2")) o.win2 = on;
     else if (!std::strcmp(key, "no_win2")) o.no_win2 = on;
+    else if (!std::strcmp(key, "gsum")) o.gsum = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "wide2")) o.wide2 = on;
     else if (!std::strcmp(key, "no_wide2")) o.no_wide2 = on;
     else return PIORAN_ERR_ARG;
@@ -370,6 +371,7 @@ static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
     pioran_ctx_set_option(ctx, "no_block", std::getenv("PIORAN_NO_BLOCK"));
     pioran_ctx_set_option(ctx, "win2", std::getenv("PIORAN_WIN2"));
     pioran_ctx_set_option(ctx, "no_win2", std::getenv("PIORAN_NO_WIN2"));
+    pioran_ctx_set_option(ctx, "gsum", std::getenv("PIORAN_GSUM"));
     pioran_ctx_set_option(ctx, "wide2", std::getenv("PIORAN_WIDE2"));
     pioran_ctx_set_option(ctx, "no_wide2", std::getenv("PIORAN_NO_WIDE2"));
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
@@ -619,6 +621,40 @@ int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const
     drm = (int32_t*)ctx->bwork.p;
     HIPCHK(ctx, hipMemcpyAsync(drm, rm.data(), rm.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     SYNC(ctx);
+    if ((int64_t)rm.size() > pioran_scan_supported_rows() && (int64_t)rm.size() <= pioran_wide_supported_rows() && !ctx->opt.force_fallback) {
+        // More rows than the throughput layouts hold (which evaluate per-draw transcendentals in the kernel): every draw gets its
+        // OWN table, built for a chunk of draws at a time, and the lean latency kernel walks it (one draw per workgroup) — the
+        // reference benchmark's j = 64 with the reference's call pattern (one random (a, b, c, d) per call,
+        // benchmark/benchmarks.jl:74-91): 16 k instead of 0.8 k evaluations per second (any-rank kernel, S in HBM).
+        const int32_t R = (int32_t)rm.size();
+        const int64_t rec = 3 * (int64_t)(R + 2) + 2, tdoubles = (int64_t)pioran_table_doubles(ds->N, R);
+        int64_t chunk = B < 256 ? B : 256;
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                while (chunk > 1 && (size_t)chunk * (size_t)tdoubles * sizeof(double) > free_b / 2 + ctx->bscratch.cap) chunk /= 2;
+        }
+        while ((rc = ensure(ctx, ctx->bscratch, (size_t)chunk * (size_t)tdoubles * sizeof(double))) == PIORAN_ERR_ALLOC && chunk > 1) chunk /= 2;
+        if (rc) return rc;
+        for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+            const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+            rc = pioran_launch_table_batch(ds->N, R, (int32_t)J, nb, drm, ds->t, dC + b0 * J, dDd + b0 * J, ds->y, ds->s2,
+                                           (double*)ctx->bscratch.p, rec, tdoubles, ctx->stream);
+            if (rc) return rc;
+            ScanParams q{};
+            q.opt = &ctx->opt;
+            q.N = ds->N; q.J = (int32_t)J; q.R = R; q.B = nb; q.standard_rows = 1;
+            q.rec_stride = rec; q.tab_draw_stride = tdoubles;
+            q.tab = (const double*)ctx->bscratch.p; q.rowmap = drm; q.t = ds->t; q.y = ds->y; q.s2 = ds->s2;
+            q.Y = dY ? dY + b0 * ds->N : nullptr; q.S2 = dS2 ? dS2 + b0 * ds->N : nullptr;
+            q.A = dA + b0 * J; q.Bc = dBc + b0 * J; q.C = dC + b0 * J; q.D = dDd + b0 * J;
+            q.mu = dmu ? dmu + b0 : nullptr; q.nu = dnu ? dnu + b0 : nullptr;
+            q.out = dout + b0; q.status = dstatus ? dstatus + b0 : nullptr;
+            rc = pioran_launch_scan_wide(q, ctx->stream);
+            if (rc) { if (rc == PIORAN_ERR_HIP) ctx->last_err = "per-draw-table latency kernel launch failed"; return rc; }
+        }
+        return PIORAN_OK;
+    }
     ScanParams p{};
     p.N = ds->N; p.J = (int32_t)J; p.R = (int32_t)rm.size(); p.B = B;
     p.standard_rows = 1;

@@ -569,9 +569,21 @@ __device__ __forceinline__ double lane_fetch(double x, int addr4)
 }
 
 // p1, p2: any lane of the DPP row across (r ^ 1, r ^ 2) — after the row sum all 16 lanes of a row hold its total
-template <int CBR, int NSRC>
+// GS (round 3) trades exchange rounds for broadcast-accumulate instructions: every DPP row of a draw holds ALL the draw's
+// row slots (rotated), so once a row vector is the same in every DPP row (after the exchange of r = T u~) a sum over
+// rows needs no exchange at all — GS = 2: all 16 lanes of the DPP row, no ds_bpermute round; GS = 1 (four DPP rows per
+// draw): the 2 NSRC lanes that this DPP row and its neighbour r ^ 1 contribute, then ONE round with the row r ^ 2.
+// One draw per wavefront leaves two wavefronts per SIMD at most, and each dependent ds_bpermute round trip (~200 cycles)
+// is then exposed; GS = 0 (NSRC lanes + log2(CBR) rounds) stays the choice where the SIMD is issue-bound anyway.
+template <int CBR, int NSRC, int GS = 0>
 __device__ __forceinline__ double group_sum(double x, bool contributes, double one, int p1, int p2)
 {
+    if constexpr (GS == 2 && CBR >= 2) {
+        return row_sum_sources<16>(x, one);
+    } else if constexpr (GS == 1 && CBR == 4) {
+        x = row_sum_sources<2 * NSRC>(x, one);
+        return x + lane_fetch(x, p2);
+    } else
     if constexpr (NSRC <= 10) {
         x = row_sum_sources<NSRC>(x, one);
     } else {
@@ -611,9 +623,14 @@ struct StepIn {           // what one time step reads: per own row (v, x, phi) +
 // RB - 1 - 2 NPB single rows (real terms), then one spare slot (padding; the y row in the last block).  All blocks
 // look alike, so the phi_i phi_k product of a pair is formed once per pair in every DPP row of the wavefront.
 // WIN2: the two-step form (below, after the slot set-up) instead of the step-by-step recurrence.
-template <int RPL, int CBR, int NSRC, bool SHARED_TAB, int MINW = 1, bool PAIRED = false, bool MIXED = false, int NPB = 0, bool WIN2 = false>
+// YC (round 3, two-step form only): y is NOT one of the row slots — every slot can be a real row, so the shape holds one more
+// row (64 in the 64-row shape: the reference benchmark's j = 32, benchmark/benchmarks.jl:16-18, which used to pay the 80-row
+// shape).  The y row of T, f = T[y][.], rides as RPL more entries per lane (the lane's own rows), its products f'u~A, f'u~B cost
+// two more row sums per pair (independent of the pass over T) and z_n = y_n - mu - f'u~ falls out in every lane.
+template <int RPL, int CBR, int NSRC, bool SHARED_TAB, int MINW = 1, bool PAIRED = false, bool MIXED = false, int NPB = 0, bool WIN2 = false, int GS = 0, bool YC = false>
 __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanParams p)
 {
+    static_assert(!YC || (WIN2 && !MIXED && NPB == 0), "y as a separate vector: two-step form, no per-draw rows, no block layout");
     static_assert(NPB == 0 || (!PAIRED && 2 * NPB < NSRC * RPL && RPL % 2 == 0),
                   "block layout: unpaired base; both columns of a pair must sit in one source lane");
     static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
@@ -631,7 +648,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     const int l = lane & 15;
     const int lam = (l + NSRC * r) & 15;     // logical lane: which rows this lane owns
     const bool contributes = l < NSRC;       // each row is counted once in u'q
-    const bool isy = lam == YLAM;            // this lane's slot YS is the y row
+    const bool isy = !YC && lam == YLAM;     // this lane's slot YS is the y row
     const int64_t b_raw = ((int64_t)blockIdx.x * 4 + wave) * EPW + e;
     const bool active = b_raw < p.B;
     const int64_t b = active ? b_raw : p.B - 1;
@@ -753,6 +770,11 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         }
     }
 
+    // one draw per wavefront (two-step form): scalar sources of (y_n, sigma2_n), see load_step
+    [[maybe_unused]] const double* ybase1 = own_series ? p.Y + b * N : p.tab + 3 * Rp;
+    [[maybe_unused]] const double* sbase1 = own_series ? p.S2 + b * N : p.tab + 3 * Rp + 1;
+    [[maybe_unused]] const int ystr1 = own_series ? 1 : (int)p.rec_stride;
+    [[maybe_unused]] const int ylast1 = own_series ? (int)N - 1 : (int)N;
     auto load_step = [&](int64_t n, StepIn<RPL>& in) {
         if constexpr (SHARED_TAB) {
             if constexpr (WIN2) n = n < N ? n : N;   // the table holds N + 1 records
@@ -769,10 +791,12 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 }
             }
             if constexpr (WIN2 && EPW == 1) {
-                // one draw per wavefront: y_n, sigma2_n are wave-uniform -> scalar loads, no vector registers
-                const int64_t ny = own_series ? (n < N ? n : N - 1) : n;
-                in.y = own_series ? p.Y[b * N + ny] : p.tab[ny * p.rec_stride + 3 * Rp];
-                in.s2 = own_series ? p.S2[b * N + ny] : p.tab[ny * p.rec_stride + 3 * Rp + 1];
+                // one draw per wavefront: y_n, sigma2_n are wave-uniform -> scalar loads, no vector registers.  Branch-free
+                // (round 3): base, stride and last index are chosen once; a conditional LOAD in the loop body is a real branch,
+                // and with it came per-block register copies (105 v_mov_b64 and ~160 scalar instructions per pair of steps)
+                const int ny = (int)n < ylast1 ? (int)n : ylast1;
+                in.y = ybase1[ny * ystr1];
+                in.s2 = sbase1[ny * ystr1];
             } else {
                 const int ysoff = (int)n * y_step;
                 in.y = buf_load_f64(rs_y, vo_y, ysoff);
@@ -832,6 +856,9 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         int Pe = 0;
         bool nonpd = false;
         StepIn<RPL> sa, sb;
+        [[maybe_unused]] double fy[RPL];   // YC: the y row of T for this lane's rows
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) fy[i] = 0.0;
         // VOIDA: step A does not exist (D = 1, m = 0, no contribution); FIRST: step A is the first of the series (log D_1, :126)
         auto pair = [&](int64_t nA, auto voidc, auto firstc) __attribute__((always_inline)) {
             constexpr bool VOIDA = decltype(voidc)::value, FIRST = decltype(firstc)::value;
@@ -848,7 +875,14 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 rA[i] = 0.0;
                 rB[i] = 0.0;
             }
-            if constexpr (COEF_LDS) {   // (register-starved shapes: a select on the lane mask instead of the multiplier ysel)
+            [[maybe_unused]] double ryA = 0.0, ryB = 0.0;
+            if constexpr (YC) {   // f'u~A, f'u~B: row vectors only, independent of the pass over T below
+                double spyA = 0.0, spyB = 0.0;
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) { spyA = fma(fy[i], tA[i], spyA); spyB = fma(fy[i], tB[i], spyB); }
+                ryA = group_sum<CBR, NSRC, GS>(spyA, contributes, one, p1, p2);
+                ryB = group_sum<CBR, NSRC, GS>(spyB, contributes, one, p1, p2);
+            } else if constexpr (COEF_LDS) {   // (register-starved shapes: a select on the lane mask instead of the multiplier ysel)
                 sa.v[YS] = isy ? sa.y - mu : sa.v[YS];
                 sb.v[YS] = isy ? sb.y - mu : sb.v[YS];
             } else {
@@ -862,7 +896,10 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 #pragma unroll
             for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(tA[i]), "+v"(tB[i]));
             asm volatile("s_nop 1");
-            static_for<0, NC>([&](auto Cc) {
+            // the single slot that closes every block of a paired or block layout is padding or the y row in EVERY DPP row:
+            // u = 0 there, so the column contributes nothing to T u~ (its own row of T is still needed: it is updated below)
+            constexpr int NCM = ((PAIRED && (NC & 1)) || NPB > 0) ? NC - 1 : NC;
+            static_for<0, NCM>([&](auto Cc) {
                 constexpr int c = decltype(Cc)::value;
                 MatVec2<RPL, c / RPL>::run(T[c], rA, rB, tA[c % RPL], tB[c % RPL]);
             });
@@ -877,8 +914,8 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             double spA = 0.0, spB = 0.0;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) { spA += tA[i] * rA[i]; spB += tB[i] * rB[i]; }
-            const double sA = group_sum<CBR, NSRC>(spA, contributes, one, p1, p2);
-            const double sB = group_sum<CBR, NSRC>(spB, contributes, one, p1, p2);
+            const double sA = group_sum<CBR, NSRC, GS>(spA, contributes, one, p1, p2);
+            const double sB = group_sum<CBR, NSRC, GS>(spB, contributes, one, p1, p2);
             const double DA = VOIDA ? 1.0 : fma(nu, sa.s2, suma) - sA;                  // :92
             const double rDA = recip_f64(DA);
             double hA[RPL], mB[RPL], wA[RPL], wB[RPL], spg = 0.0;
@@ -886,12 +923,14 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
                 const double mA = VOIDA ? 0.0 : fma(-sa.ph[i], rA[i], sa.v[i]);        // v - q      :89
-                if (i == YS) zA = mA;
+                if (!YC && i == YS) zA = mA;
                 hA[i] = sb.ph[i] * mA;
                 spg = fma(hA[i], uB[i], spg);
             }
+            if constexpr (YC) zA = VOIDA ? 0.0 : (sa.y - mu) - ryA;                      // z_A = y_A - mu - f'u~A   (phi_y = 1)
+            [[maybe_unused]] const double ymB = sb.y - mu;
             load_step(nA + 2, sa);                                                       // step A's record is consumed
-            const double g = group_sum<CBR, NSRC>(spg, contributes, one, p1, p2);
+            const double g = group_sum<CBR, NSRC, GS>(spg, contributes, one, p1, p2);
             const double gr = g * rDA;
             const double DB = fma(nu, sb.s2, suma) - sB - g * gr;
             const double rDB = recip_f64(DB);
@@ -902,7 +941,14 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 wB[i] = mB[i] * rDB;
             }
             load_step(nA + 3, sb);
-            const double zB = mB[YS];                                                    // y row: z_n = y_n - u'f      :141
+            double zB;                                                                   // y row: z_n = y_n - u'f      :141
+            if constexpr (YC) {
+                zB = ymB - ryB - zA * gr;                                                // the y row's (h_A)_y = z_A
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) fy[i] = fma(zB, wB[i], fma(zA, wA[i], pAB[i] * fy[i]));
+            } else {
+                zB = mB[YS];
+            }
             nonpd |= !(DA > 0.0) | !(DB > 0.0);
             Pm *= (FIRST ? DA : fabs(DA)) * ((VOIDA && FIRST) ? DB : fabs(DB));          // log(D[1]) :126, log(abs(D[n])) :140
             {
@@ -958,7 +1004,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             n = 2;
         }
         for (; n + 1 < N; n += 2) pair(n, std::false_type{}, std::false_type{});
-        if (active && isy && r == 0) {
+        if (active && (YC ? (lane % G) == 0 : (isy && r == 0))) {
             const double logdet = log(Pm) + (double)Pe * 0.6931471805599453094;
             const double res = -0.5 * logdet - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * quad;
             p.out[b] = res;
@@ -1094,9 +1140,27 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 
 using LaunchFn = void (*)(const ScanParams&, dim3, hipStream_t);
 
-template <int RPL, int CBR, int NSRC, int MINW = 1, bool PAIRED = false>
+// which form of the row sums (group_sum's GS): the context option "gsum" (0, 1, 2) when set, else automatic
+int gsum_mode(const ScanParams& p, int cbr)
+{
+    if (p.opt && p.opt->gsum >= 0) return p.opt->gsum > 2 ? 2 : p.opt->gsum;
+    (void)cbr;
+    return 0;
+}
+
+// GSV: the configuration also exists with the row sums of group_sum's GS = 1 / 2 (fewer exchange rounds); picked per launch
+// (gsum_mode below); two-step form, shared table without per-draw rows only
+template <int RPL, int CBR, int NSRC, int MINW = 1, bool PAIRED = false, bool GSV = false>
 void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 {
+    if constexpr (GSV) {
+        const int gs = gsum_mode(p, CBR);
+        if (gs && p.tab && p.npd_rows == 0 && !(p.opt && p.opt->no_win2)) {
+            if (gs == 2) hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true, 2>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true, CBR == 4 ? 1 : 2>), grid, dim3(256), 0, st, p);
+            return;
+        }
+    }
     // two-step form: faster wherever its working set fits the register file (tools/sweep_win2.py: RPL <= 3: +10 .. 24 %;
     // RPL = 4: +4 .. 6 % with a few spilled registers); with RPL = 5 it loses 7 %, so there it runs only when forced
     // (context option "win2")
@@ -1121,6 +1185,12 @@ void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 template <int RPL, int CBR, int NSRC, int MINW, int NPB>
 void launch_blocked(const ScanParams& p, dim3 grid, hipStream_t st)
 {
+    const int gs = gsum_mode(p, CBR);
+    if (gs && !(p.opt && p.opt->no_win2)) {
+        if (gs == 2) hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB, true, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB, true, 1>), grid, dim3(256), 0, st, p);
+        return;
+    }
     if ((RPL <= 4 && !(p.opt && p.opt->no_win2)) || (p.opt && p.opt->win2))
         hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB, true>), grid, dim3(256), 0, st, p);
     else
@@ -1134,13 +1204,21 @@ struct ScanConfig {
     bool paired = false;   // needs the standard row map (every term has both rows)
     bool autopick = true;  // false: only selectable by name (measured slower than the default of its row range)
     int npb = 0;           // > 0: block layout for "n_complex = npb * cbr two-row terms, then one-row terms" (standard_rows == 2)
-    // real rows it holds: one slot carries y; a paired config with an odd block keeps one single slot per block
+    bool ycol = false;     // y rides as a separate vector (kernel template YC): every slot is a row; two-step form, no per-draw rows
+    // real rows it holds: one slot carries y (unless ycol); a paired config with an odd block keeps one single slot per block
     int capacity() const
     {
         const int rb = rpl * nsrc;
+        if (ycol) return cbr * (paired ? (rb & ~1) : rb);
         return paired ? cbr * (rb & ~1) - ((rb & 1) ? 0 : 1) : rpl * cbr * nsrc - 1;
     }
 };
+
+template <int RPL, int CBR, int NSRC, int MINW, bool PAIRED>
+void launch_ycol(const ScanParams& p, dim3 grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true, 0, true>), grid, dim3(256), 0, st, p);
+}
 
 #define CFG(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC, RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC>}
 #define CFG_P(RPL, CBR, NSRC, MINW) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC "_p", RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC, MINW, true>, true}
@@ -1152,21 +1230,32 @@ const ScanConfig kConfigs[] = {
     CFG(1, 1, 5),  CFG(1, 1, 9),  CFG(1, 1, 13), CFG(1, 1, 16),           // R <= 15
     CFG(2, 1, 9),  CFG(2, 1, 11), CFG(2, 1, 13), CFG(2, 1, 15), CFG(2, 1, 16),  // R <= 31
     CFG(3, 2, 6),  CFG(3, 2, 7),  CFG(3, 2, 8),                           // R <= 47
-    {"rpl4_cbr4_nsrc4", 4, 4, 4, &launch_cfg<4, 4, 4, 2>},                // R <= 63: 256 registers/lane, 2 waves per SIMD
+    {"rpl4_cbr4_nsrc4", 4, 4, 4, &launch_cfg<4, 4, 4, 2, false, true>},   // R <= 63: 256 registers/lane, 2 waves per SIMD
+    {"rpl4_cbr4_nsrc4_y", 4, 4, 4, &launch_ycol<4, 4, 4, 2, false>, false, true, 0, true},   // R = 64: y as a separate vector
     CFG(5, 4, 4),                                                         // R <= 79
     // column-paired variants (standard row map only; picked automatically by pick_config when applicable)
-    CFG_P(3, 2, 7, 1), CFG_P(3, 2, 8, 1), CFG_P(3, 2, 6, 1),
+    {"rpl3_cbr2_nsrc7_p", 3, 2, 7, &launch_cfg<3, 2, 7, 1, true, true>, true}, CFG_P(3, 2, 8, 1), CFG_P(3, 2, 6, 1),
     CFG_P(1, 1, 5, 1), CFG_P(1, 1, 9, 1), CFG_P(1, 1, 13, 1), CFG_P(1, 1, 16, 1),
     CFG_P(2, 1, 9, 1), CFG_P(2, 1, 11, 1), CFG_P(2, 1, 13, 1), CFG_P(2, 1, 15, 1), CFG_P(2, 1, 16, 1),
-    CFG_P(4, 4, 4, 2), CFG_P(5, 4, 4, 1),
+    {"rpl4_cbr4_nsrc4_p", 4, 4, 4, &launch_cfg<4, 4, 4, 2, true, true>, true},
+    {"rpl4_cbr4_nsrc4_yp", 4, 4, 4, &launch_ycol<4, 4, 4, 2, true>, true, true, 0, true}, CFG_P(5, 4, 4, 1),
     // DRWCelerite with 20 components: 20 complex + 20 real terms = 5 pairs + 5 singles + 1 spare in each of the 4 blocks
     {"rpl4_cbr4_nsrc4_b5a", 4, 4, 4, &launch_blocked<4, 4, 4, 2, 5>, false, true, 5},
     // alternatives kept for tuning runs (selected by name)
-    CFG(3, 4, 4), CFG(2, 2, 8),
+    {"rpl3_cbr4_nsrc4", 3, 4, 4, &launch_cfg<3, 4, 4, 1, false, true>}, CFG(2, 2, 8),
 };
 #undef CFG
 #undef CFG_P
-constexpr int kNumPreferred = 14;
+constexpr int kNumPreferred = 15;
+
+// y-as-a-vector shapes exist in the two-step form for launches without per-draw rows only
+bool ycol_usable(const ScanConfig& c, const ScanParams* p)
+{
+    if (!c.ycol) return true;
+    // (per-draw (c, d) launches evaluate the transcendentals in the kernel: at four rows per lane the two-step form then spills —
+    // 19.5 k instead of 42.8 k evaluations per second at j = 32 — so those keep the 80-row step-by-step shape)
+    return p && p->tab && p->npd_rows == 0 && !(p->opt && p->opt->no_win2);
+}
 
 // does the block layout of `c` hold this row structure?  (shared table, no per-draw rows)
 bool blocked_fits(const ScanConfig& c, const ScanParams& p)
@@ -1183,7 +1272,8 @@ const ScanConfig* pick_config(int R, bool standard_rows, const ScanParams* p = n
     const bool no_paired = opt && opt->no_paired;
     if (const char* env = (opt && opt->scan_config[0]) ? opt->scan_config : nullptr) {
         for (const auto& c : kConfigs)
-            if (!std::strcmp(env, c.name) && c.capacity() >= R && (!c.paired || standard_rows) && (c.npb == 0 || (p && blocked_fits(c, *p))))
+            if (!std::strcmp(env, c.name) && c.capacity() >= R && (!c.paired || standard_rows) && (c.npb == 0 || (p && blocked_fits(c, *p))) &&
+                ycol_usable(c, p))
                 return &c;
     }
     if (p && !no_paired) {
@@ -1192,11 +1282,12 @@ const ScanConfig* pick_config(int R, bool standard_rows, const ScanParams* p = n
     }
     const ScanConfig* best = nullptr;
     for (int i = 0; i < kNumPreferred; ++i)
-        if (kConfigs[i].capacity() >= R) { best = &kConfigs[i]; break; }
+        if (kConfigs[i].capacity() >= R && ycol_usable(kConfigs[i], p)) { best = &kConfigs[i]; break; }
     if (standard_rows && !no_paired) {
         // a paired variant of the same shape (or the smallest paired one that fits) wins when the row map allows it
         for (const auto& c : kConfigs)
-            if (c.paired && c.npb == 0 && c.autopick && c.capacity() >= R && (!best || c.rpl * c.cbr * c.nsrc <= best->rpl * best->cbr * best->nsrc))
+            if (c.paired && c.npb == 0 && c.autopick && c.capacity() >= R && ycol_usable(c, p) &&
+                (!best || c.rpl * c.cbr * c.nsrc <= best->rpl * best->cbr * best->nsrc))
                 return &c;
     }
     return best;
@@ -1219,6 +1310,14 @@ int pioran_launch_scan(const ScanParams& p, hipStream_t stream)
 {
     const ScanConfig* c = pick_config(p.R, p.standard_rows == 1, &p);
     if (!c) return PIORAN_ERR_UNSUPPORTED;
+    // Mid-size batches: up to 2048 draws the four-draws-per-wavefront shapes of this row range put at most one wavefront on
+    // half of the chip's 1024 SIMDs, and the launch takes as long as ONE wavefront needs for the series; two draws per
+    // wavefront (rpl2_cbr2_nsrc8: half the columns per lane) is then the faster walk (tools/sweep_midbatch.py, N = 1e4,
+    // R = 30: 4.2 instead of 5.3 ms for 768 .. 2048 draws; above 2048 draws the denser shape wins again: 5.3 vs 7.3 ms)
+    if (!(p.opt && p.opt->scan_config[0]) && p.B <= 2048 && p.R >= 24 && p.R <= 31 && c->cbr == 1) {
+        for (const auto& alt : kConfigs)
+            if (!std::strcmp(alt.name, "rpl2_cbr2_nsrc8")) c = &alt;
+    }
     const int epw = 64 / (16 * c->cbr);
     const int64_t per_block = 4 * epw;
     const int64_t blocks = (p.B + per_block - 1) / per_block;

@@ -422,6 +422,7 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
     const int64_t b = blockIdx.x;                     // grid = batch
     const int64_t N = p.N;
     const int J = p.J, R = p.R, Rp = R + 2, RS = 3 * Rp + 2;
+    const double* const tabb = p.tab + b * p.tab_draw_stride;   // per-draw tables (launches with per-draw (c, d)) or the shared one
 
     __shared__ double sh_rec[2][3 * NS + 2];          // [u x NS | v x NS | phi x NS | sigma2_n], by step parity
     __shared__ double sh_num[2][NS];                  // (v - q) of every row = D_n w
@@ -437,16 +438,16 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
     // ---- slot threads: sources of (v, x, phi) of slot `tid`; address = src + min(n, last) * stride ----------------------
     const bool slot_thread = tid < NS;
     const bool yslot = tid == NS - 1;
-    const double* src[3] = {p.tab, p.tab, p.tab};
+    const double* src[3] = {tabb, tabb, tabb};
     int64_t stride[3] = {0, 0, 0}, last[3] = {N, N, N};
     double al = 0.0, be = 0.0;
     if (slot_thread) {
         if (yslot) {                                  // v <- y_n, x <- sigma2_n, phi <- the table's y row (1)
-            src[0] = p.Y ? p.Y + b * N : p.tab + 3 * Rp;
-            src[1] = p.S2 ? p.S2 + b * N : p.tab + 3 * Rp + 1;
+            src[0] = p.Y ? p.Y + b * N : tabb + 3 * Rp;
+            src[1] = p.S2 ? p.S2 + b * N : tabb + 3 * Rp + 1;
             stride[0] = stride[1] = p.Y ? 1 : p.rec_stride;
             last[0] = last[1] = p.Y ? N - 1 : N;
-            src[2] = p.tab + 2 * Rp + (R + 1);
+            src[2] = tabb + 2 * Rp + (R + 1);
             stride[2] = p.rec_stride;
         } else if (tid < R) {
             const int rm = p.rowmap[tid];
@@ -456,14 +457,14 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
             al = a;                                   // cos row: u = a co + b si ; sin row: u = a si - b co   (:59-63)
             be = ks ? -bb : bb;
             if ((rm >> 29) & 1) {                     // per-draw row (mixed mode): [draw][row][v, x, phi] inside the step record
-                const double* base = p.tab + RS + ((int64_t)b * p.npd_rows + ((rm >> 20) & 0x1ff)) * 3;
+                const double* base = tabb + RS + ((int64_t)b * p.npd_rows + ((rm >> 20) & 0x1ff)) * 3;
                 src[0] = base; src[1] = base + 1; src[2] = base + 2;
             } else {
-                src[0] = p.tab + tid; src[1] = p.tab + tid + Rp; src[2] = p.tab + tid + 2 * Rp;
+                src[0] = tabb + tid; src[1] = tabb + tid + Rp; src[2] = tabb + tid + 2 * Rp;
             }
             stride[0] = stride[1] = stride[2] = p.rec_stride;
         } else {                                      // inert padding slot: the table's padding row (v, x, phi) = (1, 0, 1), u = 0
-            src[0] = p.tab + R; src[1] = p.tab + R + Rp; src[2] = p.tab + R + 2 * Rp;
+            src[0] = tabb + R; src[1] = tabb + R + Rp; src[2] = tabb + R + 2 * Rp;
             stride[0] = stride[1] = stride[2] = p.rec_stride;
         }
     }
@@ -1065,9 +1066,10 @@ static int launch_wide_mode(const ScanParams& p, hipStream_t stream)
     if (MODE != 0 && p.R > 95) return PIORAN_ERR_UNSUPPORTED;   // store / simulate / gradient modes: up to 95 rows
     const dim3 grid((unsigned)p.B), block(256);
     if constexpr (MODE == 0) {
-        // the lean form: from 64 rows on (where celerite_wide_kernel starts moving its inputs through AGPRs), or on request
-        const bool lean = (p.opt && p.opt->wide2) || (p.R >= 64 && !(p.opt && p.opt->no_wide2));
-        if (lean || p.R > 95) {
+        // the lean form: from 48 rows on (tools/sweep_wide.py, N = 8192: R = 48 6.0 -> 5.7 ms, 80 9.1 -> 7.5, 94 9.4 -> 7.6; below
+        // that the register copies of celerite_wide_kernel are still cheaper: R = 40 4.8 vs 5.1 ms), or on request
+        const bool lean = (p.opt && p.opt->wide2) || (p.R >= 48 && !(p.opt && p.opt->no_wide2));
+        if (lean || p.R > 95 || p.tab_draw_stride != 0) {
             switch ((p.R + 1 + 15) / 16) {
             case 1: hipLaunchKernelGGL(celerite_wide2_kernel<1>, grid, block, 0, stream, p); break;
             case 2: hipLaunchKernelGGL(celerite_wide2_kernel<2>, grid, block, 0, stream, p); break;
@@ -1082,6 +1084,7 @@ static int launch_wide_mode(const ScanParams& p, hipStream_t stream)
             return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
         }
     }
+    if (p.tab_draw_stride != 0) return PIORAN_ERR_UNSUPPORTED;   // per-draw tables: celerite_wide2_kernel (log-likelihood) only
     if (3 * (p.R + 2) + 2 + 3 * p.npd_rows > kWideMaxRecord) return PIORAN_ERR_UNSUPPORTED;   // staged record too long
     if (p.R <= 15) hipLaunchKernelGGL((celerite_wide_kernel<1, MODE>), grid, block, 0, stream, p);
     else if (p.R <= 31) hipLaunchKernelGGL((celerite_wide_kernel<2, MODE>), grid, block, 0, stream, p);

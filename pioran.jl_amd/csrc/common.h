@@ -20,7 +20,8 @@ struct ScanOptions {
     char scan_config[48];   // "" automatic; "wide" / "block": that small-batch kernel for any batch size; else a throughput configuration's name
     bool no_wide, no_paired, no_mixed, force_fallback, no_block;
     bool win2, no_win2;   // throughput layouts: force / forbid the two-step form of the recurrence (celerite_scan.hip)
-    bool wide2, no_wide2; // latency layout: force / forbid the lean form (celerite_wide2_kernel; default from 64 rows on)
+    int gsum = -1;        // throughput layouts, two-step form: row sums with fewer exchange rounds (group_sum's GS); -1 = automatic
+    bool wide2, no_wide2; // latency layout: force / forbid the lean form (celerite_wide2_kernel; default from 48 rows on)
 };
 
 struct ScanParams {
@@ -51,6 +52,7 @@ struct ScanParams {
     // step record stride of `tab` in doubles: 3(R+2)+2, plus B*npd_rows*3 in mixed mode, where the rows of the few
     // terms with per-draw (c, d) read (v, x, phi) from a per-draw block appended to every step record
     int64_t rec_stride;
+    int64_t tab_draw_stride;   // celerite_wide2_kernel only: draw b reads the table at tab + b * tab_draw_stride (0: one shared table)
     int32_t npd_rows;     // per-draw rows (2 per per-draw term), 0 if none
     // celerite_wide.hip only.  Factor store (pioran_launch_scan_wide_store): W [B][N][R] (the reference's V after
     // init_semi_separable!, src/celerite_solver.jl:95-97), D [B][N], forward-solved z [B][N] (:141).
@@ -119,6 +121,9 @@ size_t pioran_table_doubles(int64_t N, int32_t R);
 int pioran_launch_table(int64_t N, int32_t R, const int32_t* rowmap, const double* t, const double* c,
                         const double* d, const double* y, const double* s2, double* tab, int64_t rec_stride,
                         hipStream_t stream);
+int pioran_launch_table_batch(int64_t N, int32_t R, int32_t J, int64_t nb, const int32_t* rowmap, const double* t, const double* C,
+                              const double* D, const double* y, const double* s2, double* tab, int64_t rec_stride,
+                              int64_t tab_draw_stride, hipStream_t stream);
 int pioran_launch_pd_table(int64_t N, int64_t B, int32_t J, int32_t npd_terms, const int32_t* pd_terms /*device*/,
                            const double* t, const double* C /*[B][J]*/, const double* D, double* tab, int64_t rec_stride,
                            int64_t rs_shared, hipStream_t stream);

@@ -15,8 +15,13 @@ namespace {
 __global__ void __launch_bounds__(256) table_kernel(int64_t N, int32_t R, const int32_t* __restrict__ rowmap,
                                                     const double* __restrict__ t, const double* __restrict__ c,
                                                     const double* __restrict__ d, const double* __restrict__ y,
-                                                    const double* __restrict__ s2, double* __restrict__ tab, int64_t RS /*record stride*/)
+                                                    const double* __restrict__ s2, double* __restrict__ tab, int64_t RS /*record stride*/,
+                                                    int64_t cd_stride, int64_t tab_draw_stride)
 {
+    // blockIdx.y: draw index of a batch of per-draw tables (its (c, d) at c + y * cd_stride, its table at tab + y * tab_draw_stride)
+    c += (int64_t)blockIdx.y * cd_stride;
+    d += (int64_t)blockIdx.y * cd_stride;
+    tab += (int64_t)blockIdx.y * tab_draw_stride;
     const int32_t Rp = R + 2;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (N + 1) * Rp) return;
@@ -147,6 +152,20 @@ int pioran_launch_table(int64_t N, int32_t R, const int32_t* rowmap, const doubl
     const int64_t blocks = (total + 255) / 256;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return PIORAN_ERR_ARG;
     if ((uint64_t)(N + 1) * (uint64_t)rec_stride * 8 > 0x7ffffff0ull) return PIORAN_ERR_UNSUPPORTED;  // 32-bit buffer offsets
-    hipLaunchKernelGGL(table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, N, R, rowmap, t, c, d, y, s2, tab, rec_stride);
+    hipLaunchKernelGGL(table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, N, R, rowmap, t, c, d, y, s2, tab, rec_stride,
+                       (int64_t)0, (int64_t)0);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
+// nb tables at once, one per draw with its own (c, d) [nb][J]: table b at tab + b * tab_draw_stride (doubles)
+int pioran_launch_table_batch(int64_t N, int32_t R, int32_t J, int64_t nb, const int32_t* rowmap, const double* t, const double* C,
+                              const double* D, const double* y, const double* s2, double* tab, int64_t rec_stride,
+                              int64_t tab_draw_stride, hipStream_t stream)
+{
+    const int64_t total = (N + 1) * (int64_t)(R + 2);
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks <= 0 || blocks > 0x7fffffffLL || nb < 1 || nb > 65535) return PIORAN_ERR_ARG;
+    hipLaunchKernelGGL(table_kernel, dim3((unsigned)blocks, (unsigned)nb), dim3(256), 0, stream, N, R, rowmap, t, C, D, y, s2, tab, rec_stride,
+                       (int64_t)J, tab_draw_stride);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }

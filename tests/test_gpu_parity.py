@@ -192,6 +192,12 @@ def test_rows_64_to_143_lean_latency_layout(ctx, J, N, B):
     finally:
         ctx.set_option("force_fallback", False)
     assert relerr(fb, ref) < 1e-11
+    if 2 * J > 79:
+        # per-draw (c, d) past the throughput layouts' 79 rows: every draw gets its own table, the same kernel walks it
+        C2 = np.tile(C, (B, 1)) * rng.uniform(0.8, 1.2, (B, J)); D2 = np.tile(Dd, (B, 1)) * rng.uniform(0.8, 1.2, (B, J))
+        got3, st3 = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu, Y=Y, S2=S2, return_status=True)
+        ref3 = np.array([O.logl(A[i], Bc[i], C2[i], D2[i], t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(B)])
+        assert relerr(got3, ref3) < 1e-11 and (st3 == 0).all()
 
 
 def test_lean_latency_layout_mixed_rows_and_nonpd(ctx):
@@ -216,6 +222,43 @@ def test_lean_latency_layout_mixed_rows_and_nonpd(ctx):
     assert (np.isnan(got3) == np.isnan(ref3)).all()
     fin = np.isfinite(ref3)
     assert relerr(got3[fin], ref3[fin]) < 1e-9 and ((st3 != 0) == (rst3 != 0)).all()
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 64, 257])
+def test_64_rows_in_the_64_row_shape(ctx, N):
+    """R = 64 rows (the reference benchmark's j = 32, benchmark/benchmarks.jl:16-18) in the 64-row throughput shape: y rides as a
+    separate vector instead of a row slot (kernel template YC, configurations rpl4_cbr4_nsrc4_y / _yp), odd and even series
+    lengths (the two-step form pairs the steps), shared and per-draw (c, d), per-draw series, a row map that is not all pairs."""
+    rng = np.random.default_rng(640 + N)
+    B, J = 70, 32
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    ds = pj.Dataset(t, y, s2, ctx)
+    try:
+        ctx.set_option("no_block", True); ctx.set_option("no_wide", True)
+        got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        cfg = pj._lib.lib().pioran_celerite_config_name(0).decode()
+        ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+        assert cfg == "rpl4_cbr4_nsrc4_yp", cfg
+        assert relerr(got, ref) < 1e-11 and (st == 0).all()
+        Y = rng.standard_normal((B, N)); S2 = rng.uniform(0.01, 0.1, (B, N))
+        got2 = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+        ref2 = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(B)])
+        assert relerr(got2, ref2) < 1e-11
+        # per-draw (c, d): no table, transcendentals in the kernel
+        C2 = np.tile(C, (B, 1)) * rng.uniform(0.8, 1.2, (B, J)); D2 = np.tile(Dd, (B, 1)) * rng.uniform(0.8, 1.2, (B, J))
+        got3 = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu)
+        ref3 = O.logl_batch(A, Bc, C2, D2, t, y, s2, mu, nu, nthreads=8)
+        assert relerr(got3, ref3) < 1e-11
+        # 30 two-row terms + 4 one-row terms = 64 rows, not all pairs: the unpaired y-vector shape
+        J4 = 34
+        t4, y4, s4, A4, B4, C4, D4, mu4, nu4 = _random_case(rng, max(N, 2), J4, 9)
+        B4[:, 30:] = 0.0; D4[30:] = 0.0
+        ds4 = pj.Dataset(t4, y4, s4, ctx)
+        got4 = ds4.logl_batch(A4, B4, C4, D4, mu=mu4, nu=nu4)
+        assert pj._lib.lib().pioran_celerite_config_name(0).decode() == "rpl4_cbr4_nsrc4_y"
+        assert relerr(got4, O.logl_batch(A4, B4, C4, D4, t4, y4, s4, mu4, nu4, nthreads=8)) < 1e-11
+    finally:
+        ctx.set_option("no_block", False); ctx.set_option("no_wide", False)
 
 
 @pytest.mark.parametrize("J", [80, 100])
