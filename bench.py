@@ -468,7 +468,7 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
     for _ in range(3):
         t0 = time.perf_counter(); vb = ctx.dense_nll_batch(Ad, Bdd, Rk.c, Rk.d, td, yd, ed ** 2, mu=np.full(Bd, mud)); wb.append(time.perf_counter() - t0)
     out[f"dense_n{Nd}_j{Jd}"]["batched"] = {
-        "workload": f"{Bd} independent factorisations per call, up to 8 concurrent (pioran_dense_nll_batch), PCIe included",
+        "workload": f"{Bd} independent factorisations per call, up to 16 concurrent (pioran_dense_nll_batch), PCIe included",
         "ms_per_call": med(wb) * 1e3, "evals_per_s": Bd / med(wb), "mfma_tflops": Bd * flop / med(wb) / 1e12,
         "mfma_frac": Bd * flop / med(wb) / 1e12 / FP64_PEAK_TFLOPS, "all_finite": bool(np.isfinite(vb).all())}
 

@@ -27,8 +27,9 @@ struct pioran_ctx {
     struct Pending { void* host; const void* pinned; size_t bytes; };
     std::vector<Pending> pending;
     // batched dense solver: independent factorisations on their own streams, one slab each (lazy)
-    hipStream_t dstream[8] = {};
-    hipEvent_t dev_[9] = {};
+    static constexpr int kDenseStreams = 16;
+    hipStream_t dstream[kDenseStreams] = {};
+    hipEvent_t dev_[kDenseStreams + 1] = {};
     // second stream + events of the gradient's reverse pass (replay of one segment overlaps the adjoint of the next); lazy
     hipStream_t aux = nullptr;
     hipEvent_t gev[5] = {};
@@ -346,6 +347,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "no_block")) o.no_block = on;
     else if (!std::strcmp(key, "win2")) o.win2 = on;
     else if (!std::strcmp(key, "no_win2")) o.no_win2 = on;
+    else if (!std::strcmp(key, "dense_streams")) o.dense_streams = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "gsum")) o.gsum = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "wide2")) o.wide2 = on;
     else if (!std::strcmp(key, "no_wide2")) o.no_wide2 = on;
@@ -1078,7 +1080,7 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
     PendingGuard pending_guard(ctx);
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
-    if (s.R > 79 || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
+    if (s.R > 95 || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
     // Workspace per draw: (m, D) of every step + S at the checkpoints + two replayed segments (celerite_wide.hip): ~15 MB at
     // N = 1e4, R = 40.  The chunk is bounded by half of the memory that is free right now (plus what this buffer already
     // holds) and halved again if the allocation still fails.
@@ -1430,9 +1432,11 @@ int pioran_dense_nll_batch(pioran_ctx* ctx, int64_t N, int64_t J, int64_t B, con
     int64_t Mp, ld;
     pioran_dense_dims(N, &Mp, &ld);
     const size_t slab = (size_t)Mp * (size_t)ld + 1024;
-    // concurrent factorisations: as many slabs as fit in a third of the free memory, at most 8 (one stream each).  A single
+    // concurrent factorisations: as many slabs as fit in a third of the free memory, at most 16 (one stream each; round 3:
+    // tools/sweep_dense_streams.py, N = 4096: 4 streams 1.25 ms per factorisation, 8 1.05, 12 1.02, 16 0.96 = 0.30 of the MFMA peak).  A single
     // N = 4096 factorisation is a chain of 64 latency-bound steps that leaves most of the chip idle; independent matrices fill it.
-    int64_t ns = B < 8 ? B : 8;
+    const int64_t max_streams = ctx->opt.dense_streams > 0 && ctx->opt.dense_streams <= pioran_ctx::kDenseStreams ? ctx->opt.dense_streams : pioran_ctx::kDenseStreams;
+    int64_t ns = B < max_streams ? B : max_streams;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
@@ -1457,9 +1461,9 @@ int pioran_dense_nll_batch(pioran_ctx* ctx, int64_t N, int64_t J, int64_t B, con
     HIPCHK(ctx, hipMemcpyAsync(dt, t, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dy, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ds2, sigma2, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(ctx->dev_[8], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->dev_[pioran_ctx::kDenseStreams], ctx->stream));
     const int sorted = is_sorted(t, N);
-    for (int64_t i = 0; i < ns; ++i) HIPCHK(ctx, hipStreamWaitEvent(ctx->dstream[i], ctx->dev_[8], 0));
+    for (int64_t i = 0; i < ns; ++i) HIPCHK(ctx, hipStreamWaitEvent(ctx->dstream[i], ctx->dev_[pioran_ctx::kDenseStreams], 0));
     for (int64_t b = 0; b < B; ++b) {
         const int64_t i = b % ns;
         rc = pioran_dense_nll_device(N, (int32_t)J, dA + b * J, dB + b * J, cd_shared ? dC : dC + b * J, cd_shared ? dD : dD + b * J, dt, dy,

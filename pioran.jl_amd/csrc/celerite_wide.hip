@@ -1092,8 +1092,7 @@ static int launch_wide_mode(const ScanParams& p, hipStream_t stream)
     else if (p.R <= 63) hipLaunchKernelGGL((celerite_wide_kernel<4, MODE>), grid, block, 0, stream, p);
     else if (p.R <= 79) hipLaunchKernelGGL((celerite_wide_kernel<5, MODE>), grid, block, 0, stream, p);
     else if (p.R <= 95) {
-        if constexpr (MODE == 3) return PIORAN_ERR_UNSUPPORTED;   // (the adjoint pass stops at 79 rows)
-        else hipLaunchKernelGGL((celerite_wide_kernel<6, MODE>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((celerite_wide_kernel<6, MODE>), grid, block, 0, stream, p);
     } else {
         return PIORAN_ERR_UNSUPPORTED;   // 96 .. 143 rows: celerite_wide2_kernel above (log-likelihood only)
     }
@@ -1114,7 +1113,7 @@ int pioran_launch_scan_wide_sim(const ScanParams& p, hipStream_t stream)
     return launch_wide_mode<2>(p, stream);
 }
 
-static int rpl_of(int R) { return R <= 15 ? 1 : R <= 31 ? 2 : R <= 47 ? 3 : R <= 63 ? 4 : 5; }
+static int rpl_of(int R) { return R <= 15 ? 1 : R <= 31 ? 2 : R <= 47 ? 3 : R <= 63 ? 4 : R <= 79 ? 5 : 6; }
 
 // checkpoint interval of the gradient's forward pass: ~2 sqrt(N), between 16 and 256 (memory K + N/K blocks of S per draw)
 static int grad_ckpt_every(int64_t N)
@@ -1142,7 +1141,7 @@ size_t pioran_grad_workspace_doubles(int64_t B, int64_t N, int32_t R)
 int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, double* grad_b, double* grad_c, double* grad_d,
                                  double* grad_nu, double* grad_mu, hipStream_t stream, hipStream_t aux, hipEvent_t* ev)
 {
-    if (!p.tab || p.R > 79 || p.npd_rows || p.B <= 0 || p.B > 0x7fffffffLL || !grad_a || !grad_b) return PIORAN_ERR_UNSUPPORTED;
+    if (!p.tab || p.R > 95 || p.npd_rows || p.B <= 0 || p.B > 0x7fffffffLL || !grad_a || !grad_b) return PIORAN_ERR_UNSUPPORTED;
     const int rpl = rpl_of(p.R), ns = 16 * rpl;
     if (3 * (p.R + 2) + 2 + 3 * p.npd_rows + ns + 1 > kWideMaxRecord) return PIORAN_ERR_UNSUPPORTED;
     const size_t sp = (size_t)((rpl * rpl + 1) & ~1), nstate = (size_t)(rpl * rpl + 3 * rpl + 4);
@@ -1200,7 +1199,8 @@ int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, dou
     case 2: run(ic<2>{}); break;
     case 3: run(ic<3>{}); break;
     case 4: run(ic<4>{}); break;
-    default: run(ic<5>{}); break;
+    case 5: run(ic<5>{}); break;
+    default: run(ic<6>{}); break;   // 80 .. 95 rows (SHO-40, the dense configuration's model): round 3
     }
     hipLaunchKernelGGL(grad_finish_kernel, grid, block, 0, stream, p, ns, grad_a, grad_b, grad_c, grad_d, grad_nu, grad_mu);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
