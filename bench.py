@@ -82,7 +82,8 @@ def pmc_traffic(basis: str, J: int, B: int, N: int, kernel_config: str):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary of this same command (bench.py cannot collect
     PMCs on itself).  Quoted only when the summary was taken on the SAME kernel: same configuration name and same
     source fingerprint; otherwise null with the reason."""
-    f = ROOT / "profiles" / f"r02_pmc_{basis.lower()}{J}_b{B}.json"
+    cands = [ROOT / "profiles" / f"{r}_pmc_{basis.lower()}{J}_b{B}.json" for r in ("r03", "r02")]
+    f = next((c for c in cands if c.exists()), cands[0])
     if N != 10_000 or not f.exists():
         return None, f"no PMC summary for this workload ({f.name})"
     d = json.loads(f.read_text())
@@ -275,7 +276,7 @@ def main():
                              "profiles/r02_mfma_probe.txt), so there is no second pipe to overlap with. Budget (DESIGN.md 4.1; "
                              "profiles/r02_pmc_*.json, profiles/r02_valu_probe.txt): one DP instruction per ~4.6 cycles at two "
                              "wavefronts per SIMD, ~1.9 GHz of 2.4 under chip-wide FP64 issue, 1.53 flop per lane-instruction "
-                             "(two-step form: 242 instead of 280 instructions per wave-step), full (not triangular) state."},
+                             "(two-step form: 239 instead of 280 instructions per wave-step), full (not triangular) state."},
         "status_ok_frac": float((st_host == 0).mean()),
     }
 
@@ -410,6 +411,28 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
         "achieved_tflops_executed_rows": f_exec, "rows_executed": R_exec, "rows_reference": 2 * Jt,
         "max_rel_dlogl_vs_oracle": float((np.abs(got[:S][ok] - ref[ok]) / np.abs(ref[ok])).max()) if ok.any() else None,
         "oracle_sample": int(ok.sum())}
+
+    # -- the headline workload at larger batches per launch: does the rate hold when a launch is several "waves" of 2048
+    #    wavefronts (tail effects) — 8192 and 16384 draws (configs[3]'s 32768 draws are 8 such launches on 8 GPUs) ----------
+    big = {}
+    for nb in (8192, 16384):
+        th2, _, _ = synth_theta(nb, t, y, seed=777)
+        A2, B2, C2, D2 = pj.approx_batch(pj.SingleBendingPowerLaw, th2[:, :3], f_min, f_max, J, th2[:, 3], basis_function=args.basis)
+        real2 = (D2 == 0.0) & (B2 == 0.0).all(axis=0)
+        ds2 = pj.Dataset(t, y, s2, ctx); ds2.prepare(C2, D2, real2.astype(np.int32))
+        d2 = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (A2, B2, th2[:, 5].copy(), th2[:, 4].copy())]
+        o2 = torch.empty(nb, dtype=torch.float64, device=dev)
+        go2 = lambda: ds2.logl_batch_dev(nb, d2[0].data_ptr(), d2[1].data_ptr(), d2[2].data_ptr(), d2[3].data_ptr(), 0, 0, o2.data_ptr(), 0)
+        go2(); torch.cuda.synchronize(dev)
+        ms2 = []
+        for _ in range(3):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream); go2(); e1.record(stream); e1.synchronize(); ms2.append(e0.elapsed_time(e1))
+        R2 = int(2 * len(C2) - real2.sum())
+        big[f"B{nb}"] = {"kernel_ms": med(ms2), "evals_per_s": nb / (med(ms2) * 1e-3),
+                         "roofline_frac": algorithmic_flops(N, R2) * nb / (med(ms2) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+        ds2.close()
+    out["headline_larger_launches"] = big
 
     # -- single evaluation: configs[0] (N = 1e3) and configs[1] (N = 1e4), B = 1 -------------------------------------
     single = {}

@@ -6,10 +6,12 @@ there is no CPU fallback anywhere in this package.
 from __future__ import annotations
 
 import ctypes
+import os
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libpioran_hip.so"
+# PIORAN_HIP_LIB: another build of the same library (A/B timing of two kernel versions on one GPU box, tools/ab_bench.py)
+LIB_PATH = Path(os.environ["PIORAN_HIP_LIB"]) if os.environ.get("PIORAN_HIP_LIB") else _PKG / "libpioran_hip.so"
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Build-container side of tools/run_profiles.sh: reads the rocprofv3 outputs merged back under gpurun_out/r02/ and writes
-the tracked summaries under profiles/ (r02_*): kernel-trace stats of the bench command, the bench lines themselves, and
+"""Build-container side of tools/run_profiles.sh: reads the rocprofv3 outputs merged back under gpurun_out/<round>/ and writes
+the tracked summaries under profiles/ (<round>_*; round defaults to r03): kernel-trace stats of the bench command, the bench lines themselves, and
 one PMC summary per workload carrying the kernel's full template signature, the configuration name and the fingerprint
 of the kernel sources it was taken on (bench.py quotes `roofline.traffic` from it only while all three still match).
-usage: python tools/collect_profiles.py [gpurun_out/r02]"""
+usage: python tools/collect_profiles.py [gpurun_out/r03 [r03]]"""
 import csv, glob, json, shutil, sys
 from pathlib import Path
 
@@ -11,16 +11,17 @@ root = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(root))
 import bench  # noqa: E402  (scan_source_hash)
 
-src = Path(sys.argv[1]) if len(sys.argv) > 1 else root / "gpurun_out" / "r02"
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "r03"
+src = Path(sys.argv[1]) if len(sys.argv) > 1 else root / "gpurun_out" / ROUND
 prof = root / "profiles"
 for tag, basis in (("sho", "SHO"), ("drwcelerite", "DRWCelerite")):
     found = glob.glob(str(src / f"trace_{tag}" / "**" / "*kernel_stats.csv"), recursive=True)
-    assert len(found) == 1, f"{len(found)} kernel-trace summaries under {src}/trace_{tag}: remove gpurun_out/r02 before a new tools/run_profiles.sh run"
+    assert len(found) == 1, f"{len(found)} kernel-trace summaries under {src}/trace_{tag}: remove gpurun_out/<round> before a new tools/run_profiles.sh run"
     ks = found[0]
-    shutil.copy(ks, prof / f"r02_bench_{tag}20_b4096_kernel_stats.csv")
+    shutil.copy(ks, prof / f"{ROUND}_bench_{tag}20_b4096_kernel_stats.csv")
     line = [ln for ln in (src / f"bench_plain_{tag}.json").read_text().splitlines() if ln.startswith("{")][-1]
     plain = json.loads(line)
-    (prof / f"r02_bench_{tag}20_b4096.json").write_text(json.dumps(plain, indent=1))
+    (prof / f"{ROUND}_bench_{tag}20_b4096.json").write_text(json.dumps(plain, indent=1))
     traced = json.loads([ln for ln in (src / f"bench_trace_{tag}.json").read_text().splitlines() if ln.startswith("{")][-1])
     rows = list(csv.DictReader(open(ks)))
     krow = [r for r in rows if "celerite_scan_kernel" in r["Name"]][0]
@@ -50,7 +51,10 @@ for tag, basis in (("sho", "SHO"), ("drwcelerite", "DRWCelerite")):
         "valu_insts_per_wave_step": pd["SQ_INSTS_VALU"] / pd["SQ_WAVES"] / (N - 1),
         "fma_f64_share_of_valu": pd["SQ_INSTS_VALU_FMA_F64"] / pd["SQ_INSTS_VALU"], "mul_f64_share_of_valu": pd["SQ_INSTS_VALU_MUL_F64"] / pd["SQ_INSTS_VALU"],
         "flop_per_valu_lane_instruction": (2 * pd["SQ_INSTS_VALU_FMA_F64"] + pd["SQ_INSTS_VALU_MUL_F64"]) / pd["SQ_INSTS_VALU"],
+        "valu_active_share_of_wave_cycles": pd["SQ_ACTIVE_INST_VALU"] / pd["SQ_WAVE_CYCLES"],
+        "waitcnt_share_of_wave_cycles": pd.get("SQ_WAIT_ANY", float("nan")) / pd["SQ_WAVE_CYCLES"],
+        "issue_wait_share_of_wave_cycles": pd.get("SQ_WAIT_INST_ANY", float("nan")) / pd["SQ_WAVE_CYCLES"],
         "note": "FETCH_SIZE / WRITE_SIZE in KB; x2 on the fetch is the gfx950 correction of MI355X_MICROARCH.md (calibrated on 16 B/lane streams; these "
                 "are 8 B/lane buffer loads of an L2-resident table, so the corrected figure is an upper bound).  Median over the dispatches of the pass."}
-    (prof / f"r02_pmc_{tag}20_b4096.json").write_text(json.dumps(out, indent=1))
+    (prof / f"{ROUND}_pmc_{tag}20_b4096.json").write_text(json.dumps(out, indent=1))
     print(tag, json.dumps(out["derived"]), out["kernel_trace"])

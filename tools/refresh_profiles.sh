@@ -1,0 +1,23 @@
+#!/bin/bash
+# GPU-box script: re-measures every secondary number DESIGN.md quotes on the CURRENT kernels (one JSON / text file each under
+# gpurun_out/$ROUND/extra/), then tools/run_profiles.sh for the two throughput workloads.  Copy the results into profiles/ with
+# tools/collect_profiles.py + a plain cp of extra/*.  ROUND defaults to r03.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROUND=${ROUND:-r03}
+X=$ROOT/gpurun_out/$ROUND/extra
+mkdir -p "$X"
+cd "$ROOT"
+run() { name=$1; shift; timeout -k 10 300 "$@" > "$X/$name" 2> "$X/$name.err" || echo "$name failed" >&2; tail -c 400 "$X/$name"; echo; }
+run predict_simulate_n1e4_b256.json python3 tools/bench_predict.py
+run gradient_sho20.json python3 tools/bench_grad.py
+BASIS=DRWCelerite run gradient_drw20.json python3 tools/bench_grad.py
+run qpo_mixed_b4096.json python3 tools/bench_qpo.py
+run shift_transform_b4096.json python3 tools/bench_shift.py
+run small_batch_latency_sho20.json python3 tools/bench_small_batch.py
+BASIS=DRWCelerite run small_batch_latency_drw20.json python3 tools/bench_small_batch.py
+run host_api_pcie_inclusive.json python3 tools/bench_host_api.py
+run dense_n4096_j40.json python3 tools/bench_dense.py
+run bench_default_full_line.json python3 bench.py
+ROUND=$ROUND "$ROOT/tools/run_profiles.sh" > "$X/run_profiles.log" 2>&1
+tail -5 "$X/run_profiles.log"
