@@ -29,6 +29,13 @@
 #include <cstring>
 #include <type_traits>
 
+// Diagnostic hooks: compiled out in the product; tools/scan_probe.hip defines them to s_memtime accumulators.
+#ifndef PIORAN_SSTAMP
+#define PIORAN_SSTAMP(i)
+#define PIORAN_SSTAMP_DECL
+#define PIORAN_SSTAMP_FLUSH
+#endif
+
 namespace {
 
 template <int I>
@@ -855,6 +862,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         double Pm = 1.0, quad = 0.0;
         int Pe = 0;
         bool nonpd = false;
+        PIORAN_SSTAMP_DECL
         StepIn<RPL> sa, sb;
         [[maybe_unused]] double fy[RPL];   // YC: the y row of T for this lane's rows
 #pragma unroll
@@ -862,6 +870,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         // VOIDA: step A does not exist (D = 1, m = 0, no contribution); FIRST: step A is the first of the series (log D_1, :126)
         auto pair = [&](int64_t nA, auto voidc, auto firstc) __attribute__((always_inline)) {
             constexpr bool VOIDA = decltype(voidc)::value, FIRST = decltype(firstc)::value;
+            PIORAN_SSTAMP(0);
             double uB[RPL], tA[RPL], tB[RPL], pAB[RPL], rA[RPL], rB[RPL];
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
@@ -895,6 +904,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             // (the "+v" operands pin every source in its register before the pass: the compiler may not sink a producer between blocks)
 #pragma unroll
             for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(tA[i]), "+v"(tB[i]));
+            PIORAN_SSTAMP(1);
             asm volatile("s_nop 1");
             // the single slot that closes every block of a paired or block layout is padding or the y row in EVERY DPP row:
             // u = 0 there, so the column contributes nothing to T u~ (its own row of T is still needed: it is updated below)
@@ -903,6 +913,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 constexpr int c = decltype(Cc)::value;
                 MatVec2<RPL, c / RPL>::run(T[c], rA, rB, tA[c % RPL], tB[c % RPL]);
             });
+            PIORAN_SSTAMP(2);
             if constexpr (CBR >= 2) {
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) { rA[i] += lane_fetch(rA[i], p1); rB[i] += lane_fetch(rB[i], p1); }
@@ -911,11 +922,13 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) { rA[i] += lane_fetch(rA[i], p2); rB[i] += lane_fetch(rB[i], p2); }
             }
+            PIORAN_SSTAMP(3);
             double spA = 0.0, spB = 0.0;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) { spA += tA[i] * rA[i]; spB += tB[i] * rB[i]; }
             const double sA = group_sum<CBR, NSRC, GS>(spA, contributes, one, p1, p2);
             const double sB = group_sum<CBR, NSRC, GS>(spB, contributes, one, p1, p2);
+            PIORAN_SSTAMP(4);
             const double DA = VOIDA ? 1.0 : fma(nu, sa.s2, suma) - sA;                  // :92
             const double rDA = recip_f64(DA);
             double hA[RPL], mB[RPL], wA[RPL], wB[RPL], spg = 0.0;
@@ -929,8 +942,10 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             }
             if constexpr (YC) zA = VOIDA ? 0.0 : (sa.y - mu) - ryA;                      // z_A = y_A - mu - f'u~A   (phi_y = 1)
             [[maybe_unused]] const double ymB = sb.y - mu;
+            PIORAN_SSTAMP(5);
             load_step(nA + 2, sa);                                                       // step A's record is consumed
             const double g = group_sum<CBR, NSRC, GS>(spg, contributes, one, p1, p2);
+            PIORAN_SSTAMP(6);
             const double gr = g * rDA;
             const double DB = fma(nu, sb.s2, suma) - sB - g * gr;
             const double rDB = recip_f64(DB);
@@ -960,6 +975,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             // ---- T <- (phAB phAB') o T + hA wA' + mB wB' ----
 #pragma unroll
             for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(wA[i]), "+v"(wB[i]), "+v"(pAB[i]));
+            PIORAN_SSTAMP(7);
             asm volatile("s_nop 1");
             if constexpr (NPB > 0) {
                 static_for<0, NPB>([&](auto Pc) {
@@ -1004,6 +1020,8 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             n = 2;
         }
         for (; n + 1 < N; n += 2) pair(n, std::false_type{}, std::false_type{});
+        PIORAN_SSTAMP(0);
+        PIORAN_SSTAMP_FLUSH
         if (active && (YC ? (lane % G) == 0 : (isy && r == 0))) {
             const double logdet = log(Pm) + (double)Pe * 0.6931471805599453094;
             const double res = -0.5 * logdet - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * quad;
