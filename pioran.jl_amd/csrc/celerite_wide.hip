@@ -414,8 +414,16 @@ template <int RPL>
 __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams p)
 {
     constexpr int NS = 16 * RPL;                      // row slots; the last one is the y row
+    // LDS pitch of a lane's block of RPL slots.  A pitch of 8 doubles = 16 dwords puts four of the 16 lanes of a DPP row on each
+    // bank pair when they read element c of their blocks (RPL = 8 ran slower than RPL = 9: 13.0 vs 11.0 ms at N = 8192 once padded);
+    // the other row counts are conflict-free or two-way at worst, and keeping their blocks 16-byte aligned (merged 16-byte
+    // reads) is worth more than the padding (RPL = 4, 6 lost 5 - 8 % with an odd pitch)
+    constexpr int PITCH = RPL == 8 ? 9 : RPL;
+    constexpr int NSP = 16 * PITCH;
     constexpr int YS = RPL - 1;
-    constexpr int DG = 4;                             // records in flight from HBM per slot thread
+    constexpr bool LAZY = RPL >= 7;                   // column operands one column ahead from LDS (do_step)
+    constexpr int DG = LAZY ? 2 : 4;                  // records in flight from HBM per slot thread (a step of the big shapes takes
+                                                      // ~2 us: two ahead cover an HBM miss, and the registers go to S)
     const int tid = threadIdx.x;
     const int g = tid >> 4;                           // row block (DPP row of the draw)
     const int l = tid & 15;                           // column block
@@ -424,8 +432,8 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
     const int J = p.J, R = p.R, Rp = R + 2, RS = 3 * Rp + 2;
     const double* const tabb = p.tab + b * p.tab_draw_stride;   // per-draw tables (launches with per-draw (c, d)) or the shared one
 
-    __shared__ double sh_rec[2][3 * NS + 2];          // [u x NS | v x NS | phi x NS | sigma2_n], by step parity
-    __shared__ double sh_num[2][NS];                  // (v - q) of every row = D_n w
+    __shared__ double sh_rec[2][3 * NSP + 2];         // [u x NSP | v x NSP | phi x NSP | sigma2_n], by step parity; slot s at (s / RPL) PITCH + s % RPL
+    __shared__ double sh_num[2][NSP];                 // (v - q) of every row = D_n w (same addressing)
     __shared__ double sh_uq[2][16];                   // u'q share of every row block
 
     double suma = 0.0;  // :21
@@ -438,6 +446,7 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
     // ---- slot threads: sources of (v, x, phi) of slot `tid`; address = src + min(n, last) * stride ----------------------
     const bool slot_thread = tid < NS;
     const bool yslot = tid == NS - 1;
+    const int sa_ = (tid / RPL) * PITCH + tid % RPL;  // LDS address of this thread's slot
     const double* src[3] = {tabb, tabb, tabb};
     int64_t stride[3] = {0, 0, 0}, last[3] = {N, N, N};
     double al = 0.0, be = 0.0;
@@ -478,10 +487,10 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
     auto stage = [&](int par, const double (&v)[3]) __attribute__((always_inline)) {
         if (slot_thread) {
             double* r = sh_rec[par];
-            r[tid] = yslot ? 0.0 : al * v[0] + be * v[1];
-            r[NS + tid] = yslot ? v[0] - mu : v[0];
-            r[2 * NS + tid] = v[2];
-            if (yslot) r[3 * NS] = has_nu ? nu * v[1] : v[1];
+            r[sa_] = yslot ? 0.0 : al * v[0] + be * v[1];
+            r[NSP + sa_] = yslot ? v[0] - mu : v[0];
+            r[2 * NSP + sa_] = v[2];
+            if (yslot) r[3 * NSP] = has_nu ? nu * v[1] : v[1];
         }
     };
 
@@ -499,12 +508,12 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
         for (int c = 0; c < RPL; ++c) S[i][c] = 0.0;
     double num[RPL];      // (v - q) of this lane's rows at the last step = D_n W_n, the `dn` of :73
     double wc[RPL];       // W_n of this lane's columns
-    double Dn = suma + sh_rec[0][3 * NS];
+    double Dn = suma + sh_rec[0][3 * NSP];
     double rD = recip_f64(Dn);
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
-        num[i] = sh_rec[0][NS + g * RPL + i];         // z_1 = y_1 in the y row      :128
-        wc[i] = sh_rec[0][NS + l * RPL + i] * rD;
+        num[i] = sh_rec[0][NSP + g * PITCH + i];      // z_1 = y_1 in the y row      :128
+        wc[i] = sh_rec[0][NSP + l * PITCH + i] * rD;
     }
     double Pm = Dn;       // running product of |D| (sign of D_1 kept: log of a negative D_1 is NaN, :126)
     int Pe = 0;
@@ -515,6 +524,9 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
     }
     double quad = num[YS] * num[YS] * rD;             // meaningful in the y-row lanes only
     bool nonpd = !(Dn > 0.0);
+    if constexpr (LAZY) {   // step 0's (v - q) = v_0 of every slot, where step 1 looks for the previous step's exchange values
+        if (slot_thread) sh_num[0][sa_] = sh_rec[0][NSP + sa_];
+    }
     stage(1, gv[1 % DG]);
     fetch(DG + 1, gv[1 % DG]);
     __syncthreads();
@@ -523,37 +535,62 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
     auto do_step = [&](int64_t n, double (&gslot)[3]) __attribute__((always_inline)) {
         const int par = (int)(n & 1);
         const double* r = sh_rec[par];
-        double uc[RPL], cp[RPL], rp[RPL], qt[RPL];
+        double rp[RPL], qt[RPL];
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            uc[i] = r[l * RPL + i];
-            cp[i] = r[2 * NS + l * RPL + i];
-            rp[i] = r[2 * NS + g * RPL + i];
+            rp[i] = r[2 * NSP + g * PITCH + i];
             qt[i] = 0.0;
         }
         // ---- S update + this lane's share of q = S u ----
+        if constexpr (LAZY) {
+            // 7 .. 9 rows per lane: S alone is 98 .. 162 registers.  The column operands (u_c, phi_c and w_c = (v - q)_c / D of the
+            // previous step, still in its exchange buffer) are read from LDS one column ahead instead of all RPL at the top of the
+            // step: 6 live registers instead of 6 RPL, and the loop stops moving S through the AGPRs.
+            const double* ncp = sh_num[par ^ 1] + l * PITCH;
+            double ucn = r[l * PITCH], cpn = r[2 * NSP + l * PITCH], wcn = ncp[0] * rD;
 #pragma unroll
-        for (int c = 0; c < RPL; ++c)
+            for (int c = 0; c < RPL; ++c) {
+                const double uc = ucn, cp = cpn, wcc = wcn;
+                if (c + 1 < RPL) { ucn = r[l * PITCH + c + 1]; cpn = r[2 * NSP + l * PITCH + c + 1]; wcn = ncp[c + 1] * rD; }
+                asm volatile("" ::: "memory");   // compiler only: keep the next column's loads here, not at the top of the step
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    const double m = fma(num[i], wcc, S[i][c]);       // S + dn * V[k,n-1]          :78
+                    const double sn = (rp[i] * cp) * m;              // phi_j phi_k ( ... )        :78,85
+                    S[i][c] = sn;
+                    qt[i] = fma(sn, uc, qt[i]);                      // (S u)_j                    :80-82,86-89
+                }
+            }
+        } else {
+            double uc[RPL], cp[RPL];
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
-                const double m = fma(num[i], wc[c], S[i][c]);     // S + dn * V[k,n-1]          :78
-                const double sn = (rp[i] * cp[c]) * m;            // phi_j phi_k ( ... )        :78,85
-                S[i][c] = sn;
-                qt[i] = fma(sn, uc[c], qt[i]);                    // (S u)_j                    :80-82,86-89
+                uc[i] = r[l * PITCH + i];
+                cp[i] = r[2 * NSP + l * PITCH + i];
             }
+#pragma unroll
+            for (int c = 0; c < RPL; ++c)
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    const double m = fma(num[i], wc[c], S[i][c]);     // S + dn * V[k,n-1]          :78
+                    const double sn = (rp[i] * cp[c]) * m;            // phi_j phi_k ( ... )        :78,85
+                    S[i][c] = sn;
+                    qt[i] = fma(sn, uc[c], qt[i]);                    // (S u)_j                    :80-82,86-89
+                }
+        }
         double sp = 0.0;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             qt[i] = row16_sum(qt[i]);                             // over the 16 column blocks
-            num[i] = r[NS + g * RPL + i] - qt[i];                 // :89
-            sp = fma(r[g * RPL + i], qt[i], sp);                  // this row block's share of u'Su   :83,88
+            num[i] = r[NSP + g * PITCH + i] - qt[i];              // :89
+            sp = fma(r[g * PITCH + i], qt[i], sp);                // this row block's share of u'Su   :83,88
         }
-        const double s2n = r[3 * NS];
+        const double s2n = r[3 * NSP];
         // ---- the one exchange of the step (+ the next record on its way through LDS) ----
         if (l == 0) {
             sh_uq[par][g] = sp;
 #pragma unroll
-            for (int i = 0; i < RPL; ++i) sh_num[par][g * RPL + i] = num[i];
+            for (int i = 0; i < RPL; ++i) sh_num[par][g * PITCH + i] = num[i];
         }
         stage(par ^ 1, gslot);
         fetch(n + 1 + DG, gslot);
@@ -561,15 +598,14 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
         double sh[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) sh[k] = sh_uq[par][k];
-        double nc[RPL];
-#pragma unroll
-        for (int i = 0; i < RPL; ++i) nc[i] = sh_num[par][l * RPL + i];
         const double s = (((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]))) +
                          (((sh[8] + sh[9]) + (sh[10] + sh[11])) + ((sh[12] + sh[13]) + (sh[14] + sh[15])));
         Dn = suma + s2n - s;                                     // :92
         rD = recip_f64(Dn);
+        if constexpr (!LAZY) {
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) wc[i] = nc[i] * rD;        // :96
+            for (int i = 0; i < RPL; ++i) wc[i] = sh_num[par][l * PITCH + i] * rD;   // :96
+        }
         const double z = num[YS];                                // y row: z_n = y_n - u'f      :141
         nonpd |= !(Dn > 0.0);
         Pm *= fabs(Dn);                                          // log(abs(D[n]))  :140
