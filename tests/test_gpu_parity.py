@@ -192,12 +192,24 @@ def test_rows_64_to_143_lean_latency_layout(ctx, J, N, B):
     finally:
         ctx.set_option("force_fallback", False)
     assert relerr(fb, ref) < 1e-11
+    plain = ds.logl_batch(A, Bc, C, Dd)                                          # no mu, no nu
+    assert relerr(plain, O.logl_batch(A, Bc, C, Dd, t, y, s2, np.zeros(B), np.ones(B), nthreads=8)) < 1e-11
     if 2 * J > 79:
         # per-draw (c, d) past the throughput layouts' 79 rows: every draw gets its own table, the same kernel walks it
         C2 = np.tile(C, (B, 1)) * rng.uniform(0.8, 1.2, (B, J)); D2 = np.tile(Dd, (B, 1)) * rng.uniform(0.8, 1.2, (B, J))
         got3, st3 = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu, Y=Y, S2=S2, return_status=True)
         ref3 = np.array([O.logl(A[i], Bc[i], C2[i], D2[i], t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(B)])
         assert relerr(got3, ref3) < 1e-11 and (st3 == 0).all()
+
+
+def test_per_draw_tables_in_chunks(ctx):
+    """Per-draw (c, d) with 80 rows and more draws than one chunk of per-draw tables holds (256): two chunks, ragged tail."""
+    rng = np.random.default_rng(77)
+    N, B, J = 24, 300, 40
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B, per_draw_cd=True)
+    got, st = pj.Dataset(t, y, s2, ctx).logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+    ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+    assert relerr(got, ref) < 1e-11 and (st == 0).all()
 
 
 def test_lean_latency_layout_mixed_rows_and_nonpd(ctx):
