@@ -1245,9 +1245,14 @@ void launch_ycol(const ScanParams& p, dim3 grid, hipStream_t st)
 // variants of round 1 were dropped when the DPP-folded ones became the faster choice in every row range
 // (SHO-30: 140 k vs 116 k evals/s, SHO-39: 60 k vs 52 k; profiles/r02_scan_variants.txt).
 const ScanConfig kConfigs[] = {
+    // (the _y entries: y as a separate vector, one more row than the shape otherwise holds — R = 16, 32, 48, 64 are the reference
+    //  benchmark's j = 8, 16, (24,) 32, benchmark/benchmarks.jl:16-18; shared-table launches only)
     CFG(1, 1, 5),  CFG(1, 1, 9),  CFG(1, 1, 13), CFG(1, 1, 16),           // R <= 15
+    {"rpl1_cbr1_nsrc16_y", 1, 1, 16, &launch_ycol<1, 1, 16, 1, false>, false, true, 0, true},   // R = 16
     CFG(2, 1, 9),  CFG(2, 1, 11), CFG(2, 1, 13), CFG(2, 1, 15), CFG(2, 1, 16),  // R <= 31
+    {"rpl2_cbr1_nsrc16_y", 2, 1, 16, &launch_ycol<2, 1, 16, 1, false>, false, true, 0, true},   // R = 32
     CFG(3, 2, 6),  CFG(3, 2, 7),  CFG(3, 2, 8),                           // R <= 47
+    {"rpl3_cbr2_nsrc8_y", 3, 2, 8, &launch_ycol<3, 2, 8, 1, false>, false, true, 0, true},      // R = 48
     {"rpl4_cbr4_nsrc4", 4, 4, 4, &launch_cfg<4, 4, 4, 2, false, true>},   // R <= 63: 256 registers/lane, 2 waves per SIMD
     {"rpl4_cbr4_nsrc4_y", 4, 4, 4, &launch_ycol<4, 4, 4, 2, false>, false, true, 0, true},   // R = 64: y as a separate vector
     CFG(5, 4, 4),                                                         // R <= 79
@@ -1257,6 +1262,9 @@ const ScanConfig kConfigs[] = {
     CFG_P(2, 1, 9, 1), CFG_P(2, 1, 11, 1), CFG_P(2, 1, 13, 1), CFG_P(2, 1, 15, 1), CFG_P(2, 1, 16, 1),
     {"rpl4_cbr4_nsrc4_p", 4, 4, 4, &launch_cfg<4, 4, 4, 2, true, true>, true},
     {"rpl4_cbr4_nsrc4_yp", 4, 4, 4, &launch_ycol<4, 4, 4, 2, true>, true, true, 0, true}, CFG_P(5, 4, 4, 1),
+    {"rpl1_cbr1_nsrc16_yp", 1, 1, 16, &launch_ycol<1, 1, 16, 1, true>, true, true, 0, true},
+    {"rpl2_cbr1_nsrc16_yp", 2, 1, 16, &launch_ycol<2, 1, 16, 1, true>, true, true, 0, true},
+    {"rpl3_cbr2_nsrc8_yp", 3, 2, 8, &launch_ycol<3, 2, 8, 1, true>, true, true, 0, true},
     // DRWCelerite with 20 components: 20 complex + 20 real terms = 5 pairs + 5 singles + 1 spare in each of the 4 blocks
     {"rpl4_cbr4_nsrc4_b5a", 4, 4, 4, &launch_blocked<4, 4, 4, 2, 5>, false, true, 5},
     // alternatives kept for tuning runs (selected by name)
@@ -1264,7 +1272,7 @@ const ScanConfig kConfigs[] = {
 };
 #undef CFG
 #undef CFG_P
-constexpr int kNumPreferred = 15;
+constexpr int kNumPreferred = 18;
 
 // y-as-a-vector shapes exist in the two-step form for launches without per-draw rows only
 bool ycol_usable(const ScanConfig& c, const ScanParams* p)

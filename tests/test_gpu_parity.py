@@ -236,6 +236,33 @@ def test_lean_latency_layout_mixed_rows_and_nonpd(ctx):
     assert relerr(got3[fin], ref3[fin]) < 1e-9 and ((st3 != 0) == (rst3 != 0)).all()
 
 
+@pytest.mark.parametrize("J,cfg", [(8, "rpl1_cbr1_nsrc16_yp"), (16, "rpl2_cbr1_nsrc16_yp"), (24, "rpl3_cbr2_nsrc8_yp")])
+@pytest.mark.parametrize("N", [1, 2, 5, 130])
+def test_one_more_row_with_y_as_a_vector(ctx, J, cfg, N):
+    """R = 16, 32, 48 rows (the reference benchmark's j = 8, 16 and SHO-24) in the 16-, 32- and 48-slot shapes: y as a separate
+    vector (kernel template YC) frees the slot it used to take; several draws per wavefront here (four, four, two)."""
+    rng = np.random.default_rng(900 + J + N)
+    B = 45
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    ds = pj.Dataset(t, y, s2, ctx)
+    try:
+        ctx.set_option("no_block", True); ctx.set_option("no_wide", True)
+        got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        assert pj._lib.lib().pioran_celerite_config_name(0).decode() == cfg
+        assert relerr(got, O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)) < 1e-11 and (st == 0).all()
+        Y = rng.standard_normal((B, N)); S2 = rng.uniform(0.01, 0.1, (B, N))
+        got2 = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+        ref2 = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(B)])
+        assert relerr(got2, ref2) < 1e-11
+        A2 = A.copy(); A2[3, 0] = -40.0                          # a draw that is not positive definite: status and log|D| semantics
+        got3, st3 = ds.logl_batch(A2, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        ref3, rst3 = O.logl_batch(A2, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8, return_status=True)
+        fin = np.isfinite(ref3)
+        assert (np.isnan(got3) == np.isnan(ref3)).all() and ((st3 != 0) == (rst3 != 0)).all() and relerr(got3[fin], ref3[fin]) < 1e-9
+    finally:
+        ctx.set_option("no_block", False); ctx.set_option("no_wide", False)
+
+
 @pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 64, 257])
 def test_64_rows_in_the_64_row_shape(ctx, N):
     """R = 64 rows (the reference benchmark's j = 32, benchmark/benchmarks.jl:16-18) in the 64-row throughput shape: y rides as a
