@@ -410,7 +410,11 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
 // every u 16 times.  With RPL >= 5 that kernel's loop moves 140 .. 200 values per step between VGPRs and AGPRs; here the
 // registers hold S (RPL x RPL), the row / column vectors of the step and nothing else, which is what makes 7 .. 9 rows per
 // lane (the reference benchmark's j = 64: 128 rows + y, benchmark/benchmarks.jl:16-18) fit at all.
-template <int RPL>
+// YC: y is not a row slot (all 16 RPL slots can be rows: R = 16 RPL exactly — the reference grid's j = 32 and 64 are R = 64 and 128 —
+// runs with one row per lane less than it would with the y slot).  The forward solve is then the reference's own recurrence
+// f <- phi o (f + W_{n-1} z_{n-1}), z_n = y_n - u_n'f (src/celerite_solver.jl:136-141) on the lane's COLUMN block (replicated in
+// the 16 DPP rows), its dot product one more 16-lane sum per step; thread 255 stages y_n - mu and sigma2_n.
+template <int RPL, bool YC = false>
 __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams p)
 {
     constexpr int NS = 16 * RPL;                      // row slots; the last one is the y row
@@ -444,8 +448,8 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
     const bool yrow = g == 15;                        // this lane's row slot YS is the y row
 
     // ---- slot threads: sources of (v, x, phi) of slot `tid`; address = src + min(n, last) * stride ----------------------
-    const bool slot_thread = tid < NS;
-    const bool yslot = tid == NS - 1;
+    const bool slot_thread = tid < NS || (YC && tid == 255);
+    const bool yslot = YC ? tid == 255 : tid == NS - 1;
     const int sa_ = (tid / RPL) * PITCH + tid % RPL;  // LDS address of this thread's slot
     const double* src[3] = {tabb, tabb, tabb};
     int64_t stride[3] = {0, 0, 0}, last[3] = {N, N, N};
@@ -487,9 +491,13 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
     auto stage = [&](int par, const double (&v)[3]) __attribute__((always_inline)) {
         if (slot_thread) {
             double* r = sh_rec[par];
-            r[sa_] = yslot ? 0.0 : al * v[0] + be * v[1];
-            r[NSP + sa_] = yslot ? v[0] - mu : v[0];
-            r[2 * NSP + sa_] = v[2];
+            if (YC && yslot) {
+                r[3 * NSP + 1] = v[0] - mu;
+            } else {
+                r[sa_] = yslot ? 0.0 : al * v[0] + be * v[1];
+                r[NSP + sa_] = yslot ? v[0] - mu : v[0];
+                r[2 * NSP + sa_] = v[2];
+            }
             if (yslot) r[3 * NSP] = has_nu ? nu * v[1] : v[1];
         }
     };
@@ -522,10 +530,14 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
         Pm = frexp(Pm, &ex);
         Pe += ex;
     }
-    double quad = num[YS] * num[YS] * rD;             // meaningful in the y-row lanes only
+    [[maybe_unused]] double fy[RPL];                  // YC: f of this lane's column block
+    [[maybe_unused]] double zprev = YC ? sh_rec[0][3 * NSP + 1] : 0.0;   // z_1 = y_1 - mu      :128
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) fy[i] = 0.0;
+    double quad = YC ? zprev * zprev * rD : num[YS] * num[YS] * rD;   // (without YC: meaningful in the y-row lanes only)
     bool nonpd = !(Dn > 0.0);
     if constexpr (LAZY) {   // step 0's (v - q) = v_0 of every slot, where step 1 looks for the previous step's exchange values
-        if (slot_thread) sh_num[0][sa_] = sh_rec[0][NSP + sa_];
+        if (tid < NS) sh_num[0][sa_] = sh_rec[0][NSP + sa_];
     }
     stage(1, gv[1 % DG]);
     fetch(DG + 1, gv[1 % DG]);
@@ -536,6 +548,7 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
         const int par = (int)(n & 1);
         const double* r = sh_rec[par];
         double rp[RPL], qt[RPL];
+        [[maybe_unused]] double zpart = 0.0;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             rp[i] = r[2 * NSP + g * PITCH + i];
@@ -553,6 +566,10 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
                 const double uc = ucn, cp = cpn, wcc = wcn;
                 if (c + 1 < RPL) { ucn = r[l * PITCH + c + 1]; cpn = r[2 * NSP + l * PITCH + c + 1]; wcn = ncp[c + 1] * rD; }
                 asm volatile("" ::: "memory");   // compiler only: keep the next column's loads here, not at the top of the step
+                if constexpr (YC) {
+                    fy[c] = cp * fma(wcc, zprev, fy[c]);             // f <- phi o (f + W_{n-1} z_{n-1})    :136
+                    zpart = fma(uc, fy[c], zpart);                   // u_n'f                               :137
+                }
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) {
                     const double m = fma(num[i], wcc, S[i][c]);       // S + dn * V[k,n-1]          :78
@@ -569,7 +586,11 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
                 cp[i] = r[2 * NSP + l * PITCH + i];
             }
 #pragma unroll
-            for (int c = 0; c < RPL; ++c)
+            for (int c = 0; c < RPL; ++c) {
+                if constexpr (YC) {
+                    fy[c] = cp[c] * fma(wc[c], zprev, fy[c]);         // f <- phi o (f + W_{n-1} z_{n-1})    :136
+                    zpart = fma(uc[c], fy[c], zpart);                 // u_n'f                               :137
+                }
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) {
                     const double m = fma(num[i], wc[c], S[i][c]);     // S + dn * V[k,n-1]          :78
@@ -577,7 +598,10 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
                     S[i][c] = sn;
                     qt[i] = fma(sn, uc[c], qt[i]);                    // (S u)_j                    :80-82,86-89
                 }
+            }
         }
+        [[maybe_unused]] double zn = 0.0;
+        if constexpr (YC) zn = r[3 * NSP + 1] - row16_sum(zpart);    // z_n = y_n - mu - u_n'f     :141
         double sp = 0.0;
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
@@ -606,7 +630,8 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
 #pragma unroll
             for (int i = 0; i < RPL; ++i) wc[i] = sh_num[par][l * PITCH + i] * rD;   // :96
         }
-        const double z = num[YS];                                // y row: z_n = y_n - u'f      :141
+        const double z = YC ? zn : num[YS];                      // (y row: z_n = y_n - u'f      :141)
+        if constexpr (YC) zprev = zn;
         nonpd |= !(Dn > 0.0);
         Pm *= fabs(Dn);                                          // log(abs(D[n]))  :140
         {                                                        // mantissa/exponent split
@@ -630,7 +655,7 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
         if (n + k < N) do_step(n + k, gv[(2 + k) % DG]);
     });
 
-    if (yrow && l == 0) {
+    if (YC ? tid == 0 : (yrow && l == 0)) {
         const double logdet = log(Pm) + (double)Pe * 0.6931471805599453094;
         const double res = -0.5 * logdet - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * quad;
         p.out[b] = res;
@@ -1106,6 +1131,17 @@ static int launch_wide_mode(const ScanParams& p, hipStream_t stream)
         // that the register copies of celerite_wide_kernel are still cheaper: R = 40 4.8 vs 5.1 ms), or on request
         const bool lean = (p.opt && p.opt->wide2) || (p.R >= 48 && !(p.opt && p.opt->no_wide2));
         if (lean || p.R > 95 || p.tab_draw_stride != 0) {
+            if (p.R % 16 == 0 && p.R >= 48 && p.npd_rows == 0) {   // exactly 16 RPL rows: y as a vector, one row per lane less
+                switch (p.R / 16) {
+                case 3: hipLaunchKernelGGL((celerite_wide2_kernel<3, true>), grid, block, 0, stream, p); break;
+                case 4: hipLaunchKernelGGL((celerite_wide2_kernel<4, true>), grid, block, 0, stream, p); break;
+                case 5: hipLaunchKernelGGL((celerite_wide2_kernel<5, true>), grid, block, 0, stream, p); break;
+                case 6: hipLaunchKernelGGL((celerite_wide2_kernel<6, true>), grid, block, 0, stream, p); break;
+                case 7: hipLaunchKernelGGL((celerite_wide2_kernel<7, true>), grid, block, 0, stream, p); break;
+                default: hipLaunchKernelGGL((celerite_wide2_kernel<8, true>), grid, block, 0, stream, p); break;
+                }
+                return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+            }
             switch ((p.R + 1 + 15) / 16) {
             case 1: hipLaunchKernelGGL(celerite_wide2_kernel<1>, grid, block, 0, stream, p); break;
             case 2: hipLaunchKernelGGL(celerite_wide2_kernel<2>, grid, block, 0, stream, p); break;
