@@ -1256,6 +1256,7 @@ const ScanConfig kConfigs[] = {
     {"rpl4_cbr4_nsrc4", 4, 4, 4, &launch_cfg<4, 4, 4, 2, false, true>},   // R <= 63: 256 registers/lane, 2 waves per SIMD
     {"rpl4_cbr4_nsrc4_y", 4, 4, 4, &launch_ycol<4, 4, 4, 2, false>, false, true, 0, true},   // R = 64: y as a separate vector
     CFG(5, 4, 4),                                                         // R <= 79
+    {"rpl5_cbr4_nsrc4_y", 5, 4, 4, &launch_ycol<5, 4, 4, 1, false>, false, true, 0, true},   // R = 80 (SHO-40: the dense configuration's model)
     // column-paired variants (standard row map only; picked automatically by pick_config when applicable)
     {"rpl3_cbr2_nsrc7_p", 3, 2, 7, &launch_cfg<3, 2, 7, 1, true, true>, true}, CFG_P(3, 2, 8, 1), CFG_P(3, 2, 6, 1),
     CFG_P(1, 1, 5, 1), CFG_P(1, 1, 9, 1), CFG_P(1, 1, 13, 1), CFG_P(1, 1, 16, 1),
@@ -1265,6 +1266,7 @@ const ScanConfig kConfigs[] = {
     {"rpl1_cbr1_nsrc16_yp", 1, 1, 16, &launch_ycol<1, 1, 16, 1, true>, true, true, 0, true},
     {"rpl2_cbr1_nsrc16_yp", 2, 1, 16, &launch_ycol<2, 1, 16, 1, true>, true, true, 0, true},
     {"rpl3_cbr2_nsrc8_yp", 3, 2, 8, &launch_ycol<3, 2, 8, 1, true>, true, true, 0, true},
+    {"rpl5_cbr4_nsrc4_yp", 5, 4, 4, &launch_ycol<5, 4, 4, 1, true>, true, true, 0, true},
     // DRWCelerite with 20 components: 20 complex + 20 real terms = 5 pairs + 5 singles + 1 spare in each of the 4 blocks
     {"rpl4_cbr4_nsrc4_b5a", 4, 4, 4, &launch_blocked<4, 4, 4, 2, 5>, false, true, 5},
     // alternatives kept for tuning runs (selected by name)
@@ -1272,7 +1274,7 @@ const ScanConfig kConfigs[] = {
 };
 #undef CFG
 #undef CFG_P
-constexpr int kNumPreferred = 18;
+constexpr int kNumPreferred = 19;
 
 // y-as-a-vector shapes exist in the two-step form for launches without per-draw rows only
 bool ycol_usable(const ScanConfig& c, const ScanParams* p)
@@ -1322,6 +1324,8 @@ const ScanConfig* pick_config(int R, bool standard_rows, const ScanParams* p = n
 }  // namespace
 
 int pioran_scan_supported_rows() { return 79; }
+// one more with a shared table and no per-draw rows (y as a separate vector): 80 rows = SHO-40
+int pioran_scan_supported_rows_shared() { return 80; }
 
 static thread_local const char* g_last_config = "none";
 

@@ -91,6 +91,7 @@ struct ScanParams {
 // celerite_scan.hip
 int pioran_launch_scan(const ScanParams& p, hipStream_t stream);
 int pioran_scan_supported_rows();
+int pioran_scan_supported_rows_shared();
 const char* pioran_scan_config_name(int R);
 // celerite_wide.hip: latency layout for small batches (one draw per workgroup); shared-table launches only
 int pioran_launch_scan_wide(const ScanParams& p, hipStream_t stream);
