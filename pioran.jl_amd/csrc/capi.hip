@@ -263,7 +263,9 @@ int block_dispatch(pioran_ds* ds, const ScanParams& p)
     const char* cfg = o.scan_config[0] ? o.scan_config : nullptr;
     const bool force = cfg && !std::strcmp(cfg, "block");
     // measured on N = 1e4 (tools/sweep_block.py): faster than both other kernels up to 512 draws from 6 rows on
-    const bool automatic = !cfg && !o.no_block && p.B <= 512 && p.R >= 6;
+    // (round 3, tools/sweep_midbatch.py: from 42 rows on three rounds of 256 workgroups still beat the throughput shapes at 768 draws:
+    //  DRWCelerite-20 7.7 vs 9.2 ms, SHO-23 6.0 vs 7.5 ms; at 40 rows it is a tie, below the throughput shapes win)
+    const bool automatic = !cfg && !o.no_block && (p.B <= 512 || (p.B <= 768 && p.R >= 42)) && p.R >= 6;
     if (!(force || automatic) || !p.tab || p.npd_rows != 0 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
     PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
     if (!s || !s->prepared || s->npd_terms != 0 || p.rec_stride != 3 * (int64_t)(s->R + 2) + 2) return PIORAN_ERR_UNSUPPORTED;
