@@ -93,8 +93,8 @@ int pioran_dataset_destroy(pioran_ds* ds);
  * differ per draw — is accepted for table-building purposes but the *_dev entries then return PIORAN_ERR_ARG: per-draw
  * terms go through the host-pointer entry with cd_shared = 0, which builds the mixed table itself.)
  * The declared state persists until the next pioran_dataset_prepare on this data set; no other entry changes it.
- * Device memory: the table takes (6 J + 8)(N + 1) * 8 bytes (10 MB at N = 1e4, J = 20); the first batch of at most 512
- * draws (6 .. 63 rows) builds a second table for the windowed small-batch kernel, ~(30 J + 300) N bytes (37 MB there),
+ * Device memory: the table takes (6 J + 8)(N + 1) * 8 bytes (10 MB at N = 1e4, J = 20); the first small batch (at most 512
+ * draws, 768 from 42 rows on; 6 .. 63 rows) builds a second table for the windowed small-batch kernel, ~(30 J + 300) N bytes (37 MB there),
  * and falls back to the other kernels if that does not fit (2 GB cap). */
 int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const double* d,
                            const int32_t* real_term);
