@@ -71,6 +71,7 @@ int pioran_ctx_trim(pioran_ctx* ctx);
  *                     small-batch kernel / the column-paired variants / the mixed shared+per-draw table / sends everything through
  *                     the any-rank kernel; NULL, "" or "0" = off.
  *   "win2" / "no_win2"  force / forbid the two-step form of the throughput layouts (default: on up to four rows per lane, i.e. R <= 63)
+ *   "win3" / "no_win3"  force / forbid the three-step form (two or three rows per lane; default: on for R = 24 .. 31 in large batches)
  *   "wide2" / "no_wide2"  force / forbid the lean form of the latency layout (default: from 48 rows on; the only form for 96 .. 143 rows)
  * Initial values come from the environment variables PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_BLOCK, PIORAN_NO_PAIRED,
  * PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK, PIORAN_WIN2, PIORAN_NO_WIN2, read once when the context is created. */

@@ -353,6 +353,8 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "no_block")) o.no_block = on;
     else if (!std::strcmp(key, "win2")) o.win2 = on;
     else if (!std::strcmp(key, "no_win2")) o.no_win2 = on;
+    else if (!std::strcmp(key, "win3")) o.win3 = on;
+    else if (!std::strcmp(key, "no_win3")) o.no_win3 = on;
     else if (!std::strcmp(key, "dense_streams")) o.dense_streams = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "gsum")) o.gsum = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "wide2")) o.wide2 = on;

@@ -25,6 +25,7 @@
 // FP64 VALU bound (no MFMA: the update is rank-1 per draw, nothing is shared across draws).
 #include "common.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -528,6 +529,139 @@ struct Update2Second<5, N> {
                      : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [g3] "v"(hA[3]), [g4] "v"(hA[4]), [m0] "v"(mB[0]), [m1] "v"(mB[1]), [m2] "v"(mB[2]), [m3] "v"(mB[3]), [m4] "v"(mB[4]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]), [p3] "v"(pp[3]), [p4] "v"(pp[4]), [wa] "v"(wa), [wb] "v"(wb), [n] "i"(N));
     }
 };
+template <int RPL, int N> struct MatVec3;
+template <int RPL, int N> struct Update3;
+template <int RPL, int N> struct Update3First;
+template <int RPL, int N> struct Update3Second;
+template <int N>
+struct MatVec3<1, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k), rC += T bcast(u~C_k) for one column k of this lane's rows
+    static __device__ __forceinline__ void run(const double (&T)[1], double (&rA)[1], double (&rB)[1], double (&rC)[1], double ua, double ub, double uc)
+    {
+        asm volatile(PD_FMAC(a0, ua, t0) PD_FMAC(b0, ub, t0) PD_FMAC(c0, uc, t0)
+                     : [a0] "+v"(rA[0]), [b0] "+v"(rB[0]), [c0] "+v"(rC[0])
+                     : [t0] "v"(T[0]), [ua] "v"(ua), [ub] "v"(ub), [uc] "v"(uc), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update3<1, N> {   // T = (cC_i bcast(cC_k)) T + hA_i bcast(wA_k) + hB_i bcast(wB_k) + mC_i bcast(wC_k)
+    static __device__ __forceinline__ void run(double (&T)[1], const double (&hA)[1], const double (&hB)[1], const double (&mC)[1], const double (&ph)[1],
+                                               double wa, double wb, double wc, double phs)
+    {
+        double pk, pp[1];
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(t0, p0, t0) PD_FMAC(t0, wa, g0) PD_FMAC(t0, wb, k0) PD_FMAC(t0, wc, m0)
+                     : [t0] "+v"(T[0]), [pk] "=&v"(pk), [p0] "=&v"(pp[0])
+                     : [g0] "v"(hA[0]), [k0] "v"(hB[0]), [m0] "v"(mC[0]), [h0] "v"(ph[0]), [wa] "v"(wa), [wb] "v"(wb), [wc] "v"(wc), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update3First<1, N> {   // first column of a (cos, sin) pair: also hands cC_i cC_k to the second
+    static __device__ __forceinline__ void run(double (&T)[1], const double (&hA)[1], const double (&hB)[1], const double (&mC)[1], const double (&ph)[1],
+                                               double wa, double wb, double wc, double phs, double (&pp)[1])
+    {
+        double pk;
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(t0, p0, t0) PD_FMAC(t0, wa, g0) PD_FMAC(t0, wb, k0) PD_FMAC(t0, wc, m0)
+                     : [t0] "+v"(T[0]), [pk] "=&v"(pk), [p0] "=&v"(pp[0])
+                     : [g0] "v"(hA[0]), [k0] "v"(hB[0]), [m0] "v"(mC[0]), [h0] "v"(ph[0]), [wa] "v"(wa), [wb] "v"(wb), [wc] "v"(wc), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update3Second<1, N> {
+    static __device__ __forceinline__ void run(double (&T)[1], const double (&hA)[1], const double (&hB)[1], const double (&mC)[1], double wa, double wb, double wc,
+                                               const double (&pp)[1])
+    {
+        asm volatile(PD_MUL(t0, p0, t0) PD_FMAC(t0, wa, g0) PD_FMAC(t0, wb, k0) PD_FMAC(t0, wc, m0)
+                     : [t0] "+v"(T[0])
+                     : [g0] "v"(hA[0]), [k0] "v"(hB[0]), [m0] "v"(mC[0]), [p0] "v"(pp[0]), [wa] "v"(wa), [wb] "v"(wb), [wc] "v"(wc), [n] "i"(N));
+    }
+};
+template <int N>
+struct MatVec3<2, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k), rC += T bcast(u~C_k) for one column k of this lane's rows
+    static __device__ __forceinline__ void run(const double (&T)[2], double (&rA)[2], double (&rB)[2], double (&rC)[2], double ua, double ub, double uc)
+    {
+        asm volatile(PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1) PD_FMAC(c0, uc, t0) PD_FMAC(c1, uc, t1)
+                     : [a0] "+v"(rA[0]), [a1] "+v"(rA[1]), [b0] "+v"(rB[0]), [b1] "+v"(rB[1]), [c0] "+v"(rC[0]), [c1] "+v"(rC[1])
+                     : [t0] "v"(T[0]), [t1] "v"(T[1]), [ua] "v"(ua), [ub] "v"(ub), [uc] "v"(uc), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update3<2, N> {   // T = (cC_i bcast(cC_k)) T + hA_i bcast(wA_k) + hB_i bcast(wB_k) + mC_i bcast(wC_k)
+    static __device__ __forceinline__ void run(double (&T)[2], const double (&hA)[2], const double (&hB)[2], const double (&mC)[2], const double (&ph)[2],
+                                               double wa, double wb, double wc, double phs)
+    {
+        double pk, pp[2];
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t0, wb, k0) PD_FMAC(t1, wb, k1) PD_FMAC(t0, wc, m0) PD_FMAC(t1, wc, m1)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [k0] "v"(hB[0]), [k1] "v"(hB[1]), [m0] "v"(mC[0]), [m1] "v"(mC[1]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [wa] "v"(wa), [wb] "v"(wb), [wc] "v"(wc), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update3First<2, N> {   // first column of a (cos, sin) pair: also hands cC_i cC_k to the second
+    static __device__ __forceinline__ void run(double (&T)[2], const double (&hA)[2], const double (&hB)[2], const double (&mC)[2], const double (&ph)[2],
+                                               double wa, double wb, double wc, double phs, double (&pp)[2])
+    {
+        double pk;
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t0, wb, k0) PD_FMAC(t1, wb, k1) PD_FMAC(t0, wc, m0) PD_FMAC(t1, wc, m1)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [k0] "v"(hB[0]), [k1] "v"(hB[1]), [m0] "v"(mC[0]), [m1] "v"(mC[1]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [wa] "v"(wa), [wb] "v"(wb), [wc] "v"(wc), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update3Second<2, N> {
+    static __device__ __forceinline__ void run(double (&T)[2], const double (&hA)[2], const double (&hB)[2], const double (&mC)[2], double wa, double wb, double wc,
+                                               const double (&pp)[2])
+    {
+        asm volatile(PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t0, wb, k0) PD_FMAC(t1, wb, k1) PD_FMAC(t0, wc, m0) PD_FMAC(t1, wc, m1)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [k0] "v"(hB[0]), [k1] "v"(hB[1]), [m0] "v"(mC[0]), [m1] "v"(mC[1]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [wa] "v"(wa), [wb] "v"(wb), [wc] "v"(wc), [n] "i"(N));
+    }
+};
+template <int N>
+struct MatVec3<3, N> {   // rA += T bcast(u~A_k), rB += T bcast(u~B_k), rC += T bcast(u~C_k) for one column k of this lane's rows
+    static __device__ __forceinline__ void run(const double (&T)[3], double (&rA)[3], double (&rB)[3], double (&rC)[3], double ua, double ub, double uc)
+    {
+        asm volatile(PD_FMAC(a0, ua, t0) PD_FMAC(a1, ua, t1) PD_FMAC(a2, ua, t2) PD_FMAC(b0, ub, t0) PD_FMAC(b1, ub, t1) PD_FMAC(b2, ub, t2) PD_FMAC(c0, uc, t0) PD_FMAC(c1, uc, t1) PD_FMAC(c2, uc, t2)
+                     : [a0] "+v"(rA[0]), [a1] "+v"(rA[1]), [a2] "+v"(rA[2]), [b0] "+v"(rB[0]), [b1] "+v"(rB[1]), [b2] "+v"(rB[2]), [c0] "+v"(rC[0]), [c1] "+v"(rC[1]), [c2] "+v"(rC[2])
+                     : [t0] "v"(T[0]), [t1] "v"(T[1]), [t2] "v"(T[2]), [ua] "v"(ua), [ub] "v"(ub), [uc] "v"(uc), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update3<3, N> {   // T = (cC_i bcast(cC_k)) T + hA_i bcast(wA_k) + hB_i bcast(wB_k) + mC_i bcast(wC_k)
+    static __device__ __forceinline__ void run(double (&T)[3], const double (&hA)[3], const double (&hB)[3], const double (&mC)[3], const double (&ph)[3],
+                                               double wa, double wb, double wc, double phs)
+    {
+        double pk, pp[3];
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t0, wb, k0) PD_FMAC(t1, wb, k1) PD_FMAC(t2, wb, k2) PD_FMAC(t0, wc, m0) PD_FMAC(t1, wc, m1) PD_FMAC(t2, wc, m2)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [k0] "v"(hB[0]), [k1] "v"(hB[1]), [k2] "v"(hB[2]), [m0] "v"(mC[0]), [m1] "v"(mC[1]), [m2] "v"(mC[2]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [wa] "v"(wa), [wb] "v"(wb), [wc] "v"(wc), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update3First<3, N> {   // first column of a (cos, sin) pair: also hands cC_i cC_k to the second
+    static __device__ __forceinline__ void run(double (&T)[3], const double (&hA)[3], const double (&hB)[3], const double (&mC)[3], const double (&ph)[3],
+                                               double wa, double wb, double wc, double phs, double (&pp)[3])
+    {
+        double pk;
+        asm volatile("v_mov_b64_dpp %[pk], %[phs]" PIORAN_DPP_CTRL(%c[n]) "\n\t"
+                     PD_MUL(p0, h0, pk) PD_MUL(p1, h1, pk) PD_MUL(p2, h2, pk) PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t0, wb, k0) PD_FMAC(t1, wb, k1) PD_FMAC(t2, wb, k2) PD_FMAC(t0, wc, m0) PD_FMAC(t1, wc, m1) PD_FMAC(t2, wc, m2)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [pk] "=&v"(pk), [p0] "=&v"(pp[0]), [p1] "=&v"(pp[1]), [p2] "=&v"(pp[2])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [k0] "v"(hB[0]), [k1] "v"(hB[1]), [k2] "v"(hB[2]), [m0] "v"(mC[0]), [m1] "v"(mC[1]), [m2] "v"(mC[2]), [h0] "v"(ph[0]), [h1] "v"(ph[1]), [h2] "v"(ph[2]), [wa] "v"(wa), [wb] "v"(wb), [wc] "v"(wc), [phs] "v"(phs), [n] "i"(N));
+    }
+};
+template <int N>
+struct Update3Second<3, N> {
+    static __device__ __forceinline__ void run(double (&T)[3], const double (&hA)[3], const double (&hB)[3], const double (&mC)[3], double wa, double wb, double wc,
+                                               const double (&pp)[3])
+    {
+        asm volatile(PD_MUL(t0, p0, t0) PD_MUL(t1, p1, t1) PD_MUL(t2, p2, t2) PD_FMAC(t0, wa, g0) PD_FMAC(t1, wa, g1) PD_FMAC(t2, wa, g2) PD_FMAC(t0, wb, k0) PD_FMAC(t1, wb, k1) PD_FMAC(t2, wb, k2) PD_FMAC(t0, wc, m0) PD_FMAC(t1, wc, m1) PD_FMAC(t2, wc, m2)
+                     : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2])
+                     : [g0] "v"(hA[0]), [g1] "v"(hA[1]), [g2] "v"(hA[2]), [k0] "v"(hB[0]), [k1] "v"(hB[1]), [k2] "v"(hB[2]), [m0] "v"(mC[0]), [m1] "v"(mC[1]), [m2] "v"(mC[2]), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]), [wa] "v"(wa), [wb] "v"(wb), [wc] "v"(wc), [n] "i"(N));
+    }
+};
 // ---- END GENERATED ----
 #undef PD_FMAC
 #undef PD_MUL
@@ -634,10 +768,15 @@ struct StepIn {           // what one time step reads: per own row (v, x, phi) +
 // row (64 in the 64-row shape: the reference benchmark's j = 32, benchmark/benchmarks.jl:16-18, which used to pay the 80-row
 // shape).  The y row of T, f = T[y][.], rides as RPL more entries per lane (the lane's own rows), its products f'u~A, f'u~B cost
 // two more row sums per pair (independent of the pass over T) and z_n = y_n - mu - f'u~ falls out in every lane.
-template <int RPL, int CBR, int NSRC, bool SHARED_TAB, int MINW = 1, bool PAIRED = false, bool MIXED = false, int NPB = 0, bool WIN2 = false, int GS = 0, bool YC = false>
+// WIN3 (round 3, experiment): the THREE-step form — the same re-association with a window of three steps: per entry of T three
+// mat-vec FMAs, ONE Hadamard scaling and three rank-1 FMAs per three steps (2.5 instead of 2.75 instructions per entry and step),
+// paid for with three more row sums per window (g_AB, g_AC, g_BC) and the h vectors that carry m_A, m_B forward.
+template <int RPL, int CBR, int NSRC, bool SHARED_TAB, int MINW = 1, bool PAIRED = false, bool MIXED = false, int NPB = 0, bool WIN2 = false, int GS = 0, bool YC = false,
+          bool WIN3 = false>
 __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanParams p)
 {
     static_assert(!YC || (WIN2 && !MIXED && NPB == 0), "y as a separate vector: two-step form, no per-draw rows, no block layout");
+    static_assert(!WIN3 || (!WIN2 && !YC && !MIXED && NPB == 0 && SHARED_TAB && RPL <= 3), "three-step form: shared table, plain or paired layout");
     static_assert(NPB == 0 || (!PAIRED && 2 * NPB < NSRC * RPL && RPL % 2 == 0),
                   "block layout: unpaired base; both columns of a pair must sit in one source lane");
     static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
@@ -740,7 +879,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     // Per-lane byte offsets of v, x, phi.  MIXED launches (some rows are per-draw) need all three per lane; otherwise
     // x and phi are the v offset plus a wave-uniform constant, which can either live in two more VGPRs per row (no
     // scalar adds per load: faster where registers allow, RPL <= 3) or be added to the scalar step offset.
-    constexpr bool LANE_OFFS = MIXED || RPL <= 3;
+    constexpr bool LANE_OFFS = MIXED || (RPL <= 3 && !WIN3);   // (the three-step form needs every register: offsets through the scalar side)
     [[maybe_unused]] int vo_v[RPL], vo_x[LANE_OFFS ? RPL : 1], vo_p[LANE_OFFS ? RPL : 1];
     [[maybe_unused]] const int step_bytes = (int)p.rec_stride * 8;
     // y_n, sigma2_n of the step: the shared series sit in the step record (columns 3 Rp, 3 Rp + 1); per-draw series are
@@ -784,7 +923,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     [[maybe_unused]] const int ylast1 = own_series ? (int)N - 1 : (int)N;
     auto load_step = [&](int64_t n, StepIn<RPL>& in) {
         if constexpr (SHARED_TAB) {
-            if constexpr (WIN2) n = n < N ? n : N;   // the table holds N + 1 records
+            if constexpr (WIN2 || WIN3) n = n < N ? n : N;   // the table holds N + 1 records
             const int soff = (int)n * step_bytes;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
@@ -831,6 +970,176 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             in.s2 = sv[nn];
         }
     };
+
+
+    // ---- three-step form ------------------------------------------------------------------------------------------------
+    // Steps A = m + 1, B = m + 2, C = m + 3 on the state T = S_m + D_m w_m w_m' (cA = phA, cB = phA phB, cC = phA phB phC):
+    //   u~s = cs o us;  rs = T u~s  (one pass over T, three FMAs per entry);  sigma_s = u~s'rs
+    //   D_A = dA - sigma_A;                                   mA = vA - cA o rA
+    //   hAB = phB o mA, g_AB = hAB'uB;  hAC = phC o hAB, g_AC = hAC'uC
+    //   D_B = dB - sigma_B - g_AB^2 / D_A;                    mB = vB - cB o rB - hAB g_AB / D_A
+    //   hBC = phC o mB, g_BC = hBC'uC
+    //   D_C = dC - sigma_C - g_AC^2 / D_A - g_BC^2 / D_B;     mC = vC - cC o rC - hAC g_AC / D_A - hBC g_BC / D_B
+    //   T <- (cC cC') o T + hAC hAC' / D_A + hBC hBC' / D_B + mC mC' / D_C
+    // The series starts with NV = (3 - N mod 3) mod 3 void steps (D = 1, m = 0).
+    if constexpr (WIN3) {
+        double T[NC][RPL];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) T[c][i] = 0.0;
+        __shared__ double sh_coef3[2 * RPL * 256];   // the row coefficients (al, be) wait in LDS (lane-private slots): 4 RPL registers
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) { sh_coef3[(2 * i) * 256 + threadIdx.x] = al[i]; sh_coef3[(2 * i + 1) * 256 + threadIdx.x] = be[i]; }
+        double one = 1.0;
+        asm volatile("" : "+v"(one));
+        const double ysel = isy ? 1.0 : 0.0;
+        double Pm = 1.0, quad = 0.0;
+        int Pe = 0;
+        bool nonpd = false;
+        StepIn<RPL> sa, sb, sc;
+        auto triple = [&](int64_t nA, auto nvc, auto firstc) __attribute__((always_inline)) {
+            constexpr int NV = decltype(nvc)::value;
+            constexpr bool FIRST = decltype(firstc)::value;
+            double uB[RPL], uC[RPL], tA[RPL], tB[RPL], tC[RPL], cB[RPL], cC[RPL], rA[RPL], rB[RPL], rC[RPL];
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const double ali = sh_coef3[(2 * i) * 256 + threadIdx.x], bei = sh_coef3[(2 * i + 1) * 256 + threadIdx.x];
+                const double uA = ali * sa.v[i] + bei * sa.x[i];
+                uB[i] = ali * sb.v[i] + bei * sb.x[i];
+                uC[i] = ali * sc.v[i] + bei * sc.x[i];
+                cB[i] = sa.ph[i] * sb.ph[i];
+                cC[i] = cB[i] * sc.ph[i];
+                tA[i] = sa.ph[i] * uA;
+                tB[i] = cB[i] * uB[i];
+                tC[i] = cC[i] * uC[i];
+                rA[i] = 0.0; rB[i] = 0.0; rC[i] = 0.0;
+            }
+            sa.v[YS] = fma(ysel, sa.y - mu, sa.v[YS]);
+            sb.v[YS] = fma(ysel, sb.y - mu, sb.v[YS]);
+            sc.v[YS] = fma(ysel, sc.y - mu, sc.v[YS]);
+            const double dA = fma(nu, sa.s2, suma), dB = fma(nu, sb.s2, suma), dC = fma(nu, sc.s2, suma);
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(tA[i]), "+v"(tB[i]), "+v"(tC[i]));
+            asm volatile("s_nop 1");
+            constexpr int NCM = (PAIRED && (NC & 1)) ? NC - 1 : NC;   // the inert single slot of an odd paired block (see the two-step form)
+            static_for<0, NCM>([&](auto Cc) {
+                constexpr int c = decltype(Cc)::value;
+                MatVec3<RPL, c / RPL>::run(T[c], rA, rB, rC, tA[c % RPL], tB[c % RPL], tC[c % RPL]);
+            });
+            if constexpr (CBR >= 2) {
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) { rA[i] += lane_fetch(rA[i], p1); rB[i] += lane_fetch(rB[i], p1); rC[i] += lane_fetch(rC[i], p1); }
+            }
+            if constexpr (CBR >= 4) {
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) { rA[i] += lane_fetch(rA[i], p2); rB[i] += lane_fetch(rB[i], p2); rC[i] += lane_fetch(rC[i], p2); }
+            }
+            double spA = 0.0, spB = 0.0, spC = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) { spA += tA[i] * rA[i]; spB += tB[i] * rB[i]; spC += tC[i] * rC[i]; }
+            const double sA = group_sum<CBR, NSRC, GS>(spA, contributes, one, p1, p2);
+            const double sB = group_sum<CBR, NSRC, GS>(spB, contributes, one, p1, p2);
+            const double sC = group_sum<CBR, NSRC, GS>(spC, contributes, one, p1, p2);
+            const double DA = NV >= 1 ? 1.0 : dA - sA;                                    // :92
+            const double rDA = recip_f64(DA);
+            double hAC[RPL], hBC[RPL], mC[RPL], wA[RPL], wB[RPL], wC[RPL], hAB[RPL];
+            double spAB = 0.0, spAC = 0.0, zA = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const double mA = NV >= 1 ? 0.0 : fma(-sa.ph[i], rA[i], sa.v[i]);         // v - q      :89
+                if (i == YS) zA = mA;
+                hAB[i] = sb.ph[i] * mA;
+                spAB = fma(hAB[i], uB[i], spAB);
+                hAC[i] = sc.ph[i] * hAB[i];
+                spAC = fma(hAC[i], uC[i], spAC);
+            }
+            load_step(nA + 3, sa);
+            const double gAB = group_sum<CBR, NSRC, GS>(spAB, contributes, one, p1, p2);
+            const double gAC = group_sum<CBR, NSRC, GS>(spAC, contributes, one, p1, p2);
+            const double yAB = gAB * rDA, yAC = gAC * rDA;
+            const double DB = NV >= 2 ? 1.0 : dB - sB - gAB * yAB;
+            const double rDB = recip_f64(DB);
+            double spBC = 0.0, zB = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const double mB = NV >= 2 ? 0.0 : fma(-hAB[i], yAB, fma(-cB[i], rB[i], sb.v[i]));
+                if (i == YS) zB = mB;
+                hBC[i] = sc.ph[i] * mB;
+                spBC = fma(hBC[i], uC[i], spBC);
+            }
+            load_step(nA + 4, sb);
+            const double gBC = group_sum<CBR, NSRC, GS>(spBC, contributes, one, p1, p2);
+            const double yBC = gBC * rDB;
+            const double DC = dC - sC - gAC * yAC - gBC * yBC;
+            const double rDC = recip_f64(DC);
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                mC[i] = fma(-hBC[i], yBC, fma(-hAC[i], yAC, fma(-cC[i], rC[i], sc.v[i])));
+                wA[i] = hAC[i] * rDA;
+                wB[i] = hBC[i] * rDB;
+                wC[i] = mC[i] * rDC;
+            }
+            load_step(nA + 5, sc);
+            const double zC = mC[YS];
+            nonpd |= !(DA > 0.0) | !(DB > 0.0) | !(DC > 0.0);
+            // log(D[1]) :126 keeps the sign of the series' FIRST step, log(abs(D[n])) :140 for the others
+            Pm *= ((FIRST && NV == 0) ? DA : fabs(DA)) * ((FIRST && NV == 1) ? DB : fabs(DB)) * ((FIRST && NV == 2) ? DC : fabs(DC));
+            {
+                int ex;
+                Pm = frexp(Pm, &ex);
+                Pe += ex;
+            }
+            quad = fma(zC * zC, rDC, fma(zB * zB, rDB, fma(zA * zA, rDA, quad)));        // z_n^2 / D_n  (== y'K^-1 y, :333)
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(wA[i]), "+v"(wB[i]), "+v"(wC[i]), "+v"(cC[i]));
+            asm volatile("s_nop 1");
+            if constexpr (PAIRED) {
+                static_for<0, NC / 2>([&](auto Pc) {
+                    constexpr int c = 2 * decltype(Pc)::value;
+                    double pp[RPL];
+                    Update3First<RPL, c / RPL>::run(T[c], hAC, hBC, mC, cC, wA[c % RPL], wB[c % RPL], wC[c % RPL], cC[c % RPL], pp);
+                    Update3Second<RPL, (c + 1) / RPL>::run(T[c + 1], hAC, hBC, mC, wA[(c + 1) % RPL], wB[(c + 1) % RPL], wC[(c + 1) % RPL], pp);
+                });
+                if constexpr (NC & 1)
+                    Update3<RPL, (NC - 1) / RPL>::run(T[NC - 1], hAC, hBC, mC, cC, wA[(NC - 1) % RPL], wB[(NC - 1) % RPL], wC[(NC - 1) % RPL], cC[(NC - 1) % RPL]);
+            } else {
+                static_for<0, NC>([&](auto Cc) {
+                    constexpr int c = decltype(Cc)::value;
+                    Update3<RPL, c / RPL>::run(T[c], hAC, hBC, mC, cC, wA[c % RPL], wB[c % RPL], wC[c % RPL], cC[c % RPL]);
+                });
+            }
+        };
+        auto void_step = [&](StepIn<RPL>& s_) {
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) { s_.v[i] = 0.0; s_.x[i] = 0.0; s_.ph[i] = 1.0; }
+            s_.y = mu;
+            s_.s2 = 0.0;
+        };
+        int64_t n;
+        const int nv = (int)((3 - N % 3) % 3);
+        if (nv == 0) {
+            load_step(0, sa); load_step(1, sb); load_step(2, sc);
+            triple(0, ic<0>{}, std::true_type{});
+            n = 3;
+        } else if (nv == 1) {
+            void_step(sa); load_step(0, sb); load_step(1, sc);
+            triple(-1, ic<1>{}, std::true_type{});
+            n = 2;
+        } else {
+            void_step(sa); void_step(sb); load_step(0, sc);
+            triple(-2, ic<2>{}, std::true_type{});
+            n = 1;
+        }
+        for (; n + 2 < N; n += 3) triple(n, ic<0>{}, std::false_type{});
+        if (active && isy && r == 0) {
+            const double logdet = log(Pm) + (double)Pe * 0.6931471805599453094;
+            const double res = -0.5 * logdet - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * quad;
+            p.out[b] = res;
+            if (p.status) p.status[b] = !isfinite(res) ? 2 : (nonpd ? 1 : 0);
+        }
+        return;
+    }
 
 
     // ---- two-step form --------------------------------------------------------------------------------------------------
@@ -1157,6 +1466,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 }
 
 using LaunchFn = void (*)(const ScanParams&, dim3, hipStream_t);
+thread_local bool g_last_win3 = false;   // the calling thread's last launch used the three-step form (diagnostics)
 
 // which form of the row sums (group_sum's GS): the context option "gsum" (0, 1, 2) when set, else automatic
 int gsum_mode(const ScanParams& p, int cbr)
@@ -1171,6 +1481,17 @@ int gsum_mode(const ScanParams& p, int cbr)
 template <int RPL, int CBR, int NSRC, int MINW = 1, bool PAIRED = false, bool GSV = false>
 void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
 {
+    if constexpr (RPL == 2 || RPL == 3) {
+        // three-step form: measured faster where its row vectors fit the register file — two rows per lane from 13 source lanes on
+        // (R = 24 .. 31: 2 .. 6 % at B = 4096, tools/sweep_win3.py); with three rows per lane it spills (SHO-20: 18 % slower) and with
+        // one the extra row sums outweigh the saved scalings (10 .. 30 % slower): those run it only when the option asks
+        const bool auto3 = RPL == 2 && CBR == 1 && NSRC >= 13 && !(p.opt && (p.opt->no_win3 || p.opt->no_win2 || p.opt->win2)) && p.B > 2048;
+        if (((p.opt && p.opt->win3) || auto3) && p.tab && p.npd_rows == 0) {
+            hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, 2, PAIRED, false, 0, false, 0, false, true>), grid, dim3(256), 0, st, p);
+            g_last_win3 = true;
+            return;
+        }
+    }
     if constexpr (GSV) {
         const int gs = gsum_mode(p, CBR);
         if (gs && p.tab && p.npd_rows == 0 && !(p.opt && p.opt->no_win2)) {
@@ -1331,7 +1652,11 @@ static thread_local const char* g_last_config = "none";
 
 const char* pioran_scan_config_name(int R)
 {
-    if (R <= 0) return g_last_config;                      // the configuration the last launch of this thread ran on
+    if (R <= 0) {                                          // the configuration the last launch of this thread ran on
+        static thread_local char buf[64];
+        std::snprintf(buf, sizeof(buf), "%s%s", g_last_config, g_last_win3 ? "+win3" : "");
+        return buf;
+    }
     const ScanConfig* c = pick_config(R, (R & 1) == 0);   // diagnostics: assumes the standard row map for even R
     return c ? c->name : "fallback";
 }
@@ -1353,6 +1678,7 @@ int pioran_launch_scan(const ScanParams& p, hipStream_t stream)
     const int64_t blocks = (p.B + per_block - 1) / per_block;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return PIORAN_ERR_ARG;
     g_last_config = c->name;
+    g_last_win3 = false;
     c->fn(p, dim3((unsigned)blocks), stream);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }

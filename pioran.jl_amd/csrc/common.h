@@ -19,6 +19,8 @@
 struct ScanOptions {
     char scan_config[48];   // "" automatic; "wide" / "block": that small-batch kernel for any batch size; else a throughput configuration's name
     bool no_wide, no_paired, no_mixed, force_fallback, no_block;
+    bool win3, no_win3;   // throughput layouts with two / three rows per lane: force / forbid the three-step form (celerite_scan.hip;
+                          // default: on for two rows per lane from 13 source lanes on, large batches)
     bool win2, no_win2;   // throughput layouts: force / forbid the two-step form of the recurrence (celerite_scan.hip)
     int dense_streams = 0;   // pioran_dense_nll_batch: concurrent factorisations (0 = default 16 = the most)
     int gsum = -1;        // throughput layouts, two-step form: row sums with fewer exchange rounds (group_sum's GS); -1 = automatic

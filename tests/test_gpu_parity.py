@@ -103,7 +103,7 @@ def _random_case(rng, N, J, B, per_draw_cd=False):
     return t, y, s2, A, Bc, C, Dd, mu, nu
 
 
-@pytest.fixture(params=["throughput", "throughput_steps", "throughput_pairs", "latency", "latency_lean", "block"])
+@pytest.fixture(params=["throughput", "throughput_steps", "throughput_pairs", "throughput_triples", "latency", "latency_lean", "block"])
 def layout(request, ctx):
     """Small batches (B <= 512) with 6 <= R <= 63 rows take the windowed kernel (celerite_block.hip) by default; "no_block" sends
     them to the one-draw-per-workgroup latency layout (celerite_wide.hip), "no_wide" as well to the throughput layouts (the ones
@@ -120,8 +120,10 @@ def layout(request, ctx):
         ctx.set_option("no_win2", True)
     if request.param == "throughput_pairs":
         ctx.set_option("win2", True)
+    if request.param == "throughput_triples":   # the three-step form wherever it exists (two / three rows per lane, shared table)
+        ctx.set_option("win3", True)
     yield request.param
-    for k in ("no_wide", "no_block", "no_win2", "win2", "wide2"):
+    for k in ("no_wide", "no_block", "no_win2", "win2", "win3", "wide2"):
         ctx.set_option(k, False)
     ctx.set_option("scan_config", None)
 
@@ -234,6 +236,18 @@ def test_lean_latency_layout_mixed_rows_and_nonpd(ctx):
     assert (np.isnan(got3) == np.isnan(ref3)).all()
     fin = np.isfinite(ref3)
     assert relerr(got3[fin], ref3[fin]) < 1e-9 and ((st3 != 0) == (rst3 != 0)).all()
+
+
+def test_three_step_form_is_the_default_for_24_to_31_rows_in_large_batches(ctx):
+    """R = 30 rows (SHO-15 / DRWCelerite-10), more than 2048 draws: the throughput scan takes its three-step form on its own
+    (two rows per lane, 16 source lanes: tools/sweep_win3.py); series lengths of every remainder mod 3."""
+    rng = np.random.default_rng(33)
+    for N in (60, 61, 62):
+        B, J = 2100, 15
+        t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+        got, st = pj.Dataset(t, y, s2, ctx).logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        assert pj._lib.lib().pioran_celerite_config_name(0).decode() == "rpl2_cbr1_nsrc16_p+win3"
+        assert relerr(got, O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)) < 1e-11 and (st == 0).all()
 
 
 @pytest.mark.parametrize("J,cfg", [(8, "rpl1_cbr1_nsrc16_yp"), (16, "rpl2_cbr1_nsrc16_yp"), (24, "rpl3_cbr2_nsrc8_yp")])
