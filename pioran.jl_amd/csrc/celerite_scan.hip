@@ -1101,8 +1101,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                     Update3First<RPL, c / RPL>::run(T[c], hAC, hBC, mC, cC, wA[c % RPL], wB[c % RPL], wC[c % RPL], cC[c % RPL], pp);
                     Update3Second<RPL, (c + 1) / RPL>::run(T[c + 1], hAC, hBC, mC, wA[(c + 1) % RPL], wB[(c + 1) % RPL], wC[(c + 1) % RPL], pp);
                 });
-                if constexpr (NC & 1)
-                    Update3<RPL, (NC - 1) / RPL>::run(T[NC - 1], hAC, hBC, mC, cC, wA[(NC - 1) % RPL], wB[(NC - 1) % RPL], wC[(NC - 1) % RPL], cC[(NC - 1) % RPL]);
+                // (an odd block's closing column is never read — see the two-step form — and is not kept)
             } else {
                 static_for<0, NC>([&](auto Cc) {
                     constexpr int c = decltype(Cc)::value;
@@ -1293,7 +1292,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                     Update2First<RPL, c / RPL>::run(T[c], hA, mB, pAB, wA[c % RPL], wB[c % RPL], pAB[c % RPL], pp);
                     Update2Second<RPL, (c + 1) / RPL>::run(T[c + 1], hA, mB, wA[(c + 1) % RPL], wB[(c + 1) % RPL], pp);
                 });
-                static_for<2 * NPB, NC>([&](auto Cc) {
+                static_for<2 * NPB, NC - 1>([&](auto Cc) {   // (the spare slot's column is never read: not updated, not kept)
                     constexpr int c = decltype(Cc)::value;
                     Update2<RPL, c / RPL>::run(T[c], hA, mB, pAB, wA[c % RPL], wB[c % RPL], pAB[c % RPL]);
                 });
@@ -1304,8 +1303,8 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                     Update2First<RPL, c / RPL>::run(T[c], hA, mB, pAB, wA[c % RPL], wB[c % RPL], pAB[c % RPL], pp);
                     Update2Second<RPL, (c + 1) / RPL>::run(T[c + 1], hA, mB, wA[(c + 1) % RPL], wB[(c + 1) % RPL], pp);
                 });
-                if constexpr (NC & 1)
-                    Update2<RPL, (NC - 1) / RPL>::run(T[NC - 1], hA, mB, pAB, wA[(NC - 1) % RPL], wB[(NC - 1) % RPL], pAB[(NC - 1) % RPL]);
+                // the closing column of an odd block multiplies u = 0 in every DPP row (NCM above): nothing ever reads it, so it is
+                // neither updated nor kept in registers (round 3)
             } else {
                 static_for<0, NC>([&](auto Cc) {
                     constexpr int c = decltype(Cc)::value;
@@ -1397,7 +1396,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 PairFirst<RPL, c / RPL>::run(S[c], qt, g, in.ph, w[c % RPL], u[c % RPL], in.ph[c % RPL], pp);
                 PairSecond<RPL, (c + 1) / RPL>::run(S[c + 1], qt, g, w[(c + 1) % RPL], u[(c + 1) % RPL], pp);
             });
-            static_for<2 * NPB, NC>([&](auto Cc) {
+            static_for<2 * NPB, NC - 1>([&](auto Cc) {   // (the spare slot's column multiplies u = 0: never read, not kept)
                 constexpr int c = decltype(Cc)::value;
                 ColBlock<RPL, c / RPL>::run(S[c], qt, g, in.ph, w[c % RPL], u[c % RPL], in.ph[c % RPL]);
             });
@@ -1409,9 +1408,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 PairFirst<RPL, c / RPL>::run(S[c], qt, g, in.ph, w[c % RPL], u[c % RPL], in.ph[c % RPL], pp);
                 PairSecond<RPL, (c + 1) / RPL>::run(S[c + 1], qt, g, w[(c + 1) % RPL], u[(c + 1) % RPL], pp);
             });
-            if constexpr (NC & 1)   // the single slot at the end of an odd block: padding or the y row
-                ColBlock<RPL, (NC - 1) / RPL>::run(S[NC - 1], qt, g, in.ph, w[(NC - 1) % RPL], u[(NC - 1) % RPL],
-                                                   in.ph[(NC - 1) % RPL]);
+            // (the single slot at the end of an odd block — padding or the y row — multiplies u = 0: its column is never read)
         } else {
             static_for<0, NC>([&](auto Cc) {
                 constexpr int c = decltype(Cc)::value;
