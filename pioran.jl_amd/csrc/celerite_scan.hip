@@ -785,6 +785,13 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     constexpr int NC = NSRC * RPL;       // columns held per lane
     constexpr int YLAM = NSRC * CBR - 1; // the y row is the LAST row slot: logical lane YLAM, slot RPL-1
     constexpr int YS = RPL - 1;
+    // Columns nobody reads (round 3).  A column whose slot has u = 0 in EVERY DPP row of the wavefront contributes nothing to S u,
+    // and an entry of S is read by nothing else, so such a column is neither updated nor kept in registers: the spare slot that
+    // closes every block of the block layout and of a paired layout with an odd block (padding, or the y row in the last block);
+    // with one DPP row per draw the y row's own slot — the last one — and, paired with an even block, the padding slot beside it
+    // (capacity() leaves it free).  With several DPP rows per draw the last slot of the other blocks is a real row.
+    constexpr int NDEAD = NPB > 0 ? 1 : (PAIRED && ((NSRC * RPL) & 1)) ? 1 : (YC || CBR > 1) ? 0 : (PAIRED ? 2 : 1);
+    constexpr int NCL = NC - NDEAD;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // known to be wave-uniform: with one draw per wavefront
@@ -1022,7 +1029,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 #pragma unroll
             for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(tA[i]), "+v"(tB[i]), "+v"(tC[i]));
             asm volatile("s_nop 1");
-            constexpr int NCM = (PAIRED && (NC & 1)) ? NC - 1 : NC;   // the inert single slot of an odd paired block (see the two-step form)
+            constexpr int NCM = NCL;   // (the columns that are ever read: see NDEAD)
             static_for<0, NCM>([&](auto Cc) {
                 constexpr int c = decltype(Cc)::value;
                 MatVec3<RPL, c / RPL>::run(T[c], rA, rB, rC, tA[c % RPL], tB[c % RPL], tC[c % RPL]);
@@ -1095,7 +1102,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             for (int i = 0; i < RPL; ++i) asm volatile("" : "+v"(wA[i]), "+v"(wB[i]), "+v"(wC[i]), "+v"(cC[i]));
             asm volatile("s_nop 1");
             if constexpr (PAIRED) {
-                static_for<0, NC / 2>([&](auto Pc) {
+                static_for<0, NCL / 2>([&](auto Pc) {
                     constexpr int c = 2 * decltype(Pc)::value;
                     double pp[RPL];
                     Update3First<RPL, c / RPL>::run(T[c], hAC, hBC, mC, cC, wA[c % RPL], wB[c % RPL], wC[c % RPL], cC[c % RPL], pp);
@@ -1103,7 +1110,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 });
                 // (an odd block's closing column is never read — see the two-step form — and is not kept)
             } else {
-                static_for<0, NC>([&](auto Cc) {
+                static_for<0, NCL>([&](auto Cc) {
                     constexpr int c = decltype(Cc)::value;
                     Update3<RPL, c / RPL>::run(T[c], hAC, hBC, mC, cC, wA[c % RPL], wB[c % RPL], wC[c % RPL], cC[c % RPL]);
                 });
@@ -1216,7 +1223,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             asm volatile("s_nop 1");
             // the single slot that closes every block of a paired or block layout is padding or the y row in EVERY DPP row:
             // u = 0 there, so the column contributes nothing to T u~ (its own row of T is still needed: it is updated below)
-            constexpr int NCM = ((PAIRED && (NC & 1)) || NPB > 0) ? NC - 1 : NC;
+            constexpr int NCM = NCL;
             static_for<0, NCM>([&](auto Cc) {
                 constexpr int c = decltype(Cc)::value;
                 MatVec2<RPL, c / RPL>::run(T[c], rA, rB, tA[c % RPL], tB[c % RPL]);
@@ -1292,12 +1299,12 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                     Update2First<RPL, c / RPL>::run(T[c], hA, mB, pAB, wA[c % RPL], wB[c % RPL], pAB[c % RPL], pp);
                     Update2Second<RPL, (c + 1) / RPL>::run(T[c + 1], hA, mB, wA[(c + 1) % RPL], wB[(c + 1) % RPL], pp);
                 });
-                static_for<2 * NPB, NC - 1>([&](auto Cc) {   // (the spare slot's column is never read: not updated, not kept)
+                static_for<2 * NPB, NCL>([&](auto Cc) {   // (the spare slot's column is never read: not updated, not kept)
                     constexpr int c = decltype(Cc)::value;
                     Update2<RPL, c / RPL>::run(T[c], hA, mB, pAB, wA[c % RPL], wB[c % RPL], pAB[c % RPL]);
                 });
             } else if constexpr (PAIRED) {
-                static_for<0, NC / 2>([&](auto Pc) {
+                static_for<0, NCL / 2>([&](auto Pc) {
                     constexpr int c = 2 * decltype(Pc)::value;
                     double pp[RPL];
                     Update2First<RPL, c / RPL>::run(T[c], hA, mB, pAB, wA[c % RPL], wB[c % RPL], pAB[c % RPL], pp);
@@ -1306,7 +1313,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 // the closing column of an odd block multiplies u = 0 in every DPP row (NCM above): nothing ever reads it, so it is
                 // neither updated nor kept in registers (round 3)
             } else {
-                static_for<0, NC>([&](auto Cc) {
+                static_for<0, NCL>([&](auto Cc) {
                     constexpr int c = decltype(Cc)::value;
                     Update2<RPL, c / RPL>::run(T[c], hA, mB, pAB, wA[c % RPL], wB[c % RPL], pAB[c % RPL]);
                 });
@@ -1396,13 +1403,13 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 PairFirst<RPL, c / RPL>::run(S[c], qt, g, in.ph, w[c % RPL], u[c % RPL], in.ph[c % RPL], pp);
                 PairSecond<RPL, (c + 1) / RPL>::run(S[c + 1], qt, g, w[(c + 1) % RPL], u[(c + 1) % RPL], pp);
             });
-            static_for<2 * NPB, NC - 1>([&](auto Cc) {   // (the spare slot's column multiplies u = 0: never read, not kept)
+            static_for<2 * NPB, NCL>([&](auto Cc) {   // (the spare slot's column multiplies u = 0: never read, not kept)
                 constexpr int c = decltype(Cc)::value;
                 ColBlock<RPL, c / RPL>::run(S[c], qt, g, in.ph, w[c % RPL], u[c % RPL], in.ph[c % RPL]);
             });
         } else if constexpr (PAIRED) {
             // column pairs (c, c+1), c even: same phi_k, so phi_i * phi_k is formed once per pair
-            static_for<0, NC / 2>([&](auto Pc) {
+            static_for<0, NCL / 2>([&](auto Pc) {
                 constexpr int c = 2 * decltype(Pc)::value;
                 double pp[RPL];
                 PairFirst<RPL, c / RPL>::run(S[c], qt, g, in.ph, w[c % RPL], u[c % RPL], in.ph[c % RPL], pp);
@@ -1410,7 +1417,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             });
             // (the single slot at the end of an odd block — padding or the y row — multiplies u = 0: its column is never read)
         } else {
-            static_for<0, NC>([&](auto Cc) {
+            static_for<0, NCL>([&](auto Cc) {
                 constexpr int c = decltype(Cc)::value;
                 ColBlock<RPL, c / RPL>::run(S[c], qt, g, in.ph, w[c % RPL], u[c % RPL], in.ph[c % RPL]);
             });
