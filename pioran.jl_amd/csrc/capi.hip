@@ -198,19 +198,22 @@ int download(pioran_ctx* ctx, void* host, const void* dev, size_t bytes)
 // Encoding: term (bits 0-19) | per-draw row index (20-28) | per-draw flag (29) | sin row (30).
 std::vector<int32_t> build_rowmap(int64_t J, const int32_t* kind)
 {
+    // shared rows first, the rows of the per-draw terms LAST (in term order, cos row then sin row): every kernel reads the row
+    // map, none assumes an order, and the windowed kernel relies on the per-draw rows being the last ones (celerite_block.hip)
     std::vector<int32_t> rm;
     rm.reserve(2 * J);
-    int32_t npd = 0;
     for (int64_t j = 0; j < J; ++j) {
         const int32_t k = kind ? kind[j] : 0;
-        if (k == 2) {
-            rm.push_back((int32_t)j | ((2 * npd) << 20) | (1 << 29));
-            rm.push_back((int32_t)j | ((2 * npd + 1) << 20) | (1 << 29) | (1 << 30));
-            ++npd;
-        } else {
-            rm.push_back((int32_t)j);
-            if (k != 1) rm.push_back((int32_t)j | (1 << 30));
-        }
+        if (k == 2) continue;
+        rm.push_back((int32_t)j);
+        if (k != 1) rm.push_back((int32_t)j | (1 << 30));
+    }
+    int32_t npd = 0;
+    for (int64_t j = 0; j < J; ++j) {
+        if (!kind || kind[j] != 2) continue;
+        rm.push_back((int32_t)j | ((2 * npd) << 20) | (1 << 29));
+        rm.push_back((int32_t)j | ((2 * npd + 1) << 20) | (1 << 29) | (1 << 30));
+        ++npd;
     }
     return rm;
 }
@@ -232,6 +235,8 @@ int set_rowmap(pioran_ds* ds, PrepState& s, const std::vector<int32_t>& rm)
     return PIORAN_OK;
 }
 
+thread_local const char* g_last_kernel = "none";   // which kernel family the calling thread's last launch ran on (diagnostics)
+
 // Register-resident scan: small shared-table batches take the latency layout (celerite_wide.hip, one draw per
 // workgroup), everything else the throughput layouts (celerite_scan.hip).  PIORAN_SCAN_CONFIG=wide forces the former
 // for any batch size, any other value names a throughput configuration; PIORAN_NO_WIDE=1 disables the former.
@@ -249,9 +254,37 @@ int scan_dispatch(const ScanParams& p, hipStream_t stream)
     //  39 k vs 27 k: tools/sweep_r80.py)
     const bool y80 = p.R == pioran_scan_supported_rows_shared() && p.tab && p.npd_rows == 0 && !o.no_win2 && p.B > 768;
     const bool only_wide = p.R > pioran_scan_supported_rows() && !o.no_wide && !y80;
-    if (p.tab && p.R <= pioran_wide_supported_rows() && (force_wide || auto_wide || only_wide)) return pioran_launch_scan_wide(p, stream);
+    if (p.tab && p.R <= pioran_wide_supported_rows() && (force_wide || auto_wide || only_wide)) {
+        g_last_kernel = "wide";
+        return pioran_launch_scan_wide(p, stream);
+    }
     if (p.R > pioran_scan_supported_rows() && !y80) return PIORAN_ERR_UNSUPPORTED;
+    g_last_kernel = "scan";
     return pioran_launch_scan(p, stream);
+}
+
+// the windowed kernel's own table of a prepared (c, d): built on first use (PIORAN_ERR_UNSUPPORTED: too long a series / no memory)
+int ensure_btab(pioran_ds* ds, PrepState& s)
+{
+    pioran_ctx* ctx = ds->ctx;
+    if (s.btab_ready) return PIORAN_OK;
+    // 60 KB per 16 time stamps at J = 20: very long series (or a device short of memory) stay on the other kernels
+    const size_t need = pioran_block_table_doubles(ds->N, s.R, s.J);
+    if (need * sizeof(double) > (size_t(2) << 30)) return PIORAN_ERR_UNSUPPORTED;
+    if (need > s.btab_cap) {
+        if (s.btab) HIPCHK(ctx, hipFree(s.btab));
+        s.btab = nullptr;
+        s.btab_cap = 0;
+        if (hipMalloc((void**)&s.btab, need * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            return PIORAN_ERR_UNSUPPORTED;
+        }
+        s.btab_cap = need;
+    }
+    int rc = pioran_launch_block_table(ds->N, s.R, s.J, s.rowmap, ds->t, s.dc, s.dd, ds->y, ds->s2, s.btab, ctx->stream);
+    if (rc) return rc;
+    s.btab_ready = true;
+    return PIORAN_OK;
 }
 
 // Small shared-table batches without per-draw rows: the windowed kernel (celerite_block.hip), which needs its own table.
@@ -269,24 +302,9 @@ int block_dispatch(pioran_ds* ds, const ScanParams& p)
     if (!(force || automatic) || !p.tab || p.npd_rows != 0 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
     PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
     if (!s || !s->prepared || s->npd_terms != 0 || p.rec_stride != 3 * (int64_t)(s->R + 2) + 2) return PIORAN_ERR_UNSUPPORTED;
-    if (!s->btab_ready) {
-        // 60 KB per 16 time stamps at J = 20: very long series (or a device short of memory) stay on the other kernels
-        const size_t need = pioran_block_table_doubles(ds->N, s->R, s->J);
-        if (need * sizeof(double) > (size_t(2) << 30)) return PIORAN_ERR_UNSUPPORTED;
-        if (need > s->btab_cap) {
-            if (s->btab) HIPCHK(ctx, hipFree(s->btab));
-            s->btab = nullptr;
-            s->btab_cap = 0;
-            if (hipMalloc((void**)&s->btab, need * sizeof(double)) != hipSuccess) {
-                (void)hipGetLastError();
-                return PIORAN_ERR_UNSUPPORTED;
-            }
-            s->btab_cap = need;
-        }
-        int rc = pioran_launch_block_table(ds->N, s->R, s->J, s->rowmap, ds->t, s->dc, s->dd, ds->y, ds->s2, s->btab, ctx->stream);
-        if (rc) return rc;
-        s->btab_ready = true;
-    }
+    int rc = ensure_btab(ds, *s);
+    if (rc) return rc;
+    g_last_kernel = "block";
     return pioran_launch_scan_block(p, s->btab, ctx->stream);
 }
 
@@ -312,6 +330,7 @@ int launch(pioran_ds* ds, ScanParams& p)
     int rc = ensure(ctx, ctx->bscratch, (size_t)chunk * pioran_fallback_scratch_doubles(p.R) * sizeof(double));
     if (rc) return rc;
     p.scratch = (double*)ctx->bscratch.p;
+    g_last_kernel = "fallback";
     rc = pioran_launch_scan_fallback(p, ctx->stream);
     if (rc == PIORAN_ERR_HIP) ctx->last_err = "fallback kernel launch failed";
     return rc;
@@ -709,15 +728,62 @@ static int mixed_core(pioran_ds* ds, int64_t B, int64_t J, const std::vector<int
     // all shared is handled by the caller; many per-draw terms: the generic per-draw path is as good.  must_run: the caller has
     // no generic path to fall back to (theta entry: the continuum's (c, d) exist only as a shared table), so the two
     // "not worth it" cuts — a performance heuristic, not a kernel constraint — are skipped
-    if (npd == 0 || npd > 8 || (!must_run && npd * 2 > J)) return 0;
+    // (the windowed kernel takes small batches with one or two per-draw terms whatever the share of per-draw terms: see below)
+    bool blk_ok = false;
+    {
+        const ScanOptions& o = ctx->opt;
+        const char* cfg = o.scan_config[0] ? o.scan_config : nullptr;
+        const bool force = cfg && !std::strcmp(cfg, "block");
+        const bool automatic = !cfg && !o.no_block && (B <= 512 || (B <= 768 && rows >= 42)) && rows >= 6;
+        blk_ok = (force || automatic) && !o.force_fallback && npd >= 1 && pioran_block_fits_pd((int32_t)rows, (int32_t)J, (int32_t)npd);
+    }
+    if (npd == 0 || npd > 8 || (!must_run && !blk_ok && npd * 2 > J)) return 0;
     if (rows > pioran_scan_supported_rows()) return 0;
     const int64_t rs_shared = 3 * (rows + 2) + 2;               // shared part of a step record (doubles)
     // combined table: (N+1) records of rs_shared + chunk * 2 npd * 3 doubles, addressed with 32-bit byte offsets
     int64_t chunk = ((int64_t)0x7fff0000 / ((ds->N + 1) * 8) - rs_shared) / (6 * npd);
     chunk = chunk > B ? B : (chunk >= 16 ? chunk & ~(int64_t)15 : chunk);
-    if (chunk < 1 || (!must_run && chunk < 16)) return 0;
+    if (chunk < 1 || (!must_run && !blk_ok && chunk < 16)) return 0;
     int rc;
     if ((rc = prepare_state(ds, s, J, C0, D0, kind.data()))) return rc;
+    // Small batches with one or two per-draw terms (a QPO feature on an approx continuum at a few hundred live points,
+    // src/psd.jl:254-261): the windowed kernel with per-draw rows (celerite_block.hip; round 3) — same automatic range as for shared
+    // batches (block_dispatch).  Needs the kernel's own table of the shared rows and the per-draw (cos, sin)(d t_n).
+    {
+        if (blk_ok && (rc = ensure_btab(ds, s)) != PIORAN_ERR_UNSUPPORTED) {
+            if (rc) return rc;
+            const int64_t cb = B < 4096 ? B : 4096;
+            const size_t trig_bytes = pioran_block_pd_trig_doubles(ds->N, cb, s.npd_terms) * sizeof(double);
+            if ((rc = ensure(ctx, ctx->bscratch, trig_bytes))) return rc;
+            if ((rc = ensure(ctx, ctx->bout, cb * sizeof(double)))) return rc;
+            if ((rc = ensure(ctx, ctx->bst, cb * sizeof(int32_t)))) return rc;
+            for (int64_t b0 = 0; b0 < B; b0 += cb) {
+                const int64_t nb = B - b0 < cb ? B - b0 : cb;
+                MixedChunk m{};
+                if ((rc = fetch(b0, nb, m))) return rc;
+                if ((rc = pioran_launch_block_pd_trig(ds->N, nb, (int32_t)J, s.npd_terms, s.dpd_terms, ds->t, m.D, (double*)ctx->bscratch.p, ctx->stream)))
+                    return rc;
+                ScanParams p{};
+                p.N = ds->N; p.J = s.J; p.R = s.R; p.B = nb;
+                p.standard_rows = s.row_layout; p.n_complex = s.n_complex;
+                p.rec_stride = 3 * (int64_t)(s.R + 2) + 2;
+                p.tab = s.tab; p.rowmap = s.rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+                p.Y = m.Y; p.S2 = m.S2; p.A = m.A; p.Bc = m.Bc; p.C = s.dc; p.D = s.dd;
+                p.mu = m.mu; p.nu = m.nu;
+                p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
+                p.npd_rows = 2 * s.npd_terms;
+                p.pd_C = m.C; p.pd_trig = (const double*)ctx->bscratch.p; p.pd_npad = (ds->N + 15) / 16 * 16;
+                p.opt = &ctx->opt;
+                g_last_kernel = "block+pd";
+                rc = pioran_launch_scan_block(p, s.btab, ctx->stream);
+                if (rc) { ctx->last_err = "windowed kernel (per-draw rows) launch failed"; return rc; }
+                if ((rc = download(ctx, out + b0, ctx->bout.p, nb * sizeof(double)))) return rc;
+                if (status) if ((rc = download(ctx, status + b0, ctx->bst.p, nb * sizeof(int32_t)))) return rc;
+                SYNC(ctx);
+            }
+            return 1;
+        }
+    }
     const int64_t rec_stride = rs_shared + chunk * 6 * npd;
     if ((rc = ensure(ctx, ctx->bscratch, (size_t)(ds->N + 1) * (size_t)rec_stride * sizeof(double)))) return rc;
     double* ctab = (double*)ctx->bscratch.p;
@@ -1269,6 +1335,7 @@ int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, c
 
 const char* pioran_celerite_config_name(int64_t R)
 {
+    if (R < 0) return g_last_kernel;                 // kernel family of the calling thread's last launch: block, block+pd, wide, scan, fallback
     if (R <= 0) return pioran_scan_config_name(0);   // what the calling thread's last throughput-layout launch ran on
     if (R > pioran_scan_supported_rows()) return "fallback";
     return pioran_scan_config_name((int)R);

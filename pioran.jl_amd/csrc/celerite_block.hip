@@ -234,20 +234,41 @@ __device__ __forceinline__ double ldl_first_mult(double (&m)[16], int c16)
     return c16 == 0 ? -2.0 : mn;
 }
 
-struct BlockShared {                // exchanges between the wavefronts of a workgroup
-    double MG[4][16 * 18];          // per wavefront: its block of M' [step][row, stride 18] for the transposing read-back, then
+template <int NB>
+struct BlockSharedT {               // exchanges between the wavefronts of a workgroup
+    double MG[NB][16 * 18];         // per owner wavefront: its block of M' [step][row, stride 18] for the transposing read-back, then
                                     // (same storage) its partial Gram U~_J' M_J as fragments [g][lane]
-    double Ab[2][2][256];           // A of window k in Ab[k & 1][0] (four block columns: the two term-parity partial sums [0] + [1])
+    double Ab[2][NB == 4 ? 2 : 1][256];   // A of window k in Ab[k & 1][0] (four block columns: the two term-parity partial sums [0] + [1])
     double Li[16 * 18];             // D_k (L^-1)_ik at [k * 18 + i], i > k; D_k at [k * 18 + k]; the rest is not L^-1 (readers mask).
                                     // Before the elimination the chain wavefront uses the same storage for Sigma [j][n] (its own
                                     // layout change; the readers of L^-1 of the previous window are two barriers behind)
-    double Yt[4 * 256];             // Y^' fragments [J][g][lane]
+    double Yt[NB * 256];            // Y^' fragments [J][g][lane]
     double fin[8];
     double2 ab[64];                 // (a_t, b_t) of this draw
     double2 albe[64];               // per row: u = al v + be x
     double ys[2][32];               // per-draw series: (y_n, sigma2_n) of window k in ys[k & 1][0..15 | 16..31]
 };
 constexpr int kBlockMaxTerms = 64;
+
+// Per-draw rows (mixed mode: a few terms whose (c, d) differ per draw — QPO features on an approx continuum, src/psd.jl:254-261;
+// round 3).  The host puts those rows LAST (rows R - 2 npd .. R - 1, cos row then sin row of each term; capi.hip build_rowmap), the
+// shared table holds nothing useful for them, and the chain wavefront — idle between barrier 2 of a window and barrier 1 of the
+// next — forms their entries of the record of window k + 2 in LDS from the per-draw (cos, sin)(d t_n) (a compact table written by
+// pd_trig_kernel, so that the entries use the same rounded phases everywhere: see block_table_kernel) and the time stamps, both
+// staged by LDS DMA a window earlier: four exponentials per lane and window.  The readers of a record (load_u, load_vh, form_A)
+// take these rows' values from here instead of the tile.
+constexpr int kBlockMaxPdTerms = 2;
+struct BlockPd {
+    double cv[2][2 * kBlockMaxPdTerms][16];   // [window parity][per-draw row][step]: C_n o v_n
+    double cx[2][2 * kBlockMaxPdTerms][16];   //                                       C_n o x_n
+    double vh[2][2 * kBlockMaxPdTerms][16];   //                                       (C_K / C_n) o v_n
+    double ck[2][2 * kBlockMaxPdTerms];       // C_K
+    // (followed in LDS by double2 E[2][npd terms][128]: e^{-c tau} (cos, sin)(d tau) per pair of the window — sized by the launch)
+    double stage[2][24 + 32 * kBlockMaxPdTerms];   // [parity]: t[16 k - 2 .. 16 k + 17] (20, padded to 24), then (cos, sin)(d t_n) x 16 per term
+    double2 ab[kBlockMaxPdTerms];             // (a, b) of the per-draw terms
+    double c[kBlockMaxPdTerms];
+    int term[kBlockMaxPdTerms];
+};
 
 // doubles of the (CV, CX, VH, CK, S2w) part of a record, rounded up to whole 1 KB pieces of the LDS DMA
 __host__ __device__ inline int block_tile_doubles(int NB) { return (3 * NB * 256 + 16 * NB + 16 + 127) & ~127; }
@@ -274,12 +295,16 @@ __device__ __forceinline__ void dma_pieces(const double* gsrc, double* ldst, int
 // With four block columns (always a single E buffer) the workgroup is filled up to eight wavefronts with COPY wavefronts that do
 // nothing but issue the LDS DMA of record k + 2 between the barriers (a piece costs its issuer ~150 cycles, ~100 pieces per window: too
 // much for the computing wavefronts' slack).
-template <int NB, bool EDBL>
-__global__ void __launch_bounds__(NB < 4 ? 256 : 512, NB < 4 ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
+template <int NB, bool EDBL, bool PD = false>
+__global__ void __launch_bounds__(NB < 4 ? (PD ? 320 : 256) : 512, (NB < 4 && !PD) ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
 {
     constexpr int NCW = NB < 4 ? 4 : 5;     // computing wavefronts: owners + chain
     constexpr bool COPYW = NB == 4;         // copy wavefronts (these shapes fill a CU's LDS with one workgroup anyway)
-    constexpr int NWV = COPYW ? 8 : NCW;    // wavefronts per workgroup
+    // per-draw rows, up to three block columns: one more wavefront forms their record entries (a whole window of time for ~4 exponentials
+    // per lane: never on the critical path; on the chain wavefront the same work delayed barrier 1 of every window — 5.1 instead of
+    // 3.3 us per window).  With four block columns the chain wavefront does it (the workgroup is full: copy wavefronts).
+    constexpr bool HELPW = PD && NB < 4;
+    constexpr int NWV = COPYW ? 8 : NCW + (HELPW ? 1 : 0);    // wavefronts per workgroup
     constexpr int CH = NCW - 1;             // the chain wavefront
     constexpr int TS = 3 * NB * 256 + 16 * NB + 16, TSP = (TS + 127) & ~127;
     extern __shared__ double lds_[];
@@ -294,8 +319,14 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 512, NB < 4 ? 2 : 1) celerite_b
     double* const tileb = lds_;
     double* const Eb = lds_ + 2 * TSP;               // E(k) lives in Eb + (EDBL ? (k & 1) * 256 J : 0)
     const int ebs = EDBL ? 256 * J : 0;
+    using BlockShared = BlockSharedT<NB>;
     BlockShared& sh = *reinterpret_cast<BlockShared*>(lds_ + 2 * TSP + (EDBL ? 2 : 1) * 256 * J);
+    [[maybe_unused]] BlockPd& pd = *reinterpret_cast<BlockPd*>(reinterpret_cast<char*>(&sh) + sizeof(BlockShared));   // (allocated only for PD launches)
+    [[maybe_unused]] double2* const pdE = reinterpret_cast<double2*>(reinterpret_cast<char*>(&pd) + sizeof(BlockPd));
+    [[maybe_unused]] const int npd = PD ? p.npd_rows / 2 : 0, npdr = PD ? p.npd_rows : 0;
+    [[maybe_unused]] const int pdr0 = p.R - npdr;                  // first per-draw row
     const bool chain = w == CH;
+    [[maybe_unused]] const bool pdw = HELPW ? w == NCW : chain;   // the wavefront that prepares the per-draw rows
     const bool owner = w < NB;                                    // this wavefront owns block column w of T
     const bool has_u = owner || chain;
     const int Jy = R >> 4, ry = R & 15;                           // block column / lane column of the y row
@@ -324,11 +355,89 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 512, NB < 4 ? 2 : 1) celerite_b
         sh.albe[tid] = double2{a, bb};
     }
 
+    if constexpr (PD) {
+        if (tid < npd) {
+            const int term = p.rowmap[pdr0 + 2 * tid] & 0xfffff;
+            pd.term[tid] = term;
+            pd.ab[tid] = double2{Ab_[term], Bb_[term]};
+            pd.c[tid] = p.pd_C[b * J + term];
+        }
+    }
+
     d4 T[NB];
 #pragma unroll
     for (int I = 0; I < NB; ++I) T[I] = d4{0.0, 0.0, 0.0, 0.0};
     double Uf[NB][4];
     double vh[4], ckc = 0.0, ckr[NB][4];
+
+    // ---- per-draw rows: staging (LDS DMA) and the record entries of one window (chain wavefront) ----
+    int pnn[2] = {1, 1}, pjj[2] = {0, 0};   // the two pairs (jj < nn) of this lane: p = lane, lane + 64
+    if constexpr (PD) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pq = lane + 64 * h;
+            int n_ = 1;
+            while ((n_ + 1) * n_ / 2 <= pq) ++n_;
+            pnn[h] = n_;
+            pjj[h] = pq - n_ * (n_ - 1) / 2;
+        }
+    }
+    [[maybe_unused]] auto stage_dma = [&](int64_t K) __attribute__((always_inline)) {
+        double* dst = pd.stage[K & 1];
+        const int64_t n0 = K * KW;
+        if (lane < 10) {   // st[j] = t[n0 - 2 + j]: 16 bytes per lane from a 16-byte aligned address inside the series (what falls
+                           // outside [0, N) is never used: the window base of window 0, steps past the end)
+            int64_t j0 = n0 - 2 + 2 * lane;
+            const int64_t jmax = (N - 1) & ~(int64_t)1;
+            j0 = j0 < 0 ? 0 : (j0 > jmax ? jmax : j0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.t + j0), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        if (lane < 16) {
+            for (int i = 0; i < npd; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.pd_trig + ((b * npd + i) * p.pd_npad + n0 + lane) * 2),
+                                                 (__attribute__((address_space(3))) void*)(dst + 24 + 32 * i), 16, 0, 0);
+        }
+    };
+    [[maybe_unused]] auto compute_pd = [&](int64_t K) __attribute__((always_inline)) {
+        const double* st = pd.stage[K & 1];
+        const int64_t n0 = K * KW;
+        const int last = (int)((n0 + KW - 1 < N ? n0 + KW - 1 : N - 1) - n0);
+        const double tb = K > 0 ? st[1] : st[2], te = st[2 + last];      // window base (irrelevant for K = 0: T = 0), window end
+        for (int i = 0; i < npd; ++i) {
+            const double cdec = pd.c[i];
+            const double* tr = st + 24 + 32 * i;
+            if (lane < 16) {
+                double cvc = 0.0, cxc = 0.0, vhc = 0.0, cvs = 0.0, cxs = 0.0, vhs = 0.0;   // cos row (v, x) = (cos, sin); sin row swapped
+                if (n0 + lane < N) {
+                    const double tn = st[2 + lane], co = tr[2 * lane], si = tr[2 * lane + 1];
+                    const double Cn = exp(-cdec * (tn - tb)), Hn = exp(-cdec * (te - tn));
+                    cvc = co * Cn; cxc = si * Cn; vhc = co * Hn;
+                    cvs = si * Cn; cxs = co * Cn; vhs = si * Hn;
+                }
+                pd.cv[K & 1][2 * i][lane] = cvc; pd.cx[K & 1][2 * i][lane] = cxc; pd.vh[K & 1][2 * i][lane] = vhc;
+                pd.cv[K & 1][2 * i + 1][lane] = cvs; pd.cx[K & 1][2 * i + 1][lane] = cxs; pd.vh[K & 1][2 * i + 1][lane] = vhs;
+            } else if (lane == 16) {
+                const double ck = exp(-cdec * (te - tb));
+                pd.ck[K & 1][2 * i] = ck;
+                pd.ck[K & 1][2 * i + 1] = ck;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pq = lane + 64 * h;
+                if (pq < 120) {
+                    double2 e = double2{0.0, 0.0};
+                    if (n0 + pnn[h] < N) {
+                        const double tn = st[2 + pnn[h]], tj = st[2 + pjj[h]];
+                        const double cn = tr[2 * pnn[h]], sn = tr[2 * pnn[h] + 1], cj = tr[2 * pjj[h]], sj = tr[2 * pjj[h] + 1];
+                        const double dec = exp(-cdec * (tn - tj));
+                        e.x = dec * fma(cn, cj, sn * sj);          // (cos, sin)(d tau) by angle addition from the rounded phases, as block_table_kernel
+                        e.y = dec * fma(sn, cj, -cn * sj);
+                    }
+                    pdE[((K & 1) * npd + i) * 128 + pq] = e;
+                }
+            }
+        }
+    };
 
     auto load_u = [&](int64_t k) __attribute__((always_inline)) {
         const double* tl = tileb + (k & 1) * TSP;
@@ -338,7 +447,12 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 512, NB < 4 ? 2 : 1) celerite_b
             for (int ks = 0; ks < 4; ++ks) {
                 const int f = (I * 4 + ks) * 64 + lane;
                 const double2 cf = sh.albe[16 * I + 4 * ks + q];
-                Uf[I][ks] = fma(cf.x, tl[f], cf.y * tl[NB * 256 + f]);
+                double cvv = tl[f], cxv = tl[NB * 256 + f];
+                if constexpr (PD) {
+                    const int r = 16 * I + 4 * ks + q - pdr0;                     // (wave-uniform up to q: four rows per (I, ks))
+                    if (16 * I + 4 * ks + 3 >= pdr0 && r >= 0 && r < npdr) { cvv = pd.cv[k & 1][r][c16]; cxv = pd.cx[k & 1][r][c16]; }
+                }
+                Uf[I][ks] = fma(cf.x, cvv, cf.y * cxv);
             }
     };
     auto load_vh = [&](int64_t k) __attribute__((always_inline)) {
@@ -347,6 +461,10 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 512, NB < 4 ? 2 : 1) celerite_b
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 double v = tl[2 * NB * 256 + (w * 4 + g) * 64 + lane];
+                if constexpr (PD) {
+                    const int r = 16 * w + c16 - pdr0;
+                    if (r >= 0 && r < npdr) v = pd.vh[k & 1][r][4 * g + q];
+                }
                 if (ycol) {
                     const int64_t n = k * KW + 4 * g + q;
                     if (p.Y) v = sh.ys[k & 1][4 * g + q];
@@ -355,10 +473,20 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 512, NB < 4 ? 2 : 1) celerite_b
                 vh[g] = v;
             }
             ckc = tl[3 * NB * 256 + 16 * w + c16];
+            if constexpr (PD) {
+                const int r = 16 * w + c16 - pdr0;
+                if (r >= 0 && r < npdr) ckc = pd.ck[k & 1][r];
+            }
 #pragma unroll
             for (int I = 0; I < NB; ++I)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) ckr[I][g] = tl[3 * NB * 256 + 16 * I + 4 * g + q];
+                for (int g = 0; g < 4; ++g) {
+                    ckr[I][g] = tl[3 * NB * 256 + 16 * I + 4 * g + q];
+                    if constexpr (PD) {
+                        const int r = 16 * I + 4 * g + q - pdr0;
+                        if (16 * I + 4 * g + 3 >= pdr0 && r >= 0 && r < npdr) ckr[I][g] = pd.ck[k & 1][r];
+                    }
+                }
         }
     };
     // A of window k (kappa, src/acvf.jl:138-140, on the window's own pairs) -> sh.Ab[k & 1].  Thread pp < 120 of a pair half owns
@@ -390,6 +518,14 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 512, NB < 4 ? 2 : 1) celerite_b
                     const double2 e = E[t * 128], cf = sh.ab[t];
                     acc0 = fma(cf.x, e.x, acc0);
                     acc1 = fma(cf.y, e.y, acc1);
+                }
+                if constexpr (PD) {
+                    if (tpar == 0)
+                        for (int i = 0; i < npd; ++i) {
+                            const double2 e = pdE[((k & 1) * npd + i) * 128 + pp], cf = pd.ab[i];
+                            acc0 = fma(cf.x, e.x, acc0);
+                            acc1 = fma(cf.y, e.y, acc1);
+                        }
                 }
                 const double acc = acc0 + acc1;
                 Ad[jj * 16 + nn] = acc;
@@ -429,7 +565,23 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 512, NB < 4 ? 2 : 1) celerite_b
     fetch_series(1);
     stage_series(1);
     fetch_series(2);
+    if constexpr (PD) {
+        if (pdw) {
+            stage_dma(0);
+            if (NW > 1) stage_dma(1);
+        }
+    }
     PIORAN_BLK_BARRIER_DMA();          // record 0 has landed
+    if constexpr (PD) {
+        // the shared table's E entries of a per-draw term mean nothing: its (a, b) leave the shared contraction of form_A
+        if (tid < npd) sh.ab[pd.term[tid]] = double2{0.0, 0.0};
+        if (pdw) {
+            compute_pd(0);
+            if (NW > 1) compute_pd(1);
+        }
+        PIORAN_BLK_BARRIER();
+        if (pdw && NW > 2) stage_dma(2);
+    }
     if (has_u) load_u(0);
     load_vh(0);
     form_A(0);
@@ -481,6 +633,15 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 512, NB < 4 ? 2 : 1) celerite_b
         PIORAN_BSTAMP(1);
         PIORAN_BLK_BARRIER_DMA();   // B1: M' published; record k + 1 has landed
         PIORAN_BSTAMP(2);
+        if constexpr (HELPW) {
+            // per-draw rows of record k + 2: its staging has landed (this barrier), buffer k & 1 held window k's values (last read before
+            // this barrier: the owners in window k - 1, the chain wavefront's load_u(k) at its end); first read after barrier 1 of
+            // window k + 1.  Then the staging of window k + 3 (its buffer was consumed one window ago).
+            if (pdw && k + 2 < NW) {
+                compute_pd(k + 2);
+                if (k + 3 < NW) stage_dma(k + 3);
+            }
+        }
         // ---- chain: Sigma = A - U~' M, LDL', L^-1 ---------------------------------------------------------------------
         if (chain) {
             const double* Ad = sh.Ab[k & 1][0];
@@ -560,6 +721,15 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 512, NB < 4 ? 2 : 1) celerite_b
         // the whole Y^ / update / M' stretch to land; issued after its own LDS reads below they land too late for barrier 1)
         if (chain && k + 2 < NW) {
             for (int c = 0; c < (EDBL ? np_chain : (COPYW ? nt_chain : np_tile)); ++c) copy_piece(c);
+        }
+        if constexpr (PD && !HELPW) {
+            // per-draw rows of record k + 2 (its staging landed before barrier 1 of this window; buffer k & 1 held window k's values,
+            // last read before this barrier), then the staging of window k + 3
+            if (chain && k + 2 < NW) {
+                compute_pd(k + 2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (k + 3 < NW) stage_dma(k + 3);
+            }
         }
         // copy wavefronts (one E buffer): everything else, E(k + 1) and tile k being consumed since this barrier; a quarter of the
         // share before barrier 3, which follows within ~1000 cycles, the rest after it
@@ -644,26 +814,28 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 512, NB < 4 ? 2 : 1) celerite_b
 }
 
 constexpr size_t kBlockLdsMax = 160 * 1024;
-__host__ inline size_t block_lds_bytes(int NB, int J, bool edbl)
+__host__ inline size_t block_lds_bytes(int NB, int J, bool edbl, int npd = 0 /*per-draw terms*/)
 {
-    return (size_t)(2 * block_tile_doubles(NB) + (edbl ? 2 : 1) * 256 * J) * sizeof(double) + sizeof(BlockShared);
+    const size_t shared = NB == 1 ? sizeof(BlockSharedT<1>) : NB == 2 ? sizeof(BlockSharedT<2>) : NB == 3 ? sizeof(BlockSharedT<3>) : sizeof(BlockSharedT<4>);
+    return (size_t)(2 * block_tile_doubles(NB) + (edbl ? 2 : 1) * 256 * J) * sizeof(double) + shared +
+           (npd > 0 ? sizeof(BlockPd) + (size_t)2 * npd * 128 * sizeof(double2) : 0);
 }
 
-template <int NB, bool EDBL>
+template <int NB, bool EDBL, bool PD = false>
 int launch_block2(const ScanParams& p, const double* btab, hipStream_t stream)
 {
-    const size_t lds = block_lds_bytes(NB, p.J, EDBL);
+    const size_t lds = block_lds_bytes(NB, p.J, EDBL, PD ? p.npd_rows / 2 : 0);
     // the attribute belongs to (function, device): one process may drive several devices (pioran_farm_*).  Racing threads at
     // worst set it twice.
     static size_t granted[64] = {};   // per template instance
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
     if (lds > granted[dev]) {
-        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, EDBL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, EDBL, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PIORAN_ERR_HIP;
         granted[dev] = lds;
     }
-    hipLaunchKernelGGL((celerite_block_kernel<NB, EDBL>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
+    hipLaunchKernelGGL((celerite_block_kernel<NB, EDBL, PD>), dim3((unsigned)p.B), dim3(NB < 4 ? (PD ? 320 : 256) : 512), lds, stream, p, btab);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
@@ -672,6 +844,11 @@ int launch_block(const ScanParams& p, const double* btab, hipStream_t stream)
 {
     // two E buffers only while one workgroup per CU is all there is to run: above 256 draws the smaller footprint lets several
     // workgroups share a CU, which is worth more (tools/sweep_block.py)
+    if (p.npd_rows > 0) {   // per-draw rows
+        if (p.B <= 256 && block_lds_bytes(NB, p.J, true, p.npd_rows / 2) <= kBlockLdsMax) return launch_block2<NB, true, true>(p, btab, stream);
+        if (block_lds_bytes(NB, p.J, false, p.npd_rows / 2) <= kBlockLdsMax) return launch_block2<NB, false, true>(p, btab, stream);
+        return PIORAN_ERR_UNSUPPORTED;
+    }
     if (p.B <= 256 && block_lds_bytes(NB, p.J, true) <= kBlockLdsMax) return launch_block2<NB, true>(p, btab, stream);
     if (block_lds_bytes(NB, p.J, false) <= kBlockLdsMax) return launch_block2<NB, false>(p, btab, stream);
     return PIORAN_ERR_UNSUPPORTED;
@@ -695,6 +872,46 @@ int pioran_block_fits(int32_t R, int32_t J)
     return block_lds_bytes(NB, J, false) <= kBlockLdsMax;
 }
 
+// ... with `npd_terms` per-draw terms (their rows last)
+int pioran_block_fits_pd(int32_t R, int32_t J, int32_t npd_terms)
+{
+    const int NB = (R + 1 + 15) / 16;
+    if (R < 1 || NB > 4 || J < 1 || J > kBlockMaxTerms || npd_terms < 1 || npd_terms > kBlockMaxPdTerms || R < 2 * npd_terms) return 0;
+    return block_lds_bytes(NB, J, false, npd_terms) <= kBlockLdsMax;
+}
+
+namespace {
+// (cos, sin)(d_term t_n) of the per-draw terms, [draw][per-draw term][step (npad = 16 windows)][2]: what the block kernel stages per
+// window for its per-draw rows.  Same sincos as the shared tables (full-range reduction), evaluated once per (draw, term, step).
+__global__ void __launch_bounds__(256) pd_trig_kernel(int64_t N, int64_t npad, int64_t B, int32_t J, int32_t npd,
+                                                      const int32_t* __restrict__ pd_terms, const double* __restrict__ t,
+                                                      const double* __restrict__ D, double* __restrict__ out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * npd * npad) return;
+    const int64_t n = idx % npad, bi = idx / npad;
+    const int i = (int)(bi % npd);
+    const int64_t b = bi / npd;
+    double si = 0.0, co = 0.0;
+    if (n < N) sincos(D[b * J + pd_terms[i]] * t[n], &si, &co);   // :52-53
+    reinterpret_cast<double2*>(out)[idx] = double2{co, si};
+}
+}  // namespace
+
+size_t pioran_block_pd_trig_doubles(int64_t N, int64_t B, int32_t npd_terms)
+{
+    return (size_t)B * (size_t)npd_terms * (size_t)((N + KW - 1) / KW * KW) * 2;
+}
+
+int pioran_launch_block_pd_trig(int64_t N, int64_t B, int32_t J, int32_t npd_terms, const int32_t* pd_terms, const double* t,
+                                const double* D, double* out, hipStream_t stream)
+{
+    const int64_t npad = (N + KW - 1) / KW * KW, total = B * npd_terms * npad;
+    if (total <= 0 || (total + 255) / 256 > 0x7fffffffLL) return PIORAN_ERR_ARG;
+    hipLaunchKernelGGL(pd_trig_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, N, npad, B, J, npd_terms, pd_terms, t, D, out);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
 int pioran_launch_block_table(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,
                               const double* d, const double* y, const double* s2, double* btab, hipStream_t stream)
 {
@@ -705,10 +922,16 @@ int pioran_launch_block_table(int64_t N, int32_t R, int32_t J, const int32_t* ro
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
-// shared-(c, d) launches without per-draw rows; btab from pioran_launch_block_table for the same (N, R, J, rowmap)
+// shared-(c, d) launches; btab from pioran_launch_block_table for the same (N, R, J, rowmap).  Per-draw rows (npd_rows = 2 or 4, the
+// LAST rows of the row map) need p.pd_C ([B][J]) and p.pd_trig (pioran_launch_block_pd_trig), p.pd_npad
 int pioran_launch_scan_block(const ScanParams& p, const double* btab, hipStream_t stream)
 {
-    if (!btab || p.npd_rows != 0 || p.B < 1 || p.N < 1 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    if (!btab || p.B < 1 || p.N < 1) return PIORAN_ERR_UNSUPPORTED;
+    if (p.npd_rows != 0) {
+        if ((p.npd_rows & 1) || !p.pd_C || !p.pd_trig || p.pd_npad < p.N || !pioran_block_fits_pd(p.R, p.J, p.npd_rows / 2)) return PIORAN_ERR_UNSUPPORTED;
+    } else if (!pioran_block_fits(p.R, p.J)) {
+        return PIORAN_ERR_UNSUPPORTED;
+    }
     if ((p.Y == nullptr) != (p.S2 == nullptr)) return PIORAN_ERR_ARG;
     switch ((p.R + 1 + 15) / 16) {
         case 1: return launch_block<1>(p, btab, stream);

@@ -57,6 +57,11 @@ struct ScanParams {
     int64_t rec_stride;
     int64_t tab_draw_stride;   // celerite_wide2_kernel only: draw b reads the table at tab + b * tab_draw_stride (0: one shared table)
     int32_t npd_rows;     // per-draw rows (2 per per-draw term), 0 if none
+    // celerite_block.hip with per-draw rows (the last npd_rows rows of the row map): the per-draw c [B][J] and the compact table of
+    // (cos, sin)(d t_n) [B][npd terms][pd_npad][2] (pioran_launch_block_pd_trig)
+    const double* pd_C;
+    const double* pd_trig;
+    int64_t pd_npad;
     // celerite_wide.hip only.  Factor store (pioran_launch_scan_wide_store): W [B][N][R] (the reference's V after
     // init_semi_separable!, src/celerite_solver.jl:95-97), D [B][N], forward-solved z [B][N] (:141).
     double* st_w;
@@ -109,6 +114,10 @@ int64_t pioran_wide_max_batch();
 // per-draw rows; its own table (fragment order), built once per prepared (c, d)
 int pioran_block_supported_rows();
 int pioran_block_fits(int32_t R, int32_t J);   // rows and terms within the kernel's LDS budget
+int pioran_block_fits_pd(int32_t R, int32_t J, int32_t npd_terms);   // ... with per-draw terms (at most two)
+size_t pioran_block_pd_trig_doubles(int64_t N, int64_t B, int32_t npd_terms);
+int pioran_launch_block_pd_trig(int64_t N, int64_t B, int32_t J, int32_t npd_terms, const int32_t* pd_terms /*device*/, const double* t,
+                                const double* D /*[B][J]*/, double* out, hipStream_t stream);
 size_t pioran_block_table_doubles(int64_t N, int32_t R, int32_t J);
 int pioran_launch_block_table(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,
                               const double* d, const double* y, const double* s2, double* btab, hipStream_t stream);

@@ -923,6 +923,8 @@ def test_mixed_shared_and_per_draw_terms(ctx, J, npd, with_real, layout):
     ref = O.logl_batch(A, Bc, C2, D2, t, y, s2, mu, nu, nthreads=8)
     got = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu)
     assert relerr(got, ref) < 1e-11
+    if layout == "block":   # small batches with one or two per-draw terms: the windowed kernel with per-draw rows (round 3)
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block+pd"
     try:
         ctx.set_option("no_mixed", True)
         gen = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu)
@@ -934,6 +936,43 @@ def test_mixed_shared_and_per_draw_terms(ctx, J, npd, with_real, layout):
     got2 = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu, Y=Y, S2=S2)
     ref2 = np.array([O.logl(A[i], Bc[i], C2[i], D2[i], t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(B)])
     assert relerr(got2, ref2) < 1e-11
+
+
+@pytest.mark.parametrize("J,npd,nreal", [(3, 1, 0), (7, 2, 1), (15, 1, 0), (16, 2, 3), (23, 1, 0), (24, 2, 0), (30, 2, 0), (31, 1, 0), (33, 2, 8)])
+def test_block_kernel_per_draw_rows_edges(ctx, J, npd, nreal):
+    """The windowed kernel with per-draw rows (celerite_block.hip, BlockPd): every block count NB = 1 .. 4, the per-draw rows inside one
+    16-row block and across a block boundary, series of 1 .. 3 windows and a ragged tail, batches on both sides of 256 draws (one /
+    two E buffers), per-draw series; against the oracle and against the throughput layouts' mixed mode."""
+    rng = np.random.default_rng(7700 + 10 * J + npd)
+    for N, B in ((1, 3), (2, 5), (15, 4), (16, 9), (17, 9), (33, 37), (48, 6), (100, 300)):
+        t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+        C2 = np.broadcast_to(C, (B, J)).copy(); D2 = np.broadcast_to(Dd, (B, J)).copy()
+        cols = rng.choice(J, npd, replace=False)
+        C2[:, cols] = rng.uniform(0.05, 2.0, (B, npd)); D2[:, cols] = rng.uniform(0.1, 3.0, (B, npd))
+        real_cols = [j for j in range(J) if j not in cols][:nreal]
+        Bc[:, real_cols] = 0.0; D2[:, real_cols] = 0.0
+        if B == 1:
+            continue
+        ds = pj.Dataset(t, y, s2, ctx)
+        ref = O.logl_batch(A, Bc, C2, D2, t, y, s2, mu, nu, nthreads=8)
+        got, st = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu, return_status=True)
+        name = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+        if J < 32:   # (beyond, the kernel's LDS record does not fit beside the per-draw block: the latency layout takes it)
+            assert name == "block+pd", name
+        assert (st == 0).all() and relerr(got, ref) < 1e-11, (N, B)
+        if N in (17, 100):
+            Y = y[None, :] + 0.01 * rng.standard_normal((B, N)); S2 = np.broadcast_to(s2, (B, N)) * rng.uniform(0.5, 2, (B, 1))
+            got2 = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu, Y=Y, S2=S2)
+            ref2 = np.array([O.logl(A[i], Bc[i], C2[i], D2[i], t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(B)])
+            assert relerr(got2, ref2) < 1e-11
+            try:
+                ctx.set_option("no_block", True)
+                alt = ds.logl_batch(A, Bc, C2, D2, mu=mu, nu=nu)
+                assert pj._lib.lib().pioran_celerite_config_name(-1).decode() in ("wide", "scan")
+            finally:
+                ctx.set_option("no_block", False)
+            assert relerr(alt, got) < 1e-11
+        ds.close()
 
 
 def test_mixed_mode_qpo_model_full_size(ctx, full_size):
@@ -952,10 +991,17 @@ def test_mixed_mode_qpo_model_full_size(ctx, full_size):
     assert A.shape == (B, 21) and (C2[:, :20] == C2[0, :20]).all() and not (C2[:, 20] == C2[0, 20]).all()
     ds = pj.Dataset(t, y, yerr ** 2, ctx)
     got, st = ds.logl_batch(A, Bc, C2, D2, mu=th[:, 5], nu=th[:, 4], return_status=True)
+    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block+pd"   # 24 draws: the windowed kernel with per-draw rows
     ref, rst = O.logl_batch(A, Bc, C2, D2, t, y, yerr ** 2, th[:, 5].copy(), th[:, 4].copy(), nthreads=8, return_status=True)
     ok = rst == 0
     assert ok.sum() >= B // 2 and (st[ok] == 0).all()
     assert relerr(got[ok], ref[ok]) < 1e-8
+    try:   # ... and the latency layout's mixed mode on the same inputs
+        ctx.set_option("no_block", True)
+        alt = ds.logl_batch(A, Bc, C2, D2, mu=th[:, 5], nu=th[:, 4])
+    finally:
+        ctx.set_option("no_block", False)
+    assert relerr(alt[ok], ref[ok]) < 1e-8 and relerr(alt[ok], got[ok]) < 1e-8
 
 
 def test_in_process_farm_sharding(golden_dir):
