@@ -13,6 +13,7 @@ run predict_simulate_n1e4_b256.json python3 tools/bench_predict.py
 run gradient_sho20.json python3 tools/bench_grad.py
 BASIS=DRWCelerite run gradient_drw20.json python3 tools/bench_grad.py
 run qpo_mixed_b4096.json python3 tools/bench_qpo.py
+run qpo_small_batches.txt python3 tools/bench_qpo_small.py
 run shift_transform_b4096.json python3 tools/bench_shift.py
 run small_batch_latency_sho20.json python3 tools/bench_small_batch.py
 BASIS=DRWCelerite run small_batch_latency_drw20.json python3 tools/bench_small_batch.py
