@@ -276,7 +276,7 @@ def main():
                              "profiles/r02_mfma_probe.txt), so there is no second pipe to overlap with. Budget (DESIGN.md 4.1; "
                              "profiles/r02_pmc_*.json, profiles/r02_valu_probe.txt): one DP instruction per ~4.6 cycles at two "
                              "wavefronts per SIMD, ~1.9 GHz of 2.4 under chip-wide FP64 issue, 1.53 flop per lane-instruction "
-                             "(two-step form: 239 instead of 280 instructions per wave-step), full (not triangular) state."},
+                             "(two-step form, dead column dropped: 232.5 instead of 280 instructions per wave-step), full (not triangular) state."},
         "status_ok_frac": float((st_host == 0).mean()),
     }
 
