@@ -281,7 +281,9 @@ int ensure_btab(pioran_ds* ds, PrepState& s)
         }
         s.btab_cap = need;
     }
-    int rc = pioran_launch_block_table(ds->N, s.R, s.J, s.rowmap, ds->t, s.dc, s.dd, ds->y, ds->s2, s.btab, ctx->stream);
+    int rc = ctx->opt.btab_reference
+                 ? pioran_launch_block_table_reference(ds->N, s.R, s.J, s.rowmap, ds->t, s.dc, s.dd, ds->y, ds->s2, s.btab, ctx->stream)
+                 : pioran_launch_block_table(ds->N, s.R, s.J, s.rowmap, ds->t, s.dc, s.dd, ds->y, ds->s2, s.btab, ctx->stream);
     if (rc) return rc;
     s.btab_ready = true;
     return PIORAN_OK;
@@ -374,6 +376,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "no_win2")) o.no_win2 = on;
     else if (!std::strcmp(key, "win3")) o.win3 = on;
     else if (!std::strcmp(key, "no_win3")) o.no_win3 = on;
+    else if (!std::strcmp(key, "btab_reference")) o.btab_reference = on;
     else if (!std::strcmp(key, "dense_streams")) o.dense_streams = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "gsum")) o.gsum = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "wide2")) o.wide2 = on;
@@ -684,6 +687,46 @@ int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const
         }
         return PIORAN_OK;
     }
+    {
+        // Small batches, up to 63 rows: every draw gets its own table of the WINDOWED kernel (celerite_block.hip; one workgroup per
+        // (window, draw) builds it: ~8 us per table at N = 1e4, J = 20) instead of evaluating 3 J transcendentals per step and draw inside
+        // the throughput layout (14.7 ms per launch at N = 1e4, J = 20 whatever the batch): free Celerite / CARMA terms under a sampler
+        // (src/CARMA.jl:98-143).  tools/bench_per_draw_small.py.
+        const ScanOptions& o = ctx->opt;
+        const int32_t R = (int32_t)rm.size();
+        const bool automatic = !o.scan_config[0] && !o.no_block && B <= 768 && R >= 6;
+        const bool force = !std::strcmp(o.scan_config, "block");
+        if ((automatic || force) && !o.force_fallback && pioran_block_fits(R, (int32_t)J)) {
+            const int64_t tdoubles = (int64_t)pioran_block_table_doubles(ds->N, R, (int32_t)J);
+            int64_t chunk = B < 256 ? B : 256;
+            {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                    while (chunk > 1 && (size_t)chunk * (size_t)tdoubles * sizeof(double) > free_b / 2 + ctx->bscratch.cap) chunk /= 2;
+            }
+            while ((rc = ensure(ctx, ctx->bscratch, (size_t)chunk * (size_t)tdoubles * sizeof(double))) == PIORAN_ERR_ALLOC && chunk > 1) chunk /= 2;
+            if (rc) return rc;
+            for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+                const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+                rc = pioran_launch_block_table_batch(ds->N, R, (int32_t)J, nb, drm, ds->t, dC + b0 * J, dDd + b0 * J, ds->y, ds->s2,
+                                                     (double*)ctx->bscratch.p, tdoubles, ctx->stream);
+                if (rc) return rc;
+                ScanParams q{};
+                q.opt = &ctx->opt;
+                q.N = ds->N; q.J = (int32_t)J; q.R = R; q.B = nb; q.standard_rows = 1;
+                q.rec_stride = 3 * (int64_t)(R + 2) + 2; q.tab_draw_stride = tdoubles;
+                q.rowmap = drm; q.t = ds->t; q.y = ds->y; q.s2 = ds->s2;
+                q.Y = dY ? dY + b0 * ds->N : nullptr; q.S2 = dS2 ? dS2 + b0 * ds->N : nullptr;
+                q.A = dA + b0 * J; q.Bc = dBc + b0 * J; q.C = dC + b0 * J; q.D = dDd + b0 * J;
+                q.mu = dmu ? dmu + b0 : nullptr; q.nu = dnu ? dnu + b0 : nullptr;
+                q.out = dout + b0; q.status = dstatus ? dstatus + b0 : nullptr;
+                g_last_kernel = "block (per-draw tables)";
+                rc = pioran_launch_scan_block(q, (const double*)ctx->bscratch.p, ctx->stream);
+                if (rc) { if (rc == PIORAN_ERR_HIP) ctx->last_err = "windowed kernel (per-draw tables) launch failed"; return rc; }
+            }
+            return PIORAN_OK;
+        }
+    }
     ScanParams p{};
     p.N = ds->N; p.J = (int32_t)J; p.R = (int32_t)rm.size(); p.B = B;
     p.standard_rows = 1;
@@ -872,6 +915,12 @@ static int batch_host_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A,
     const size_t bj = (size_t)B * (size_t)J * sizeof(double);
     const size_t bn = (size_t)B * (size_t)ds->N * sizeof(double);
     int rc;
+    if (!cd_shared) {   // one draw, or the same (c, d) in every draw: that IS the shared case (table built once, windowed kernel for small batches)
+        bool same = true;
+        for (int64_t b = 1; b < B && same; ++b)
+            same = !std::memcmp(C + b * J, C, (size_t)J * sizeof(double)) && !std::memcmp(Dd + b * J, Dd, (size_t)J * sizeof(double));
+        if (same) cd_shared = 1;
+    }
     if (!cd_shared && B > 1) {
         rc = batch_host_mixed(ds, B, J, A, Bc, C, Dd, mu, nu, Y, S2, series_on_device, out, status);
         if (rc < 0) return rc;

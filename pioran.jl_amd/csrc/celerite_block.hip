@@ -160,6 +160,94 @@ __global__ void __launch_bounds__(256) block_table_kernel(int64_t N, int32_t R, 
     tab[idx] = val;
 }
 
+// The same record, one workgroup per (window, draw): the transcendentals a window needs are evaluated ONCE — (cos, sin)(d t_n) and the
+// two decays per (term, step), e^{-c tau} per (term, pair) — and every entry is a product of those (round 3; block_table_kernel above
+// re-evaluates two sincos and an exponential per ENTRY: 44 us per table at N = 1e4, J = 20; this one 8x fewer instructions).  Same
+// expressions on the same arguments, so the two tables are bit-identical (tests/test_gpu_parity.py compares them).  blockIdx.y = draw
+// of a batch of per-draw tables: (c, d) at c + y J, table at tab + y tab_draw_stride.
+__global__ void __launch_bounds__(256) block_table_window_kernel(int64_t N, int32_t R, int32_t J, int32_t NB, const int32_t* __restrict__ rowmap,
+                                                                 const double* __restrict__ t, const double* __restrict__ c,
+                                                                 const double* __restrict__ d, const double* __restrict__ y,
+                                                                 const double* __restrict__ s2, double* __restrict__ tab, int64_t cd_stride,
+                                                                 int64_t tab_draw_stride)
+{
+    __shared__ double cs[64 * 16], sn[64 * 16], Cn[64 * 16], Hn[64 * 16], ckt[64], tt[16];
+    c += (int64_t)blockIdx.y * cd_stride;
+    d += (int64_t)blockIdx.y * cd_stride;
+    tab += (int64_t)blockIdx.y * tab_draw_stride;
+    const int64_t RSB = block_rec_doubles(NB, J);
+    const int64_t k = blockIdx.x;
+    const int64_t n0 = k * KW;
+    const int64_t nlast = n0 + KW - 1 < N ? n0 + KW - 1 : N - 1;
+    const double tb = k > 0 ? t[n0 - 1] : t[0];    // window base (irrelevant for k = 0: T = 0)
+    const double te = t[nlast];                    // window end
+    for (int it = threadIdx.x; it < J * 16; it += 256) {
+        const int term = it >> 4, s = it & 15;
+        const int64_t n = n0 + s;
+        double si = 0.0, co = 0.0, cn = 0.0, hn = 0.0;
+        if (n < N) {
+            const double tn = t[n];
+            sincos(d[term] * tn, &si, &co);                                  // :52-53
+            cn = exp(-c[term] * (tn - tb));
+            hn = exp(-c[term] * (te - tn));
+        }
+        cs[it] = co; sn[it] = si; Cn[it] = cn; Hn[it] = hn;
+        if (s == 0) ckt[term] = exp(-c[term] * (te - tb));
+    }
+    if (threadIdx.x < 16) tt[threadIdx.x] = n0 + threadIdx.x < N ? t[n0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    const int64_t nfrag = (int64_t)NB * 256;
+    const int64_t tile_end = RSB - (int64_t)J * 256;
+    double* rec = tab + k * RSB;
+    for (int64_t e0 = threadIdx.x; e0 < RSB; e0 += 256) {
+        int64_t e = e0;
+        double val = 0.0;
+        if (e < 3 * nfrag) {
+            const int sec = (int)(e / nfrag);
+            const int f = (int)(e - sec * nfrag);
+            const int blk = f >> 8, reg = (f >> 6) & 3, lane = f & 63;
+            int row, s;
+            if (sec < 2) { row = 16 * blk + 4 * reg + (lane >> 4); s = lane & 15; }
+            else { s = 4 * reg + (lane >> 4); row = 16 * blk + (lane & 15); }
+            const int64_t n = n0 + s;
+            if (n < N) {
+                if (row < R) {
+                    const int32_t rm = rowmap[row];
+                    const int it = (rm & 0xfffff) * 16 + s;
+                    const bool ks = (rm >> 30) & 1;
+                    if (sec == 2) val = (ks ? sn[it] : cs[it]) * Hn[it];
+                    else val = ((sec == 0) == ks ? sn[it] : cs[it]) * Cn[it];   // sec 0: v, sec 1: x
+                } else if (row == R && sec == 2) {
+                    val = y[n];
+                }
+            }
+        } else if ((e -= 3 * nfrag) < 16 * NB) {
+            const int row = (int)e;
+            if (row < R) val = ckt[rowmap[row] & 0xfffff];
+            else if (row == R) val = 1.0;
+        } else if ((e -= 16 * NB) < 16) {
+            const int64_t n = n0 + e;
+            val = n < N ? s2[n] : 1.0;
+        } else if (e0 < tile_end) {
+            val = 0.0;   // padding of the tile part
+        } else {
+            e = e0 - tile_end;
+            const int term = (int)(e >> 8), p = (int)((e >> 1) & 127), h = (int)(e & 1);
+            if (p < 120) {
+                int nn = 1;
+                while ((nn + 1) * nn / 2 <= p) ++nn;       // p = nn (nn - 1) / 2 + jj, jj < nn
+                const int jj = p - nn * (nn - 1) / 2;
+                if (n0 + nn < N) {
+                    const double cn_ = cs[term * 16 + nn], sn_ = sn[term * 16 + nn], cj = cs[term * 16 + jj], sj = sn[term * 16 + jj];
+                    const double trig = h ? fma(sn_, cj, -cn_ * sj) : fma(cn_, cj, sn_ * sj);   // angle addition from the rounded phases (see above)
+                    val = exp(-c[term] * (tt[nn] - tt[jj])) * trig;
+                }
+            }
+        }
+        rec[e0] = val;
+    }
+}
+
 // ---- the 16 x 16 LDL' of the chain wavefront -------------------------------------------------------------------------
 // In-place Gauss-Jordan form.  Lane (q, n) holds column n in m[0..15]; the four DPP rows q hold copies.  Before step P, lanes
 // n >= P hold the reduced Sigma (column n, rows >= P matter), lanes n < P already hold column n of L^-1 (rows > n).  Step P:
@@ -316,6 +404,7 @@ __global__ void __launch_bounds__(NB < 4 ? (PD ? 320 : 256) : 512, (NB < 4 && !P
     const int J = p.J, R = p.R;
     const int64_t NW = (N + KW - 1) / KW;
     const int64_t RSB = TSP + 256 * (int64_t)J;
+    btab += b * p.tab_draw_stride;                   // per-draw tables (every term's (c, d) per draw): 0 for the shared table
     double* const tileb = lds_;
     double* const Eb = lds_ + 2 * TSP;               // E(k) lives in Eb + (EDBL ? (k & 1) * 256 J : 0)
     const int ebs = EDBL ? 256 * J : 0;
@@ -917,8 +1006,30 @@ int pioran_launch_block_table(int64_t N, int32_t R, int32_t J, const int32_t* ro
 {
     const int NB = (R + 1 + 15) / 16;
     const int64_t total = (int64_t)pioran_block_table_doubles(N, R, J);
+    (void)total;
+    return pioran_launch_block_table_batch(N, R, J, 1, rowmap, t, c, d, y, s2, btab, 0, stream);
+}
+
+// the entry-per-thread table kernel (round 2), kept as the cross-check of the windowed one
+int pioran_launch_block_table_reference(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,
+                                        const double* d, const double* y, const double* s2, double* btab, hipStream_t stream)
+{
+    const int NB = (R + 1 + 15) / 16;
+    const int64_t total = (int64_t)pioran_block_table_doubles(N, R, J);
     hipLaunchKernelGGL(block_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, N, R, J, NB, rowmap, t, c, d, y,
                        s2, btab);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
+// nb tables at once: draw i uses (c, d) + i J and writes btab + i draw_stride (draw_stride >= pioran_block_table_doubles)
+int pioran_launch_block_table_batch(int64_t N, int32_t R, int32_t J, int64_t nb, const int32_t* rowmap, const double* t, const double* C,
+                                    const double* D, const double* y, const double* s2, double* btab, int64_t draw_stride, hipStream_t stream)
+{
+    const int NB = (R + 1 + 15) / 16;
+    const int64_t NW = (N + KW - 1) / KW;
+    if (J < 1 || J > kBlockMaxTerms || NB > 4 || nb < 1 || nb > 65535 || NW > 0x7fffffffLL) return PIORAN_ERR_ARG;
+    hipLaunchKernelGGL(block_table_window_kernel, dim3((unsigned)NW, (unsigned)nb), dim3(256), 0, stream, N, R, J, NB, rowmap, t, C, D, y, s2,
+                       btab, (int64_t)J, draw_stride);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 

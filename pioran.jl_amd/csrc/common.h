@@ -24,6 +24,7 @@ struct ScanOptions {
     bool win2, no_win2;   // throughput layouts: force / forbid the two-step form of the recurrence (celerite_scan.hip)
     int dense_streams = 0;   // pioran_dense_nll_batch: concurrent factorisations (0 = default 16 = the most)
     int gsum = -1;        // throughput layouts, two-step form: row sums with fewer exchange rounds (group_sum's GS); -1 = automatic
+    bool btab_reference;  // windowed kernel: build its table with the entry-per-thread kernel of round 2 (cross-check of the windowed table kernel)
     bool wide2, no_wide2; // latency layout: force / forbid the lean form (celerite_wide2_kernel; default from 48 rows on)
 };
 
@@ -121,7 +122,11 @@ int pioran_launch_block_pd_trig(int64_t N, int64_t B, int32_t J, int32_t npd_ter
 size_t pioran_block_table_doubles(int64_t N, int32_t R, int32_t J);
 int pioran_launch_block_table(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,
                               const double* d, const double* y, const double* s2, double* btab, hipStream_t stream);
-int pioran_launch_scan_block(const ScanParams& p, const double* btab, hipStream_t stream);
+int pioran_launch_scan_block(const ScanParams& p, const double* btab, hipStream_t stream);   // p.tab_draw_stride: doubles between per-draw tables (0: one shared table)
+int pioran_launch_block_table_batch(int64_t N, int32_t R, int32_t J, int64_t nb, const int32_t* rowmap, const double* t, const double* C /*[nb][J]*/,
+                                    const double* D, const double* y, const double* s2, double* btab, int64_t draw_stride, hipStream_t stream);
+int pioran_launch_block_table_reference(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,
+                                        const double* d, const double* y, const double* s2, double* btab, hipStream_t stream);
 // celerite_predict.hip: posterior mean at new times (pred, src/celerite_solver.jl:363-483)
 size_t pioran_predict_workspace_doubles(int64_t B, int64_t N, int32_t R);
 int pioran_launch_predict(ScanParams p, double* work, const double* t, int64_t M, const double* tau, double* mean_out,

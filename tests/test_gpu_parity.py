@@ -150,6 +150,42 @@ def test_random_batches_per_draw_cd(ctx, J, layout):
     got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
     ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
     assert relerr(got, ref) < 1e-11
+    kern = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    if layout == "block":   # small batches, 6 .. 63 rows: every draw its own table of the windowed kernel (round 3)
+        assert kern == ("block (per-draw tables)" if J >= 3 else "scan"), kern
+    else:
+        assert kern in ("scan", "wide"), kern
+    # one draw, or the same (c, d) in every draw, handed over as per-draw arrays: that is the shared case
+    same, st = ds.logl_batch(A, Bc, np.tile(C[:1], (B, 1)), np.tile(Dd[:1], (B, 1)), mu=mu, nu=nu, return_status=True)
+    ref_same = O.logl_batch(A, Bc, C[0], Dd[0], t, y, s2, mu, nu, nthreads=8)
+    assert relerr(same, ref_same) < 1e-11
+    one = ds.logl_batch(A[:1], Bc[:1], C[:1], Dd[:1], mu=mu[:1], nu=nu[:1])
+    assert relerr(one, ref[:1]) < 1e-11
+    if layout == "block":
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == ("block" if J >= 3 else "scan")
+
+
+def test_windowed_table_kernels_agree(ctx):
+    """The windowed kernel's table is built by one workgroup per window (transcendentals once per (term, step) / (term, pair));
+    the entry-per-thread kernel of round 2 is kept as its cross-check: same expressions on the same arguments, so log L comes out
+    bit-identical — shared table, ragged last window, one-row terms, R + 1 = 16 NB exactly."""
+    rng = np.random.default_rng(4242)
+    for J, N, nreal in ((20, 333, 0), (5, 48, 2), (31, 100, 1), (8, 17, 1), (24, 1000, 0)):
+        B = 9
+        t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+        Bc[:, :nreal] = 0.0; Dd[:nreal] = 0.0
+        outs = []
+        for ref_tab in (False, True):
+            try:
+                ctx.set_option("btab_reference", ref_tab)
+                ds = pj.Dataset(t, y, s2, ctx)          # a fresh data set: the table is built on its first small batch
+                outs.append(ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu))
+                assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block"
+                ds.close()
+            finally:
+                ctx.set_option("btab_reference", False)
+        assert np.array_equal(outs[0], outs[1]), (J, N)
+        assert relerr(outs[0], O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)) < 1e-11
 
 
 @pytest.mark.parametrize("J,B", [(40, 5), (44, 5), (47, 300), (40, 300)])
