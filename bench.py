@@ -460,6 +460,33 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
         small[f"{basis}{J}_N{N}_B256"] = {"resident_launch_ms": msb, "evals_per_s": 256 / (msb * 1e-3)}
     out["small_batch_B256"] = small
 
+    # -- small batches with per-draw (c, d): a QPO feature on the approx continuum (src/psd.jl:254-261) and (c, d) per draw in every
+    #    term (free Celerite / CARMA terms, src/CARMA.jl:98-143) — host-pointer entry (PCIe included), 256 draws --------------------
+    nb = 256
+    A0, B0, C0, D0 = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:nb, :3], f_min, f_max, J, theta[:nb, 3], basis_function="SHO")
+    rq = np.random.default_rng(3)
+    qa = np.array([pj.convert_feature(pj.QPO(rq.uniform(0.01, 0.1), np.exp(rq.uniform(np.log(1e-2), 0.0)), rq.uniform(2, 20))) for _ in range(nb)])
+    Aq = np.concatenate([A0, 2 * qa[:, :1]], axis=1); Bq = np.concatenate([B0, 2 * qa[:, 1:2]], axis=1)
+    Cq = np.concatenate([np.broadcast_to(C0, (nb, J)), qa[:, 2:3]], axis=1); Dq = np.concatenate([np.broadcast_to(D0, (nb, J)), qa[:, 3:4]], axis=1)
+    Cp = np.broadcast_to(C0, (nb, J)) * rq.uniform(0.97, 1.03, (nb, J)); Dp = np.broadcast_to(D0, (nb, J)) * rq.uniform(0.97, 1.03, (nb, J))
+    dsm = pj.Dataset(t, y, s2, ctx)
+    pd_small = {}
+    for key, (Ax, Bx, Cx, Dx) in {"qpo_feature": (Aq, Bq, Cq, Dq), "every_term_per_draw": (A0, B0, Cp, Dp)}.items():
+        got, stx = dsm.logl_batch(Ax, Bx, Cx, Dx, mu=mu[:nb], nu=nu[:nb], return_status=True)
+        kern = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+        wall = []
+        for _ in range(5):
+            t0 = time.perf_counter(); dsm.logl_batch(Ax, Bx, Cx, Dx, mu=mu[:nb], nu=nu[:nb]); wall.append(time.perf_counter() - t0)
+        Sx = 16
+        refx, rstx = O.logl_batch(Ax[:Sx], Bx[:Sx], Cx[:Sx], Dx[:Sx], t, y, s2, mu[:Sx].copy(), nu[:Sx].copy(),
+                                  nthreads=min(32, os.cpu_count() or 1), return_status=True)
+        okx = (rstx == 0) & (stx[:Sx] == 0)
+        pd_small[key] = {"ms_per_call_incl_pcie": med(wall) * 1e3, "evals_per_s": nb / med(wall), "kernel": kern,
+                         "max_rel_dlogl_vs_oracle": float((np.abs(got[:Sx][okx] - refx[okx]) / np.abs(refx[okx])).max()) if okx.any() else None,
+                         "oracle_sample": int(okx.sum())}
+    dsm.close()
+    out["small_batch_B256_per_draw_cd"] = pd_small
+
     # -- dense path: configs[4], N = 4096, J = 40 (SHO-40) -------------------------------------------------------------
     Nd, Jd = min(4096, N), 40
     td, yd, ed = t[:Nd], y[:Nd], yerr[:Nd]
