@@ -297,10 +297,13 @@ int block_dispatch(pioran_ds* ds, const ScanParams& p)
     const ScanOptions& o = ctx->opt;
     const char* cfg = o.scan_config[0] ? o.scan_config : nullptr;
     const bool force = cfg && !std::strcmp(cfg, "block");
-    // measured on N = 1e4 (tools/sweep_block.py): faster than both other kernels up to 512 draws from 6 rows on
-    // (round 3, tools/sweep_midbatch.py: from 42 rows on three rounds of 256 workgroups still beat the throughput shapes at 768 draws:
-    //  DRWCelerite-20 7.7 vs 9.2 ms, SHO-23 6.0 vs 7.5 ms; at 40 rows it is a tie, below the throughput shapes win)
-    const bool automatic = !cfg && !o.no_block && (p.B <= 512 || (p.B <= 768 && p.R >= 42)) && p.R >= 6;
+    // measured on N = 1e4 (tools/sweep_block.py, tools/sweep_midbatch.py, tools/sweep_block_emode.py): faster than both other kernels
+    // up to 512 draws from 6 rows on.  Late round 3: with the pair table read from global memory two workgroups share a CU at three
+    // block columns, which moves the crossover up — R = 32 .. 35: 768 draws 4.9 vs 5.4 ms; R = 36 .. 47: 1024 draws 5.3 .. 5.8 vs
+    // 5.7 .. 7.5 ms on the throughput shapes.  With four block columns (48 rows and more) the table stays in LDS and 512 draws is the
+    // limit (DRWCelerite-20 at 768 draws: 7.8 vs 7.1 ms on the throughput shape, which got faster this round).
+    const bool automatic = !cfg && !o.no_block && p.R >= 6 &&
+                           (p.B <= 512 || (p.B <= 768 && p.R >= 32 && p.R <= 47) || (p.B <= 1024 && p.R >= 36 && p.R <= 47));
     if (!(force || automatic) || !p.tab || p.npd_rows != 0 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
     PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
     if (!s || !s->prepared || s->npd_terms != 0 || p.rec_stride != 3 * (int64_t)(s->R + 2) + 2) return PIORAN_ERR_UNSUPPORTED;
@@ -377,6 +380,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "win3")) o.win3 = on;
     else if (!std::strcmp(key, "no_win3")) o.no_win3 = on;
     else if (!std::strcmp(key, "btab_reference")) o.btab_reference = on;
+    else if (!std::strcmp(key, "block_emode")) o.block_emode = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "dense_streams")) o.dense_streams = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "gsum")) o.gsum = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "wide2")) o.wide2 = on;
@@ -777,7 +781,7 @@ static int mixed_core(pioran_ds* ds, int64_t B, int64_t J, const std::vector<int
         const ScanOptions& o = ctx->opt;
         const char* cfg = o.scan_config[0] ? o.scan_config : nullptr;
         const bool force = cfg && !std::strcmp(cfg, "block");
-        const bool automatic = !cfg && !o.no_block && (B <= 512 || (B <= 768 && rows >= 42)) && rows >= 6;
+        const bool automatic = !cfg && !o.no_block && B <= 512 && rows >= 6;
         blk_ok = (force || automatic) && !o.force_fallback && npd >= 1 && pioran_block_fits_pd((int32_t)rows, (int32_t)J, (int32_t)npd);
     }
     if (npd == 0 || npd > 8 || (!must_run && !blk_ok && npd * 2 > J)) return 0;

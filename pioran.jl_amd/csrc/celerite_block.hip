@@ -383,9 +383,13 @@ __device__ __forceinline__ void dma_pieces(const double* gsrc, double* ldst, int
 // With four block columns (always a single E buffer) the workgroup is filled up to eight wavefronts with COPY wavefronts that do
 // nothing but issue the LDS DMA of record k + 2 between the barriers (a piece costs its issuer ~150 cycles, ~100 pieces per window: too
 // much for the computing wavefronts' slack).
-template <int NB, bool EDBL, bool PD = false>
+// EM (E mode): 0 = one LDS buffer for the pair table E, 1 = two (EDBL above), 2 = none — form_A reads E of the next window straight
+// from global memory (L2: every workgroup of the launch reads the same 256 J doubles at about the same time), which takes 41 KB
+// (J = 20) out of the workgroup's LDS and two thirds out of its LDS DMA: two workgroups then share a CU (round 3; batches above 256 draws).
+template <int NB, int EM, bool PD = false>
 __global__ void __launch_bounds__(NB < 4 ? (PD ? 320 : 256) : 512, (NB < 4 && !PD) ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
 {
+    constexpr bool EDBL = EM == 1, EGLOB = EM == 2;
     constexpr int NCW = NB < 4 ? 4 : 5;     // computing wavefronts: owners + chain
     constexpr bool COPYW = NB == 4;         // copy wavefronts (these shapes fill a CU's LDS with one workgroup anyway)
     // per-draw rows, up to three block columns: one more wavefront forms their record entries (a whole window of time for ~4 exponentials
@@ -406,10 +410,11 @@ __global__ void __launch_bounds__(NB < 4 ? (PD ? 320 : 256) : 512, (NB < 4 && !P
     const int64_t RSB = TSP + 256 * (int64_t)J;
     btab += b * p.tab_draw_stride;                   // per-draw tables (every term's (c, d) per draw): 0 for the shared table
     double* const tileb = lds_;
-    double* const Eb = lds_ + 2 * TSP;               // E(k) lives in Eb + (EDBL ? (k & 1) * 256 J : 0)
+    double* const Eb = lds_ + 2 * TSP;               // E(k) lives in Eb + (EDBL ? (k & 1) * 256 J : 0)   (EGLOB: not in LDS)
     const int ebs = EDBL ? 256 * J : 0;
+    const int e_lds = EGLOB ? 0 : (EDBL ? 2 : 1) * 256 * J;   // doubles of LDS the pair table takes
     using BlockShared = BlockSharedT<NB>;
-    BlockShared& sh = *reinterpret_cast<BlockShared*>(lds_ + 2 * TSP + (EDBL ? 2 : 1) * 256 * J);
+    BlockShared& sh = *reinterpret_cast<BlockShared*>(lds_ + 2 * TSP + e_lds);
     [[maybe_unused]] BlockPd& pd = *reinterpret_cast<BlockPd*>(reinterpret_cast<char*>(&sh) + sizeof(BlockShared));   // (allocated only for PD launches)
     [[maybe_unused]] double2* const pdE = reinterpret_cast<double2*>(reinterpret_cast<char*>(&pd) + sizeof(BlockPd));
     [[maybe_unused]] const int npd = PD ? p.npd_rows / 2 : 0, npdr = PD ? p.npd_rows : 0;
@@ -429,7 +434,7 @@ __global__ void __launch_bounds__(NB < 4 ? (PD ? 320 : 256) : 512, (NB < 4 && !P
     for (int j = 0; j < J; ++j) suma += Ab_[j];
 
     dma_pieces(btab, tileb, TSP / 128, w, NWV, lane);
-    dma_pieces(btab + TSP, Eb, 2 * J, w, NWV, lane);
+    if constexpr (!EGLOB) dma_pieces(btab + TSP, Eb, 2 * J, w, NWV, lane);
     if (tid < J) sh.ab[tid] = double2{Ab_[tid], Bb_[tid]};
 
     // u = al v + be x per row (:59-63)
@@ -592,10 +597,11 @@ __global__ void __launch_bounds__(NB < 4 ? (PD ? 320 : 256) : 512, (NB < 4 && !P
         if (w < (SPLIT4 ? 4 : 3)) {
             double* Ad = sh.Ab[k & 1][tpar];
             if (pp < 120) {
-                const double2* E = reinterpret_cast<const double2*>(Eb + (k & 1) * ebs) + pp;
+                const double2* E = EGLOB ? reinterpret_cast<const double2*>(btab + k * RSB + TSP) + pp
+                                         : reinterpret_cast<const double2*>(Eb + (k & 1) * ebs) + pp;
                 double acc0 = 0.0, acc1 = 0.0;
                 int t = tpar;
-                constexpr int UN = 10;   // LDS reads in flight per chunk (two chunks at J = 20)
+                constexpr int UN = 10;   // reads in flight per chunk (two chunks at J = 20)
                 for (; t + (UN - 1) * tstep < J; t += UN * tstep) {
                     double2 e[UN], cf[UN];
 #pragma unroll
@@ -603,10 +609,26 @@ __global__ void __launch_bounds__(NB < 4 ? (PD ? 320 : 256) : 512, (NB < 4 && !P
 #pragma unroll
                     for (int i = 0; i < UN; ++i) { acc0 = fma(cf[i].x, e[i].x, acc0); acc1 = fma(cf[i].y, e[i].y, acc1); }
                 }
-                for (; t < J; t += tstep) {
-                    const double2 e = E[t * 128], cf = sh.ab[t];
-                    acc0 = fma(cf.x, e.x, acc0);
-                    acc1 = fma(cf.y, e.y, acc1);
+                if constexpr (EGLOB) {
+                    // the remainder in ONE batch as well: from global memory every dependent read is a round trip of its own
+                    // (J = 16: six of them made 512 draws take 3.2 instead of 2.6 ms)
+                    if (t < J) {
+                        double2 e[UN], cf[UN];
+#pragma unroll
+                        for (int i = 0; i < UN; ++i) {
+                            const int ti = t + i * tstep;
+                            e[i] = E[(ti < J ? ti : t) * 128];
+                            cf[i] = ti < J ? sh.ab[ti] : double2{0.0, 0.0};
+                        }
+#pragma unroll
+                        for (int i = 0; i < UN; ++i) { acc0 = fma(cf[i].x, e[i].x, acc0); acc1 = fma(cf[i].y, e[i].y, acc1); }
+                    }
+                } else {
+                    for (; t < J; t += tstep) {
+                        const double2 e = E[t * 128], cf = sh.ab[t];
+                        acc0 = fma(cf.x, e.x, acc0);
+                        acc1 = fma(cf.y, e.y, acc1);
+                    }
                 }
                 if constexpr (PD) {
                     if (tpar == 0)
@@ -681,7 +703,7 @@ __global__ void __launch_bounds__(NB < 4 ? (PD ? 320 : 256) : 512, (NB < 4 && !P
     PIORAN_BLK_BARRIER();              // every wavefront is done with E(0)
     if (NW > 1) {
         dma_pieces(btab + RSB, tileb + TSP, TSP / 128, w, NWV, lane);
-        dma_pieces(btab + RSB + TSP, Eb + ebs, 2 * J, w, NWV, lane);
+        if constexpr (!EGLOB) dma_pieces(btab + RSB + TSP, Eb + ebs, 2 * J, w, NWV, lane);
     }
 
     PIORAN_BSTAMP_DECL
@@ -784,14 +806,14 @@ __global__ void __launch_bounds__(NB < 4 ? (PD ? 320 : 256) : 512, (NB < 4 && !P
         // record k + 2: tile k (buffer k & 1) has no reader left since barrier 1.  One E buffer: the E pieces a wavefront refills
         // are the ones only it reads (piece 2 t + h = term t, pairs 64 h .. 64 h + 63), just consumed by its own form_A above.
         // Two E buffers: the target held E(k), last read before barrier 2 of window k - 1.
-        const int np_tile = TSP / 128, np_all = np_tile + 2 * J, np_chain = np_all / 4;
+        const int np_tile = TSP / 128, np_all = np_tile + (EGLOB ? 0 : 2 * J), np_chain = np_all / 4;
         auto copy_piece = [&](int c) __attribute__((always_inline)) {
             const double* src = btab + (k + 2) * RSB + c * 128 + lane * 2;
             double* dst = c < np_tile ? tileb + (k & 1) * TSP + c * 128 : Eb + (k & 1) * ebs + (c - np_tile) * 128;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         };
         if (k + 2 < NW && !chain) {
-            if constexpr (EDBL) {
+            if constexpr (EDBL || EGLOB) {
                 // contiguous shares; wavefronts 0 and 1 carry the pair contraction, the others take twice as much
                 const int rest = np_all - np_chain, unit = rest / (NWV == 4 ? 4 : 6);
                 const int lo = np_chain + (w == 0 ? 0 : w == 1 ? unit : w == 2 ? 2 * unit : 4 * unit);
@@ -809,7 +831,7 @@ __global__ void __launch_bounds__(NB < 4 ? (PD ? 320 : 256) : 512, (NB < 4 && !P
         // the chain wavefront idles until the next barrier 1: its share of record k + 2 (issued right away: the copies then have
         // the whole Y^ / update / M' stretch to land; issued after its own LDS reads below they land too late for barrier 1)
         if (chain && k + 2 < NW) {
-            for (int c = 0; c < (EDBL ? np_chain : (COPYW ? nt_chain : np_tile)); ++c) copy_piece(c);
+            for (int c = 0; c < ((EDBL || EGLOB) ? np_chain : (COPYW ? nt_chain : np_tile)); ++c) copy_piece(c);
         }
         if constexpr (PD && !HELPW) {
             // per-draw rows of record k + 2 (its staging landed before barrier 1 of this window; buffer k & 1 held window k's values,
@@ -903,43 +925,51 @@ __global__ void __launch_bounds__(NB < 4 ? (PD ? 320 : 256) : 512, (NB < 4 && !P
 }
 
 constexpr size_t kBlockLdsMax = 160 * 1024;
-__host__ inline size_t block_lds_bytes(int NB, int J, bool edbl, int npd = 0 /*per-draw terms*/)
+__host__ inline size_t block_lds_bytes(int NB, int J, int emode /*E buffers in LDS: 0 one, 1 two, 2 none*/, int npd = 0 /*per-draw terms*/)
 {
     const size_t shared = NB == 1 ? sizeof(BlockSharedT<1>) : NB == 2 ? sizeof(BlockSharedT<2>) : NB == 3 ? sizeof(BlockSharedT<3>) : sizeof(BlockSharedT<4>);
-    return (size_t)(2 * block_tile_doubles(NB) + (edbl ? 2 : 1) * 256 * J) * sizeof(double) + shared +
+    return (size_t)(2 * block_tile_doubles(NB) + (emode == 2 ? 0 : emode == 1 ? 2 : 1) * 256 * J) * sizeof(double) + shared +
            (npd > 0 ? sizeof(BlockPd) + (size_t)2 * npd * 128 * sizeof(double2) : 0);
 }
 
-template <int NB, bool EDBL, bool PD = false>
+template <int NB, int EM, bool PD = false>
 int launch_block2(const ScanParams& p, const double* btab, hipStream_t stream)
 {
-    const size_t lds = block_lds_bytes(NB, p.J, EDBL, PD ? p.npd_rows / 2 : 0);
+    const size_t lds = block_lds_bytes(NB, p.J, EM, PD ? p.npd_rows / 2 : 0);
     // the attribute belongs to (function, device): one process may drive several devices (pioran_farm_*).  Racing threads at
     // worst set it twice.
     static size_t granted[64] = {};   // per template instance
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
     if (lds > granted[dev]) {
-        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, EDBL, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, EM, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PIORAN_ERR_HIP;
         granted[dev] = lds;
     }
-    hipLaunchKernelGGL((celerite_block_kernel<NB, EDBL, PD>), dim3((unsigned)p.B), dim3(NB < 4 ? (PD ? 320 : 256) : 512), lds, stream, p, btab);
+    hipLaunchKernelGGL((celerite_block_kernel<NB, EM, PD>), dim3((unsigned)p.B), dim3(NB < 4 ? (PD ? 320 : 256) : 512), lds, stream, p, btab);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
 template <int NB>
 int launch_block(const ScanParams& p, const double* btab, hipStream_t stream)
 {
-    // two E buffers only while one workgroup per CU is all there is to run: above 256 draws the smaller footprint lets several
-    // workgroups share a CU, which is worth more (tools/sweep_block.py)
+    // Where the pair table E lives (tools/sweep_block_emode.py, N = 1e4, late round 3): one LDS buffer is as fast as two or faster at
+    // every size measured (SHO-20, 256 draws: 1.92 vs 2.10 ms — the second buffer was worth its LDS in round 2, before the shared block
+    // shrank), so two buffers are an option only; above 256 draws what counts is whether TWO workgroups fit a CU — if they do not with E
+    // in LDS but do without, E is read from global memory (SHO-20, 512 draws: 2.68 instead of 3.75 ms).
     if (p.npd_rows > 0) {   // per-draw rows
-        if (p.B <= 256 && block_lds_bytes(NB, p.J, true, p.npd_rows / 2) <= kBlockLdsMax) return launch_block2<NB, true, true>(p, btab, stream);
-        if (block_lds_bytes(NB, p.J, false, p.npd_rows / 2) <= kBlockLdsMax) return launch_block2<NB, false, true>(p, btab, stream);
+        if (p.B <= 256 && block_lds_bytes(NB, p.J, 1, p.npd_rows / 2) <= kBlockLdsMax) return launch_block2<NB, 1, true>(p, btab, stream);
+        if (block_lds_bytes(NB, p.J, 0, p.npd_rows / 2) <= kBlockLdsMax) return launch_block2<NB, 0, true>(p, btab, stream);
         return PIORAN_ERR_UNSUPPORTED;
     }
-    if (p.B <= 256 && block_lds_bytes(NB, p.J, true) <= kBlockLdsMax) return launch_block2<NB, true>(p, btab, stream);
-    if (block_lds_bytes(NB, p.J, false) <= kBlockLdsMax) return launch_block2<NB, false>(p, btab, stream);
+    const int em = p.opt ? p.opt->block_emode : -1;   // diagnostics: force an E mode
+    if (em == 2 && NB < 4) return launch_block2<NB < 4 ? NB : 1, 2>(p, btab, stream);
+    if (em == 1 && block_lds_bytes(NB, p.J, 1) <= kBlockLdsMax) return launch_block2<NB, 1>(p, btab, stream);
+    if constexpr (NB < 4) {
+        if (em < 0 && p.B > 256 && 2 * block_lds_bytes(NB, p.J, 0) > kBlockLdsMax && 2 * block_lds_bytes(NB, p.J, 2) <= kBlockLdsMax)
+            return launch_block2<NB, 2>(p, btab, stream);
+    }
+    if (block_lds_bytes(NB, p.J, 0) <= kBlockLdsMax) return launch_block2<NB, 0>(p, btab, stream);
     return PIORAN_ERR_UNSUPPORTED;
 }
 
@@ -958,7 +988,7 @@ int pioran_block_fits(int32_t R, int32_t J)
 {
     const int NB = (R + 1 + 15) / 16;
     if (R < 1 || NB > 4 || J < 1 || J > kBlockMaxTerms) return 0;
-    return block_lds_bytes(NB, J, false) <= kBlockLdsMax;
+    return block_lds_bytes(NB, J, 0) <= kBlockLdsMax;
 }
 
 // ... with `npd_terms` per-draw terms (their rows last)
@@ -966,7 +996,7 @@ int pioran_block_fits_pd(int32_t R, int32_t J, int32_t npd_terms)
 {
     const int NB = (R + 1 + 15) / 16;
     if (R < 1 || NB > 4 || J < 1 || J > kBlockMaxTerms || npd_terms < 1 || npd_terms > kBlockMaxPdTerms || R < 2 * npd_terms) return 0;
-    return block_lds_bytes(NB, J, false, npd_terms) <= kBlockLdsMax;
+    return block_lds_bytes(NB, J, 0, npd_terms) <= kBlockLdsMax;
 }
 
 namespace {

@@ -24,6 +24,7 @@ struct ScanOptions {
     bool win2, no_win2;   // throughput layouts: force / forbid the two-step form of the recurrence (celerite_scan.hip)
     int dense_streams = 0;   // pioran_dense_nll_batch: concurrent factorisations (0 = default 16 = the most)
     int gsum = -1;        // throughput layouts, two-step form: row sums with fewer exchange rounds (group_sum's GS); -1 = automatic
+    int block_emode = -1; // windowed kernel, diagnostics: where the pair table E lives (0 one LDS buffer, 1 two, 2 global memory); -1 automatic
     bool btab_reference;  // windowed kernel: build its table with the entry-per-thread kernel of round 2 (cross-check of the windowed table kernel)
     bool wide2, no_wide2; // latency layout: force / forbid the lean form (celerite_wide2_kernel; default from 48 rows on)
 };

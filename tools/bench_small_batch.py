@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small-batch latency of the celerite scan (BASELINE config 2 and the MCMC-walker regime): ms per call of the
-HBM-resident batch entry for B = 1 .. 1024 at N = 1e4, default layout choice vs PIORAN_NO_WIDE=1 (throughput layouts
-only), plus the scalar drop-in `logl`.  Optional: PIORAN_SCAN_CONFIG to pin one configuration."""
+HBM-resident batch entry for B = 1 .. 1024 at N = 1e4: the default choice (windowed kernel up to 512 .. 1024 draws), the latency
+layout (option "no_block") and the throughput layouts ("no_block" + "no_wide"), plus the scalar drop-in `logl`."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,15 +41,16 @@ def run(B, reps=5):
     return float(np.median(ts)) * 1e3, err
 
 res = {"workload": f"N={N}, {basis}-{J}, shared (c,d) table, HBM-resident inputs", "ms_per_call": {}}
-for mode in ("default", "throughput_only"):
-    ctx.set_option("no_wide", mode == "throughput_only")
+for mode in ("default", "latency_layout", "throughput_layouts"):
+    ctx.set_option("no_block", mode != "default")
+    ctx.set_option("no_wide", mode == "throughput_layouts")
     row = {}
     for B in (1, 4, 16, 64, 128, 256, 512, 1024):
         ms, err = run(B)
         row[str(B)] = round(ms, 3)
         assert err < 1e-8, (mode, B, err)
     res["ms_per_call"][mode] = row
-    ctx.set_option("no_wide", False)
+    ctx.set_option("no_wide", False); ctx.set_option("no_block", False)
 R = pj.approx(pj.SingleBendingPowerLaw(0.82, 0.01, 3.3), f_min, f_max, J, 1.0, basis_function=basis)
 for n in (10_000, 1000):
     pj.logl(R.a, R.b, R.c, R.d, t[:n], y[:n], yerr[:n] ** 2, ctx=ctx)
