@@ -386,16 +386,21 @@ __device__ __forceinline__ void dma_pieces(const double* gsrc, double* ldst, int
 // EM (E mode): 0 = one LDS buffer for the pair table E, 1 = two (EDBL above), 2 = none — form_A reads E of the next window straight
 // from global memory (L2: every workgroup of the launch reads the same 256 J doubles at about the same time), which takes 41 KB
 // (J = 20) out of the workgroup's LDS and two thirds out of its LDS DMA: two workgroups then share a CU (round 3; batches above 256 draws).
-template <int NB, int EM, bool PD = false>
-__global__ void __launch_bounds__(NB < 4 ? (PD ? 320 : 256) : 512, (NB < 4 && !PD) ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
+// PDM (per-draw rows): 0 none; 1 a helper wavefront prepares them (up to three block columns: five wavefronts, one workgroup per CU);
+// 2 the chain wavefront does, in its idle stretch (four block columns; and above 256 draws, where two workgroups of FOUR wavefronts
+// share a CU — with EM = 2 — and that is worth more than the helper)
+template <int NB, int EM, int PDM = 0>
+__global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4 && PDM != 1) ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
 {
+    constexpr bool PD = PDM != 0;
     constexpr bool EDBL = EM == 1, EGLOB = EM == 2;
     constexpr int NCW = NB < 4 ? 4 : 5;     // computing wavefronts: owners + chain
     constexpr bool COPYW = NB == 4;         // copy wavefronts (these shapes fill a CU's LDS with one workgroup anyway)
     // per-draw rows, up to three block columns: one more wavefront forms their record entries (a whole window of time for ~4 exponentials
     // per lane: never on the critical path; on the chain wavefront the same work delayed barrier 1 of every window — 5.1 instead of
     // 3.3 us per window).  With four block columns the chain wavefront does it (the workgroup is full: copy wavefronts).
-    constexpr bool HELPW = PD && NB < 4;
+    constexpr bool HELPW = PDM == 1;
+    static_assert(PDM != 1 || NB < 4, "the helper wavefront exists up to three block columns");
     constexpr int NWV = COPYW ? 8 : NCW + (HELPW ? 1 : 0);    // wavefronts per workgroup
     constexpr int CH = NCW - 1;             // the chain wavefront
     constexpr int TS = 3 * NB * 256 + 16 * NB + 16, TSP = (TS + 127) & ~127;
@@ -932,21 +937,21 @@ __host__ inline size_t block_lds_bytes(int NB, int J, int emode /*E buffers in L
            (npd > 0 ? sizeof(BlockPd) + (size_t)2 * npd * 128 * sizeof(double2) : 0);
 }
 
-template <int NB, int EM, bool PD = false>
+template <int NB, int EM, int PDM = 0>
 int launch_block2(const ScanParams& p, const double* btab, hipStream_t stream)
 {
-    const size_t lds = block_lds_bytes(NB, p.J, EM, PD ? p.npd_rows / 2 : 0);
+    const size_t lds = block_lds_bytes(NB, p.J, EM, PDM ? p.npd_rows / 2 : 0);
     // the attribute belongs to (function, device): one process may drive several devices (pioran_farm_*).  Racing threads at
     // worst set it twice.
     static size_t granted[64] = {};   // per template instance
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
     if (lds > granted[dev]) {
-        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, EM, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, EM, PDM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PIORAN_ERR_HIP;
         granted[dev] = lds;
     }
-    hipLaunchKernelGGL((celerite_block_kernel<NB, EM, PD>), dim3((unsigned)p.B), dim3(NB < 4 ? (PD ? 320 : 256) : 512), lds, stream, p, btab);
+    hipLaunchKernelGGL((celerite_block_kernel<NB, EM, PDM>), dim3((unsigned)p.B), dim3(NB < 4 ? (PDM == 1 ? 320 : 256) : 512), lds, stream, p, btab);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
@@ -958,8 +963,16 @@ int launch_block(const ScanParams& p, const double* btab, hipStream_t stream)
     // shrank), so two buffers are an option only; above 256 draws what counts is whether TWO workgroups fit a CU — if they do not with E
     // in LDS but do without, E is read from global memory (SHO-20, 512 draws: 2.68 instead of 3.75 ms).
     if (p.npd_rows > 0) {   // per-draw rows
-        if (p.B <= 256 && block_lds_bytes(NB, p.J, 1, p.npd_rows / 2) <= kBlockLdsMax) return launch_block2<NB, 1, true>(p, btab, stream);
-        if (block_lds_bytes(NB, p.J, 0, p.npd_rows / 2) <= kBlockLdsMax) return launch_block2<NB, 0, true>(p, btab, stream);
+        constexpr int PDH = NB < 4 ? 1 : 2;   // helper wavefront where the workgroup has room for one
+        const int npd = p.npd_rows / 2;
+        if constexpr (NB < 4) {
+            // above 256 draws: two workgroups of four wavefronts per CU (the chain wavefront prepares the per-draw rows, the shared
+            // terms' pair table comes from global memory) instead of one of five
+            const int pm = p.opt ? p.opt->block_emode : -1;
+            if ((pm == 2 || (pm < 0 && p.B > 256)) && 2 * block_lds_bytes(NB, p.J, 2, npd) <= kBlockLdsMax) return launch_block2<NB, 2, 2>(p, btab, stream);
+        }
+        if (p.B <= 256 && block_lds_bytes(NB, p.J, 1, npd) <= kBlockLdsMax) return launch_block2<NB, 1, PDH>(p, btab, stream);
+        if (block_lds_bytes(NB, p.J, 0, npd) <= kBlockLdsMax) return launch_block2<NB, 0, PDH>(p, btab, stream);
         return PIORAN_ERR_UNSUPPORTED;
     }
     const int em = p.opt ? p.opt->block_emode : -1;   // diagnostics: force an E mode
