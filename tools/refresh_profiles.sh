@@ -14,11 +14,14 @@ run gradient_sho20.json python3 tools/bench_grad.py
 BASIS=DRWCelerite run gradient_drw20.json python3 tools/bench_grad.py
 run qpo_mixed_b4096.json python3 tools/bench_qpo.py
 run qpo_small_batches.txt python3 tools/bench_qpo_small.py
+run per_draw_small_batches.json python3 tools/bench_per_draw_small.py
+run sweep_block_emode.txt python3 tools/sweep_block_emode.py
 run shift_transform_b4096.json python3 tools/bench_shift.py
 run small_batch_latency_sho20.json python3 tools/bench_small_batch.py
 BASIS=DRWCelerite run small_batch_latency_drw20.json python3 tools/bench_small_batch.py
 run host_api_pcie_inclusive.json python3 tools/bench_host_api.py
 run dense_n4096_j40.json python3 tools/bench_dense.py
 run bench_default_full_line.json python3 bench.py
+timeout -k 10 900 python3 tools/bench_grid.py > "$X/grid.json" 2> "$X/grid.json.err" || echo "grid failed" >&2
 ROUND=$ROUND "$ROOT/tools/run_profiles.sh" > "$X/run_profiles.log" 2>&1
 tail -5 "$X/run_profiles.log"
