@@ -389,10 +389,16 @@ __device__ __forceinline__ void dma_pieces(const double* gsrc, double* ldst, int
 // PDM (per-draw rows): 0 none; 1 a helper wavefront prepares them (up to three block columns: five wavefronts, one workgroup per CU);
 // 2 the chain wavefront does, in its idle stretch (four block columns; and above 256 draws, where two workgroups of FOUR wavefronts
 // share a CU — with EM = 2 — and that is worth more than the helper)
-template <int NB, int EM, int PDM = 0>
-__global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4 && PDM != 1) ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
+// ST (gradient, round 3): the forward pass of the windowed reverse mode — per window it leaves in p.gw what the reverse pass
+// (celerite_block_adjoint_kernel) needs: the state T at the window start, M', Q' = Sigma^-1 X' (both in C/D order and, Q, in A-operand
+// order) and K = Sigma^-1 (block_grad_ws_doubles gives the layout).  The value it returns is bit-identical to the plain kernel's.
+__host__ __device__ inline int64_t block_grad_ws_doubles(int NB) { return (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256; }
+template <int NB, int EM, int PDM = 0, bool ST = false>
+__global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4 && PDM != 1 && !ST) ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
 {
     constexpr bool PD = PDM != 0;
+    [[maybe_unused]] constexpr int64_t GWS = (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256;
+    [[maybe_unused]] constexpr int OFF_M = NB * NB * 256, OFF_Q = OFF_M + NB * 256, OFF_QF = OFF_Q + NB * 256, OFF_K = OFF_QF + NB * 256;
     constexpr bool EDBL = EM == 1, EGLOB = EM == 2;
     constexpr int NCW = NB < 4 ? 4 : 5;     // computing wavefronts: owners + chain
     constexpr bool COPYW = NB == 4;         // copy wavefronts (these shapes fill a CU's LDS with one workgroup anyway)
@@ -722,6 +728,15 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
             for (int I = 0; I < NB; ++I)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[I][ks], T[I][ks], acc, 0, 0, 0);
+            if constexpr (ST) {
+                double* gwk = p.gw + (b * NW + k) * GWS;
+#pragma unroll
+                for (int I = 0; I < NB; ++I)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gwk[((w * NB + I) * 4 + g) * 64 + lane] = T[I][g];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gwk[OFF_M + (w * 4 + g) * 64 + lane] = acc[g];
+            }
             double* mg = sh.MG[w];
 #pragma unroll
             for (int g = 0; g < 4; ++g) mg[(4 * g + q) * 18 + c16] = acc[g];
@@ -879,6 +894,41 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
                 ysc[g] = yt[g] * idv[g];
                 if (w == Jy) quad = fma(yt[g], ysc[g], quad);     // z_n^2 / D_n (== y'K^-1 y, :333)
             }
+            if constexpr (ST) {
+                // Q' = L^-T D^-1 Y^' = Sigma^-1 X' (steps x rows of this block); A operand (m = c16, k = kk): (L^-1)[kk][m] / D_kk
+                const double idm = recip_f64(sh.Li[c16 * 18 + c16]);
+                d4 qv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int kk = 4 * ks + q;
+                    const double lt = (kk > c16 ? sh.Li[c16 * 18 + kk] * idm : (kk == c16 ? 1.0 : 0.0)) * idv[ks];
+                    qv = __builtin_amdgcn_mfma_f64_16x16x4f64(lt, yt[ks], qv, 0, 0, 0);
+                }
+                double* gwk = p.gw + (b * NW + k) * GWS;
+                double* mg = sh.MG[w];                    // (its Gram partial was consumed before barrier 2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { gwk[OFF_Q + (w * 4 + g) * 64 + lane] = qv[g]; mg[(4 * g + q) * 18 + c16] = qv[g]; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) gwk[OFF_QF + (w * 4 + ks) * 64 + lane] = mg[c16 * 18 + 4 * ks + q];   // Q [row 16 w + 4 ks + q][step c16]
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        if constexpr (ST) {
+            if (chain) {   // K = Sigma^-1 = L^-T D^-1 L^-1: both operands are the same per-lane expression (A: (m, k) = (c16, kk); B: (k, n) = (kk, c16))
+                const double idm = recip_f64(sh.Li[c16 * 18 + c16]);
+                d4 kv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int kk = 4 * ks + q;
+                    const double lb = kk > c16 ? sh.Li[c16 * 18 + kk] * idm : (kk == c16 ? 1.0 : 0.0);
+                    const double la = lb * recip_f64(sh.Li[kk * 18 + kk]);
+                    kv = __builtin_amdgcn_mfma_f64_16x16x4f64(la, lb, kv, 0, 0, 0);
+                }
+                double* gwk = p.gw + (b * NW + k) * GWS;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gwk[OFF_K + g * 64 + lane] = kv[g];
+            }
         }
         PIORAN_BSTAMP(9);
         PIORAN_BLK_BARRIER();   // B3: Y^' published
@@ -927,6 +977,323 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
         p.out[b] = res;
         if (p.status) p.status[b] = !isfinite(res) ? 2 : (nonpd ? 1 : 0);
     }
+}
+
+
+// ---- windowed reverse mode (round 3) --------------------------------------------------------------------------------------
+// Gradient of log L with respect to (a_j, b_j, mu, nu) through the windowed form, one window of 16 steps at a time, walking the
+// windows backwards.  With K = Sigma^-1, Q' = K X' (both left by the forward pass, ST above) the window's adjoint needs no adjoint
+// of the LDL' factorisation (tools/block_adjoint_proto.py is the numpy prototype, checked against the complex-step oracle):
+//   T' = (cK cK') o T + X K X',  l_k = -1/2 log det Sigma - 1/2 x_y' K x_y             (forward, steps x rows written with a prime)
+//   X-' = 2 Q' T-  (- Q'[:, y] in the y column);     S- = -1/2 K - Q' T- Q + 1/2 q_y q_y'
+//   M-' = -cK o X-' - S- U~';      U~-' = -S- M' + M-' T;      T- <- (cK cK') o T- + 1/2 (U~ M-' + M- U~')
+//   d/dal_r += sum_n U~-'[n][r] (C v)[n][r], d/dbe_r likewise with x;  d/dmu -= sum_n X-'[n][y];  d/dsum(a) += tr S-;
+//   d/dnu += sum_n S-_nn sigma2_n;  d/da_t += 2 sum_pairs S-_jn E_t,p.cos,  d/db_t += 2 sum_pairs S-_jn E_t,p.sin
+// One workgroup per draw; wavefront w < NB owns block column w of T- (same register layout as T in the forward kernel), one more
+// wavefront assembles S-.  Six GEMM stages per window (60 MFMAs per owner at three block columns against the forward's 32), no
+// factorisation: the reverse window is owner-bound.
+// Table of the reverse pass (block_gtable_window_kernel), per window: C o v and C o x in C/D order ([block][g][lane]: step 4 g + (lane >> 4),
+// row 16 block + (lane & 15)), then C_K [16 NB], sigma2 [16].
+__host__ __device__ inline int64_t block_gtab_doubles(int NB) { return 2 * (int64_t)NB * 256 + 16 * NB + 16; }
+
+__global__ void __launch_bounds__(256) block_gtable_window_kernel(int64_t N, int32_t R, int32_t J, int32_t NB, const int32_t* __restrict__ rowmap,
+                                                                  const double* __restrict__ t, const double* __restrict__ c,
+                                                                  const double* __restrict__ d, const double* __restrict__ s2, double* __restrict__ tab)
+{
+    __shared__ double cs[64 * 16], sn[64 * 16], Cn[64 * 16], ckt[64];
+    const int64_t GS = block_gtab_doubles(NB);
+    const int64_t k = blockIdx.x;
+    const int64_t n0 = k * KW;
+    const int64_t nlast = n0 + KW - 1 < N ? n0 + KW - 1 : N - 1;
+    const double tb = k > 0 ? t[n0 - 1] : t[0];
+    const double te = t[nlast];
+    for (int it = threadIdx.x; it < J * 16; it += 256) {
+        const int term = it >> 4, s = it & 15;
+        const int64_t n = n0 + s;
+        double si = 0.0, co = 0.0, cn = 0.0;
+        if (n < N) {
+            const double tn = t[n];
+            sincos(d[term] * tn, &si, &co);
+            cn = exp(-c[term] * (tn - tb));
+        }
+        cs[it] = co; sn[it] = si; Cn[it] = cn;
+        if (s == 0) ckt[term] = exp(-c[term] * (te - tb));
+    }
+    __syncthreads();
+    const int64_t nfrag = (int64_t)NB * 256;
+    double* rec = tab + k * GS;
+    for (int64_t e0 = threadIdx.x; e0 < GS; e0 += 256) {
+        int64_t e = e0;
+        double val = 0.0;
+        if (e < 2 * nfrag) {
+            const int sec = (int)(e / nfrag);
+            const int f = (int)(e - sec * nfrag);
+            const int blk = f >> 8, reg = (f >> 6) & 3, lane = f & 63;
+            const int s = 4 * reg + (lane >> 4), row = 16 * blk + (lane & 15);
+            if (n0 + s < N && row < R) {
+                const int32_t rm = rowmap[row];
+                const int it = (rm & 0xfffff) * 16 + s;
+                const bool ks = (rm >> 30) & 1;
+                val = ((sec == 0) == ks ? sn[it] : cs[it]) * Cn[it];   // sec 0: C o v, sec 1: C o x
+            }
+        } else if ((e -= 2 * nfrag) < 16 * NB) {
+            const int row = (int)e;
+            if (row < R) val = ckt[rowmap[row] & 0xfffff];
+            else if (row == R) val = 1.0;
+        } else {
+            e -= 16 * NB;
+            val = n0 + e < N ? s2[n0 + e] : 0.0;
+        }
+        rec[e0] = val;
+    }
+}
+
+template <int NB>
+struct BlockAdjShared {
+    double tileU[2][NB][288];   // U~' of window parity: [block][step * 18 + row]
+    double tileM[2][NB][288];   // M-'
+    double scr[NB][288];        // per owner: transposing scratch
+    double P[NB][256];          // partial Q' T- Q of each owner, C/D fragments [g][lane]
+    double Srm[256];            // S- row-major
+    double qy[16];
+    double2 albe[64];
+    double ra[64], rb[64];      // per-term reductions
+    double rs[8];
+    unsigned char pn[120], pj[120];
+};
+
+template <int NB>
+__global__ void __launch_bounds__(NB < 4 ? 256 : 320, 1) celerite_block_adjoint_kernel(const ScanParams p, const double* __restrict__ btab,
+                                                                                      const double* __restrict__ gtab, double* __restrict__ grad_a,
+                                                                                      double* __restrict__ grad_b, double* __restrict__ grad_nu,
+                                                                                      double* __restrict__ grad_mu)
+{
+    constexpr int NCW = NB < 4 ? 4 : 5, CH = NCW - 1, NT = NCW * 64;
+    constexpr int64_t GWS = (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256;
+    constexpr int OFF_M = NB * NB * 256, OFF_Q = OFF_M + NB * 256, OFF_QF = OFF_Q + NB * 256, OFF_K = OFF_QF + NB * 256;
+    constexpr int TSP = (3 * NB * 256 + 16 * NB + 16 + 127) & ~127;
+    constexpr int64_t GS = 2 * (int64_t)NB * 256 + 16 * NB + 16;
+    __shared__ BlockAdjShared<NB> sh;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, q = lane >> 4, c16 = lane & 15;
+    const int64_t b = blockIdx.x;
+    const int64_t N = p.N;
+    const int J = p.J, R = p.R;
+    const int64_t NW = (N + KW - 1) / KW;
+    const int64_t RSB = TSP + 256 * (int64_t)J;
+    const bool chain = w == CH, owner = w < NB;
+    const int Jy = R >> 4, ry = R & 15;
+    const bool ycol = owner && w == Jy && c16 == ry;
+    const double nu = p.nu ? p.nu[b] : 1.0;
+    const double* __restrict__ Ab_ = p.A + b * J;
+    const double* __restrict__ Bb_ = p.Bc + b * J;
+    const double* gwb = p.gw + b * NW * GWS;
+    (void)nu;
+    if (tid < 64) {
+        double a = 0.0, bb = 0.0;
+        if (tid < R) {
+            const int rm = p.rowmap[tid];
+            const int term = rm & 0xfffff;
+            a = Ab_[term];
+            bb = ((rm >> 30) & 1) ? -Bb_[term] : Bb_[term];
+        }
+        sh.albe[tid] = double2{a, bb};
+        sh.ra[tid] = 0.0; sh.rb[tid] = 0.0;
+    }
+    if (tid < 8) sh.rs[tid] = 0.0;
+    if (tid < 120) {
+        int nn = 1;
+        while ((nn + 1) * nn / 2 <= tid) ++nn;
+        sh.pn[tid] = (unsigned char)nn;
+        sh.pj[tid] = (unsigned char)(tid - nn * (nn - 1) / 2);
+    }
+    __syncthreads();
+    const double2 myab = owner ? sh.albe[16 * w + c16] : double2{0.0, 0.0};
+
+    // pair contraction threads: TPT threads per term, each a subset of the 120 pairs
+    const int TPT = J <= 16 ? 8 : (J <= 32 ? 4 : 2);        // TPT * J <= 128 .. 256 threads
+    const bool ethread = tid < TPT * J;
+    const int et = tid / TPT, es = tid - et * TPT;
+    double acc_ga = 0.0, acc_gb = 0.0;
+
+    d4 Tb[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) Tb[I] = d4{0.0, 0.0, 0.0, 0.0};
+    double acc_al = 0.0, acc_be = 0.0, acc_mu = 0.0, acc_sa = 0.0, acc_nu = 0.0;
+
+    for (int64_t k = NW - 1; k >= 0; --k) {
+        const int par = (int)(k & 1);
+        const double* gwk = gwb + k * GWS;
+        const double* grec = gtab + k * GS;
+        const int64_t n0 = k * KW;
+        double qf[NB][4], tk[NB][4], mw[4], qw[4], cvc[4], cxc[4], ckc = 0.0, ckr[NB][4];
+        d4 kf = {0.0, 0.0, 0.0, 0.0};
+        if (owner) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qf[I][ks] = gwk[OFF_QF + (I * 4 + ks) * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                qw[g] = gwk[OFF_Q + (w * 4 + g) * 64 + lane];
+                cvc[g] = grec[(w * 4 + g) * 64 + lane];
+                cxc[g] = grec[NB * 256 + (w * 4 + g) * 64 + lane];
+                mw[g] = gwk[OFF_M + (w * 4 + g) * 64 + lane];
+            }
+            ckc = grec[2 * NB * 256 + 16 * w + c16];
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    ckr[I][g] = grec[2 * NB * 256 + 16 * I + 4 * g + q];
+                    tk[I][g] = gwk[((w * NB + I) * 4 + g) * 64 + lane];
+                }
+        }
+        if (chain) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) kf[g] = gwk[OFF_K + g * 64 + lane];
+        }
+        // ---- A: X-' = 2 Q' T-, the partial Q' T- Q, U~' ---------------------------------------------------------------
+        double xb[4], uw[4];
+        if (owner) {
+            d4 qt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qt = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[I][ks], Tb[I][ks], qt, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                xb[g] = 2.0 * qt[g];
+                if (ycol) {
+                    xb[g] -= qw[g];
+                    if (n0 + 4 * g + q < N) acc_mu -= xb[g];
+                    sh.qy[4 * g + q] = qw[g];
+                }
+                uw[g] = fma(myab.x, cvc[g], myab.y * cxc[g]);
+                sh.tileU[par][w][(4 * g + q) * 18 + c16] = uw[g];
+                sh.scr[w][(4 * g + q) * 18 + c16] = qt[g];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double qtT[4], qfw[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qtT[ks] = sh.scr[w][c16 * 18 + 4 * ks + q];
+            static_for<0, NB>([&](auto Ic) __attribute__((always_inline)) {
+                constexpr int I = decltype(Ic)::value;
+                if (w == I) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) qfw[ks] = qf[I][ks];
+                }
+            });
+            d4 pw = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) pw = __builtin_amdgcn_mfma_f64_16x16x4f64(qfw[ks], qtT[ks], pw, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sh.P[w][g * 64 + lane] = pw[g];
+        }
+        __syncthreads();   // B1
+        // ---- B: S- (chain); the owners rescale T- -----------------------------------------------------------------------
+        if (chain) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                double ps = sh.P[0][g * 64 + lane];
+#pragma unroll
+                for (int I = 1; I < NB; ++I) ps += sh.P[I][g * 64 + lane];
+                const double sb = -0.5 * kf[g] - ps + 0.5 * sh.qy[4 * g + q] * sh.qy[c16];
+                sh.Srm[(4 * g + q) * 16 + c16] = sb;
+                if (4 * g + q == c16 && n0 + c16 < N) {
+                    acc_sa += sb;
+                    acc_nu = fma(sb, grec[2 * NB * 256 + 16 * NB + c16], acc_nu);
+                }
+            }
+        }
+        if (owner) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Tb[I][g] *= ckr[I][g] * ckc;
+        }
+        __syncthreads();   // B2
+        // ---- C: M-' = -cK o X-' - S- U~';  S- M' ------------------------------------------------------------------------
+        double mbw[4];
+        d4 sm = {0.0, 0.0, 0.0, 0.0};
+        if (owner) {
+            double sA[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) sA[ks] = 0.5 * (sh.Srm[c16 * 16 + 4 * ks + q] + sh.Srm[(4 * ks + q) * 16 + c16]);   // symmetrised
+            d4 su = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                su = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[ks], uw[ks], su, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[ks], mw[ks], sm, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                mbw[g] = fma(-ckc, xb[g], -su[g]);
+                sh.tileM[par][w][(4 * g + q) * 18 + c16] = mbw[g];
+            }
+        }
+        if (ethread) {   // d/da_t, d/db_t: 2 sum over the window's pairs of S-_jn E_t,p
+            const double2* E = reinterpret_cast<const double2*>(btab + k * RSB + TSP) + et * 128;
+            for (int pp = es; pp < 120; pp += TPT) {
+                const int nn = sh.pn[pp], jj = sh.pj[pp];
+                const double sv = sh.Srm[nn * 16 + jj] + sh.Srm[jj * 16 + nn];
+                const double2 e = E[pp];
+                acc_ga = fma(sv, e.x, acc_ga);
+                acc_gb = fma(sv, e.y, acc_gb);
+            }
+        }
+        __syncthreads();   // B3
+        // ---- D: U~-' = -S- M' + M-' T;  T- += 1/2 (U~ M-' + M- U~') ----------------------------------------------------
+        if (owner) {
+            d4 mt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    mt = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][c16 * 18 + 4 * ks + q], tk[I][ks], mt, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const double ub = mt[g] - sm[g];
+                acc_al = fma(ub, cvc[g], acc_al);
+                acc_be = fma(ub, cxc[g], acc_be);
+            }
+            double hm[4], hu[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { hm[ks] = 0.5 * mbw[ks]; hu[ks] = 0.5 * uw[ks]; }
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileU[par][I][(4 * ks + q) * 18 + c16], hm[ks], Tb[I], 0, 0, 0);
+                    Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][(4 * ks + q) * 18 + c16], hu[ks], Tb[I], 0, 0, 0);
+                }
+        }
+    }
+    // ---- reductions: rows -> terms ------------------------------------------------------------------------------------------------
+    __syncthreads();
+    if (owner) {
+        const int row = 16 * w + c16;
+        if (row < R) {
+            const int rm = p.rowmap[row];
+            const int term = rm & 0xfffff;
+            atomicAdd(&sh.ra[term], acc_al);
+            atomicAdd(&sh.rb[term], ((rm >> 30) & 1) ? -acc_be : acc_be);
+        }
+        if (ycol) atomicAdd(&sh.rs[0], acc_mu);
+    }
+    if (chain) { atomicAdd(&sh.rs[1], acc_sa); atomicAdd(&sh.rs[2], acc_nu); }
+    if (ethread) { atomicAdd(&sh.ra[et], acc_ga); atomicAdd(&sh.rb[et], acc_gb); }
+    __syncthreads();
+    if (tid < J) {
+        grad_a[b * J + tid] = sh.ra[tid] + sh.rs[1];
+        grad_b[b * J + tid] = sh.rb[tid];
+    }
+    if (tid == 0) {
+        if (grad_mu) grad_mu[b] = sh.rs[0];
+        if (grad_nu) grad_nu[b] = sh.rs[2];
+    }
+    (void)NT;
 }
 
 constexpr size_t kBlockLdsMax = 160 * 1024;
@@ -986,7 +1353,61 @@ int launch_block(const ScanParams& p, const double* btab, hipStream_t stream)
     return PIORAN_ERR_UNSUPPORTED;
 }
 
+template <int NB>
+int launch_block_grad(const ScanParams& p, const double* btab, const double* gtab, double* ga, double* gb, double* gnu, double* gmu,
+                      hipStream_t stream)
+{
+    const size_t lds = block_lds_bytes(NB, p.J, 0);
+    if (lds > kBlockLdsMax) return PIORAN_ERR_UNSUPPORTED;
+    static size_t granted[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
+    if (lds > granted[dev]) {
+        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PIORAN_ERR_HIP;
+        granted[dev] = lds;
+    }
+    hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, true>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
+    hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 320), 0, stream, p, btab, gtab, ga, gb, gnu, gmu);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
 }  // namespace
+
+// ---- windowed reverse mode: host side ----
+size_t pioran_block_grad_workspace_doubles(int64_t B, int64_t N, int32_t R)
+{
+    const int NB = (R + 1 + 15) / 16;
+    return (size_t)B * (size_t)((N + KW - 1) / KW) * (size_t)block_grad_ws_doubles(NB);
+}
+size_t pioran_block_gtab_doubles(int64_t N, int32_t R)
+{
+    const int NB = (R + 1 + 15) / 16;
+    return (size_t)((N + KW - 1) / KW) * (size_t)block_gtab_doubles(NB);
+}
+int pioran_launch_block_gtab(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c, const double* d,
+                             const double* s2, double* gtab, hipStream_t stream)
+{
+    const int NB = (R + 1 + 15) / 16;
+    const int64_t NW = (N + KW - 1) / KW;
+    if (J < 1 || J > kBlockMaxTerms || NB > 4 || NW > 0x7fffffffLL) return PIORAN_ERR_ARG;
+    hipLaunchKernelGGL(block_gtable_window_kernel, dim3((unsigned)NW), dim3(256), 0, stream, N, R, J, NB, rowmap, t, c, d, s2, gtab);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+// log L (p.out, p.status) and d/d(a_j, b_j) [B][J], d/dnu, d/dmu [B] (either may be nullptr) for shared (c, d) without per-draw rows
+// or series; p.gw: pioran_block_grad_workspace_doubles; btab, gtab: the two tables of this (c, d)
+int pioran_launch_block_grad(const ScanParams& p, const double* btab, const double* gtab, double* grad_a, double* grad_b, double* grad_nu,
+                             double* grad_mu, hipStream_t stream)
+{
+    if (!btab || !gtab || !p.gw || p.npd_rows != 0 || p.Y || p.S2 || p.B < 1 || p.N < 1 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    switch ((p.R + 1 + 15) / 16) {
+        case 1: return launch_block_grad<1>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, stream);
+        case 2: return launch_block_grad<2>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, stream);
+        case 3: return launch_block_grad<3>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, stream);
+        case 4: return launch_block_grad<4>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, stream);
+    }
+    return PIORAN_ERR_UNSUPPORTED;
+}
 
 int pioran_block_supported_rows() { return 63; }
 

@@ -61,6 +61,7 @@ struct ScanParams {
     int32_t npd_rows;     // per-draw rows (2 per per-draw term), 0 if none
     // celerite_block.hip with per-draw rows (the last npd_rows rows of the row map): the per-draw c [B][J] and the compact table of
     // (cos, sin)(d t_n) [B][npd terms][pd_npad][2] (pioran_launch_block_pd_trig)
+    double* gw;           // celerite_block.hip, gradient: workspace [B][windows][block_grad_ws_doubles] the forward pass leaves for the reverse pass
     const double* pd_C;
     const double* pd_trig;
     int64_t pd_npad;
@@ -126,6 +127,13 @@ int pioran_launch_block_table(int64_t N, int32_t R, int32_t J, const int32_t* ro
 int pioran_launch_scan_block(const ScanParams& p, const double* btab, hipStream_t stream);   // p.tab_draw_stride: doubles between per-draw tables (0: one shared table)
 int pioran_launch_block_table_batch(int64_t N, int32_t R, int32_t J, int64_t nb, const int32_t* rowmap, const double* t, const double* C /*[nb][J]*/,
                                     const double* D, const double* y, const double* s2, double* btab, int64_t draw_stride, hipStream_t stream);
+// windowed reverse mode (gradient w.r.t. a, b, mu, nu): forward pass with stores + adjoint kernel
+size_t pioran_block_grad_workspace_doubles(int64_t B, int64_t N, int32_t R);
+size_t pioran_block_gtab_doubles(int64_t N, int32_t R);
+int pioran_launch_block_gtab(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c, const double* d,
+                             const double* s2, double* gtab, hipStream_t stream);
+int pioran_launch_block_grad(const ScanParams& p, const double* btab, const double* gtab, double* grad_a, double* grad_b, double* grad_nu,
+                             double* grad_mu, hipStream_t stream);
 int pioran_launch_block_table_reference(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,
                                         const double* d, const double* y, const double* s2, double* btab, hipStream_t stream);
 // celerite_predict.hip: posterior mean at new times (pred, src/celerite_solver.jl:363-483)

@@ -1250,6 +1250,39 @@ def test_gradient_matches_complex_step(ctx, J, N, B):
             assert np.max(np.abs(g["grad_sigma2"][i] - nu[i] * ref["grad_sigma2"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_sigma2"])))
 
 
+@pytest.mark.parametrize("J,N,B,nreal", [(3, 40, 3, 0), (5, 16, 2, 0), (7, 33, 4, 2), (8, 100, 3, 1), (12, 17, 2, 0), (15, 130, 5, 0), (20, 257, 3, 0),
+                                         (23, 48, 2, 0), (24, 70, 2, 0), (30, 95, 2, 5), (31, 64, 3, 0)])
+def test_windowed_gradient_matches_complex_step(ctx, J, N, B, nreal):
+    """d log L / d(a_j, b_j, mu, nu) by the windowed reverse mode (celerite_block_adjoint_kernel; what a sampler of an approx-based
+    model asks for: (c, d) fixed by the spectral grid): against the complex-step derivatives of the oracle and against the
+    step-by-step adjoint kernels; every block count NB = 1 .. 4, ragged last windows, one-row terms; the value is bit-identical to the
+    windowed forward kernel's."""
+    rng = np.random.default_rng(8800 + J + N)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    Bc[:, :nreal] = 0.0; Dd[:nreal] = 0.0
+    ds = pj.Dataset(t, y, s2, ctx)
+    g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block (windowed gradient)"
+    val = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block"
+    assert (g["logl"] == val).all() and (g["status"] == 0).all()
+    assert relerr(g["logl"], O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu)) < 1e-11
+    try:
+        ctx.set_option("no_block", True)
+        old = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+    finally:
+        ctx.set_option("no_block", False)
+    for i in range(B):
+        ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2)
+        for key in ("grad_a", "grad_b"):
+            tol = 1e-9 * (1 + np.max(np.abs(ref[key])))
+            assert np.max(np.abs(g[key][i] - ref[key])) <= tol, (key, i)
+            assert np.max(np.abs(g[key][i] - old[key][i])) <= tol, (key, i)
+        gm = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, dy=-np.ones(N))
+        gn = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, ds2=s2)
+        assert abs(g["grad_mu"][i] - gm) <= 1e-9 * (1 + abs(gm)) and abs(g["grad_nu"][i] - gn) <= 1e-9 * (1 + abs(gn))
+
+
 def test_gradient_full_size_and_real_terms(ctx, full_size):
     """N = 1e4 (BASELINE shape), SHO-20 and DRWCelerite-20 (terms with b = d = 0: one row each), against one complex
     step per direction for a few directions, bar 1e-7 relative to the gradient scale."""

@@ -19,11 +19,19 @@ def timed(f, reps=3):
     for _ in range(reps):
         t0 = time.perf_counter(); r = f(); ts.append(time.perf_counter() - t0)
     return float(np.median(ts)) * 1e3, r
-res = {"workload": f"N={N}, {basis}-{J}, gradient w.r.t. (a, b) [J each], mu, nu"}
-for B in (1, 16, 64):
-    tg, g = timed(lambda: ds.logl_grad(A[:B], Bc[:B], C, Dd, mu=mu[:B], nu=nu[:B]))
+res = {"workload": f"N={N}, {basis}-{J}: value + gradient; 'abmunu': d/d(a_j, b_j, mu, nu) (windowed reverse mode); 'full': also d/d(c_j, d_j) "
+                   "(step-by-step adjoint kernels); host-pointer entry, PCIe included"}
+name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+for B in (1, 16, 64, 256):
+    tw, gw = timed(lambda: ds.logl_grad(A[:B], Bc[:B], C, Dd, mu=mu[:B], nu=nu[:B], cd_grad=False)); kw = name()
     tv, v = timed(lambda: ds.logl_batch(A[:B], Bc[:B], C, Dd, mu=mu[:B], nu=nu[:B]))
-    res[f"B{B}"] = {"value_and_gradient_ms": round(tg, 2), "value_only_ms": round(tv, 2)}
+    row = {"value_and_gradient_abmunu_ms": round(tw, 2), "kernel": kw, "value_only_ms": round(tv, 2)}
+    if B <= 64:
+        tg, g = timed(lambda: ds.logl_grad(A[:B], Bc[:B], C, Dd, mu=mu[:B], nu=nu[:B]))
+        row["value_and_gradient_full_ms"] = round(tg, 2)
+        row["max_rel_diff_abmunu_vs_full"] = float(max(np.max(np.abs(gw[k] - g[k])) / (1 + np.max(np.abs(g[k]))) for k in ("grad_a", "grad_b", "grad_mu", "grad_nu")))
+    res[f"B{B}"] = row
+g = gw
 t0 = time.perf_counter(); ref = O.logl_dir(A[0], Bc[0], C, Dd, t, y - mu[0], nu[0] * yerr ** 2, da=np.ones(A.shape[1])); tc = time.perf_counter() - t0
 res["cpu_one_complex_step_ms"] = round(tc * 1e3, 1)
 res["directional_check_rel"] = float(abs(g["grad_a"][0].sum() - ref) / (1 + abs(ref)))
