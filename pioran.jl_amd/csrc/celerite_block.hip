@@ -1063,12 +1063,13 @@ struct BlockAdjShared {
 };
 
 template <int NB>
-__global__ void __launch_bounds__(NB < 4 ? 256 : 320, 1) celerite_block_adjoint_kernel(const ScanParams p, const double* __restrict__ btab,
+__global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const ScanParams p, const double* __restrict__ btab,
                                                                                       const double* __restrict__ gtab, double* __restrict__ grad_a,
                                                                                       double* __restrict__ grad_b, double* __restrict__ grad_nu,
                                                                                       double* __restrict__ grad_mu)
 {
-    constexpr int NCW = NB < 4 ? 4 : 5, CH = NCW - 1, NT = NCW * 64;
+    constexpr int CH = 3;      // four wavefronts (512 registers each: the hand-pipelined loads live in them); with four block columns
+                               // the last owner also assembles S-
     constexpr int64_t GWS = (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256;
     constexpr int OFF_M = NB * NB * 256, OFF_Q = OFF_M + NB * 256, OFF_QF = OFF_Q + NB * 256, OFF_K = OFF_QF + NB * 256;
     constexpr int TSP = (3 * NB * 256 + 16 * NB + 16 + 127) & ~127;
@@ -1112,7 +1113,7 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 1) celerite_block_adjoint_
     const double2 myab = owner ? sh.albe[16 * w + c16] : double2{0.0, 0.0};
 
     // pair contraction threads: TPT threads per term, each a subset of the 120 pairs
-    const int TPT = J <= 16 ? 8 : (J <= 32 ? 4 : 2);        // TPT * J <= 128 .. 256 threads
+    const int TPT = J <= 32 ? 8 : 4;                        // TPT * J <= 256 threads
     const bool ethread = tid < TPT * J;
     const int et = tid / TPT, es = tid - et * TPT;
     double acc_ga = 0.0, acc_gb = 0.0;
@@ -1122,38 +1123,40 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 1) celerite_block_adjoint_
     for (int I = 0; I < NB; ++I) Tb[I] = d4{0.0, 0.0, 0.0, 0.0};
     double acc_al = 0.0, acc_be = 0.0, acc_mu = 0.0, acc_sa = 0.0, acc_nu = 0.0;
 
+    // Loads are software-pipelined by hand: what phase A of a window needs (Q in both layouts, C o v, C o x; the chain wavefront's K and
+    // sigma2) is fetched one window ahead into a second register set; T_k, M', C_K and the pair table of the window itself are
+    // issued right after phase A's matrix instructions and land during the barrier waits.  Barriers wait for LDS only.
+    constexpr int EPT = 15;    // pairs per contraction thread with eight threads per term (up to 32 terms): prefetched; beyond, read in the loop
+    double qf[NB][4], qw[4], cvc[4], cxc[4];
+    d4 kf = {0.0, 0.0, 0.0, 0.0};
+    double s2w = 0.0;
+    auto fetch_a = [&](int64_t kk, double (&qf_)[NB][4], double (&qw_)[4], double (&cvc_)[4], double (&cxc_)[4], d4& kf_, double& s2w_) __attribute__((always_inline)) {
+        const double* gwk = gwb + kk * GWS;
+        const double* grec = gtab + kk * GS;
+        if (owner) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qf_[I][ks] = gwk[OFF_QF + (I * 4 + ks) * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                qw_[g] = gwk[OFF_Q + (w * 4 + g) * 64 + lane];
+                cvc_[g] = grec[(w * 4 + g) * 64 + lane];
+                cxc_[g] = grec[NB * 256 + (w * 4 + g) * 64 + lane];
+            }
+        }
+        if (chain) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) kf_[g] = gwk[OFF_K + g * 64 + lane];
+            s2w_ = grec[2 * NB * 256 + 16 * NB + c16];
+        }
+    };
+    fetch_a(NW - 1, qf, qw, cvc, cxc, kf, s2w);
     for (int64_t k = NW - 1; k >= 0; --k) {
         const int par = (int)(k & 1);
         const double* gwk = gwb + k * GWS;
         const double* grec = gtab + k * GS;
         const int64_t n0 = k * KW;
-        double qf[NB][4], tk[NB][4], mw[4], qw[4], cvc[4], cxc[4], ckc = 0.0, ckr[NB][4];
-        d4 kf = {0.0, 0.0, 0.0, 0.0};
-        if (owner) {
-#pragma unroll
-            for (int I = 0; I < NB; ++I)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qf[I][ks] = gwk[OFF_QF + (I * 4 + ks) * 64 + lane];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                qw[g] = gwk[OFF_Q + (w * 4 + g) * 64 + lane];
-                cvc[g] = grec[(w * 4 + g) * 64 + lane];
-                cxc[g] = grec[NB * 256 + (w * 4 + g) * 64 + lane];
-                mw[g] = gwk[OFF_M + (w * 4 + g) * 64 + lane];
-            }
-            ckc = grec[2 * NB * 256 + 16 * w + c16];
-#pragma unroll
-            for (int I = 0; I < NB; ++I)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    ckr[I][g] = grec[2 * NB * 256 + 16 * I + 4 * g + q];
-                    tk[I][g] = gwk[((w * NB + I) * 4 + g) * 64 + lane];
-                }
-        }
-        if (chain) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) kf[g] = gwk[OFF_K + g * 64 + lane];
-        }
         // ---- A: X-' = 2 Q' T-, the partial Q' T- Q, U~' ---------------------------------------------------------------
         double xb[4], uw[4];
         if (owner) {
@@ -1191,29 +1194,51 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 1) celerite_block_adjoint_
 #pragma unroll
             for (int g = 0; g < 4; ++g) sh.P[w][g * 64 + lane] = pw[g];
         }
-        __syncthreads();   // B1
-        // ---- B: S- (chain); the owners rescale T- -----------------------------------------------------------------------
+        // ---- this window's own operands, and the next window's phase-A operands ----
+        double tk[NB][4], mw[4], ckc = 0.0, ckr[NB][4];
+        double2 ev[EPT];
+        if (owner) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mw[g] = gwk[OFF_M + (w * 4 + g) * 64 + lane];
+            ckc = grec[2 * NB * 256 + 16 * w + c16];
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    ckr[I][g] = grec[2 * NB * 256 + 16 * I + 4 * g + q];
+                    tk[I][g] = gwk[((w * NB + I) * 4 + g) * 64 + lane];
+                }
+        }
+        if (ethread && TPT == 8) {
+            const double2* E = reinterpret_cast<const double2*>(btab + k * RSB + TSP) + et * 128;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int pp = es + i * TPT;
+                ev[i] = pp < 120 ? E[pp] : double2{0.0, 0.0};
+            }
+        }
+        double nqf[NB][4], nqw[4], ncvc[4], ncxc[4], ns2w = 0.0;
+        d4 nkf = {0.0, 0.0, 0.0, 0.0};
+        const double kdiag = s2w;
+        d4 kcur = kf;
+        if (k > 0) fetch_a(k - 1, nqf, nqw, ncvc, ncxc, nkf, ns2w);
+        PIORAN_BLK_BARRIER();   // B1
+        // ---- B: S- (chain) -------------------------------------------------------------------------------------------------
         if (chain) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 double ps = sh.P[0][g * 64 + lane];
 #pragma unroll
                 for (int I = 1; I < NB; ++I) ps += sh.P[I][g * 64 + lane];
-                const double sb = -0.5 * kf[g] - ps + 0.5 * sh.qy[4 * g + q] * sh.qy[c16];
+                const double sb = -0.5 * kcur[g] - ps + 0.5 * sh.qy[4 * g + q] * sh.qy[c16];
                 sh.Srm[(4 * g + q) * 16 + c16] = sb;
                 if (4 * g + q == c16 && n0 + c16 < N) {
                     acc_sa += sb;
-                    acc_nu = fma(sb, grec[2 * NB * 256 + 16 * NB + c16], acc_nu);
+                    acc_nu = fma(sb, kdiag, acc_nu);
                 }
             }
         }
-        if (owner) {
-#pragma unroll
-            for (int I = 0; I < NB; ++I)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) Tb[I][g] *= ckr[I][g] * ckc;
-        }
-        __syncthreads();   // B2
+        PIORAN_BLK_BARRIER();   // B2
         // ---- C: M-' = -cK o X-' - S- U~';  S- M' ------------------------------------------------------------------------
         double mbw[4];
         d4 sm = {0.0, 0.0, 0.0, 0.0};
@@ -1234,17 +1259,30 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 1) celerite_block_adjoint_
             }
         }
         if (ethread) {   // d/da_t, d/db_t: 2 sum over the window's pairs of S-_jn E_t,p
-            const double2* E = reinterpret_cast<const double2*>(btab + k * RSB + TSP) + et * 128;
-            for (int pp = es; pp < 120; pp += TPT) {
-                const int nn = sh.pn[pp], jj = sh.pj[pp];
-                const double sv = sh.Srm[nn * 16 + jj] + sh.Srm[jj * 16 + nn];
-                const double2 e = E[pp];
-                acc_ga = fma(sv, e.x, acc_ga);
-                acc_gb = fma(sv, e.y, acc_gb);
+            if (TPT == 8) {
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int pp = es + i * TPT;
+                    if (pp < 120) {
+                        const int nn = sh.pn[pp], jj = sh.pj[pp];
+                        const double sv = sh.Srm[nn * 16 + jj] + sh.Srm[jj * 16 + nn];
+                        acc_ga = fma(sv, ev[i].x, acc_ga);
+                        acc_gb = fma(sv, ev[i].y, acc_gb);
+                    }
+                }
+            } else {
+                const double2* E = reinterpret_cast<const double2*>(btab + k * RSB + TSP) + et * 128;
+                for (int pp = es; pp < 120; pp += TPT) {
+                    const int nn = sh.pn[pp], jj = sh.pj[pp];
+                    const double sv = sh.Srm[nn * 16 + jj] + sh.Srm[jj * 16 + nn];
+                    const double2 e = E[pp];
+                    acc_ga = fma(sv, e.x, acc_ga);
+                    acc_gb = fma(sv, e.y, acc_gb);
+                }
             }
         }
-        __syncthreads();   // B3
-        // ---- D: U~-' = -S- M' + M-' T;  T- += 1/2 (U~ M-' + M- U~') ----------------------------------------------------
+        PIORAN_BLK_BARRIER();   // B3
+        // ---- D: U~-' = -S- M' + M-' T;  T- <- (cK cK') o T- + 1/2 (U~ M-' + M- U~') -------------------------------------
         if (owner) {
             d4 mt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1252,6 +1290,10 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 1) celerite_block_adjoint_
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
                     mt = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][c16 * 18 + 4 * ks + q], tk[I][ks], mt, 0, 0, 0);
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Tb[I][g] *= ckr[I][g] * ckc;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const double ub = mt[g] - sm[g];
@@ -1268,6 +1310,15 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 1) celerite_block_adjoint_
                     Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileU[par][I][(4 * ks + q) * 18 + c16], hm[ks], Tb[I], 0, 0, 0);
                     Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][(4 * ks + q) * 18 + c16], hu[ks], Tb[I], 0, 0, 0);
                 }
+        }
+        if (k > 0) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qf[I][ks] = nqf[I][ks];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { qw[g] = nqw[g]; cvc[g] = ncvc[g]; cxc[g] = ncxc[g]; }
+            kf = nkf; s2w = ns2w;
         }
     }
     // ---- reductions: rows -> terms ------------------------------------------------------------------------------------------------
@@ -1293,7 +1344,6 @@ __global__ void __launch_bounds__(NB < 4 ? 256 : 320, 1) celerite_block_adjoint_
         if (grad_mu) grad_mu[b] = sh.rs[0];
         if (grad_nu) grad_nu[b] = sh.rs[2];
     }
-    (void)NT;
 }
 
 constexpr size_t kBlockLdsMax = 160 * 1024;
@@ -1368,7 +1418,7 @@ int launch_block_grad(const ScanParams& p, const double* btab, const double* gta
         granted[dev] = lds;
     }
     hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, true>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
-    hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 320), 0, stream, p, btab, gtab, ga, gb, gnu, gmu);
+    hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB>), dim3((unsigned)p.B), dim3(256), 0, stream, p, btab, gtab, ga, gb, gnu, gmu);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
