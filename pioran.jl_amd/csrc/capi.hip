@@ -38,7 +38,7 @@ struct pioran_ctx {
         void* p = nullptr;
         size_t cap = 0;
     };
-    Buf bA, bB, bC, bD, bmu, bnu, bY, bS2, bout, bst, bscratch, bK, bwork, bshift;
+    Buf bA, bB, bC, bD, bmu, bnu, bY, bS2, bout, bst, bscratch, bK, bwork, bshift, bgtab;
     // scalar entry point: the last series' time stamps stay resident (samplers call logl with the same t)
     pioran_ds* scalar_ds = nullptr;
     std::vector<double> scalar_t;
@@ -438,7 +438,7 @@ int pioran_ctx_destroy(pioran_ctx* ctx)
     if (ctx->scalar_ds) pioran_dataset_destroy(ctx->scalar_ds);
     ctx->scalar_ds = nullptr;
     pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
-                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift};
+                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab};
     for (auto* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : ctx->ev)
@@ -462,7 +462,7 @@ int pioran_ctx_trim(pioran_ctx* ctx)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     SYNC(ctx);
     pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
-                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift};
+                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab};
     for (auto* b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;
@@ -1208,76 +1208,38 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
     if (s.R > 95 || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
-    // Windowed reverse mode (celerite_block.hip, round 3) when only d/d(a, b, mu, nu) are asked for — the approx-based models under
-    // NUTS: (c, d) are fixed by the spectral grid — and the rows fit the windowed kernel: ~5 ms instead of 25 at N = 1e4, J = 20.
-    if (!grad_c && !grad_d && !grad_y && !grad_sigma2 && !shift && !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] &&
-        s.R >= 6 && pioran_block_fits(s.R, s.J) && (rc = ensure_btab(ds, s)) != PIORAN_ERR_UNSUPPORTED) {
-        if (rc) return rc;
-        const size_t gt = pioran_block_gtab_doubles(ds->N, s.R) * sizeof(double);
-        int64_t chunk = B < 256 ? B : 256;
-        {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                const size_t allowed = free_b / 2 + ctx->bwork.cap;
-                while (chunk > 1 && pioran_block_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double) > allowed) chunk /= 2;
-            }
-        }
-        while ((rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double))) == PIORAN_ERR_ALLOC && chunk > 1)
-            chunk /= 2;
-        if (rc) return rc;
-        if ((rc = ensure(ctx, ctx->bscratch, gt))) return rc;
-        if ((rc = pioran_launch_block_gtab(ds->N, s.R, s.J, s.rowmap, ds->t, s.dc, s.dd, ds->s2, (double*)ctx->bscratch.p, ctx->stream))) return rc;
-        const size_t cj = (size_t)chunk * (size_t)J * sizeof(double);
-        if ((rc = ensure(ctx, ctx->bC, 2 * cj))) return rc;
-        if ((rc = ensure(ctx, ctx->bD, 2 * chunk * sizeof(double)))) return rc;
-        if ((rc = ensure(ctx, ctx->bout, chunk * sizeof(double)))) return rc;
-        if ((rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t)))) return rc;
-        for (int64_t b0 = 0; b0 < B; b0 += chunk) {
-            const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
-            if ((rc = upload(ctx, ctx->bA, A + b0 * J, (size_t)nb * J * sizeof(double)))) return rc;
-            if ((rc = upload(ctx, ctx->bB, Bc + b0 * J, (size_t)nb * J * sizeof(double)))) return rc;
-            if (mu && (rc = upload(ctx, ctx->bmu, mu + b0, nb * sizeof(double)))) return rc;
-            if (nu && (rc = upload(ctx, ctx->bnu, nu + b0, nb * sizeof(double)))) return rc;
-            ScanParams p{};
-            p.opt = &ctx->opt;
-            p.N = ds->N; p.J = s.J; p.R = s.R; p.B = nb;
-            p.standard_rows = s.row_layout; p.n_complex = s.n_complex;
-            p.rec_stride = 3 * (int64_t)(s.R + 2) + 2;
-            p.tab = s.tab; p.rowmap = s.rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
-            p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = s.dc; p.D = s.dd;
-            p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
-            p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
-            p.gw = (double*)ctx->bwork.p;
-            double* dga = (double*)ctx->bC.p; double* dgb = dga + (size_t)chunk * J;
-            double* dgn = (double*)ctx->bD.p; double* dgm = dgn + chunk;
-            g_last_kernel = "block (windowed gradient)";
-            rc = pioran_launch_block_grad(p, s.btab, (const double*)ctx->bscratch.p, dga, dgb, dgn, dgm, ctx->stream);
-            if (rc) { ctx->last_err = "windowed gradient launch failed"; return rc; }
-            const size_t nbj = (size_t)nb * J * sizeof(double);
-            if ((rc = download(ctx, out + b0, ctx->bout.p, nb * sizeof(double)))) return rc;
-            if (status) if ((rc = download(ctx, status + b0, ctx->bst.p, nb * sizeof(int32_t)))) return rc;
-            if ((rc = download(ctx, grad_a + b0 * J, dga, nbj))) return rc;
-            if ((rc = download(ctx, grad_b + b0 * J, dgb, nbj))) return rc;
-            if (grad_nu) if ((rc = download(ctx, grad_nu + b0, dgn, nb * sizeof(double)))) return rc;
-            if (grad_mu) if ((rc = download(ctx, grad_mu + b0, dgm, nb * sizeof(double)))) return rc;
-            SYNC(ctx);
-        }
-        return PIORAN_OK;
+    // Windowed reverse mode (celerite_block.hip, round 3) whenever d/d(c, d) are not asked for — the approx-based models under NUTS:
+    // (c, d) are fixed by the spectral grid — and the rows fit the windowed kernel: 6.3 ms instead of 25 at N = 1e4, J = 20 (series
+    // gradients and the shifted log-flux models included).
+    bool windowed = !grad_c && !grad_d && !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R >= 6 &&
+                    pioran_block_fits(s.R, s.J);
+    if (windowed) {
+        rc = ensure_btab(ds, s);
+        if (rc == PIORAN_ERR_UNSUPPORTED) windowed = false;
+        else if (rc) return rc;
     }
+    auto ws_doubles = [&](int64_t nb) { return windowed ? pioran_block_grad_workspace_doubles(nb, ds->N, s.R) : pioran_grad_workspace_doubles(nb, ds->N, s.R); };
     // Workspace per draw: (m, D) of every step + S at the checkpoints + two replayed segments (celerite_wide.hip): ~15 MB at
     // N = 1e4, R = 40.  The chunk is bounded by half of the memory that is free right now (plus what this buffer already
     // holds) and halved again if the allocation still fails.
     int64_t chunk = B < 1024 ? B : 1024;
+    if (windowed && chunk > 256) chunk = 256;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t allowed = free_b / 2 + ctx->bwork.cap;
-            while (chunk > 1 && pioran_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double) > allowed) chunk /= 2;
+            while (chunk > 1 && ws_doubles(chunk) * sizeof(double) > allowed) chunk /= 2;
         }
     }
-    while ((rc = ensure(ctx, ctx->bwork, pioran_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double))) == PIORAN_ERR_ALLOC && chunk > 1)
+    while ((rc = ensure(ctx, ctx->bwork, ws_doubles(chunk) * sizeof(double))) == PIORAN_ERR_ALLOC && chunk > 1)
         chunk /= 2;
     if (rc) return rc;
+    double* gtab = nullptr;
+    if (windowed) {   // the reverse pass's table (C o v, C o x in C/D order, C_K, sigma2): 13 KB per window, rebuilt per call (10 us)
+        if ((rc = ensure(ctx, ctx->bgtab, pioran_block_gtab_doubles(ds->N, s.R) * sizeof(double)))) return rc;
+        gtab = (double*)ctx->bgtab.p;
+        if ((rc = pioran_launch_block_gtab(ds->N, s.R, s.J, s.rowmap, ds->t, s.dc, s.dd, ds->s2, gtab, ctx->stream))) return rc;
+    }
     const size_t cj = (size_t)chunk * (size_t)J * sizeof(double), cn = (size_t)chunk * (size_t)ds->N * sizeof(double);
     if ((rc = ensure(ctx, ctx->bC, 4 * cj))) return rc;              // grad_a | grad_b | grad_c | grad_d
     if ((rc = ensure(ctx, ctx->bD, 2 * chunk * sizeof(double)))) return rc;   // grad_nu | grad_mu
@@ -1318,8 +1280,16 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
             HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
             for (auto& e : ctx->gev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
-        rc = pioran_launch_scan_wide_grad(p, (double*)ctx->bwork.p, dga, dgb, grad_c ? dgc : nullptr, grad_d ? dgd : nullptr, dgn, dgm,
-                                          ctx->stream, ctx->aux, ctx->gev);
+        if (windowed) {
+            p.opt = &ctx->opt;
+            p.gw = (double*)ctx->bwork.p;
+            g_last_kernel = "block (windowed gradient)";
+            rc = pioran_launch_block_grad(p, s.btab, gtab, dga, dgb, dgn, dgm, ctx->stream);
+        } else {
+            g_last_kernel = "wide (step-by-step gradient)";
+            rc = pioran_launch_scan_wide_grad(p, (double*)ctx->bwork.p, dga, dgb, grad_c ? dgc : nullptr, grad_d ? dgd : nullptr, dgn, dgm,
+                                              ctx->stream, ctx->aux, ctx->gev);
+        }
         if (rc) { ctx->last_err = "gradient launch failed"; return rc; }
         if (shift) {
             rc = pioran_launch_shift_grad(ds->N, nb, ds->y, ds->s2, dshift, p.g_y, p.g_s2, dshift + chunk, ctx->stream);

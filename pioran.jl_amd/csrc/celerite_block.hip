@@ -1090,7 +1090,6 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
     const double* __restrict__ Ab_ = p.A + b * J;
     const double* __restrict__ Bb_ = p.Bc + b * J;
     const double* gwb = p.gw + b * NW * GWS;
-    (void)nu;
     if (tid < 64) {
         double a = 0.0, bb = 0.0;
         if (tid < R) {
@@ -1148,7 +1147,8 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
         if (chain) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) kf_[g] = gwk[OFF_K + g * 64 + lane];
-            s2w_ = grec[2 * NB * 256 + 16 * NB + c16];
+            const int64_t n = kk * KW + c16;
+            s2w_ = p.S2 ? (n < N ? p.S2[b * N + n] : 0.0) : grec[2 * NB * 256 + 16 * NB + c16];   // per-draw series: the shifted log-flux models
         }
     };
     fetch_a(NW - 1, qf, qw, cvc, cxc, kf, s2w);
@@ -1170,7 +1170,10 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                 xb[g] = 2.0 * qt[g];
                 if (ycol) {
                     xb[g] -= qw[g];
-                    if (n0 + 4 * g + q < N) acc_mu -= xb[g];
+                    if (n0 + 4 * g + q < N) {
+                        acc_mu -= xb[g];
+                        if (p.g_y) p.g_y[b * N + n0 + 4 * g + q] = xb[g];      // dL/dy_n (v_y = y_n - mu)
+                    }
                     sh.qy[4 * g + q] = qw[g];
                 }
                 uw[g] = fma(myab.x, cvc[g], myab.y * cxc[g]);
@@ -1235,6 +1238,7 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                 if (4 * g + q == c16 && n0 + c16 < N) {
                     acc_sa += sb;
                     acc_nu = fma(sb, kdiag, acc_nu);
+                    if (p.g_s2) p.g_s2[b * N + n0 + c16] = nu * sb;            // dL/dsigma2_n (the diagonal holds nu sigma2_n)
                 }
             }
         }
@@ -1444,12 +1448,14 @@ int pioran_launch_block_gtab(int64_t N, int32_t R, int32_t J, const int32_t* row
     hipLaunchKernelGGL(block_gtable_window_kernel, dim3((unsigned)NW), dim3(256), 0, stream, N, R, J, NB, rowmap, t, c, d, s2, gtab);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
-// log L (p.out, p.status) and d/d(a_j, b_j) [B][J], d/dnu, d/dmu [B] (either may be nullptr) for shared (c, d) without per-draw rows
-// or series; p.gw: pioran_block_grad_workspace_doubles; btab, gtab: the two tables of this (c, d)
+// log L (p.out, p.status) and d/d(a_j, b_j) [B][J], d/dnu, d/dmu [B] (either may be nullptr), optionally d/dy_n, d/dsigma2_n (p.g_y, p.g_s2:
+// [B][N]) for shared (c, d) without per-draw rows; per-draw series p.Y / p.S2 allowed; p.gw: pioran_block_grad_workspace_doubles;
+// btab, gtab: the two tables of this (c, d)
 int pioran_launch_block_grad(const ScanParams& p, const double* btab, const double* gtab, double* grad_a, double* grad_b, double* grad_nu,
                              double* grad_mu, hipStream_t stream)
 {
-    if (!btab || !gtab || !p.gw || p.npd_rows != 0 || p.Y || p.S2 || p.B < 1 || p.N < 1 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    if (!btab || !gtab || !p.gw || p.npd_rows != 0 || p.B < 1 || p.N < 1 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    if ((p.Y == nullptr) != (p.S2 == nullptr)) return PIORAN_ERR_ARG;
     switch ((p.R + 1 + 15) / 16) {
         case 1: return launch_block_grad<1>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, stream);
         case 2: return launch_block_grad<2>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, stream);

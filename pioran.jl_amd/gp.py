@@ -312,7 +312,7 @@ class Dataset:
         theta = np.atleast_2d(_f64(theta))
         A, Bc, C, Dd = approx_batch(model, theta, f_min, f_max, n_components, norm, S_low, S_high,
                                     is_integrated_power=is_integrated_power, basis_function=basis_function)
-        g = self.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, shift=shift)
+        g = self.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, shift=shift, cd_grad=False)   # (c, d) are fixed by the spectral grid: windowed reverse mode
         gth, gnorm = approx_batch_vjp(model, theta, f_min, f_max, n_components, norm, g["grad_a"], g["grad_b"], S_low, S_high,
                                       is_integrated_power=is_integrated_power, basis_function=basis_function)
         return {"logl": g["logl"], "status": g["status"], "grad_theta": gth, "grad_norm": gnorm,

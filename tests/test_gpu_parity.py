@@ -1281,6 +1281,31 @@ def test_windowed_gradient_matches_complex_step(ctx, J, N, B, nreal):
         gm = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, dy=-np.ones(N))
         gn = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, ds2=s2)
         assert abs(g["grad_mu"][i] - gm) <= 1e-9 * (1 + abs(gm)) and abs(g["grad_nu"][i] - gn) <= 1e-9 * (1 + abs(gn))
+    # series gradients (what a per-draw data transform chains through) from the same kernels
+    gs = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False, series_grad=True)
+    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block (windowed gradient)"
+    assert (gs["logl"] == val).all() and np.array_equal(gs["grad_a"], g["grad_a"]) and np.array_equal(gs["grad_mu"], g["grad_mu"])
+    for i in range(min(B, 2)):
+        ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, series=True)
+        assert np.max(np.abs(gs["grad_y"][i] - ref["grad_y"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_y"])))
+        assert np.max(np.abs(gs["grad_sigma2"][i] - nu[i] * ref["grad_sigma2"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_sigma2"])))
+
+
+def test_windowed_gradient_shifted_log_flux_model(ctx, golden_dir):
+    """The shifted log-flux models (docs/src/turing.md:205-230) through the windowed reverse mode: per-draw transformed series in,
+    series gradients chained to d/dshift — equal to the step-by-step adjoint path on the reference's own nested-sampling points."""
+    un = np.load(golden_dir / "ultranest_points.npz")
+    t, y, yerr, P = un["t"], un["y"], un["yerr"], un["params"][:6]
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, P[:, :3], f_min, f_max, 20, P[:, 3], is_integrated_power=False)
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    gw = ds.logl_grad(A, Bc, C, Dd, mu=P[:, 5], nu=P[:, 4], shift=P[:, 6], cd_grad=False)
+    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block (windowed gradient)"
+    go = ds.logl_grad(A, Bc, C, Dd, mu=P[:, 5], nu=P[:, 4], shift=P[:, 6])
+    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "wide (step-by-step gradient)"
+    assert relerr(gw["logl"], un["logl"][:6]) < 1e-10
+    for k in ("grad_a", "grad_b", "grad_mu", "grad_nu", "grad_shift"):
+        assert np.max(np.abs(gw[k] - go[k])) <= 1e-8 * (1 + np.max(np.abs(go[k]))), k
 
 
 def test_gradient_full_size_and_real_terms(ctx, full_size):
