@@ -1315,9 +1315,10 @@ def test_gradient_full_size_and_real_terms(ctx, full_size):
     th = O.synthetic_theta(3, t, y)
     ds = pj.Dataset(t, y, yerr ** 2, ctx)
     rng = np.random.default_rng(5)
-    for basis in ("SHO", "DRWCelerite"):
+    for basis, windowed in (("SHO", False), ("DRWCelerite", False), ("SHO", True), ("DRWCelerite", True)):
         A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, 20, basis)
-        g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+        g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=not windowed)   # without d/d(c, d): the windowed reverse mode (round 3)
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == ("block (windowed gradient)" if windowed else "wide (step-by-step gradient)")
         ref_l, rst = O.logl_batch(A, Bc, C, Dd, t, y, yerr ** 2, mu, nu, nthreads=4, return_status=True)
         for i in np.flatnonzero(rst == 0)[:2]:
             assert abs(g["logl"][i] - ref_l[i]) <= 1e-8 * abs(ref_l[i])
