@@ -1211,7 +1211,7 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
     // Windowed reverse mode (celerite_block.hip, round 3) whenever d/d(c, d) are not asked for — the approx-based models under NUTS:
     // (c, d) are fixed by the spectral grid — and the rows fit the windowed kernel: 6.3 ms instead of 25 at N = 1e4, J = 20 (series
     // gradients and the shifted log-flux models included).
-    bool windowed = !grad_c && !grad_d && !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R >= 6 &&
+    bool windowed = !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R >= 6 &&
                     pioran_block_fits(s.R, s.J);
     if (windowed) {
         rc = ensure_btab(ds, s);
@@ -1284,7 +1284,7 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
             p.opt = &ctx->opt;
             p.gw = (double*)ctx->bwork.p;
             g_last_kernel = "block (windowed gradient)";
-            rc = pioran_launch_block_grad(p, s.btab, gtab, dga, dgb, dgn, dgm, ctx->stream);
+            rc = pioran_launch_block_grad(p, s.btab, gtab, dga, dgb, dgn, dgm, grad_c ? dgc : nullptr, grad_d ? dgd : nullptr, ctx->stream);
         } else {
             g_last_kernel = "wide (step-by-step gradient)";
             rc = pioran_launch_scan_wide_grad(p, (double*)ctx->bwork.p, dga, dgb, grad_c ? dgc : nullptr, grad_d ? dgd : nullptr, dgn, dgm,

@@ -993,14 +993,15 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
 // wavefront assembles S-.  Six GEMM stages per window (60 MFMAs per owner at three block columns against the forward's 32), no
 // factorisation: the reverse window is owner-bound.
 // Table of the reverse pass (block_gtable_window_kernel), per window: C o v and C o x in C/D order ([block][g][lane]: step 4 g + (lane >> 4),
-// row 16 block + (lane & 15)), then C_K [16 NB], sigma2 [16].
-__host__ __device__ inline int64_t block_gtab_doubles(int NB) { return 2 * (int64_t)NB * 256 + 16 * NB + 16; }
+// row 16 block + (lane & 15)), then C_K [16 NB], sigma2 [16], then — for d/d(c, d) — (C_K / C) o v and (C_K / C) o x in the same order and
+// the window's times [t_n x 16 | t_base | t_end | pad].
+__host__ __device__ inline int64_t block_gtab_doubles(int NB) { return 4 * (int64_t)NB * 256 + 16 * NB + 16 + 24; }
 
 __global__ void __launch_bounds__(256) block_gtable_window_kernel(int64_t N, int32_t R, int32_t J, int32_t NB, const int32_t* __restrict__ rowmap,
                                                                   const double* __restrict__ t, const double* __restrict__ c,
                                                                   const double* __restrict__ d, const double* __restrict__ s2, double* __restrict__ tab)
 {
-    __shared__ double cs[64 * 16], sn[64 * 16], Cn[64 * 16], ckt[64];
+    __shared__ double cs[64 * 16], sn[64 * 16], Cn[64 * 16], Hn[64 * 16], ckt[64];
     const int64_t GS = block_gtab_doubles(NB);
     const int64_t k = blockIdx.x;
     const int64_t n0 = k * KW;
@@ -1010,13 +1011,14 @@ __global__ void __launch_bounds__(256) block_gtable_window_kernel(int64_t N, int
     for (int it = threadIdx.x; it < J * 16; it += 256) {
         const int term = it >> 4, s = it & 15;
         const int64_t n = n0 + s;
-        double si = 0.0, co = 0.0, cn = 0.0;
+        double si = 0.0, co = 0.0, cn = 0.0, hn = 0.0;
         if (n < N) {
             const double tn = t[n];
             sincos(d[term] * tn, &si, &co);
             cn = exp(-c[term] * (tn - tb));
+            hn = exp(-c[term] * (te - tn));
         }
-        cs[it] = co; sn[it] = si; Cn[it] = cn;
+        cs[it] = co; sn[it] = si; Cn[it] = cn; Hn[it] = hn;
         if (s == 0) ckt[term] = exp(-c[term] * (te - tb));
     }
     __syncthreads();
@@ -1040,9 +1042,22 @@ __global__ void __launch_bounds__(256) block_gtable_window_kernel(int64_t N, int
             const int row = (int)e;
             if (row < R) val = ckt[rowmap[row] & 0xfffff];
             else if (row == R) val = 1.0;
-        } else {
-            e -= 16 * NB;
+        } else if ((e -= 16 * NB) < 16) {
             val = n0 + e < N ? s2[n0 + e] : 0.0;
+        } else if ((e -= 16) < 2 * nfrag) {
+            const int sec = (int)(e / nfrag);
+            const int f = (int)(e - sec * nfrag);
+            const int blk = f >> 8, reg = (f >> 6) & 3, lane = f & 63;
+            const int s = 4 * reg + (lane >> 4), row = 16 * blk + (lane & 15);
+            if (n0 + s < N && row < R) {
+                const int32_t rm = rowmap[row];
+                const int it = (rm & 0xfffff) * 16 + s;
+                const bool ks = (rm >> 30) & 1;
+                val = ((sec == 0) == ks ? sn[it] : cs[it]) * Hn[it];   // sec 0: (C_K / C) o v, sec 1: (C_K / C) o x
+            }
+        } else {
+            e -= 2 * nfrag;
+            val = e < 16 ? (n0 + e < N ? t[n0 + e] : te) : (e == 16 ? tb : (e == 17 ? te : 0.0));
         }
         rec[e0] = val;
     }
@@ -1058,22 +1073,33 @@ struct BlockAdjShared {
     double qy[16];
     double2 albe[64];
     double ra[64], rb[64];      // per-term reductions
+    double rc[64], rd[64];
+    double tt[16];
     double rs[8];
     unsigned char pn[120], pj[120];
 };
 
-template <int NB>
+// CD: also d/d(c_j, d_j) (QPO features, CARMA kernels and free Celerite terms under NUTS).  Rows: c enters through the three decays
+// (C in U~, C_K / C in V^, C_K in the rescaling and in X'), d through (v, x) = (cos, sin)(d t_n); terms: both enter the window's own
+// covariance through the pair table, d/dc E = -tau E, d/dd (E.cos, E.sin) = tau (-E.sin, E.cos):
+//   d/dc_r -= sum_n U~-'[n][r] U~'[n][r] (t_n - t_b) + sum_n X-'[n][r] V^'[n][r] (t_e - t_n) + cK-_r cK_r (t_e - t_b),
+//             cK-_r = 2 sum_j T-'_rj cK_j T_rj - sum_n X-'[n][r] M'[n][r]
+//   d/dd_r += s_r sum_n t_n (U~-'[n][r] (al_r C x - be_r C v)[n][r] + X-'[n][r] ((C_K / C) x)[n][r]),  s_r = -1 (cos row), +1 (sin row)
+//   d/dc_t -= 2 sum_pairs S-_jn tau (a_t E.cos + b_t E.sin);   d/dd_t += 2 sum_pairs S-_jn tau (b_t E.cos - a_t E.sin)
+template <int NB, bool CD>
 __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const ScanParams p, const double* __restrict__ btab,
                                                                                       const double* __restrict__ gtab, double* __restrict__ grad_a,
                                                                                       double* __restrict__ grad_b, double* __restrict__ grad_nu,
-                                                                                      double* __restrict__ grad_mu)
+                                                                                      double* __restrict__ grad_mu, double* __restrict__ grad_c,
+                                                                                      double* __restrict__ grad_d)
 {
     constexpr int CH = 3;      // four wavefronts (512 registers each: the hand-pipelined loads live in them); with four block columns
                                // the last owner also assembles S-
     constexpr int64_t GWS = (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256;
     constexpr int OFF_M = NB * NB * 256, OFF_Q = OFF_M + NB * 256, OFF_QF = OFF_Q + NB * 256, OFF_K = OFF_QF + NB * 256;
     constexpr int TSP = (3 * NB * 256 + 16 * NB + 16 + 127) & ~127;
-    constexpr int64_t GS = 2 * (int64_t)NB * 256 + 16 * NB + 16;
+    constexpr int64_t GS = 4 * (int64_t)NB * 256 + 16 * NB + 16 + 24;
+    constexpr int OFF_H = 2 * NB * 256 + 16 * NB + 16, OFF_TM = OFF_H + 2 * NB * 256;
     __shared__ BlockAdjShared<NB> sh;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1099,7 +1125,7 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
             bb = ((rm >> 30) & 1) ? -Bb_[term] : Bb_[term];
         }
         sh.albe[tid] = double2{a, bb};
-        sh.ra[tid] = 0.0; sh.rb[tid] = 0.0;
+        sh.ra[tid] = 0.0; sh.rb[tid] = 0.0; sh.rc[tid] = 0.0; sh.rd[tid] = 0.0;
     }
     if (tid < 8) sh.rs[tid] = 0.0;
     if (tid < 120) {
@@ -1116,6 +1142,8 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
     const bool ethread = tid < TPT * J;
     const int et = tid / TPT, es = tid - et * TPT;
     double acc_ga = 0.0, acc_gb = 0.0;
+    [[maybe_unused]] double acc_gc = 0.0, acc_gd = 0.0, acc_c = 0.0, acc_d = 0.0;
+    [[maybe_unused]] const double ea = (CD && ethread) ? Ab_[et] : 0.0, eb = (CD && ethread) ? Bb_[et] : 0.0;
 
     d4 Tb[NB];
 #pragma unroll
@@ -1200,6 +1228,20 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
         // ---- this window's own operands, and the next window's phase-A operands ----
         double tk[NB][4], mw[4], ckc = 0.0, ckr[NB][4];
         double2 ev[EPT];
+        [[maybe_unused]] double hv[4], hx[4], tn[4], tbw = 0.0, tew = 0.0;
+        if constexpr (CD) {
+            if (owner) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    hv[g] = grec[OFF_H + (w * 4 + g) * 64 + lane];
+                    hx[g] = grec[OFF_H + NB * 256 + (w * 4 + g) * 64 + lane];
+                    tn[g] = grec[OFF_TM + 4 * g + q];
+                }
+                tbw = grec[OFF_TM + 16];
+                tew = grec[OFF_TM + 17];
+            }
+            if (chain && lane < 16) sh.tt[lane] = grec[OFF_TM + lane];   // (read by the contraction threads after barrier 2; rewritten after barrier 3 at the earliest)
+        }
         if (owner) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) mw[g] = gwk[OFF_M + (w * 4 + g) * 64 + lane];
@@ -1272,6 +1314,11 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                         const double sv = sh.Srm[nn * 16 + jj] + sh.Srm[jj * 16 + nn];
                         acc_ga = fma(sv, ev[i].x, acc_ga);
                         acc_gb = fma(sv, ev[i].y, acc_gb);
+                        if constexpr (CD) {
+                            const double st = sv * (sh.tt[nn] - sh.tt[jj]);
+                            acc_gc = fma(-st, fma(ea, ev[i].x, eb * ev[i].y), acc_gc);
+                            acc_gd = fma(st, fma(eb, ev[i].x, -ea * ev[i].y), acc_gd);
+                        }
                     }
                 }
             } else {
@@ -1282,6 +1329,11 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                     const double2 e = E[pp];
                     acc_ga = fma(sv, e.x, acc_ga);
                     acc_gb = fma(sv, e.y, acc_gb);
+                    if constexpr (CD) {
+                        const double st = sv * (sh.tt[nn] - sh.tt[jj]);
+                        acc_gc = fma(-st, fma(ea, e.x, eb * e.y), acc_gc);
+                        acc_gd = fma(st, fma(eb, e.x, -ea * e.y), acc_gd);
+                    }
                 }
             }
         }
@@ -1294,6 +1346,14 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
                     mt = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][c16 * 18 + 4 * ks + q], tk[I][ks], mt, 0, 0, 0);
+            [[maybe_unused]] double ckb = 0.0;     // this lane's share of cK-_r for r = its column (T-', T symmetric): sum over its rows
+            if constexpr (CD) {
+#pragma unroll
+                for (int I = 0; I < NB; ++I)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) ckb = fma(Tb[I][g] * ckr[I][g], tk[I][g], ckb);
+                ckb *= 2.0;
+            }
 #pragma unroll
             for (int I = 0; I < NB; ++I)
 #pragma unroll
@@ -1303,7 +1363,14 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                 const double ub = mt[g] - sm[g];
                 acc_al = fma(ub, cvc[g], acc_al);
                 acc_be = fma(ub, cxc[g], acc_be);
+                if constexpr (CD) {
+                    ckb = fma(-xb[g], mw[g], ckb);
+                    acc_c = fma(-ub * uw[g], tn[g] - tbw, acc_c);
+                    acc_c = fma(-xb[g] * hv[g], tew - tn[g], acc_c);
+                    acc_d = fma(tn[g], fma(ub, fma(myab.x, cxc[g], -myab.y * cvc[g]), xb[g] * hx[g]), acc_d);
+                }
             }
+            if constexpr (CD) acc_c = fma(-ckb * ckc, tew - tbw, acc_c);
             double hm[4], hu[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { hm[ks] = 0.5 * mbw[ks]; hu[ks] = 0.5 * uw[ks]; }
@@ -1334,15 +1401,26 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
             const int term = rm & 0xfffff;
             atomicAdd(&sh.ra[term], acc_al);
             atomicAdd(&sh.rb[term], ((rm >> 30) & 1) ? -acc_be : acc_be);
+            if constexpr (CD) {
+                atomicAdd(&sh.rc[term], acc_c);
+                atomicAdd(&sh.rd[term], ((rm >> 30) & 1) ? acc_d : -acc_d);
+            }
         }
         if (ycol) atomicAdd(&sh.rs[0], acc_mu);
     }
     if (chain) { atomicAdd(&sh.rs[1], acc_sa); atomicAdd(&sh.rs[2], acc_nu); }
-    if (ethread) { atomicAdd(&sh.ra[et], acc_ga); atomicAdd(&sh.rb[et], acc_gb); }
+    if (ethread) {
+        atomicAdd(&sh.ra[et], acc_ga); atomicAdd(&sh.rb[et], acc_gb);
+        if constexpr (CD) { atomicAdd(&sh.rc[et], acc_gc); atomicAdd(&sh.rd[et], acc_gd); }
+    }
     __syncthreads();
     if (tid < J) {
         grad_a[b * J + tid] = sh.ra[tid] + sh.rs[1];
         grad_b[b * J + tid] = sh.rb[tid];
+        if constexpr (CD) {
+            if (grad_c) grad_c[b * J + tid] = sh.rc[tid];
+            if (grad_d) grad_d[b * J + tid] = sh.rd[tid];
+        }
     }
     if (tid == 0) {
         if (grad_mu) grad_mu[b] = sh.rs[0];
@@ -1409,7 +1487,7 @@ int launch_block(const ScanParams& p, const double* btab, hipStream_t stream)
 
 template <int NB>
 int launch_block_grad(const ScanParams& p, const double* btab, const double* gtab, double* ga, double* gb, double* gnu, double* gmu,
-                      hipStream_t stream)
+                      double* gc, double* gd, hipStream_t stream)
 {
     const size_t lds = block_lds_bytes(NB, p.J, 0);
     if (lds > kBlockLdsMax) return PIORAN_ERR_UNSUPPORTED;
@@ -1422,7 +1500,10 @@ int launch_block_grad(const ScanParams& p, const double* btab, const double* gta
         granted[dev] = lds;
     }
     hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, true>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
-    hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB>), dim3((unsigned)p.B), dim3(256), 0, stream, p, btab, gtab, ga, gb, gnu, gmu);
+    if (gc || gd)
+        hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB, true>), dim3((unsigned)p.B), dim3(256), 0, stream, p, btab, gtab, ga, gb, gnu, gmu, gc, gd);
+    else
+        hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB, false>), dim3((unsigned)p.B), dim3(256), 0, stream, p, btab, gtab, ga, gb, gnu, gmu, gc, gd);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
@@ -1452,15 +1533,15 @@ int pioran_launch_block_gtab(int64_t N, int32_t R, int32_t J, const int32_t* row
 // [B][N]) for shared (c, d) without per-draw rows; per-draw series p.Y / p.S2 allowed; p.gw: pioran_block_grad_workspace_doubles;
 // btab, gtab: the two tables of this (c, d)
 int pioran_launch_block_grad(const ScanParams& p, const double* btab, const double* gtab, double* grad_a, double* grad_b, double* grad_nu,
-                             double* grad_mu, hipStream_t stream)
+                             double* grad_mu, double* grad_c, double* grad_d, hipStream_t stream)
 {
     if (!btab || !gtab || !p.gw || p.npd_rows != 0 || p.B < 1 || p.N < 1 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
     if ((p.Y == nullptr) != (p.S2 == nullptr)) return PIORAN_ERR_ARG;
     switch ((p.R + 1 + 15) / 16) {
-        case 1: return launch_block_grad<1>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, stream);
-        case 2: return launch_block_grad<2>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, stream);
-        case 3: return launch_block_grad<3>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, stream);
-        case 4: return launch_block_grad<4>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, stream);
+        case 1: return launch_block_grad<1>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, grad_c, grad_d, stream);
+        case 2: return launch_block_grad<2>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, grad_c, grad_d, stream);
+        case 3: return launch_block_grad<3>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, grad_c, grad_d, stream);
+        case 4: return launch_block_grad<4>(p, btab, gtab, grad_a, grad_b, grad_nu, grad_mu, grad_c, grad_d, stream);
     }
     return PIORAN_ERR_UNSUPPORTED;
 }

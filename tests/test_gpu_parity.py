@@ -1261,20 +1261,25 @@ def test_windowed_gradient_matches_complex_step(ctx, J, N, B, nreal):
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
     Bc[:, :nreal] = 0.0; Dd[:nreal] = 0.0
     ds = pj.Dataset(t, y, s2, ctx)
-    g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+    g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
     assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block (windowed gradient)"
+    g0 = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)          # the variant without d/d(c, d)
+    assert g0["grad_c"] is None and np.array_equal(g0["logl"], g["logl"])
+    for key in ("grad_a", "grad_b", "grad_mu", "grad_nu"):
+        assert np.max(np.abs(g0[key] - g[key])) <= 1e-12 * (1 + np.max(np.abs(g[key])))
     val = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
     assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block"
     assert (g["logl"] == val).all() and (g["status"] == 0).all()
     assert relerr(g["logl"], O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu)) < 1e-11
     try:
         ctx.set_option("no_block", True)
-        old = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+        old = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "wide (step-by-step gradient)"
     finally:
         ctx.set_option("no_block", False)
     for i in range(B):
-        ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2)
-        for key in ("grad_a", "grad_b"):
+        ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, cd=True)
+        for key in ("grad_a", "grad_b", "grad_c", "grad_d"):
             tol = 1e-9 * (1 + np.max(np.abs(ref[key])))
             assert np.max(np.abs(g[key][i] - ref[key])) <= tol, (key, i)
             assert np.max(np.abs(g[key][i] - old[key][i])) <= tol, (key, i)
@@ -1299,12 +1304,16 @@ def test_windowed_gradient_shifted_log_flux_model(ctx, golden_dir):
     f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
     A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, P[:, :3], f_min, f_max, 20, P[:, 3], is_integrated_power=False)
     ds = pj.Dataset(t, y, yerr ** 2, ctx)
-    gw = ds.logl_grad(A, Bc, C, Dd, mu=P[:, 5], nu=P[:, 4], shift=P[:, 6], cd_grad=False)
+    gw = ds.logl_grad(A, Bc, C, Dd, mu=P[:, 5], nu=P[:, 4], shift=P[:, 6])
     assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block (windowed gradient)"
-    go = ds.logl_grad(A, Bc, C, Dd, mu=P[:, 5], nu=P[:, 4], shift=P[:, 6])
+    try:
+        ctx.set_option("no_block", True)
+        go = ds.logl_grad(A, Bc, C, Dd, mu=P[:, 5], nu=P[:, 4], shift=P[:, 6])
+    finally:
+        ctx.set_option("no_block", False)
     assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "wide (step-by-step gradient)"
     assert relerr(gw["logl"], un["logl"][:6]) < 1e-10
-    for k in ("grad_a", "grad_b", "grad_mu", "grad_nu", "grad_shift"):
+    for k in ("grad_a", "grad_b", "grad_c", "grad_d", "grad_mu", "grad_nu", "grad_shift"):
         assert np.max(np.abs(gw[k] - go[k])) <= 1e-8 * (1 + np.max(np.abs(go[k]))), k
 
 
@@ -1317,7 +1326,11 @@ def test_gradient_full_size_and_real_terms(ctx, full_size):
     rng = np.random.default_rng(5)
     for basis, windowed in (("SHO", False), ("DRWCelerite", False), ("SHO", True), ("DRWCelerite", True)):
         A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, 20, basis)
-        g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=not windowed)   # without d/d(c, d): the windowed reverse mode (round 3)
+        try:   # both reverse modes: the windowed one (round 3; the default up to 63 rows) and the step-by-step adjoint kernels
+            ctx.set_option("no_block", not windowed)
+            g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+        finally:
+            ctx.set_option("no_block", False)
         assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == ("block (windowed gradient)" if windowed else "wide (step-by-step gradient)")
         ref_l, rst = O.logl_batch(A, Bc, C, Dd, t, y, yerr ** 2, mu, nu, nthreads=4, return_status=True)
         for i in np.flatnonzero(rst == 0)[:2]:
@@ -1407,25 +1420,28 @@ def test_gradient_wrt_c_and_d_qpo_and_carma(ctx, golden_dir, full_size):
 
 
 def test_gradient_workspace_is_small(ctx, full_size):
-    """64 chains at N = 1e4, J = 20: the reverse pass keeps checkpoints + one replayed segment, not every S_n
-    (180 MB per draw before): the context's memory grows by well under 1 GB, and pioran_ctx_trim gives it back."""
+    """64 chains at N = 1e4, J = 20.  Step-by-step reverse mode: checkpoints + one replayed segment, not every S_n (180 MB per draw
+    in round 1): ~10 MB per draw, the context grows by well under 1 GB.  Windowed reverse mode (round 3): what the forward pass leaves
+    per 16-step window (T, M', Q' twice, Sigma^-1: 38 KB) = 24 MB per draw, under 2 GB.  pioran_ctx_trim gives either back."""
     import torch
     t, y, yerr = full_size
     th = O.synthetic_theta(64, t, y, seed=3)
     A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, 20, "SHO")
-    c2 = pj.Context(0)
-    ds = pj.Dataset(t, y, yerr ** 2, c2)
-    ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
-    g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
-    used = free0 - torch.cuda.mem_get_info()[0]
-    assert used < 1.0e9, used
-    ok = g["status"] == 0
-    assert ok.sum() > 32 and relerr(g["logl"][ok], ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)[ok]) < 1e-10
-    c2.trim()
-    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
-    ds.close(); c2.close()
+    for mode, bound in (("windowed", 2.0e9), ("step-by-step", 1.0e9)):
+        c2 = pj.Context(0)
+        c2.set_option("no_block", mode != "windowed")
+        ds = pj.Dataset(t, y, yerr ** 2, c2)
+        val = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+        used = free0 - torch.cuda.mem_get_info()[0]
+        assert used < bound, (mode, used)
+        ok = g["status"] == 0
+        assert ok.sum() > 32 and relerr(g["logl"][ok], val[ok]) < 1e-10
+        c2.trim()
+        assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+        ds.close(); c2.close()
 
 
 def test_gradient_wrt_sampled_parameters(ctx, golden_dir):
