@@ -487,6 +487,23 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
     dsm.close()
     out["small_batch_B256_per_draw_cd"] = pd_small
 
+    # -- value + gradient (what NUTS drives: test/test_likelihood.jl:55-60, docs/src/turing.md) — windowed reverse mode, host entry -----
+    Ag, Bg, Cg, Dg = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:64, :3], f_min, f_max, J, theta[:64, 3], basis_function="SHO")
+    dsg = pj.Dataset(t, y, s2, ctx)
+    grad = {}
+    for nb_ in (1, 64):
+        dsg.logl_grad(Ag[:nb_], Bg[:nb_], Cg, Dg, mu=mu[:nb_], nu=nu[:nb_])
+        kern = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+        wall = []
+        for _ in range(3):
+            t0 = time.perf_counter(); gg = dsg.logl_grad(Ag[:nb_], Bg[:nb_], Cg, Dg, mu=mu[:nb_], nu=nu[:nb_]); wall.append(time.perf_counter() - t0)
+        grad[f"chains_{nb_}"] = {"value_and_gradient_abcd_mu_nu_ms_incl_pcie": med(wall) * 1e3, "kernel": kern}
+    da_ = np.ones(J)
+    dref = O.logl_dir(Ag[0], Bg[0], Cg, Dg, t, y - mu[0], nu[0] * s2, da=da_)
+    grad["directional_check_rel_vs_complex_step_oracle"] = float(abs(gg["grad_a"][0].sum() - dref) / (1 + abs(dref)))
+    dsg.close()
+    out[f"gradient_sho{J}_N{N}"] = grad
+
     # -- dense path: configs[4], N = 4096, J = 40 (SHO-40) -------------------------------------------------------------
     Nd, Jd = min(4096, N), 40
     td, yd, ed = t[:Nd], y[:Nd], yerr[:Nd]
