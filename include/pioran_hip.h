@@ -182,7 +182,7 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
  * C, Dd: [J] when cd_shared != 0, else [B][J] (each draw is then evaluated as its own one-draw batch).
  * Two reverse modes.  With 6 .. 63 rows the WINDOWED reverse mode runs (celerite_block.hip, round 3): the windowed forward pass leaves T,
  * M', Sigma^-1 X' and Sigma^-1 of every 16-step window (38 KB per window at J = 20: 24 MB per draw at N = 1e4) and the adjoint kernel
- * walks the windows backwards with six GEMM stages each — value + gradient 6.3 ms for one chain, 6.7 ms for 256 (7.2 .. 7.7 ms with
+ * walks the windows backwards with six GEMM stages each — value + gradient 6.2 ms for one chain, 6.6 ms for 256 (7.0 .. 7.5 ms with
  * grad_c / grad_d), against 25 .. 35 ms for the step-by-step adjoint below, which remains the path for 64 .. 95 rows and as a
  * cross-check (context option "no_block").
  * Memory (step-by-step mode): the forward pass keeps the R x R state only at checkpoints (every ~2 sqrt(N) steps) and the reverse pass replays one

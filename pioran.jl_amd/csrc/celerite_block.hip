@@ -1074,7 +1074,7 @@ struct BlockAdjShared {
     double2 albe[64];
     double ra[64], rb[64];      // per-term reductions
     double rc[64], rd[64];
-    double tt[16];
+    double tt[2][16];
     double rs[8];
     unsigned char pn[120], pj[120];
 };
@@ -1086,7 +1086,7 @@ struct BlockAdjShared {
 //             cK-_r = 2 sum_j T-'_rj cK_j T_rj - sum_n X-'[n][r] M'[n][r]
 //   d/dd_r += s_r sum_n t_n (U~-'[n][r] (al_r C x - be_r C v)[n][r] + X-'[n][r] ((C_K / C) x)[n][r]),  s_r = -1 (cos row), +1 (sin row)
 //   d/dc_t -= 2 sum_pairs S-_jn tau (a_t E.cos + b_t E.sin);   d/dd_t += 2 sum_pairs S-_jn tau (b_t E.cos - a_t E.sin)
-template <int NB, bool CD>
+template <int NB, bool CD, int TPT /*contraction threads per term: 8 (up to 32 terms) or 4*/>
 __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const ScanParams p, const double* __restrict__ btab,
                                                                                       const double* __restrict__ gtab, double* __restrict__ grad_a,
                                                                                       double* __restrict__ grad_b, double* __restrict__ grad_nu,
@@ -1138,7 +1138,7 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
     const double2 myab = owner ? sh.albe[16 * w + c16] : double2{0.0, 0.0};
 
     // pair contraction threads: TPT threads per term, each a subset of the 120 pairs
-    const int TPT = J <= 32 ? 8 : 4;                        // TPT * J <= 256 threads
+    static_assert(TPT == 8 || TPT == 4, "TPT * J <= 256 threads");
     const bool ethread = tid < TPT * J;
     const int et = tid / TPT, es = tid - et * TPT;
     double acc_ga = 0.0, acc_gb = 0.0;
@@ -1240,7 +1240,7 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                 tbw = grec[OFF_TM + 16];
                 tew = grec[OFF_TM + 17];
             }
-            if (chain && lane < 16) sh.tt[lane] = grec[OFF_TM + lane];   // (read by the contraction threads after barrier 2; rewritten after barrier 3 at the earliest)
+            if (chain && lane < 16) sh.tt[par][lane] = grec[OFF_TM + lane];   // (read by the contraction threads after barrier 2, up to the end of the window)
         }
         if (owner) {
 #pragma unroll
@@ -1254,12 +1254,15 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                     tk[I][g] = gwk[((w * NB + I) * 4 + g) * 64 + lane];
                 }
         }
-        if (ethread && TPT == 8) {
-            const double2* E = reinterpret_cast<const double2*>(btab + k * RSB + TSP) + et * 128;
+        // pair table of the window: fifteen entries per contraction thread are in flight at a time — all of a thread's pairs with eight
+        // threads per term (up to 32 terms); with four (more terms: DRWCelerite-20 has 40) the second fifteen are fetched into the same
+        // registers while phase C runs and contracted in phase D
+        const double2* Ewin = reinterpret_cast<const double2*>(btab + k * RSB + TSP) + et * 128;
+        if (ethread) {
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
                 const int pp = es + i * TPT;
-                ev[i] = pp < 120 ? E[pp] : double2{0.0, 0.0};
+                ev[i] = pp < 120 ? Ewin[pp] : double2{0.0, 0.0};
             }
         }
         double nqf[NB][4], nqw[4], ncvc[4], ncxc[4], ns2w = 0.0;
@@ -1304,36 +1307,30 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                 sh.tileM[par][w][(4 * g + q) * 18 + c16] = mbw[g];
             }
         }
-        if (ethread) {   // d/da_t, d/db_t: 2 sum over the window's pairs of S-_jn E_t,p
-            if (TPT == 8) {
+        auto contract = [&](int i0) __attribute__((always_inline)) {   // d/da_t, d/db_t (, d/dc_t, d/dd_t): 2 sum over pairs of S-_jn E_t,p (tau ...)
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) {
-                    const int pp = es + i * TPT;
-                    if (pp < 120) {
-                        const int nn = sh.pn[pp], jj = sh.pj[pp];
-                        const double sv = sh.Srm[nn * 16 + jj] + sh.Srm[jj * 16 + nn];
-                        acc_ga = fma(sv, ev[i].x, acc_ga);
-                        acc_gb = fma(sv, ev[i].y, acc_gb);
-                        if constexpr (CD) {
-                            const double st = sv * (sh.tt[nn] - sh.tt[jj]);
-                            acc_gc = fma(-st, fma(ea, ev[i].x, eb * ev[i].y), acc_gc);
-                            acc_gd = fma(st, fma(eb, ev[i].x, -ea * ev[i].y), acc_gd);
-                        }
-                    }
-                }
-            } else {
-                const double2* E = reinterpret_cast<const double2*>(btab + k * RSB + TSP) + et * 128;
-                for (int pp = es; pp < 120; pp += TPT) {
+            for (int i = 0; i < EPT; ++i) {
+                const int pp = es + (i0 + i) * TPT;
+                if (pp < 120) {
                     const int nn = sh.pn[pp], jj = sh.pj[pp];
                     const double sv = sh.Srm[nn * 16 + jj] + sh.Srm[jj * 16 + nn];
-                    const double2 e = E[pp];
-                    acc_ga = fma(sv, e.x, acc_ga);
-                    acc_gb = fma(sv, e.y, acc_gb);
+                    acc_ga = fma(sv, ev[i].x, acc_ga);
+                    acc_gb = fma(sv, ev[i].y, acc_gb);
                     if constexpr (CD) {
-                        const double st = sv * (sh.tt[nn] - sh.tt[jj]);
-                        acc_gc = fma(-st, fma(ea, e.x, eb * e.y), acc_gc);
-                        acc_gd = fma(st, fma(eb, e.x, -ea * e.y), acc_gd);
+                        const double st = sv * (sh.tt[par][nn] - sh.tt[par][jj]);
+                        acc_gc = fma(-st, fma(ea, ev[i].x, eb * ev[i].y), acc_gc);
+                        acc_gd = fma(st, fma(eb, ev[i].x, -ea * ev[i].y), acc_gd);
                     }
+                }
+            }
+        };
+        if (ethread) {
+            contract(0);
+            if (TPT == 4) {
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int pp = es + (EPT + i) * TPT;
+                    ev[i] = pp < 120 ? Ewin[pp] : double2{0.0, 0.0};
                 }
             }
         }
@@ -1382,6 +1379,7 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                     Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][(4 * ks + q) * 18 + c16], hu[ks], Tb[I], 0, 0, 0);
                 }
         }
+        if (ethread && TPT == 4) contract(EPT);
         if (k > 0) {
 #pragma unroll
             for (int I = 0; I < NB; ++I)
@@ -1500,10 +1498,14 @@ int launch_block_grad(const ScanParams& p, const double* btab, const double* gta
         granted[dev] = lds;
     }
     hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, true>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
-    if (gc || gd)
-        hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB, true>), dim3((unsigned)p.B), dim3(256), 0, stream, p, btab, gtab, ga, gb, gnu, gmu, gc, gd);
-    else
-        hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB, false>), dim3((unsigned)p.B), dim3(256), 0, stream, p, btab, gtab, ga, gb, gnu, gmu, gc, gd);
+    const bool cd = gc || gd;
+    if (p.J <= 32) {
+        if (cd) hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB, true, 8>), dim3((unsigned)p.B), dim3(256), 0, stream, p, btab, gtab, ga, gb, gnu, gmu, gc, gd);
+        else hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB, false, 8>), dim3((unsigned)p.B), dim3(256), 0, stream, p, btab, gtab, ga, gb, gnu, gmu, gc, gd);
+    } else {
+        if (cd) hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB, true, 4>), dim3((unsigned)p.B), dim3(256), 0, stream, p, btab, gtab, ga, gb, gnu, gmu, gc, gd);
+        else hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB, false, 4>), dim3((unsigned)p.B), dim3(256), 0, stream, p, btab, gtab, ga, gb, gnu, gmu, gc, gd);
+    }
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 

@@ -339,7 +339,7 @@ end
 
 log L and ∂log L/∂(a_j, b_j, c_j, d_j) (`J × nbatch` each), ∂/∂ν, ∂/∂μ for every draw; with `series = true` also ∂/∂y_n and
 ∂/∂σ²_n (`N × nbatch`).  `cd = false` leaves out ∂/∂(c_j, d_j) — all an `approx`-based model needs, whose `(c, d)` are fixed by the
-spectral grid (6.3 instead of 7.2 ms at N = 1e4, J = 20; `grad_c`, `grad_d` are then `nothing`).  `c`, `d`: length-`J` vectors shared by the draws or `J × nbatch` matrices (QPO features, CARMA,
+spectral grid (6.2 instead of 7.0 ms at N = 1e4, J = 20; `grad_c`, `grad_d` are then `nothing`).  `c`, `d`: length-`J` vectors shared by the draws or `J × nbatch` matrices (QPO features, CARMA,
 free Celerite terms).  This is what a `ChainRulesCore.rrule` / `LogDensityProblems.logdensity_and_gradient` for the GP
 likelihood returns instead of pushing ForwardDiff Duals through `Pioran.logl` (test/test_likelihood.jl:55-60); the chain
 rule from (a, b, c, d) to the PSD parameters goes through `approx`, which stays in Julia.
