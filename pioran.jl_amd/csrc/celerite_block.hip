@@ -1179,9 +1179,13 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
             s2w_ = p.S2 ? (n < N ? p.S2[b * N + n] : 0.0) : grec[2 * NB * 256 + 16 * NB + c16];   // per-draw series: the shifted log-flux models
         }
     };
-    fetch_a(NW - 1, qf, qw, cvc, cxc, kf, s2w);
+    // (four block columns with d/d(c, d): no second register set — the kernel would spill 133 registers — the phase-A operands are
+    //  fetched at the top of their own window)
+    constexpr bool PF = !(NB == 4 && CD);
+    if constexpr (PF) fetch_a(NW - 1, qf, qw, cvc, cxc, kf, s2w);
     for (int64_t k = NW - 1; k >= 0; --k) {
         const int par = (int)(k & 1);
+        if constexpr (!PF) fetch_a(k, qf, qw, cvc, cxc, kf, s2w);
         const double* gwk = gwb + k * GWS;
         const double* grec = gtab + k * GS;
         const int64_t n0 = k * KW;
@@ -1265,11 +1269,13 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                 ev[i] = pp < 120 ? Ewin[pp] : double2{0.0, 0.0};
             }
         }
-        double nqf[NB][4], nqw[4], ncvc[4], ncxc[4], ns2w = 0.0;
-        d4 nkf = {0.0, 0.0, 0.0, 0.0};
+        [[maybe_unused]] double nqf[PF ? NB : 1][4], nqw[4], ncvc[4], ncxc[4], ns2w = 0.0;
+        [[maybe_unused]] d4 nkf = {0.0, 0.0, 0.0, 0.0};
         const double kdiag = s2w;
         d4 kcur = kf;
-        if (k > 0) fetch_a(k - 1, nqf, nqw, ncvc, ncxc, nkf, ns2w);
+        if constexpr (PF) {
+            if (k > 0) fetch_a(k - 1, nqf, nqw, ncvc, ncxc, nkf, ns2w);
+        }
         PIORAN_BLK_BARRIER();   // B1
         // ---- B: S- (chain) -------------------------------------------------------------------------------------------------
         if (chain) {
@@ -1380,7 +1386,7 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                 }
         }
         if (ethread && TPT == 4) contract(EPT);
-        if (k > 0) {
+        if constexpr (PF) if (k > 0) {
 #pragma unroll
             for (int I = 0; I < NB; ++I)
 #pragma unroll
