@@ -1312,6 +1312,95 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
     return PIORAN_OK;
 }
 
+// Per-draw (c, d) in every term, several chains (CARMA kernels, QPO features, free Celerite sums under NUTS): the windowed reverse
+// mode with one pair of tables per draw (the forward table of pioran_launch_block_table_batch and the reverse pass's), all chains in
+// one launch — 16 chains in the time of one instead of 16 one-draw calls.  Returns PIORAN_ERR_UNSUPPORTED when the shape does not
+// fit the windowed kernel (the caller then evaluates draw by draw).
+static int logl_grad_perdraw_windowed(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                                      const double* Dd, const double* mu, const double* nu, double* out, int32_t* status,
+                                      double* grad_a, double* grad_b, double* grad_c, double* grad_d, double* grad_nu, double* grad_mu,
+                                      double* grad_y, double* grad_sigma2)
+{
+    pioran_ctx* ctx = ds->ctx;
+    PrepState& s = ds->host;
+    if (ctx->opt.no_block || ctx->opt.force_fallback || ctx->opt.scan_config[0] || 2 * J < 6 || !pioran_block_fits((int32_t)(2 * J), (int32_t)J))
+        return PIORAN_ERR_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PendingGuard pending_guard(ctx);
+    int rc;
+    if ((rc = prepare_state(ds, s, J, C, Dd, nullptr))) return rc;    // row map with both rows of every term (tables of draw 0: unused)
+    const int64_t N = ds->N;
+    const int64_t bt = (int64_t)pioran_block_table_doubles(N, s.R, s.J), gt = (int64_t)pioran_block_gtab_doubles(N, s.R);
+    const size_t per_draw = ((size_t)bt + (size_t)gt + pioran_block_grad_workspace_doubles(1, N, s.R)) * sizeof(double);
+    int64_t chunk = B < 256 ? B : 256;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            while (chunk > 1 && (size_t)chunk * per_draw > free_b / 2 + ctx->bwork.cap + ctx->bscratch.cap + ctx->bgtab.cap) chunk /= 2;
+    }
+    for (;;) {
+        rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bscratch, (size_t)chunk * (size_t)bt * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bgtab, (size_t)chunk * (size_t)gt * sizeof(double));
+        if (rc != PIORAN_ERR_ALLOC || chunk == 1) break;
+        chunk /= 2;
+    }
+    if (rc) return rc;
+    const size_t cj = (size_t)chunk * (size_t)J * sizeof(double), cn = (size_t)chunk * (size_t)N * sizeof(double);
+    if ((rc = ensure(ctx, ctx->bK, 4 * cj))) return rc;                   // grad_a | grad_b | grad_c | grad_d of the chunk
+    if ((rc = ensure(ctx, ctx->bshift, 2 * chunk * sizeof(double)))) return rc;   // grad_nu | grad_mu
+    const bool want_series = grad_y || grad_sigma2;
+    if (want_series && (rc = ensure(ctx, ctx->bY, cn))) return rc;
+    if (want_series && (rc = ensure(ctx, ctx->bS2, cn))) return rc;
+    if ((rc = ensure(ctx, ctx->bout, chunk * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t)))) return rc;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+        const size_t nbj = (size_t)nb * J * sizeof(double);
+        if ((rc = upload(ctx, ctx->bA, A + b0 * J, nbj))) return rc;
+        if ((rc = upload(ctx, ctx->bB, Bc + b0 * J, nbj))) return rc;
+        if ((rc = upload(ctx, ctx->bC, C + b0 * J, nbj))) return rc;
+        if ((rc = upload(ctx, ctx->bD, Dd + b0 * J, nbj))) return rc;
+        if (mu && (rc = upload(ctx, ctx->bmu, mu + b0, nb * sizeof(double)))) return rc;
+        if (nu && (rc = upload(ctx, ctx->bnu, nu + b0, nb * sizeof(double)))) return rc;
+        double* btab = (double*)ctx->bscratch.p; double* gtab = (double*)ctx->bgtab.p;
+        if ((rc = pioran_launch_block_table_batch(N, s.R, s.J, nb, s.rowmap, ds->t, (const double*)ctx->bC.p, (const double*)ctx->bD.p, ds->y, ds->s2,
+                                                  btab, bt, ctx->stream))) return rc;
+        if ((rc = pioran_launch_block_gtab_batch(N, s.R, s.J, nb, s.rowmap, ds->t, (const double*)ctx->bC.p, (const double*)ctx->bD.p, ds->s2, gtab,
+                                                 gt, ctx->stream))) return rc;
+        ScanParams p{};
+        p.opt = &ctx->opt;
+        p.N = N; p.J = s.J; p.R = s.R; p.B = nb; p.standard_rows = 1;
+        p.rec_stride = 3 * (int64_t)(s.R + 2) + 2;
+        p.tab_draw_stride = bt; p.gtab_draw_stride = gt;
+        p.rowmap = s.rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+        p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = (const double*)ctx->bC.p; p.D = (const double*)ctx->bD.p;
+        p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
+        p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
+        p.g_y = want_series ? (double*)ctx->bY.p : nullptr;
+        p.g_s2 = want_series ? (double*)ctx->bS2.p : nullptr;
+        p.gw = (double*)ctx->bwork.p;
+        double* dga = (double*)ctx->bK.p; double* dgb = dga + (size_t)chunk * J;
+        double* dgc = dgb + (size_t)chunk * J; double* dgd = dgc + (size_t)chunk * J;
+        double* dgn = (double*)ctx->bshift.p; double* dgm = dgn + chunk;
+        g_last_kernel = "block (windowed gradient, per-draw tables)";
+        rc = pioran_launch_block_grad(p, btab, gtab, dga, dgb, dgn, dgm, grad_c ? dgc : nullptr, grad_d ? dgd : nullptr, ctx->stream);
+        if (rc) { ctx->last_err = "windowed gradient launch failed"; return rc; }
+        if ((rc = download(ctx, out + b0, ctx->bout.p, nb * sizeof(double)))) return rc;
+        if (status) if ((rc = download(ctx, status + b0, ctx->bst.p, nb * sizeof(int32_t)))) return rc;
+        if ((rc = download(ctx, grad_a + b0 * J, dga, nbj))) return rc;
+        if ((rc = download(ctx, grad_b + b0 * J, dgb, nbj))) return rc;
+        if (grad_c) if ((rc = download(ctx, grad_c + b0 * J, dgc, nbj))) return rc;
+        if (grad_d) if ((rc = download(ctx, grad_d + b0 * J, dgd, nbj))) return rc;
+        if (grad_nu) if ((rc = download(ctx, grad_nu + b0, dgn, nb * sizeof(double)))) return rc;
+        if (grad_mu) if ((rc = download(ctx, grad_mu + b0, dgm, nb * sizeof(double)))) return rc;
+        if (grad_y) if ((rc = download(ctx, grad_y + b0 * N, ctx->bY.p, (size_t)nb * N * sizeof(double)))) return rc;
+        if (grad_sigma2) if ((rc = download(ctx, grad_sigma2 + b0 * N, ctx->bS2.p, (size_t)nb * N * sizeof(double)))) return rc;
+        SYNC(ctx);
+    }
+    return PIORAN_OK;
+}
+
 static int logl_grad_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
                           const double* Dd, int cd_shared, const double* mu, const double* nu, const double* shift, double* out,
                           int32_t* status, double* grad_a, double* grad_b, double* grad_c, double* grad_d, double* grad_nu,
@@ -1322,8 +1411,13 @@ static int logl_grad_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
     if (cd_shared || B == 1)
         return logl_grad_shared(ds, B, J, A, Bc, C, Dd, mu, nu, shift, out, status, grad_a, grad_b, grad_c, grad_d, grad_nu, grad_mu,
                                 grad_y, grad_sigma2, grad_shift);
-    // per-draw (c, d) — CARMA, QPO features, free Celerite sums under NUTS (a handful of chains): every draw is its own
-    // one-draw batch with its own table
+    // per-draw (c, d) — CARMA, QPO features, free Celerite sums under NUTS (a handful of chains): all chains in one launch of the
+    // windowed reverse mode where the shape fits it, else every draw is its own one-draw batch with its own table
+    if (!shift) {
+        const int rc = logl_grad_perdraw_windowed(ds, B, J, A, Bc, C, Dd, mu, nu, out, status, grad_a, grad_b, grad_c, grad_d, grad_nu, grad_mu,
+                                                  grad_y, grad_sigma2);
+        if (rc != PIORAN_ERR_UNSUPPORTED) return rc;
+    }
     const int64_t N = ds->N;
     for (int64_t b = 0; b < B; ++b) {
         const int rc = logl_grad_shared(ds, 1, J, A + b * J, Bc + b * J, C + b * J, Dd + b * J, mu ? mu + b : nullptr,

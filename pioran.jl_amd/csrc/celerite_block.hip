@@ -999,9 +999,13 @@ __host__ __device__ inline int64_t block_gtab_doubles(int NB) { return 4 * (int6
 
 __global__ void __launch_bounds__(256) block_gtable_window_kernel(int64_t N, int32_t R, int32_t J, int32_t NB, const int32_t* __restrict__ rowmap,
                                                                   const double* __restrict__ t, const double* __restrict__ c,
-                                                                  const double* __restrict__ d, const double* __restrict__ s2, double* __restrict__ tab)
+                                                                  const double* __restrict__ d, const double* __restrict__ s2, double* __restrict__ tab,
+                                                                  int64_t cd_stride, int64_t tab_draw_stride)
 {
     __shared__ double cs[64 * 16], sn[64 * 16], Cn[64 * 16], Hn[64 * 16], ckt[64];
+    c += (int64_t)blockIdx.y * cd_stride;          // blockIdx.y: draw of a batch of per-draw tables
+    d += (int64_t)blockIdx.y * cd_stride;
+    tab += (int64_t)blockIdx.y * tab_draw_stride;
     const int64_t GS = block_gtab_doubles(NB);
     const int64_t k = blockIdx.x;
     const int64_t n0 = k * KW;
@@ -1116,6 +1120,8 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
     const double* __restrict__ Ab_ = p.A + b * J;
     const double* __restrict__ Bb_ = p.Bc + b * J;
     const double* gwb = p.gw + b * NW * GWS;
+    btab += b * p.tab_draw_stride;                 // per-draw tables (every term's (c, d) per draw): strides 0 for shared tables
+    gtab += b * p.gtab_draw_stride;
     if (tid < 64) {
         double a = 0.0, bb = 0.0;
         if (tid < R) {
@@ -1531,10 +1537,17 @@ size_t pioran_block_gtab_doubles(int64_t N, int32_t R)
 int pioran_launch_block_gtab(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c, const double* d,
                              const double* s2, double* gtab, hipStream_t stream)
 {
+    return pioran_launch_block_gtab_batch(N, R, J, 1, rowmap, t, c, d, s2, gtab, 0, stream);
+}
+// nb tables at once: draw i uses (c, d) + i J and writes gtab + i draw_stride
+int pioran_launch_block_gtab_batch(int64_t N, int32_t R, int32_t J, int64_t nb, const int32_t* rowmap, const double* t, const double* C,
+                                   const double* D, const double* s2, double* gtab, int64_t draw_stride, hipStream_t stream)
+{
     const int NB = (R + 1 + 15) / 16;
     const int64_t NW = (N + KW - 1) / KW;
-    if (J < 1 || J > kBlockMaxTerms || NB > 4 || NW > 0x7fffffffLL) return PIORAN_ERR_ARG;
-    hipLaunchKernelGGL(block_gtable_window_kernel, dim3((unsigned)NW), dim3(256), 0, stream, N, R, J, NB, rowmap, t, c, d, s2, gtab);
+    if (J < 1 || J > kBlockMaxTerms || NB > 4 || nb < 1 || nb > 65535 || NW > 0x7fffffffLL) return PIORAN_ERR_ARG;
+    hipLaunchKernelGGL(block_gtable_window_kernel, dim3((unsigned)NW, (unsigned)nb), dim3(256), 0, stream, N, R, J, NB, rowmap, t, C, D, s2, gtab,
+                       (int64_t)J, draw_stride);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 // log L (p.out, p.status) and d/d(a_j, b_j) [B][J], d/dnu, d/dmu [B] (either may be nullptr), optionally d/dy_n, d/dsigma2_n (p.g_y, p.g_s2:

@@ -61,6 +61,7 @@ struct ScanParams {
     int32_t npd_rows;     // per-draw rows (2 per per-draw term), 0 if none
     // celerite_block.hip with per-draw rows (the last npd_rows rows of the row map): the per-draw c [B][J] and the compact table of
     // (cos, sin)(d t_n) [B][npd terms][pd_npad][2] (pioran_launch_block_pd_trig)
+    int64_t gtab_draw_stride;   // celerite_block_adjoint_kernel: doubles between per-draw reverse-pass tables (0: one shared table)
     double* gw;           // celerite_block.hip, gradient: workspace [B][windows][block_grad_ws_doubles] the forward pass leaves for the reverse pass
     const double* pd_C;
     const double* pd_trig;
@@ -132,6 +133,8 @@ size_t pioran_block_grad_workspace_doubles(int64_t B, int64_t N, int32_t R);
 size_t pioran_block_gtab_doubles(int64_t N, int32_t R);
 int pioran_launch_block_gtab(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c, const double* d,
                              const double* s2, double* gtab, hipStream_t stream);
+int pioran_launch_block_gtab_batch(int64_t N, int32_t R, int32_t J, int64_t nb, const int32_t* rowmap, const double* t, const double* C /*[nb][J]*/,
+                                   const double* D, const double* s2, double* gtab, int64_t draw_stride, hipStream_t stream);
 int pioran_launch_block_grad(const ScanParams& p, const double* btab, const double* gtab, double* grad_a, double* grad_b, double* grad_nu,
                              double* grad_mu, double* grad_c /*nullptr: not wanted*/, double* grad_d, hipStream_t stream);
 int pioran_launch_block_table_reference(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,

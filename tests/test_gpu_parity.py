@@ -1296,6 +1296,26 @@ def test_windowed_gradient_matches_complex_step(ctx, J, N, B, nreal):
         assert np.max(np.abs(gs["grad_sigma2"][i] - nu[i] * ref["grad_sigma2"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_sigma2"])))
 
 
+@pytest.mark.parametrize("J,N,B", [(3, 50, 4), (7, 33, 3), (12, 100, 5), (20, 130, 3), (31, 40, 2)])
+def test_windowed_gradient_per_draw_cd_all_chains_in_one_launch(ctx, J, N, B):
+    """(c, d) per draw in every term (CARMA kernels, QPO features, free Celerite sums under NUTS): all chains in one launch of the
+    windowed reverse mode, one pair of tables per draw — against the complex-step oracle draw by draw, series gradients included."""
+    rng = np.random.default_rng(9900 + J + N)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B, per_draw_cd=True)
+    ds = pj.Dataset(t, y, s2, ctx)
+    g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, series_grad=True)
+    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block (windowed gradient, per-draw tables)"
+    assert relerr(g["logl"], O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu)) < 1e-11 and (g["status"] == 0).all()
+    for i in range(B):
+        ref = O.logl_grad(A[i], Bc[i], C[i], Dd[i], t, y - mu[i], nu[i] * s2, cd=True, series=True)
+        for key in ("grad_a", "grad_b", "grad_c", "grad_d", "grad_y"):
+            assert np.max(np.abs(g[key][i] - ref[key])) <= 1e-9 * (1 + np.max(np.abs(ref[key]))), (key, i)
+        assert np.max(np.abs(g["grad_sigma2"][i] - nu[i] * ref["grad_sigma2"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_sigma2"])))
+        gm = O.logl_dir(A[i], Bc[i], C[i], Dd[i], t, y - mu[i], nu[i] * s2, dy=-np.ones(N))
+        gn = O.logl_dir(A[i], Bc[i], C[i], Dd[i], t, y - mu[i], nu[i] * s2, ds2=s2)
+        assert abs(g["grad_mu"][i] - gm) <= 1e-9 * (1 + abs(gm)) and abs(g["grad_nu"][i] - gn) <= 1e-9 * (1 + abs(gn))
+
+
 def test_windowed_gradient_shifted_log_flux_model(ctx, golden_dir):
     """The shifted log-flux models (docs/src/turing.md:205-230) through the windowed reverse mode: per-draw transformed series in,
     series gradients chained to d/dshift — equal to the step-by-step adjoint path on the reference's own nested-sampling points."""

@@ -36,6 +36,17 @@ for B in (1, 16, 64, 256):
                                                                for k in ("grad_a", "grad_b", "grad_c", "grad_d", "grad_mu", "grad_nu")))
     res[f"B{B}"] = row
 g = gw
+# (c, d) per draw in every term (CARMA / QPO / free Celerite terms under NUTS): 16 chains
+rngc = np.random.default_rng(5)
+C2 = np.broadcast_to(C, (16, len(C))) * rngc.uniform(0.97, 1.03, (16, len(C))); D2 = np.broadcast_to(Dd, (16, len(C))) * rngc.uniform(0.97, 1.03, (16, len(C)))
+tp, gp = timed(lambda: ds.logl_grad(A[:16], Bc[:16], C2, D2, mu=mu[:16], nu=nu[:16])); kp = name()
+ctx.set_option("no_block", True)
+tq, gq = timed(lambda: ds.logl_grad(A[:16], Bc[:16], C2, D2, mu=mu[:16], nu=nu[:16]), reps=1)
+ctx.set_option("no_block", False)
+okp = (gp["status"] == 0) & (gq["status"] == 0)
+res["per_draw_cd_16_chains"] = {"windowed_full_ms": round(tp, 2), "kernel": kp, "step_by_step_draw_by_draw_ms": round(tq, 2),
+                                "max_rel_diff": float(max(np.max(np.abs(gp[k][okp] - gq[k][okp])) / (1 + np.max(np.abs(gq[k][okp])))
+                                                          for k in ("grad_a", "grad_b", "grad_c", "grad_d", "grad_mu", "grad_nu")))}
 t0 = time.perf_counter(); ref = O.logl_dir(A[0], Bc[0], C, Dd, t, y - mu[0], nu[0] * yerr ** 2, da=np.ones(A.shape[1])); tc = time.perf_counter() - t0
 res["cpu_one_complex_step_ms"] = round(tc * 1e3, 1)
 res["directional_check_rel"] = float(abs(g["grad_a"][0].sum() - ref) / (1 + abs(ref)))
