@@ -208,7 +208,10 @@ int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, c
                              const double* C, const double* Dd, int cd_shared, const double* t, const double* sigma2,
                              const double* q, double* y_out);
 /* Name of the kernel configuration a large batch with R active rows (all terms with both rows when R is even) runs on;
- * R <= 0: the configuration the calling thread's last throughput-layout launch actually ran on (diagnostics). */
+ * R == 0: the configuration the calling thread's last throughput-layout launch actually ran on; R < 0: the kernel FAMILY of the
+ * calling thread's last launch — "block" (windowed kernel), "block+pd" (with per-draw rows), "block (per-draw tables)", "wide"
+ * (latency layout), "scan" (throughput layouts), "fallback", "block (windowed gradient[, per-draw tables])",
+ * "wide (step-by-step gradient)" (diagnostics). */
 const char* pioran_celerite_config_name(int64_t R);
 
 /* ---- in-process farm over several GPUs ---------------------------------------------------------------------------
