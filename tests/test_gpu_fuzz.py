@@ -38,3 +38,58 @@ def test_fuzz_slice_block_and_scan_vs_oracle(capsys):
     assert s["cases"] == NCASES
     assert not s["failures"], s["failures"][:5]
     assert s["worst_dev"] < 1e-8
+
+
+def test_fuzz_windowed_gradient_vs_step_by_step_and_oracle(capsys):
+    """Randomized shapes for the windowed reverse mode (celerite_block_adjoint_kernel): 300 seeded cases — 3..31 terms, some of them
+    one-row terms, N = 1..400 with occasional long gaps, 1..4 chains, shared or per-draw (c, d) — every gradient component against
+    the step-by-step adjoint kernels (a different algorithm on a different kernel), every tenth case against the complex-step oracle."""
+    import numpy as np
+    import pioran_jl_amd as pj
+    from oracle import oracle as O
+    ctx = pj.Context(0)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    worst = {"dev": 0.0}
+    keys = ("grad_a", "grad_b", "grad_c", "grad_d", "grad_mu", "grad_nu")
+    for idx in range(300):
+        rng = np.random.default_rng([20261004, idx])
+        J = int(rng.integers(3, 32)); N = int(rng.integers(1, 401)); B = int(rng.integers(1, 5))
+        gaps = rng.uniform(0.05, 2.0, N)
+        if rng.random() < 0.3:
+            gaps[rng.integers(0, N, max(1, N // 20))] *= rng.uniform(5, 400)
+        t = np.cumsum(gaps); y = rng.standard_normal(N); s2 = rng.uniform(0.01, 0.1, N)
+        A = rng.uniform(0.1, 2.0, (B, J)); Bc = rng.uniform(-0.05, 0.05, (B, J)) * A
+        per_draw = bool(rng.random() < 0.35) and B > 1
+        C = rng.uniform(0.05, 2.0, (B, J) if per_draw else (J,)); Dd = rng.uniform(0.0, 3.0, (B, J) if per_draw else (J,))
+        nreal = 0 if per_draw else int(rng.integers(0, J // 2 + 1)) * int(rng.random() < 0.4)
+        Bc[:, :nreal] = 0.0
+        if not per_draw:
+            Dd[:nreal] = 0.0
+        mu = rng.standard_normal(B) * 0.1; nu = rng.uniform(0.5, 2.0, B)
+        ds = pj.Dataset(t, y, s2, ctx)
+        gw = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+        R = 2 * J - nreal
+        want = "block (windowed gradient, per-draw tables)" if per_draw else ("block (windowed gradient)" if R >= 6 else "wide (step-by-step gradient)")
+        assert name() == want, (idx, name(), R)     # (fewer than six rows: not worth a 16-row block column)
+        try:
+            ctx.set_option("no_block", True)
+            go = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+        finally:
+            ctx.set_option("no_block", False)
+        ok = (gw["status"] == 0) & (go["status"] == 0)
+        assert np.array_equal(gw["status"], go["status"]), idx
+        for k in keys:
+            if not ok.any():
+                continue
+            dev = float(np.max(np.abs(gw[k][ok] - go[k][ok])) / (1 + np.max(np.abs(go[k][ok]))))
+            if dev > worst["dev"]:
+                worst = {"dev": dev, "idx": idx, "key": k, "J": J, "N": N, "B": B, "nreal": nreal, "per_draw": per_draw}
+        if idx % 10 == 0 and ok[0]:
+            cd0 = (C[0], Dd[0]) if per_draw else (C, Dd)
+            ref = O.logl_grad(A[0], Bc[0], cd0[0], cd0[1], t, y - mu[0], nu[0] * s2, cd=True)
+            for k in ("grad_a", "grad_b", "grad_c", "grad_d"):
+                assert np.max(np.abs(gw[k][0] - ref[k])) <= 1e-8 * (1 + np.max(np.abs(ref[k]))), (idx, k)
+        ds.close()
+    with capsys.disabled():
+        print(f"\nwindowed gradient fuzz: 300 cases, worst deviation from the step-by-step adjoint {worst}", file=sys.stderr)
+    assert worst["dev"] < 1e-8, worst
