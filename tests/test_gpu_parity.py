@@ -165,6 +165,27 @@ def test_random_batches_per_draw_cd(ctx, J, layout):
         assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == ("block" if J >= 3 else "scan")
 
 
+@pytest.mark.parametrize("J,N,B", [(20, 100, 300), (16, 49, 700), (23, 33, 1000), (9, 80, 400), (20, 260, 513)])
+def test_windowed_kernel_pair_table_modes_agree(ctx, J, N, B):
+    """Above 256 draws the windowed kernel reads its pair table from global memory where that lets two workgroups share a CU (round 3);
+    one LDS buffer, two, or none: the same numbers to the last bit, and the oracle's."""
+    rng = np.random.default_rng(5100 + J + N)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    ds = pj.Dataset(t, y, s2, ctx)
+    outs = {}
+    try:
+        ctx.set_option("scan_config", "block")
+        for em in (None, 0, 1, 2):
+            ctx.set_option("block_emode", em)
+            outs[em] = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+            assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block"
+    finally:
+        ctx.set_option("block_emode", None); ctx.set_option("scan_config", None)
+    for em in (0, 1, 2):
+        assert np.array_equal(outs[em], outs[None]), em
+    assert relerr(outs[None], O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)) < 1e-11
+
+
 def test_windowed_table_kernels_agree(ctx):
     """The windowed kernel's table is built by one workgroup per window (transcendentals once per (term, step) / (term, pair));
     the entry-per-thread kernel of round 2 is kept as its cross-check: same expressions on the same arguments, so log L comes out
