@@ -3,6 +3,14 @@
 #include "../../include/pioran_hip.h"
 #include "common.h"
 
+// (celerite_predict.hip; declared here: the windowed prediction was added after the PMC profiles of common.h's kernels were taken)
+size_t pioran_predict_q_workspace_doubles(int64_t B, int64_t N, int32_t R);
+int pioran_launch_block_solve(const ScanParams& p, const double* btab, const double* gtab, double* gy, hipStream_t stream);   // celerite_block.hip
+size_t pioran_predict_tau_workspace_doubles(int64_t M, int32_t R);
+int pioran_launch_predict_from_gy(ScanParams p, double* work, double* tau_work, const double* t, int64_t M, const double* tau, double* mean_out,
+                                  hipStream_t stream);
+
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1150,8 +1158,33 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
     if (s.R > pioran_wide_supported_rows() || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
-    const int64_t chunk = B < 256 ? B : 256;
-    if ((rc = ensure(ctx, ctx->bwork, pioran_predict_workspace_doubles(chunk, ds->N, s.R) * sizeof(double)))) return rc;
+    int64_t chunk = B < 256 ? B : 256;
+    // Windowed path (round 3): z = K^-1 (y - mu) from the windowed factorisation and a block back-substitution (celerite_block.hip),
+    // then the two Q recurrences segment-parallel (celerite_predict.hip) — no step-by-step factor, no per-step wave reduction
+    bool windowed = !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R >= 6 && s.R <= 63 &&
+                    pioran_block_fits(s.R, s.J);
+    if (windowed) {
+        rc = ensure_btab(ds, s);
+        if (rc == PIORAN_ERR_UNSUPPORTED) windowed = false;
+        else if (rc) return rc;
+    }
+    if (windowed) {
+        size_t free_b = 0, total_b = 0;
+        auto need = [&](int64_t nb) {
+            return (pioran_block_grad_workspace_doubles(nb, ds->N, s.R) + pioran_predict_q_workspace_doubles(nb, ds->N, s.R)) * sizeof(double);
+        };
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            while (chunk > 1 && need(chunk) > free_b / 2 + ctx->bwork.cap + ctx->bscratch.cap) chunk /= 2;
+        rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bscratch, pioran_predict_q_workspace_doubles(chunk, ds->N, s.R) * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bgtab, pioran_block_gtab_doubles(ds->N, s.R) * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bK, pioran_predict_tau_workspace_doubles(M, s.R) * sizeof(double));
+        if (rc == PIORAN_ERR_ALLOC) { windowed = false; chunk = B < 256 ? B : 256; }
+        else if (rc) return rc;
+        if (windowed && (rc = pioran_launch_block_gtab(ds->N, s.R, s.J, s.rowmap, ds->t, s.dc, s.dd, ds->s2, (double*)ctx->bgtab.p, ctx->stream)))
+            return rc;
+    }
+    if (!windowed && (rc = ensure(ctx, ctx->bwork, pioran_predict_workspace_doubles(chunk, ds->N, s.R) * sizeof(double)))) return rc;
     if ((rc = upload(ctx, ctx->bshift, tau, (size_t)M * sizeof(double)))) return rc;          // tau
     if ((rc = ensure(ctx, ctx->bY, (size_t)chunk * (size_t)M * sizeof(double)))) return rc;   // mean [chunk][M]
     if ((rc = ensure(ctx, ctx->bout, chunk * sizeof(double)))) return rc;
@@ -1170,8 +1203,19 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
         p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = s.dc; p.D = s.dd;
         p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
         p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
-        rc = pioran_launch_predict(p, (double*)ctx->bwork.p, ds->t, M, (const double*)ctx->bshift.p, (double*)ctx->bY.p,
-                                   ctx->stream);
+        if (windowed) {
+            p.opt = &ctx->opt;
+            p.gw = (double*)ctx->bwork.p;
+            g_last_kernel = "block (windowed prediction)";
+            // -z = -K^-1 (y - mu) [nb][N] into the head of the Q workspace
+            rc = pioran_launch_block_solve(p, s.btab, (const double*)ctx->bgtab.p, (double*)ctx->bscratch.p, ctx->stream);
+            if (!rc) rc = pioran_launch_predict_from_gy(p, (double*)ctx->bscratch.p, (double*)ctx->bK.p, ds->t, M, (const double*)ctx->bshift.p, (double*)ctx->bY.p,
+                                                        ctx->stream);
+        } else {
+            g_last_kernel = "wide (step-by-step prediction)";
+            rc = pioran_launch_predict(p, (double*)ctx->bwork.p, ds->t, M, (const double*)ctx->bshift.p, (double*)ctx->bY.p,
+                                       ctx->stream);
+        }
         if (rc) { ctx->last_err = "prediction launch failed"; return rc; }
         if ((rc = download(ctx, mean_out + b0 * M, ctx->bY.p, (size_t)nb * M * sizeof(double)))) return rc;
         if (status) if ((rc = download(ctx, status + b0, ctx->bst.p, nb * sizeof(int32_t)))) return rc;

@@ -1521,7 +1521,127 @@ int launch_block_grad(const ScanParams& p, const double* btab, const double* gta
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
+// ---- z = K^-1 (y - mu) by block back-substitution (the prediction's first half; round 3) ---------------------------------------
+// The windowed factorisation is a block LDL' of the covariance with 16-step blocks: the block of L between a later window v and
+// window w is U~_v Phi Q_w' (Phi: the decay between the two windows), Q_w = Sigma_w^-1 X_w as left by the forward pass (ST).  Hence
+//   z_w = q_y,w - Q_w h ,      h <- C_K o h + U~_w z_w        (windows backwards; h = sum over later windows of decayed U~ z)
+// With h[y row] held at -1 the product Q_w h is -z_w in one go (the y row of U~ is zero and its C_K is one, so it stays -1).
+// One wavefront per draw; both products on the matrix cores with the vector replicated over the 16 columns: Q_w is stored in A-operand
+// order (OFF_QF), the result's C/D registers are the A operand of the second product as they are, and U~ in C/D order (the reverse
+// pass's table) is its B operand; only h needs one LDS round trip per window (row index from lane & 15 to lane >> 4).
+// Output: gy[b][n] = -z_n (what the reverse mode calls dL/dy: pioran_launch_predict_from_gy takes it from there).
+template <int NB>
+__global__ void __launch_bounds__(64) celerite_block_backsolve_kernel(const ScanParams p, const double* __restrict__ gtab, double* __restrict__ gy)
+{
+    constexpr int64_t GWS = (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256;
+    constexpr int OFF_QF = NB * NB * 256 + 2 * NB * 256;
+    constexpr int64_t GTS = 4 * (int64_t)NB * 256 + 16 * NB + 16 + 24;
+    __shared__ double hs[NB * 16];
+    const int64_t b = blockIdx.x, N = p.N, NW = (N + KW - 1) / KW;
+    const int lane = threadIdx.x, q = lane >> 4, c16 = lane & 15;
+    const int R = p.R, J = p.J;
+    double al[NB], be[NB], h[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        const int row = 16 * I + c16;
+        al[I] = be[I] = 0.0;
+        if (row < R) {
+            const int rm = p.rowmap[row];
+            const int term = rm & 0xfffff;
+            const bool ks = (rm >> 30) & 1;
+            al[I] = p.A[b * J + term];
+            be[I] = ks ? -p.Bc[b * J + term] : p.Bc[b * J + term];
+        }
+        h[I] = row == R ? -1.0 : 0.0;
+    }
+    const double* gwb = p.gw + b * NW * GWS + OFF_QF + lane;
+    const double* gtl = gtab + lane;
+    // operands of one window: Q (A-operand order), C o v and C o x (C/D order), C_K — fetched a window ahead of their use
+    struct Ops { double qf[NB][4], cv[NB][4], cx[NB][4], ck[NB]; };
+    auto fetch = [&](int64_t k, Ops& o) __attribute__((always_inline)) {
+        const double* gq = gwb + k * GWS;
+        const double* gt = gtl + k * GTS;
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                o.qf[I][ks] = gq[(I * 4 + ks) * 64];
+                o.cv[I][ks] = gt[(I * 4 + ks) * 64];
+                o.cx[I][ks] = gt[NB * 256 + (I * 4 + ks) * 64];
+            }
+            o.ck[I] = gtab[k * GTS + 2 * NB * 256 + 16 * I + c16];
+        }
+    };
+    Ops cur, nxt;
+    fetch(NW - 1, cur);
+    for (int64_t k = NW - 1; k >= 0; --k) {
+        fetch(k > 0 ? k - 1 : 0, nxt);
+        if (q == 0) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I) hs[16 * I + c16] = h[I];
+        }
+        __syncthreads();
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.qf[I][ks], hs[16 * I + 4 * ks + q], acc, 0, 0, 0);
+        // acc[g] (every column) = sum_r Q[r][step 4 g + q] h[r] = -z[step]
+        if (c16 == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t n = k * KW + 4 * g + q;
+                if (n < N) gy[b * N + n] = acc[g];
+            }
+        }
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            d4 dh = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                dh = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[ks], fma(al[I], cur.cv[I][ks], be[I] * cur.cx[I][ks]), dh, 0, 0, 0);
+            h[I] = fma(cur.ck[I], h[I], dh[0]);     // (every row of the result is the same vector: U~ z over the rows 16 I + c16)
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+}
+
+template <int NB>
+int launch_block_solve(const ScanParams& p, const double* btab, const double* gtab, double* gy, hipStream_t stream)
+{
+    const size_t lds = block_lds_bytes(NB, p.J, 0);
+    if (lds > kBlockLdsMax) return PIORAN_ERR_UNSUPPORTED;
+    static size_t granted[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
+    if (lds > granted[dev]) {
+        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PIORAN_ERR_HIP;
+        granted[dev] = lds;
+    }
+    hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, true>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
+    hipLaunchKernelGGL((celerite_block_backsolve_kernel<NB>), dim3((unsigned)p.B), dim3(64), 0, stream, p, gtab, gy);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
 }  // namespace
+
+// log L (p.out, p.status) and gy [B][N] = -K^-1 (y - mu): the windowed forward pass with its per-window stores (p.gw:
+// pioran_block_grad_workspace_doubles) followed by the block back-substitution.  gtab: pioran_launch_block_gtab.
+int pioran_launch_block_solve(const ScanParams& p, const double* btab, const double* gtab, double* gy, hipStream_t stream)
+{
+    if (!btab || !gtab || !gy || !p.gw || p.npd_rows != 0 || p.B < 1 || p.N < 1 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    if ((p.Y == nullptr) != (p.S2 == nullptr)) return PIORAN_ERR_ARG;
+    switch ((p.R + 1 + 15) / 16) {
+        case 1: return launch_block_solve<1>(p, btab, gtab, gy, stream);
+        case 2: return launch_block_solve<2>(p, btab, gtab, gy, stream);
+        case 3: return launch_block_solve<3>(p, btab, gtab, gy, stream);
+        case 4: return launch_block_solve<4>(p, btab, gtab, gy, stream);
+    }
+    return PIORAN_ERR_UNSUPPORTED;
+}
 
 // ---- windowed reverse mode: host side ----
 size_t pioran_block_grad_workspace_doubles(int64_t B, int64_t N, int32_t R)

@@ -188,7 +188,197 @@ __global__ void __launch_bounds__(256) predict_eval_kernel(const ScanParams p, c
     out[b * M + m] = acc + (p.mu ? p.mu[b] : 0.0);
 }
 
+// ---- evaluation in two kernels (windowed path): what depends on tau alone is computed once, not once per draw ----------------
+// predict_tau_kernel, one thread per tau_m: n0 (as above) and, per row, ef cos(d tau), ef sin(d tau), eb V_r(tau) with
+// ef = e^{-c (tau - t_{n0-1})}, eb = e^{-c (t_{n0} - tau)} (zero where that side has no data point)  -> W [M][3][RP], RP = R rounded up to 16.
+__global__ void __launch_bounds__(256) predict_tau_kernel(const ScanParams p, const double* __restrict__ t, int64_t M,
+                                                          const double* __restrict__ tau, int32_t* __restrict__ n0s, double* __restrict__ W)
+{
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int64_t N = p.N;
+    const int R = p.R, RP = (R + 15) & ~15;
+    const double tm = tau[m];
+    int64_t lo = 0, hi = N;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (t[mid] < tm) lo = mid + 1; else hi = mid;
+    }
+    n0s[m] = (int32_t)lo;
+    const double dtf = lo > 0 ? tm - t[lo - 1] : 0.0, dtb = lo < N ? t[lo] - tm : 0.0;
+    double* w = W + m * 3 * RP;
+    for (int r = 0; r < RP; ++r) {
+        double wc = 0.0, wsn = 0.0, wv = 0.0;
+        if (r < R) {
+            const int rm = p.rowmap[r];
+            const int term = rm & 0xfffff;
+            const bool ks = (rm >> 30) & 1;
+            const double c = p.C[term], d = p.D[term];
+            double s_, c_;
+            sincos(d * tm, &s_, &c_);
+            const double ef = lo > 0 ? exp(-c * dtf) : 0.0, eb = lo < N ? exp(-c * dtb) : 0.0;
+            wc = ef * c_; wsn = ef * s_; wv = eb * (ks ? s_ : c_);
+        }
+        w[r] = wc; w[RP + r] = wsn; w[2 * RP + r] = wv;
+    }
+}
+
+// predict_eval16_kernel: sixteen lanes per (draw, tau), lane = row (mod 16): the two Q rows and the three W rows of a tau are read
+// as contiguous runs (the one-thread-per-tau kernel above reads them with a stride of R doubles between lanes).
+//   mu_m = sum_r Qf[n0-1][r] (al_r Wc + be_r Ws) + Qb[n0][r] Wv ,   (al, be) = (a, b) on a cos row, (-b, a) on a sin row
+constexpr int EVT = 8;   // taus per 16-lane group
+__global__ void __launch_bounds__(256) predict_eval16_kernel(const ScanParams p, const double* __restrict__ Qf, const double* __restrict__ Qb,
+                                                             int64_t M, const int32_t* __restrict__ n0s, const double* __restrict__ W,
+                                                             double* __restrict__ out)
+{
+    const int64_t b = blockIdx.y, N = p.N;
+    const int R = p.R, RP = (R + 15) & ~15, J = p.J, l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    constexpr int MAXI = 8;   // R <= 128
+    double al[MAXI], be[MAXI];
+    const int ni = RP >> 4;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        al[i] = be[i] = 0.0;
+        const int r = l16 + 16 * i;
+        if (i < ni && r < R) {
+            const int rm = p.rowmap[r];
+            const int term = rm & 0xfffff;
+            const bool ks = (rm >> 30) & 1;
+            const double a = p.A[b * J + term], bb = p.Bc[b * J + term];
+            al[i] = ks ? -bb : a;
+            be[i] = ks ? a : bb;
+        }
+    }
+    const double mu = p.mu ? p.mu[b] : 0.0;
+    const double* qfb = Qf + b * N * R;
+    const double* qbb = Qb + b * N * R;
+    const int64_t m0 = ((int64_t)blockIdx.x * 16 + grp) * EVT;
+#pragma unroll 2
+    for (int e = 0; e < EVT; ++e) {
+        const int64_t m = m0 + e;
+        if (m >= M) break;            // (uniform within the 16-lane group)
+        const int64_t n0 = n0s[m];
+        const double* w = W + m * 3 * RP;
+        const double* qf = qfb + (n0 > 0 ? n0 - 1 : 0) * R;
+        const double* qb = qbb + (n0 < N ? n0 : N - 1) * R;
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int r = l16 + 16 * i;
+            if (i < ni && r < R) {
+                acc = fma(qf[r], fma(al[i], w[r], be[i] * w[RP + r]), acc);   // (W is zero on a side without data: the clamped row is harmless)
+                acc = fma(qb[r], w[2 * RP + r], acc);
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (l16 == 0) out[b * M + m] = acc + mu;
+    }
+}
+
+// ---- the two Q recurrences from a KNOWN z (windowed path below): no reduction, so the series is cut into segments --------------
+// z = K^-1 (y - mu) comes out of the windowed reverse mode as -dL/dy (celerite_block.hip).  Then, per draw and row,
+//   Qf_n = phi_n Qf_{n-1} + z_n V_n        Qb_n = U_n z_n + phi_{n+1} Qb_{n+1}
+// are first-order linear recurrences: segment s (QSEG steps) first computes its own sum with a zero carry (E_s) and the product of
+// its phis (P_s) [pass 0], one wavefront per (draw, direction) chains the carries over the segments [q_carry_kernel], and pass 1
+// repeats the segment from its carry and stores every step.  One workgroup of 64 lanes = one (segment, draw, direction); lane = row.
+constexpr int QSEG = 128;
+
+template <int PASS>
+__global__ void __launch_bounds__(64) q_segment_kernel(const ScanParams p, const double* __restrict__ gy, double* __restrict__ Qf,
+                                                       double* __restrict__ Qb, double* __restrict__ EP, const double* __restrict__ Cin)
+{
+    const int64_t N = p.N, s = blockIdx.x, b = blockIdx.y, nseg = gridDim.x;
+    const int dir = blockIdx.z, lane = threadIdx.x, R = p.R, Rp = R + 2, J = p.J;
+    if (lane >= R) return;
+    const int64_t rec = p.rec_stride;
+    const int64_t n_lo = s * QSEG, n_hi = n_lo + QSEG < N ? n_lo + QSEG : N;
+    const double* zz = gy + b * N;
+    const double* tabr = p.tab + lane;
+    const int64_t slot = ((b * 2 + dir) * nseg + s) * R + lane;
+    if (dir == 0) {
+        double q = PASS ? Cin[slot] : 0.0, prod = 1.0;
+        double* qf = Qf + b * N * R + lane;
+#pragma unroll 4
+        for (int64_t n = n_lo; n < n_hi; ++n) {
+            const double v = tabr[n * rec], ph = n > 0 ? tabr[n * rec + 2 * Rp] : 0.0;
+            q = fma(-zz[n], v, ph * q);                              // z_n = -dL/dy_n
+            if (PASS) qf[n * R] = q; else prod *= ph;
+        }
+        if (!PASS) { EP[2 * slot] = q; EP[2 * slot + 1] = prod; }
+    } else {
+        const int rm = p.rowmap[lane];
+        const int term = rm & 0xfffff;
+        const bool ks = (rm >> 30) & 1;
+        const double al = p.A[b * J + term], be = ks ? -p.Bc[b * J + term] : p.Bc[b * J + term];
+        double q = PASS ? Cin[slot] : 0.0, prod = 1.0;
+        double* qb = Qb + b * N * R + lane;
+#pragma unroll 4
+        for (int64_t n = n_hi - 1; n >= n_lo; --n) {
+            const double u = al * tabr[n * rec] + be * tabr[n * rec + Rp];
+            const double ph = n + 1 < N ? tabr[(n + 1) * rec + 2 * Rp] : 0.0;   // phi between t_n and t_{n+1} (record n+1)
+            q = fma(-zz[n], u, ph * q);
+            if (PASS) qb[n * R] = q; else prod *= ph;
+        }
+        if (!PASS) { EP[2 * slot] = q; EP[2 * slot + 1] = prod; }
+    }
+}
+
+// carries into the segments: forward C_0 = 0, C_{s+1} = E_s + P_s C_s; backward the same from the last segment down
+__global__ void __launch_bounds__(64) q_carry_kernel(int R, int64_t nseg, const double* __restrict__ EP, double* __restrict__ Cin)
+{
+    const int64_t b = blockIdx.x;
+    const int dir = blockIdx.y, lane = threadIdx.x;
+    if (lane >= R) return;
+    const int64_t base = (b * 2 + dir) * nseg;
+    double c = 0.0;
+    for (int64_t k = 0; k < nseg; ++k) {
+        const int64_t s = dir == 0 ? k : nseg - 1 - k;
+        const int64_t slot = (base + s) * R + lane;
+        Cin[slot] = c;
+        c = fma(EP[2 * slot + 1], c, EP[2 * slot]);
+    }
+}
+
 }  // namespace
+
+size_t pioran_predict_q_workspace_doubles(int64_t B, int64_t N, int32_t R)
+{
+    // Qf, Qb: [B][N][R]; -z: [B][N]; E, P, C per (draw, direction, segment, row)
+    const size_t nseg = (size_t)((N + QSEG - 1) / QSEG);
+    return (size_t)B * (size_t)N * (2 * (size_t)R + 1) + (size_t)B * 2 * nseg * (size_t)R * 3;
+}
+// tau-only factors of the evaluation: W [M][3][RP] + n0 [M] (as int32, rounded up to whole doubles)
+size_t pioran_predict_tau_workspace_doubles(int64_t M, int32_t R) { return (size_t)M * 3 * (size_t)((R + 15) & ~15) + (size_t)(M + 1) / 2 + 1; }
+
+// Windowed path: gy [B][N] = dL/dy of the windowed reverse mode (pioran_launch_block_grad with p.g_y) already on the stream.
+// work: pioran_predict_q_workspace_doubles doubles whose FIRST B N hold gy; tau_work: pioran_predict_tau_workspace_doubles.
+// R <= 64 (the windowed kernels stop at 63 rows).
+int pioran_launch_predict_from_gy(ScanParams p, double* work, double* tau_work, const double* t, int64_t M, const double* tau, double* mean_out,
+                                  hipStream_t stream)
+{
+    if (!p.tab || p.npd_rows != 0 || p.R > 64 || M < 0 || p.N > 0x7fffffff) return PIORAN_ERR_UNSUPPORTED;
+    const size_t BN = (size_t)p.B * (size_t)p.N;
+    const int64_t nseg = (p.N + QSEG - 1) / QSEG;
+    const double* gy = work;
+    double* Qf = work + BN;
+    double* Qb = Qf + BN * p.R;
+    double* EP = Qb + BN * p.R;
+    double* Cin = EP + (size_t)p.B * 2 * (size_t)nseg * (size_t)p.R * 2;
+    const dim3 grid((unsigned)nseg, (unsigned)p.B, 2);
+    hipLaunchKernelGGL(q_segment_kernel<0>, grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin);
+    hipLaunchKernelGGL(q_carry_kernel, dim3((unsigned)p.B, 2), dim3(64), 0, stream, (int)p.R, nseg, EP, Cin);
+    hipLaunchKernelGGL(q_segment_kernel<1>, grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin);
+    if (M > 0) {
+        // tau_work: pioran_predict_tau_workspace_doubles(M, R); filled here (once per chunk of draws: 10 us)
+        double* W = tau_work;
+        int32_t* n0s = (int32_t*)(tau_work + (size_t)M * 3 * (size_t)((p.R + 15) & ~15));
+        hipLaunchKernelGGL(predict_tau_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, p, t, M, tau, n0s, W);
+        hipLaunchKernelGGL(predict_eval16_kernel, dim3((unsigned)((M + 16 * EVT - 1) / (16 * EVT)), (unsigned)p.B), dim3(256), 0, stream, p, Qf,
+                           Qb, M, n0s, W, mean_out);
+    }
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
 
 size_t pioran_predict_workspace_doubles(int64_t B, int64_t N, int32_t R)
 {

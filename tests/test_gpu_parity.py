@@ -1143,6 +1143,34 @@ def test_predict_random_batches(ctx, J, N, B):
     assert np.isfinite(ll).all()
 
 
+@pytest.mark.parametrize("J,N,B,basis", [(20, 1000, 40, "SHO"), (3, 333, 5, "SHO"), (12, 4097, 3, "DRWCelerite"), (31, 160, 2, "SHO")])
+def test_predict_windowed_path_matches_step_by_step(ctx, J, N, B, basis):
+    """6 .. 63 rows: the prediction runs on the windowed kernels (z = -dL/dy of the windowed reverse mode, Q recurrences in
+    segments); with `no_block` the same call takes the step-by-step kernels — both against the oracle, and against each other."""
+    rng = np.random.default_rng(4100 + J)
+    t = np.cumsum(rng.uniform(0.2, 1.5, N)); y = rng.standard_normal(N); s2 = rng.uniform(0.01, 0.1, N)
+    th = O.synthetic_theta(B, t, y)
+    A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, J, basis)
+    tau = np.sort(np.concatenate([rng.uniform(t[0] - 3, t[-1] + 3, 500), t[[0, 127, 128, N - 1]]]))
+    ds = pj.Dataset(t, y, s2, ctx)
+    lib = pj._lib.lib()
+    got, st = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu, return_status=True)
+    fam = lib.pioran_celerite_config_name(-1).decode()
+    assert (st == 0).all()
+    ctx.set_option("no_block", "1")
+    try:
+        ref_dev = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu)
+        fam2 = lib.pioran_celerite_config_name(-1).decode()
+    finally:
+        ctx.set_option("no_block", "0")
+    assert "windowed prediction" in fam and "step-by-step" in fam2, (fam, fam2)
+    scale = np.max(np.abs(ref_dev), axis=1, keepdims=True)
+    assert np.max(np.abs(got - ref_dev) / scale) < 1e-9
+    for i in (0, B - 1):
+        ref = O.predict(A[i], Bc[i], C, Dd, tau, t, y - mu[i], nu[i] * s2) + mu[i]
+        assert np.max(np.abs(got[i] - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
+
+
 def test_predict_and_simulate_per_draw_cd(ctx):
     """predict / simulate with (c, d) given per draw [B][J] (QPO / CARMA posterior samples): every draw against the oracle."""
     rng = np.random.default_rng(91)
