@@ -5,6 +5,7 @@
 
 // (celerite_predict.hip; declared here: the windowed prediction was added after the PMC profiles of common.h's kernels were taken)
 size_t pioran_predict_q_workspace_doubles(int64_t B, int64_t N, int32_t R);
+int pioran_launch_block_sim(const ScanParams& p, const double* btab, double* xi, hipStream_t stream);   // celerite_block.hip
 int pioran_launch_block_solve(const ScanParams& p, const double* btab, const double* gtab, double* gy, hipStream_t stream);   // celerite_block.hip
 size_t pioran_predict_tau_workspace_doubles(int64_t M, int32_t R);
 int pioran_launch_predict_from_gy(ScanParams p, double* work, double* tau_work, const double* t, int64_t M, const double* tau, double* mean_out,
@@ -1508,7 +1509,25 @@ static int simulate_shared(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, con
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return done(rc);
     PrepState& s = ds->host;
     if (s.R > pioran_wide_supported_rows() || s.npd_terms) return done(PIORAN_ERR_UNSUPPORTED);
-    const int64_t chunk = B < 256 ? B : 256;
+    int64_t chunk = B < 256 ? B : 256;
+    // Windowed path (round 3; 6 .. 63 rows): the windowed factorisation with its per-window stores, then L applied window by window
+    bool windowed = !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R >= 6 && s.R <= 63 &&
+                    pioran_block_fits(s.R, s.J);
+    if (windowed) {
+        rc = ensure_btab(ds, s);
+        if (rc == PIORAN_ERR_UNSUPPORTED) windowed = false;
+        else if (rc) return done(rc);
+    }
+    if (windowed) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            while (chunk > 1 && pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double) > free_b / 2 + ctx->bwork.cap) chunk /= 2;
+        rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bscratch, (size_t)chunk * (size_t)N * sizeof(double));   // xi
+        if (!rc) rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t));
+        if (rc == PIORAN_ERR_ALLOC) { windowed = false; chunk = B < 256 ? B : 256; }
+        else if (rc) return done(rc);
+    }
     const size_t cn = (size_t)chunk * (size_t)N * sizeof(double);
     if ((rc = ensure(ctx, ctx->bY, cn))) return done(rc);     // noise
     if ((rc = ensure(ctx, ctx->bS2, cn))) return done(rc);    // realisations
@@ -1526,7 +1545,16 @@ static int simulate_shared(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, con
         p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = s.dc; p.D = s.dd;
         p.out = (double*)ctx->bout.p;
         p.noise = (const double*)ctx->bY.p; p.ysim = (double*)ctx->bS2.p;
-        rc = pioran_launch_scan_wide_sim(p, ctx->stream);
+        if (windowed) {
+            p.opt = &ctx->opt;
+            p.gw = (double*)ctx->bwork.p;
+            p.status = (int32_t*)ctx->bst.p;
+            g_last_kernel = "block (windowed simulation)";
+            rc = pioran_launch_block_sim(p, s.btab, (double*)ctx->bscratch.p, ctx->stream);
+        } else {
+            g_last_kernel = "wide (step-by-step simulation)";
+            rc = pioran_launch_scan_wide_sim(p, ctx->stream);
+        }
         if (rc) { ctx->last_err = "simulation launch failed"; return done(rc); }
         if (hipMemcpyAsync(y_out + b0 * N, ctx->bS2.p, (size_t)nb * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             ctx_sync(ctx) != PIORAN_OK) {

@@ -392,12 +392,13 @@ __device__ __forceinline__ void dma_pieces(const double* gsrc, double* ldst, int
 // ST (gradient, round 3): the forward pass of the windowed reverse mode — per window it leaves in p.gw what the reverse pass
 // (celerite_block_adjoint_kernel) needs: the state T at the window start, M', Q' = Sigma^-1 X' (both in C/D order and, Q, in A-operand
 // order) and K = Sigma^-1 (block_grad_ws_doubles gives the layout).  The value it returns is bit-identical to the plain kernel's.
-__host__ __device__ inline int64_t block_grad_ws_doubles(int NB) { return (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256; }
-template <int NB, int EM, int PDM = 0, bool ST = false>
+// (the last 320: the chain wavefront's D_k and D_k (L^-1)_ik, sh.Li as it stands — the simulation applies L with it)
+__host__ __device__ constexpr int64_t block_grad_ws_doubles(int NB) { return (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256 + 320; }
+template <int NB, int EM, int PDM = 0, int ST = 0>   // ST: 0 no stores, 1 everything the reverse pass needs, 2 only Q (both orders) and L^-1, D (prediction, simulation)
 __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4 && PDM != 1 && !ST) ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
 {
     constexpr bool PD = PDM != 0;
-    [[maybe_unused]] constexpr int64_t GWS = (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256;
+    [[maybe_unused]] constexpr int64_t GWS = block_grad_ws_doubles(NB);
     [[maybe_unused]] constexpr int OFF_M = NB * NB * 256, OFF_Q = OFF_M + NB * 256, OFF_QF = OFF_Q + NB * 256, OFF_K = OFF_QF + NB * 256;
     constexpr bool EDBL = EM == 1, EGLOB = EM == 2;
     constexpr int NCW = NB < 4 ? 4 : 5;     // computing wavefronts: owners + chain
@@ -728,7 +729,7 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
             for (int I = 0; I < NB; ++I)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[I][ks], T[I][ks], acc, 0, 0, 0);
-            if constexpr (ST) {
+            if constexpr (ST == 1) {
                 double* gwk = p.gw + (b * NW + k) * GWS;
 #pragma unroll
                 for (int I = 0; I < NB; ++I)
@@ -916,18 +917,22 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
         }
         if constexpr (ST) {
             if (chain) {   // K = Sigma^-1 = L^-T D^-1 L^-1: both operands are the same per-lane expression (A: (m, k) = (c16, kk); B: (k, n) = (kk, c16))
-                const double idm = recip_f64(sh.Li[c16 * 18 + c16]);
-                d4 kv = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int kk = 4 * ks + q;
-                    const double lb = kk > c16 ? sh.Li[c16 * 18 + kk] * idm : (kk == c16 ? 1.0 : 0.0);
-                    const double la = lb * recip_f64(sh.Li[kk * 18 + kk]);
-                    kv = __builtin_amdgcn_mfma_f64_16x16x4f64(la, lb, kv, 0, 0, 0);
-                }
                 double* gwk = p.gw + (b * NW + k) * GWS;
+                if constexpr (ST == 1) {
+                    const double idm = recip_f64(sh.Li[c16 * 18 + c16]);
+                    d4 kv = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gwk[OFF_K + g * 64 + lane] = kv[g];
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int kk = 4 * ks + q;
+                        const double lb = kk > c16 ? sh.Li[c16 * 18 + kk] * idm : (kk == c16 ? 1.0 : 0.0);
+                        const double la = lb * recip_f64(sh.Li[kk * 18 + kk]);
+                        kv = __builtin_amdgcn_mfma_f64_16x16x4f64(la, lb, kv, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gwk[OFF_K + g * 64 + lane] = kv[g];
+                }
+#pragma unroll
+                for (int i = lane; i < 16 * 18; i += 64) gwk[OFF_K + 256 + i] = sh.Li[i];
             }
         }
         PIORAN_BSTAMP(9);
@@ -1099,7 +1104,7 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
 {
     constexpr int CH = 3;      // four wavefronts (512 registers each: the hand-pipelined loads live in them); with four block columns
                                // the last owner also assembles S-
-    constexpr int64_t GWS = (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256;
+    constexpr int64_t GWS = block_grad_ws_doubles(NB);
     constexpr int OFF_M = NB * NB * 256, OFF_Q = OFF_M + NB * 256, OFF_QF = OFF_Q + NB * 256, OFF_K = OFF_QF + NB * 256;
     constexpr int TSP = (3 * NB * 256 + 16 * NB + 16 + 127) & ~127;
     constexpr int64_t GS = 4 * (int64_t)NB * 256 + 16 * NB + 16 + 24;
@@ -1505,11 +1510,11 @@ int launch_block_grad(const ScanParams& p, const double* btab, const double* gta
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
     if (lds > granted[dev]) {
-        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, 0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PIORAN_ERR_HIP;
         granted[dev] = lds;
     }
-    hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, true>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
+    hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, 1>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
     const bool cd = gc || gd;
     if (p.J <= 32) {
         if (cd) hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB, true, 8>), dim3((unsigned)p.B), dim3(256), 0, stream, p, btab, gtab, ga, gb, gnu, gmu, gc, gd);
@@ -1533,7 +1538,7 @@ int launch_block_grad(const ScanParams& p, const double* btab, const double* gta
 template <int NB>
 __global__ void __launch_bounds__(64) celerite_block_backsolve_kernel(const ScanParams p, const double* __restrict__ gtab, double* __restrict__ gy)
 {
-    constexpr int64_t GWS = (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256;
+    constexpr int64_t GWS = block_grad_ws_doubles(NB);
     constexpr int OFF_QF = NB * NB * 256 + 2 * NB * 256;
     constexpr int64_t GTS = 4 * (int64_t)NB * 256 + 16 * NB + 16 + 24;
     __shared__ double hs[NB * 16];
@@ -1608,6 +1613,137 @@ __global__ void __launch_bounds__(64) celerite_block_backsolve_kernel(const Scan
     }
 }
 
+// ---- simulation on the windowed factorisation (sim, src/celerite_solver.jl:515-549; round 3) -----------------------------------------
+// y = L D^1/2 q with K = L D L'.  In the block factorisation L = (block L) blockdiag(L_w), Sigma_w = L_w D_w L_w' the window's own LDL'
+// (D_w holds the reference's D_n):   xi_w = L_w (D_w^1/2 o q_w)   (every window on its own: block_sim_xi_kernel, sixteen lanes per window,
+// forward substitution with the L_w^-1 the chain wavefront left),   y_w = xi_w + U~_w f ,  f <- C_K o f + Q_w' xi_w   (windows forwards;
+// f = what the earlier windows contribute, in window-base coordinates: celerite_block_sim_kernel, the mirror image of the back-substitution).
+template <int NB>
+__global__ void __launch_bounds__(256) block_sim_xi_kernel(const ScanParams p, double* __restrict__ xi)
+{
+    constexpr int64_t GWS = block_grad_ws_doubles(NB);
+    constexpr int OFF_LI = NB * NB * 256 + 3 * NB * 256 + 256;
+    const int64_t N = p.N, NW = (N + KW - 1) / KW, b = blockIdx.y;
+    const int64_t k = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int i = threadIdx.x & 15;
+    const bool live = k < NW;
+    const double* li = p.gw + (b * NW + (live ? k : 0)) * GWS + OFF_LI;
+    const int64_t n = k * KW + i;
+    double x = (live && n < N) ? sqrt(li[i * 18 + i]) * p.noise[b * N + n] : 0.0;
+    double row[16];   // (L^-1)[i][j], j < i
+#pragma unroll
+    for (int j = 0; j < 16; ++j) row[j] = j < i ? li[j * 18 + i] / li[j * 18 + j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 15; ++j) {
+        const double xj = __shfl(x, j, 16);      // xi_j: final once the columns before j have been taken out
+        x = fma(-row[j], xj, x);
+    }
+    if (live && n < N) xi[b * N + n] = x;
+}
+
+template <int NB>
+__global__ void __launch_bounds__(64) celerite_block_sim_kernel(const ScanParams p, const double* __restrict__ btab, const double* __restrict__ xi)
+{
+    constexpr int64_t GWS = block_grad_ws_doubles(NB);
+    constexpr int OFF_Q = NB * NB * 256 + NB * 256;
+    __shared__ double fs[NB * 16];
+    const int64_t b = blockIdx.x, N = p.N, NW = (N + KW - 1) / KW;
+    const int lane = threadIdx.x, q = lane >> 4, c16 = lane & 15;
+    const int R = p.R, J = p.J;
+    const int64_t RSB = block_rec_doubles(NB, J);
+    double al[NB][4], be[NB][4], f[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int row = 16 * I + 4 * ks + q;
+            al[I][ks] = be[I][ks] = 0.0;
+            if (row < R) {
+                const int rm = p.rowmap[row];
+                const int term = rm & 0xfffff;
+                const bool sn = (rm >> 30) & 1;
+                al[I][ks] = p.A[b * J + term];
+                be[I][ks] = sn ? -p.Bc[b * J + term] : p.Bc[b * J + term];
+            }
+        }
+        f[I] = 0.0;
+    }
+    const double* gwb = p.gw + b * NW * GWS + OFF_Q + lane;
+    const double* xib = xi + b * N;
+    struct Ops { double qc[NB][4], cv[NB][4], cx[NB][4], ck[NB], x[4]; };
+    auto fetch = [&](int64_t k, Ops& o) __attribute__((always_inline)) {
+        const double* gq = gwb + k * GWS;
+        const double* rec = btab + k * RSB;
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                o.qc[I][ks] = gq[(I * 4 + ks) * 64];
+                o.cv[I][ks] = rec[(I * 4 + ks) * 64 + lane];
+                o.cx[I][ks] = rec[NB * 256 + (I * 4 + ks) * 64 + lane];
+            }
+            o.ck[I] = rec[3 * NB * 256 + 16 * I + c16];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t n = k * KW + 4 * g + q;
+            o.x[g] = n < N ? xib[n] : 0.0;
+        }
+    };
+    Ops cur, nxt;
+    fetch(0, cur);
+    for (int64_t k = 0; k < NW; ++k) {
+        fetch(k + 1 < NW ? k + 1 : k, nxt);
+        if (q == 0) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I) fs[16 * I + c16] = f[I];
+        }
+        __syncthreads();
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fma(al[I][ks], cur.cv[I][ks], be[I][ks] * cur.cx[I][ks]), fs[16 * I + 4 * ks + q], acc, 0, 0, 0);
+        if (c16 == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t n = k * KW + 4 * g + q;
+                if (n < N) p.ysim[b * N + n] = cur.x[g] + acc[g];
+            }
+        }
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            d4 df = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) df = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.x[ks], cur.qc[I][ks], df, 0, 0, 0);
+            f[I] = fma(cur.ck[I], f[I], df[0]);
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+}
+
+template <int NB>
+int launch_block_sim(const ScanParams& p, const double* btab, double* xi, hipStream_t stream)
+{
+    const size_t lds = block_lds_bytes(NB, p.J, 0);
+    if (lds > kBlockLdsMax) return PIORAN_ERR_UNSUPPORTED;
+    static size_t granted[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
+    if (lds > granted[dev]) {
+        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, 0, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PIORAN_ERR_HIP;
+        granted[dev] = lds;
+    }
+    const int64_t NW = (p.N + KW - 1) / KW;
+    hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, 2>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
+    hipLaunchKernelGGL((block_sim_xi_kernel<NB>), dim3((unsigned)((NW + 15) / 16), (unsigned)p.B), dim3(256), 0, stream, p, xi);
+    hipLaunchKernelGGL((celerite_block_sim_kernel<NB>), dim3((unsigned)p.B), dim3(64), 0, stream, p, btab, xi);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
 template <int NB>
 int launch_block_solve(const ScanParams& p, const double* btab, const double* gtab, double* gy, hipStream_t stream)
 {
@@ -1617,11 +1753,11 @@ int launch_block_solve(const ScanParams& p, const double* btab, const double* gt
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
     if (lds > granted[dev]) {
-        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, 0, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PIORAN_ERR_HIP;
         granted[dev] = lds;
     }
-    hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, true>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
+    hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, 2>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
     hipLaunchKernelGGL((celerite_block_backsolve_kernel<NB>), dim3((unsigned)p.B), dim3(64), 0, stream, p, gtab, gy);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
@@ -1639,6 +1775,20 @@ int pioran_launch_block_solve(const ScanParams& p, const double* btab, const dou
         case 2: return launch_block_solve<2>(p, btab, gtab, gy, stream);
         case 3: return launch_block_solve<3>(p, btab, gtab, gy, stream);
         case 4: return launch_block_solve<4>(p, btab, gtab, gy, stream);
+    }
+    return PIORAN_ERR_UNSUPPORTED;
+}
+
+// GP realisations p.ysim [B][N] from the normals p.noise [B][N]: the windowed factorisation of the covariance (data set with y = 0;
+// p.gw: pioran_block_grad_workspace_doubles; xi: B N doubles of scratch), then the two simulation kernels above.
+int pioran_launch_block_sim(const ScanParams& p, const double* btab, double* xi, hipStream_t stream)
+{
+    if (!btab || !xi || !p.gw || !p.noise || !p.ysim || p.npd_rows != 0 || p.B < 1 || p.N < 1 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    switch ((p.R + 1 + 15) / 16) {
+        case 1: return launch_block_sim<1>(p, btab, xi, stream);
+        case 2: return launch_block_sim<2>(p, btab, xi, stream);
+        case 3: return launch_block_sim<3>(p, btab, xi, stream);
+        case 4: return launch_block_sim<4>(p, btab, xi, stream);
     }
     return PIORAN_ERR_UNSUPPORTED;
 }

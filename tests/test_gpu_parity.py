@@ -1230,6 +1230,32 @@ def test_simulate_matches_oracle(ctx, golden_dir):
     assert np.max(np.abs(ys[7] - O.sim(a, b, c, d, tt, s2, q[7]))) < 1e-12
 
 
+@pytest.mark.parametrize("J,N,B,basis", [(20, 1000, 40, "SHO"), (3, 333, 5, "SHO"), (12, 4097, 3, "DRWCelerite"), (31, 160, 2, "SHO")])
+def test_simulate_windowed_path_matches_step_by_step(ctx, J, N, B, basis):
+    """6 .. 63 rows: the simulation runs on the windowed factorisation (L applied window by window); with `no_block` the same call
+    takes the step-by-step kernel — both against the oracle's `sim` on the same normals, and against each other."""
+    rng = np.random.default_rng(5200 + J)
+    t = np.cumsum(rng.uniform(0.2, 1.5, N)); y = rng.standard_normal(N); s2 = rng.uniform(0.01, 0.1, N)
+    th = O.synthetic_theta(B, t, y)
+    A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, J, basis)
+    q = rng.standard_normal((B, N))
+    lib = pj._lib.lib()
+    ys = ctx.simulate(A, Bc, C, Dd, t, s2, q)
+    fam = lib.pioran_celerite_config_name(-1).decode()
+    ctx.set_option("no_block", "1")
+    try:
+        ys2 = ctx.simulate(A, Bc, C, Dd, t, s2, q)
+        fam2 = lib.pioran_celerite_config_name(-1).decode()
+    finally:
+        ctx.set_option("no_block", "0")
+    assert "windowed simulation" in fam and "step-by-step" in fam2, (fam, fam2)
+    scale = np.max(np.abs(ys2), axis=1, keepdims=True)
+    assert np.isfinite(ys).all() and np.max(np.abs(ys - ys2) / scale) < 1e-9
+    for i in (0, B - 1):
+        ref = O.sim(A[i], Bc[i], C, Dd, t, s2, q[i])
+        assert np.max(np.abs(ys[i] - ref)) <= 1e-9 * np.max(np.abs(ref))
+
+
 def test_predict_cov_reference_cases(ctx, golden_dir):
     """cov / std of the posterior (src/direct_solver.jl:28-69 through src/scalable_GP.jl:73-104) on the inputs of
     test/test_scalablegp.jl:134-175: finite, positive definite, equal to the numpy restatement of predict_cov."""
