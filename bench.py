@@ -504,6 +504,33 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
     dsg.close()
     out[f"gradient_sho{J}_N{N}"] = grad
 
+    # -- posterior mean and simulation for a set of posterior draws (the callers after sampling:
+    #    src/celerite_solver.jl:363-483, 515-549) — windowed factorisation, host entries (transfers included) -----------------
+    nbp = min(256, B)
+    Ap, Bp, Cp, Dp = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:nbp, :3], f_min, f_max, J, theta[:nbp, 3], basis_function="SHO")
+    dsp = pj.Dataset(t, y, s2, ctx)
+    taup = np.linspace(t[0] - 10, t[-1] + 10, N)
+    post = {"workload": f"N={N}, SHO-{J}, {nbp} posterior draws, {N} evaluation times"}
+    got = dsp.predict(Ap, Bp, Cp, Dp, taup, mu=mu[:nbp], nu=nu[:nbp])
+    post["predict_kernel"] = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    wall = []
+    for _ in range(3):
+        t0 = time.perf_counter(); got = dsp.predict(Ap, Bp, Cp, Dp, taup, mu=mu[:nbp], nu=nu[:nbp]); wall.append(time.perf_counter() - t0)
+    post["predict_ms_per_call_incl_pcie"] = med(wall) * 1e3
+    refp = O.predict(Ap[0], Bp[0], Cp, Dp, taup, t, y - mu[0], nu[0] * s2) + mu[0]
+    post["predict_max_rel_err_vs_oracle"] = float(np.max(np.abs(got[0] - refp)) / np.max(np.abs(refp)))
+    qn = np.random.default_rng(1).standard_normal((nbp, N))
+    ys = ctx.simulate(Ap, Bp, Cp, Dp, t, s2, qn)
+    post["simulate_kernel"] = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    wall = []
+    for _ in range(3):
+        t0 = time.perf_counter(); ys = ctx.simulate(Ap, Bp, Cp, Dp, t, s2, qn); wall.append(time.perf_counter() - t0)
+    post["simulate_ms_per_call_incl_pcie"] = med(wall) * 1e3
+    refs = O.sim(Ap[0], Bp[0], Cp, Dp, t, s2, qn[0])
+    post["simulate_max_rel_err_vs_oracle"] = float(np.max(np.abs(ys[0] - refs)) / np.max(np.abs(refs)))
+    dsp.close()
+    out["posterior_mean_and_simulation"] = post
+
     # -- dense path: configs[4], N = 4096, J = 40 (SHO-40) -------------------------------------------------------------
     Nd, Jd = min(4096, N), 40
     td, yd, ed = t[:Nd], y[:Nd], yerr[:Nd]

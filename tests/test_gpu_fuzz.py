@@ -93,3 +93,63 @@ def test_fuzz_windowed_gradient_vs_step_by_step_and_oracle(capsys):
     with capsys.disabled():
         print(f"\nwindowed gradient fuzz: 300 cases, worst deviation from the step-by-step adjoint {worst}", file=sys.stderr)
     assert worst["dev"] < 1e-8, worst
+
+
+def test_fuzz_windowed_prediction_and_simulation_vs_step_by_step_and_oracle(capsys):
+    """Randomized shapes for the windowed prediction (block back-substitution + segment-parallel running vectors) and simulation
+    (L applied window by window): 200 seeded cases — 3..31 terms, some one-row terms, N = 1..700 (segment and window edges: 16, 128,
+    129 ...) with occasional long gaps, 1..5 draws, tau inside / outside / exactly on the data — against the step-by-step kernels, every
+    tenth case against the oracle's `pred` and `sim`."""
+    import numpy as np
+    import pioran_jl_amd as pj
+    from oracle import oracle as O
+    ctx = pj.Context(0)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    worst = {"dev": 0.0}
+    edges = (1, 2, 15, 16, 17, 127, 128, 129, 256, 257)
+    for idx in range(200):
+        rng = np.random.default_rng([20261005, idx])
+        J = int(rng.integers(3, 32)); B = int(rng.integers(1, 6))
+        N = int(edges[idx % len(edges)]) if idx < 40 else int(rng.integers(1, 701))
+        gaps = rng.uniform(0.05, 2.0, N)
+        if rng.random() < 0.3:
+            gaps[rng.integers(0, N, max(1, N // 20))] *= rng.uniform(5, 400)
+        t = np.cumsum(gaps); y = rng.standard_normal(N); s2 = rng.uniform(0.01, 0.1, N)
+        A = rng.uniform(0.1, 2.0, (B, J)); Bc = rng.uniform(-0.05, 0.05, (B, J)) * A
+        C = rng.uniform(0.05, 2.0, J); Dd = rng.uniform(0.0, 3.0, J)
+        nreal = int(rng.integers(0, J // 2 + 1)) * int(rng.random() < 0.4)
+        Bc[:, :nreal] = 0.0; Dd[:nreal] = 0.0
+        mu = rng.standard_normal(B) * 0.1; nu = rng.uniform(0.5, 2.0, B)
+        M = int(rng.integers(1, 200))
+        tau = rng.uniform(t[0] - 3, t[-1] + 3, M); tau[: min(M, 3)] = t[rng.integers(0, N, min(M, 3))]
+        tau = np.sort(tau)
+        q = rng.standard_normal((B, N))
+        R = 2 * J - nreal
+        ds = pj.Dataset(t, y, s2, ctx)
+        pw, st = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu, return_status=True)
+        assert name() == ("block (windowed prediction)" if R >= 6 else "wide (step-by-step prediction)"), (idx, name(), R)
+        sw = ctx.simulate(A, Bc, C, Dd, t, s2, q)
+        assert name() == ("block (windowed simulation)" if R >= 6 else "wide (step-by-step simulation)"), (idx, name(), R)
+        try:
+            ctx.set_option("no_block", True)
+            po, st2 = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu, return_status=True)
+            so = ctx.simulate(A, Bc, C, Dd, t, s2, q)
+        finally:
+            ctx.set_option("no_block", False)
+        assert np.array_equal(st, st2), idx
+        ok = (st == 0)
+        for k, a_, b_ in (("predict", pw, po), ("simulate", sw, so)):
+            if not ok.any():
+                continue
+            dev = float(np.max(np.abs(a_[ok] - b_[ok]) / (1e-30 + np.max(np.abs(b_[ok]), axis=1, keepdims=True))))
+            if dev > worst["dev"]:
+                worst = {"dev": dev, "idx": idx, "what": k, "J": J, "N": N, "B": B, "nreal": nreal, "M": M}
+        if idx % 10 == 0 and ok[0]:
+            ref = O.predict(A[0], Bc[0], C, Dd, tau, t, y - mu[0], nu[0] * s2) + mu[0]
+            assert np.max(np.abs(pw[0] - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))), idx
+            ref = O.sim(A[0], Bc[0], C, Dd, t, s2, q[0])
+            assert np.max(np.abs(sw[0] - ref)) <= 1e-9 * np.max(np.abs(ref)), idx
+        ds.close()
+    with capsys.disabled():
+        print(f"\nwindowed prediction / simulation fuzz: 200 cases, worst deviation from the step-by-step kernels {worst}", file=sys.stderr)
+    assert worst["dev"] < 1e-8, worst
