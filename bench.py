@@ -553,8 +553,8 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
                      "frac": flop / (fac * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                      "note": "N^3/3 + 2N^2 flop over the event-timed factorisation (all panel + trailing-update launches)"},
         "info": info, "rel_diff_vs_celerite_path": abs(cel + v) / abs(v)}
-    # batched dense: independent factorisations on concurrent streams (the chain of 64 latency-bound steps of ONE
-    # factorisation leaves most of the chip idle)
+    # batched dense: 32 independent factorisations per launch of every kernel of the chain (gridDim.z; the 64 latency-bound
+    # steps of ONE factorisation leave most of the chip idle)
     Bd = 32
     Ad = np.tile(Rk.a, (Bd, 1)) * np.linspace(0.8, 1.2, Bd)[:, None]; Bdd = np.tile(Rk.b, (Bd, 1)) * np.linspace(0.8, 1.2, Bd)[:, None]
     ctx.dense_nll_batch(Ad, Bdd, Rk.c, Rk.d, td, yd, ed ** 2, mu=np.full(Bd, mud))
@@ -562,7 +562,7 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
     for _ in range(3):
         t0 = time.perf_counter(); vb = ctx.dense_nll_batch(Ad, Bdd, Rk.c, Rk.d, td, yd, ed ** 2, mu=np.full(Bd, mud)); wb.append(time.perf_counter() - t0)
     out[f"dense_n{Nd}_j{Jd}"]["batched"] = {
-        "workload": f"{Bd} independent factorisations per call, up to 16 concurrent (pioran_dense_nll_batch), PCIe included",
+        "workload": f"{Bd} independent factorisations per call, all in one batched launch per kernel (pioran_dense_nll_batch), covariance build and PCIe included",
         "ms_per_call": med(wb) * 1e3, "evals_per_s": Bd / med(wb), "mfma_tflops": Bd * flop / med(wb) / 1e12,
         "mfma_frac": Bd * flop / med(wb) / 1e12 / FP64_PEAK_TFLOPS, "all_finite": bool(np.isfinite(vb).all())}
 

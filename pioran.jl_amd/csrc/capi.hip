@@ -5,6 +5,11 @@
 
 // (celerite_predict.hip; declared here: the windowed prediction was added after the PMC profiles of common.h's kernels were taken)
 size_t pioran_predict_q_workspace_doubles(int64_t B, int64_t N, int32_t R);
+int pioran_dense_nll_device_batch(int64_t nbatch, int64_t N, int32_t J, const double* a, const double* b, const double* c, const double* d,
+                                  int64_t cd_stride, const double* t, const double* y, const double* s2, double* K, int64_t slab,
+                                  const double* mu, const double* nu, double* out, int32_t* info, int sorted, hipStream_t stream);   // dense.hip
+void pioran_dense_set_batch_pair_threshold(int v);   // dense.hip, diagnostics
+void pioran_dense_set_quad_threshold(int v);
 int pioran_launch_block_sim(const ScanParams& p, const double* btab, double* xi, hipStream_t stream);   // celerite_block.hip
 int pioran_launch_block_solve(const ScanParams& p, const double* btab, const double* gtab, double* gy, hipStream_t stream);   // celerite_block.hip
 size_t pioran_predict_tau_workspace_doubles(int64_t M, int32_t R);
@@ -390,6 +395,8 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "no_win3")) o.no_win3 = on;
     else if (!std::strcmp(key, "btab_reference")) o.btab_reference = on;
     else if (!std::strcmp(key, "block_emode")) o.block_emode = (value && value[0]) ? std::atoi(value) : -1;
+    else if (!std::strcmp(key, "dense_quad_threshold")) pioran_dense_set_quad_threshold((value && value[0]) ? std::atoi(value) : -1);
+    else if (!std::strcmp(key, "dense_batch_pair_threshold")) pioran_dense_set_batch_pair_threshold((value && value[0]) ? std::atoi(value) : -1);
     else if (!std::strcmp(key, "dense_streams")) o.dense_streams = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "gsum")) o.gsum = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "wide2")) o.wide2 = on;
@@ -1752,11 +1759,12 @@ int pioran_dense_nll_batch(pioran_ctx* ctx, int64_t N, int64_t J, int64_t B, con
     int64_t Mp, ld;
     pioran_dense_dims(N, &Mp, &ld);
     const size_t slab = (size_t)Mp * (size_t)ld + 1024;
-    // concurrent factorisations: as many slabs as fit in a third of the free memory, at most 16 (one stream each; round 3:
-    // tools/sweep_dense_streams.py, N = 4096: 4 streams 1.25 ms per factorisation, 8 1.05, 12 1.02, 16 0.96 = 0.30 of the MFMA peak).  A single
-    // N = 4096 factorisation is a chain of 64 latency-bound steps that leaves most of the chip idle; independent matrices fill it.
-    const int64_t max_streams = ctx->opt.dense_streams > 0 && ctx->opt.dense_streams <= pioran_ctx::kDenseStreams ? ctx->opt.dense_streams : pioran_ctx::kDenseStreams;
-    int64_t ns = B < max_streams ? B : max_streams;
+    // Several factorisations per launch (round 3, late): a single N = 4096 factorisation is a chain of 64 latency-bound steps that
+    // leaves most of the chip idle; with gridDim.z = nb matrices every kernel of the chain is launched once per BATCH (16 concurrent
+    // streams of single-matrix launches gave 0.96 ms per factorisation, tools/sweep_dense_streams.py).  As many slabs as fit in a
+    // third of the free memory, at most 32 (option dense_streams: fewer).
+    const int64_t max_batch = ctx->opt.dense_streams > 0 && ctx->opt.dense_streams <= 64 ? ctx->opt.dense_streams : 32;
+    int64_t ns = B < max_batch ? B : max_batch;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
@@ -1764,16 +1772,13 @@ int pioran_dense_nll_batch(pioran_ctx* ctx, int64_t N, int64_t J, int64_t B, con
     }
     while ((rc = ensure(ctx, ctx->bK, (size_t)ns * slab * sizeof(double))) == PIORAN_ERR_ALLOC && ns > 1) --ns;
     if (rc) return rc;
-    for (int64_t i = 0; i < ns; ++i)
-        if (!ctx->dstream[i]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->dstream[i], hipStreamNonBlocking));
-    for (auto& e : ctx->dev_)
-        if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    // staging: A Bc [B][J] | C D ([J] or [B][J]) | t y s2 [N] | out [B] | info [B] (int32)
+    // staging: A Bc [B][J] | C D ([J] or [B][J]) | t y s2 [N] | mu nu [B] | out [B] | info [B] (int32)
     const size_t ncd = cd_shared ? (size_t)J : (size_t)B * J;
-    const size_t nd = 2 * (size_t)B * J + 2 * ncd + 3 * (size_t)N + 2 * (size_t)B;
+    const size_t nd = 2 * (size_t)B * J + 2 * ncd + 3 * (size_t)N + 4 * (size_t)B;
     if ((rc = ensure(ctx, ctx->bwork, nd * sizeof(double)))) return rc;
     double* dA = (double*)ctx->bwork.p; double* dB = dA + (size_t)B * J; double* dC = dB + (size_t)B * J; double* dD = dC + ncd;
-    double* dt = dD + ncd; double* dy = dt + N; double* ds2 = dy + N; double* dout = ds2 + N; int32_t* dinfo = (int32_t*)(dout + B);
+    double* dt = dD + ncd; double* dy = dt + N; double* ds2 = dy + N; double* dmu = ds2 + N; double* dnu = dmu + B;
+    double* dout = dnu + B; int32_t* dinfo = (int32_t*)(dout + B);
     HIPCHK(ctx, hipMemcpyAsync(dA, A, (size_t)B * J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dB, Bc, (size_t)B * J * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dC, C, ncd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -1781,19 +1786,15 @@ int pioran_dense_nll_batch(pioran_ctx* ctx, int64_t N, int64_t J, int64_t B, con
     HIPCHK(ctx, hipMemcpyAsync(dt, t, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dy, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ds2, sigma2, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(ctx->dev_[pioran_ctx::kDenseStreams], ctx->stream));
+    if (mu) HIPCHK(ctx, hipMemcpyAsync(dmu, mu, (size_t)B * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (nu) HIPCHK(ctx, hipMemcpyAsync(dnu, nu, (size_t)B * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     const int sorted = is_sorted(t, N);
-    for (int64_t i = 0; i < ns; ++i) HIPCHK(ctx, hipStreamWaitEvent(ctx->dstream[i], ctx->dev_[pioran_ctx::kDenseStreams], 0));
-    for (int64_t b = 0; b < B; ++b) {
-        const int64_t i = b % ns;
-        rc = pioran_dense_nll_device(N, (int32_t)J, dA + b * J, dB + b * J, cd_shared ? dC : dC + b * J, cd_shared ? dD : dD + b * J, dt, dy,
-                                     ds2, (double*)ctx->bK.p + (size_t)i * slab, nullptr, dout + b, dinfo + b, sorted, ctx->dstream[i],
-                                     mu ? mu[b] : 0.0, nu ? nu[b] : 1.0);
+    for (int64_t b0 = 0; b0 < B; b0 += ns) {
+        const int64_t nb = B - b0 < ns ? B - b0 : ns;
+        rc = pioran_dense_nll_device_batch(nb, N, (int32_t)J, dA + b0 * J, dB + b0 * J, cd_shared ? dC : dC + b0 * J, cd_shared ? dD : dD + b0 * J,
+                                           cd_shared ? 0 : J, dt, dy, ds2, (double*)ctx->bK.p, (int64_t)slab, mu ? dmu + b0 : nullptr,
+                                           nu ? dnu + b0 : nullptr, dout + b0, dinfo + b0, sorted, ctx->stream);
         if (rc) { ctx->last_err = "dense kernel launch failed"; return rc; }
-    }
-    for (int64_t i = 0; i < ns; ++i) {
-        HIPCHK(ctx, hipEventRecord(ctx->dev_[i], ctx->dstream[i]));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->dev_[i], 0));
     }
     if ((rc = download(ctx, out, dout, (size_t)B * sizeof(double)))) return rc;
     if (info) if ((rc = download(ctx, info, dinfo, (size_t)B * sizeof(int32_t)))) return rc;

@@ -34,6 +34,15 @@
 namespace {
 
 constexpr int NB = 64;
+
+// Several matrices of the same size in ONE launch of every kernel below (blockIdx.z = matrix): slab z at A + z slab (its workspace
+// behind it, as for one matrix), coefficients at a + z ab_stride, c + z cd_stride, mu[z] / nu[z] when the arrays are given, info[z],
+// out[z].  All zero / nullptr with gridDim.z = 1: one matrix, the scalar mu / nu arguments.
+struct DenseBatch {
+    int64_t slab, ab_stride, cd_stride;
+    const double* mu;
+    const double* nu;
+};
 constexpr int kPairThreshold = 24;   // trailing tiles per side above which steps are taken in pairs (128-deep updates)
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
@@ -42,8 +51,14 @@ __global__ void __launch_bounds__(256) dense_build_kernel(int64_t N, int64_t Mp,
                                                           const double* __restrict__ c, const double* __restrict__ d,
                                                           const double* __restrict__ t, const double* __restrict__ s2,
                                                           const double* __restrict__ y, double* __restrict__ A, int diag_only,
-                                                          double mu, double nu)
+                                                          double mu, double nu, DenseBatch bt)
 {
+    {
+        const int64_t mz = blockIdx.z;
+        a += mz * bt.ab_stride; b += mz * bt.ab_stride; c += mz * bt.cd_stride; d += mz * bt.cd_stride; A += mz * bt.slab;
+        if (bt.mu) mu = bt.mu[mz];
+        if (bt.nu) nu = bt.nu[mz];
+    }
     if (diag_only && (blockIdx.x >> 2) != (blockIdx.y >> 2)) return;  // keep only the diagonal 64 x 64 tiles
     // 16 x 16 tile of (i, k); i is the fast index (threadIdx.x) = memory-contiguous
     const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
@@ -113,8 +128,12 @@ constexpr int BJ = 16;    // terms per LDS chunk
 __global__ void __launch_bounds__(256) dense_build_fast_kernel(int64_t N, int64_t ld, int32_t J,
                                                                const double* __restrict__ a, const double* __restrict__ b,
                                                                const double* __restrict__ c, const double* __restrict__ d,
-                                                               const double* __restrict__ t, double* __restrict__ A)
+                                                               const double* __restrict__ t, double* __restrict__ A, DenseBatch bt)
 {
+    {
+        const int64_t mz = blockIdx.z;
+        a += mz * bt.ab_stride; b += mz * bt.ab_stride; c += mz * bt.cd_stride; d += mz * bt.cd_stride; A += mz * bt.slab;
+    }
     __shared__ double Ps[BJ][BT], Qs[BJ][BT], Gs[BJ][BT], Hs[BJ][BT];
     // linear block id -> strictly-lower tile pair (ti > tj)
     const int bid = blockIdx.x;
@@ -370,8 +389,9 @@ __device__ __forceinline__ void store_block_lower(const double* __restrict__ Ls,
 
 // First diagonal block (no trailing update precedes it): load, factor, write back.
 __global__ void __launch_bounds__(256) dense_diag0_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ ws,
-                                                          int32_t* __restrict__ info)
+                                                          int32_t* __restrict__ info, DenseBatch bt)
 {
+    A += (int64_t)blockIdx.z * bt.slab; ws += (int64_t)blockIdx.z * bt.slab; info += blockIdx.z;
     __shared__ double Ls[NB * LP];
     __shared__ int flag;
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
@@ -399,8 +419,9 @@ __global__ void __launch_bounds__(256) dense_diag0_kernel(double* __restrict__ A
 // next B operand with no data movement.
 template <int RT>   // 16-row tiles per wave
 __global__ void __launch_bounds__(256) dense_panel_kernel(double* __restrict__ A, int64_t ld, int64_t kb,
-                                                          const double* __restrict__ ws)
+                                                          const double* __restrict__ ws, DenseBatch bt)
 {
+    A += (int64_t)blockIdx.z * bt.slab; ws += (int64_t)blockIdx.z * bt.slab;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     const int64_t row0 = kb + NB + ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
@@ -464,8 +485,9 @@ __global__ void __launch_bounds__(256) dense_panel_kernel(double* __restrict__ A
 template <int KP>
 __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__ A, int64_t ld, int64_t kb, int64_t Mp,
                                                          double* __restrict__ ws, int32_t* __restrict__ info, int factor_next,
-                                                         int col0_only)
+                                                         int col0_only, DenseBatch bt)
 {
+    A += (int64_t)blockIdx.z * bt.slab; ws += (int64_t)blockIdx.z * bt.slab; info += blockIdx.z;
     // Workgroups of four wavefronts.  Workgroup 0 is the critical path: its four waves share tile (0,0) — the NEXT
     // diagonal block — one 16-column strip each, keep the updated tile in LDS and factor it right away
     // (factor_block64) while the other tiles are still being updated; the next panel kernel then starts from a
@@ -599,8 +621,9 @@ __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__
 
 __global__ void __launch_bounds__(256) dense_finish_kernel(const double* __restrict__ A, int64_t ld, int64_t N,
                                                            int64_t Mp, double* __restrict__ out,
-                                                           const int32_t* __restrict__ info)
+                                                           const int32_t* __restrict__ info, DenseBatch bt)
 {
+    A += (int64_t)blockIdx.z * bt.slab; out += blockIdx.z; info += blockIdx.z;
     __shared__ double s1[256], s2[256];
     double ld_ = 0.0, zz = 0.0;
     for (int64_t k = threadIdx.x; k < N; k += 256) {
@@ -656,65 +679,114 @@ __global__ void __launch_bounds__(256) dense_predict_mean_kernel(const double* _
 // K must hold ld * Mp + 1024 doubles with Mp = roundup(N, 64), ld = Mp + 64 (slab + inverse workspace).
 static void launch_build(int64_t N, int64_t Mp, int64_t ld, int32_t J, const double* a, const double* b, const double* c,
                          const double* d, const double* t, const double* y, const double* s2, double* K, int sorted,
-                         hipStream_t stream, double mu = 0.0, double nu = 1.0)
+                         hipStream_t stream, double mu = 0.0, double nu = 1.0, unsigned nbatch = 1, DenseBatch bt = DenseBatch{})
 {
     const unsigned tiles = (unsigned)(Mp / 16);
     const int64_t nt = Mp / BT;
     const bool fast = sorted && nt > 1;
-    hipLaunchKernelGGL(dense_build_kernel, dim3(tiles, tiles), dim3(256), 0, stream, N, Mp, ld, J, a, b, c, d, t, s2, y, K,
-                       fast ? 1 : 0, mu, nu);
+    hipLaunchKernelGGL(dense_build_kernel, dim3(tiles, tiles, nbatch), dim3(256), 0, stream, N, Mp, ld, J, a, b, c, d, t, s2, y, K,
+                       fast ? 1 : 0, mu, nu, bt);
     if (fast)
-        hipLaunchKernelGGL(dense_build_fast_kernel, dim3((unsigned)(nt * (nt - 1) / 2)), dim3(256), 0, stream, N, ld, J, a,
-                           b, c, d, t, K);
+        hipLaunchKernelGGL(dense_build_fast_kernel, dim3((unsigned)(nt * (nt - 1) / 2), 1, nbatch), dim3(256), 0, stream, N, ld, J, a,
+                           b, c, d, t, K, bt);
+}
+
+static int g_batch_pair_threshold = -1;   // diagnostics (tools/sweep_dense_streams.py): -1 = the defaults below
+static int g_quad_threshold = -1;
+constexpr int kQuadThreshold = 1 << 20;        // one matrix: off
+constexpr int kBatchQuadThreshold = 16;        // batched launches (tools/sweep_dense_streams.py: 0.628 -> 0.554 ms per N = 4096 factorisation, 32 per launch)
+void pioran_dense_set_batch_pair_threshold(int v) { g_batch_pair_threshold = v; }
+void pioran_dense_set_quad_threshold(int v) { g_quad_threshold = v; }
+
+// nbatch matrices of the same size (same t, y, s2; coefficients strided, see DenseBatch): every kernel of the factorisation is
+// launched ONCE with gridDim.z = nbatch, so the 64 latency-bound steps of a factorisation are paid once per batch, not once per
+// matrix.  info / out: [nbatch].
+static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, const double* a, const double* b, const double* c, const double* d,
+                          const double* t, const double* y, const double* s2, double* K, hipEvent_t* phase_ev,
+                          double* out, int32_t* info, int sorted, hipStream_t stream, double mu, double nu)
+{
+    // phase_ev (nullptr or 3 events): recorded after the covariance build, after the factorisation loop, after the finish
+    const int64_t Mp = (N + NB - 1) / NB * NB, ld = Mp + NB;
+    launch_build(N, Mp, ld, J, a, b, c, d, t, y, s2, K, sorted, stream, mu, nu, nbatch, bt);
+    if (phase_ev) (void)hipEventRecord(phase_ev[0], stream);
+    if (hipMemsetAsync(info, 0, nbatch * sizeof(int32_t), stream) != hipSuccess) return PIORAN_ERR_HIP;
+    double* ws = K + (size_t)ld * (size_t)Mp;   // WS_DOUBLES doubles right behind the slab
+    hipLaunchKernelGGL(dense_diag0_kernel, dim3(1, 1, nbatch), dim3(256), 0, stream, K, ld, ws, info, bt);
+    auto panel = [&](int64_t kb) {
+        // rows below the block: kb+NB .. Mp+63 (the y row Mp and the scratch rows of its 64-row tile)
+        const int64_t below = Mp - kb;
+        // one 16-row strip per wave while that still fills the chip's 1024 SIMDs at most a few times over (the step
+        // is latency-bound: 40 dependent-ish MFMAs per strip); two strips per wave beyond
+        if (below * nbatch <= 65536)
+            hipLaunchKernelGGL(dense_panel_kernel<1>, dim3((unsigned)((below + 63) / 64), 1, nbatch), dim3(256), 0, stream, K, ld, kb, ws, bt);
+        else
+            hipLaunchKernelGGL(dense_panel_kernel<2>, dim3((unsigned)((below + 127) / 128), 1, nbatch), dim3(256), 0, stream, K, ld, kb, ws, bt);
+    };
+    // While the trailing update is bound by the traffic of C (more tile-waves than the chip holds at once), steps go in
+    // PAIRS: panel k, narrow update of block column k+1 (+ its diagonal factor), panel k+1, then ONE 128-deep update of the
+    // rest; afterwards (latency-bound steps) one 64-deep update per step as before.  (A batch is bound by that traffic for longer:
+    // pairs down to a quarter of the single matrix's threshold.)
+    const int64_t pair_threshold = nbatch > 1 ? (g_batch_pair_threshold >= 0 ? g_batch_pair_threshold : kPairThreshold / 4) : kPairThreshold;
+    // ... and in FOURS above quad_threshold: three narrow updates (block column k+1 with one panel, k+2 with two, k+3 with three), then ONE
+    // 256-deep update of the rest — the trailing matrix goes through L2 / HBM once per 256 columns.
+    const int64_t quad_threshold = g_quad_threshold >= 0 ? g_quad_threshold : (nbatch > 1 ? kBatchQuadThreshold : kQuadThreshold);
+    auto col0 = [&](auto kp, int64_t kb0, int64_t ntc) {      // block column 0 of the trailing matrix behind KP panels (+ its diagonal factor)
+        hipLaunchKernelGGL(dense_syrk_kernel<decltype(kp)::value>, dim3((unsigned)(1 + (ntc - 1 + 3) / 4), 1, nbatch), dim3(256), 0, stream, K, ld, kb0, Mp,
+                           ws, info, 1, 1, bt);
+    };
+    int64_t kb = 0;
+    while (kb < Mp) {
+        const int64_t nt = (Mp - kb - NB) / NB + 1;           // i tiles of the trailing matrix of step kb (incl. the y-row tile)
+        if (nt > quad_threshold && kb + 4 * NB < Mp) {
+            panel(kb);
+            col0(std::integral_constant<int, 1>{}, kb, nt);
+            panel(kb + NB);
+            col0(std::integral_constant<int, 2>{}, kb, nt - 1);
+            panel(kb + 2 * NB);
+            col0(std::integral_constant<int, 3>{}, kb, nt - 2);
+            panel(kb + 3 * NB);
+            const int64_t nt4 = nt - 3;
+            hipLaunchKernelGGL(dense_syrk_kernel<4>, dim3((unsigned)(1 + (nt4 * (nt4 + 1) / 2 - 1 + 3) / 4), 1, nbatch), dim3(256), 0, stream, K, ld,
+                               kb, Mp, ws, info, 1, 0, bt);
+            kb += 4 * NB;
+        } else if (nt > pair_threshold && kb + 2 * NB < Mp) {
+            panel(kb);
+            hipLaunchKernelGGL(dense_syrk_kernel<1>, dim3((unsigned)(1 + (nt - 1 + 3) / 4), 1, nbatch), dim3(256), 0, stream, K, ld, kb, Mp, ws, info, 1, 1, bt);
+            panel(kb + NB);
+            const int64_t nt2 = nt - 1;                        // trailing matrix of the pair starts one block further
+            hipLaunchKernelGGL(dense_syrk_kernel<2>, dim3((unsigned)(1 + (nt2 * (nt2 + 1) / 2 - 1 + 3) / 4), 1, nbatch), dim3(256), 0, stream, K, ld,
+                               kb, Mp, ws, info, 1, 0, bt);
+            kb += 2 * NB;
+        } else {
+            panel(kb);
+            if (nt > 1)
+                hipLaunchKernelGGL(dense_syrk_kernel<1>, dim3((unsigned)(1 + (nt * (nt + 1) / 2 - 1 + 3) / 4), 1, nbatch), dim3(256), 0, stream, K, ld,
+                                   kb, Mp, ws, info, 1, 0, bt);
+            kb += NB;
+        }
+    }
+    if (phase_ev) (void)hipEventRecord(phase_ev[1], stream);
+    hipLaunchKernelGGL(dense_finish_kernel, dim3(1, 1, nbatch), dim3(256), 0, stream, K, ld, N, Mp, out, info, bt);
+    if (phase_ev) (void)hipEventRecord(phase_ev[2], stream);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c, const double* d,
                             const double* t, const double* y, const double* s2, double* K, hipEvent_t* phase_ev,
                             double* out, int32_t* info, int sorted, hipStream_t stream, double mu, double nu)
 {
-    // phase_ev (nullptr or 3 events): recorded after the covariance build, after the factorisation loop, after the finish
-    const int64_t Mp = (N + NB - 1) / NB * NB, ld = Mp + NB;
-    launch_build(N, Mp, ld, J, a, b, c, d, t, y, s2, K, sorted, stream, mu, nu);
-    if (phase_ev) (void)hipEventRecord(phase_ev[0], stream);
-    if (hipMemsetAsync(info, 0, sizeof(int32_t), stream) != hipSuccess) return PIORAN_ERR_HIP;
-    double* ws = K + (size_t)ld * (size_t)Mp;   // WS_DOUBLES doubles right behind the slab
-    hipLaunchKernelGGL(dense_diag0_kernel, dim3(1), dim3(256), 0, stream, K, ld, ws, info);
-    auto panel = [&](int64_t kb) {
-        // rows below the block: kb+NB .. Mp+63 (the y row Mp and the scratch rows of its 64-row tile)
-        const int64_t below = Mp - kb;
-        // one 16-row strip per wave while that still fills the chip's 1024 SIMDs at most a few times over (the step
-        // is latency-bound: 40 dependent-ish MFMAs per strip); two strips per wave beyond
-        if (below <= 65536)
-            hipLaunchKernelGGL(dense_panel_kernel<1>, dim3((unsigned)((below + 63) / 64)), dim3(256), 0, stream, K, ld, kb, ws);
-        else
-            hipLaunchKernelGGL(dense_panel_kernel<2>, dim3((unsigned)((below + 127) / 128)), dim3(256), 0, stream, K, ld, kb, ws);
-    };
-    // While the trailing update is bound by the traffic of C (more tile-waves than the chip holds at once), steps go in
-    // PAIRS: panel k, narrow update of block column k+1 (+ its diagonal factor), panel k+1, then ONE 128-deep update of the
-    // rest; afterwards (latency-bound steps) one 64-deep update per step as before.
-    int64_t kb = 0;
-    while (kb < Mp) {
-        const int64_t nt = (Mp - kb - NB) / NB + 1;           // i tiles of the trailing matrix of step kb (incl. the y-row tile)
-        if (nt > kPairThreshold && kb + 2 * NB < Mp) {
-            panel(kb);
-            hipLaunchKernelGGL(dense_syrk_kernel<1>, dim3((unsigned)(1 + (nt - 1 + 3) / 4)), dim3(256), 0, stream, K, ld, kb, Mp, ws, info, 1, 1);
-            panel(kb + NB);
-            const int64_t nt2 = nt - 1;                        // trailing matrix of the pair starts one block further
-            hipLaunchKernelGGL(dense_syrk_kernel<2>, dim3((unsigned)(1 + (nt2 * (nt2 + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
-                               kb, Mp, ws, info, 1, 0);
-            kb += 2 * NB;
-        } else {
-            panel(kb);
-            if (nt > 1)
-                hipLaunchKernelGGL(dense_syrk_kernel<1>, dim3((unsigned)(1 + (nt * (nt + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
-                                   kb, Mp, ws, info, 1, 0);
-            kb += NB;
-        }
-    }
-    if (phase_ev) (void)hipEventRecord(phase_ev[1], stream);
-    hipLaunchKernelGGL(dense_finish_kernel, dim3(1), dim3(256), 0, stream, K, ld, N, Mp, out, info);
-    if (phase_ev) (void)hipEventRecord(phase_ev[2], stream);
-    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+    return dense_nll_impl(1, DenseBatch{}, N, J, a, b, c, d, t, y, s2, K, phase_ev, out, info, sorted, stream, mu, nu);
+}
+
+// nbatch <= 65535 matrices at K + z slab (slab >= ld Mp + 1024 doubles); a, b: [nbatch][J]; c, d: [J] (cd_stride = 0) or [nbatch][J]
+// (cd_stride = J); mu, nu: device [nbatch] or nullptr (0 / 1); out, info: device [nbatch].
+int pioran_dense_nll_device_batch(int64_t nbatch, int64_t N, int32_t J, const double* a, const double* b, const double* c, const double* d,
+                                  int64_t cd_stride, const double* t, const double* y, const double* s2, double* K, int64_t slab,
+                                  const double* mu, const double* nu, double* out, int32_t* info, int sorted, hipStream_t stream)
+{
+    if (nbatch < 1 || nbatch > 65535) return PIORAN_ERR_ARG;
+    DenseBatch bt{slab, (int64_t)J, cd_stride, mu, nu};
+    return dense_nll_impl((unsigned)nbatch, bt, N, J, a, b, c, d, t, y, s2, K, nullptr, out, info, sorted, stream, 0.0, 1.0);
 }
 
 // predict_cov (src/direct_solver.jl:28-69): K(tau,tau) - K(tau,t) (K(t,t) + diag(s2))^-1 K(t,tau) as the Schur complement
@@ -733,16 +805,16 @@ int pioran_dense_predict_cov_device(int64_t N, int64_t M, int32_t J, const doubl
     hipLaunchKernelGGL(dense_build_aug_kernel, dim3(tiles, tiles), dim3(256), 0, stream, Mtot, ld, J, a, b, c, d, te, s2e, K);
     if (y) hipLaunchKernelGGL(dense_set_yrow_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, K, ld, Mtot, N, y);
     double* ws = K + (size_t)ld * (size_t)Mtot;
-    hipLaunchKernelGGL(dense_diag0_kernel, dim3(1), dim3(256), 0, stream, K, ld, ws, info);
+    hipLaunchKernelGGL(dense_diag0_kernel, dim3(1), dim3(256), 0, stream, K, ld, ws, info, DenseBatch{});
     for (int64_t kb = 0; kb < Mp; kb += NB) {
         const int64_t below = Mtot - kb;
         if (below <= 65536)
-            hipLaunchKernelGGL(dense_panel_kernel<1>, dim3((unsigned)((below + 63) / 64)), dim3(256), 0, stream, K, ld, kb, ws);
+            hipLaunchKernelGGL(dense_panel_kernel<1>, dim3((unsigned)((below + 63) / 64)), dim3(256), 0, stream, K, ld, kb, ws, DenseBatch{});
         else
-            hipLaunchKernelGGL(dense_panel_kernel<2>, dim3((unsigned)((below + 127) / 128)), dim3(256), 0, stream, K, ld, kb, ws);
+            hipLaunchKernelGGL(dense_panel_kernel<2>, dim3((unsigned)((below + 127) / 128)), dim3(256), 0, stream, K, ld, kb, ws, DenseBatch{});
         const int64_t nt = (Mtot - kb - NB) / NB + 1;   // >= 2: the tau block is never empty
         hipLaunchKernelGGL(dense_syrk_kernel<1>, dim3((unsigned)(1 + (nt * (nt + 1) / 2 - 1 + 3) / 4)), dim3(256), 0, stream, K, ld,
-                           kb, Mtot, ws, info, kb + NB < Mp ? 1 : 0, 0);
+                           kb, Mtot, ws, info, kb + NB < Mp ? 1 : 0, 0, DenseBatch{});
     }
     if (y && mean)
         hipLaunchKernelGGL(dense_predict_mean_kernel, dim3((unsigned)M), dim3(256), 0, stream, K, ld, Mtot, Mp, M, mean, info);

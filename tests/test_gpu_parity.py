@@ -670,7 +670,7 @@ def test_dense_reference_relation(ctx, golden_dir):
 
 
 def test_dense_batch(ctx, golden_dir):
-    """pioran_dense_nll_batch: B factorisations on concurrent streams == B single calls == -celerite path; per-draw mu / nu;
+    """pioran_dense_nll_batch: B factorisations in batched launches == B single calls == -celerite path; per-draw mu / nu;
     shared and per-draw (c, d); one non-PD draw in the middle only flags itself."""
     rng = np.random.default_rng(17)
     A_ = np.loadtxt(golden_dir / "simu.txt")
@@ -689,6 +689,33 @@ def test_dense_batch(ctx, golden_dir):
     Abad = A.copy(); Abad[7] = -3.0
     got3, info3 = ctx.dense_nll_batch(Abad, Bc, C, Dd, t, y, yerr ** 2, mu=mu, nu=nu, return_info=True)
     assert info3[7] != 0 and np.isnan(got3[7]) and (np.delete(info3, 7) == 0).all() and relerr(np.delete(got3, 7), np.delete(one, 7)) < 1e-13
+
+
+def test_dense_batch_long_series_grouped_steps(ctx):
+    """Batched launches take the steps of the factorisation in fours and pairs (256- / 128-deep trailing updates) where one matrix takes
+    them in pairs and singles: N = 2100 (33 tiles per side), 5 matrices per launch, per-draw mu / nu, shared and per-draw (c, d) —
+    against single calls, the oracle's dense path and the celerite path."""
+    rng = np.random.default_rng(23)
+    N, J, B = 2100, 5, 5
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    one = np.array([ctx.dense_nll(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2) for i in range(B)])
+    got, info = ctx.dense_nll_batch(A, Bc, C, Dd, t, y, s2, mu=mu, nu=nu, return_info=True)
+    assert (info == 0).all() and relerr(got, one) < 1e-11
+    ref = np.array([O.dense_nll_numpy(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2) for i in (0, B - 1)])   # (LAPACK: the C restatement is O(N^3) scalar code)
+    assert relerr(got[[0, B - 1]], ref) < 1e-10
+    cel = pj.Dataset(t, y, s2, ctx).logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    assert relerr(-got, cel) < 1e-9
+    C2 = np.tile(C, (B, 1)) * rng.uniform(0.8, 1.2, (B, J)); D2 = np.tile(Dd, (B, 1)) * rng.uniform(0.8, 1.2, (B, J))
+    got2 = ctx.dense_nll_batch(A, Bc, C2, D2, t, y, s2, mu=mu, nu=nu)
+    one2 = np.array([ctx.dense_nll(A[i], Bc[i], C2[i], D2[i], t, y - mu[i], nu[i] * s2) for i in range(B)])
+    assert relerr(got2, one2) < 1e-11
+    # fewer matrices per launch than draws: several batched launches per call
+    ctx.set_option("dense_streams", 2)
+    try:
+        got3 = ctx.dense_nll_batch(A, Bc, C, Dd, t, y, s2, mu=mu, nu=nu)
+    finally:
+        ctx.set_option("dense_streams", None)
+    assert relerr(got3, got) < 1e-11
 
 
 def test_dense_not_positive_definite(ctx):
