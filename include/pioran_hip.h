@@ -255,7 +255,7 @@ int pioran_dense_nll(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, con
  * out[b] = +NLL of draw b, info[b] (may be NULL) as above.  The factorisations are independent: up to 32 (fewer when memory is short:
  * one slab of about N^2 doubles each) go through every kernel of the chain in ONE launch (the matrix index is a grid dimension), which is
  * what fills the matrix cores at N of a few thousand — one factorisation alone is a chain of N/64 latency-bound steps (N = 4096, J = 40:
- * 1.65 ms alone, 0.55 ms each in a batch). */
+ * 1.65 ms alone, 0.49 ms each in a batch). */
 int pioran_dense_nll_batch(pioran_ctx* ctx, int64_t N, int64_t J, int64_t B, const double* A, const double* Bc,
                            const double* C, const double* Dd, int cd_shared, const double* t, const double* y,
                            const double* sigma2, const double* mu, const double* nu, double* out, int32_t* info);

@@ -200,6 +200,118 @@ __global__ void __launch_bounds__(256) dense_build_fast_kernel(int64_t N, int64_
         }
 }
 
+// ---- covariance build of a BATCH with shared (c, d) (late round 3) ----------------------------------------------------------------
+// What depends on (c, d, t) alone — every exp and sincos — is computed once per tile for all matrices of the launch; the matrices differ
+// in (a_j, b_j), mu and nu only.
+// Off-diagonal tiles: P, Q (row side) and FC = F cos(d t_k), FS = F sin(d t_k) (column side) of ALL terms stay in LDS (4 x 64 J doubles:
+// J <= 64); per matrix z the tile is the product over the 2 J-long axis  K'[k][i] = sum_j G_z[j][k] P[j][i] + H_z[j][k] Q[j][i],
+// G_z = a_zj FC - b_zj FS, H_z = a_zj FS + b_zj FC, on the matrix cores: the A operand (column side) is formed in registers from two LDS
+// reads, the product is oriented so that the result's lane index runs along i, the memory-contiguous index of the slab.
+__global__ void __launch_bounds__(256) dense_build_fast_batch_kernel(int64_t N, int64_t ld, int32_t J, int32_t nbatch,
+                                                                     const double* __restrict__ a, const double* __restrict__ b,
+                                                                     const double* __restrict__ c, const double* __restrict__ d,
+                                                                     const double* __restrict__ t, double* __restrict__ A, DenseBatch bt)
+{
+    extern __shared__ double bsh[];
+    const int JP = (J + 3) & ~3;                      // terms padded to whole k-steps of the 16x16x4 product
+    double* Ps = bsh;                                 // [JP][64]
+    double* Qs = Ps + JP * BT;
+    double* FCs = Qs + JP * BT;
+    double* FSs = FCs + JP * BT;
+    const int bid = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * bid + 1.0) + 1.0) * 0.5);
+    while ((int64_t)ti * (ti - 1) / 2 > bid) --ti;
+    while ((int64_t)(ti + 1) * ti / 2 <= bid) ++ti;
+    const int tj = bid - (int)((int64_t)ti * (ti - 1) / 2);
+    const int64_t i0 = (int64_t)ti * BT, k0 = (int64_t)tj * BT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const double tref = t[i0 < N ? i0 : N - 1];
+    for (int e = tid; e < 2 * BT * JP; e += 256) {
+        const int j = e / (2 * BT), rr = e % (2 * BT);
+        double v0 = 0.0, v1 = 0.0;
+        if (j < J) {
+            const int64_t n = rr < BT ? i0 + rr : k0 + rr - BT;
+            const double tn = t[n < N ? n : N - 1];
+            double sn, cs;
+            sincos(d[j] * tn, &sn, &cs);
+            const double E = exp(rr < BT ? -c[j] * (tn - tref) : -c[j] * (tref - tn));
+            v0 = n < N ? E * cs : 0.0;                // (identity padding: rows / columns past N contribute zeros)
+            v1 = n < N ? E * sn : 0.0;
+        }
+        if (rr < BT) { Ps[j * BT + rr] = v0; Qs[j * BT + rr] = v1; } else { FCs[j * BT + rr - BT] = v0; FSs[j * BT + rr - BT] = v1; }
+    }
+    __syncthreads();
+    const int nks = JP >> 2;
+    for (int z = 0; z < nbatch; ++z) {
+        const double* az = a + (int64_t)z * bt.ab_stride;
+        const double* bz = b + (int64_t)z * bt.ab_stride;
+        f64x4 acc[4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) acc[ib] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int ks = 0; ks < nks; ++ks) {
+            const int j = 4 * ks + lk;
+            const double aj = j < J ? az[j] : 0.0, bj = j < J ? bz[j] : 0.0;
+            const double fc = FCs[j * BT + 16 * wave + lr], fs = FSs[j * BT + 16 * wave + lr];
+            const double g = fma(aj, fc, -bj * fs), h = fma(aj, fs, bj * fc);     // A operand: [m = column k][k-step = term]
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(g, Ps[j * BT + 16 * ib + lr], acc[ib], 0, 0, 0);
+                acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(h, Qs[j * BT + 16 * ib + lr], acc[ib], 0, 0, 0);
+            }
+        }
+        // result register g of lane (lk, lr): column k0 + 16 wave + lk + 4 g, row i0 + 16 ib + lr
+        double* Az = A + (int64_t)z * bt.slab;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Az[(i0 + 16 * ib + lr) + (k0 + 16 * wave + lk + 4 * g) * ld] = acc[ib][g];
+    }
+}
+
+// Diagonal 64 x 64 tiles (direct evaluation, as dense_build_kernel's) for up to ZC matrices per pass: one thread per entry, the
+// exp / sincos of a term once, then two FMAs per matrix; also the y row (y - mu_z), nu_z sigma2 on the diagonal and the identity padding.
+constexpr int ZC = 16;
+__global__ void __launch_bounds__(256) dense_build_diag_batch_kernel(int64_t N, int64_t Mp, int64_t ld, int32_t J, int32_t nbatch,
+                                                                     const double* __restrict__ a, const double* __restrict__ b,
+                                                                     const double* __restrict__ c, const double* __restrict__ d,
+                                                                     const double* __restrict__ t, const double* __restrict__ s2,
+                                                                     const double* __restrict__ y, double* __restrict__ A, DenseBatch bt)
+{
+    // blockIdx.x: 16-row block, blockIdx.y: 16-column block within the same 64-tile (4 x 4 per diagonal tile), blockIdx.z: pass of ZC matrices
+    const int64_t tile = blockIdx.x >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const int64_t k = tile * 64 + (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+    const int z0 = blockIdx.z * ZC;
+    const int nz = nbatch - z0 < ZC ? nbatch - z0 : ZC;
+    if (i >= Mp || k >= Mp || i < k) return;
+    double v[ZC];
+#pragma unroll
+    for (int z = 0; z < ZC; ++z) v[z] = 0.0;
+    const bool data = i < N && k < N;
+    if (data) {
+        const double tau = fabs(t[i] - t[k]);
+        for (int j = 0; j < J; ++j) {
+            double sn, cs;
+            sincos(d[j] * tau, &sn, &cs);
+            const double e = exp(-c[j] * tau);
+            const double e1 = e * cs, e2 = e * sn;
+#pragma unroll
+            for (int z = 0; z < ZC; ++z)
+                if (z < nz) v[z] = fma(a[(int64_t)(z0 + z) * bt.ab_stride + j], e1, fma(b[(int64_t)(z0 + z) * bt.ab_stride + j], e2, v[z]));
+        }
+    }
+#pragma unroll
+    for (int z = 0; z < ZC; ++z) {
+        if (z >= nz) break;
+        double* Az = A + (int64_t)(z0 + z) * bt.slab;
+        const double mu = bt.mu ? bt.mu[z0 + z] : 0.0, nu = bt.nu ? bt.nu[z0 + z] : 1.0;
+        double val = data ? v[z] : (i == k ? 1.0 : 0.0);
+        if (data && i == k) val = fma(nu, s2[i], val);
+        Az[i + k * ld] = val;
+        if (i == k) Az[Mp + k * ld] = k < N ? y[k] - mu : 0.0;
+    }
+}
+
 template <int I>
 using icd = std::integral_constant<int, I>;
 template <class F, int... Is>
@@ -684,6 +796,22 @@ static void launch_build(int64_t N, int64_t Mp, int64_t ld, int32_t J, const dou
     const unsigned tiles = (unsigned)(Mp / 16);
     const int64_t nt = Mp / BT;
     const bool fast = sorted && nt > 1;
+    if (nbatch > 1 && bt.cd_stride == 0 && sorted && J <= 64) {   // shared (c, d): the transcendental part once for the whole batch
+        hipLaunchKernelGGL(dense_build_diag_batch_kernel, dim3(tiles, 4, (nbatch + ZC - 1) / ZC), dim3(256), 0, stream, N, Mp, ld, J, (int32_t)nbatch, a, b,
+                           c, d, t, s2, y, K, bt);
+        if (nt > 1) {
+            const size_t lds = (size_t)4 * ((J + 3) & ~3) * BT * sizeof(double);
+            static bool granted[64] = {};   // the attribute belongs to (function, device); racing threads at worst set it twice
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !granted[dev]) {
+                (void)hipFuncSetAttribute((const void*)dense_build_fast_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * BT * (int)sizeof(double));
+                granted[dev] = true;
+            }
+            hipLaunchKernelGGL(dense_build_fast_batch_kernel, dim3((unsigned)(nt * (nt - 1) / 2)), dim3(256), lds, stream, N, ld, J, (int32_t)nbatch, a, b,
+                               c, d, t, K, bt);
+        }
+        return;
+    }
     hipLaunchKernelGGL(dense_build_kernel, dim3(tiles, tiles, nbatch), dim3(256), 0, stream, N, Mp, ld, J, a, b, c, d, t, s2, y, K,
                        fast ? 1 : 0, mu, nu, bt);
     if (fast)
