@@ -9,6 +9,10 @@ X=$ROOT/gpurun_out/$ROUND/extra
 mkdir -p "$X"
 cd "$ROOT"
 run() { name=$1; shift; timeout -k 10 300 "$@" > "$X/$name" 2> "$X/$name.err" || echo "$name failed" >&2; tail -c 400 "$X/$name"; echo; }
+# PART=1: the secondary measurements; PART=2: the reference's benchmark grid; PART=3: rocprofv3 trace + PMC passes (default: all three;
+# a gpurun call is limited to 20 minutes — run the parts as separate calls)
+PART=${PART:-all}
+if [[ $PART == all || $PART == 1 ]]; then
 run predict_simulate_n1e4_b256.json python3 tools/bench_predict.py
 run gradient_sho20.json python3 tools/bench_grad.py
 BASIS=DRWCelerite run gradient_drw20.json python3 tools/bench_grad.py
@@ -21,7 +25,13 @@ run small_batch_latency_sho20.json python3 tools/bench_small_batch.py
 BASIS=DRWCelerite run small_batch_latency_drw20.json python3 tools/bench_small_batch.py
 run host_api_pcie_inclusive.json python3 tools/bench_host_api.py
 run dense_n4096_j40.json python3 tools/bench_dense.py
+run dense_batched_launches.txt python3 tools/sweep_dense_streams.py
 run bench_default_full_line.json python3 bench.py
+fi
+if [[ $PART == all || $PART == 2 ]]; then
 timeout -k 10 900 python3 tools/bench_grid.py > "$X/grid.json" 2> "$X/grid.json.err" || echo "grid failed" >&2
+fi
+if [[ $PART == all || $PART == 3 ]]; then
 ROUND=$ROUND "$ROOT/tools/run_profiles.sh" > "$X/run_profiles.log" 2>&1
 tail -5 "$X/run_profiles.log"
+fi
