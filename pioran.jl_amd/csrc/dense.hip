@@ -275,7 +275,8 @@ __global__ void __launch_bounds__(256) dense_build_diag_batch_kernel(int64_t N, 
                                                                      const double* __restrict__ a, const double* __restrict__ b,
                                                                      const double* __restrict__ c, const double* __restrict__ d,
                                                                      const double* __restrict__ t, const double* __restrict__ s2,
-                                                                     const double* __restrict__ y, double* __restrict__ A, DenseBatch bt)
+                                                                     const double* __restrict__ y, double* __restrict__ A, DenseBatch bt,
+                                                                     double mu0, double nu0)
 {
     // blockIdx.x: 16-row block, blockIdx.y: 16-column block within the same 64-tile (4 x 4 per diagonal tile), blockIdx.z: pass of ZC matrices
     const int64_t tile = blockIdx.x >> 2;
@@ -304,7 +305,7 @@ __global__ void __launch_bounds__(256) dense_build_diag_batch_kernel(int64_t N, 
     for (int z = 0; z < ZC; ++z) {
         if (z >= nz) break;
         double* Az = A + (int64_t)(z0 + z) * bt.slab;
-        const double mu = bt.mu ? bt.mu[z0 + z] : 0.0, nu = bt.nu ? bt.nu[z0 + z] : 1.0;
+        const double mu = bt.mu ? bt.mu[z0 + z] : mu0, nu = bt.nu ? bt.nu[z0 + z] : nu0;
         double val = data ? v[z] : (i == k ? 1.0 : 0.0);
         if (data && i == k) val = fma(nu, s2[i], val);
         Az[i + k * ld] = val;
@@ -796,9 +797,10 @@ static void launch_build(int64_t N, int64_t Mp, int64_t ld, int32_t J, const dou
     const unsigned tiles = (unsigned)(Mp / 16);
     const int64_t nt = Mp / BT;
     const bool fast = sorted && nt > 1;
-    if (nbatch > 1 && bt.cd_stride == 0 && sorted && J <= 64) {   // shared (c, d): the transcendental part once for the whole batch
+    // shared (c, d) (or one matrix): the transcendental part once per tile, the tiles themselves on the matrix cores
+    if ((nbatch == 1 || bt.cd_stride == 0) && sorted && J <= 64) {
         hipLaunchKernelGGL(dense_build_diag_batch_kernel, dim3(tiles, 4, (nbatch + ZC - 1) / ZC), dim3(256), 0, stream, N, Mp, ld, J, (int32_t)nbatch, a, b,
-                           c, d, t, s2, y, K, bt);
+                           c, d, t, s2, y, K, bt, mu, nu);
         if (nt > 1) {
             const size_t lds = (size_t)4 * ((J + 3) & ~3) * BT * sizeof(double);
             static bool granted[64] = {};   // the attribute belongs to (function, device); racing threads at worst set it twice
