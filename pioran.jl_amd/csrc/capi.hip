@@ -12,9 +12,9 @@ void pioran_dense_set_batch_pair_threshold(int v);   // dense.hip, diagnostics
 void pioran_dense_set_quad_threshold(int v);
 int pioran_launch_block_sim(const ScanParams& p, const double* btab, double* xi, hipStream_t stream);   // celerite_block.hip
 int pioran_launch_block_solve(const ScanParams& p, const double* btab, const double* gtab, double* gy, hipStream_t stream);   // celerite_block.hip
-size_t pioran_predict_tau_workspace_doubles(int64_t M, int32_t R);
+size_t pioran_predict_tau_workspace_doubles(int64_t M, int32_t R, int64_t ntab);
 int pioran_launch_predict_from_gy(ScanParams p, double* work, double* tau_work, const double* t, int64_t M, const double* tau, double* mean_out,
-                                  hipStream_t stream);
+                                  hipStream_t stream, int cd_per_draw);
 
 
 #include <cmath>
@@ -52,7 +52,7 @@ struct pioran_ctx {
         void* p = nullptr;
         size_t cap = 0;
     };
-    Buf bA, bB, bC, bD, bmu, bnu, bY, bS2, bout, bst, bscratch, bK, bwork, bshift, bgtab;
+    Buf bA, bB, bC, bD, bmu, bnu, bY, bS2, bout, bst, bscratch, bK, bwork, bshift, bgtab, bq;
     // scalar entry point: the last series' time stamps stay resident (samplers call logl with the same t)
     pioran_ds* scalar_ds = nullptr;
     std::vector<double> scalar_t;
@@ -454,7 +454,7 @@ int pioran_ctx_destroy(pioran_ctx* ctx)
     if (ctx->scalar_ds) pioran_dataset_destroy(ctx->scalar_ds);
     ctx->scalar_ds = nullptr;
     pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
-                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab};
+                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab, &ctx->bq};
     for (auto* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : ctx->ev)
@@ -478,7 +478,7 @@ int pioran_ctx_trim(pioran_ctx* ctx)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     SYNC(ctx);
     pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
-                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab};
+                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab, &ctx->bq};
     for (auto* b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;
@@ -1186,7 +1186,7 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
         rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bscratch, pioran_predict_q_workspace_doubles(chunk, ds->N, s.R) * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bgtab, pioran_block_gtab_doubles(ds->N, s.R) * sizeof(double));
-        if (!rc) rc = ensure(ctx, ctx->bK, pioran_predict_tau_workspace_doubles(M, s.R) * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bK, pioran_predict_tau_workspace_doubles(M, s.R, 1) * sizeof(double));
         if (rc == PIORAN_ERR_ALLOC) { windowed = false; chunk = B < 256 ? B : 256; }
         else if (rc) return rc;
         if (windowed && (rc = pioran_launch_block_gtab(ds->N, s.R, s.J, s.rowmap, ds->t, s.dc, s.dd, ds->s2, (double*)ctx->bgtab.p, ctx->stream)))
@@ -1218,7 +1218,7 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
             // -z = -K^-1 (y - mu) [nb][N] into the head of the Q workspace
             rc = pioran_launch_block_solve(p, s.btab, (const double*)ctx->bgtab.p, (double*)ctx->bscratch.p, ctx->stream);
             if (!rc) rc = pioran_launch_predict_from_gy(p, (double*)ctx->bscratch.p, (double*)ctx->bK.p, ds->t, M, (const double*)ctx->bshift.p, (double*)ctx->bY.p,
-                                                        ctx->stream);
+                                                        ctx->stream, 0);
         } else {
             g_last_kernel = "wide (step-by-step prediction)";
             rc = pioran_launch_predict(p, (double*)ctx->bwork.p, ds->t, M, (const double*)ctx->bshift.p, (double*)ctx->bY.p,
@@ -1232,12 +1232,92 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
     return PIORAN_OK;
 }
 
+// Per-draw (c, d) in every term (posterior draws of QPO / CARMA / free Celerite models), several draws: every draw its own windowed-kernel
+// tables, all draws of a chunk in one launch of every kernel (as logl_grad_perdraw_windowed below).  PIORAN_ERR_UNSUPPORTED when the
+// shape does not fit the windowed kernel (the caller then goes draw by draw).
+static int predict_perdraw_windowed(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C, const double* Dd,
+                                    const double* mu, const double* nu, int64_t M, const double* tau, double* mean_out, int32_t* status)
+{
+    pioran_ctx* ctx = ds->ctx;
+    PrepState& s = ds->host;
+    if (ctx->opt.no_block || ctx->opt.force_fallback || ctx->opt.scan_config[0] || 2 * J < 6 || !pioran_block_fits((int32_t)(2 * J), (int32_t)J))
+        return PIORAN_ERR_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PendingGuard pending_guard(ctx);
+    int rc;
+    if ((rc = prepare_state(ds, s, J, C, Dd, nullptr))) return rc;    // row map with both rows of every term
+    const int64_t N = ds->N;
+    const int64_t bt = (int64_t)pioran_block_table_doubles(N, s.R, s.J), gt = (int64_t)pioran_block_gtab_doubles(N, s.R);
+    auto per_chunk = [&](int64_t nb) {
+        return ((size_t)nb * ((size_t)bt + (size_t)gt) + pioran_block_grad_workspace_doubles(nb, N, s.R) + pioran_predict_q_workspace_doubles(nb, N, s.R) +
+                pioran_predict_tau_workspace_doubles(M, s.R, nb) + (size_t)nb * (size_t)M) * sizeof(double);
+    };
+    int64_t chunk = B < 256 ? B : 256;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            while (chunk > 1 && per_chunk(chunk) > free_b / 2 + ctx->bwork.cap + ctx->bscratch.cap + ctx->bgtab.cap + ctx->bK.cap + ctx->bq.cap) chunk /= 2;
+    }
+    for (;;) {
+        rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bscratch, (size_t)chunk * (size_t)bt * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bgtab, (size_t)chunk * (size_t)gt * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bq, pioran_predict_q_workspace_doubles(chunk, N, s.R) * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bK, pioran_predict_tau_workspace_doubles(M, s.R, chunk) * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bY, (size_t)chunk * (size_t)M * sizeof(double));
+        if (rc != PIORAN_ERR_ALLOC || chunk == 1) break;
+        chunk /= 2;
+    }
+    if (rc) return rc;
+    if ((rc = upload(ctx, ctx->bshift, tau, (size_t)M * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->bout, chunk * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t)))) return rc;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+        const size_t nbj = (size_t)nb * J * sizeof(double);
+        if ((rc = upload(ctx, ctx->bA, A + b0 * J, nbj))) return rc;
+        if ((rc = upload(ctx, ctx->bB, Bc + b0 * J, nbj))) return rc;
+        if ((rc = upload(ctx, ctx->bC, C + b0 * J, nbj))) return rc;
+        if ((rc = upload(ctx, ctx->bD, Dd + b0 * J, nbj))) return rc;
+        if (mu && (rc = upload(ctx, ctx->bmu, mu + b0, nb * sizeof(double)))) return rc;
+        if (nu && (rc = upload(ctx, ctx->bnu, nu + b0, nb * sizeof(double)))) return rc;
+        double* btab = (double*)ctx->bscratch.p; double* gtab = (double*)ctx->bgtab.p;
+        if ((rc = pioran_launch_block_table_batch(N, s.R, s.J, nb, s.rowmap, ds->t, (const double*)ctx->bC.p, (const double*)ctx->bD.p, ds->y, ds->s2,
+                                                  btab, bt, ctx->stream))) return rc;
+        if ((rc = pioran_launch_block_gtab_batch(N, s.R, s.J, nb, s.rowmap, ds->t, (const double*)ctx->bC.p, (const double*)ctx->bD.p, ds->s2, gtab,
+                                                 gt, ctx->stream))) return rc;
+        ScanParams p{};
+        p.opt = &ctx->opt;
+        p.N = N; p.J = s.J; p.R = s.R; p.B = nb; p.standard_rows = 1;
+        p.rec_stride = 3 * (int64_t)(s.R + 2) + 2;
+        p.tab_draw_stride = bt; p.gtab_draw_stride = gt;
+        p.rowmap = s.rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+        p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = (const double*)ctx->bC.p; p.D = (const double*)ctx->bD.p;
+        p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
+        p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
+        p.gw = (double*)ctx->bwork.p;
+        g_last_kernel = "block (windowed prediction, per-draw tables)";
+        rc = pioran_launch_block_solve(p, btab, gtab, (double*)ctx->bq.p, ctx->stream);
+        if (!rc) rc = pioran_launch_predict_from_gy(p, (double*)ctx->bq.p, (double*)ctx->bK.p, ds->t, M, (const double*)ctx->bshift.p,
+                                                    (double*)ctx->bY.p, ctx->stream, 1);
+        if (rc) { ctx->last_err = "windowed prediction launch failed"; return rc; }
+        if ((rc = download(ctx, mean_out + b0 * M, ctx->bY.p, (size_t)nb * M * sizeof(double)))) return rc;
+        if (status) if ((rc = download(ctx, status + b0, ctx->bst.p, nb * sizeof(int32_t)))) return rc;
+        SYNC(ctx);
+    }
+    return PIORAN_OK;
+}
+
 int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
                             const double* Dd, int cd_shared, const double* mu, const double* nu, int64_t M, const double* tau,
                             double* mean_out, int32_t* status)
 {
     if (!ds || B < 1 || J < 1 || M < 1 || !A || !Bc || !C || !Dd || !tau || !mean_out) return PIORAN_ERR_ARG;
     if (cd_shared || B == 1) return predict_shared(ds, B, J, A, Bc, C, Dd, mu, nu, M, tau, mean_out, status);
+    {
+        const int rc = predict_perdraw_windowed(ds, B, J, A, Bc, C, Dd, mu, nu, M, tau, mean_out, status);
+        if (rc != PIORAN_ERR_UNSUPPORTED) return rc;
+    }
     for (int64_t b = 0; b < B; ++b) {   // per-draw (c, d): every draw is its own one-draw batch with its own table
         const int rc = predict_shared(ds, 1, J, A + b * J, Bc + b * J, C + b * J, Dd + b * J, mu ? mu + b : nullptr, nu ? nu + b : nullptr,
                                       M, tau, mean_out + b * M, status ? status + b : nullptr);

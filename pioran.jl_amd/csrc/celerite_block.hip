@@ -1559,6 +1559,7 @@ __global__ void __launch_bounds__(64) celerite_block_backsolve_kernel(const Scan
         }
         h[I] = row == R ? -1.0 : 0.0;
     }
+    gtab += b * p.gtab_draw_stride;                // per-draw tables (every term's (c, d) per draw): 0 for the shared table
     const double* gwb = p.gw + b * NW * GWS + OFF_QF + lane;
     const double* gtl = gtab + lane;
     // operands of one window: Q (A-operand order), C o v and C o x (C/D order), C_K — fetched a window ahead of their use
@@ -1668,6 +1669,7 @@ __global__ void __launch_bounds__(64) celerite_block_sim_kernel(const ScanParams
         }
         f[I] = 0.0;
     }
+    btab += b * p.tab_draw_stride;                 // per-draw tables: 0 for the shared table
     const double* gwb = p.gw + b * NW * GWS + OFF_Q + lane;
     const double* xib = xi + b * N;
     struct Ops { double qc[NB][4], cv[NB][4], cx[NB][4], ck[NB], x[4]; };

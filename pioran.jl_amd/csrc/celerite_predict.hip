@@ -191,11 +191,16 @@ __global__ void __launch_bounds__(256) predict_eval_kernel(const ScanParams p, c
 // ---- evaluation in two kernels (windowed path): what depends on tau alone is computed once, not once per draw ----------------
 // predict_tau_kernel, one thread per tau_m: n0 (as above) and, per row, ef cos(d tau), ef sin(d tau), eb V_r(tau) with
 // ef = e^{-c (tau - t_{n0-1})}, eb = e^{-c (t_{n0} - tau)} (zero where that side has no data point)  -> W [M][3][RP], RP = R rounded up to 16.
+// blockIdx.y: draw of a batch with per-draw (c, d) (cd_stride = J, W at W + y W_stride); one shared table: gridDim.y = 1, strides 0.
 __global__ void __launch_bounds__(256) predict_tau_kernel(const ScanParams p, const double* __restrict__ t, int64_t M,
-                                                          const double* __restrict__ tau, int32_t* __restrict__ n0s, double* __restrict__ W)
+                                                          const double* __restrict__ tau, int32_t* __restrict__ n0s, double* __restrict__ W,
+                                                          int64_t cd_stride, int64_t W_stride)
 {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
+    const double* Cc = p.C + (int64_t)blockIdx.y * cd_stride;
+    const double* Dc = p.D + (int64_t)blockIdx.y * cd_stride;
+    W += (int64_t)blockIdx.y * W_stride;
     const int64_t N = p.N;
     const int R = p.R, RP = (R + 15) & ~15;
     const double tm = tau[m];
@@ -213,7 +218,7 @@ __global__ void __launch_bounds__(256) predict_tau_kernel(const ScanParams p, co
             const int rm = p.rowmap[r];
             const int term = rm & 0xfffff;
             const bool ks = (rm >> 30) & 1;
-            const double c = p.C[term], d = p.D[term];
+            const double c = Cc[term], d = Dc[term];
             double s_, c_;
             sincos(d * tm, &s_, &c_);
             const double ef = lo > 0 ? exp(-c * dtf) : 0.0, eb = lo < N ? exp(-c * dtb) : 0.0;
@@ -229,9 +234,10 @@ __global__ void __launch_bounds__(256) predict_tau_kernel(const ScanParams p, co
 constexpr int EVT = 8;   // taus per 16-lane group
 __global__ void __launch_bounds__(256) predict_eval16_kernel(const ScanParams p, const double* __restrict__ Qf, const double* __restrict__ Qb,
                                                              int64_t M, const int32_t* __restrict__ n0s, const double* __restrict__ W,
-                                                             double* __restrict__ out)
+                                                             double* __restrict__ out, int64_t W_stride)
 {
     const int64_t b = blockIdx.y, N = p.N;
+    W += b * W_stride;
     const int R = p.R, RP = (R + 15) & ~15, J = p.J, l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     constexpr int MAXI = 8;   // R <= 128
     double al[MAXI], be[MAXI];
@@ -284,39 +290,60 @@ __global__ void __launch_bounds__(256) predict_eval16_kernel(const ScanParams p,
 // repeats the segment from its carry and stores every step.  One workgroup of 64 lanes = one (segment, draw, direction); lane = row.
 constexpr int QSEG = 128;
 
-template <int PASS>
+// PD: (c, d) per draw (no shared table: cos / sin / exp of a step are computed where they are used; t: the time stamps)
+template <int PASS, bool PD>
 __global__ void __launch_bounds__(64) q_segment_kernel(const ScanParams p, const double* __restrict__ gy, double* __restrict__ Qf,
-                                                       double* __restrict__ Qb, double* __restrict__ EP, const double* __restrict__ Cin)
+                                                       double* __restrict__ Qb, double* __restrict__ EP, const double* __restrict__ Cin,
+                                                       const double* __restrict__ t)
 {
     const int64_t N = p.N, s = blockIdx.x, b = blockIdx.y, nseg = gridDim.x;
     const int dir = blockIdx.z, lane = threadIdx.x, R = p.R, Rp = R + 2, J = p.J;
     if (lane >= R) return;
-    const int64_t rec = p.rec_stride;
+    const int64_t rec = PD ? 0 : p.rec_stride;
+    const int rm0 = p.rowmap[lane];
+    [[maybe_unused]] const bool sinrow = (rm0 >> 30) & 1;
+    [[maybe_unused]] const double cpd = PD ? p.C[b * J + (rm0 & 0xfffff)] : 0.0, dpd = PD ? p.D[b * J + (rm0 & 0xfffff)] : 0.0;
+    // (v, x, phi) of step n for this lane's row
+    auto step = [&](int64_t n, double& v, double& x, double& ph) __attribute__((always_inline)) {
+        if constexpr (PD) {
+            double sn, cs;
+            sincos(dpd * t[n], &sn, &cs);
+            v = sinrow ? sn : cs; x = sinrow ? cs : sn;
+            ph = n > 0 ? exp(-cpd * (t[n] - t[n - 1])) : 0.0;
+        } else {
+            const double* r = p.tab + lane + n * rec;
+            v = r[0]; x = r[Rp]; ph = r[2 * Rp];
+        }
+    };
     const int64_t n_lo = s * QSEG, n_hi = n_lo + QSEG < N ? n_lo + QSEG : N;
     const double* zz = gy + b * N;
-    const double* tabr = p.tab + lane;
     const int64_t slot = ((b * 2 + dir) * nseg + s) * R + lane;
     if (dir == 0) {
         double q = PASS ? Cin[slot] : 0.0, prod = 1.0;
         double* qf = Qf + b * N * R + lane;
 #pragma unroll 4
         for (int64_t n = n_lo; n < n_hi; ++n) {
-            const double v = tabr[n * rec], ph = n > 0 ? tabr[n * rec + 2 * Rp] : 0.0;
+            double v, x, ph;
+            step(n, v, x, ph);
+            if (n == 0) ph = 0.0;
             q = fma(-zz[n], v, ph * q);                              // z_n = -dL/dy_n
             if (PASS) qf[n * R] = q; else prod *= ph;
         }
         if (!PASS) { EP[2 * slot] = q; EP[2 * slot + 1] = prod; }
     } else {
-        const int rm = p.rowmap[lane];
-        const int term = rm & 0xfffff;
-        const bool ks = (rm >> 30) & 1;
-        const double al = p.A[b * J + term], be = ks ? -p.Bc[b * J + term] : p.Bc[b * J + term];
+        const int term = rm0 & 0xfffff;
+        const double al = p.A[b * J + term], be = sinrow ? -p.Bc[b * J + term] : p.Bc[b * J + term];
         double q = PASS ? Cin[slot] : 0.0, prod = 1.0;
         double* qb = Qb + b * N * R + lane;
+        double vn, xn, phn;                                          // the step after n: its phi links n to n + 1
+        if (n_hi < N) step(n_hi, vn, xn, phn); else phn = 0.0;
 #pragma unroll 4
         for (int64_t n = n_hi - 1; n >= n_lo; --n) {
-            const double u = al * tabr[n * rec] + be * tabr[n * rec + Rp];
-            const double ph = n + 1 < N ? tabr[(n + 1) * rec + 2 * Rp] : 0.0;   // phi between t_n and t_{n+1} (record n+1)
+            double v, x, phc;
+            step(n, v, x, phc);
+            const double u = al * v + be * x;
+            const double ph = phn;                                   // phi between t_n and t_{n+1} (record n+1)
+            phn = phc;
             q = fma(-zz[n], u, ph * q);
             if (PASS) qb[n * R] = q; else prod *= ph;
         }
@@ -349,15 +376,20 @@ size_t pioran_predict_q_workspace_doubles(int64_t B, int64_t N, int32_t R)
     return (size_t)B * (size_t)N * (2 * (size_t)R + 1) + (size_t)B * 2 * nseg * (size_t)R * 3;
 }
 // tau-only factors of the evaluation: W [M][3][RP] + n0 [M] (as int32, rounded up to whole doubles)
-size_t pioran_predict_tau_workspace_doubles(int64_t M, int32_t R) { return (size_t)M * 3 * (size_t)((R + 15) & ~15) + (size_t)(M + 1) / 2 + 1; }
+// (ntab: 1 for a shared (c, d), the number of draws of a launch with per-draw (c, d))
+size_t pioran_predict_tau_workspace_doubles(int64_t M, int32_t R, int64_t ntab)
+{
+    return (size_t)ntab * (size_t)M * 3 * (size_t)((R + 15) & ~15) + (size_t)(M + 1) / 2 + 1;
+}
 
 // Windowed path: gy [B][N] = dL/dy of the windowed reverse mode (pioran_launch_block_grad with p.g_y) already on the stream.
 // work: pioran_predict_q_workspace_doubles doubles whose FIRST B N hold gy; tau_work: pioran_predict_tau_workspace_doubles.
 // R <= 64 (the windowed kernels stop at 63 rows).
 int pioran_launch_predict_from_gy(ScanParams p, double* work, double* tau_work, const double* t, int64_t M, const double* tau, double* mean_out,
-                                  hipStream_t stream)
+                                  hipStream_t stream, int cd_per_draw)
 {
-    if (!p.tab || p.npd_rows != 0 || p.R > 64 || M < 0 || p.N > 0x7fffffff) return PIORAN_ERR_UNSUPPORTED;
+    // cd_per_draw: p.C, p.D are [B][J], no shared table (p.tab unused), tau_work holds B sets of factors (n0 after the last one)
+    if ((!p.tab && !cd_per_draw) || p.npd_rows != 0 || p.R > 64 || M < 0 || p.N > 0x7fffffff) return PIORAN_ERR_UNSUPPORTED;
     const size_t BN = (size_t)p.B * (size_t)p.N;
     const int64_t nseg = (p.N + QSEG - 1) / QSEG;
     const double* gy = work;
@@ -366,16 +398,21 @@ int pioran_launch_predict_from_gy(ScanParams p, double* work, double* tau_work, 
     double* EP = Qb + BN * p.R;
     double* Cin = EP + (size_t)p.B * 2 * (size_t)nseg * (size_t)p.R * 2;
     const dim3 grid((unsigned)nseg, (unsigned)p.B, 2);
-    hipLaunchKernelGGL(q_segment_kernel<0>, grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin);
+    if (cd_per_draw) hipLaunchKernelGGL((q_segment_kernel<0, true>), grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin, t);
+    else hipLaunchKernelGGL((q_segment_kernel<0, false>), grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin, t);
     hipLaunchKernelGGL(q_carry_kernel, dim3((unsigned)p.B, 2), dim3(64), 0, stream, (int)p.R, nseg, EP, Cin);
-    hipLaunchKernelGGL(q_segment_kernel<1>, grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin);
+    if (cd_per_draw) hipLaunchKernelGGL((q_segment_kernel<1, true>), grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin, t);
+    else hipLaunchKernelGGL((q_segment_kernel<1, false>), grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin, t);
     if (M > 0) {
         // tau_work: pioran_predict_tau_workspace_doubles(M, R); filled here (once per chunk of draws: 10 us)
         double* W = tau_work;
-        int32_t* n0s = (int32_t*)(tau_work + (size_t)M * 3 * (size_t)((p.R + 15) & ~15));
-        hipLaunchKernelGGL(predict_tau_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, p, t, M, tau, n0s, W);
+        const int64_t W_stride = cd_per_draw ? (int64_t)M * 3 * ((p.R + 15) & ~15) : 0;
+        const int64_t ntab = cd_per_draw ? p.B : 1;
+        int32_t* n0s = (int32_t*)(tau_work + (size_t)ntab * (size_t)M * 3 * (size_t)((p.R + 15) & ~15));
+        hipLaunchKernelGGL(predict_tau_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)ntab), dim3(256), 0, stream, p, t, M, tau, n0s, W,
+                           cd_per_draw ? (int64_t)p.J : (int64_t)0, W_stride);
         hipLaunchKernelGGL(predict_eval16_kernel, dim3((unsigned)((M + 16 * EVT - 1) / (16 * EVT)), (unsigned)p.B), dim3(256), 0, stream, p, Qf,
-                           Qb, M, n0s, W, mean_out);
+                           Qb, M, n0s, W, mean_out, W_stride);
     }
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }

@@ -1198,6 +1198,30 @@ def test_predict_windowed_path_matches_step_by_step(ctx, J, N, B, basis):
         assert np.max(np.abs(got[i] - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
 
 
+@pytest.mark.parametrize("J,N,B", [(12, 1000, 9), (3, 130, 3), (20, 517, 20)])
+def test_predict_per_draw_cd_all_draws_in_one_launch(ctx, J, N, B):
+    """(c, d) per draw in every term, several draws: one launch of every kernel with per-draw windowed tables — against the draw-by-draw
+    path (`no_block`: step-by-step kernels) and the oracle."""
+    rng = np.random.default_rng(6100 + J)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B, per_draw_cd=True)
+    tau = np.sort(np.concatenate([rng.uniform(t[0] - 2, t[-1] + 2, 300), t[[0, N // 2, N - 1]]]))
+    ds = pj.Dataset(t, y, s2, ctx)
+    lib = pj._lib.lib()
+    got, st = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu, return_status=True)
+    assert lib.pioran_celerite_config_name(-1).decode() == "block (windowed prediction, per-draw tables)"
+    assert (st == 0).all()
+    ctx.set_option("no_block", "1")
+    try:
+        ref_dev = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu)
+    finally:
+        ctx.set_option("no_block", "0")
+    scale = np.max(np.abs(ref_dev), axis=1, keepdims=True)
+    assert np.max(np.abs(got - ref_dev) / scale) < 1e-9
+    for i in (0, B - 1):
+        ref = O.predict(A[i], Bc[i], C[i], Dd[i], tau, t, y - mu[i], nu[i] * s2) + mu[i]
+        assert np.max(np.abs(got[i] - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
+
+
 def test_predict_and_simulate_per_draw_cd(ctx):
     """predict / simulate with (c, d) given per draw [B][J] (QPO / CARMA posterior samples): every draw against the oracle."""
     rng = np.random.default_rng(91)
