@@ -1652,12 +1652,85 @@ static int simulate_shared(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, con
     return done(PIORAN_OK);
 }
 
+// (c, d) per draw in every term, several draws: per-draw windowed tables, all draws of a chunk in one launch of every kernel
+// (PIORAN_ERR_UNSUPPORTED: the shape does not fit the windowed kernel — the caller goes draw by draw)
+static int simulate_perdraw_windowed(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
+                                     const double* Dd, const double* t, const double* sigma2, const double* q, double* y_out)
+{
+    if (ctx->opt.no_block || ctx->opt.force_fallback || ctx->opt.scan_config[0] || 2 * J < 6 || !pioran_block_fits((int32_t)(2 * J), (int32_t)J))
+        return PIORAN_ERR_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pioran_ds* ds = nullptr;
+    std::vector<double> zeros((size_t)N, 0.0);
+    int rc = pioran_dataset_create(ctx, N, t, zeros.data(), sigma2, &ds);
+    if (rc) return rc;
+    auto done = [&](int code) { pioran_dataset_destroy(ds); return code; };
+    PrepState& s = ds->host;
+    if ((rc = prepare_state(ds, s, J, C, Dd, nullptr))) return done(rc);    // row map with both rows of every term
+    const int64_t bt = (int64_t)pioran_block_table_doubles(N, s.R, s.J);
+    int64_t chunk = B < 256 ? B : 256;
+    {
+        size_t free_b = 0, total_b = 0;
+        auto need = [&](int64_t nb) { return ((size_t)nb * (size_t)bt + pioran_block_grad_workspace_doubles(nb, N, s.R) + 3 * (size_t)nb * (size_t)N) * sizeof(double); };
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            while (chunk > 1 && need(chunk) > free_b / 2 + ctx->bwork.cap + ctx->bscratch.cap + ctx->bq.cap) chunk /= 2;
+    }
+    for (;;) {
+        rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bscratch, (size_t)chunk * (size_t)bt * sizeof(double));
+        if (!rc) rc = ensure(ctx, ctx->bq, (size_t)chunk * (size_t)N * sizeof(double));     // xi
+        if (rc != PIORAN_ERR_ALLOC || chunk == 1) break;
+        chunk /= 2;
+    }
+    if (rc) return done(rc);
+    const size_t cn = (size_t)chunk * (size_t)N * sizeof(double);
+    if ((rc = ensure(ctx, ctx->bY, cn))) return done(rc);     // noise
+    if ((rc = ensure(ctx, ctx->bS2, cn))) return done(rc);    // realisations
+    if ((rc = ensure(ctx, ctx->bout, chunk * sizeof(double)))) return done(rc);
+    if ((rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t)))) return done(rc);
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+        const size_t nbj = (size_t)nb * J * sizeof(double);
+        if ((rc = upload(ctx, ctx->bA, A + b0 * J, nbj))) return done(rc);
+        if ((rc = upload(ctx, ctx->bB, Bc + b0 * J, nbj))) return done(rc);
+        if ((rc = upload(ctx, ctx->bC, C + b0 * J, nbj))) return done(rc);
+        if ((rc = upload(ctx, ctx->bD, Dd + b0 * J, nbj))) return done(rc);
+        if ((rc = upload(ctx, ctx->bY, q + b0 * N, (size_t)nb * N * sizeof(double)))) return done(rc);
+        double* btab = (double*)ctx->bscratch.p;
+        if ((rc = pioran_launch_block_table_batch(N, s.R, s.J, nb, s.rowmap, ds->t, (const double*)ctx->bC.p, (const double*)ctx->bD.p, ds->y, ds->s2,
+                                                  btab, bt, ctx->stream))) return done(rc);
+        ScanParams p{};
+        p.opt = &ctx->opt;
+        p.N = N; p.J = s.J; p.R = s.R; p.B = nb; p.standard_rows = 1;
+        p.rec_stride = 3 * (int64_t)(s.R + 2) + 2;
+        p.tab_draw_stride = bt;
+        p.rowmap = s.rowmap; p.t = ds->t; p.y = ds->y; p.s2 = ds->s2;
+        p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = (const double*)ctx->bC.p; p.D = (const double*)ctx->bD.p;
+        p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
+        p.noise = (const double*)ctx->bY.p; p.ysim = (double*)ctx->bS2.p;
+        p.gw = (double*)ctx->bwork.p;
+        g_last_kernel = "block (windowed simulation, per-draw tables)";
+        rc = pioran_launch_block_sim(p, btab, (double*)ctx->bq.p, ctx->stream);
+        if (rc) { ctx->last_err = "windowed simulation launch failed"; return done(rc); }
+        if (hipMemcpyAsync(y_out + b0 * N, ctx->bS2.p, (size_t)nb * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            ctx_sync(ctx) != PIORAN_OK) {
+            ctx->last_err = "simulation copy-back failed";
+            return done(PIORAN_ERR_HIP);
+        }
+    }
+    return done(PIORAN_OK);
+}
+
 int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc,
                              const double* C, const double* Dd, int cd_shared, const double* t, const double* sigma2,
                              const double* q, double* y_out)
 {
     if (!ctx || N < 1 || B < 1 || J < 1 || !A || !Bc || !C || !Dd || !t || !sigma2 || !q || !y_out) return PIORAN_ERR_ARG;
     if (cd_shared || B == 1) return simulate_shared(ctx, N, B, J, A, Bc, C, Dd, t, sigma2, q, y_out);
+    {
+        const int rc = simulate_perdraw_windowed(ctx, N, B, J, A, Bc, C, Dd, t, sigma2, q, y_out);
+        if (rc != PIORAN_ERR_UNSUPPORTED) return rc;
+    }
     for (int64_t b = 0; b < B; ++b) {
         const int rc = simulate_shared(ctx, N, 1, J, A + b * J, Bc + b * J, C + b * J, Dd + b * J, t, sigma2, q + b * N, y_out + b * N);
         if (rc) return rc;

@@ -1199,7 +1199,7 @@ def test_predict_windowed_path_matches_step_by_step(ctx, J, N, B, basis):
 
 
 @pytest.mark.parametrize("J,N,B", [(12, 1000, 9), (3, 130, 3), (20, 517, 20)])
-def test_predict_per_draw_cd_all_draws_in_one_launch(ctx, J, N, B):
+def test_predict_and_simulate_per_draw_cd_all_draws_in_one_launch(ctx, J, N, B):
     """(c, d) per draw in every term, several draws: one launch of every kernel with per-draw windowed tables — against the draw-by-draw
     path (`no_block`: step-by-step kernels) and the oracle."""
     rng = np.random.default_rng(6100 + J)
@@ -1220,6 +1220,19 @@ def test_predict_per_draw_cd_all_draws_in_one_launch(ctx, J, N, B):
     for i in (0, B - 1):
         ref = O.predict(A[i], Bc[i], C[i], Dd[i], tau, t, y - mu[i], nu[i] * s2) + mu[i]
         assert np.max(np.abs(got[i] - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
+    # the simulation likewise
+    q = rng.standard_normal((B, N))
+    ys = ctx.simulate(A, Bc, C, Dd, t, s2, q)
+    assert lib.pioran_celerite_config_name(-1).decode() == "block (windowed simulation, per-draw tables)"
+    ctx.set_option("no_block", "1")
+    try:
+        ys2 = ctx.simulate(A, Bc, C, Dd, t, s2, q)
+    finally:
+        ctx.set_option("no_block", "0")
+    assert np.max(np.abs(ys - ys2) / np.max(np.abs(ys2), axis=1, keepdims=True)) < 1e-9
+    for i in (0, B - 1):
+        ref = O.sim(A[i], Bc[i], C[i], Dd[i], t, s2, q[i])
+        assert np.max(np.abs(ys[i] - ref)) <= 1e-9 * np.max(np.abs(ref))
 
 
 def test_predict_and_simulate_per_draw_cd(ctx):
