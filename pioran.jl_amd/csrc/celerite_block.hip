@@ -394,7 +394,7 @@ __device__ __forceinline__ void dma_pieces(const double* gsrc, double* ldst, int
 // order) and K = Sigma^-1 (block_grad_ws_doubles gives the layout).  The value it returns is bit-identical to the plain kernel's.
 // (the last 320: the chain wavefront's D_k and D_k (L^-1)_ik, sh.Li as it stands — the simulation applies L with it)
 __host__ __device__ constexpr int64_t block_grad_ws_doubles(int NB) { return (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256 + 320; }
-template <int NB, int EM, int PDM = 0, int ST = 0>   // ST: 0 no stores, 1 everything the reverse pass needs, 2 only Q (both orders) and L^-1, D (prediction, simulation)
+template <int NB, int EM, int PDM = 0, int ST = 0>   // ST: 0 no stores, 1 everything the reverse pass needs, 2 Q in A-operand order (prediction), 3 Q in C/D order and L^-1, D (simulation)
 __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4 && PDM != 1 && !ST) ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
 {
     constexpr bool PD = PDM != 0;
@@ -907,12 +907,18 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
                 }
                 double* gwk = p.gw + (b * NW + k) * GWS;
                 double* mg = sh.MG[w];                    // (its Gram partial was consumed before barrier 2)
+                if constexpr (ST != 2) {     // C/D order: the reverse pass and the simulation
 #pragma unroll
-                for (int g = 0; g < 4; ++g) { gwk[OFF_Q + (w * 4 + g) * 64 + lane] = qv[g]; mg[(4 * g + q) * 18 + c16] = qv[g]; }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    for (int g = 0; g < 4; ++g) gwk[OFF_Q + (w * 4 + g) * 64 + lane] = qv[g];
+                }
+                if constexpr (ST != 3) {     // A-operand order (one transposing LDS round trip): the reverse pass and the back-substitution
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) gwk[OFF_QF + (w * 4 + ks) * 64 + lane] = mg[c16 * 18 + 4 * ks + q];   // Q [row 16 w + 4 ks + q][step c16]
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    for (int g = 0; g < 4; ++g) mg[(4 * g + q) * 18 + c16] = qv[g];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) gwk[OFF_QF + (w * 4 + ks) * 64 + lane] = mg[c16 * 18 + 4 * ks + q];   // Q [row 16 w + 4 ks + q][step c16]
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
             }
         }
         if constexpr (ST) {
@@ -931,8 +937,10 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
 #pragma unroll
                     for (int g = 0; g < 4; ++g) gwk[OFF_K + g * 64 + lane] = kv[g];
                 }
+                if constexpr (ST != 2) {
 #pragma unroll
-                for (int i = lane; i < 16 * 18; i += 64) gwk[OFF_K + 256 + i] = sh.Li[i];
+                    for (int i = lane; i < 16 * 18; i += 64) gwk[OFF_K + 256 + i] = sh.Li[i];
+                }
             }
         }
         PIORAN_BSTAMP(9);
@@ -1735,12 +1743,12 @@ int launch_block_sim(const ScanParams& p, const double* btab, double* xi, hipStr
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
     if (lds > granted[dev]) {
-        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, 0, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, 0, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PIORAN_ERR_HIP;
         granted[dev] = lds;
     }
     const int64_t NW = (p.N + KW - 1) / KW;
-    hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, 2>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
+    hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, 3>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
     hipLaunchKernelGGL((block_sim_xi_kernel<NB>), dim3((unsigned)((NW + 15) / 16), (unsigned)p.B), dim3(256), 0, stream, p, xi);
     hipLaunchKernelGGL((celerite_block_sim_kernel<NB>), dim3((unsigned)p.B), dim3(64), 0, stream, p, btab, xi);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
