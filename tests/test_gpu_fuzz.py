@@ -153,3 +153,73 @@ def test_fuzz_windowed_prediction_and_simulation_vs_step_by_step_and_oracle(caps
     with capsys.disabled():
         print(f"\nwindowed prediction / simulation fuzz: 200 cases, worst deviation from the step-by-step kernels {worst}", file=sys.stderr)
     assert worst["dev"] < 1e-8, worst
+
+
+def test_fuzz_per_draw_prediction_simulation_and_dense_batches(capsys):
+    """Randomized shapes for the paths added last in round 3: (a) prediction / simulation with (c, d) per draw, all draws in one launch
+    (per-draw windowed tables), against the draw-by-draw step-by-step kernels — 80 cases; (b) batched dense launches (matrix index as a
+    grid dimension, steps in fours / pairs, shared-(c, d) batch build on the matrix cores; unsorted time stamps and more than 64 terms
+    take the older build kernels) against one matrix per call — 40 cases, every fifth against the LAPACK twin of the oracle."""
+    import numpy as np
+    import pioran_jl_amd as pj
+    from oracle import oracle as O
+    ctx = pj.Context(0)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    worst = {"dev": 0.0}
+    for idx in range(80):
+        rng = np.random.default_rng([20261006, idx])
+        J = int(rng.integers(3, 32)); B = int(rng.integers(2, 7)); N = int(rng.integers(1, 500))
+        gaps = rng.uniform(0.05, 2.0, N)
+        if rng.random() < 0.3:
+            gaps[rng.integers(0, N, max(1, N // 20))] *= rng.uniform(5, 200)
+        t = np.cumsum(gaps); y = rng.standard_normal(N); s2 = rng.uniform(0.01, 0.1, N)
+        A = rng.uniform(0.1, 2.0, (B, J)); Bc = rng.uniform(-0.05, 0.05, (B, J)) * A
+        C = rng.uniform(0.05, 2.0, (B, J)); Dd = rng.uniform(0.0, 3.0, (B, J))
+        mu = rng.standard_normal(B) * 0.1; nu = rng.uniform(0.5, 2.0, B)
+        M = int(rng.integers(1, 150))
+        tau = np.sort(rng.uniform(t[0] - 3, t[-1] + 3, M))
+        q = rng.standard_normal((B, N))
+        ds = pj.Dataset(t, y, s2, ctx)
+        pw, st = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu, return_status=True)
+        assert name() == "block (windowed prediction, per-draw tables)", (idx, name())
+        sw = ctx.simulate(A, Bc, C, Dd, t, s2, q)
+        assert name() == "block (windowed simulation, per-draw tables)", (idx, name())
+        try:
+            ctx.set_option("no_block", True)
+            po, st2 = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu, return_status=True)
+            so = ctx.simulate(A, Bc, C, Dd, t, s2, q)
+        finally:
+            ctx.set_option("no_block", False)
+        assert np.array_equal(st, st2), idx
+        ok = st == 0
+        for k, a_, b_ in (("predict", pw, po), ("simulate", sw, so)):
+            if ok.any():
+                dev = float(np.max(np.abs(a_[ok] - b_[ok]) / (1e-30 + np.max(np.abs(b_[ok]), axis=1, keepdims=True))))
+                if dev > worst["dev"]:
+                    worst = {"dev": dev, "idx": idx, "what": k + " (per-draw c, d)", "J": J, "N": N, "B": B}
+        ds.close()
+    for idx in range(40):
+        rng = np.random.default_rng([20261007, idx])
+        J = int(rng.integers(1, 9)) if idx % 8 else 70        # (more than 64 terms: the older build kernels)
+        B = int(rng.integers(2, 9)); N = int(rng.integers(1, 900)) if idx % 4 else int(rng.integers(1100, 1700))
+        t = np.cumsum(rng.uniform(0.05, 2.0, N))
+        if idx % 7 == 3:
+            t = rng.permutation(t)                              # unsorted: direct evaluation of every entry
+        y = rng.standard_normal(N); s2 = rng.uniform(0.01, 0.1, N)
+        A = rng.uniform(0.1, 2.0, (B, J)) / J; Bc = rng.uniform(-0.05, 0.05, (B, J)) * A
+        per_draw = bool(rng.random() < 0.3)
+        C = rng.uniform(0.05, 2.0, (B, J) if per_draw else (J,)); Dd = rng.uniform(0.0, 3.0, (B, J) if per_draw else (J,))
+        mu = rng.standard_normal(B) * 0.1; nu = rng.uniform(0.5, 2.0, B)
+        got, info = ctx.dense_nll_batch(A, Bc, C, Dd, t, y, s2, mu=mu, nu=nu, return_info=True)
+        one = np.array([ctx.dense_nll(A[i], Bc[i], C[i] if per_draw else C, Dd[i] if per_draw else Dd, t, y - mu[i], nu[i] * s2) for i in range(B)])
+        assert (info == 0).all(), idx
+        dev = float(np.max(np.abs(got - one) / np.abs(one)))
+        if dev > worst["dev"]:
+            worst = {"dev": dev, "idx": idx, "what": "dense batch", "J": J, "N": N, "B": B, "per_draw": per_draw}
+        if idx % 5 == 0:
+            i = B - 1
+            ref = O.dense_nll_numpy(A[i], Bc[i], C[i] if per_draw else C, Dd[i] if per_draw else Dd, t, y - mu[i], nu[i] * s2)
+            assert abs(got[i] - ref) <= 1e-10 * abs(ref), (idx, got[i], ref)
+    with capsys.disabled():
+        print(f"\nper-draw prediction / simulation and dense batch fuzz: 120 cases, worst deviation from the one-at-a-time paths {worst}", file=sys.stderr)
+    assert worst["dev"] < 1e-8, worst
