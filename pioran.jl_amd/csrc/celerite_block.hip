@@ -1539,9 +1539,10 @@ int launch_block_grad(const ScanParams& p, const double* btab, const double* gta
 // window w is U~_v Phi Q_w' (Phi: the decay between the two windows), Q_w = Sigma_w^-1 X_w as left by the forward pass (ST).  Hence
 //   z_w = q_y,w - Q_w h ,      h <- C_K o h + U~_w z_w        (windows backwards; h = sum over later windows of decayed U~ z)
 // With h[y row] held at -1 the product Q_w h is -z_w in one go (the y row of U~ is zero and its C_K is one, so it stays -1).
-// One wavefront per draw; both products on the matrix cores with the vector replicated over the 16 columns: Q_w is stored in A-operand
-// order (OFF_QF), the result's C/D registers are the A operand of the second product as they are, and U~ in C/D order (the reverse
-// pass's table) is its B operand; only h needs one LDS round trip per window (row index from lane & 15 to lane >> 4).
+// One wavefront per draw, plain FMAs (a first version ran both products on the matrix cores with the vector replicated over the 16
+// columns: 24 products of 64 cycles each per window, 0.88 ms per 625 windows — sixteen times the work for the convenience of the
+// layouts): Q_w in A-operand order gives every lane its rows' share of step lane & 15 (12 FMAs, two exchange rounds over the four row
+// quarters); for the update every lane owns one row and reads its sixteen steps of U~ (C/D order of the reverse pass's table) and z from LDS.
 // Output: gy[b][n] = -z_n (what the reverse mode calls dL/dy: pioran_launch_predict_from_gy takes it from there).
 template <int NB>
 __global__ void __launch_bounds__(64) celerite_block_backsolve_kernel(const ScanParams p, const double* __restrict__ gtab, double* __restrict__ gy)
@@ -1549,75 +1550,73 @@ __global__ void __launch_bounds__(64) celerite_block_backsolve_kernel(const Scan
     constexpr int64_t GWS = block_grad_ws_doubles(NB);
     constexpr int OFF_QF = NB * NB * 256 + 2 * NB * 256;
     constexpr int64_t GTS = 4 * (int64_t)NB * 256 + 16 * NB + 16 + 24;
-    __shared__ double hs[NB * 16];
+    __shared__ double hs[64], zs[16];
     const int64_t b = blockIdx.x, N = p.N, NW = (N + KW - 1) / KW;
     const int lane = threadIdx.x, q = lane >> 4, c16 = lane & 15;
     const int R = p.R, J = p.J;
-    double al[NB], be[NB], h[NB];
-#pragma unroll
-    for (int I = 0; I < NB; ++I) {
-        const int row = 16 * I + c16;
-        al[I] = be[I] = 0.0;
-        if (row < R) {
-            const int rm = p.rowmap[row];
-            const int term = rm & 0xfffff;
-            const bool ks = (rm >> 30) & 1;
-            al[I] = p.A[b * J + term];
-            be[I] = ks ? -p.Bc[b * J + term] : p.Bc[b * J + term];
-        }
-        h[I] = row == R ? -1.0 : 0.0;
+    // lane = row for h and its update (rows 0 .. 16 NB - 1); lane = (q, step c16) for the product Q_w h
+    const bool rowlane = lane < 16 * NB;
+    const int Ir = lane >> 4;                       // block column of this lane's row
+    double al = 0.0, be = 0.0;
+    if (lane < R) {
+        const int rm = p.rowmap[lane];
+        const int term = rm & 0xfffff;
+        al = p.A[b * J + term];
+        be = ((rm >> 30) & 1) ? -p.Bc[b * J + term] : p.Bc[b * J + term];
     }
+    double h = lane == R ? -1.0 : 0.0;              // (the y row held at -1: Q_w h is -z_w in one go)
     gtab += b * p.gtab_draw_stride;                // per-draw tables (every term's (c, d) per draw): 0 for the shared table
     const double* gwb = p.gw + b * NW * GWS + OFF_QF + lane;
-    const double* gtl = gtab + lane;
-    // operands of one window: Q (A-operand order), C o v and C o x (C/D order), C_K — fetched a window ahead of their use
-    struct Ops { double qf[NB][4], cv[NB][4], cx[NB][4], ck[NB]; };
+    // operands of one window: Q in A-operand order ((row 16 I + 4 ks + q, step c16) at [(I 4 + ks) 64 + lane]); C o v, C o x in C/D order
+    // ((step 4 g + q', row 16 I + c') at [(I 4 + g) 64 + 16 q' + c']: this lane's row, all sixteen steps); C_K of the row — a window ahead
+    struct Ops { double qf[NB][4], cv[16], cx[16], ck; };
     auto fetch = [&](int64_t k, Ops& o) __attribute__((always_inline)) {
         const double* gq = gwb + k * GWS;
-        const double* gt = gtl + k * GTS;
+        const double* gt = gtab + k * GTS;
 #pragma unroll
-        for (int I = 0; I < NB; ++I) {
+        for (int I = 0; I < NB; ++I)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                o.qf[I][ks] = gq[(I * 4 + ks) * 64];
-                o.cv[I][ks] = gt[(I * 4 + ks) * 64];
-                o.cx[I][ks] = gt[NB * 256 + (I * 4 + ks) * 64];
-            }
-            o.ck[I] = gtab[k * GTS + 2 * NB * 256 + 16 * I + c16];
+            for (int ks = 0; ks < 4; ++ks) o.qf[I][ks] = gq[(I * 4 + ks) * 64];
+        const int rl = rowlane ? lane : 0;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            const int off = ((rl >> 4) * 4 + (s_ >> 2)) * 64 + (s_ & 3) * 16 + (rl & 15);
+            o.cv[s_] = gt[off];
+            o.cx[s_] = gt[NB * 256 + off];
         }
+        o.ck = gt[2 * NB * 256 + rl];
     };
+    (void)Ir;
     Ops cur, nxt;
     fetch(NW - 1, cur);
     for (int64_t k = NW - 1; k >= 0; --k) {
         fetch(k > 0 ? k - 1 : 0, nxt);
-        if (q == 0) {
-#pragma unroll
-            for (int I = 0; I < NB; ++I) hs[16 * I + c16] = h[I];
-        }
+        hs[lane] = rowlane ? h : 0.0;
         __syncthreads();
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int I = 0; I < NB; ++I)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.qf[I][ks], hs[16 * I + 4 * ks + q], acc, 0, 0, 0);
-        // acc[g] (every column) = sum_r Q[r][step 4 g + q] h[r] = -z[step]
-        if (c16 == 0) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int64_t n = k * KW + 4 * g + q;
-                if (n < N) gy[b * N + n] = acc[g];
-            }
-        }
+        double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int I = 0; I < NB; ++I) {
-            d4 dh = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                dh = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[ks], fma(al[I], cur.cv[I][ks], be[I] * cur.cx[I][ks]), dh, 0, 0, 0);
-            h[I] = fma(cur.ck[I], h[I], dh[0]);     // (every row of the result is the same vector: U~ z over the rows 16 I + c16)
+            p0 = fma(cur.qf[I][0], hs[16 * I + q], p0);
+            p1 = fma(cur.qf[I][1], hs[16 * I + 4 + q], p1);
+            p0 = fma(cur.qf[I][2], hs[16 * I + 8 + q], p0);
+            p1 = fma(cur.qf[I][3], hs[16 * I + 12 + q], p1);
+        }
+        double acc = p0 + p1;                       // this lane's rows; the other three quarters of the rows sit 16, 32, 48 lanes away
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);                 // = sum_r Q[r][step c16] h[r] = -z[step c16]
+        if (q == 0) {
+            const int64_t n = k * KW + c16;
+            if (n < N) gy[b * N + n] = acc;
+            zs[c16] = -acc;
         }
         __syncthreads();
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; s_ += 2) {
+            d0 = fma(fma(al, cur.cv[s_], be * cur.cx[s_]), zs[s_], d0);
+            d1 = fma(fma(al, cur.cv[s_ + 1], be * cur.cx[s_ + 1]), zs[s_ + 1], d1);
+        }
+        h = fma(cur.ck, h, d0 + d1);                // h <- C_K o h + U~_w z_w
         cur = nxt;
     }
 }
@@ -1655,14 +1654,16 @@ __global__ void __launch_bounds__(64) celerite_block_sim_kernel(const ScanParams
 {
     constexpr int64_t GWS = block_grad_ws_doubles(NB);
     constexpr int OFF_Q = NB * NB * 256 + NB * 256;
-    __shared__ double fs[NB * 16];
+    __shared__ double fs[64], xs[16];
     const int64_t b = blockIdx.x, N = p.N, NW = (N + KW - 1) / KW;
     const int lane = threadIdx.x, q = lane >> 4, c16 = lane & 15;
     const int R = p.R, J = p.J;
     const int64_t RSB = block_rec_doubles(NB, J);
-    double al[NB][4], be[NB][4], f[NB];
+    const bool rowlane = lane < 16 * NB;
+    // lane = (q, step c16) for y_w = xi_w + U~_w f (U~ in A-operand order: rows 16 I + 4 ks + q); lane = row for f and its update
+    double al[NB][4], be[NB][4];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) {
+    for (int I = 0; I < NB; ++I)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int row = 16 * I + 4 * ks + q;
@@ -1670,65 +1671,62 @@ __global__ void __launch_bounds__(64) celerite_block_sim_kernel(const ScanParams
             if (row < R) {
                 const int rm = p.rowmap[row];
                 const int term = rm & 0xfffff;
-                const bool sn = (rm >> 30) & 1;
                 al[I][ks] = p.A[b * J + term];
-                be[I][ks] = sn ? -p.Bc[b * J + term] : p.Bc[b * J + term];
+                be[I][ks] = ((rm >> 30) & 1) ? -p.Bc[b * J + term] : p.Bc[b * J + term];
             }
         }
-        f[I] = 0.0;
-    }
+    double f = 0.0;
     btab += b * p.tab_draw_stride;                 // per-draw tables: 0 for the shared table
-    const double* gwb = p.gw + b * NW * GWS + OFF_Q + lane;
+    const double* gwb = p.gw + b * NW * GWS + OFF_Q;
     const double* xib = xi + b * N;
-    struct Ops { double qc[NB][4], cv[NB][4], cx[NB][4], ck[NB], x[4]; };
+    // Q in C/D order ((row 16 I + c', step 4 g + q') at [(I 4 + g) 64 + 16 q' + c']: this lane's row, all sixteen steps)
+    struct Ops { double cv[NB][4], cx[NB][4], qr[16], ck, x; };
     auto fetch = [&](int64_t k, Ops& o) __attribute__((always_inline)) {
         const double* gq = gwb + k * GWS;
         const double* rec = btab + k * RSB;
 #pragma unroll
-        for (int I = 0; I < NB; ++I) {
+        for (int I = 0; I < NB; ++I)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                o.qc[I][ks] = gq[(I * 4 + ks) * 64];
                 o.cv[I][ks] = rec[(I * 4 + ks) * 64 + lane];
                 o.cx[I][ks] = rec[NB * 256 + (I * 4 + ks) * 64 + lane];
             }
-            o.ck[I] = rec[3 * NB * 256 + 16 * I + c16];
-        }
+        const int rl = rowlane ? lane : 0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int64_t n = k * KW + 4 * g + q;
-            o.x[g] = n < N ? xib[n] : 0.0;
-        }
+        for (int s_ = 0; s_ < 16; ++s_) o.qr[s_] = gq[((rl >> 4) * 4 + (s_ >> 2)) * 64 + (s_ & 3) * 16 + (rl & 15)];
+        o.ck = rec[3 * NB * 256 + rl];
+        const int64_t n = k * KW + c16;
+        o.x = n < N ? xib[n] : 0.0;
     };
     Ops cur, nxt;
     fetch(0, cur);
     for (int64_t k = 0; k < NW; ++k) {
         fetch(k + 1 < NW ? k + 1 : k, nxt);
-        if (q == 0) {
-#pragma unroll
-            for (int I = 0; I < NB; ++I) fs[16 * I + c16] = f[I];
-        }
+        fs[lane] = rowlane ? f : 0.0;
+        if (q == 0) xs[c16] = cur.x;
         __syncthreads();
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int I = 0; I < NB; ++I)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fma(al[I][ks], cur.cv[I][ks], be[I][ks] * cur.cx[I][ks]), fs[16 * I + 4 * ks + q], acc, 0, 0, 0);
-        if (c16 == 0) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int64_t n = k * KW + 4 * g + q;
-                if (n < N) p.ysim[b * N + n] = cur.x[g] + acc[g];
-            }
-        }
+        double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int I = 0; I < NB; ++I) {
-            d4 df = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) df = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.x[ks], cur.qc[I][ks], df, 0, 0, 0);
-            f[I] = fma(cur.ck[I], f[I], df[0]);
+            p0 = fma(fma(al[I][0], cur.cv[I][0], be[I][0] * cur.cx[I][0]), fs[16 * I + q], p0);
+            p1 = fma(fma(al[I][1], cur.cv[I][1], be[I][1] * cur.cx[I][1]), fs[16 * I + 4 + q], p1);
+            p0 = fma(fma(al[I][2], cur.cv[I][2], be[I][2] * cur.cx[I][2]), fs[16 * I + 8 + q], p0);
+            p1 = fma(fma(al[I][3], cur.cv[I][3], be[I][3] * cur.cx[I][3]), fs[16 * I + 12 + q], p1);
         }
+        double acc = p0 + p1;
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);                 // (U~_w f)[step c16]
+        if (q == 0) {
+            const int64_t n = k * KW + c16;
+            if (n < N) p.ysim[b * N + n] = cur.x + acc;
+        }
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; s_ += 2) {
+            d0 = fma(cur.qr[s_], xs[s_], d0);
+            d1 = fma(cur.qr[s_ + 1], xs[s_ + 1], d1);
+        }
+        f = fma(cur.ck, f, d0 + d1);                // f <- C_K o f + Q_w' xi_w
         __syncthreads();
         cur = nxt;
     }
