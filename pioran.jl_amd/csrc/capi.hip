@@ -14,7 +14,7 @@ int pioran_launch_block_sim(const ScanParams& p, const double* btab, double* xi,
 int pioran_launch_block_solve(const ScanParams& p, const double* btab, const double* gtab, double* gy, hipStream_t stream);   // celerite_block.hip
 size_t pioran_predict_tau_workspace_doubles(int64_t M, int32_t R, int64_t ntab);
 int pioran_launch_predict_from_gy(ScanParams p, double* work, double* tau_work, const double* t, int64_t M, const double* tau, double* mean_out,
-                                  hipStream_t stream, int cd_per_draw);
+                                  hipStream_t stream, int cd_per_draw, int tau_sorted);
 
 
 #include <cmath>
@@ -1152,6 +1152,8 @@ int pioran_celerite_logl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a,
     return pioran_celerite_logl_batch(ctx->scalar_ds, 1, J, a, b, c, d, 1, nullptr, nullptr, y, sigma2, out, status);
 }
 
+static int is_sorted(const double* t, int64_t N);   // (below, with the dense solver)
+
 // ---- posterior mean / simulation --------------------------------------------------------------------
 // shared (c, d) only; draws are processed in chunks of at most 256 (one workgroup per draw, factor kept in HBM)
 static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
@@ -1218,7 +1220,7 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
             // -z = -K^-1 (y - mu) [nb][N] into the head of the Q workspace
             rc = pioran_launch_block_solve(p, s.btab, (const double*)ctx->bgtab.p, (double*)ctx->bscratch.p, ctx->stream);
             if (!rc) rc = pioran_launch_predict_from_gy(p, (double*)ctx->bscratch.p, (double*)ctx->bK.p, ds->t, M, (const double*)ctx->bshift.p, (double*)ctx->bY.p,
-                                                        ctx->stream, 0);
+                                                        ctx->stream, 0, is_sorted(tau, M));
         } else {
             g_last_kernel = "wide (step-by-step prediction)";
             rc = pioran_launch_predict(p, (double*)ctx->bwork.p, ds->t, M, (const double*)ctx->bshift.p, (double*)ctx->bY.p,
@@ -1299,7 +1301,7 @@ static int predict_perdraw_windowed(pioran_ds* ds, int64_t B, int64_t J, const d
         g_last_kernel = "block (windowed prediction, per-draw tables)";
         rc = pioran_launch_block_solve(p, btab, gtab, (double*)ctx->bq.p, ctx->stream);
         if (!rc) rc = pioran_launch_predict_from_gy(p, (double*)ctx->bq.p, (double*)ctx->bK.p, ds->t, M, (const double*)ctx->bshift.p,
-                                                    (double*)ctx->bY.p, ctx->stream, 1);
+                                                    (double*)ctx->bY.p, ctx->stream, 1, is_sorted(tau, M));
         if (rc) { ctx->last_err = "windowed prediction launch failed"; return rc; }
         if ((rc = download(ctx, mean_out + b0 * M, ctx->bY.p, (size_t)nb * M * sizeof(double)))) return rc;
         if (status) if ((rc = download(ctx, status + b0, ctx->bst.p, nb * sizeof(int32_t)))) return rc;

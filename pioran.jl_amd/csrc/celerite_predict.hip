@@ -351,6 +351,108 @@ __global__ void __launch_bounds__(64) q_segment_kernel(const ScanParams p, const
     }
 }
 
+// ---- ascending tau: the second pass and the evaluation in one kernel, Qf / Qb never written ---------------------------------------
+// With tau sorted (the reference requires it) n0 is non-decreasing, so the evaluation times that need Qf of step n (n0 - 1 = n) or Qb of
+// step n (n0 = n) are a contiguous run of indices: the wavefront that walks a segment (as pass 1 would, from the segment's carry) forms
+//   sum_r Qf_n[r] (al_r Wc + be_r Ws)   resp.   sum_r Qb_n[r] Wv      (one wave reduction per evaluation time)
+// right where q is in its registers and writes it to part[dir][b][m] (zero where a side has no data point: predict_part_init_kernel);
+// predict_part_sum_kernel adds the two parts and mu_b (no atomics: the result does not depend on the order the blocks finish in).
+// Saves the 2 N R doubles per draw that pass 1 writes and the evaluation reads back.
+__global__ void __launch_bounds__(256) predict_part_init_kernel(int64_t n, double* __restrict__ part)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) part[i] = 0.0;
+}
+__global__ void __launch_bounds__(256) predict_part_sum_kernel(const ScanParams p, int64_t M, const double* __restrict__ part, double* __restrict__ out)
+{
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t b = blockIdx.y, BM = (int64_t)gridDim.y * M;
+    if (m < M) out[b * M + m] = (part[b * M + m] + part[BM + b * M + m]) + (p.mu ? p.mu[b] : 0.0);
+}
+
+template <bool PD>
+__global__ void __launch_bounds__(64) q_eval_fused_kernel(const ScanParams p, const double* __restrict__ gy, const double* __restrict__ Cin,
+                                                          const double* __restrict__ t, int64_t M, const int32_t* __restrict__ n0s,
+                                                          const double* __restrict__ W, int64_t W_stride, double* __restrict__ out)
+{
+    const int64_t N = p.N, s = blockIdx.x, b = blockIdx.y, nseg = gridDim.x;
+    const int dir = blockIdx.z, lane = threadIdx.x, R = p.R, Rp = R + 2, J = p.J, RP = (R + 15) & ~15;
+    const bool live = lane < R;                        // (idle lanes stay in: the wave reductions below want all 64)
+    const int rl = live ? lane : 0;
+    const int64_t rec = PD ? 0 : p.rec_stride;
+    const int rm0 = p.rowmap[rl];
+    const bool sinrow = (rm0 >> 30) & 1;
+    const int term = rm0 & 0xfffff;
+    [[maybe_unused]] const double cpd = PD ? p.C[b * J + term] : 0.0, dpd = PD ? p.D[b * J + term] : 0.0;
+    auto step = [&](int64_t n, double& v, double& x, double& ph) __attribute__((always_inline)) {
+        if constexpr (PD) {
+            double sn, cs;
+            sincos(dpd * t[n], &sn, &cs);
+            v = sinrow ? sn : cs; x = sinrow ? cs : sn;
+            ph = n > 0 ? exp(-cpd * (t[n] - t[n - 1])) : 0.0;
+        } else {
+            const double* r = p.tab + rl + n * rec;
+            v = r[0]; x = r[Rp]; ph = r[2 * Rp];
+        }
+    };
+    auto lower = [&](int64_t key) {                    // first m with n0s[m] >= key
+        int64_t lo = 0, hi = M;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (n0s[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const int64_t n_lo = s * QSEG, n_hi = n_lo + QSEG < N ? n_lo + QSEG : N;
+    const double* zz = gy + b * N;
+    const int64_t slot = ((b * 2 + dir) * nseg + s) * R + rl;
+    const double a_ = p.A[b * J + term], b_ = p.Bc[b * J + term];
+    const double* Wb = W + b * W_stride + rl;
+    double* ob = out + ((int64_t)dir * gridDim.y + b) * M;      // out: part[2][B][M]
+    double q = live ? Cin[slot] : 0.0;
+    if (dir == 0) {
+        const double ae = live ? (sinrow ? -b_ : a_) : 0.0, bee = live ? (sinrow ? a_ : b_) : 0.0;   // U~_r(tau) = ae cos + bee sin
+        int64_t mp = lower(n_lo + 1);                  // evaluation times with n0 - 1 in [n_lo, n_hi)
+        const int64_t m_hi = lower(n_hi + 1);
+        int64_t nn = mp < m_hi ? n0s[mp] - 1 : N;      // the step the next evaluation time waits for
+        for (int64_t n = n_lo; n < n_hi; ++n) {
+            double v, x, ph;
+            step(n, v, x, ph);
+            if (n == 0) ph = 0.0;
+            q = fma(-zz[n], v, ph * q);
+            while (nn == n) {
+                const double* w = Wb + mp * 3 * RP;
+                const double sum = wave_sum(q * fma(ae, w[0], bee * w[RP]));
+                if (lane == 0) ob[mp] = sum;
+                ++mp;
+                nn = mp < m_hi ? n0s[mp] - 1 : N;
+            }
+        }
+    } else {
+        const double al = live ? a_ : 0.0, be = live ? (sinrow ? -b_ : b_) : 0.0;
+        const int64_t m_lo = lower(n_lo);              // evaluation times with n0 in [n_lo, n_hi)
+        int64_t mp = lower(n_hi) - 1;
+        int64_t nn = mp >= m_lo ? n0s[mp] : -1;
+        double vn, xn, phn;
+        if (n_hi < N) step(n_hi, vn, xn, phn); else phn = 0.0;
+        for (int64_t n = n_hi - 1; n >= n_lo; --n) {
+            double v, x, phc;
+            step(n, v, x, phc);
+            const double u = al * v + be * x;
+            const double ph = phn;
+            phn = phc;
+            q = fma(-zz[n], u, ph * q);
+            while (nn == n) {
+                const double* w = Wb + mp * 3 * RP;
+                const double sum = wave_sum(live ? q * w[2 * RP] : 0.0);
+                if (lane == 0) ob[mp] = sum;
+                --mp;
+                nn = mp >= m_lo ? n0s[mp] : -1;
+            }
+        }
+    }
+}
+
 // carries into the segments: forward C_0 = 0, C_{s+1} = E_s + P_s C_s; backward the same from the last segment down
 __global__ void __launch_bounds__(64) q_carry_kernel(int R, int64_t nseg, const double* __restrict__ EP, double* __restrict__ Cin)
 {
@@ -386,7 +488,7 @@ size_t pioran_predict_tau_workspace_doubles(int64_t M, int32_t R, int64_t ntab)
 // work: pioran_predict_q_workspace_doubles doubles whose FIRST B N hold gy; tau_work: pioran_predict_tau_workspace_doubles.
 // R <= 64 (the windowed kernels stop at 63 rows).
 int pioran_launch_predict_from_gy(ScanParams p, double* work, double* tau_work, const double* t, int64_t M, const double* tau, double* mean_out,
-                                  hipStream_t stream, int cd_per_draw)
+                                  hipStream_t stream, int cd_per_draw, int tau_sorted)
 {
     // cd_per_draw: p.C, p.D are [B][J], no shared table (p.tab unused), tau_work holds B sets of factors (n0 after the last one)
     if ((!p.tab && !cd_per_draw) || p.npd_rows != 0 || p.R > 64 || M < 0 || p.N > 0x7fffffff) return PIORAN_ERR_UNSUPPORTED;
@@ -401,19 +503,29 @@ int pioran_launch_predict_from_gy(ScanParams p, double* work, double* tau_work, 
     if (cd_per_draw) hipLaunchKernelGGL((q_segment_kernel<0, true>), grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin, t);
     else hipLaunchKernelGGL((q_segment_kernel<0, false>), grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin, t);
     hipLaunchKernelGGL(q_carry_kernel, dim3((unsigned)p.B, 2), dim3(64), 0, stream, (int)p.R, nseg, EP, Cin);
-    if (cd_per_draw) hipLaunchKernelGGL((q_segment_kernel<1, true>), grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin, t);
-    else hipLaunchKernelGGL((q_segment_kernel<1, false>), grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin, t);
-    if (M > 0) {
-        // tau_work: pioran_predict_tau_workspace_doubles(M, R); filled here (once per chunk of draws: 10 us)
-        double* W = tau_work;
-        const int64_t W_stride = cd_per_draw ? (int64_t)M * 3 * ((p.R + 15) & ~15) : 0;
-        const int64_t ntab = cd_per_draw ? p.B : 1;
-        int32_t* n0s = (int32_t*)(tau_work + (size_t)ntab * (size_t)M * 3 * (size_t)((p.R + 15) & ~15));
+    // tau_work: pioran_predict_tau_workspace_doubles; the tau-only factors are computed here (once per chunk of draws: 10 us)
+    double* W = tau_work;
+    const int64_t W_stride = cd_per_draw ? (int64_t)M * 3 * ((p.R + 15) & ~15) : 0;
+    const int64_t ntab = cd_per_draw ? p.B : 1;
+    int32_t* n0s = (int32_t*)(tau_work + (size_t)ntab * (size_t)M * 3 * (size_t)((p.R + 15) & ~15));
+    if (M > 0)
         hipLaunchKernelGGL(predict_tau_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)ntab), dim3(256), 0, stream, p, t, M, tau, n0s, W,
                            cd_per_draw ? (int64_t)p.J : (int64_t)0, W_stride);
+    if (M > 0 && tau_sorted && M <= p.N * (int64_t)p.R) {
+        // ascending tau: second pass and evaluation fused, Qf / Qb never written (their storage holds the two parts of the result)
+        double* part = Qf;
+        const int64_t np = 2 * (int64_t)p.B * M;
+        hipLaunchKernelGGL(predict_part_init_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, np, part);
+        if (cd_per_draw) hipLaunchKernelGGL((q_eval_fused_kernel<true>), grid, dim3(64), 0, stream, p, gy, Cin, t, M, n0s, W, W_stride, part);
+        else hipLaunchKernelGGL((q_eval_fused_kernel<false>), grid, dim3(64), 0, stream, p, gy, Cin, t, M, n0s, W, W_stride, part);
+        hipLaunchKernelGGL(predict_part_sum_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)p.B), dim3(256), 0, stream, p, M, part, mean_out);
+        return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+    }
+    if (cd_per_draw) hipLaunchKernelGGL((q_segment_kernel<1, true>), grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin, t);
+    else hipLaunchKernelGGL((q_segment_kernel<1, false>), grid, dim3(64), 0, stream, p, gy, Qf, Qb, EP, Cin, t);
+    if (M > 0)
         hipLaunchKernelGGL(predict_eval16_kernel, dim3((unsigned)((M + 16 * EVT - 1) / (16 * EVT)), (unsigned)p.B), dim3(256), 0, stream, p, Qf,
                            Qb, M, n0s, W, mean_out, W_stride);
-    }
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
