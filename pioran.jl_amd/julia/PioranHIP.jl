@@ -283,8 +283,10 @@ end
 """
     predict_batch(ds, A, B, c, d, τ; μ, ν)
 
-Posterior mean at the times `τ` for every draw (column) of `A`, `B` with shared `c`, `d`: what `mean(posterior(f(t, σ²), y), τ)`
-(src/scalable_GP.jl:64-72) computes one draw at a time.  Returns an `length(τ) × nbatch` matrix and the status vector.
+Posterior mean at the times `τ` for every draw (column) of `A`, `B`: what `mean(posterior(f(t, σ²), y), τ)`
+(src/scalable_GP.jl:64-72) computes one draw at a time.  `c`, `d`: length-`J` vectors shared by the draws, or `J × nbatch` matrices
+(posterior draws of QPO / CARMA / free Celerite models: all draws still go through every kernel in one launch, each with its own
+tables).  Ascending `τ` takes the fused evaluation.  Returns an `length(τ) × nbatch` matrix and the status vector.
 """
 function predict_batch(ds::Dataset, A::Matrix{Float64}, B::Matrix{Float64}, c::VecOrMat{Float64}, d::VecOrMat{Float64},
                        τ::Vector{Float64}; μ::Union{Nothing, Vector{Float64}} = nothing, ν::Union{Nothing, Vector{Float64}} = nothing)
@@ -316,7 +318,8 @@ end
 """
     simulate_batch(A, B, c, d, t, σ², q)
 
-GP realisations `y = L D^(1/2) q` for every column of `A`, `B` from the standard normals `q` (`length(t) × nbatch`);
+GP realisations `y = L D^(1/2) q` for every column of `A`, `B` (`c`, `d` shared vectors or `J × nbatch` matrices) from the standard
+normals `q` (`length(t) × nbatch`);
 `simulate(rng, cov, t, σ²)` (src/celerite_solver.jl:497-513) is `simulate_batch(..., randn(rng, N, 1))`.
 """
 function simulate_batch(A::Matrix{Float64}, B::Matrix{Float64}, c::VecOrMat{Float64}, d::VecOrMat{Float64}, t::Vector{Float64},
