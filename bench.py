@@ -101,6 +101,45 @@ def algorithmic_flops(N: int, R: int) -> float:
     return (N - 1) * (5.5 * R * R + 18.0 * R)
 
 
+def spawn_ranks(n: int, script: str, argv, timeout_s: float | None = None) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), relay the child's
+    stdout (rank 0's JSON line) and return its exit code.  Called before anything in this process has touched the GPU
+    (`import torch` and `torch.cuda.device_count()` do not); this process is never replaced (no exec), it only waits.
+    The farm of docs/src/ultranest.md:143-149 is `mpiexec -n N julia script.jl`; this is its one-node counterpart."""
+    import signal
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, n))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script, *argv]
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("PIORAN_BENCH_SPAWN_TIMEOUT", "1500"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        # the process group we started ourselves (start_new_session): the launcher and its ranks, nothing else
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, _ = proc.communicate()
+        sys.stdout.write(out or "")
+        print(json.dumps({"error": f"the {n} ranks did not finish within {timeout_s:.0f} s; killed", "n_gpus": n}), flush=True)
+        return 124
+    sys.stdout.write(out or "")
+    sys.stdout.flush()
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,9 +159,29 @@ def main():
                          "on ONE device, which RCCL refuses — tests/test_gpu_multi.py)")
     ap.add_argument("--device", type=int, default=None,
                     help="GPU of this rank (default LOCAL_RANK); with --dist-backend gloo several ranks may name the same one")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks through the child launcher even for --gpus 1 (tests: the spawned path at N = 1)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
     import torch
+
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # under torch.distributed.run (or any launcher)
+    if not launched and (args.gpus > 1 or args.spawn):
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet (device_count does not).
+        ndev = torch.cuda.device_count()
+        need = args.gpus if (args.dist_backend == "nccl" and args.device is None) else 1
+        if ndev < need:
+            print(json.dumps({"error": f"--gpus {args.gpus} over {args.dist_backend} needs {need} visible GPU(s), this host has {ndev}",
+                              "n_gpus": args.gpus, "visible_gpus": ndev}), flush=True)
+            raise SystemExit(2)
+        if args.dist_backend == "nccl" and args.device is not None and args.gpus > 1:
+            print(json.dumps({"error": "RCCL refuses several ranks on one device: --device with --gpus > 1 needs --dist-backend gloo",
+                              "n_gpus": args.gpus}), flush=True)
+            raise SystemExit(2)
+        raise SystemExit(spawn_ranks(args.gpus, str(Path(__file__).resolve()), [a for a in sys.argv[1:] if a != "--spawn"]))
+
     import torch.distributed as dist
     import pioran_jl_amd as pj
 
@@ -130,8 +189,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        # the launcher's world size is what actually runs (and what n_gpus reports); say so instead of guessing
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; reporting n_gpus={world}",
+                  file=sys.stderr)
     if args.device is not None:
         local_rank = args.device
     torch.cuda.set_device(local_rank)

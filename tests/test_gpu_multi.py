@@ -1,13 +1,14 @@
-"""GPU test (-m gpu) of the process-per-GPU farm on REAL devices: bench.py under torch.distributed.run with one rank per
-GPU over RCCL — BASELINE.json configs[3] (N = 1e4, J = 20, 4096 draws per GPU, all-gather of log L).  Skipped on boxes
-with fewer than two GPUs; tests/test_farm.py covers the same sharding / gather logic with gloo on CPU, and
+"""GPU test (-m gpu) of the process-per-GPU farm on REAL devices: `python bench.py --gpus N` — the exact command the driver
+runs, NO launcher in the test: bench.py starts its own ranks (bench.spawn_ranks: torch.distributed.run as a child process)
+— with one rank per GPU over RCCL: BASELINE.json configs[3] (N = 1e4, J = 20, 4096 draws per GPU, all-gather of log L).
+The RCCL test is skipped on boxes with fewer than two GPUs; tests/test_farm.py covers the same sharding / gather logic with
+gloo on CPU, tests/test_bench_spawn.py the launcher-less start on CPU, and
 tests/test_gpu_configs.py::test_config4_global_batch_on_one_gpu the 8-way cut at full size on one device.
 
-The launcher runs as a fresh CHILD process (subprocess): the pytest process itself is never replaced.
+bench.py runs as a fresh CHILD process (subprocess): the pytest process itself is never replaced.
 """
 import json
 import os
-import socket
 import subprocess
 import sys
 from pathlib import Path
@@ -21,33 +22,25 @@ ROOT = Path(__file__).resolve().parents[1]
 NGPU = torch.cuda.device_count()          # counting devices does not initialise the GPU
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def _bench(n, extra=(), steps=3):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    base = [sys.executable]
-    if n > 1:
-        base += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-                 "--master-port", str(_free_port())]
-    cmd = base + [str(ROOT / "bench.py"), "--gpus", str(n), "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline",
-                  "--no-secondary", *extra]
+    """`python bench.py --gpus n ...` exactly as the driver types it: no torch.distributed.run here."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline",
+           "--no-secondary", *extra]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     return json.loads(line)
 
 
 def test_bench_multi_rank_loop_two_ranks_on_one_gpu():
     """bench.py's multi-rank loop (double-buffered scan / gather, slice check, --verify-gather, MAX-reduced timing) run for real
-    on ONE GPU: two ranks under torch.distributed.run, both on cuda:0, log-L gathered over gloo (RCCL refuses two ranks on
-    one device; the transport is the only difference from the 8-GPU run).  A fresh child process — pytest is never replaced."""
+    on ONE GPU: `python bench.py --gpus 2` starts its own two ranks, both on cuda:0, log-L gathered over gloo (RCCL refuses
+    two ranks on one device; the transport is the only difference from the 8-GPU run)."""
     one = _bench(1, ["--batch", "1024"], steps=4)
+    # the spawned path at N = 1 (one rank under the child launcher, collective path taken) against the plain process
+    one_spawned = _bench(1, ["--batch", "1024", "--spawn", "--dist-backend", "gloo"], steps=4)
+    assert one_spawned["n_gpus"] == 1 and 0.8 * one["value"] < one_spawned["value"] < 1.25 * one["value"], (one["value"], one_spawned["value"])
     two = _bench(2, ["--dist-backend", "gloo", "--device", "0", "--batch", "1024", "--verify-gather"], steps=4)
     assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 2048 and two["steps"] == 4
     assert two["gather_verified"] is True          # rank 1's slice == a single-process evaluation of rank 1's batch, bit for bit
