@@ -23,6 +23,10 @@ What it extracts (data only — inputs and expected outputs, never source text):
     (simu_single: integrated-power normalisation; simu_double: DoubleBendingPowerLaw; simu_periodic: a CustomMean
     sinusoid, i.e. a per-draw mean FUNCTION): 6075 + 6142 + 8080 points with the reference's own log-likelihoods.
 
+ 1c. turing_chain.npz — the reference's stored NUTS chains (docs/src/data/subset_simu_single.h5, 9 x 1000 draws): the
+    sampler's `log_density` per draw minus the closed-form log prior and log Jacobian = log-likelihoods the reference
+    computed in the high-likelihood region (make_turing_chain_fixture).  HDF5 read by oracle/h5mini.py.
+
  2. reference_literals.json — numeric literals of the reference's tests that pin the path:
     test/test_psd.jl:30-39 (20 SHO amplitudes), test/test_acvf.jl:19-33, test/test_covariancefunctions.jl,
     test/test_carma.jl:55-69, test/test_scalablegp.jl:110-118 (N=6 series x 10 parameter sets),
@@ -187,6 +191,69 @@ def example_run_logl(name, t, y, yerr, params):
     return vals
 
 
+def make_turing_chain_fixture():
+    """The reference's stored NUTS chains: docs/src/data/subset_simu_single.h5 (= examples/turing_distributed/inference/
+    subset_simu_single.h5, byte-identical), written by the script of docs/src/turing.md:170-256 — 9 chains x 1000 draws (the
+    adaptation phase included) of the model with the sampled shift `c`, on docs/src/data/subset_simu.txt (N = 250, SHO-20).
+    AdvancedHMC's `log_density` statistic is stored per draw: the log-density the sampler evaluated in UNCONSTRAINED space,
+        log_density = log L(theta) + sum_k log prior_k(theta_k) + sum_k log |d theta_k / d phi_k|,
+    with the priors of docs/src/turing.md:209-215 (all literal) and Bijectors' transforms — the logit of the scaled variable for
+    the bounded supports (Uniform, LogUniform: log|J| = log((x - a)(b - x) / (b - a))), log for the positive ones (LogNormal,
+    Gamma: log|J| = log x), identity for the Normal.  Prior and Jacobian are closed forms of theta alone, so
+        logl = log_density - (log prior + log |J|)
+    is a log-likelihood the REFERENCE computed (through its ForwardDiff Duals, whose value part is the same arithmetic), at the
+    draws of a converged sampler — the high-likelihood region the nested-sampling prior draws of (1) under-sample.  (`lp`, the
+    other stored statistic, is not the density at the stored draw — it lags it — and is not used.)  The model matching the
+    stored numbers: approx(P, f_min, f_max, 20, variance, "SHO") with the variance normalisation (`is_integrated_power = false`,
+    as in (1): the normalisation in force when these docs runs were made).  Stored only after the decomposition closes to
+    < 1e-10 relative on a sample of draws with this oracle."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    from h5mini import H5
+    from scipy import stats
+    f = H5(REF / "docs/src/data/subset_simu_single.h5")
+    assert (REF / "docs/src/data/subset_simu_single.h5").read_bytes() == (REF / "examples/turing_distributed/inference/subset_simu_single.h5").read_bytes()
+    tr = f.tree()
+    names = ["α₁", "f₁", "α₂", "variance", "ν", "μ", "c"]
+    P = np.stack([f.read_data(tr["/parameters/" + k]).reshape(-1) for k in names], axis=1)       # [chain * 1000 + draw][7]
+    ld = f.read_data(tr["/internals/log_density"]).reshape(-1)
+    nchain, ndraw = f.read_data(tr["/internals/log_density"]).shape
+    series = np.loadtxt(REF / "docs/src/data/subset_simu.txt")
+    t, y, yerr = series[:, 0], series[:, 1], series[:, 2]
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    f0, fM = f_min / 20.0, f_max * 20.0
+    lo_f, hi_f = f0 * 4.0, fM / 4.0
+    hi_c = np.min(y) * 0.99
+    a1, f1, a2, var, nu, mu, cs = P.T
+
+    def bounded(x, a, b):
+        return np.log((x - a) * (b - x) / (b - a))
+    lprior = (stats.uniform.logpdf(a1, 0.0, 1.25) + (-np.log(f1) - np.log(np.log(hi_f / lo_f))) + stats.uniform.logpdf(a2, 1.0, 3.0)
+              + stats.lognorm.logpdf(var, 1.25, scale=0.5) + stats.gamma.logpdf(nu, 2.0, scale=0.5) + stats.norm.logpdf(mu, 0.0, 2.0)
+              + (-np.log(cs) - np.log(np.log(hi_c / 1e-6))))
+    ljac = bounded(a1, 0.0, 1.25) + bounded(f1, lo_f, hi_f) + bounded(a2, 1.0, 4.0) + np.log(var) + np.log(nu) + bounded(cs, 1e-6, hi_c)
+    logl = ld - lprior - ljac
+    # one row per distinct draw (a rejected proposal repeats the previous one)
+    _, first = np.unique(P, axis=0, return_index=True)
+    first = np.sort(first)
+    keep = first[np.isfinite(logl[first])]
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for i in rng.choice(keep, 96, replace=False):
+        a, b, c, d = O.approx(lambda fr: O.single_bending_power_law(fr, a1[i], f1[i], a2[i]), f_min, f_max, 20, var[i], is_integrated_power=False)
+        v = O.logl(a, b, c, d, t, np.log(y - cs[i]) - mu[i], nu[i] * yerr ** 2 / (y - cs[i]) ** 2)
+        worst = max(worst, abs(v - logl[i]) / abs(logl[i]))
+    print(f"turing chain fixture: {nchain} chains x {ndraw} draws, {len(keep)} distinct, N={len(t)}; oracle vs (log_density - prior - Jacobian) "
+          f"worst rel err on 96 = {worst:.2e}")
+    assert worst < 1e-10
+    np.savez_compressed(
+        OUT / "turing_chain.npz", t=t, y=y, yerr=yerr, params=P[keep], logl=logl[keep], log_density=ld[keep],
+        log_prior_plus_log_jacobian=(lprior + ljac)[keep], chain=(keep // ndraw).astype(np.int32), draw=(keep % ndraw).astype(np.int32),
+        paramnames=np.array(["alpha1", "f1", "alpha2", "variance", "nu", "mu", "c"]), n_components=20, basis_function="SHO",
+        is_integrated_power=False,
+        note="logl = log_density (stored by the reference's NUTS run) - log prior - log |Jacobian| (closed forms of theta); "
+             "see oracle/make_golden.py make_turing_chain_fixture")
+
+
 def make_literals():
     lit = {
         "psd_amplitudes": {  # test/test_psd.jl:30-39
@@ -314,6 +381,7 @@ def main():
         (OUT / f).chmod(0o644)
     make_ultranest_fixture()
     make_example_runs_fixture()
+    make_turing_chain_fixture()
     lit = make_literals()
     make_relation_cases(lit)
 

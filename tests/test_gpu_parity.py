@@ -63,6 +63,30 @@ def test_reference_outputs_ultranest_device_transform(ctx, golden_dir):
     assert st[0] == 2 and np.isnan(bad[0]) and st[1] == 0 and abs(bad[1] - ref[1]) <= 1e-10 * abs(ref[1])
 
 
+def test_reference_outputs_turing_chain(ctx, golden_dir):
+    """8183 log-likelihoods out of the reference's stored NUTS chains (docs/src/data/subset_simu_single.h5: `log_density` minus
+    the closed-form prior and Jacobian, tests/golden/turing_chain.npz) — the high-likelihood region — through three entries:
+    coefficients + caller-side transform, coefficients + device-side shift transform, and theta only."""
+    tc = np.load(golden_dir / "turing_chain.npz")
+    t, y, yerr, P, ref = tc["t"], tc["y"], tc["yerr"], tc["params"], tc["logl"]
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, P[:, :3], f_min, f_max, 20, P[:, 3], is_integrated_power=False)
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    cs = P[:, 6:7]
+    bar = lambda got: np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))   # noqa: E731
+    got1, st = ds.logl_batch(A, Bc, C, Dd, mu=P[:, 5], nu=P[:, 4], Y=np.log(y[None, :] - cs), S2=yerr[None, :] ** 2 / (y[None, :] - cs) ** 2,
+                             return_status=True)
+    assert (st == 0).all() and bar(got1) < 1e-10
+    got2, st = ds.logl_batch(A, Bc, C, Dd, mu=P[:, 5], nu=P[:, 4], shift=P[:, 6], return_status=True)
+    assert (st == 0).all() and bar(got2) < 1e-10
+    got3, st = ds.logpdf_theta(pj.SingleBendingPowerLaw, P[:, :3], P[:, 3], f_min, f_max, 20, is_integrated_power=False,
+                               mu=P[:, 5], nu=P[:, 4], shift=P[:, 6], return_status=True)
+    assert (st == 0).all() and bar(got3) < 1e-10
+    # a sampler-sized batch of the same draws takes the windowed kernel: same bar
+    got4 = ds.logl_batch(A[:200], Bc[:200], C, Dd, mu=P[:200, 5], nu=P[:200, 4], shift=P[:200, 6])
+    assert np.max(np.abs(got4 - ref[:200]) / np.maximum(1.0, np.abs(ref[:200]))) < 1e-10
+
+
 def test_reference_literal_cases(ctx, golden_dir):
     lit = json.loads((golden_dir / "reference_literals.json").read_text())
     rel = {c["name"]: c for c in json.loads((golden_dir / "relation_cases.json").read_text())["cases"]}

@@ -249,3 +249,23 @@ def test_reference_outputs_example_runs(runs, name):
     assert np.median(rel) < 1e-13
     assert np.quantile(rel, 0.999) < 1e-10
     assert rel.max() < 1e-9, rel.max()
+
+
+# ---- the reference's stored NUTS chains (docs/src/data/subset_simu_single.h5): log_density - log prior - log |Jacobian| ----------
+def test_reference_outputs_turing_chain(golden_dir):
+    """8183 distinct draws of the reference's own NUTS run (docs/src/turing.md:170-256; N = 250, SHO-20, sampled shift): the
+    log-likelihood inside the `log_density` the sampler stored — high-likelihood region — is reproduced by the C oracle.
+    (The fixture's decomposition is closed-form in theta: oracle/make_golden.py make_turing_chain_fixture.)"""
+    tc = np.load(golden_dir / "turing_chain.npz")
+    t, y, yerr, P, ref = tc["t"], tc["y"], tc["yerr"], tc["params"], tc["logl"]
+    assert len(ref) > 8000 and np.allclose(tc["log_density"] - tc["log_prior_plus_log_jacobian"], ref, rtol=0, atol=1e-11)
+    f_min, f_max = 1 / (t[-1] - t[0]), 1 / np.min(np.diff(t)) / 2
+    got = np.empty_like(ref)
+    for i, (a1, f1, a2, var, nu, mu, cs) in enumerate(P):
+        a, b, c, d = O.approx(lambda f: O.single_bending_power_law(f, a1, f1, a2), f_min, f_max, 20, var, is_integrated_power=False)
+        got[i] = O.logl(a, b, c, d, t, np.log(y - cs) - mu, nu * yerr ** 2 / (y - cs) ** 2)
+    err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    # the stored draws are the constrained images of the sampler's unconstrained points: one ulp of that round trip times the
+    # posterior's curvature is all that separates the two evaluations
+    assert err.max() < 1e-10, (err.max(), int(np.argmax(err)))
+    assert (ref > ref.max() - 30).sum() > 6000          # most of them sit where a sampler lives
