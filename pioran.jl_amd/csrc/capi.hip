@@ -10,6 +10,7 @@ int pioran_dense_nll_device_batch(int64_t nbatch, int64_t N, int32_t J, const do
                                   const double* mu, const double* nu, double* out, int32_t* info, int sorted, hipStream_t stream);   // dense.hip
 void pioran_dense_set_batch_pair_threshold(int v);   // dense.hip, diagnostics
 void pioran_dense_set_quad_threshold(int v);
+void pioran_dense_set_old_chain(int v);
 int pioran_launch_block_sim(const ScanParams& p, const double* btab, double* xi, hipStream_t stream);   // celerite_block.hip
 int pioran_launch_block_solve(const ScanParams& p, const double* btab, const double* gtab, double* gy, hipStream_t stream);   // celerite_block.hip
 size_t pioran_predict_tau_workspace_doubles(int64_t M, int32_t R, int64_t ntab);
@@ -397,6 +398,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "block_emode")) o.block_emode = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "dense_quad_threshold")) pioran_dense_set_quad_threshold((value && value[0]) ? std::atoi(value) : -1);
     else if (!std::strcmp(key, "dense_batch_pair_threshold")) pioran_dense_set_batch_pair_threshold((value && value[0]) ? std::atoi(value) : -1);
+    else if (!std::strcmp(key, "dense_old_chain")) pioran_dense_set_old_chain(on ? 1 : 0);
     else if (!std::strcmp(key, "dense_streams")) o.dense_streams = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "gsum")) o.gsum = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "wide2")) o.wide2 = on;
@@ -1867,7 +1869,7 @@ static int dense_stage(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, c
     dv[8] = base + off + 1;  // info (int32 in the first 4 bytes)
     int64_t Mp, ld;
     pioran_dense_dims(N, &Mp, &ld);
-    return ensure(ctx, ctx->bK, ((size_t)Mp * (size_t)ld + 1024) * sizeof(double));
+    return ensure(ctx, ctx->bK, ((size_t)Mp * (size_t)ld + PIORAN_DENSE_WS) * sizeof(double));
 }
 
 static int dense_nll_impl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a, const double* b, const double* c,
@@ -1913,7 +1915,7 @@ int pioran_dense_nll_batch(pioran_ctx* ctx, int64_t N, int64_t J, int64_t B, con
     int rc;
     int64_t Mp, ld;
     pioran_dense_dims(N, &Mp, &ld);
-    const size_t slab = (size_t)Mp * (size_t)ld + 1024;
+    const size_t slab = (size_t)Mp * (size_t)ld + PIORAN_DENSE_WS;
     // Several factorisations per launch (round 3, late): a single N = 4096 factorisation is a chain of 64 latency-bound steps that
     // leaves most of the chip idle; with gridDim.z = nb matrices every kernel of the chain is launched once per BATCH (16 concurrent
     // streams of single-matrix launches gave 0.96 ms per factorisation, tools/sweep_dense_streams.py).  As many slabs as fit in a

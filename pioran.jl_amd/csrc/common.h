@@ -173,10 +173,12 @@ int pioran_launch_approx(int64_t B, int model, int P, int J, int basis, int inte
                          int n_qpo, const double* qpo /*[B][n_qpo][3]: S0, f0, Q*/, double* A, double* Bc,
                          double* Cq /*[B][Jt]: per-draw c of the feature terms*/, double* Dq, hipStream_t stream);
 // dense.hip
+// doubles behind a slab: 1024 (the four 16 x 16 inverses of the current diagonal block) + 4 x 4096 (dense_step_kernel's tile snapshots)
+#define PIORAN_DENSE_WS (1024 + 4 * 4096)
 void pioran_dense_dims(int64_t N, int64_t* Mp, int64_t* ld);
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,
                             const double* d, const double* t, const double* y, const double* s2,
-                            double* K /*ld*Mp + 1024*/, hipEvent_t* phase_ev /*nullptr or [3]*/, double* out, int32_t* info,
+                            double* K /*ld*Mp + PIORAN_DENSE_WS*/, hipEvent_t* phase_ev /*nullptr or [3]*/, double* out, int32_t* info,
                             int sorted, hipStream_t stream, double mu = 0.0 /*subtracted from y*/, double nu = 1.0 /*scales s2*/);
 int pioran_dense_predict_cov_device(int64_t N, int64_t M, int32_t J, const double* a, const double* b, const double* c,
                                     const double* d, const double* te, const double* s2e, double* K, int32_t* info,

@@ -501,6 +501,7 @@ __device__ __forceinline__ void store_block_lower(const double* __restrict__ Ls,
 }
 
 // First diagonal block (no trailing update precedes it): load, factor, write back.
+// (blockIdx.x = 1, 2, only launched on the one-launch-per-column path: the raw tiles (1, 0), (2, 0) -> the snapshot of step 0.)
 __global__ void __launch_bounds__(256) dense_diag0_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ ws,
                                                           int32_t* __restrict__ info, DenseBatch bt)
 {
@@ -508,6 +509,13 @@ __global__ void __launch_bounds__(256) dense_diag0_kernel(double* __restrict__ A
     __shared__ double Ls[NB * LP];
     __shared__ int flag;
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+    if (blockIdx.x > 0) {
+        double* sn = ws + WS_DOUBLES + (size_t)(blockIdx.x - 1) * (NB * NB);
+        const double* T = A + (int64_t)blockIdx.x * NB;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sn[lane + (16 * h + q) * NB] = T[lane + (int64_t)(16 * h + q) * ld];
+        return;
+    }
     {
         double v[16];
 #pragma unroll
@@ -595,6 +603,76 @@ __global__ void __launch_bounds__(256) dense_panel_kernel(double* __restrict__ A
 // (each 64 x 64 x 64 tile moves 128 KB through L2 for 0.5 Mflop), happens once per 128 columns instead of once per 64.
 // col0_only (KP = 1): only block column 0 of the trailing matrix (the next panel) and its diagonal tile — the narrow
 // update between the two panel solves of a pair.
+// One 64 x 64 tile (ti, tj), ti >= tj, of the trailing matrix with origin j0:  C -= P_i P_j',  P = A[:, pc : pc + 64 KP]  (one wavefront).
+template <int KP>
+__device__ __forceinline__ void syrk_tile(double* __restrict__ A, int64_t ld, int64_t pc, int64_t j0, int ti, int tj, int lr, int lk)
+{
+    // Row permutation inside the tile: MFMA strip s (s = 0..3) takes the rows 32 (s >> 1) + 2 r + (s & 1), r = 0..15,
+    // instead of 16 s + r.  Lane (lr, lk) then needs rows 2 lr and 2 lr + 1 of each half of the tile — ADJACENT in the
+    // column-major slab — for strips 2h and 2h + 1: one 16-byte load feeds two operand fragments, and the C entries of
+    // the strip pair (2h, 2h + 1) are adjacent too.  128 vector-memory instructions per tile instead of 256: with eight
+    // waves per CU the texture path was as busy as the matrix pipe.  (All addresses are even multiples of 8 bytes:
+    // j0, NB and ld are multiples of 64.)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double* Pi = A + (j0 + (int64_t)ti * NB) + pc * ld + 2 * lr + (int64_t)lk * ld;  // rows of the i tile
+    const double* Pj = A + (j0 + (int64_t)tj * NB) + pc * ld + 2 * lr + (int64_t)lk * ld;  // rows of the j tile
+    f64x4 acc[4][4];  // [jb][ib]
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) acc[jb][ib] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    // operand fragments one k-step (4 panel columns: 4 + 4 doubles per lane) at a time, three buffers deep: the
+    // loads of k-step ks+2 are issued before the 16 MFMAs (1024 issue cycles) of k-step ks.  With the 128
+    // accumulator registers this stays under 256 registers per lane, so two wavefronts share a SIMD and the
+    // second one hides whatever latency is left (launch bounds below).
+    double xa[3][4], yb[3][4];   // [buffer][strip]
+    auto load_kstep = [&](int ks, int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t off = 32 * h + (int64_t)(4 * ks) * ld;
+            const d2 x = *reinterpret_cast<const d2*>(Pj + off);   // X[row][k] = P[j][k], rows 32h + 2lr + {0, 1}
+            const d2 y = *reinterpret_cast<const d2*>(Pi + off);   // Y[k][col] = P[i][k]
+            xa[buf][2 * h] = x.x; xa[buf][2 * h + 1] = x.y;
+            yb[buf][2 * h] = y.x; yb[buf][2 * h + 1] = y.y;
+        }
+    };
+    load_kstep(0, 0);
+    load_kstep(1, 1);
+#pragma unroll
+    for (int ks = 0; ks < 16 * KP; ++ks) {
+        if (ks + 2 < 16 * KP) load_kstep(ks + 2, (ks + 2) % 3);
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+                acc[jb][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks % 3][jb], yb[ks % 3][ib], acc[jb][ib], 0, 0, 0);
+    }
+
+    // C -= acc.  D row (l>>4) + 4g of strip jb is the j-row 32 (jb >> 1) + 2 (lk + 4g) + (jb & 1); D column l&15 of strip
+    // ib is the i-row 32 (ib >> 1) + 2 lr + (ib & 1): the strip pair (2h, 2h + 1) is one 16-byte access.  One j strip
+    // (8 accesses per lane) at a time: its loads are all in flight before the first store.
+    double* C = A + (j0 + (int64_t)ti * NB) + (j0 + (int64_t)tj * NB) * ld + 2 * lr;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        d2 cv[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                cv[h][g] = *reinterpret_cast<const d2*>(C + 32 * h + (int64_t)(32 * (jb >> 1) + 2 * (lk + 4 * g) + (jb & 1)) * ld);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                d2 v = cv[h][g];
+                v.x -= acc[jb][2 * h][g];
+                v.y -= acc[jb][2 * h + 1][g];
+                *reinterpret_cast<d2*>(C + 32 * h + (int64_t)(32 * (jb >> 1) + 2 * (lk + 4 * g) + (jb & 1)) * ld) = v;
+            }
+    }
+}
+
 template <int KP>
 __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__ A, int64_t ld, int64_t kb, int64_t Mp,
                                                          double* __restrict__ ws, int32_t* __restrict__ info, int factor_next,
@@ -666,69 +744,211 @@ __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__
         tj = bid - (int)((int64_t)ti * (ti + 1) / 2);
     }
     if (ti >= nt || tj >= nt - 1) return;   // wave-uniform; no workgroup barrier below
-    // Row permutation inside the tile: MFMA strip s (s = 0..3) takes the rows 32 (s >> 1) + 2 r + (s & 1), r = 0..15,
-    // instead of 16 s + r.  Lane (lr, lk) then needs rows 2 lr and 2 lr + 1 of each half of the tile — ADJACENT in the
-    // column-major slab — for strips 2h and 2h + 1: one 16-byte load feeds two operand fragments, and the C entries of
-    // the strip pair (2h, 2h + 1) are adjacent too.  128 vector-memory instructions per tile instead of 256: with eight
-    // waves per CU the texture path was as busy as the matrix pipe.  (All addresses are even multiples of 8 bytes:
-    // j0, NB and ld are multiples of 64.)
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const double* Pi = A + (j0 + (int64_t)ti * NB) + kb * ld + 2 * lr + (int64_t)lk * ld;  // rows of the i tile
-    const double* Pj = A + (j0 + (int64_t)tj * NB) + kb * ld + 2 * lr + (int64_t)lk * ld;  // rows of the j tile
-    f64x4 acc[4][4];  // [jb][ib]
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib) acc[jb][ib] = f64x4{0.0, 0.0, 0.0, 0.0};
+    syrk_tile<KP>(A, ld, kb, j0, ti, tj, lr, lk);
+}
 
-    // operand fragments one k-step (4 panel columns: 4 + 4 doubles per lane) at a time, three buffers deep: the
-    // loads of k-step ks+2 are issued before the 16 MFMAs (1024 issue cycles) of k-step ks.  With the 128
-    // accumulator registers this stays under 256 registers per lane, so two wavefronts share a SIMD and the
-    // second one hides whatever latency is left (launch bounds below).
-    double xa[3][4], yb[3][4];   // [buffer][strip]
-    auto load_kstep = [&](int ks, int buf) {
+// ---- one launch per block column (round 4; one matrix) ---------------------------------------------------------------------------------
+// The chain above pays two kernel boundaries per 64 columns (panel, update + factor) and, in its paired steps, leaves the chip idle while
+// the 13.9 us narrow launches run.  Here step k is ONE launch in which four roles run side by side, none waiting for another:
+//   CRIT   workgroup 0, row tile k+1: solves its 64 rows of panel k against L_kk (four waves x 16 rows, on the matrix cores, the four
+//          16 x 16 inverses read from the strictly-upper part of the diagonal block, where the factor parks them), applies panel k to the
+//          next diagonal tile (k+1, k+1) and factors it at once (factor_block64).  Nothing else is on the chain.
+//   DIAG2  workgroup 1: brings the diagonal tile AFTER next, (k+2, k+2), up to panel k (panel k-1 from memory, panel k from its own
+//          re-solved rows of tile (k+2, k)), so that the next launch's CRIT finds it one panel short only.
+//   STRIP  one workgroup per row tile i = k+2 .. nb (nb = the tile of the y row): solves its rows of panel k (final L rows), RE-solves the
+//          rows of tile (k+1, k) — 40 dependent matrix instructions per wave instead of a kernel boundary — and applies panels k-1 and k
+//          to tile (i, k+1): block column k+1 leaves the launch complete, ready to be panel k+1.
+//   BULK   one wavefront per tile (i, j), j >= k+2 (except (k+2, k+2)): applies panel k-1, which the PREVIOUS launch finished — the bulk
+//          update lags one step, so it never waits for the chain: the work that used to sit between the chain's launches rides along.
+// Two tiles of block column k are solved IN PLACE by one workgroup while others re-solve them: (k+1, k) and (k+2, k).  Their raw form is
+// therefore kept as a snapshot (two 64 x 64 tiles behind the slab, double-buffered by the parity of k), written by whoever produced the
+// tile: the STRIP workgroups of rows k+1, k+2 of the previous launch, dense_diag0_kernel for k = 0.
+// Invariant at launch k: diagonal block k factored; block column k updated through panel k-1; block columns >= k+1 through panel k-2,
+// the diagonal tile (k+1, k+1) through k-1.  1 + nb launches instead of 2.5 nb; chain per step: launch + 40 + 64 MFMAs + factor.
+// (rows: the 16 x 64 raw rows to solve, column stride lds — in place, or the snapshot of a tile another workgroup overwrites meanwhile)
+__device__ __forceinline__ void solve_rows16_load(const double* __restrict__ A, int64_t ld, int64_t kb, const double* __restrict__ rows,
+                                                  int64_t lds, int lr, int lk, f64x4 (&Y)[4], double (&lop)[4][4][4], double (&iop)[4][4])
+{
+    const double* Lb = A + kb + kb * ld;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t off = 32 * h + (int64_t)(4 * ks) * ld;
-            const d2 x = *reinterpret_cast<const d2*>(Pj + off);   // X[row][k] = P[j][k], rows 32h + 2lr + {0, 1}
-            const d2 y = *reinterpret_cast<const d2*>(Pi + off);   // Y[k][col] = P[i][k]
-            xa[buf][2 * h] = x.x; xa[buf][2 * h + 1] = x.y;
-            yb[buf][2 * h] = y.x; yb[buf][2 * h + 1] = y.y;
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Y[s][g] = rows[lr + (int64_t)(16 * s + lk + 4 * g) * lds];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int sp = 0; sp < s; ++sp)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) lop[s][sp][ks] = -Lb[(16 * s + lr) + (int64_t)(16 * sp + 4 * ks + lk) * ld];
+        const int ir0 = s == 3 ? 16 : 0, ic0 = s == 3 ? 32 : 16 * (s + 1);   // where factor_block64 parks inv(L_ss)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) iop[s][ks] = Lb[(ir0 + lr) + (int64_t)(ic0 + 4 * ks + lk) * ld];
+    }
+}
+// Y_s = inv(L_ss) (A_s' - sum_{s' < s} L[s][s'] Y_s'), tiles transposed in the C/D layout (dense_panel_kernel)
+__device__ __forceinline__ void solve_rows16_compute(f64x4 (&Y)[4], const double (&lop)[4][4][4], const double (&iop)[4][4])
+{
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int sp = 0; sp < s; ++sp)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) Y[s] = mfma4(lop[s][sp][ks], Y[sp][ks], Y[s]);
+        f64x4 Z = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) Z = mfma4(iop[s][ks], Y[s][ks], Z);
+        Y[s] = Z;
+    }
+}
+
+// The three solving roles.  it: row tile of this workgroup (wave w takes its rows 16 w ..); qt: the row tile whose solved rows are the other
+// operand; the target tile is (it, qt).  CRIT: it = qt = k+1, no panel k-1 term, result factored.  DIAG2: it = qt = k+2, nothing of panel k
+// stored.  STRIP: qt = k+1, the solved rows stored.
+constexpr int SNAP_TILE = NB * NB;                        // snapshot tile: column-major 64 x 64, column stride 64
+template <bool CRIT>
+__device__ __forceinline__ void step_solve_role(double* __restrict__ A, int64_t ld, int64_t Mp, int k, int it, int qt, bool store_rows,
+                                                bool with_prev, double* __restrict__ Ls, double* __restrict__ Xq, int* flag,
+                                                int32_t* __restrict__ info, int tid)
+{
+    const int64_t kb = (int64_t)k * NB, i0 = (int64_t)it * NB, q0 = (int64_t)qt * NB;
+    const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const bool has_target = qt < (int)(Mp / NB);        // a block column qt exists (else: only the y rows are left to solve)
+    double* snap = A + (size_t)ld * (size_t)Mp + WS_DOUBLES;                   // [parity][which of the two tiles][64 x 64]
+    const double* snap_k = snap + (size_t)(k & 1) * 2 * SNAP_TILE;             // raw (k+1, k) and (k+2, k)
+    f64x4 Yi[4];
+    double lop[4][4][4], iop[4][4];
+    if (store_rows)   // in place: this workgroup is the only one that reads these raw rows from the slab, and it overwrites them
+        solve_rows16_load(A, ld, kb, A + i0 + 16 * wave + kb * ld, ld, lr, lk, Yi, lop, iop);
+    else              // DIAG2: tile (k+2, k) is being overwritten by its STRIP workgroup
+        solve_rows16_load(A, ld, kb, snap_k + SNAP_TILE + 16 * wave, NB, lr, lk, Yi, lop, iop);
+    f64x4 acc[4];                                        // tile (it, qt), transposed: [jb] D[row = j][col = i], i = 16 wave + lr
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = f64x4{0.0, 0.0, 0.0, 0.0};
+    if constexpr (!CRIT) {
+        if (has_target && with_prev) {                   // panel k-1 (finished by the previous launch)
+            const double* Pj = A + q0 + (kb - NB) * ld + lr + (int64_t)lk * ld;              // rows of tile qt
+            const double* Pi = A + i0 + 16 * wave + (kb - NB) * ld + lr + (int64_t)lk * ld;  // this wave's 16 rows
+#pragma unroll 1
+            for (int c4 = 0; c4 < 4; ++c4) {
+                double xa[4][4], yb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    yb[q] = Pi[(int64_t)(4 * (4 * c4 + q)) * ld];
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb) xa[q][jb] = Pj[16 * jb + (int64_t)(4 * (4 * c4 + q)) * ld];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb) acc[jb] = mfma4(xa[q][jb], yb[q], acc[jb]);
+            }
         }
-    };
-    load_kstep(0, 0);
-    load_kstep(1, 1);
+    }
+    solve_rows16_compute(Yi, lop, iop);
+    if (store_rows) {   // the solved rows are final entries of L
+        double* P = A + i0 + 16 * wave + kb * ld;
 #pragma unroll
-    for (int ks = 0; ks < 16 * KP; ++ks) {
-        if (ks + 2 < 16 * KP) load_kstep(ks + 2, (ks + 2) % 3);
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) P[lr + (int64_t)(16 * s + lk + 4 * g) * ld] = Yi[s][g];
+    }
+    if (!has_target) return;                            // (workgroup-uniform)
+    if (it == qt) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Xq[(wave * 16 + s * 4 + g) * 64 + lane] = Yi[s][g];
+    } else {                                            // the rows of tile (k+1, k), re-solved here (same L operands) from their snapshot
+        f64x4 Yq[4];
+        const double* P = snap_k + 16 * wave;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Yq[s][g] = P[lr + (16 * s + lk + 4 * g) * NB];
+        solve_rows16_compute(Yq, lop, iop);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Xq[(wave * 16 + s * 4 + g) * 64 + lane] = Yq[s][g];
+    }
+    double* C = A + i0 + 16 * wave + lr + q0 * ld;
+    double cv[4][4];
+    if constexpr (CRIT) {                               // the diagonal tile: its load overlaps the exchange
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib)
-                acc[jb][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks % 3][jb], yb[ks % 3][ib], acc[jb][ib], 0, 0, 0);
+            for (int g = 0; g < 4; ++g) cv[jb][g] = C[(int64_t)(16 * jb + lk + 4 * g) * ld];
     }
+    __syncthreads();
+    // panel k: A operand X[row = j][k = c] = the solved rows of tile qt (C/D register (s, g) IS the operand of k-step (s, g)),
+    // B operand Y[k = c][col = i] = this wave's own solved rows
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[jb] = mfma4(Xq[(jb * 16 + s * 4 + g) * 64 + lane], Yi[s][g], acc[jb]);
+    if constexpr (!CRIT) {
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cv[jb][g] = C[(int64_t)(16 * jb + lk + 4 * g) * ld];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cv[jb][g] -= acc[jb][g];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) C[(int64_t)(16 * jb + lk + 4 * g) * ld] = cv[jb][g];
+        if (store_rows && it - qt <= 2) {               // rows k+2, k+3 of block column k+1: the next launch re-solves them elsewhere
+            double* sn = snap + (size_t)((k + 1) & 1) * 2 * SNAP_TILE + (size_t)(it - qt - 1) * SNAP_TILE + 16 * wave + lr;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sn[(16 * jb + lk + 4 * g) * NB] = cv[jb][g];
+        }
+    } else {
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Ls[(16 * wave + lr) * LP + 16 * jb + lk + 4 * g] = cv[jb][g] - acc[jb][g];   // row i, column j
+        __syncthreads();
+        double* ws = A + (size_t)ld * (size_t)Mp;        // (the copy of the inverses the older kernels read; unused on this path)
+        const int bad = factor_block64(Ls, ws, flag, tid);
+        __syncthreads();
+        store_block_lower(Ls, A + q0 + q0 * ld, ld, tid);
+        if (tid == 0 && bad && *info == 0) *info = (int32_t)(q0 + bad);
+    }
+}
 
-    // C -= acc.  D row (l>>4) + 4g of strip jb is the j-row 32 (jb >> 1) + 2 (lk + 4g) + (jb & 1); D column l&15 of strip
-    // ib is the i-row 32 (ib >> 1) + 2 lr + (ib & 1): the strip pair (2h, 2h + 1) is one 16-byte access.  One j strip
-    // (8 accesses per lane) at a time: its loads are all in flight before the first store.
-    double* C = A + (j0 + (int64_t)ti * NB) + (j0 + (int64_t)tj * NB) * ld + 2 * lr;
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-        d2 cv[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                cv[h][g] = *reinterpret_cast<const d2*>(C + 32 * h + (int64_t)(32 * (jb >> 1) + 2 * (lk + 4 * g) + (jb & 1)) * ld);
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                d2 v = cv[h][g];
-                v.x -= acc[jb][2 * h][g];
-                v.y -= acc[jb][2 * h + 1][g];
-                *reinterpret_cast<d2*>(C + 32 * h + (int64_t)(32 * (jb >> 1) + 2 * (lk + 4 * g) + (jb & 1)) * ld) = v;
-            }
+__global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__ A, int64_t ld, int64_t Mp, int k,
+                                                            int32_t* __restrict__ info)
+{
+    __shared__ double Ls[NB * LP];
+    __shared__ double Xq[4 * 16 * 64];   // the solved rows of the operand tile: [piece of 16 rows][s * 4 + g][lane]
+    __shared__ int flag;
+    const int nb = (int)(Mp / NB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nstrip = nb - k - 1;                      // row tiles k+2 .. nb
+    const int bx = (int)blockIdx.x;
+    if (bx == 0) {
+        step_solve_role<true>(A, ld, Mp, k, k + 1, k + 1, true, false, Ls, Xq, &flag, info, tid);
+    } else if (bx == 1) {
+        if (k + 2 < nb) step_solve_role<false>(A, ld, Mp, k, k + 2, k + 2, false, k > 0, Ls, Xq, &flag, info, tid);
+    } else if (bx < 2 + nstrip) {
+        step_solve_role<false>(A, ld, Mp, k, k + bx, k + 1, true, k > 0, Ls, Xq, &flag, info, tid);
+    } else {
+        // ---- BULK: panel k-1 onto the tiles of block columns >= k+2 (all but (k+2, k+2): DIAG2's) ---------------------------------
+        const int64_t j0 = ((int64_t)k + 2) * NB;
+        const int nt = (int)((Mp - j0) / NB) + 1;       // i tiles (the last one holds the y row), j tiles 0 .. nt-2
+        const int bid = (bx - 2 - nstrip) * 4 + wave + 1;
+        int ti = (int)((sqrt(8.0 * bid + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+        while ((int64_t)ti * (ti + 1) / 2 > bid) --ti;
+        const int tj = bid - (int)((int64_t)ti * (ti + 1) / 2);
+        if (ti >= nt || tj >= nt - 1) return;           // wave-uniform; no workgroup barrier on this path
+        syrk_tile<1>(A, ld, ((int64_t)k - 1) * NB, j0, ti, tj, lane & 15, lane >> 4);
     }
 }
 
@@ -789,7 +1009,7 @@ __global__ void __launch_bounds__(256) dense_predict_mean_kernel(const double* _
 
 }  // namespace
 
-// K must hold ld * Mp + 1024 doubles with Mp = roundup(N, 64), ld = Mp + 64 (slab + inverse workspace).
+// K must hold ld * Mp + PIORAN_DENSE_WS doubles with Mp = roundup(N, 64), ld = Mp + 64 (slab + inverse workspace + tile snapshots).
 static void launch_build(int64_t N, int64_t Mp, int64_t ld, int32_t J, const double* a, const double* b, const double* c,
                          const double* d, const double* t, const double* y, const double* s2, double* K, int sorted,
                          hipStream_t stream, double mu = 0.0, double nu = 1.0, unsigned nbatch = 1, DenseBatch bt = DenseBatch{})
@@ -823,6 +1043,8 @@ static void launch_build(int64_t N, int64_t Mp, int64_t ld, int32_t J, const dou
 
 static int g_batch_pair_threshold = -1;   // diagnostics (tools/sweep_dense_streams.py): -1 = the defaults below
 static int g_quad_threshold = -1;
+static int g_dense_old_chain = 0;         // 1: one matrix on the panel / update chain of rounds 1-3 (A/B and cross-check of dense_step_kernel)
+void pioran_dense_set_old_chain(int v) { g_dense_old_chain = v; }
 constexpr int kQuadThreshold = 1 << 20;        // one matrix: off
 constexpr int kBatchQuadThreshold = 16;        // batched launches (tools/sweep_dense_streams.py: 0.628 -> 0.554 ms per N = 4096 factorisation, 32 per launch)
 void pioran_dense_set_batch_pair_threshold(int v) { g_batch_pair_threshold = v; }
@@ -841,7 +1063,22 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
     if (phase_ev) (void)hipEventRecord(phase_ev[0], stream);
     if (hipMemsetAsync(info, 0, nbatch * sizeof(int32_t), stream) != hipSuccess) return PIORAN_ERR_HIP;
     double* ws = K + (size_t)ld * (size_t)Mp;   // WS_DOUBLES doubles right behind the slab
-    hipLaunchKernelGGL(dense_diag0_kernel, dim3(1, 1, nbatch), dim3(256), 0, stream, K, ld, ws, info, bt);
+    const bool steps = nbatch == 1 && !g_dense_old_chain && Mp >= 3 * NB;
+    hipLaunchKernelGGL(dense_diag0_kernel, dim3(steps ? 3 : 1, 1, nbatch), dim3(256), 0, stream, K, ld, ws, info, bt);
+    if (steps) {
+        // one matrix: one launch per block column (dense_step_kernel)
+        const int nb = (int)(Mp / NB);
+        for (int k = 0; k < nb; ++k) {
+            const int nstrip = nb - k - 1;
+            const int64_t nt = (Mp - ((int64_t)k + 2) * NB) / NB + 1;            // i tiles of the bulk's origin (block column k+2)
+            const int64_t ntile = (k > 0 && nt >= 2) ? nt * (nt + 1) / 2 - 1 : 0;   // (0, 0) of that origin is DIAG2's
+            hipLaunchKernelGGL(dense_step_kernel, dim3((unsigned)(2 + nstrip + (ntile + 3) / 4)), dim3(256), 0, stream, K, ld, Mp, k, info);
+        }
+        if (phase_ev) (void)hipEventRecord(phase_ev[1], stream);
+        hipLaunchKernelGGL(dense_finish_kernel, dim3(1, 1, 1), dim3(256), 0, stream, K, ld, N, Mp, out, info, bt);
+        if (phase_ev) (void)hipEventRecord(phase_ev[2], stream);
+        return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+    }
     auto panel = [&](int64_t kb) {
         // rows below the block: kb+NB .. Mp+63 (the y row Mp and the scratch rows of its 64-row tile)
         const int64_t below = Mp - kb;

@@ -1,0 +1,22 @@
+#!/bin/bash
+# tools/kres.sh <file.hip> [name filter]: compile one source of the library for gfx950 with -save-temps and print every kernel's
+# registers / spills / LDS / scratch from the code object's metadata.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+f=$1; stem=$(basename "$f" .hip); filt=${2:-.}
+mkdir -p /tmp/kres && cd /tmp/kres
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -c "$ROOT/pioran.jl_amd/csrc/$stem.hip" -o "$ROOT/pioran.jl_amd/_obj/$stem.o" -save-temps=obj 2>&1 | grep -v "^$" || true
+mv -f "$ROOT"/pioran.jl_amd/_obj/$stem-hip-amdgcn-amd-amdhsa-gfx950.s /tmp/kres/$stem.s
+rm -f "$ROOT"/pioran.jl_amd/_obj/$stem-h* "$ROOT"/pioran.jl_amd/_obj/$stem.hip-*
+python3 - "$stem" "$filt" <<'PY'
+import re, sys, subprocess
+stem, filt = sys.argv[1], sys.argv[2]
+s = open(f'/tmp/kres/{stem}.s').read()
+md = s[s.index('amdhsa.kernels'):]
+for b in md.split('  - .agpr_count:')[1:]:
+    name = re.search(r'\.name:\s+(\S+)', b).group(1)
+    if not re.search(filt, name): continue
+    g = lambda k: re.search(r'\.' + k + r':\s+(\d+)', b).group(1)
+    dem = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip()
+    print(f"{dem[:110]:110s} agpr {b.split(chr(10))[0].strip():>3s} vgpr {g('vgpr_count'):>3s} spill {g('vgpr_spill_count'):>3s} lds {g('group_segment_fixed_size'):>6s} scratch {g('private_segment_fixed_size'):>4s}")
+PY
