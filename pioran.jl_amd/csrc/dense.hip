@@ -358,6 +358,45 @@ __device__ __forceinline__ double bcast16(double x)
     return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true);
 }
 
+// One 16-column right-looking sweep over a 16 x 16 tile (r, lane & 15 = row) and its companion strip m (factor_block64 below).
+// Column step p: pivot broadcast -> rsqrt -> scale column p -> rank-1 update of the columns q > p with the broadcast of l_qp FOLDED into
+// the FMAs (v_fmac_f64_dpp row_newbcast:q takes its src0 from lane q of the DPP row; the negation rides as a source modifier): two DP
+// instructions per (p, q) for the tile and the strip instead of a v_mov_b64_dpp + two FMAs (a DP DPP operand costs no extra issue cycles:
+// tools/valu_probe.hip, profiles/r02_valu_probe.txt).  A DPP read of a register written by the preceding VALU instructions needs two
+// wait states: s_nop 1 in front of every such read.
+// Measured (tools/factor_probe.hip, profiles/r04_factor_probe.txt; cycles per 16-column sweep): compiler-scheduled v_mov_b64_dpp + two FMAs per
+// (p, q) 3280-3530; this folded form 3100-3290; folded AND software-pipelined (the pivot chain of column p+1 — broadcast, v_rsq_f64, third-order
+// correction, scale: eight dependent DP operations — spread between the remaining FMAs of column p, every piece its own asm volatile
+// statement) 3360-3570.  A 64-bit DPP operand takes TWO issue slots wherever it stands (120 broadcasts x 8 + 240 FMA slots x 4 + 16 pivot
+// chains x ~80 cycles = the 3100 measured), so folding saves only the moves' register traffic, and the pinned order of the pipelined form
+// cost more in hazard nops than its overlap won.  The sweep is bound by the 120 lane broadcasts of the rank-1 updates.
+template <int P, int Q>
+__device__ __forceinline__ void chol_rank1(double (&r)[16], double (&m)[16])
+{
+    if constexpr (Q < 16) {
+        // a_iq -= l_ip l_qp (tile) and the same column step on the companion strip
+        asm volatile("v_fmac_f64_dpp %0, %2, -%2 row_newbcast:%c4 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %2, -%3 row_newbcast:%c4 row_mask:0xf bank_mask:0xf"
+                     : "+v"(r[Q]), "+v"(m[Q])
+                     : "v"(r[P]), "v"(m[P]), "i"(Q));
+        chol_rank1<P, Q + 1>(r, m);
+    }
+}
+template <int P>
+__device__ __forceinline__ void chol_sweep16(double (&r)[16], double (&m)[16], int& bad, int c0)
+{
+    if constexpr (P < 16) {
+        double piv;
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%c2 row_mask:0xf bank_mask:0xf" : "=v"(piv) : "v"(r[P]), "i"(P));
+        if (!(piv > 0.0) && !bad) bad = c0 + P + 1;
+        const double rinv = rsqrt_f64(piv);     // 1 / l_pp
+        // lane p: piv * rinv = l_pp; rows above p: junk, never used
+        asm volatile("v_mul_f64 %0, %0, %2\n\tv_mul_f64 %1, %1, %2\n\ts_nop 1" : "+v"(r[P]), "+v"(m[P]) : "v"(rinv));
+        chol_rank1<P, P + 1>(r, m);
+        chol_sweep16<P + 1>(r, m, bad, c0);
+    }
+}
+
 // Factor the 64 x 64 block held row-major (padded) in LDS `Ls`, in place, by a FOUR-wave workgroup (tid 0..255);
 // writes the four 16 x 16 inverses to `ws` (global).  Returns the 1-based index of the first non-positive pivot
 // (0 = none) to every thread.  `flag` is one int of LDS.
@@ -412,23 +451,7 @@ __device__ __forceinline__ int factor_block64(double* __restrict__ Ls, double* _
                 const double v = Ls[mrow * LP + c0 + p];
                 m[p] = lk == 0 ? (lr == p ? 1.0 : 0.0) : v;
             }
-            static_for16([&](auto Pc) {
-                constexpr int p = decltype(Pc)::value;
-                const double piv = bcast16<p>(r[p]);
-                if (!(piv > 0.0) && !bad) bad = c0 + p + 1;
-                const double rinv = rsqrt_f64(piv);     // 1 / l_pp
-                r[p] *= rinv;                           // lane p: piv * rinv = l_pp; rows above p: junk, never used
-                m[p] *= rinv;
-                const double nrp = -r[p], nmp = -m[p];
-                static_for16([&](auto Qc) {
-                    constexpr int q = decltype(Qc)::value;
-                    if constexpr (q > p) {
-                        const double lqp = bcast16<q>(r[p]);
-                        r[q] = fma(lqp, nrp, r[q]);     // a_iq -= l_ip l_qp
-                        m[q] = fma(lqp, nmp, m[q]);
-                    }
-                });
-            });
+            chol_sweep16<0>(r, m, bad, c0);
             // keep the compiler from sinking the m updates into the publish branches below
 #pragma unroll
             for (int p = 0; p < 16; ++p) asm volatile("" : "+v"(m[p]));
@@ -747,6 +770,53 @@ __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__
     syrk_tile<KP>(A, ld, kb, j0, ti, tj, lr, lk);
 }
 
+// One 64 x 64 tile per WORKGROUP (dense_step_kernel's bulk role):  C(ti, tj) -= P_i P_j',  P = A[:, pc : pc + 64].  The i rows of the panel
+// (B operand of all four waves) go through LDS once, column-major with a row pitch of 80 doubles (the four k-lanes of a fragment read land
+// in disjoint bank groups); wave w takes the 16 j rows 16 w .. of the tile (A operand straight from L2) and all 64 i rows: 64 matrix
+// instructions per wave, every SIMD of the CU busy on the same tile.  Against one tile per wavefront: half the operand traffic, and the
+// launch's work is balanced per CU, not per SIMD (a lone tile-wave leaves its SIMD's matrix pipe idle half of the time, two on a SIMD
+// take 25 us together).
+constexpr int BP = 80;
+constexpr bool kBulkPerWorkgroup = false;   // dense_step_kernel's bulk role: one tile per workgroup (measured slower, see there)
+__device__ __forceinline__ void syrk_tile_wg(double* __restrict__ A, int64_t ld, int64_t pc, int64_t j0, int ti, int tj,
+                                             double* __restrict__ Bs, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int64_t i0 = j0 + (int64_t)ti * NB, jr0 = j0 + (int64_t)tj * NB;
+    {
+        const double* Pi = A + i0 + lane + (pc + 16 * wave) * ld;
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = Pi[(int64_t)q * ld];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Bs[(16 * wave + q) * BP + lane] = v[q];
+    }
+    double xa[16];
+    {
+        const double* Pj = A + jr0 + 16 * wave + lr + (pc + lk) * ld;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) xa[ks] = Pj[(int64_t)(4 * ks) * ld];
+    }
+    double* C = A + i0 + lr + (jr0 + 16 * wave + lk) * ld;
+    double cv[4][4];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cv[ib][g] = C[16 * ib + (int64_t)(4 * g) * ld];
+    __syncthreads();
+    f64x4 acc[4];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) acc[ib] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) acc[ib] = mfma4(xa[ks], Bs[(4 * ks + lk) * BP + 16 * ib + lr], acc[ib]);
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) C[16 * ib + (int64_t)(4 * g) * ld] = cv[ib][g] - acc[ib][g];
+}
+
 // ---- one launch per block column (round 4; one matrix) ---------------------------------------------------------------------------------
 // The chain above pays two kernel boundaries per 64 columns (panel, update + factor) and, in its paired steps, leaves the chip idle while
 // the 13.9 us narrow launches run.  Here step k is ONE launch in which four roles run side by side, none waiting for another:
@@ -925,11 +995,12 @@ __device__ __forceinline__ void step_solve_role(double* __restrict__ A, int64_t 
 __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__ A, int64_t ld, int64_t Mp, int k,
                                                             int32_t* __restrict__ info)
 {
-    __shared__ double Ls[NB * LP];
-    __shared__ double Xq[4 * 16 * 64];   // the solved rows of the operand tile: [piece of 16 rows][s * 4 + g][lane]
+    __shared__ double Sh[NB * LP + 4 * 16 * 64];
+    double* Ls = Sh;                     // the diagonal tile being factored (CRIT)
+    double* Xq = Sh + NB * LP;           // the solved rows of the operand tile: [piece of 16 rows][s * 4 + g][lane]
     __shared__ int flag;
     const int nb = (int)(Mp / NB);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int nstrip = nb - k - 1;                      // row tiles k+2 .. nb
     const int bx = (int)blockIdx.x;
     if (bx == 0) {
@@ -940,15 +1011,23 @@ __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__
         step_solve_role<false>(A, ld, Mp, k, k + bx, k + 1, true, k > 0, Ls, Xq, &flag, info, tid);
     } else {
         // ---- BULK: panel k-1 onto the tiles of block columns >= k+2 (all but (k+2, k+2): DIAG2's) ---------------------------------
+        // One tile per wavefront.  (One tile per WORKGROUP — syrk_tile_wg — was built and measured: steps 1-3, where the per-wavefront
+        // form needs a second round of workgroups, 38 instead of 41 us, but 19-22 instead of 16-18 us from step 20 on, where a workgroup
+        // has too little matrix work — 64 instructions per wave — to hide its load -> LDS -> product -> C round trips at the two
+        // workgroups per CU this kernel's registers allow: N = 4096 1.37 instead of 1.29 ms.  profiles/r04_dense_steps_wg_tiles.txt)
         const int64_t j0 = ((int64_t)k + 2) * NB;
         const int nt = (int)((Mp - j0) / NB) + 1;       // i tiles (the last one holds the y row), j tiles 0 .. nt-2
-        const int bid = (bx - 2 - nstrip) * 4 + wave + 1;
+        const int lane = tid & 63, wave = tid >> 6;
+        const int bid = (bx - 2 - nstrip) * (kBulkPerWorkgroup ? 1 : 4) + (kBulkPerWorkgroup ? 0 : wave) + 1;
         int ti = (int)((sqrt(8.0 * bid + 1.0) - 1.0) * 0.5);
         while ((int64_t)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
         while ((int64_t)ti * (ti + 1) / 2 > bid) --ti;
         const int tj = bid - (int)((int64_t)ti * (ti + 1) / 2);
-        if (ti >= nt || tj >= nt - 1) return;           // wave-uniform; no workgroup barrier on this path
-        syrk_tile<1>(A, ld, ((int64_t)k - 1) * NB, j0, ti, tj, lane & 15, lane >> 4);
+        if (ti >= nt || tj >= nt - 1) return;           // wave-uniform (workgroup-uniform with one tile per workgroup)
+        if constexpr (kBulkPerWorkgroup)
+            syrk_tile_wg(A, ld, ((int64_t)k - 1) * NB, j0, ti, tj, Sh, tid);
+        else
+            syrk_tile<1>(A, ld, ((int64_t)k - 1) * NB, j0, ti, tj, lane & 15, lane >> 4);
     }
 }
 
@@ -1063,7 +1142,9 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
     if (phase_ev) (void)hipEventRecord(phase_ev[0], stream);
     if (hipMemsetAsync(info, 0, nbatch * sizeof(int32_t), stream) != hipSuccess) return PIORAN_ERR_HIP;
     double* ws = K + (size_t)ld * (size_t)Mp;   // WS_DOUBLES doubles right behind the slab
-    const bool steps = nbatch == 1 && !g_dense_old_chain && Mp >= 3 * NB;
+    // one launch per block column: from three block columns on, and while the 64-deep lagging bulk update is not bound by the traffic of
+    // the trailing matrix (N = 8192: 6.6 ms against 6.2 ms on the paired chain below, whose 128-deep updates read and write C half as often)
+    const bool steps = nbatch == 1 && !g_dense_old_chain && Mp >= 3 * NB && Mp <= 6144;
     hipLaunchKernelGGL(dense_diag0_kernel, dim3(steps ? 3 : 1, 1, nbatch), dim3(256), 0, stream, K, ld, ws, info, bt);
     if (steps) {
         // one matrix: one launch per block column (dense_step_kernel)
@@ -1072,7 +1153,7 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
             const int nstrip = nb - k - 1;
             const int64_t nt = (Mp - ((int64_t)k + 2) * NB) / NB + 1;            // i tiles of the bulk's origin (block column k+2)
             const int64_t ntile = (k > 0 && nt >= 2) ? nt * (nt + 1) / 2 - 1 : 0;   // (0, 0) of that origin is DIAG2's
-            hipLaunchKernelGGL(dense_step_kernel, dim3((unsigned)(2 + nstrip + (ntile + 3) / 4)), dim3(256), 0, stream, K, ld, Mp, k, info);
+            hipLaunchKernelGGL(dense_step_kernel, dim3((unsigned)(2 + nstrip + (kBulkPerWorkgroup ? ntile : (ntile + 3) / 4))), dim3(256), 0, stream, K, ld, Mp, k, info);
         }
         if (phase_ev) (void)hipEventRecord(phase_ev[1], stream);
         hipLaunchKernelGGL(dense_finish_kernel, dim3(1, 1, 1), dim3(256), 0, stream, K, ld, N, Mp, out, info, bt);
