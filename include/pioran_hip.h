@@ -95,8 +95,11 @@ int pioran_dataset_destroy(pioran_ds* ds);
  * terms go through the host-pointer entry with cd_shared = 0, which builds the mixed table itself.)
  * The declared state persists until the next pioran_dataset_prepare on this data set; no other entry changes it.
  * Device memory: the table takes (6 J + 8)(N + 1) * 8 bytes (10 MB at N = 1e4, J = 20); the first small batch (at most 512
- * draws, 768 from 42 rows on; 6 .. 63 rows) builds a second table for the windowed small-batch kernel, ~(30 J + 300) N bytes (37 MB there),
- * and falls back to the other kernels if that does not fit (2 GB cap). */
+ * draws; 768 with 32 .. 47 rows, 1024 with 36 .. 47 rows; 6 .. 63 rows) builds a second table for the windowed small-batch kernel,
+ * ~(30 J + 300) N bytes (37 MB there), and falls back to the other kernels if that does not fit (2 GB cap).
+ * Entries that chunk their draws (per-draw (c, d) tables: 37 MB per draw; prediction: 8.3 GB, gradient: 6 GB per 256 draws at
+ * N = 1e4, J = 20) take at most half of the free device memory and never more than the context option "workspace_limit_mb"
+ * (default 16384); the buffers stay with the context until pioran_ctx_trim. */
 int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const double* d,
                            const int32_t* real_term);
 
@@ -165,8 +168,8 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
 /* ---- posterior mean and simulation (the callers either side of the likelihood) -----------
  * predict (src/celerite_solver.jl:348-361 -> pred :363-483; mean(::PosteriorGP, tau) of src/scalable_GP.jl:64-72,90-91):
  *     mean_out[b][m] = mu_b + sum_n z_n k_b(|tau_m - t_n|),   z = K_b^-1 (y - mu_b),  K_b = kernel_b + diag(nu_b sigma2)
- * for B draws of (a, b); (c, d) [J] shared (cd_shared != 0) or [B][J] per draw (each draw then runs as its own one-draw
- * batch).  tau: M evaluation times, any order (the reference wants them sorted).
+ * for B draws of (a, b); (c, d) [J] shared (cd_shared != 0) or [B][J] per draw (see the last paragraph).  tau: M evaluation
+ * times, any order (the reference wants them sorted).
  * status (may be NULL) as in pioran_celerite_logl_batch.  Host pointers, blocking.
  * With 6 .. 63 rows and shared (c, d) both calls run on the windowed factorisation (celerite_block.hip, round 3): z by a block
  * back-substitution, the two running vectors of `pred` in 128-step segments, the tau-only factors once per call — 6.9 ms per 256

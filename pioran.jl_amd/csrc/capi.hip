@@ -7,10 +7,8 @@
 size_t pioran_predict_q_workspace_doubles(int64_t B, int64_t N, int32_t R);
 int pioran_dense_nll_device_batch(int64_t nbatch, int64_t N, int32_t J, const double* a, const double* b, const double* c, const double* d,
                                   int64_t cd_stride, const double* t, const double* y, const double* s2, double* K, int64_t slab,
-                                  const double* mu, const double* nu, double* out, int32_t* info, int sorted, hipStream_t stream);   // dense.hip
-void pioran_dense_set_batch_pair_threshold(int v);   // dense.hip, diagnostics
-void pioran_dense_set_quad_threshold(int v);
-void pioran_dense_set_old_chain(int v);
+                                  const double* mu, const double* nu, double* out, int32_t* info, int sorted, hipStream_t stream,
+                                  const DenseOptions* dopt);   // dense.hip
 int pioran_launch_block_sim(const ScanParams& p, const double* btab, double* xi, hipStream_t stream);   // celerite_block.hip
 int pioran_launch_block_solve(const ScanParams& p, const double* btab, const double* gtab, double* gy, hipStream_t stream);   // celerite_block.hip
 size_t pioran_predict_tau_workspace_doubles(int64_t M, int32_t R, int64_t ntab);
@@ -101,6 +99,17 @@ namespace {
             return PIORAN_ERR_HIP;                                                          \
         }                                                                                   \
     } while (0)
+
+// How much NEW device memory a call may take for its chunked workspaces (per-draw tables, factor stores, gradient / prediction
+// workspaces): half of what is free, but never more than the context's absolute budget (option "workspace_limit_mb", default 16 GiB —
+// the 256-draw chunks of every entry fit: per-draw windowed tables 9.5 GB, prediction 8.3 GB, gradient 6 GB at N = 1e4, J = 20), so
+// that a co-resident allocator (torch's caching allocator, a second context) is not starved on a 288 GB device.  The buffers stay in
+// the context until pioran_ctx_trim.
+static size_t ws_allow(const pioran_ctx* ctx, size_t free_b)
+{
+    const size_t cap = (size_t)(ctx->opt.workspace_limit_mb > 0 ? ctx->opt.workspace_limit_mb : 16384) << 20;
+    return free_b / 2 < cap ? free_b / 2 : cap;
+}
 
 int ensure(pioran_ctx* ctx, pioran_ctx::Buf& b, size_t bytes)
 {
@@ -396,9 +405,10 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "no_win3")) o.no_win3 = on;
     else if (!std::strcmp(key, "btab_reference")) o.btab_reference = on;
     else if (!std::strcmp(key, "block_emode")) o.block_emode = (value && value[0]) ? std::atoi(value) : -1;
-    else if (!std::strcmp(key, "dense_quad_threshold")) pioran_dense_set_quad_threshold((value && value[0]) ? std::atoi(value) : -1);
-    else if (!std::strcmp(key, "dense_batch_pair_threshold")) pioran_dense_set_batch_pair_threshold((value && value[0]) ? std::atoi(value) : -1);
-    else if (!std::strcmp(key, "dense_old_chain")) pioran_dense_set_old_chain(on ? 1 : 0);
+    else if (!std::strcmp(key, "dense_quad_threshold")) o.dense.quad_threshold = (value && value[0]) ? std::atoi(value) : -1;
+    else if (!std::strcmp(key, "dense_batch_pair_threshold")) o.dense.batch_pair_threshold = (value && value[0]) ? std::atoi(value) : -1;
+    else if (!std::strcmp(key, "dense_old_chain")) o.dense.old_chain = on ? 1 : 0;
+    else if (!std::strcmp(key, "workspace_limit_mb")) o.workspace_limit_mb = (value && value[0]) ? std::atoll(value) : 0;
     else if (!std::strcmp(key, "dense_streams")) o.dense_streams = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "gsum")) o.gsum = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "wide2")) o.wide2 = on;
@@ -686,7 +696,7 @@ int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const
         {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-                while (chunk > 1 && (size_t)chunk * (size_t)tdoubles * sizeof(double) > free_b / 2 + ctx->bscratch.cap) chunk /= 2;
+                while (chunk > 1 && (size_t)chunk * (size_t)tdoubles * sizeof(double) > ws_allow(ctx, free_b) + ctx->bscratch.cap) chunk /= 2;
         }
         while ((rc = ensure(ctx, ctx->bscratch, (size_t)chunk * (size_t)tdoubles * sizeof(double))) == PIORAN_ERR_ALLOC && chunk > 1) chunk /= 2;
         if (rc) return rc;
@@ -704,6 +714,7 @@ int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const
             q.A = dA + b0 * J; q.Bc = dBc + b0 * J; q.C = dC + b0 * J; q.D = dDd + b0 * J;
             q.mu = dmu ? dmu + b0 : nullptr; q.nu = dnu ? dnu + b0 : nullptr;
             q.out = dout + b0; q.status = dstatus ? dstatus + b0 : nullptr;
+            g_last_kernel = "wide (per-draw tables)";
             rc = pioran_launch_scan_wide(q, ctx->stream);
             if (rc) { if (rc == PIORAN_ERR_HIP) ctx->last_err = "per-draw-table latency kernel launch failed"; return rc; }
         }
@@ -724,7 +735,7 @@ int pioran_celerite_logl_batch_dev_cd(pioran_ds* ds, int64_t B, int64_t J, const
             {
                 size_t free_b = 0, total_b = 0;
                 if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-                    while (chunk > 1 && (size_t)chunk * (size_t)tdoubles * sizeof(double) > free_b / 2 + ctx->bscratch.cap) chunk /= 2;
+                    while (chunk > 1 && (size_t)chunk * (size_t)tdoubles * sizeof(double) > ws_allow(ctx, free_b) + ctx->bscratch.cap) chunk /= 2;
             }
             while ((rc = ensure(ctx, ctx->bscratch, (size_t)chunk * (size_t)tdoubles * sizeof(double))) == PIORAN_ERR_ALLOC && chunk > 1) chunk /= 2;
             if (rc) return rc;
@@ -1169,7 +1180,7 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
     PendingGuard pending_guard(ctx);
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
-    if (s.R > pioran_wide_supported_rows() || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
+    if (s.R > pioran_wide_supported_rows_modes() || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;   // before any upload / workspace
     int64_t chunk = B < 256 ? B : 256;
     // Windowed path (round 3): z = K^-1 (y - mu) from the windowed factorisation and a block back-substitution (celerite_block.hip),
     // then the two Q recurrences segment-parallel (celerite_predict.hip) — no step-by-step factor, no per-step wave reduction
@@ -1186,7 +1197,7 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
             return (pioran_block_grad_workspace_doubles(nb, ds->N, s.R) + pioran_predict_q_workspace_doubles(nb, ds->N, s.R)) * sizeof(double);
         };
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            while (chunk > 1 && need(chunk) > free_b / 2 + ctx->bwork.cap + ctx->bscratch.cap) chunk /= 2;
+            while (chunk > 1 && need(chunk) > ws_allow(ctx, free_b) + ctx->bwork.cap + ctx->bscratch.cap) chunk /= 2;
         rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bscratch, pioran_predict_q_workspace_doubles(chunk, ds->N, s.R) * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bgtab, pioran_block_gtab_doubles(ds->N, s.R) * sizeof(double));
@@ -1260,7 +1271,7 @@ static int predict_perdraw_windowed(pioran_ds* ds, int64_t B, int64_t J, const d
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            while (chunk > 1 && per_chunk(chunk) > free_b / 2 + ctx->bwork.cap + ctx->bscratch.cap + ctx->bgtab.cap + ctx->bK.cap + ctx->bq.cap) chunk /= 2;
+            while (chunk > 1 && per_chunk(chunk) > ws_allow(ctx, free_b) + ctx->bwork.cap + ctx->bscratch.cap + ctx->bgtab.cap + ctx->bK.cap + ctx->bq.cap) chunk /= 2;
     }
     for (;;) {
         rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double));
@@ -1344,9 +1355,8 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
     if (s.R > 95 || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
-    // Windowed reverse mode (celerite_block.hip, round 3) whenever d/d(c, d) are not asked for — the approx-based models under NUTS:
-    // (c, d) are fixed by the spectral grid — and the rows fit the windowed kernel: 6.3 ms instead of 25 at N = 1e4, J = 20 (series
-    // gradients and the shifted log-flux models included).
+    // Windowed reverse mode (celerite_block.hip, round 3) whenever the rows fit the windowed kernel, with or without d/d(c, d):
+    // 6.3 ms (7.0 with d/d(c, d)) instead of 25 at N = 1e4, J = 20 (series gradients and the shifted log-flux models included).
     bool windowed = !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R >= 6 &&
                     pioran_block_fits(s.R, s.J);
     if (windowed) {
@@ -1363,7 +1373,7 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t allowed = free_b / 2 + ctx->bwork.cap;
+            const size_t allowed = ws_allow(ctx, free_b) + ctx->bwork.cap;
             while (chunk > 1 && ws_doubles(chunk) * sizeof(double) > allowed) chunk /= 2;
         }
     }
@@ -1472,7 +1482,7 @@ static int logl_grad_perdraw_windowed(pioran_ds* ds, int64_t B, int64_t J, const
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            while (chunk > 1 && (size_t)chunk * per_draw > free_b / 2 + ctx->bwork.cap + ctx->bscratch.cap + ctx->bgtab.cap) chunk /= 2;
+            while (chunk > 1 && (size_t)chunk * per_draw > ws_allow(ctx, free_b) + ctx->bwork.cap + ctx->bscratch.cap + ctx->bgtab.cap) chunk /= 2;
     }
     for (;;) {
         rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double));
@@ -1599,7 +1609,7 @@ static int simulate_shared(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, con
     auto done = [&](int code) { pioran_dataset_destroy(ds); return code; };
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return done(rc);
     PrepState& s = ds->host;
-    if (s.R > pioran_wide_supported_rows() || s.npd_terms) return done(PIORAN_ERR_UNSUPPORTED);
+    if (s.R > pioran_wide_supported_rows_modes() || s.npd_terms) return done(PIORAN_ERR_UNSUPPORTED);   // before any upload / workspace
     int64_t chunk = B < 256 ? B : 256;
     // Windowed path (round 3; 6 .. 63 rows): the windowed factorisation with its per-window stores, then L applied window by window
     bool windowed = !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R >= 6 && s.R <= 63 &&
@@ -1612,7 +1622,7 @@ static int simulate_shared(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, con
     if (windowed) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            while (chunk > 1 && pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double) > free_b / 2 + ctx->bwork.cap) chunk /= 2;
+            while (chunk > 1 && pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double) > ws_allow(ctx, free_b) + ctx->bwork.cap) chunk /= 2;
         rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bscratch, (size_t)chunk * (size_t)N * sizeof(double));   // xi
         if (!rc) rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t));
@@ -1677,7 +1687,7 @@ static int simulate_perdraw_windowed(pioran_ctx* ctx, int64_t N, int64_t B, int6
         size_t free_b = 0, total_b = 0;
         auto need = [&](int64_t nb) { return ((size_t)nb * (size_t)bt + pioran_block_grad_workspace_doubles(nb, N, s.R) + 3 * (size_t)nb * (size_t)N) * sizeof(double); };
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            while (chunk > 1 && need(chunk) > free_b / 2 + ctx->bwork.cap + ctx->bscratch.cap + ctx->bq.cap) chunk /= 2;
+            while (chunk > 1 && need(chunk) > ws_allow(ctx, free_b) + ctx->bwork.cap + ctx->bscratch.cap + ctx->bq.cap) chunk /= 2;
     }
     for (;;) {
         rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double));
@@ -1746,7 +1756,8 @@ const char* pioran_celerite_config_name(int64_t R)
 {
     if (R < 0) return g_last_kernel;                 // kernel family of the calling thread's last launch: block, block+pd, wide, scan, fallback
     if (R <= 0) return pioran_scan_config_name(0);   // what the calling thread's last throughput-layout launch ran on
-    if (R > pioran_scan_supported_rows()) return "fallback";
+    if (R > pioran_wide_supported_rows()) return "fallback";
+    if (R > pioran_scan_supported_rows()) return "wide";   // 80 .. 143 rows: the lean latency kernel (80 with a shared table and a large batch: the scan)
     return pioran_scan_config_name((int)R);
 }
 
@@ -1885,7 +1896,7 @@ static int dense_nll_impl(pioran_ctx* ctx, int64_t N, int64_t J, const double* a
     if (rc) return rc;
     if (phase_ms) HIPCHK(ctx, hipEventRecord(ctx->ev[12], ctx->stream));
     rc = pioran_dense_nll_device(N, (int32_t)J, dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], (double*)ctx->bK.p,
-                                 phase_ms ? &ctx->ev[13] : nullptr, dv[7], (int32_t*)dv[8], is_sorted(t, N), ctx->stream);
+                                 phase_ms ? &ctx->ev[13] : nullptr, dv[7], (int32_t*)dv[8], is_sorted(t, N), ctx->stream, 0.0, 1.0, &ctx->opt.dense);
     if (rc) { ctx->last_err = "dense kernel launch failed"; return rc; }
     int32_t hinfo = 0;
     if ((rc = download(ctx, out, dv[7], sizeof(double)))) return rc;
@@ -1950,7 +1961,7 @@ int pioran_dense_nll_batch(pioran_ctx* ctx, int64_t N, int64_t J, int64_t B, con
         const int64_t nb = B - b0 < ns ? B - b0 : ns;
         rc = pioran_dense_nll_device_batch(nb, N, (int32_t)J, dA + b0 * J, dB + b0 * J, cd_shared ? dC : dC + b0 * J, cd_shared ? dD : dD + b0 * J,
                                            cd_shared ? 0 : J, dt, dy, ds2, (double*)ctx->bK.p, (int64_t)slab, mu ? dmu + b0 : nullptr,
-                                           nu ? dnu + b0 : nullptr, dout + b0, dinfo + b0, sorted, ctx->stream);
+                                           nu ? dnu + b0 : nullptr, dout + b0, dinfo + b0, sorted, ctx->stream, &ctx->opt.dense);
         if (rc) { ctx->last_err = "dense kernel launch failed"; return rc; }
     }
     if ((rc = download(ctx, out, dout, (size_t)B * sizeof(double)))) return rc;

@@ -1116,6 +1116,8 @@ __global__ void __launch_bounds__(256) grad_finish_kernel(const ScanParams p, in
 // wavefront per SIMD with the 512-register budget — the reference's own benchmark grid goes up to j = 64 terms = 128 rows
 // (benchmark/benchmarks.jl:16-18), which used to fall to the HBM-resident any-rank kernel.
 int pioran_wide_supported_rows() { return 143; }
+// ... the store (prediction), simulate and gradient-forward modes exist for the shapes of rounds 1-2 only
+int pioran_wide_supported_rows_modes() { return 95; }
 
 // Batches up to this size take the latency layout (at most one workgroup per CU on the chip's 256 CUs).
 int64_t pioran_wide_max_batch() { return 256; }

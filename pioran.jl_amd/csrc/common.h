@@ -16,13 +16,21 @@
 // Diagnostic switches of a context (none is needed in production).  Read ONCE from the environment when the context is
 // created (PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_BLOCK, PIORAN_NO_PAIRED, PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK) and changed
 // afterwards only through pioran_ctx_set_option — the launch path never calls getenv.
+// dense path (dense.hip): diagnostics / tuning of the factorisation schedule, carried per context (-1 = the defaults of dense.hip)
+struct DenseOptions {
+    int quad_threshold = -1;        // trailing tiles per side above which a batched launch takes its steps in fours
+    int batch_pair_threshold = -1;  // ... in pairs
+    int old_chain = 0;              // 1: one matrix on the panel / update chain of rounds 1-3 (A/B and cross-check of dense_step_kernel)
+};
 struct ScanOptions {
     char scan_config[48];   // "" automatic; "wide" / "block": that small-batch kernel for any batch size; else a throughput configuration's name
     bool no_wide, no_paired, no_mixed, force_fallback, no_block;
     bool win3, no_win3;   // throughput layouts with two / three rows per lane: force / forbid the three-step form (celerite_scan.hip;
                           // default: on for two rows per lane from 13 source lanes on, large batches)
     bool win2, no_win2;   // throughput layouts: force / forbid the two-step form of the recurrence (celerite_scan.hip)
-    int dense_streams = 0;   // pioran_dense_nll_batch: concurrent factorisations (0 = default 16 = the most)
+    int dense_streams = 0;   // pioran_dense_nll_batch: factorisations per batched launch (0 = default 32; at most 64)
+    DenseOptions dense;
+    long long workspace_limit_mb = 0;   // absolute cap on a call's NEW chunked workspace, MiB (0 = default 16384; capi.hip ws_allow)
     int gsum = -1;        // throughput layouts, two-step form: row sums with fewer exchange rounds (group_sum's GS); -1 = automatic
     int block_emode = -1; // windowed kernel, diagnostics: where the pair table E lives (0 one LDS buffer, 1 two, 2 global memory); -1 automatic
     bool btab_reference;  // windowed kernel: build its table with the entry-per-thread kernel of round 2 (cross-check of the windowed table kernel)
@@ -113,6 +121,7 @@ size_t pioran_grad_workspace_doubles(int64_t B, int64_t N, int32_t R);
 int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, double* grad_b, double* grad_c, double* grad_d,
                                  double* grad_nu, double* grad_mu, hipStream_t stream, hipStream_t aux, hipEvent_t* ev /*[5]*/);
 int pioran_wide_supported_rows();
+int pioran_wide_supported_rows_modes();   // store / simulate / gradient modes of the latency kernel (95)
 int64_t pioran_wide_max_batch();
 // celerite_block.hip: windowed form (16 steps per window on the matrix cores), one draw per workgroup; shared (c, d) without
 // per-draw rows; its own table (fragment order), built once per prepared (c, d)
@@ -179,7 +188,8 @@ void pioran_dense_dims(int64_t N, int64_t* Mp, int64_t* ld);
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,
                             const double* d, const double* t, const double* y, const double* s2,
                             double* K /*ld*Mp + PIORAN_DENSE_WS*/, hipEvent_t* phase_ev /*nullptr or [3]*/, double* out, int32_t* info,
-                            int sorted, hipStream_t stream, double mu = 0.0 /*subtracted from y*/, double nu = 1.0 /*scales s2*/);
+                            int sorted, hipStream_t stream, double mu = 0.0 /*subtracted from y*/, double nu = 1.0 /*scales s2*/,
+                            const DenseOptions* dopt = nullptr);
 int pioran_dense_predict_cov_device(int64_t N, int64_t M, int32_t J, const double* a, const double* b, const double* c,
                                     const double* d, const double* te, const double* s2e, double* K, int32_t* info,
                                     const double* y, double* mean, hipStream_t stream);

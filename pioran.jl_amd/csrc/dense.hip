@@ -1097,17 +1097,25 @@ static void launch_build(int64_t N, int64_t Mp, int64_t ld, int32_t J, const dou
     const int64_t nt = Mp / BT;
     const bool fast = sorted && nt > 1;
     // shared (c, d) (or one matrix): the transcendental part once per tile, the tiles themselves on the matrix cores
-    if ((nbatch == 1 || bt.cd_stride == 0) && sorted && J <= 64) {
+    bool tile_build = (nbatch == 1 || bt.cd_stride == 0) && sorted && J <= 64;
+    if (tile_build && nt > 1) {
+        // dense_build_fast_batch_kernel needs 2 KB x roundup4(J) of dynamic LDS (80 KB at J = 40, 128 KB at J = 64): ask once per device,
+        // and take this path only where the device grants it — otherwise the entry-per-thread + per-tile pair below
+        static int granted[64] = {};    // 0 unknown, 1 granted, -1 refused; racing threads at worst ask twice
+        int dev = 0;
+        bool ok = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+        if (ok && granted[dev] == 0) {
+            granted[dev] = hipFuncSetAttribute((const void*)dense_build_fast_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               4 * 64 * BT * (int)sizeof(double)) == hipSuccess ? 1 : -1;
+            if (granted[dev] < 0) (void)hipGetLastError();
+        }
+        tile_build = ok && granted[dev] == 1;
+    }
+    if (tile_build) {
         hipLaunchKernelGGL(dense_build_diag_batch_kernel, dim3(tiles, 4, (nbatch + ZC - 1) / ZC), dim3(256), 0, stream, N, Mp, ld, J, (int32_t)nbatch, a, b,
                            c, d, t, s2, y, K, bt, mu, nu);
         if (nt > 1) {
             const size_t lds = (size_t)4 * ((J + 3) & ~3) * BT * sizeof(double);
-            static bool granted[64] = {};   // the attribute belongs to (function, device); racing threads at worst set it twice
-            int dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !granted[dev]) {
-                (void)hipFuncSetAttribute((const void*)dense_build_fast_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * BT * (int)sizeof(double));
-                granted[dev] = true;
-            }
             hipLaunchKernelGGL(dense_build_fast_batch_kernel, dim3((unsigned)(nt * (nt - 1) / 2)), dim3(256), lds, stream, N, ld, J, (int32_t)nbatch, a, b,
                                c, d, t, K, bt);
         }
@@ -1120,22 +1128,19 @@ static void launch_build(int64_t N, int64_t Mp, int64_t ld, int32_t J, const dou
                            b, c, d, t, K, bt);
 }
 
-static int g_batch_pair_threshold = -1;   // diagnostics (tools/sweep_dense_streams.py): -1 = the defaults below
-static int g_quad_threshold = -1;
-static int g_dense_old_chain = 0;         // 1: one matrix on the panel / update chain of rounds 1-3 (A/B and cross-check of dense_step_kernel)
-void pioran_dense_set_old_chain(int v) { g_dense_old_chain = v; }
+// (diagnostics / tuning: DenseOptions in common.h, carried by the context — tools/sweep_dense_streams.py, tools/dense_ab.py)
 constexpr int kQuadThreshold = 1 << 20;        // one matrix: off
 constexpr int kBatchQuadThreshold = 16;        // batched launches (tools/sweep_dense_streams.py: 0.628 -> 0.554 ms per N = 4096 factorisation, 32 per launch)
-void pioran_dense_set_batch_pair_threshold(int v) { g_batch_pair_threshold = v; }
-void pioran_dense_set_quad_threshold(int v) { g_quad_threshold = v; }
 
 // nbatch matrices of the same size (same t, y, s2; coefficients strided, see DenseBatch): every kernel of the factorisation is
 // launched ONCE with gridDim.z = nbatch, so the 64 latency-bound steps of a factorisation are paid once per batch, not once per
 // matrix.  info / out: [nbatch].
 static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, const double* a, const double* b, const double* c, const double* d,
                           const double* t, const double* y, const double* s2, double* K, hipEvent_t* phase_ev,
-                          double* out, int32_t* info, int sorted, hipStream_t stream, double mu, double nu)
+                          double* out, int32_t* info, int sorted, hipStream_t stream, double mu, double nu, const DenseOptions* dopt)
 {
+    const DenseOptions dflt{};
+    const DenseOptions& dop = dopt ? *dopt : dflt;
     // phase_ev (nullptr or 3 events): recorded after the covariance build, after the factorisation loop, after the finish
     const int64_t Mp = (N + NB - 1) / NB * NB, ld = Mp + NB;
     launch_build(N, Mp, ld, J, a, b, c, d, t, y, s2, K, sorted, stream, mu, nu, nbatch, bt);
@@ -1144,7 +1149,7 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
     double* ws = K + (size_t)ld * (size_t)Mp;   // WS_DOUBLES doubles right behind the slab
     // one launch per block column: from three block columns on, and while the 64-deep lagging bulk update is not bound by the traffic of
     // the trailing matrix (N = 8192: 6.6 ms against 6.2 ms on the paired chain below, whose 128-deep updates read and write C half as often)
-    const bool steps = nbatch == 1 && !g_dense_old_chain && Mp >= 3 * NB && Mp <= 6144;
+    const bool steps = nbatch == 1 && !dop.old_chain && Mp >= 3 * NB && Mp <= 6144;
     hipLaunchKernelGGL(dense_diag0_kernel, dim3(steps ? 3 : 1, 1, nbatch), dim3(256), 0, stream, K, ld, ws, info, bt);
     if (steps) {
         // one matrix: one launch per block column (dense_step_kernel)
@@ -1174,10 +1179,10 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
     // PAIRS: panel k, narrow update of block column k+1 (+ its diagonal factor), panel k+1, then ONE 128-deep update of the
     // rest; afterwards (latency-bound steps) one 64-deep update per step as before.  (A batch is bound by that traffic for longer:
     // pairs down to a quarter of the single matrix's threshold.)
-    const int64_t pair_threshold = nbatch > 1 ? (g_batch_pair_threshold >= 0 ? g_batch_pair_threshold : kPairThreshold / 4) : kPairThreshold;
+    const int64_t pair_threshold = nbatch > 1 ? (dop.batch_pair_threshold >= 0 ? dop.batch_pair_threshold : kPairThreshold / 4) : kPairThreshold;
     // ... and in FOURS above quad_threshold: three narrow updates (block column k+1 with one panel, k+2 with two, k+3 with three), then ONE
     // 256-deep update of the rest — the trailing matrix goes through L2 / HBM once per 256 columns.
-    const int64_t quad_threshold = g_quad_threshold >= 0 ? g_quad_threshold : (nbatch > 1 ? kBatchQuadThreshold : kQuadThreshold);
+    const int64_t quad_threshold = dop.quad_threshold >= 0 ? dop.quad_threshold : (nbatch > 1 ? kBatchQuadThreshold : kQuadThreshold);
     auto col0 = [&](auto kp, int64_t kb0, int64_t ntc) {      // block column 0 of the trailing matrix behind KP panels (+ its diagonal factor)
         hipLaunchKernelGGL(dense_syrk_kernel<decltype(kp)::value>, dim3((unsigned)(1 + (ntc - 1 + 3) / 4), 1, nbatch), dim3(256), 0, stream, K, ld, kb0, Mp,
                            ws, info, 1, 1, bt);
@@ -1221,20 +1226,21 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
 
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c, const double* d,
                             const double* t, const double* y, const double* s2, double* K, hipEvent_t* phase_ev,
-                            double* out, int32_t* info, int sorted, hipStream_t stream, double mu, double nu)
+                            double* out, int32_t* info, int sorted, hipStream_t stream, double mu, double nu, const DenseOptions* dopt)
 {
-    return dense_nll_impl(1, DenseBatch{}, N, J, a, b, c, d, t, y, s2, K, phase_ev, out, info, sorted, stream, mu, nu);
+    return dense_nll_impl(1, DenseBatch{}, N, J, a, b, c, d, t, y, s2, K, phase_ev, out, info, sorted, stream, mu, nu, dopt);
 }
 
 // nbatch <= 65535 matrices at K + z slab (slab >= ld Mp + 1024 doubles); a, b: [nbatch][J]; c, d: [J] (cd_stride = 0) or [nbatch][J]
 // (cd_stride = J); mu, nu: device [nbatch] or nullptr (0 / 1); out, info: device [nbatch].
 int pioran_dense_nll_device_batch(int64_t nbatch, int64_t N, int32_t J, const double* a, const double* b, const double* c, const double* d,
                                   int64_t cd_stride, const double* t, const double* y, const double* s2, double* K, int64_t slab,
-                                  const double* mu, const double* nu, double* out, int32_t* info, int sorted, hipStream_t stream)
+                                  const double* mu, const double* nu, double* out, int32_t* info, int sorted, hipStream_t stream,
+                                  const DenseOptions* dopt)
 {
     if (nbatch < 1 || nbatch > 65535) return PIORAN_ERR_ARG;
     DenseBatch bt{slab, (int64_t)J, cd_stride, mu, nu};
-    return dense_nll_impl((unsigned)nbatch, bt, N, J, a, b, c, d, t, y, s2, K, nullptr, out, info, sorted, stream, 0.0, 1.0);
+    return dense_nll_impl((unsigned)nbatch, bt, N, J, a, b, c, d, t, y, s2, K, nullptr, out, info, sorted, stream, 0.0, 1.0, dopt);
 }
 
 // predict_cov (src/direct_solver.jl:28-69): K(tau,tau) - K(tau,t) (K(t,t) + diag(s2))^-1 K(t,tau) as the Schur complement
