@@ -49,7 +49,8 @@ def test_predict_601_draws_three_chunks(case):
     k = np.unravel_index(np.argmax(diff / np.maximum(np.abs(g1[okd]), 1e-300)), diff.shape)
     kd = np.unravel_index(np.argmax(diff / scale), diff.shape)
     d = int(np.flatnonzero(okd)[kd[0]])
-    ref = O.predict(c["A"][d], c["Bc"][d], c["C"], c["Dd"], c["tau"][perm], c["t"], c["y"] - c["mu"][d], c["nu"][d] * c["yerr"] ** 2) + c["mu"][d]
+    # (the oracle walks the merged (t, tau) sequence like the reference, src/celerite_solver.jl:392-479: ascending tau, then permuted)
+    ref = (O.predict(c["A"][d], c["Bc"][d], c["C"], c["Dd"], c["tau"], c["t"], c["y"] - c["mu"][d], c["nu"][d] * c["yerr"] ** 2) + c["mu"][d])[perm]
     print(f"unsorted vs sorted: max |diff| / curve scale = {np.max(diff / scale):.2e} (draw {d}, time index {kd[1]}: fused - oracle "
           f"{(g1[okd][kd] - ref[kd[1]]) / scale[kd[0], 0]:.2e}, two-kernel - oracle {(g2[okd][kd] - ref[kd[1]]) / scale[kd[0], 0]:.2e} of the scale); "
           f"worst elementwise ratio {diff[k] / abs(g1[okd][k]):.2e} at |value| / scale = {abs(g1[okd][k]) / scale[k[0], 0]:.2e}")
