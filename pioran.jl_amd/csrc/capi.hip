@@ -276,7 +276,7 @@ int scan_dispatch(const ScanParams& p, hipStream_t stream)
     // (exactly 80 rows with a shared table: the throughput layout holds them with y as a vector — large batches go there: 54 k
     //  instead of 43 k evaluations per second at B = 1024 .. 4096, N = 1e4; at 512 draws the latency layout is still ahead,
     //  39 k vs 27 k: tools/sweep_r80.py)
-    const bool y80 = p.R == pioran_scan_supported_rows_shared() && p.tab && p.npd_rows == 0 && !o.no_win2 && p.B > 768;
+    const bool y80 = p.R == pioran_scan_supported_rows_shared() && p.tab && p.npd_rows == 0 && !o.no_win2 && (p.B > 768 || o.no_wide);
     const bool only_wide = p.R > pioran_scan_supported_rows() && !o.no_wide && !y80;
     if (p.tab && p.R <= pioran_wide_supported_rows() && (force_wide || auto_wide || only_wide)) {
         g_last_kernel = "wide";

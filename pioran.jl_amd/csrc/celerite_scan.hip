@@ -771,19 +771,28 @@ struct StepIn {           // what one time step reads: per own row (v, x, phi) +
 // WIN3 (round 3, experiment): the THREE-step form — the same re-association with a window of three steps: per entry of T three
 // mat-vec FMAs, ONE Hadamard scaling and three rank-1 FMAs per three steps (2.5 instead of 2.75 instructions per entry and step),
 // paid for with three more row sums per window (g_AB, g_AC, g_BC) and the h vectors that carry m_A, m_B forward.
+// WS = 2 (round 4; two-step form, y as a vector, GS = 2): ONE DRAW OVER TWO WAVEFRONTS.  80 rows at five rows per lane leave one
+// wavefront 100 entries of T per lane — 200 of 256 registers before a single row vector: the two-step form does not fit and the shape ran
+// step by step with AGPR copies at a quarter of the FP64 roof.  Here the draw's column blocks are spread over the 8 DPP rows of a PAIR of
+// wavefronts (NSRC * 8 <= 16 source lanes; a workgroup is that pair = one draw, so its barrier couples nothing else): 50 entries per lane, the same loop body as
+// the 48-row shapes.  Per pair of steps ONE exchange crosses the pair — the partial products r = T u~ (2 RPL doubles per lane) through
+// LDS behind a workgroup barrier, double-buffered by the parity of the pair so that one barrier per exchange suffices; every row sum
+// after it is taken over the 16 lanes of a DPP row (GS = 2: once r is complete every DPP row of both wavefronts holds ALL row slots,
+// rotated), so no scalar ever crosses.
 template <int RPL, int CBR, int NSRC, bool SHARED_TAB, int MINW = 1, bool PAIRED = false, bool MIXED = false, int NPB = 0, bool WIN2 = false, int GS = 0, bool YC = false,
-          bool WIN3 = false>
+          bool WIN3 = false, int WS = 1>
 __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanParams p)
 {
+    static_assert(WS == 1 || (WS == 2 && WIN2 && YC && GS == 2 && CBR == 4 && SHARED_TAB), "one draw over two wavefronts: two-step form, y as a vector, row sums over all 16 lanes");
     static_assert(!YC || (WIN2 && !MIXED && NPB == 0), "y as a separate vector: two-step form, no per-draw rows, no block layout");
     static_assert(!WIN3 || (!WIN2 && !YC && !MIXED && NPB == 0 && SHARED_TAB && RPL <= 3), "three-step form: shared table, plain or paired layout");
     static_assert(NPB == 0 || (!PAIRED && 2 * NPB < NSRC * RPL && RPL % 2 == 0),
                   "block layout: unpaired base; both columns of a pair must sit in one source lane");
-    static_assert(NSRC * CBR <= 16, "source lanes must fit a DPP row");
-    constexpr int G = 16 * CBR;          // lanes per draw
+    static_assert(NSRC * CBR * WS <= 16, "source lanes must fit a DPP row");
+    constexpr int G = 16 * CBR;          // lanes per draw (WS = 2: per wavefront of the draw's pair)
     constexpr int EPW = 64 / G;          // draws per wavefront
     constexpr int NC = NSRC * RPL;       // columns held per lane
-    constexpr int YLAM = NSRC * CBR - 1; // the y row is the LAST row slot: logical lane YLAM, slot RPL-1
+    constexpr int YLAM = NSRC * CBR * WS - 1; // the y row is the LAST row slot: logical lane YLAM, slot RPL-1
     constexpr int YS = RPL - 1;
     // Columns nobody reads (round 3).  A column whose slot has u = 0 in EVERY DPP row of the wavefront contributes nothing to S u,
     // and an entry of S is read by nothing else, so such a column is neither updated nor kept in registers: the spare slot that
@@ -797,12 +806,13 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // known to be wave-uniform: with one draw per wavefront
                                                                          // (CBR = 4) mu, nu, sum(a) then live in SGPRs
     const int e = EPW == 1 ? 0 : lane / G;
-    const int r = (lane % G) >> 4;           // DPP row inside the draw = column block
+    [[maybe_unused]] const int half = WS == 2 ? (wave & 1) : 0;   // which wavefront of the draw's pair
+    const int r = ((lane % G) >> 4) + (WS == 2 ? 4 * half : 0);   // DPP row inside the draw = column block
     const int l = lane & 15;
     const int lam = (l + NSRC * r) & 15;     // logical lane: which rows this lane owns
     const bool contributes = l < NSRC;       // each row is counted once in u'q
     const bool isy = !YC && lam == YLAM;     // this lane's slot YS is the y row
-    const int64_t b_raw = ((int64_t)blockIdx.x * 4 + wave) * EPW + e;
+    const int64_t b_raw = WS == 2 ? (int64_t)blockIdx.x : ((int64_t)blockIdx.x * 4 + wave) * EPW + e;   // WS = 2: workgroups of TWO wavefronts = one draw
     const bool active = b_raw < p.B;
     const int64_t b = active ? b_raw : p.B - 1;
 
@@ -872,8 +882,10 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     [[maybe_unused]] const double* sv = own_series ? p.S2 + b * N : p.s2;
 
     [[maybe_unused]] int p1 = 0, p2 = 0;  // byte addresses (ds_bpermute) of the lanes holding the same rows in the other column blocks
-    if constexpr (CBR >= 2) p1 = 4 * (e * G + (r ^ 1) * 16 + ((lam - NSRC * (r ^ 1)) & 15));
-    if constexpr (CBR >= 4) p2 = 4 * (e * G + (r ^ 2) * 16 + ((lam - NSRC * (r ^ 2)) & 15));
+    if constexpr (CBR >= 2) p1 = 4 * (e * G + ((r ^ 1) & 3) * 16 + ((lam - NSRC * (r ^ 1)) & 15));
+    if constexpr (CBR >= 4) p2 = 4 * (e * G + ((r ^ 2) & 3) * 16 + ((lam - NSRC * (r ^ 2)) & 15));
+    // WS = 2: the lane of the PARTNER wavefront that holds the same rows (column block r ^ 4: same DPP row index there)
+    [[maybe_unused]] const int px = (r & 3) * 16 + ((lam - NSRC * (r ^ 4)) & 15);
 
     // Table record of step n: [v x Rp | x x Rp | phi x Rp | y_n, sigma2_n | per-draw block]; N + 1 records (the last
     // one is a readable dummy so the prefetch of step n + 1 needs no bounds test).  The per-draw block (mixed mode:
@@ -898,7 +910,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
     [[maybe_unused]] int vo_y = 3 * Rp * 8, vo_s = 3 * Rp * 8 + 8, y_step = step_bytes;
     if constexpr (SHARED_TAB) {
         if (own_series) {
-            int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * EPW;
+            int64_t b0 = WS == 2 ? (int64_t)blockIdx.x : ((int64_t)blockIdx.x * 4 + wave) * EPW;
             b0 = b0 < p.B ? b0 : p.B - 1;
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b0), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b0 >> 32));
             const int64_t b0u = (int64_t)(((uint64_t)hi << 32) | lo);
@@ -932,15 +944,17 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         if constexpr (SHARED_TAB) {
             if constexpr (WIN2 || WIN3) n = n < N ? n : N;   // the table holds N + 1 records
             const int soff = (int)n * step_bytes;
+            if constexpr (WS != 2) {   // (WS = 2: the rows' (v, x, phi) come through the LDS ring of the two-step loop, not through registers)
 #pragma unroll
-            for (int i = 0; i < RPL; ++i) {
-                in.v[i] = buf_load_f64(rs, vo_v[i], soff);
-                if constexpr (LANE_OFFS) {
-                    in.x[i] = buf_load_f64(rs, vo_x[i], soff);
-                    in.ph[i] = buf_load_f64(rs, vo_p[i], soff);
-                } else {
-                    in.x[i] = buf_load_f64(rs, vo_v[i], soff + Rp * 8);
-                    in.ph[i] = buf_load_f64(rs, vo_v[i], soff + 2 * Rp * 8);
+                for (int i = 0; i < RPL; ++i) {
+                    in.v[i] = buf_load_f64(rs, vo_v[i], soff);
+                    if constexpr (LANE_OFFS) {
+                        in.x[i] = buf_load_f64(rs, vo_x[i], soff);
+                        in.ph[i] = buf_load_f64(rs, vo_p[i], soff);
+                    } else {
+                        in.x[i] = buf_load_f64(rs, vo_v[i], soff + Rp * 8);
+                        in.ph[i] = buf_load_f64(rs, vo_v[i], soff + 2 * Rp * 8);
+                    }
                 }
             }
             if constexpr (WIN2 && EPW == 1) {
@@ -948,8 +962,17 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
                 // (round 3): base, stride and last index are chosen once; a conditional LOAD in the loop body is a real branch,
                 // and with it came per-block register copies (105 v_mov_b64 and ~160 scalar instructions per pair of steps)
                 const int ny = (int)n < ylast1 ? (int)n : ylast1;
-                in.y = ybase1[ny * ystr1];
-                in.s2 = sbase1[ny * ystr1];
+                if constexpr (WS == 2) {
+                    // (the workgroup barrier in this shape's loop is a fence: a plain load would no longer be provably unclobbered and would
+                    // become a VECTOR load, whose s_waitcnt vmcnt then also waits for the LDS copies in flight — the series are read-only
+                    // here, so read them through the constant address space: scalar loads whatever stands between)
+                    typedef const __attribute__((address_space(4))) double* cptr;
+                    in.y = ((cptr)(uintptr_t)ybase1)[ny * ystr1];
+                    in.s2 = ((cptr)(uintptr_t)sbase1)[ny * ystr1];
+                } else {
+                    in.y = ybase1[ny * ystr1];
+                    in.s2 = sbase1[ny * ystr1];
+                }
             } else {
                 const int ysoff = (int)n * y_step;
                 in.y = buf_load_f64(rs_y, vo_y, ysoff);
@@ -1166,10 +1189,13 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             for (int i = 0; i < RPL; ++i) T[c][i] = 0.0;
         // RPL >= 4: the row coefficients (al, be) wait in LDS (lane-private slots) instead of 4 RPL registers
         constexpr bool COEF_LDS = RPL >= 4;
-        __shared__ double sh_coef[COEF_LDS ? 2 * RPL * 256 : 1];
+        // (WS = 2: one copy per LOGICAL lane — the eight DPP rows of the draw hold the same rows, rotated: 1.3 KB instead of 10)
+        constexpr int CTH = WS == 2 ? 16 : 256;
+        const int cix = WS == 2 ? lam : (int)threadIdx.x;
+        __shared__ double sh_coef[COEF_LDS ? 2 * RPL * CTH : 1];
         if constexpr (COEF_LDS) {
 #pragma unroll
-            for (int i = 0; i < RPL; ++i) { sh_coef[(2 * i) * 256 + threadIdx.x] = al[i]; sh_coef[(2 * i + 1) * 256 + threadIdx.x] = be[i]; }
+            for (int i = 0; i < RPL; ++i) { sh_coef[(2 * i) * CTH + cix] = al[i]; sh_coef[(2 * i + 1) * CTH + cix] = be[i]; }
         }
         double one = 1.0;
         asm volatile("" : "+v"(one));
@@ -1179,22 +1205,79 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
         bool nonpd = false;
         PIORAN_SSTAMP_DECL
         StepIn<RPL> sa, sb;
+        __shared__ double sh_x[WS == 2 ? 2 * 2 * 2 * RPL * 64 : 1];   // [parity][wavefront of the pair][2 RPL values][lane]
+        [[maybe_unused]] int xpar = 0;
+        // WS = 2: the per-step inputs (v, x, phi of this lane's rows, two steps) never occupy registers.  Each wavefront of the pair copies
+        // ONE record of a pair of steps into LDS two pairs ahead (LDS DMA, 256 B per instruction: no registers, any alignment), the
+        // workgroup barrier of the pair in between is what publishes it, and the values are read where they are used (twice: before the
+        // pass over T and after the exchange) — 6 RPL doubles per lane less than the prefetched register sets of the other shapes, which
+        // is what lets the two-step body of five rows per lane stay clear of scratch (a reload's s_waitcnt vmcnt(0) would otherwise wait
+        // for a table record's round trip from L2 every pair of steps).
+        // LDS layout of a record: the three sections (v, x, phi: R + 2 <= 82 doubles each) at a FIXED pitch of 656 bytes, so that every read
+        // is `row address + immediate` whatever R is; a slot holds the two records of a pair of steps.
+        constexpr int RSEC = 656, RREC = 3 * RSEC, RSLOT = 2 * RREC;   // bytes
+        // THREE SEPARATE arrays, the slot a compile-time constant of every pair body (the loop below is unrolled by three): the compiler
+        // orders an LDS read behind a preceding LDS DMA (s_waitcnt vmcnt(0)) unless it can see that they touch different objects — with one
+        // array and a run-time slot every pair waited for the copy it had just issued (3.8 instead of ~3 us per pair of steps).
+        __shared__ double sh_ring0[WS == 2 ? RSLOT / 8 : 1], sh_ring1[WS == 2 ? RSLOT / 8 : 1], sh_ring2[WS == 2 ? RSLOT / 8 : 1];
+        [[maybe_unused]] auto ring_ptr = [&](auto slotc) __attribute__((always_inline)) -> double* {
+            constexpr int SL = decltype(slotc)::value;
+            if constexpr (SL == 0) return sh_ring0; else if constexpr (SL == 1) return sh_ring1; else return sh_ring2;
+        };
+        [[maybe_unused]] auto ring_dma = [&](auto slotc, int64_t n) __attribute__((always_inline)) {
+            if constexpr (WS == 2) {
+                const int64_t nn = n < 0 ? 0 : (n < N ? n : N);       // (the table holds N + 1 records)
+                const char* rec = (const char*)(p.tab + nn * p.rec_stride);
+                const int lim = Rp * 8 - 4;
+                char* dst = (char*)ring_ptr(slotc) + half * RREC;
+#pragma unroll
+                for (int sct = 0; sct < 3; ++sct)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        int off = c * 256 + lane * 4;
+                        off = off < lim ? off : lim;                   // past the section: a harmless repeat of its last word
+                        if (c < 2 || lane < (RSEC - 512) / 4)          // (the third piece stops at the section's pitch: the next section is another copy's)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + sct * Rp * 8 + off),
+                                                             (__attribute__((address_space(3))) void*)(dst + sct * RSEC + c * 256), 4, 0, 0);
+                    }
+            }
+        };
         [[maybe_unused]] double fy[RPL];   // YC: the y row of T for this lane's rows
 #pragma unroll
         for (int i = 0; i < RPL; ++i) fy[i] = 0.0;
+        // (WS = 2: f waits in lane-private LDS slots between its two uses of a pair — ten more registers for the pass over T)
+        __shared__ double sh_fy[WS == 2 ? RPL * 128 : 1];
+        if constexpr (WS == 2) {
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) sh_fy[i * 128 + threadIdx.x] = 0.0;
+        }
         // VOIDA: step A does not exist (D = 1, m = 0, no contribution); FIRST: step A is the first of the series (log D_1, :126)
-        auto pair = [&](int64_t nA, auto voidc, auto firstc) __attribute__((always_inline)) {
+        auto pair = [&](int64_t nA, auto voidc, auto firstc, auto slotc) __attribute__((always_inline)) {
             constexpr bool VOIDA = decltype(voidc)::value, FIRST = decltype(firstc)::value;
+            [[maybe_unused]] constexpr int SL = decltype(slotc)::value;   // WS = 2: ring slot of this pair
             PIORAN_SSTAMP(0);
             double uB[RPL], tA[RPL], tB[RPL], pAB[RPL], rA[RPL], rB[RPL];
+            // per-step inputs: the prefetched register sets, or (WS = 2) the ring slot of this pair, read at the point of use
+            [[maybe_unused]] const char* ra_[RPL];    // this pair's slot + the lane's row offset: every read below is ra_[i] + an immediate
+            if constexpr (WS == 2) {
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) ra_[i] = (const char*)ring_ptr(slotc) + vo_v[i];
+            }
+            auto A_v = [&](int i) { if constexpr (WS == 2) return VOIDA ? 0.0 : *(const double*)(ra_[i]); else return sa.v[i]; };
+            auto A_x = [&](int i) { if constexpr (WS == 2) return VOIDA ? 0.0 : *(const double*)(ra_[i] + RSEC); else return sa.x[i]; };
+            auto A_ph = [&](int i) { if constexpr (WS == 2) return VOIDA ? 1.0 : *(const double*)(ra_[i] + 2 * RSEC); else return sa.ph[i]; };
+            auto B_v = [&](int i) { if constexpr (WS == 2) return *(const double*)(ra_[i] + RREC); else return sb.v[i]; };
+            auto B_x = [&](int i) { if constexpr (WS == 2) return *(const double*)(ra_[i] + RREC + RSEC); else return sb.x[i]; };
+            auto B_ph = [&](int i) { if constexpr (WS == 2) return *(const double*)(ra_[i] + RREC + 2 * RSEC); else return sb.ph[i]; };
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
                 double ali = al[i], bei = be[i];
-                if constexpr (COEF_LDS) { ali = sh_coef[(2 * i) * 256 + threadIdx.x]; bei = sh_coef[(2 * i + 1) * 256 + threadIdx.x]; }
-                const double uA = ali * sa.v[i] + bei * sa.x[i];
-                uB[i] = ali * sb.v[i] + bei * sb.x[i];
-                pAB[i] = sa.ph[i] * sb.ph[i];
-                tA[i] = sa.ph[i] * uA;
+                if constexpr (COEF_LDS) { ali = sh_coef[(2 * i) * CTH + cix]; bei = sh_coef[(2 * i + 1) * CTH + cix]; }
+                const double aph = A_ph(i);
+                const double uA = ali * A_v(i) + bei * A_x(i);
+                uB[i] = ali * B_v(i) + bei * B_x(i);
+                pAB[i] = aph * B_ph(i);
+                tA[i] = aph * uA;
                 tB[i] = pAB[i] * uB[i];
                 rA[i] = 0.0;
                 rB[i] = 0.0;
@@ -1203,7 +1286,10 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             if constexpr (YC) {   // f'u~A, f'u~B: row vectors only, independent of the pass over T below
                 double spyA = 0.0, spyB = 0.0;
 #pragma unroll
-                for (int i = 0; i < RPL; ++i) { spyA = fma(fy[i], tA[i], spyA); spyB = fma(fy[i], tB[i], spyB); }
+                for (int i = 0; i < RPL; ++i) {
+                    const double fi = WS == 2 ? sh_fy[i * 128 + threadIdx.x] : fy[i];
+                    spyA = fma(fi, tA[i], spyA); spyB = fma(fi, tB[i], spyB);
+                }
                 ryA = group_sum<CBR, NSRC, GS>(spyA, contributes, one, p1, p2);
                 ryB = group_sum<CBR, NSRC, GS>(spyB, contributes, one, p1, p2);
             } else if constexpr (COEF_LDS) {   // (register-starved shapes: a select on the lane mask instead of the multiplier ysel)
@@ -1237,10 +1323,31 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) { rA[i] += lane_fetch(rA[i], p2); rB[i] += lane_fetch(rB[i], p2); }
             }
+            if constexpr (WS == 2) {   // the other wavefront's four column blocks
+                double* xo = sh_x + (xpar * 2 + half) * (2 * RPL * 64);
+                const double* xi = sh_x + (xpar * 2 + (half ^ 1)) * (2 * RPL * 64);
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) { xo[(2 * i) * 64 + lane] = rA[i]; xo[(2 * i + 1) * 64 + lane] = rB[i]; }
+                __syncthreads();           // (also: the records copied during the previous pair are complete and visible)
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) { rA[i] += xi[(2 * i) * 64 + px]; rB[i] += xi[(2 * i + 1) * 64 + px]; }
+                xpar ^= 1;
+                // this wavefront's record of the pair after next: its slot was last read before this barrier
+                ring_dma(ic<(SL + 2) % 3>{}, nA + 4 + half);
+            }
             PIORAN_SSTAMP(3);
             double spA = 0.0, spB = 0.0;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) { spA += tA[i] * rA[i]; spB += tB[i] * rB[i]; }
+            if constexpr (WS == 2) {   // u_B and phi_A phi_B again from the ring: ten registers each that need not live through the pass over T
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    asm volatile("" : "+v"(tA[i]), "+v"(tB[i]));      // (ends the first definitions' live ranges here)
+                    const double ali = sh_coef[(2 * i) * CTH + cix], bei = sh_coef[(2 * i + 1) * CTH + cix];
+                    uB[i] = ali * B_v(i) + bei * B_x(i);
+                    pAB[i] = A_ph(i) * B_ph(i);
+                }
+            }
             const double sA = group_sum<CBR, NSRC, GS>(spA, contributes, one, p1, p2);
             const double sB = group_sum<CBR, NSRC, GS>(spB, contributes, one, p1, p2);
             PIORAN_SSTAMP(4);
@@ -1250,9 +1357,9 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             double zA = 0.0;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
-                const double mA = VOIDA ? 0.0 : fma(-sa.ph[i], rA[i], sa.v[i]);        // v - q      :89
+                const double mA = VOIDA ? 0.0 : fma(-A_ph(i), rA[i], A_v(i));          // v - q      :89
                 if (!YC && i == YS) zA = mA;
-                hA[i] = sb.ph[i] * mA;
+                hA[i] = B_ph(i) * mA;
                 spg = fma(hA[i], uB[i], spg);
             }
             if constexpr (YC) zA = VOIDA ? 0.0 : (sa.y - mu) - ryA;                      // z_A = y_A - mu - f'u~A   (phi_y = 1)
@@ -1266,7 +1373,7 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             const double rDB = recip_f64(DB);
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
-                mB[i] = fma(-hA[i], gr, fma(-pAB[i], rB[i], sb.v[i]));
+                mB[i] = fma(-hA[i], gr, fma(-pAB[i], rB[i], B_v(i)));
                 wA[i] = hA[i] * rDA;
                 wB[i] = mB[i] * rDB;
             }
@@ -1275,7 +1382,10 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             if constexpr (YC) {
                 zB = ymB - ryB - zA * gr;                                                // the y row's (h_A)_y = z_A
 #pragma unroll
-                for (int i = 0; i < RPL; ++i) fy[i] = fma(zB, wB[i], fma(zA, wA[i], pAB[i] * fy[i]));
+                for (int i = 0; i < RPL; ++i) {
+                    if constexpr (WS == 2) sh_fy[i * 128 + threadIdx.x] = fma(zB, wB[i], fma(zA, wA[i], pAB[i] * sh_fy[i * 128 + threadIdx.x]));
+                    else fy[i] = fma(zB, wB[i], fma(zA, wA[i], pAB[i] * fy[i]));
+                }
             } else {
                 zB = mB[YS];
             }
@@ -1320,24 +1430,43 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
             }
         };
         int64_t n;
+        if constexpr (WS == 2) {   // the first two pairs' records, published by a barrier before the first read
+            const int64_t nA0 = (N & 1) ? -1 : 0;
+            ring_dma(ic<0>{}, nA0 + half);
+            ring_dma(ic<1>{}, nA0 + 2 + half);
+            __syncthreads();
+        }
         if (N & 1) {   // (void, step 0), then (1, 2), (3, 4), ...
             load_step(0, sb);
 #pragma unroll
             for (int i = 0; i < RPL; ++i) { sa.v[i] = 0.0; sa.x[i] = 0.0; sa.ph[i] = 1.0; }
             sa.y = mu;
             sa.s2 = 0.0;
-            pair(-1, std::true_type{}, std::true_type{});
+            pair(-1, std::true_type{}, std::true_type{}, ic<0>{});
             n = 1;
         } else {       // (0, 1), (2, 3), ...
             load_step(0, sa);
             load_step(1, sb);
-            pair(0, std::false_type{}, std::true_type{});
+            pair(0, std::false_type{}, std::true_type{}, ic<0>{});
             n = 2;
         }
-        for (; n + 1 < N; n += 2) pair(n, std::false_type{}, std::false_type{});
+        if constexpr (WS == 2) {   // ring slots 1, 2, 0, 1, 2, 0, ... as compile-time constants
+            for (; n + 5 < N; n += 6) {
+                pair(n, std::false_type{}, std::false_type{}, ic<1>{});
+                pair(n + 2, std::false_type{}, std::false_type{}, ic<2>{});
+                pair(n + 4, std::false_type{}, std::false_type{}, ic<0>{});
+            }
+            if (n + 1 < N) {
+                pair(n, std::false_type{}, std::false_type{}, ic<1>{});
+                n += 2;
+                if (n + 1 < N) { pair(n, std::false_type{}, std::false_type{}, ic<2>{}); n += 2; }
+            }
+        } else {
+            for (; n + 1 < N; n += 2) pair(n, std::false_type{}, std::false_type{}, ic<0>{});
+        }
         PIORAN_SSTAMP(0);
         PIORAN_SSTAMP_FLUSH
-        if (active && (YC ? (lane % G) == 0 : (isy && r == 0))) {
+        if (active && (YC ? ((lane % G) == 0 && half == 0) : (isy && r == 0))) {
             const double logdet = log(Pm) + (double)Pe * 0.6931471805599453094;
             const double res = -0.5 * logdet - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * quad;
             p.out[b] = res;
@@ -1548,11 +1677,12 @@ struct ScanConfig {
     bool autopick = true;  // false: only selectable by name (measured slower than the default of its row range)
     int npb = 0;           // > 0: block layout for "n_complex = npb * cbr two-row terms, then one-row terms" (standard_rows == 2)
     bool ycol = false;     // y rides as a separate vector (kernel template YC): every slot is a row; two-step form, no per-draw rows
+    int ws = 1;            // wavefronts per draw (2: the draw's column blocks over a pair of wavefronts, kernel template WS)
     // real rows it holds: one slot carries y (unless ycol); a paired config with an odd block keeps one single slot per block
     int capacity() const
     {
         const int rb = rpl * nsrc;
-        if (ycol) return cbr * (paired ? (rb & ~1) : rb);
+        if (ycol) return cbr * ws * (paired ? (rb & ~1) : rb);
         return paired ? cbr * (rb & ~1) - ((rb & 1) ? 0 : 1) : rpl * cbr * nsrc - 1;
     }
 };
@@ -1561,6 +1691,12 @@ template <int RPL, int CBR, int NSRC, int MINW, bool PAIRED>
 void launch_ycol(const ScanParams& p, dim3 grid, hipStream_t st)
 {
     hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true, 0, true>), grid, dim3(256), 0, st, p);
+}
+
+template <int RPL, int NSRC, bool PAIRED>
+void launch_ycol_w2(const ScanParams& p, dim3 grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((celerite_scan_kernel<RPL, 4, NSRC, true, 2, PAIRED, false, 0, true, 2, true, false, 2>), grid, dim3(128), 0, st, p);
 }
 
 #define CFG(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC, RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC>}
@@ -1582,6 +1718,13 @@ const ScanConfig kConfigs[] = {
     {"rpl4_cbr4_nsrc4_y", 4, 4, 4, &launch_ycol<4, 4, 4, 2, false>, false, true, 0, true},   // R = 64: y as a separate vector
     CFG(5, 4, 4),                                                         // R <= 79
     {"rpl5_cbr4_nsrc4_y", 5, 4, 4, &launch_ycol<5, 4, 4, 1, false>, false, true, 0, true},   // R = 80 (SHO-40: the dense configuration's model)
+    // 65 .. 80 rows, shared table: one draw over a PAIR of wavefronts (round 4; kernel template WS = 2): 50 entries of T per lane in the
+    // two-step form, no scratch, no AGPR copies — and exactly the speed of the one-wavefront shapes above at 80 rows (54.6 k against 54 k
+    // evaluations per second for SHO-40, B = 4096), slower below (the stream is the same for 65 .. 80 rows; SHO-39 runs at 64 k on
+    // rpl5_cbr4_nsrc4_p).  589 VALU instructions per wavefront and pair of steps, of which only 280 are the passes over T: the row-vector
+    // work of five rows per lane, the five 16-lane row sums and the exchange are paid by BOTH wavefronts (profiles/r04_r80.txt).  Selected
+    // by name only (context option scan_config); kept as the measured answer to "split the draw over two wavefronts".
+    {"rpl5_cbr4_nsrc2_w2_y", 5, 4, 2, &launch_ycol_w2<5, 2, false>, false, false, 0, true, 2},
     // column-paired variants (standard row map only; picked automatically by pick_config when applicable)
     {"rpl3_cbr2_nsrc7_p", 3, 2, 7, &launch_cfg<3, 2, 7, 1, true, true>, true}, CFG_P(3, 2, 8, 1), CFG_P(3, 2, 6, 1),
     CFG_P(1, 1, 5, 1), CFG_P(1, 1, 9, 1), CFG_P(1, 1, 13, 1), CFG_P(1, 1, 16, 1),
@@ -1592,6 +1735,7 @@ const ScanConfig kConfigs[] = {
     {"rpl2_cbr1_nsrc16_yp", 2, 1, 16, &launch_ycol<2, 1, 16, 1, true>, true, true, 0, true},
     {"rpl3_cbr2_nsrc8_yp", 3, 2, 8, &launch_ycol<3, 2, 8, 1, true>, true, true, 0, true},
     {"rpl5_cbr4_nsrc4_yp", 5, 4, 4, &launch_ycol<5, 4, 4, 1, true>, true, true, 0, true},
+    {"rpl5_cbr4_nsrc2_w2_yp", 5, 4, 2, &launch_ycol_w2<5, 2, true>, true, false, 0, true, 2},
     // DRWCelerite with 20 components: 20 complex + 20 real terms = 5 pairs + 5 singles + 1 spare in each of the 4 blocks
     {"rpl4_cbr4_nsrc4_b5a", 4, 4, 4, &launch_blocked<4, 4, 4, 2, 5>, false, true, 5},
     // alternatives kept for tuning runs (selected by name)
@@ -1599,7 +1743,7 @@ const ScanConfig kConfigs[] = {
 };
 #undef CFG
 #undef CFG_P
-constexpr int kNumPreferred = 19;
+constexpr int kNumPreferred = 20;
 
 // y-as-a-vector shapes exist in the two-step form for launches without per-draw rows only
 bool ycol_usable(const ScanConfig& c, const ScanParams* p)
@@ -1635,7 +1779,7 @@ const ScanConfig* pick_config(int R, bool standard_rows, const ScanParams* p = n
     }
     const ScanConfig* best = nullptr;
     for (int i = 0; i < kNumPreferred; ++i)
-        if (kConfigs[i].capacity() >= R && ycol_usable(kConfigs[i], p)) { best = &kConfigs[i]; break; }
+        if (kConfigs[i].autopick && kConfigs[i].capacity() >= R && ycol_usable(kConfigs[i], p)) { best = &kConfigs[i]; break; }
     if (standard_rows && !no_paired) {
         // a paired variant of the same shape (or the smallest paired one that fits) wins when the row map allows it
         for (const auto& c : kConfigs)
@@ -1678,7 +1822,7 @@ int pioran_launch_scan(const ScanParams& p, hipStream_t stream)
             if (!std::strcmp(alt.name, "rpl2_cbr2_nsrc8")) c = &alt;
     }
     const int epw = 64 / (16 * c->cbr);
-    const int64_t per_block = 4 * epw;
+    const int64_t per_block = c->ws == 2 ? 1 : 4 * epw;
     const int64_t blocks = (p.B + per_block - 1) / per_block;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return PIORAN_ERR_ARG;
     g_last_config = c->name;

@@ -254,6 +254,43 @@ def test_rows_80_to_95_stay_register_resident(ctx, J, B):
     np.testing.assert_allclose(pm[0], O.predict(A[0], Bc[0], C, Dd, tau, t, y - mu[0], nu[0] * s2) + mu[0], rtol=1e-10, atol=1e-11)
 
 
+@pytest.mark.parametrize("J,nreal,N,B", [(40, 0, 61, 300), (40, 0, 90, 5), (33, 0, 130, 290), (36, 0, 47, 301), (39, 0, 1, 280), (39, 0, 2, 280),
+                                          (40, 0, 3, 7), (40, 0, 4, 7), (40, 0, 5, 7), (40, 0, 6, 7), (40, 0, 7, 7), (40, 0, 8, 7), (40, 0, 9, 7),
+                                          (45, 20, 75, 300), (50, 22, 64, 258), (42, 4, 333, 259), (44, 12, 51, 3)])
+def test_rows_65_to_80_one_draw_over_two_wavefronts(ctx, J, nreal, N, B):
+    """65 .. 80 active rows, shared table (SHO-33 .. 40 — the dense configuration's model is SHO-40 —, DRWCelerite-22 .. 26 and other mixes
+    of two-row and one-row terms): the throughput layout that spreads one draw's column blocks over a PAIR of wavefronts (round 4,
+    rpl5_cbr4_nsrc2_w2_y[p], selected by name: two-step form with 50 entries of the state per lane, per-step inputs through an LDS ring,
+    one LDS exchange per pair of steps).  Against the oracle, the one-wavefront 80-row shapes (the default) and the lean latency kernel;
+    series of odd and even length and of every remainder of the ring's three slots, N = 1 and 2, per-draw series."""
+    rng = np.random.default_rng(8000 + J + N)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    if nreal:      # one-row terms (b = d = 0: Exp / DRW): rows = 2 J - nreal
+        Bc[:, -nreal:] = 0.0; Dd[-nreal:] = 0.0
+    R = 2 * J - nreal
+    assert 65 <= R <= 80
+    ds = pj.Dataset(t, y, s2, ctx)
+    ref, rst = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8, return_status=True)
+    try:
+        ctx.set_option("no_wide", True)       # (batches up to 256 draws would take the latency layout)
+        one = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan" and "w2" not in pj._lib.lib().pioran_celerite_config_name(0).decode()
+        ctx.set_option("scan_config", "rpl5_cbr4_nsrc2_w2_yp" if nreal == 0 else "rpl5_cbr4_nsrc2_w2_y")
+        got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        cfg = pj._lib.lib().pioran_celerite_config_name(0).decode()
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan" and "_w2_y" in cfg, cfg
+        Y = rng.standard_normal((B, N)); S2 = rng.uniform(0.01, 0.1, (B, N))
+        got2 = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+    finally:
+        ctx.set_option("scan_config", None); ctx.set_option("no_wide", False)
+    assert np.array_equal(st, rst)
+    assert relerr(got, ref) < 1e-11 and relerr(one, ref) < 1e-11
+    ref2 = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(min(B, 40))])
+    assert relerr(got2[:len(ref2)], ref2) < 1e-11
+    lat = ds.logl_batch(A[:5], Bc[:5], C, Dd, mu=mu[:5], nu=nu[:5])     # five draws: the lean latency kernel
+    assert relerr(lat, ref[:5]) < 1e-11
+
+
 @pytest.mark.parametrize("J,N,B", [(48, 60, 5), (52, 33, 2), (56, 130, 3), (60, 61, 1), (64, 60, 5), (64, 700, 2), (71, 45, 3), (32, 300, 4), (40, 77, 2)])
 def test_rows_64_to_143_lean_latency_layout(ctx, J, N, B):
     """R = 64 .. 143 rows stay register-resident (round 3): celerite_wide2_kernel, 5 .. 9 rows per lane.  The reference's own

@@ -15,8 +15,8 @@ s = open(f'/tmp/kres/{stem}.s').read()
 md = s[s.index('amdhsa.kernels'):]
 for b in md.split('  - .agpr_count:')[1:]:
     name = re.search(r'\.name:\s+(\S+)', b).group(1)
-    if not re.search(filt, name): continue
     g = lambda k: re.search(r'\.' + k + r':\s+(\d+)', b).group(1)
     dem = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip()
+    if not re.search(filt, dem): continue
     print(f"{dem[:110]:110s} agpr {b.split(chr(10))[0].strip():>3s} vgpr {g('vgpr_count'):>3s} spill {g('vgpr_spill_count'):>3s} lds {g('group_segment_fixed_size'):>6s} scratch {g('private_segment_fixed_size'):>4s}")
 PY
