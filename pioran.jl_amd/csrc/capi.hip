@@ -337,6 +337,70 @@ int block_dispatch(pioran_ds* ds, const ScanParams& p)
     return pioran_launch_scan_block(p, s->btab, ctx->stream);
 }
 
+// Batches that are not a whole number of passes (round 4).  A throughput launch is a sequence of PASSES — every SIMD of the chip holding as
+// many wavefronts as the kernel's registers allow (SHO-20: 2 x 1024 wavefronts x 2 draws = 4096 draws) — and a wavefront walks the whole
+// series whatever its pass carries: 4200 draws cost two passes' time less what the scheduler backfills (16.9 against 11.9 ms for 4096).
+// Small remainders are what the windowed kernel (celerite_block.hip) is fast at, and its workgroups fit BESIDE a resident scan wavefront
+// (205 + 250 registers per SIMD lane pair): so the remainder goes to that kernel on the context's second stream, launched first, while the
+// whole passes run on the main stream.  The two launches write disjoint slices of out / status; the main stream waits for the second
+// one's event, so the call is stream-ordered like any other.
+static ScanParams slice_draws(const ScanParams& p, int64_t off, int64_t n)
+{
+    ScanParams q = p;
+    q.B = n;
+    q.A = p.A + off * p.J; q.Bc = p.Bc + off * p.J;
+    if (p.mu) q.mu = p.mu + off;
+    if (p.nu) q.nu = p.nu + off;
+    if (p.Y) q.Y = p.Y + off * p.N;
+    if (p.S2) q.S2 = p.S2 + off * p.N;
+    q.out = p.out + off;
+    if (p.status) q.status = p.status + off;
+    return q;
+}
+
+static int split_dispatch(pioran_ds* ds, const ScanParams& p)
+{
+    pioran_ctx* ctx = ds->ctx;
+    const ScanOptions& o = ctx->opt;
+    if (o.no_split || o.scan_config[0] || o.no_block || o.force_fallback || !p.tab || p.npd_rows != 0 || p.R < 6 || p.R > 63 ||
+        !pioran_block_fits(p.R, p.J))
+        return PIORAN_ERR_UNSUPPORTED;
+    PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
+    if (!s || !s->prepared || s->npd_terms != 0 || p.rec_stride != 3 * (int64_t)(s->R + 2) + 2) return PIORAN_ERR_UNSUPPORTED;
+    int wps = 0;
+    const int64_t pass = pioran_scan_pass_draws(p, &wps);
+    if (pass < 1024) return PIORAN_ERR_UNSUPPORTED;
+    (void)wps;
+    // ONE round of the windowed kernel's workgroups: 512 draws (two workgroups per CU) up to three block columns, 256 with four
+    // (tools/sweep_batch_sizes.py, profiles/r04_batch_sizes.txt: SHO-20 4200 draws 16.8 -> 13.1 ms, 4608 16.8 -> 14.8; DRWCelerite-20 4200
+    // 32.5 -> 28.6.  A second round no longer hides behind the scan — SHO-20 5000 draws: 19.7 against 16.8 ms in one launch — and neither
+    // does sending what exceeds HALF a pass: 2500 draws 11.6 against 10.6 ms; both were measured and are not done.)
+    const int64_t rem_max = p.R <= 47 ? 512 : 256;
+    int64_t main_n = 0;
+    const int64_t k = p.B / pass, r = p.B - k * pass;
+    if (k >= 1 && r > 0 && r <= rem_max) main_n = k * pass;
+    if (main_n <= 0 || main_n >= p.B) return PIORAN_ERR_UNSUPPORTED;
+    int rc = ensure_btab(ds, *s);
+    if (rc) return rc == PIORAN_ERR_UNSUPPORTED ? rc : rc;
+    if (!ctx->aux) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+        for (auto& e : ctx->gev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    // fork: the second stream sees everything the main stream has queued so far (inputs, tables)
+    HIPCHK(ctx, hipEventRecord(ctx->gev[3], ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->gev[3], 0));
+    ScanParams qr = slice_draws(p, main_n, p.B - main_n);
+    rc = pioran_launch_scan_block(qr, s->btab, ctx->aux);
+    if (rc) { if (rc == PIORAN_ERR_HIP) ctx->last_err = "block kernel launch failed"; return rc; }
+    HIPCHK(ctx, hipEventRecord(ctx->gev[4], ctx->aux));
+    ScanParams qm = slice_draws(p, 0, main_n);
+    rc = scan_dispatch(qm, ctx->stream);
+    if (rc) { if (rc == PIORAN_ERR_HIP) ctx->last_err = "scan kernel launch failed"; return rc; }
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->gev[4], 0));   // join
+    g_last_kernel = "scan + block (remainder)";
+    return PIORAN_OK;
+}
+
 int launch(pioran_ds* ds, ScanParams& p)
 {
     pioran_ctx* ctx = ds->ctx;
@@ -347,6 +411,8 @@ int launch(pioran_ds* ds, ScanParams& p)
             if (rc == PIORAN_ERR_HIP) ctx->last_err = "block kernel launch failed";
             return rc;
         }
+        rc = split_dispatch(ds, p);
+        if (rc != PIORAN_ERR_UNSUPPORTED) return rc;
     }
     if (p.R <= pioran_wide_supported_rows() && !ctx->opt.force_fallback) {
         int rc = scan_dispatch(p, ctx->stream);
@@ -399,6 +465,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "no_mixed")) o.no_mixed = on;
     else if (!std::strcmp(key, "force_fallback")) o.force_fallback = on;
     else if (!std::strcmp(key, "no_block")) o.no_block = on;
+    else if (!std::strcmp(key, "no_split")) o.no_split = on;
     else if (!std::strcmp(key, "win2")) o.win2 = on;
     else if (!std::strcmp(key, "no_win2")) o.no_win2 = on;
     else if (!std::strcmp(key, "win3")) o.win3 = on;

@@ -1599,6 +1599,19 @@ __global__ void __launch_bounds__(256, MINW) celerite_scan_kernel(const ScanPara
 }
 
 using LaunchFn = void (*)(const ScanParams&, dim3, hipStream_t);
+// Every launch of this file goes through SCAN_LAUNCH: with g_occ_query set (pioran_scan_pass_draws) the SAME selection logic asks the
+// runtime how many wavefronts of the selected instantiation a CU holds instead of launching it.
+thread_local int* g_occ_query = nullptr;
+#define SCAN_LAUNCH(KERN, grid, threads, st, p)                                                         \
+    do {                                                                                               \
+        if (g_occ_query) {                                                                             \
+            int nb_ = 0;                                                                               \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, KERN, threads, 0) != hipSuccess) nb_ = 0; \
+            *g_occ_query = nb_ * ((threads) / 64);                                                     \
+        } else {                                                                                       \
+            hipLaunchKernelGGL(KERN, grid, dim3(threads), 0, st, p);                                   \
+        }                                                                                              \
+    } while (0)
 thread_local bool g_last_win3 = false;   // the calling thread's last launch used the three-step form (diagnostics)
 
 // which form of the row sums (group_sum's GS): the context option "gsum" (0, 1, 2) when set, else automatic
@@ -1620,7 +1633,7 @@ void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
         // one the extra row sums outweigh the saved scalings (10 .. 30 % slower): those run it only when the option asks
         const bool auto3 = RPL == 2 && CBR == 1 && NSRC >= 13 && !(p.opt && (p.opt->no_win3 || p.opt->no_win2 || p.opt->win2)) && p.B > 2048;
         if (((p.opt && p.opt->win3) || auto3) && p.tab && p.npd_rows == 0) {
-            hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, 2, PAIRED, false, 0, false, 0, false, true>), grid, dim3(256), 0, st, p);
+            SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, 2, PAIRED, false, 0, false, 0, false, true>), grid, 256, st, p);
             g_last_win3 = true;
             return;
         }
@@ -1628,8 +1641,8 @@ void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
     if constexpr (GSV) {
         const int gs = gsum_mode(p, CBR);
         if (gs && p.tab && p.npd_rows == 0 && !(p.opt && p.opt->no_win2)) {
-            if (gs == 2) hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true, 2>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true, CBR == 4 ? 1 : 2>), grid, dim3(256), 0, st, p);
+            if (gs == 2) SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true, 2>), grid, 256, st, p);
+            else SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true, CBR == 4 ? 1 : 2>), grid, 256, st, p);
             return;
         }
     }
@@ -1638,19 +1651,19 @@ void launch_cfg(const ScanParams& p, dim3 grid, hipStream_t st)
     // (context option "win2")
     if ((RPL <= 4 && !(p.opt && p.opt->no_win2)) || (p.opt && p.opt->win2)) {
         if (p.tab && p.npd_rows > 0)
-            hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, true, 0, true>), grid, dim3(256), 0, st, p);
+            SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, true, 0, true>), grid, 256, st, p);
         else if (p.tab)
-            hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true>), grid, dim3(256), 0, st, p);
+            SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true>), grid, 256, st, p);
         else
-            hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false, MINW, PAIRED, false, 0, true>), grid, dim3(256), 0, st, p);
+            SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, false, MINW, PAIRED, false, 0, true>), grid, 256, st, p);
         return;
     }
     if (p.tab && p.npd_rows > 0)
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, true>), grid, dim3(256), 0, st, p);
+        SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, true>), grid, 256, st, p);
     else if (p.tab)
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED>), grid, dim3(256), 0, st, p);
+        SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED>), grid, 256, st, p);
     else
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, false, MINW, PAIRED>), grid, dim3(256), 0, st, p);
+        SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, false, MINW, PAIRED>), grid, 256, st, p);
 }
 
 // block layout (NPB pairs per block): shared-table launches without per-draw rows only
@@ -1659,14 +1672,14 @@ void launch_blocked(const ScanParams& p, dim3 grid, hipStream_t st)
 {
     const int gs = gsum_mode(p, CBR);
     if (gs && !(p.opt && p.opt->no_win2)) {
-        if (gs == 2) hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB, true, 2>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB, true, 1>), grid, dim3(256), 0, st, p);
+        if (gs == 2) SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB, true, 2>), grid, 256, st, p);
+        else SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB, true, 1>), grid, 256, st, p);
         return;
     }
     if ((RPL <= 4 && !(p.opt && p.opt->no_win2)) || (p.opt && p.opt->win2))
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB, true>), grid, dim3(256), 0, st, p);
+        SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB, true>), grid, 256, st, p);
     else
-        hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB>), grid, dim3(256), 0, st, p);
+        SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, false, false, NPB>), grid, 256, st, p);
 }
 
 struct ScanConfig {
@@ -1690,13 +1703,13 @@ struct ScanConfig {
 template <int RPL, int CBR, int NSRC, int MINW, bool PAIRED>
 void launch_ycol(const ScanParams& p, dim3 grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true, 0, true>), grid, dim3(256), 0, st, p);
+    SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true, 0, true>), grid, 256, st, p);
 }
 
 template <int RPL, int NSRC, bool PAIRED>
 void launch_ycol_w2(const ScanParams& p, dim3 grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((celerite_scan_kernel<RPL, 4, NSRC, true, 2, PAIRED, false, 0, true, 2, true, false, 2>), grid, dim3(128), 0, st, p);
+    SCAN_LAUNCH((celerite_scan_kernel<RPL, 4, NSRC, true, 2, PAIRED, false, 0, true, 2, true, false, 2>), grid, 128, st, p);
 }
 
 #define CFG(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC, RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC>}
@@ -1809,10 +1822,15 @@ const char* pioran_scan_config_name(int R)
     return c ? c->name : "fallback";
 }
 
-int pioran_launch_scan(const ScanParams& p, hipStream_t stream)
+static const ScanConfig* launch_config(const ScanParams& p);
+
+// Draws that ONE full pass of the throughput layout holds for this launch (every SIMD of the chip with as many wavefronts as the selected
+// instantiation's registers and LDS allow); 0 if unknown.  A launch of k such passes plus a remainder runs the remainder as a second,
+// mostly empty pass of full-length wavefronts: capi.hip sends small remainders to the windowed kernel on a second stream instead.
+static const ScanConfig* launch_config(const ScanParams& p)
 {
     const ScanConfig* c = pick_config(p.R, p.standard_rows == 1, &p);
-    if (!c) return PIORAN_ERR_UNSUPPORTED;
+    if (!c) return nullptr;
     // Mid-size batches: up to 2048 draws the four-draws-per-wavefront shapes of this row range put at most one wavefront on
     // half of the chip's 1024 SIMDs, and the launch takes as long as ONE wavefront needs for the series; two draws per
     // wavefront (rpl2_cbr2_nsrc8: half the columns per lane) is then the faster walk (tools/sweep_midbatch.py, N = 1e4,
@@ -1821,6 +1839,30 @@ int pioran_launch_scan(const ScanParams& p, hipStream_t stream)
         for (const auto& alt : kConfigs)
             if (!std::strcmp(alt.name, "rpl2_cbr2_nsrc8")) c = &alt;
     }
+    return c;
+}
+
+int64_t pioran_scan_pass_draws(const ScanParams& p, int* waves_per_simd)
+{
+    if (waves_per_simd) *waves_per_simd = 0;
+    const ScanConfig* c = launch_config(p);
+    if (!c) return 0;
+    int waves_per_cu = 0, ncu = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    g_occ_query = &waves_per_cu;
+    c->fn(p, dim3(1), nullptr);
+    g_occ_query = nullptr;
+    (void)hipGetLastError();
+    const int epw = 64 / (16 * c->cbr);
+    if (waves_per_cu <= 0 || ncu <= 0) return 0;
+    if (waves_per_simd) *waves_per_simd = waves_per_cu / 4;
+    return c->ws == 2 ? (int64_t)ncu * (waves_per_cu / 2) : (int64_t)ncu * waves_per_cu * epw;
+}
+
+int pioran_launch_scan(const ScanParams& p, hipStream_t stream)
+{
+    const ScanConfig* c = launch_config(p);
+    if (!c) return PIORAN_ERR_UNSUPPORTED;
     const int epw = 64 / (16 * c->cbr);
     const int64_t per_block = c->ws == 2 ? 1 : 4 * epw;
     const int64_t blocks = (p.B + per_block - 1) / per_block;

@@ -25,6 +25,7 @@ struct DenseOptions {
 struct ScanOptions {
     char scan_config[48];   // "" automatic; "wide" / "block": that small-batch kernel for any batch size; else a throughput configuration's name
     bool no_wide, no_paired, no_mixed, force_fallback, no_block;
+    bool no_split;        // never send the remainder of a multi-pass batch to the windowed kernel on the second stream (capi.hip split_dispatch)
     bool win3, no_win3;   // throughput layouts with two / three rows per lane: force / forbid the three-step form (celerite_scan.hip;
                           // default: on for two rows per lane from 13 source lanes on, large batches)
     bool win2, no_win2;   // throughput layouts: force / forbid the two-step form of the recurrence (celerite_scan.hip)
@@ -109,6 +110,7 @@ struct ScanParams {
 
 // celerite_scan.hip
 int pioran_launch_scan(const ScanParams& p, hipStream_t stream);
+int64_t pioran_scan_pass_draws(const ScanParams& p, int* waves_per_simd);   // draws one full pass of the selected throughput kernel holds (0: unknown)
 int pioran_scan_supported_rows();
 int pioran_scan_supported_rows_shared();
 const char* pioran_scan_config_name(int R);

@@ -254,6 +254,49 @@ def test_rows_80_to_95_stay_register_resident(ctx, J, B):
     np.testing.assert_allclose(pm[0], O.predict(A[0], Bc[0], C, Dd, tau, t, y - mu[0], nu[0] * s2) + mu[0], rtol=1e-10, atol=1e-11)
 
 
+@pytest.mark.parametrize("basis,B", [("SHO", 4096 + 104), ("SHO", 8192 + 500), ("DRWCelerite", 2048 + 77), ("DRWCelerite", 4096 + 200)])
+def test_remainder_of_a_multi_pass_batch_on_the_second_stream(ctx, basis, B):
+    """A batch that is not a whole number of passes of the throughput kernel (SHO-20: 4096 draws per pass, DRWCelerite-20: 2048): the
+    remainder — or what exceeds half a pass — runs on the windowed kernel on the context's second stream, concurrently (capi.hip
+    split_dispatch).  Same values as the single launch (another kernel family: to rounding) and as the oracle; option no_split."""
+    rng = np.random.default_rng(B)
+    N, J = 150, 20
+    t = np.cumsum(rng.uniform(0.05, 2.0, N)); y = rng.standard_normal(N); yerr = rng.uniform(0.01, 0.05, N)
+    th = O.synthetic_theta(B, t, y, seed=B)
+    A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, J, basis)
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan + block (remainder)"
+    try:
+        ctx.set_option("no_split", True)
+        one, st1 = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan"
+    finally:
+        ctx.set_option("no_split", False)
+    ok = (st == 0) & (st1 == 0)
+    assert np.array_equal(st == 0, st1 == 0) and ok.sum() > B // 2
+    # Two kernel families on PRIOR draws.  Where a sampler lives (here: within 1e3 of the best draw) they agree to 1e-10; in the far tail
+    # (nu -> 0.04: measurement variance 1e-5 of the signal variance, |log L| ~ 2e5) the windowed form's 16-step elimination works on a
+    # 16 x 16 block whose entries carry m m' / D with D ~ 1e-5 and loses up to 1e-7 relative (0.03 in log L at -2e5; the scan holds 2e-10)
+    kept = ok & (one > one[ok].max() - 1e3)
+    assert kept.sum() > B // 3 and relerr(got[kept], one[kept]) < 5e-10
+    assert relerr(got[ok], one[ok]) < 1e-6
+    idx = np.concatenate([np.arange(0, B, 97), np.arange(B - 20, B)])          # incl. the tail that went to the second stream
+    ref, rst = O.logl_batch(A[idx], Bc[idx], C, Dd, t, y, yerr ** 2, mu[idx], nu[idx], nthreads=8, return_status=True)
+    k = (rst == 0) & ok[idx]
+    assert relerr(got[idx][k & kept[idx]], ref[k & kept[idx]]) < 1e-9 and relerr(got[idx][k], ref[k]) < 1e-6
+    # per-draw series ride along (the windowed kernel stages them through LDS)
+    Bs = 2048 + 64 if basis == "DRWCelerite" else 4096 + 64
+    Y = rng.standard_normal((Bs, N)); S2 = rng.uniform(0.01, 0.1, (Bs, N))
+    sl = slice(0, Bs)
+    if Bs <= B:
+        g2 = ds.logl_batch(A[sl], Bc[sl], C, Dd, mu=mu[sl], nu=nu[sl], Y=Y, S2=S2)
+        tail = np.arange(Bs - 8, Bs)
+        r2 = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in tail])
+        fin = np.isfinite(r2) & np.isfinite(g2[tail])
+        assert relerr(g2[tail][fin], r2[fin]) < 1e-10
+
+
 @pytest.mark.parametrize("J,nreal,N,B", [(40, 0, 61, 300), (40, 0, 90, 5), (33, 0, 130, 290), (36, 0, 47, 301), (39, 0, 1, 280), (39, 0, 2, 280),
                                           (40, 0, 3, 7), (40, 0, 4, 7), (40, 0, 5, 7), (40, 0, 6, 7), (40, 0, 7, 7), (40, 0, 8, 7), (40, 0, 9, 7),
                                           (45, 20, 75, 300), (50, 22, 64, 258), (42, 4, 333, 259), (44, 12, 51, 3)])
