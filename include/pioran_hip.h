@@ -52,7 +52,7 @@ typedef struct pioran_ds pioran_ds;   /* a time series resident in HBM + its cac
 const char* pioran_strerror(int code);
 const char* pioran_last_hip_error(const pioran_ctx* ctx);
 /* ABI version of this header (bumped on any signature change). */
-int pioran_abi_version(void);   /* currently 6 */
+int pioran_abi_version(void);   /* currently 7 */
 
 /* ---- context ------------------------------------------------------------------------------- */
 /* Creates a context on GPU `device` with its own non-blocking stream. */
@@ -224,6 +224,10 @@ int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, c
  * (latency layout), "scan" (throughput layouts), "fallback", "block (windowed gradient[, per-draw tables])",
  * "wide (step-by-step gradient)" (diagnostics). */
 const char* pioran_celerite_config_name(int64_t R);
+/* Diagnostics: the FP64 FMA rate (TFLOP/s) the device sustains right now with `waves_per_simd` (1 .. 8) wavefronts on every SIMD — about
+ * `ms` milliseconds of a pure stream of independent v_fma_f64, event-timed on the context's stream.  The measured ceiling of any FP64
+ * vector kernel on this box at that occupancy (the 78.6 TFLOP/s vendor figure assumes one FMA per SIMD every 4 cycles at 2.4 GHz). */
+int pioran_ctx_fp64_probe(pioran_ctx* ctx, int waves_per_simd, double ms, double* tflops);
 
 /* ---- in-process farm over several GPUs ---------------------------------------------------------------------------
  * For hosts without a process-per-GPU launcher (a single Julia process driving the 8 GPUs of a node): one context and

@@ -449,7 +449,33 @@ const char* pioran_strerror(int code)
 
 const char* pioran_last_hip_error(const pioran_ctx* ctx) { return ctx ? ctx->last_err.c_str() : ""; }
 
-int pioran_abi_version(void) { return 6; }
+int pioran_abi_version(void) { return 7; }
+
+// The FP64 FMA rate the device sustains now, at `waves_per_simd` (1 .. 8) wavefronts per SIMD on every SIMD: ~`ms` milliseconds of a pure
+// v_fma_f64 stream, event-timed on the context's stream (table.hip).  Diagnostics: bench.py's frac_of_measured_fma_ceiling.
+int pioran_ctx_fp64_probe(pioran_ctx* ctx, int waves_per_simd, double ms, double* tflops)
+{
+    if (!ctx || !tflops || waves_per_simd < 1 || waves_per_simd > 8 || !(ms > 0.0) || ms > 1000.0) return PIORAN_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int ncu = 0;
+    HIPCHK(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    const int blocks = ncu * waves_per_simd;
+    int rc = ensure(ctx, ctx->bscratch, (size_t)blocks * 256 * sizeof(double));
+    if (rc) return rc;
+    // 64 FMAs per trip at ~4.6 issue cycles each and `waves_per_simd` wavefronts sharing the SIMD, ~2 GHz
+    int iters = (int)(ms * 1e-3 * 2.0e9 / (64.0 * 4.6 * waves_per_simd));
+    if (iters < 64) iters = 64;
+    double flop = 0.0;
+    if ((rc = pioran_launch_fma_stream(blocks, 64, (double*)ctx->bscratch.p, nullptr, ctx->stream))) return rc;   // warm
+    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if ((rc = pioran_launch_fma_stream(blocks, iters, (double*)ctx->bscratch.p, &flop, ctx->stream))) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
+    float t = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
+    *tflops = t > 0.f ? flop / (t * 1e-3) / 1e12 : 0.0;
+    return PIORAN_OK;
+}
 
 int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
 {

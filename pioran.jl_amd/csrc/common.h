@@ -183,6 +183,8 @@ int pioran_launch_approx(int64_t B, int model, int P, int J, int basis, int inte
                          const double* sp, const double* LU, const int32_t* piv, const double* theta, const double* norm,
                          int n_qpo, const double* qpo /*[B][n_qpo][3]: S0, f0, Q*/, double* A, double* Bc,
                          double* Cq /*[B][Jt]: per-draw c of the feature terms*/, double* Dq, hipStream_t stream);
+// table.hip (diagnostics)
+int pioran_launch_fma_stream(int blocks, int iters, double* scratch, double* flop, hipStream_t stream);
 // dense.hip
 // doubles behind a slab: 1024 (the four 16 x 16 inverses of the current diagonal block) + 4 x 4096 (dense_step_kernel's tile snapshots)
 #define PIORAN_DENSE_WS (1024 + 4 * 4096)

@@ -169,3 +169,35 @@ int pioran_launch_table_batch(int64_t N, int32_t R, int32_t J, int64_t nb, const
                        (int64_t)J, tab_draw_stride);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
+
+
+// ---- diagnostics: the FP64 FMA rate this device sustains right now -----------------------------------------------------------------
+// A pure stream of independent v_fma_f64 (eight accumulators per lane, 64 instructions per loop trip) on every SIMD of the chip with
+// `waves_per_simd` wavefronts each: what ANY FP64 vector kernel can reach on this box at this occupancy — the vendor peak (78.6 TFLOP/s =
+// one DP FMA per SIMD every 4 cycles at 2.4 GHz) is not reachable by construction (4.3 .. 5.4 issue cycles per instruction, 1.9 .. 2.2 GHz
+// under chip-wide FP64 load: tools/valu_probe.hip).  bench.py quotes the scan kernels against it beside the roofline fraction.
+namespace {
+__global__ void __launch_bounds__(256) fma_stream_kernel(double* out, int iters)
+{
+    double a0 = threadIdx.x * 1e-9 + 1.0, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const double b = 1.0000001, c = 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#define PIORAN_F8 "v_fma_f64 %0, %0, %8, %9\n\tv_fma_f64 %1, %1, %8, %9\n\tv_fma_f64 %2, %2, %8, %9\n\tv_fma_f64 %3, %3, %8, %9\n\t" \
+                  "v_fma_f64 %4, %4, %8, %9\n\tv_fma_f64 %5, %5, %8, %9\n\tv_fma_f64 %6, %6, %8, %9\n\tv_fma_f64 %7, %7, %8, %9\n\t"
+        asm volatile(PIORAN_F8 PIORAN_F8 PIORAN_F8 PIORAN_F8 PIORAN_F8 PIORAN_F8 PIORAN_F8 PIORAN_F8
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(b), "v"(c));
+#undef PIORAN_F8
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+}  // namespace
+
+// scratch: blocks * 256 doubles; returns the kernel's flop count through *flop (the caller times the stream)
+int pioran_launch_fma_stream(int blocks, int iters, double* scratch, double* flop, hipStream_t stream)
+{
+    if (blocks < 1 || iters < 1 || !scratch) return PIORAN_ERR_ARG;
+    hipLaunchKernelGGL(fma_stream_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, scratch, iters);
+    if (flop) *flop = 2.0 * 64.0 * 256.0 * (double)blocks * (double)iters;
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}

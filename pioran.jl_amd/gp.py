@@ -75,6 +75,12 @@ class Context:
     def event_record(self, slot: int):
         _lib.check(_lib.lib().pioran_ctx_event_record(self._h, slot), self._h)
 
+    def fp64_probe(self, waves_per_simd: int = 2, ms: float = 10.0) -> float:
+        """The FP64 FMA rate (TFLOP/s) this device sustains now at `waves_per_simd` wavefronts per SIMD (pioran_ctx_fp64_probe)."""
+        out = ctypes.c_double()
+        _lib.check(_lib.lib().pioran_ctx_fp64_probe(self._h, int(waves_per_simd), float(ms), ctypes.byref(out)), self._h)
+        return out.value
+
     def event_elapsed_ms(self, a: int, b: int) -> float:
         ms = ctypes.c_float()
         _lib.check(_lib.lib().pioran_ctx_event_elapsed_ms(self._h, a, b, ctypes.byref(ms)), self._h)

@@ -16,7 +16,7 @@ import Pioran: log_likelihood, SumOfCelerite, SemiSeparable, CARMA, celerite_coe
 import ChainRulesCore
 
 const LIB = get(ENV, "PIORAN_HIP_LIB", "libpioran_hip")
-const ABI_VERSION = 6
+const ABI_VERSION = 7
 
 # PIORAN_BACKEND=julia keeps every call on Pioran's own Julia code (the escape hatch a deployment wants when no GPU is
 # visible or for A/B comparisons); anything else (default "hip") routes Float64 calls to libpioran_hip.so.

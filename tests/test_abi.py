@@ -34,12 +34,13 @@ def test_library_is_gfx950_code_object():
 
 def test_version_and_strerror():
     L = pj._lib.lib()
-    assert L.pioran_abi_version() == 6
+    assert L.pioran_abi_version() == 7
     assert L.pioran_strerror(0) == b"ok"
     assert L.pioran_strerror(-4) == b"unsupported size"
     assert L.pioran_celerite_config_name(40) == b"rpl3_cbr2_nsrc7_p"   # column-paired variant for the standard row map
     assert L.pioran_celerite_config_name(60).startswith(b"rpl4_cbr4")
-    assert L.pioran_celerite_config_name(128) == b"fallback"
+    assert L.pioran_celerite_config_name(128) == b"wide" and L.pioran_celerite_config_name(80) == b"wide"   # lean latency kernel, 80 .. 143 rows
+    assert L.pioran_celerite_config_name(144) == b"fallback"
 
 
 def test_argument_validation_without_gpu():

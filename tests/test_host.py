@@ -247,4 +247,4 @@ def test_julia_shim_matches_header():
     for must in ("pioran_abi_version", "pioran_celerite_logl", "pioran_celerite_logl_batch", "pioran_celerite_logl_grad",
                  "pioran_logpdf_batch_theta", "pioran_dense_nll", "pioran_celerite_predict", "pioran_farm_logl_batch"):
         assert must in seen, must
-    assert "pioran_abi_version" in jl and "ABI_VERSION = 6" in jl
+    assert "pioran_abi_version" in jl and "ABI_VERSION = 7" in jl
