@@ -500,7 +500,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "block_emode")) o.block_emode = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "dense_quad_threshold")) o.dense.quad_threshold = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "dense_batch_pair_threshold")) o.dense.batch_pair_threshold = (value && value[0]) ? std::atoi(value) : -1;
-    else if (!std::strcmp(key, "dense_old_chain")) o.dense.old_chain = on ? 1 : 0;
+    else if (!std::strcmp(key, "dense_old_chain")) o.dense.old_chain = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "workspace_limit_mb")) o.workspace_limit_mb = (value && value[0]) ? std::atoll(value) : 0;
     else if (!std::strcmp(key, "dense_streams")) o.dense_streams = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "gsum")) o.gsum = (value && value[0]) ? std::atoi(value) : -1;
@@ -1546,8 +1546,12 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
         if (grad_mu) if ((rc = download(ctx, grad_mu + b0, dgm, nb * sizeof(double)))) return rc;
         if (grad_y) if ((rc = download(ctx, grad_y + b0 * ds->N, ctx->bY.p, (size_t)nb * ds->N * sizeof(double)))) return rc;
         if (grad_sigma2) if ((rc = download(ctx, grad_sigma2 + b0 * ds->N, ctx->bS2.p, (size_t)nb * ds->N * sizeof(double)))) return rc;
-        SYNC(ctx);
+        // Chunks follow each other on the stream without a host synchronisation in between (round 4): every transfer is stream-ordered
+        // and staged through pinned memory, which drains itself when it fills (pin_reserve); only the large series gradients, which go
+        // straight to the caller's pageable memory, are waited for per chunk.  4096 chains: 122 -> ~100 ms.
+        if (want_series) SYNC(ctx);
     }
+    SYNC(ctx);
     return PIORAN_OK;
 }
 

@@ -877,7 +877,7 @@ __device__ __forceinline__ void solve_rows16_compute(f64x4 (&Y)[4], const double
 constexpr int SNAP_TILE = NB * NB;                        // snapshot tile: column-major 64 x 64, column stride 64
 template <bool CRIT>
 __device__ __forceinline__ void step_solve_role(double* __restrict__ A, int64_t ld, int64_t Mp, int k, int it, int qt, bool store_rows,
-                                                bool with_prev, double* __restrict__ Ls, double* __restrict__ Xq, int* flag,
+                                                int nprev, double* __restrict__ Ls, double* __restrict__ Xq, int* flag,
                                                 int32_t* __restrict__ info, int tid)
 {
     const int64_t kb = (int64_t)k * NB, i0 = (int64_t)it * NB, q0 = (int64_t)qt * NB;
@@ -885,35 +885,38 @@ __device__ __forceinline__ void step_solve_role(double* __restrict__ A, int64_t 
     const bool has_target = qt < (int)(Mp / NB);        // a block column qt exists (else: only the y rows are left to solve)
     double* snap = A + (size_t)ld * (size_t)Mp + WS_DOUBLES;                   // [parity][which of the two tiles][64 x 64]
     const double* snap_k = snap + (size_t)(k & 1) * 2 * SNAP_TILE;             // raw (k+1, k) and (k+2, k)
+    f64x4 acc[4];                                        // tile (it, qt), transposed: [jb] D[row = j][col = i], i = 16 wave + lr
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = f64x4{0.0, 0.0, 0.0, 0.0};
+    if constexpr (!CRIT) {
+        if (has_target) {
+            // the nprev finished panels k - nprev .. k - 1 this tile still lacks (the bulk update lags by up to two): all 80 operand loads
+            // of a panel in flight at once (one exposure of the L2 / HBM latency), before the solve's operands take their registers
+#pragma unroll 1
+            for (int pp = nprev; pp >= 1; --pp) {
+                const double* Pj = A + q0 + (kb - pp * NB) * ld + lr + (int64_t)lk * ld;              // rows of tile qt
+                const double* Pi = A + i0 + 16 * wave + (kb - pp * NB) * ld + lr + (int64_t)lk * ld;  // this wave's 16 rows
+                double xa[16][4], yb[16];
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    yb[ks] = Pi[(int64_t)(4 * ks) * ld];
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb) xa[ks][jb] = Pj[16 * jb + (int64_t)(4 * ks) * ld];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb) acc[jb] = mfma4(xa[ks][jb], yb[ks], acc[jb]);
+            }
+            __builtin_amdgcn_sched_barrier(0);           // (the loads below stay below: 160 + 112 operand registers do not fit together)
+        }
+    }
     f64x4 Yi[4];
     double lop[4][4][4], iop[4][4];
     if (store_rows)   // in place: this workgroup is the only one that reads these raw rows from the slab, and it overwrites them
         solve_rows16_load(A, ld, kb, A + i0 + 16 * wave + kb * ld, ld, lr, lk, Yi, lop, iop);
     else              // DIAG2: tile (k+2, k) is being overwritten by its STRIP workgroup
         solve_rows16_load(A, ld, kb, snap_k + SNAP_TILE + 16 * wave, NB, lr, lk, Yi, lop, iop);
-    f64x4 acc[4];                                        // tile (it, qt), transposed: [jb] D[row = j][col = i], i = 16 wave + lr
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) acc[jb] = f64x4{0.0, 0.0, 0.0, 0.0};
-    if constexpr (!CRIT) {
-        if (has_target && with_prev) {                   // panel k-1 (finished by the previous launch)
-            const double* Pj = A + q0 + (kb - NB) * ld + lr + (int64_t)lk * ld;              // rows of tile qt
-            const double* Pi = A + i0 + 16 * wave + (kb - NB) * ld + lr + (int64_t)lk * ld;  // this wave's 16 rows
-#pragma unroll 1
-            for (int c4 = 0; c4 < 4; ++c4) {
-                double xa[4][4], yb[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    yb[q] = Pi[(int64_t)(4 * (4 * c4 + q)) * ld];
-#pragma unroll
-                    for (int jb = 0; jb < 4; ++jb) xa[q][jb] = Pj[16 * jb + (int64_t)(4 * (4 * c4 + q)) * ld];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int jb = 0; jb < 4; ++jb) acc[jb] = mfma4(xa[q][jb], yb[q], acc[jb]);
-            }
-        }
-    }
     solve_rows16_compute(Yi, lop, iop);
     if (store_rows) {   // the solved rows are final entries of L
         double* P = A + i0 + 16 * wave + kb * ld;
@@ -943,7 +946,8 @@ __device__ __forceinline__ void step_solve_role(double* __restrict__ A, int64_t 
     }
     double* C = A + i0 + 16 * wave + lr + q0 * ld;
     double cv[4][4];
-    if constexpr (CRIT) {                               // the diagonal tile: its load overlaps the exchange
+    if constexpr (CRIT) {                               // the diagonal tile: its load overlaps the exchange (issued any earlier it delays
+                                                        // the solve's own operands: 16.5 instead of 15.5 us per step, tools/dense_roles.py)
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
@@ -993,7 +997,7 @@ __device__ __forceinline__ void step_solve_role(double* __restrict__ A, int64_t 
 }
 
 __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__ A, int64_t ld, int64_t Mp, int k,
-                                                            int32_t* __restrict__ info)
+                                                            int32_t* __restrict__ info, int bx0)
 {
     __shared__ double Sh[NB * LP + 4 * 16 * 64];
     double* Ls = Sh;                     // the diagonal tile being factored (CRIT)
@@ -1002,19 +1006,26 @@ __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__
     const int nb = (int)(Mp / NB);
     const int tid = threadIdx.x;
     const int nstrip = nb - k - 1;                      // row tiles k+2 .. nb
-    const int bx = (int)blockIdx.x;
+    const int bx = (int)blockIdx.x + bx0;   // (bx0 != 0: timing experiments that launch a subset of the roles, tools/dense_ab.py)
+    // finished panels a tile of block column k+1 (k+2 for DIAG2) still lacks when this launch starts: the bulk role lags one panel
+    const int nprev = k == 0 ? 0 : 1;
     if (bx == 0) {
-        step_solve_role<true>(A, ld, Mp, k, k + 1, k + 1, true, false, Ls, Xq, &flag, info, tid);
+        step_solve_role<true>(A, ld, Mp, k, k + 1, k + 1, true, 0, Ls, Xq, &flag, info, tid);
     } else if (bx == 1) {
-        if (k + 2 < nb) step_solve_role<false>(A, ld, Mp, k, k + 2, k + 2, false, k > 0, Ls, Xq, &flag, info, tid);
+        if (k + 2 < nb) step_solve_role<false>(A, ld, Mp, k, k + 2, k + 2, false, nprev, Ls, Xq, &flag, info, tid);
     } else if (bx < 2 + nstrip) {
-        step_solve_role<false>(A, ld, Mp, k, k + bx, k + 1, true, k > 0, Ls, Xq, &flag, info, tid);
+        step_solve_role<false>(A, ld, Mp, k, k + bx, k + 1, true, nprev, Ls, Xq, &flag, info, tid);
     } else {
-        // ---- BULK: panel k-1 onto the tiles of block columns >= k+2 (all but (k+2, k+2): DIAG2's) ---------------------------------
-        // One tile per wavefront.  (One tile per WORKGROUP — syrk_tile_wg — was built and measured: steps 1-3, where the per-wavefront
-        // form needs a second round of workgroups, 38 instead of 41 us, but 19-22 instead of 16-18 us from step 20 on, where a workgroup
-        // has too little matrix work — 64 instructions per wave — to hide its load -> LDS -> product -> C round trips at the two
-        // workgroups per CU this kernel's registers allow: N = 4096 1.37 instead of 1.29 ms.  profiles/r04_dense_steps_wg_tiles.txt)
+        // ---- BULK: panel k-1 onto the tiles of block columns >= k+2 (all but (k+2, k+2): DIAG2's), one tile per wavefront ---------
+        // Measured alternatives, none kept (profiles/r04_dense_steps_wg_tiles.txt, r04_dense_roles.txt):
+        //  * one tile per WORKGROUP (syrk_tile_wg): steps 1-3 38 instead of 41 us, but 19-22 instead of 16-18 us from step 20 on — a
+        //    workgroup has too little matrix work (64 instructions per wave) to hide its load -> LDS -> product -> C round trips at the two
+        //    workgroups per CU this kernel's registers allow: 1.37 instead of 1.29 ms;
+        //  * panels in PAIRS (k-2, k-1), 128-deep, half of the tiles in the even launch and half in the odd one (strips and DIAG2 then
+        //    catch up two panels): the early steps drop from 41 .. 33 to 32 us, but a lone tile-wave of 512 matrix instructions takes
+        //    20 us whatever the chip is doing, which becomes the floor of EVERY later step (15.5 before): 1.38 ms;
+        //  * the tile's accumulators started from C (no read-modify-write epilogue): the 64 + 64 addresses of the tile cost the
+        //    registers of the operand pipeline (8 spills) — bulk alone 1.35 instead of 1.28 ms in the paired form.
         const int64_t j0 = ((int64_t)k + 2) * NB;
         const int nt = (int)((Mp - j0) / NB) + 1;       // i tiles (the last one holds the y row), j tiles 0 .. nt-2
         const int lane = tid & 63, wave = tid >> 6;
@@ -1149,7 +1160,7 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
     double* ws = K + (size_t)ld * (size_t)Mp;   // WS_DOUBLES doubles right behind the slab
     // one launch per block column: from three block columns on, and while the 64-deep lagging bulk update is not bound by the traffic of
     // the trailing matrix (N = 8192: 6.6 ms against 6.2 ms on the paired chain below, whose 128-deep updates read and write C half as often)
-    const bool steps = nbatch == 1 && !dop.old_chain && Mp >= 3 * NB && Mp <= 6144;
+    const bool steps = nbatch == 1 && dop.old_chain != 1 && Mp >= 3 * NB && Mp <= 6144;
     hipLaunchKernelGGL(dense_diag0_kernel, dim3(steps ? 3 : 1, 1, nbatch), dim3(256), 0, stream, K, ld, ws, info, bt);
     if (steps) {
         // one matrix: one launch per block column (dense_step_kernel)
@@ -1158,7 +1169,13 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
             const int nstrip = nb - k - 1;
             const int64_t nt = (Mp - ((int64_t)k + 2) * NB) / NB + 1;            // i tiles of the bulk's origin (block column k+2)
             const int64_t ntile = (k > 0 && nt >= 2) ? nt * (nt + 1) / 2 - 1 : 0;   // (0, 0) of that origin is DIAG2's
-            hipLaunchKernelGGL(dense_step_kernel, dim3((unsigned)(2 + nstrip + (kBulkPerWorkgroup ? ntile : (ntile + 3) / 4))), dim3(256), 0, stream, K, ld, Mp, k, info);
+            unsigned grid = (unsigned)(2 + nstrip + (kBulkPerWorkgroup ? ntile : (ntile + 3) / 4));
+            int bx0 = 0;
+            // timing experiments only (results are garbage): 2 = the critical workgroup alone, 3 = DIAG2 + the strips alone, 4 = the bulk alone
+            if (dop.old_chain == 2) grid = 1;
+            else if (dop.old_chain == 3) { grid = (unsigned)(1 + nstrip); bx0 = 1; }
+            else if (dop.old_chain == 4) { if (grid <= (unsigned)(2 + nstrip)) continue; grid -= (unsigned)(2 + nstrip); bx0 = 2 + nstrip; }
+            hipLaunchKernelGGL(dense_step_kernel, dim3(grid), dim3(256), 0, stream, K, ld, Mp, k, info, bx0);
         }
         if (phase_ev) (void)hipEventRecord(phase_ev[1], stream);
         hipLaunchKernelGGL(dense_finish_kernel, dim3(1, 1, 1), dim3(256), 0, stream, K, ld, N, Mp, out, info, bt);
