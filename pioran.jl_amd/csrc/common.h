@@ -20,7 +20,9 @@
 struct DenseOptions {
     int quad_threshold = -1;        // trailing tiles per side above which a batched launch takes its steps in fours
     int batch_pair_threshold = -1;  // ... in pairs
-    int old_chain = 0;              // 1: one matrix on the panel / update chain of rounds 1-3 (A/B and cross-check of dense_step_kernel)
+    int old_chain = 0;              // 1: one matrix on the panel / update chain of rounds 1-3 (A/B and cross-check of dense_step_kernel);
+                                    // 2 / 3 / 4: timing experiments of dense_step_kernel's roles (tools/dense_roles.py)
+    int no_pairs = 0;               // 1: dense_step_kernel's bulk one panel per launch from the start (no paired phase)
 };
 struct ScanOptions {
     char scan_config[48];   // "" automatic; "wide" / "block": that small-batch kernel for any batch size; else a throughput configuration's name

@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(256) dense_panel_kernel(double* __restrict__ A
 // col0_only (KP = 1): only block column 0 of the trailing matrix (the next panel) and its diagonal tile — the narrow
 // update between the two panel solves of a pair.
 // One 64 x 64 tile (ti, tj), ti >= tj, of the trailing matrix with origin j0:  C -= P_i P_j',  P = A[:, pc : pc + 64 KP]  (one wavefront).
-template <int KP>
+template <int KP, int NBUF = 3>   // NBUF: k-steps of operand fragments in flight
 __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int64_t ld, int64_t pc, int64_t j0, int ti, int tj, int lr, int lk)
 {
     // Row permutation inside the tile: MFMA strip s (s = 0..3) takes the rows 32 (s >> 1) + 2 r + (s & 1), r = 0..15,
@@ -649,7 +649,7 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int64_t ld, in
     // loads of k-step ks+2 are issued before the 16 MFMAs (1024 issue cycles) of k-step ks.  With the 128
     // accumulator registers this stays under 256 registers per lane, so two wavefronts share a SIMD and the
     // second one hides whatever latency is left (launch bounds below).
-    double xa[3][4], yb[3][4];   // [buffer][strip]
+    double xa[NBUF][4], yb[NBUF][4];   // [buffer][strip]
     auto load_kstep = [&](int ks, int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -660,16 +660,16 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int64_t ld, in
             yb[buf][2 * h] = y.x; yb[buf][2 * h + 1] = y.y;
         }
     };
-    load_kstep(0, 0);
-    load_kstep(1, 1);
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) load_kstep(b, b);
 #pragma unroll
     for (int ks = 0; ks < 16 * KP; ++ks) {
-        if (ks + 2 < 16 * KP) load_kstep(ks + 2, (ks + 2) % 3);
+        if (ks + NBUF - 1 < 16 * KP) load_kstep(ks + NBUF - 1, (ks + NBUF - 1) % NBUF);
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib)
-                acc[jb][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks % 3][jb], yb[ks % 3][ib], acc[jb][ib], 0, 0, 0);
+                acc[jb][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks % NBUF][jb], yb[ks % NBUF][ib], acc[jb][ib], 0, 0, 0);
     }
 
     // C -= acc.  D row (l>>4) + 4g of strip jb is the j-row 32 (jb >> 1) + 2 (lk + 4g) + (jb & 1); D column l&15 of strip
@@ -777,7 +777,6 @@ __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__
 // launch's work is balanced per CU, not per SIMD (a lone tile-wave leaves its SIMD's matrix pipe idle half of the time, two on a SIMD
 // take 25 us together).
 constexpr int BP = 80;
-constexpr bool kBulkPerWorkgroup = false;   // dense_step_kernel's bulk role: one tile per workgroup (measured slower, see there)
 __device__ __forceinline__ void syrk_tile_wg(double* __restrict__ A, int64_t ld, int64_t pc, int64_t j0, int ti, int tj,
                                              double* __restrict__ Bs, int tid)
 {
@@ -996,8 +995,15 @@ __device__ __forceinline__ void step_solve_role(double* __restrict__ A, int64_t 
     }
 }
 
+// What the bulk role of one launch does: panels pcb .. pcb + kp - 1 (block columns; all final) onto the tiles (ti >= tj) of the trailing matrix
+// whose origin is block column org, tiles in COLUMN order (id -> (tj, ti)), ids id0 .. id0 + cnt - 1 (id 0 = tile (0, 0): DIAG2's, never listed).
+constexpr int kStepBulkBuffers = 6;   // operand k-steps in flight in dense_step_kernel's bulk tiles (mostly one wavefront per SIMD there)
+struct StepBulk {
+    int pcb, kp, org, id0, cnt;
+};
+template <int KP>   // depth of the bulk role's update in panels (one instantiation per depth: both tile bodies in one kernel cost 14 spilled registers)
 __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__ A, int64_t ld, int64_t Mp, int k,
-                                                            int32_t* __restrict__ info, int bx0)
+                                                            int32_t* __restrict__ info, int bx0, int nprev, StepBulk bulk)
 {
     __shared__ double Sh[NB * LP + 4 * 16 * 64];
     double* Ls = Sh;                     // the diagonal tile being factored (CRIT)
@@ -1006,9 +1012,9 @@ __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__
     const int nb = (int)(Mp / NB);
     const int tid = threadIdx.x;
     const int nstrip = nb - k - 1;                      // row tiles k+2 .. nb
-    const int bx = (int)blockIdx.x + bx0;   // (bx0 != 0: timing experiments that launch a subset of the roles, tools/dense_ab.py)
-    // finished panels a tile of block column k+1 (k+2 for DIAG2) still lacks when this launch starts: the bulk role lags one panel
-    const int nprev = k == 0 ? 0 : 1;
+    const int bx = (int)blockIdx.x + bx0;   // (bx0 != 0: timing experiments that launch a subset of the roles, tools/dense_roles.py)
+    // nprev: finished panels a tile of block column k+1 (k+2 for DIAG2) still lacks when this launch starts (the bulk role lags: 1 in the
+    // one-panel schedule, 1 or 2 in the paired one)
     if (bx == 0) {
         step_solve_role<true>(A, ld, Mp, k, k + 1, k + 1, true, 0, Ls, Xq, &flag, info, tid);
     } else if (bx == 1) {
@@ -1016,29 +1022,20 @@ __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__
     } else if (bx < 2 + nstrip) {
         step_solve_role<false>(A, ld, Mp, k, k + bx, k + 1, true, nprev, Ls, Xq, &flag, info, tid);
     } else {
-        // ---- BULK: panel k-1 onto the tiles of block columns >= k+2 (all but (k+2, k+2): DIAG2's), one tile per wavefront ---------
-        // Measured alternatives, none kept (profiles/r04_dense_steps_wg_tiles.txt, r04_dense_roles.txt):
-        //  * one tile per WORKGROUP (syrk_tile_wg): steps 1-3 38 instead of 41 us, but 19-22 instead of 16-18 us from step 20 on — a
-        //    workgroup has too little matrix work (64 instructions per wave) to hide its load -> LDS -> product -> C round trips at the two
-        //    workgroups per CU this kernel's registers allow: 1.37 instead of 1.29 ms;
-        //  * panels in PAIRS (k-2, k-1), 128-deep, half of the tiles in the even launch and half in the odd one (strips and DIAG2 then
-        //    catch up two panels): the early steps drop from 41 .. 33 to 32 us, but a lone tile-wave of 512 matrix instructions takes
-        //    20 us whatever the chip is doing, which becomes the floor of EVERY later step (15.5 before): 1.38 ms;
-        //  * the tile's accumulators started from C (no read-modify-write epilogue): the 64 + 64 addresses of the tile cost the
-        //    registers of the operand pipeline (8 spills) — bulk alone 1.35 instead of 1.28 ms in the paired form.
-        const int64_t j0 = ((int64_t)k + 2) * NB;
+        // ---- BULK: one tile per wavefront (schedule: dense_nll_impl) -----------------------------------------------------------------------
+        // Measured alternatives to this role, none kept (profiles/r04_dense_steps_wg_tiles.txt, r04_dense_roles.txt): one tile per WORKGROUP
+        // (syrk_tile_wg: 1.37 instead of 1.29 ms — a workgroup has too little matrix work to hide its load -> LDS -> product -> C round trips
+        // at two workgroups per CU); the tile's accumulators started from C (no read-modify-write epilogue: the tile's 128 addresses cost the
+        // registers of the operand pipeline, 8 spills, bulk alone 5 % slower).
+        const int64_t j0 = (int64_t)bulk.org * NB;
         const int nt = (int)((Mp - j0) / NB) + 1;       // i tiles (the last one holds the y row), j tiles 0 .. nt-2
         const int lane = tid & 63, wave = tid >> 6;
-        const int bid = (bx - 2 - nstrip) * (kBulkPerWorkgroup ? 1 : 4) + (kBulkPerWorkgroup ? 0 : wave) + 1;
-        int ti = (int)((sqrt(8.0 * bid + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
-        while ((int64_t)ti * (ti + 1) / 2 > bid) --ti;
-        const int tj = bid - (int)((int64_t)ti * (ti + 1) / 2);
-        if (ti >= nt || tj >= nt - 1) return;           // wave-uniform (workgroup-uniform with one tile per workgroup)
-        if constexpr (kBulkPerWorkgroup)
-            syrk_tile_wg(A, ld, ((int64_t)k - 1) * NB, j0, ti, tj, Sh, tid);
-        else
-            syrk_tile<1>(A, ld, ((int64_t)k - 1) * NB, j0, ti, tj, lane & 15, lane >> 4);
+        const int w = (bx - 2 - nstrip) * 4 + wave;
+        if (w >= bulk.cnt) return;                      // wave-uniform
+        int id = bulk.id0 + w, tj = 0;
+        while (id >= nt - tj) { id -= nt - tj; ++tj; }  // column tj holds rows tj .. nt-1
+        const int ti = tj + id;
+        syrk_tile<KP, kStepBulkBuffers>(A, ld, (int64_t)bulk.pcb * NB, j0, ti, tj, lane & 15, lane >> 4);
     }
 }
 
@@ -1163,19 +1160,53 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
     const bool steps = nbatch == 1 && dop.old_chain != 1 && Mp >= 3 * NB && Mp <= 6144;
     hipLaunchKernelGGL(dense_diag0_kernel, dim3(steps ? 3 : 1, 1, nbatch), dim3(256), 0, stream, K, ld, ws, info, bt);
     if (steps) {
-        // one matrix: one launch per block column (dense_step_kernel)
+        // one matrix: one launch per block column (dense_step_kernel).  Schedule of the lagging bulk update:
+        //  * while the trailing matrix is large (more than kPairTiles tiles) the launch is bound by the traffic of the bulk tiles (6.8 TB/s at
+        //    64-deep: 128 KB per tile and panel): panels go in PAIRS — launches 2m and 2m+1 share the 128-deep update B(2m) = panels (2m-2,
+        //    2m-1) onto block columns >= 2m+2, first half of its tiles (column order: block column 2m+2 and tile (2m+3, 2m+3) included, which
+        //    the odd launch's strips and DIAG2 read) in the even launch, the rest in the odd one; strips and DIAG2 catch up two panels / one;
+        //  * from the switch launch ks (even) on, one panel per launch, 64-deep, lagging one: a lone 128-deep tile-wave (512 matrix instructions)
+        //    takes 20 us whatever the chip is doing, which would be the floor of every later step (the chain is 15); the switch launch itself
+        //    carries the whole of B(ks).
+        // tools/dense_ab.py, profiles/r04_dense_roles.txt: pairs only 1.38 ms, one panel per launch only 1.29 ms at N = 4096.
         const int nb = (int)(Mp / NB);
+        auto tiles_of = [&](int org) -> int64_t {             // tiles (ti >= tj, tj <= nt-2) of the trailing matrix with origin `org`, incl. (0, 0)
+            const int64_t nt = (int64_t)(nb - org) + 1;
+            return nt >= 2 ? (nt - 1) * (nt + 2) / 2 : 0;
+        };
+        constexpr int64_t kPairTiles = 900;
+        int ks = 2;
+        if (!dop.no_pairs) while (ks + 2 < nb && tiles_of(ks + 2) > kPairTiles) ks += 2;
         for (int k = 0; k < nb; ++k) {
             const int nstrip = nb - k - 1;
-            const int64_t nt = (Mp - ((int64_t)k + 2) * NB) / NB + 1;            // i tiles of the bulk's origin (block column k+2)
-            const int64_t ntile = (k > 0 && nt >= 2) ? nt * (nt + 1) / 2 - 1 : 0;   // (0, 0) of that origin is DIAG2's
-            unsigned grid = (unsigned)(2 + nstrip + (kBulkPerWorkgroup ? ntile : (ntile + 3) / 4));
+            StepBulk bk{0, 1, 0, 0, 0};
+            int nprev;
+            if (k > ks) {                                     // one panel per launch
+                nprev = 1;
+                const int64_t tot = tiles_of(k + 2);
+                bk = StepBulk{k - 1, 1, k + 2, 1, (int)(tot > 1 ? tot - 1 : 0)};
+            } else {
+                nprev = k == 0 ? 0 : ((k & 1) ? 1 : 2);
+                const int ke = k & ~1;
+                const int64_t tot = ke >= 2 ? tiles_of(ke + 2) : 0;
+                if (tot > 1) {
+                    const int64_t nt = (int64_t)(nb - (ke + 2)) + 1;
+                    int64_t split = (tot + 1) / 2;
+                    const int64_t need = nt + (nt >= 3 ? 1 : 0);          // block column 0 of that origin and tile (1, 1)
+                    if (split < need) split = need < tot ? need : tot;
+                    if (k == ks) split = tot;                              // the switch launch takes all of B(ks)
+                    if (k & 1) bk = StepBulk{ke - 2, 2, ke + 2, (int)split, (int)(tot - split)};
+                    else bk = StepBulk{ke - 2, 2, ke + 2, 1, (int)(split - 1)};
+                }
+            }
+            unsigned grid = (unsigned)(2 + nstrip + (bk.cnt + 3) / 4);
             int bx0 = 0;
             // timing experiments only (results are garbage): 2 = the critical workgroup alone, 3 = DIAG2 + the strips alone, 4 = the bulk alone
             if (dop.old_chain == 2) grid = 1;
             else if (dop.old_chain == 3) { grid = (unsigned)(1 + nstrip); bx0 = 1; }
             else if (dop.old_chain == 4) { if (grid <= (unsigned)(2 + nstrip)) continue; grid -= (unsigned)(2 + nstrip); bx0 = 2 + nstrip; }
-            hipLaunchKernelGGL(dense_step_kernel, dim3(grid), dim3(256), 0, stream, K, ld, Mp, k, info, bx0);
+            if (bk.kp == 2) hipLaunchKernelGGL(dense_step_kernel<2>, dim3(grid), dim3(256), 0, stream, K, ld, Mp, k, info, bx0, nprev, bk);
+            else hipLaunchKernelGGL(dense_step_kernel<1>, dim3(grid), dim3(256), 0, stream, K, ld, Mp, k, info, bx0, nprev, bk);
         }
         if (phase_ev) (void)hipEventRecord(phase_ev[1], stream);
         hipLaunchKernelGGL(dense_finish_kernel, dim3(1, 1, 1), dim3(256), 0, stream, K, ld, N, Mp, out, info, bt);
