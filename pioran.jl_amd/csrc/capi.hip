@@ -502,6 +502,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "dense_batch_pair_threshold")) o.dense.batch_pair_threshold = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "dense_old_chain")) o.dense.old_chain = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "dense_no_pairs")) o.dense.no_pairs = on ? 1 : 0;
+    else if (!std::strcmp(key, "dense_no_halves")) o.dense.no_halves = on ? 1 : 0;
     else if (!std::strcmp(key, "workspace_limit_mb")) o.workspace_limit_mb = (value && value[0]) ? std::atoll(value) : 0;
     else if (!std::strcmp(key, "dense_streams")) o.dense_streams = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "gsum")) o.gsum = (value && value[0]) ? std::atoi(value) : -1;

@@ -22,6 +22,7 @@ struct DenseOptions {
     int batch_pair_threshold = -1;  // ... in pairs
     int old_chain = 0;              // 1: one matrix on the panel / update chain of rounds 1-3 (A/B and cross-check of dense_step_kernel);
                                     // 2 / 3 / 4: timing experiments of dense_step_kernel's roles (tools/dense_roles.py)
+    int no_halves = 0;              // 1: dense_step_kernel's bulk never splits a tile over two wavefronts
     int no_pairs = 0;               // 1: dense_step_kernel's bulk one panel per launch from the start (no paired phase)
 };
 struct ScanOptions {

@@ -696,6 +696,62 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int64_t ld, in
     }
 }
 
+// Half of such a tile — the j rows 32 h .. 32 h + 31 (MFMA strips 2h, 2h + 1) against all 64 i rows — per wavefront: half the matrix work
+// per work item (256 KP instructions) for the launches in which whole tiles would leave SIMDs idle and make the slowest wavefront the
+// launch's length (a lone 128-deep tile-wave takes 20 us; dense_step_kernel's bulk role).  The B operand is loaded by both halves.
+template <int KP, int NBUF>
+__device__ __forceinline__ void syrk_half_tile(double* __restrict__ A, int64_t ld, int64_t pc, int64_t j0, int ti, int tj, int h, int lr, int lk)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double* Pi = A + (j0 + (int64_t)ti * NB) + pc * ld + 2 * lr + (int64_t)lk * ld;           // rows of the i tile
+    const double* Pj = A + (j0 + (int64_t)tj * NB) + 32 * h + pc * ld + 2 * lr + (int64_t)lk * ld;  // this half's rows of the j tile
+    f64x4 acc[2][4];  // [strip 2h + jj][ib]
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) acc[jj][ib] = f64x4{0.0, 0.0, 0.0, 0.0};
+    double xa[NBUF][2], yb[NBUF][4];
+    auto load_kstep = [&](int ks, int buf) {
+        const d2 x = *reinterpret_cast<const d2*>(Pj + (int64_t)(4 * ks) * ld);
+        xa[buf][0] = x.x; xa[buf][1] = x.y;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const d2 y = *reinterpret_cast<const d2*>(Pi + 32 * hh + (int64_t)(4 * ks) * ld);
+            yb[buf][2 * hh] = y.x; yb[buf][2 * hh + 1] = y.y;
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) load_kstep(b, b);
+#pragma unroll
+    for (int ks = 0; ks < 16 * KP; ++ks) {
+        if (ks + NBUF - 1 < 16 * KP) load_kstep(ks + NBUF - 1, (ks + NBUF - 1) % NBUF);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+                acc[jj][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks % NBUF][jj], yb[ks % NBUF][ib], acc[jj][ib], 0, 0, 0);
+    }
+    double* C = A + (j0 + (int64_t)ti * NB) + (j0 + (int64_t)tj * NB) * ld + 2 * lr;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        d2 cv[2][4];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                cv[hh][g] = *reinterpret_cast<const d2*>(C + 32 * hh + (int64_t)(32 * h + 2 * (lk + 4 * g) + jj) * ld);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                d2 v = cv[hh][g];
+                v.x -= acc[jj][2 * hh][g];
+                v.y -= acc[jj][2 * hh + 1][g];
+                *reinterpret_cast<d2*>(C + 32 * hh + (int64_t)(32 * h + 2 * (lk + 4 * g) + jj) * ld) = v;
+            }
+    }
+}
+
 template <int KP>
 __global__ void __launch_bounds__(256, 2) dense_syrk_kernel(double* __restrict__ A, int64_t ld, int64_t kb, int64_t Mp,
                                                          double* __restrict__ ws, int32_t* __restrict__ info, int factor_next,
@@ -999,7 +1055,8 @@ __device__ __forceinline__ void step_solve_role(double* __restrict__ A, int64_t 
 // whose origin is block column org, tiles in COLUMN order (id -> (tj, ti)), ids id0 .. id0 + cnt - 1 (id 0 = tile (0, 0): DIAG2's, never listed).
 constexpr int kStepBulkBuffers = 6;   // operand k-steps in flight in dense_step_kernel's bulk tiles (mostly one wavefront per SIMD there)
 struct StepBulk {
-    int pcb, kp, org, id0, cnt;
+    int pcb, kp, org, id0, cnt;   // cnt: work items (tiles, or half tiles when `halves`)
+    int halves;                   // 1: two wavefronts per tile (syrk_half_tile)
 };
 template <int KP>   // depth of the bulk role's update in panels (one instantiation per depth: both tile bodies in one kernel cost 14 spilled registers)
 __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__ A, int64_t ld, int64_t Mp, int k,
@@ -1012,10 +1069,18 @@ __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__
     const int nb = (int)(Mp / NB);
     const int tid = threadIdx.x;
     const int nstrip = nb - k - 1;                      // row tiles k+2 .. nb
-    const int bx = (int)blockIdx.x + bx0;   // (bx0 != 0: timing experiments that launch a subset of the roles, tools/dense_roles.py)
+    // Workgroup 256 of a launch is a BLANK: the dispatcher hands the first 256 workgroups one CU each and starts the second round on the first
+    // CU again, i.e. beside workgroup 0 — the chain, whose sweeps then share their SIMDs' DP pipe with a neighbour's matrix instructions
+    // (15.5 -> 20.7 us per step in the launches of 257 .. 512 workgroups).  The blank exits at once and the chain keeps its CU to itself
+    // unless the launch has more than 512 workgroups (where the bulk bounds the step anyway).
+    if (bx0 == 0 && blockIdx.x == 256) return;
+    const int bx = (int)blockIdx.x - (bx0 == 0 && blockIdx.x > 256 ? 1 : 0) + bx0;   // (bx0 != 0: timing experiments, tools/dense_roles.py)
     // nprev: finished panels a tile of block column k+1 (k+2 for DIAG2) still lacks when this launch starts (the bulk role lags: 1 in the
     // one-panel schedule, 1 or 2 in the paired one)
     if (bx == 0) {
+        // the chain: its wavefronts share their SIMDs with bulk tile-waves, whose fp64 matrix instructions occupy the same DP pipe for 64
+        // cycles each (tools/mfma_probe.hip: an MFMA stream starves a VALU wavefront beside it) — highest issue priority for this workgroup
+        __builtin_amdgcn_s_setprio(3);
         step_solve_role<true>(A, ld, Mp, k, k + 1, k + 1, true, 0, Ls, Xq, &flag, info, tid);
     } else if (bx == 1) {
         if (k + 2 < nb) step_solve_role<false>(A, ld, Mp, k, k + 2, k + 2, false, nprev, Ls, Xq, &flag, info, tid);
@@ -1032,10 +1097,11 @@ __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__
         const int lane = tid & 63, wave = tid >> 6;
         const int w = (bx - 2 - nstrip) * 4 + wave;
         if (w >= bulk.cnt) return;                      // wave-uniform
-        int id = bulk.id0 + w, tj = 0;
+        int id = bulk.id0 + (bulk.halves ? w >> 1 : w), tj = 0;
         while (id >= nt - tj) { id -= nt - tj; ++tj; }  // column tj holds rows tj .. nt-1
         const int ti = tj + id;
-        syrk_tile<KP, kStepBulkBuffers>(A, ld, (int64_t)bulk.pcb * NB, j0, ti, tj, lane & 15, lane >> 4);
+        if (bulk.halves) syrk_half_tile<KP, kStepBulkBuffers>(A, ld, (int64_t)bulk.pcb * NB, j0, ti, tj, w & 1, lane & 15, lane >> 4);
+        else syrk_tile<KP, kStepBulkBuffers>(A, ld, (int64_t)bulk.pcb * NB, j0, ti, tj, lane & 15, lane >> 4);
     }
 }
 
@@ -1175,16 +1241,17 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
             return nt >= 2 ? (nt - 1) * (nt + 2) / 2 : 0;
         };
         constexpr int64_t kPairTiles = 900;
+        constexpr int kHalfTileLimit = 1024;      // tiles per launch up to which every tile is split over two wavefronts
         int ks = 2;
         if (!dop.no_pairs) while (ks + 2 < nb && tiles_of(ks + 2) > kPairTiles) ks += 2;
         for (int k = 0; k < nb; ++k) {
             const int nstrip = nb - k - 1;
-            StepBulk bk{0, 1, 0, 0, 0};
+            StepBulk bk{0, 1, 0, 0, 0, 0};
             int nprev;
             if (k > ks) {                                     // one panel per launch
                 nprev = 1;
                 const int64_t tot = tiles_of(k + 2);
-                bk = StepBulk{k - 1, 1, k + 2, 1, (int)(tot > 1 ? tot - 1 : 0)};
+                bk = StepBulk{k - 1, 1, k + 2, 1, (int)(tot > 1 ? tot - 1 : 0), 0};
             } else {
                 nprev = k == 0 ? 0 : ((k & 1) ? 1 : 2);
                 const int ke = k & ~1;
@@ -1195,16 +1262,19 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
                     const int64_t need = nt + (nt >= 3 ? 1 : 0);          // block column 0 of that origin and tile (1, 1)
                     if (split < need) split = need < tot ? need : tot;
                     if (k == ks) split = tot;                              // the switch launch takes all of B(ks)
-                    if (k & 1) bk = StepBulk{ke - 2, 2, ke + 2, (int)split, (int)(tot - split)};
-                    else bk = StepBulk{ke - 2, 2, ke + 2, 1, (int)(split - 1)};
+                    if (k & 1) bk = StepBulk{ke - 2, 2, ke + 2, (int)split, (int)(tot - split), 0};
+                    else bk = StepBulk{ke - 2, 2, ke + 2, 1, (int)(split - 1), 0};
                 }
             }
+            // half tiles (two wavefronts per tile) once whole tiles would leave SIMDs idle: the launch then lasts as long as its slowest wavefront
+            if (!dop.no_halves && bk.cnt > 0 && bk.cnt <= kHalfTileLimit) { bk.halves = 1; bk.cnt *= 2; }
             unsigned grid = (unsigned)(2 + nstrip + (bk.cnt + 3) / 4);
             int bx0 = 0;
             // timing experiments only (results are garbage): 2 = the critical workgroup alone, 3 = DIAG2 + the strips alone, 4 = the bulk alone
             if (dop.old_chain == 2) grid = 1;
             else if (dop.old_chain == 3) { grid = (unsigned)(1 + nstrip); bx0 = 1; }
             else if (dop.old_chain == 4) { if (grid <= (unsigned)(2 + nstrip)) continue; grid -= (unsigned)(2 + nstrip); bx0 = 2 + nstrip; }
+            if (bx0 == 0 && grid > 256) ++grid;                  // the blank workgroup (see the kernel)
             if (bk.kp == 2) hipLaunchKernelGGL(dense_step_kernel<2>, dim3(grid), dim3(256), 0, stream, K, ld, Mp, k, info, bx0, nprev, bk);
             else hipLaunchKernelGGL(dense_step_kernel<1>, dim3(grid), dim3(256), 0, stream, K, ld, Mp, k, info, bx0, nprev, bk);
         }
