@@ -66,6 +66,16 @@ function close!(ctx::Context)
     return
 end
 
+# diagnostic switches of a context (pioran_ctx_set_option: "no_split", "workspace_limit_mb", "dense_old_chain", ...) and the FP64 FMA rate
+# the device sustains right now (TFLOP/s; the measured ceiling of any FP64 vector kernel on this box)
+set_option!(ctx::Context, key::AbstractString, value::Union{Nothing, AbstractString} = "1") =
+    check(ccall((:pioran_ctx_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Cstring), ctx.h, key, value === nothing ? C_NULL : value))
+function fp64_probe(ctx::Context = default_context(); waves_per_simd::Integer = 2, ms::Real = 10.0)
+    out = Ref{Cdouble}(0.0)
+    check(ccall((:pioran_ctx_fp64_probe, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Ref{Cdouble}), ctx.h, waves_per_simd, ms, out))
+    return out[]
+end
+
 const DEFAULT_CTX = Ref{Union{Nothing, Context}}(nothing)
 default_context() = (DEFAULT_CTX[] === nothing && (DEFAULT_CTX[] = Context(parse(Int, get(ENV, "PIORAN_HIP_DEVICE", "0")))); DEFAULT_CTX[])
 
