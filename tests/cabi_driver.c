@@ -54,7 +54,7 @@ int main(int argc, char** argv)
     if (fscanf(f, "%lf", &want_dense) != 1) return 3;
     fclose(f);
 
-    if (pioran_abi_version() != 6) { fprintf(stderr, "ABI version %d, this driver was written for 6\n", pioran_abi_version()); return 2; }
+    if (pioran_abi_version() != 7) { fprintf(stderr, "ABI version %d, this driver was written for 7\n", pioran_abi_version()); return 2; }
     CHECK(pioran_ctx_create(0, &ctx));
     pioran_ds* ds = NULL;
     CHECK(pioran_dataset_create(ctx, N, t, y, s2, &ds));
