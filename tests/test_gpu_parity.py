@@ -747,6 +747,42 @@ def test_dense_nll_vs_oracle(ctx, N, J):
     assert abs(got - ref) <= 1e-11 * abs(ref)
 
 
+@pytest.mark.parametrize("N", [129, 191, 192, 193, 257, 320, 1000, 2760, 2881, 3100])
+def test_dense_one_launch_per_block_column_equals_the_panel_update_chain(ctx, N):
+    """log_likelihood_direct (src/direct_solver.jl:6-21) for one matrix: the one-launch-per-block-column factorisation of round 4
+    (dense_step_kernel: critical workgroup + strips + lagging bulk, paired / single-panel phases, half tiles) against the panel / update
+    chain of rounds 1-3 (option dense_old_chain) and the oracle, at sizes on both sides of every schedule switch (3 .. 49 block columns)."""
+    rng = np.random.default_rng(9000 + N)
+    J = 5
+    t = np.cumsum(rng.uniform(0.05, 2.0, N)); y = rng.standard_normal(N); s2 = rng.uniform(0.01, 0.1, N)
+    a = rng.uniform(0.1, 2, J); b = rng.uniform(-0.05, 0.05, J) * a; c = rng.uniform(0.05, 2, J); d = rng.uniform(0, 3, J)
+    new, i1 = ctx.dense_nll(a, b, c, d, t, y, s2, return_info=True)
+    try:
+        ctx.set_option("dense_old_chain", 1)
+        old, i0 = ctx.dense_nll(a, b, c, d, t, y, s2, return_info=True)
+        ctx.set_option("dense_old_chain", 0); ctx.set_option("dense_no_pairs", True)
+        single, i2 = ctx.dense_nll(a, b, c, d, t, y, s2, return_info=True)
+        ctx.set_option("dense_no_pairs", False); ctx.set_option("dense_no_halves", True)
+        whole, i3 = ctx.dense_nll(a, b, c, d, t, y, s2, return_info=True)
+    finally:
+        ctx.set_option("dense_old_chain", 0); ctx.set_option("dense_no_pairs", False); ctx.set_option("dense_no_halves", False)
+    assert i0 == i1 == i2 == i3 == 0
+    assert abs(new - old) <= 1e-12 * abs(old) and abs(single - old) <= 1e-12 * abs(old) and whole == new
+    if N <= 1000:
+        ref = O.dense_nll(a, b, c, d, t, y, s2)
+        assert abs(new - ref) <= 1e-11 * abs(ref)
+    # a matrix that stops being positive definite in the middle: both chains report the same first bad pivot (LAPACK's info)
+    bad = int(0.6 * N)
+    s2b = s2.copy(); s2b[bad] = -50.0
+    try:
+        v1, j1 = ctx.dense_nll(a, b, c, d, t, y, s2b, return_info=True)
+        ctx.set_option("dense_old_chain", 1)
+        v0, j0 = ctx.dense_nll(a, b, c, d, t, y, s2b, return_info=True)
+    finally:
+        ctx.set_option("dense_old_chain", 0)
+    assert np.isnan(v1) and np.isnan(v0) and j1 == j0 == bad + 1
+
+
 def test_dense_reference_relation(ctx, golden_dir):
     """The reference's own test relation: logpdf (celerite) == -log_likelihood_direct, isapprox rtol 1.49e-8
     (test/test_likelihood.jl:58-59, test/test_scalablegp.jl:128) — here both sides on the GPU, bar 1e-10."""
