@@ -39,6 +39,40 @@ def relerr(got, ref):
     return np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300))
 
 
+def test_config3_batch_with_a_remainder_at_full_size(ctx, full_size):
+    """configs[2]'s workload with a batch that is NOT a whole number of passes (a sampler's live points are user-chosen, README.md:97):
+    N = 1e4, SHO-20, B = 4096 + 104 through the device-pointer entry.  The first 4096 draws run as one pass of the scan, the remainder on
+    the windowed kernel on the second stream (capi.hip split_dispatch): the scan's share is bit-identical to the single launch, the
+    remainder against the oracle."""
+    import torch
+    t, y, yerr = full_size
+    B = 4200
+    th = O.synthetic_theta(B, t, y, seed=4321)
+    A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, 20, "SHO")
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    ds.prepare(C, Dd, np.zeros(20, dtype=np.int32))
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (A, Bc, mu, nu)]
+    outs = []
+    for flag in (False, True):
+        ctx.set_option("no_split", flag)
+        dout = torch.full((B,), float("nan"), dtype=torch.float64, device=dev)
+        dst = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        ds.logl_batch_dev(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, 0, dout.data_ptr(), dst.data_ptr())
+        torch.cuda.synchronize()
+        outs.append((dout.cpu().numpy(), dst.cpu().numpy(), pj._lib.lib().pioran_celerite_config_name(-1).decode()))
+    ctx.set_option("no_split", False)
+    (got, st, kern), (one, st1, kern1) = outs
+    assert kern == "scan + block (remainder)" and kern1 == "scan"
+    assert np.array_equal(got[:4096], one[:4096], equal_nan=True) and np.array_equal(st[:4096], st1[:4096])
+    assert (st >= 0).all() and np.array_equal(st == 0, st1 == 0)
+    idx = np.arange(4096, B)
+    ref, rst = O.logl_batch(A[idx], Bc[idx], C, Dd, t, y, yerr ** 2, mu[idx], nu[idx], nthreads=NTHREADS, return_status=True)
+    ok = (rst == 0) & (st[idx] == 0)
+    assert ok.sum() > 90
+    assert relerr(got[idx][ok], ref[ok]) < 1e-8 and relerr(one[idx][ok], ref[ok]) < 1e-8
+
+
 @pytest.mark.parametrize("basis", ["SHO", "DRWCelerite"])
 def test_config3_full_batch(ctx, full_size, basis):
     """configs[2]: N = 1e4, n_components = 20, B = 4096 through the device-pointer batch entry (what bench.py times);
