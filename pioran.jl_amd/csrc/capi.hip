@@ -1449,7 +1449,7 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
     PendingGuard pending_guard(ctx);
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
-    if (s.R > 95 || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
+    if (s.R > pioran_wide_supported_rows_grad() || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
     // Windowed reverse mode (celerite_block.hip, round 3) whenever the rows fit the windowed kernel, with or without d/d(c, d):
     // 6.3 ms (7.0 with d/d(c, d)) instead of 25 at N = 1e4, J = 20 (series gradients and the shifted log-flux models included).
     bool windowed = !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R >= 6 &&

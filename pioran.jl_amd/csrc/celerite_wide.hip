@@ -414,9 +414,12 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
 // runs with one row per lane less than it would with the y slot).  The forward solve is then the reference's own recurrence
 // f <- phi o (f + W_{n-1} z_{n-1}), z_n = y_n - u_n'f (src/celerite_solver.jl:136-141) on the lane's COLUMN block (replicated in
 // the 16 DPP rows), its dot product one more 16-lane sum per step; thread 255 stages y_n - mu and sigma2_n.
-template <int RPL, bool YC = false>
+// GM (round 4): the forward pass of the step-by-step reverse mode for 96 .. 143 rows — what celerite_wide_kernel<RPL, 3> leaves for
+// RPL <= 6: v - q of all 16 RPL slots and D_n of every step, S_n (lane layout) at the checkpoints n = k * ckpt_every.
+template <int RPL, bool YC = false, bool GM = false>
 __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams p)
 {
+    static_assert(!(YC && GM), "the reverse pass expects y as the last row slot");
     constexpr int NS = 16 * RPL;                      // row slots; the last one is the y row
     // LDS pitch of a lane's block of RPL slots.  A pitch of 8 doubles = 16 dwords puts four of the 16 lanes of a DPP row on each
     // bank pair when they read element c of their blocks (RPL = 8 ran slower than RPL = 9: 13.0 vs 11.0 ms at N = 8192 once padded);
@@ -539,6 +542,14 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
     if constexpr (LAZY) {   // step 0's (v - q) = v_0 of every slot, where step 1 looks for the previous step's exchange values
         if (tid < NS) sh_num[0][sa_] = sh_rec[0][NSP + sa_];
     }
+    [[maybe_unused]] auto emit = [&](int64_t n) __attribute__((always_inline)) {
+        if (l == 0) {
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) p.st_w[(b * N + n) * NS + g * RPL + i] = num[i];
+            if (yrow) p.st_d[b * N + n] = Dn;
+        }
+    };
+    if constexpr (GM) emit(0);
     stage(1, gv[1 % DG]);
     fetch(DG + 1, gv[1 % DG]);
     __syncthreads();
@@ -600,6 +611,21 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
                 }
             }
         }
+        if constexpr (GM) {   // checkpoint of S_n: same layout as celerite_wide_kernel<RPL, 3>
+            if (n % p.ckpt_every == 0) {   // uniform
+                constexpr int SP = (RPL * RPL + 1) & ~1;
+                const size_t nck = (size_t)((N - 1) / p.ckpt_every + 1);
+                d2* dst = reinterpret_cast<d2*>(p.st_ck + (((size_t)b * nck + (size_t)(n / p.ckpt_every)) * 256 + tid) * SP);
+#pragma unroll
+                for (int e = 0; e < SP / 2; ++e) {
+                    const int e0 = 2 * e, e1 = 2 * e + 1;
+                    d2 v;
+                    v.x = S[e0 / RPL][e0 % RPL];
+                    v.y = e1 < RPL * RPL ? S[e1 / RPL][e1 % RPL] : 0.0;
+                    dst[e] = v;
+                }
+            }
+        }
         [[maybe_unused]] double zn = 0.0;
         if constexpr (YC) zn = r[3 * NSP + 1] - row16_sum(zpart);    // z_n = y_n - mu - u_n'f     :141
         double sp = 0.0;
@@ -640,6 +666,7 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
             Pe += ex;
         }
         quad = fma(z * z, rD, quad);                             // z_n^2 / D_n  (== y'K^-1 y, :333)
+        if constexpr (GM) emit(n);
     };
 
     int64_t n = 1;
@@ -698,7 +725,7 @@ __global__ void __launch_bounds__(256) celerite_replay_kernel(const ScanParams p
 {
     constexpr int NS = 16 * RPL, SP = (RPL * RPL + 1) & ~1;
     constexpr int SB = 8;                              // steps per staged block
-    constexpr int EMAX = 96 + 2 + NS + 1;              // phi of <= 95 rows + padding + y | m | D
+    constexpr int EMAX = (RPL <= 6 ? 96 : 144) + 2 + NS + 1;   // phi of <= 95 (143) rows + padding + y | m | D
     constexpr int PT = (SB * EMAX + 255) / 256;        // staged elements per thread and block
     const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
     const int64_t b = blockIdx.x, N = p.N;
@@ -806,7 +833,8 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
     const int L = RS + 3 * p.npd_rows;                // table part of the staged record
     const int LT = L + NS + 1;                        // + m_{n-1} of every slot + D_{n-1}
 
-    __shared__ double sh_rec[2][kWideMaxRecord];
+    constexpr int NE = RPL >= 7 ? 3 : 2;              // staged elements per thread and step (96 .. 143 rows: up to 582 doubles)
+    __shared__ double sh_rec[2][NE * 256];
     __shared__ double sh_num[2][NS];
     __shared__ double sh_uq[2][16];
     // row accumulators of d/d(al), d/d(be), d/dd: identical in the 16 lanes of a DPP row, so they live here (updated by
@@ -833,10 +861,10 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
 
     // staged element e of step n: e < L table record n (as in the forward kernel); L <= e < L + NS: m_{n-1}[e - L];
     // e == L + NS: D_{n-1}.  address = src + clamp(n + shift, 0, last) * stride
-    const double* src[2];
-    int64_t stride[2], last[2], shift[2];
+    const double* src[NE];
+    int64_t stride[NE], last[NE], shift[NE];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NE; ++h) {
         const int e = tid + 256 * h;
         src[h] = p.tab + (e < RS ? e : e + (int64_t)b * p.npd_rows * 3);
         stride[h] = p.rec_stride; last[h] = N; shift[h] = 0;
@@ -848,19 +876,20 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
         if (e == L + NS) { src[h] = dst_; stride[h] = 1; last[h] = N - 1; shift[h] = -1; }
         if (e >= LT) { src[h] = p.tab; stride[h] = 0; }
     }
-    const bool two = LT > 256;
-    auto fetch = [&](int64_t n, double (&dstv)[2]) __attribute__((always_inline)) {
+    const int ne = (LT + 255) / 256;                  // uniform
+    auto fetch = [&](int64_t n, double (&dstv)[NE]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h == 1 && !two) break;
+        for (int h = 0; h < NE; ++h) {
+            if (h >= ne) break;
             int64_t k = n + shift[h];
             k = k < 0 ? 0 : (k > last[h] ? last[h] : k);
             dstv[h] = src[h][k * stride[h]];
         }
     };
-    auto stage = [&](int par, const double (&v)[2]) __attribute__((always_inline)) {
-        sh_rec[par][tid] = v[0];
-        if (two) sh_rec[par][tid + 256] = v[1];
+    auto stage = [&](int par, const double (&v)[NE]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < NE; ++h)
+            if (h < ne) sh_rec[par][tid + 256 * h] = v[h];
     };
     // S_n of this lane from the replayed segment (slot n - seg_n0 - 1), SD steps ahead in registers
     constexpr int SP = (RPL * RPL + 1) & ~1;          // padded block (16-byte pairs)
@@ -882,7 +911,7 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
     };
 
     // steps are visited in DEscending n; "position" s = n_hi - n plays the role n plays in the forward kernel
-    double gv[DG][2];
+    double gv[DG][NE];
 #pragma unroll
     for (int m = 0; m < DG; ++m) fetch(n_hi - m, gv[m]);
     constexpr int SD = RPL <= 3 ? 2 : 1;              // S_n buffers (steps ahead); one where registers are short
@@ -932,7 +961,7 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
     }
     __syncthreads();
 
-    auto do_step = [&](int64_t n, double (&gslot)[2], double (&sn)[RPL * RPL]) __attribute__((always_inline)) {
+    auto do_step = [&](int64_t n, double (&gslot)[NE], double (&sn)[RPL * RPL]) __attribute__((always_inline)) {
         const double* r = sh_rec[n & 1];               // record n: table part, then m_{n-1} of every slot, D_{n-1}
         double ur[RPL], uc[RPL], qbr[RPL], qbc[RPL], ub[RPL];
         const double rDn = recip_f64(Dn);
@@ -1118,6 +1147,8 @@ __global__ void __launch_bounds__(256) grad_finish_kernel(const ScanParams p, in
 int pioran_wide_supported_rows() { return 143; }
 // ... the store (prediction), simulate and gradient-forward modes exist for the shapes of rounds 1-2 only
 int pioran_wide_supported_rows_modes() { return 95; }
+// the step-by-step reverse mode: RPL 7 .. 9 since round 4 (forward pass: the lean kernel with GM)
+int pioran_wide_supported_rows_grad() { return 143; }
 
 // Batches up to this size take the latency layout (at most one workgroup per CU on the chip's 256 CUs).
 int64_t pioran_wide_max_batch() { return 256; }
@@ -1187,7 +1218,7 @@ int pioran_launch_scan_wide_sim(const ScanParams& p, hipStream_t stream)
     return launch_wide_mode<2>(p, stream);
 }
 
-static int rpl_of(int R) { return R <= 15 ? 1 : R <= 31 ? 2 : R <= 47 ? 3 : R <= 63 ? 4 : R <= 79 ? 5 : 6; }
+static int rpl_of(int R) { return R <= 15 ? 1 : R <= 31 ? 2 : R <= 47 ? 3 : R <= 63 ? 4 : R <= 79 ? 5 : R <= 95 ? 6 : R <= 111 ? 7 : R <= 127 ? 8 : 9; }
 
 // checkpoint interval of the gradient's forward pass: ~2 sqrt(N), between 16 and 256 (memory K + N/K blocks of S per draw)
 static int grad_ckpt_every(int64_t N)
@@ -1215,9 +1246,9 @@ size_t pioran_grad_workspace_doubles(int64_t B, int64_t N, int32_t R)
 int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, double* grad_b, double* grad_c, double* grad_d,
                                  double* grad_nu, double* grad_mu, hipStream_t stream, hipStream_t aux, hipEvent_t* ev)
 {
-    if (!p.tab || p.R > 95 || p.npd_rows || p.B <= 0 || p.B > 0x7fffffffLL || !grad_a || !grad_b) return PIORAN_ERR_UNSUPPORTED;
+    if (!p.tab || p.R > 143 || p.npd_rows || p.B <= 0 || p.B > 0x7fffffffLL || !grad_a || !grad_b) return PIORAN_ERR_UNSUPPORTED;
     const int rpl = rpl_of(p.R), ns = 16 * rpl;
-    if (3 * (p.R + 2) + 2 + 3 * p.npd_rows + ns + 1 > kWideMaxRecord) return PIORAN_ERR_UNSUPPORTED;
+    if (3 * (p.R + 2) + 2 + 3 * p.npd_rows + ns + 1 > (rpl >= 7 ? 768 : kWideMaxRecord)) return PIORAN_ERR_UNSUPPORTED;
     const size_t sp = (size_t)((rpl * rpl + 1) & ~1), nstate = (size_t)(rpl * rpl + 3 * rpl + 4);
     const int K = grad_ckpt_every(p.N);
     const size_t nck = (size_t)((p.N - 1) / K + 1), B = (size_t)p.B, BN = B * (size_t)p.N;
@@ -1236,7 +1267,8 @@ int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, dou
     const dim3 grid((unsigned)p.B), block(256);
     auto run = [&](auto Rc) {
         constexpr int RPL = decltype(Rc)::value;
-        hipLaunchKernelGGL((celerite_wide_kernel<RPL, 3>), grid, block, 0, stream, p);
+        if constexpr (RPL >= 7) hipLaunchKernelGGL((celerite_wide2_kernel<RPL, false, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((celerite_wide_kernel<RPL, 3>), grid, block, 0, stream, p);
         // reverse pass, last segment first; segment k holds steps k K + 1 .. min((k + 1) K, N - 1); the first segment's
         // adjoint launch also takes step 0
         const int64_t nseg = (p.N - 1 + K - 1) / K;
@@ -1274,7 +1306,10 @@ int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, dou
     case 3: run(ic<3>{}); break;
     case 4: run(ic<4>{}); break;
     case 5: run(ic<5>{}); break;
-    default: run(ic<6>{}); break;   // 80 .. 95 rows (SHO-40, the dense configuration's model): round 3
+    case 6: run(ic<6>{}); break;    // 80 .. 95 rows (SHO-40, the dense configuration's model): round 3
+    case 7: run(ic<7>{}); break;    // 96 .. 143 rows (the reference grid's j = 64 is 128): round 4
+    case 8: run(ic<8>{}); break;
+    default: run(ic<9>{}); break;
     }
     hipLaunchKernelGGL(grad_finish_kernel, grid, block, 0, stream, p, ns, grad_a, grad_b, grad_c, grad_d, grad_nu, grad_mu);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;

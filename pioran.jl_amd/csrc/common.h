@@ -126,6 +126,7 @@ size_t pioran_grad_workspace_doubles(int64_t B, int64_t N, int32_t R);
 int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, double* grad_b, double* grad_c, double* grad_d,
                                  double* grad_nu, double* grad_mu, hipStream_t stream, hipStream_t aux, hipEvent_t* ev /*[5]*/);
 int pioran_wide_supported_rows();
+int pioran_wide_supported_rows_grad();    // step-by-step reverse mode (143)
 int pioran_wide_supported_rows_modes();   // store / simulate / gradient modes of the latency kernel (95)
 int64_t pioran_wide_max_batch();
 // celerite_block.hip: windowed form (16 steps per window on the matrix cores), one draw per workgroup; shared (c, d) without

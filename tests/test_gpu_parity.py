@@ -1501,7 +1501,8 @@ def test_predict_cov_reference_cases(ctx, golden_dir):
 # gradient of log L by reverse mode through the recurrence
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("J,N,B", [(3, 40, 2), (7, 64, 3), (10, 257, 3), (20, 500, 2), (30, 129, 2), (39, 100, 2), (4, 1, 1), (9, 2, 2),
-                                   (9, 3, 2), (9, 6, 2), (40, 70, 2), (47, 37, 1)])   # 40, 47: 80 / 94 rows (SHO-40 is the dense configuration's model)
+                                   (9, 3, 2), (9, 6, 2), (40, 70, 2), (47, 37, 1),    # 40, 47: 80 / 94 rows (SHO-40 is the dense configuration's model)
+                                   (48, 50, 2), (55, 33, 1), (56, 20, 2), (64, 40, 2), (71, 37, 1)])   # 96 .. 142 rows (round 4; j = 64: the reference grid's largest)
 def test_gradient_matches_complex_step(ctx, J, N, B):
     """dlogL/d(a_j, b_j, c_j, d_j, mu, nu, y_n, sigma2_n) against the complex-step derivatives of the oracle (exact to
     rounding): every RPL of the adjoint kernel, every prologue / tail length of its pipelines, series shorter and longer
