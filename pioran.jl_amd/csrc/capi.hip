@@ -506,6 +506,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "workspace_limit_mb")) o.workspace_limit_mb = (value && value[0]) ? std::atoll(value) : 0;
     else if (!std::strcmp(key, "dense_streams")) o.dense_streams = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "gsum")) o.gsum = (value && value[0]) ? std::atoi(value) : -1;
+    else if (!std::strcmp(key, "exp")) o.exp = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "wide2")) o.wide2 = on;
     else if (!std::strcmp(key, "no_wide2")) o.no_wide2 = on;
     else return PIORAN_ERR_ARG;
@@ -532,6 +533,7 @@ static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
     pioran_ctx_set_option(ctx, "no_win2", std::getenv("PIORAN_NO_WIN2"));
     pioran_ctx_set_option(ctx, "gsum", std::getenv("PIORAN_GSUM"));
     pioran_ctx_set_option(ctx, "wide2", std::getenv("PIORAN_WIDE2"));
+    pioran_ctx_set_option(ctx, "exp", std::getenv("PIORAN_EXP"));
     pioran_ctx_set_option(ctx, "no_wide2", std::getenv("PIORAN_NO_WIDE2"));
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
     if (own) {
@@ -1521,8 +1523,8 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
             HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
             for (auto& e : ctx->gev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
+        p.opt = &ctx->opt;
         if (windowed) {
-            p.opt = &ctx->opt;
             p.gw = (double*)ctx->bwork.p;
             g_last_kernel = "block (windowed gradient)";
             rc = pioran_launch_block_grad(p, s.btab, gtab, dga, dgb, dgn, dgm, grad_c ? dgc : nullptr, grad_d ? dgd : nullptr, ctx->stream);

@@ -319,14 +319,14 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
             if (n % p.ckpt_every == 0) {   // uniform
                 constexpr int SP = (RPL * RPL + 1) & ~1;
                 const size_t nck = (size_t)((N - 1) / p.ckpt_every + 1);
-                d2* dst = reinterpret_cast<d2*>(p.st_ck + (((size_t)b * nck + (size_t)(n / p.ckpt_every)) * 256 + tid) * SP);
+                d2* dst = reinterpret_cast<d2*>(p.st_ck + ((size_t)b * nck + (size_t)(n / p.ckpt_every)) * 256 * SP) + tid;
 #pragma unroll
                 for (int e = 0; e < SP / 2; ++e) {
                     const int e0 = 2 * e, e1 = 2 * e + 1;
                     d2 v;
                     v.x = S[e0 / RPL][e0 % RPL];
                     v.y = e1 < RPL * RPL ? S[e1 / RPL][e1 % RPL] : 0.0;
-                    dst[e] = v;
+                    dst[e * 256] = v;   // [pair][lane]: a wavefront's store is one contiguous KB
                 }
             }
         }
@@ -615,14 +615,14 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
             if (n % p.ckpt_every == 0) {   // uniform
                 constexpr int SP = (RPL * RPL + 1) & ~1;
                 const size_t nck = (size_t)((N - 1) / p.ckpt_every + 1);
-                d2* dst = reinterpret_cast<d2*>(p.st_ck + (((size_t)b * nck + (size_t)(n / p.ckpt_every)) * 256 + tid) * SP);
+                d2* dst = reinterpret_cast<d2*>(p.st_ck + ((size_t)b * nck + (size_t)(n / p.ckpt_every)) * 256 * SP) + tid;
 #pragma unroll
                 for (int e = 0; e < SP / 2; ++e) {
                     const int e0 = 2 * e, e1 = 2 * e + 1;
                     d2 v;
                     v.x = S[e0 / RPL][e0 % RPL];
                     v.y = e1 < RPL * RPL ? S[e1 / RPL][e1 % RPL] : 0.0;
-                    dst[e] = v;
+                    dst[e * 256] = v;   // [pair][lane]: a wavefront's store is one contiguous KB
                 }
             }
         }
@@ -751,15 +751,15 @@ __global__ void __launch_bounds__(256) celerite_replay_kernel(const ScanParams p
             for (int c = 0; c < RPL; ++c) S[i][c] = 0.0;
     } else {
         const size_t nck = (size_t)((N - 1) / p.ckpt_every + 1);
-        const d2* src = reinterpret_cast<const d2*>(p.st_ck + (((size_t)b * nck + (size_t)(p.seg_n0 / p.ckpt_every)) * 256 + tid) * SP);
+        const d2* src = reinterpret_cast<const d2*>(p.st_ck + ((size_t)b * nck + (size_t)(p.seg_n0 / p.ckpt_every)) * 256 * SP) + tid;
 #pragma unroll
         for (int e = 0; e < SP / 2; ++e) {
-            const d2 v = src[e];
+            const d2 v = src[e * 256];
             S[(2 * e) / RPL][(2 * e) % RPL] = v.x;
             if (2 * e + 1 < RPL * RPL) S[(2 * e + 1) / RPL][(2 * e + 1) % RPL] = v.y;
         }
     }
-    d2* out = reinterpret_cast<d2*>(p.st_s + ((size_t)b * (size_t)p.ckpt_every * 256 + tid) * SP);
+    d2* out = reinterpret_cast<d2*>(p.st_s + (size_t)b * (size_t)p.ckpt_every * 256 * SP) + tid;   // [step][pair][lane]
     double regs[PT];
     auto fetch_block = [&](int64_t blk) __attribute__((always_inline)) {
 #pragma unroll
@@ -807,10 +807,11 @@ __global__ void __launch_bounds__(256) celerite_replay_kernel(const ScanParams p
             d2* dst = out + (size_t)(n - n_first) * 256 * (SP / 2);
 #pragma unroll
             for (int e = 0; e < SP / 2; ++e) {
+                const int e0 = 2 * e, e1 = 2 * e + 1;
                 d2 v;
-                v.x = S[(2 * e) / RPL][(2 * e) % RPL];
-                v.y = 2 * e + 1 < RPL * RPL ? S[(2 * e + 1) / RPL][(2 * e + 1) % RPL] : 0.0;
-                dst[e] = v;
+                v.x = S[e0 / RPL][e0 % RPL];
+                v.y = e1 < RPL * RPL ? S[e1 / RPL][e1 % RPL] : 0.0;
+                dst[e * 256] = v;
             }
         }
         if (blk + 1 < nblk) put_block((int)((blk + 1) & 1));
@@ -893,18 +894,18 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
     };
     // S_n of this lane from the replayed segment (slot n - seg_n0 - 1), SD steps ahead in registers
     constexpr int SP = (RPL * RPL + 1) & ~1;          // padded block (16-byte pairs)
-    const double* sbase = p.st_s + ((size_t)b * (size_t)p.ckpt_every * 256 + tid) * SP;
+    const double* sbase = p.st_s + (size_t)b * (size_t)p.ckpt_every * 256 * SP;
     const int64_t s_first = p.seg_n0 + 1;             // lowest step present in the segment buffer
     auto fetch_s = [&](int64_t n, double (&dsts)[RPL * RPL]) __attribute__((always_inline)) {
         int64_t k = n < s_first ? s_first : n;        // below the segment (or S_0): never used, any readable slot will do
         k = k > n_hi ? n_hi : k;
         const bool have = n_hi >= s_first;            // N = 1: nothing was replayed
-        const d2* q_ = reinterpret_cast<const d2*>(sbase + (size_t)(have ? k - s_first : 0) * 256 * SP);
+        const d2* q_ = reinterpret_cast<const d2*>(sbase + (size_t)(have ? k - s_first : 0) * 256 * SP) + tid;
 #pragma unroll
         for (int e = 0; e < SP / 2; ++e) {
             d2 v;
             v.x = 0.0; v.y = 0.0;
-            if (have) v = q_[e];
+            if (have) v = q_[e * 256];
             dsts[2 * e] = v.x;
             if (2 * e + 1 < RPL * RPL) dsts[2 * e + 1] = v.y;
         }
@@ -1108,6 +1109,312 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
     }
 }
 
+// ---- lean form of the reverse pass (round 4) ------------------------------------------------------------------------------------
+// Same mathematics, segments, workspace and parked state as celerite_adjoint_kernel; what changes is where the per-step inputs live.
+// As in celerite_wide2_kernel a SLOT THREAD s < 16 RPL fetches (v, x, phi) of its table row and m_{n-1}[s] (DG steps ahead) and
+// publishes per slot  u | v | x | phi | m_{n-1} | q = v - m_n  (+ sigma2_n, D_{n-1}); the 256 lanes read row and column operands from
+// LDS at the point of use (column operands one column ahead).  The registers then hold the adjoint state Sb, the replayed S_n and
+// 5 RPL row vectors — celerite_adjoint_kernel kept 126 registers of slot descriptors and 11 RPL row / column vectors (147 spilled
+// registers at RPL = 6, 3000 at RPL = 9).  The mat-vec S_n qb (only the accumulators of d/d(al, be, d) need it) is fused into the
+// loop that updates Sb, so S_n is read once, in the middle of the step: its loads (one buffer ahead, two where the registers allow)
+// have most of a step to land.
+template <int RPL>
+__global__ void __launch_bounds__(256, 1) celerite_adjoint2_kernel(const ScanParams p)
+{
+    constexpr int YS = RPL - 1;
+    constexpr int DG = RPL >= 6 ? 2 : 4;             // records in flight per slot thread
+    constexpr int NS = 16 * RPL;
+    constexpr int PITCH = RPL == 8 ? 9 : RPL;         // (as celerite_wide2_kernel)
+    constexpr int NSP = 16 * PITCH;
+    constexpr int NSTATE = RPL * RPL + 3 * RPL + 4;   // layout of celerite_adjoint_kernel's parked state (the mbc slots stay unused)
+    constexpr int SP = (RPL * RPL + 1) & ~1;
+    constexpr int SD = RPL <= 5 ? 2 : 1;              // S_n buffers (a second one where the registers allow)
+    constexpr int oU = 0, oV = NSP, oX = 2 * NSP, oP = 3 * NSP, oM = 4 * NSP, oQ = 5 * NSP, oS = 6 * NSP;   // oS: sigma2_n, D_{n-1}
+    const int tid = threadIdx.x;
+    const int g = tid >> 4, l = tid & 15;
+    const int64_t b = blockIdx.x, N = p.N;
+    const int64_t n_hi = p.seg_hi, n_lo = p.seg_lo, NP = n_hi - n_lo + 1;
+    const int R = p.R, Rp = R + 2;
+
+    __shared__ double sh_rec[2][6 * NSP + 2];
+    __shared__ double sh_num[2][NSP];                 // mb of every row slot (the exchange of the step)
+    __shared__ double sh_uq[2][16];
+    __shared__ double sh_acc[3][NSP];                 // row accumulators of d/d(al), d/d(be), d/dd
+    __shared__ double sh_c[3][NSP];                   // al | be | sign of the d-derivative (-1 cos row, +1 sin row, 0 otherwise)
+
+    const double mu = p.mu ? p.mu[b] : 0.0;
+    const double nu = p.nu ? p.nu[b] : 1.0;
+    const bool yrow = g == 15, ycol = l == 15;
+    const double* numst = p.st_w + (size_t)b * (size_t)N * NS;
+    const double* dst_ = p.st_d + (size_t)b * (size_t)N;
+
+    // ---- slot threads -------------------------------------------------------------------------------------------------------
+    const bool slot_thread = tid < NS;
+    const bool yslot = tid == NS - 1;
+    const int sa_ = (tid / RPL) * PITCH + tid % RPL;
+    const double* src[5] = {p.tab, p.tab, p.tab, p.tab, p.tab};    // v | x | phi | m_{n-1} | D_{n-1} (y slot)
+    int64_t stride[5] = {0, 0, 0, 0, 0}, last[5] = {N, N, N, N - 1, N - 1}, shift[5] = {0, 0, 0, -1, -1};
+    double al = 0.0, be = 0.0, sgn = 0.0;
+    if (slot_thread) {
+        if (yslot) {
+            src[0] = p.Y ? p.Y + b * N : p.tab + 3 * Rp;
+            src[1] = p.S2 ? p.S2 + b * N : p.tab + 3 * Rp + 1;
+            stride[0] = stride[1] = p.Y ? 1 : p.rec_stride;
+            last[0] = last[1] = p.Y ? N - 1 : N;
+            src[2] = p.tab + 2 * Rp + (R + 1);
+            stride[2] = p.rec_stride;
+            src[4] = dst_; stride[4] = 1;
+        } else {
+            const int trow = tid < R ? tid : R;       // inert padding slots: the table's padding row (v, x, phi) = (1, 0, 1), u = 0
+            if (tid < R) {
+                const int rm = p.rowmap[tid];
+                const int term = rm & 0xfffff;
+                const bool ks = (rm >> 30) & 1;
+                al = p.A[b * p.J + term];
+                be = ks ? -p.Bc[b * p.J + term] : p.Bc[b * p.J + term];
+                sgn = ks ? 1.0 : -1.0;
+            }
+            src[0] = p.tab + trow; src[1] = p.tab + trow + Rp; src[2] = p.tab + trow + 2 * Rp;
+            stride[0] = stride[1] = stride[2] = p.rec_stride;
+        }
+        src[3] = numst + tid; stride[3] = NS;
+        sh_c[0][sa_] = al; sh_c[1][sa_] = be; sh_c[2][sa_] = sgn;
+    }
+    double gv[DG][5];
+    auto fetch = [&](int64_t n, double (&d)[5]) __attribute__((always_inline)) {
+        if (slot_thread) {
+#pragma unroll
+            for (int h = 0; h < 5; ++h) {
+                if (h == 4 && !yslot) break;
+                int64_t k = n + shift[h];
+                k = k < 0 ? 0 : (k > last[h] ? last[h] : k);
+                d[h] = src[h][k * stride[h]];
+            }
+        }
+    };
+    double pm = slot_thread ? numst[(size_t)n_hi * NS + tid] : 0.0;   // m_n[s] of the record about to be staged
+    auto stage = [&](int par, const double (&v)[5]) __attribute__((always_inline)) {
+        if (slot_thread) {
+            double* r = sh_rec[par];
+            const double vv = yslot ? v[0] - mu : v[0];
+            r[oU + sa_] = yslot ? 0.0 : al * v[0] + be * v[1];
+            r[oV + sa_] = vv;
+            r[oX + sa_] = yslot ? 0.0 : v[1];
+            r[oP + sa_] = v[2];
+            r[oM + sa_] = v[3];
+            r[oQ + sa_] = vv - pm;
+            pm = v[3];
+            if (yslot) { r[oS] = v[1]; r[oS + 1] = v[4]; }
+        }
+    };
+    const double* sbase = p.st_s + (size_t)b * (size_t)p.ckpt_every * 256 * SP;   // [step][pair][lane]
+    const int64_t s_first = p.seg_n0 + 1;
+    auto fetch_s = [&](int64_t n, double (&dsts)[RPL * RPL]) __attribute__((always_inline)) {
+        int64_t k = n < s_first ? s_first : n;        // below the segment (or S_0): never used, any readable slot will do
+        k = k > n_hi ? n_hi : k;
+        const bool have = n_hi >= s_first;            // N = 1: nothing was replayed
+        const d2* q_ = reinterpret_cast<const d2*>(sbase + (size_t)(have ? k - s_first : 0) * 256 * SP) + tid;
+#pragma unroll
+        for (int e = 0; e < SP / 2; ++e) {
+            d2 v;
+            v.x = 0.0; v.y = 0.0;
+            if (have) v = q_[e * 256];
+            dsts[2 * e] = v.x;
+            if (2 * e + 1 < RPL * RPL) dsts[2 * e + 1] = v.y;
+        }
+    };
+
+#pragma unroll
+    for (int m = 0; m < DG; ++m) fetch(n_hi - m, gv[m]);
+    double sv[SD][RPL * RPL];
+    fetch_s(n_hi, sv[0]);
+    if constexpr (SD == 2) fetch_s(n_hi - 1, sv[1]);
+    stage((int)(n_hi & 1), gv[0]);
+    fetch(n_hi - DG, gv[0]);
+
+    double Dn = dst_[n_hi];
+    double zn = numst[(size_t)n_hi * NS + NS - 1];
+
+    double Sb[RPL][RPL];
+    double mbr[RPL], gphr[RPL];
+    double Db = 0.0, gA = 0.0, gnu = 0.0, gmu = 0.0;
+    double* state = p.st_state + (size_t)b * (NSTATE * 256 + 3 * NS) + tid;
+    double* state_acc = p.st_state + (size_t)b * (NSTATE * 256 + 3 * NS) + NSTATE * 256;
+    if (p.seg_first) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+#pragma unroll
+            for (int c = 0; c < RPL; ++c) Sb[i][c] = 0.0;
+            mbr[i] = 0.0; gphr[i] = 0.0;
+        }
+        for (int e = tid; e < 3 * NSP; e += 256) (&sh_acc[0][0])[e] = 0.0;
+    } else {
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i)
+#pragma unroll
+            for (int c = 0; c < RPL; ++c) Sb[i][c] = state[256 * e++];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) { mbr[i] = state[256 * (e + 0 * RPL + i)]; gphr[i] = state[256 * (e + 2 * RPL + i)]; }
+        e += 3 * RPL;
+        Db = state[256 * e]; gA = state[256 * (e + 1)]; gnu = state[256 * (e + 2)]; gmu = state[256 * (e + 3)];
+        if (slot_thread) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sh_acc[k][sa_] = state_acc[k * NS + tid];
+        }
+    }
+    // mb of the step above this launch's first one, where the column loop looks for it
+    if (l == 0) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) sh_num[(n_hi + 1) & 1][g * PITCH + i] = mbr[i];
+    }
+    __syncthreads();
+
+    auto do_step = [&](int64_t n, double (&gslot)[5], double (&sn)[RPL * RPL]) __attribute__((always_inline)) {
+        const int par = (int)(n & 1);
+        const double* r = sh_rec[par];
+        const double rDn = recip_f64(Dn);
+        const double tn = p.t[n];                      // uniform (scalar load)
+        const double dtn = n > 0 ? tn - p.t[n - 1] : 0.0;
+        Db += -0.5 * rDn + 0.5 * zn * zn * rDn * rDn;
+        const double yadj = zn * rDn;
+        if (yrow) mbr[YS] -= yadj;
+        double hq[RPL], hu[RPL], rp[RPL], ub[RPL], nb[RPL], gp[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const double ur = r[oU + g * PITCH + i];
+            hq[i] = 0.5 * (-mbr[i] - Db * ur);         // qb / 2
+            hu[i] = 0.5 * ur;
+            rp[i] = r[oP + g * PITCH + i];
+            ub[i] = 0.0; nb[i] = 0.0; gp[i] = 0.0;
+        }
+        if (n > 0) {
+            // ---- adjoints of (S_{n-1}, m_{n-1}); d/dc through phi_n; S_n qb -------------------------------------------------
+            const double* mbp = sh_num[par ^ 1] + l * PITCH;   // mb of the columns (the exchange of step n + 1)
+            double ucn = r[oU + l * PITCH], cpn = r[oP + l * PITCH], pcn = r[oM + l * PITCH], mcn = mbp[0];
+#pragma unroll
+            for (int c = 0; c < RPL; ++c) {
+                const double uc = ucn, cp = cpn, pc = pcn;
+                double mbc = mcn;
+                if (c + 1 < RPL) { ucn = r[oU + l * PITCH + c + 1]; cpn = r[oP + l * PITCH + c + 1]; pcn = r[oM + l * PITCH + c + 1]; mcn = mbp[c + 1]; }
+                asm volatile("" ::: "memory");   // compiler only: the next column's loads stay here
+                if (c == YS && ycol) mbc -= yadj;
+                const double qbc = -mbc - Db * uc;
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    const double s_ = sn[i * RPL + c];
+                    const double t_ = fma(hq[i], uc, fma(hu[i], qbc, Sb[i][c]));   // total adjoint of S_n[i][c]
+                    ub[i] = fma(s_, qbc, ub[i]);
+                    gp[i] = fma(t_, s_, gp[i]);
+                    const double sbn = (rp[i] * cp) * t_;
+                    Sb[i][c] = sbn;
+                    nb[i] = fma(sbn, pc, nb[i]);
+                }
+            }
+            if (!(p.exp & 1)) fetch_s(n - SD, sn);
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                ub[i] = row16_sum(ub[i]);
+                gphr[i] = fma(dtn, gp[i], gphr[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            ub[i] = fma(-Db, r[oQ + g * PITCH + i], ub[i]);   // q = v - m
+            if (l == 0) {
+                const int sa = g * PITCH + i;
+                const double rv = r[oV + sa], rx = r[oX + sa];
+                const double vb = fma(ub[i], sh_c[0][sa], mbr[i]), xb = ub[i] * sh_c[1][sa];
+                sh_acc[0][sa] = fma(ub[i], rv, sh_acc[0][sa]);
+                sh_acc[1][sa] = fma(ub[i], rx, sh_acc[1][sa]);
+                sh_acc[2][sa] = fma(sh_c[2][sa] * tn, fma(vb, rx, -xb * rv), sh_acc[2][sa]);
+            }
+        }
+        gA += Db;
+        gnu = fma(Db, r[oS], gnu);
+        if (yrow) {
+            gmu -= mbr[YS];
+            if (l == 0) {
+                if (p.g_y) p.g_y[b * N + n] = mbr[YS];
+                if (p.g_s2) p.g_s2[b * N + n] = nu * Db;
+            }
+        }
+        if (n == 0) return;
+        const double Dp = r[oS + 1];
+        const double rDp = recip_f64(Dp);
+        double share = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            nb[i] = 2.0 * row16_sum(nb[i]) * rDp;
+            share = fma(r[oM + g * PITCH + i], nb[i], share);
+            mbr[i] = nb[i];
+        }
+        if (l == 0) {
+            sh_uq[par][g] = share;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) sh_num[par][g * PITCH + i] = nb[i];
+        }
+        Dn = Dp;
+        zn = r[oM + 15 * PITCH + YS];                  // the y slot is the last one
+        stage(par ^ 1, gslot);
+        fetch(n - 1 - DG, gslot);
+        __syncthreads();
+        double sh[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sh[k] = sh_uq[par][k];
+        const double tot = (((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]))) +
+                           (((sh[8] + sh[9]) + (sh[10] + sh[11])) + ((sh[12] + sh[13]) + (sh[14] + sh[15])));
+        Db = -0.5 * tot * rDp;
+    };
+
+    int64_t s0 = 0;
+    for (; s0 + DG <= NP; s0 += DG)
+        static_for<0, DG>([&](auto Kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(Kc)::value;
+            do_step(n_hi - (s0 + k), gv[(k + 1) % DG], sv[k % SD]);
+        });
+    static_for<0, DG - 1>([&](auto Kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(Kc)::value;
+        if (s0 + k < NP) do_step(n_hi - (s0 + k), gv[(k + 1) % DG], sv[k % SD]);
+    });
+
+    __syncthreads();
+    if (n_lo > 0) {
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i)
+#pragma unroll
+            for (int c = 0; c < RPL; ++c) state[256 * e++] = Sb[i][c];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) { state[256 * (e + 0 * RPL + i)] = mbr[i]; state[256 * (e + 2 * RPL + i)] = gphr[i]; }
+        e += 3 * RPL;
+        state[256 * e] = Db; state[256 * (e + 1)] = gA; state[256 * (e + 2)] = gnu; state[256 * (e + 3)] = gmu;
+        if (slot_thread) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) state_acc[k * NS + tid] = sh_acc[k][sa_];
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) gphr[i] = row16_sum(gphr[i]);
+    if (l == 0) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int sa = g * PITCH + i;
+            p.g_al[b * NS + g * RPL + i] = sh_acc[0][sa];
+            p.g_be[b * NS + g * RPL + i] = sh_acc[1][sa];
+            p.g_d[b * NS + g * RPL + i] = sh_acc[2][sa];
+            p.g_c[b * NS + g * RPL + i] = -2.0 * gphr[i];
+        }
+        if (yrow) {
+            p.g_scal[b * 4 + 0] = gA;
+            p.g_scal[b * 4 + 1] = gnu;
+            p.g_scal[b * 4 + 2] = gmu;
+            p.g_scal[b * 4 + 3] = 0.0;
+        }
+    }
+}
+
 // row adjoints -> term gradients: a_j enters al of both rows and sum(a); b_j enters be of the cos row and -be of the sin row;
 // c_j and d_j collect the accumulators of their rows
 __global__ void __launch_bounds__(256) grad_finish_kernel(const ScanParams p, int NS, double* __restrict__ grad_a,
@@ -1248,6 +1555,7 @@ int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, dou
 {
     if (!p.tab || p.R > 143 || p.npd_rows || p.B <= 0 || p.B > 0x7fffffffLL || !grad_a || !grad_b) return PIORAN_ERR_UNSUPPORTED;
     const int rpl = rpl_of(p.R), ns = 16 * rpl;
+    p.exp = p.opt ? p.opt->exp : 0;
     if (3 * (p.R + 2) + 2 + 3 * p.npd_rows + ns + 1 > (rpl >= 7 ? 768 : kWideMaxRecord)) return PIORAN_ERR_UNSUPPORTED;
     const size_t sp = (size_t)((rpl * rpl + 1) & ~1), nstate = (size_t)(rpl * rpl + 3 * rpl + 4);
     const int K = grad_ckpt_every(p.N);
@@ -1267,8 +1575,16 @@ int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, dou
     const dim3 grid((unsigned)p.B), block(256);
     auto run = [&](auto Rc) {
         constexpr int RPL = decltype(Rc)::value;
-        if constexpr (RPL >= 7) hipLaunchKernelGGL((celerite_wide2_kernel<RPL, false, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((celerite_wide_kernel<RPL, 3>), grid, block, 0, stream, p);
+        // the lean reverse pass (celerite_adjoint2_kernel): always from 7 rows per lane on; below, by option (wide2 = 1: on, no_wide2: off)
+        const bool lean = RPL >= 7 || (RPL >= 4 && !(p.opt && p.opt->no_wide2)) || (p.opt && p.opt->wide2);
+        if constexpr (RPL >= 7) {
+            hipLaunchKernelGGL((celerite_wide2_kernel<RPL, false, true>), grid, block, 0, stream, p);
+        } else if constexpr (RPL >= 4) {   // (64 .. 95 rows: the lean forward kernel is the faster one, 9.0 against 13.1 ms at 80 rows)
+            if (lean) hipLaunchKernelGGL((celerite_wide2_kernel<RPL, false, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((celerite_wide_kernel<RPL, 3>), grid, block, 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((celerite_wide_kernel<RPL, 3>), grid, block, 0, stream, p);
+        }
         // reverse pass, last segment first; segment k holds steps k K + 1 .. min((k + 1) K, N - 1); the first segment's
         // adjoint launch also takes step 0
         const int64_t nseg = (p.N - 1 + K - 1) / K;
@@ -1276,7 +1592,8 @@ int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, dou
         q.seg_first = 1;
         if (nseg == 0) {                               // N = 1
             q.seg_n0 = 0; q.seg_hi = 0; q.seg_lo = 0;
-            hipLaunchKernelGGL(celerite_adjoint_kernel<RPL>, grid, block, 0, stream, q);
+            if (lean) hipLaunchKernelGGL(celerite_adjoint2_kernel<RPL>, grid, block, 0, stream, q);
+            else hipLaunchKernelGGL(celerite_adjoint_kernel<RPL>, grid, block, 0, stream, q);
         }
         // events: ev[0] forward done; ev[1 + (k & 1)] replay of segment k done; ev[3 + (k & 1)] adjoint of segment k done
         hipStream_t rs = aux ? aux : stream;
@@ -1295,7 +1612,8 @@ int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, dou
                 (void)hipEventRecord(ev[1 + (k & 1)], aux);
                 (void)hipStreamWaitEvent(stream, ev[1 + (k & 1)], 0);
             }
-            hipLaunchKernelGGL(celerite_adjoint_kernel<RPL>, grid, block, 0, stream, q);
+            if (lean) hipLaunchKernelGGL(celerite_adjoint2_kernel<RPL>, grid, block, 0, stream, q);
+            else hipLaunchKernelGGL(celerite_adjoint_kernel<RPL>, grid, block, 0, stream, q);
             if (aux) (void)hipEventRecord(ev[3 + (k & 1)], stream);
             q.seg_first = 0;
         }

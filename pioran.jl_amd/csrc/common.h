@@ -38,6 +38,7 @@ struct ScanOptions {
     int gsum = -1;        // throughput layouts, two-step form: row sums with fewer exchange rounds (group_sum's GS); -1 = automatic
     int block_emode = -1; // windowed kernel, diagnostics: where the pair table E lives (0 one LDS buffer, 1 two, 2 global memory); -1 automatic
     bool btab_reference;  // windowed kernel: build its table with the entry-per-thread kernel of round 2 (cross-check of the windowed table kernel)
+    int exp;              // diagnostics: experiment selector of the kernel under study (0 in the product; tools/ only)
     bool wide2, no_wide2; // latency layout: force / forbid the lean form (celerite_wide2_kernel; default from 48 rows on)
 };
 
@@ -97,6 +98,7 @@ struct ScanParams {
     double* st_s;
     double* st_ck;
     double* st_state;
+    int32_t exp;          // diagnostics (ScanOptions::exp, copied by the launcher: kernels never dereference `opt`, a host pointer)
     int32_t ckpt_every;   // K
     int32_t seg_first;    // 1: the first launch of the reverse pass (adjoint state starts at zero)
     int64_t seg_n0;       // checkpoint step of the segment: st_s slot j holds S_{seg_n0 + 1 + j}
