@@ -195,10 +195,12 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
  * Two reverse modes.  With 6 .. 63 rows the WINDOWED reverse mode runs (celerite_block.hip, round 3): the windowed forward pass leaves T,
  * M', Sigma^-1 X' and Sigma^-1 of every 16-step window (38 KB per window at J = 20: 24 MB per draw at N = 1e4) and the adjoint kernel
  * walks the windows backwards with six GEMM stages each — value + gradient 6.2 ms for one chain, 6.6 ms for 256 (7.0 .. 7.5 ms with
- * grad_c / grad_d), against 25 .. 35 ms for the step-by-step adjoint below, which remains the path for 64 .. 95 rows and as a
- * cross-check (context option "no_block").
+ * grad_c / grad_d).  With 64 .. 143 rows (and as a cross-check: context option "no_block") the STEP-BY-STEP reverse mode runs
+ * (celerite_wide.hip: forward pass with checkpoints, replayed segments, lean adjoint kernel since round 4): 43 .. 45 ms at 64 .. 95 rows,
+ * 93 .. 230 ms at 96 .. 143 (the reference benchmark grid's j = 64 is 128 rows) at N = 1e4.  More than 143 rows: PIORAN_ERR_UNSUPPORTED.
  * Memory (step-by-step mode): the forward pass keeps the R x R state only at checkpoints (every ~2 sqrt(N) steps) and the reverse pass replays one
- * segment at a time: ~15 MB of workspace per draw at N = 1e4, J = 20 (two replayed segments + checkpoints 11 MB, stored m / D 4 MB: pioran_grad_workspace_doubles); draws are processed in chunks sized to the free memory.
+ * segment at a time: ~15 MB of workspace per draw at N = 1e4, J = 20 (two replayed segments + checkpoints 11 MB, stored m / D 4 MB: pioran_grad_workspace_doubles;
+ * 55 MB at 80 rows, 105 MB at 128); draws are processed in chunks sized to the free memory.
  * The workspace stays in the context for the next call; pioran_ctx_trim releases it. */
 int pioran_celerite_logl_grad(pioran_ds* ds, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
                               const double* Dd, int cd_shared, const double* mu, const double* nu, double* out,

@@ -1552,7 +1552,7 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
         if (grad_sigma2) if ((rc = download(ctx, grad_sigma2 + b0 * ds->N, ctx->bS2.p, (size_t)nb * ds->N * sizeof(double)))) return rc;
         // Chunks follow each other on the stream without a host synchronisation in between (round 4): every transfer is stream-ordered
         // and staged through pinned memory, which drains itself when it fills (pin_reserve); only the large series gradients, which go
-        // straight to the caller's pageable memory, are waited for per chunk.  4096 chains: 122 -> ~100 ms.
+        // straight to the caller's pageable memory, are waited for per chunk.  (No change in time: 4096 chains are 16 launches of 7.5 ms, 122 ms.)
         if (want_series) SYNC(ctx);
     }
     SYNC(ctx);
