@@ -1277,7 +1277,7 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
     PendingGuard pending_guard(ctx);
     int rc;
     if ((rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
-    if (s.R > pioran_wide_supported_rows_modes() || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;   // before any upload / workspace
+    if (s.R > pioran_predict_supported_rows() || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;   // before any upload / workspace
     int64_t chunk = B < 256 ? B : 256;
     // Windowed path (round 3): z = K^-1 (y - mu) from the windowed factorisation and a block back-substitution (celerite_block.hip),
     // then the two Q recurrences segment-parallel (celerite_predict.hip) — no step-by-step factor, no per-step wave reduction
@@ -1323,8 +1323,8 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
         p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = s.dc; p.D = s.dd;
         p.mu = mu ? (const double*)ctx->bmu.p : nullptr; p.nu = nu ? (const double*)ctx->bnu.p : nullptr;
         p.out = (double*)ctx->bout.p; p.status = (int32_t*)ctx->bst.p;
+        p.opt = &ctx->opt;
         if (windowed) {
-            p.opt = &ctx->opt;
             p.gw = (double*)ctx->bwork.p;
             g_last_kernel = "block (windowed prediction)";
             // -z = -K^-1 (y - mu) [nb][N] into the head of the Q workspace
@@ -1747,8 +1747,8 @@ static int simulate_shared(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, con
         p.A = (const double*)ctx->bA.p; p.Bc = (const double*)ctx->bB.p; p.C = s.dc; p.D = s.dd;
         p.out = (double*)ctx->bout.p;
         p.noise = (const double*)ctx->bY.p; p.ysim = (double*)ctx->bS2.p;
+        p.opt = &ctx->opt;
         if (windowed) {
-            p.opt = &ctx->opt;
             p.gw = (double*)ctx->bwork.p;
             p.status = (int32_t*)ctx->bst.p;
             g_last_kernel = "block (windowed simulation)";

@@ -414,12 +414,14 @@ __global__ void __launch_bounds__(256, 1) celerite_wide_kernel(const ScanParams 
 // runs with one row per lane less than it would with the y slot).  The forward solve is then the reference's own recurrence
 // f <- phi o (f + W_{n-1} z_{n-1}), z_n = y_n - u_n'f (src/celerite_solver.jl:136-141) on the lane's COLUMN block (replicated in
 // the 16 DPP rows), its dot product one more 16-lane sum per step; thread 255 stages y_n - mu and sigma2_n.
-// GM (round 4): the forward pass of the step-by-step reverse mode for 96 .. 143 rows — what celerite_wide_kernel<RPL, 3> leaves for
-// RPL <= 6: v - q of all 16 RPL slots and D_n of every step, S_n (lane layout) at the checkpoints n = k * ckpt_every.
-template <int RPL, bool YC = false, bool GM = false>
+// SM (round 4): the MODEs of celerite_wide_kernel on this kernel — 1: the factor (W_n, D_n, forward-solved z_n) goes to HBM for the
+// prediction; 2: simulation (the noise rides where y would); 3: the forward pass of the step-by-step reverse mode (v - q of all 16 RPL
+// slots and D_n of every step, S_n at the checkpoints n = k * ckpt_every).  These carry 96 .. 143 rows, and 64 .. 95 faster than before.
+template <int RPL, bool YC = false, int SM = 0>
 __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams p)
 {
-    static_assert(!(YC && GM), "the reverse pass expects y as the last row slot");
+    static_assert(!(YC && SM), "the store / simulate / gradient modes expect y as the last row slot");
+    constexpr bool GM = SM == 3;
     constexpr int NS = 16 * RPL;                      // row slots; the last one is the y row
     // LDS pitch of a lane's block of RPL slots.  A pitch of 8 doubles = 16 dwords puts four of the 16 lanes of a DPP row on each
     // bank pair when they read element c of their blocks (RPL = 8 ran slower than RPL = 9: 13.0 vs 11.0 ms at N = 8192 once padded);
@@ -463,6 +465,7 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
             src[1] = p.S2 ? p.S2 + b * N : tabb + 3 * Rp + 1;
             stride[0] = stride[1] = p.Y ? 1 : p.rec_stride;
             last[0] = last[1] = p.Y ? N - 1 : N;
+            if constexpr (SM == 2) { src[0] = p.noise + b * N; stride[0] = 1; last[0] = N - 1; }   // the noise rides where y would
             src[2] = tabb + 2 * Rp + (R + 1);
             stride[2] = p.rec_stride;
         } else if (tid < R) {
@@ -542,14 +545,35 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
     if constexpr (LAZY) {   // step 0's (v - q) = v_0 of every slot, where step 1 looks for the previous step's exchange values
         if (tid < NS) sh_num[0][sa_] = sh_rec[0][NSP + sa_];
     }
-    [[maybe_unused]] auto emit = [&](int64_t n) __attribute__((always_inline)) {
-        if (l == 0) {
+    [[maybe_unused]] auto emit = [&](int64_t n) __attribute__((always_inline)) {   // (as celerite_wide_kernel's)
+        if constexpr (SM == 1) {
+            if (l == 0) {
 #pragma unroll
-            for (int i = 0; i < RPL; ++i) p.st_w[(b * N + n) * NS + g * RPL + i] = num[i];
-            if (yrow) p.st_d[b * N + n] = Dn;
+                for (int i = 0; i < RPL; ++i)
+                    if (g * RPL + i < R) p.st_w[(b * N + n) * R + g * RPL + i] = num[i] * rD;
+                if (yrow) {
+                    p.st_d[b * N + n] = Dn;
+                    p.st_z[b * N + n] = num[YS];
+                }
+            }
+        }
+        if constexpr (SM == 2) {
+            if (yrow) {
+                const double yn = sh_rec[n & 1][NSP + 15 * PITCH + YS];   // q_n - mu
+                const double x = sqrt(Dn) * (yn + mu);                    // x_n = sqrt(D_n) q_n      :539,546
+                if (l == 0) p.ysim[b * N + n] = x + (yn - num[YS]);       // x_n + u_n'f  (num = v - u'f)
+                num[YS] = x;                                              // what the extra row adds next step: W_n x_n   :543
+            }
+        }
+        if constexpr (SM == 3) {
+            if (l == 0) {
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) p.st_w[(b * N + n) * NS + g * RPL + i] = num[i];
+                if (yrow) p.st_d[b * N + n] = Dn;
+            }
         }
     };
-    if constexpr (GM) emit(0);
+    if constexpr (SM != 0) emit(0);
     stage(1, gv[1 % DG]);
     fetch(DG + 1, gv[1 % DG]);
     __syncthreads();
@@ -666,7 +690,7 @@ __global__ void __launch_bounds__(256, 1) celerite_wide2_kernel(const ScanParams
             Pe += ex;
         }
         quad = fma(z * z, rD, quad);                             // z_n^2 / D_n  (== y'K^-1 y, :333)
-        if constexpr (GM) emit(n);
+        if constexpr (SM != 0) emit(n);
     };
 
     int64_t n = 1;
@@ -1452,8 +1476,9 @@ __global__ void __launch_bounds__(256) grad_finish_kernel(const ScanParams p, in
 // wavefront per SIMD with the 512-register budget — the reference's own benchmark grid goes up to j = 64 terms = 128 rows
 // (benchmark/benchmarks.jl:16-18), which used to fall to the HBM-resident any-rank kernel.
 int pioran_wide_supported_rows() { return 143; }
-// ... the store (prediction), simulate and gradient-forward modes exist for the shapes of rounds 1-2 only
-int pioran_wide_supported_rows_modes() { return 95; }
+// ... the store (prediction) and simulate modes: on the lean kernel since round 4 (the prediction's sweeps hold two rows per lane: 128)
+int pioran_wide_supported_rows_modes() { return 143; }
+int pioran_predict_supported_rows() { return 128; }
 // the step-by-step reverse mode: RPL 7 .. 9 since round 4 (forward pass: the lean kernel with GM)
 int pioran_wide_supported_rows_grad() { return 143; }
 
@@ -1464,7 +1489,6 @@ template <int MODE>
 static int launch_wide_mode(const ScanParams& p, hipStream_t stream)
 {
     if (!p.tab || p.R > 143 || p.B <= 0 || p.B > 0x7fffffffLL) return PIORAN_ERR_UNSUPPORTED;
-    if (MODE != 0 && p.R > 95) return PIORAN_ERR_UNSUPPORTED;   // store / simulate / gradient modes: up to 95 rows
     const dim3 grid((unsigned)p.B), block(256);
     if constexpr (MODE == 0) {
         // the lean form: from 48 rows on (tools/sweep_wide.py, N = 8192: R = 48 6.0 -> 5.7 ms, 80 9.1 -> 7.5, 94 9.4 -> 7.6; below
@@ -1492,6 +1516,19 @@ static int launch_wide_mode(const ScanParams& p, hipStream_t stream)
             case 7: hipLaunchKernelGGL(celerite_wide2_kernel<7>, grid, block, 0, stream, p); break;
             case 8: hipLaunchKernelGGL(celerite_wide2_kernel<8>, grid, block, 0, stream, p); break;
             default: hipLaunchKernelGGL(celerite_wide2_kernel<9>, grid, block, 0, stream, p); break;
+            }
+            return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+        }
+    }
+    if constexpr (MODE == 1 || MODE == 2) {
+        // store / simulate on the lean kernel: 96 .. 143 rows (round 4), and from 64 rows on (where the windowed kernels end) unless `no_wide2`
+        if (p.tab_draw_stride == 0 && p.npd_rows == 0 && (p.R > 95 || (p.R >= 64 && !(p.opt && p.opt->no_wide2)))) {
+            switch ((p.R + 1 + 15) / 16) {
+            case 5: hipLaunchKernelGGL((celerite_wide2_kernel<5, false, MODE>), grid, block, 0, stream, p); break;
+            case 6: hipLaunchKernelGGL((celerite_wide2_kernel<6, false, MODE>), grid, block, 0, stream, p); break;
+            case 7: hipLaunchKernelGGL((celerite_wide2_kernel<7, false, MODE>), grid, block, 0, stream, p); break;
+            case 8: hipLaunchKernelGGL((celerite_wide2_kernel<8, false, MODE>), grid, block, 0, stream, p); break;
+            default: hipLaunchKernelGGL((celerite_wide2_kernel<9, false, MODE>), grid, block, 0, stream, p); break;
             }
             return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
         }
@@ -1578,9 +1615,9 @@ int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, dou
         // the lean reverse pass (celerite_adjoint2_kernel): always from 7 rows per lane on; below, by option (wide2 = 1: on, no_wide2: off)
         const bool lean = RPL >= 7 || (RPL >= 4 && !(p.opt && p.opt->no_wide2)) || (p.opt && p.opt->wide2);
         if constexpr (RPL >= 7) {
-            hipLaunchKernelGGL((celerite_wide2_kernel<RPL, false, true>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((celerite_wide2_kernel<RPL, false, 3>), grid, block, 0, stream, p);
         } else if constexpr (RPL >= 4) {   // (64 .. 95 rows: the lean forward kernel is the faster one, 9.0 against 13.1 ms at 80 rows)
-            if (lean) hipLaunchKernelGGL((celerite_wide2_kernel<RPL, false, true>), grid, block, 0, stream, p);
+            if (lean) hipLaunchKernelGGL((celerite_wide2_kernel<RPL, false, 3>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((celerite_wide_kernel<RPL, 3>), grid, block, 0, stream, p);
         } else {
             hipLaunchKernelGGL((celerite_wide_kernel<RPL, 3>), grid, block, 0, stream, p);

@@ -129,7 +129,8 @@ int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, dou
                                  double* grad_nu, double* grad_mu, hipStream_t stream, hipStream_t aux, hipEvent_t* ev /*[5]*/);
 int pioran_wide_supported_rows();
 int pioran_wide_supported_rows_grad();    // step-by-step reverse mode (143)
-int pioran_wide_supported_rows_modes();   // store / simulate / gradient modes of the latency kernel (95)
+int pioran_wide_supported_rows_modes();   // store / simulate modes of the latency kernels (143)
+int pioran_predict_supported_rows();      // step-by-step prediction (128: celerite_predict.hip)
 int64_t pioran_wide_max_batch();
 // celerite_block.hip: windowed form (16 steps per window on the matrix cores), one draw per workgroup; shared (c, d) without
 // per-draw rows; its own table (fragment order), built once per prepared (c, d)

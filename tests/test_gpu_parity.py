@@ -1404,6 +1404,42 @@ def test_predict_full_size(ctx, full_size):
         assert np.max(np.abs(got[i] - ref)) <= 1e-8 * max(1.0, np.max(np.abs(ref)))
 
 
+@pytest.mark.parametrize("J,N,B", [(32, 90, 3), (40, 130, 2), (47, 61, 2), (48, 77, 3), (56, 40, 2), (64, 100, 2), (71, 50, 2)])
+def test_predict_and_simulate_64_to_143_rows(ctx, J, N, B):
+    """64 .. 143 rows (past the windowed kernels): posterior mean and simulation from the factor the LEAN latency kernel stores
+    (celerite_wide2_kernel<RPL, false, 1 | 2>, round 4).  Before: 95 rows at most, on the round-1 kernel, which stays behind `no_wide2`.
+    The reference benchmark grid's largest model (j = 64: 128 rows) is in; the prediction's sweeps hold two rows per lane, so 142 rows
+    have a simulation and a gradient but no posterior mean (PIORAN_ERR_UNSUPPORTED, before any workspace is taken)."""
+    rng = np.random.default_rng(4200 + J)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    tau = np.sort(np.concatenate([rng.uniform(t[0] - 5, t[-1] + 5, 60), t[[0, N // 2, N - 1]]]))
+    ds = pj.Dataset(t, y, s2, ctx)
+    q = rng.standard_normal((B, N))
+    ys = ctx.simulate(A, Bc, C, Dd, t, s2, q)
+    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "wide (step-by-step simulation)"
+    for i in range(B):
+        ref = O.sim(A[i], Bc[i], C, Dd, t, s2, q[i])
+        assert np.max(np.abs(ys[i] - ref)) <= 1e-10 * np.max(np.abs(ref))
+    if 2 * J > 128:
+        with pytest.raises(pj._lib.PioranHipError):
+            ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu)
+        return
+    got, st = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu, return_status=True)
+    assert (st == 0).all() and pj._lib.lib().pioran_celerite_config_name(-1).decode() == "wide (step-by-step prediction)"
+    for i in range(B):
+        ref = O.predict(A[i], Bc[i], C, Dd, tau, t, y - mu[i], nu[i] * s2) + mu[i]
+        np.testing.assert_allclose(got[i], ref, rtol=1e-9, atol=1e-10)
+    if 2 * J <= 95:
+        try:
+            ctx.set_option("no_wide2", True)
+            old = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu)
+            ys_old = ctx.simulate(A, Bc, C, Dd, t, s2, q)
+        finally:
+            ctx.set_option("no_wide2", False)
+        np.testing.assert_allclose(got, old, rtol=1e-11, atol=1e-12)
+        assert np.max(np.abs(ys - ys_old)) <= 1e-12 * np.max(np.abs(ys_old))
+
+
 def test_simulate_matches_oracle(ctx, golden_dir):
     """simulate / rand: y = L D^(1/2) q for the same normals q as the oracle's `sim` (src/celerite_solver.jl:515-549)."""
     A = np.loadtxt(golden_dir / "simu.txt")
