@@ -223,3 +223,55 @@ def test_fuzz_per_draw_prediction_simulation_and_dense_batches(capsys):
     with capsys.disabled():
         print(f"\nper-draw prediction / simulation and dense batch fuzz: 120 cases, worst deviation from the one-at-a-time paths {worst}", file=sys.stderr)
     assert worst["dev"] < 1e-8, worst
+
+
+def test_fuzz_64_to_143_rows_gradient_prediction_simulation_vs_oracle(capsys):
+    """Randomized shapes past the windowed kernels (round 4: lean latency kernel with stores, lean reverse pass): 40 seeded cases —
+    32..71 terms, some of them one-row terms (64..142 rows), N = 1..300 over one and several checkpoint segments, 1..3 draws —
+    value + gradient against the complex-step oracle, posterior mean (up to 128 rows) and simulation against the oracle's `pred` / `sim`."""
+    import numpy as np
+    import pioran_jl_amd as pj
+    from oracle import oracle as O
+    ctx = pj.Context(0)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    worst = {"grad": 0.0, "pred": 0.0, "sim": 0.0}
+    edges = (1, 2, 15, 16, 17, 31, 32, 33, 48, 65)
+    for idx in range(40):
+        rng = np.random.default_rng([20261006, idx])
+        J = int(rng.integers(32, 72)); B = int(rng.integers(1, 4))
+        N = int(edges[idx]) if idx < len(edges) else int(rng.integers(1, 301))
+        nreal = int(rng.integers(0, J // 3)) * int(rng.random() < 0.4)
+        while 2 * J - nreal < 64:
+            nreal -= 1
+        R = 2 * J - nreal
+        gaps = rng.uniform(0.05, 2.0, N)
+        if rng.random() < 0.3:
+            gaps[rng.integers(0, N, max(1, N // 20))] *= rng.uniform(5, 400)
+        t = np.cumsum(gaps); y = rng.standard_normal(N); s2 = rng.uniform(0.01, 0.1, N)
+        A = rng.uniform(0.1, 2.0, (B, J)) / J; Bc = rng.uniform(-0.05, 0.05, (B, J)) * A
+        C = rng.uniform(0.05, 2.0, J); Dd = rng.uniform(0.0, 3.0, J)
+        Bc[:, :nreal] = 0.0; Dd[:nreal] = 0.0
+        mu = rng.standard_normal(B) * 0.1; nu = rng.uniform(0.5, 2.0, B)
+        ds = pj.Dataset(t, y, s2, ctx)
+        g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert name() == "wide (step-by-step gradient)" and (g["status"] == 0).all(), (idx, name(), R)
+        ref_l = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu)
+        assert np.max(np.abs(g["logl"] - ref_l) / np.maximum(1.0, np.abs(ref_l))) < 1e-10, idx
+        ref = O.logl_grad(A[0], Bc[0], C, Dd, t, y - mu[0], nu[0] * s2, cd=True)
+        for k in ("grad_a", "grad_b", "grad_c", "grad_d"):
+            worst["grad"] = max(worst["grad"], float(np.max(np.abs(g[k][0] - ref[k])) / (1 + np.max(np.abs(ref[k])))))
+        q = rng.standard_normal((B, N))
+        ys = ctx.simulate(A, Bc, C, Dd, t, s2, q)
+        assert name() == "wide (step-by-step simulation)", idx
+        rs = O.sim(A[B - 1], Bc[B - 1], C, Dd, t, s2, q[B - 1])
+        worst["sim"] = max(worst["sim"], float(np.max(np.abs(ys[B - 1] - rs)) / np.max(np.abs(rs))))
+        if R <= 128:
+            tau = np.sort(np.concatenate([rng.uniform(t[0] - 5, t[-1] + 5, 40), t[[0, N - 1]]]))
+            got = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu)
+            assert name() == "wide (step-by-step prediction)", idx
+            rp = O.predict(A[0], Bc[0], C, Dd, tau, t, y - mu[0], nu[0] * s2) + mu[0]
+            worst["pred"] = max(worst["pred"], float(np.max(np.abs(got[0] - rp)) / max(1.0, np.max(np.abs(rp)))))
+        ds.close()
+    with capsys.disabled():
+        print(f"\n64..143-row fuzz: 40 cases, worst deviations from the oracle {worst}", file=sys.stderr)
+    assert worst["grad"] < 1e-8 and worst["pred"] < 1e-8 and worst["sim"] < 1e-9, worst
