@@ -633,6 +633,17 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
     da_ = np.ones(J)
     dref = O.logl_dir(Ag[0], Bg[0], Cg, Dg, t, y - mu[0], nu[0] * s2, da=da_)
     grad["directional_check_rel_vs_complex_step_oracle"] = float(abs(gg["grad_a"][0].sum() - dref) / (1 + abs(dref)))
+    # ... and past the windowed kernels (step-by-step reverse mode, lean adjoint kernel of round 4): the dense configuration's model
+    # (SHO-40, 80 rows) and the reference benchmark grid's largest (j = 64, 128 rows; refused before round 4)
+    for Jg in (40, 64):
+        Aw, Bw, Cw, Dw = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:1, :3], f_min, f_max, Jg, theta[:1, 3], basis_function="SHO")
+        dsg.logl_grad(Aw, Bw, Cw, Dw, mu=mu[:1], nu=nu[:1])
+        kern = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+        wall, wv = [], []
+        for _ in range(2):
+            t0 = time.perf_counter(); dsg.logl_grad(Aw, Bw, Cw, Dw, mu=mu[:1], nu=nu[:1]); wall.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); dsg.logl_batch(Aw, Bw, Cw, Dw, mu=mu[:1], nu=nu[:1]); wv.append(time.perf_counter() - t0)
+        grad[f"sho{Jg}_rows{2 * Jg}_chains_1"] = {"value_and_gradient_abcd_mu_nu_ms_incl_pcie": min(wall) * 1e3, "value_ms_incl_pcie": min(wv) * 1e3, "kernel": kern}
     dsg.close()
     out[f"gradient_sho{J}_N{N}"] = grad
 

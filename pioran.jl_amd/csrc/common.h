@@ -194,7 +194,7 @@ int pioran_launch_approx(int64_t B, int model, int P, int J, int basis, int inte
 int pioran_launch_fma_stream(int blocks, int iters, double* scratch, double* flop, hipStream_t stream);
 // dense.hip
 // doubles behind a slab: 1024 (the four 16 x 16 inverses of the current diagonal block) + 4 x 4096 (dense_step_kernel's tile snapshots)
-#define PIORAN_DENSE_WS (1024 + 4 * 4096)
+#define PIORAN_DENSE_WS (1024 + 4 * 4096 + 1024)   // inverse copies | tile snapshots | flags of the persistent-chain prototype
 void pioran_dense_dims(int64_t N, int64_t* Mp, int64_t* ld);
 int pioran_dense_nll_device(int64_t N, int32_t J, const double* a, const double* b, const double* c,
                             const double* d, const double* t, const double* y, const double* s2,

@@ -1051,6 +1051,35 @@ __device__ __forceinline__ void step_solve_role(double* __restrict__ A, int64_t 
     }
 }
 
+// ---- prototype (round 4, DenseOptions::old_chain == 5): the chain without kernel boundaries -------------------------------------------
+// One persistent workgroup (dense_crit_chain_kernel, on a second stream) runs the CRIT role of every step; the step launches carry DIAG2,
+// the strips and the bulk only.  Hand-offs through flags in device memory (release: fence + atomic add; acquire: atomic load + fence):
+//   factored[k]  posted by CRIT(k-1) once block k is factored and its inverses are parked — DIAG2 and the strips of launch k wait for it;
+//   ready[k]     posted by STRIP(row k+1) and DIAG2 of launch k-1 (they leave tile (k+1, k) and the diagonal tile (k+1, k+1) one panel
+//                short) — CRIT(k) waits for both.
+// Only the bulk-side consumers wait on the chain's flag; the chain waits for two workgroups that started a whole step earlier.  Every wait
+// is bounded (kFlagSpinLimit polls): on expiry the workgroup reports info = -7 and leaves, so a lost hand-off cannot hang the device.
+constexpr int kFlagSpinLimit = 1 << 19;
+constexpr int FLG_FACTORED = 0, FLG_READY = 128;
+__device__ __forceinline__ bool flag_wait(int* f, int need, int32_t* info, int* sh_ok, int tid, bool fence = true)
+{
+    if (tid == 0) {
+        int it = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++it < kFlagSpinLimit) __builtin_amdgcn_s_sleep(1);
+        *sh_ok = it < kFlagSpinLimit;
+        if (it >= kFlagSpinLimit) *info = -7;
+    }
+    __syncthreads();
+    if (fence) __threadfence();                          // acquire (every wavefront: its own view of L1 / L2)
+    return *sh_ok != 0;
+}
+__device__ __forceinline__ void flag_post(int* f, int tid, bool fence = true)
+{
+    if (fence) __threadfence();                          // release: this workgroup's stores are visible device-wide before the flag is
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // What the bulk role of one launch does: panels pcb .. pcb + kp - 1 (block columns; all final) onto the tiles (ti >= tj) of the trailing matrix
 // whose origin is block column org, tiles in COLUMN order (id -> (tj, ti)), ids id0 .. id0 + cnt - 1 (id 0 = tile (0, 0): DIAG2's, never listed).
 constexpr int kStepBulkBuffers = 6;   // operand k-steps in flight in dense_step_kernel's bulk tiles (mostly one wavefront per SIMD there)
@@ -1060,12 +1089,13 @@ struct StepBulk {
 };
 template <int KP>   // depth of the bulk role's update in panels (one instantiation per depth: both tile bodies in one kernel cost 14 spilled registers)
 __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__ A, int64_t ld, int64_t Mp, int k,
-                                                            int32_t* __restrict__ info, int bx0, int nprev, StepBulk bulk)
+                                                            int32_t* __restrict__ info, int bx0, int nprev, StepBulk bulk, int* flg)
 {
     __shared__ double Sh[NB * LP + 4 * 16 * 64];
     double* Ls = Sh;                     // the diagonal tile being factored (CRIT)
     double* Xq = Sh + NB * LP;           // the solved rows of the operand tile: [piece of 16 rows][s * 4 + g][lane]
     __shared__ int flag;
+    __shared__ int sh_ok;
     const int nb = (int)(Mp / NB);
     const int tid = threadIdx.x;
     const int nstrip = nb - k - 1;                      // row tiles k+2 .. nb
@@ -1083,9 +1113,13 @@ __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__
         __builtin_amdgcn_s_setprio(3);
         step_solve_role<true>(A, ld, Mp, k, k + 1, k + 1, true, 0, Ls, Xq, &flag, info, tid);
     } else if (bx == 1) {
+        if (flg && k >= 1 && !flag_wait(flg + FLG_FACTORED + k, 1, info, &sh_ok, tid)) return;
         if (k + 2 < nb) step_solve_role<false>(A, ld, Mp, k, k + 2, k + 2, false, nprev, Ls, Xq, &flag, info, tid);
+        if (flg) flag_post(flg + FLG_READY + k + 1, tid);
     } else if (bx < 2 + nstrip) {
+        if (flg && k >= 1 && !flag_wait(flg + FLG_FACTORED + k, 1, info, &sh_ok, tid)) return;
         step_solve_role<false>(A, ld, Mp, k, k + bx, k + 1, true, nprev, Ls, Xq, &flag, info, tid);
+        if (flg && bx == 2) flag_post(flg + FLG_READY + k + 1, tid);
     } else {
         // ---- BULK: one tile per wavefront (schedule: dense_nll_impl) -----------------------------------------------------------------------
         // Measured alternatives to this role, none kept (profiles/r04_dense_steps_wg_tiles.txt, r04_dense_roles.txt): one tile per WORKGROUP
@@ -1102,6 +1136,28 @@ __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__
         const int ti = tj + id;
         if (bulk.halves) syrk_half_tile<KP, kStepBulkBuffers>(A, ld, (int64_t)bulk.pcb * NB, j0, ti, tj, w & 1, lane & 15, lane >> 4);
         else syrk_tile<KP, kStepBulkBuffers>(A, ld, (int64_t)bulk.pcb * NB, j0, ti, tj, lane & 15, lane >> 4);
+    }
+}
+
+// The persistent chain of the prototype: CRIT(0 .. nb-1) in one workgroup.
+// (launched with kChainPadLds bytes of dynamic LDS it never touches: no workgroup of a step launch then fits beside it, and the chain keeps
+//  its CU's DP pipes to itself — what the blank workgroup 256 achieves for the launched chain)
+constexpr int kChainPadLds = 56 * 1024;
+__global__ void __launch_bounds__(256, 1) dense_crit_chain_kernel(double* __restrict__ A, int64_t ld, int64_t Mp, int32_t* __restrict__ info, int* flg, int mode)
+{
+    __shared__ double Sh[NB * LP + 4 * 16 * 64];
+    double* Ls = Sh;
+    double* Xq = Sh + NB * LP;
+    __shared__ int flag;
+    __shared__ int sh_ok;
+    const int nb = (int)(Mp / NB);
+    const int tid = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);
+    for (int k = 0; k < nb; ++k) {
+        // mode (timing experiments; results may then be stale): bit 0 no release fence here, bit 1 no acquire fence here
+        if (k >= 1 && !flag_wait(flg + FLG_READY + k, 2, info, &sh_ok, tid, !(mode & 2))) return;
+        step_solve_role<true>(A, ld, Mp, k, k + 1, k + 1, true, 0, Ls, Xq, &flag, info, tid);
+        flag_post(flg + FLG_FACTORED + k + 1, tid, !(mode & 1));
     }
 }
 
@@ -1244,6 +1300,28 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
         constexpr int kHalfTileLimit = 1024;      // tiles per launch up to which every tile is split over two wavefronts
         int ks = 2;
         if (!dop.no_pairs) while (ks + 2 < nb && tiles_of(ks + 2) > kPairTiles) ks += 2;
+        // prototype: the chain as one persistent workgroup on a second stream (see flag_wait above); the step launches start at DIAG2
+        const bool persist = dop.old_chain >= 5 && dop.old_chain <= 8;
+        int* flg = persist ? reinterpret_cast<int*>(ws + WS_DOUBLES + 4 * SNAP_TILE) : nullptr;
+        static thread_local hipStream_t chain_stream = nullptr;
+        static thread_local hipEvent_t chain_ev[2] = {nullptr, nullptr};
+        if (persist) {
+            if (!chain_stream) {
+                if (hipStreamCreateWithFlags(&chain_stream, hipStreamNonBlocking) != hipSuccess) return PIORAN_ERR_HIP;
+                for (auto& e : chain_ev)
+                    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return PIORAN_ERR_HIP;
+            }
+            if (hipMemsetAsync(flg, 0, 1024 * sizeof(int), stream) != hipSuccess) return PIORAN_ERR_HIP;
+            (void)hipEventRecord(chain_ev[0], stream);
+            (void)hipStreamWaitEvent(chain_stream, chain_ev[0], 0);
+            static thread_local bool chain_attr = false;
+            if (!chain_attr) {
+                if (hipFuncSetAttribute((const void*)dense_crit_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainPadLds) != hipSuccess) return PIORAN_ERR_HIP;
+                chain_attr = true;
+            }
+            hipLaunchKernelGGL(dense_crit_chain_kernel, dim3(1), dim3(256), kChainPadLds, chain_stream, K, ld, Mp, info, flg, dop.old_chain - 5);
+            (void)hipEventRecord(chain_ev[1], chain_stream);
+        }
         for (int k = 0; k < nb; ++k) {
             const int nstrip = nb - k - 1;
             StepBulk bk{0, 1, 0, 0, 0, 0};
@@ -1274,10 +1352,12 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
             if (dop.old_chain == 2) grid = 1;
             else if (dop.old_chain == 3) { grid = (unsigned)(1 + nstrip); bx0 = 1; }
             else if (dop.old_chain == 4) { if (grid <= (unsigned)(2 + nstrip)) continue; grid -= (unsigned)(2 + nstrip); bx0 = 2 + nstrip; }
+            if (persist) { grid -= 1; bx0 = 1; }
             if (bx0 == 0 && grid > 256) ++grid;                  // the blank workgroup (see the kernel)
-            if (bk.kp == 2) hipLaunchKernelGGL(dense_step_kernel<2>, dim3(grid), dim3(256), 0, stream, K, ld, Mp, k, info, bx0, nprev, bk);
-            else hipLaunchKernelGGL(dense_step_kernel<1>, dim3(grid), dim3(256), 0, stream, K, ld, Mp, k, info, bx0, nprev, bk);
+            if (bk.kp == 2) hipLaunchKernelGGL(dense_step_kernel<2>, dim3(grid), dim3(256), 0, stream, K, ld, Mp, k, info, bx0, nprev, bk, flg);
+            else hipLaunchKernelGGL(dense_step_kernel<1>, dim3(grid), dim3(256), 0, stream, K, ld, Mp, k, info, bx0, nprev, bk, flg);
         }
+        if (persist) (void)hipStreamWaitEvent(stream, chain_ev[1], 0);
         if (phase_ev) (void)hipEventRecord(phase_ev[1], stream);
         hipLaunchKernelGGL(dense_finish_kernel, dim3(1, 1, 1), dim3(256), 0, stream, K, ld, N, Mp, out, info, bt);
         if (phase_ev) (void)hipEventRecord(phase_ev[2], stream);

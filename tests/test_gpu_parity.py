@@ -764,10 +764,14 @@ def test_dense_one_launch_per_block_column_equals_the_panel_update_chain(ctx, N)
         single, i2 = ctx.dense_nll(a, b, c, d, t, y, s2, return_info=True)
         ctx.set_option("dense_no_pairs", False); ctx.set_option("dense_no_halves", True)
         whole, i3 = ctx.dense_nll(a, b, c, d, t, y, s2, return_info=True)
+        # the persistent-chain prototype (one resident workgroup runs the critical role of every step; flags instead of kernel boundaries
+        # on the chain; every wait bounded): measured slower, kept as an option — same arithmetic, same bits
+        ctx.set_option("dense_no_halves", False); ctx.set_option("dense_old_chain", 5)
+        pers, i4 = ctx.dense_nll(a, b, c, d, t, y, s2, return_info=True)
     finally:
         ctx.set_option("dense_old_chain", 0); ctx.set_option("dense_no_pairs", False); ctx.set_option("dense_no_halves", False)
-    assert i0 == i1 == i2 == i3 == 0
-    assert abs(new - old) <= 1e-12 * abs(old) and abs(single - old) <= 1e-12 * abs(old) and whole == new
+    assert i0 == i1 == i2 == i3 == i4 == 0
+    assert abs(new - old) <= 1e-12 * abs(old) and abs(single - old) <= 1e-12 * abs(old) and whole == new and pers == new
     if N <= 1000:
         ref = O.dense_nll(a, b, c, d, t, y, s2)
         assert abs(new - ref) <= 1e-11 * abs(ref)
