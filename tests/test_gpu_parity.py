@@ -1909,3 +1909,16 @@ def test_gradient_shifted_log_flux_model(ctx, golden_dir):
     # y - c <= 0: status 2, as in the value-only entry
     bad = ds.logl_grad(A[:1], Bc[:1], C, Dd, mu=mu[:1], nu=nu[:1], shift=[y.min() + 1.0])
     assert bad["status"][0] == 2 and np.isnan(bad["logl"][0])
+    # the same model with 36 and 52 components (72 / 104 rows): the step-by-step reverse mode with per-draw series (lean kernels, round 4)
+    for Jw in (36, 52):
+        A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, P[:2, :3], f_min, f_max, Jw, P[:2, 3], is_integrated_power=False)
+        g = ds.logl_grad(A, Bc, C, Dd, mu=mu[:2], nu=nu[:2], shift=cs[:2])
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "wide (step-by-step gradient)" and (g["status"] == 0).all()
+        assert relerr(g["logl"], ds.logl_batch(A, Bc, C, Dd, mu=mu[:2], nu=nu[:2], shift=cs[:2])) < 1e-11
+        for i in range(2):
+            v = y - cs[i]
+            Yt, St = np.log(v), yerr ** 2 / v ** 2
+            ref = O.logl_dir(A[i], Bc[i], C, Dd, t, Yt - mu[i], nu[i] * St, dy=-1 / v, ds2=nu[i] * 2 * yerr ** 2 / v ** 3)
+            assert abs(g["grad_shift"][i] - ref) <= 1e-8 * (1 + abs(ref)), (Jw, g["grad_shift"][i], ref)
+            gn = O.logl_dir(A[i], Bc[i], C, Dd, t, Yt - mu[i], nu[i] * St, ds2=St)
+            assert abs(g["grad_nu"][i] - gn) <= 1e-8 * (1 + abs(gn))
