@@ -42,6 +42,13 @@
 #include <type_traits>
 
 // Diagnostic hooks: compiled out in the product; tools/block_probe.hip defines them to s_memtime accumulators.
+#ifndef PIORAN_ASTAMP
+// (celerite_block_adjoint_kernel: the phase boundaries are scheduling fences in the product as well — left to itself the compiler moves the
+//  loads that are issued in one phase to land during the next back to their uses: 6.2 instead of 4.7 ms per 625 windows)
+#define PIORAN_ASTAMP(i) __builtin_amdgcn_sched_barrier(0)
+#define PIORAN_ASTAMP_DECL
+#define PIORAN_ASTAMP_FLUSH
+#endif
 #ifndef PIORAN_BSTAMP
 #define PIORAN_BSTAMP(i)
 #define PIORAN_BSTAMP_DECL
@@ -367,6 +374,20 @@ __device__ __forceinline__ void dma_pieces(const double* gsrc, double* ldst, int
     for (int c = w; c < npieces; c += nwaves)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + c * 128 + lane * 2),
                                          (__attribute__((address_space(3))) void*)(ldst + c * 128), 16, 0, 0);
+}
+// The same as inline assembly: the compiler's wait-count pass does not see an LDS write here.  With the builtin it puts s_waitcnt vmcnt(0) in
+// front of LDS reads it cannot tell apart from the DMA's target (celerite_block_adjoint_kernel: in front of nearly every LDS read of one of the
+// two copies of its window body — the DMA of the NEXT window's block was waited for at once).  The caller owns the ordering: every read of the
+// target comes after an explicit s_waitcnt vmcnt(0) + barrier (PIORAN_BLK_BARRIER_DMA).  vmcnt stays conservative for the compiler's own
+// loads: the counter retires in order, an unaccounted operation in flight can only make a wait longer.
+__device__ __forceinline__ void dma_pieces_asm(const double* gsrc, double* ldst, int npieces, int w, int nwaves, int lane)
+{
+    const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)ldst;
+    for (int c = w; c < npieces; c += nwaves) {
+        const double* g = gsrc + c * 128 + lane * 2;
+        const unsigned l = __builtin_amdgcn_readfirstlane(lbase + (unsigned)c * 1024u);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+    }
 }
 // workgroup barrier that publishes LDS writes but leaves LDS DMAs / global loads in flight (__syncthreads() would drain them)
 #define PIORAN_BLK_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -1159,6 +1180,7 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
     // pair contraction threads: TPT threads per term, each a subset of the 120 pairs
     static_assert(TPT == 8 || TPT == 4, "TPT * J <= 256 threads");
     const bool ethread = tid < TPT * J;
+    const bool ewave = 64 * w < TPT * J;           // this wavefront has contraction threads (wave-uniform)
     const int et = tid / TPT, es = tid - et * TPT;
     double acc_ga = 0.0, acc_gb = 0.0;
     [[maybe_unused]] double acc_gc = 0.0, acc_gd = 0.0, acc_c = 0.0, acc_d = 0.0;
@@ -1169,63 +1191,155 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
     for (int I = 0; I < NB; ++I) Tb[I] = d4{0.0, 0.0, 0.0, 0.0};
     double acc_al = 0.0, acc_be = 0.0, acc_mu = 0.0, acc_sa = 0.0, acc_nu = 0.0;
 
-    // Loads are software-pipelined by hand: what phase A of a window needs (Q in both layouts, C o v, C o x; the chain wavefront's K and
-    // sigma2) is fetched one window ahead into a second register set; T_k, M', C_K and the pair table of the window itself are
-    // issued right after phase A's matrix instructions and land during the barrier waits.  Barriers wait for LDS only.
+    // Where a window's operands come from.  NB <= 3 (round 4): the block the forward pass left for the window — T | M' | Q | Q (A order) | K,
+    // 4864 doubles at three block columns — is copied verbatim into LDS by the LDS DMA (38 pieces of 1 KB, spread over the four wavefronts,
+    // no registers) one window ahead, two buffers; the owners read Q at the top of phase A, M' in phase C and T in phase D from there.
+    // Before: ~70 global loads per lane and window — more than the 63 a wavefront can have in flight, so issuing them took a memory latency
+    // (3700 cycles of the window's 15 000, tools/block_adjoint_probe.hip) and phase C waited another one for M' and the pair table.
+    // What stays a global load: C o v, C o x and sigma2 (one window ahead, in registers), C_K, the d/d(c, d) extras and the pair table
+    // (issued at the top of their window, used in phases C and D).  NB = 4: everything through registers as in round 3.
+    constexpr bool DMA = NB <= 3;
+    constexpr int GWL = NB * NB * 256 + 3 * NB * 256 + 256;      // doubles of the block the reverse pass reads (a whole number of 1 KB pieces)
+    static_assert(GWL % 128 == 0, "whole DMA pieces");
+    __shared__ double gwl0[DMA ? GWL : 2], gwl1[DMA ? GWL : 2];   // two arrays, selected at compile time: reads of one never wait for the DMA into the other
     constexpr int EPT = 15;    // pairs per contraction thread with eight threads per term (up to 32 terms): prefetched; beyond, read in the loop
-    double qf[NB][4], qw[4], cvc[4], cxc[4];
+    double qf[DMA ? 1 : NB][4], qw[4], cvc[4], cxc[4];
     d4 kf = {0.0, 0.0, 0.0, 0.0};
     double s2w = 0.0;
-    auto fetch_a = [&](int64_t kk, double (&qf_)[NB][4], double (&qw_)[4], double (&cvc_)[4], double (&cxc_)[4], d4& kf_, double& s2w_) __attribute__((always_inline)) {
+    [[maybe_unused]] double ttw = 0.0;
+    auto fetch_a = [&](int64_t kk, double (&qf_)[DMA ? 1 : NB][4], double (&qw_)[4], double (&cvc_)[4], double (&cxc_)[4], d4& kf_, double& s2w_, double& ttw_) __attribute__((always_inline)) {
         const double* gwk = gwb + kk * GWS;
         const double* grec = gtab + kk * GS;
         if (owner) {
+            if constexpr (!DMA) {
 #pragma unroll
-            for (int I = 0; I < NB; ++I)
+                for (int I = 0; I < NB; ++I)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qf_[I][ks] = gwk[OFF_QF + (I * 4 + ks) * 64 + lane];
+                    for (int ks = 0; ks < 4; ++ks) qf_[I][ks] = gwk[OFF_QF + (I * 4 + ks) * 64 + lane];
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                qw_[g] = gwk[OFF_Q + (w * 4 + g) * 64 + lane];
+                if constexpr (!DMA) qw_[g] = gwk[OFF_Q + (w * 4 + g) * 64 + lane];
                 cvc_[g] = grec[(w * 4 + g) * 64 + lane];
                 cxc_[g] = grec[NB * 256 + (w * 4 + g) * 64 + lane];
             }
         }
         if (chain) {
+            if constexpr (!DMA) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) kf_[g] = gwk[OFF_K + g * 64 + lane];
+                for (int g = 0; g < 4; ++g) kf_[g] = gwk[OFF_K + g * 64 + lane];
+            }
             const int64_t n = kk * KW + c16;
             s2w_ = p.S2 ? (n < N ? p.S2[b * N + n] : 0.0) : grec[2 * NB * 256 + 16 * NB + c16];   // per-draw series: the shifted log-flux models
+            if constexpr (CD && DMA) ttw_ = grec[OFF_TM + c16];   // the window's time stamps -> sh.tt in phase B (a window ahead: behind the DMA pieces
+                                                                  // in the in-order counter, a load of the window itself would make phase B wait for them)
         }
     };
     // (four block columns with d/d(c, d): no second register set — the kernel would spill 133 registers — the phase-A operands are
     //  fetched at the top of their own window)
     constexpr bool PF = !(NB == 4 && CD);
-    if constexpr (PF) fetch_a(NW - 1, qf, qw, cvc, cxc, kf, s2w);
-    for (int64_t k = NW - 1; k >= 0; --k) {
+    if constexpr (DMA) dma_pieces_asm(gwb + (NW - 1) * GWS, gwl0, GWL / 128, w, 4, lane);
+    if constexpr (PF) fetch_a(NW - 1, qf, qw, cvc, cxc, kf, s2w, ttw);
+    PIORAN_ASTAMP_DECL
+    // one window; BC: which of the two LDS buffers holds its block (alternates from window to window)
+    auto window = [&](int64_t k, auto BC) __attribute__((always_inline)) {
+        constexpr int BI = decltype(BC)::value;
+        [[maybe_unused]] const double* cur = BI ? gwl1 : gwl0;
+        [[maybe_unused]] double* nxt = BI ? gwl0 : gwl1;
+        PIORAN_ASTAMP(0);
         const int par = (int)(k & 1);
-        if constexpr (!PF) fetch_a(k, qf, qw, cvc, cxc, kf, s2w);
+        if constexpr (!PF) fetch_a(k, qf, qw, cvc, cxc, kf, s2w, ttw);
         const double* gwk = gwb + k * GWS;
         const double* grec = gtab + k * GS;
         const int64_t n0 = k * KW;
-        // ---- A: X-' = 2 Q' T-, the partial Q' T- Q, U~' ---------------------------------------------------------------
+        [[maybe_unused]] double ttv;
+        if constexpr (DMA) {
+            PIORAN_BLK_BARRIER_DMA();   // B0: this window's block has landed (every wavefront's pieces); everybody is done with the other buffer
+            PIORAN_ASTAMP(9);
+        }
+        // ---- this window's own operands (global), and the next window's phase-A operands ----
+        double ckc, ckr[NB][4];
+        double2 ev[EPT];
+        [[maybe_unused]] double hv[4], hx[4], tn[4], tbw, tew;
+        [[maybe_unused]] double tk[DMA ? 1 : NB][4], mwg[4];
+        const double2* Ewin = reinterpret_cast<const double2*>(btab + k * RSB + TSP) + (ethread ? et : 0) * 128;
+        // (no default values on anything loaded under a branch: `x = 0; if (owner) x = load` costs an s_waitcnt vmcnt(0) at the join — measured:
+        //  3000 cycles per window in the middle of the issue, tools/block_adjoint_probe.hip; idle contraction threads load clamped addresses)
+        auto issue_window_loads = [&]() __attribute__((always_inline)) {
+            if constexpr (CD) {
+                if (owner) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        hv[g] = grec[OFF_H + (w * 4 + g) * 64 + lane];
+                        hx[g] = grec[OFF_H + NB * 256 + (w * 4 + g) * 64 + lane];
+                        tn[g] = grec[OFF_TM + 4 * g + q];
+                    }
+                    tbw = grec[OFF_TM + 16];
+                    tew = grec[OFF_TM + 17];
+                }
+                if constexpr (!DMA) {
+                    if (chain) ttv = grec[OFF_TM + c16];   // -> sh.tt in phase B (read by the contraction threads after barrier 2); with four block
+                }                                          //    columns the chain wavefront is an owner as well
+            }
+            if (owner) {
+                if constexpr (!DMA) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mwg[g] = gwk[OFF_M + (w * 4 + g) * 64 + lane];
+                }
+                ckc = grec[2 * NB * 256 + 16 * w + c16];
+#pragma unroll
+                for (int I = 0; I < NB; ++I)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        ckr[I][g] = grec[2 * NB * 256 + 16 * I + 4 * g + q];
+                        if constexpr (!DMA) tk[I][g] = gwk[((w * NB + I) * 4 + g) * 64 + lane];
+                    }
+            }
+        };
+        // pair table of the window: fifteen entries per contraction thread are in flight at a time — all of a thread's pairs with eight
+        // threads per term (up to 32 terms); with four (more terms: DRWCelerite-20 has 40) the second fifteen are fetched into the same
+        // registers while phase C runs and contracted in phase D.  (NB <= 3: issued after barrier 1 — 41 KB at J = 20, the issuer stalls
+        // ~1000 cycles on the CU's memory path, and that is when the owners wait for the chain wavefront anyway)
+        auto issue_pair_table = [&]() __attribute__((always_inline)) {
+            if (ewave) {
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int pp = es + i * TPT;
+                    ev[i] = Ewin[pp < 120 ? pp : 119];
+                }
+            }
+        };
+        PIORAN_ASTAMP(10);
+        // ---- A: X-' = 2 Q'T-, the partial Q' T- Q, U~' ---------------------------------------------------------------
         double xb[4], uw[4];
         if (owner) {
-            d4 qt = {0.0, 0.0, 0.0, 0.0};
+            // (one accumulator per block column: NB chains of four dependent matrix instructions instead of one of 4 NB)
+            d4 qtI[NB];
 #pragma unroll
-            for (int I = 0; I < NB; ++I)
+            for (int I = 0; I < NB; ++I) qtI[I] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qt = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[I][ks], Tb[I][ks], qt, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {
+                    double qfv;
+                    if constexpr (DMA) qfv = cur[OFF_QF + (I * 4 + ks) * 64 + lane]; else qfv = qf[I][ks];
+                    qtI[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(qfv, Tb[I][ks], qtI[I], 0, 0, 0);
+                }
+            d4 qt = qtI[0];
+#pragma unroll
+            for (int I = 1; I < NB; ++I) qt += qtI[I];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                double qwv;
+                if constexpr (DMA) qwv = cur[OFF_Q + (w * 4 + g) * 64 + lane]; else qwv = qw[g];
                 xb[g] = 2.0 * qt[g];
                 if (ycol) {
-                    xb[g] -= qw[g];
+                    xb[g] -= qwv;
                     if (n0 + 4 * g + q < N) {
                         acc_mu -= xb[g];
                         if (p.g_y) p.g_y[b * N + n0 + 4 * g + q] = xb[g];      // dL/dy_n (v_y = y_n - mu)
                     }
-                    sh.qy[4 * g + q] = qw[g];
+                    sh.qy[4 * g + q] = qwv;
                 }
                 uw[g] = fma(myab.x, cvc[g], myab.y * cxc[g]);
                 sh.tileU[par][w][(4 * g + q) * 18 + c16] = uw[g];
@@ -1235,69 +1349,49 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
             double qtT[4], qfw[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qtT[ks] = sh.scr[w][c16 * 18 + 4 * ks + q];
-            static_for<0, NB>([&](auto Ic) __attribute__((always_inline)) {
-                constexpr int I = decltype(Ic)::value;
-                if (w == I) {
+            if constexpr (DMA) {
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) qfw[ks] = qf[I][ks];
-                }
-            });
+                for (int ks = 0; ks < 4; ++ks) qfw[ks] = cur[OFF_QF + (w * 4 + ks) * 64 + lane];
+            } else {
+                static_for<0, NB>([&](auto Ic) __attribute__((always_inline)) {
+                    constexpr int I = decltype(Ic)::value;
+                    if (w == I) {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) qfw[ks] = qf[DMA ? 0 : I][ks];
+                    }
+                });
+            }
             d4 pw = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) pw = __builtin_amdgcn_mfma_f64_16x16x4f64(qfw[ks], qtT[ks], pw, 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) sh.P[w][g * 64 + lane] = pw[g];
         }
-        // ---- this window's own operands, and the next window's phase-A operands ----
-        double tk[NB][4], mw[4], ckc = 0.0, ckr[NB][4];
-        double2 ev[EPT];
-        [[maybe_unused]] double hv[4], hx[4], tn[4], tbw = 0.0, tew = 0.0;
-        if constexpr (CD) {
-            if (owner) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    hv[g] = grec[OFF_H + (w * 4 + g) * 64 + lane];
-                    hx[g] = grec[OFF_H + NB * 256 + (w * 4 + g) * 64 + lane];
-                    tn[g] = grec[OFF_TM + 4 * g + q];
-                }
-                tbw = grec[OFF_TM + 16];
-                tew = grec[OFF_TM + 17];
-            }
-            if (chain && lane < 16) sh.tt[par][lane] = grec[OFF_TM + lane];   // (read by the contraction threads after barrier 2, up to the end of the window)
-        }
-        if (owner) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) mw[g] = gwk[OFF_M + (w * 4 + g) * 64 + lane];
-            ckc = grec[2 * NB * 256 + 16 * w + c16];
-#pragma unroll
-            for (int I = 0; I < NB; ++I)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    ckr[I][g] = grec[2 * NB * 256 + 16 * I + 4 * g + q];
-                    tk[I][g] = gwk[((w * NB + I) * 4 + g) * 64 + lane];
-                }
-        }
-        // pair table of the window: fifteen entries per contraction thread are in flight at a time — all of a thread's pairs with eight
-        // threads per term (up to 32 terms); with four (more terms: DRWCelerite-20 has 40) the second fifteen are fetched into the same
-        // registers while phase C runs and contracted in phase D
-        const double2* Ewin = reinterpret_cast<const double2*>(btab + k * RSB + TSP) + et * 128;
-        if (ethread) {
-#pragma unroll
-            for (int i = 0; i < EPT; ++i) {
-                const int pp = es + i * TPT;
-                ev[i] = pp < 120 ? Ewin[pp] : double2{0.0, 0.0};
-            }
-        }
-        [[maybe_unused]] double nqf[PF ? NB : 1][4], nqw[4], ncvc[4], ncxc[4], ns2w = 0.0;
-        [[maybe_unused]] d4 nkf = {0.0, 0.0, 0.0, 0.0};
+        PIORAN_ASTAMP(1);
+        issue_window_loads();
+        if constexpr (!DMA) issue_pair_table();
+        // (no initialisers: a default value on a register that a branch loads into is a write the compiler orders after the loads in flight —
+        //  s_waitcnt vmcnt(0) in the middle of the issue, 2000 cycles per window)
+        [[maybe_unused]] double nqf[(PF && !DMA) ? NB : 1][4], nqw[4], ncvc[4], ncxc[4], ns2w, nttw;
+        [[maybe_unused]] d4 nkf;
         const double kdiag = s2w;
         d4 kcur = kf;
         if constexpr (PF) {
-            if (k > 0) fetch_a(k - 1, nqf, nqw, ncvc, ncxc, nkf, ns2w);
+            if (k > 0) fetch_a(k - 1, nqf, nqw, ncvc, ncxc, nkf, ns2w, nttw);
         }
+        PIORAN_ASTAMP(2);
         PIORAN_BLK_BARRIER();   // B1
+        if constexpr (DMA) issue_pair_table();
+        PIORAN_ASTAMP(3);
         // ---- B: S- (chain) -------------------------------------------------------------------------------------------------
         if (chain) {
+            if constexpr (CD) {
+                if (lane < 16) sh.tt[par][lane] = DMA ? ttw : ttv;
+            }
+            if constexpr (DMA) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) kcur[g] = cur[OFF_K + g * 64 + lane];
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 double ps = sh.P[0][g * 64 + lane];
@@ -1312,11 +1406,22 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                 }
             }
         }
+        PIORAN_ASTAMP(4);
         PIORAN_BLK_BARRIER();   // B2
+        // the next window's block: all the pieces from the chain wavefront, which has nothing to do until barrier 0 of the next window (the
+        // CU's memory path takes ~25 cycles per KB and the issuer stalls on it; up to here that path belonged to the owners' loads)
+        if constexpr (DMA) {
+            if (chain && k > 0) dma_pieces_asm(gwb + (k - 1) * GWS, nxt, GWL / 128, 0, 1, lane);
+        }
+        PIORAN_ASTAMP(5);
         // ---- C: M-' = -cK o X-' - S- U~';  S- M' ------------------------------------------------------------------------
-        double mbw[4];
+        double mbw[4], mw[4];
         d4 sm = {0.0, 0.0, 0.0, 0.0};
         if (owner) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (DMA) mw[g] = cur[OFF_M + (w * 4 + g) * 64 + lane]; else mw[g] = mwg[g];
+            }
             double sA[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) sA[ks] = 0.5 * (sh.Srm[c16 * 16 + 4 * ks + q] + sh.Srm[(4 * ks + q) * 16 + c16]);   // symmetrised
@@ -1349,37 +1454,51 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                 }
             }
         };
+        PIORAN_ASTAMP(11);
         if (ethread) {
             contract(0);
             if (TPT == 4) {
 #pragma unroll
                 for (int i = 0; i < EPT; ++i) {
                     const int pp = es + (EPT + i) * TPT;
-                    ev[i] = pp < 120 ? Ewin[pp] : double2{0.0, 0.0};
+                    ev[i] = Ewin[pp < 120 ? pp : 119];
                 }
             }
         }
+        PIORAN_ASTAMP(6);
         PIORAN_BLK_BARRIER();   // B3
+        PIORAN_ASTAMP(7);
         // ---- D: U~-' = -S- M' + M-' T;  T- <- (cK cK') o T- + 1/2 (U~ M-' + M- U~') -------------------------------------
         if (owner) {
-            d4 mt = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int I = 0; I < NB; ++I)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    mt = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][c16 * 18 + 4 * ks + q], tk[I][ks], mt, 0, 0, 0);
+            auto tkv = [&](int I, int g) __attribute__((always_inline)) -> double {
+                if constexpr (DMA) return cur[((w * NB + I) * 4 + g) * 64 + lane]; else return tk[I][g];
+            };
             [[maybe_unused]] double ckb = 0.0;     // this lane's share of cK-_r for r = its column (T-', T symmetric): sum over its rows
             if constexpr (CD) {
 #pragma unroll
                 for (int I = 0; I < NB; ++I)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) ckb = fma(Tb[I][g] * ckr[I][g], tk[I][g], ckb);
+                    for (int g = 0; g < 4; ++g) ckb = fma(Tb[I][g] * ckr[I][g], tkv(I, g), ckb);
                 ckb *= 2.0;
             }
 #pragma unroll
             for (int I = 0; I < NB; ++I)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) Tb[I][g] *= ckr[I][g] * ckc;
+            double hm[4], hu[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { hm[ks] = 0.5 * mbw[ks]; hu[ks] = 0.5 * uw[ks]; }
+            // M-' T (one chain of 4 NB dependent matrix instructions) interleaved with the rank-32 update of T- (NB chains of eight):
+            // the matrix pipe takes an independent instruction every ~32 cycles, a dependent one every ~64
+            d4 mt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {
+                    mt = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][c16 * 18 + 4 * ks + q], tkv(I, ks), mt, 0, 0, 0);
+                    Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileU[par][I][(4 * ks + q) * 18 + c16], hm[ks], Tb[I], 0, 0, 0);
+                    Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][(4 * ks + q) * 18 + c16], hu[ks], Tb[I], 0, 0, 0);
+                }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const double ub = mt[g] - sm[g];
@@ -1393,28 +1512,33 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                 }
             }
             if constexpr (CD) acc_c = fma(-ckb * ckc, tew - tbw, acc_c);
-            double hm[4], hu[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { hm[ks] = 0.5 * mbw[ks]; hu[ks] = 0.5 * uw[ks]; }
-#pragma unroll
-            for (int I = 0; I < NB; ++I)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileU[par][I][(4 * ks + q) * 18 + c16], hm[ks], Tb[I], 0, 0, 0);
-                    Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][(4 * ks + q) * 18 + c16], hu[ks], Tb[I], 0, 0, 0);
-                }
         }
         if (ethread && TPT == 4) contract(EPT);
         if constexpr (PF) if (k > 0) {
+            if constexpr (!DMA) {
 #pragma unroll
-            for (int I = 0; I < NB; ++I)
+                for (int I = 0; I < NB; ++I)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qf[I][ks] = nqf[I][ks];
+                    for (int ks = 0; ks < 4; ++ks) qf[I][ks] = nqf[I][ks];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { qw[g] = nqw[g]; cvc[g] = ncvc[g]; cxc[g] = ncxc[g]; }
-            kf = nkf; s2w = ns2w;
+                for (int g = 0; g < 4; ++g) qw[g] = nqw[g];
+                kf = nkf;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { cvc[g] = ncvc[g]; cxc[g] = ncxc[g]; }
+            s2w = ns2w; ttw = nttw;
         }
+        PIORAN_ASTAMP(8);
+    };
+    if constexpr (DMA) {
+        for (int64_t k = NW - 1; k >= 0; k -= 2) {
+            window(k, ic<0>{});
+            if (k >= 1) window(k - 1, ic<1>{});
+        }
+    } else {
+        for (int64_t k = NW - 1; k >= 0; --k) window(k, ic<0>{});
     }
+    PIORAN_ASTAMP_FLUSH
     // ---- reductions: rows -> terms ------------------------------------------------------------------------------------------------
     __syncthreads();
     if (owner) {

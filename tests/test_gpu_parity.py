@@ -1617,7 +1617,10 @@ def test_windowed_gradient_matches_complex_step(ctx, J, N, B, nreal):
     # series gradients (what a per-draw data transform chains through) from the same kernels
     gs = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False, series_grad=True)
     assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block (windowed gradient)"
-    assert (gs["logl"] == val).all() and np.array_equal(gs["grad_a"], g["grad_a"]) and np.array_equal(gs["grad_mu"], g["grad_mu"])
+    # (another instantiation of the reverse kernel; its per-term sums are LDS atomics, whose order is not fixed: equal to rounding)
+    assert (gs["logl"] == val).all()
+    for key in ("grad_a", "grad_mu"):
+        assert np.max(np.abs(gs[key] - g[key])) <= 1e-13 * (1 + np.max(np.abs(g[key]))), key
     for i in range(min(B, 2)):
         ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, series=True)
         assert np.max(np.abs(gs["grad_y"][i] - ref["grad_y"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_y"])))

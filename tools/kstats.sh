@@ -3,7 +3,7 @@
 # (env for the script is inherited; the program itself follows `--`).
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out
+mkdir -p gpurun_out; rm -rf gpurun_out/$tag
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag -- python3 "$@" > gpurun_out/$tag.log 2>&1 || { tail -20 gpurun_out/$tag.log; exit 1; }
 python3 - "$tag" <<'PY'
 import csv, glob, sys
