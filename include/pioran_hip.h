@@ -196,7 +196,7 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
  *   8 ms at N = 1e4, J = 20; shapes past 63 rows: each draw evaluated as its own one-draw batch).
  * Two reverse modes.  With 6 .. 63 rows the WINDOWED reverse mode runs (celerite_block.hip, round 3): the windowed forward pass leaves T,
  * M', Sigma^-1 X' and Sigma^-1 of every 16-step window (38 KB per window at J = 20: 24 MB per draw at N = 1e4) and the adjoint kernel
- * walks the windows backwards with six GEMM stages each — value + gradient 6.2 ms for one chain, 6.6 ms for 256 (7.0 .. 7.5 ms with
+ * walks the windows backwards with six GEMM stages each — value + gradient 5.4 ms for one chain, 5.8 ms for 256 (6.1 .. 6.3 ms with
  * grad_c / grad_d).  With 64 .. 143 rows (and as a cross-check: context option "no_block") the STEP-BY-STEP reverse mode runs
  * (celerite_wide.hip: forward pass with checkpoints, replayed segments, lean adjoint kernel since round 4): 43 .. 45 ms at 64 .. 95 rows,
  * 93 .. 230 ms at 96 .. 143 (the reference benchmark grid's j = 64 is 128 rows) at N = 1e4.  More than 143 rows: PIORAN_ERR_UNSUPPORTED.
