@@ -1191,83 +1191,73 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
     for (int I = 0; I < NB; ++I) Tb[I] = d4{0.0, 0.0, 0.0, 0.0};
     double acc_al = 0.0, acc_be = 0.0, acc_mu = 0.0, acc_sa = 0.0, acc_nu = 0.0;
 
-    // Where a window's operands come from.  NB <= 3 (round 4): the block the forward pass left for the window — T | M' | Q | Q (A order) | K,
-    // 4864 doubles at three block columns — is copied verbatim into LDS by the LDS DMA (38 pieces of 1 KB, spread over the four wavefronts,
-    // no registers) one window ahead, two buffers; the owners read Q at the top of phase A, M' in phase C and T in phase D from there.
+    // Where a window's operands come from (round 4).  The block the forward pass left for the window — T | M' | Q | Q (A order) | K, 4864 doubles
+    // at three block columns, stored in fragment order — is copied verbatim into LDS by the LDS DMA (1 KB pieces, no registers) and read from
+    // there at the point of use: Q at the top of phase A, K in phase B, M' in phase C, T in phase D.
+    //   up to three block columns: the whole block one window ahead into one of two buffers, all pieces issued by the chain wavefront after
+    //     barrier 2 (it has nothing to do until the next window; the CU's memory path takes ~25 cycles per KB and the issuer stalls on it);
+    //   four block columns (every wavefront owns a block column, LDS is short): M' | Q | Q | K (26 pieces) one window ahead into one of two
+    //     buffers, T (32 pieces) of the window itself into a single buffer — both issued after barrier 1 by the three wavefronts that wait for
+    //     the chain there; T is needed in phase D only (barrier 3 waits for it).
     // Before: ~70 global loads per lane and window — more than the 63 a wavefront can have in flight, so issuing them took a memory latency
     // (3700 cycles of the window's 15 000, tools/block_adjoint_probe.hip) and phase C waited another one for M' and the pair table.
-    // What stays a global load: C o v, C o x and sigma2 (one window ahead, in registers), C_K, the d/d(c, d) extras and the pair table
-    // (issued at the top of their window, used in phases C and D).  NB = 4: everything through registers as in round 3.
-    constexpr bool DMA = NB <= 3;
-    constexpr int GWL = NB * NB * 256 + 3 * NB * 256 + 256;      // doubles of the block the reverse pass reads (a whole number of 1 KB pieces)
-    static_assert(GWL % 128 == 0, "whole DMA pieces");
-    __shared__ double gwl0[DMA ? GWL : 2], gwl1[DMA ? GWL : 2];   // two arrays, selected at compile time: reads of one never wait for the DMA into the other
+    // What stays a global load: C o v, C o x, sigma2 and the time stamps (one window ahead, in registers), C_K and the d/d(c, d) extras (after
+    // phase A) and the pair table (after barrier 1: 41 KB at J = 20, its issue hides behind the chain wavefront's phase B).
+    constexpr int DM = NB <= 3 ? 1 : 2;
+    constexpr int GWE = DM == 1 ? NB * NB * 256 + 3 * NB * 256 + 256 : 3 * NB * 256 + 256;   // doubles per double-buffered copy
+    constexpr int GWT = DM == 1 ? 2 : NB * NB * 256;                                           // the single T buffer (four block columns)
+    constexpr int EOFF = DM == 1 ? 0 : OFF_M;                                                  // offset of the double-buffered part inside the block
+    static_assert(GWE % 128 == 0 && (DM == 1 || GWT % 128 == 0), "whole DMA pieces");
+    __shared__ double gwl0[GWE], gwl1[GWE];   // two arrays, selected at compile time: reads of one never wait for the DMA into the other
+    __shared__ double gwt[GWT];
     constexpr int EPT = 15;    // pairs per contraction thread with eight threads per term (up to 32 terms): prefetched; beyond, read in the loop
-    double qf[DMA ? 1 : NB][4], qw[4], cvc[4], cxc[4];
-    d4 kf = {0.0, 0.0, 0.0, 0.0};
+    double cvc[4], cxc[4];
     double s2w = 0.0;
     [[maybe_unused]] double ttw = 0.0;
-    auto fetch_a = [&](int64_t kk, double (&qf_)[DMA ? 1 : NB][4], double (&qw_)[4], double (&cvc_)[4], double (&cxc_)[4], d4& kf_, double& s2w_, double& ttw_) __attribute__((always_inline)) {
-        const double* gwk = gwb + kk * GWS;
+    // phase-A operands that stay global loads, one window ahead
+    auto fetch_a = [&](int64_t kk, double (&cvc_)[4], double (&cxc_)[4], double& s2w_, double& ttw_) __attribute__((always_inline)) {
         const double* grec = gtab + kk * GS;
         if (owner) {
-            if constexpr (!DMA) {
-#pragma unroll
-                for (int I = 0; I < NB; ++I)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) qf_[I][ks] = gwk[OFF_QF + (I * 4 + ks) * 64 + lane];
-            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if constexpr (!DMA) qw_[g] = gwk[OFF_Q + (w * 4 + g) * 64 + lane];
                 cvc_[g] = grec[(w * 4 + g) * 64 + lane];
                 cxc_[g] = grec[NB * 256 + (w * 4 + g) * 64 + lane];
             }
         }
         if (chain) {
-            if constexpr (!DMA) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) kf_[g] = gwk[OFF_K + g * 64 + lane];
-            }
             const int64_t n = kk * KW + c16;
             s2w_ = p.S2 ? (n < N ? p.S2[b * N + n] : 0.0) : grec[2 * NB * 256 + 16 * NB + c16];   // per-draw series: the shifted log-flux models
-            if constexpr (CD && DMA) ttw_ = grec[OFF_TM + c16];   // the window's time stamps -> sh.tt in phase B (a window ahead: behind the DMA pieces
-                                                                  // in the in-order counter, a load of the window itself would make phase B wait for them)
+            if constexpr (CD) ttw_ = grec[OFF_TM + c16];   // the window's time stamps -> sh.tt in phase B (a window ahead: a load of the window itself
+                                                           // would sit behind the DMA pieces in the in-order counter and make phase B wait for them)
         }
     };
-    // (four block columns with d/d(c, d): no second register set — the kernel would spill 133 registers — the phase-A operands are
-    //  fetched at the top of their own window)
-    constexpr bool PF = !(NB == 4 && CD);
-    if constexpr (DMA) dma_pieces_asm(gwb + (NW - 1) * GWS, gwl0, GWL / 128, w, 4, lane);
-    if constexpr (PF) fetch_a(NW - 1, qf, qw, cvc, cxc, kf, s2w, ttw);
+    dma_pieces_asm(gwb + (NW - 1) * GWS + EOFF, gwl0, GWE / 128, w, 4, lane);
+    fetch_a(NW - 1, cvc, cxc, s2w, ttw);
     PIORAN_ASTAMP_DECL
     // one window; BC: which of the two LDS buffers holds its block (alternates from window to window)
     auto window = [&](int64_t k, auto BC) __attribute__((always_inline)) {
         constexpr int BI = decltype(BC)::value;
-        [[maybe_unused]] const double* cur = BI ? gwl1 : gwl0;
-        [[maybe_unused]] double* nxt = BI ? gwl0 : gwl1;
+        const double* cur = BI ? gwl1 : gwl0;
+        double* nxt = BI ? gwl0 : gwl1;
+        auto ldE = [&](int off) __attribute__((always_inline)) -> double { return cur[off - EOFF]; };                      // M' | Q | Q | K
+        auto ldT = [&](int off) __attribute__((always_inline)) -> double { if constexpr (DM == 1) return cur[off]; else return gwt[off]; };
         PIORAN_ASTAMP(0);
         const int par = (int)(k & 1);
-        if constexpr (!PF) fetch_a(k, qf, qw, cvc, cxc, kf, s2w, ttw);
         const double* gwk = gwb + k * GWS;
         const double* grec = gtab + k * GS;
         const int64_t n0 = k * KW;
-        [[maybe_unused]] double ttv;
-        if constexpr (DMA) {
-            PIORAN_BLK_BARRIER_DMA();   // B0: this window's block has landed (every wavefront's pieces); everybody is done with the other buffer
-            PIORAN_ASTAMP(9);
-        }
-        // ---- this window's own operands (global), and the next window's phase-A operands ----
+        PIORAN_BLK_BARRIER_DMA();   // B0: this window's block has landed (every wavefront's pieces); everybody is done with the other buffer (and with T)
+        PIORAN_ASTAMP(9);
+        // ---- this window's own operands (global) ----
+        // (no default values on anything loaded under a branch: `x = 0; if (owner) x = load` is a register write the compiler orders after the
+        //  loads in flight — s_waitcnt vmcnt(0) at the join, 2000 .. 3000 cycles per window in the middle of the issue)
         double ckc, ckr[NB][4];
         double2 ev[EPT];
         [[maybe_unused]] double hv[4], hx[4], tn[4], tbw, tew;
-        [[maybe_unused]] double tk[DMA ? 1 : NB][4], mwg[4];
         const double2* Ewin = reinterpret_cast<const double2*>(btab + k * RSB + TSP) + (ethread ? et : 0) * 128;
-        // (no default values on anything loaded under a branch: `x = 0; if (owner) x = load` costs an s_waitcnt vmcnt(0) at the join — measured:
-        //  3000 cycles per window in the middle of the issue, tools/block_adjoint_probe.hip; idle contraction threads load clamped addresses)
         auto issue_window_loads = [&]() __attribute__((always_inline)) {
-            if constexpr (CD) {
-                if (owner) {
+            if (owner) {
+                if constexpr (CD) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         hv[g] = grec[OFF_H + (w * 4 + g) * 64 + lane];
@@ -1277,29 +1267,16 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                     tbw = grec[OFF_TM + 16];
                     tew = grec[OFF_TM + 17];
                 }
-                if constexpr (!DMA) {
-                    if (chain) ttv = grec[OFF_TM + c16];   // -> sh.tt in phase B (read by the contraction threads after barrier 2); with four block
-                }                                          //    columns the chain wavefront is an owner as well
-            }
-            if (owner) {
-                if constexpr (!DMA) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) mwg[g] = gwk[OFF_M + (w * 4 + g) * 64 + lane];
-                }
                 ckc = grec[2 * NB * 256 + 16 * w + c16];
 #pragma unroll
                 for (int I = 0; I < NB; ++I)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        ckr[I][g] = grec[2 * NB * 256 + 16 * I + 4 * g + q];
-                        if constexpr (!DMA) tk[I][g] = gwk[((w * NB + I) * 4 + g) * 64 + lane];
-                    }
+                    for (int g = 0; g < 4; ++g) ckr[I][g] = grec[2 * NB * 256 + 16 * I + 4 * g + q];
             }
         };
         // pair table of the window: fifteen entries per contraction thread are in flight at a time — all of a thread's pairs with eight
         // threads per term (up to 32 terms); with four (more terms: DRWCelerite-20 has 40) the second fifteen are fetched into the same
-        // registers while phase C runs and contracted in phase D.  (NB <= 3: issued after barrier 1 — 41 KB at J = 20, the issuer stalls
-        // ~1000 cycles on the CU's memory path, and that is when the owners wait for the chain wavefront anyway)
+        // registers while phase C runs and contracted in phase D.  Idle threads of a wavefront with contraction threads load clamped addresses.
         auto issue_pair_table = [&]() __attribute__((always_inline)) {
             if (ewave) {
 #pragma unroll
@@ -1313,25 +1290,15 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
         // ---- A: X-' = 2 Q'T-, the partial Q' T- Q, U~' ---------------------------------------------------------------
         double xb[4], uw[4];
         if (owner) {
-            // (one accumulator per block column: NB chains of four dependent matrix instructions instead of one of 4 NB)
-            d4 qtI[NB];
+            d4 qt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int I = 0; I < NB; ++I) qtI[I] = d4{0.0, 0.0, 0.0, 0.0};
+            for (int I = 0; I < NB; ++I)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int I = 0; I < NB; ++I) {
-                    double qfv;
-                    if constexpr (DMA) qfv = cur[OFF_QF + (I * 4 + ks) * 64 + lane]; else qfv = qf[I][ks];
-                    qtI[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(qfv, Tb[I][ks], qtI[I], 0, 0, 0);
-                }
-            d4 qt = qtI[0];
-#pragma unroll
-            for (int I = 1; I < NB; ++I) qt += qtI[I];
+                for (int ks = 0; ks < 4; ++ks)
+                    qt = __builtin_amdgcn_mfma_f64_16x16x4f64(ldE(OFF_QF + (I * 4 + ks) * 64 + lane), Tb[I][ks], qt, 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                double qwv;
-                if constexpr (DMA) qwv = cur[OFF_Q + (w * 4 + g) * 64 + lane]; else qwv = qw[g];
+                const double qwv = ldE(OFF_Q + (w * 4 + g) * 64 + lane);
                 xb[g] = 2.0 * qt[g];
                 if (ycol) {
                     xb[g] -= qwv;
@@ -1348,18 +1315,9 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             double qtT[4], qfw[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qtT[ks] = sh.scr[w][c16 * 18 + 4 * ks + q];
-            if constexpr (DMA) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qfw[ks] = cur[OFF_QF + (w * 4 + ks) * 64 + lane];
-            } else {
-                static_for<0, NB>([&](auto Ic) __attribute__((always_inline)) {
-                    constexpr int I = decltype(Ic)::value;
-                    if (w == I) {
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) qfw[ks] = qf[DMA ? 0 : I][ks];
-                    }
-                });
+            for (int ks = 0; ks < 4; ++ks) {
+                qtT[ks] = sh.scr[w][c16 * 18 + 4 * ks + q];
+                qfw[ks] = ldE(OFF_QF + (w * 4 + ks) * 64 + lane);
             }
             d4 pw = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1369,35 +1327,32 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
         }
         PIORAN_ASTAMP(1);
         issue_window_loads();
-        if constexpr (!DMA) issue_pair_table();
-        // (no initialisers: a default value on a register that a branch loads into is a write the compiler orders after the loads in flight —
-        //  s_waitcnt vmcnt(0) in the middle of the issue, 2000 cycles per window)
-        [[maybe_unused]] double nqf[(PF && !DMA) ? NB : 1][4], nqw[4], ncvc[4], ncxc[4], ns2w, nttw;
-        [[maybe_unused]] d4 nkf;
+        // (no initialisers: see above)
+        double ncvc[4], ncxc[4], ns2w;
+        [[maybe_unused]] double nttw;
         const double kdiag = s2w;
-        d4 kcur = kf;
-        if constexpr (PF) {
-            if (k > 0) fetch_a(k - 1, nqf, nqw, ncvc, ncxc, nkf, ns2w, nttw);
-        }
+        if (k > 0) fetch_a(k - 1, ncvc, ncxc, ns2w, nttw);
         PIORAN_ASTAMP(2);
         PIORAN_BLK_BARRIER();   // B1
-        if constexpr (DMA) issue_pair_table();
+        issue_pair_table();
+        if constexpr (DM == 2) {     // wavefronts 0 .. 2 wait for wavefront 3 (the chain) here
+            if (w < 3) {
+                dma_pieces_asm(gwk, gwt, GWT / 128, w, 3, lane);                                         // T of this window (phase D)
+                if (k > 0) dma_pieces_asm(gwb + (k - 1) * GWS + EOFF, nxt, GWE / 128, w, 3, lane);       // M' | Q | Q | K of the next one
+            }
+        }
         PIORAN_ASTAMP(3);
         // ---- B: S- (chain) -------------------------------------------------------------------------------------------------
         if (chain) {
             if constexpr (CD) {
-                if (lane < 16) sh.tt[par][lane] = DMA ? ttw : ttv;
-            }
-            if constexpr (DMA) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) kcur[g] = cur[OFF_K + g * 64 + lane];
+                if (lane < 16) sh.tt[par][lane] = ttw;
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 double ps = sh.P[0][g * 64 + lane];
 #pragma unroll
                 for (int I = 1; I < NB; ++I) ps += sh.P[I][g * 64 + lane];
-                const double sb = -0.5 * kcur[g] - ps + 0.5 * sh.qy[4 * g + q] * sh.qy[c16];
+                const double sb = -0.5 * ldE(OFF_K + g * 64 + lane) - ps + 0.5 * sh.qy[4 * g + q] * sh.qy[c16];
                 sh.Srm[(4 * g + q) * 16 + c16] = sb;
                 if (4 * g + q == c16 && n0 + c16 < N) {
                     acc_sa += sb;
@@ -1408,10 +1363,8 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
         }
         PIORAN_ASTAMP(4);
         PIORAN_BLK_BARRIER();   // B2
-        // the next window's block: all the pieces from the chain wavefront, which has nothing to do until barrier 0 of the next window (the
-        // CU's memory path takes ~25 cycles per KB and the issuer stalls on it; up to here that path belonged to the owners' loads)
-        if constexpr (DMA) {
-            if (chain && k > 0) dma_pieces_asm(gwb + (k - 1) * GWS, nxt, GWL / 128, 0, 1, lane);
+        if constexpr (DM == 1) {   // the next window's block: from the chain wavefront, which has nothing to do until barrier 0 of the next window
+            if (chain && k > 0) dma_pieces_asm(gwb + (k - 1) * GWS, nxt, GWE / 128, 0, 1, lane);
         }
         PIORAN_ASTAMP(5);
         // ---- C: M-' = -cK o X-' - S- U~';  S- M' ------------------------------------------------------------------------
@@ -1419,9 +1372,7 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
         d4 sm = {0.0, 0.0, 0.0, 0.0};
         if (owner) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if constexpr (DMA) mw[g] = cur[OFF_M + (w * 4 + g) * 64 + lane]; else mw[g] = mwg[g];
-            }
+            for (int g = 0; g < 4; ++g) mw[g] = ldE(OFF_M + (w * 4 + g) * 64 + lane);
             double sA[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) sA[ks] = 0.5 * (sh.Srm[c16 * 16 + 4 * ks + q] + sh.Srm[(4 * ks + q) * 16 + c16]);   // symmetrised
@@ -1466,13 +1417,17 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
             }
         }
         PIORAN_ASTAMP(6);
-        PIORAN_BLK_BARRIER();   // B3
+        if constexpr (DM == 2) { PIORAN_BLK_BARRIER_DMA(); } else { PIORAN_BLK_BARRIER(); }   // B3 (four block columns: T has landed)
         PIORAN_ASTAMP(7);
         // ---- D: U~-' = -S- M' + M-' T;  T- <- (cK cK') o T- + 1/2 (U~ M-' + M- U~') -------------------------------------
         if (owner) {
-            auto tkv = [&](int I, int g) __attribute__((always_inline)) -> double {
-                if constexpr (DMA) return cur[((w * NB + I) * 4 + g) * 64 + lane]; else return tk[I][g];
-            };
+            auto tkv = [&](int I, int g) __attribute__((always_inline)) -> double { return ldT(((w * NB + I) * 4 + g) * 64 + lane); };
+            d4 mt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    mt = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][c16 * 18 + 4 * ks + q], tkv(I, ks), mt, 0, 0, 0);
             [[maybe_unused]] double ckb = 0.0;     // this lane's share of cK-_r for r = its column (T-', T symmetric): sum over its rows
             if constexpr (CD) {
 #pragma unroll
@@ -1485,20 +1440,6 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
             for (int I = 0; I < NB; ++I)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) Tb[I][g] *= ckr[I][g] * ckc;
-            double hm[4], hu[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { hm[ks] = 0.5 * mbw[ks]; hu[ks] = 0.5 * uw[ks]; }
-            // M-' T (one chain of 4 NB dependent matrix instructions) interleaved with the rank-32 update of T- (NB chains of eight):
-            // the matrix pipe takes an independent instruction every ~32 cycles, a dependent one every ~64
-            d4 mt = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int I = 0; I < NB; ++I) {
-                    mt = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][c16 * 18 + 4 * ks + q], tkv(I, ks), mt, 0, 0, 0);
-                    Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileU[par][I][(4 * ks + q) * 18 + c16], hm[ks], Tb[I], 0, 0, 0);
-                    Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][(4 * ks + q) * 18 + c16], hu[ks], Tb[I], 0, 0, 0);
-                }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const double ub = mt[g] - sm[g];
@@ -1512,31 +1453,29 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
                 }
             }
             if constexpr (CD) acc_c = fma(-ckb * ckc, tew - tbw, acc_c);
+            double hm[4], hu[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { hm[ks] = 0.5 * mbw[ks]; hu[ks] = 0.5 * uw[ks]; }
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileU[par][I][(4 * ks + q) * 18 + c16], hm[ks], Tb[I], 0, 0, 0);
+                    Tb[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.tileM[par][I][(4 * ks + q) * 18 + c16], hu[ks], Tb[I], 0, 0, 0);
+                }
         }
         if (ethread && TPT == 4) contract(EPT);
-        if constexpr (PF) if (k > 0) {
-            if constexpr (!DMA) {
-#pragma unroll
-                for (int I = 0; I < NB; ++I)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) qf[I][ks] = nqf[I][ks];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) qw[g] = nqw[g];
-                kf = nkf;
-            }
+        if (k > 0) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) { cvc[g] = ncvc[g]; cxc[g] = ncxc[g]; }
-            s2w = ns2w; ttw = nttw;
+            s2w = ns2w;
+            if constexpr (CD) ttw = nttw;
         }
         PIORAN_ASTAMP(8);
     };
-    if constexpr (DMA) {
-        for (int64_t k = NW - 1; k >= 0; k -= 2) {
-            window(k, ic<0>{});
-            if (k >= 1) window(k - 1, ic<1>{});
-        }
-    } else {
-        for (int64_t k = NW - 1; k >= 0; --k) window(k, ic<0>{});
+    for (int64_t k = NW - 1; k >= 0; k -= 2) {
+        window(k, ic<0>{});
+        if (k >= 1) window(k - 1, ic<1>{});
     }
     PIORAN_ASTAMP_FLUSH
     // ---- reductions: rows -> terms ------------------------------------------------------------------------------------------------
