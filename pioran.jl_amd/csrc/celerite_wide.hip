@@ -923,13 +923,13 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint_kernel(const ScanPara
     auto fetch_s = [&](int64_t n, double (&dsts)[RPL * RPL]) __attribute__((always_inline)) {
         int64_t k = n < s_first ? s_first : n;        // below the segment (or S_0): never used, any readable slot will do
         k = k > n_hi ? n_hi : k;
-        const bool have = n_hi >= s_first;            // N = 1: nothing was replayed
+        const bool have = n_hi >= s_first;            // N = 1: nothing was replayed (the buffer exists; what is read then is never used)
         const d2* q_ = reinterpret_cast<const d2*>(sbase + (size_t)(have ? k - s_first : 0) * 256 * SP) + tid;
+        // (unconditional: `v = 0; if (have) v = load` is a default value on a loaded register — the compiler waits for the loads in flight
+        //  at the join, i.e. the prefetch would be consumed at once)
 #pragma unroll
         for (int e = 0; e < SP / 2; ++e) {
-            d2 v;
-            v.x = 0.0; v.y = 0.0;
-            if (have) v = q_[e * 256];
+            const d2 v = q_[e * 256];
             dsts[2 * e] = v.x;
             if (2 * e + 1 < RPL * RPL) dsts[2 * e + 1] = v.y;
         }
@@ -1236,13 +1236,13 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint2_kernel(const ScanPar
     auto fetch_s = [&](int64_t n, double (&dsts)[RPL * RPL]) __attribute__((always_inline)) {
         int64_t k = n < s_first ? s_first : n;        // below the segment (or S_0): never used, any readable slot will do
         k = k > n_hi ? n_hi : k;
-        const bool have = n_hi >= s_first;            // N = 1: nothing was replayed
+        const bool have = n_hi >= s_first;            // N = 1: nothing was replayed (the buffer exists; what is read then is never used)
         const d2* q_ = reinterpret_cast<const d2*>(sbase + (size_t)(have ? k - s_first : 0) * 256 * SP) + tid;
+        // (unconditional: `v = 0; if (have) v = load` is a default value on a loaded register — the compiler waits for the loads in flight
+        //  at the join, i.e. the prefetch would be consumed at once)
 #pragma unroll
         for (int e = 0; e < SP / 2; ++e) {
-            d2 v;
-            v.x = 0.0; v.y = 0.0;
-            if (have) v = q_[e * 256];
+            const d2 v = q_[e * 256];
             dsts[2 * e] = v.x;
             if (2 * e + 1 < RPL * RPL) dsts[2 * e + 1] = v.y;
         }
