@@ -176,8 +176,8 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
  * draws x 1e4 times at N = 1e4, J = 20 (18.5 ms before); the simulation applies L window by window (5.0 ms per 256 draws, 8.7 before).
  * Workspace: the reverse mode's layout for the factor (41 KB per 16-step window and draw, 6 .. 9 KB of it written) + 2 N R doubles per draw
  * for the running vectors (8.3 GB for 256 draws at N = 1e4, R = 40; the chunk of draws shrinks to what is free).  Other shapes: the step-by-step
- * kernels — the factor stored by the latency kernels (the lean one from 64 rows on, round 4): posterior mean up to 128 rows (the reference
- * benchmark grid's j = 64), simulation up to 143; beyond: PIORAN_ERR_UNSUPPORTED before any workspace is taken.  pioran_celerite_config_name(-1)
+ * kernels — the factor stored by the latency kernels (the lean one from 64 rows on, round 4): posterior mean and simulation up to 143 rows (the reference
+ * benchmark grid's j = 64 is 128); beyond: PIORAN_ERR_UNSUPPORTED before any workspace is taken.  pioran_celerite_config_name(-1)
  * tells which ran ("block (windowed prediction)" / "wide (step-by-step prediction)", likewise "... simulation").
  * cd_shared == 0 with several draws: where 2 J rows fit the windowed kernel all draws of a chunk go through every kernel in one launch, each
  * with its own tables (64 draws: 7.5 ms predict, 4.6 ms simulate at N = M = 1e4, J = 20; draw by draw 910 / 439 ms). */

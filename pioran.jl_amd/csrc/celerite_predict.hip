@@ -55,16 +55,17 @@ struct RowDesc {
     int row;         // table row, < 0: lane idle
 };
 
-// Lane j of the wavefront owns rows j and j + 64 (R <= 128 here; the scan path allows R <= 79).
+// Lane j of the wavefront owns rows j, j + 64 (and j + 128 with NR = 3: 129 .. 143 rows, round 4).
+template <int NR>
 __global__ void __launch_bounds__(64) predict_sweep_kernel(const ScanParams p, double* __restrict__ z, double* __restrict__ Qf,
                                                            double* __restrict__ Qb)
 {
     const int64_t b = blockIdx.x, N = p.N;
     const int lane = threadIdx.x, R = p.R, Rp = R + 2, J = p.J;
     const int64_t rec = p.rec_stride;
-    RowDesc rd[2];
+    RowDesc rd[NR];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NR; ++h) {
         const int r = lane + 64 * h;
         rd[h].row = r < R ? r : -1;
         rd[h].al = rd[h].be = 0.0;
@@ -87,13 +88,13 @@ __global__ void __launch_bounds__(64) predict_sweep_kernel(const ScanParams p, d
     // What step n reads that does not depend on the recurrence (table record n, W_n, z'_n, D_n), fetched one step ahead
     // of its use: a lone wavefront per draw has nothing else to hide the latency behind.
     struct StepData {
-        double v[2], x[2], ph[2], w[2], zf, Dn;
+        double v[NR], x[NR], ph[NR], w[NR], zf, Dn;
     };
     auto fetch = [&](int64_t n, StepData& sd) __attribute__((always_inline)) {
         const int64_t nn = n < 0 ? 0 : (n >= N ? N - 1 : n);
         const double* recn = p.tab + nn * rec;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NR; ++h) {
             const int r = rd[h].row >= 0 ? rd[h].row : 0;
             sd.v[h] = recn[r];
             sd.x[h] = recn[Rp + r];
@@ -105,17 +106,19 @@ __global__ void __launch_bounds__(64) predict_sweep_kernel(const ScanParams p, d
     };
 
     // ---- backward sweep, :145-155 ----
-    double g[2] = {0.0, 0.0};
+    double g[NR] = {};
     double znext = 0.0;
-    double unext[2] = {0.0, 0.0}, phnext[2] = {1.0, 1.0};   // U_{n+1}, phi between t_n and t_{n+1} (record n+1)
+    double unext[NR] = {}, phnext[NR];
+#pragma unroll
+    for (int h = 0; h < NR; ++h) phnext[h] = 1.0;   // U_{n+1}, phi between t_n and t_{n+1} (record n+1)
     StepData cur, nxt;
     fetch(N - 1, cur);
     for (int64_t n = N - 1; n >= 0; --n) {
         fetch(n - 1, nxt);
-        double u[2];
+        double u[NR];
         double dot = 0.0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NR; ++h) {
             u[h] = 0.0;
             if (rd[h].row >= 0) {
                 u[h] = rd[h].al * cur.v[h] + rd[h].be * cur.x[h];
@@ -126,7 +129,7 @@ __global__ void __launch_bounds__(64) predict_sweep_kernel(const ScanParams p, d
         dot = wave_sum(dot);
         const double zn = cur.zf / cur.Dn - dot;                                // :146,151
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NR; ++h)
             if (rd[h].row >= 0) {
                 qb[n * R + rd[h].row] = g[h] + u[h] * zn;
                 unext[h] = u[h];
@@ -138,15 +141,15 @@ __global__ void __launch_bounds__(64) predict_sweep_kernel(const ScanParams p, d
     }
     // ---- forward recurrence of the prediction, :397-404 (lane 0 wrote z: make it visible to the wavefront) ----
     __threadfence_block();
-    double q[2] = {0.0, 0.0};
+    double q[NR] = {};
     constexpr int FD = 4;   // z and the table record four steps ahead (no dependence on q)
-    double zr[FD], vr[FD][2], pr[FD][2];
+    double zr[FD], vr[FD][NR], pr[FD][NR];
     auto fetch_f = [&](int64_t n, int slot) __attribute__((always_inline)) {
         const int64_t nn = n >= N ? N - 1 : n;
         const double* recn = p.tab + nn * rec;
         zr[slot] = zb[nn];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NR; ++h) {
             const int r = rd[h].row >= 0 ? rd[h].row : 0;
             vr[slot][h] = recn[r];
             pr[slot][h] = recn[2 * Rp + r];
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(64) predict_sweep_kernel(const ScanParams p, d
             const int64_t n = n0 + k;
             if (n < N) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NR; ++h)
                     if (rd[h].row >= 0) {
                         q[h] = fma(zr[k], vr[k][h], n > 0 ? pr[k][h] * q[h] : 0.0);
                         qf[n * R + rd[h].row] = q[h];
@@ -560,7 +563,7 @@ size_t pioran_predict_workspace_doubles(int64_t B, int64_t N, int32_t R)
 int pioran_launch_predict(ScanParams p, double* work, const double* t, int64_t M, const double* tau, double* mean_out,
                           hipStream_t stream)
 {
-    if (!p.tab || p.npd_rows != 0 || p.R > 128 || M < 0) return PIORAN_ERR_UNSUPPORTED;
+    if (!p.tab || p.npd_rows != 0 || p.R > 192 || M < 0) return PIORAN_ERR_UNSUPPORTED;
     const size_t BN = (size_t)p.B * (size_t)p.N;
     double* W = work;
     double* Qf = W + BN * p.R;
@@ -571,7 +574,8 @@ int pioran_launch_predict(ScanParams p, double* work, const double* t, int64_t M
     p.st_w = W; p.st_d = Dd; p.st_z = zf;
     int rc = pioran_launch_scan_wide_store(p, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(predict_sweep_kernel, dim3((unsigned)p.B), dim3(64), 0, stream, p, z, Qf, Qb);
+    if (p.R > 128) hipLaunchKernelGGL(predict_sweep_kernel<3>, dim3((unsigned)p.B), dim3(64), 0, stream, p, z, Qf, Qb);
+    else hipLaunchKernelGGL(predict_sweep_kernel<2>, dim3((unsigned)p.B), dim3(64), 0, stream, p, z, Qf, Qb);
     if (M > 0)
         hipLaunchKernelGGL(predict_eval_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)p.B), dim3(256), 0, stream, p, t, Qf,
                            Qb, M, tau, mean_out);

@@ -1476,9 +1476,9 @@ __global__ void __launch_bounds__(256) grad_finish_kernel(const ScanParams p, in
 // wavefront per SIMD with the 512-register budget — the reference's own benchmark grid goes up to j = 64 terms = 128 rows
 // (benchmark/benchmarks.jl:16-18), which used to fall to the HBM-resident any-rank kernel.
 int pioran_wide_supported_rows() { return 143; }
-// ... the store (prediction) and simulate modes: on the lean kernel since round 4 (the prediction's sweeps hold two rows per lane: 128)
+// ... the store (prediction) and simulate modes: on the lean kernel since round 4
 int pioran_wide_supported_rows_modes() { return 143; }
-int pioran_predict_supported_rows() { return 128; }
+int pioran_predict_supported_rows() { return 143; }
 // the step-by-step reverse mode: RPL 7 .. 9 since round 4 (forward pass: the lean kernel with GM)
 int pioran_wide_supported_rows_grad() { return 143; }
 
