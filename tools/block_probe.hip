@@ -24,21 +24,22 @@ __device__ unsigned long long g_acc[8][16];
 int main(int argc, char** argv)
 {
     const int64_t N = 10000; const int J = argc > 1 ? atoi(argv[1]) : 20; const int R = 2 * J;
-    std::vector<double> t(N), y(N), s2(N), c(J), d(J), A(J, 0.05), Bc(J, 0.01);
+    const int B = argc > 2 ? atoi(argv[2]) : 1;   // draws (workgroups): 512 = two per CU (the pair table then comes from global memory)
+    std::vector<double> t(N), y(N), s2(N), c(J), d(J), A((size_t)J * B, 0.05), Bc((size_t)J * B, 0.01);
     for (int64_t n = 0; n < N; ++n) { t[n] = n + 0.3 * sin(1.7 * n); y[n] = sin(0.3 * n); s2[n] = 0.01; }
     for (int j = 0; j < J; ++j) { c[j] = 0.01 * (j + 1); d[j] = 0.02 * (j + 1); }
     std::vector<int32_t> rm(R);
     for (int j = 0; j < R; ++j) rm[j] = (j / 2) | ((j & 1) << 30);
     double *dt, *dy, *ds2, *dc, *dd, *dA, *dB, *dout, *btab; int32_t *drm, *dst;
     hipMalloc(&dt, N * 8); hipMalloc(&dy, N * 8); hipMalloc(&ds2, N * 8); hipMalloc(&dc, J * 8); hipMalloc(&dd, J * 8);
-    hipMalloc(&dA, J * 8); hipMalloc(&dB, J * 8); hipMalloc(&dout, 8); hipMalloc(&drm, R * 4); hipMalloc(&dst, 4);
+    hipMalloc(&dA, (size_t)J * B * 8); hipMalloc(&dB, (size_t)J * B * 8); hipMalloc(&dout, 8 * B); hipMalloc(&drm, R * 4); hipMalloc(&dst, 4 * B);
     hipMemcpy(dt, t.data(), N * 8, hipMemcpyHostToDevice); hipMemcpy(dy, y.data(), N * 8, hipMemcpyHostToDevice);
     hipMemcpy(ds2, s2.data(), N * 8, hipMemcpyHostToDevice); hipMemcpy(dc, c.data(), J * 8, hipMemcpyHostToDevice);
-    hipMemcpy(dd, d.data(), J * 8, hipMemcpyHostToDevice); hipMemcpy(dA, A.data(), J * 8, hipMemcpyHostToDevice);
-    hipMemcpy(dB, Bc.data(), J * 8, hipMemcpyHostToDevice); hipMemcpy(drm, rm.data(), R * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dd, d.data(), J * 8, hipMemcpyHostToDevice); hipMemcpy(dA, A.data(), (size_t)J * B * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dB, Bc.data(), (size_t)J * B * 8, hipMemcpyHostToDevice); hipMemcpy(drm, rm.data(), R * 4, hipMemcpyHostToDevice);
     hipMalloc(&btab, pioran_block_table_doubles(N, R, J) * 8);
     pioran_launch_block_table(N, R, J, drm, dt, dc, dd, dy, ds2, btab, 0);
-    ScanParams p{}; p.N = N; p.J = J; p.R = R; p.standard_rows = 1; p.B = 1; p.rowmap = drm; p.A = dA; p.Bc = dB;
+    ScanParams p{}; p.N = N; p.J = J; p.R = R; p.standard_rows = 1; p.B = B; p.rowmap = drm; p.A = dA; p.Bc = dB;
     p.out = dout; p.status = dst; p.npd_rows = 0;
     for (int rep = 0; rep < 2; ++rep) { pioran_launch_scan_block(p, btab, 0); hipDeviceSynchronize(); }
     unsigned long long acc[8][16]; double out;
