@@ -1,3 +1,4 @@
+"""GPU: a few value + gradient calls at N = 1e4 (J, B in the environment) — the workload of tools/kstats.sh runs."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
