@@ -72,7 +72,14 @@ int pioran_ctx_trim(pioran_ctx* ctx);
  *                     the any-rank kernel; NULL, "" or "0" = off.
  *   "win2" / "no_win2"  force / forbid the two-step form of the throughput layouts (default: on up to four rows per lane, i.e. R <= 63)
  *   "win3" / "no_win3"  force / forbid the three-step form (two or three rows per lane; default: on for R = 24 .. 31 in large batches)
- *   "wide2" / "no_wide2"  force / forbid the lean form of the latency layout (default: from 48 rows on; the only form for 96 .. 143 rows)
+ *   "wide2" / "no_wide2"  force / forbid the lean form of the latency layout (default: from 48 rows on; the only form for 96 .. 143 rows);
+ *                     also selects the lean / round-1 kernels of the step-by-step gradient, prediction and simulation (64 .. 95 rows)
+ *   "no_split"        a batch that is not a whole number of passes runs as one launch (default: the remainder goes to the windowed kernel)
+ *   "workspace_limit_mb"  cap on the per-call workspaces (default 16384)
+ *   "dense_old_chain" 0 one launch per block column (default), 1 the panel / update chain of rounds 1-3, 2 .. 4 timing experiments of the
+ *                     roles (results are garbage), 5 the persistent-chain prototype (6 .. 8: the same without its fences; timing only);
+ *                     "dense_no_pairs", "dense_no_halves", "dense_quad_threshold", "dense_batch_pair_threshold", "dense_streams": schedule knobs
+ *   "block_emode", "gsum", "exp"   tuning / experiment selectors of single kernels (tools/ only; "exp" can make results meaningless)
  * Initial values come from the environment variables PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_BLOCK, PIORAN_NO_PAIRED,
  * PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK, PIORAN_WIN2, PIORAN_NO_WIN2, read once when the context is created. */
 int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value);
