@@ -386,7 +386,12 @@ __device__ __forceinline__ void dma_pieces_asm(const double* gsrc, double* ldst,
     for (int c = w; c < npieces; c += nwaves) {
         const double* g = gsrc + c * 128 + lane * 2;
         const unsigned l = __builtin_amdgcn_readfirstlane(lbase + (unsigned)c * 1024u);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+        // (m0 is a reserved register: saved and restored around the instruction, which reads it at issue)
+        unsigned m0_save;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_save)
+                     : "v"(g), "s"(l)
+                     : "memory");
     }
 }
 // workgroup barrier that publishes LDS writes but leaves LDS DMAs / global loads in flight (__syncthreads() would drain them)
@@ -1967,9 +1972,6 @@ int pioran_launch_block_pd_trig(int64_t N, int64_t B, int32_t J, int32_t npd_ter
 int pioran_launch_block_table(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,
                               const double* d, const double* y, const double* s2, double* btab, hipStream_t stream)
 {
-    const int NB = (R + 1 + 15) / 16;
-    const int64_t total = (int64_t)pioran_block_table_doubles(N, R, J);
-    (void)total;
     return pioran_launch_block_table_batch(N, R, J, 1, rowmap, t, c, d, y, s2, btab, 0, stream);
 }
 
