@@ -205,8 +205,8 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
  * M', Sigma^-1 X' and Sigma^-1 of every 16-step window (38 KB per window at J = 20: 24 MB per draw at N = 1e4) and the adjoint kernel
  * walks the windows backwards with six GEMM stages each — value + gradient 5.4 ms for one chain, 5.8 ms for 256 (6.1 .. 6.3 ms with
  * grad_c / grad_d).  With 64 .. 143 rows (and as a cross-check: context option "no_block") the STEP-BY-STEP reverse mode runs
- * (celerite_wide.hip: forward pass with checkpoints, replayed segments, lean adjoint kernel since round 4): 43 .. 45 ms at 64 .. 95 rows,
- * 93 .. 230 ms at 96 .. 143 (the reference benchmark grid's j = 64 is 128 rows) at N = 1e4.  More than 143 rows: PIORAN_ERR_UNSUPPORTED.
+ * (celerite_wide.hip: forward pass with checkpoints, replayed segments, lean adjoint kernel since round 4): 40 .. 45 ms at 64 .. 95 rows,
+ * 62 .. 157 ms at 96 .. 143 (the reference benchmark grid's j = 64 is 128 rows) at N = 1e4.  More than 143 rows: PIORAN_ERR_UNSUPPORTED.
  * Memory (step-by-step mode): the forward pass keeps the R x R state only at checkpoints (every ~2 sqrt(N) steps) and the reverse pass replays one
  * segment at a time: ~15 MB of workspace per draw at N = 1e4, J = 20 (two replayed segments + checkpoints 11 MB, stored m / D 4 MB: pioran_grad_workspace_doubles;
  * 55 MB at 80 rows, 105 MB at 128); draws are processed in chunks sized to the free memory.

@@ -1153,6 +1153,13 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint2_kernel(const ScanPar
     constexpr int NSTATE = RPL * RPL + 3 * RPL + 4;   // layout of celerite_adjoint_kernel's parked state (the mbc slots stay unused)
     constexpr int SP = (RPL * RPL + 1) & ~1;
     constexpr int SD = RPL <= 5 ? 2 : 1;              // S_n buffers (a second one where the registers allow)
+    // PL pairs of S_n do not pass through registers: every wavefront copies that part of its own lanes' block of the replayed segment
+    // ([pair][lane], verbatim) into LDS with the LDS DMA one step ahead and reads the elements at their use; the other pairs are fetched into
+    // registers as before.  7 and 8 rows per lane: all of S_n (Sb + S_n were 196 .. 256 of the 256 registers the vector ALU addresses: scratch);
+    // 9 rows per lane: 33 of the 41 pairs (all of them would take 166 KB of LDS); up to 6: none (measured at 6: 47.8 against 45.3 ms).
+    constexpr int PL = (RPL == 7 || RPL == 8) ? ((RPL * RPL + 1) & ~1) / 2 : (RPL == 9 ? 33 : 0);
+    constexpr bool SL = PL > 0;
+    constexpr int NREG = ((RPL * RPL + 1) & ~1) - 2 * PL;   // doubles of S_n that live in registers
     constexpr int oU = 0, oV = NSP, oX = 2 * NSP, oP = 3 * NSP, oM = 4 * NSP, oQ = 5 * NSP, oS = 6 * NSP;   // oS: sigma2_n, D_{n-1}
     const int tid = threadIdx.x;
     const int g = tid >> 4, l = tid & 15;
@@ -1165,6 +1172,7 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint2_kernel(const ScanPar
     __shared__ double sh_uq[2][16];
     __shared__ double sh_acc[3][NSP];                 // row accumulators of d/d(al), d/d(be), d/dd
     __shared__ double sh_c[3][NSP];                   // al | be | sign of the d-derivative (-1 cos row, +1 sin row, 0 otherwise)
+    __shared__ double sh_s[SL ? 256 * 2 * PL : 2];    // the first PL pairs of S_n of the step, [pair][lane][2]
 
     const double mu = p.mu ? p.mu[b] : 0.0;
     const double nu = p.nu ? p.nu[b] : 1.0;
@@ -1233,7 +1241,7 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint2_kernel(const ScanPar
     };
     const double* sbase = p.st_s + (size_t)b * (size_t)p.ckpt_every * 256 * SP;   // [step][pair][lane]
     const int64_t s_first = p.seg_n0 + 1;
-    auto fetch_s = [&](int64_t n, double (&dsts)[RPL * RPL]) __attribute__((always_inline)) {
+    auto fetch_s = [&](int64_t n, double (&dsts)[NREG > 0 ? NREG : 1]) __attribute__((always_inline)) {
         int64_t k = n < s_first ? s_first : n;        // below the segment (or S_0): never used, any readable slot will do
         k = k > n_hi ? n_hi : k;
         const bool have = n_hi >= s_first;            // N = 1: nothing was replayed (the buffer exists; what is read then is never used)
@@ -1241,18 +1249,41 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint2_kernel(const ScanPar
         // (unconditional: `v = 0; if (have) v = load` is a default value on a loaded register — the compiler waits for the loads in flight
         //  at the join, i.e. the prefetch would be consumed at once)
 #pragma unroll
-        for (int e = 0; e < SP / 2; ++e) {
+        for (int e = PL; e < SP / 2; ++e) {
             const d2 v = q_[e * 256];
-            dsts[2 * e] = v.x;
-            if (2 * e + 1 < RPL * RPL) dsts[2 * e + 1] = v.y;
+            dsts[2 * (e - PL)] = v.x;
+            if (2 * e + 1 < RPL * RPL) dsts[2 * (e - PL) + 1] = v.y;
         }
     };
 
+    // (SL) this wavefront's 64 lanes x SP doubles of S_n -> sh_s: SP / 2 pieces of 1 KB.  Inline assembly: the compiler's wait-count pass
+    // must not see an LDS write (it would wait for it in front of every LDS read); ordering is explicit — s_waitcnt vmcnt(0) before the
+    // element loop reads, lgkmcnt(0) before the next copy is issued; only the issuing wavefront's lanes read what it copied.
+    [[maybe_unused]] auto dma_s = [&](int64_t n) __attribute__((always_inline)) {
+        int64_t k = n < s_first ? s_first : n;
+        k = k > n_hi ? n_hi : k;
+        const bool have = n_hi >= s_first;
+        const double* g0 = sbase + (size_t)(have ? k - s_first : 0) * 256 * SP + (size_t)tid * 2;
+        const unsigned l0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)sh_s + (unsigned)(tid & ~63) * 16u;
+#pragma unroll
+        for (int e = 0; e < PL; ++e) {
+            const double* g_ = g0 + e * 512;
+            const unsigned l = __builtin_amdgcn_readfirstlane(l0 + (unsigned)e * 4096u);
+            unsigned m0_save;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_save)
+                         : "v"(g_), "s"(l)
+                         : "memory");
+        }
+    };
 #pragma unroll
     for (int m = 0; m < DG; ++m) fetch(n_hi - m, gv[m]);
-    double sv[SD][RPL * RPL];
-    fetch_s(n_hi, sv[0]);
-    if constexpr (SD == 2) fetch_s(n_hi - 1, sv[1]);
+    double sv[SD][NREG > 0 ? NREG : 1];
+    if constexpr (SL) dma_s(n_hi);
+    if constexpr (NREG > 0) {
+        fetch_s(n_hi, sv[0]);
+        if constexpr (SD == 2) fetch_s(n_hi - 1, sv[1]);
+    }
     stage((int)(n_hi & 1), gv[0]);
     fetch(n_hi - DG, gv[0]);
 
@@ -1294,7 +1325,7 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint2_kernel(const ScanPar
     }
     __syncthreads();
 
-    auto do_step = [&](int64_t n, double (&gslot)[5], double (&sn)[RPL * RPL]) __attribute__((always_inline)) {
+    auto do_step = [&](int64_t n, double (&gslot)[5], double (&sn)[NREG > 0 ? NREG : 1]) __attribute__((always_inline)) {
         const int par = (int)(n & 1);
         const double* r = sh_rec[par];
         const double rDn = recip_f64(Dn);
@@ -1314,6 +1345,7 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint2_kernel(const ScanPar
         }
         if (n > 0) {
             // ---- adjoints of (S_{n-1}, m_{n-1}); d/dc through phi_n; S_n qb -------------------------------------------------
+            if constexpr (SL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // S_n has landed in sh_s
             const double* mbp = sh_num[par ^ 1] + l * PITCH;   // mb of the columns (the exchange of step n + 1)
             double ucn = r[oU + l * PITCH], cpn = r[oP + l * PITCH], pcn = r[oM + l * PITCH], mcn = mbp[0];
 #pragma unroll
@@ -1326,7 +1358,9 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint2_kernel(const ScanPar
                 const double qbc = -mbc - Db * uc;
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) {
-                    const double s_ = sn[i * RPL + c];
+                    double s_;
+                    if ((i * RPL + c) < 2 * PL) s_ = sh_s[(((i * RPL + c) >> 1) * 256 + tid) * 2 + ((i * RPL + c) & 1)];   // (compile-time choice)
+                    else s_ = sn[i * RPL + c - 2 * PL];
                     const double t_ = fma(hq[i], uc, fma(hu[i], qbc, Sb[i][c]));   // total adjoint of S_n[i][c]
                     ub[i] = fma(s_, qbc, ub[i]);
                     gp[i] = fma(t_, s_, gp[i]);
@@ -1335,7 +1369,13 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint2_kernel(const ScanPar
                     nb[i] = fma(sbn, pc, nb[i]);
                 }
             }
-            if (!(p.exp & 1)) fetch_s(n - SD, sn);
+            if constexpr (SL) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of S_n has returned
+                dma_s(n - 1);
+            }
+            if constexpr (NREG > 0) {
+                if (!(p.exp & 1)) fetch_s(n - SD, sn);
+            }
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
                 ub[i] = row16_sum(ub[i]);
@@ -1402,6 +1442,7 @@ __global__ void __launch_bounds__(256, 1) celerite_adjoint2_kernel(const ScanPar
         if (s0 + k < NP) do_step(n_hi - (s0 + k), gv[(k + 1) % DG], sv[k % SD]);
     });
 
+    if constexpr (SL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last copy (never read) must not outlive the workgroup's LDS
     __syncthreads();
     if (n_lo > 0) {
         int e = 0;
