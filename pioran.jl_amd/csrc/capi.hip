@@ -1466,7 +1466,8 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
     // N = 1e4, R = 40.  The chunk is bounded by half of the memory that is free right now (plus what this buffer already
     // holds) and halved again if the allocation still fails.
     int64_t chunk = B < 1024 ? B : 1024;
-    if (windowed && chunk > 256) chunk = 256;
+    // windowed: 512 chains per launch pair (the forward pass then runs two workgroups per CU, the reverse pass two rounds of one)
+    if (windowed && chunk > 512) chunk = 512;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {

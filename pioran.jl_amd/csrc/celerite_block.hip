@@ -421,7 +421,7 @@ __device__ __forceinline__ void dma_pieces_asm(const double* gsrc, double* ldst,
 // (the last 320: the chain wavefront's D_k and D_k (L^-1)_ik, sh.Li as it stands — the simulation applies L with it)
 __host__ __device__ constexpr int64_t block_grad_ws_doubles(int NB) { return (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256 + 320; }
 template <int NB, int EM, int PDM = 0, int ST = 0>   // ST: 0 no stores, 1 everything the reverse pass needs, 2 Q in A-operand order (prediction), 3 Q in C/D order and L^-1, D (simulation)
-__global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4 && PDM != 1 && !ST) ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
+__global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4 && PDM != 1 && (!ST || (ST == 1 && EM == 2))) ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
 {
     constexpr bool PD = PDM != 0;
     [[maybe_unused]] constexpr int64_t GWS = block_grad_ws_doubles(NB);
@@ -1590,7 +1590,23 @@ int launch_block_grad(const ScanParams& p, const double* btab, const double* gta
             return PIORAN_ERR_HIP;
         granted[dev] = lds;
     }
-    hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, 1>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
+    // more than 256 chains: the forward pass with two workgroups per CU (pair table from global memory, as the plain kernel does above 256
+    // draws); the reverse pass stays at one (its LDS holds two copies of a window's block)
+    bool fwd2 = false;
+    if constexpr (NB <= 3) {
+        const size_t lds2 = block_lds_bytes(NB, p.J, 2);
+        if (p.B > 256 && 2 * lds2 <= kBlockLdsMax && !(p.opt && (p.opt->exp & 16))) {
+            static size_t granted2[64] = {};
+            if (lds2 > granted2[dev]) {
+                if (hipFuncSetAttribute((const void*)celerite_block_kernel<NB, 2, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+                    return PIORAN_ERR_HIP;
+                granted2[dev] = lds2;
+            }
+            hipLaunchKernelGGL((celerite_block_kernel<NB, 2, 0, 1>), dim3((unsigned)p.B), dim3(256), lds2, stream, p, btab);
+            fwd2 = true;
+        }
+    }
+    if (!fwd2) hipLaunchKernelGGL((celerite_block_kernel<NB, 0, 0, 1>), dim3((unsigned)p.B), dim3(NB < 4 ? 256 : 512), lds, stream, p, btab);
     const bool cd = gc || gd;
     if (p.J <= 32) {
         if (cd) hipLaunchKernelGGL((celerite_block_adjoint_kernel<NB, true, 8>), dim3((unsigned)p.B), dim3(256), 0, stream, p, btab, gtab, ga, gb, gnu, gmu, gc, gd);
