@@ -202,7 +202,8 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
  * C, Dd: [J] when cd_shared != 0, else [B][J] (windowed reverse mode: every draw its own tables, all draws in one launch — 16 chains
  *   8 ms at N = 1e4, J = 20; shapes past 63 rows: each draw evaluated as its own one-draw batch).
  * Two reverse modes.  With 6 .. 63 rows the WINDOWED reverse mode runs (celerite_block.hip, round 3): the windowed forward pass leaves T,
- * M', Sigma^-1 X' and Sigma^-1 of every 16-step window (38 KB per window at J = 20: 24 MB per draw at N = 1e4) and the adjoint kernel
+ * M', Sigma^-1 X' and Sigma^-1 of every 16-step window (38 KB per window at J = 20: 24 MB per draw at N = 1e4; chains are
+ * processed 512 at a time — 12 GB —, fewer when the context option "workspace_limit_mb" or the free memory say so) and the adjoint kernel
  * walks the windows backwards with six GEMM stages each — value + gradient 5.4 ms for one chain, 5.8 ms for 256 (6.1 .. 6.3 ms with
  * grad_c / grad_d).  With 64 .. 143 rows (and as a cross-check: context option "no_block") the STEP-BY-STEP reverse mode runs
  * (celerite_wide.hip: forward pass with checkpoints, replayed segments, lean adjoint kernel since round 4): 40 .. 45 ms at 64 .. 95 rows,
