@@ -326,9 +326,12 @@ int block_dispatch(pioran_ds* ds, const ScanParams& p)
     // block columns, which moves the crossover up — R = 32 .. 35: 768 draws 4.9 vs 5.4 ms; R = 36 .. 47: 1024 draws 5.3 .. 5.8 vs
     // 5.7 .. 7.5 ms on the throughput shapes.  With four block columns (48 rows and more) the table stays in LDS and 512 draws is the
     // limit (DRWCelerite-20 at 768 draws: 7.8 vs 7.1 ms on the throughput shape, which got faster this round).
+    // Round 4: five and six block columns (64 .. 95 rows; value only, one workgroup per CU: up to 256 draws).
     const bool automatic = !cfg && !o.no_block && p.R >= 6 &&
-                           (p.B <= 512 || (p.B <= 768 && p.R >= 32 && p.R <= 47) || (p.B <= 1024 && p.R >= 36 && p.R <= 47));
-    if (!(force || automatic) || !p.tab || p.npd_rows != 0 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+                           (p.R > pioran_block_supported_rows()
+                                ? p.B <= 256
+                                : (p.B <= 512 || (p.B <= 768 && p.R >= 32 && p.R <= 47) || (p.B <= 1024 && p.R >= 36 && p.R <= 47)));
+    if (!(force || automatic) || !p.tab || p.npd_rows != 0 || !pioran_block_fits_value(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
     PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
     if (!s || !s->prepared || s->npd_terms != 0 || p.rec_stride != 3 * (int64_t)(s->R + 2) + 2) return PIORAN_ERR_UNSUPPORTED;
     int rc = ensure_btab(ds, *s);

@@ -333,14 +333,14 @@ template <int NB>
 struct BlockSharedT {               // exchanges between the wavefronts of a workgroup
     double MG[NB][16 * 18];         // per owner wavefront: its block of M' [step][row, stride 18] for the transposing read-back, then
                                     // (same storage) its partial Gram U~_J' M_J as fragments [g][lane]
-    double Ab[2][NB == 4 ? 2 : 1][256];   // A of window k in Ab[k & 1][0] (four block columns: the two term-parity partial sums [0] + [1])
+    double Ab[2][NB >= 4 ? 2 : 1][256];   // A of window k in Ab[k & 1][0] (from four block columns on: the two term-parity partial sums [0] + [1])
     double Li[16 * 18];             // D_k (L^-1)_ik at [k * 18 + i], i > k; D_k at [k * 18 + k]; the rest is not L^-1 (readers mask).
                                     // Before the elimination the chain wavefront uses the same storage for Sigma [j][n] (its own
                                     // layout change; the readers of L^-1 of the previous window are two barriers behind)
     double Yt[NB * 256];            // Y^' fragments [J][g][lane]
     double fin[8];
     double2 ab[64];                 // (a_t, b_t) of this draw
-    double2 albe[64];               // per row: u = al v + be x
+    double2 albe[NB > 4 ? 16 * NB : 64];   // per row: u = al v + be x
     double ys[2][32];               // per-draw series: (y_n, sigma2_n) of window k in ys[k & 1][0..15 | 16..31]
 };
 constexpr int kBlockMaxTerms = 64;
@@ -427,8 +427,10 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
     [[maybe_unused]] constexpr int64_t GWS = block_grad_ws_doubles(NB);
     [[maybe_unused]] constexpr int OFF_M = NB * NB * 256, OFF_Q = OFF_M + NB * 256, OFF_QF = OFF_Q + NB * 256, OFF_K = OFF_QF + NB * 256;
     constexpr bool EDBL = EM == 1, EGLOB = EM == 2;
-    constexpr int NCW = NB < 4 ? 4 : 5;     // computing wavefronts: owners + chain
-    constexpr bool COPYW = NB == 4;         // copy wavefronts (these shapes fill a CU's LDS with one workgroup anyway)
+    constexpr int NCW = NB < 4 ? 4 : NB + 1;   // computing wavefronts: owners + chain (five and six block columns, round 4: 64 .. 95 rows,
+                                               // value only — the reference grid's j = 32 is 64 rows + y)
+    constexpr bool COPYW = NB >= 4;         // copy wavefronts (these shapes fill a CU's LDS with one workgroup anyway)
+    static_assert(NB <= 6, "eight wavefronts: owners + chain + at least one copy wavefront");
     // per-draw rows, up to three block columns: one more wavefront forms their record entries (a whole window of time for ~4 exponentials
     // per lane: never on the critical path; on the chain wavefront the same work delayed barrier 1 of every window — 5.1 instead of
     // 3.3 us per window).  With four block columns the chain wavefront does it (the workgroup is full: copy wavefronts).
@@ -476,7 +478,7 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
     if (tid < J) sh.ab[tid] = double2{Ab_[tid], Bb_[tid]};
 
     // u = al v + be x per row (:59-63)
-    if (tid < 64) {
+    if (tid < (NB > 4 ? 16 * NB : 64)) {
         double a = 0.0, bb = 0.0;
         if (tid < R) {
             const int rm = p.rowmap[tid];
@@ -625,7 +627,7 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
     // the pair (jj < nn), threads 120 .. 135 the diagonal.  NB <= 3: wavefronts 0 .. 2, all terms.  NB = 4 (SPLIT4; the E buffer
     // is single and a wavefront refills what it alone reads): wavefronts 0 .. 3 = (pair half w & 1) x (terms of parity w >> 1),
     // two partial sums that the chain adds; E piece 2 t + h then belongs to wavefront h + 2 (t & 1).
-    constexpr bool SPLIT4 = NB == 4;
+    constexpr bool SPLIT4 = NB >= 4;
     const int pp = SPLIT4 ? 64 * (w & 1) + lane : 64 * w + lane;
     const int tpar = SPLIT4 ? (w >> 1) : 0, tstep = SPLIT4 ? 2 : 1;
     int nn = 1;
@@ -860,7 +862,7 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         };
         if (k + 2 < NW && !chain) {
-            if constexpr (EDBL || EGLOB) {
+            if constexpr ((EDBL || EGLOB) && !COPYW) {
                 // contiguous shares; wavefronts 0 and 1 carry the pair contraction, the others take twice as much
                 const int rest = np_all - np_chain, unit = rest / (NWV == 4 ? 4 : 6);
                 const int lo = np_chain + (w == 0 ? 0 : w == 1 ? unit : w == 2 ? 2 * unit : 4 * unit);
@@ -878,7 +880,7 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
         // the chain wavefront idles until the next barrier 1: its share of record k + 2 (issued right away: the copies then have
         // the whole Y^ / update / M' stretch to land; issued after its own LDS reads below they land too late for barrier 1)
         if (chain && k + 2 < NW) {
-            for (int c = 0; c < ((EDBL || EGLOB) ? np_chain : (COPYW ? nt_chain : np_tile)); ++c) copy_piece(c);
+            for (int c = 0; c < (COPYW ? nt_chain : ((EDBL || EGLOB) ? np_chain : np_tile)); ++c) copy_piece(c);
         }
         if constexpr (PD && !HELPW) {
             // per-draw rows of record k + 2 (its staging landed before barrier 1 of this window; buffer k & 1 held window k's values,
@@ -1522,7 +1524,8 @@ __global__ void __launch_bounds__(256, 1) celerite_block_adjoint_kernel(const Sc
 constexpr size_t kBlockLdsMax = 160 * 1024;
 __host__ inline size_t block_lds_bytes(int NB, int J, int emode /*E buffers in LDS: 0 one, 1 two, 2 none*/, int npd = 0 /*per-draw terms*/)
 {
-    const size_t shared = NB == 1 ? sizeof(BlockSharedT<1>) : NB == 2 ? sizeof(BlockSharedT<2>) : NB == 3 ? sizeof(BlockSharedT<3>) : sizeof(BlockSharedT<4>);
+    const size_t shared = NB == 1 ? sizeof(BlockSharedT<1>) : NB == 2 ? sizeof(BlockSharedT<2>) : NB == 3 ? sizeof(BlockSharedT<3>) : NB == 4 ? sizeof(BlockSharedT<4>)
+                          : NB == 5 ? sizeof(BlockSharedT<5>) : sizeof(BlockSharedT<6>);
     return (size_t)(2 * block_tile_doubles(NB) + (emode == 2 ? 0 : emode == 1 ? 2 : 1) * 256 * J) * sizeof(double) + shared +
            (npd > 0 ? sizeof(BlockPd) + (size_t)2 * npd * 128 * sizeof(double2) : 0);
 }
@@ -1548,6 +1551,12 @@ int launch_block2(const ScanParams& p, const double* btab, hipStream_t stream)
 template <int NB>
 int launch_block(const ScanParams& p, const double* btab, hipStream_t stream)
 {
+    if constexpr (NB >= 5) {   // 64 .. 95 rows (round 4): value only, no per-draw rows; the pair table in LDS where it fits, else from global memory
+        if (p.npd_rows > 0) return PIORAN_ERR_UNSUPPORTED;
+        if (block_lds_bytes(NB, p.J, 0) <= kBlockLdsMax) return launch_block2<NB, 0>(p, btab, stream);
+        if (block_lds_bytes(NB, p.J, 2) <= kBlockLdsMax) return launch_block2<NB, 2>(p, btab, stream);
+        return PIORAN_ERR_UNSUPPORTED;
+    } else {
     // Where the pair table E lives (tools/sweep_block_emode.py, N = 1e4, late round 3): one LDS buffer is as fast as two or faster at
     // every size measured (SHO-20, 256 draws: 1.92 vs 2.10 ms — the second buffer was worth its LDS in round 2, before the shared block
     // shrank), so two buffers are an option only; above 256 draws what counts is whether TWO workgroups fit a CU — if they do not with E
@@ -1574,6 +1583,7 @@ int launch_block(const ScanParams& p, const double* btab, hipStream_t stream)
     }
     if (block_lds_bytes(NB, p.J, 0) <= kBlockLdsMax) return launch_block2<NB, 0>(p, btab, stream);
     return PIORAN_ERR_UNSUPPORTED;
+    }
 }
 
 template <int NB>
@@ -1945,6 +1955,15 @@ int pioran_block_fits(int32_t R, int32_t J)
     return block_lds_bytes(NB, J, 0) <= kBlockLdsMax;
 }
 
+// ... the value-only kernel also runs five and six block columns (64 .. 95 rows)
+int pioran_block_fits_value(int32_t R, int32_t J)
+{
+    const int NB = (R + 1 + 15) / 16;
+    if (NB <= 4) return pioran_block_fits(R, J);
+    if (NB > 6 || J < 1 || J > kBlockMaxTerms) return 0;
+    return block_lds_bytes(NB, J, 0) <= kBlockLdsMax || block_lds_bytes(NB, J, 2) <= kBlockLdsMax;
+}
+
 // ... with `npd_terms` per-draw terms (their rows last)
 int pioran_block_fits_pd(int32_t R, int32_t J, int32_t npd_terms)
 {
@@ -2008,7 +2027,7 @@ int pioran_launch_block_table_batch(int64_t N, int32_t R, int32_t J, int64_t nb,
 {
     const int NB = (R + 1 + 15) / 16;
     const int64_t NW = (N + KW - 1) / KW;
-    if (J < 1 || J > kBlockMaxTerms || NB > 4 || nb < 1 || nb > 65535 || NW > 0x7fffffffLL) return PIORAN_ERR_ARG;
+    if (J < 1 || J > kBlockMaxTerms || NB > 6 || nb < 1 || nb > 65535 || NW > 0x7fffffffLL) return PIORAN_ERR_ARG;
     hipLaunchKernelGGL(block_table_window_kernel, dim3((unsigned)NW, (unsigned)nb), dim3(256), 0, stream, N, R, J, NB, rowmap, t, C, D, y, s2,
                        btab, (int64_t)J, draw_stride);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
@@ -2021,7 +2040,7 @@ int pioran_launch_scan_block(const ScanParams& p, const double* btab, hipStream_
     if (!btab || p.B < 1 || p.N < 1) return PIORAN_ERR_UNSUPPORTED;
     if (p.npd_rows != 0) {
         if ((p.npd_rows & 1) || !p.pd_C || !p.pd_trig || p.pd_npad < p.N || !pioran_block_fits_pd(p.R, p.J, p.npd_rows / 2)) return PIORAN_ERR_UNSUPPORTED;
-    } else if (!pioran_block_fits(p.R, p.J)) {
+    } else if (!pioran_block_fits_value(p.R, p.J)) {
         return PIORAN_ERR_UNSUPPORTED;
     }
     if ((p.Y == nullptr) != (p.S2 == nullptr)) return PIORAN_ERR_ARG;
@@ -2030,6 +2049,8 @@ int pioran_launch_scan_block(const ScanParams& p, const double* btab, hipStream_
         case 2: return launch_block<2>(p, btab, stream);
         case 3: return launch_block<3>(p, btab, stream);
         case 4: return launch_block<4>(p, btab, stream);
+        case 5: return launch_block<5>(p, btab, stream);
+        case 6: return launch_block<6>(p, btab, stream);
     }
     return PIORAN_ERR_UNSUPPORTED;
 }

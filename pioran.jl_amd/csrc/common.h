@@ -136,6 +136,7 @@ int64_t pioran_wide_max_batch();
 // per-draw rows; its own table (fragment order), built once per prepared (c, d)
 int pioran_block_supported_rows();
 int pioran_block_fits(int32_t R, int32_t J);   // rows and terms within the kernel's LDS budget
+int pioran_block_fits_value(int32_t R, int32_t J);   // the value-only kernel: also five and six block columns (64 .. 95 rows)
 int pioran_block_fits_pd(int32_t R, int32_t J, int32_t npd_terms);   // ... with per-draw terms (at most two)
 size_t pioran_block_pd_trig_doubles(int64_t N, int64_t B, int32_t npd_terms);
 int pioran_launch_block_pd_trig(int64_t N, int64_t B, int32_t J, int32_t npd_terms, const int32_t* pd_terms /*device*/, const double* t,

@@ -315,7 +315,7 @@ def test_rows_65_to_80_one_draw_over_two_wavefronts(ctx, J, nreal, N, B):
     ds = pj.Dataset(t, y, s2, ctx)
     ref, rst = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8, return_status=True)
     try:
-        ctx.set_option("no_wide", True)       # (batches up to 256 draws would take the latency layout)
+        ctx.set_option("no_wide", True); ctx.set_option("no_block", True)   # (batches up to 256 draws would take the windowed / the latency kernel)
         one = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
         assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan" and "w2" not in pj._lib.lib().pioran_celerite_config_name(0).decode()
         ctx.set_option("scan_config", "rpl5_cbr4_nsrc2_w2_yp" if nreal == 0 else "rpl5_cbr4_nsrc2_w2_y")
@@ -325,13 +325,53 @@ def test_rows_65_to_80_one_draw_over_two_wavefronts(ctx, J, nreal, N, B):
         Y = rng.standard_normal((B, N)); S2 = rng.uniform(0.01, 0.1, (B, N))
         got2 = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
     finally:
-        ctx.set_option("scan_config", None); ctx.set_option("no_wide", False)
+        ctx.set_option("scan_config", None); ctx.set_option("no_wide", False); ctx.set_option("no_block", False)
     assert np.array_equal(st, rst)
     assert relerr(got, ref) < 1e-11 and relerr(one, ref) < 1e-11
     ref2 = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(min(B, 40))])
     assert relerr(got2[:len(ref2)], ref2) < 1e-11
-    lat = ds.logl_batch(A[:5], Bc[:5], C, Dd, mu=mu[:5], nu=nu[:5])     # five draws: the lean latency kernel
+    try:
+        ctx.set_option("no_block", True)
+        lat = ds.logl_batch(A[:5], Bc[:5], C, Dd, mu=mu[:5], nu=nu[:5])     # five draws: the lean latency kernel
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "wide"
+    finally:
+        ctx.set_option("no_block", False)
     assert relerr(lat, ref[:5]) < 1e-11
+
+
+@pytest.mark.parametrize("J,nreal,N,B", [(32, 0, 300, 4), (33, 0, 61, 3), (36, 0, 1, 2), (36, 0, 2, 2), (36, 0, 15, 2), (36, 0, 16, 2), (36, 0, 17, 2),
+                                          (39, 0, 129, 5), (40, 0, 33, 3), (40, 0, 500, 2), (44, 0, 48, 2), (47, 0, 77, 7), (45, 20, 75, 6),
+                                          (50, 22, 64, 3), (60, 30, 90, 2), (47, 0, 40, 256)])
+def test_rows_64_to_95_windowed_kernel_with_five_and_six_block_columns(ctx, J, nreal, N, B):
+    """64 .. 95 rows, up to 256 draws (round 4): the windowed kernel with five / six block columns (value only; the reference benchmark
+    grid's j = 32 is 64 rows + y).  Against the oracle and the lean latency kernel (`no_block`), ragged windows, N = 1 and 2, one-row
+    terms, per-draw series; more than 256 draws stay on the other kernels."""
+    rng = np.random.default_rng(6400 + J + N)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    if nreal:
+        Bc[:, -nreal:] = 0.0; Dd[-nreal:] = 0.0
+    R = 2 * J - nreal
+    assert 64 <= R <= 95
+    ds = pj.Dataset(t, y, s2, ctx)
+    ref, rst = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8, return_status=True)
+    got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block"
+    assert np.array_equal(st, rst) and relerr(got, ref) < 1e-11
+    Y = rng.standard_normal((B, N)); S2 = rng.uniform(0.01, 0.1, (B, N))
+    got2 = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "block"
+    ref2 = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(min(B, 6))])
+    assert relerr(got2[:len(ref2)], ref2) < 1e-11
+    try:
+        ctx.set_option("no_block", True)
+        lat = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "wide"
+    finally:
+        ctx.set_option("no_block", False)
+    assert relerr(got, lat) < 1e-10
+    if B == 256:     # one more draw: not the windowed kernel's any more
+        ds.logl_batch(np.vstack([A, A[:1]]), np.vstack([Bc, Bc[:1]]), C, Dd, mu=np.append(mu, mu[0]), nu=np.append(nu, nu[0]))
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() != "block"
 
 
 @pytest.mark.parametrize("J,N,B", [(48, 60, 5), (52, 33, 2), (56, 130, 3), (60, 61, 1), (64, 60, 5), (64, 700, 2), (71, 45, 3), (32, 300, 4), (40, 77, 2)])
