@@ -102,7 +102,7 @@ int pioran_dataset_destroy(pioran_ds* ds);
  * terms go through the host-pointer entry with cd_shared = 0, which builds the mixed table itself.)
  * The declared state persists until the next pioran_dataset_prepare on this data set; no other entry changes it.
  * Device memory: the table takes (6 J + 8)(N + 1) * 8 bytes (10 MB at N = 1e4, J = 20); the first small batch (at most 512
- * draws; 768 with 32 .. 47 rows, 1024 with 36 .. 47 rows; 6 .. 63 rows) builds a second table for the windowed small-batch kernel,
+ * draws; 768 with 32 .. 47 rows, 1024 with 36 .. 47 rows; 6 .. 63 rows — and up to 256 draws with 64 .. 95 rows) builds a second table for the windowed small-batch kernel,
  * ~(30 J + 300) N bytes (37 MB there), and falls back to the other kernels if that does not fit (2 GB cap).
  * Entries that chunk their draws (per-draw (c, d) tables: 37 MB per draw; prediction: 8.3 GB, gradient: 6 GB per 256 draws at
  * N = 1e4, J = 20) take at most half of the free device memory and never more than the context option "workspace_limit_mb"
