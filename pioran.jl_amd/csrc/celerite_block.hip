@@ -641,7 +641,7 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
                                          : reinterpret_cast<const double2*>(Eb + (k & 1) * ebs) + pp;
                 double acc0 = 0.0, acc1 = 0.0;
                 int t = tpar;
-                constexpr int UN = 10;   // reads in flight per chunk (two chunks at J = 20)
+                constexpr int UN = NB == 5 ? 6 : (NB == 6 ? 4 : 10);   // reads in flight per chunk (two chunks at J = 20; five and six block columns are short of registers)
                 for (; t + (UN - 1) * tstep < J; t += UN * tstep) {
                     double2 e[UN], cf[UN];
 #pragma unroll
