@@ -365,8 +365,8 @@ static int split_dispatch(pioran_ds* ds, const ScanParams& p)
 {
     pioran_ctx* ctx = ds->ctx;
     const ScanOptions& o = ctx->opt;
-    if (o.no_split || o.scan_config[0] || o.no_block || o.force_fallback || !p.tab || p.npd_rows != 0 || p.R < 6 || p.R > 63 ||
-        !pioran_block_fits(p.R, p.J))
+    if (o.no_split || o.scan_config[0] || o.no_block || o.force_fallback || !p.tab || p.npd_rows != 0 || p.R < 6 || p.R > 95 ||
+        !pioran_block_fits_value(p.R, p.J))
         return PIORAN_ERR_UNSUPPORTED;
     PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
     if (!s || !s->prepared || s->npd_terms != 0 || p.rec_stride != 3 * (int64_t)(s->R + 2) + 2) return PIORAN_ERR_UNSUPPORTED;
@@ -378,7 +378,7 @@ static int split_dispatch(pioran_ds* ds, const ScanParams& p)
     // (tools/sweep_batch_sizes.py, profiles/r04_batch_sizes.txt: SHO-20 4200 draws 16.8 -> 13.1 ms, 4608 16.8 -> 14.8; DRWCelerite-20 4200
     // 32.5 -> 28.6.  A second round no longer hides behind the scan — SHO-20 5000 draws: 19.7 against 16.8 ms in one launch — and neither
     // does sending what exceeds HALF a pass: 2500 draws 11.6 against 10.6 ms; both were measured and are not done.)
-    const int64_t rem_max = p.R <= 47 ? 512 : 256;
+    const int64_t rem_max = p.R <= 47 ? 512 : 256;   // (64 .. 95 rows, five / six block columns: a pass of the scan is 1024 .. 2048 draws there)
     int64_t main_n = 0;
     const int64_t k = p.B / pass, r = p.B - k * pass;
     if (k >= 1 && r > 0 && r <= rem_max) main_n = k * pass;

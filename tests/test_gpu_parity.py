@@ -297,6 +297,33 @@ def test_remainder_of_a_multi_pass_batch_on_the_second_stream(ctx, basis, B):
         assert relerr(g2[tail][fin], r2[fin]) < 1e-10
 
 
+@pytest.mark.parametrize("J,B", [(40, 1024 + 70), (32, 2048 + 100), (39, 1024 + 256)])
+def test_remainder_of_a_multi_pass_batch_64_to_95_rows(ctx, J, B):
+    """64 .. 95 rows (a pass of the throughput kernel is 1024 .. 2048 draws there): the remainder, up to 256 draws, runs on the windowed
+    kernel's five / six block columns on the second stream (round 4; SHO-40, 1100 draws at N = 1e4: 25 instead of 37 ms)."""
+    rng = np.random.default_rng(B + J)
+    N = 120
+    t = np.cumsum(rng.uniform(0.05, 2.0, N)); y = rng.standard_normal(N); yerr = rng.uniform(0.01, 0.05, N)
+    th = O.synthetic_theta(B, t, y, seed=B)
+    A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, J, "SHO")
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan + block (remainder)"
+    try:
+        ctx.set_option("no_split", True)
+        one, st1 = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan"
+    finally:
+        ctx.set_option("no_split", False)
+    ok = (st == 0) & (st1 == 0)
+    kept = ok & (one > one[ok].max() - 1e3)
+    assert np.array_equal(st == 0, st1 == 0) and kept.sum() > B // 4 and relerr(got[kept], one[kept]) < 5e-10
+    idx = np.concatenate([np.arange(0, B, 211), np.arange(B - 12, B)])
+    ref, rst = O.logl_batch(A[idx], Bc[idx], C, Dd, t, y, yerr ** 2, mu[idx], nu[idx], nthreads=8, return_status=True)
+    k = (rst == 0) & kept[idx]
+    assert k.sum() >= 4 and relerr(got[idx][k], ref[k]) < 1e-9
+
+
 @pytest.mark.parametrize("J,nreal,N,B", [(40, 0, 61, 300), (40, 0, 90, 5), (33, 0, 130, 290), (36, 0, 47, 301), (39, 0, 1, 280), (39, 0, 2, 280),
                                           (40, 0, 3, 7), (40, 0, 4, 7), (40, 0, 5, 7), (40, 0, 6, 7), (40, 0, 7, 7), (40, 0, 8, 7), (40, 0, 9, 7),
                                           (45, 20, 75, 300), (50, 22, 64, 258), (42, 4, 333, 259), (44, 12, 51, 3)])
