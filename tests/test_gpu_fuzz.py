@@ -40,6 +40,23 @@ def test_fuzz_slice_block_and_scan_vs_oracle(capsys):
     assert s["worst_dev"] < 1e-8
 
 
+def test_fuzz_slice_32_to_47_terms_block_and_scan_vs_oracle(capsys):
+    """The same generator with 32..47 terms (64..94 rows less the one-row terms): the windowed kernel's five / six block columns
+    (round 4) and the throughput scan's 80- and 96-row shapes, 400 cases."""
+    import pioran_jl_amd as pj
+    from oracle import oracle as O
+    fz = _fuzz_module()
+    s = fz.fuzz(pj, O, pj.Context(0), seed=fz.SEED, ncases=400, keep=3, jrange=(32, 48))
+    with capsys.disabled():
+        print(f"\nfuzz slice, 32..47 terms: {s['cases']} cases in {s['seconds']:.1f} s, worst deviation {s['worst_dev']:.2e}", file=sys.stderr)
+        for r in s["worst"]:
+            print(f"  case {r['idx']}: J={r['J']} N={r['N']} B={r['B']} nreal={r['nreal']} per-draw-series={r['useY']} layout={r['layout']} "
+                  f"draw={r['draw']} dev={r['dev']:.2e}", file=sys.stderr)
+    assert s["cases"] == 400
+    assert not s["failures"], s["failures"][:5]
+    assert s["worst_dev"] < 1e-8
+
+
 def test_fuzz_windowed_gradient_vs_step_by_step_and_oracle(capsys):
     """Randomized shapes for the windowed reverse mode (celerite_block_adjoint_kernel): 300 seeded cases — 3..31 terms, some of them
     one-row terms, N = 1..400 with occasional long gaps, 1..4 chains, shared or per-draw (c, d) — every gradient component against

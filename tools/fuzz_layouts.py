@@ -4,7 +4,9 @@ term counts (1..31, some of them one-row terms), series lengths 1..700 with occa
 per-draw series.  Every case is generated from (seed, index) alone, so the worst ones can be regenerated anywhere (also on a
 box without a GPU, for an extended-precision look at them: tools/explain_outliers.py).
 
-usage: python tools/fuzz_layouts.py [seconds] [--dump gpurun_out/fuzz_worst.json]
+usage: python tools/fuzz_layouts.py [seconds] [--dump gpurun_out/fuzz_worst.json] [--terms LO HI]
+  --terms 32 47: 64 .. 94 rows less the one-row terms (windowed kernel with five / six block columns, round 4; the throughput
+  scan's 80- and 96-row shapes)
   round 2: 26 533 cases in 150 s, worst relative deviation 2.6e-9, no status / NaN mismatch
 tests/test_gpu_fuzz.py runs a case-bounded slice of the same generator under -m gpu."""
 import json
@@ -20,9 +22,10 @@ SEED = 20261003
 LAYOUTS = (("block", "block"), ("scan", None))
 
 
-def make_case(seed: int, idx: int) -> dict:
+def make_case(seed: int, idx: int, jrange=(1, 32)) -> dict:
+    """jrange = (lowest, highest + 1) number of terms; the default reproduces the cases of rounds 2 and 3 bit for bit."""
     rng = np.random.default_rng([seed, idx])
-    J = int(rng.integers(1, 32)); N = int(rng.integers(1, 700)); B = int(rng.integers(1, 40))
+    J = int(rng.integers(*jrange)); N = int(rng.integers(1, 700)); B = int(rng.integers(1, 40))
     nreal = int(rng.integers(0, J + 1)) if rng.random() < 0.4 else 0
     t = np.cumsum(rng.uniform(0.01, 3.0, N) * (rng.random(N) < 0.9) + rng.uniform(0, 40, N) * (rng.random(N) < 0.05) + 1e-3)
     y = rng.standard_normal(N); s2 = rng.uniform(1e-4, 0.1, N)
@@ -64,12 +67,12 @@ def gpu_values(pj, ctx, c: dict) -> dict:
     return res
 
 
-def fuzz(pj, O, ctx, seed=SEED, ncases=None, seconds=None, first=0, keep=8):
+def fuzz(pj, O, ctx, seed=SEED, ncases=None, seconds=None, first=0, keep=8, jrange=(1, 32)):
     """Runs cases first, first + 1, ... until `ncases` are done or `seconds` have passed.  Returns a summary: the number of
     cases, the worst deviation relative to max(1, |log L|), the `keep` worst (case, layout, draw) records, the failures."""
     t0 = time.time(); it = 0; worst = []; failures = []
     while (ncases is None or it < ncases) and (seconds is None or time.time() - t0 < seconds):
-        c = make_case(seed, first + it); it += 1
+        c = make_case(seed, first + it, jrange); it += 1
         ref = oracle_values(O, c)
         for name, (got, st) in gpu_values(pj, ctx, c).items():
             ok = np.isfinite(ref) & (st == 0)
@@ -93,7 +96,11 @@ if __name__ == "__main__":
     from oracle import oracle as O
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     budget = float(args[0]) if args else 150.0
-    s = fuzz(pj, O, pj.Context(0), seconds=budget)
+    jr = (1, 32)
+    if "--terms" in sys.argv:
+        k = sys.argv.index("--terms"); jr = (int(sys.argv[k + 1]), int(sys.argv[k + 2]) + 1); args = [a for a in args if a not in sys.argv[k + 1:k + 3]]
+        budget = float(args[0]) if args else 150.0
+    s = fuzz(pj, O, pj.Context(0), seconds=budget, jrange=jr)
     for r in s["worst"]:
         print("worst", r)
     for f in s["failures"]:
