@@ -327,8 +327,13 @@ int block_dispatch(pioran_ds* ds, const ScanParams& p)
     // 5.7 .. 7.5 ms on the throughput shapes.  With four block columns (48 rows and more) the table stays in LDS and 512 draws is the
     // limit (DRWCelerite-20 at 768 draws: 7.8 vs 7.1 ms on the throughput shape, which got faster this round).
     // Round 4: five and six block columns (64 .. 95 rows; value only, one workgroup per CU: up to 256 draws).
-    const bool automatic = !cfg && !o.no_block && p.R >= 6 &&
-                           (p.R > pioran_block_supported_rows()
+    // Late round 4 (tools/scalar_small_j.py, profiles/r04_few_rows.txt): five rows 1.84 -> 1.48 ms at N = 1e4; four and fewer rows stay on the
+    // throughput layout (1.42 against 1.47 ms) except for long series — its 20-double step records outgrow the L2 (N = 65536: 13.4 against
+    // 9.5 ms up to 256 draws, 11.2 at 512) — and for the scalar call, whose series arrive as per-draw (y, sigma2): N = 8192 1.36 -> 1.25 ms.
+    const bool few_rows = p.R < 5 && ((p.N >= 16384 && p.B <= 512) || (p.Y && p.B == 1 && p.N >= 2048));
+    const bool automatic = !cfg && !o.no_block &&
+                           (p.R < 5 ? few_rows
+                            : p.R > pioran_block_supported_rows()
                                 ? p.B <= 256
                                 : (p.B <= 512 || (p.B <= 768 && p.R >= 32 && p.R <= 47) || (p.B <= 1024 && p.R >= 36 && p.R <= 47)));
     if (!(force || automatic) || !p.tab || p.npd_rows != 0 || !pioran_block_fits_value(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;

@@ -324,6 +324,30 @@ def test_remainder_of_a_multi_pass_batch_64_to_95_rows(ctx, J, B):
     assert k.sum() >= 4 and relerr(got[idx][k], ref[k]) < 1e-9
 
 
+@pytest.mark.parametrize("J,nreal", [(1, 1), (1, 0), (2, 1), (2, 0), (3, 3), (4, 4), (3, 1)])
+def test_fewer_than_six_rows_long_series_and_scalar_call(ctx, J, nreal):
+    """1 .. 5 rows (the reference grid's j = 2 is four, benchmark/benchmarks.jl:16-18): five rows, long series (N >= 16384, up to 512 draws) and
+    the scalar call from N = 2048 on run on the windowed kernel since late round 4 (N = 65536: 14.3 -> 9.5 ms); everything else on the
+    throughput layout as before.  Both against the oracle, and which kernel ran."""
+    rng = np.random.default_rng(7000 + 10 * J + nreal)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    R = 2 * J - nreal
+    for N, B in ((16384 + 77, 3), (2500, 1), (900, 1), (2500, 4)):
+        t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+        if nreal:
+            Bc[:, -nreal:] = 0.0; Dd[-nreal:] = 0.0
+        ds = pj.Dataset(t, y, s2, ctx)
+        got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert name() == ("block" if (R == 5 or N >= 16384) else "scan"), (name(), R, N)
+        ref = np.array([O.logl(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2) for i in range(B)])
+        assert relerr(got, ref) < 1e-10
+        if B == 1:
+            one = ctx.logl(A[0], Bc[0], C, Dd, t, y - mu[0], nu[0] * s2)
+            assert name() == ("block" if (R == 5 or N >= 2048) else "scan"), (name(), R, N)
+            assert abs(one - ref[0]) <= 1e-10 * max(1.0, abs(ref[0]))
+        ds.close()
+
+
 @pytest.mark.parametrize("J,nreal,N,B", [(40, 0, 61, 300), (40, 0, 90, 5), (33, 0, 130, 290), (36, 0, 47, 301), (39, 0, 1, 280), (39, 0, 2, 280),
                                           (40, 0, 3, 7), (40, 0, 4, 7), (40, 0, 5, 7), (40, 0, 6, 7), (40, 0, 7, 7), (40, 0, 8, 7), (40, 0, 9, 7),
                                           (45, 20, 75, 300), (50, 22, 64, 258), (42, 4, 333, 259), (44, 12, 51, 3)])
