@@ -102,9 +102,9 @@ int pioran_dataset_destroy(pioran_ds* ds);
  * terms go through the host-pointer entry with cd_shared = 0, which builds the mixed table itself.)
  * The declared state persists until the next pioran_dataset_prepare on this data set; no other entry changes it.
  * Device memory: the table takes (6 J + 8)(N + 1) * 8 bytes (10 MB at N = 1e4, J = 20); the first small batch (at most 512
- * draws; 768 with 32 .. 47 rows, 1024 with 36 .. 47 rows; 6 .. 63 rows — and up to 256 draws with 64 .. 95 rows) builds a second table for the windowed small-batch kernel,
+ * draws; 768 with 32 .. 47 rows, 1024 with 36 .. 47 rows; 5 .. 63 rows — and up to 256 draws with 64 .. 95 rows; fewer than five rows: series of 16384 and more stamps, and the scalar call from N = 2048 on) builds a second table for the windowed small-batch kernel,
  * ~(30 J + 300) N bytes (37 MB there), and falls back to the other kernels if that does not fit (2 GB cap).
- * Entries that chunk their draws (per-draw (c, d) tables: 37 MB per draw; prediction: 8.3 GB, gradient: 6 GB per 256 draws at
+ * Entries that chunk their draws (per-draw (c, d) tables: 37 MB per draw; prediction: 2.6 GB, simulation: 1.4 GB, gradient: 6 GB per 256 draws at
  * N = 1e4, J = 20) take at most half of the free device memory and never more than the context option "workspace_limit_mb"
  * (default 16384); the buffers stay with the context until pioran_ctx_trim. */
 int pioran_dataset_prepare(pioran_ds* ds, int64_t J, const double* c, const double* d,
@@ -179,10 +179,11 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
  * times, any order (the reference wants them sorted).
  * status (may be NULL) as in pioran_celerite_logl_batch.  Host pointers, blocking.
  * With 6 .. 63 rows and shared (c, d) both calls run on the windowed factorisation (celerite_block.hip, round 3): z by a block
- * back-substitution, the two running vectors of `pred` in 128-step segments, the tau-only factors once per call — 6.9 ms per 256
+ * back-substitution, the two running vectors of `pred` in 128-step segments, the tau-only factors once per call — 6.1 ms per 256
  * draws x 1e4 times at N = 1e4, J = 20 (18.5 ms before); the simulation applies L window by window (5.0 ms per 256 draws, 8.7 before).
- * Workspace: the reverse mode's layout for the factor (41 KB per 16-step window and draw, 6 .. 9 KB of it written) + 2 N R doubles per draw
- * for the running vectors (8.3 GB for 256 draws at N = 1e4, R = 40; the chunk of draws shrinks to what is free).  Other shapes: the step-by-step
+ * Workspace: the factor as the consumer reads it (6 KB per 16-step window and draw at three block columns; 8.5 KB for the simulation — up to
+ * late round 4 both used the reverse mode's 41 KB layout) + 2 N R doubles per draw for the running vectors (2.6 GB for 256 draws at N = 1e4,
+ * R = 40, 8.3 GB before; the chunk of draws shrinks to what is free).  Other shapes: the step-by-step
  * kernels — the factor stored by the latency kernels (the lean one from 64 rows on, round 4): posterior mean and simulation up to 143 rows (the reference
  * benchmark grid's j = 64 is 128); beyond: PIORAN_ERR_UNSUPPORTED before any workspace is taken.  pioran_celerite_config_name(-1)
  * tells which ran ("block (windowed prediction)" / "wide (step-by-step prediction)", likewise "... simulation").

@@ -102,7 +102,7 @@ namespace {
 
 // How much NEW device memory a call may take for its chunked workspaces (per-draw tables, factor stores, gradient / prediction
 // workspaces): half of what is free, but never more than the context's absolute budget (option "workspace_limit_mb", default 16 GiB —
-// the 256-draw chunks of every entry fit: per-draw windowed tables 9.5 GB, prediction 8.3 GB, gradient 6 GB at N = 1e4, J = 20), so
+// the 256-draw chunks of every entry fit: per-draw windowed tables 9.5 GB, prediction 2.6 GB, gradient 6 GB at N = 1e4, J = 20), so
 // that a co-resident allocator (torch's caching allocator, a second context) is not starved on a 288 GB device.  The buffers stay in
 // the context until pioran_ctx_trim.
 static size_t ws_allow(const pioran_ctx* ctx, size_t free_b)
@@ -1299,11 +1299,11 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
     if (windowed) {
         size_t free_b = 0, total_b = 0;
         auto need = [&](int64_t nb) {
-            return (pioran_block_grad_workspace_doubles(nb, ds->N, s.R) + pioran_predict_q_workspace_doubles(nb, ds->N, s.R)) * sizeof(double);
+            return (pioran_block_store_workspace_doubles(nb, ds->N, s.R, 2) + pioran_predict_q_workspace_doubles(nb, ds->N, s.R)) * sizeof(double);
         };
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             while (chunk > 1 && need(chunk) > ws_allow(ctx, free_b) + ctx->bwork.cap + ctx->bscratch.cap) chunk /= 2;
-        rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, ds->N, s.R) * sizeof(double));
+        rc = ensure(ctx, ctx->bwork, pioran_block_store_workspace_doubles(chunk, ds->N, s.R, 2) * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bscratch, pioran_predict_q_workspace_doubles(chunk, ds->N, s.R) * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bgtab, pioran_block_gtab_doubles(ds->N, s.R) * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bK, pioran_predict_tau_workspace_doubles(M, s.R, 1) * sizeof(double));
@@ -1369,7 +1369,7 @@ static int predict_perdraw_windowed(pioran_ds* ds, int64_t B, int64_t J, const d
     const int64_t N = ds->N;
     const int64_t bt = (int64_t)pioran_block_table_doubles(N, s.R, s.J), gt = (int64_t)pioran_block_gtab_doubles(N, s.R);
     auto per_chunk = [&](int64_t nb) {
-        return ((size_t)nb * ((size_t)bt + (size_t)gt) + pioran_block_grad_workspace_doubles(nb, N, s.R) + pioran_predict_q_workspace_doubles(nb, N, s.R) +
+        return ((size_t)nb * ((size_t)bt + (size_t)gt) + pioran_block_store_workspace_doubles(nb, N, s.R, 2) + pioran_predict_q_workspace_doubles(nb, N, s.R) +
                 pioran_predict_tau_workspace_doubles(M, s.R, nb) + (size_t)nb * (size_t)M) * sizeof(double);
     };
     int64_t chunk = B < 256 ? B : 256;
@@ -1379,7 +1379,7 @@ static int predict_perdraw_windowed(pioran_ds* ds, int64_t B, int64_t J, const d
             while (chunk > 1 && per_chunk(chunk) > ws_allow(ctx, free_b) + ctx->bwork.cap + ctx->bscratch.cap + ctx->bgtab.cap + ctx->bK.cap + ctx->bq.cap) chunk /= 2;
     }
     for (;;) {
-        rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double));
+        rc = ensure(ctx, ctx->bwork, pioran_block_store_workspace_doubles(chunk, N, s.R, 2) * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bscratch, (size_t)chunk * (size_t)bt * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bgtab, (size_t)chunk * (size_t)gt * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bq, pioran_predict_q_workspace_doubles(chunk, N, s.R) * sizeof(double));
@@ -1732,8 +1732,8 @@ static int simulate_shared(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, con
     if (windowed) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            while (chunk > 1 && pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double) > ws_allow(ctx, free_b) + ctx->bwork.cap) chunk /= 2;
-        rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double));
+            while (chunk > 1 && pioran_block_store_workspace_doubles(chunk, N, s.R, 3) * sizeof(double) > ws_allow(ctx, free_b) + ctx->bwork.cap) chunk /= 2;
+        rc = ensure(ctx, ctx->bwork, pioran_block_store_workspace_doubles(chunk, N, s.R, 3) * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bscratch, (size_t)chunk * (size_t)N * sizeof(double));   // xi
         if (!rc) rc = ensure(ctx, ctx->bst, chunk * sizeof(int32_t));
         if (rc == PIORAN_ERR_ALLOC) { windowed = false; chunk = B < 256 ? B : 256; }
@@ -1795,12 +1795,12 @@ static int simulate_perdraw_windowed(pioran_ctx* ctx, int64_t N, int64_t B, int6
     int64_t chunk = B < 256 ? B : 256;
     {
         size_t free_b = 0, total_b = 0;
-        auto need = [&](int64_t nb) { return ((size_t)nb * (size_t)bt + pioran_block_grad_workspace_doubles(nb, N, s.R) + 3 * (size_t)nb * (size_t)N) * sizeof(double); };
+        auto need = [&](int64_t nb) { return ((size_t)nb * (size_t)bt + pioran_block_store_workspace_doubles(nb, N, s.R, 3) + 3 * (size_t)nb * (size_t)N) * sizeof(double); };
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             while (chunk > 1 && need(chunk) > ws_allow(ctx, free_b) + ctx->bwork.cap + ctx->bscratch.cap + ctx->bq.cap) chunk /= 2;
     }
     for (;;) {
-        rc = ensure(ctx, ctx->bwork, pioran_block_grad_workspace_doubles(chunk, N, s.R) * sizeof(double));
+        rc = ensure(ctx, ctx->bwork, pioran_block_store_workspace_doubles(chunk, N, s.R, 3) * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bscratch, (size_t)chunk * (size_t)bt * sizeof(double));
         if (!rc) rc = ensure(ctx, ctx->bq, (size_t)chunk * (size_t)N * sizeof(double));     // xi
         if (rc != PIORAN_ERR_ALLOC || chunk == 1) break;

@@ -420,12 +420,19 @@ __device__ __forceinline__ void dma_pieces_asm(const double* gsrc, double* ldst,
 // order) and K = Sigma^-1 (block_grad_ws_doubles gives the layout).  The value it returns is bit-identical to the plain kernel's.
 // (the last 320: the chain wavefront's D_k and D_k (L^-1)_ik, sh.Li as it stands — the simulation applies L with it)
 __host__ __device__ constexpr int64_t block_grad_ws_doubles(int NB) { return (int64_t)NB * NB * 256 + 3 * (int64_t)NB * 256 + 256 + 320; }
+// The prediction (ST = 2: Q in A-operand order) and the simulation (ST = 3: Q in C/D order, then sh.Li) keep only what they read, packed
+// (late round 4; before, they used the reverse mode's 41 KB per window with 6 .. 9 KB of it written: 8.3 GB for 256 draws at N = 1e4, J = 20).
+__host__ __device__ constexpr int64_t block_ws_doubles(int NB, int ST) { return ST == 2 ? (int64_t)NB * 256 : (ST == 3 ? (int64_t)NB * 256 + 320 : block_grad_ws_doubles(NB)); }
+__host__ __device__ constexpr int block_ws_off_q(int NB, int ST) { return ST == 3 ? 0 : NB * NB * 256 + NB * 256; }
+__host__ __device__ constexpr int block_ws_off_qf(int NB, int ST) { return ST == 2 ? 0 : NB * NB * 256 + 2 * NB * 256; }
+__host__ __device__ constexpr int block_ws_off_li(int NB, int ST) { return ST == 3 ? NB * 256 : NB * NB * 256 + 3 * NB * 256 + 256; }
 template <int NB, int EM, int PDM = 0, int ST = 0>   // ST: 0 no stores, 1 everything the reverse pass needs, 2 Q in A-operand order (prediction), 3 Q in C/D order and L^-1, D (simulation)
 __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4 && PDM != 1 && (!ST || (ST == 1 && EM == 2))) ? 2 : 1) celerite_block_kernel(const ScanParams p, const double* __restrict__ btab)
 {
     constexpr bool PD = PDM != 0;
-    [[maybe_unused]] constexpr int64_t GWS = block_grad_ws_doubles(NB);
-    [[maybe_unused]] constexpr int OFF_M = NB * NB * 256, OFF_Q = OFF_M + NB * 256, OFF_QF = OFF_Q + NB * 256, OFF_K = OFF_QF + NB * 256;
+    [[maybe_unused]] constexpr int64_t GWS = block_ws_doubles(NB, ST);
+    [[maybe_unused]] constexpr int OFF_M = NB * NB * 256, OFF_Q = block_ws_off_q(NB, ST), OFF_QF = block_ws_off_qf(NB, ST), OFF_K = NB * NB * 256 + 3 * NB * 256,
+                                   OFF_LI = block_ws_off_li(NB, ST);
     constexpr bool EDBL = EM == 1, EGLOB = EM == 2;
     constexpr int NCW = NB < 4 ? 4 : NB + 1;   // computing wavefronts: owners + chain (five and six block columns, round 4: 64 .. 95 rows,
                                                // value only — the reference grid's j = 32 is 64 rows + y)
@@ -967,7 +974,7 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
                 }
                 if constexpr (ST != 2) {
 #pragma unroll
-                    for (int i = lane; i < 16 * 18; i += 64) gwk[OFF_K + 256 + i] = sh.Li[i];
+                    for (int i = lane; i < 16 * 18; i += 64) gwk[OFF_LI + i] = sh.Li[i];
                 }
             }
         }
@@ -1641,8 +1648,8 @@ int launch_block_grad(const ScanParams& p, const double* btab, const double* gta
 template <int NB>
 __global__ void __launch_bounds__(64) celerite_block_backsolve_kernel(const ScanParams p, const double* __restrict__ gtab, double* __restrict__ gy)
 {
-    constexpr int64_t GWS = block_grad_ws_doubles(NB);
-    constexpr int OFF_QF = NB * NB * 256 + 2 * NB * 256;
+    constexpr int64_t GWS = block_ws_doubles(NB, 2);
+    constexpr int OFF_QF = block_ws_off_qf(NB, 2);
     constexpr int64_t GTS = 4 * (int64_t)NB * 256 + 16 * NB + 16 + 24;
     __shared__ double hs[64], zs[16];
     const int64_t b = blockIdx.x, N = p.N, NW = (N + KW - 1) / KW;
@@ -1723,8 +1730,8 @@ __global__ void __launch_bounds__(64) celerite_block_backsolve_kernel(const Scan
 template <int NB>
 __global__ void __launch_bounds__(256) block_sim_xi_kernel(const ScanParams p, double* __restrict__ xi)
 {
-    constexpr int64_t GWS = block_grad_ws_doubles(NB);
-    constexpr int OFF_LI = NB * NB * 256 + 3 * NB * 256 + 256;
+    constexpr int64_t GWS = block_ws_doubles(NB, 3);
+    constexpr int OFF_LI = block_ws_off_li(NB, 3);
     const int64_t N = p.N, NW = (N + KW - 1) / KW, b = blockIdx.y;
     const int64_t k = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int i = threadIdx.x & 15;
@@ -1746,8 +1753,8 @@ __global__ void __launch_bounds__(256) block_sim_xi_kernel(const ScanParams p, d
 template <int NB>
 __global__ void __launch_bounds__(64) celerite_block_sim_kernel(const ScanParams p, const double* __restrict__ btab, const double* __restrict__ xi)
 {
-    constexpr int64_t GWS = block_grad_ws_doubles(NB);
-    constexpr int OFF_Q = NB * NB * 256 + NB * 256;
+    constexpr int64_t GWS = block_ws_doubles(NB, 3);
+    constexpr int OFF_Q = block_ws_off_q(NB, 3);
     __shared__ double fs[64], xs[16];
     const int64_t b = blockIdx.x, N = p.N, NW = (N + KW - 1) / KW;
     const int lane = threadIdx.x, q = lane >> 4, c16 = lane & 15;
@@ -1867,7 +1874,7 @@ int launch_block_solve(const ScanParams& p, const double* btab, const double* gt
 }  // namespace
 
 // log L (p.out, p.status) and gy [B][N] = -K^-1 (y - mu): the windowed forward pass with its per-window stores (p.gw:
-// pioran_block_grad_workspace_doubles) followed by the block back-substitution.  gtab: pioran_launch_block_gtab.
+// pioran_block_store_workspace_doubles(.., 2)) followed by the block back-substitution.  gtab: pioran_launch_block_gtab.
 int pioran_launch_block_solve(const ScanParams& p, const double* btab, const double* gtab, double* gy, hipStream_t stream)
 {
     if (!btab || !gtab || !gy || !p.gw || p.npd_rows != 0 || p.B < 1 || p.N < 1 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
@@ -1882,7 +1889,7 @@ int pioran_launch_block_solve(const ScanParams& p, const double* btab, const dou
 }
 
 // GP realisations p.ysim [B][N] from the normals p.noise [B][N]: the windowed factorisation of the covariance (data set with y = 0;
-// p.gw: pioran_block_grad_workspace_doubles; xi: B N doubles of scratch), then the two simulation kernels above.
+// p.gw: pioran_block_store_workspace_doubles(.., 3); xi: B N doubles of scratch), then the two simulation kernels above.
 int pioran_launch_block_sim(const ScanParams& p, const double* btab, double* xi, hipStream_t stream)
 {
     if (!btab || !xi || !p.gw || !p.noise || !p.ysim || p.npd_rows != 0 || p.B < 1 || p.N < 1 || !pioran_block_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
@@ -1900,6 +1907,12 @@ size_t pioran_block_grad_workspace_doubles(int64_t B, int64_t N, int32_t R)
 {
     const int NB = (R + 1 + 15) / 16;
     return (size_t)B * (size_t)((N + KW - 1) / KW) * (size_t)block_grad_ws_doubles(NB);
+}
+// p.gw of pioran_launch_block_solve (what = 2) / pioran_launch_block_sim (what = 3): the packed per-window stores
+size_t pioran_block_store_workspace_doubles(int64_t B, int64_t N, int32_t R, int what)
+{
+    const int NB = (R + 1 + 15) / 16;
+    return (size_t)B * (size_t)((N + KW - 1) / KW) * (size_t)block_ws_doubles(NB, what == 2 ? 2 : 3);
 }
 size_t pioran_block_gtab_doubles(int64_t N, int32_t R)
 {

@@ -149,6 +149,7 @@ int pioran_launch_block_table_batch(int64_t N, int32_t R, int32_t J, int64_t nb,
                                     const double* D, const double* y, const double* s2, double* btab, int64_t draw_stride, hipStream_t stream);
 // windowed reverse mode (gradient w.r.t. a, b, mu, nu): forward pass with stores + adjoint kernel
 size_t pioran_block_grad_workspace_doubles(int64_t B, int64_t N, int32_t R);
+size_t pioran_block_store_workspace_doubles(int64_t B, int64_t N, int32_t R, int what);   // prediction (what = 2) / simulation (3): packed stores
 size_t pioran_block_gtab_doubles(int64_t N, int32_t R);
 int pioran_launch_block_gtab(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c, const double* d,
                              const double* s2, double* gtab, hipStream_t stream);
