@@ -49,7 +49,8 @@ int main(int argc, char** argv)
                           "Y^' = L^-1 X', publish", "barrier 3", "tail"};
     const double nw = (double)((N + 15) / 16);
     printf("J = %d: logl = %.6f\n", J, out);
-    for (int wv = 0; wv < (R + 1 > 48 ? 5 : 4); ++wv) {
+    const int nbk = (R + 1 + 15) / 16;
+    for (int wv = 0; wv < (nbk >= 4 ? (nbk + 2 > 8 ? 8 : nbk + 2) : 4); ++wv) {
         unsigned long long tot = 0; for (int i = 0; i < 11; ++i) tot += acc[wv][i];
         printf("wavefront %d: %.0f cycles per window (stamps included)\n", wv, (double)tot / nw);
         for (int i = 0; i < 11; ++i) printf("  %-46s %8.1f\n", nm[i], (double)acc[wv][i] / nw);
