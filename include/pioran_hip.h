@@ -178,7 +178,7 @@ int pioran_logpdf_batch_theta(pioran_ds* ds, int64_t B, int model, int64_t n_com
  * for B draws of (a, b); (c, d) [J] shared (cd_shared != 0) or [B][J] per draw (see the last paragraph).  tau: M evaluation
  * times, any order (the reference wants them sorted).
  * status (may be NULL) as in pioran_celerite_logl_batch.  Host pointers, blocking.
- * With 6 .. 63 rows and shared (c, d) both calls run on the windowed factorisation (celerite_block.hip, round 3): z by a block
+ * Up to 63 rows (from one row on since late round 4; six before) and shared (c, d) both calls run on the windowed factorisation (celerite_block.hip, round 3): z by a block
  * back-substitution, the two running vectors of `pred` in 128-step segments, the tau-only factors once per call — 6.1 ms per 256
  * draws x 1e4 times at N = 1e4, J = 20 (18.5 ms before); the simulation applies L window by window (5.0 ms per 256 draws, 8.7 before).
  * Workspace: the factor as the consumer reads it (6 KB per 16-step window and draw at three block columns; 8.5 KB for the simulation — up to
@@ -202,7 +202,7 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
  *       model that transforms the data per draw (the sampled shift of docs/src/ultranest.md:199-205) chains through.
  * C, Dd: [J] when cd_shared != 0, else [B][J] (windowed reverse mode: every draw its own tables, all draws in one launch — 16 chains
  *   8 ms at N = 1e4, J = 20; shapes past 63 rows: each draw evaluated as its own one-draw batch).
- * Two reverse modes.  With 6 .. 63 rows the WINDOWED reverse mode runs (celerite_block.hip, round 3): the windowed forward pass leaves T,
+ * Two reverse modes.  Up to 63 rows (from one row on since late round 4: 16.4 -> 4.4 ms at N = 1e4; six before) the WINDOWED reverse mode runs (celerite_block.hip, round 3): the windowed forward pass leaves T,
  * M', Sigma^-1 X' and Sigma^-1 of every 16-step window (38 KB per window at J = 20: 24 MB per draw at N = 1e4; chains are
  * processed 512 at a time — 12 GB —, fewer when the context option "workspace_limit_mb" or the free memory say so) and the adjoint kernel
  * walks the windows backwards with six GEMM stages each — value + gradient 5.4 ms for one chain, 5.8 ms for 256 (6.1 .. 6.3 ms with

@@ -1289,7 +1289,7 @@ static int predict_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A, 
     int64_t chunk = B < 256 ? B : 256;
     // Windowed path (round 3): z = K^-1 (y - mu) from the windowed factorisation and a block back-substitution (celerite_block.hip),
     // then the two Q recurrences segment-parallel (celerite_predict.hip) — no step-by-step factor, no per-step wave reduction
-    bool windowed = !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R >= 6 && s.R <= 63 &&
+    bool windowed = !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R <= 63 &&
                     pioran_block_fits(s.R, s.J);
     if (windowed) {
         rc = ensure_btab(ds, s);
@@ -1360,7 +1360,7 @@ static int predict_perdraw_windowed(pioran_ds* ds, int64_t B, int64_t J, const d
 {
     pioran_ctx* ctx = ds->ctx;
     PrepState& s = ds->host;
-    if (ctx->opt.no_block || ctx->opt.force_fallback || ctx->opt.scan_config[0] || 2 * J < 6 || !pioran_block_fits((int32_t)(2 * J), (int32_t)J))
+    if (ctx->opt.no_block || ctx->opt.force_fallback || ctx->opt.scan_config[0] || !pioran_block_fits((int32_t)(2 * J), (int32_t)J))
         return PIORAN_ERR_UNSUPPORTED;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PendingGuard pending_guard(ctx);
@@ -1462,7 +1462,7 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
     if (s.R > pioran_wide_supported_rows_grad() || s.npd_terms) return PIORAN_ERR_UNSUPPORTED;
     // Windowed reverse mode (celerite_block.hip, round 3) whenever the rows fit the windowed kernel, with or without d/d(c, d):
     // 6.3 ms (7.0 with d/d(c, d)) instead of 25 at N = 1e4, J = 20 (series gradients and the shifted log-flux models included).
-    bool windowed = !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R >= 6 &&
+    bool windowed = !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] &&
                     pioran_block_fits(s.R, s.J);
     if (windowed) {
         rc = ensure_btab(ds, s);
@@ -1579,7 +1579,7 @@ static int logl_grad_perdraw_windowed(pioran_ds* ds, int64_t B, int64_t J, const
 {
     pioran_ctx* ctx = ds->ctx;
     PrepState& s = ds->host;
-    if (ctx->opt.no_block || ctx->opt.force_fallback || ctx->opt.scan_config[0] || 2 * J < 6 || !pioran_block_fits((int32_t)(2 * J), (int32_t)J))
+    if (ctx->opt.no_block || ctx->opt.force_fallback || ctx->opt.scan_config[0] || !pioran_block_fits((int32_t)(2 * J), (int32_t)J))
         return PIORAN_ERR_UNSUPPORTED;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PendingGuard pending_guard(ctx);
@@ -1722,7 +1722,7 @@ static int simulate_shared(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, con
     if (s.R > pioran_wide_supported_rows_modes() || s.npd_terms) return done(PIORAN_ERR_UNSUPPORTED);   // before any upload / workspace
     int64_t chunk = B < 256 ? B : 256;
     // Windowed path (round 3; 6 .. 63 rows): the windowed factorisation with its per-window stores, then L applied window by window
-    bool windowed = !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R >= 6 && s.R <= 63 &&
+    bool windowed = !ctx->opt.no_block && !ctx->opt.force_fallback && !ctx->opt.scan_config[0] && s.R <= 63 &&
                     pioran_block_fits(s.R, s.J);
     if (windowed) {
         rc = ensure_btab(ds, s);
@@ -1781,7 +1781,7 @@ static int simulate_shared(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, con
 static int simulate_perdraw_windowed(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, const double* A, const double* Bc, const double* C,
                                      const double* Dd, const double* t, const double* sigma2, const double* q, double* y_out)
 {
-    if (ctx->opt.no_block || ctx->opt.force_fallback || ctx->opt.scan_config[0] || 2 * J < 6 || !pioran_block_fits((int32_t)(2 * J), (int32_t)J))
+    if (ctx->opt.no_block || ctx->opt.force_fallback || ctx->opt.scan_config[0] || !pioran_block_fits((int32_t)(2 * J), (int32_t)J))
         return PIORAN_ERR_UNSUPPORTED;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     pioran_ds* ds = nullptr;

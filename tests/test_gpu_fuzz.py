@@ -58,7 +58,7 @@ def test_fuzz_slice_32_to_47_terms_block_and_scan_vs_oracle(capsys):
 
 
 def test_fuzz_windowed_gradient_vs_step_by_step_and_oracle(capsys):
-    """Randomized shapes for the windowed reverse mode (celerite_block_adjoint_kernel): 300 seeded cases — 3..31 terms, some of them
+    """Randomized shapes for the windowed reverse mode (celerite_block_adjoint_kernel): 300 seeded cases — 3..31 terms (every seventh case: one or two), some of them
     one-row terms, N = 1..400 with occasional long gaps, 1..4 chains, shared or per-draw (c, d) — every gradient component against
     the step-by-step adjoint kernels (a different algorithm on a different kernel), every tenth case against the complex-step oracle."""
     import numpy as np
@@ -71,6 +71,8 @@ def test_fuzz_windowed_gradient_vs_step_by_step_and_oracle(capsys):
     for idx in range(300):
         rng = np.random.default_rng([20261004, idx])
         J = int(rng.integers(3, 32)); N = int(rng.integers(1, 401)); B = int(rng.integers(1, 5))
+        if idx % 7 == 3:
+            J = 1 + idx % 2          # one and two terms (1 .. 4 rows)
         gaps = rng.uniform(0.05, 2.0, N)
         if rng.random() < 0.3:
             gaps[rng.integers(0, N, max(1, N // 20))] *= rng.uniform(5, 400)
@@ -86,8 +88,8 @@ def test_fuzz_windowed_gradient_vs_step_by_step_and_oracle(capsys):
         ds = pj.Dataset(t, y, s2, ctx)
         gw = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
         R = 2 * J - nreal
-        want = "block (windowed gradient, per-draw tables)" if per_draw else ("block (windowed gradient)" if R >= 6 else "wide (step-by-step gradient)")
-        assert name() == want, (idx, name(), R)     # (fewer than six rows: not worth a 16-row block column)
+        want = "block (windowed gradient, per-draw tables)" if per_draw else "block (windowed gradient)"
+        assert name() == want, (idx, name(), R)     # (fewer than six rows too, since late round 4: 16.4 -> 4.4 ms at N = 1e4)
         try:
             ctx.set_option("no_block", True)
             go = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
@@ -127,6 +129,8 @@ def test_fuzz_windowed_prediction_and_simulation_vs_step_by_step_and_oracle(caps
     for idx in range(200):
         rng = np.random.default_rng([20261005, idx])
         J = int(rng.integers(3, 32)); B = int(rng.integers(1, 6))
+        if idx % 7 == 3:
+            J = 1 + idx % 2          # one and two terms (1 .. 4 rows: windowed too since late round 4)
         N = int(edges[idx % len(edges)]) if idx < 40 else int(rng.integers(1, 701))
         gaps = rng.uniform(0.05, 2.0, N)
         if rng.random() < 0.3:
@@ -144,9 +148,9 @@ def test_fuzz_windowed_prediction_and_simulation_vs_step_by_step_and_oracle(caps
         R = 2 * J - nreal
         ds = pj.Dataset(t, y, s2, ctx)
         pw, st = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu, return_status=True)
-        assert name() == ("block (windowed prediction)" if R >= 6 else "wide (step-by-step prediction)"), (idx, name(), R)
+        assert name() == "block (windowed prediction)", (idx, name(), R)
         sw = ctx.simulate(A, Bc, C, Dd, t, s2, q)
-        assert name() == ("block (windowed simulation)" if R >= 6 else "wide (step-by-step simulation)"), (idx, name(), R)
+        assert name() == "block (windowed simulation)", (idx, name(), R)
         try:
             ctx.set_option("no_block", True)
             po, st2 = ds.predict(A, Bc, C, Dd, tau, mu=mu, nu=nu, return_status=True)
