@@ -915,7 +915,9 @@ static int mixed_core(pioran_ds* ds, int64_t B, int64_t J, const std::vector<int
         const ScanOptions& o = ctx->opt;
         const char* cfg = o.scan_config[0] ? o.scan_config : nullptr;
         const bool force = cfg && !std::strcmp(cfg, "block");
-        const bool automatic = !cfg && !o.no_block && B <= 512 && rows >= 6;
+        // (fewer than six rows, late round 4, tools/per_draw_few_rows.py: the generic per-draw path took 7.5 ms for 16 draws of ONE term at N = 1e4 —
+        //  1.7 ms here; 768 draws 8.2 -> 4.2 ms)
+        const bool automatic = !cfg && !o.no_block && (rows >= 6 ? B <= 512 : B <= 768);
         blk_ok = (force || automatic) && !o.force_fallback && npd >= 1 && pioran_block_fits_pd((int32_t)rows, (int32_t)J, (int32_t)npd);
     }
     if (npd == 0 || npd > 8 || (!must_run && !blk_ok && npd * 2 > J)) return 0;
