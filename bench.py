@@ -570,6 +570,27 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
     out["single_evaluation_B1"] = single
     out["single_evaluation_B1"]["kernel"] = ("celerite_block_kernel (windowed form, 16 steps per window on the fp64 matrix cores; "
                                              "celerite_block.hip) for B <= 512 and 6 <= rows <= 63")
+    # -- the reference's own benchmark (benchmark/benchmarks.jl:16-18, 74-91: ONE scalar `logl` call, j terms with random coefficients, the suite's
+    #    yerr passed as the variance) at its N = 8192 column; the published figure's values read off BASELINE.md section 1 (+-15 %, unstated CPU).
+    #    tools/bench_grid.py runs the whole grid (profiles/r04_grid.json). -----------------------------------------------------------------------
+    grid = {}
+    published_ms = {2: 0.85, 4: 1.6, 8: 3.7, 16: 10.0, 32: 32.0, 64: 180.0}
+    rgrid = np.random.Generator(np.random.PCG64(1234))
+    abcd = rgrid.random((64, 4)); abcd[:, 0] *= 5
+    ng = min(8192, N)
+    tg, yg, eg = t[:ng], y[:ng], yerr[:ng]
+    for jg in (2, 4, 8, 16, 32, 64):
+        ag, bg, cg, dg = (np.ascontiguousarray(abcd[:jg, k]) for k in range(4))
+        vg = ctx.logl(ag, bg, cg, dg, tg, yg, eg)
+        kern = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+        wall = []
+        for _ in range(5):
+            t0 = time.perf_counter(); ctx.logl(ag, bg, cg, dg, tg, yg, eg); wall.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); rg_ = O.logl(ag, bg, cg, dg, tg, yg, eg); cpu_ms = (time.perf_counter() - t0) * 1e3
+        grid[f"j{jg}"] = {"scalar_call_ms_incl_pcie": med(wall) * 1e3, "kernel": kern, "reference_figure_ms": published_ms[jg],
+                          "cpu_one_core_ms_this_host": cpu_ms, "rel_dlogl_vs_oracle": abs(vg - rg_) / abs(rg_)}
+    out["reference_benchmark_grid_N8192"] = grid
+
     # -- small batches (MCMC walkers / a few live points): one workgroup per draw, the same windowed kernel --------------
     small = {}
     for basis in ("SHO", "DRWCelerite"):
