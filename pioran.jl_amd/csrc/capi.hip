@@ -1067,6 +1067,43 @@ static int batch_host_impl(pioran_ds* ds, int64_t B, int64_t J, const double* A,
         if (rc == 1) return PIORAN_OK;
     }
     if (cd_shared && (rc = prepare_shared(ds, B, J, Bc, C, Dd))) return rc;
+    // Small calls with shared (c, d) — the scalar drop-in, a few walkers (late round 4): the kernels read the coefficients straight from
+    // pinned host memory (each value once) and write log L / status straight into it, so the call issues no copy command for them; a
+    // per-draw series, which the kernels stream step by step, still goes to HBM, (y | sigma2) in ONE copy.  Scalar call, N = 32: 44 -> 3x us.
+    const size_t zc_in = 2 * bj + (mu ? B * sizeof(double) : 0) + (nu ? B * sizeof(double) : 0);
+    const size_t zc_all = zc_in + B * sizeof(double) + ((B * sizeof(int32_t) + 7) & ~size_t(7));
+    const size_t zc_pad = (zc_all + 255) & ~size_t(255);
+    const bool y_staged = Y && zc_pad + 2 * bn <= kPinMaxRequest;      // (ONE reservation: a second one could drain or move the staging area)
+    char* zc = (cd_shared && zc_all <= (size_t(16) << 10) && !(ctx->opt.exp & 64)) ? (char*)pin_reserve(ctx, zc_pad + (y_staged ? 2 * bn : 0)) : nullptr;
+    if (zc) {
+        const double *dA = (const double*)zc, *dB = dA + B * J, *dmu = nullptr, *dnu = nullptr;
+        char* q = zc + 2 * bj;
+        std::memcpy(zc, A, bj); std::memcpy(zc + bj, Bc, bj);
+        if (mu) { std::memcpy(q, mu, B * sizeof(double)); dmu = (const double*)q; q += B * sizeof(double); }
+        if (nu) { std::memcpy(q, nu, B * sizeof(double)); dnu = (const double*)q; q += B * sizeof(double); }
+        double* dout = (double*)q; q += B * sizeof(double);
+        int32_t* dst = (int32_t*)q;
+        const double *dY = nullptr, *dS2 = nullptr;
+        if (Y) {
+            if ((rc = ensure(ctx, ctx->bY, 2 * bn))) return rc;
+            if (y_staged) {
+                char* sy = zc + zc_pad;
+                std::memcpy(sy, Y, bn); std::memcpy(sy + bn, S2, bn);
+                HIPCHK(ctx, hipMemcpyAsync(ctx->bY.p, sy, 2 * bn, hipMemcpyHostToDevice, ctx->stream));
+            } else {
+                HIPCHK(ctx, hipMemcpyAsync(ctx->bY.p, Y, bn, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync((char*)ctx->bY.p + bn, S2, bn, hipMemcpyHostToDevice, ctx->stream));
+            }
+            dY = (const double*)ctx->bY.p; dS2 = dY + (size_t)B * (size_t)ds->N;
+        } else if (series_on_device) {
+            dY = (const double*)ctx->bY.p; dS2 = (const double*)ctx->bS2.p;
+        }
+        if ((rc = batch_dev_impl(ds, ds->host, B, dA, dB, dmu, dnu, dY, dS2, dout, dst))) return rc;
+        ctx->pending.push_back({out, dout, B * sizeof(double)});
+        if (status) ctx->pending.push_back({status, dst, B * sizeof(int32_t)});
+        SYNC(ctx);
+        return PIORAN_OK;
+    }
     if ((rc = upload(ctx, ctx->bA, A, bj))) return rc;
     if ((rc = upload(ctx, ctx->bB, Bc, bj))) return rc;
     if (!cd_shared) {
