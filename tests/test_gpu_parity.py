@@ -324,6 +324,34 @@ def test_remainder_of_a_multi_pass_batch_64_to_95_rows(ctx, J, B):
     assert k.sum() >= 4 and relerr(got[idx][k], ref[k]) < 1e-9
 
 
+@pytest.mark.parametrize("J,N,B,series", [(2, 40, 1, True), (20, 300, 8, False), (20, 300, 8, True), (5, 1000, 37, False), (31, 77, 3, True), (40, 64, 2, False)])
+def test_small_host_calls_without_copy_commands(ctx, J, N, B, series):
+    """Host-pointer calls whose coefficients and results fit 16 KB (the scalar drop-in, a few walkers): the kernels read a, b, mu, nu from and
+    write log L / status to pinned host memory, (y | sigma2) go up in one copy (late round 4).  Bit for bit what the path with copy commands
+    (context option exp = 64) returns, status included, and the oracle's values."""
+    rng = np.random.default_rng(7300 + J + N + B)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    A[B - 1] *= 1e3                                   # one draw the solver may flag
+    Y = rng.standard_normal((B, N)) if series else None
+    S2 = rng.uniform(0.01, 0.1, (B, N)) if series else None
+    ds = pj.Dataset(t, y, s2, ctx)
+    res = []
+    try:
+        for e in (64, 0, 0):
+            ctx.set_option("exp", e)
+            res.append(ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2, return_status=True))
+    finally:
+        ctx.set_option("exp", 0)
+    for got, st in res[1:]:
+        assert np.array_equal(got, res[0][0], equal_nan=True) and np.array_equal(st, res[0][1])
+    ref = np.array([O.logl(A[i], Bc[i], C, Dd, t, (Y[i] if series else y) - mu[i], nu[i] * (S2[i] if series else s2)) for i in range(B)])
+    ok = (res[1][1] == 0) & np.isfinite(ref)
+    assert ok[: B - 1].all() and relerr(res[1][0][ok], ref[ok]) < 1e-10
+    if B == 1:
+        one, st1 = ctx.logl(A[0], Bc[0], C, Dd, t, Y[0] - mu[0], nu[0] * S2[0], return_status=True)
+        assert st1 == 0 and abs(one - ref[0]) <= 1e-10 * abs(ref[0])
+
+
 @pytest.mark.parametrize("J,N,B", [(1, 300, 16), (2, 129, 70), (2, 1000, 300), (1, 77, 700), (2, 40, 2)])
 def test_fewer_than_six_rows_per_draw_cd_on_the_windowed_kernel(ctx, J, N, B):
     """One or two terms with (c, d) per draw (a free Celerite / Exp term under a sampler): up to 768 draws run on the windowed kernel with per-draw
