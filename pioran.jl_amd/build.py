@@ -12,8 +12,8 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OBJ = PKG / "_obj"
 LIB = PKG / "libpioran_hip.so"
-SOURCES = ["celerite_scan.hip", "celerite_wide.hip", "celerite_block.hip", "celerite_predict.hip", "celerite_fallback.hip", "table.hip", "approx.hip", "dense.hip", "capi.hip"]
-HEADERS = [CSRC / "common.h", PKG.parent / "include" / "pioran_hip.h"]
+SOURCES = ["celerite_scan.hip", "celerite_wide.hip", "celerite_block.hip", "celerite_tile.hip", "celerite_predict.hip", "celerite_fallback.hip", "table.hip", "approx.hip", "dense.hip", "capi.hip"]
+HEADERS = [CSRC / "common.h", CSRC / "window_common.h", PKG.parent / "include" / "pioran_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -51,7 +51,7 @@ struct pioran_ctx {
         void* p = nullptr;
         size_t cap = 0;
     };
-    Buf bA, bB, bC, bD, bmu, bnu, bY, bS2, bout, bst, bscratch, bK, bwork, bshift, bgtab, bq;
+    Buf bA, bB, bC, bD, bmu, bnu, bY, bS2, bout, bst, bscratch, bK, bwork, bshift, bgtab, bq, bpair;
     // scalar entry point: the last series' time stamps stay resident (samplers call logl with the same t)
     pioran_ds* scalar_ds = nullptr;
     std::vector<double> scalar_t;
@@ -366,6 +366,41 @@ static ScanParams slice_draws(const ScanParams& p, int64_t off, int64_t n)
     return q;
 }
 
+// Large shared-table batches: the windowed form with one draw per wavefront (celerite_tile.hip, round 5).  Same table as the windowed
+// kernel for small batches.  scan_config = "tile" forces it for any batch size.
+int tile_dispatch(pioran_ds* ds, const ScanParams& p)
+{
+    pioran_ctx* ctx = ds->ctx;
+    const ScanOptions& o = ctx->opt;
+    const char* cfg = o.scan_config[0] ? o.scan_config : nullptr;
+    const bool force = cfg && !std::strcmp(cfg, "tile");
+    const bool automatic = false;
+    if (!(force || automatic) || !p.tab || p.npd_rows != 0 || p.Y || p.S2 || !pioran_tile_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
+    if (!s || !s->prepared || s->npd_terms != 0 || p.rec_stride != 3 * (int64_t)(s->R + 2) + 2) return PIORAN_ERR_UNSUPPORTED;
+    int rc = ensure_btab(ds, *s);
+    if (rc) return rc;
+    // workspace: 1 KB per draw and window (the windows' own covariance blocks); large batches in chunks of whole passes
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
+    int ncu = 0;
+    HIPCHK(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    const int64_t pass = pioran_tile_pass_draws(p.R, ncu);
+    int64_t chunk = p.B;
+    while (chunk > pass && pioran_tile_workspace_doubles(chunk, p.N) * sizeof(double) > ws_allow(ctx, free_b) + ctx->bpair.cap)
+        chunk = ((chunk / 2 + pass - 1) / pass) * pass;
+    if (pioran_tile_workspace_doubles(chunk, p.N) * sizeof(double) > ws_allow(ctx, free_b) + ctx->bpair.cap) return PIORAN_ERR_UNSUPPORTED;
+    rc = ensure(ctx, ctx->bpair, pioran_tile_workspace_doubles(chunk, p.N) * sizeof(double));
+    if (rc) return rc == PIORAN_ERR_ALLOC ? PIORAN_ERR_UNSUPPORTED : rc;
+    g_last_kernel = "tile";
+    for (int64_t off = 0; off < p.B; off += chunk) {
+        const ScanParams qc = slice_draws(p, off, p.B - off < chunk ? p.B - off : chunk);
+        rc = pioran_launch_scan_tile(qc, s->btab, (double*)ctx->bpair.p, ctx->stream);
+        if (rc) return rc;
+    }
+    return PIORAN_OK;
+}
+
 static int split_dispatch(pioran_ds* ds, const ScanParams& p)
 {
     pioran_ctx* ctx = ds->ctx;
@@ -414,7 +449,12 @@ int launch(pioran_ds* ds, ScanParams& p)
     pioran_ctx* ctx = ds->ctx;
     p.opt = &ctx->opt;
     if (!ctx->opt.force_fallback) {
-        int rc = block_dispatch(ds, p);
+        int rc = tile_dispatch(ds, p);
+        if (rc != PIORAN_ERR_UNSUPPORTED) {
+            if (rc == PIORAN_ERR_HIP) ctx->last_err = "tile kernel launch failed";
+            return rc;
+        }
+        rc = block_dispatch(ds, p);
         if (rc != PIORAN_ERR_UNSUPPORTED) {
             if (rc == PIORAN_ERR_HIP) ctx->last_err = "block kernel launch failed";
             return rc;
@@ -571,7 +611,7 @@ int pioran_ctx_destroy(pioran_ctx* ctx)
     if (ctx->scalar_ds) pioran_dataset_destroy(ctx->scalar_ds);
     ctx->scalar_ds = nullptr;
     pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
-                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab, &ctx->bq};
+                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab, &ctx->bq, &ctx->bpair};
     for (auto* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : ctx->ev)
@@ -595,7 +635,7 @@ int pioran_ctx_trim(pioran_ctx* ctx)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     SYNC(ctx);
     pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
-                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab, &ctx->bq};
+                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab, &ctx->bq, &ctx->bpair};
     for (auto* b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;

@@ -1,0 +1,413 @@
+// Windowed form of the celerite factorisation for LARGE batches (gfx950, round 5): ONE DRAW PER WAVEFRONT, sixteen time steps
+// per window, the O(R^2) work of a window on the fp64 matrix cores.
+//
+// Same mathematics as celerite_block.hip (init_semi_separable! + the forward half of solve_prec!, src/celerite_solver.jl:12-100,
+// 115-142; logl :312-334, re-associated into windows: the header of celerite_block.hip has the algebra), same table
+// (window_common.h: one fragment-order record per window, built once per prepared (c, d)).  What differs is the work split.
+// celerite_block.hip spreads ONE draw over a workgroup (a block column of T per wavefront, a chain wavefront, three barriers per
+// window): latency.  Here a wavefront owns the WHOLE state T of its draw as NB x NB accumulator tiles of v_mfma_f64_16x16x4_f64
+// (register g of tile (I, J) = element (16 I + 4 g + (lane >> 4), 16 J + (lane & 15))) and walks the whole window by itself:
+//   M'  = U~' T            4 NB^2 matrix instructions (T's registers are the B operand as they stand; T is symmetric and only its lower
+//                          tiles are kept: an off-diagonal tile serves twice, as B operand and — transposed for free — as A operand)
+//   G   = U~' M            4 NB   (one transposing LDS round trip per block of M')
+//   Sigma = A - G ; Sigma = L D L' ; L^-1    on v_fmac_f64_dpp row_newbcast (window_common.h), no LDS inside the factorisation
+//   Y^' = L^-1 X'          4 NB
+//   T  <- (C_K C_K') o T + Y^ D^-1 Y^'       2 NB (NB + 1)
+// No exchange between wavefronts at all: the four wavefronts of a workgroup (four draws) only share the LDS copy of the window's
+// record (LDS DMA, two buffers, one barrier per window); two workgroups share a CU up to four block columns (<= 256 registers), so
+// every SIMD holds two independent instruction streams — one can run its vector phase (the LDL', the rescaling of T, the pair
+// contraction) while the other has the matrix pipe.  Per step and draw at 60 rows: 10 matrix instructions (640 SIMD cycles) + ~45
+// vector instructions, against ~1300 SIMD cycles of the register-resident step-by-step scan (celerite_scan.hip), whose every FMA is
+// a vector instruction.
+// The window's own covariance block A (kappa on the 120 pairs of the window: a contraction of the pair table E with the draw's
+// (a, b)) does not depend on the state: tile_pairs_kernel forms it for every (draw, window) of the launch beforehand — E in
+// registers, 32 draws per workgroup — into a workspace of 1 KB per draw and window that the factorisation reads one window ahead
+// (first version: the contraction inside the window loop, 40 .. 80 dependent reads of E from L2 per window: a third of the time).
+// Restrictions: shared (c, d) without per-draw rows, shared series (y, sigma2); 1 .. 95 active rows.  Everything else stays on the other kernels.
+#include "common.h"
+#include "window_common.h"
+
+// Diagnostic hooks: compiled out in the product; tools/tile_probe.hip defines them to s_memtime accumulators.
+#ifndef PIORAN_TSTAMP
+#define PIORAN_TSTAMP(i) __builtin_amdgcn_sched_barrier(0)
+#define PIORAN_TSTAMP_DECL
+#define PIORAN_TSTAMP_FLUSH
+#endif
+
+namespace {
+
+constexpr int kTileMaxTerms = 64;
+constexpr int kTileWaves = 4;      // wavefronts (= draws) per workgroup
+
+template <int NB>
+struct TileWave {                  // LDS of one wavefront
+    double scr[16 * 18];           // in turn: a block of M' for the transposing read-back; Sigma [j][n]; D_k (L^-1)_ik at [k * 18 + i]
+    double2 albe[16 * NB];         // per row: u = al v + be x (:59-63)
+    double up[NB > 1 ? NB * (NB - 1) / 2 : 1][16 * 18];   // the strictly lower tiles of T once more, [row][column, stride 18]: read back transposed
+                                                          // they are the upper tiles as B operands
+};
+
+// A_p = sum_t a_t E_t,p.cos + b_t E_t,p.sin for the 120 pairs p of every window and every draw of the launch (kappa, src/acvf.jl:138-140, on the
+// window's own pairs): out[(b * NW + k) * 128 + p].  Workgroup (k, chunk of DC draws): thread p reads E_t,p once per term and serves DC draws
+// from it; the coefficients of the chunk sit in LDS as [t][draw] (broadcast reads).
+constexpr int kPairDraws = 32;
+__global__ void __launch_bounds__(128) tile_pairs_kernel(const ScanParams p, const double* __restrict__ btab, int64_t rsb, int64_t tsp, double* __restrict__ out)
+{
+    constexpr int DC = kPairDraws;
+    __shared__ double2 cf[kTileMaxTerms * DC];
+    const int J = p.J;
+    const int64_t NW = (p.N + KW - 1) / KW;
+    const int64_t k = blockIdx.x, b0 = (int64_t)blockIdx.y * DC;
+    const int pp = threadIdx.x;
+    for (int it = threadIdx.x; it < DC * J; it += 128) {
+        const int i = it / J, t = it - i * J;
+        const int64_t b = b0 + i < p.B ? b0 + i : p.B - 1;
+        cf[t * DC + i] = double2{p.A[b * J + t], p.Bc[b * J + t]};
+    }
+    __syncthreads();
+    const double2* E = reinterpret_cast<const double2*>(btab + k * rsb + tsp) + pp;
+    double acc0[DC], acc1[DC];
+#pragma unroll
+    for (int i = 0; i < DC; ++i) { acc0[i] = 0.0; acc1[i] = 0.0; }
+    int t = 0;
+    for (; t + 3 < J; t += 4) {
+        double2 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = E[(t + u) * 128];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < DC; ++i) {
+                const double2 c = cf[(t + u) * DC + i];
+                acc0[i] = fma(c.x, e[u].x, acc0[i]);
+                acc1[i] = fma(c.y, e[u].y, acc1[i]);
+            }
+    }
+    for (; t < J; ++t) {
+        const double2 e = E[t * 128];
+#pragma unroll
+        for (int i = 0; i < DC; ++i) {
+            const double2 c = cf[t * DC + i];
+            acc0[i] = fma(c.x, e.x, acc0[i]);
+            acc1[i] = fma(c.y, e.y, acc1[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DC; ++i)
+        if (b0 + i < p.B) out[((b0 + i) * NW + k) * 128 + pp] = acc0[i] + acc1[i];
+}
+
+template <int NB>
+__global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_tile_kernel(const ScanParams p, const double* __restrict__ btab,
+                                                                                          const double* __restrict__ pairs)
+{
+    constexpr int TS = 3 * NB * 256 + 16 * NB + 16, TSP = (TS + 127) & ~127;
+    extern __shared__ double lds_[];
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, q = lane >> 4, c16 = lane & 15;
+    const int64_t b = (int64_t)blockIdx.x * kTileWaves + w;
+    if (b >= p.B) return;          // (no workgroup-level synchronisation anywhere below: a wavefront is on its own)
+    const int64_t N = p.N;
+    const int J = p.J, R = p.R;
+    const int64_t NW = (N + KW - 1) / KW;
+    const int64_t RSB = TSP + 256 * (int64_t)J;
+    TileWave<NB>& sw = reinterpret_cast<TileWave<NB>*>(lds_)[w];
+    const int Jy = R >> 4, ry = R & 15;            // block column / lane column of the y row
+    const double mu = p.mu ? p.mu[b] : 0.0;
+    const double nu = p.nu ? p.nu[b] : 1.0;
+    const bool has_nu = p.nu != nullptr;
+    const double* __restrict__ Ab_ = p.A + b * J;
+    const double* __restrict__ Bb_ = p.Bc + b * J;
+    double suma = 0.0;  // :21
+    for (int j = 0; j < J; ++j) suma += Ab_[j];
+
+    for (int r = lane; r < 16 * NB; r += 64) {
+        double a = 0.0, bb = 0.0;
+        if (r < R) {
+            const int rm = p.rowmap[r];
+            const int term = rm & 0xfffff;
+            a = Ab_[term];
+            bb = ((rm >> 30) & 1) ? -Bb_[term] : Bb_[term];
+        }
+        sw.albe[r] = double2{a, bb};
+    }
+    constexpr int NU = NB * (NB - 1) / 2;
+    for (int i = lane; i < (NU > 0 ? NU : 1) * 16 * 18; i += 64) (&sw.up[0][0])[i] = 0.0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    constexpr int NT = NB * (NB + 1) / 2;          // T is symmetric: the tiles (I, Jc), I >= Jc, live in registers
+    auto tix = [](int I, int Jc) constexpr { return I * (I + 1) / 2 + Jc; };
+    auto uix = [](int I, int Jc) constexpr { return I * (I - 1) / 2 + Jc; };   // I > Jc: slot of the tile's LDS copy
+    d4 T[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) T[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double Uf[NB][4];
+
+    // U~ of window k, A-operand order: (row 16 I + 4 ks + q, step c16), from the record's C o v and C o x (coalesced 512-byte reads), one
+    // row block at a time: the reads of block I are issued a row of the update ahead of their use
+    double cvn[2][4], cxn[2][4];
+    auto fetch_u = [&](int64_t k, int I) __attribute__((always_inline)) {
+        const double* tl = btab + k * RSB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int f = (I * 4 + ks) * 64 + lane;
+            cvn[I & 1][ks] = tl[f];
+            cxn[I & 1][ks] = tl[NB * 256 + f];
+        }
+    };
+    auto form_u = [&](int I) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const double2 cf = sw.albe[16 * I + 4 * ks + q];
+            Uf[I][ks] = fma(cf.x, cvn[I & 1][ks], cf.y * cxn[I & 1][ks]);
+        }
+    };
+    // A of window k, C/D order (row 4 g + q, column c16): the off-diagonal entries from the workspace of tile_pairs_kernel (pair p =
+    // nn (nn - 1) / 2 + jj, jj < nn), fetched one window ahead; the diagonal sum(a) + nu sigma2_n here (:92)
+    int pidx[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int r = 4 * g + q, hi = r > c16 ? r : c16, lo = r > c16 ? c16 : r;
+        pidx[g] = r == c16 ? 127 : hi * (hi - 1) / 2 + lo;      // (127: a padding entry of the record, never used)
+    }
+    const int gd = (c16 - q) >> 2;                               // the register that holds this lane's diagonal entry, if (c16 - q) % 4 == 0
+    const bool on_diag = ((c16 - q) & 3) == 0;
+    const double* __restrict__ pw = pairs + b * NW * 128;
+    double apre[4];
+    auto fetch_A = [&](int64_t k) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) apre[g] = pw[k * 128 + pidx[g]];
+    };
+    fetch_A(0);
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        fetch_u(0, I);
+        form_u(I);
+    }
+    double quad = 0.0;                 // meaningful in the y-row lanes
+    double Pm = 1.0;                   // per lane (step c16 of every window): running product of |D| (sign of D_1 kept: :126)
+    int Pe = 0;
+    bool nonpd = false;
+
+    PIORAN_TSTAMP_DECL
+    for (int64_t k = 0; k < NW; ++k) {
+        PIORAN_TSTAMP(0);
+        const double* tl = btab + k * RSB;
+        // ---- M' = U~' T: the lower tiles from registers, the upper ones as transposed reads of their LDS copies -------------------
+        d4 x[NB];
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int I = 0; I < Jc; ++I) {
+                double bt[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) bt[ks] = sw.up[uix(Jc, I)][c16 * 18 + 4 * ks + q];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[I][ks], bt[ks], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int I = Jc; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[I][ks], T[tix(I, Jc)][ks], acc, 0, 0, 0);
+            x[Jc] = acc;
+        }
+        PIORAN_TSTAMP(1);
+        // the record's (C_K / C) o v, C_K and sigma2: on their way while the Gram block is formed
+        double vh[NB][4], ckc[NB];
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) {
+            ckc[Jc] = tl[3 * NB * 256 + 16 * Jc + c16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) vh[Jc][g] = tl[2 * NB * 256 + (Jc * 4 + g) * 64 + lane];
+        }
+        const double s2n = tl[3 * NB * 256 + 16 * NB + c16];
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- G = U~' M: each block of M' transposed through LDS into the B operand ------------------------------------------
+        d4 G = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 18 + c16] = x[Jc][g];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double mb[4];   // M [row 16 Jc + 4 ks + q][step c16]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) mb[ks] = sw.scr[c16 * 18 + 4 * ks + q];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) G = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[Jc][ks], mb[ks], G, 0, 0, 0);
+        }
+        PIORAN_TSTAMP(2);
+        // ---- X' = V^' - C_K o M' ----------------------------------------------------------------------------------------
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                double v = vh[Jc][g];
+                if (Jc == Jy && c16 == ry) v = k * KW + 4 * g + q < N ? v - mu : 0.0;   // z_n = y_n - u'f   :141
+                x[Jc][g] = fma(-ckc[Jc], x[Jc][g], v);
+            }
+        PIORAN_TSTAMP(3);
+        // ---- Sigma = A - G, Sigma = L D L', L^-1 ----------------------------------------------------------------------------
+        {
+            const double dg = k * KW + c16 < N ? suma + (has_nu ? nu * s2n : s2n) : 1.0;   // :92; padded steps of the last window: D = 1
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 16 + c16] = ((on_diag && g == gd) ? dg : apre[g]) - G[g];
+        }
+        if (k + 1 < NW) fetch_A(k + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double m[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) m[j] = sw.scr[j * 16 + c16];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIORAN_TSTAMP(4);
+        double mult = ldl_first_mult(m, c16);
+        static_for<0, 16>([&](auto Pc) __attribute__((always_inline)) { ldl_step<decltype(Pc)::value>(m, mult, c16); });
+        PIORAN_TSTAMP(5);
+        if (q == 0) {   // lane n holds column n of L^-1 (scaled by D_n) in m[j], j > n, D_n in m[n]; the rest of m is left-over Sigma (masked below)
+            double2* dst = reinterpret_cast<double2*>(sw.scr + c16 * 18);
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) dst[j / 2] = double2{m[j], m[j + 1]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double li[4], idv[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = 4 * ks + q;                             // L^-1 [i = c16][k = kk]: unit lower triangular
+            const double lv = sw.scr[kk * 18 + c16];
+            idv[ks] = recip_f64(sw.scr[kk * 18 + kk]);             // D_n sits on the diagonal
+            li[ks] = kk < c16 ? lv * idv[ks] : (kk == c16 ? 1.0 : 0.0);   // the column arrives scaled by D_kk
+        }
+        {   // log-determinant bookkeeping: this lane follows step c16 of every window
+            const double dj = sw.scr[c16 * 18 + c16];
+            nonpd |= !(dj > 0.0);
+            Pm *= (k == 0 && c16 == 0) ? dj : fabs(dj);    // log(D[1]) :126, log(abs(D[n])) :140
+            int ex;
+            Pm = frexp(Pm, &ex);
+            Pe += ex;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIORAN_TSTAMP(6);
+        // ---- Y^' = L^-1 X' ------------------------------------------------------------------------------------------------
+        const bool more = k + 1 < NW;
+        if (more) fetch_u(k + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        d4 yt[NB], ysc[NB];
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) {
+            d4 a = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f64_16x16x4f64(li[ks], x[Jc][ks], a, 0, 0, 0);
+            yt[Jc] = a;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                ysc[Jc][g] = a[g] * idv[g];
+                if (Jc == Jy) quad = fma(a[g], ysc[Jc][g], quad);     // z_n^2 / D_n (== y'K^-1 y, :333), in the y-row lanes
+            }
+        }
+        PIORAN_TSTAMP(7);
+        // ---- T <- (C_K C_K') o T + Y^ D^-1 Y^', lower tiles; the off-diagonal ones are copied to LDS for the next window's M' --------
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            if (I + 1 < NB && more) fetch_u(k + 1, I + 1);     // U~ of the next window, a row of tiles ahead
+            double ckr[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ckr[g] = tl[3 * NB * 256 + 16 * I + 4 * g + q];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int Jc = 0; Jc <= I; ++Jc) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) T[tix(I, Jc)][g] *= ckr[g] * ckc[Jc];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) T[tix(I, Jc)] = __builtin_amdgcn_mfma_f64_16x16x4f64(yt[I][ks], ysc[Jc][ks], T[tix(I, Jc)], 0, 0, 0);
+                if (Jc < I) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) sw.up[uix(I, Jc)][(4 * g + q) * 18 + c16] = T[tix(I, Jc)][g];
+                }
+            }
+            if (more) form_u(I);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        PIORAN_TSTAMP(8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    PIORAN_TSTAMP_FLUSH
+    // ---- result ------------------------------------------------------------------------------------------------------------
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (c16 == ry) sw.scr[q] = quad;
+    if (q == 0) sw.scr[16 + c16] = log(Pm) + (double)Pe * 0.6931471805599453094;
+    const bool any_nonpd = __builtin_amdgcn_ballot_w64(nonpd) != 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        const double qs = (sw.scr[0] + sw.scr[1]) + (sw.scr[2] + sw.scr[3]);
+        double logdet = 0.0;
+        for (int j = 0; j < 16; ++j) logdet += sw.scr[16 + j];
+        const double res = -0.5 * logdet - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * qs;
+        p.out[b] = res;
+        if (p.status) p.status[b] = !isfinite(res) ? 2 : (any_nonpd ? 1 : 0);
+    }
+}
+
+template <int NB>
+constexpr size_t tile_lds_bytes() { return kTileWaves * sizeof(TileWave<NB>); }
+
+template <int NB>
+int launch_tile(const ScanParams& p, const double* btab, double* pairs, hipStream_t stream)
+{
+    constexpr size_t lds = tile_lds_bytes<NB>();
+    static_assert(lds <= 160 * 1024, "one workgroup must fit a CU");
+    static bool granted[64] = {};   // (function, device): one process may drive several devices (pioran_farm_*); racing threads at worst set it twice
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
+    if (!granted[dev]) {
+        if (hipFuncSetAttribute((const void*)celerite_tile_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PIORAN_ERR_HIP;
+        granted[dev] = true;
+    }
+    const int64_t groups = (p.B + kTileWaves - 1) / kTileWaves;
+    if (groups > 0x7fffffffLL) return PIORAN_ERR_UNSUPPORTED;
+    const int64_t NW = (p.N + KW - 1) / KW;
+    if (NW > 0x7fffffffLL || (p.B + kPairDraws - 1) / kPairDraws > 65535) return PIORAN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(tile_pairs_kernel, dim3((unsigned)NW, (unsigned)((p.B + kPairDraws - 1) / kPairDraws)), dim3(128), 0, stream, p, btab,
+                       block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs);
+    hipLaunchKernelGGL((celerite_tile_kernel<NB>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds, stream, p, btab, (const double*)pairs);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
+}  // namespace
+
+int pioran_tile_supported_rows() { return 95; }
+
+int pioran_tile_fits(int32_t R, int32_t J)
+{
+    const int NB = (R + 1 + 15) / 16;
+    return R >= 1 && NB <= 6 && J >= 1 && J <= kTileMaxTerms;
+}
+
+// draws one full pass of the kernel holds on `cus` compute units
+int64_t pioran_tile_pass_draws(int32_t R, int cus)
+{
+    const int NB = (R + 1 + 15) / 16;
+    return (int64_t)cus * kTileWaves * (NB <= 4 ? 2 : 1);
+}
+
+// shared-(c, d) launches without per-draw rows or per-draw series; btab from pioran_launch_block_table for the same (N, R, J, rowmap);
+// work: pioran_tile_workspace_doubles(B, N) doubles
+// doubles of workspace a launch of B draws needs (the window's own covariance block per draw and window)
+size_t pioran_tile_workspace_doubles(int64_t B, int64_t N) { return (size_t)B * (size_t)((N + KW - 1) / KW) * 128; }
+
+int pioran_launch_scan_tile(const ScanParams& p, const double* btab, double* work, hipStream_t stream)
+{
+    if (!work) return PIORAN_ERR_ARG;
+    if (!btab || p.B < 1 || p.N < 1 || p.npd_rows != 0 || p.Y || p.S2 || !pioran_tile_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    switch ((p.R + 1 + 15) / 16) {
+        case 1: return launch_tile<1>(p, btab, work, stream);
+        case 2: return launch_tile<2>(p, btab, work, stream);
+        case 3: return launch_tile<3>(p, btab, work, stream);
+        case 4: return launch_tile<4>(p, btab, work, stream);
+        case 5: return launch_tile<5>(p, btab, work, stream);
+        case 6: return launch_tile<6>(p, btab, work, stream);
+    }
+    return PIORAN_ERR_UNSUPPORTED;
+}

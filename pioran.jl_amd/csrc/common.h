@@ -157,6 +157,12 @@ int pioran_launch_block_gtab_batch(int64_t N, int32_t R, int32_t J, int64_t nb, 
                                    const double* D, const double* s2, double* gtab, int64_t draw_stride, hipStream_t stream);
 int pioran_launch_block_grad(const ScanParams& p, const double* btab, const double* gtab, double* grad_a, double* grad_b, double* grad_nu,
                              double* grad_mu, double* grad_c /*nullptr: not wanted*/, double* grad_d, hipStream_t stream);
+// celerite_tile.hip: the windowed form for LARGE batches, one draw per wavefront (round 5); same table as celerite_block.hip
+int pioran_tile_supported_rows();
+int pioran_tile_fits(int32_t R, int32_t J);
+int64_t pioran_tile_pass_draws(int32_t R, int cus);
+size_t pioran_tile_workspace_doubles(int64_t B, int64_t N);
+int pioran_launch_scan_tile(const ScanParams& p, const double* btab, double* work, hipStream_t stream);
 int pioran_launch_block_table_reference(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,
                                         const double* d, const double* y, const double* s2, double* btab, hipStream_t stream);
 // celerite_predict.hip: posterior mean at new times (pred, src/celerite_solver.jl:363-483)
