@@ -372,9 +372,12 @@ int tile_dispatch(pioran_ds* ds, const ScanParams& p)
 {
     pioran_ctx* ctx = ds->ctx;
     const ScanOptions& o = ctx->opt;
-    const char* cfg = o.scan_config[0] ? o.scan_config : nullptr;
-    const bool force = cfg && !std::strcmp(cfg, "tile");
-    const bool automatic = false;
+    const bool force = o.force_tile;
+    // measured on N = 1e4 (tools/ab_tile.py, profiles/r05_tile_batch_sweep.txt): from 49 rows on (four block columns and more) it beats the
+    // step-by-step layouts at every batch size above the small-batch windowed kernel's range — DRWCelerite-20 (60 rows) 1024 draws 6.3
+    // against 7.8 ms, 4096 draws 17.5 against 25.1 ms; SHO-40 (80 rows) 512 draws 10.0 against 13.1 ms, 4096 draws 41.3 against 75.3 ms.
+    // Up to 48 rows the throughput layouts (two draws per wavefront) are level with it (SHO-20: 11.2 against 11.4 ms) and stay the default.
+    const bool automatic = !o.scan_config[0] && !o.no_tile && !o.no_block && p.R >= 49 && p.B > (p.R > pioran_block_supported_rows() ? 256 : 512);
     if (!(force || automatic) || !p.tab || p.npd_rows != 0 || p.Y || p.S2 || !pioran_tile_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
     PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
     if (!s || !s->prepared || s->npd_terms != 0 || p.rec_stride != 3 * (int64_t)(s->R + 2) + 2) return PIORAN_ERR_UNSUPPORTED;
@@ -533,8 +536,10 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     if (!std::strcmp(key, "scan_config")) {
         if (value && std::strlen(value) >= sizeof(o.scan_config)) return PIORAN_ERR_ARG;
         std::memset(o.scan_config, 0, sizeof(o.scan_config));
-        if (value) std::strcpy(o.scan_config, value);
-    } else if (!std::strcmp(key, "no_wide")) o.no_wide = on;
+        // "tile": celerite_tile.hip for every launch it can take (any batch size); the launches it cannot take stay automatic
+        o.force_tile = value && !std::strcmp(value, "tile");
+        if (value && !o.force_tile) std::strcpy(o.scan_config, value);
+    } else if (!std::strcmp(key, "no_tile")) o.no_tile = on; else if (!std::strcmp(key, "no_wide")) o.no_wide = on;
     else if (!std::strcmp(key, "no_paired")) o.no_paired = on;
     else if (!std::strcmp(key, "no_mixed")) o.no_mixed = on;
     else if (!std::strcmp(key, "force_fallback")) o.force_fallback = on;
@@ -577,6 +582,7 @@ static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
     pioran_ctx_set_option(ctx, "no_mixed", std::getenv("PIORAN_NO_MIXED"));
     pioran_ctx_set_option(ctx, "force_fallback", std::getenv("PIORAN_FORCE_FALLBACK"));
     pioran_ctx_set_option(ctx, "no_block", std::getenv("PIORAN_NO_BLOCK"));
+    pioran_ctx_set_option(ctx, "no_tile", std::getenv("PIORAN_NO_TILE"));
     pioran_ctx_set_option(ctx, "win2", std::getenv("PIORAN_WIN2"));
     pioran_ctx_set_option(ctx, "no_win2", std::getenv("PIORAN_NO_WIN2"));
     pioran_ctx_set_option(ctx, "gsum", std::getenv("PIORAN_GSUM"));

@@ -43,6 +43,7 @@ template <int NB>
 struct TileWave {                  // LDS of one wavefront
     double scr[16 * 18];           // in turn: a block of M' for the transposing read-back; Sigma [j][n]; D_k (L^-1)_ik at [k * 18 + i]
     double2 albe[16 * NB];         // per row: u = al v + be x (:59-63)
+    double ck[16 * NB + 16];       // the window's C_K per row, then sigma2 per step (staged from the record: read again and again by the update)
     double up[NB > 1 ? NB * (NB - 1) / 2 : 1][16 * 18];   // the strictly lower tiles of T once more, [row][column, stride 18]: read back transposed
                                                           // they are the upper tiles as B operands
 };
@@ -145,23 +146,31 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
     double Uf[NB][4];
 
     // U~ of window k, A-operand order: (row 16 I + 4 ks + q, step c16), from the record's C o v and C o x (coalesced 512-byte reads), one
-    // row block at a time: the reads of block I are issued a row of the update ahead of their use
-    double cvn[2][4], cxn[2][4];
+    // row block at a time: the reads of block I + 1 are on their way while block column I of T is updated
+    double cvn[4], cxn[4];
     auto fetch_u = [&](int64_t k, int I) __attribute__((always_inline)) {
         const double* tl = btab + k * RSB;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int f = (I * 4 + ks) * 64 + lane;
-            cvn[I & 1][ks] = tl[f];
-            cxn[I & 1][ks] = tl[NB * 256 + f];
+            cvn[ks] = tl[f];
+            cxn[ks] = tl[NB * 256 + f];
         }
     };
     auto form_u = [&](int I) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const double2 cf = sw.albe[16 * I + 4 * ks + q];
-            Uf[I][ks] = fma(cf.x, cvn[I & 1][ks], cf.y * cxn[I & 1][ks]);
+            Uf[I][ks] = fma(cf.x, cvn[ks], cf.y * cxn[ks]);
         }
+    };
+    // C_K and sigma2 of window k: fetched a window ahead, staged in LDS at the start of the window
+    constexpr int NCK = (16 * NB + 16 + 63) / 64;
+    double ckpre[NCK];
+    auto fetch_ck = [&](int64_t k) __attribute__((always_inline)) {
+        const double* tl = btab + k * RSB + 3 * NB * 256;
+#pragma unroll
+        for (int i = 0; i < NCK; ++i) ckpre[i] = tl[(lane + 64 * i) < 16 * NB + 16 ? lane + 64 * i : 0];
     };
     // A of window k, C/D order (row 4 g + q, column c16): the off-diagonal entries from the workspace of tile_pairs_kernel (pair p =
     // nn (nn - 1) / 2 + jj, jj < nn), fetched one window ahead; the diagonal sum(a) + nu sigma2_n here (:92)
@@ -180,6 +189,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
         for (int g = 0; g < 4; ++g) apre[g] = pw[k * 128 + pidx[g]];
     };
     fetch_A(0);
+    fetch_ck(0);
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
         fetch_u(0, I);
@@ -194,6 +204,11 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
     for (int64_t k = 0; k < NW; ++k) {
         PIORAN_TSTAMP(0);
         const double* tl = btab + k * RSB;
+        const bool more = k + 1 < NW;
+#pragma unroll
+        for (int i = 0; i < NCK; ++i)
+            if (lane + 64 * i < 16 * NB + 16) sw.ck[lane + 64 * i] = ckpre[i];
+        if (more) fetch_ck(k + 1);
         // ---- M' = U~' T: the lower tiles from registers, the upper ones as transposed reads of their LDS copies -------------------
         d4 x[NB];
 #pragma unroll
@@ -214,18 +229,12 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
             x[Jc] = acc;
         }
         PIORAN_TSTAMP(1);
-        // the record's (C_K / C) o v, C_K and sigma2: on their way while the Gram block is formed
-        double vh[NB][4], ckc[NB];
-#pragma unroll
-        for (int Jc = 0; Jc < NB; ++Jc) {
-            ckc[Jc] = tl[3 * NB * 256 + 16 * Jc + c16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) vh[Jc][g] = tl[2 * NB * 256 + (Jc * 4 + g) * 64 + lane];
-        }
-        const double s2n = tl[3 * NB * 256 + 16 * NB + c16];
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- G = U~' M: each block of M' transposed through LDS into the B operand ------------------------------------------
+        // ---- G = U~' M: each block of M' transposed through LDS into the B operand; X' = V^' - C_K o M' behind it (the record's
+        //      (C_K / C) o v is fetched a block ahead) ------------------------------------------------------------------------
         d4 G = {0.0, 0.0, 0.0, 0.0};
+        double vh[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) vh[g] = tl[2 * NB * 256 + g * 64 + lane];
 #pragma unroll
         for (int Jc = 0; Jc < NB; ++Jc) {
 #pragma unroll
@@ -234,23 +243,28 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
             double mb[4];   // M [row 16 Jc + 4 ks + q][step c16]
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) mb[ks] = sw.scr[c16 * 18 + 4 * ks + q];
+            const double ckc = sw.ck[16 * Jc + c16];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) G = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[Jc][ks], mb[ks], G, 0, 0, 0);
-        }
-        PIORAN_TSTAMP(2);
-        // ---- X' = V^' - C_K o M' ----------------------------------------------------------------------------------------
-#pragma unroll
-        for (int Jc = 0; Jc < NB; ++Jc)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                double v = vh[Jc][g];
+                double v = vh[g];
                 if (Jc == Jy && c16 == ry) v = k * KW + 4 * g + q < N ? v - mu : 0.0;   // z_n = y_n - u'f   :141
-                x[Jc][g] = fma(-ckc[Jc], x[Jc][g], v);
+                x[Jc][g] = fma(-ckc, x[Jc][g], v);
+                asm volatile("" : "+v"(x[Jc][g]));   // formed HERE: left to itself the compiler sinks these FMAs below the LDL' and keeps (C_K / C) o v live across it
             }
+            if (Jc + 1 < NB) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) vh[g] = tl[2 * NB * 256 + ((Jc + 1) * 4 + g) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        PIORAN_TSTAMP(2);
         PIORAN_TSTAMP(3);
         // ---- Sigma = A - G, Sigma = L D L', L^-1 ----------------------------------------------------------------------------
         {
+            const double s2n = sw.ck[16 * NB + c16];
             const double dg = k * KW + c16 < N ? suma + (has_nu ? nu * s2n : s2n) : 1.0;   // :92; padded steps of the last window: D = 1
 #pragma unroll
             for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 16 + c16] = ((on_diag && g == gd) ? dg : apre[g]) - G[g];
@@ -290,43 +304,43 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PIORAN_TSTAMP(6);
         // ---- Y^' = L^-1 X' ------------------------------------------------------------------------------------------------
-        const bool more = k + 1 < NW;
         if (more) fetch_u(k + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        d4 yt[NB], ysc[NB];
+        d4 yt[NB];
 #pragma unroll
         for (int Jc = 0; Jc < NB; ++Jc) {
             d4 a = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f64_16x16x4f64(li[ks], x[Jc][ks], a, 0, 0, 0);
             yt[Jc] = a;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                ysc[Jc][g] = a[g] * idv[g];
-                if (Jc == Jy) quad = fma(a[g], ysc[Jc][g], quad);     // z_n^2 / D_n (== y'K^-1 y, :333), in the y-row lanes
-            }
         }
         PIORAN_TSTAMP(7);
-        // ---- T <- (C_K C_K') o T + Y^ D^-1 Y^', lower tiles; the off-diagonal ones are copied to LDS for the next window's M' --------
+        // ---- T <- (C_K C_K') o T + Y^ D^-1 Y^', lower tiles, one block column at a time; the off-diagonal ones are copied to LDS for the
+        //      next window's M'; U~ of the next window is formed on the way ------------------------------------------------------
 #pragma unroll
-        for (int I = 0; I < NB; ++I) {
-            if (I + 1 < NB && more) fetch_u(k + 1, I + 1);     // U~ of the next window, a row of tiles ahead
-            double ckr[4];
+        for (int Jc = 0; Jc < NB; ++Jc) {
+            if (more) {
+                form_u(Jc);
+                if (Jc + 1 < NB) fetch_u(k + 1, Jc + 1);
+            }
+            double ysc[4];
+            const double ckc = sw.ck[16 * Jc + c16];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) ckr[g] = tl[3 * NB * 256 + 16 * I + 4 * g + q];
-            __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < 4; ++g) {
+                ysc[g] = yt[Jc][g] * idv[g];
+                if (Jc == Jy) quad = fma(yt[Jc][g], ysc[g], quad);     // z_n^2 / D_n (== y'K^-1 y, :333), in the y-row lanes
+            }
 #pragma unroll
-            for (int Jc = 0; Jc <= I; ++Jc) {
+            for (int I = Jc; I < NB; ++I) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) T[tix(I, Jc)][g] *= ckr[g] * ckc[Jc];
+                for (int g = 0; g < 4; ++g) T[tix(I, Jc)][g] *= sw.ck[16 * I + 4 * g + q] * ckc;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) T[tix(I, Jc)] = __builtin_amdgcn_mfma_f64_16x16x4f64(yt[I][ks], ysc[Jc][ks], T[tix(I, Jc)], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) T[tix(I, Jc)] = __builtin_amdgcn_mfma_f64_16x16x4f64(yt[I][ks], ysc[ks], T[tix(I, Jc)], 0, 0, 0);
                 if (Jc < I) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) sw.up[uix(I, Jc)][(4 * g + q) * 18 + c16] = T[tix(I, Jc)][g];
                 }
             }
-            if (more) form_u(I);
             __builtin_amdgcn_sched_barrier(0);
         }
         PIORAN_TSTAMP(8);

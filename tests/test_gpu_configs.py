@@ -100,8 +100,12 @@ def test_config3_full_batch(ctx, full_size, basis):
     assert (st[ok] == 0).all()
     assert relerr(got[ok], ref[ok]) < 1e-8, basis
     assert np.array_equal(st != 0, rst != 0)
-    cfg = pj._lib.lib().pioran_celerite_config_name(0).decode()
-    assert cfg.startswith("rpl"), cfg     # a register-resident throughput configuration ran, not the fallback
+    kern = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    if basis == "SHO":
+        cfg = pj._lib.lib().pioran_celerite_config_name(0).decode()
+        assert kern == "scan" and cfg.startswith("rpl"), (kern, cfg)     # a register-resident throughput configuration ran, not the fallback
+    else:
+        assert kern == "tile", kern       # 60 active rows: the windowed form with one draw per wavefront (celerite_tile.hip, round 5)
     # the host-pointer entry gives the same bits for the same batch
     host = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
     assert np.array_equal(host[ok], got[ok])

@@ -127,13 +127,15 @@ def _random_case(rng, N, J, B, per_draw_cd=False):
     return t, y, s2, A, Bc, C, Dd, mu, nu
 
 
-@pytest.fixture(params=["throughput", "throughput_steps", "throughput_pairs", "throughput_triples", "latency", "latency_lean", "block"])
+@pytest.fixture(params=["throughput", "throughput_steps", "throughput_pairs", "throughput_triples", "latency", "latency_lean", "block", "tile"])
 def layout(request, ctx):
     """Small batches (B <= 512) with 6 <= R <= 63 rows take the windowed kernel (celerite_block.hip) by default; "no_block" sends
     them to the one-draw-per-workgroup latency layout (celerite_wide.hip), "no_wide" as well to the throughput layouts (the ones
     large batches use).  The throughput layouts run the two-step form up to four rows per lane (R <= 63) and the step-by-step recurrence
     above ("no_win2" / "win2" force either everywhere).  All are checked on the same inputs."""
-    if request.param != "block":
+    if request.param == "tile":             # celerite_tile.hip (windowed form, one draw per wavefront; default for large batches from 49 rows
+        ctx.set_option("scan_config", "tile")   # on) forced for every launch it can take, whatever the batch size
+    elif request.param != "block":
         ctx.set_option("no_block", True)
     if request.param.startswith("throughput"):
         ctx.set_option("no_wide", True)
@@ -163,6 +165,8 @@ def test_random_batches_shared_cd(ctx, J, layout):
     ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
     assert relerr(got, ref) < 1e-11, pj._lib.lib().pioran_celerite_config_name(2 * J)
     assert (st == 0).all()
+    if layout == "tile":
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "tile"
 
 
 @pytest.mark.parametrize("J", [2, 7, 20, 30])
@@ -175,7 +179,7 @@ def test_random_batches_per_draw_cd(ctx, J, layout):
     ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
     assert relerr(got, ref) < 1e-11
     kern = pj._lib.lib().pioran_celerite_config_name(-1).decode()
-    if layout == "block":   # small batches, 6 .. 63 rows: every draw its own table of the windowed kernel (round 3)
+    if layout in ("block", "tile"):   # small batches, 6 .. 63 rows: every draw its own table of the windowed kernel (round 3); "tile" takes no per-draw (c, d): automatic choice
         assert kern == ("block (per-draw tables)" if J >= 3 else "block+pd"), kern   # (one or two terms: per-draw ROWS, late round 4)
     else:
         assert kern in ("scan", "wide"), kern
@@ -187,6 +191,8 @@ def test_random_batches_per_draw_cd(ctx, J, layout):
     assert relerr(one, ref[:1]) < 1e-11
     if layout == "block":
         assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == ("block" if J >= 3 else "scan")
+    if layout == "tile":    # ... and the one-draw shared case is a launch it can take
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "tile"
 
 
 @pytest.mark.parametrize("J,N,B", [(20, 100, 300), (16, 49, 700), (23, 33, 1000), (9, 80, 400), (20, 260, 513)])
@@ -265,14 +271,18 @@ def test_remainder_of_a_multi_pass_batch_on_the_second_stream(ctx, basis, B):
     th = O.synthetic_theta(B, t, y, seed=B)
     A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, J, basis)
     ds = pj.Dataset(t, y, yerr ** 2, ctx)
-    got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
-    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan + block (remainder)"
+    # (round 5: from 49 rows on a shared series is celerite_tile.hip's by default, which has no passes to split; the step-by-step layouts
+    #  and this split still serve per-draw series and "no_tile")
+    ctx.set_option("no_tile", True)
     try:
+        got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan + block (remainder)"
         ctx.set_option("no_split", True)
         one, st1 = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
         assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan"
     finally:
         ctx.set_option("no_split", False)
+        ctx.set_option("no_tile", False)
     ok = (st == 0) & (st1 == 0)
     assert np.array_equal(st == 0, st1 == 0) and ok.sum() > B // 2
     # Two kernel families on PRIOR draws.  Where a sampler lives (here: within 1e3 of the best draw) they agree to 1e-10.  In the far tail both
@@ -307,14 +317,18 @@ def test_remainder_of_a_multi_pass_batch_64_to_95_rows(ctx, J, B):
     th = O.synthetic_theta(B, t, y, seed=B)
     A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, J, "SHO")
     ds = pj.Dataset(t, y, yerr ** 2, ctx)
-    got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
-    assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan + block (remainder)"
+    # (round 5: from 49 rows on a shared series is celerite_tile.hip's by default, which has no passes to split; the step-by-step layouts
+    #  and this split still serve per-draw series and "no_tile")
+    ctx.set_option("no_tile", True)
     try:
+        got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan + block (remainder)"
         ctx.set_option("no_split", True)
         one, st1 = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
         assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan"
     finally:
         ctx.set_option("no_split", False)
+        ctx.set_option("no_tile", False)
     ok = (st == 0) & (st1 == 0)
     kept = ok & (one > one[ok].max() - 1e3)
     assert np.array_equal(st == 0, st1 == 0) and kept.sum() > B // 4 and relerr(got[kept], one[kept]) < 5e-10
@@ -791,6 +805,95 @@ def test_all_kernel_configs_agree(ctx):
     finally:
         ctx.set_option("scan_config", None)
         ctx.set_option("force_fallback", False)
+
+def test_tile_kernel_edges(ctx):
+    """Windowed form with one draw per wavefront (celerite_tile.hip; default for large batches from 49 rows on): series shorter than,
+    equal to and just past a window / two windows, every block count NB = 1..6, batches that do not fill their last workgroup, the y row
+    in the last lane of a block and in the first lane of the next one, one-row terms, no mu / nu, non-positive-definite draws; a draw's
+    value does not depend on its position in the batch nor on how the batch is cut into workspace chunks."""
+    rng = np.random.default_rng(771)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()   # noqa: E731
+    ctx.set_option("scan_config", "tile")
+    try:
+        for J, N, B in [(1, 1, 3), (2, 15, 4), (8, 16, 5), (8, 17, 5), (12, 31, 2), (16, 32, 3), (16, 33, 301), (20, 100, 7),
+                        (24, 64, 3), (30, 49, 2), (31, 130, 3), (32, 47, 9), (39, 81, 6), (40, 160, 5), (47, 35, 6)]:
+            t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+            ds = pj.Dataset(t, y, s2, ctx)
+            got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+            assert name() == "tile"
+            ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+            assert relerr(got, ref) < 1e-11, (J, N, B)
+            assert (st == 0).all()
+        # odd row counts through real (one-row) terms: R = 15, 16, 31, 47, 63, 64, 79, 95
+        for J, nreal in [(8, 1), (9, 2), (16, 1), (24, 1), (32, 1), (33, 2), (40, 1), (48, 1)]:
+            t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 70, J, 5)
+            Bc[:, :nreal] = 0.0
+            Dd[:nreal] = 0.0
+            ds = pj.Dataset(t, y, s2, ctx)
+            got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+            assert name() == "tile"
+            ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+            assert relerr(got, ref) < 1e-11, (J, nreal)
+        # 96 rows and more, per-draw series: launches it does not take (the automatic choice runs)
+        t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 40, 48, 3)
+        got = pj.Dataset(t, y, s2, ctx).logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert name() != "tile" and relerr(got, O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=4)) < 1e-11
+        t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 90, 20, 6)
+        Y = rng.standard_normal((6, 90)); S2 = rng.uniform(0.01, 0.1, (6, 90))
+        ds = pj.Dataset(t, y, s2, ctx)
+        got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+        assert name() != "tile"
+        ref = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(6)])
+        assert relerr(got, ref) < 1e-11
+        # neither mu nor nu
+        got = ds.logl_batch(A, Bc, C, Dd)
+        assert name() == "tile" and relerr(got, O.logl_batch(A, Bc, C, Dd, t, y, s2, np.zeros(6), np.ones(6), nthreads=4)) < 1e-11
+        # non-positive-definite draws follow the reference's log(abs(D_n)) (src/celerite_solver.jl:140) and are flagged
+        t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 60, 20, 4)
+        A[1] *= -1.0
+        got, st = pj.Dataset(t, y, s2, ctx).logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        ref, rst = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=4, return_status=True)
+        assert name() == "tile" and (st == rst).all() and st[1] != 0
+        ok = np.isfinite(ref)
+        assert relerr(got[ok], ref[ok]) < 1e-9 and (np.isnan(got) == np.isnan(ref)).all()
+        # position in the batch and workspace chunks: same bits
+        t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 200, 26, 2600)     # 52 rows: four block columns, a pass is 2048 draws
+        ds = pj.Dataset(t, y, s2, ctx)
+        whole = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert name() == "tile"
+        perm = rng.permutation(2600)
+        shuffled = ds.logl_batch(A[perm], Bc[perm], C, Dd, mu=mu[perm], nu=nu[perm])
+        assert np.array_equal(shuffled, whole[perm])
+        ctx.trim()                                        # (the limit is on NEW workspace: drop the 34 MB the call above left)
+        ctx.set_option("workspace_limit_mb", 32)          # 13 windows x 1 KB x 2600 draws = 34 MB: two chunks
+        try:
+            chunked = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        finally:
+            ctx.set_option("workspace_limit_mb", None)
+        assert name() == "tile" and np.array_equal(chunked, whole)
+        assert relerr(whole, O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)) < 1e-11
+    finally:
+        ctx.set_option("scan_config", None)
+
+
+def test_tile_kernel_is_the_default_for_large_batches_from_49_rows(ctx):
+    """capi.hip tile_dispatch: shared (c, d), no per-draw rows or series, 49 rows and more, batches above the small-batch windowed kernel's
+    range; "no_tile" switches it off."""
+    rng = np.random.default_rng(772)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()   # noqa: E731
+    for J, B, want in [(25, 513, "tile"), (25, 512, "block"), (24, 600, "scan"), (32, 257, "tile"), (40, 300, "tile"), (40, 256, "block")]:
+        t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 50, J, B)
+        ds = pj.Dataset(t, y, s2, ctx)
+        got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert name().startswith(want), (J, B, name())
+        assert relerr(got, O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)) < 1e-11
+        if want == "tile":
+            ctx.set_option("no_tile", True)
+            try:
+                other = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+            finally:
+                ctx.set_option("no_tile", False)
+            assert name() != "tile" and relerr(other, got) < 1e-11
 
 
 # ---------------------------------------------------------------------------------------------
