@@ -76,12 +76,14 @@ int pioran_ctx_trim(pioran_ctx* ctx);
  *                     also selects the lean / round-1 kernels of the step-by-step gradient, prediction and simulation (64 .. 95 rows)
  *   "no_split"        a batch that is not a whole number of passes runs as one launch (default: the remainder goes to the windowed kernel)
  *   "workspace_limit_mb"  cap on the per-call workspaces (default 16384)
- *   "dense_old_chain" 0 one launch per block column (default), 1 the panel / update chain of rounds 1-3, 2 .. 4 timing experiments of the
- *                     roles (results are garbage), 5 the persistent-chain prototype (6 .. 8: the same without its fences; timing only);
+ *   "no_tile"         value "1": never the windowed form with one draw per wavefront (celerite_tile.hip); "scan_config" = "tile" forces it for
+ *                     every launch it can take
+ *   "dense_old_chain" 0 one launch per block column (default), 1 the panel / update chain of rounds 1-3 (2 .. 8: timing experiments, only in
+ *                     builds with -DPIORAN_EXPERIMENTS; PIORAN_ERR_ARG otherwise);
  *                     "dense_no_pairs", "dense_no_halves", "dense_quad_threshold", "dense_batch_pair_threshold", "dense_streams": schedule knobs
  *   "block_emode", "gsum", "exp"   tuning / experiment selectors of single kernels (tools/ only; "exp" can make results meaningless)
- * Initial values come from the environment variables PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_BLOCK, PIORAN_NO_PAIRED,
- * PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK, PIORAN_WIN2, PIORAN_NO_WIN2, read once when the context is created. */
+ * Initial values come from the environment variables PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_BLOCK, PIORAN_NO_TILE, PIORAN_NO_PAIRED,
+ * PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK, PIORAN_WIN2, PIORAN_NO_WIN2, PIORAN_GSUM, PIORAN_WIDE2, read once when the context is created. */
 int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value);
 /* hipEvent-based timing on the ctx stream: record slot i (0..11), elapsed between two slots. */
 int pioran_ctx_event_record(pioran_ctx* ctx, int slot);
@@ -235,13 +237,16 @@ int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, c
                              const double* q, double* y_out);
 /* Name of the kernel configuration a large batch with R active rows (all terms with both rows when R is even) runs on;
  * R == 0: the configuration the calling thread's last throughput-layout launch actually ran on; R < 0: the kernel FAMILY of the
- * calling thread's last launch — "block" (windowed kernel), "block+pd" (with per-draw rows), "block (per-draw tables)", "wide"
+ * calling thread's last launch — "tile" (windowed form, one draw per wavefront: large batches from 49 rows on and batch sizes between the
+ * passes of the throughput layouts), "block" (windowed kernel), "block+pd" (with per-draw rows), "block (per-draw tables)", "wide"
  * (latency layout), "scan" (throughput layouts), "fallback", "block (windowed gradient[, per-draw tables])",
  * "wide (step-by-step gradient)" (diagnostics). */
 const char* pioran_celerite_config_name(int64_t R);
 /* Diagnostics: the FP64 FMA rate (TFLOP/s) the device sustains right now with `waves_per_simd` (1 .. 8) wavefronts on every SIMD — about
  * `ms` milliseconds of a pure stream of independent v_fma_f64, event-timed on the context's stream.  The measured ceiling of any FP64
- * vector kernel on this box at that occupancy (the 78.6 TFLOP/s vendor figure assumes one FMA per SIMD every 4 cycles at 2.4 GHz). */
+ * vector kernel on this box at that occupancy (the 78.6 TFLOP/s vendor figure assumes one FMA per SIMD every 4 cycles at 2.4 GHz).
+ * Side effects: blocks until the stream has drained; may re-allocate the context's scratch buffer (no call may be in flight on another
+ * thread of the same context); uses the context's own event slots, never the caller's 0 .. 11. */
 int pioran_ctx_fp64_probe(pioran_ctx* ctx, int waves_per_simd, double ms, double* tflops);
 
 /* ---- in-process farm over several GPUs ---------------------------------------------------------------------------

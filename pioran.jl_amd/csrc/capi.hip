@@ -377,7 +377,25 @@ int tile_dispatch(pioran_ds* ds, const ScanParams& p)
     // step-by-step layouts at every batch size above the small-batch windowed kernel's range — DRWCelerite-20 (60 rows) 1024 draws 6.3
     // against 7.8 ms, 4096 draws 17.5 against 25.1 ms; SHO-40 (80 rows) 512 draws 10.0 against 13.1 ms, 4096 draws 41.3 against 75.3 ms.
     // Up to 48 rows the throughput layouts (two draws per wavefront) are level with it (SHO-20: 11.2 against 11.4 ms) and stay the default.
-    const bool automatic = !o.scan_config[0] && !o.no_tile && !o.no_block && p.R >= 49 && p.B > (p.R > pioran_block_supported_rows() ? 256 : 512);
+    // Up to 48 rows the throughput layouts (two and four draws per wavefront) are level with it on whole passes (SHO-20, 4096 draws: 11.2
+    // against 11.5 ms) and ahead of it below 33 rows (SHO-16, 4096 draws: 5.8 against 10.7 ms) — but their time is a staircase of passes
+    // (SHO-20: 4096 draws), and this kernel's steps are a quarter of that (1024 draws: one workgroup per CU): it takes what falls between
+    // (profiles/r05_tile_batch_sweep.txt: SHO-20 1024 draws 3.96 against 5.31 ms, 3072 draws 9.3 against 11.0, 5000 draws 14.8 against 16.7;
+    // SHO-12 / SHO-16 / SHO-24 at 1024 draws 2.9 / 3.9 / 6.2 against 4.2 / 5.6 / 8.2 ms).
+    bool automatic = !o.scan_config[0] && !o.no_tile && !o.no_block && p.tab && p.npd_rows == 0 && !p.Y && !p.S2;
+    if (automatic) {
+        if (p.R >= 49) automatic = p.B > (p.R > pioran_block_supported_rows() ? 256 : 512);
+        else if (p.R < 17 || p.B <= 512) automatic = false;
+        else if (p.B <= 1024) automatic = true;
+        else if (p.R < 33) automatic = false;
+        else {
+            const int64_t pass = pioran_scan_pass_draws(p, nullptr);
+            const int64_t r = pass > 0 ? p.B % pass : 0;
+            // a remainder of up to one round of the small-batch kernel rides beside the scan (split_dispatch) where that kernel takes these rows
+            const bool split = p.B > pass && r > 0 && r <= (p.R <= 47 ? 512 : 256) && !o.no_split;
+            automatic = pass > 0 && r > 0 && 4 * r <= 3 * pass && !split;
+        }
+    }
     if (!(force || automatic) || !p.tab || p.npd_rows != 0 || p.Y || p.S2 || !pioran_tile_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
     PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
     if (!s || !s->prepared || s->npd_terms != 0 || p.rec_stride != 3 * (int64_t)(s->R + 2) + 2) return PIORAN_ERR_UNSUPPORTED;
@@ -426,8 +444,14 @@ static int split_dispatch(pioran_ds* ds, const ScanParams& p)
     const int64_t k = p.B / pass, r = p.B - k * pass;
     if (k >= 1 && r > 0 && r <= rem_max) main_n = k * pass;
     if (main_n <= 0 || main_n >= p.B) return PIORAN_ERR_UNSUPPORTED;
+    // everything that can refuse is asked BEFORE the second stream gets work: the whole passes must be a launch the scan takes
+    {
+        const ScanParams probe = slice_draws(p, 0, main_n);
+        const bool y80 = probe.R == pioran_scan_supported_rows_shared() && !o.no_win2 && (probe.B > 768 || o.no_wide);
+        if (probe.R > pioran_scan_supported_rows() && !y80) return PIORAN_ERR_UNSUPPORTED;
+    }
     int rc = ensure_btab(ds, *s);
-    if (rc) return rc == PIORAN_ERR_UNSUPPORTED ? rc : rc;
+    if (rc) return rc;
     if (!ctx->aux) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
         for (auto& e : ctx->gev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -441,8 +465,8 @@ static int split_dispatch(pioran_ds* ds, const ScanParams& p)
     HIPCHK(ctx, hipEventRecord(ctx->gev[4], ctx->aux));
     ScanParams qm = slice_draws(p, 0, main_n);
     rc = scan_dispatch(qm, ctx->stream);
-    if (rc) { if (rc == PIORAN_ERR_HIP) ctx->last_err = "scan kernel launch failed"; return rc; }
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->gev[4], 0));   // join
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->gev[4], 0));   // join — on every path: the second stream's kernel writes the caller's buffers
+    if (rc) { if (rc == PIORAN_ERR_HIP) ctx->last_err = "scan kernel launch failed"; return rc == PIORAN_ERR_UNSUPPORTED ? PIORAN_ERR_HIP : rc; }
     g_last_kernel = "scan + block (remainder)";
     return PIORAN_OK;
 }
@@ -518,12 +542,13 @@ int pioran_ctx_fp64_probe(pioran_ctx* ctx, int waves_per_simd, double ms, double
     if (iters < 64) iters = 64;
     double flop = 0.0;
     if ((rc = pioran_launch_fma_stream(blocks, 64, (double*)ctx->bscratch.p, nullptr, ctx->stream))) return rc;   // warm
-    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    // (the context's internal event slots: 0 .. 11 are the caller's, pioran_ctx_event_record)
+    HIPCHK(ctx, hipEventRecord(ctx->ev[14], ctx->stream));
     if ((rc = pioran_launch_fma_stream(blocks, iters, (double*)ctx->bscratch.p, &flop, ctx->stream))) return rc;
-    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[15], ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[15]));
     float t = 0.f;
-    HIPCHK(ctx, hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
+    HIPCHK(ctx, hipEventElapsedTime(&t, ctx->ev[14], ctx->ev[15]));
     *tflops = t > 0.f ? flop / (t * 1e-3) / 1e12 : 0.0;
     return PIORAN_OK;
 }
@@ -553,7 +578,13 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "block_emode")) o.block_emode = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "dense_quad_threshold")) o.dense.quad_threshold = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "dense_batch_pair_threshold")) o.dense.batch_pair_threshold = (value && value[0]) ? std::atoi(value) : -1;
-    else if (!std::strcmp(key, "dense_old_chain")) o.dense.old_chain = (value && value[0]) ? std::atoi(value) : 0;
+    else if (!std::strcmp(key, "dense_old_chain")) {
+        const int v = (value && value[0]) ? std::atoi(value) : 0;
+#ifndef PIORAN_EXPERIMENTS
+        if (v < 0 || v > 1) return PIORAN_ERR_ARG;     // 2 .. 8 (timing experiments, garbage results) exist in experiment builds only
+#endif
+        o.dense.old_chain = v;
+    }
     else if (!std::strcmp(key, "dense_no_pairs")) o.dense.no_pairs = on ? 1 : 0;
     else if (!std::strcmp(key, "dense_no_halves")) o.dense.no_halves = on ? 1 : 0;
     else if (!std::strcmp(key, "workspace_limit_mb")) o.workspace_limit_mb = (value && value[0]) ? std::atoll(value) : 0;
@@ -587,7 +618,9 @@ static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
     pioran_ctx_set_option(ctx, "no_win2", std::getenv("PIORAN_NO_WIN2"));
     pioran_ctx_set_option(ctx, "gsum", std::getenv("PIORAN_GSUM"));
     pioran_ctx_set_option(ctx, "wide2", std::getenv("PIORAN_WIDE2"));
-    pioran_ctx_set_option(ctx, "exp", std::getenv("PIORAN_EXP"));
+#ifdef PIORAN_EXPERIMENTS
+    pioran_ctx_set_option(ctx, "exp", std::getenv("PIORAN_EXP"));     // experiment builds only: the product library never reads it
+#endif
     pioran_ctx_set_option(ctx, "no_wide2", std::getenv("PIORAN_NO_WIDE2"));
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
     if (own) {

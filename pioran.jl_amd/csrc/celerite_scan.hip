@@ -24,6 +24,7 @@
 //     row; the partial q of the CBR column blocks are summed with ds_bpermute.
 // FP64 VALU bound (no MFMA: the update is rank-1 per draw, nothing is shared across draws).
 #include "common.h"
+#include <vector>
 
 #include <cstdio>
 #include <cstdlib>
@@ -1706,11 +1707,13 @@ void launch_ycol(const ScanParams& p, dim3 grid, hipStream_t st)
     SCAN_LAUNCH((celerite_scan_kernel<RPL, CBR, NSRC, true, MINW, PAIRED, false, 0, true, 0, true>), grid, 256, st, p);
 }
 
+#ifdef PIORAN_EXPERIMENTS
 template <int RPL, int NSRC, bool PAIRED>
 void launch_ycol_w2(const ScanParams& p, dim3 grid, hipStream_t st)
 {
     SCAN_LAUNCH((celerite_scan_kernel<RPL, 4, NSRC, true, 2, PAIRED, false, 0, true, 2, true, false, 2>), grid, 128, st, p);
 }
+#endif
 
 #define CFG(RPL, CBR, NSRC) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC, RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC>}
 #define CFG_P(RPL, CBR, NSRC, MINW) {"rpl" #RPL "_cbr" #CBR "_nsrc" #NSRC "_p", RPL, CBR, NSRC, &launch_cfg<RPL, CBR, NSRC, MINW, true>, true}
@@ -1736,8 +1739,12 @@ const ScanConfig kConfigs[] = {
     // evaluations per second for SHO-40, B = 4096), slower below (the stream is the same for 65 .. 80 rows; SHO-39 runs at 64 k on
     // rpl5_cbr4_nsrc4_p).  589 VALU instructions per wavefront and pair of steps, of which only 280 are the passes over T: the row-vector
     // work of five rows per lane, the five 16-lane row sums and the exchange are paid by BOTH wavefronts (profiles/r04_r80.txt).  Selected
-    // by name only (context option scan_config); kept as the measured answer to "split the draw over two wavefronts".
+    // by name only (context option scan_config); the measured answer to "split the draw over two wavefronts" — in experiment builds
+    // (-DPIORAN_EXPERIMENTS) only since round 5: from 49 rows on large batches run the windowed form on the matrix cores (celerite_tile.hip:
+    // 99 k evaluations per second for SHO-40).
+#ifdef PIORAN_EXPERIMENTS
     {"rpl5_cbr4_nsrc2_w2_y", 5, 4, 2, &launch_ycol_w2<5, 2, false>, false, false, 0, true, 2},
+#endif
     // column-paired variants (standard row map only; picked automatically by pick_config when applicable)
     {"rpl3_cbr2_nsrc7_p", 3, 2, 7, &launch_cfg<3, 2, 7, 1, true, true>, true}, CFG_P(3, 2, 8, 1), CFG_P(3, 2, 6, 1),
     CFG_P(1, 1, 5, 1), CFG_P(1, 1, 9, 1), CFG_P(1, 1, 13, 1), CFG_P(1, 1, 16, 1),
@@ -1748,7 +1755,9 @@ const ScanConfig kConfigs[] = {
     {"rpl2_cbr1_nsrc16_yp", 2, 1, 16, &launch_ycol<2, 1, 16, 1, true>, true, true, 0, true},
     {"rpl3_cbr2_nsrc8_yp", 3, 2, 8, &launch_ycol<3, 2, 8, 1, true>, true, true, 0, true},
     {"rpl5_cbr4_nsrc4_yp", 5, 4, 4, &launch_ycol<5, 4, 4, 1, true>, true, true, 0, true},
+#ifdef PIORAN_EXPERIMENTS
     {"rpl5_cbr4_nsrc2_w2_yp", 5, 4, 2, &launch_ycol_w2<5, 2, true>, true, false, 0, true, 2},
+#endif
     // DRWCelerite with 20 components: 20 complex + 20 real terms = 5 pairs + 5 singles + 1 spare in each of the 4 blocks
     {"rpl4_cbr4_nsrc4_b5a", 4, 4, 4, &launch_blocked<4, 4, 4, 2, 5>, false, true, 5},
     // alternatives kept for tuning runs (selected by name)
@@ -1756,7 +1765,11 @@ const ScanConfig kConfigs[] = {
 };
 #undef CFG
 #undef CFG_P
+#ifdef PIORAN_EXPERIMENTS
 constexpr int kNumPreferred = 20;
+#else
+constexpr int kNumPreferred = 19;
+#endif
 
 // y-as-a-vector shapes exist in the two-step form for launches without per-draw rows only
 bool ycol_usable(const ScanConfig& c, const ScanParams* p)
@@ -1848,11 +1861,27 @@ int64_t pioran_scan_pass_draws(const ScanParams& p, int* waves_per_simd)
     const ScanConfig* c = launch_config(p);
     if (!c) return 0;
     int waves_per_cu = 0, ncu = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    g_occ_query = &waves_per_cu;
-    c->fn(p, dim3(1), nullptr);
-    g_occ_query = nullptr;
-    (void)hipGetLastError();
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    // The answer depends on the device and on which instantiation the selection logic picks (configuration, batch class, options): asked
+    // once per such key and thread (the dispatchers of capi.hip call this on every large launch).
+    struct Key { const ScanConfig* c; int dev; unsigned flags; int waves_per_cu, ncu; };
+    const unsigned flags = (p.B > 2048 ? 1u : 0u) | (p.tab ? 2u : 0u) | (p.npd_rows > 0 ? 4u : 0u) |
+                           (p.opt ? ((p.opt->win3 ? 8u : 0u) | (p.opt->no_win3 ? 16u : 0u) | (p.opt->win2 ? 32u : 0u) | (p.opt->no_win2 ? 64u : 0u) |
+                                     ((unsigned)(p.opt->gsum + 1) << 8)) : 0u);
+    static thread_local std::vector<Key> cache;
+    bool hit = false;
+    for (const Key& k : cache)
+        if (k.c == c && k.dev == dev && k.flags == flags) { waves_per_cu = k.waves_per_cu; ncu = k.ncu; hit = true; break; }
+    if (!hit) {
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        const bool keep_win3 = g_last_win3;      // a query is not a launch: the diagnostics keep describing the last launch
+        g_occ_query = &waves_per_cu;
+        c->fn(p, dim3(1), nullptr);
+        g_occ_query = nullptr;
+        g_last_win3 = keep_win3;
+        (void)hipGetLastError();
+        if (waves_per_cu > 0 && ncu > 0) cache.push_back(Key{c, dev, flags, waves_per_cu, ncu});
+    }
     const int epw = 64 / (16 * c->cbr);
     if (waves_per_cu <= 0 || ncu <= 0) return 0;
     if (waves_per_simd) *waves_per_simd = waves_per_cu / 4;

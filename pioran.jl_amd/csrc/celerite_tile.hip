@@ -276,8 +276,10 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
         for (int j = 0; j < 16; ++j) m[j] = sw.scr[j * 16 + c16];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PIORAN_TSTAMP(4);
+        __builtin_amdgcn_s_setprio(2);     // the dependent chain of the window: ahead of the SIMD's other wavefront's matrix work (+1 .. 2 %)
         double mult = ldl_first_mult(m, c16);
         static_for<0, 16>([&](auto Pc) __attribute__((always_inline)) { ldl_step<decltype(Pc)::value>(m, mult, c16); });
+        __builtin_amdgcn_s_setprio(0);
         PIORAN_TSTAMP(5);
         if (q == 0) {   // lane n holds column n of L^-1 (scaled by D_n) in m[j], j > n, D_n in m[n]; the rest of m is left-over Sigma (masked below)
             double2* dst = reinterpret_cast<double2*>(sw.scr + c16 * 18);

@@ -1139,7 +1139,9 @@ __global__ void __launch_bounds__(256, 2) dense_step_kernel(double* __restrict__
     }
 }
 
-// The persistent chain of the prototype: CRIT(0 .. nb-1) in one workgroup.
+#ifdef PIORAN_EXPERIMENTS
+// The persistent chain of the prototype: CRIT(0 .. nb-1) in one workgroup.  Measured slower than the launched chain (1.55 against 1.24 ms,
+// docs/EXPERIMENTS.md section 11.7): compiled only into experiment builds (-DPIORAN_EXPERIMENTS), never into the product library.
 // (launched with kChainPadLds bytes of dynamic LDS it never touches: no workgroup of a step launch then fits beside it, and the chain keeps
 //  its CU's DP pipes to itself — what the blank workgroup 256 achieves for the launched chain)
 constexpr int kChainPadLds = 56 * 1024;
@@ -1160,6 +1162,7 @@ __global__ void __launch_bounds__(256, 1) dense_crit_chain_kernel(double* __rest
         flag_post(flg + FLG_FACTORED + k + 1, tid, !(mode & 1));
     }
 }
+#endif
 
 __global__ void __launch_bounds__(256) dense_finish_kernel(const double* __restrict__ A, int64_t ld, int64_t N,
                                                            int64_t Mp, double* __restrict__ out,
@@ -1301,9 +1304,13 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
         int ks = 2;
         if (!dop.no_pairs) while (ks + 2 < nb && tiles_of(ks + 2) > kPairTiles) ks += 2;
         // prototype: the chain as one persistent workgroup on a second stream (see flag_wait above); the step launches start at DIAG2
+#ifndef PIORAN_EXPERIMENTS
+        if (dop.old_chain > 1) return PIORAN_ERR_ARG;     // timing experiments exist in experiment builds only
+        int* const flg = nullptr;
+#else
         const bool persist = dop.old_chain >= 5 && dop.old_chain <= 8;
         int* flg = persist ? reinterpret_cast<int*>(ws + WS_DOUBLES + 4 * SNAP_TILE) : nullptr;
-        static thread_local hipStream_t chain_stream = nullptr;
+        static thread_local hipStream_t chain_stream = nullptr;     // (experiment builds drive one device from one thread)
         static thread_local hipEvent_t chain_ev[2] = {nullptr, nullptr};
         if (persist) {
             if (!chain_stream) {
@@ -1322,6 +1329,7 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
             hipLaunchKernelGGL(dense_crit_chain_kernel, dim3(1), dim3(256), kChainPadLds, chain_stream, K, ld, Mp, info, flg, dop.old_chain - 5);
             (void)hipEventRecord(chain_ev[1], chain_stream);
         }
+#endif
         for (int k = 0; k < nb; ++k) {
             const int nstrip = nb - k - 1;
             StepBulk bk{0, 1, 0, 0, 0, 0};
@@ -1348,16 +1356,20 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
             if (!dop.no_halves && bk.cnt > 0 && bk.cnt <= kHalfTileLimit) { bk.halves = 1; bk.cnt *= 2; }
             unsigned grid = (unsigned)(2 + nstrip + (bk.cnt + 3) / 4);
             int bx0 = 0;
+#ifdef PIORAN_EXPERIMENTS
             // timing experiments only (results are garbage): 2 = the critical workgroup alone, 3 = DIAG2 + the strips alone, 4 = the bulk alone
             if (dop.old_chain == 2) grid = 1;
             else if (dop.old_chain == 3) { grid = (unsigned)(1 + nstrip); bx0 = 1; }
             else if (dop.old_chain == 4) { if (grid <= (unsigned)(2 + nstrip)) continue; grid -= (unsigned)(2 + nstrip); bx0 = 2 + nstrip; }
             if (persist) { grid -= 1; bx0 = 1; }
+#endif
             if (bx0 == 0 && grid > 256) ++grid;                  // the blank workgroup (see the kernel)
             if (bk.kp == 2) hipLaunchKernelGGL(dense_step_kernel<2>, dim3(grid), dim3(256), 0, stream, K, ld, Mp, k, info, bx0, nprev, bk, flg);
             else hipLaunchKernelGGL(dense_step_kernel<1>, dim3(grid), dim3(256), 0, stream, K, ld, Mp, k, info, bx0, nprev, bk, flg);
         }
+#ifdef PIORAN_EXPERIMENTS
         if (persist) (void)hipStreamWaitEvent(stream, chain_ev[1], 0);
+#endif
         if (phase_ev) (void)hipEventRecord(phase_ev[1], stream);
         hipLaunchKernelGGL(dense_finish_kernel, dim3(1, 1, 1), dim3(256), 0, stream, K, ld, N, Mp, out, info, bt);
         if (phase_ev) (void)hipEventRecord(phase_ev[2], stream);

@@ -433,10 +433,12 @@ def test_rows_65_to_80_one_draw_over_two_wavefronts(ctx, J, nreal, N, B):
         ctx.set_option("no_wide", True); ctx.set_option("no_block", True)   # (batches up to 256 draws would take the windowed / the latency kernel)
         one = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
         assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan" and "w2" not in pj._lib.lib().pioran_celerite_config_name(0).decode()
+        # the two-wavefront shape is compiled into experiment builds only (-DPIORAN_EXPERIMENTS, round 5): where the library has it, it is
+        # checked; in the product library the one-wavefront shape stands in for the rest of the test
         ctx.set_option("scan_config", "rpl5_cbr4_nsrc2_w2_yp" if nreal == 0 else "rpl5_cbr4_nsrc2_w2_y")
         got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
-        cfg = pj._lib.lib().pioran_celerite_config_name(0).decode()
-        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan" and "_w2_y" in cfg, cfg
+        cfg = pj._lib.lib().pioran_celerite_config_name(0).decode()     # (a name the library does not know leaves the choice automatic)
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan" and ("_w2_y" in cfg or cfg.startswith("rpl5_cbr4_nsrc4")), cfg
         Y = rng.standard_normal((B, N)); S2 = rng.uniform(0.01, 0.1, (B, N))
         got2 = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
     finally:
@@ -877,11 +879,13 @@ def test_tile_kernel_edges(ctx):
 
 
 def test_tile_kernel_is_the_default_for_large_batches_from_49_rows(ctx):
-    """capi.hip tile_dispatch: shared (c, d), no per-draw rows or series, 49 rows and more, batches above the small-batch windowed kernel's
-    range; "no_tile" switches it off."""
+    """capi.hip tile_dispatch: shared (c, d), no per-draw rows or series; 49 rows and more: every batch above the small-batch windowed kernel's
+    range; 33 .. 48 rows: what falls between the passes of the throughput layouts (up to three quarters of a pass past the last whole one,
+    unless the small-batch kernel takes the remainder beside the scan); 17 .. 32 rows: 513 .. 1024 draws; "no_tile" switches it off."""
     rng = np.random.default_rng(772)
     name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()   # noqa: E731
-    for J, B, want in [(25, 513, "tile"), (25, 512, "block"), (24, 600, "scan"), (32, 257, "tile"), (40, 300, "tile"), (40, 256, "block")]:
+    for J, B, want in [(25, 513, "tile"), (25, 512, "block"), (24, 600, "tile"), (24, 2048, "scan"), (24, 2500, "tile"), (24, 4000, "scan"), (20, 4096, "scan"),
+                       (16, 1024, "tile"), (16, 1025, "scan"), (8, 700, "scan"), (32, 257, "tile"), (40, 300, "tile"), (40, 256, "block")]:
         t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 50, J, B)
         ds = pj.Dataset(t, y, s2, ctx)
         got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
@@ -1008,14 +1012,16 @@ def test_dense_one_launch_per_block_column_equals_the_panel_update_chain(ctx, N)
         single, i2 = ctx.dense_nll(a, b, c, d, t, y, s2, return_info=True)
         ctx.set_option("dense_no_pairs", False); ctx.set_option("dense_no_halves", True)
         whole, i3 = ctx.dense_nll(a, b, c, d, t, y, s2, return_info=True)
-        # the persistent-chain prototype (one resident workgroup runs the critical role of every step; flags instead of kernel boundaries
-        # on the chain; every wait bounded): measured slower, kept as an option — same arithmetic, same bits
-        ctx.set_option("dense_no_halves", False); ctx.set_option("dense_old_chain", 5)
-        pers, i4 = ctx.dense_nll(a, b, c, d, t, y, s2, return_info=True)
+        ctx.set_option("dense_no_halves", False)
+        # the timing experiments of round 4 (2 .. 4: single roles, garbage results; 5 .. 8: the persistent-chain prototype, measured slower)
+        # are not in the product library (-DPIORAN_EXPERIMENTS builds only): the option refuses them
+        for v in (2, 5, 8):
+            with pytest.raises(pj._lib.PioranHipError):
+                ctx.set_option("dense_old_chain", v)
     finally:
         ctx.set_option("dense_old_chain", 0); ctx.set_option("dense_no_pairs", False); ctx.set_option("dense_no_halves", False)
-    assert i0 == i1 == i2 == i3 == i4 == 0
-    assert abs(new - old) <= 1e-12 * abs(old) and abs(single - old) <= 1e-12 * abs(old) and whole == new and pers == new
+    assert i0 == i1 == i2 == i3 == 0
+    assert abs(new - old) <= 1e-12 * abs(old) and abs(single - old) <= 1e-12 * abs(old) and whole == new
     if N <= 1000:
         ref = O.dense_nll(a, b, c, d, t, y, s2)
         assert abs(new - ref) <= 1e-11 * abs(ref)
