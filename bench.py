@@ -104,22 +104,20 @@ def algorithmic_flops(N: int, R: int) -> float:
 def spawn_ranks(n: int, script: str, argv, timeout_s: float | None = None) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process
     (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), relay the child's
-    stdout (rank 0's JSON line) and return its exit code.  Called before anything in this process has touched the GPU
-    (`import torch` and `torch.cuda.device_count()` do not); this process is never replaced (no exec), it only waits.
+    stdout (rank 0's JSON line) and return its exit code.  Called before this process has launched anything on the GPU (`import torch`
+    does not touch it; `torch.cuda.device_count()` may initialise the HIP runtime on builds without amdsmi — harmless here: this process
+    is never replaced (no exec), it only starts a child and waits).
     The farm of docs/src/ultranest.md:143-149 is `mpiexec -n N julia script.jl`; this is its one-node counterpart."""
     import signal
-    import socket
     import subprocess
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # --standalone: the launcher's own rendezvous picks a free port when it binds it (no bind-close-reuse window in which a parallel run
+    # could take the port); --local-addr: the container's host name may not resolve
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_ADDR", "MASTER_PORT")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, n))))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), script, *argv]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
+           script, *argv]
     if timeout_s is None:
         timeout_s = float(os.environ.get("PIORAN_BENCH_SPAWN_TIMEOUT", "1500"))
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)

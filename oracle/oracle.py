@@ -86,6 +86,64 @@ def _c(x):
 
 
 # ---------------------------------------------------------------------------------------------
+# higher-precision truth: the same recurrence in __float128 (celerite_oracle_q.c, libquadmath) — its own small library, built on first use
+# ---------------------------------------------------------------------------------------------
+_SRC_Q = _HERE / "celerite_oracle_q.c"
+_LIB_Q = _BUILD / "liboracle_q.so"
+_lib_q = None
+
+
+def build_quad(force: bool = False) -> Path:
+    if not force and _LIB_Q.exists() and _LIB_Q.stat().st_mtime >= _SRC_Q.stat().st_mtime:
+        return _LIB_Q
+    _BUILD.mkdir(exist_ok=True)
+    tmp = _BUILD / f"liboracle_q.{os.getpid()}.so"
+    subprocess.run(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=gnu11", str(_SRC_Q), "-o", str(tmp), "-lquadmath", "-lm"], check=True)
+    os.replace(tmp, _LIB_Q)
+    return _LIB_Q
+
+
+def _libq():
+    global _lib_q
+    if _lib_q is None:
+        build_quad()
+        L = ctypes.CDLL(str(_LIB_Q))
+        i64 = ctypes.c_int64
+        L.oracle_logl_quad.restype = ctypes.c_double
+        L.oracle_logl_quad.argtypes = [i64, i64] + [_dp] * 7 + [_dp]
+        L.oracle_logl_quad_batch.restype = None
+        L.oracle_logl_quad_batch.argtypes = [i64, i64, i64] + [_dp] * 11 + [ctypes.c_int]
+        _lib_q = L
+    return _lib_q
+
+
+def logl_quad(a, b, c, d, t, y, sigma2, return_dmin=False):
+    """logl (src/celerite_solver.jl:312-334) evaluated in __float128 and rounded to fp64: the truth the fp64 evaluations are held against."""
+    a, pa = _c(a); b, pb = _c(b); c, pc = _c(c); d, pd = _c(d)
+    t, pt = _c(t); y, py = _c(y); s2, ps = _c(sigma2)
+    dm = ctypes.c_double(0.0)
+    v = _libq().oracle_logl_quad(len(t), len(a), pa, pb, pc, pd, pt, py, ps, ctypes.cast(ctypes.byref(dm), _dp))
+    return (v, dm.value) if return_dmin else v
+
+
+def logl_quad_batch(A, Bc, C, Dd, t, y, sigma2, mu=None, nu=None, nthreads=1, return_dmin=False):
+    """B independent quad-precision evaluations (shared c, d); mu / nu applied in fp64 exactly as the fp64 paths apply them."""
+    A, pA = _c(A); Bc, pB = _c(Bc); C, pC = _c(C); Dd, pD = _c(Dd)
+    t, pt = _c(t); y, py = _c(y); s2, ps = _c(sigma2)
+    B, J = A.shape
+    assert C.ndim == 1
+    pmu = pnu = None
+    if mu is not None:
+        mu, pmu = _c(mu)
+    if nu is not None:
+        nu, pnu = _c(nu)
+    out = np.empty(B); dmin = np.empty(B)
+    _libq().oracle_logl_quad_batch(len(t), J, B, pA, pB, pC, pD, pmu, pnu, pt, py, ps, out.ctypes.data_as(_dp), dmin.ctypes.data_as(_dp),
+                                   int(nthreads))
+    return (out, dmin) if return_dmin else out
+
+
+# ---------------------------------------------------------------------------------------------
 # solver front-ends (C)
 # ---------------------------------------------------------------------------------------------
 def logl(a, b, c, d, t, y, sigma2, return_status=False):

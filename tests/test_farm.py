@@ -62,7 +62,7 @@ def _worker(rank, world, port, B, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,B", [(2, 64), (2, 37), (3, 10)])
+@pytest.mark.parametrize("world,B", [(2, 64), (2, 37), (3, 10), (8, 64), (8, 45)])   # 8: the driver's world size (one rank per GPU of a node)
 def test_farm_gloo(world, B):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -52,6 +52,18 @@ def test_bench_multi_rank_loop_two_ranks_on_one_gpu():
     assert two["ms_per_step"] >= 0.8 * one["ms_per_step"]
 
 
+def test_bench_multi_rank_loop_three_ranks_on_one_gpu():
+    """The same loop at an odd world size: three ranks on cuda:0 over gloo.  (One GPU of this pool admits six processes on its card at once,
+    and this pytest process, bench.py's parent and the launcher count: five ranks were refused by the box's process guard.  The driver's eight
+    ranks need eight GPUs — their rendezvous, thread division and gather order at world size 8 are exercised on the CPU:
+    tests/test_bench_spawn.py::test_spawn_ranks_at_the_drivers_world_size, tests/test_farm.py.)  Per-rank seeds, the rank-ordered gather
+    and the MAX-reduced time with ranks that finish apart."""
+    three = _bench(3, ["--dist-backend", "gloo", "--device", "0", "--batch", "512", "--verify-gather"], steps=3)
+    assert three["n_gpus"] == 3 and three["config"]["global_batch"] == 1536 and three["steps"] == 3
+    assert three["gather_verified"] is True
+    assert three["status_ok_frac"] > 0.9
+
+
 @pytest.mark.skipif(NGPU < 2, reason="needs at least two GPUs (RCCL ranks)")
 def test_bench_over_rccl_ranks():
     n = min(8, NGPU)

@@ -269,3 +269,28 @@ def test_reference_outputs_turing_chain(golden_dir):
     # posterior's curvature is all that separates the two evaluations
     assert err.max() < 1e-10, (err.max(), int(np.argmax(err)))
     assert (ref > ref.max() - 30).sum() > 6000          # most of them sit where a sampler lives
+
+
+# ---- ill-conditioned draws: the fp64 oracle against the same recurrence in __float128 (oracle/celerite_oracle_q.c) -------------------
+def test_quad_truth_fixture_and_fp64_oracle(golden_dir):
+    """tests/golden/quad_truth.npz (oracle/make_quad_truth.py): prior draws of the bench model with ratio = nu min(sigma2) / sum(a) ~
+    1 / cond(K) down to 3e-10, log L evaluated in quad precision.  (1) The quad code reproduces the stored values (a few draws at N = 150:
+    libquadmath is software arithmetic); (2) the fp64 oracle — the reference's algorithm and operation order — is itself up to 8e-9 from the
+    exact value of its fp64 inputs below ratio 1e-8 (rounding sum(a), nu sigma2 and the phases d t alone moves log L by ~ eps / ratio there:
+    tools/window_precision_study.py), and within 2e-9 from ratio 1e-8 on.  The GPU families are held against the same truth in
+    tests/test_gpu_parity.py::test_ill_conditioned_draws_vs_quad_truth."""
+    q = np.load(golden_dir / "quad_truth.npz")
+    t, y, yerr = q["n150_t"], q["n150_y"], q["n150_yerr"]
+    A, Bc, C, Dd, mu, nu = (q[f"n150_{k}"] for k in ("A", "Bc", "C", "Dd", "mu", "nu"))
+    pick = np.argsort(q["n150_ratio"])[[0, 3, 40, 200]]
+    again = O.logl_quad_batch(A[pick], Bc[pick], C, Dd, t, y, yerr ** 2, mu[pick], nu[pick], nthreads=4)
+    assert np.array_equal(again, q["n150_truth"][pick])
+    for tag, series in (("n150", (t, y, yerr)), ("n1000", (q["n1000_t"], q["n1000_y"], q["n1000_yerr"]))):
+        tt, yy, ee = series
+        A, Bc, C, Dd, mu, nu = (q[f"{tag}_{k}"] for k in ("A", "Bc", "C", "Dd", "mu", "nu"))
+        truth, ratio = q[f"{tag}_truth"], q[f"{tag}_ratio"]
+        got, st = O.logl_batch(A, Bc, C, Dd, tt, yy, ee ** 2, mu, nu, nthreads=8, return_status=True)
+        assert (st == 0).all() and (q[f"{tag}_dmin"] > 0).all()
+        err = np.abs(got - truth) / np.abs(truth)
+        assert err[ratio >= 1e-8].max() < 2e-9 and err[ratio < 1e-8].max() < 1e-8, (tag, err[ratio >= 1e-8].max(), err[ratio < 1e-8].max())
+        assert np.median(err) < 1e-11
