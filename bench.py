@@ -71,9 +71,10 @@ def synth_theta(B: int, t, y, seed: int):
 
 
 def scan_source_hash() -> str:
-    """Fingerprint of the scan kernel's sources: a committed PMC summary is only quoted while it matches."""
+    """Fingerprint of the sources of the kernels the headline can run on (the step-by-step scan; since round 5 the windowed tile kernel):
+    a committed PMC summary is only quoted while it matches."""
     h = hashlib.sha256()
-    for f in ("celerite_scan.hip", "common.h"):
+    for f in ("celerite_scan.hip", "celerite_tile.hip", "window_common.h", "common.h"):
         h.update((ROOT / "pioran.jl_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()[:16]
 
@@ -82,7 +83,7 @@ def pmc_traffic(basis: str, J: int, B: int, N: int, kernel_config: str):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary of this same command (bench.py cannot collect
     PMCs on itself).  Quoted only when the summary was taken on the SAME kernel: same configuration name and same
     source fingerprint; otherwise null with the reason."""
-    cands = [ROOT / "profiles" / f"{r}_pmc_{basis.lower()}{J}_b{B}.json" for r in ("r04", "r03", "r02")]
+    cands = [ROOT / "profiles" / f"{r}_pmc_{basis.lower()}{J}_b{B}.json" for r in ("r05", "r04", "r03", "r02")]
     f = next((c for c in cands if c.exists()), cands[0])
     if N != 10_000 or not f.exists():
         return None, f"no PMC summary for this workload ({f.name})"
@@ -93,6 +94,17 @@ def pmc_traffic(basis: str, J: int, B: int, N: int, kernel_config: str):
         return None, f"{f.name} predates the current kernel source ({d.get('scan_source_hash')} != {scan_source_hash()})"
     return d["derived"]["hbm_traffic_bytes"], (f"profiles/{f.name}: 2*FETCH_SIZE + WRITE_SIZE (KB -> B, gfx950 x2 on fetch), separate "
                                                f"--pmc passes of this command; kernel {d['kernel']}")
+
+
+NOTE_TILE = ("celerite_tile_kernel (round 5): the windowed form of the recurrence — 16 time steps per window eliminated through GEMMs against the R x R state "
+             "and one 16 x 16 LDL' — with ONE DRAW PER WAVEFRONT: the state lives in the accumulator tiles of v_mfma_f64_16x16x4_f64 (lower tiles in registers, "
+             "transposed LDS copies as the upper ones), 84 matrix instructions (64 cycles each) + ~500 vector instructions per window and draw at three "
+             "block columns, two wavefronts per SIMD; the window's own covariance block comes from a pre-pass kernel (tile_pairs_kernel: pair table in "
+             "registers, coefficients as scalar operands), whose time is inside kernel_ms.  The fp64 matrix instructions run on the DP vector pipe "
+             "(profiles/r02_mfma_probe.txt): peak = 78.6 TFLOP/s either way; `achieved` counts the ALGORITHMIC flops of the reference's recurrence "
+             "(5.5 R^2 + 18 R per step), the windowed form executes fewer (4 R'^2 per step on the padded R' = 48 rows + the window's 16 x 16 work).  "
+             "measured_fma_ceiling_tflops: a pure v_fma_f64 stream at two wavefronts per SIMD on this box, timed right after the loop.  "
+             "`secondary.tile_kernel_windowed_one_draw_per_wavefront` has the same-box A/B against the step-by-step layout (no_tile).")
 
 
 def algorithmic_flops(N: int, R: int) -> float:
@@ -309,7 +321,8 @@ def main():
     achieved = algorithmic_flops(N, R) * B / (kern_ms * 1e-3) / 1e12
     achieved_ref_rows = algorithmic_flops(N, 2 * Jt) * B / (kern_ms * 1e-3) / 1e12
 
-    kernel_config = pj._lib.lib().pioran_celerite_config_name(0).decode()   # what the last launch ran on
+    kernel_family = pj._lib.lib().pioran_celerite_config_name(-1).decode()  # "scan" (step-by-step throughput layouts) or "tile" (windowed form, one draw per wavefront)
+    kernel_config = pj._lib.lib().pioran_celerite_config_name(0).decode() if kernel_family.startswith("scan") else kernel_family   # what the last launch ran on
     traffic, traffic_src = pmc_traffic(args.basis, J, B, N, kernel_config)
     # what a pure stream of independent v_fma_f64 reaches on THIS box right now at the headline kernel's occupancy (two wavefronts per
     # SIMD), measured straight after the timed loop while the chip is warm: the ceiling of any FP64 vector kernel here (the vendor peak
@@ -334,14 +347,16 @@ def main():
                    "kernel_config": kernel_config,
                    "parallelism": f"batch-sharded x{world}, all-gather of logL"
                                   + (f" ({args.dist_backend}, rank devices: cuda:{local_rank})" if use_dist else "")},
-        "roofline": {"bound": "valu-fp64", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "roofline": {"bound": "valu-fp64" if kernel_family.startswith("scan") else "mfma-fp64 (+ valu-fp64: one DP pipe)", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "measured_fma_ceiling_tflops": fma_ceiling,
                      "frac_of_measured_fma_ceiling": (achieved / fma_ceiling) if fma_ceiling else None,
-                     "kernel": "celerite_scan_kernel", "kernel_ms": kern_ms, "scan_source_hash": scan_source_hash(),
+                     "kernel": "celerite_scan_kernel" if kernel_family.startswith("scan") else "celerite_tile_kernel (+ tile_pairs_kernel, its pre-pass: both inside kernel_ms)",
+                     "kernel_family": kernel_family, "kernel_ms": kern_ms, "scan_source_hash": scan_source_hash(),
                      "algorithmic_flop_per_eval": algorithmic_flops(N, R), "rows_executed": R, "rows_reference": 2 * Jt,
                      "frac_on_reference_rows": achieved_ref_rows / FP64_PEAK_TFLOPS,
-                     "note": "FP64 vector-ALU bound (per draw: two matrix-vector products and a rank-2 update of the R x R state per "
+                     "note": NOTE_TILE if not kernel_family.startswith("scan") else
+                             "FP64 vector-ALU bound (per draw: two matrix-vector products and a rank-2 update of the R x R state per "
                              "pair of time steps; not HBM). peak = MI355X FP64 vector peak (at 2.4 GHz) = the dense FP64 MFMA peak: "
                              "on gfx950 the fp64 matrix instructions run on the DP vector pipe (tools/mfma_probe.hip, "
                              "profiles/r02_mfma_probe.txt), so there is no second pipe to overlap with. Budget (DESIGN.md 4.1; "
@@ -477,7 +492,8 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record(stream); go(); e1.record(stream); e1.synchronize()
             ms.append(e0.elapsed_time(e1))
-        cfg = pj._lib.lib().pioran_celerite_config_name(0).decode()
+        fam = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+        cfg = pj._lib.lib().pioran_celerite_config_name(0).decode() if fam.startswith("scan") else fam
         return med(ms), A, Bc, C, Dd, int(2 * len(C) - real.sum()), do.cpu().numpy(), dsx.cpu().numpy(), cfg, (tt, yy, ee)
 
     # -- the other basis at the headline size (BASELINE's configs name DRWCelerite-20; SURVEY 8 note A) -------------
@@ -548,6 +564,47 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
         sizes[f"B{nb}"] = row
     ds5.close()
     out["batch_sizes_between_passes"] = sizes
+
+    # -- round 5: the windowed form with one draw per wavefront (celerite_tile.hip: the state in v_mfma_f64_16x16x4_f64 accumulator tiles, a
+    #    pre-pass kernel for the windows' own covariance blocks).  Default from 49 rows on and between the passes of the step-by-step layouts;
+    #    here forced ("scan_config" = "tile") beside the automatic choice with it switched off ("no_tile"), same resident inputs, event-timed.
+    tile = {}
+    for label, basis, ncomp in (("sho20_rows40_A_B_at_the_headline", "SHO", J), ("drwcelerite20_rows60", "DRWCelerite", J), ("sho40_rows80", "SHO", 2 * J)):
+        At, Bt, Ct, Dt = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:B, :3], f_min, f_max, ncomp, theta[:B, 3], basis_function=basis)
+        realt = (Dt == 0.0) & (Bt == 0.0).all(axis=0)
+        Rt = int(2 * len(Ct) - realt.sum())
+        dst_ = pj.Dataset(t, y, s2, ctx); dst_.prepare(Ct, Dt, realt.astype(np.int32))
+        dt_ = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (At, Bt, mu[:B].copy(), nu[:B].copy())]
+        ot = torch.empty(B, dtype=torch.float64, device=dev); stt = torch.zeros(B, dtype=torch.int32, device=dev)
+        got_ = lambda: dst_.logl_batch_dev(B, dt_[0].data_ptr(), dt_[1].data_ptr(), dt_[2].data_ptr(), dt_[3].data_ptr(), 0, 0, ot.data_ptr(), stt.data_ptr())
+        row = {"rows_executed": Rt}
+        vals = {}
+        for key, opt in (("tile", ("scan_config", "tile")), ("step_by_step", ("no_tile", True))):
+            ctx.set_option(*opt)
+            got_(); torch.cuda.synchronize(dev)
+            mst = []
+            for _ in range(5):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream); got_(); e1.record(stream); e1.synchronize(); mst.append(e0.elapsed_time(e1))
+            fam = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+            row[key] = {"ms": med(mst), "evals_per_s": B / (med(mst) * 1e-3), "kernel": fam if not fam.startswith("scan") else pj._lib.lib().pioran_celerite_config_name(0).decode(),
+                        "roofline_frac": algorithmic_flops(N, Rt) * B / (med(mst) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+            vals[key] = (ot.cpu().numpy().copy(), stt.cpu().numpy().copy())
+            ctx.set_option("scan_config", None); ctx.set_option("no_tile", False)
+        St = min(B, 48)
+        reft, rstt = O.logl_batch(At[:St], Bt[:St], Ct, Dt, t, y, s2, mu[:St], nu[:St], nthreads=min(32, os.cpu_count() or 1), return_status=True)
+        okt = (rstt == 0) & (vals["tile"][1][:St] == 0)
+        row["tile"]["max_rel_dlogl_vs_oracle"] = float((np.abs(vals["tile"][0][:St][okt] - reft[okt]) / np.abs(reft[okt])).max()) if okt.any() else None
+        both = (vals["tile"][1] == 0) & (vals["step_by_step"][1] == 0)
+        row["max_rel_between_the_two_families"] = float((np.abs(vals["tile"][0][both] - vals["step_by_step"][0][both]) / np.abs(vals["tile"][0][both])).max())
+        row["speedup"] = row["step_by_step"]["ms"] / row["tile"]["ms"]
+        tile[label] = row
+        dst_.close()
+    tile["kernel"] = ("celerite_tile_kernel<NB> + tile_pairs_kernel (celerite_tile.hip): windowed form, 16 steps per window, ONE draw per wavefront: T as NB x NB "
+                      "accumulator tiles of v_mfma_f64_16x16x4_f64 (lower tiles in registers, transposed LDS copies as the upper ones), 84 / 136 / 276 matrix "
+                      "instructions per window at 3 / 4 / 6 block columns against ~700 / ~1300 / ~4500 SIMD cycles per STEP of the step-by-step layouts; "
+                      "ms includes the pre-pass")
+    out["tile_kernel_windowed_one_draw_per_wavefront"] = tile
 
     # -- single evaluation: configs[0] (N = 1e3) and configs[1] (N = 1e4), B = 1 -------------------------------------
     single = {}

@@ -377,8 +377,8 @@ int tile_dispatch(pioran_ds* ds, const ScanParams& p)
     // step-by-step layouts at every batch size above the small-batch windowed kernel's range — DRWCelerite-20 (60 rows) 1024 draws 6.3
     // against 7.8 ms, 4096 draws 17.5 against 25.1 ms; SHO-40 (80 rows) 512 draws 10.0 against 13.1 ms, 4096 draws 41.3 against 75.3 ms.
     // Up to 48 rows the throughput layouts (two draws per wavefront) are level with it (SHO-20: 11.2 against 11.4 ms) and stay the default.
-    // Up to 48 rows the throughput layouts (two and four draws per wavefront) are level with it on whole passes (SHO-20, 4096 draws: 11.2
-    // against 11.5 ms) and ahead of it below 33 rows (SHO-16, 4096 draws: 5.8 against 10.7 ms) — but their time is a staircase of passes
+    // Up to 38 rows (and at 48) the throughput layouts (two and four draws per wavefront) are level with it or ahead on whole passes (SHO-24, 4096
+    // draws: 16.5 against 16.9 ms), well ahead of it below 33 rows (SHO-16, 4096 draws: 5.8 against 10.7 ms) — but their time is a staircase of passes
     // (SHO-20: 4096 draws), and this kernel's steps are a quarter of that (1024 draws: one workgroup per CU): it takes what falls between
     // (profiles/r05_tile_batch_sweep.txt: SHO-20 1024 draws 3.96 against 5.31 ms, 3072 draws 9.3 against 11.0, 5000 draws 14.8 against 16.7;
     // SHO-12 / SHO-16 / SHO-24 at 1024 draws 2.9 / 3.9 / 6.2 against 4.2 / 5.6 / 8.2 ms).
@@ -388,6 +388,8 @@ int tile_dispatch(pioran_ds* ds, const ScanParams& p)
         else if (p.R < 17 || p.B <= 512) automatic = false;
         else if (p.B <= 1024) automatic = true;
         else if (p.R < 33) automatic = false;
+        else if (p.R >= 39 && p.R <= 47) automatic = true;   // three block columns cost the same for 33 .. 47 rows, the step-by-step layouts ~R^2: from 39
+                                                             // rows on this kernel is ahead on whole passes too (SHO-20, 4096 draws: 10.7 against 11.4 .. 12.0 ms)
         else {
             const int64_t pass = pioran_scan_pass_draws(p, nullptr);
             const int64_t r = pass > 0 ? p.B % pass : 0;

@@ -98,6 +98,34 @@ __global__ void __launch_bounds__(128) tile_pairs_kernel(const ScanParams p, con
         if (b0 + i < p.B) out[((b0 + i) * NW + k) * 128 + pp] = acc0[i] + acc1[i];
 }
 
+// The same with the pair table in REGISTERS and the coefficients as scalar operands (wave-uniform loads straight from A / Bc: no LDS, two FMAs per
+// term, draw and pair and nothing else): JC = number of terms, compile-time (the launch picks 20 / 40 — the approx models of the benchmark — and
+// falls back to the kernel above).  Workgroup (k, chunk of DCR draws) of two wavefronts.
+constexpr int kPairDrawsReg = 64;
+template <int JC>
+__global__ void __launch_bounds__(128) tile_pairs_reg_kernel(const ScanParams p, const double* __restrict__ btab, int64_t rsb, int64_t tsp, double* __restrict__ out)
+{
+    const int64_t NW = (p.N + KW - 1) / KW;
+    const int64_t k = blockIdx.x, b0 = (int64_t)blockIdx.y * kPairDrawsReg;
+    const int pp = threadIdx.x;
+    const double2* E = reinterpret_cast<const double2*>(btab + k * rsb + tsp) + pp;
+    double2 e[JC];
+#pragma unroll
+    for (int t = 0; t < JC; ++t) e[t] = E[t * 128];
+    const int64_t nb = p.B - b0 < kPairDrawsReg ? p.B - b0 : kPairDrawsReg;
+    for (int64_t i = 0; i < nb; ++i) {
+        const double* __restrict__ ar = p.A + (b0 + i) * JC;      // (uniform addresses: scalar loads)
+        const double* __restrict__ br = p.Bc + (b0 + i) * JC;
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < JC; ++t) {
+            acc0 = fma(ar[t], e[t].x, acc0);
+            acc1 = fma(br[t], e[t].y, acc1);
+        }
+        out[((b0 + i) * NW + k) * 128 + pp] = acc0 + acc1;
+    }
+}
+
 template <int NB>
 __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_tile_kernel(const ScanParams p, const double* __restrict__ btab,
                                                                                           const double* __restrict__ pairs)
@@ -385,6 +413,10 @@ int launch_tile(const ScanParams& p, const double* btab, double* pairs, hipStrea
     if (groups > 0x7fffffffLL) return PIORAN_ERR_UNSUPPORTED;
     const int64_t NW = (p.N + KW - 1) / KW;
     if (NW > 0x7fffffffLL || (p.B + kPairDraws - 1) / kPairDraws > 65535) return PIORAN_ERR_UNSUPPORTED;
+    const dim3 gr((unsigned)NW, (unsigned)((p.B + kPairDrawsReg - 1) / kPairDrawsReg));
+    if (p.J == 20) hipLaunchKernelGGL(tile_pairs_reg_kernel<20>, gr, dim3(128), 0, stream, p, btab, block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs);
+    else if (p.J == 40) hipLaunchKernelGGL(tile_pairs_reg_kernel<40>, gr, dim3(128), 0, stream, p, btab, block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs);
+    else
     hipLaunchKernelGGL(tile_pairs_kernel, dim3((unsigned)NW, (unsigned)((p.B + kPairDraws - 1) / kPairDraws)), dim3(128), 0, stream, p, btab,
                        block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs);
     hipLaunchKernelGGL((celerite_tile_kernel<NB>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds, stream, p, btab, (const double*)pairs);

@@ -102,11 +102,18 @@ def test_config3_full_batch(ctx, full_size, basis):
     assert relerr(got[ok], ref[ok]) < 1e-8, basis
     assert np.array_equal(st != 0, rst != 0)
     kern = pj._lib.lib().pioran_celerite_config_name(-1).decode()
-    if basis == "SHO":
+    assert kern == "tile", kern           # 40 / 60 active rows: the windowed form with one draw per wavefront (celerite_tile.hip, round 5)
+    # ... and the step-by-step throughput layouts (the default up to round 4; "no_tile") on the same batch: the same values to rounding
+    ctx.set_option("no_tile", True)
+    try:
+        dout2 = torch.empty(B, dtype=torch.float64, device=dev)
+        ds.logl_batch_dev(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, 0, dout2.data_ptr(), 0)
+        ctx.synchronize()
         cfg = pj._lib.lib().pioran_celerite_config_name(0).decode()
-        assert kern == "scan" and cfg.startswith("rpl"), (kern, cfg)     # a register-resident throughput configuration ran, not the fallback
-    else:
-        assert kern == "tile", kern       # 60 active rows: the windowed form with one draw per wavefront (celerite_tile.hip, round 5)
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "scan" and cfg.startswith("rpl"), cfg
+    finally:
+        ctx.set_option("no_tile", False)
+    assert relerr(dout2.cpu().numpy()[ok], ref[ok]) < 1e-8, basis
     # the host-pointer entry gives the same bits for the same batch
     host = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
     assert np.array_equal(host[ok], got[ok])

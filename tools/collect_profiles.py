@@ -11,7 +11,7 @@ root = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(root))
 import bench  # noqa: E402  (scan_source_hash)
 
-ROUND = sys.argv[2] if len(sys.argv) > 2 else "r04"
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "r05"
 src = Path(sys.argv[1]) if len(sys.argv) > 1 else root / "gpurun_out" / ROUND
 prof = root / "profiles"
 for tag, basis in (("sho", "SHO"), ("drwcelerite", "DRWCelerite")):
@@ -24,13 +24,19 @@ for tag, basis in (("sho", "SHO"), ("drwcelerite", "DRWCelerite")):
     (prof / f"{ROUND}_bench_{tag}20_b4096.json").write_text(json.dumps(plain, indent=1))
     traced = json.loads([ln for ln in (src / f"bench_trace_{tag}.json").read_text().splitlines() if ln.startswith("{")][-1])
     rows = list(csv.DictReader(open(ks)))
-    krow = [r for r in rows if "celerite_scan_kernel" in r["Name"]][0]
+    # the headline's main kernel: the step-by-step scan or (round 5) the windowed tile kernel — whichever carries the time; the tile kernel's
+    # pre-pass (tile_pairs*_kernel) is reported beside it
+    krow = max((r for r in rows if "celerite_scan_kernel" in r["Name"] or "celerite_tile_kernel" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
+    pre = [r for r in rows if "tile_pairs" in r["Name"]]
+    kmatch = "celerite_tile_kernel" if "celerite_tile_kernel" in krow["Name"] else "celerite_scan_kernel"
     out = {"command": f"rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary --basis {basis} "
                       "--steps 2 --warmup 1   (one pass per counter group: FETCH_SIZE | WRITE_SIZE | SQ_* | GRBM_*; tools/run_profiles.sh)",
            "kernel": krow["Name"], "kernel_config": plain["config"]["kernel_config"], "scan_source_hash": bench.scan_source_hash(),
            "workload": plain["config"]["workload"],
            "kernel_trace": {"calls": int(krow["Calls"]), "average_ms": float(krow["AverageNs"]) / 1e6, "min_ms": float(krow["MinNs"]) / 1e6,
-                            "bench_kernel_ms_same_run": traced["roofline"]["kernel_ms"], "bench_kernel_ms_unprofiled_run": plain["roofline"]["kernel_ms"]},
+                            "pre_pass": ({"kernel": pre[0]["Name"], "average_ms": float(pre[0]["AverageNs"]) / 1e6} if pre and kmatch == "celerite_tile_kernel" else None),
+                            "bench_kernel_ms_same_run": traced["roofline"]["kernel_ms"], "bench_kernel_ms_unprofiled_run": plain["roofline"]["kernel_ms"],
+                            "same_box_fp64_fma_ceiling_tflops": plain["roofline"].get("measured_fma_ceiling_tflops")},
            "per_dispatch": {}}
     for d in sorted(glob.glob(str(src / f"pmc_{tag}_*"))):
         if d.endswith(".err"):
@@ -38,7 +44,7 @@ for tag, basis in (("sho", "SHO"), ("drwcelerite", "DRWCelerite")):
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             agg = {}
             for r in csv.DictReader(open(f)):
-                if "celerite_scan_kernel" in r["Kernel_Name"]:
+                if kmatch in r["Kernel_Name"]:
                     assert r["Kernel_Name"] == krow["Name"], (r["Kernel_Name"], krow["Name"])
                     agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             for k, v in agg.items():
@@ -54,6 +60,8 @@ for tag, basis in (("sho", "SHO"), ("drwcelerite", "DRWCelerite")):
         "valu_active_share_of_wave_cycles": pd["SQ_ACTIVE_INST_VALU"] / pd["SQ_WAVE_CYCLES"],
         "waitcnt_share_of_wave_cycles": pd.get("SQ_WAIT_ANY", float("nan")) / pd["SQ_WAVE_CYCLES"],
         "issue_wait_share_of_wave_cycles": pd.get("SQ_WAIT_INST_ANY", float("nan")) / pd["SQ_WAVE_CYCLES"],
+        "mfma_f64_insts_per_wave_window": (pd["SQ_INSTS_MFMA"] / pd["SQ_WAVES"] / ((N + 15) // 16)) if "SQ_INSTS_MFMA" in pd else None,
+        "mfma_busy_share_of_busy_cycles": (pd["SQ_VALU_MFMA_BUSY_CYCLES"] / pd["SQ_BUSY_CYCLES"]) if ("SQ_VALU_MFMA_BUSY_CYCLES" in pd and pd.get("SQ_BUSY_CYCLES")) else None,
         "note": "FETCH_SIZE / WRITE_SIZE in KB; x2 on the fetch is the gfx950 correction of MI355X_MICROARCH.md (calibrated on 16 B/lane streams; these "
                 "are 8 B/lane buffer loads of an L2-resident table, so the corrected figure is an upper bound).  Median over the dispatches of the pass."}
     (prof / f"{ROUND}_pmc_{tag}20_b4096.json").write_text(json.dumps(out, indent=1))
