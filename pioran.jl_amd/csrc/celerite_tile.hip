@@ -39,6 +39,15 @@ namespace {
 constexpr int kTileMaxTerms = 64;
 constexpr int kTileWaves = 4;      // wavefronts (= draws) per workgroup
 
+typedef unsigned int tile_u32x2 __attribute__((ext_vector_type(2)));
+// 8 bytes through a buffer resource: per-lane byte offset in a VGPR (constant over the kernel), everything that moves (window, block, register
+// of the fragment) in the scalar offset — no vector address arithmetic in the window loop
+__device__ __forceinline__ double tile_bload(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    const tile_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+
 template <int NB>
 struct TileWave {                  // LDS of one wavefront
     double scr[16 * 18];           // in turn: a block of M' for the transposing read-back; Sigma [j][n]; D_k (L^-1)_ik at [k * 18 + i]
@@ -142,6 +151,11 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
     const int64_t NW = (N + KW - 1) / KW;
     const int64_t RSB = TSP + 256 * (int64_t)J;
     TileWave<NB>& sw = reinterpret_cast<TileWave<NB>*>(lds_)[w];
+    // the table (at most 2 GB: capi.hip ensure_btab) and this draw's slice of the pre-pass workspace as buffer resources
+    const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(btab), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_pw = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pairs + b * NW * 128), 0, 0x7ffffffc, 0x00020000);
+    const int lane8 = lane * 8;
+    const int rsb8 = (int)(RSB * 8);
     const int Jy = R >> 4, ry = R & 15;            // block column / lane column of the y row
     const double mu = p.mu ? p.mu[b] : 0.0;
     const double nu = p.nu ? p.nu[b] : 1.0;
@@ -177,12 +191,11 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
     // row block at a time: the reads of block I + 1 are on their way while block column I of T is updated
     double cvn[4], cxn[4];
     auto fetch_u = [&](int64_t k, int I) __attribute__((always_inline)) {
-        const double* tl = btab + k * RSB;
+        const int so = (int)k * rsb8;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int f = (I * 4 + ks) * 64 + lane;
-            cvn[ks] = tl[f];
-            cxn[ks] = tl[NB * 256 + f];
+            cvn[ks] = tile_bload(rs_tab, lane8, so + (I * 4 + ks) * 512);
+            cxn[ks] = tile_bload(rs_tab, lane8, so + (NB * 256 + (I * 4 + ks) * 64) * 8);
         }
     };
     auto form_u = [&](int I) __attribute__((always_inline)) {
@@ -196,9 +209,9 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
     constexpr int NCK = (16 * NB + 16 + 63) / 64;
     double ckpre[NCK];
     auto fetch_ck = [&](int64_t k) __attribute__((always_inline)) {
-        const double* tl = btab + k * RSB + 3 * NB * 256;
+        const int so = (int)k * rsb8 + 3 * NB * 256 * 8;
 #pragma unroll
-        for (int i = 0; i < NCK; ++i) ckpre[i] = tl[(lane + 64 * i) < 16 * NB + 16 ? lane + 64 * i : 0];
+        for (int i = 0; i < NCK; ++i) ckpre[i] = tile_bload(rs_tab, lane8, so + 512 * i);   // (past 16 NB + 16 doubles: padding / the pair table, not used)
     };
     // A of window k, C/D order (row 4 g + q, column c16): the off-diagonal entries from the workspace of tile_pairs_kernel (pair p =
     // nn (nn - 1) / 2 + jj, jj < nn), fetched one window ahead; the diagonal sum(a) + nu sigma2_n here (:92)
@@ -206,15 +219,14 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int r = 4 * g + q, hi = r > c16 ? r : c16, lo = r > c16 ? c16 : r;
-        pidx[g] = r == c16 ? 127 : hi * (hi - 1) / 2 + lo;      // (127: a padding entry of the record, never used)
+        pidx[g] = 8 * (r == c16 ? 127 : hi * (hi - 1) / 2 + lo);      // byte offset (127: a padding entry of the record, never used)
     }
     const int gd = (c16 - q) >> 2;                               // the register that holds this lane's diagonal entry, if (c16 - q) % 4 == 0
     const bool on_diag = ((c16 - q) & 3) == 0;
-    const double* __restrict__ pw = pairs + b * NW * 128;
     double apre[4];
     auto fetch_A = [&](int64_t k) __attribute__((always_inline)) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) apre[g] = pw[k * 128 + pidx[g]];
+        for (int g = 0; g < 4; ++g) apre[g] = tile_bload(rs_pw, pidx[g], (int)k * 1024);
     };
     fetch_A(0);
     fetch_ck(0);
@@ -223,6 +235,11 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
         fetch_u(0, I);
         form_u(I);
     }
+    // the y row's column of X': v = y_n - mu in the lane column ry of block Jy (z_n = y_n - u'f, :141); elsewhere mu_sel = 0
+    double mu_sel[NB];
+#pragma unroll
+    for (int Jc = 0; Jc < NB; ++Jc) mu_sel[Jc] = (Jc == Jy && c16 == ry) ? mu : 0.0;
+    const int64_t k_ragged = (N % KW) ? NW - 1 : NW;   // the window whose steps past N are padding (none if N is a multiple of 16)
     double quad = 0.0;                 // meaningful in the y-row lanes
     double Pm = 1.0;                   // per lane (step c16 of every window): running product of |D| (sign of D_1 kept: :126)
     int Pe = 0;
@@ -231,7 +248,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
     PIORAN_TSTAMP_DECL
     for (int64_t k = 0; k < NW; ++k) {
         PIORAN_TSTAMP(0);
-        const double* tl = btab + k * RSB;
+        const int wso = (int)k * rsb8;
         const bool more = k + 1 < NW;
 #pragma unroll
         for (int i = 0; i < NCK; ++i)
@@ -262,7 +279,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
         d4 G = {0.0, 0.0, 0.0, 0.0};
         double vh[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) vh[g] = tl[2 * NB * 256 + g * 64 + lane];
+        for (int g = 0; g < 4; ++g) vh[g] = tile_bload(rs_tab, lane8, wso + (2 * NB * 256 + g * 64) * 8);
 #pragma unroll
         for (int Jc = 0; Jc < NB; ++Jc) {
 #pragma unroll
@@ -277,14 +294,14 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
             for (int ks = 0; ks < 4; ++ks) G = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[Jc][ks], mb[ks], G, 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                double v = vh[g];
-                if (Jc == Jy && c16 == ry) v = k * KW + 4 * g + q < N ? v - mu : 0.0;   // z_n = y_n - u'f   :141
+                double v = vh[g] - mu_sel[Jc];
+                if (k == k_ragged && k * KW + 4 * g + q >= N) v = 0.0;     // (wave-uniform test first: only the last, ragged window pays for the mask)
                 x[Jc][g] = fma(-ckc, x[Jc][g], v);
                 asm volatile("" : "+v"(x[Jc][g]));   // formed HERE: left to itself the compiler sinks these FMAs below the LDL' and keeps (C_K / C) o v live across it
             }
             if (Jc + 1 < NB) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) vh[g] = tl[2 * NB * 256 + ((Jc + 1) * 4 + g) * 64 + lane];
+                for (int g = 0; g < 4; ++g) vh[g] = tile_bload(rs_tab, lane8, wso + (2 * NB * 256 + ((Jc + 1) * 4 + g) * 64) * 8);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
