@@ -79,3 +79,30 @@ def test_product_never_imports_oracle():
     for f in list(pkg.glob("*.py")) + list((pkg / "csrc").glob("*")):
         txt = f.read_text(errors="ignore")
         assert "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_shipped_library_is_what_build_py_makes(tmp_path):
+    """The library in the tree is newer than every source it is built from, its objects are the ones build.py links, and a fresh compile
+    of one small source with build.py's own flags reproduces the shipped object's size (round 4 shipped a library linked from an object
+    that a diagnostic tool had overwritten: same source and flags, but nothing checked it)."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("_pioran_build_chk", ROOT / "pioran.jl_amd" / "build.py")
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    lib_m = b.LIB.stat().st_mtime
+    deps = [b.CSRC / s for s in b.SOURCES] + list(b.HEADERS)
+    stale = [d.name for d in deps if d.stat().st_mtime > lib_m]
+    assert not stale, f"libpioran_hip.so is older than {stale}: run python pioran.jl_amd/build.py"
+    for s in b.SOURCES:
+        obj = b.OBJ / (Path(s).stem + ".o")
+        assert obj.exists() and obj.stat().st_mtime <= lib_m + 1.0, obj
+        assert obj.stat().st_mtime >= (b.CSRC / s).stat().st_mtime, f"{obj.name} is older than its source"
+    assert "celerite_tile.hip" in b.SOURCES and b"celerite_tile_kernel" in b.LIB.read_bytes()
+    small = "celerite_fallback.hip"
+    fresh = tmp_path / "fresh.o"
+    subprocess.run([b.hipcc(), *b.FLAGS, "-c", str(b.CSRC / small), "-o", str(fresh)], check=True)
+    assert fresh.stat().st_size == (b.OBJ / "celerite_fallback.o").stat().st_size
+    # no experiment code in the product: the persistent dense chain and the two-wavefront scan shape need -DPIORAN_EXPERIMENTS
+    data = b.LIB.read_bytes()
+    assert b"dense_crit_chain_kernel" not in data and b"rpl5_cbr4_nsrc2_w2" not in data

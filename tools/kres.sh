@@ -5,9 +5,9 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 f=$1; stem=$(basename "$f" .hip); filt=${2:-.}
 mkdir -p /tmp/kres && cd /tmp/kres
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -c "$ROOT/pioran.jl_amd/csrc/$stem.hip" -o "$ROOT/pioran.jl_amd/_obj/$stem.o" -save-temps=obj 2>&1 | grep -v "^$" || true
-mv -f "$ROOT"/pioran.jl_amd/_obj/$stem-hip-amdgcn-amd-amdhsa-gfx950.s /tmp/kres/$stem.s
-rm -f "$ROOT"/pioran.jl_amd/_obj/$stem-h* "$ROOT"/pioran.jl_amd/_obj/$stem.hip-*
+# everything under /tmp/kres: the product's objects (pioran.jl_amd/_obj, what libpioran_hip.so is linked from) are never touched by this tool
+# (up to round 4 it compiled INTO _obj with -save-temps, and the shipped library was linked from that object)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -S --cuda-device-only "$ROOT/pioran.jl_amd/csrc/$stem.hip" -o /tmp/kres/$stem.s 2>&1 | grep -v "^$" || true
 python3 - "$stem" "$filt" <<'PY'
 import re, sys, subprocess
 stem, filt = sys.argv[1], sys.argv[2]
