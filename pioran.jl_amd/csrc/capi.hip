@@ -382,7 +382,7 @@ int tile_dispatch(pioran_ds* ds, const ScanParams& p)
     // (SHO-20: 4096 draws), and this kernel's steps are a quarter of that (1024 draws: one workgroup per CU): it takes what falls between
     // (profiles/r05_tile_batch_sweep.txt: SHO-20 1024 draws 3.96 against 5.31 ms, 3072 draws 9.3 against 11.0, 5000 draws 14.8 against 16.7;
     // SHO-12 / SHO-16 / SHO-24 at 1024 draws 2.9 / 3.9 / 6.2 against 4.2 / 5.6 / 8.2 ms).
-    bool automatic = !o.scan_config[0] && !o.no_tile && !o.no_block && p.tab && p.npd_rows == 0 && !p.Y && !p.S2;
+    bool automatic = !o.scan_config[0] && !o.no_tile && !o.no_block && p.tab && p.npd_rows == 0;
     if (automatic) {
         if (p.R >= 49) automatic = p.B > (p.R > pioran_block_supported_rows() ? 256 : 512);
         else if (p.R < 17 || p.B <= 512) automatic = false;
@@ -398,7 +398,7 @@ int tile_dispatch(pioran_ds* ds, const ScanParams& p)
             automatic = pass > 0 && r > 0 && 4 * r <= 3 * pass && !split;
         }
     }
-    if (!(force || automatic) || !p.tab || p.npd_rows != 0 || p.Y || p.S2 || !pioran_tile_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    if (!(force || automatic) || !p.tab || p.npd_rows != 0 || !pioran_tile_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
     PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
     if (!s || !s->prepared || s->npd_terms != 0 || p.rec_stride != 3 * (int64_t)(s->R + 2) + 2) return PIORAN_ERR_UNSUPPORTED;
     int rc = ensure_btab(ds, *s);

@@ -23,7 +23,8 @@
 // (a, b)) does not depend on the state: tile_pairs_kernel forms it for every (draw, window) of the launch beforehand — E in
 // registers, 32 draws per workgroup — into a workspace of 1 KB per draw and window that the factorisation reads one window ahead
 // (first version: the contraction inside the window loop, 40 .. 80 dependent reads of E from L2 per window: a third of the time).
-// Restrictions: shared (c, d) without per-draw rows, shared series (y, sigma2); 1 .. 95 active rows.  Everything else stays on the other kernels.
+// Restrictions: shared (c, d) without per-draw rows; 1 .. 95 active rows; the series shared or per draw (Y, S2: the shifted log-flux models).
+// Everything else stays on the other kernels.
 #include "common.h"
 #include "window_common.h"
 
@@ -53,6 +54,7 @@ struct TileWave {                  // LDS of one wavefront
     double scr[16 * 18];           // in turn: a block of M' for the transposing read-back; Sigma [j][n]; D_k (L^-1)_ik at [k * 18 + i]
     double2 albe[16 * NB];         // per row: u = al v + be x (:59-63)
     double ck[16 * NB + 16];       // the window's C_K per row, then sigma2 per step (staged from the record: read again and again by the update)
+    double ys[16];                 // per-draw series (p.Y: the shifted log-flux models, docs/src/ultranest.md:199-205): y_n of the window's steps
     double up[NB > 1 ? NB * (NB - 1) / 2 : 1][16 * 18];   // the strictly lower tiles of T once more, [row][column, stride 18]: read back transposed
                                                           // they are the upper tiles as B operands
 };
@@ -108,8 +110,8 @@ __global__ void __launch_bounds__(128) tile_pairs_kernel(const ScanParams p, con
 }
 
 // The same with the pair table in REGISTERS and the coefficients as scalar operands (wave-uniform loads straight from A / Bc: no LDS, two FMAs per
-// term, draw and pair and nothing else): JC = number of terms, compile-time (the launch picks 20 / 40 — the approx models of the benchmark — and
-// falls back to the kernel above).  Workgroup (k, chunk of DCR draws) of two wavefronts.
+// term, draw and pair and nothing else): JC = number of terms, compile-time (the launch picks it for 20 terms — the approx model of the benchmark —
+// and falls back to the kernel above).  Workgroup (k, chunk of DCR draws) of two wavefronts.
 constexpr int kPairDrawsReg = 64;
 template <int JC>
 __global__ void __launch_bounds__(128) tile_pairs_reg_kernel(const ScanParams p, const double* __restrict__ btab, int64_t rsb, int64_t tsp, double* __restrict__ out)
@@ -228,8 +230,20 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
 #pragma unroll
         for (int g = 0; g < 4; ++g) apre[g] = tile_bload(rs_pw, pidx[g], (int)k * 1024);
     };
+    // per-draw series (y, sigma2) [B][N]: lanes 0 .. 15 fetch the window's sixteen steps a window ahead (clamped past the end: those steps are masked)
+    const bool has_series = p.Y != nullptr;
+    double ypre = 0.0, spre = 0.0;
+    auto fetch_series = [&](int64_t k) __attribute__((always_inline)) {
+        if (has_series) {
+            int64_t n = k * KW + c16;
+            n = n < N ? n : N - 1;
+            ypre = p.Y[b * N + n];
+            spre = p.S2[b * N + n];
+        }
+    };
     fetch_A(0);
     fetch_ck(0);
+    fetch_series(0);
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
         fetch_u(0, I);
@@ -253,7 +267,11 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
 #pragma unroll
         for (int i = 0; i < NCK; ++i)
             if (lane + 64 * i < 16 * NB + 16) sw.ck[lane + 64 * i] = ckpre[i];
-        if (more) fetch_ck(k + 1);
+        if (has_series) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < 16) { sw.ys[lane] = ypre; sw.ck[16 * NB + lane] = spre; }
+        }
+        if (more) { fetch_ck(k + 1); fetch_series(k + 1); }
         // ---- M' = U~' T: the lower tiles from registers, the upper ones as transposed reads of their LDS copies -------------------
         d4 x[NB];
 #pragma unroll
@@ -294,7 +312,9 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
             for (int ks = 0; ks < 4; ++ks) G = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[Jc][ks], mb[ks], G, 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                double v = vh[g] - mu_sel[Jc];
+                double v = vh[g];
+                if (has_series && Jc == Jy && c16 == ry) v = sw.ys[4 * g + q];     // (the table's y row holds the shared series)
+                v -= mu_sel[Jc];
                 if (k == k_ragged && k * KW + 4 * g + q >= N) v = 0.0;     // (wave-uniform test first: only the last, ragged window pays for the mask)
                 x[Jc][g] = fma(-ckc, x[Jc][g], v);
                 asm volatile("" : "+v"(x[Jc][g]));   // formed HERE: left to itself the compiler sinks these FMAs below the LDL' and keeps (C_K / C) o v live across it
@@ -431,8 +451,9 @@ int launch_tile(const ScanParams& p, const double* btab, double* pairs, hipStrea
     const int64_t NW = (p.N + KW - 1) / KW;
     if (NW > 0x7fffffffLL || (p.B + kPairDraws - 1) / kPairDraws > 65535) return PIORAN_ERR_UNSUPPORTED;
     const dim3 gr((unsigned)NW, (unsigned)((p.B + kPairDrawsReg - 1) / kPairDrawsReg));
+    // (measured, profiles/r05_*kernel_stats.csv: 20 terms 0.93 ms per 4096 draws at N = 1e4 against 1.11 ms on the LDS form; with 40 terms the 160
+    //  registers of table entries cost it its occupancy — 2.76 against 1.96 ms — so that count stays on the LDS form)
     if (p.J == 20) hipLaunchKernelGGL(tile_pairs_reg_kernel<20>, gr, dim3(128), 0, stream, p, btab, block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs);
-    else if (p.J == 40) hipLaunchKernelGGL(tile_pairs_reg_kernel<40>, gr, dim3(128), 0, stream, p, btab, block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs);
     else
     hipLaunchKernelGGL(tile_pairs_kernel, dim3((unsigned)NW, (unsigned)((p.B + kPairDraws - 1) / kPairDraws)), dim3(128), 0, stream, p, btab,
                        block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs);
@@ -457,7 +478,7 @@ int64_t pioran_tile_pass_draws(int32_t R, int cus)
     return (int64_t)cus * kTileWaves * (NB <= 4 ? 2 : 1);
 }
 
-// shared-(c, d) launches without per-draw rows or per-draw series; btab from pioran_launch_block_table for the same (N, R, J, rowmap);
+// shared-(c, d) launches without per-draw rows; btab from pioran_launch_block_table for the same (N, R, J, rowmap);
 // work: pioran_tile_workspace_doubles(B, N) doubles
 // doubles of workspace a launch of B draws needs (the window's own covariance block per draw and window)
 size_t pioran_tile_workspace_doubles(int64_t B, int64_t N) { return (size_t)B * (size_t)((N + KW - 1) / KW) * 128; }
@@ -465,7 +486,8 @@ size_t pioran_tile_workspace_doubles(int64_t B, int64_t N) { return (size_t)B * 
 int pioran_launch_scan_tile(const ScanParams& p, const double* btab, double* work, hipStream_t stream)
 {
     if (!work) return PIORAN_ERR_ARG;
-    if (!btab || p.B < 1 || p.N < 1 || p.npd_rows != 0 || p.Y || p.S2 || !pioran_tile_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    if (!btab || p.B < 1 || p.N < 1 || p.npd_rows != 0 || !pioran_tile_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
+    if ((p.Y == nullptr) != (p.S2 == nullptr)) return PIORAN_ERR_ARG;
     switch ((p.R + 1 + 15) / 16) {
         case 1: return launch_tile<1>(p, btab, work, stream);
         case 2: return launch_tile<2>(p, btab, work, stream);

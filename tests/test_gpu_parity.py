@@ -873,17 +873,21 @@ def test_tile_kernel_edges(ctx):
             assert name() == "tile"
             ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
             assert relerr(got, ref) < 1e-11, (J, nreal)
-        # 96 rows and more, per-draw series: launches it does not take (the automatic choice runs)
+        # 96 rows and more: launches it does not take (the automatic choice runs)
         t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 40, 48, 3)
         got = pj.Dataset(t, y, s2, ctx).logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
         assert name() != "tile" and relerr(got, O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=4)) < 1e-11
+        # per-draw series (the shifted log-flux models hand every draw its own y and sigma2): ragged last window, every block count
+        for J, N, B in [(20, 90, 6), (7, 16, 5), (27, 33, 7), (40, 50, 5)]:
+            t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+            Y = rng.standard_normal((B, N)); S2 = rng.uniform(0.01, 0.1, (B, N))
+            ds = pj.Dataset(t, y, s2, ctx)
+            got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+            assert name() == "tile"
+            ref = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(B)])
+            assert relerr(got, ref) < 1e-11, (J, N, B)
         t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, 90, 20, 6)
-        Y = rng.standard_normal((6, 90)); S2 = rng.uniform(0.01, 0.1, (6, 90))
         ds = pj.Dataset(t, y, s2, ctx)
-        got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
-        assert name() != "tile"
-        ref = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(6)])
-        assert relerr(got, ref) < 1e-11
         # neither mu nor nu
         got = ds.logl_batch(A, Bc, C, Dd)
         assert name() == "tile" and relerr(got, O.logl_batch(A, Bc, C, Dd, t, y, s2, np.zeros(6), np.ones(6), nthreads=4)) < 1e-11

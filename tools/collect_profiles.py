@@ -61,7 +61,10 @@ for tag, basis in (("sho", "SHO"), ("drwcelerite", "DRWCelerite")):
         "waitcnt_share_of_wave_cycles": pd.get("SQ_WAIT_ANY", float("nan")) / pd["SQ_WAVE_CYCLES"],
         "issue_wait_share_of_wave_cycles": pd.get("SQ_WAIT_INST_ANY", float("nan")) / pd["SQ_WAVE_CYCLES"],
         "mfma_f64_insts_per_wave_window": (pd["SQ_INSTS_MFMA"] / pd["SQ_WAVES"] / ((N + 15) // 16)) if "SQ_INSTS_MFMA" in pd else None,
-        "mfma_busy_share_of_busy_cycles": (pd["SQ_VALU_MFMA_BUSY_CYCLES"] / pd["SQ_BUSY_CYCLES"]) if ("SQ_VALU_MFMA_BUSY_CYCLES" in pd and pd.get("SQ_BUSY_CYCLES")) else None,
+        # share of the kernel's time in which a SIMD's matrix pipe is busy: (matrix instructions x 64 cycles each) / (1024 SIMDs x kernel cycles),
+        # kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs)
+        "mfma_pipe_busy_share": (pd["SQ_INSTS_MFMA"] * 64.0 / 1024.0 / (pd["GRBM_GUI_ACTIVE"] / 8.0)) if ("SQ_INSTS_MFMA" in pd and pd.get("GRBM_GUI_ACTIVE")) else None,
+        "effective_clock_ghz": (pd["GRBM_GUI_ACTIVE"] / 8.0 / (float(krow["AverageNs"]))) if pd.get("GRBM_GUI_ACTIVE") else None,
         "note": "FETCH_SIZE / WRITE_SIZE in KB; x2 on the fetch is the gfx950 correction of MI355X_MICROARCH.md (calibrated on 16 B/lane streams; these "
                 "are 8 B/lane buffer loads of an L2-resident table, so the corrected figure is an upper bound).  Median over the dispatches of the pass."}
     (prof / f"{ROUND}_pmc_{tag}20_b4096.json").write_text(json.dumps(out, indent=1))
