@@ -1589,20 +1589,31 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
         if (rc == PIORAN_ERR_UNSUPPORTED) windowed = false;
         else if (rc) return rc;
     }
-    auto ws_doubles = [&](int64_t nb) { return windowed ? pioran_block_grad_workspace_doubles(nb, ds->N, s.R) : pioran_grad_workspace_doubles(nb, ds->N, s.R); };
+    // Many chains (round 5): the one-draw-per-wavefront reverse mode (celerite_tile.hip) — value and d/d(a, b, mu, nu) only, shared series.  Its
+    // forward pass keeps the lower tiles of T per window (12 KB at three block columns) and the reverse kernel recomputes the rest, where the
+    // small-batch kernels keep 41 KB per window and chain and hold one chain per CU.  scan_config = "tile" forces it for any chain count.
+    const bool tilegrad = windowed && !grad_c && !grad_d && !grad_y && !grad_sigma2 && !shift && s.R <= pioran_tile_grad_supported_rows() &&
+                          (ctx->opt.force_tile || (!ctx->opt.no_tile && B > 256 && s.R >= 17));
+    auto ws_doubles = [&](int64_t nb) {
+        return tilegrad ? pioran_tile_grad_workspace_doubles(nb, ds->N, s.R)
+                        : (windowed ? pioran_block_grad_workspace_doubles(nb, ds->N, s.R) : pioran_grad_workspace_doubles(nb, ds->N, s.R));
+    };
     // Workspace per draw: (m, D) of every step + S at the checkpoints + two replayed segments (celerite_wide.hip): ~15 MB at
     // N = 1e4, R = 40.  The chunk is bounded by half of the memory that is free right now (plus what this buffer already
     // holds) and halved again if the allocation still fails.
     int64_t chunk = B < 1024 ? B : 1024;
     // windowed: 512 chains per launch pair (the forward pass then runs two workgroups per CU, the reverse pass two rounds of one)
     if (windowed && chunk > 512) chunk = 512;
+    if (tilegrad) chunk = B < 4096 ? B : 4096;      // whole passes of 2048 (1024) chains: 7.7 GB of T per 1024 chains at N = 1e4, three block columns
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t allowed = ws_allow(ctx, free_b) + ctx->bwork.cap;
-            while (chunk > 1 && ws_doubles(chunk) * sizeof(double) > allowed) chunk /= 2;
+            // (tile: the limit holds for the buffer as a whole — "limit + what it holds" let the second call grow a 16 GB buffer to 31 GB)
+            const size_t allowed = tilegrad ? ws_allow(ctx, free_b + ctx->bwork.cap) : ws_allow(ctx, free_b) + ctx->bwork.cap;
+            while (chunk > 1 && ws_doubles(chunk) * sizeof(double) > allowed) chunk = tilegrad && chunk > 1024 ? chunk - 1024 : chunk / 2;
         }
     }
+    if (tilegrad && (rc = ensure(ctx, ctx->bpair, pioran_tile_workspace_doubles(chunk, ds->N) * sizeof(double)))) return rc;
     while ((rc = ensure(ctx, ctx->bwork, ws_doubles(chunk) * sizeof(double))) == PIORAN_ERR_ALLOC && chunk > 1)
         chunk /= 2;
     if (rc) return rc;
@@ -1653,7 +1664,11 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
             for (auto& e : ctx->gev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
         p.opt = &ctx->opt;
-        if (windowed) {
+        if (tilegrad) {
+            p.gw = (double*)ctx->bwork.p;
+            g_last_kernel = "tile (windowed gradient, one draw per wavefront)";
+            rc = pioran_launch_tile_grad(p, s.btab, gtab, (double*)ctx->bpair.p, dga, dgb, dgn, dgm, ctx->stream);
+        } else if (windowed) {
             p.gw = (double*)ctx->bwork.p;
             g_last_kernel = "block (windowed gradient)";
             rc = pioran_launch_block_grad(p, s.btab, gtab, dga, dgb, dgn, dgm, grad_c ? dgc : nullptr, grad_d ? dgd : nullptr, ctx->stream);

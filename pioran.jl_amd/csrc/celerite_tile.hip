@@ -34,6 +34,11 @@
 #define PIORAN_TSTAMP_DECL
 #define PIORAN_TSTAMP_FLUSH
 #endif
+#ifndef PIORAN_ASTAMP2
+#define PIORAN_ASTAMP2(i) __builtin_amdgcn_sched_barrier(0)
+#define PIORAN_ASTAMP2_DECL
+#define PIORAN_ASTAMP2_FLUSH
+#endif
 
 namespace {
 
@@ -137,7 +142,10 @@ __global__ void __launch_bounds__(128) tile_pairs_reg_kernel(const ScanParams p,
     }
 }
 
-template <int NB>
+// ST (gradient, round 5): the forward pass of the one-draw-per-wavefront reverse mode — it leaves the lower tiles of T at the START of every window
+// in p.gw ([draw][window][tile][lane][register], NB (NB + 1) / 2 x 2 KB per window) and nothing else: the reverse kernel
+// (celerite_tile_adjoint_kernel) recomputes M', Sigma, the LDL' and Q' from it.  The value is bit-identical to the plain kernel's.
+template <int NB, bool ST = false>
 __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_tile_kernel(const ScanParams p, const double* __restrict__ btab,
                                                                                           const double* __restrict__ pairs)
 {
@@ -272,6 +280,11 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
             if (lane < 16) { sw.ys[lane] = ypre; sw.ck[16 * NB + lane] = spre; }
         }
         if (more) { fetch_ck(k + 1); fetch_series(k + 1); }
+        if constexpr (ST) {
+            d4* gtk = reinterpret_cast<d4*>(p.gw + ((b * NW + k) * NT) * 256);      // [tile][lane][register]: 32 bytes per lane, two 16-byte stores
+#pragma unroll
+            for (int i = 0; i < NT; ++i) gtk[i * 64 + lane] = T[i];
+        }
         // ---- M' = U~' T: the lower tiles from registers, the upper ones as transposed reads of their LDS copies -------------------
         d4 x[NB];
 #pragma unroll
@@ -431,6 +444,568 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
     }
 }
 
+// ---- reverse mode, one draw per wavefront (round 5) --------------------------------------------------------------------------------------
+// Gradient of log L with respect to (a_j, b_j, mu, nu) through the windowed form, walking the windows backwards.  Same adjoint algebra as
+// celerite_block_adjoint_kernel (celerite_block.hip; numpy prototype tools/block_adjoint_proto.py, checked against the complex-step oracle), with
+// K = Sigma^-1, Q' = K X' (primes: steps x rows):
+//   X-' = 2 Q' T-  (- Q'[:, y] in the y column);   S- = -1/2 K - Q' T- Q + 1/2 q_y q_y';   M-' = -cK o X-' - S- U~'
+//   U~-' = (M-' - S- U~') T   (= -S- M' + M-' T: ONE product with T instead of two);   T- <- (cK cK') o T- + 1/2 (U~ M-' + M- U~')
+//   d/dal_r += sum_n U~-'[n][r] (C v)[n][r], d/dbe_r likewise with x;  d/dmu -= sum_n X-'[n][y];  d/dsum(a) += tr S-;  d/dnu += sum_n S-_nn sigma2_n;
+//   d/da_t += 2 sum_pairs S-_jn E_t,p.cos, d/db_t += 2 sum_pairs S-_jn E_t,p.sin   (tile_pairs_grad_kernel, from the symmetrised S- this kernel leaves
+//   where the pre-pass left A)
+// What differs from the small-batch reverse kernel is what the forward pass keeps: there T, M', Q' (twice) and K per window — 41 KB per window and chain
+// each way, 210 GB for 4096 chains at N = 1e4 — here ONLY the lower tiles of T (12 KB at three block columns); M', Sigma, the LDL', Q' and K are
+// recomputed from it (76 matrix instructions + the factorisation), then the adjoint's products run on tiles (144): ~2.6 forward windows per reverse window.
+// T_k is read twice as B operand (M' and U~-'): its lower tiles as fragments straight from the workspace (the second time from L2), its upper
+// tiles as transposed reads of LDS copies; T- lives like T in the forward kernel (lower tiles in registers, transposed LDS copies).
+template <int NB>
+struct TileAdjWave {
+    double scr[16 * 18];           // transposing scratch (blocks of M', Q', X-' ... in turn); D_k (L^-1)_ik
+    double srm[16 * 16];           // S- row-major
+    double2 albe[16 * NB];
+    double ck[16 * NB + 16];       // C_K per row, sigma2 per step
+    double qy[16];
+    double red[16 * NB][4];        // end of the kernel: per-row sums over the four step quarters
+    double tk[NB * (NB + 1) / 2][16 * 18];                 // the lower tiles of T_k, [row][column]: read as they stand (tiles on and below the
+                                                           // diagonal) and transposed (above it) — registers hold T_k only on its way here
+    double upB[NB > 1 ? NB * (NB - 1) / 2 : 1][16 * 18];   // strictly lower tiles of T-
+};
+
+template <int NB>
+__global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kernel(const ScanParams p, const double* __restrict__ btab,
+                                                                                                  const double* __restrict__ gtab, double* __restrict__ pairs,
+                                                                                                  double* __restrict__ grad_a, double* __restrict__ grad_b,
+                                                                                                  double* __restrict__ grad_nu, double* __restrict__ grad_mu)
+{
+    constexpr int TS = 3 * NB * 256 + 16 * NB + 16, TSP = (TS + 127) & ~127;
+    constexpr int64_t GS = 4 * (int64_t)NB * 256 + 16 * NB + 16 + 24;     // block_gtab_doubles (celerite_block.hip): C o v | C o x (C/D order) | C_K | sigma2 | ...
+    constexpr int NT = NB * (NB + 1) / 2, NU = NB * (NB - 1) / 2;
+    extern __shared__ double lds_[];
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, q = lane >> 4, c16 = lane & 15;
+    const int64_t b = (int64_t)blockIdx.x * kTileWaves + w;
+    if (b >= p.B) return;
+    const int64_t N = p.N;
+    const int J = p.J, R = p.R;
+    const int64_t NW = (N + KW - 1) / KW;
+    const int64_t RSB = TSP + 256 * (int64_t)J;
+    TileAdjWave<NB>& sw = reinterpret_cast<TileAdjWave<NB>*>(lds_)[w];
+    const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(btab), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_gt = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(gtab), 0, 0x7ffffffc, 0x00020000);
+    double* const pw = pairs + b * NW * 128;
+    const double* const gtb = p.gw + b * NW * NT * 256;       // T_k of this draw
+    const int lane8 = lane * 8;
+    const int rsb8 = (int)(RSB * 8), gs8 = (int)(GS * 8);
+    const int Jy = R >> 4, ry = R & 15;
+    const double mu = p.mu ? p.mu[b] : 0.0;
+    const double nu = p.nu ? p.nu[b] : 1.0;
+    const bool has_nu = p.nu != nullptr;
+    const double* __restrict__ Ab_ = p.A + b * J;
+    const double* __restrict__ Bb_ = p.Bc + b * J;
+    double suma = 0.0;
+    for (int j = 0; j < J; ++j) suma += Ab_[j];
+    for (int r = lane; r < 16 * NB; r += 64) {
+        double a = 0.0, bb = 0.0;
+        if (r < R) {
+            const int rm = p.rowmap[r];
+            const int term = rm & 0xfffff;
+            a = Ab_[term];
+            bb = ((rm >> 30) & 1) ? -Bb_[term] : Bb_[term];
+        }
+        sw.albe[r] = double2{a, bb};
+    }
+    for (int i = lane; i < (NU > 0 ? NU : 1) * 16 * 18; i += 64) (&sw.upB[0][0])[i] = 0.0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double2 myab[NB];          // (al, be) of the row this lane's column stands for in block w
+    double ymask[NB], mu_sel[NB];
+#pragma unroll
+    for (int Jc = 0; Jc < NB; ++Jc) {
+        myab[Jc] = sw.albe[16 * Jc + c16];
+        ymask[Jc] = (Jc == Jy && c16 == ry) ? 1.0 : 0.0;
+        mu_sel[Jc] = ymask[Jc] * mu;
+    }
+    auto tix = [](int I, int Jc) constexpr { return I * (I + 1) / 2 + Jc; };
+    auto uix = [](int I, int Jc) constexpr { return I * (I - 1) / 2 + Jc; };
+    d4 Tb[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) Tb[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double acc_al[NB], acc_be[NB];
+#pragma unroll
+    for (int Jc = 0; Jc < NB; ++Jc) { acc_al[Jc] = 0.0; acc_be[Jc] = 0.0; }
+    double acc_mu = 0.0, acc_sa = 0.0, acc_nu = 0.0;
+    int pidx[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int r = 4 * g + q, hi = r > c16 ? r : c16, lo = r > c16 ? c16 : r;
+        pidx[g] = r == c16 ? 127 : hi * (hi - 1) / 2 + lo;
+    }
+    const int gd = (c16 - q) >> 2;
+    const bool on_diag = ((c16 - q) & 3) == 0;
+    int pnn[2], pjj[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int pq = lane + 64 * h;
+        int n_ = 1;
+        while ((n_ + 1) * n_ / 2 <= pq) ++n_;
+        pnn[h] = n_ < 16 ? n_ : 15;
+        pjj[h] = n_ < 16 ? pq - n_ * (n_ - 1) / 2 : 0;
+    }
+    const int64_t k_ragged = (N % KW) ? NW - 1 : NW;
+    // Global reads of a window and when they are issued (one wavefront per SIMD, 512 registers: no operand is a load inside a chain of matrix
+    // instructions — the first version had T_k's fragments there, at two wavefronts per SIMD with 58 spilled registers: 48.8 ms per 2048 chains):
+    //   T_k (lower tiles, two 16-byte loads each), C o v / C o x in A-operand order, C_K / sigma2, the pre-pass's pair block: for window k - 1 right after
+    //   the last use of T_k in window k (the update of T- and the head of the next window cover their latency);
+    //   (C_K / C) o v at the head of the window (used after M'), C o v / C o x in C/D order before phase A (used in C and D).
+    // T_k itself sits in LDS for the window (lower tiles, read as they stand or transposed): registers hold it only on its way there.
+    constexpr int NCK = (16 * NB + 16 + 63) / 64;
+    struct WinIn {
+        d4 T[NT];
+        double cva[NB][4], cxa[NB][4];      // C o v, C o x, A-operand order (btab)
+        double ckp[NCK];
+        double ap[4];
+    };
+    auto fetch_win = [&](int64_t kk, WinIn& wi) __attribute__((always_inline)) {
+        const int wso = (int)kk * rsb8;
+        const d4* tk = reinterpret_cast<const d4*>(gtb + kk * NT * 256);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) wi.T[i] = tk[i * 64 + lane];
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                wi.cva[I][ks] = tile_bload(rs_tab, lane8, wso + (I * 4 + ks) * 512);
+                wi.cxa[I][ks] = tile_bload(rs_tab, lane8, wso + (NB * 256 + (I * 4 + ks) * 64) * 8);
+            }
+#pragma unroll
+        for (int i = 0; i < NCK; ++i) wi.ckp[i] = tile_bload(rs_tab, lane8, wso + 3 * NB * 256 * 8 + 512 * i);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wi.ap[g] = pw[kk * 128 + pidx[g]];
+    };
+    WinIn cur;
+    fetch_win(NW - 1, cur);
+    PIORAN_ASTAMP2_DECL
+
+    for (int64_t k = NW - 1; k >= 0; --k) {
+        PIORAN_ASTAMP2(0);
+        const int wso = (int)k * rsb8, gso = (int)k * gs8;
+        double vhs[NB][4];
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) vhs[I][g] = tile_bload(rs_tab, lane8, wso + (2 * NB * 256 + (I * 4 + g) * 64) * 8);
+        // ---- this window's inputs ---------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < NCK; ++i)
+            if (lane + 64 * i < 16 * NB + 16) sw.ck[lane + 64 * i] = cur.ckp[i];
+        double apre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) apre[g] = cur.ap[g];
+        double Uf[NB][4];
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double2 cf = sw.albe[16 * I + 4 * ks + q];
+                Uf[I][ks] = fma(cf.x, cur.cva[I][ks], cf.y * cur.cxa[I][ks]);
+            }
+        // the lower tiles of T_k -> LDS
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sw.tk[i][(4 * g + q) * 18 + c16] = cur.T[i][g];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        PIORAN_ASTAMP2(1);
+        // ---- forward window again: M' = U~' T_k ----------------------------------------------------------------------------------
+        d4 x[NB];
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int I = 0; I < Jc; ++I) {
+                double bt[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) bt[ks] = sw.tk[tix(Jc, I)][c16 * 18 + 4 * ks + q];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[I][ks], bt[ks], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int I = Jc; I < NB; ++I) {
+                double bt[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) bt[ks] = sw.tk[tix(I, Jc)][(4 * ks + q) * 18 + c16];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[I][ks], bt[ks], acc, 0, 0, 0);
+            }
+            x[Jc] = acc;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PIORAN_ASTAMP2(2);
+        // ---- G = U~' M, X' = V^' - C_K o M' ----------------------------------------------------------------------------------------
+        d4 G = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 18 + c16] = x[Jc][g];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double mb[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) mb[ks] = sw.scr[c16 * 18 + 4 * ks + q];
+            const double ckc = sw.ck[16 * Jc + c16];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) G = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[Jc][ks], mb[ks], G, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                double v = vhs[Jc][g] - mu_sel[Jc];
+                if (k == k_ragged && k * KW + 4 * g + q >= N) v = 0.0;
+                x[Jc][g] = fma(-ckc, x[Jc][g], v);
+                asm volatile("" : "+v"(x[Jc][g]));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PIORAN_ASTAMP2(3);
+        // ---- Sigma = A - G, LDL', L^-1 ---------------------------------------------------------------------------------------------
+        const double s2n = sw.ck[16 * NB + c16];
+        const bool live = k * KW + c16 < N;
+        {
+            const double dg = live ? suma + (has_nu ? nu * s2n : s2n) : 1.0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 16 + c16] = ((on_diag && g == gd) ? dg : apre[g]) - G[g];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double m[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) m[j] = sw.scr[j * 16 + c16];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIORAN_ASTAMP2(4);
+        double mult = ldl_first_mult(m, c16);
+        static_for<0, 16>([&](auto Pc) __attribute__((always_inline)) { ldl_step<decltype(Pc)::value>(m, mult, c16); });
+        PIORAN_ASTAMP2(5);
+        if (q == 0) {
+            double2* dst = reinterpret_cast<double2*>(sw.scr + c16 * 18);
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) dst[j / 2] = double2{m[j], m[j + 1]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // operands: L^-1 (A operand of Y^' = L^-1 X'), L^-T D^-1 (A operand of Q' = L^-T D^-1 Y^'), and K = L^-T D^-1 L^-1
+        double li[4], lt[4], la[4], lb[4];
+        {
+            const double idm = recip_f64(sw.scr[c16 * 18 + c16]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int kk = 4 * ks + q;
+                const double idk = recip_f64(sw.scr[kk * 18 + kk]);
+                const double lv = sw.scr[kk * 18 + c16];          // D_kk (L^-1)[c16][kk], c16 > kk
+                const double lu = sw.scr[c16 * 18 + kk];          // D_c16 (L^-1)[kk][c16], kk > c16
+                li[ks] = kk < c16 ? lv * idk : (kk == c16 ? 1.0 : 0.0);
+                lb[ks] = kk > c16 ? lu * idm : (kk == c16 ? 1.0 : 0.0);      // (L^-1)[kk][c16]
+                la[ks] = lb[ks] * idk;
+                lt[ks] = la[ks];                                               // (L^-T D^-1)[c16][kk] = (L^-1)[kk][c16] / D_kk
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        d4 Kv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) Kv = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], lb[ks], Kv, 0, 0, 0);
+        PIORAN_ASTAMP2(6);
+        // ---- Q' = Sigma^-1 X' ---------------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) {
+            d4 yt = {0.0, 0.0, 0.0, 0.0}, qv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) yt = __builtin_amdgcn_mfma_f64_16x16x4f64(li[ks], x[Jc][ks], yt, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qv = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[ks], yt[ks], qv, 0, 0, 0);
+            x[Jc] = qv;                                            // from here on x holds Q'
+        }
+        if (c16 == ry) {                                            // q_y: the y column of Q' (block Jy), by step
+            static_for<0, NB>([&](auto Ic) __attribute__((always_inline)) {
+                constexpr int I = decltype(Ic)::value;
+                if (I == Jy) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) sw.qy[4 * g + q] = x[I][g];
+                }
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PIORAN_ASTAMP2(7);
+        double cvs[NB][4], cxs[NB][4];      // C o v, C o x, C/D order (gtab): on their way during phases A and B
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                cvs[I][g] = tile_bload(rs_gt, lane8, gso + ((I * 4 + g) * 64) * 8);
+                cxs[I][g] = tile_bload(rs_gt, lane8, gso + (NB * 256 + (I * 4 + g) * 64) * 8);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- A: Q in A-operand order; X-' = 2 Q' T- (- q_y in the y column); P = Q' T- Q -----------------------------------------------
+        double qf[NB][4];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 18 + c16] = x[I][g];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[I][ks] = sw.scr[c16 * 18 + 4 * ks + q];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        d4 xb[NB];
+        d4 P = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) {
+            d4 qt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int I = 0; I < Jc; ++I) {
+                double bt[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) bt[ks] = sw.upB[uix(Jc, I)][c16 * 18 + 4 * ks + q];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qt = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[I][ks], bt[ks], qt, 0, 0, 0);
+            }
+#pragma unroll
+            for (int I = Jc; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qt = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[I][ks], Tb[tix(I, Jc)][ks], qt, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 18 + c16] = qt[g];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double qtT[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qtT[ks] = sw.scr[c16 * 18 + 4 * ks + q];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) P = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[Jc][ks], qtT[ks], P, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                xb[Jc][g] = fma(-ymask[Jc], x[Jc][g], 2.0 * qt[g]);
+                acc_mu = fma(-ymask[Jc], xb[Jc][g], acc_mu);      // (padded steps: Q' = 0 there, nothing to mask)
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PIORAN_ASTAMP2(8);
+        // ---- B: S- = -1/2 K - P + 1/2 q_y q_y' -------------------------------------------------------------------------------------------
+        {
+            const double qyc = sw.qy[c16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const double sb = fma(0.5 * sw.qy[4 * g + q], qyc, fma(-0.5, Kv[g], -P[g]));
+                sw.srm[(4 * g + q) * 16 + c16] = sb;
+                if (on_diag && g == gd && live) {
+                    acc_sa += sb;
+                    acc_nu = fma(sb, s2n, acc_nu);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double sA[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) sA[ks] = 0.5 * (sw.srm[c16 * 16 + 4 * ks + q] + sw.srm[(4 * ks + q) * 16 + c16]);   // symmetrised
+        // the pairs' S-_nj + S-_jn for the pair-table contraction of the post-pass: where the pre-pass left A (read above)
+        {
+            const double sv0 = sw.srm[pnn[0] * 16 + pjj[0]] + sw.srm[pjj[0] * 16 + pnn[0]];
+            const double sv1 = sw.srm[pnn[1] * 16 + pjj[1]] + sw.srm[pjj[1] * 16 + pnn[1]];
+            pw[k * 128 + lane] = sv0;
+            pw[k * 128 + 64 + lane] = lane < 120 - 64 ? sv1 : 0.0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        PIORAN_ASTAMP2(9);
+        // ---- C: U~' (C/D order), S- U~', W' = M-' - S- U~' = -cK o X-' - 2 S- U~', M-' ------------------------------------------------------
+        d4 uw[NB], mbk[NB];
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) uw[Jc][g] = fma(myab[Jc].x, cvs[Jc][g], myab[Jc].y * cxs[Jc][g]);
+        double wa[NB][4];          // W' in A-operand order
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) {
+            d4 su = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) su = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[ks], uw[Jc][ks], su, 0, 0, 0);
+            const double ckc = sw.ck[16 * Jc + c16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const double cx_ = -ckc * xb[Jc][g];
+                mbk[Jc][g] = cx_ - su[g];
+                sw.scr[(4 * g + q) * 18 + c16] = cx_ - 2.0 * su[g];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wa[Jc][ks] = sw.scr[c16 * 18 + 4 * ks + q];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PIORAN_ASTAMP2(10);
+        // ---- D: U~-' = W' T_k -> d/dal, d/dbe;  T- <- (cK cK') o T- + 1/2 (U~ M-' + M- U~') --------------------------------------------------
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) {
+            d4 ub = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int I = 0; I < Jc; ++I) {
+                double bt[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) bt[ks] = sw.tk[tix(Jc, I)][c16 * 18 + 4 * ks + q];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) ub = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[I][ks], bt[ks], ub, 0, 0, 0);
+            }
+#pragma unroll
+            for (int I = Jc; I < NB; ++I) {
+                double bt[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) bt[ks] = sw.tk[tix(I, Jc)][(4 * ks + q) * 18 + c16];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) ub = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[I][ks], bt[ks], ub, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc_al[Jc] = fma(ub[g], cvs[Jc][g], acc_al[Jc]);
+                acc_be[Jc] = fma(ub[g], cxs[Jc][g], acc_be[Jc]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PIORAN_ASTAMP2(11);
+        if (k > 0) fetch_win(k - 1, cur);          // T_k has had its last use: window k - 1's inputs, straight into the same registers
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) {
+            const double ckc = sw.ck[16 * Jc + c16];
+            double hm[4], hu[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { hm[ks] = 0.5 * mbk[Jc][ks]; hu[ks] = 0.5 * uw[Jc][ks]; }
+#pragma unroll
+            for (int I = Jc; I < NB; ++I) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Tb[tix(I, Jc)][g] *= sw.ck[16 * I + 4 * g + q] * ckc;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    Tb[tix(I, Jc)] = __builtin_amdgcn_mfma_f64_16x16x4f64(uw[I][ks], hm[ks], Tb[tix(I, Jc)], 0, 0, 0);
+                    Tb[tix(I, Jc)] = __builtin_amdgcn_mfma_f64_16x16x4f64(mbk[I][ks], hu[ks], Tb[tix(I, Jc)], 0, 0, 0);
+                }
+                if (Jc < I) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) sw.upB[uix(I, Jc)][(4 * g + q) * 18 + c16] = Tb[tix(I, Jc)][g];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIORAN_ASTAMP2(12);
+    }
+    PIORAN_ASTAMP2_FLUSH
+
+    // ---- reductions: steps -> rows -> terms --------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int Jc = 0; Jc < NB; ++Jc) {
+        sw.red[16 * Jc + c16][q] = acc_al[Jc];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double row_al = 0.0, row_be = 0.0;     // lane r < 16 NB (two rounds when NB > 4 is not reached here: 16 NB <= 64)
+    if (lane < 16 * NB) row_al = (sw.red[lane][0] + sw.red[lane][1]) + (sw.red[lane][2] + sw.red[lane][3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int Jc = 0; Jc < NB; ++Jc) sw.red[16 * Jc + c16][q] = acc_be[Jc];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < 16 * NB) row_be = (sw.red[lane][0] + sw.red[lane][1]) + (sw.red[lane][2] + sw.red[lane][3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // scalars: sum over the wavefront (every lane holds a share)
+    double s_mu = acc_mu, s_sa = acc_sa, s_nu = acc_nu;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s_mu += __shfl_xor(s_mu, off);
+        s_sa += __shfl_xor(s_sa, off);
+        s_nu += __shfl_xor(s_nu, off);
+    }
+    // rows -> terms through LDS (scr as ra | rb, at most 64 terms... 16 x 18 doubles hold 2 x 64)
+    double* ra = sw.scr;
+    double* rb = sw.scr + 64;
+    for (int t = lane; t < 128; t += 64) sw.scr[t] = 0.0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < R) {
+        const int rm = p.rowmap[lane];
+        const int term = rm & 0xfffff;
+        atomicAdd(&ra[term], row_al);
+        atomicAdd(&rb[term], ((rm >> 30) & 1) ? -row_be : row_be);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int t = lane; t < J; t += 64) {
+        grad_a[b * J + t] = ra[t] + s_sa;
+        grad_b[b * J + t] = rb[t];
+    }
+    if (lane == 0) {
+        if (grad_mu) grad_mu[b] = s_mu;
+        if (grad_nu) grad_nu[b] = s_nu;
+    }
+}
+
+// d/da_t += sum over windows and pairs of (S-_nj + S-_jn) E_t,p.cos, d/db_t likewise with sin: the pair-table contraction of the reverse pass, from
+// the symmetrised S- that celerite_tile_adjoint_kernel left in the pre-pass workspace.  It is a GEMM — out[draw][(t, cos | sin)] = sum over (window,
+// pair) of S-[draw][(window, pair)] E[(window, pair)][(t, cos | sin)], 4096 x 2 J x 80 000 at the bench shape, 26 GFLOP — and runs on the matrix cores:
+// a workgroup owns 16 draws (the A operand's rows) and its eight wavefronts split the windows; per 16 pairs a lane loads four consecutive values of
+// its draw (A operand of four MFMA steps: the k index of step s in lane group q is pair 16 g + 4 q + s on both operands) and, per 16 output columns
+// (eight terms x (cos, sin)), four consecutive table entries; the eight partial tiles are summed through LDS in a fixed order.
+// (Vector forms measured before, per 4096 chains at N = 1e4, 20 terms: thread = (draw, term) with the table in LDS 6.8 .. 8.0 ms — one 16-byte LDS read
+//  per two FMAs; lanes = pairs with the table from L2 14.5 ms; lanes = pairs with the table in LDS and 40 accumulators per lane ~5 ms, two draws per
+//  wavefront 247 spilled registers.)
+constexpr int kPairGradTiles = 6;      // 16-column tiles of (term, cos | sin): 2 J <= 94 columns at the 47 rows of three block columns
+__global__ void __launch_bounds__(512) tile_pairs_grad_kernel(const ScanParams p, const double* __restrict__ btab, int64_t rsb, int64_t tsp,
+                                                              const double* __restrict__ pairs, double* __restrict__ grad_a, double* __restrict__ grad_b)
+{
+    __shared__ double red[8][256];
+    const int J = p.J, nct = (2 * J + 15) / 16;
+    const int64_t NW = (p.N + KW - 1) / KW;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+    const int64_t b0 = (int64_t)blockIdx.x * 16;
+    const int64_t draw = b0 + i < p.B ? b0 + i : p.B - 1;       // (rows past the batch: a live draw's values, never written)
+    d4 acc[kPairGradTiles];
+#pragma unroll
+    for (int ct = 0; ct < kPairGradTiles; ++ct) acc[ct] = d4{0.0, 0.0, 0.0, 0.0};
+    int toff[kPairGradTiles];
+#pragma unroll
+    for (int ct = 0; ct < kPairGradTiles; ++ct) {               // (columns past the last term: the last term's entries, never written)
+        const int t = 8 * ct + (i >> 1);
+        toff[ct] = (t < J ? t : J - 1) * 128 + 4 * q;
+    }
+    const bool sine = i & 1;
+    for (int64_t k = w; k < NW; k += 8) {
+        const double* sv = pairs + (draw * NW + k) * 128 + 4 * q;
+        const double2* E = reinterpret_cast<const double2*>(btab + k * rsb + tsp);
+#pragma unroll 2
+        for (int g = 0; g < 8; ++g) {                           // (pairs 120 .. 127: zeros from the reverse kernel, zeros in the table)
+            const d4 a = *reinterpret_cast<const d4*>(sv + 16 * g);
+#pragma unroll
+            for (int ct = 0; ct < kPairGradTiles; ++ct) {
+                if (ct < nct) {
+                    const double2* e = E + toff[ct] + 16 * g;
+                    const double2 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], sine ? e0.y : e0.x, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], sine ? e1.y : e1.x, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], sine ? e2.y : e2.x, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], sine ? e3.y : e3.x, acc[ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < kPairGradTiles; ++ct) {
+        if (ct < nct) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) red[w][g * 64 + lane] = acc[ct][g];
+            __syncthreads();
+            if (threadIdx.x < 256) {
+                double sum = 0.0;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) sum += red[ww][threadIdx.x];
+                const int gg = threadIdx.x >> 6, ll = threadIdx.x & 63;      // C/D order: register gg of lane ll = (row 4 gg + (ll >> 4), column ll & 15)
+                const int64_t b = b0 + 4 * gg + (ll >> 4);
+                const int col = 16 * ct + (ll & 15), t = col >> 1;
+                if (b < p.B && t < J) { double* o = (col & 1) ? grad_b : grad_a; o[b * J + t] += sum; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <int NB>
 constexpr size_t tile_lds_bytes() { return kTileWaves * sizeof(TileWave<NB>); }
 
@@ -461,9 +1036,64 @@ int launch_tile(const ScanParams& p, const double* btab, double* pairs, hipStrea
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
+template <int NB>
+constexpr size_t tile_adj_lds_bytes() { return kTileWaves * sizeof(TileAdjWave<NB>); }
+
+template <int NB>
+int launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab, double* pairs, double* grad_a, double* grad_b, double* grad_nu,
+                     double* grad_mu, hipStream_t stream)
+{
+    constexpr size_t lds_f = tile_lds_bytes<NB>(), lds_r = tile_adj_lds_bytes<NB>();
+    static_assert(lds_f <= 160 * 1024 && lds_r <= 160 * 1024, "one workgroup must fit a CU");
+    static bool granted[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
+    if (!granted[dev]) {
+        if (hipFuncSetAttribute((const void*)celerite_tile_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f) != hipSuccess) return PIORAN_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)celerite_tile_adjoint_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r) != hipSuccess) return PIORAN_ERR_HIP;
+        granted[dev] = true;
+    }
+    const int64_t groups = (p.B + kTileWaves - 1) / kTileWaves;
+    const int64_t NW = (p.N + KW - 1) / KW;
+    if (groups > 0x7fffffffLL || NW > 0x7fffffffLL || (p.B + kPairDraws - 1) / kPairDraws > 65535) return PIORAN_ERR_UNSUPPORTED;
+    const int64_t rsb = block_rec_doubles(NB, p.J), tsp = block_tile_doubles(NB);
+    const dim3 gr((unsigned)NW, (unsigned)((p.B + kPairDrawsReg - 1) / kPairDrawsReg));
+    if (p.J == 20) hipLaunchKernelGGL(tile_pairs_reg_kernel<20>, gr, dim3(128), 0, stream, p, btab, rsb, tsp, pairs);
+    else hipLaunchKernelGGL(tile_pairs_kernel, dim3((unsigned)NW, (unsigned)((p.B + kPairDraws - 1) / kPairDraws)), dim3(128), 0, stream, p, btab, rsb, tsp, pairs);
+    hipLaunchKernelGGL((celerite_tile_kernel<NB, true>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_f, stream, p, btab, (const double*)pairs);
+    hipLaunchKernelGGL((celerite_tile_adjoint_kernel<NB>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_r, stream, p, btab, gtab, pairs, grad_a, grad_b,
+                       grad_nu, grad_mu);
+    hipLaunchKernelGGL(tile_pairs_grad_kernel, dim3((unsigned)((p.B + 15) / 16)), dim3(512), 0, stream, p, btab, rsb, tsp, (const double*)pairs, grad_a, grad_b);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
 }  // namespace
 
 int pioran_tile_supported_rows() { return 95; }
+int pioran_tile_grad_supported_rows() { return 47; }   // three block columns (four: T_k and T- of four draws do not fit a CU's LDS)
+
+// doubles of the state workspace of the reverse mode: the lower tiles of T at the start of every window, per draw
+size_t pioran_tile_grad_workspace_doubles(int64_t B, int64_t N, int32_t R)
+{
+    const int NB = (R + 1 + 15) / 16;
+    return (size_t)B * (size_t)((N + KW - 1) / KW) * (size_t)(NB * (NB + 1) / 2) * 256;
+}
+
+// log L and its gradient with respect to (a, b, mu, nu), shared (c, d), shared series; p.gw: pioran_tile_grad_workspace_doubles, pairs:
+// pioran_tile_workspace_doubles; btab / gtab: the tables of pioran_launch_block_table / pioran_launch_block_gtab for the same (N, R, J, rowmap)
+int pioran_launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab, double* pairs, double* grad_a, double* grad_b, double* grad_nu,
+                            double* grad_mu, hipStream_t stream)
+{
+    if (!btab || !gtab || !pairs || !p.gw || !grad_a || !grad_b || p.B < 1 || p.N < 1 || p.npd_rows != 0 || p.Y || p.S2 || p.J > kTileMaxTerms ||
+        p.R < 1 || p.R > pioran_tile_grad_supported_rows())
+        return PIORAN_ERR_UNSUPPORTED;
+    switch ((p.R + 1 + 15) / 16) {
+        case 1: return launch_tile_grad<1>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, stream);
+        case 2: return launch_tile_grad<2>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, stream);
+        case 3: return launch_tile_grad<3>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, stream);
+    }
+    return PIORAN_ERR_UNSUPPORTED;
+}
 
 int pioran_tile_fits(int32_t R, int32_t J)
 {

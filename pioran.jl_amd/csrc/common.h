@@ -164,6 +164,11 @@ int pioran_tile_fits(int32_t R, int32_t J);
 int64_t pioran_tile_pass_draws(int32_t R, int cus);
 size_t pioran_tile_workspace_doubles(int64_t B, int64_t N);
 int pioran_launch_scan_tile(const ScanParams& p, const double* btab, double* work, hipStream_t stream);
+// ... its reverse mode: log L and d/d(a, b, mu, nu), one draw per wavefront (1 .. 63 rows; shared (c, d) and series)
+int pioran_tile_grad_supported_rows();
+size_t pioran_tile_grad_workspace_doubles(int64_t B, int64_t N, int32_t R);
+int pioran_launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab, double* pairs, double* grad_a, double* grad_b, double* grad_nu,
+                            double* grad_mu, hipStream_t stream);
 int pioran_launch_block_table_reference(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,
                                         const double* d, const double* y, const double* s2, double* btab, hipStream_t stream);
 // celerite_predict.hip: posterior mean at new times (pred, src/celerite_solver.jl:363-483)

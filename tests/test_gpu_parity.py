@@ -1952,6 +1952,141 @@ def test_windowed_gradient_matches_complex_step(ctx, J, N, B, nreal):
         assert np.max(np.abs(gs["grad_sigma2"][i] - nu[i] * ref["grad_sigma2"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_sigma2"])))
 
 
+TILE_GRAD = "tile (windowed gradient, one draw per wavefront)"
+
+
+@pytest.mark.parametrize("J,N,B,nreal", [(1, 40, 3, 0), (3, 50, 5, 0), (5, 16, 2, 0), (8, 37, 6, 0), (8, 100, 3, 1), (10, 17, 4, 0), (12, 64, 4, 2), (15, 130, 5, 0),
+                                         (16, 33, 70, 0), (20, 257, 9, 0), (23, 48, 2, 0), (23, 95, 3, 5)])
+def test_tile_gradient_matches_complex_step(ctx, J, N, B, nreal):
+    """d log L / d(a_j, b_j, mu, nu) by the one-draw-per-wavefront reverse mode (celerite_tile_adjoint_kernel, round 5; what many chains of an
+    approx-based model ask for), forced here at every batch size: against the complex-step derivatives of the oracle and the small-batch windowed
+    reverse mode; block columns NB = 1 .. 3 (up to 47 rows), ragged last windows, N = 16 and 17 (one window / one step in the second), one-row
+    terms, more draws than one workgroup holds; the value is bit-identical to the tile forward kernel's."""
+    rng = np.random.default_rng(7700 + J + N)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    Bc[:, :nreal] = 0.0; Dd[:nreal] = 0.0
+    ds = pj.Dataset(t, y, s2, ctx)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    try:
+        ctx.set_option("scan_config", "tile")
+        g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+        assert name() == TILE_GRAD
+        val = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert name() == "tile"
+        gc = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)               # d/d(c, d) asked for: not this kernel's, whatever is forced
+        assert name() == "block (windowed gradient)"
+    finally:
+        ctx.set_option("scan_config", None)
+    assert (g["logl"] == val).all() and (g["status"] == 0).all()
+    assert relerr(g["logl"], O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu)) < 1e-11
+    for key in ("grad_a", "grad_b", "grad_mu", "grad_nu"):
+        assert np.max(np.abs(g[key] - gc[key])) <= 1e-11 * (1 + np.max(np.abs(gc[key]))), key
+    for i in range(min(B, 4)):
+        ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2)
+        for key in ("grad_a", "grad_b"):
+            assert np.max(np.abs(g[key][i] - ref[key])) <= 1e-9 * (1 + np.max(np.abs(ref[key]))), (key, i)
+        gm = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, dy=-np.ones(N))
+        gn = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, ds2=s2)
+        assert abs(g["grad_mu"][i] - gm) <= 1e-9 * (1 + abs(gm)) and abs(g["grad_nu"][i] - gn) <= 1e-9 * (1 + abs(gn))
+
+
+def test_tile_gradient_dispatch_chunks_and_flagged_draws(ctx):
+    """The automatic choice (more than 256 chains, 17 .. 47 rows, d/d(a, b, mu, nu) only), "no_tile", a workspace limit that forces several
+    launches (the chunk is cut by 1024 chains, then halved), optional outputs left out, and a draw that is not positive definite: its status
+    is the forward kernel's and the other chains are untouched."""
+    rng = np.random.default_rng(4242)
+    J, N, B = 10, 300, 700
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    ds = pj.Dataset(t, y, s2, ctx)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+    assert name() == TILE_GRAD and (g["status"] == 0).all()
+    assert ds.logl_grad(A[:256], Bc[:256], C, Dd, mu=mu[:256], nu=nu[:256], cd_grad=False)["logl"].shape == (256,) and name() == "block (windowed gradient)"
+    assert ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)["grad_c"] is not None and name() == "block (windowed gradient)"
+    assert ds.logl_grad(A[:, :8], Bc[:, :8], C[:8], Dd[:8], mu=mu, nu=nu, cd_grad=False)["logl"].shape == (B,) and name() == "block (windowed gradient)"   # 16 rows
+    try:
+        ctx.set_option("no_tile", True)
+        h = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+        assert name() == "block (windowed gradient)"
+    finally:
+        ctx.set_option("no_tile", False)
+    assert relerr(g["logl"], h["logl"]) < 1e-12
+    for key in ("grad_a", "grad_b", "grad_mu", "grad_nu"):
+        assert np.max(np.abs(g[key] - h[key])) <= 1e-11 * (1 + np.max(np.abs(h[key]))), key
+    try:       # 19 windows x 3 tiles x 2 KB = 114 KB of T per chain: 1 MB holds nine chains -> 700 -> 350 -> ... -> 5 per launch
+        ctx.set_option("workspace_limit_mb", 1)
+        gs = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+        assert name() == TILE_GRAD
+    finally:
+        ctx.set_option("workspace_limit_mb", 0)
+    assert np.array_equal(gs["logl"], g["logl"])
+    for key in ("grad_a", "grad_b", "grad_mu", "grad_nu"):       # (sums over lanes by LDS atomics: equal to rounding)
+        assert np.max(np.abs(gs[key] - g[key])) <= 1e-13 * (1 + np.max(np.abs(g[key]))), key
+    g2 = ds.logl_grad(A, Bc, C, Dd, cd_grad=False)               # no mu, no nu
+    assert name() == TILE_GRAD and relerr(g2["logl"], O.logl_batch(A, Bc, C, Dd, t, y, s2, None, None, nthreads=8)) < 1e-11
+    A2 = A.copy(); A2[3, 0] = -40.0; A2[699, 1] = -60.0
+    gb = ds.logl_grad(A2, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+    assert name() == TILE_GRAD
+    try:
+        ctx.set_option("no_tile", True)
+        hb = ds.logl_grad(A2, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+    finally:
+        ctx.set_option("no_tile", False)
+    assert np.array_equal(gb["status"], hb["status"]) and gb["status"][3] != 0 and gb["status"][699] != 0 and (np.delete(gb["status"], [3, 699]) == 0).all()
+    ok = gb["status"] == 0
+    assert np.array_equal(gb["logl"][ok], g["logl"][ok])
+    for key in ("grad_a", "grad_b", "grad_mu", "grad_nu"):
+        assert np.max(np.abs(gb[key][ok] - g[key][ok])) <= 1e-13 * (1 + np.max(np.abs(g[key]))), key
+
+
+def test_tile_gradient_full_size(ctx, full_size):
+    """N = 1e4 (BASELINE shape), 1024 prior draws of SHO-20 (40 rows) and DRWCelerite-15 (45 rows, 15 of the 30 terms with one row): the
+    one-draw-per-wavefront reverse mode against the small-batch windowed reverse mode on every chain both call positive definite, and against
+    complex steps of the oracle.  (DRWCelerite-20 has 60 rows: four block columns, which the reverse kernel's LDS does not hold — block.)"""
+    t, y, yerr = full_size
+    th = O.synthetic_theta(1024, t, y, seed=77)
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    rng = np.random.default_rng(6)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th[:300], t, 20, "DRWCelerite")
+    ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+    assert name() == "block (windowed gradient)"
+    for basis, ncomp in (("SHO", 20), ("DRWCelerite", 15)):
+        A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, ncomp, basis)
+        g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+        assert name() == TILE_GRAD
+        try:
+            ctx.set_option("no_tile", True)
+            h = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
+            assert name() == "block (windowed gradient)"
+        finally:
+            ctx.set_option("no_tile", False)
+        assert np.array_equal(g["status"] != 0, h["status"] != 0)
+        ok = g["status"] == 0
+        assert ok.mean() > 0.9
+        # (prior draws include ill-conditioned ones, where every fp64 evaluation is up to 8e-9 from the __float128 truth: profiles/r05_quad_truth.txt)
+        el = np.abs(g["logl"][ok] - h["logl"][ok]) / np.abs(h["logl"][ok])
+        assert np.median(el) < 1e-12 and el.max() < 2e-8, (float(np.median(el)), float(el.max()))
+        # per chain, relative to the chain's gradient scale.  Both are fp64 evaluations of an ill-conditioned sum at the worst draws (DESIGN.md §5):
+        # the bulk agrees to 1e-10, the worst chain of 1024 to 1e-6
+        for key in ("grad_a", "grad_b", "grad_mu", "grad_nu"):
+            a_, b_ = g[key][ok].reshape(ok.sum(), -1), h[key][ok].reshape(ok.sum(), -1)
+            sc = np.max(np.abs(h["grad_a"][ok]), axis=1) + 1.0 if key in ("grad_a", "grad_b") else np.abs(b_[:, 0]) + 1.0
+            d = np.max(np.abs(a_ - b_), axis=1) / sc
+            assert np.median(d) < 1e-10 and d.max() < 1e-6, (basis, key, float(np.median(d)), float(d.max()))
+        for i in np.flatnonzero(ok)[:2]:
+            J = A.shape[1]
+            scale = 1 + max(np.max(np.abs(g["grad_a"][i])), np.max(np.abs(g["grad_b"][i])))
+            for _ in range(2):
+                da, db = rng.standard_normal(J), rng.standard_normal(J)
+                if basis == "DRWCelerite":
+                    db[Dd == 0.0] = 0.0
+                ref = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * yerr ** 2, da=da, db=db)
+                assert abs(g["grad_a"][i] @ da + g["grad_b"][i] @ db - ref) <= 1e-7 * scale * np.sqrt(J), basis
+            gm = O.logl_dir(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * yerr ** 2, dy=-np.ones(len(t)))
+            assert abs(g["grad_mu"][i] - gm) <= 1e-7 * (1 + abs(gm))
+
+
 @pytest.mark.parametrize("J,N,B", [(1, 45, 3), (2, 60, 4), (3, 50, 4), (7, 33, 3), (12, 100, 5), (20, 130, 3), (31, 40, 2)])
 def test_windowed_gradient_per_draw_cd_all_chains_in_one_launch(ctx, J, N, B):
     """(c, d) per draw in every term (CARMA kernels, QPO features, free Celerite sums under NUTS): all chains in one launch of the

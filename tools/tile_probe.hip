@@ -15,6 +15,10 @@ __device__ unsigned long long g_tacc[4][16];
         wprev_ = t_;                                                                     \
     } while (0)
 #define PIORAN_TSTAMP_FLUSH if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { for (int i_ = 0; i_ < 16; ++i_) g_tacc[threadIdx.x >> 6][i_] = wacc_[i_]; }
+__device__ unsigned long long g_aacc[4][16];
+#define PIORAN_ASTAMP2_DECL PIORAN_TSTAMP_DECL
+#define PIORAN_ASTAMP2(i) PIORAN_TSTAMP(i)
+#define PIORAN_ASTAMP2_FLUSH if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { for (int i_ = 0; i_ < 16; ++i_) g_aacc[threadIdx.x >> 6][i_] = wacc_[i_]; }
 #include "../pioran.jl_amd/csrc/celerite_block.hip"
 #include "../pioran.jl_amd/csrc/celerite_tile.hip"
 #include <cstdio>
@@ -67,6 +71,28 @@ int main(int argc, char** argv)
         printf("wavefront %d: %.0f cycles per window (stamps included)\n", wv, (double)tot / nw);
         for (int i = 0; i < 12; ++i) printf("  %-46s %8.1f\n", nm[i], (double)acc[wv][i] / nw);
         printf("  %-46s %8.1f\n", "U~ of the next window", (double)acc[wv][0] / nw);
+    }
+    if (argc > 4 && R <= 63) {       // the reverse mode: forward pass with T stores + reverse kernel + post-pass
+        double *gw, *gtab, *ga, *gb, *gn, *gm;
+        hipMalloc(&gw, pioran_tile_grad_workspace_doubles(B, N, R) * 8); hipMalloc(&gtab, pioran_block_gtab_doubles(N, R) * 8);
+        hipMalloc(&ga, (size_t)J * B * 8); hipMalloc(&gb, (size_t)J * B * 8); hipMalloc(&gn, 8 * B); hipMalloc(&gm, 8 * B);
+        pioran_launch_block_gtab(N, R, J, drm, dt, dc, dd, ds2, gtab, 0);
+        p.gw = gw;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, 0);
+            int rc = pioran_launch_tile_grad(p, btab, gtab, work, ga, gb, gn, gm, 0);
+            hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            if (rc) { printf("grad launch rc %d\n", rc); return 1; }
+        }
+        unsigned long long aacc[4][16];
+        hipMemcpyFromSymbol(aacc, HIP_SYMBOL(g_aacc), sizeof(aacc));
+        const char* an[13] = {"(loop edge)", "head: C_K stage, U~, T_k upper tiles -> LDS", "M' = U~'T_k", "G, X'", "C/D table loads, Sigma -> columns", "LDL'", "L^-1 operands, K",
+                              "Q' = Sigma^-1 X'", "A: Q transposes, Q'T-, P", "B: S-, pair values out", "C: U~', S-U~', W' transposes", "D1: U~-' = W'T_k, accumulators",
+                              "D2: next window's loads + T- update"};
+        printf("value + gradient: %.3f ms per launch of %d chains (pre-pass + forward with T stores + reverse + post-pass; stamps included)\n", ms, B);
+        unsigned long long tot = 0; for (int i = 0; i < 13; ++i) tot += aacc[0][i];
+        printf("reverse kernel, wavefront 0: %.0f cycles per window\n", (double)tot / nw);
+        for (int i = 1; i < 13; ++i) printf("  %-58s %8.1f\n", an[i], (double)aacc[0][i] / nw);
     }
     return 0;
 }
