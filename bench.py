@@ -691,21 +691,33 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
         for _ in range(3):
             t0 = time.perf_counter(); gg = dsg.logl_grad(Ag[:nb_], Bg[:nb_], Cg, Dg, mu=mu[:nb_], nu=nu[:nb_]); wall.append(time.perf_counter() - t0)
         grad[f"chains_{nb_}"] = {"value_and_gradient_abcd_mu_nu_ms_incl_pcie": med(wall) * 1e3, "kernel": kern}
-    # ... at a sampler's scale: 4096 chains through the same host entry (chunks of 256 chains: one workgroup per chain and CU).  Flop model of
-    # the pair of passes: the forward recurrence plus a reverse pass of twice its arithmetic (every multiply-add of the forward pass has two
-    # in the adjoint) = 3 F_cel per chain — the figure a reverse mode costs at best; the fraction says how far the windowed pair is from it
+    # ... at a sampler's scale: 4096 chains through the same host entry.  Flop model of the pair of passes: the forward recurrence plus a reverse
+    # pass of twice its arithmetic (every multiply-add of the forward pass has two in the adjoint) = 3 F_cel per chain — the figure a reverse mode
+    # costs at best; the fraction says how far the pair is from it.
+    # chains_4096: value + d/d(a, b, mu, nu) — what Dataset.logpdf_theta_grad / PioranHIP's rrule ask for: with (c, d) SHARED by the chains they are
+    # fixed by the spectral grid of `approx` (src/psd.jl:214-289), there is no parameter behind them (chains that sample (c, d) have them per draw:
+    # small_batch / per-draw entries).  Round 5: the one-draw-per-wavefront reverse mode (celerite_tile.hip).  chains_4096_with_cd: the same call with
+    # d/d(c, d) as well (the measurement of rounds 3 and 4: chunks of 512 chains on the small-batch windowed reverse mode).
     nch = min(4096, B)
     Agc, Bgc, _, _ = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:nch, :3], f_min, f_max, J, theta[:nch, 3], basis_function="SHO")
-    dsg.logl_grad(Agc[:256], Bgc[:256], Cg, Dg, mu=mu[:256], nu=nu[:256])
-    wall = []
-    for _ in range(2):
-        t0 = time.perf_counter(); ggc = dsg.logl_grad(Agc, Bgc, Cg, Dg, mu=mu[:nch], nu=nu[:nch]); wall.append(time.perf_counter() - t0)
-    wg = min(wall)
-    grad[f"chains_{nch}"] = {"value_and_gradient_abcd_mu_nu_ms_incl_pcie": wg * 1e3, "value_and_gradients_per_s": nch / wg,
-                             "kernel": pj._lib.lib().pioran_celerite_config_name(-1).decode(),
-                             "flop_model": "3 x F_cel(N, R) per chain (forward + reverse pass of twice the arithmetic)",
-                             "roofline_frac": 3 * algorithmic_flops(N, 2 * J) * nch / wg / 1e12 / FP64_PEAK_TFLOPS,
-                             "all_finite_frac": float(np.isfinite(ggc["grad_a"]).all(axis=1).mean())}
+    for key, cd in ((f"chains_{nch}", False), (f"chains_{nch}_with_cd", True)):
+        dsg.logl_grad(Agc, Bgc, Cg, Dg, mu=mu[:nch], nu=nu[:nch], cd_grad=cd)      # (workspace of this chain count allocated outside the timing)
+        wall = []
+        for _ in range(3):
+            t0 = time.perf_counter(); ggc = dsg.logl_grad(Agc, Bgc, Cg, Dg, mu=mu[:nch], nu=nu[:nch], cd_grad=cd); wall.append(time.perf_counter() - t0)
+        wg = min(wall)
+        grad[key] = {("value_and_gradient_abcd_mu_nu_ms_incl_pcie" if cd else "value_and_gradient_ab_mu_nu_ms_incl_pcie"): wg * 1e3,
+                     "value_and_gradients_per_s": nch / wg,
+                     "kernel": pj._lib.lib().pioran_celerite_config_name(-1).decode(),
+                     "flop_model": "3 x F_cel(N, R) per chain (forward + reverse pass of twice the arithmetic)",
+                     "roofline_frac": 3 * algorithmic_flops(N, 2 * J) * nch / wg / 1e12 / FP64_PEAK_TFLOPS,
+                     "all_finite_frac": float(np.isfinite(ggc["grad_a"]).all(axis=1).mean())}
+        if not cd:
+            ggt = ggc
+    okc = (ggt["status"] == 0) & (ggc["status"] == 0)
+    scg = np.max(np.abs(ggc["grad_a"][okc]), axis=1) + 1.0
+    dgr = np.max(np.abs(ggt["grad_a"][okc] - ggc["grad_a"][okc]), axis=1) / scg
+    grad[f"chains_{nch}"]["grad_a_vs_small_batch_reverse_mode_rel_median_max"] = [float(np.median(dgr)), float(dgr.max())]
     da_ = np.ones(J)
     dref = O.logl_dir(Ag[0], Bg[0], Cg, Dg, t, y - mu[0], nu[0] * s2, da=da_)
     grad["directional_check_rel_vs_complex_step_oracle"] = float(abs(gg["grad_a"][0].sum() - dref) / (1 + abs(dref)))
