@@ -78,11 +78,15 @@ int pioran_ctx_trim(pioran_ctx* ctx);
  *   "workspace_limit_mb"  cap on the per-call workspaces (default 16384)
  *   "no_tile"         value "1": never the windowed form with one draw per wavefront (celerite_tile.hip); "scan_config" = "tile" forces it for
  *                     every launch it can take
+ *   "no_tp"           value "1": never the time-parallel evaluation (celerite_tp.hip: segments of the series on different CUs, for a handful of
+ *                     draws of a long series — automatic for up to 8 draws with up to 16 state rows from 2048 .. 6144 steps on);
+ *                     "scan_config" = "tp" forces it wherever it applies (shared (c, d), up to 48 state rows, up to 64 draws);
+ *                     "tp_segments" its segment count (0 / NULL = automatic)
  *   "dense_old_chain" 0 one launch per block column (default), 1 the panel / update chain of rounds 1-3 (2 .. 8: timing experiments, only in
  *                     builds with -DPIORAN_EXPERIMENTS; PIORAN_ERR_ARG otherwise);
  *                     "dense_no_pairs", "dense_no_halves", "dense_quad_threshold", "dense_batch_pair_threshold", "dense_streams": schedule knobs
  *   "block_emode", "gsum", "exp"   tuning / experiment selectors of single kernels (tools/ only; "exp" can make results meaningless)
- * Initial values come from the environment variables PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_BLOCK, PIORAN_NO_TILE, PIORAN_NO_PAIRED,
+ * Initial values come from the environment variables PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_BLOCK, PIORAN_NO_TILE, PIORAN_NO_TP, PIORAN_NO_PAIRED,
  * PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK, PIORAN_WIN2, PIORAN_NO_WIN2, PIORAN_GSUM, PIORAN_WIDE2, read once when the context is created. */
 int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value);
 /* hipEvent-based timing on the ctx stream: record slot i (0..11), elapsed between two slots. */

@@ -12,7 +12,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OBJ = PKG / "_obj"
 LIB = PKG / "libpioran_hip.so"
-SOURCES = ["celerite_scan.hip", "celerite_wide.hip", "celerite_block.hip", "celerite_tile.hip", "celerite_predict.hip", "celerite_fallback.hip", "table.hip", "approx.hip", "dense.hip", "capi.hip"]
+SOURCES = ["celerite_scan.hip", "celerite_wide.hip", "celerite_block.hip", "celerite_tile.hip", "celerite_tp.hip", "celerite_predict.hip", "celerite_fallback.hip", "table.hip", "approx.hip", "dense.hip", "capi.hip"]
 HEADERS = [CSRC / "common.h", CSRC / "window_common.h", PKG.parent / "include" / "pioran_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-source additions.  celerite_tile.hip: keep the operands and results of the matrix instructions in VGPRs where the allocator has the choice — the

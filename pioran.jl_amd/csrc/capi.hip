@@ -51,7 +51,7 @@ struct pioran_ctx {
         void* p = nullptr;
         size_t cap = 0;
     };
-    Buf bA, bB, bC, bD, bmu, bnu, bY, bS2, bout, bst, bscratch, bK, bwork, bshift, bgtab, bq, bpair;
+    Buf bA, bB, bC, bD, bmu, bnu, bY, bS2, bout, bst, bscratch, bK, bwork, bshift, bgtab, bq, bpair, btp, btprow;
     // scalar entry point: the last series' time stamps stay resident (samplers call logl with the same t)
     pioran_ds* scalar_ds = nullptr;
     std::vector<double> scalar_t;
@@ -366,6 +366,57 @@ static ScanParams slice_draws(const ScanParams& p, int64_t off, int64_t n)
     return q;
 }
 
+// A handful of draws of a long series: the time-parallel evaluation (celerite_tp.hip, round 5) — segments of the series on different CUs instead
+// of one serial chain per draw.  scan_config = "tp" forces it wherever it applies (shared (c, d), at most 64 state rows, at most 64 draws).
+int tp_dispatch(pioran_ds* ds, const ScanParams& p)
+{
+    pioran_ctx* ctx = ds->ctx;
+    const ScanOptions& o = ctx->opt;
+    if (o.no_tp || (!o.force_tp && (o.scan_config[0] || o.force_tile)) || !p.tab || p.npd_rows != 0 || p.B > 64) return PIORAN_ERR_UNSUPPORTED;
+    PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
+    if (!s || !s->prepared || s->npd_terms != 0 || !s->dc || !s->dd) return PIORAN_ERR_UNSUPPORTED;
+    // state rows: the two-row terms first (pairs on even / odd lanes), then the one-row terms, padded to an even count
+    const int J = s->J;
+    std::vector<int32_t> rows;
+    rows.reserve(256);
+    std::vector<int32_t> term, kind;
+    for (int j = 0; j < J; ++j)
+        if (!s->real_host[j]) { term.push_back(j); kind.push_back(0); term.push_back(j); kind.push_back(1); }
+    for (int j = 0; j < J; ++j)
+        if (s->real_host[j]) { term.push_back(j); kind.push_back(2); }
+    if ((int)term.size() > pioran_tp_supported_rows() || p.N < 64) return PIORAN_ERR_UNSUPPORTED;
+    const int RP = pioran_tp_padded_rows((int)term.size());
+    // measured (tools/ab_tp.py sweep, profiles/r05_time_parallel_gpu.txt): with up to 8 draws it beats the serial-chain kernels from 2048 steps on at
+    // up to 4 state rows (N = 8192, one SHO term: 0.37 against 1.16 ms), from 4096 at up to 8, from 6144 at up to 16 (eight terms: 1.06 against
+    // 1.44 ms); with more rows the boundary solves (R^3 each, one after the other) eat the gain (20 terms, N = 1e4: 2.8 against 1.86 ms), and at 64
+    // draws the one-draw-per-CU kernels have the chip filled anyway.
+    if (!o.force_tp && !(p.B <= 8 && RP <= 16 && p.N >= (RP <= 4 ? 2048 : (RP <= 8 ? 4096 : 6144)))) return PIORAN_ERR_UNSUPPORTED;
+    while ((int)term.size() < RP) { term.push_back(0); kind.push_back(3); }
+    // segments: phases 1 + 3 cost tau ~ 0.7 + R / 8 us per step, phase 2 t2 ~ 5 + R^2 / 20 us per boundary (measured at 4, 16 and 40 rows,
+    // tools/ab_tp.py): N / nseg tau + nseg t2 is least at sqrt(tau N / t2)
+    int nseg = o.tp_segments;
+    if (nseg <= 0) {
+        const double tau = 0.7 + RP / 8.0, t2 = 5.0 + (double)RP * RP / 20.0;
+        nseg = (int)std::lround(std::sqrt(tau * (double)p.N / t2));
+    }
+    if (nseg < 1) nseg = 1;
+    if (nseg > 128) nseg = 128;
+    if ((int64_t)nseg * 16 > p.N) nseg = (int)(p.N / 16);
+    const int64_t L = (p.N + nseg - 1) / nseg;
+    nseg = (int)((p.N + L - 1) / L);
+    rows = term;
+    rows.insert(rows.end(), kind.begin(), kind.end());
+    int rc = upload(ctx, ctx->btprow, rows.data(), rows.size() * sizeof(int32_t));
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->btp, pioran_tp_workspace_doubles(p.B, p.N, RP, nseg) * sizeof(double));
+    if (rc) return rc == PIORAN_ERR_ALLOC ? PIORAN_ERR_UNSUPPORTED : rc;
+    ScanParams q = p;
+    q.C = s->dc; q.D = s->dd; q.J = J;
+    g_last_kernel = "tp";
+    const int32_t* dr = (const int32_t*)ctx->btprow.p;
+    return pioran_launch_tp(q, RP, nseg, L, dr, dr + RP, (double*)ctx->btp.p, ctx->stream);
+}
+
 // Large shared-table batches: the windowed form with one draw per wavefront (celerite_tile.hip, round 5).  Same table as the windowed
 // kernel for small batches.  scan_config = "tile" forces it for any batch size.
 int tile_dispatch(pioran_ds* ds, const ScanParams& p)
@@ -478,7 +529,12 @@ int launch(pioran_ds* ds, ScanParams& p)
     pioran_ctx* ctx = ds->ctx;
     p.opt = &ctx->opt;
     if (!ctx->opt.force_fallback) {
-        int rc = tile_dispatch(ds, p);
+        int rc = tp_dispatch(ds, p);
+        if (rc != PIORAN_ERR_UNSUPPORTED) {
+            if (rc == PIORAN_ERR_HIP) ctx->last_err = "time-parallel kernel launch failed";
+            return rc;
+        }
+        rc = tile_dispatch(ds, p);
         if (rc != PIORAN_ERR_UNSUPPORTED) {
             if (rc == PIORAN_ERR_HIP) ctx->last_err = "tile kernel launch failed";
             return rc;
@@ -565,8 +621,10 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
         std::memset(o.scan_config, 0, sizeof(o.scan_config));
         // "tile": celerite_tile.hip for every launch it can take (any batch size); the launches it cannot take stay automatic
         o.force_tile = value && !std::strcmp(value, "tile");
-        if (value && !o.force_tile) std::strcpy(o.scan_config, value);
-    } else if (!std::strcmp(key, "no_tile")) o.no_tile = on; else if (!std::strcmp(key, "no_wide")) o.no_wide = on;
+        o.force_tp = value && !std::strcmp(value, "tp");
+        if (value && !o.force_tile && !o.force_tp) std::strcpy(o.scan_config, value);
+    } else if (!std::strcmp(key, "no_tp")) o.no_tp = on; else if (!std::strcmp(key, "tp_segments")) o.tp_segments = (value && value[0]) ? std::atoi(value) : 0;
+    else if (!std::strcmp(key, "no_tile")) o.no_tile = on; else if (!std::strcmp(key, "no_wide")) o.no_wide = on;
     else if (!std::strcmp(key, "no_paired")) o.no_paired = on;
     else if (!std::strcmp(key, "no_mixed")) o.no_mixed = on;
     else if (!std::strcmp(key, "force_fallback")) o.force_fallback = on;
@@ -616,6 +674,7 @@ static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
     pioran_ctx_set_option(ctx, "force_fallback", std::getenv("PIORAN_FORCE_FALLBACK"));
     pioran_ctx_set_option(ctx, "no_block", std::getenv("PIORAN_NO_BLOCK"));
     pioran_ctx_set_option(ctx, "no_tile", std::getenv("PIORAN_NO_TILE"));
+    pioran_ctx_set_option(ctx, "no_tp", std::getenv("PIORAN_NO_TP"));
     pioran_ctx_set_option(ctx, "win2", std::getenv("PIORAN_WIN2"));
     pioran_ctx_set_option(ctx, "no_win2", std::getenv("PIORAN_NO_WIN2"));
     pioran_ctx_set_option(ctx, "gsum", std::getenv("PIORAN_GSUM"));
@@ -652,7 +711,7 @@ int pioran_ctx_destroy(pioran_ctx* ctx)
     if (ctx->scalar_ds) pioran_dataset_destroy(ctx->scalar_ds);
     ctx->scalar_ds = nullptr;
     pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
-                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab, &ctx->bq, &ctx->bpair};
+                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab, &ctx->bq, &ctx->bpair, &ctx->btp, &ctx->btprow};
     for (auto* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : ctx->ev)
@@ -676,7 +735,7 @@ int pioran_ctx_trim(pioran_ctx* ctx)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     SYNC(ctx);
     pioran_ctx::Buf* bufs[] = {&ctx->bA, &ctx->bB, &ctx->bC, &ctx->bD, &ctx->bmu, &ctx->bnu, &ctx->bY,
-                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab, &ctx->bq, &ctx->bpair};
+                               &ctx->bS2, &ctx->bout, &ctx->bst, &ctx->bscratch, &ctx->bK, &ctx->bwork, &ctx->bshift, &ctx->bgtab, &ctx->bq, &ctx->bpair, &ctx->btp, &ctx->btprow};
     for (auto* b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;

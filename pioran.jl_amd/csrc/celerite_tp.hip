@@ -1,0 +1,696 @@
+// Time-parallel evaluation of the celerite log-likelihood for a HANDFUL of draws (round 5; the reference's own benchmark is one evaluation at a
+// time: benchmark/benchmarks.jl:76-91, BASELINE configs[1]).  The step-by-step and windowed kernels run one draw as a serial chain of N steps on one
+// CU; this family cuts the series into segments that run on different CUs.
+//
+// Form (numpy prototype with the derivation and the accuracy study: tools/time_parallel_proto.py, profiles/r05_time_parallel_proto.txt).  A celerite
+// kernel is the covariance of a linear-Gaussian state-space model — two state components per term with transition F = e^{-c dt} Rot(d dt), observation
+// h = (1, 0), stationary covariance P_inf = [[a, -b], [-b, a]]; one component for a term with b = d = 0 — and the recurrence of
+// src/celerite_solver.jl:12-100 (init_semi_separable!) with the forward half of solve_prec! (:115-142) is its Kalman filter in the coordinates
+// S_n = P_inf - P_n: D_n is the innovation variance, z_n the innovation, log L = -1/2 sum (log |D_n| + z_n^2 / D_n) - N/2 log 2 pi (:312-334).
+// The filter parallelises over time with the associative elements of Sarkka & Garcia-Fernandez (IEEE TAC 66 (2021) 299): a = (A, b, C, eta, J),
+//     p(x_k | y_k, x_k-1) = N(A x_k-1 + b, C),   p(y_k | x_k-1) ~ N_information(eta, J),
+//     a_i (x) a_j:  A = A_j M A_i,  b = A_j M (b_i + C_i eta_j) + b_j,  C = A_j M C_i A_j' + C_j,   M = (I + C_i J_j)^-1,
+//                   eta = A_i' M' (eta_j - J_j b_i) + eta_i,  J = A_i' M' J_j A_i + J_i.
+// Phases (kernels below):
+//   0  tp_records_kernel    per step and state row: the transition, the process noise Q = P_inf - F P_inf F' in closed form (no difference of nearly
+//                           equal numbers at small c dt), the gain of the single-step element — everything that does not depend on the state;
+//   1  tp_element_kernel    one workgroup per (draw, segment): the segment's element, composed step by step.  A single step's J_j is rank one, so M
+//                           is a Sherman-Morrison correction and a composition is rotations of adjacent rows / columns, rank-one updates and
+//                           matrix-vector sums: O(R^2) per step (about 30 R^2 flop against the recurrence's 5.5 R^2), two barriers per step;
+//   2  tp_boundary_kernel   one workgroup per draw, sequential over the segments: the filtered state (m, P) at every segment boundary, one R x R
+//                           solve with partial pivoting and two products each;
+//   3  tp_filter_kernel     one workgroup per (draw, segment): the ordinary filter from the boundary state — sum log |D_n| and sum z_n^2 / D_n of the
+//                           segment; tp_finish_kernel adds the segments up in a fixed order.
+// Layout of a matrix in phases 1 and 3: lane = row (R <= 64 state rows: two-row terms first, then the one-row terms), wavefront w of the four owns
+// the column PAIRS 4 s + w; a pair is the two rows of a two-row term or two one-row terms.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "common.h"
+
+namespace {
+
+struct __attribute__((aligned(16))) TpRec { double al, be, g, K, qd, qo; };         // per (draw, step, row): three 16-byte units (al, be), (g, K), (qd, qo)
+struct __attribute__((aligned(32))) TpStep { double s, y, s2, yos; };                // per (draw, step): h Q h' + sigma2, y - mu, nu sigma2, y / s
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load in flight (s_waitcnt vmcnt(0)): the records and the
+// element matrices are loaded a chunk / a boundary AHEAD on purpose, and each barrier made them arrive first — ~2 us per load point (6 us per boundary at
+// four rows).  All data that passes between the threads of these kernels passes through LDS.
+#define TP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+constexpr int TP_ELEM_DOUBLES = (3 * 64 + 2) * 64;     // A' | C | J (64 x 64 each, row-major, rows = lanes), b, eta
+constexpr int TP_BND_DOUBLES = 65 * 64;                // m | P (64 x 64 row-major)
+
+__device__ __forceinline__ double tp_readlane(double x, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double tp_dpp(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// the neighbour lane of a row pair (lane ^ 1): quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ double tp_partner(double x) { return tp_dpp<0xB1>(x); }
+
+// sums over the wavefront, two at a time: four DPP rounds inside the rows of 16 lanes, then the four row totals as scalar operands
+// (ds_bpermute-based shuffles cost ~700 cycles for the same: the first version of these kernels spent a third of a step there)
+__device__ __forceinline__ void tp_sum2(double& a, double& b)
+{
+    a += tp_dpp<0xB1>(a);  b += tp_dpp<0xB1>(b);
+    a += tp_dpp<0x4E>(a);  b += tp_dpp<0x4E>(b);
+    a += tp_dpp<0x141>(a); b += tp_dpp<0x141>(b);
+    a += tp_dpp<0x140>(a); b += tp_dpp<0x140>(b);
+    a = (tp_readlane(a, 0) + tp_readlane(a, 16)) + (tp_readlane(a, 32) + tp_readlane(a, 48));
+    b = (tp_readlane(b, 0) + tp_readlane(b, 16)) + (tp_readlane(b, 32) + tp_readlane(b, 48));
+}
+
+// 1 / x to fp64 accuracy: v_rcp_f64 and two Newton steps (as in celerite_scan.hip)
+__device__ __forceinline__ double tp_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+__device__ __forceinline__ double tp_max(double a)
+{
+    a = fmax(a, tp_dpp<0xB1>(a));
+    a = fmax(a, tp_dpp<0x4E>(a));
+    a = fmax(a, tp_dpp<0x141>(a));
+    a = fmax(a, tp_dpp<0x140>(a));
+    return fmax(fmax(tp_readlane(a, 0), tp_readlane(a, 16)), fmax(tp_readlane(a, 32), tp_readlane(a, 48)));
+}
+
+// ---- phase 0 ---------------------------------------------------------------------------------------------------------------------------------
+// kind: 0 / 1 first / second row of a two-row term, 2 one-row term, 3 padding.  Step 0 is the prior as "filtered state before the first step":
+// dt = 0 gives F = I and Q = 0 by the same formulas.
+__global__ void __launch_bounds__(64) tp_records_kernel(int64_t N, int RP, int J, const int32_t* __restrict__ row_term, const int32_t* __restrict__ row_kind,
+                                                        const double* __restrict__ t, const double* __restrict__ y, const double* __restrict__ s2,
+                                                        const double* __restrict__ Y, const double* __restrict__ S2, const double* __restrict__ A,
+                                                        const double* __restrict__ Bc, const double* __restrict__ C, const double* __restrict__ D,
+                                                        const double* __restrict__ mu, const double* __restrict__ nu, TpRec* __restrict__ rec,
+                                                        TpStep* __restrict__ stp)
+{
+    const int64_t n = blockIdx.x, b = blockIdx.y;
+    const int r = threadIdx.x;
+    const double dt = n > 0 ? t[n] - t[n - 1] : 0.0;
+    TpRec o{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double hq = 0.0, qh = 0.0;
+    if (r < RP) {
+        const int kind = row_kind[r];
+        if (kind != 3) {
+            const int j = row_term[r];
+            const double c = C[j], d = kind == 2 ? 0.0 : D[j], a = A[b * J + j], bb = kind == 2 ? 0.0 : Bc[b * J + j];
+            const double e = exp(-c * dt);
+            double sn, cs;
+            sincos(d * dt, &sn, &cs);
+            const double si = e * sn;
+            o.al = e * cs;
+            o.be = kind == 0 ? -si : (kind == 1 ? si : 0.0);
+            const double gam = -expm1(-2.0 * c * dt);
+            o.qd = fma(a, gam, 2.0 * bb * o.al * o.be);
+            o.qo = -bb * fma(2.0 * o.be, o.be, gam);
+            o.g = kind == 1 ? -o.be : o.al;
+            qh = kind == 1 ? o.qo : o.qd;
+            hq = kind == 1 ? 0.0 : o.qd;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) hq += __shfl_xor(hq, off);
+    const double s2v = (S2 ? S2[b * N + n] : s2[n]) * (nu ? nu[b] : 1.0);
+    const double yv = (Y ? Y[b * N + n] : y[n]) - (mu ? mu[b] : 0.0);
+    const double s = hq + s2v;
+    o.K = qh / s;
+    if (r < RP) rec[(b * N + n) * RP + r] = o;
+    if (r == 0) stp[b * N + n] = TpStep{s, yv, s2v, yv / s};
+}
+
+// The records reach a workgroup a CHUNK of steps ahead: while chunk c runs from one LDS buffer, the threads hold chunk c + 1 in registers (loaded a
+// chunk earlier) and copy it to the other buffer in the chunk's last step, then issue the loads of chunk c + 2.  (Records loaded where they were used
+// cost 1.7 us per step; two steps ahead still left 0.75 us per step at four state rows: one cold HBM line per step, 1.5 us away.)
+template <int NWV>
+struct TpStage {
+    static constexpr int CH = NWV == 1 ? 16 : 8, RMAX = NWV == 1 ? 16 : 64, T = 64 * NWV, NU = CH * RMAX * 3 / T;
+    double2 r[NU], s;
+    __device__ __forceinline__ void load(const TpRec* rec0, const TpStep* stp0, int steps, int RP, int t)
+    {
+        const double2* a = reinterpret_cast<const double2*>(rec0);
+        const double2* c = reinterpret_cast<const double2*>(stp0);
+        const int units = steps * RP * 3;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) r[i] = t + T * i < units ? a[t + T * i] : double2{0.0, 0.0};
+        s = t < 2 * steps ? c[t] : double2{0.0, 0.0};
+    }
+    __device__ __forceinline__ void store(double2* rdst, double2* sdst, int RP, int t) const
+    {
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+            if (t + T * i < CH * RP * 3) rdst[t + T * i] = r[i];
+        if (t < 2 * CH) sdst[t] = s;
+    }
+};
+
+// ---- phase 3 ---------------------------------------------------------------------------------------------------------------------------------
+// The records of a step reach the wavefronts one step ahead: every lane loads its row's record of step n + 2 while step n runs, wavefront 0 copies the
+// record of step n + 1 into LDS before the step's barrier, and the column entries (wave-uniform) are LDS broadcast reads — no global load sits on
+// the chain of a step (the first version loaded them where it used them: 1.7 us per step).
+template <int NP, int NWV>     // NWV wavefronts per workgroup (1: up to 16 rows, no barrier at all; 4: up to 64), NP column pairs per wavefront: RP = 2 NP NWV
+__global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, int nseg, int64_t L, const int32_t* __restrict__ row_kind,
+                                                             const TpRec* __restrict__ rec, const TpStep* __restrict__ stp, const double* __restrict__ bnd,
+                                                             double* __restrict__ part, double* __restrict__ sval)
+{
+    using Stage = TpStage<NWV>;
+    constexpr int CH = Stage::CH;
+    __shared__ double red[2][NWV][64];
+    __shared__ double2 rbuf[2][CH * Stage::RMAX * 3], sbuf[2][CH * 2];
+    const int lane = threadIdx.x & 63, w = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int seg = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    const int64_t n0 = seg * L, n1 = n0 + L < N ? n0 + L : N;
+    const int len = (int)(n1 - n0);
+    const double* bs = bnd + (b * nseg + seg) * TP_BND_DOUBLES;
+    double m = bs[lane];
+    double P[NP][2], hc[NP][2];
+    const TpRec* rb = rec + (b * N + n0) * RP;
+    const TpStep* sb = stp + b * N + n0;
+    const int rl = lane < RP ? lane : RP - 1;        // (lanes past the rows: a live row's record; their state is zero and stays zero)
+    const int mykind = row_kind[rl];
+    const double hh = (lane < RP && (mykind == 0 || mykind == 2)) ? 1.0 : 0.0;
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+        const int c0 = 2 * (NWV * s + w);
+        P[s][0] = bs[64 + lane * 64 + c0];
+        P[s][1] = bs[64 + lane * 64 + c0 + 1];
+        const int k0 = row_kind[c0], k1 = row_kind[c0 + 1];
+        hc[s][0] = (k0 == 0 || k0 == 2) ? 1.0 : 0.0;
+        hc[s][1] = (k1 == 0 || k1 == 2) ? 1.0 : 0.0;
+    }
+    const bool odd = lane & 1;
+    Stage stg;
+    stg.load(rb, sb, len < CH ? len : CH, RP, threadIdx.x);
+    stg.store(rbuf[0], sbuf[0], RP, threadIdx.x);
+    {
+        const int rest = len - CH;
+        stg.load(rb + (int64_t)CH * RP, sb + CH, rest < 0 ? 0 : (rest < CH ? rest : CH), RP, threadIdx.x);
+    }
+    TP_BARRIER();
+    double quad = 0.0;
+    for (int k = 0; k < len; ++k) {
+        const int ci = k / CH, si = k % CH, buf = ci & 1;
+        const double2* rr = rbuf[buf] + si * RP * 3;
+        const double2 mab = rr[rl * 3], mq = rr[rl * 3 + 2];
+        const double2 s0 = sbuf[buf][si * 2];
+        const double al = mab.x, be = mab.y;
+        m = fma(al, m, be * tp_partner(m));
+        double ph = 0.0;
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const int jj = NWV * s + w, c0 = 2 * jj;
+            const double2 ab0 = rr[c0 * 3], ab1 = rr[c0 * 3 + 3];
+            const double p0 = P[s][0], p1 = P[s][1];
+            const double r0 = fma(al, p0, be * tp_partner(p0)), r1 = fma(al, p1, be * tp_partner(p1));
+            double v0 = fma(ab0.x, r0, ab0.y * r1), v1 = fma(ab1.x, r1, ab1.y * r0);
+            const bool mine = (lane >> 1) == jj;
+            v0 += mine ? (odd ? mq.y : mq.x) : 0.0;
+            v1 += mine ? (odd ? mq.x : mq.y) : 0.0;
+            P[s][0] = v0;
+            P[s][1] = v1;
+            ph = fma(v0, hc[s][0], fma(v1, hc[s][1], ph));
+        }
+        double Ph = ph;
+        if (si == CH - 1) {
+            stg.store(rbuf[buf ^ 1], sbuf[buf ^ 1], RP, threadIdx.x);
+            const int rest = len - (ci + 2) * CH;
+            stg.load(rb + (int64_t)(ci + 2) * CH * RP, sb + (ci + 2) * CH, rest < 0 ? 0 : (rest < CH ? rest : CH), RP, threadIdx.x);
+        }
+        if constexpr (NWV > 1) {
+            red[k & 1][w][lane] = ph;
+            TP_BARRIER();
+            Ph = (red[k & 1][0][lane] + red[k & 1][1][lane]) + (red[k & 1][2][lane] + red[k & 1][3][lane]);
+        }
+        double sS = hh * Ph, sm = hh * m;
+        tp_sum2(sS, sm);
+        const double S = sbuf[buf][si * 2 + 1].x + sS, v = s0.y - sm;
+        const double iS = tp_rcp(S);
+        if (threadIdx.x == 0) sval[b * N + n0 + k] = S;          // log |D_n| and the status: tp_finish_kernel, off the chain
+        quad = fma(v * v, iS, quad);
+        const double K = Ph * iS;
+        m = fma(K, v, m);
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const int c0 = 2 * (NWV * s + w);
+            P[s][0] = fma(-K, tp_readlane(Ph, c0), P[s][0]);
+            P[s][1] = fma(-K, tp_readlane(Ph, c0 + 1), P[s][1]);
+        }
+    }
+    if (threadIdx.x == 0) part[b * nseg + seg] = quad;
+}
+
+// log L = -1/2 sum log |D_n| (log D_1: src/celerite_solver.jl:126, 140) - N/2 log 2 pi - 1/2 sum z_n^2 / D_n; one workgroup per draw, fixed order
+__global__ void __launch_bounds__(256) tp_finish_kernel(int64_t N, int nseg, const double* __restrict__ part, const double* __restrict__ sval,
+                                                        double* __restrict__ out, int32_t* __restrict__ status)
+{
+    __shared__ double sh[256];
+    __shared__ int shb[256];
+    const int64_t b = blockIdx.x;
+    double ld = 0.0;
+    int bad = 0;
+    for (int64_t n = threadIdx.x; n < N; n += 256) {
+        const double S = sval[b * N + n];
+        ld += n == 0 ? log(S) : log(fabs(S));
+        bad |= !(S > 0.0);
+    }
+    sh[threadIdx.x] = ld;
+    shb[threadIdx.x] = bad;
+    TP_BARRIER();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[threadIdx.x] += sh[threadIdx.x + o]; shb[threadIdx.x] |= shb[threadIdx.x + o]; }
+        TP_BARRIER();
+    }
+    if (threadIdx.x == 0) {
+        double q = 0.0;
+        for (int s2 = 0; s2 < nseg; ++s2) q += part[b * nseg + s2];
+        const double res = -0.5 * sh[0] - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * q;
+        out[b] = res;
+        if (status) status[b] = !isfinite(res) ? 2 : (shb[0] ? 1 : 0);
+    }
+}
+
+// ---- phase 1 ---------------------------------------------------------------------------------------------------------------------------------
+// A is kept TRANSPOSED (At: lane = column of A): then every product is an in-lane column rotation / a rank-one update with one lane-indexed and one
+// register-indexed (wave-uniform) factor / a matrix-vector sum over the wavefront's columns — tools/time_parallel_proto.py::lane_form_element is this
+// loop in numpy, checked against the textbook composition.  Records as in the filter kernel (one step ahead through LDS).
+template <int NP, int NWV>
+__global__ void __launch_bounds__(64 * NWV) tp_element_kernel(int64_t N, int RP, int nseg, int64_t L, const int32_t* __restrict__ row_kind,
+                                                              const TpRec* __restrict__ rec, const TpStep* __restrict__ stp, double* __restrict__ elem)
+{
+    using Stage = TpStage<NWV>;
+    constexpr int CH = Stage::CH;
+    __shared__ double red[2][2][NWV][64], red2[2][2][NWV][64];     // by step parity: no wavefront is more than one barrier ahead of another
+    __shared__ double2 rbuf[2][CH * Stage::RMAX * 3], sbuf[2][CH * 2];
+    const int lane = threadIdx.x & 63, w = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int seg = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    const int64_t n0 = seg * L, n1 = n0 + L < N ? n0 + L : N;
+    const int len = (int)(n1 - n0);
+    const TpRec* rb = rec + (b * N + n0) * RP;
+    const TpStep* sb = stp + b * N + n0;
+    const int rl = lane < RP ? lane : RP - 1;
+    const bool rowok = lane < RP;
+    const int mykind = row_kind[rl];
+    const double mh = (rowok && (mykind == 0 || mykind == 2)) ? 1.0 : 0.0;
+    double At[NP][2], C[NP][2], Jm[NP][2], hc[NP][2];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+        const int c0 = 2 * (NWV * s + w);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            At[s][k] = (lane == c0 + k && lane < RP) ? 1.0 : 0.0;
+            C[s][k] = 0.0;
+            Jm[s][k] = 0.0;
+            const int kc = row_kind[c0 + k];
+            hc[s][k] = (kc == 0 || kc == 2) ? 1.0 : 0.0;
+        }
+    }
+    double bv = 0.0, eta = 0.0;
+    const bool odd = lane & 1;
+    Stage stg;
+    stg.load(rb, sb, len < CH ? len : CH, RP, threadIdx.x);
+    stg.store(rbuf[0], sbuf[0], RP, threadIdx.x);
+    {
+        const int rest = len - CH;
+        stg.load(rb + (int64_t)CH * RP, sb + CH, rest < 0 ? 0 : (rest < CH ? rest : CH), RP, threadIdx.x);
+    }
+    TP_BARRIER();
+    for (int kk = 0; kk < len; ++kk) {
+        const int ci = kk / CH, si = kk % CH, buf = ci & 1;
+        const double2* rr = rbuf[buf] + si * RP * 3;
+        const double2 mab = rr[rl * 3], mgk = rr[rl * 3 + 1], mq = rr[rl * 3 + 2];
+        const double2 s0 = sbuf[buf][si * 2], s1 = sbuf[buf][si * 2 + 1];
+        const double st_s = s0.x, st_y = s0.y, st_yos = s1.y;
+        const double mal = mab.x, mbe = mab.y;
+        const double mg = rowok ? mgk.x : 0.0, Kr = rowok ? mgk.y : 0.0;
+        double al_[NP][2], be_[NP][2], K_[NP][2];
+        double up = 0.0, ap = 0.0;
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const int c0 = 2 * (NWV * s + w);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double2 ab = rr[(c0 + k) * 3], gk = rr[(c0 + k) * 3 + 1];
+                al_[s][k] = ab.x; be_[s][k] = ab.y; K_[s][k] = gk.y;
+                up = fma(C[s][k], gk.x, up);
+                ap = fma(At[s][k], gk.x, ap);
+            }
+        }
+        double u = up, ag = ap;
+        if (si == CH - 1) {
+            stg.store(rbuf[buf ^ 1], sbuf[buf ^ 1], RP, threadIdx.x);
+            const int rest = len - (ci + 2) * CH;
+            stg.load(rb + (int64_t)(ci + 2) * CH * RP, sb + (ci + 2) * CH, rest < 0 ? 0 : (rest < CH ? rest : CH), RP, threadIdx.x);
+        }
+        if constexpr (NWV > 1) {
+            red[kk & 1][0][w][lane] = up;
+            red[kk & 1][1][w][lane] = ap;
+            TP_BARRIER();
+            u = (red[kk & 1][0][0][lane] + red[kk & 1][0][1][lane]) + (red[kk & 1][0][2][lane] + red[kk & 1][0][3][lane]);
+            ag = (red[kk & 1][1][0][lane] + red[kk & 1][1][1][lane]) + (red[kk & 1][1][2][lane] + red[kk & 1][1][3][lane]);
+        }
+        double gu = mg * u, gb = mg * bv;
+        tp_sum2(gu, gb);
+        const double delta = st_s + gu, idel = tp_rcp(delta);
+        const double agd = ag * idel, ud = u * idel;
+        double xf[NP][2], yv[NP][2];
+        double hfx = 0.0, yh = 0.0;
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const int c0 = 2 * (NWV * s + w);
+            const double u0 = tp_readlane(u, c0), u1 = tp_readlane(u, c0 + 1);
+            const double x0 = fma(-agd, u0, At[s][0]), x1 = fma(-agd, u1, At[s][1]);
+            xf[s][0] = fma(al_[s][0], x0, be_[s][0] * x1);
+            xf[s][1] = fma(al_[s][1], x1, be_[s][1] * x0);
+            hfx = fma(xf[s][0], hc[s][0], fma(xf[s][1], hc[s][1], hfx));
+            const double c_0 = fma(-ud, u0, C[s][0]), c_1 = fma(-ud, u1, C[s][1]);
+            const double r0 = fma(mal, c_0, mbe * tp_partner(c_0)), r1 = fma(mal, c_1, mbe * tp_partner(c_1));
+            yv[s][0] = fma(al_[s][0], r0, be_[s][0] * r1);
+            yv[s][1] = fma(al_[s][1], r1, be_[s][1] * r0);
+            yh = fma(yv[s][0], hc[s][0], fma(yv[s][1], hc[s][1], yh));
+        }
+        double hFX = hfx, Yh = yh;
+        if constexpr (NWV > 1) {
+            red2[kk & 1][0][w][lane] = hfx;
+            red2[kk & 1][1][w][lane] = yh;
+            TP_BARRIER();
+            hFX = (red2[kk & 1][0][0][lane] + red2[kk & 1][0][1][lane]) + (red2[kk & 1][0][2][lane] + red2[kk & 1][0][3][lane]);
+            Yh = (red2[kk & 1][1][0][lane] + red2[kk & 1][1][1][lane]) + (red2[kk & 1][1][2][lane] + red2[kk & 1][1][3][lane]);
+        }
+        double bb = fma(u, st_yos, bv);
+        const double gbb = fma(gu, st_yos, gb);
+        bb = fma(-u, gbb * idel, bb);
+        const double Fb = fma(mal, bb, mbe * tp_partner(bb));
+        double hYh = mh * Yh, hFb = mh * Fb;
+        tp_sum2(hYh, hFb);
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const int jj = NWV * s + w, c0 = 2 * jj;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double Kc = K_[s][k], yhc = tp_readlane(Yh, c0 + k);
+                At[s][k] = fma(-hFX, Kc, xf[s][k]);
+                double cn = yv[s][k] - Kr * yhc - Yh * Kc + Kr * Kc * hYh - Kr * (Kc * st_s);
+                cn += (lane >> 1) == jj ? ((odd == (k == 1)) ? mq.x : mq.y) : 0.0;
+                C[s][k] = cn;
+                Jm[s][k] = fma(agd, tp_readlane(ag, c0 + k), Jm[s][k]);
+            }
+        }
+        eta = fma(ag, (st_y - gb) * idel, eta);
+        bv = fma(Kr, st_y - hFb, Fb);
+    }
+    double* e = elem + (b * nseg + seg) * TP_ELEM_DOUBLES;
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+        const int c0 = 2 * (NWV * s + w);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            e[lane * 64 + c0 + k] = At[s][k];
+            e[4096 + lane * 64 + c0 + k] = C[s][k];
+            e[8192 + lane * 64 + c0 + k] = Jm[s][k];
+        }
+    }
+    if (w == 0) { e[12288 + lane] = bv; e[12288 + 64 + lane] = eta; }
+}
+
+// ---- phase 2 ---------------------------------------------------------------------------------------------------------------------------------
+// (m, P) at the start of segment p + 1 from (m, P) at the start of segment p and the element of segment p:
+//     [z | Z] = (I + P J)^-1 [m + P eta | P],   m' = A z + b,   P' = A Z A' + C.
+// One workgroup per draw.  W = I + P J and the right-hand sides in LDS; Gauss-Jordan elimination with partial pivoting WITHOUT row exchanges (the
+// pivot of column k is the largest entry among the rows not used yet; the row keeps its place and remembers its column): one barrier per pivot.
+// (I + P J is the identity plus a product of two symmetric positive semi-definite matrices: not symmetric, eigenvalues >= 1.)
+// Thread (lane = row, wavefront = every fourth column).  The products run over the RP live rows only.
+__global__ void __launch_bounds__(256) tp_boundary_kernel(int RP, int nseg, int J, const int32_t* __restrict__ row_term, const int32_t* __restrict__ row_kind,
+                                                          const double* __restrict__ A_, const double* __restrict__ Bc_, const double* __restrict__ elem,
+                                                          double* __restrict__ bnd)
+{
+    extern __shared__ double lds[];
+    const int S1 = RP + 1, LW = 2 * RP + 3;      // odd strides
+    double* X = lds;                     // [RP][LW]: [W, later A Z | right-hand sides z (1), Z (RP)]
+    double* Pm = X + RP * LW;            // [RP][S1]: P, later Z, then P'
+    double* JL = Pm + RP * S1;           // J
+    double* AL = JL + RP * S1;           // A' (as stored: AL[k][r] = A[r][k])
+    double* CL = AL + RP * S1;           // C
+    double* mv = CL + RP * S1;           // [64] m, later z
+    double* ev = mv + 64;                // [64] eta
+    double* bl = ev + 64;                // [64] b
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b = blockIdx.x;
+    double* bs = bnd + b * nseg * TP_BND_DOUBLES;
+    const int NC = 2 * RP + 1;           // live columns of [W | z | Z], packed: W 0 .. RP-1, z RP, Z RP+1 .. 2 RP
+    // entry i = tid + 256 q of an RP x RP matrix: (row, col) = (i / RP, i % RP) — consecutive lanes, consecutive columns
+    const int nq = (RP * RP + 255) / 256;      // <= 9 at the 48 rows this kernel takes
+    constexpr int NQ = 9;
+    int row[NQ], col[NQ];
+    bool ok[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = tid + 256 * q;
+        ok[q] = q < nq && i < RP * RP;
+        row[q] = ok[q] ? i / RP : 0;
+        col[q] = ok[q] ? i % RP : 0;
+    }
+    // An element's matrices (J, A', C, eta, b) come through registers with ONE point of use per boundary: the top of the iteration copies element p
+    // into LDS and the loads of element p + 1 are issued right behind it — they have the whole iteration.  (The compiler waits with vmcnt(0) at
+    // every use of a loaded register: with the uses spread over the iteration each one also waited for the loads just issued, ~2 us three times
+    // per boundary, 6 us per boundary at four rows whatever else was tuned.)
+    double rj[NQ], ra[NQ], rc[NQ], reta = 0.0, rb = 0.0;
+    auto fetch_elem = [&](const double* e) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int o = row[q] * 64 + col[q];
+            rj[q] = ok[q] ? e[8192 + o] : 0.0;
+            ra[q] = ok[q] ? e[o] : 0.0;
+            rc[q] = ok[q] ? e[4096 + o] : 0.0;
+        }
+        if (tid < RP) { reta = e[12288 + 64 + tid]; rb = e[12288 + tid]; }
+    };
+    if (nseg > 1) fetch_elem(elem + b * nseg * TP_ELEM_DOUBLES);
+    double pn[NQ], mnew = 0.0;
+    auto publish = [&](int pb) __attribute__((always_inline)) {
+        double* bo = bs + (int64_t)pb * TP_BND_DOUBLES;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (ok[q]) bo[64 + row[q] * 64 + col[q]] = pn[q];
+        if (tid < RP) bo[tid] = mnew;
+    };
+    // the prior: m = 0, P = P_inf (the boundary states' rows and columns past RP are zero: the launcher clears the buffer)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (ok[q]) {
+            const int r = row[q], c = col[q];
+            double v = 0.0;
+            const int kr = row_kind[r], kc = row_kind[c];
+            if (kr != 3 && kc != 3) {
+                if (r == c) v = A_[b * J + row_term[r]];
+                else if ((r ^ 1) == c && kr < 2 && kc < 2) v = -Bc_[b * J + row_term[r]];
+            }
+            Pm[r * S1 + c] = v;
+            bs[64 + r * 64 + c] = v;
+        }
+    }
+    if (tid < 64) mv[tid] = 0.0;
+    TP_BARRIER();
+    for (int p = 0; p + 1 < nseg; ++p) {
+        const double* e = elem + (b * nseg + p) * TP_ELEM_DOUBLES;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (ok[q]) {
+                const int o = row[q] * S1 + col[q];
+                JL[o] = rj[q];
+                AL[o] = ra[q];
+                CL[o] = rc[q];
+            }
+        }
+        if (tid < RP) { ev[tid] = reta; bl[tid] = rb; }
+        if (p + 2 < nseg) fetch_elem(e + TP_ELEM_DOUBLES);
+        if (p > 0) publish(p);       // (the state this iteration starts from: its stores, too, have the iteration — vmcnt counts them)
+        TP_BARRIER();
+        // W = I + P J, z = m + P eta, Z = P
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (ok[q]) {
+                const int r = row[q], c = col[q];
+                double acc = r == c ? 1.0 : 0.0;
+#pragma unroll 8
+                for (int k = 0; k < RP; ++k) acc = fma(Pm[r * S1 + k], JL[k * S1 + c], acc);
+                X[r * LW + c] = acc;
+                X[r * LW + RP + 1 + c] = Pm[r * S1 + c];
+            }
+        }
+        if (tid < RP) {
+            double acc = mv[tid];
+#pragma unroll 8
+            for (int k = 0; k < RP; ++k) acc = fma(Pm[tid * S1 + k], ev[k], acc);
+            X[tid * LW + RP] = acc;
+        }
+        TP_BARRIER();
+        bool used = lane >= RP;
+        int mycol = 0;
+        const int lr = lane < RP ? lane : 0;
+        for (int k = 0; k < RP; ++k) {
+            const double xk = X[lr * LW + k];
+            const double cand = used ? -1.0 : fabs(xk);
+            const double mx = tp_max(cand);
+            const unsigned long long bal = __ballot(cand == mx);
+            const int pr = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(bal));
+            const double ipv = tp_rcp(X[pr * LW + k]);
+            const double f = (lane == pr || lane >= RP) ? 0.0 : xk * ipv;
+            if (lane == pr) { used = true; mycol = k; }
+            // (reads of a batch before its writes: a write-then-read chain per column costs an LDS round trip each)
+            if (lane < RP) {
+                for (int c = k + 1 + w; c < NC; c += 32) {
+                    double pv[8], xv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int cc = c + 4 * i < NC ? c + 4 * i : c;
+                        pv[i] = X[pr * LW + cc];
+                        xv[i] = X[lane * LW + cc];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (c + 4 * i < NC) X[lane * LW + c + 4 * i] = fma(-f, pv[i], xv[i]);
+                }
+            }
+            TP_BARRIER();
+        }
+        // row `lane` solved column mycol: [z | Z][mycol] = its right-hand sides / its pivot.  Z into Pm (P is dead), z into mv.
+        if (lane < RP) {
+            const double ipv = tp_rcp(X[lane * LW + mycol]);
+            for (int c = w; c < RP; c += 4) Pm[mycol * S1 + c] = X[lane * LW + RP + 1 + c] * ipv;
+            if (w == 0) mv[mycol] = X[lane * LW + RP] * ipv;
+        }
+        TP_BARRIER();
+        // m' = A z + b; T = A Z (into X, columns 0 .. RP-1); P' = T A' + C.  A[r][k] = AL[k][r].
+        if (tid < RP) {
+            double acc = bl[tid];
+#pragma unroll 8
+            for (int k = 0; k < RP; ++k) acc = fma(AL[k * S1 + tid], mv[k], acc);
+            mnew = acc;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (ok[q]) {
+                const int r = row[q], c = col[q];
+                double acc = 0.0;
+#pragma unroll 8
+                for (int k = 0; k < RP; ++k) acc = fma(AL[k * S1 + r], Pm[k * S1 + c], acc);
+                X[r * LW + c] = acc;
+            }
+        }
+        TP_BARRIER();
+        if (tid < RP) mv[tid] = mnew;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            pn[q] = 0.0;
+            if (ok[q]) {
+                const int r = row[q], c = col[q];
+                double acc = CL[r * S1 + c];
+#pragma unroll 8
+                for (int k = 0; k < RP; ++k) acc = fma(X[r * LW + k], AL[k * S1 + c], acc);
+                pn[q] = acc;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (ok[q]) Pm[row[q] * S1 + col[q]] = pn[q];
+        TP_BARRIER();
+        // symmetrise (the two products round differently); published at the top of the next iteration
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (ok[q]) pn[q] = 0.5 * (pn[q] + Pm[col[q] * S1 + row[q]]);
+        TP_BARRIER();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (ok[q]) Pm[row[q] * S1 + col[q]] = pn[q];
+        TP_BARRIER();
+    }
+    if (nseg > 1) publish(nseg - 1);
+}
+
+template <int NP, int NWV>
+int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream)
+{
+    const int64_t B = p.B, N = p.N;
+    TpRec* rec = reinterpret_cast<TpRec*>(work);
+    TpStep* stp = reinterpret_cast<TpStep*>(work + (size_t)B * N * RP * 6);
+    double* sval = work + (size_t)B * N * RP * 6 + (size_t)B * N * 4;
+    double* elem = sval + (size_t)B * N;
+    double* bnd = elem + (size_t)B * nseg * TP_ELEM_DOUBLES;
+    double* part = bnd + (size_t)B * nseg * TP_BND_DOUBLES;
+    if (hipMemsetAsync(bnd, 0, (size_t)B * nseg * TP_BND_DOUBLES * sizeof(double), stream) != hipSuccess) return PIORAN_ERR_HIP;
+    hipLaunchKernelGGL(tp_records_kernel, dim3((unsigned)N, (unsigned)B), dim3(64), 0, stream, N, RP, p.J, row_term, row_kind, p.t, p.y, p.s2, p.Y, p.S2, p.A,
+                       p.Bc, p.C, p.D, p.mu, p.nu, rec, stp);
+    if (nseg > 1)
+        hipLaunchKernelGGL((tp_element_kernel<NP, NWV>), dim3((unsigned)(nseg - 1), (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
+                           (const TpRec*)rec, (const TpStep*)stp, elem);
+    const size_t lds2 = ((size_t)RP * (2 * RP + 3) + 4 * (size_t)RP * (RP + 1) + 192) * sizeof(double);
+    static size_t granted[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
+    if (lds2 > granted[dev]) {
+        if (hipFuncSetAttribute((const void*)tp_boundary_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return PIORAN_ERR_HIP;
+        granted[dev] = lds2;
+    }
+    hipLaunchKernelGGL(tp_boundary_kernel, dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
+    hipLaunchKernelGGL((tp_filter_kernel<NP, NWV>), dim3((unsigned)nseg, (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
+                       (const TpRec*)rec, (const TpStep*)stp, (const double*)bnd, part, sval);
+    hipLaunchKernelGGL(tp_finish_kernel, dim3((unsigned)B), dim3(256), 0, stream, N, nseg, (const double*)part, (const double*)sval, p.out, p.status);
+    return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
+}
+
+}  // namespace
+
+int pioran_tp_supported_rows() { return 48; }     // (tp_boundary_kernel's LDS: five R x R matrices and the 2 R + 1 columns of the solve)
+
+// state rows as the kernels want them: a multiple of 2 up to 16 rows (one wavefront per segment), of 8 above (four)
+int pioran_tp_padded_rows(int rows) { return rows <= 16 ? (rows + 1) & ~1 : (rows + 7) & ~7; }
+
+size_t pioran_tp_workspace_doubles(int64_t B, int64_t N, int RP, int nseg)
+{
+    return (size_t)B * N * RP * 6 + (size_t)B * N * 5 + (size_t)B * nseg * (TP_ELEM_DOUBLES + TP_BND_DOUBLES + 1);
+}
+
+// RP = pioran_tp_padded_rows(rows) state rows in the layout of row_term / row_kind (device arrays, [RP]; kind 3 = padding); nseg segments of L steps
+// (the last one shorter)
+int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream)
+{
+    if (RP < 2 || RP > 48 || RP != pioran_tp_padded_rows(RP) || nseg < 1 || L < 2 || (int64_t)nseg * L < p.N || (int64_t)(nseg - 1) * L >= p.N || p.B < 1 ||
+        p.B > 65535 || p.N > 0x7fffffffLL)
+        return PIORAN_ERR_UNSUPPORTED;
+    if (RP <= 16) {
+        switch (RP / 2) {
+            case 1: return tp_launch<1, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
+            case 2: return tp_launch<2, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
+            case 3: return tp_launch<3, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
+            case 4: return tp_launch<4, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
+            case 5: return tp_launch<5, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
+            case 6: return tp_launch<6, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
+            case 7: return tp_launch<7, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
+            case 8: return tp_launch<8, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
+        }
+        return PIORAN_ERR_UNSUPPORTED;
+    }
+    switch (RP / 8) {
+        case 3: return tp_launch<3, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
+        case 4: return tp_launch<4, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
+        case 5: return tp_launch<5, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
+        case 6: return tp_launch<6, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
+    }
+    return PIORAN_ERR_UNSUPPORTED;
+}

@@ -28,6 +28,8 @@ struct DenseOptions {
 struct ScanOptions {
     char scan_config[48];   // "" automatic; "wide" / "block": that small-batch kernel for any batch size; else a throughput configuration's name
     bool no_wide, no_paired, no_mixed, force_fallback, no_block;
+    bool force_tp, no_tp;       // celerite_tp.hip (time-parallel evaluation of a handful of draws): force (scan_config "tp") / forbid
+    int tp_segments = 0;        // ... its segment count (0 = automatic)
     bool force_tile, no_tile;   // celerite_tile.hip (windowed form, one draw per wavefront; default from 49 rows on above the small-batch range): force / forbid
     bool no_split;        // never send the remainder of a multi-pass batch to the windowed kernel on the second stream (capi.hip split_dispatch)
     bool win3, no_win3;   // throughput layouts with two / three rows per lane: force / forbid the three-step form (celerite_scan.hip;
@@ -166,6 +168,11 @@ size_t pioran_tile_workspace_doubles(int64_t B, int64_t N);
 int pioran_launch_scan_tile(const ScanParams& p, const double* btab, double* work, hipStream_t stream);
 // ... its reverse mode: log L and d/d(a, b, mu, nu), one draw per wavefront (1 .. 63 rows; shared (c, d) and series)
 int pioran_tile_grad_supported_rows();
+// celerite_tp.hip: time-parallel evaluation for a handful of draws (state-space form, associative filter elements; round 5)
+int pioran_tp_supported_rows();
+int pioran_tp_padded_rows(int rows);
+size_t pioran_tp_workspace_doubles(int64_t B, int64_t N, int RP, int nseg);
+int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream);
 size_t pioran_tile_grad_workspace_doubles(int64_t B, int64_t N, int32_t R);
 int pioran_launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab, double* pairs, double* grad_a, double* grad_b, double* grad_nu,
                             double* grad_mu, hipStream_t stream);

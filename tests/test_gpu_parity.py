@@ -8,6 +8,9 @@ import ctypes
 import json
 import os
 
+import sys
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -401,13 +404,27 @@ def test_fewer_than_six_rows_long_series_and_scalar_call(ctx, J, nreal):
         if nreal:
             Bc[:, -nreal:] = 0.0; Dd[-nreal:] = 0.0
         ds = pj.Dataset(t, y, s2, ctx)
-        got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
-        assert name() == ("block" if (R == 5 or N >= 16384) else "scan"), (name(), R, N)
         ref = np.array([O.logl(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2) for i in range(B)])
+        # round 5: up to 8 draws of a long series take the time-parallel family (celerite_tp.hip) — from 2048 steps on at up to 4 state rows, from
+        # 4096 at up to 8; the serial-chain kernels this test is about are what "no_tp" leaves
+        tp_takes = N >= (2048 if R <= 4 else 4096)
+        got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert (name() == "tp") == tp_takes, (name(), R, N)
         assert relerr(got, ref) < 1e-10
+        try:
+            ctx.set_option("no_tp", True)
+            got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+            assert name() == ("block" if (R == 5 or N >= 16384) else "scan"), (name(), R, N)
+            assert relerr(got, ref) < 1e-10
+            if B == 1:
+                one = ctx.logl(A[0], Bc[0], C, Dd, t, y - mu[0], nu[0] * s2)
+                assert name() == ("block" if (R == 5 or N >= 2048) else "scan"), (name(), R, N)
+                assert abs(one - ref[0]) <= 1e-10 * max(1.0, abs(ref[0]))
+        finally:
+            ctx.set_option("no_tp", False)
         if B == 1:
             one = ctx.logl(A[0], Bc[0], C, Dd, t, y - mu[0], nu[0] * s2)
-            assert name() == ("block" if (R == 5 or N >= 2048) else "scan"), (name(), R, N)
+            assert (name() == "tp") == tp_takes, (name(), R, N)
             assert abs(one - ref[0]) <= 1e-10 * max(1.0, abs(ref[0]))
         ds.close()
 
@@ -1950,6 +1967,89 @@ def test_windowed_gradient_matches_complex_step(ctx, J, N, B, nreal):
         ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2, series=True)
         assert np.max(np.abs(gs["grad_y"][i] - ref["grad_y"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_y"])))
         assert np.max(np.abs(gs["grad_sigma2"][i] - nu[i] * ref["grad_sigma2"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_sigma2"])))
+
+
+# ---- time-parallel evaluation of a handful of draws (celerite_tp.hip, round 5) -----------------------------------------------------------------
+@pytest.mark.parametrize("J,N,B,nreal,nseg", [(1, 100, 1, 0, 2), (1, 100, 1, 1, 2), (2, 200, 1, 0, 4), (3, 500, 2, 1, 5), (6, 300, 3, 0, 0), (8, 640, 2, 0, 7),
+                                              (9, 400, 4, 4, 6), (12, 2000, 8, 3, 0), (20, 1000, 2, 0, 8), (20, 777, 1, 0, 3), (21, 500, 1, 20, 5),
+                                              (24, 640, 2, 0, 4), (5, 64, 1, 0, 4), (4, 333, 64, 0, 3)])
+def test_time_parallel_family_vs_oracle(ctx, J, N, B, nreal, nseg):
+    """The state-space / associative-element form (segments of the series on different CUs), forced at every shape it takes: one wavefront per
+    segment (up to 16 state rows) and four (up to 48), one-row terms packed in pairs, padded row counts, segment counts that do not divide N, the
+    shortest segments (16 steps), 64 draws.  Against the oracle at 1e-11 (the prototype's study: profiles/r05_time_parallel_proto.txt)."""
+    rng = np.random.default_rng(3300 + J + N)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    Dd = np.maximum(Dd, 0.05)
+    Bc[:, :nreal] = 0.0; Dd[:nreal] = 0.0
+    ds = pj.Dataset(t, y, s2, ctx)
+    ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+    try:
+        ctx.set_option("scan_config", "tp"); ctx.set_option("tp_segments", nseg)
+        got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        assert pj._lib.lib().pioran_celerite_config_name(-1).decode() == "tp"
+        one = ds.logl_batch(A[:1], Bc[:1], C, Dd)                 # no mu, no nu
+    finally:
+        ctx.set_option("scan_config", None); ctx.set_option("tp_segments", 0)
+    assert relerr(got, ref) < 1e-11 and (st == 0).all()
+    assert relerr(one, O.logl_batch(A[:1], Bc[:1], C, Dd, t, y, s2, None, None)) < 1e-11
+
+
+def test_time_parallel_dispatch_reference_values_and_flagged_draws(ctx, golden_dir):
+    """(i) The automatic choice: up to 8 draws, up to 16 state rows, long series; "no_tp" and everything else stay on the serial-chain kernels.
+    (ii) Values the REFERENCE computed (stored ultranest run, N = 242, SHO-20: 40 rows, four wavefronts per segment), forced.
+    (iii) A draw that is not positive definite: the status and the log |D_n| semantics of the other families (src/celerite_solver.jl:126, 140).
+    (iv) Per-draw series (Y, S2)."""
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    rng = np.random.default_rng(515)
+    N, J, B = 8192, 2, 3
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    ds = pj.Dataset(t, y, s2, ctx)
+    ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+    got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    assert name() == "tp" and relerr(got, ref) < 1e-11
+    try:
+        ctx.set_option("no_tp", True)
+        chain = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert name() != "tp" and relerr(chain, ref) < 1e-11
+    finally:
+        ctx.set_option("no_tp", False)
+    A9 = np.tile(A, (3, 1)); B9 = np.tile(Bc, (3, 1))
+    ds.logl_batch(A9, B9, C, Dd)
+    assert name() != "tp"                                           # nine draws
+    ds2 = pj.Dataset(t[:1500], y[:1500], s2[:1500], ctx)
+    ds2.logl_batch(A, Bc, C, Dd)
+    assert name() != "tp"                                           # a short series
+    # (iv) per-draw series
+    Y = y[None, :] + 0.01 * rng.standard_normal((B, N)); S2 = s2[None, :] * rng.uniform(0.8, 1.2, (B, 1))
+    gy = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+    assert name() == "tp"
+    ry = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(B)])
+    assert relerr(gy, ry) < 1e-11
+    # (iii)
+    A2 = A.copy(); A2[1, 0] = -40.0
+    gb, sb = ds.logl_batch(A2, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+    assert name() == "tp"
+    rb, rs = O.logl_batch(A2, Bc, C, Dd, t, y, s2, mu, nu, return_status=True)
+    assert sb[1] != 0 and rs[1] != 0 and sb[0] == 0 and sb[2] == 0
+    assert relerr(gb[[0, 2]], rb[[0, 2]]) < 1e-11
+    assert (np.isnan(gb[1]) and np.isnan(rb[1])) or abs(gb[1] - rb[1]) <= 1e-6 * abs(rb[1])
+    # (ii)
+    un = np.load(golden_dir / "ultranest_points.npz")
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_oracle import _un_inputs
+    try:
+        ctx.set_option("scan_config", "tp")
+        worst = 0.0
+        for i in np.linspace(0, len(un["logl"]) - 1, 40).astype(int):
+            a, b, c, d, tt, yy, ss = _un_inputs(un, i)
+            dsu = pj.Dataset(tt, yy, ss, ctx)
+            g = dsu.logl_batch(a[None, :], b[None, :], c, d)[0]
+            assert name() == "tp"
+            worst = max(worst, abs(g - un["logl"][i]) / abs(un["logl"][i]))
+            dsu.close()
+    finally:
+        ctx.set_option("scan_config", None)
+    assert worst < 1e-10, worst
 
 
 TILE_GRAD = "tile (windowed gradient, one draw per wavefront)"

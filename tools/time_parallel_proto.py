@@ -160,6 +160,60 @@ class StateSpace:
         return -0.5 * ld - 0.5 * N * LOG2PI - 0.5 * q, states
 
 
+def lane_form_tables(a, b, c, d, t, s2):
+    """What the GPU kernels read per step (celerite_tp.hip): co, si = e^{-c dt} (cos, sin)(d dt), gam = -expm1(-2 c dt) per term; step 0 is the prior
+    as 'filtered state before the first step' (F = I, Q = 0).  Q_j = [[a gam - 2 b co si, -b (gam + 2 si^2)], [., a gam + 2 b co si]] — no
+    subtraction of nearly equal numbers at small c dt."""
+    dt = np.diff(t, prepend=t[0])
+    ec = np.exp(-np.outer(dt, c))
+    co, si = ec * np.cos(np.outer(dt, d)), ec * np.sin(np.outer(dt, d))
+    gam = -np.expm1(-2.0 * np.outer(dt, c))
+    return co, si, gam
+
+
+def lane_form_element(a, b, c, d, t, y, s2, n0, n1):
+    """The segment element in the form the GPU kernel composes it (A kept transposed; every product a rotation of adjacent rows / columns, a
+    rank-one update, or a matrix-vector sum): checked here against StateSpace.segment_element."""
+    J = len(a); R = 2 * J
+    co, si, gam = lane_form_tables(a, b, c, d, t, s2)
+    par = np.arange(R) & 1; term = np.arange(R) >> 1
+    At = np.eye(R); C = np.zeros((R, R)); Jm = np.zeros((R, R)); bv = np.zeros(R); eta = np.zeros(R)
+    ev = par == 0
+
+    def rot_cols(X, al, be):      # X F': column r <- al_r X[:, r] + be_r X[:, r ^ 1]
+        return X * al[None, :] + X[:, np.arange(R) ^ 1] * be[None, :]
+
+    def rot_rows(X, al, be):
+        return X * al[:, None] + X[np.arange(R) ^ 1, :] * be[:, None]
+    for n in range(n0, n1):
+        al = co[n][term]; be = np.where(ev, -si[n][term], si[n][term])
+        g = np.where(ev, co[n][term], -si[n][term])
+        q00 = a * gam[n] - 2 * b * co[n] * si[n]; q01 = -b * (gam[n] + 2 * si[n] ** 2); q11 = a * gam[n] + 2 * b * co[n] * si[n]
+        Qh = np.where(ev, q00[term], q01[term])
+        s = q00.sum() + s2[n]
+        K = Qh / s
+        yj = y[n]
+        u = C @ g; delta = s + g @ u; ag = At @ g; gb = g @ bv
+        Xt = At - np.outer(ag, u) / delta
+        XtF = rot_cols(Xt, al, be)
+        hFX = XtF[:, ev].sum(axis=1)
+        At_new = XtF - np.outer(hFX, K)
+        bb = bv + u * (yj / s); bb = bb - u * ((g @ bb) / delta)
+        Fb = al * bb + be * bb[np.arange(R) ^ 1]
+        b_new = Fb - K * Fb[ev].sum() + K * yj
+        Cm = C - np.outer(u, u) / delta
+        Y = rot_cols(rot_rows(Cm, al, be), al, be)
+        Yh = Y[:, ev].sum(axis=1); hYh = Yh[ev].sum()
+        Qd = np.zeros((R, R))
+        for j in range(J):
+            Qd[2 * j, 2 * j] = q00[j]; Qd[2 * j + 1, 2 * j + 1] = q11[j]; Qd[2 * j, 2 * j + 1] = Qd[2 * j + 1, 2 * j] = q01[j]
+        C = Y - np.outer(K, Yh) - np.outer(Yh, K) + np.outer(K, K) * hYh + Qd - np.outer(K, Qh)
+        eta = eta + ag * ((yj - gb) / delta)
+        Jm = Jm + np.outer(ag, ag) / delta
+        At, bv = At_new, b_new
+    return At.T, bv, C, eta, Jm
+
+
 def rel(a, b):
     return abs(a - b) / abs(b)
 
