@@ -644,6 +644,18 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
         t0 = time.perf_counter(); rg_ = O.logl(ag, bg, cg, dg, tg, yg, eg); cpu_ms = (time.perf_counter() - t0) * 1e3
         grid[f"j{jg}"] = {"scalar_call_ms_incl_pcie": med(wall) * 1e3, "kernel": kern, "reference_figure_ms": published_ms[jg],
                           "cpu_one_core_ms_this_host": cpu_ms, "rel_dlogl_vs_oracle": abs(vg - rg_) / abs(rg_)}
+        if kern == "tp":      # the time-parallel family (celerite_tp.hip, round 5) took it: the serial-chain kernel it replaced, same call
+            ctx.set_option("no_tp", True)
+            try:
+                ctx.logl(ag, bg, cg, dg, tg, yg, eg)
+                kser = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+                wser = []
+                for _ in range(5):
+                    t0 = time.perf_counter(); ctx.logl(ag, bg, cg, dg, tg, yg, eg); wser.append(time.perf_counter() - t0)
+            finally:
+                ctx.set_option("no_tp", False)
+            grid[f"j{jg}"]["serial_chain_ms_incl_pcie"] = med(wser) * 1e3
+            grid[f"j{jg}"]["serial_chain_kernel"] = kser
     out["reference_benchmark_grid_N8192"] = grid
 
     # -- small batches (MCMC walkers / a few live points): one workgroup per draw, the same windowed kernel --------------

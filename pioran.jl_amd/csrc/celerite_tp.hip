@@ -36,6 +36,11 @@ struct __attribute__((aligned(32))) TpStep { double s, y, s2, yos; };           
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load in flight (s_waitcnt vmcnt(0)): the records and the
 // element matrices are loaded a chunk / a boundary AHEAD on purpose, and each barrier made them arrive first — ~2 us per load point (6 us per boundary at
 // four rows).  All data that passes between the threads of these kernels passes through LDS.
+#define TP_SYNC()                                       \
+    do {                                                \
+        if constexpr (TW == 1) asm volatile("" ::: "memory"); \
+        else TP_BARRIER();                              \
+    } while (0)
 #define TP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 constexpr int TP_ELEM_DOUBLES = (3 * 64 + 2) * 64;     // A' | C | J (64 x 64 each, row-major, rows = lanes), b, eta
@@ -435,7 +440,8 @@ __global__ void __launch_bounds__(64 * NWV) tp_element_kernel(int64_t N, int RP,
 // pivot of column k is the largest entry among the rows not used yet; the row keeps its place and remembers its column): one barrier per pivot.
 // (I + P J is the identity plus a product of two symmetric positive semi-definite matrices: not symmetric, eigenvalues >= 1.)
 // Thread (lane = row, wavefront = every fourth column).  The products run over the RP live rows only.
-__global__ void __launch_bounds__(256) tp_boundary_kernel(int RP, int nseg, int J, const int32_t* __restrict__ row_term, const int32_t* __restrict__ row_kind,
+template <int TW>      // wavefronts: 4, or 1 up to 16 rows (no barrier at all: LDS traffic of one wavefront is served in order)
+__global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, int J, const int32_t* __restrict__ row_term, const int32_t* __restrict__ row_kind,
                                                           const double* __restrict__ A_, const double* __restrict__ Bc_, const double* __restrict__ elem,
                                                           double* __restrict__ bnd)
 {
@@ -449,18 +455,19 @@ __global__ void __launch_bounds__(256) tp_boundary_kernel(int RP, int nseg, int 
     double* mv = CL + RP * S1;           // [64] m, later z
     double* ev = mv + 64;                // [64] eta
     double* bl = ev + 64;                // [64] b
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int T = 64 * TW;
+    const int tid = threadIdx.x, lane = tid & 63, w = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t b = blockIdx.x;
     double* bs = bnd + b * nseg * TP_BND_DOUBLES;
     const int NC = 2 * RP + 1;           // live columns of [W | z | Z], packed: W 0 .. RP-1, z RP, Z RP+1 .. 2 RP
-    // entry i = tid + 256 q of an RP x RP matrix: (row, col) = (i / RP, i % RP) — consecutive lanes, consecutive columns
-    const int nq = (RP * RP + 255) / 256;      // <= 9 at the 48 rows this kernel takes
-    constexpr int NQ = 9;
+    // entry i = tid + T q of an RP x RP matrix: (row, col) = (i / RP, i % RP) — consecutive lanes, consecutive columns
+    const int nq = (RP * RP + T - 1) / T;      // <= 9 at the 48 rows four wavefronts take, 4 at the 16 of one
+    constexpr int NQ = TW == 1 ? 4 : 9;
     int row[NQ], col[NQ];
     bool ok[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int i = tid + 256 * q;
+        const int i = tid + T * q;
         ok[q] = q < nq && i < RP * RP;
         row[q] = ok[q] ? i / RP : 0;
         col[q] = ok[q] ? i % RP : 0;
@@ -505,7 +512,7 @@ __global__ void __launch_bounds__(256) tp_boundary_kernel(int RP, int nseg, int 
         }
     }
     if (tid < 64) mv[tid] = 0.0;
-    TP_BARRIER();
+    TP_SYNC();
     for (int p = 0; p + 1 < nseg; ++p) {
         const double* e = elem + (b * nseg + p) * TP_ELEM_DOUBLES;
 #pragma unroll
@@ -520,7 +527,7 @@ __global__ void __launch_bounds__(256) tp_boundary_kernel(int RP, int nseg, int 
         if (tid < RP) { ev[tid] = reta; bl[tid] = rb; }
         if (p + 2 < nseg) fetch_elem(e + TP_ELEM_DOUBLES);
         if (p > 0) publish(p);       // (the state this iteration starts from: its stores, too, have the iteration — vmcnt counts them)
-        TP_BARRIER();
+        TP_SYNC();
         // W = I + P J, z = m + P eta, Z = P
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -539,7 +546,7 @@ __global__ void __launch_bounds__(256) tp_boundary_kernel(int RP, int nseg, int 
             for (int k = 0; k < RP; ++k) acc = fma(Pm[tid * S1 + k], ev[k], acc);
             X[tid * LW + RP] = acc;
         }
-        TP_BARRIER();
+        TP_SYNC();
         bool used = lane >= RP;
         int mycol = 0;
         const int lr = lane < RP ? lane : 0;
@@ -554,28 +561,28 @@ __global__ void __launch_bounds__(256) tp_boundary_kernel(int RP, int nseg, int 
             if (lane == pr) { used = true; mycol = k; }
             // (reads of a batch before its writes: a write-then-read chain per column costs an LDS round trip each)
             if (lane < RP) {
-                for (int c = k + 1 + w; c < NC; c += 32) {
+                for (int c = k + 1 + w; c < NC; c += 8 * TW) {
                     double pv[8], xv[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const int cc = c + 4 * i < NC ? c + 4 * i : c;
+                        const int cc = c + TW * i < NC ? c + TW * i : c;
                         pv[i] = X[pr * LW + cc];
                         xv[i] = X[lane * LW + cc];
                     }
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        if (c + 4 * i < NC) X[lane * LW + c + 4 * i] = fma(-f, pv[i], xv[i]);
+                        if (c + TW * i < NC) X[lane * LW + c + TW * i] = fma(-f, pv[i], xv[i]);
                 }
             }
-            TP_BARRIER();
+            TP_SYNC();
         }
         // row `lane` solved column mycol: [z | Z][mycol] = its right-hand sides / its pivot.  Z into Pm (P is dead), z into mv.
         if (lane < RP) {
             const double ipv = tp_rcp(X[lane * LW + mycol]);
-            for (int c = w; c < RP; c += 4) Pm[mycol * S1 + c] = X[lane * LW + RP + 1 + c] * ipv;
+            for (int c = w; c < RP; c += TW) Pm[mycol * S1 + c] = X[lane * LW + RP + 1 + c] * ipv;
             if (w == 0) mv[mycol] = X[lane * LW + RP] * ipv;
         }
-        TP_BARRIER();
+        TP_SYNC();
         // m' = A z + b; T = A Z (into X, columns 0 .. RP-1); P' = T A' + C.  A[r][k] = AL[k][r].
         if (tid < RP) {
             double acc = bl[tid];
@@ -593,7 +600,7 @@ __global__ void __launch_bounds__(256) tp_boundary_kernel(int RP, int nseg, int 
                 X[r * LW + c] = acc;
             }
         }
-        TP_BARRIER();
+        TP_SYNC();
         if (tid < RP) mv[tid] = mnew;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -609,16 +616,16 @@ __global__ void __launch_bounds__(256) tp_boundary_kernel(int RP, int nseg, int 
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
             if (ok[q]) Pm[row[q] * S1 + col[q]] = pn[q];
-        TP_BARRIER();
+        TP_SYNC();
         // symmetrise (the two products round differently); published at the top of the next iteration
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
             if (ok[q]) pn[q] = 0.5 * (pn[q] + Pm[col[q] * S1 + row[q]]);
-        TP_BARRIER();
+        TP_SYNC();
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
             if (ok[q]) Pm[row[q] * S1 + col[q]] = pn[q];
-        TP_BARRIER();
+        TP_SYNC();
     }
     if (nseg > 1) publish(nseg - 1);
 }
@@ -640,14 +647,20 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
         hipLaunchKernelGGL((tp_element_kernel<NP, NWV>), dim3((unsigned)(nseg - 1), (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
                            (const TpRec*)rec, (const TpStep*)stp, elem);
     const size_t lds2 = ((size_t)RP * (2 * RP + 3) + 4 * (size_t)RP * (RP + 1) + 192) * sizeof(double);
-    static size_t granted[64] = {};
+    static size_t granted[2][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
-    if (lds2 > granted[dev]) {
-        if (hipFuncSetAttribute((const void*)tp_boundary_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return PIORAN_ERR_HIP;
-        granted[dev] = lds2;
+    // one wavefront (no barriers) up to 4 rows: 4.2 against 5.2 us per boundary; at 16 rows its products cost more than the barriers (27 against 15 us)
+    const bool one = RP <= 4;
+    if (lds2 > granted[one][dev]) {
+        const void* fn = one ? (const void*)tp_boundary_kernel<1> : (const void*)tp_boundary_kernel<4>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return PIORAN_ERR_HIP;
+        granted[one][dev] = lds2;
     }
-    hipLaunchKernelGGL(tp_boundary_kernel, dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
+    if (one)
+        hipLaunchKernelGGL((tp_boundary_kernel<1>), dim3((unsigned)B), dim3(64), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
+    else
+        hipLaunchKernelGGL((tp_boundary_kernel<4>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
     hipLaunchKernelGGL((tp_filter_kernel<NP, NWV>), dim3((unsigned)nseg, (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
                        (const TpRec*)rec, (const TpStep*)stp, (const double*)bnd, part, sval);
     hipLaunchKernelGGL(tp_finish_kernel, dim3((unsigned)B), dim3(256), 0, stream, N, nseg, (const double*)part, (const double*)sval, p.out, p.status);

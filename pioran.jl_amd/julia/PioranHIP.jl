@@ -21,13 +21,16 @@ const ABI_VERSION = 7
 # PIORAN_BACKEND=julia keeps every call on Pioran's own Julia code (the escape hatch a deployment wants when no GPU is
 # visible or for A/B comparisons); anything else (default "hip") routes Float64 calls to libpioran_hip.so.
 const USE_HIP = Ref(lowercase(get(ENV, "PIORAN_BACKEND", "hip")) != "julia")
-# A drop-in must not be slower than what it replaces.  One scalar evaluation on the GPU walks the N steps as a serial chain at ~0.15 us per
-# step whatever the term count (1.22 ms at N = 8192), Pioran.logl on one CPU core costs ~0.04 us per step and ROW (j = 2 terms: 0.60 ms,
-# j = 4: 1.31 ms, j = 8: 2.6 ms on the bench host; the reference's own figure: 0.85 / 1.6 / 3.7 ms — benchmark/benchmarks.jl:76-91,
-# bench.py "reference_benchmark_grid_N8192").  So scalar calls with fewer than PIORAN_HIP_MIN_ROWS rows (R = 2 J; default 9, i.e. up to
-# four terms) stay on Pioran's own code; batched calls (logpdf_batch and friends) always use the GPU.  0 sends everything to the GPU.
+# A drop-in must not be slower than what it replaces.  One scalar evaluation on the GPU walks a short series as a serial chain at ~0.15 us per
+# step whatever the term count, Pioran.logl on one CPU core costs ~0.04 us per step and ROW (N = 8192: j = 2 terms 0.60 ms, j = 4 1.31 ms, j = 8
+# 2.6 ms on the bench host; the reference's own figure: 0.85 / 1.6 / 3.7 ms — benchmark/benchmarks.jl:76-91, bench.py
+# "reference_benchmark_grid_N8192").  So scalar calls with fewer than PIORAN_HIP_MIN_ROWS rows (R = 2 J; default 9, i.e. up to four terms)
+# stay on Pioran's own code — unless the series is long: from PIORAN_HIP_MIN_STEPS steps on (default 6144) the library's time-parallel
+# family (celerite_tp.hip, round 5: segments of the series on different CUs) is ahead of one core at every term count (N = 8192: j = 2
+# 0.47 ms, j = 4 0.66 ms).  Batched calls (logpdf_batch and friends) always use the GPU.  PIORAN_HIP_MIN_ROWS = 0 sends everything to the GPU.
 const MIN_ROWS = Ref(parse(Int, get(ENV, "PIORAN_HIP_MIN_ROWS", "9")))
-use_hip_scalar(nterms::Integer) = USE_HIP[] && 2 * nterms >= MIN_ROWS[]
+const MIN_STEPS = Ref(parse(Int, get(ENV, "PIORAN_HIP_MIN_STEPS", "6144")))
+use_hip_scalar(nterms::Integer, nsteps::Integer) = USE_HIP[] && (2 * nterms >= MIN_ROWS[] || nsteps >= MIN_STEPS[])
 
 function __init__()
     USE_HIP[] || return
@@ -107,7 +110,7 @@ end
 function log_likelihood(cov::SumOfCelerite, τ::Vector{Float64}, y::Vector{Float64}, σ2::Vector{Float64}; solver = :celerite)
     (solver == :celerite || solver == :celerite_matrix) ||
         error("solver $solver not recognised, use either :celerite or :celerite_matrix")
-    if use_hip_scalar(length(cov.a)) && eltype(cov.a) === Float64
+    if use_hip_scalar(length(cov.a), length(τ)) && eltype(cov.a) === Float64
         return logl_hip(collect(cov.a), collect(cov.b), collect(cov.c), collect(cov.d), τ, y, σ2)
     end
     return Pioran.logl(cov.a, cov.b, cov.c, cov.d, τ, y, σ2)
@@ -118,7 +121,7 @@ function _log_likelihood_coefs(cov, τ::Vector{Float64}, y::Vector{Float64}, σ2
     (solver == :celerite || solver == :celerite_matrix) ||
         error("solver $solver not recognised, use either :celerite or :celerite_matrix")
     a, b, c, d = celerite_coefs(cov)
-    if use_hip_scalar(length(a)) && all(v -> eltype(v) <: Union{Float64, ComplexF64}, (a, b, c, d)) && all(v -> all(iszero, imag.(v)), (a, b, c, d))
+    if use_hip_scalar(length(a), length(τ)) && all(v -> eltype(v) <: Union{Float64, ComplexF64}, (a, b, c, d)) && all(v -> all(iszero, imag.(v)), (a, b, c, d))
         return logl_hip(collect(Float64, real.(a)), collect(Float64, real.(b)), collect(Float64, real.(c)), collect(Float64, real.(d)), τ, y, σ2)
     end
     return real(Pioran.logl(a, b, c, d, τ, y, σ2))
