@@ -387,7 +387,7 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     if ((int)term.size() > pioran_tp_supported_rows() || p.N < 64) return PIORAN_ERR_UNSUPPORTED;
     const int RP = pioran_tp_padded_rows((int)term.size());
     // measured (tools/ab_tp.py sweep, profiles/r05_time_parallel_gpu.txt): with up to 8 draws it beats the serial-chain kernels from 2048 steps on at
-    // up to 4 state rows (N = 8192, one SHO term: 0.37 against 1.16 ms), from 4096 at up to 8, from 6144 at up to 16 (eight terms: 1.06 against
+    // up to 4 state rows (N = 8192, one SHO term: 0.33 against 1.16 ms), from 4096 at up to 8, from 6144 at up to 16 (eight terms: 1.05 against
     // 1.44 ms); with more rows the boundary solves (R^3 each, one after the other) eat the gain (20 terms, N = 1e4: 2.8 against 1.86 ms), and at 64
     // draws the one-draw-per-CU kernels have the chip filled anyway.
     if (!o.force_tp && !(p.B <= 8 && RP <= 16 && p.N >= (RP <= 4 ? 2048 : (RP <= 8 ? 4096 : 6144)))) return PIORAN_ERR_UNSUPPORTED;
