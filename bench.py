@@ -179,7 +179,8 @@ def main():
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # under torch.distributed.run (or any launcher)
     if not launched and (args.gpus > 1 or args.spawn):
-        # plain `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet (device_count does not).
+        # plain `python bench.py --gpus N`: become the launcher.  No kernel, allocation or context of this process exists yet (device_count at most
+        # initialises the runtime: see spawn_ranks); the ranks are a CHILD process, this one only waits for it.
         ndev = torch.cuda.device_count()
         need = args.gpus if (args.dist_backend == "nccl" and args.device is None) else 1
         if ndev < need:

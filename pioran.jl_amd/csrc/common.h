@@ -133,7 +133,7 @@ int pioran_launch_scan_wide_grad(ScanParams p, double* work, double* grad_a, dou
 int pioran_wide_supported_rows();
 int pioran_wide_supported_rows_grad();    // step-by-step reverse mode (143)
 int pioran_wide_supported_rows_modes();   // store / simulate modes of the latency kernels (143)
-int pioran_predict_supported_rows();      // step-by-step prediction (128: celerite_predict.hip)
+int pioran_predict_supported_rows();      // step-by-step prediction (143: lean latency kernel's factor store + celerite_predict.hip)
 int64_t pioran_wide_max_batch();
 // celerite_block.hip: windowed form (16 steps per window on the matrix cores), one draw per workgroup; shared (c, d) without
 // per-draw rows; its own table (fragment order), built once per prepared (c, d)

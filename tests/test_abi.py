@@ -106,3 +106,14 @@ def test_shipped_library_is_what_build_py_makes(tmp_path):
     # no experiment code in the product: the persistent dense chain and the two-wavefront scan shape need -DPIORAN_EXPERIMENTS
     data = b.LIB.read_bytes()
     assert b"dense_crit_chain_kernel" not in data and b"rpl5_cbr4_nsrc2_w2" not in data
+
+
+def test_probe_and_option_arguments_without_a_gpu():
+    """Argument validation of the ABI-7 additions happens before any GPU call: NULL context / NULL output / out-of-range arguments are
+    PIORAN_ERR_ARG (pioran_ctx_fp64_probe, pioran_ctx_set_option)."""
+    import ctypes
+    import pioran_jl_amd as pj
+    L = pj._lib.lib()
+    out = ctypes.c_double(0.0)
+    assert L.pioran_ctx_fp64_probe(None, 2, 10.0, ctypes.byref(out)) != 0
+    assert L.pioran_ctx_set_option(None, b"no_tp", b"1") != 0

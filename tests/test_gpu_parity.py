@@ -2485,3 +2485,18 @@ def test_gradient_shifted_log_flux_model(ctx, golden_dir):
             assert abs(g["grad_shift"][i] - ref) <= 1e-8 * (1 + abs(ref)), (Jw, g["grad_shift"][i], ref)
             gn = O.logl_dir(A[i], Bc[i], C, Dd, t, Yt - mu[i], nu[i] * St, ds2=St)
             assert abs(g["grad_nu"][i] - gn) <= 1e-8 * (1 + abs(gn))
+
+
+def test_fp64_probe_leaves_the_callers_event_slots_alone(ctx):
+    """pioran_ctx_fp64_probe (ABI 7): a plausible FP64 FMA rate, argument checks, and the caller's timing slots 0 .. 11 are not touched by it
+    (it records into the context's internal slots)."""
+    ctx.event_record(0)
+    r = ctx.fp64_probe(2, 5.0)
+    ctx.event_record(1)
+    assert 20.0 < r < 90.0, r
+    ms = ctx.event_elapsed_ms(0, 1)
+    assert ms >= 1.0                      # the probe ran between the two records: had it re-recorded slot 0 or 1, this would be ~0 or an error
+    L = pj._lib.lib()
+    out = ctypes.c_double(0.0)
+    assert L.pioran_ctx_fp64_probe(ctx._h, 0, 5.0, ctypes.byref(out)) != 0 and L.pioran_ctx_fp64_probe(ctx._h, 2, -1.0, ctypes.byref(out)) != 0
+    assert L.pioran_ctx_fp64_probe(ctx._h, 2, 5.0, None) != 0
