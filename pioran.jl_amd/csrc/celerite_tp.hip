@@ -66,14 +66,20 @@ __device__ __forceinline__ double tp_partner(double x) { return tp_dpp<0xB1>(x);
 
 // sums over the wavefront, two at a time: four DPP rounds inside the rows of 16 lanes, then the four row totals as scalar operands
 // (ds_bpermute-based shuffles cost ~700 cycles for the same: the first version of these kernels spent a third of a step there)
+template <bool ROW0 = false>      // ROW0: every contributing lane sits in the first row of 16 lanes (up to 16 state rows): the row total is the total
 __device__ __forceinline__ void tp_sum2(double& a, double& b)
 {
     a += tp_dpp<0xB1>(a);  b += tp_dpp<0xB1>(b);
     a += tp_dpp<0x4E>(a);  b += tp_dpp<0x4E>(b);
     a += tp_dpp<0x141>(a); b += tp_dpp<0x141>(b);
     a += tp_dpp<0x140>(a); b += tp_dpp<0x140>(b);
-    a = (tp_readlane(a, 0) + tp_readlane(a, 16)) + (tp_readlane(a, 32) + tp_readlane(a, 48));
-    b = (tp_readlane(b, 0) + tp_readlane(b, 16)) + (tp_readlane(b, 32) + tp_readlane(b, 48));
+    if constexpr (ROW0) {
+        a = tp_readlane(a, 0);
+        b = tp_readlane(b, 0);
+    } else {
+        a = (tp_readlane(a, 0) + tp_readlane(a, 16)) + (tp_readlane(a, 32) + tp_readlane(a, 48));
+        b = (tp_readlane(b, 0) + tp_readlane(b, 16)) + (tp_readlane(b, 32) + tp_readlane(b, 48));
+    }
 }
 
 // 1 / x to fp64 accuracy: v_rcp_f64 and two Newton steps (as in celerite_scan.hip)
@@ -242,7 +248,7 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
             Ph = (red[k & 1][0][lane] + red[k & 1][1][lane]) + (red[k & 1][2][lane] + red[k & 1][3][lane]);
         }
         double sS = hh * Ph, sm = hh * m;
-        tp_sum2(sS, sm);
+        tp_sum2<NWV == 1>(sS, sm);
         const double S = sbuf[buf][si * 2 + 1].x + sS, v = s0.y - sm;
         const double iS = tp_rcp(S);
         if (threadIdx.x == 0) sval[b * N + n0 + k] = S;          // log |D_n| and the status: tp_finish_kernel, off the chain
@@ -370,7 +376,7 @@ __global__ void __launch_bounds__(64 * NWV) tp_element_kernel(int64_t N, int RP,
             ag = (red[kk & 1][1][0][lane] + red[kk & 1][1][1][lane]) + (red[kk & 1][1][2][lane] + red[kk & 1][1][3][lane]);
         }
         double gu = mg * u, gb = mg * bv;
-        tp_sum2(gu, gb);
+        tp_sum2<NWV == 1>(gu, gb);
         const double delta = st_s + gu, idel = tp_rcp(delta);
         const double agd = ag * idel, ud = u * idel;
         double xf[NP][2], yv[NP][2];
@@ -402,7 +408,7 @@ __global__ void __launch_bounds__(64 * NWV) tp_element_kernel(int64_t N, int RP,
         bb = fma(-u, gbb * idel, bb);
         const double Fb = fma(mal, bb, mbe * tp_partner(bb));
         double hYh = mh * Yh, hFb = mh * Fb;
-        tp_sum2(hYh, hFb);
+        tp_sum2<NWV == 1>(hYh, hFb);
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
             const int jj = NWV * s + w, c0 = 2 * jj;
@@ -630,6 +636,130 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
     if (nseg > 1) publish(nseg - 1);
 }
 
+// The same for two or four state rows (the reference benchmark grid's j = 2: benchmark/benchmarks.jl:16-18), ONE THREAD per draw, everything in
+// registers, fully unrolled; partial pivoting by conditional row exchanges.  A boundary is ~550 dependent-chain-free instructions (1.3 us) where the
+// workgroup kernel spends 4.2 us in LDS round trips.
+template <int R>
+__global__ void __launch_bounds__(64) tp_boundary_small_kernel(int nseg, int J, int64_t B, const int32_t* __restrict__ row_term,
+                                                               const int32_t* __restrict__ row_kind, const double* __restrict__ A_,
+                                                               const double* __restrict__ Bc_, const double* __restrict__ elem, double* __restrict__ bnd)
+{
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double* bs = bnd + b * nseg * TP_BND_DOUBLES;
+    double P[R][R], m[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        m[r] = 0.0;
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            double v = 0.0;
+            const int kr = row_kind[r], kc = row_kind[c];
+            if (kr != 3 && kc != 3) {
+                if (r == c) v = A_[b * J + row_term[r]];
+                else if ((r ^ 1) == c && kr < 2 && kc < 2) v = -Bc_[b * J + row_term[r]];
+            }
+            P[r][c] = v;
+            bs[64 + r * 64 + c] = v;
+        }
+    }
+    struct Elem { double A[R][R], C[R][R], Jm[R][R], b[R], eta[R]; };
+    auto load = [&](Elem& E, const double* e) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                E.A[r][c] = e[c * 64 + r];              // A[r][c] = At[c][r]
+                E.C[r][c] = e[4096 + r * 64 + c];
+                E.Jm[r][c] = e[8192 + r * 64 + c];
+            }
+            E.b[r] = e[12288 + r];
+            E.eta[r] = e[12288 + 64 + r];
+        }
+    };
+    Elem cur, nxt;
+    if (nseg > 1) load(cur, elem + b * nseg * TP_ELEM_DOUBLES);
+    nxt = cur;
+    for (int p = 0; p + 1 < nseg; ++p) {
+        if (p + 2 < nseg) load(nxt, elem + (b * nseg + p + 1) * TP_ELEM_DOUBLES);
+        double X[R][2 * R + 1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double z = m[r];
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                double acc = r == c ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) acc = fma(P[r][k], cur.Jm[k][c], acc);
+                X[r][c] = acc;
+                X[r][R + 1 + c] = P[r][c];
+                z = fma(P[r][c], cur.eta[c], z);
+            }
+            X[r][R] = z;
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+#pragma unroll
+            for (int i = k + 1; i < R; ++i) {
+                const bool sw = fabs(X[i][k]) > fabs(X[k][k]);
+#pragma unroll
+                for (int c = k; c < 2 * R + 1; ++c) {
+                    const double a0 = X[k][c], a1 = X[i][c];
+                    X[k][c] = sw ? a1 : a0;
+                    X[i][c] = sw ? a0 : a1;
+                }
+            }
+            const double ipv = tp_rcp(X[k][k]);
+#pragma unroll
+            for (int c = k + 1; c < 2 * R + 1; ++c) X[k][c] *= ipv;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                if (i != k) {
+                    const double f = X[i][k];
+#pragma unroll
+                    for (int c = k + 1; c < 2 * R + 1; ++c) X[i][c] = fma(-f, X[k][c], X[i][c]);
+                }
+            }
+        }
+        double T[R][R], mn[R], Pn[R][R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double acc = cur.b[r];
+#pragma unroll
+            for (int k = 0; k < R; ++k) acc = fma(cur.A[r][k], X[k][R], acc);
+            mn[r] = acc;
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) t = fma(cur.A[r][k], X[k][R + 1 + c], t);
+                T[r][c] = t;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                double acc = cur.C[r][c];
+#pragma unroll
+                for (int k = 0; k < R; ++k) acc = fma(T[r][k], cur.A[c][k], acc);
+                Pn[r][c] = acc;
+            }
+        double* bo = bs + (int64_t)(p + 1) * TP_BND_DOUBLES;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            m[r] = mn[r];
+            bo[r] = mn[r];
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                P[r][c] = 0.5 * (Pn[r][c] + Pn[c][r]);
+                bo[64 + r * 64 + c] = P[r][c];
+            }
+        }
+        cur = nxt;
+    }
+}
+
 template <int NP, int NWV>
 int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream)
 {
@@ -657,7 +787,11 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return PIORAN_ERR_HIP;
         granted[one][dev] = lds2;
     }
-    if (one)
+    if (RP == 2)
+        hipLaunchKernelGGL((tp_boundary_small_kernel<2>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, nseg, p.J, B, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
+    else if (RP == 4)
+        hipLaunchKernelGGL((tp_boundary_small_kernel<4>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, nseg, p.J, B, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
+    else if (one)
         hipLaunchKernelGGL((tp_boundary_kernel<1>), dim3((unsigned)B), dim3(64), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
     else
         hipLaunchKernelGGL((tp_boundary_kernel<4>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);

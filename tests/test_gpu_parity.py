@@ -405,9 +405,9 @@ def test_fewer_than_six_rows_long_series_and_scalar_call(ctx, J, nreal):
             Bc[:, -nreal:] = 0.0; Dd[-nreal:] = 0.0
         ds = pj.Dataset(t, y, s2, ctx)
         ref = np.array([O.logl(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2) for i in range(B)])
-        # round 5: up to 8 draws of a long series take the time-parallel family (celerite_tp.hip) — from 2048 steps on at up to 4 state rows, from
+        # round 5: up to 8 draws of a long series take the time-parallel family (celerite_tp.hip) — from 1024 steps on at up to 4 state rows, from
         # 4096 at up to 8; the serial-chain kernels this test is about are what "no_tp" leaves
-        tp_takes = N >= (2048 if R <= 4 else 4096)
+        tp_takes = N >= (1024 if R <= 4 else 4096)
         got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
         assert (name() == "tp") == tp_takes, (name(), R, N)
         assert relerr(got, ref) < 1e-10
@@ -1995,7 +1995,8 @@ def test_time_parallel_family_vs_oracle(ctx, J, N, B, nreal, nseg):
 
 
 def test_time_parallel_dispatch_reference_values_and_flagged_draws(ctx, golden_dir):
-    """(i) The automatic choice: up to 8 draws, up to 16 state rows, long series; "no_tp" and everything else stay on the serial-chain kernels.
+    """(i) The automatic choice: up to 8 draws (64 at up to four state rows), up to 16 state rows, long series; "no_tp" and everything else stay on
+    the serial-chain kernels.
     (ii) Values the REFERENCE computed (stored ultranest run, N = 242, SHO-20: 40 rows, four wavefronts per segment), forced.
     (iii) A draw that is not positive definite: the status and the log |D_n| semantics of the other families (src/celerite_solver.jl:126, 140).
     (iv) Per-draw series (Y, S2)."""
@@ -2014,11 +2015,20 @@ def test_time_parallel_dispatch_reference_values_and_flagged_draws(ctx, golden_d
     finally:
         ctx.set_option("no_tp", False)
     A9 = np.tile(A, (3, 1)); B9 = np.tile(Bc, (3, 1))
-    ds.logl_batch(A9, B9, C, Dd)
-    assert name() != "tp"                                           # nine draws
-    ds2 = pj.Dataset(t[:1500], y[:1500], s2[:1500], ctx)
+    g9 = ds.logl_batch(A9, B9, C, Dd, mu=np.tile(mu, 3), nu=np.tile(nu, 3))
+    assert name() == "tp" and np.array_equal(g9[:3], got)            # up to 64 draws at up to four state rows from 4096 steps on
+    ds.logl_batch(np.tile(A, (22, 1)), np.tile(Bc, (22, 1)), C, Dd)
+    assert name() != "tp"                                           # 66 draws
+    ds2 = pj.Dataset(t[:900], y[:900], s2[:900], ctx)
     ds2.logl_batch(A, Bc, C, Dd)
     assert name() != "tp"                                           # a short series
+    rng2 = np.random.default_rng(516)
+    t8, y8, s8, A8, B8, C8, D8, mu8, nu8 = _random_case(rng2, 5000, 5, 2)      # ten state rows: from 6144 steps on
+    ds3 = pj.Dataset(t8, y8, s8, ctx)
+    ds3.logl_batch(A8, B8, C8, D8)
+    assert name() != "tp"
+    ds3.logl_batch(A8[:, :4], B8[:, :4], C8[:4], D8[:4])
+    assert name() == "tp"                                           # eight state rows: from 4096
     # (iv) per-draw series
     Y = y[None, :] + 0.01 * rng.standard_normal((B, N)); S2 = s2[None, :] * rng.uniform(0.8, 1.2, (B, 1))
     gy = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
