@@ -388,11 +388,12 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     const int RP = pioran_tp_padded_rows((int)term.size());
     // measured (tools/ab_tp.py sweep, profiles/r05_time_parallel_gpu.txt): with up to 8 draws it beats the serial-chain kernels from 1024 steps on at
     // up to 4 state rows (N = 8192: one SHO term 0.17 against 1.16 ms, two 0.27 against 1.15; there also at 64 draws from 4096 steps on: 0.90
-    // against 1.16 ms), from 4096 steps at up to 8 rows, from 6144 at up to 16 (eight terms: 1.05 against 1.44 ms); with more rows the boundary
-    // solves (R^3 each, one after the other) eat the gain (20 terms, N = 1e4: 2.6 against 1.83 ms).
+    // against 1.16 ms), from 2048 steps at up to 8 rows (four terms, N = 8192: 0.47 against 1.21), from 4096 at up to 12, from 6144 at up to 16
+    // (eight terms: 0.96 against 1.47 ms); with more rows the boundary solves (R^3 each, one after the other) eat the gain (20 terms, N = 1e4:
+    // 2.6 against 1.83 ms).
     if (!o.force_tp) {
         const bool few = RP <= 4 && ((p.B <= 8 && p.N >= 1024) || p.N >= 4096);
-        const bool mid = RP > 4 && p.B <= 8 && p.N >= (RP <= 8 ? 4096 : 6144) && RP <= 16;
+        const bool mid = RP > 4 && p.B <= 8 && p.N >= (RP <= 8 ? 2048 : (RP <= 12 ? 4096 : 6144)) && RP <= 16;
         if (!few && !mid) return PIORAN_ERR_UNSUPPORTED;
     }
     while ((int)term.size() < RP) { term.push_back(0); kind.push_back(3); }
@@ -400,7 +401,7 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     // tools/ab_tp.py): N / nseg tau + nseg t2 is least at sqrt(tau N / t2)
     int nseg = o.tp_segments;
     if (nseg <= 0) {
-        const double tau = 0.7 + RP / 8.0, t2 = RP == 2 ? 0.6 : (RP == 4 ? 2.0 : 5.0 + (double)RP * RP / 20.0);   // (2 / 4 rows: one thread per draw)
+        const double tau = 0.7 + RP / 8.0, t2 = RP == 2 ? 0.6 : (RP == 4 ? 2.0 : (RP <= 16 ? 1.3 + RP * RP / 21.0 : 5.0 + (double)RP * RP / 20.0));   // (2 / 4 rows: one thread per draw; up to 16: one wavefront, in registers)
         nseg = (int)std::lround(std::sqrt(tau * (double)p.N / t2));
     }
     if (nseg < 1) nseg = 1;

@@ -760,6 +760,131 @@ __global__ void __launch_bounds__(64) tp_boundary_small_kernel(int nseg, int J, 
     }
 }
 
+// Six to sixteen state rows: ONE WAVEFRONT per draw, lane = row, every matrix row in the lane's registers; the wave-uniform operands (a row of J, of Z,
+// a column of A', the pivot row of the elimination) come from the owning lane by v_readlane — no LDS round trip, no barrier (LDS only for the two
+// permutations at the end: rows back into natural order, the transpose of the symmetrisation).
+template <int R>
+__global__ void __launch_bounds__(64) tp_boundary_wave_kernel(int nseg, int J, const int32_t* __restrict__ row_term, const int32_t* __restrict__ row_kind,
+                                                              const double* __restrict__ A_, const double* __restrict__ Bc_, const double* __restrict__ elem,
+                                                              double* __restrict__ bnd)
+{
+    __shared__ double tr[16][17];
+    __shared__ int inv[16];
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const bool live = lane < R;
+    const int r = live ? lane : 0;
+    double* bs = bnd + b * nseg * TP_BND_DOUBLES;
+    double P[R], m = 0.0;
+    {
+        const int kr = row_kind[r];
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            double v = 0.0;
+            const int kc = row_kind[c];
+            if (live && kr != 3 && kc != 3) {
+                if (r == c) v = A_[b * J + row_term[r]];
+                else if ((r ^ 1) == c && kr < 2 && kc < 2) v = -Bc_[b * J + row_term[r]];
+            }
+            P[c] = v;
+            if (live) bs[64 + r * 64 + c] = v;
+        }
+    }
+    struct Elem { double A[R], C[R], Jm[R], b, eta; };      // this lane's ROW of A, C, J (C, J symmetric: read as columns, coalesced)
+    auto load = [&](Elem& E, const double* e) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            E.A[k] = e[k * 64 + r];                 // A[r][k] = At[k][r]
+            E.C[k] = e[4096 + k * 64 + r];
+            E.Jm[k] = e[8192 + k * 64 + r];
+        }
+        E.b = e[12288 + r];
+        E.eta = e[12288 + 64 + r];
+    };
+    Elem cur, nxt;
+    if (nseg > 1) load(cur, elem + b * nseg * TP_ELEM_DOUBLES);
+    nxt = cur;
+    for (int p = 0; p + 1 < nseg; ++p) {
+        if (p + 2 < nseg) load(nxt, elem + (b * nseg + p + 1) * TP_ELEM_DOUBLES);
+        // X = [W | z | Z] with W = I + P J, z = m + P eta, Z = P: this lane's row
+        double X[2 * R + 1];
+        {
+            double z = m;
+#pragma unroll
+            for (int c = 0; c < R; ++c) X[c] = lane == c ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double pk = P[k];
+                z = fma(pk, tp_readlane(cur.eta, k), z);
+#pragma unroll
+                for (int c = 0; c < R; ++c) X[c] = fma(pk, tp_readlane(cur.Jm[c], k), X[c]);      // J[k][c]: lane k's entry c
+            }
+            X[R] = z;
+#pragma unroll
+            for (int c = 0; c < R; ++c) X[R + 1 + c] = P[c];
+        }
+        bool used = !live;
+        int mycol = 0;
+        double mypiv = 1.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double cand = used ? -1.0 : fabs(X[k]);
+            double mx = cand;
+            mx = fmax(mx, tp_dpp<0xB1>(mx));
+            mx = fmax(mx, tp_dpp<0x4E>(mx));
+            mx = fmax(mx, tp_dpp<0x141>(mx));
+            mx = fmax(mx, tp_dpp<0x140>(mx));
+            mx = tp_readlane(mx, 0);                       // (the live lanes sit in the first row of 16)
+            const unsigned long long bal = __ballot(cand == mx);
+            const int pr = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(bal));
+            const double ipv = tp_rcp(tp_readlane(X[k], pr));
+            const double f = (lane == pr || !live) ? 0.0 : X[k] * ipv;
+            if (lane == pr) { used = true; mycol = k; mypiv = ipv; }
+#pragma unroll
+            for (int c = k + 1; c < 2 * R + 1; ++c) X[c] = fma(-f, tp_readlane(X[c], pr), X[c]);
+        }
+        // the row this lane solved is row `mycol` of [z | Z]: back into natural order through LDS
+        if (live) inv[mycol] = lane;
+        const int src = inv[r];
+        double zn = __shfl(X[R] * mypiv, src);
+        double Z[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) Z[c] = __shfl(X[R + 1 + c] * mypiv, src);
+        // m' = A z + b;  T = A Z;  P' = T A' + C
+        double mn = cur.b, T[R], Pn[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) T[c] = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double ak = cur.A[k];
+            mn = fma(ak, tp_readlane(zn, k), mn);
+#pragma unroll
+            for (int c = 0; c < R; ++c) T[c] = fma(ak, tp_readlane(Z[c], k), T[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            double acc = cur.C[c];
+#pragma unroll
+            for (int k = 0; k < R; ++k) acc = fma(T[k], tp_readlane(cur.A[k], c), acc);          // A[c][k]: lane c's entry k
+            Pn[c] = acc;
+        }
+        // symmetrise (the two products round differently): the transpose through LDS
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) tr[r][c] = Pn[c];
+        }
+        double* bo = bs + (int64_t)(p + 1) * TP_BND_DOUBLES;
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            P[c] = live ? 0.5 * (Pn[c] + tr[c][r]) : 0.0;
+            if (live) bo[64 + r * 64 + c] = P[c];
+        }
+        m = live ? mn : 0.0;
+        if (live) bo[r] = mn;
+        cur = nxt;
+    }
+}
+
 template <int NP, int NWV>
 int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream)
 {
@@ -791,7 +916,14 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
         hipLaunchKernelGGL((tp_boundary_small_kernel<2>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, nseg, p.J, B, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
     else if (RP == 4)
         hipLaunchKernelGGL((tp_boundary_small_kernel<4>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, nseg, p.J, B, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
-    else if (one)
+    else if (RP <= 16) {
+#define TP_WAVE_CASE(RR) case RR: hipLaunchKernelGGL((tp_boundary_wave_kernel<RR>), dim3((unsigned)B), dim3(64), 0, stream, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd); break;
+        switch (RP) {
+            TP_WAVE_CASE(6) TP_WAVE_CASE(8) TP_WAVE_CASE(10) TP_WAVE_CASE(12) TP_WAVE_CASE(14) TP_WAVE_CASE(16)
+            default: return PIORAN_ERR_UNSUPPORTED;
+        }
+#undef TP_WAVE_CASE
+    } else if (one)
         hipLaunchKernelGGL((tp_boundary_kernel<1>), dim3((unsigned)B), dim3(64), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
     else
         hipLaunchKernelGGL((tp_boundary_kernel<4>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);

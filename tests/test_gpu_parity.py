@@ -406,8 +406,8 @@ def test_fewer_than_six_rows_long_series_and_scalar_call(ctx, J, nreal):
         ds = pj.Dataset(t, y, s2, ctx)
         ref = np.array([O.logl(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2) for i in range(B)])
         # round 5: up to 8 draws of a long series take the time-parallel family (celerite_tp.hip) — from 1024 steps on at up to 4 state rows, from
-        # 4096 at up to 8; the serial-chain kernels this test is about are what "no_tp" leaves
-        tp_takes = N >= (1024 if R <= 4 else 4096)
+        # 2048 at up to 8; the serial-chain kernels this test is about are what "no_tp" leaves
+        tp_takes = N >= (1024 if R <= 4 else 2048)
         got = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
         assert (name() == "tp") == tp_takes, (name(), R, N)
         assert relerr(got, ref) < 1e-10
@@ -2023,12 +2023,13 @@ def test_time_parallel_dispatch_reference_values_and_flagged_draws(ctx, golden_d
     ds2.logl_batch(A, Bc, C, Dd)
     assert name() != "tp"                                           # a short series
     rng2 = np.random.default_rng(516)
-    t8, y8, s8, A8, B8, C8, D8, mu8, nu8 = _random_case(rng2, 5000, 5, 2)      # ten state rows: from 6144 steps on
+    t8, y8, s8, A8, B8, C8, D8, mu8, nu8 = _random_case(rng2, 5000, 7, 2)      # fourteen state rows: from 6144 steps on
     ds3 = pj.Dataset(t8, y8, s8, ctx)
     ds3.logl_batch(A8, B8, C8, D8)
     assert name() != "tp"
-    ds3.logl_batch(A8[:, :4], B8[:, :4], C8[:4], D8[:4])
-    assert name() == "tp"                                           # eight state rows: from 4096
+    g6 = ds3.logl_batch(A8[:, :6], B8[:, :6], C8[:6], D8[:6])
+    assert name() == "tp"                                           # twelve state rows: from 4096
+    assert relerr(g6, O.logl_batch(A8[:, :6], B8[:, :6], C8[:6], D8[:6], t8, y8, s8, None, None)) < 1e-11
     # (iv) per-draw series
     Y = y[None, :] + 0.01 * rng.standard_normal((B, N)); S2 = s2[None, :] * rng.uniform(0.8, 1.2, (B, 1))
     gy = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
