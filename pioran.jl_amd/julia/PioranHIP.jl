@@ -25,11 +25,11 @@ const USE_HIP = Ref(lowercase(get(ENV, "PIORAN_BACKEND", "hip")) != "julia")
 # step whatever the term count, Pioran.logl on one CPU core costs ~0.04 us per step and ROW (N = 8192: j = 2 terms 0.60 ms, j = 4 1.31 ms, j = 8
 # 2.6 ms on the bench host; the reference's own figure: 0.85 / 1.6 / 3.7 ms — benchmark/benchmarks.jl:76-91, bench.py
 # "reference_benchmark_grid_N8192").  So scalar calls with fewer than PIORAN_HIP_MIN_ROWS rows (R = 2 J; default 9, i.e. up to four terms)
-# stay on Pioran's own code — unless the series is long: from PIORAN_HIP_MIN_STEPS steps on (default 6144) the library's time-parallel
+# stay on Pioran's own code — unless the series is long: from PIORAN_HIP_MIN_STEPS steps on (default 3072) the library's time-parallel
 # family (celerite_tp.hip, round 5: segments of the series on different CUs) is ahead of one core at every term count (N = 8192: j = 2
 # 0.27 ms, j = 4 0.47 ms).  Batched calls (logpdf_batch and friends) always use the GPU.  PIORAN_HIP_MIN_ROWS = 0 sends everything to the GPU.
 const MIN_ROWS = Ref(parse(Int, get(ENV, "PIORAN_HIP_MIN_ROWS", "9")))
-const MIN_STEPS = Ref(parse(Int, get(ENV, "PIORAN_HIP_MIN_STEPS", "6144")))
+const MIN_STEPS = Ref(parse(Int, get(ENV, "PIORAN_HIP_MIN_STEPS", "3072")))
 use_hip_scalar(nterms::Integer, nsteps::Integer) = USE_HIP[] && (2 * nterms >= MIN_ROWS[] || nsteps >= MIN_STEPS[])
 
 function __init__()
