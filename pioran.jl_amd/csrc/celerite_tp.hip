@@ -182,11 +182,14 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
     constexpr int CH = Stage::CH;
     __shared__ double red[2][NWV][64];
     __shared__ double2 rbuf[2][CH * Stage::RMAX * 3], sbuf[2][CH * 2];
+    __shared__ double sring[256];          // D_n of the last (up to) 256 steps: their logarithms are taken 256 at a time by all threads, off the chain
     const int lane = threadIdx.x & 63, w = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seg = blockIdx.x;
     const int64_t b = blockIdx.y;
     const int64_t n0 = seg * L, n1 = n0 + L < N ? n0 + L : N;
     const int len = (int)(n1 - n0);
+    double ldsum = 0.0;
+    int bad = 0;
     const double* bs = bnd + (b * nseg + seg) * TP_BND_DOUBLES;
     double m = bs[lane];
     double P[NP][2], hc[NP][2];
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
         tp_sum2<NWV == 1>(sS, sm);
         const double S = sbuf[buf][si * 2 + 1].x + sS, v = s0.y - sm;
         const double iS = tp_rcp(S);
-        if (threadIdx.x == 0) sval[b * N + n0 + k] = S;          // log |D_n| and the status: tp_finish_kernel, off the chain
+        if (threadIdx.x == 0) sring[k & 255] = S;
         quad = fma(v * v, iS, quad);
         const double K = Ph * iS;
         m = fma(K, v, m);
@@ -261,38 +264,49 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
             P[s][0] = fma(-K, tp_readlane(Ph, c0), P[s][0]);
             P[s][1] = fma(-K, tp_readlane(Ph, c0 + 1), P[s][1]);
         }
+        if ((k & 255) == 255 || k == len - 1) {
+            TP_BARRIER();
+            const int base = k & ~255, cnt = k - base + 1;
+            for (int i = threadIdx.x; i < cnt; i += 64 * NWV) {
+                const double Sv = sring[i];
+                ldsum += (n0 + base + i == 0) ? log(Sv) : log(fabs(Sv));       // (src/celerite_solver.jl:126, 140: log D_1, log |D_n|)
+                bad |= !(Sv > 0.0);
+            }
+            TP_BARRIER();
+        }
     }
-    if (threadIdx.x == 0) part[b * nseg + seg] = quad;
-}
-
-// log L = -1/2 sum log |D_n| (log D_1: src/celerite_solver.jl:126, 140) - N/2 log 2 pi - 1/2 sum z_n^2 / D_n; one workgroup per draw, fixed order
-__global__ void __launch_bounds__(256) tp_finish_kernel(int64_t N, int nseg, const double* __restrict__ part, const double* __restrict__ sval,
-                                                        double* __restrict__ out, int32_t* __restrict__ status)
-{
-    __shared__ double sh[256];
-    __shared__ int shb[256];
-    const int64_t b = blockIdx.x;
-    double ld = 0.0;
-    int bad = 0;
-    for (int64_t n = threadIdx.x; n < N; n += 256) {
-        const double S = sval[b * N + n];
-        ld += n == 0 ? log(S) : log(fabs(S));
-        bad |= !(S > 0.0);
+    // the segment's sums: sum over the threads' shares of log |D_n| (fixed order: the share of a thread is fixed by the segment's length)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ldsum += __shfl_xor(ldsum, off);
+        bad |= __shfl_xor(bad, off);
     }
-    sh[threadIdx.x] = ld;
-    shb[threadIdx.x] = bad;
-    TP_BARRIER();
-    for (int o = 128; o >= 1; o >>= 1) {
-        if ((int)threadIdx.x < o) { sh[threadIdx.x] += sh[threadIdx.x + o]; shb[threadIdx.x] |= shb[threadIdx.x + o]; }
+    if constexpr (NWV > 1) {
+        if (lane == 0) { red[0][w][0] = ldsum; red[0][w][1] = (double)bad; }
         TP_BARRIER();
+        ldsum = (red[0][0][0] + red[0][1][0]) + (red[0][2][0] + red[0][3][0]);
+        bad = (red[0][0][1] + red[0][1][1] + red[0][2][1] + red[0][3][1]) > 0.0;
     }
     if (threadIdx.x == 0) {
-        double q = 0.0;
-        for (int s2 = 0; s2 < nseg; ++s2) q += part[b * nseg + s2];
-        const double res = -0.5 * sh[0] - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * q;
-        out[b] = res;
-        if (status) status[b] = !isfinite(res) ? 2 : (shb[0] ? 1 : 0);
+        double* o = part + (b * nseg + seg) * 4;
+        o[0] = quad; o[1] = ldsum; o[2] = (double)bad; o[3] = 0.0;
     }
+}
+
+// log L = -1/2 sum log |D_n| - N/2 log 2 pi - 1/2 sum z_n^2 / D_n from the segments' sums, in a fixed order
+__global__ void __launch_bounds__(64) tp_finish_kernel(int64_t N, int nseg, int64_t B, const double* __restrict__ part, double* __restrict__ out,
+                                                       int32_t* __restrict__ status)
+{
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double ld = 0.0, q = 0.0, bad = 0.0;
+    for (int s2 = 0; s2 < nseg; ++s2) {
+        const double* o = part + (b * nseg + s2) * 4;
+        q += o[0]; ld += o[1]; bad += o[2];
+    }
+    const double res = -0.5 * ld - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * q;
+    out[b] = res;
+    if (status) status[b] = !isfinite(res) ? 2 : (bad > 0.0 ? 1 : 0);
 }
 
 // ---- phase 1 ---------------------------------------------------------------------------------------------------------------------------------
@@ -929,7 +943,7 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
         hipLaunchKernelGGL((tp_boundary_kernel<4>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
     hipLaunchKernelGGL((tp_filter_kernel<NP, NWV>), dim3((unsigned)nseg, (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
                        (const TpRec*)rec, (const TpStep*)stp, (const double*)bnd, part, sval);
-    hipLaunchKernelGGL(tp_finish_kernel, dim3((unsigned)B), dim3(256), 0, stream, N, nseg, (const double*)part, (const double*)sval, p.out, p.status);
+    hipLaunchKernelGGL(tp_finish_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, N, nseg, B, (const double*)part, p.out, p.status);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
@@ -942,7 +956,7 @@ int pioran_tp_padded_rows(int rows) { return rows <= 16 ? (rows + 1) & ~1 : (row
 
 size_t pioran_tp_workspace_doubles(int64_t B, int64_t N, int RP, int nseg)
 {
-    return (size_t)B * N * RP * 6 + (size_t)B * N * 5 + (size_t)B * nseg * (TP_ELEM_DOUBLES + TP_BND_DOUBLES + 1);
+    return (size_t)B * N * RP * 6 + (size_t)B * N * 5 + (size_t)B * nseg * (TP_ELEM_DOUBLES + TP_BND_DOUBLES + 4);
 }
 
 // RP = pioran_tp_padded_rows(rows) state rows in the layout of row_term / row_kind (device arrays, [RP]; kind 3 = padding); nseg segments of L steps
