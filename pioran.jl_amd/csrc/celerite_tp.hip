@@ -691,11 +691,15 @@ __global__ void __launch_bounds__(64) tp_boundary_small_kernel(int nseg, int J, 
             E.eta[r] = e[12288 + 64 + r];
         }
     };
-    Elem cur, nxt;
-    if (nseg > 1) load(cur, elem + b * nseg * TP_ELEM_DOUBLES);
-    nxt = cur;
-    for (int p = 0; p + 1 < nseg; ++p) {
-        if (p + 2 < nseg) load(nxt, elem + (b * nseg + p + 1) * TP_ELEM_DOUBLES);
+    // Three register sets in rotation, the loop unrolled by three (no copies between the sets: a copy is a use, and the compiler waits for every
+    // load in flight at a use): element p + 2 is loaded while element p is applied — a boundary is ~1 us of arithmetic, a load ~2 us away.
+    Elem S0, S1, S2;
+    if (nseg > 1) load(S0, elem + b * nseg * TP_ELEM_DOUBLES);
+    S1 = S0;
+    if (nseg > 2) load(S1, elem + (b * nseg + 1) * TP_ELEM_DOUBLES);
+    S2 = S0;
+    auto step = [&](const Elem& cur, Elem& fill, int p) __attribute__((always_inline)) {
+        if (p + 3 < nseg) load(fill, elem + (b * nseg + p + 2) * TP_ELEM_DOUBLES);
         double X[R][2 * R + 1];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -770,7 +774,14 @@ __global__ void __launch_bounds__(64) tp_boundary_small_kernel(int nseg, int J, 
                 bo[64 + r * 64 + c] = P[r][c];
             }
         }
-        cur = nxt;
+    };
+    for (int p = 0;;) {
+        if (p + 1 >= nseg) break;
+        step(S0, S2, p); ++p;
+        if (p + 1 >= nseg) break;
+        step(S1, S0, p); ++p;
+        if (p + 1 >= nseg) break;
+        step(S2, S1, p); ++p;
     }
 }
 
