@@ -30,6 +30,8 @@
 
 namespace {
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
 struct __attribute__((aligned(16))) TpRec { double al, be, g, K, qd, qo; };         // per (draw, step, row): three 16-byte units (al, be), (g, K), (qd, qo)
 struct __attribute__((aligned(32))) TpStep { double s, y, s2, yos; };                // per (draw, step): h Q h' + sigma2, y - mu, nu sigma2, y / s
 
@@ -466,13 +468,14 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
                                                           double* __restrict__ bnd)
 {
     extern __shared__ double lds[];
-    const int S1 = RP + 1, LW = 2 * RP + 3;      // odd strides
-    double* X = lds;                     // [RP][LW]: [W, later A Z | right-hand sides z (1), Z (RP)]
-    double* Pm = X + RP * LW;            // [RP][S1]: P, later Z, then P'
-    double* JL = Pm + RP * S1;           // J
-    double* AL = JL + RP * S1;           // A' (as stored: AL[k][r] = A[r][k])
-    double* CL = AL + RP * S1;           // C
-    double* mv = CL + RP * S1;           // [64] m, later z
+    const int RT = (RP + 15) / 16, R16 = 16 * RT;      // the products run on 16 x 16 tiles: rows and columns RP .. R16 - 1 of every matrix stay zero
+    const int S1 = R16 + 1, LW = 2 * R16 + 3;          // odd strides
+    double* X = lds;                     // [R16][LW]: [W, later A Z | right-hand sides z (1), Z (RP)]
+    double* Pm = X + R16 * LW;           // [R16][S1]: P, later Z, then P'
+    double* JL = Pm + R16 * S1;          // J
+    double* AL = JL + R16 * S1;          // A' (as stored: AL[k][r] = A[r][k])
+    double* CL = AL + R16 * S1;          // C
+    double* mv = CL + R16 * S1;          // [64] m, later z
     double* ev = mv + 64;                // [64] eta
     double* bl = ev + 64;                // [64] b
     constexpr int T = 64 * TW;
@@ -480,6 +483,24 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
     const int64_t b = blockIdx.x;
     double* bs = bnd + b * nseg * TP_BND_DOUBLES;
     const int NC = 2 * RP + 1;           // live columns of [W | z | Z], packed: W 0 .. RP-1, z RP, Z RP+1 .. 2 RP
+    for (int i = tid; i < R16 * LW + 4 * R16 * S1; i += T) lds[i] = 0.0;
+    // One R x R x R product on the matrix cores: tile (I, Jt) of the result by wavefront (I RT + Jt) mod 4, operands straight from LDS
+    // (A operand: row 16 I + (lane & 15), k = 4 ks + (lane >> 4); B operand: k, column 16 Jt + (lane & 15); result register g: row 4 g + (lane >> 4)).
+    // (Scalar products — one output per thread, two LDS reads per FMA — took 9 us each at 40 rows, the LDS's bandwidth.)
+    const int li = lane & 15, lk = lane >> 4;
+    auto gemm = [&](auto aop, auto bop, auto store) __attribute__((always_inline)) {
+        for (int tI = w; tI < RT * RT; tI += TW) {
+            const int I = tI / RT, Jt = tI - I * RT;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int ks = 0; ks < 4 * RT; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop(16 * I + li, 4 * ks + lk), bop(4 * ks + lk, 16 * Jt + li), acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = 16 * I + 4 * g + lk, c = 16 * Jt + li;
+                if (r < RP && c < RP) store(r, c, acc[g]);
+            }
+        }
+    };
+    TP_SYNC();
     // entry i = tid + T q of an RP x RP matrix: (row, col) = (i / RP, i % RP) — consecutive lanes, consecutive columns
     const int nq = (RP * RP + T - 1) / T;      // <= 9 at the 48 rows four wavefronts take, 4 at the 16 of one
     constexpr int NQ = TW == 1 ? 4 : 9;
@@ -549,17 +570,11 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
         if (p > 0) publish(p);       // (the state this iteration starts from: its stores, too, have the iteration — vmcnt counts them)
         TP_SYNC();
         // W = I + P J, z = m + P eta, Z = P
+        gemm([&](int r, int kk) { return Pm[r * S1 + kk]; }, [&](int kk, int c) { return JL[kk * S1 + c]; },
+             [&](int r, int c, double v) { X[r * LW + c] = v + (r == c ? 1.0 : 0.0); });
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (ok[q]) {
-                const int r = row[q], c = col[q];
-                double acc = r == c ? 1.0 : 0.0;
-#pragma unroll 8
-                for (int k = 0; k < RP; ++k) acc = fma(Pm[r * S1 + k], JL[k * S1 + c], acc);
-                X[r * LW + c] = acc;
-                X[r * LW + RP + 1 + c] = Pm[r * S1 + c];
-            }
-        }
+        for (int q = 0; q < NQ; ++q)
+            if (ok[q]) X[row[q] * LW + RP + 1 + col[q]] = Pm[row[q] * S1 + col[q]];
         if (tid < RP) {
             double acc = mv[tid];
 #pragma unroll 8
@@ -567,40 +582,59 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
             X[tid * LW + RP] = acc;
         }
         TP_SYNC();
+        // Gauss-Jordan elimination with partial pivoting, FOUR pivots per barrier: every wavefront factors the 4-column panel itself (lane = row, the
+        // panel in registers, pivot rows by v_readlane: no LDS, no barrier), then the rank-4 update of its share of the other columns with the four
+        // pivot rows as they stand after the earlier pivots of the block (u_j = row pr_j - sum_{i<j} f_i[pr_j] u_i), one barrier per block.
+        // (One pivot per barrier with its column through LDS: 1.1 us per pivot, 43 of a boundary's 77 us at 40 rows.)
         bool used = lane >= RP;
         int mycol = 0;
+        double mypiv = 1.0;
         const int lr = lane < RP ? lane : 0;
-        for (int k = 0; k < RP; ++k) {
-            const double xk = X[lr * LW + k];
-            const double cand = used ? -1.0 : fabs(xk);
-            const double mx = tp_max(cand);
-            const unsigned long long bal = __ballot(cand == mx);
-            const int pr = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(bal));
-            const double ipv = tp_rcp(X[pr * LW + k]);
-            const double f = (lane == pr || lane >= RP) ? 0.0 : xk * ipv;
-            if (lane == pr) { used = true; mycol = k; }
-            // (reads of a batch before its writes: a write-then-read chain per column costs an LDS round trip each)
-            if (lane < RP) {
-                for (int c = k + 1 + w; c < NC; c += 8 * TW) {
-                    double pv[8], xv[8];
+        for (int k0 = 0; k0 < RP; k0 += 4) {          // (RP is a multiple of 8 here)
+            double xp[4], f[4];
+            int pr[4];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
+            for (int j = 0; j < 4; ++j) xp[j] = X[lr * LW + k0 + j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double cand = used ? -1.0 : fabs(xp[j]);
+                const double mx = tp_max(cand);
+                const unsigned long long bal = __ballot(cand == mx);
+                pr[j] = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(bal));
+                const double ipv = tp_rcp(tp_readlane(xp[j], pr[j]));
+                f[j] = (lane == pr[j] || lane >= RP) ? 0.0 : xp[j] * ipv;
+                if (lane == pr[j]) { used = true; mycol = k0 + j; mypiv = ipv; }
+#pragma unroll
+                for (int jj = j + 1; jj < 4; ++jj) xp[jj] = fma(-f[j], tp_readlane(xp[jj], pr[j]), xp[jj]);
+            }
+            const double f01 = tp_readlane(f[0], pr[1]), f02 = tp_readlane(f[0], pr[2]), f03 = tp_readlane(f[0], pr[3]);
+            const double f12 = tp_readlane(f[1], pr[2]), f13 = tp_readlane(f[1], pr[3]), f23 = tp_readlane(f[2], pr[3]);
+            if (lane < RP) {
+                for (int c = k0 + 4 + w; c < NC; c += 4 * TW) {
+                    double u[4][4], xv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
                         const int cc = c + TW * i < NC ? c + TW * i : c;
-                        pv[i] = X[pr * LW + cc];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) u[i][j] = X[pr[j] * LW + cc];
                         xv[i] = X[lane * LW + cc];
                     }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (c + TW * i < NC) X[lane * LW + c + TW * i] = fma(-f, pv[i], xv[i]);
+                    for (int i = 0; i < 4; ++i) {
+                        u[i][1] = fma(-f01, u[i][0], u[i][1]);
+                        u[i][2] = fma(-f12, u[i][1], fma(-f02, u[i][0], u[i][2]));
+                        u[i][3] = fma(-f23, u[i][2], fma(-f13, u[i][1], fma(-f03, u[i][0], u[i][3])));
+                        const double v = fma(-f[3], u[i][3], fma(-f[2], u[i][2], fma(-f[1], u[i][1], fma(-f[0], u[i][0], xv[i]))));
+                        if (c + TW * i < NC) X[lane * LW + c + TW * i] = v;
+                    }
                 }
             }
             TP_SYNC();
         }
         // row `lane` solved column mycol: [z | Z][mycol] = its right-hand sides / its pivot.  Z into Pm (P is dead), z into mv.
         if (lane < RP) {
-            const double ipv = tp_rcp(X[lane * LW + mycol]);
-            for (int c = w; c < RP; c += TW) Pm[mycol * S1 + c] = X[lane * LW + RP + 1 + c] * ipv;
-            if (w == 0) mv[mycol] = X[lane * LW + RP] * ipv;
+            for (int c = w; c < RP; c += TW) Pm[mycol * S1 + c] = X[lane * LW + RP + 1 + c] * mypiv;
+            if (w == 0) mv[mycol] = X[lane * LW + RP] * mypiv;
         }
         TP_SYNC();
         // m' = A z + b; T = A Z (into X, columns 0 .. RP-1); P' = T A' + C.  A[r][k] = AL[k][r].
@@ -610,37 +644,18 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
             for (int k = 0; k < RP; ++k) acc = fma(AL[k * S1 + tid], mv[k], acc);
             mnew = acc;
         }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (ok[q]) {
-                const int r = row[q], c = col[q];
-                double acc = 0.0;
-#pragma unroll 8
-                for (int k = 0; k < RP; ++k) acc = fma(AL[k * S1 + r], Pm[k * S1 + c], acc);
-                X[r * LW + c] = acc;
-            }
-        }
+        gemm([&](int r, int kk) { return AL[kk * S1 + r]; }, [&](int kk, int c) { return Pm[kk * S1 + c]; },
+             [&](int r, int c, double v) { X[r * LW + c] = v; });
         TP_SYNC();
         if (tid < RP) mv[tid] = mnew;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            pn[q] = 0.0;
-            if (ok[q]) {
-                const int r = row[q], c = col[q];
-                double acc = CL[r * S1 + c];
-#pragma unroll 8
-                for (int k = 0; k < RP; ++k) acc = fma(X[r * LW + k], AL[k * S1 + c], acc);
-                pn[q] = acc;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            if (ok[q]) Pm[row[q] * S1 + col[q]] = pn[q];
+        // (the A operand runs over columns up to R16 - 1 of X: past RP sit z and Z, multiplied by the zero rows of A')
+        gemm([&](int r, int kk) { return X[r * LW + kk]; }, [&](int kk, int c) { return AL[kk * S1 + c]; },
+             [&](int r, int c, double v) { Pm[r * S1 + c] = v + CL[r * S1 + c]; });
         TP_SYNC();
         // symmetrise (the two products round differently); published at the top of the next iteration
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (ok[q]) pn[q] = 0.5 * (pn[q] + Pm[col[q] * S1 + row[q]]);
+            if (ok[q]) pn[q] = 0.5 * (Pm[row[q] * S1 + col[q]] + Pm[col[q] * S1 + row[q]]);
         TP_SYNC();
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
@@ -926,7 +941,7 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
     if (nseg > 1)
         hipLaunchKernelGGL((tp_element_kernel<NP, NWV>), dim3((unsigned)(nseg - 1), (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
                            (const TpRec*)rec, (const TpStep*)stp, elem);
-    const size_t lds2 = ((size_t)RP * (2 * RP + 3) + 4 * (size_t)RP * (RP + 1) + 192) * sizeof(double);
+    const size_t r16 = (size_t)((RP + 15) / 16) * 16, lds2 = (r16 * (2 * r16 + 3) + 4 * r16 * (r16 + 1) + 192) * sizeof(double);
     static size_t granted[2][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
