@@ -396,19 +396,19 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
         const bool mid = RP > 4 && p.B <= 8 && p.N >= (RP <= 8 ? 2048 : (RP <= 12 ? 4096 : 6144)) && RP <= 16;
         // 17 .. 48 state rows: the boundary solves cost 17 .. 55 us each (four wavefronts, products on the matrix cores, four pivots per barrier), and
         // the gain comes with the length of the series (its time grows like sqrt(N), the serial chain's like N): SHO-12 (24 rows) N = 1e4 / 65536
-        // 1.18 / 3.0 against 1.80 / 11.8 ms, SHO-20 (40 rows) N = 16384 / 65536 2.7 / 5.4 against 3.0 / 11.9 ms (at N = 1e4: 2.08 against 1.85, not
-        // chosen); with 3 .. 8 draws later (segments x draws workgroups, one boundary walk per draw)
-        const int64_t nmin12 = RP <= 24 ? 6144 : (RP <= 32 ? 8192 : (RP <= 40 ? 14336 : 12288));
-        const int64_t nmin8 = RP <= 24 ? 8192 : (RP <= 32 ? 12288 : (RP <= 40 ? 32768 : 16384));
+        // 1.14 / 2.9 against 1.80 / 11.8 ms, SHO-20 (40 rows) N = 16384 / 65536 2.45 / 4.9 against 3.0 / 11.9 ms (at N = 1e4: 1.91 against 1.84, not
+        // chosen), SHO-24 (48 rows; three block columns on the serial chain) N = 1e4 2.2 against 2.5 ms; with 3 .. 8 draws slightly later
+        const int64_t nmin12 = RP <= 24 ? 6144 : (RP <= 32 ? 8192 : (RP <= 40 ? 12288 : 8192));
+        const int64_t nmin8 = RP <= 24 ? 6144 : (RP <= 32 ? 8192 : (RP <= 40 ? 14336 : 10240));
         const bool many = RP > 16 && ((p.B <= 2 && p.N >= nmin12) || (p.B <= 8 && p.N >= nmin8));
         if (!few && !mid && !many) return PIORAN_ERR_UNSUPPORTED;
     }
     while ((int)term.size() < RP) { term.push_back(0); kind.push_back(3); }
-    // segments: phases 1 + 3 cost tau ~ 0.7 + R / 8 us per step, phase 2 t2 ~ 5 + R^2 / 20 us per boundary (measured at 4, 16 and 40 rows,
-    // tools/ab_tp.py): N / nseg tau + nseg t2 is least at sqrt(tau N / t2)
+    // segments: phases 1 + 3 cost tau ~ 0.7 + R / 8 us per step with one wavefront per segment (up to 16 rows), ~ 1 + R / 32 with four; phase 2 t2 per
+    // boundary as below (measured at 2 .. 48 rows, tools/ab_tp.py): N / nseg tau + nseg t2 is least at sqrt(tau N / t2)
     int nseg = o.tp_segments;
     if (nseg <= 0) {
-        const double tau = 0.7 + RP / 8.0, t2 = RP == 2 ? 0.6 : (RP == 4 ? 2.0 : (RP <= 16 ? 1.3 + RP * RP / 21.0 : 5.0 + (double)RP * RP / 45.0));   // (2 / 4 rows: one thread per draw; up to 16: one wavefront, in registers;
+        const double tau = RP <= 16 ? 0.7 + RP / 8.0 : 1.0 + RP / 32.0, t2 = RP == 2 ? 0.6 : (RP == 4 ? 2.0 : (RP <= 16 ? 1.3 + RP * RP / 21.0 : 5.0 + (double)RP * RP / 45.0));   // (2 / 4 rows: one thread per draw; up to 16: one wavefront, in registers;
                                                                                  //  above: four wavefronts, products on the matrix cores, four pivots per barrier)
         nseg = (int)std::lround(std::sqrt(tau * (double)p.N / t2));
     }

@@ -2035,10 +2035,12 @@ def test_time_parallel_dispatch_reference_values_and_flagged_draws(ctx, golden_d
     ds9 = pj.Dataset(t9, y9, s9, ctx)
     g9_ = ds9.logl_batch(A9_[:2, :12], B9_[:2, :12], C9[:12], D9[:12], mu=mu9[:2], nu=nu9[:2])       # 24 state rows: from 6144 steps on
     assert name() == "tp" and relerr(g9_, O.logl_batch(A9_[:2, :12], B9_[:2, :12], C9[:12], D9[:12], t9, y9, s9, mu9[:2], nu9[:2], nthreads=8)) < 1e-10
+    ds9.logl_batch(A9_, B9_, C9, D9)
+    assert name() != "tp"                                           # 40 state rows, four draws: from 14336 steps on
     ds9.logl_batch(A9_[:2], B9_[:2], C9, D9)
-    assert name() != "tp"                                           # 40 state rows: from 14336 steps on
+    assert name() == "tp"                                           # 40 state rows, two draws: from 12288
     ds9.logl_batch(A9_[:, :16], B9_[:, :16], C9[:16], D9[:16])
-    assert name() == "tp"                                           # 32 state rows, four draws: from 12288
+    assert name() == "tp"                                           # 32 state rows, four draws: from 8192
     ds9.close()
     # (iv) per-draw series
     Y = y[None, :] + 0.01 * rng.standard_normal((B, N)); S2 = s2[None, :] * rng.uniform(0.8, 1.2, (B, 1))
