@@ -614,6 +614,7 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
             ms1, A1, B1, C1, D1, R1, got1, st1, _, (tt, yy, ee) = resident_batch(basis, n, 1, 7)
             ys, ss = yy - mu[0], nu[0] * ee ** 2
             ctx.logl(A1[0], B1[0], C1, D1, tt, ys, ss)
+            kern1 = pj._lib.lib().pioran_celerite_config_name(-1).decode()
             wall = []
             for _ in range(5):
                 t0 = time.perf_counter(); v = ctx.logl(A1[0], B1[0], C1, D1, tt, ys, ss); wall.append(time.perf_counter() - t0)
@@ -621,11 +622,13 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
             for _ in range(3):
                 t0 = time.perf_counter(); r = O.logl(A1[0], B1[0], C1, D1, tt, ys, ss); cpu.append(time.perf_counter() - t0)
             single[f"{basis}{J}_N{n}"] = {"resident_launch_ms": ms1, "scalar_entry_ms_incl_pcie": med(wall) * 1e3,
-                                         "cpu_one_core_ms": med(cpu) * 1e3, "rows_executed": R1,
+                                         "cpu_one_core_ms": med(cpu) * 1e3, "rows_executed": R1, "scalar_entry_kernel": kern1,
                                          "rel_dlogl_vs_oracle": abs(v - r) / abs(r)}
     out["single_evaluation_B1"] = single
-    out["single_evaluation_B1"]["kernel"] = ("celerite_block_kernel (windowed form, 16 steps per window on the fp64 matrix cores; "
-                                             "celerite_block.hip) for B <= 512 and 6 <= rows <= 63")
+    out["single_evaluation_B1"]["kernel"] = ("resident_launch_ms: what the automatic choice takes for one resident draw; scalar_entry_kernel names it for the "
+                                             "scalar entry — 'block': celerite_block_kernel (windowed form, 16 steps per window on the fp64 matrix cores, a "
+                                             "serial chain of windows; celerite_block.hip), 'tp': the time-parallel family (celerite_tp.hip, round 5: "
+                                             "segments of the series on different CUs; up to 48 state rows on series that are long enough for their rows)")
     # -- the reference's own benchmark (benchmark/benchmarks.jl:16-18, 74-91: ONE scalar `logl` call, j terms with random coefficients, the suite's
     #    yerr passed as the variance) at its N = 8192 column; the published figure's values read off BASELINE.md section 1 (+-15 %, unstated CPU).
     #    tools/bench_grid.py runs the whole grid (profiles/r04_grid.json). -----------------------------------------------------------------------

@@ -93,6 +93,18 @@ __device__ __forceinline__ double tp_rcp(double x)
     return r;
 }
 
+// max over the wavefront of non-negative 32-bit keys (the high words of |x|: monotonic for non-negative doubles), DPP folded into v_max_u32
+__device__ __forceinline__ unsigned tp_max_u32(unsigned a)
+{
+    a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xf, 0xf, true));
+    a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xf, 0xf, true));
+    a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x141, 0xf, 0xf, true));
+    a = max(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x140, 0xf, 0xf, true));
+    const unsigned r0 = __builtin_amdgcn_readlane((int)a, 0), r1 = __builtin_amdgcn_readlane((int)a, 16), r2 = __builtin_amdgcn_readlane((int)a, 32),
+                   r3 = __builtin_amdgcn_readlane((int)a, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+
 __device__ __forceinline__ double tp_max(double a)
 {
     a = fmax(a, tp_dpp<0xB1>(a));
@@ -492,7 +504,25 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
         for (int tI = w; tI < RT * RT; tI += TW) {
             const int I = tI / RT, Jt = tI - I * RT;
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-            for (int ks = 0; ks < 4 * RT; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop(16 * I + li, 4 * ks + lk), bop(4 * ks + lk, 16 * Jt + li), acc, 0, 0, 0);
+            // (every operand read of the tile in flight before its first matrix instruction: one read pair at a time cost 4.6 us per product, four
+            //  pairs at a time 2.4; RT <= 3 at the 48 rows this kernel takes)
+            double av[3][4], bv[3][4];
+#pragma unroll
+            for (int k4 = 0; k4 < 3; ++k4) {
+                const int kq = k4 < RT ? k4 : RT - 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    av[k4][i] = aop(16 * I + li, 16 * kq + 4 * i + lk);
+                    bv[k4][i] = bop(16 * kq + 4 * i + lk, 16 * Jt + li);
+                }
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 3; ++k4) {
+                if (k4 < RT) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k4][i], bv[k4][i], acc, 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r = 16 * I + 4 * g + lk, c = 16 * Jt + li;
@@ -597,8 +627,9 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
             for (int j = 0; j < 4; ++j) xp[j] = X[lr * LW + k0 + j];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const double cand = used ? -1.0 : fabs(xp[j]);
-                const double mx = tp_max(cand);
+                // the pivot: a row whose |x| agrees with the column's largest in its high word (within 2^-20 of it)
+                const unsigned cand = used ? 0u : ((unsigned)__double2hiint(xp[j]) & 0x7fffffffu) + 1u;
+                const unsigned mx = tp_max_u32(cand);
                 const unsigned long long bal = __ballot(cand == mx);
                 pr[j] = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(bal));
                 const double ipv = tp_rcp(tp_readlane(xp[j], pr[j]));
@@ -610,17 +641,17 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
             const double f01 = tp_readlane(f[0], pr[1]), f02 = tp_readlane(f[0], pr[2]), f03 = tp_readlane(f[0], pr[3]);
             const double f12 = tp_readlane(f[1], pr[2]), f13 = tp_readlane(f[1], pr[3]), f23 = tp_readlane(f[2], pr[3]);
             if (lane < RP) {
-                for (int c = k0 + 4 + w; c < NC; c += 4 * TW) {
-                    double u[4][4], xv[4];
+                for (int c = k0 + 4 + w; c < NC; c += 6 * TW) {
+                    double u[6][4], xv[6];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < 6; ++i) {
                         const int cc = c + TW * i < NC ? c + TW * i : c;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) u[i][j] = X[pr[j] * LW + cc];
                         xv[i] = X[lane * LW + cc];
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < 6; ++i) {
                         u[i][1] = fma(-f01, u[i][0], u[i][1]);
                         u[i][2] = fma(-f12, u[i][1], fma(-f02, u[i][0], u[i][2]));
                         u[i][3] = fma(-f23, u[i][2], fma(-f13, u[i][1], fma(-f03, u[i][0], u[i][3])));
