@@ -394,10 +394,10 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     if (!o.force_tp) {
         const bool few = RP <= 4 && ((p.B <= 8 && p.N >= 1024) || p.N >= 4096);
         const bool mid = RP > 4 && p.B <= 8 && p.N >= (RP <= 8 ? 2048 : (RP <= 12 ? 4096 : 6144)) && RP <= 16;
-        // 17 .. 48 state rows: the boundary solves cost 15 .. 45 us each (four wavefronts, products on the matrix cores, four pivots per barrier), and
+        // 17 .. 48 state rows: the boundary solves cost 14 .. 42 us each (four wavefronts, products and rank-4 updates on the matrix cores, four pivots per barrier), and
         // the gain comes with the length of the series (its time grows like sqrt(N), the serial chain's like N): SHO-12 (24 rows) N = 8192 / 1e4 /
-        // 65536 1.00 / 1.09 / 2.8 against 1.45 / 1.82 / 11.6 ms; SHO-20 (40 rows) N = 8192 1.58 against 1.50 (not chosen), N = 1e4 1.75 against 1.84,
-        // N = 16384 / 65536 2.2 / 4.5 against 3.0 / 11.7; SHO-24 (48 rows; three block columns on the serial chain) N = 1e4 2.06 against 2.48
+        // 65536 0.93 / 1.03 / 2.6 against 1.45 / 1.77 / 11.6 ms; SHO-20 (40 rows) N = 8192 1.50 against 1.50 (not chosen), N = 1e4 1.67 against 1.83,
+        // N = 16384 / 65536 2.1 / 4.2 against 3.0 / 11.9; SHO-24 (48 rows; three block columns on the serial chain) N = 1e4 1.97 against 2.47
         const int64_t nmin12 = RP <= 24 ? 5120 : (RP <= 32 ? 6144 : (RP <= 40 ? 10000 : 8192));
         const int64_t nmin8 = RP <= 24 ? 6144 : (RP <= 32 ? 8192 : (RP <= 40 ? 10000 : 8192));
         const bool many = RP > 16 && ((p.B <= 2 && p.N >= nmin12) || (p.B <= 8 && p.N >= nmin8));
@@ -408,7 +408,7 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     // boundary as below (measured at 2 .. 48 rows, tools/ab_tp.py): N / nseg tau + nseg t2 is least at sqrt(tau N / t2)
     int nseg = o.tp_segments;
     if (nseg <= 0) {
-        const double tau = RP <= 16 ? 0.7 + RP / 8.0 : 1.0 + RP / 32.0, t2 = RP == 2 ? 0.6 : (RP == 4 ? 2.0 : (RP <= 16 ? 1.3 + RP * RP / 21.0 : 5.0 + (double)RP * RP / 57.0));   // (2 / 4 rows: one thread per draw; up to 16: one wavefront, in registers;
+        const double tau = RP <= 16 ? 0.7 + RP / 8.0 : 1.0 + RP / 32.0, t2 = RP == 2 ? 0.6 : (RP == 4 ? 2.0 : (RP <= 16 ? 1.3 + RP * RP / 21.0 : 5.0 + (double)RP * RP / 64.0));   // (2 / 4 rows: one thread per draw; up to 16: one wavefront, in registers;
                                                                                  //  above: four wavefronts, products on the matrix cores, four pivots per barrier)
         nseg = (int)std::lround(std::sqrt(tau * (double)p.N / t2));
     }

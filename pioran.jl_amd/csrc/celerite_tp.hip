@@ -490,6 +490,7 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
     double* mv = CL + R16 * S1;          // [64] m, later z
     double* ev = mv + 64;                // [64] eta
     double* bl = ev + 64;                // [64] b
+    double* fneg = bl + 64;              // [TW][4][64]: the block's multipliers, negated, per wavefront (A operand of the rank-4 update)
     constexpr int T = 64 * TW;
     const int tid = threadIdx.x, lane = tid & 63, w = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t b = blockIdx.x;
@@ -640,23 +641,32 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
             }
             const double f01 = tp_readlane(f[0], pr[1]), f02 = tp_readlane(f[0], pr[2]), f03 = tp_readlane(f[0], pr[3]);
             const double f12 = tp_readlane(f[1], pr[2]), f13 = tp_readlane(f[1], pr[3]), f23 = tp_readlane(f[2], pr[3]);
-            if (lane < RP) {
-                for (int c = k0 + 4 + w; c < NC; c += 6 * TW) {
-                    double u[6][4], xv[6];
+            // the rank-4 update of the other columns on the matrix cores: X[:, cols] -= F U, F = (f_0 .. f_3) (rows x 4), U = the four pivot rows as they
+            // stand after the earlier pivots of the block (4 x cols).  A wavefront owns whole column tiles of 16 (every row tile of them): the pivot
+            // rows of a column are read before any wavefront writes that column.  (As vector FMAs, lane = row: 14 of a boundary's 33 us at 40 rows.)
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        const int cc = c + TW * i < NC ? c + TW * i : c;
+            for (int j = 0; j < 4; ++j) fneg[(w * 4 + j) * 64 + lane] = -f[j];
+            for (int ct = w; k0 + 4 + 16 * ct < NC; ct += TW) {
+                const int c0 = k0 + 4 + 16 * ct, col = c0 + li, cc = col < NC ? col : NC - 1;
+                const double x0 = X[pr[0] * LW + cc], x1 = X[pr[1] * LW + cc], x2 = X[pr[2] * LW + cc], x3 = X[pr[3] * LW + cc];
+                const double u0 = x0, u1 = fma(-f01, u0, x1), u2 = fma(-f12, u1, fma(-f02, u0, x2)), u3 = fma(-f23, u2, fma(-f13, u1, fma(-f03, u0, x3)));
+                const double ub = lk == 0 ? u0 : (lk == 1 ? u1 : (lk == 2 ? u2 : u3));
+                f64x4 acc[3];
+                double fa[3];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) u[i][j] = X[pr[j] * LW + cc];
-                        xv[i] = X[lane * LW + cc];
-                    }
+                for (int It = 0; It < 3; ++It) {
+                    const int Iq = It < RT ? It : RT - 1;
+                    fa[It] = fneg[(w * 4 + lk) * 64 + 16 * Iq + li];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        u[i][1] = fma(-f01, u[i][0], u[i][1]);
-                        u[i][2] = fma(-f12, u[i][1], fma(-f02, u[i][0], u[i][2]));
-                        u[i][3] = fma(-f23, u[i][2], fma(-f13, u[i][1], fma(-f03, u[i][0], u[i][3])));
-                        const double v = fma(-f[3], u[i][3], fma(-f[2], u[i][2], fma(-f[1], u[i][1], fma(-f[0], u[i][0], xv[i]))));
-                        if (c + TW * i < NC) X[lane * LW + c + TW * i] = v;
+                    for (int g = 0; g < 4; ++g) acc[It][g] = X[(16 * Iq + 4 * g + lk) * LW + cc];
+                }
+#pragma unroll
+                for (int It = 0; It < 3; ++It) {
+                    if (It < RT) {
+                        acc[It] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[It], ub, acc[It], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (col < NC && 16 * It + 4 * g + lk < RP) X[(16 * It + 4 * g + lk) * LW + col] = acc[It][g];
                     }
                 }
             }
@@ -972,7 +982,7 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
     if (nseg > 1)
         hipLaunchKernelGGL((tp_element_kernel<NP, NWV>), dim3((unsigned)(nseg - 1), (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
                            (const TpRec*)rec, (const TpStep*)stp, elem);
-    const size_t r16 = (size_t)((RP + 15) / 16) * 16, lds2 = (r16 * (2 * r16 + 3) + 4 * r16 * (r16 + 1) + 192) * sizeof(double);
+    const size_t r16 = (size_t)((RP + 15) / 16) * 16, lds2 = (r16 * (2 * r16 + 3) + 4 * r16 * (r16 + 1) + 192 + 1024) * sizeof(double);
     static size_t granted[2][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
