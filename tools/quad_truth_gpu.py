@@ -29,8 +29,14 @@ for N in (150, 1000, 10000):
     res["windowed (block)"], stb = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True); assert name() == "block"
     ctx.set_option("scan_config", "tile")
     res["windowed (tile)"], stt = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True); assert name() == "tile"
+    ctx.set_option("scan_config", "tp")         # the time-parallel family (celerite_tp.hip), 64 draws per call
+    tpv = np.empty(B); stp = np.empty(B, dtype=np.int32)
+    for b0 in range(0, B, 64):
+        sl = slice(b0, min(B, b0 + 64))
+        tpv[sl], stp[sl] = ds.logl_batch(A[sl], Bc[sl], C, Dd, mu=mu[sl], nu=nu[sl], return_status=True); assert name() == "tp"
+    res["time-parallel"] = tpv
     ctx.set_option("scan_config", None)
-    print(f"N = {N}: {B} draws; status: block {int((stb != 0).sum())} flagged, tile {int((stt != 0).sum())} flagged")
+    print(f"N = {N}: {B} draws; status: block {int((stb != 0).sum())} flagged, tile {int((stt != 0).sum())} flagged, time-parallel {int((stp != 0).sum())} flagged")
     edges = [0, 1e-9, 1e-8, 1e-7, 1e-6, 1e-5]
     for lo, hi in zip(edges, edges[1:]):
         m = (ratio >= lo) & (ratio < hi)
