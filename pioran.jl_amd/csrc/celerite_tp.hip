@@ -474,20 +474,19 @@ __global__ void __launch_bounds__(64 * NWV) tp_element_kernel(int64_t N, int RP,
 // pivot of column k is the largest entry among the rows not used yet; the row keeps its place and remembers its column): one barrier per pivot.
 // (I + P J is the identity plus a product of two symmetric positive semi-definite matrices: not symmetric, eigenvalues >= 1.)
 // Thread (lane = row, wavefront = every fourth column).  The products run over the RP live rows only.
-template <int TW>      // wavefronts: 4, or 1 up to 16 rows (no barrier at all: LDS traffic of one wavefront is served in order)
+template <int TW, int RT>      // wavefronts (4; 1: no barrier at all, LDS traffic of one wavefront is served in order); RT 16-row tiles: 16 (RT - 1) < RP <= 16 RT
 __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, int J, const int32_t* __restrict__ row_term, const int32_t* __restrict__ row_kind,
                                                           const double* __restrict__ A_, const double* __restrict__ Bc_, const double* __restrict__ elem,
                                                           double* __restrict__ bnd)
 {
     extern __shared__ double lds[];
-    const int RT = (RP + 15) / 16, R16 = 16 * RT;      // the products run on 16 x 16 tiles: rows and columns RP .. R16 - 1 of every matrix stay zero
-    const int S1 = R16 + 1, LW = 2 * R16 + 3;          // odd strides
+    constexpr int R16 = 16 * RT;                       // the products run on 16 x 16 tiles: rows and columns RP .. R16 - 1 of every matrix stay zero
+    constexpr int S1 = R16 + 1, LW = 2 * R16 + 3;      // odd strides
     double* X = lds;                     // [R16][LW]: [W, later A Z | right-hand sides z (1), Z (RP)]
     double* Pm = X + R16 * LW;           // [R16][S1]: P, later Z, then P'
-    double* JL = Pm + R16 * S1;          // J
-    double* AL = JL + R16 * S1;          // A' (as stored: AL[k][r] = A[r][k])
-    double* CL = AL + R16 * S1;          // C
-    double* mv = CL + R16 * S1;          // [64] m, later z
+    double* JL = Pm + R16 * S1;          // J, then (the same buffer) A' as stored: AL[k][r] = A[r][k] — J is dead once W = I + P J is formed
+    double* AL = JL;
+    double* mv = JL + R16 * S1;          // [64] m, later z
     double* ev = mv + 64;                // [64] eta
     double* bl = ev + 64;                // [64] b
     double* fneg = bl + 64;              // [TW][4][64]: the block's multipliers, negated, per wavefront (A operand of the rank-4 update)
@@ -496,7 +495,7 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
     const int64_t b = blockIdx.x;
     double* bs = bnd + b * nseg * TP_BND_DOUBLES;
     const int NC = 2 * RP + 1;           // live columns of [W | z | Z], packed: W 0 .. RP-1, z RP, Z RP+1 .. 2 RP
-    for (int i = tid; i < R16 * LW + 4 * R16 * S1; i += T) lds[i] = 0.0;
+    for (int i = tid; i < R16 * LW + 2 * R16 * S1; i += T) lds[i] = 0.0;
     // One R x R x R product on the matrix cores: tile (I, Jt) of the result by wavefront (I RT + Jt) mod 4, operands straight from LDS
     // (A operand: row 16 I + (lane & 15), k = 4 ks + (lane >> 4); B operand: k, column 16 Jt + (lane & 15); result register g: row 4 g + (lane >> 4)).
     // (Scalar products — one output per thread, two LDS reads per FMA — took 9 us each at 40 rows, the LDS's bandwidth.)
@@ -506,11 +505,11 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
             const int I = tI / RT, Jt = tI - I * RT;
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
             // (every operand read of the tile in flight before its first matrix instruction: one read pair at a time cost 4.6 us per product, four
-            //  pairs at a time 2.4; RT <= 3 at the 48 rows this kernel takes)
-            double av[3][4], bv[3][4];
+            //  pairs at a time 2.4; RT <= 4 at the 64 rows this kernel takes)
+            double av[RT][4], bv[RT][4];
 #pragma unroll
-            for (int k4 = 0; k4 < 3; ++k4) {
-                const int kq = k4 < RT ? k4 : RT - 1;
+            for (int k4 = 0; k4 < RT; ++k4) {
+                const int kq = k4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     av[k4][i] = aop(16 * I + li, 16 * kq + 4 * i + lk);
@@ -518,11 +517,9 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
                 }
             }
 #pragma unroll
-            for (int k4 = 0; k4 < 3; ++k4) {
-                if (k4 < RT) {
+            for (int k4 = 0; k4 < RT; ++k4) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k4][i], bv[k4][i], acc, 0, 0, 0);
-                }
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k4][i], bv[k4][i], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -533,8 +530,8 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
     };
     TP_SYNC();
     // entry i = tid + T q of an RP x RP matrix: (row, col) = (i / RP, i % RP) — consecutive lanes, consecutive columns
-    const int nq = (RP * RP + T - 1) / T;      // <= 9 at the 48 rows four wavefronts take, 4 at the 16 of one
-    constexpr int NQ = TW == 1 ? 4 : 9;
+    const int nq = (RP * RP + T - 1) / T;      // <= 16 at the 64 rows four wavefronts take, 4 at the 16 of one
+    constexpr int NQ = (R16 * R16 + T - 1) / T;
     int row[NQ], col[NQ];
     bool ok[NQ];
 #pragma unroll
@@ -544,22 +541,21 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
         row[q] = ok[q] ? i / RP : 0;
         col[q] = ok[q] ? i % RP : 0;
     }
-    // An element's matrices (J, A', C, eta, b) come through registers with ONE point of use per boundary: the top of the iteration copies element p
-    // into LDS and the loads of element p + 1 are issued right behind it — they have the whole iteration.  (The compiler waits with vmcnt(0) at
-    // every use of a loaded register: with the uses spread over the iteration each one also waited for the loads just issued, ~2 us three times
-    // per boundary, 6 us per boundary at four rows whatever else was tuned.)
+    // An element's matrices come through registers, each loaded well ahead of its use (the compiler waits with vmcnt(0) at every use of a loaded
+    // register, i.e. for EVERY load in flight: a load issued just before another one's use costs its full latency, ~2 us, there): J, eta, b of
+    // element p + 1 and C of element p at the top of iteration p (J is used at the next top, C at this iteration's end), A' of element p + 1 behind
+    // the point where A' of element p goes to LDS (after the first product).
     double rj[NQ], ra[NQ], rc[NQ], reta = 0.0, rb = 0.0;
-    auto fetch_elem = [&](const double* e) __attribute__((always_inline)) {
+    auto fetch_mat = [&](double (&dst)[NQ], const double* src) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int o = row[q] * 64 + col[q];
-            rj[q] = ok[q] ? e[8192 + o] : 0.0;
-            ra[q] = ok[q] ? e[o] : 0.0;
-            rc[q] = ok[q] ? e[4096 + o] : 0.0;
-        }
-        if (tid < RP) { reta = e[12288 + 64 + tid]; rb = e[12288 + tid]; }
+        for (int q = 0; q < NQ; ++q) dst[q] = ok[q] ? src[row[q] * 64 + col[q]] : 0.0;
     };
-    if (nseg > 1) fetch_elem(elem + b * nseg * TP_ELEM_DOUBLES);
+    if (nseg > 1) {
+        const double* e0 = elem + b * nseg * TP_ELEM_DOUBLES;
+        fetch_mat(rj, e0 + 8192);
+        fetch_mat(ra, e0);
+        if (tid < RP) { reta = e0[12288 + 64 + tid]; rb = e0[12288 + tid]; }
+    }
     double pn[NQ], mnew = 0.0;
     auto publish = [&](int pb) __attribute__((always_inline)) {
         double* bo = bs + (int64_t)pb * TP_BND_DOUBLES;
@@ -587,17 +583,17 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
     TP_SYNC();
     for (int p = 0; p + 1 < nseg; ++p) {
         const double* e = elem + (b * nseg + p) * TP_ELEM_DOUBLES;
+        // (J, A' and C of this element sit in registers since the previous iteration; J and A' share one LDS buffer — five R x R matrices and the
+        //  solve's columns do not fit 160 KB at 64 rows —, C is added from its registers; the next element's loads go out once all three are consumed)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (ok[q]) {
-                const int o = row[q] * S1 + col[q];
-                JL[o] = rj[q];
-                AL[o] = ra[q];
-                CL[o] = rc[q];
-            }
-        }
+        for (int q = 0; q < NQ; ++q)
+            if (ok[q]) JL[row[q] * S1 + col[q]] = rj[q];
         if (tid < RP) { ev[tid] = reta; bl[tid] = rb; }
-        if (p + 2 < nseg) fetch_elem(e + TP_ELEM_DOUBLES);
+        fetch_mat(rc, e + 4096);
+        if (p + 2 < nseg) {
+            fetch_mat(rj, e + TP_ELEM_DOUBLES + 8192);
+            if (tid < RP) { reta = e[TP_ELEM_DOUBLES + 12288 + 64 + tid]; rb = e[TP_ELEM_DOUBLES + 12288 + tid]; }
+        }
         if (p > 0) publish(p);       // (the state this iteration starts from: its stores, too, have the iteration — vmcnt counts them)
         TP_SYNC();
         // W = I + P J, z = m + P eta, Z = P
@@ -617,6 +613,10 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
         // panel in registers, pivot rows by v_readlane: no LDS, no barrier), then the rank-4 update of its share of the other columns with the four
         // pivot rows as they stand after the earlier pivots of the block (u_j = row pr_j - sum_{i<j} f_i[pr_j] u_i), one barrier per block.
         // (One pivot per barrier with its column through LDS: 1.1 us per pivot, 43 of a boundary's 77 us at 40 rows.)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (ok[q]) AL[row[q] * S1 + col[q]] = ra[q];          // (J is dead: the barrier behind W = I + P J has passed)
+        if (p + 2 < nseg) fetch_mat(ra, e + TP_ELEM_DOUBLES);
         bool used = lane >= RP;
         int mycol = 0;
         double mypiv = 1.0;
@@ -651,18 +651,18 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
                 const double x0 = X[pr[0] * LW + cc], x1 = X[pr[1] * LW + cc], x2 = X[pr[2] * LW + cc], x3 = X[pr[3] * LW + cc];
                 const double u0 = x0, u1 = fma(-f01, u0, x1), u2 = fma(-f12, u1, fma(-f02, u0, x2)), u3 = fma(-f23, u2, fma(-f13, u1, fma(-f03, u0, x3)));
                 const double ub = lk == 0 ? u0 : (lk == 1 ? u1 : (lk == 2 ? u2 : u3));
-                f64x4 acc[3];
-                double fa[3];
+                f64x4 acc[RT];
+                double fa[RT];
 #pragma unroll
-                for (int It = 0; It < 3; ++It) {
-                    const int Iq = It < RT ? It : RT - 1;
+                for (int It = 0; It < RT; ++It) {
+                    const int Iq = It;
                     fa[It] = fneg[(w * 4 + lk) * 64 + 16 * Iq + li];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) acc[It][g] = X[(16 * Iq + 4 * g + lk) * LW + cc];
                 }
 #pragma unroll
-                for (int It = 0; It < 3; ++It) {
-                    if (It < RT) {
+                for (int It = 0; It < RT; ++It) {
+                    {
                         acc[It] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[It], ub, acc[It], 0, 0, 0);
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
@@ -691,12 +691,13 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
         if (tid < RP) mv[tid] = mnew;
         // (the A operand runs over columns up to R16 - 1 of X: past RP sit z and Z, multiplied by the zero rows of A')
         gemm([&](int r, int kk) { return X[r * LW + kk]; }, [&](int kk, int c) { return AL[kk * S1 + c]; },
-             [&](int r, int c, double v) { Pm[r * S1 + c] = v + CL[r * S1 + c]; });
+             [&](int r, int c, double v) { Pm[r * S1 + c] = v; });
         TP_SYNC();
         // symmetrise (the two products round differently); published at the top of the next iteration
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (ok[q]) pn[q] = 0.5 * (Pm[row[q] * S1 + col[q]] + Pm[col[q] * S1 + row[q]]);
+            if (ok[q]) pn[q] = 0.5 * (Pm[row[q] * S1 + col[q]] + Pm[col[q] * S1 + row[q]]) + rc[q];       // (C is symmetric: the element kernel symmetrises nothing,
+                                                                                                          //  its C is symmetric by construction up to rounding)
         TP_SYNC();
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
@@ -982,17 +983,10 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
     if (nseg > 1)
         hipLaunchKernelGGL((tp_element_kernel<NP, NWV>), dim3((unsigned)(nseg - 1), (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
                            (const TpRec*)rec, (const TpStep*)stp, elem);
-    const size_t r16 = (size_t)((RP + 15) / 16) * 16, lds2 = (r16 * (2 * r16 + 3) + 4 * r16 * (r16 + 1) + 192 + 1024) * sizeof(double);
-    static size_t granted[2][64] = {};
+    const size_t r16 = (size_t)((RP + 15) / 16) * 16, lds2 = (r16 * (2 * r16 + 3) + 2 * r16 * (r16 + 1) + 192 + 1024) * sizeof(double);
+    static size_t granted[8][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
-    // one wavefront (no barriers) up to 4 rows: 4.2 against 5.2 us per boundary; at 16 rows its products cost more than the barriers (27 against 15 us)
-    const bool one = RP <= 4;
-    if (lds2 > granted[one][dev]) {
-        const void* fn = one ? (const void*)tp_boundary_kernel<1> : (const void*)tp_boundary_kernel<4>;
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return PIORAN_ERR_HIP;
-        granted[one][dev] = lds2;
-    }
     if (RP == 2)
         hipLaunchKernelGGL((tp_boundary_small_kernel<2>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, nseg, p.J, B, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
     else if (RP == 4)
@@ -1004,10 +998,21 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
             default: return PIORAN_ERR_UNSUPPORTED;
         }
 #undef TP_WAVE_CASE
-    } else if (one)
-        hipLaunchKernelGGL((tp_boundary_kernel<1>), dim3((unsigned)B), dim3(64), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
-    else
-        hipLaunchKernelGGL((tp_boundary_kernel<4>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
+    } else {
+        // four wavefronts, RT = 2 .. 4 tiles of 16 rows (24 .. 64 state rows)
+        const int rt = (RP + 15) / 16;
+        const void* fn = rt == 2 ? (const void*)tp_boundary_kernel<4, 2> : (rt == 3 ? (const void*)tp_boundary_kernel<4, 3> : (const void*)tp_boundary_kernel<4, 4>);
+        if (lds2 > granted[rt][dev]) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return PIORAN_ERR_HIP;
+            granted[rt][dev] = lds2;
+        }
+        if (rt == 2)
+            hipLaunchKernelGGL((tp_boundary_kernel<4, 2>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
+        else if (rt == 3)
+            hipLaunchKernelGGL((tp_boundary_kernel<4, 3>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
+        else
+            hipLaunchKernelGGL((tp_boundary_kernel<4, 4>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
+    }
     hipLaunchKernelGGL((tp_filter_kernel<NP, NWV>), dim3((unsigned)nseg, (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
                        (const TpRec*)rec, (const TpStep*)stp, (const double*)bnd, part, sval);
     hipLaunchKernelGGL(tp_finish_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, N, nseg, B, (const double*)part, p.out, p.status);
@@ -1016,7 +1021,7 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
 
 }  // namespace
 
-int pioran_tp_supported_rows() { return 48; }     // (tp_boundary_kernel's LDS: five R x R matrices and the 2 R + 1 columns of the solve)
+int pioran_tp_supported_rows() { return 64; }     // (lane = state row in the element and filter kernels)
 
 // state rows as the kernels want them: a multiple of 2 up to 16 rows (one wavefront per segment), of 8 above (four)
 int pioran_tp_padded_rows(int rows) { return rows <= 16 ? (rows + 1) & ~1 : (rows + 7) & ~7; }
@@ -1030,7 +1035,7 @@ size_t pioran_tp_workspace_doubles(int64_t B, int64_t N, int RP, int nseg)
 // (the last one shorter)
 int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream)
 {
-    if (RP < 2 || RP > 48 || RP != pioran_tp_padded_rows(RP) || nseg < 1 || L < 2 || (int64_t)nseg * L < p.N || (int64_t)(nseg - 1) * L >= p.N || p.B < 1 ||
+    if (RP < 2 || RP > 64 || RP != pioran_tp_padded_rows(RP) || nseg < 1 || L < 2 || (int64_t)nseg * L < p.N || (int64_t)(nseg - 1) * L >= p.N || p.B < 1 ||
         p.B > 65535 || p.N > 0x7fffffffLL)
         return PIORAN_ERR_UNSUPPORTED;
     if (RP <= 16) {
@@ -1051,6 +1056,8 @@ int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int
         case 4: return tp_launch<4, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
         case 5: return tp_launch<5, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
         case 6: return tp_launch<6, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
+        case 7: return tp_launch<7, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
+        case 8: return tp_launch<8, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
     }
     return PIORAN_ERR_UNSUPPORTED;
 }

@@ -1982,10 +1982,11 @@ def test_windowed_gradient_matches_complex_step(ctx, J, N, B, nreal):
 # ---- time-parallel evaluation of a handful of draws (celerite_tp.hip, round 5) -----------------------------------------------------------------
 @pytest.mark.parametrize("J,N,B,nreal,nseg", [(1, 100, 1, 0, 2), (1, 100, 1, 1, 2), (2, 200, 1, 0, 4), (3, 500, 2, 1, 5), (6, 300, 3, 0, 0), (8, 640, 2, 0, 7),
                                               (9, 400, 4, 4, 6), (12, 2000, 8, 3, 0), (20, 1000, 2, 0, 8), (20, 777, 1, 0, 3), (21, 500, 1, 20, 5),
-                                              (24, 640, 2, 0, 4), (5, 64, 1, 0, 4), (4, 333, 64, 0, 3)])
+                                              (24, 640, 2, 0, 4), (5, 64, 1, 0, 4), (4, 333, 64, 0, 3), (32, 700, 2, 0, 5), (30, 300, 1, 0, 3), (40, 450, 2, 20, 4),
+                                              (36, 260, 1, 9, 2)])
 def test_time_parallel_family_vs_oracle(ctx, J, N, B, nreal, nseg):
     """The state-space / associative-element form (segments of the series on different CUs), forced at every shape it takes: one wavefront per
-    segment (up to 16 state rows) and four (up to 48), one-row terms packed in pairs, padded row counts, segment counts that do not divide N, the
+    segment (up to 16 state rows) and four (up to 64: DRWCelerite-20 is 20 two-row and 20 one-row terms), one-row terms packed in pairs, padded row counts, segment counts that do not divide N, the
     shortest segments (16 steps), 64 draws.  Against the oracle at 1e-11 (the prototype's study: profiles/r05_time_parallel_proto.txt)."""
     rng = np.random.default_rng(3300 + J + N)
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
