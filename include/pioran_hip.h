@@ -79,7 +79,7 @@ int pioran_ctx_trim(pioran_ctx* ctx);
  *   "no_tile"         value "1": never the windowed form with one draw per wavefront (celerite_tile.hip); "scan_config" = "tile" forces it for
  *                     every launch it can take
  *   "no_tp"           value "1": never the time-parallel evaluation (celerite_tp.hip: segments of the series on different CUs, for a handful of
- *                     draws of a long series — automatic for up to 8 draws with up to 4 / 8 / 12 / 16 state rows from 1024 / 2048 / 4096 / 6144 steps on, up to 64 draws at up to 4 rows from 4096, up to 8 draws with up to 24 / 32 / 40 / 48 / 64 rows from 6144 / 8192 / 10000 / 8192 / 12288);
+ *                     draws of a long series — automatic for up to 8 draws with up to 4 / 8 / 12 / 16 state rows from 1024 / 2048 / 4096 / 6144 steps on, up to 64 draws at up to 4 rows from 4096, up to 8 draws with up to 24 / 32 / 40 / 48 / 64 rows from 5120 / 6144 / 8192 / 8192 / 12288);
  *                     "scan_config" = "tp" forces it wherever it applies (shared (c, d), up to 64 state rows, up to 64 draws);
  *                     "tp_segments" its segment count (0 / NULL = automatic)
  *   "dense_old_chain" 0 one launch per block column (default), 1 the panel / update chain of rounds 1-3 (2 .. 8: timing experiments, only in

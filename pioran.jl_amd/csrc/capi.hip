@@ -396,13 +396,13 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
         const bool mid = RP > 4 && p.B <= 8 && p.N >= (RP <= 8 ? 2048 : (RP <= 12 ? 4096 : 6144)) && RP <= 16;
         // 17 .. 64 state rows: the boundary solves cost 14 .. 47 us each (four wavefronts, products and rank-4 updates on the matrix cores, four pivots per barrier), and
         // the gain comes with the length of the series (its time grows like sqrt(N), the serial chain's like N): SHO-12 (24 rows) N = 8192 / 1e4 /
-        // 65536 0.93 / 1.03 / 2.6 against 1.45 / 1.77 / 11.6 ms; SHO-20 (40 rows) N = 8192 1.50 against 1.50 (not chosen), N = 1e4 1.67 against 1.83,
-        // N = 16384 / 65536 2.1 / 4.2 against 3.0 / 11.9; SHO-24 (48 rows; three block columns on the serial chain) N = 1e4 1.97 against 2.47
+        // 65536 0.84 / 0.93 / 2.4 against 1.45 / 1.77 / 11.6 ms; SHO-20 (40 rows) N = 8192 / 1e4 / 65536 1.39 / 1.54 / 3.9 against 1.50 / 1.83 / 11.9;
+        // SHO-24 (48 rows; three block columns on the serial chain) N = 1e4 1.80 against 2.47
         // 49 .. 64 state rows: DRWCelerite-20 (60 rows; four block columns on the serial chain) N = 1e4 2.71 against 2.61 (not chosen), N = 16384 / 65536
         // 3.5 / 7.0 against 4.3 / 19.1 ms; SHO-32 (64 rows; FIVE block columns on the serial chain) N = 8192 / 65536 2.45 / 7.0 against 3.7 / 34.4 ms
         const int64_t nwide = p.R + 1 > 64 ? 6144 : 12288;
-        const int64_t nmin12 = RP <= 24 ? 5120 : (RP <= 32 ? 6144 : (RP <= 40 ? 10000 : (RP <= 48 ? 8192 : nwide)));
-        const int64_t nmin8 = RP <= 24 ? 6144 : (RP <= 32 ? 8192 : (RP <= 40 ? 10000 : (RP <= 48 ? 8192 : nwide)));
+        const int64_t nmin12 = RP <= 24 ? 4096 : (RP <= 32 ? 5120 : (RP <= 40 ? 8192 : (RP <= 48 ? 6144 : nwide)));
+        const int64_t nmin8 = RP <= 24 ? 5120 : (RP <= 32 ? 6144 : (RP <= 40 ? 8192 : (RP <= 48 ? 8192 : nwide)));
         const bool many = RP > 16 && ((p.B <= 2 && p.N >= nmin12) || (p.B <= 8 && p.N >= nmin8));
         if (!few && !mid && !many) return PIORAN_ERR_UNSUPPORTED;
     }

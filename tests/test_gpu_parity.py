@@ -2041,15 +2041,15 @@ def test_time_parallel_dispatch_reference_values_and_flagged_draws(ctx, golden_d
     g6 = ds3.logl_batch(A8[:, :6], B8[:, :6], C8[:6], D8[:6])
     assert name() == "tp"                                           # twelve state rows: from 4096
     assert relerr(g6, O.logl_batch(A8[:, :6], B8[:, :6], C8[:6], D8[:6], t8, y8, s8, None, None)) < 1e-11
-    # 17 .. 48 state rows: long series only (the boundary solves are R^3 each)
-    t9, y9, s9, A9_, B9_, C9, D9, mu9, nu9 = _random_case(np.random.default_rng(517), 9000, 20, 4)
+    # 17 .. 64 state rows: long series only (the boundary solves are R^3 each)
+    t9, y9, s9, A9_, B9_, C9, D9, mu9, nu9 = _random_case(np.random.default_rng(517), 7000, 20, 4)
     ds9 = pj.Dataset(t9, y9, s9, ctx)
-    g9_ = ds9.logl_batch(A9_[:2, :12], B9_[:2, :12], C9[:12], D9[:12], mu=mu9[:2], nu=nu9[:2])       # 24 state rows: from 5120 steps on
+    g9_ = ds9.logl_batch(A9_[:2, :12], B9_[:2, :12], C9[:12], D9[:12], mu=mu9[:2], nu=nu9[:2])       # 24 state rows: from 4096 steps on
     assert name() == "tp" and relerr(g9_, O.logl_batch(A9_[:2, :12], B9_[:2, :12], C9[:12], D9[:12], t9, y9, s9, mu9[:2], nu9[:2], nthreads=8)) < 1e-10
     ds9.logl_batch(A9_, B9_, C9, D9)
-    assert name() != "tp"                                           # 40 state rows: from 10000 steps on
+    assert name() != "tp"                                           # 40 state rows: from 8192 steps on
     ds9.logl_batch(A9_[:, :16], B9_[:, :16], C9[:16], D9[:16])
-    assert name() == "tp"                                           # 32 state rows, four draws: from 8192
+    assert name() == "tp"                                           # 32 state rows, four draws: from 6144
     ds9.close()
     # (iv) per-draw series
     Y = y[None, :] + 0.01 * rng.standard_normal((B, N)); S2 = s2[None, :] * rng.uniform(0.8, 1.2, (B, 1))
