@@ -196,7 +196,8 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
     constexpr int CH = Stage::CH;
     __shared__ double red[2][NWV][64];
     __shared__ double2 rbuf[2][CH * Stage::RMAX * 3], sbuf[2][CH * 2];
-    __shared__ double sring[256];          // D_n of the last (up to) 256 steps: their logarithms are taken 256 at a time by all threads, off the chain
+    __shared__ double sring[256];
+    __shared__ double2 uni[NWV][32];       // a lane vector back as wave-uniform column pairs (one 16-byte broadcast read per pair; v_readlane: two per value)          // D_n of the last (up to) 256 steps: their logarithms are taken 256 at a time by all threads, off the chain
     const int lane = threadIdx.x & 63, w = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seg = blockIdx.x;
     const int64_t b = blockIdx.y;
@@ -264,6 +265,10 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
             TP_BARRIER();
             Ph = (red[k & 1][0][lane] + red[k & 1][1][lane]) + (red[k & 1][2][lane] + red[k & 1][3][lane]);
         }
+        reinterpret_cast<double*>(uni[w])[lane] = Ph;
+        double2 phc[NP];
+#pragma unroll
+        for (int s = 0; s < NP; ++s) phc[s] = uni[w][NWV * s + w];
         double sS = hh * Ph, sm = hh * m;
         tp_sum2<NWV == 1>(sS, sm);
         const double S = sbuf[buf][si * 2 + 1].x + sS, v = s0.y - sm;
@@ -274,9 +279,9 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
         m = fma(K, v, m);
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
-            const int c0 = 2 * (NWV * s + w);
-            P[s][0] = fma(-K, tp_readlane(Ph, c0), P[s][0]);
-            P[s][1] = fma(-K, tp_readlane(Ph, c0 + 1), P[s][1]);
+            const double2 pc = phc[s];
+            P[s][0] = fma(-K, pc.x, P[s][0]);
+            P[s][1] = fma(-K, pc.y, P[s][1]);
         }
         if ((k & 255) == 255 || k == len - 1) {
             TP_BARRIER();
@@ -335,6 +340,7 @@ __global__ void __launch_bounds__(64 * NWV) tp_element_kernel(int64_t N, int RP,
     constexpr int CH = Stage::CH;
     __shared__ double red[2][2][NWV][64], red2[2][2][NWV][64];     // by step parity: no wavefront is more than one barrier ahead of another
     __shared__ double2 rbuf[2][CH * Stage::RMAX * 3], sbuf[2][CH * 2];
+    __shared__ double2 uni[NWV][3][32];    // u, A'g, Y h back as wave-uniform column pairs (one 16-byte broadcast read per pair; v_readlane: two per value)
     const int lane = threadIdx.x & 63, w = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seg = blockIdx.x;
     const int64_t b = blockIdx.y;
@@ -403,6 +409,11 @@ __global__ void __launch_bounds__(64 * NWV) tp_element_kernel(int64_t N, int RP,
             u = (red[kk & 1][0][0][lane] + red[kk & 1][0][1][lane]) + (red[kk & 1][0][2][lane] + red[kk & 1][0][3][lane]);
             ag = (red[kk & 1][1][0][lane] + red[kk & 1][1][1][lane]) + (red[kk & 1][1][2][lane] + red[kk & 1][1][3][lane]);
         }
+        reinterpret_cast<double*>(uni[w][0])[lane] = u;
+        reinterpret_cast<double*>(uni[w][1])[lane] = ag;
+        double2 uc[NP], agc[NP];
+#pragma unroll
+        for (int s = 0; s < NP; ++s) { uc[s] = uni[w][0][NWV * s + w]; agc[s] = uni[w][1][NWV * s + w]; }
         double gu = mg * u, gb = mg * bv;
         tp_sum2<NWV == 1>(gu, gb);
         const double delta = st_s + gu, idel = tp_rcp(delta);
@@ -411,8 +422,7 @@ __global__ void __launch_bounds__(64 * NWV) tp_element_kernel(int64_t N, int RP,
         double hfx = 0.0, yh = 0.0;
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
-            const int c0 = 2 * (NWV * s + w);
-            const double u0 = tp_readlane(u, c0), u1 = tp_readlane(u, c0 + 1);
+            const double u0 = uc[s].x, u1 = uc[s].y;
             const double x0 = fma(-agd, u0, At[s][0]), x1 = fma(-agd, u1, At[s][1]);
             xf[s][0] = fma(al_[s][0], x0, be_[s][0] * x1);
             xf[s][1] = fma(al_[s][1], x1, be_[s][1] * x0);
@@ -435,19 +445,23 @@ __global__ void __launch_bounds__(64 * NWV) tp_element_kernel(int64_t N, int RP,
         const double gbb = fma(gu, st_yos, gb);
         bb = fma(-u, gbb * idel, bb);
         const double Fb = fma(mal, bb, mbe * tp_partner(bb));
+        reinterpret_cast<double*>(uni[w][2])[lane] = Yh;
+        double2 yhc2[NP];
+#pragma unroll
+        for (int s = 0; s < NP; ++s) yhc2[s] = uni[w][2][NWV * s + w];
         double hYh = mh * Yh, hFb = mh * Fb;
         tp_sum2<NWV == 1>(hYh, hFb);
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
-            const int jj = NWV * s + w, c0 = 2 * jj;
+            const int jj = NWV * s + w;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const double Kc = K_[s][k], yhc = tp_readlane(Yh, c0 + k);
+                const double Kc = K_[s][k], yhc = k == 0 ? yhc2[s].x : yhc2[s].y;
                 At[s][k] = fma(-hFX, Kc, xf[s][k]);
                 double cn = yv[s][k] - Kr * yhc - Yh * Kc + Kr * Kc * hYh - Kr * (Kc * st_s);
                 cn += (lane >> 1) == jj ? ((odd == (k == 1)) ? mq.x : mq.y) : 0.0;
                 C[s][k] = cn;
-                Jm[s][k] = fma(agd, tp_readlane(ag, c0 + k), Jm[s][k]);
+                Jm[s][k] = fma(agd, k == 0 ? agc[s].x : agc[s].y, Jm[s][k]);
             }
         }
         eta = fma(ag, (st_y - gb) * idel, eta);
