@@ -1037,8 +1037,8 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
 
 int pioran_tp_supported_rows() { return 64; }     // (lane = state row in the element and filter kernels)
 
-// state rows as the kernels want them: a multiple of 2 up to 16 rows (one wavefront per segment), of 8 above (four)
-int pioran_tp_padded_rows(int rows) { return rows <= 16 ? (rows + 1) & ~1 : (rows + 7) & ~7; }
+// state rows as the kernels want them: a multiple of 2 up to 12 rows (one wavefront per segment), of 8 above (four; at 16 rows four are 9 % ahead of one)
+int pioran_tp_padded_rows(int rows) { return rows <= 12 ? (rows + 1) & ~1 : (rows + 7) & ~7; }
 
 size_t pioran_tp_workspace_doubles(int64_t B, int64_t N, int RP, int nseg)
 {
@@ -1052,7 +1052,7 @@ int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int
     if (RP < 2 || RP > 64 || RP != pioran_tp_padded_rows(RP) || nseg < 1 || L < 2 || (int64_t)nseg * L < p.N || (int64_t)(nseg - 1) * L >= p.N || p.B < 1 ||
         p.B > 65535 || p.N > 0x7fffffffLL)
         return PIORAN_ERR_UNSUPPORTED;
-    if (RP <= 16) {
+    if (RP <= 12) {
         switch (RP / 2) {
             case 1: return tp_launch<1, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
             case 2: return tp_launch<2, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
@@ -1066,6 +1066,7 @@ int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int
         return PIORAN_ERR_UNSUPPORTED;
     }
     switch (RP / 8) {
+        case 2: return tp_launch<2, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
         case 3: return tp_launch<3, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
         case 4: return tp_launch<4, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
         case 5: return tp_launch<5, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
