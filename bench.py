@@ -629,6 +629,33 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
                                              "scalar entry — 'block': celerite_block_kernel (windowed form, 16 steps per window on the fp64 matrix cores, a "
                                              "serial chain of windows; celerite_block.hip), 'tp': the time-parallel family (celerite_tp.hip, round 5: "
                                              "segments of the series on different CUs; up to 48 state rows on series that are long enough for their rows)")
+    # -- one evaluation of a LONG series (the reference grid goes to N = 65536, benchmark/benchmarks.jl:16-18): the time-parallel family (celerite_tp.hip,
+    #    round 5) against the serial-chain kernel it replaces there ("no_tp"), scalar entry, PCIe included -------------------------------------------
+    longs = {}
+    NL = 65536
+    tL, yL, eL = synth_series(NL)
+    fmL, fML = 1.0 / (tL[-1] - tL[0]), 1.0 / (2 * np.min(np.diff(tL)))
+    for basis in ("SHO", "DRWCelerite"):
+        AL_, BL_, CL_, DL_ = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:1, :3], fmL, fML, J, theta[:1, 3], basis_function=basis)
+        ysL, ssL = yL - mu[0], nu[0] * eL ** 2
+        entry = {}
+        for key, off in (("ms_incl_pcie", False), ("serial_chain_ms_incl_pcie", True)):
+            ctx.set_option("no_tp", off)
+            try:
+                vL = ctx.logl(AL_[0], BL_[0], CL_, DL_, tL, ysL, ssL)
+                kL = pj._lib.lib().pioran_celerite_config_name(-1).decode()
+                wL = []
+                for _ in range(3):
+                    t0 = time.perf_counter(); ctx.logl(AL_[0], BL_[0], CL_, DL_, tL, ysL, ssL); wL.append(time.perf_counter() - t0)
+            finally:
+                ctx.set_option("no_tp", False)
+            entry[key] = med(wL) * 1e3
+            entry["kernel" if not off else "serial_chain_kernel"] = kL
+            entry["value" if not off else "serial_chain_value"] = vL
+        entry["rel_between_the_two"] = abs(entry["value"] - entry["serial_chain_value"]) / abs(entry["serial_chain_value"])
+        longs[f"{basis}{J}_N{NL}"] = entry
+    out["single_evaluation_long_series"] = longs
+
     # -- the reference's own benchmark (benchmark/benchmarks.jl:16-18, 74-91: ONE scalar `logl` call, j terms with random coefficients, the suite's
     #    yerr passed as the variance) at its N = 8192 column; the published figure's values read off BASELINE.md section 1 (+-15 %, unstated CPU).
     #    tools/bench_grid.py runs the whole grid (profiles/r04_grid.json). -----------------------------------------------------------------------
