@@ -217,7 +217,7 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
  * grad_c / grad_d).  With 64 .. 143 rows (and as a cross-check: context option "no_block") the STEP-BY-STEP reverse mode runs
  * (celerite_wide.hip: forward pass with checkpoints, replayed segments, lean adjoint kernel since round 4): 40 .. 45 ms at 64 .. 95 rows,
  * 62 .. 157 ms at 96 .. 143 (the reference benchmark grid's j = 64 is 128 rows) at N = 1e4.  More than 143 rows: PIORAN_ERR_UNSUPPORTED.
- * Many chains (round 5): with more than 256 chains, 17 .. 47 rows, shared (c, d), grad_c = grad_d = grad_y = grad_sigma2 = NULL (value and
+ * Many chains (round 5): with more than 512 chains, 17 .. 47 rows, shared (c, d), grad_c = grad_d = grad_y = grad_sigma2 = NULL (value and
  * d/d(a, b, mu, nu): what the approx-based models' samplers ask for — (c, d) shared by the chains are fixed by the spectral grid) the reverse mode
  * with ONE DRAW PER WAVEFRONT runs (celerite_tile.hip): its forward pass keeps only the lower tiles of T per window (7.5 MB per chain at N = 1e4,
  * chunks of 2048 chains under the default workspace limit) and the reverse kernel recomputes the rest — 4096 chains 54 ms (100 ms on the

@@ -2123,7 +2123,7 @@ def test_tile_gradient_matches_complex_step(ctx, J, N, B, nreal):
 
 
 def test_tile_gradient_dispatch_chunks_and_flagged_draws(ctx):
-    """The automatic choice (more than 256 chains, 17 .. 47 rows, d/d(a, b, mu, nu) only), "no_tile", a workspace limit that forces several
+    """The automatic choice (more than 512 chains, 17 .. 47 rows, d/d(a, b, mu, nu) only), "no_tile", a workspace limit that forces several
     launches (the chunk is cut by 1024 chains, then halved), optional outputs left out, and a draw that is not positive definite: its status
     is the forward kernel's and the other chains are untouched."""
     rng = np.random.default_rng(4242)
@@ -2133,7 +2133,7 @@ def test_tile_gradient_dispatch_chunks_and_flagged_draws(ctx):
     name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
     g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
     assert name() == TILE_GRAD and (g["status"] == 0).all()
-    assert ds.logl_grad(A[:256], Bc[:256], C, Dd, mu=mu[:256], nu=nu[:256], cd_grad=False)["logl"].shape == (256,) and name() == "block (windowed gradient)"
+    assert ds.logl_grad(A[:512], Bc[:512], C, Dd, mu=mu[:512], nu=nu[:512], cd_grad=False)["logl"].shape == (512,) and name() == "block (windowed gradient)"
     assert ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)["grad_c"] is not None and name() == "block (windowed gradient)"
     assert ds.logl_grad(A[:, :8], Bc[:, :8], C[:8], Dd[:8], mu=mu, nu=nu, cd_grad=False)["logl"].shape == (B,) and name() == "block (windowed gradient)"   # 16 rows
     try:
