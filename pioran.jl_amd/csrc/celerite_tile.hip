@@ -142,6 +142,67 @@ __global__ void __launch_bounds__(128) tile_pairs_reg_kernel(const ScanParams p,
     }
 }
 
+// The same contraction as what it is, a GEMM — out[draw][(window, pair)] = sum over (t, cos | sin) of coef[draw][(t, cos | sin)] E[(t, cos | sin)][(window, pair)],
+// 4096 x 2 J x 80 000 at the bench shape — on v_mfma_f64_16x16x4_f64: a wavefront owns 16 draws (their coefficients as A operands in 2 JQ registers for
+// the whole launch) and walks kPairWin windows x 8 tiles of 16 pairs; per tile JQ 16-byte table reads per lane (cos and sin of one term: both halves feed a
+// matrix instruction), 2 JQ matrix instructions, four 8-byte stores per lane (128 contiguous bytes per draw).  JQ = ceil(J / 4), compile-time.
+// (Vector forms above: 0.93 ms per 4096 draws at 20 terms with the table in registers, 1.97 ms at 40 terms with the coefficients in LDS.)
+constexpr int kPairWin = 5;
+template <int JQ>
+__global__ void __launch_bounds__(256) tile_pairs_mfma_kernel(const ScanParams p, const double* __restrict__ btab, int64_t rsb, int64_t tsp, double* __restrict__ out)
+{
+    const int J = p.J;
+    const int64_t NW = (p.N + KW - 1) / KW;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+    const int64_t b0 = ((int64_t)blockIdx.y * 4 + w) * 16;
+    if (b0 >= p.B) return;                         // (no workgroup-level synchronisation in this kernel)
+    const int64_t draw = b0 + li < p.B ? b0 + li : p.B - 1;
+    double aop[JQ], bop[JQ];
+    int toff[JQ];
+#pragma unroll
+    for (int q = 0; q < JQ; ++q) {
+        const int t = 4 * q + lk;
+        aop[q] = t < J ? p.A[draw * J + t] : 0.0;
+        bop[q] = t < J ? p.Bc[draw * J + t] : 0.0;
+        toff[q] = (t < J ? t : J - 1) * 128 + li;
+    }
+    const int64_t k0 = (int64_t)blockIdx.x * kPairWin, k1 = k0 + kPairWin < NW ? k0 + kPairWin : NW;
+    for (int64_t k = k0; k < k1; ++k) {
+        const double2* E = reinterpret_cast<const double2*>(btab + k * rsb + tsp);
+#pragma unroll 2
+        for (int pt = 0; pt < 8; ++pt) {
+            double2 e[JQ];
+#pragma unroll
+            for (int q = 0; q < JQ; ++q) e[q] = E[toff[q] + 16 * pt];
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < JQ; ++q) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[q], e[q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bop[q], e[q].y, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t bd = b0 + 4 * g + lk;
+                if (bd < p.B) out[(bd * NW + k) * 128 + 16 * pt + li] = acc[g];
+            }
+        }
+    }
+}
+
+template <typename... Args>
+static inline bool launch_pairs_mfma(const ScanParams& p, hipStream_t stream, Args... args)
+{
+    const int64_t NW = (p.N + KW - 1) / KW;
+    const dim3 gr((unsigned)((NW + kPairWin - 1) / kPairWin), (unsigned)((p.B + 63) / 64));
+    if (gr.y > 65535) return false;
+    const int jq = (p.J + 3) / 4;
+    if (jq <= 5) hipLaunchKernelGGL(tile_pairs_mfma_kernel<5>, gr, dim3(256), 0, stream, p, args...);
+    else if (jq <= 10) hipLaunchKernelGGL(tile_pairs_mfma_kernel<10>, gr, dim3(256), 0, stream, p, args...);
+    else if (jq <= 16) hipLaunchKernelGGL(tile_pairs_mfma_kernel<16>, gr, dim3(256), 0, stream, p, args...);
+    else return false;
+    return true;
+}
+
 // ST (gradient, round 5): the forward pass of the one-draw-per-wavefront reverse mode — it leaves the lower tiles of T at the START of every window
 // in p.gw ([draw][window][tile][lane][register], NB (NB + 1) / 2 x 2 KB per window) and nothing else: the reverse kernel
 // (celerite_tile_adjoint_kernel) recomputes M', Sigma, the LDL' and Q' from it.  The value is bit-identical to the plain kernel's.
@@ -1028,7 +1089,8 @@ int launch_tile(const ScanParams& p, const double* btab, double* pairs, hipStrea
     const dim3 gr((unsigned)NW, (unsigned)((p.B + kPairDrawsReg - 1) / kPairDrawsReg));
     // (measured, profiles/r05_*kernel_stats.csv: 20 terms 0.93 ms per 4096 draws at N = 1e4 against 1.11 ms on the LDS form; with 40 terms the 160
     //  registers of table entries cost it its occupancy — 2.76 against 1.96 ms — so that count stays on the LDS form)
-    if (p.J == 20) hipLaunchKernelGGL(tile_pairs_reg_kernel<20>, gr, dim3(128), 0, stream, p, btab, block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs);
+    if (launch_pairs_mfma(p, stream, btab, (int64_t)block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs)) {}
+    else if (p.J == 20) hipLaunchKernelGGL(tile_pairs_reg_kernel<20>, gr, dim3(128), 0, stream, p, btab, block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs);
     else
     hipLaunchKernelGGL(tile_pairs_kernel, dim3((unsigned)NW, (unsigned)((p.B + kPairDraws - 1) / kPairDraws)), dim3(128), 0, stream, p, btab,
                        block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs);
@@ -1058,7 +1120,8 @@ int launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab
     if (groups > 0x7fffffffLL || NW > 0x7fffffffLL || (p.B + kPairDraws - 1) / kPairDraws > 65535) return PIORAN_ERR_UNSUPPORTED;
     const int64_t rsb = block_rec_doubles(NB, p.J), tsp = block_tile_doubles(NB);
     const dim3 gr((unsigned)NW, (unsigned)((p.B + kPairDrawsReg - 1) / kPairDrawsReg));
-    if (p.J == 20) hipLaunchKernelGGL(tile_pairs_reg_kernel<20>, gr, dim3(128), 0, stream, p, btab, rsb, tsp, pairs);
+    if (launch_pairs_mfma(p, stream, btab, rsb, tsp, pairs)) {}
+    else if (p.J == 20) hipLaunchKernelGGL(tile_pairs_reg_kernel<20>, gr, dim3(128), 0, stream, p, btab, rsb, tsp, pairs);
     else hipLaunchKernelGGL(tile_pairs_kernel, dim3((unsigned)NW, (unsigned)((p.B + kPairDraws - 1) / kPairDraws)), dim3(128), 0, stream, p, btab, rsb, tsp, pairs);
     hipLaunchKernelGGL((celerite_tile_kernel<NB, true>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_f, stream, p, btab, (const double*)pairs);
     hipLaunchKernelGGL((celerite_tile_adjoint_kernel<NB>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_r, stream, p, btab, gtab, pairs, grad_a, grad_b,
