@@ -99,8 +99,8 @@ def pmc_traffic(basis: str, J: int, B: int, N: int, kernel_config: str):
 NOTE_TILE = ("celerite_tile_kernel (round 5): the windowed form of the recurrence — 16 time steps per window eliminated through GEMMs against the R x R state "
              "and one 16 x 16 LDL' — with ONE DRAW PER WAVEFRONT: the state lives in the accumulator tiles of v_mfma_f64_16x16x4_f64 (lower tiles in registers, "
              "transposed LDS copies as the upper ones), 84 matrix instructions (64 cycles each) + ~500 vector instructions per window and draw at three "
-             "block columns, two wavefronts per SIMD; the window's own covariance block comes from a pre-pass kernel (tile_pairs_kernel: pair table in "
-             "registers, coefficients as scalar operands), whose time is inside kernel_ms.  The fp64 matrix instructions run on the DP vector pipe "
+             "block columns, two wavefronts per SIMD; the window's own covariance block comes from a pre-pass kernel (tile_pairs_mfma_kernel: the "
+             "contraction of the pair table with the draws' (a, b) as a GEMM on the same matrix instructions), whose time is inside kernel_ms.  The fp64 matrix instructions run on the DP vector pipe "
              "(profiles/r02_mfma_probe.txt): peak = 78.6 TFLOP/s either way; `achieved` counts the ALGORITHMIC flops of the reference's recurrence "
              "(5.5 R^2 + 18 R per step), the windowed form executes fewer (4 R'^2 per step on the padded R' = 48 rows + the window's 16 x 16 work).  "
              "measured_fma_ceiling_tflops: a pure v_fma_f64 stream at two wavefronts per SIMD on this box, timed right after the loop.  "
@@ -352,7 +352,7 @@ def main():
                      "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "measured_fma_ceiling_tflops": fma_ceiling,
                      "frac_of_measured_fma_ceiling": (achieved / fma_ceiling) if fma_ceiling else None,
-                     "kernel": "celerite_scan_kernel" if kernel_family.startswith("scan") else "celerite_tile_kernel (+ tile_pairs_kernel, its pre-pass: both inside kernel_ms)",
+                     "kernel": "celerite_scan_kernel" if kernel_family.startswith("scan") else "celerite_tile_kernel (+ tile_pairs_mfma_kernel, its pre-pass: both inside kernel_ms)",
                      "kernel_family": kernel_family, "kernel_ms": kern_ms, "scan_source_hash": scan_source_hash(),
                      "algorithmic_flop_per_eval": algorithmic_flops(N, R), "rows_executed": R, "rows_reference": 2 * Jt,
                      "frac_on_reference_rows": achieved_ref_rows / FP64_PEAK_TFLOPS,
@@ -601,7 +601,7 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
         row["speedup"] = row["step_by_step"]["ms"] / row["tile"]["ms"]
         tile[label] = row
         dst_.close()
-    tile["kernel"] = ("celerite_tile_kernel<NB> + tile_pairs_kernel (celerite_tile.hip): windowed form, 16 steps per window, ONE draw per wavefront: T as NB x NB "
+    tile["kernel"] = ("celerite_tile_kernel<NB> + tile_pairs_mfma_kernel (celerite_tile.hip): windowed form, 16 steps per window, ONE draw per wavefront: T as NB x NB "
                       "accumulator tiles of v_mfma_f64_16x16x4_f64 (lower tiles in registers, transposed LDS copies as the upper ones), 84 / 136 / 276 matrix "
                       "instructions per window at 3 / 4 / 6 block columns against ~700 / ~1300 / ~4500 SIMD cycles per STEP of the step-by-step layouts; "
                       "ms includes the pre-pass")
