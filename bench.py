@@ -107,6 +107,61 @@ NOTE_TILE = ("celerite_tile_kernel (round 5): the windowed form of the recurrenc
              "`secondary.tile_kernel_windowed_one_draw_per_wavefront` has the same-box A/B against the step-by-step layout (no_tile).")
 
 
+LINE_LIMIT = 6000      # bytes of the final stdout line (the driver keeps an 8 KB tail of stdout)
+_PROSE = ("note", "kernel_note", "workload", "traffic_source", "kept_rule", "flop_model", "sample_detail")
+
+
+def _numbers_only(o, depth=0):
+    """The same tree without prose: strings longer than 40 characters and the keys of _PROSE go (they are in bench_full.json and DESIGN.md 7)."""
+    if isinstance(o, dict):
+        return {k: _numbers_only(v, depth + 1) for k, v in o.items()
+                if k not in _PROSE and not (isinstance(v, str) and len(v) > 40)}
+    if isinstance(o, float):
+        return float(f"{o:.6g}")
+    if isinstance(o, list):
+        return [_numbers_only(v, depth + 1) for v in o]
+    return o
+
+
+def emit(result: dict) -> None:
+    """Rank 0's output: the LONG form (every note and secondary measurement) to bench_full.json beside this file (and to
+    $PIORAN_BENCH_FULL if set), ONE compact line of at most LINE_LIMIT bytes to stdout — the contract's keys first, then `roofline`, `cpu_baseline`,
+    the parity figures and the other basis, and only then `secondary` (numbers only; its sub-objects are dropped from the end while the line is too long, never the front)."""
+    full = json.dumps(result)
+    for dest in (os.environ.get("PIORAN_BENCH_FULL"), str(ROOT / "bench_full.json")):
+        if dest:
+            try:
+                Path(dest).write_text(full + "\n")
+            except OSError as exc:
+                print(f"bench.py: could not write {dest}: {exc}", file=sys.stderr)
+    head_keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                 "roofline", "cpu_baseline", "max_rel_dlogl_vs_oracle", "max_abs_dlogl_vs_oracle_kept", "status_ok_frac")
+    line = {k: result[k] for k in head_keys if k in result}
+    line["config"] = dict(result["config"])
+    line["roofline"] = _numbers_only(result["roofline"])
+    if "cpu_baseline" in result:
+        line["cpu_baseline"] = {k: v for k, v in result["cpu_baseline"].items() if k != "sample_detail"}
+    sec = result.get("secondary") or {}
+    other = next((v for k, v in sec.items() if k.startswith(("drwcelerite", "sho")) and "evals_per_s" in v), None)
+    if other is not None:
+        line["other_basis"] = {"model": next(k for k, v in sec.items() if v is other), "evals_per_s": float(f"{other['evals_per_s']:.6g}"),
+                               "frac": float(f"{other['roofline_frac_executed_rows']:.4g}"), "rows_executed": other["rows_executed"],
+                               "max_rel_dlogl_vs_oracle": other["max_rel_dlogl_vs_oracle"]}
+    for k in ("kept_draws", "oracle_sample_draws", "max_abs_dlogl_vs_oracle_all_prior_draws", "gather_verified"):
+        if k in result:
+            line[k] = result[k]
+    line["full_form"] = "bench_full.json (notes, every secondary measurement); DESIGN.md section 7"
+    if sec:
+        first = [k for k in sec if k.startswith(("drwcelerite", "sho", "dense_", "single_evaluation_B1", "small_batch_B256", "gradient_", "batch_sizes"))]
+        sec = {**{k: sec[k] for k in first}, **{k: v for k, v in sec.items() if k not in first}}
+        line["secondary"] = _numbers_only(sec)
+        order = list(line["secondary"].keys())
+        while len(json.dumps(line)) > LINE_LIMIT and order:
+            line["secondary"].pop(order.pop())          # from the end: the least BASELINE-relevant sections are last
+            line["secondary_truncated"] = True
+    print(json.dumps(line), flush=True)
+
+
 def algorithmic_flops(N: int, R: int) -> float:
     """F_cel(N, R) = (N-1)(5.5 R^2 + 18 R) fp64 flop per evaluation — SURVEY.md section 8(d), counted
     from src/celerite_solver.jl:69-98,132-155 (mul, add, div = 1 each)."""
@@ -342,8 +397,7 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"N={N} irregular series, {args.basis}-{J} (J={Jt} celerite terms, R={R} active rows), "
-                               f"batch={B} draws per GPU, shared (c,d) table, per-draw mu/nu; inputs HBM-resident, every "
-                               f"step re-evaluates the resident batch (PCIe-inclusive rates: secondary.host_api)",
+                               f"batch={B} draws per GPU, shared (c,d), per-draw mu/nu; inputs HBM-resident",
                    "N": N, "J": Jt, "R_active": R, "batch_per_gpu": B, "global_batch": B * world,
                    "kernel_config": kernel_config,
                    "parallelism": f"batch-sharded x{world}, all-gather of logL"
@@ -398,7 +452,7 @@ def main():
                 assert bool(same.all()), f"gathered slice of rank {r} differs from the single-GPU evaluation"
             result["gather_verified"] = True
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -448,9 +502,11 @@ def cpu_baseline_leg(O, A, Bc, C, Dd, t, y, yerr, mu, nu, out_host, st_host, N, 
             "value": S / cpu_s, "unit": "evals/s", "cores": cores, "kind": "port",
             "one_thread_evals_per_s": sweep[1],
             "sweep_evals_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
-            "sample": f"first {S} draws of the same batch (N={N}, J={Jt}), oracle/celerite_oracle.c (reference algorithm and "
-                      f"memory layout), OpenMP over draws; median of 3 warmed repeats of {cpu_s:.1f} s at the best thread "
-                      f"count of a warmed sweep (>= 1 s of timed work per count) over {{1, 1/8, 1/4, 1/2, 1}} x {ncpu} logical CPUs"},
+            "sample": f"first {S} draws of the same batch, oracle/celerite_oracle.c, OpenMP over draws, median of 3 repeats of {cpu_s:.1f} s, "
+                      f"best of a thread sweep over {ncpu} logical CPUs",
+            "sample_detail": f"first {S} draws of the same batch (N={N}, J={Jt}), oracle/celerite_oracle.c (reference algorithm and "
+                             f"memory layout), OpenMP over draws; median of 3 warmed repeats of {cpu_s:.1f} s at the best thread "
+                             f"count of a warmed sweep (>= 1 s of timed work per count) over {{1, 1/8, 1/4, 1/2, 1}} x {ncpu} logical CPUs"},
         # the metric's tolerance is RELATIVE (north_star: 1e-8): that figure first.  The absolute figures: over the draws a sampler keeps,
         # and — only for completeness — over every prior draw of the sample, where |log L| reaches 1e7 and 1e-10 of it is 1e-3
         "max_rel_dlogl_vs_oracle": float((err / np.abs(ref[ok])).max()) if ok.any() else None,

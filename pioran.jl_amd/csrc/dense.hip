@@ -358,142 +358,294 @@ __device__ __forceinline__ double bcast16(double x)
     return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true);
 }
 
-// One 16-column right-looking sweep over a 16 x 16 tile (r, lane & 15 = row) and its companion strip m (factor_block64 below).
-// Column step p: pivot broadcast -> rsqrt -> scale column p -> rank-1 update of the columns q > p with the broadcast of l_qp FOLDED into
-// the FMAs (v_fmac_f64_dpp row_newbcast:q takes its src0 from lane q of the DPP row; the negation rides as a source modifier): two DP
-// instructions per (p, q) for the tile and the strip instead of a v_mov_b64_dpp + two FMAs (a DP DPP operand costs no extra issue cycles:
-// tools/valu_probe.hip, profiles/r02_valu_probe.txt).  A DPP read of a register written by the preceding VALU instructions needs two
-// wait states: s_nop 1 in front of every such read.
-// Measured (tools/factor_probe.hip, profiles/r04_factor_probe.txt; cycles per 16-column sweep): compiler-scheduled v_mov_b64_dpp + two FMAs per
-// (p, q) 3280-3530; this folded form 3100-3290; folded AND software-pipelined (the pivot chain of column p+1 — broadcast, v_rsq_f64, third-order
-// correction, scale: eight dependent DP operations — spread between the remaining FMAs of column p, every piece its own asm volatile
-// statement) 3360-3570.  A 64-bit DPP operand takes TWO issue slots wherever it stands (120 broadcasts x 8 + 240 FMA slots x 4 + 16 pivot
-// chains x ~80 cycles = the 3100 measured), so folding saves only the moves' register traffic, and the pinned order of the pipelined form
-// cost more in hazard nops than its overlap won.  The sweep is bound by the 120 lane broadcasts of the rank-1 updates.
-template <int P, int Q>
-__device__ __forceinline__ void chol_rank1(double (&r)[16], double (&m)[16])
+// ---- the 64 x 64 diagonal factor (round 6) -----------------------------------------------------------------------------------------
+// 1 / x to fp64 accuracy: v_rcp_f64 + two Newton steps.
+__device__ __forceinline__ double recip_f64d(double x)
 {
-    if constexpr (Q < 16) {
-        // a_iq -= l_ip l_qp (tile) and the same column step on the companion strip
-        asm volatile("v_fmac_f64_dpp %0, %2, -%2 row_newbcast:%c4 row_mask:0xf bank_mask:0xf\n\t"
-                     "v_fmac_f64_dpp %1, %2, -%3 row_newbcast:%c4 row_mask:0xf bank_mask:0xf"
-                     : "+v"(r[Q]), "+v"(m[Q])
-                     : "v"(r[P]), "v"(m[P]), "i"(Q));
-        chol_rank1<P, Q + 1>(r, m);
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
+// The 16 x 16 LDL' + L^-1 of one diagonal tile as an in-place Gauss-Jordan sweep on DPP broadcasts — the form of the windowed celerite
+// kernels (window_common.h), restated here for a tile that lives in the dense slab.  Lane (q, n) holds column n of the (symmetric) tile
+// in m[0..15]; the four DPP rows q hold copies.  Step P: d_P = m[P] of lane P; mult_n = -m[P]_n / d_P (lane P: -2);
+// m[j]_n += bcast_P(m[j]) mult_n for j > P — the rank-1 update of the reduced tile for n > P, the row operation on the identity for
+// n < P, and lane P's own column becomes -L_jP d_P: column P of L^-1 scaled by d_P.  ONE v_fmac_f64_dpp per (P, j): 120 for the
+// factorisation AND the inverse (the column sweep of rounds 1-5 spent 240 plus sixteen rsqrt chains on the same two results).
+// Afterwards lane n holds   m[j]_n = L_nj d_j (j < n: row n of L D, frozen when step j passed it),  m[n]_n = d_n,
+// m[j]_n = d_n (L^-1)_jn (j > n).  The next pivot's multiplier chain (broadcast, v_rcp_f64, third-order correction: four dependent DP
+// operations) is spread between the updates of the current step, which do not depend on it.
+// DPP hazard (two wait states between a VALU write of a register and a DPP read of it; not interlocked): the DPP source of every update
+// is the row's own register m[j], last written by the PREVIOUS step's update of that row — at least the seven instructions of the
+// multiplier chain earlier — so the updates need no s_nop (window_common.h's form pays one per group of four: 168 s_nop per sweep in
+// the ISA); only the broadcast of the next pivot, which reads the register the instruction before it wrote, keeps its s_nop 1.
+#define PIORAN_GJ_DPP " row_newbcast:%c[p] row_mask:0xf bank_mask:0xf"
+template <int P, int J0, int CNT>
+__device__ __forceinline__ void gj_rows(double (&m)[16], double mult)
+{
+    if constexpr (CNT >= 4) {
+        asm volatile("v_fmac_f64_dpp %[c0], %[c0], %[t]" PIORAN_GJ_DPP "\n\tv_fmac_f64_dpp %[c1], %[c1], %[t]" PIORAN_GJ_DPP "\n\t"
+                     "v_fmac_f64_dpp %[c2], %[c2], %[t]" PIORAN_GJ_DPP "\n\tv_fmac_f64_dpp %[c3], %[c3], %[t]" PIORAN_GJ_DPP
+                     : [c0] "+v"(m[J0]), [c1] "+v"(m[J0 + 1]), [c2] "+v"(m[J0 + 2]), [c3] "+v"(m[J0 + 3])
+                     : [t] "v"(mult), [p] "i"(P));
+        gj_rows<P, J0 + 4, CNT - 4>(m, mult);
+    } else if constexpr (CNT >= 1) {
+        asm volatile("v_fmac_f64_dpp %[c0], %[c0], %[t]" PIORAN_GJ_DPP : [c0] "+v"(m[J0]) : [t] "v"(mult), [p] "i"(P));
+        gj_rows<P, J0 + 1, CNT - 1>(m, mult);
+    }
+}
+// multiplier -m / d without a finished reciprocal: r0 = v_rcp_f64(d), e = 1 - d r0, t0 = -m r0, mult = t0 (1 + e + e^2) (relative error e^3 < 1e-22)
+__device__ __forceinline__ double gj_mult_of(double dn, double mrow)
+{
+    double r0, e, t0, pq, mn;
+    asm volatile("v_rcp_f64 %0, %1" : "=v"(r0) : "v"(dn));
+    asm volatile("s_nop 0\n\tv_fma_f64 %0, -%2, %3, 1.0\n\tv_mul_f64 %1, -%4, %2" : "=&v"(e), "=&v"(t0) : "v"(r0), "v"(dn), "v"(mrow));
+    asm volatile("v_fma_f64 %0, %1, %1, %1" : "=v"(pq) : "v"(e));
+    asm volatile("v_fma_f64 %0, %1, %2, %1" : "=v"(mn) : "v"(t0), "v"(pq));
+    return mn;
+}
+template <int P>
+__device__ __forceinline__ void gj_step(double (&m)[16], double& mult, int c16)
+{
+    constexpr int NR = 15 - P;                       // rows below the pivot
+    constexpr int NA = NR >= 1 ? 1 : 0;              // the next pivot's row first
+    constexpr int NBk = NR - NA >= 4 ? 4 : NR - NA;
+    constexpr int NCk = NR - NA - NBk >= 4 ? 4 : NR - NA - NBk;
+    constexpr int NDk = NR - NA - NBk - NCk;
+    gj_rows<P, P + 1, NA>(m, mult);
+    if constexpr (P < 15) {
+        double dn, r0, e, t0, pq, mn;
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%c2 row_mask:0xf bank_mask:0xf" : "=v"(dn) : "v"(m[P + 1]), "i"(P + 1));
+        if constexpr (NBk == 0) asm volatile("s_nop 0");
+        asm volatile("v_rcp_f64 %0, %1" : "=v"(r0) : "v"(dn));
+        gj_rows<P, P + 1 + NA, NBk>(m, mult);
+        asm volatile("s_nop 0\n\tv_fma_f64 %0, -%2, %3, 1.0\n\tv_mul_f64 %1, -%4, %2" : "=&v"(e), "=&v"(t0) : "v"(r0), "v"(dn), "v"(m[P + 1]));
+        gj_rows<P, P + 1 + NA + NBk, NCk>(m, mult);
+        asm volatile("v_fma_f64 %0, %1, %1, %1" : "=v"(pq) : "v"(e));
+        gj_rows<P, P + 1 + NA + NBk + NCk, NDk>(m, mult);
+        asm volatile("v_fma_f64 %0, %1, %2, %1" : "=v"(mn) : "v"(t0), "v"(pq));
+        mult = c16 == P + 1 ? -2.0 : mn;
     }
 }
 template <int P>
-__device__ __forceinline__ void chol_sweep16(double (&r)[16], double (&m)[16], int& bad, int c0)
+__device__ __forceinline__ void gj_sweep(double (&m)[16], double& mult, int c16)
 {
     if constexpr (P < 16) {
-        double piv;
-        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%c2 row_mask:0xf bank_mask:0xf" : "=v"(piv) : "v"(r[P]), "i"(P));
-        if (!(piv > 0.0) && !bad) bad = c0 + P + 1;
-        const double rinv = rsqrt_f64(piv);     // 1 / l_pp
-        // lane p: piv * rinv = l_pp; rows above p: junk, never used
-        asm volatile("v_mul_f64 %0, %0, %2\n\tv_mul_f64 %1, %1, %2\n\ts_nop 1" : "+v"(r[P]), "+v"(m[P]) : "v"(rinv));
-        chol_rank1<P, P + 1>(r, m);
-        chol_sweep16<P + 1>(r, m, bad, c0);
+        gj_step<P>(m, mult, c16);
+        gj_sweep<P + 1>(m, mult, c16);
     }
 }
 
-// Factor the 64 x 64 block held row-major (padded) in LDS `Ls`, in place, by a FOUR-wave workgroup (tid 0..255);
-// writes the four 16 x 16 inverses to `ws` (global).  Returns the 1-based index of the first non-positive pivot
-// (0 = none) to every thread.  `flag` is one int of LDS.
+// Factor the 64 x 64 block held row-major (padded) in LDS `Ls`, in place, by a FOUR-wave workgroup (tid 0..255): on return the lower
+// triangle holds the Cholesky factor C, the four 16 x 16 inverses inv(C_ss) (exact zeros above their diagonals) are parked in the
+// block's strictly-upper part (s = 0, 1, 2: rows 0 .. 15, columns 16 (s + 1) ..; s = 3: rows 16 .. 31, columns 32 ..) and copied to
+// `ws` (global, row-major 16 x 16 each).  Only the lower triangle of the input is read.  Returns the 1-based index of the first
+// non-positive pivot (0 = none) to every thread.  `flag` is one int of LDS.
 //
-// Per 16-column sub-panel s:
-//   wave 0      the whole 64 x 16 sub-panel as ONE right-looking column sweep.  Every DPP row of the wave carries the
-//               16 x 16 diagonal tile (lane l&15 = tile row; r) and, beside it, one more 16-row strip m that goes
-//               through the same column steps: DPP row 0 the identity (Cholesky of [[A, I], [I, *]] leaves
-//               inv(L_ss)' there — lane j ends with column j of the inverse), DPP rows 1..3 the tiles BELOW the
-//               diagonal one, which come out as X_t = A_ts inv(L_ss)' with no triangular solve of their own.
-//               Cross-lane operands come from v_mov_b64_dpp row_newbcast, each shared by the r and the m update;
-//               per-column critical path bcast -> rsqrt -> mul -> fma.  The sweep is issue-bound (about 640
-//               DP instructions); folding the broadcast into v_fmac_f64_dpp was measured slower (DP DPP operands
-//               cost more issue cycles than the shared v_mov_b64_dpp they replace).
-//   waves 1..3  update of the next sub-panel's tiles A_r,s+1 -= X_r X_s+1' on the matrix cores (4 MFMAs per tile)
-//               while wave 0 stores its L rows; then wave 0 goes straight on to the next sweep while waves 1..3
-//               finish the remaining tiles of the in-block update (lookahead).
+// Round s (16-column sub-panel s), ONE workgroup barrier per round:
+//   wave 0      the dependent chain and nothing else: Gauss-Jordan sweep of the tile (s, s) (gj_sweep: d, L D and d L^-1 in registers),
+//               raw result to LDS (G[s]), barrier; then — its inputs are its own or a round old — Y = L^-1 A~(s+1, s)' (4 matrix
+//               instructions), tile (s+1, s+1) -= Y' D^-1 Y (4 more), and on to the next sweep.  No square root and no scaling on the chain.
+//   waves 1..3  after the barrier, beside the chain's next sweep: the outputs of sub-panel s — C_ss = (L D)(n, j) d_j^-1/2 and
+//               inv(C_ss) = d_i^-1/2 L^-1 straight from G[s]; X_t = A~(t, s) inv(C_ss)' (t > s) on the matrix cores, kept in registers and
+//               stored in place after the NEXT barrier (other waves read the raw tile meanwhile) — and the right-looking update of the tiles
+//               (rt, ct), ct > s, except (s+1, s+1), every wave forming the X tiles it needs itself (no second barrier).
+// Measured (tools/factor_probe.hip, profiles/r06_factor_probe.txt): see there; rounds 1-5: 20 750 cycles with a 64 x 16 column sweep per
+// sub-panel (3100 cycles each) and three barriers per round.
+constexpr int GS = 18;       // row pitch of a raw Gauss-Jordan result in LDS
 __device__ __forceinline__ int factor_block64(double* __restrict__ Ls, double* __restrict__ ws, int* __restrict__ flag,
                                               int tid)
 {
+    __shared__ double Gsh[4][16 * GS];
     const int lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     int bad = 0;
-    auto update_tile = [&](int rt, int ct, int c0) {
-        f64x4 c;
-        double ya[4], yb[4];   // X_t as A operand: M[row = c][k] -> X_t[c][k]; as B operand: B[k][col = r] -> the same
+    f64x4 xown = f64x4{0.0, 0.0, 0.0, 0.0};     // waves 1..3: X(wave, s-1), stored in place after the barrier of round s
+    // A operand of the solves: L^-1 [row lr][k = 4 ks + lk] (unit lower triangular), 1 / d_k and d_k^-1/2 (k = 4 ks + lk), d_lr^-1/2, from the
+    // raw result of a sweep.  Nine independent Newton chains (four reciprocals, five reciprocal square roots), written LEVEL BY LEVEL
+    // with scheduling fences in between: one wavefront per SIMD issues in order, and the compiler's own order finished one chain
+    // before it started the next (five dependent DP operations each) and issued the LDS reads one by one between them.
+    auto load_linv = [&](auto want_rs, const double* G, double (&li)[4], double (&idv)[4], double (&rs)[4], double& rsl, double& dl) {
+        constexpr int NS = decltype(want_rs)::value ? 5 : 0;     // the chain wavefront needs no square roots
+        double lv[4], dk[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            c[g] = Ls[(16 * rt + lr) * LP + 16 * ct + lk + 4 * g];
-            ya[g] = Ls[(16 * ct + lr) * LP + c0 + lk + 4 * g];
-            yb[g] = Ls[(16 * rt + lr) * LP + c0 + lk + 4 * g];
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = 4 * ks + lk;
+            lv[ks] = G[kk * GS + lr];
+            dk[ks] = G[kk * GS + kk];
         }
+        dl = G[lr * GS + lr];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        double x[5], y[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, e[5], u[5];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) c = mfma4(-ya[ks], yb[ks], c);
+        for (int ks = 0; ks < 4; ++ks) x[ks] = dk[ks];
+        x[4] = dl;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) idv[ks] = __builtin_amdgcn_rcp(dk[ks]);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) y[i] = __builtin_amdgcn_rsq(x[i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) e[ks] = fma(-dk[ks], idv[ks], 1.0);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) u[i] = x[i] * y[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) idv[ks] = fma(e[ks], idv[ks], idv[ks]);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) u[i] = fma(-u[i], y[i], 1.0);          // e = 1 - x y^2
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) e[ks] = fma(-dk[ks], idv[ks], 1.0);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { x[i] = y[i] * u[i]; u[i] = fma(0.375, u[i], 0.5); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) idv[ks] = fma(e[ks], idv[ks], idv[ks]);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) y[i] = fma(x[i], u[i], y[i]);          // y (1 + e/2 + 3 e^2/8): rsqrt_f64's third-order step
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = 4 * ks + lk;
+            li[ks] = kk < lr ? lv[ks] * idv[ks] : (kk == lr ? 1.0 : 0.0);     // the column arrives scaled by d_k
+            rs[ks] = NS ? y[ks] : 0.0;
+        }
+        rsl = NS ? y[4] : 0.0;
+    };
+    // op' (16 x 16, rows = result rows) times the raw tile (t, s): register g of lane (lk, lr) = result[lr][lk + 4 g]
+    auto solve_tile = [&](int t, int c0, const double (&aop)[4]) -> f64x4 {
+        double bq[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bq[ks] = Ls[(16 * t + lr) * LP + c0 + 4 * ks + lk];
+        f64x4 x = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x = mfma4(aop[ks], bq[ks], x);
+        return x;
+    };
+    // tile (rt, ct) -= X_rt X_ct'
+    auto update_tile = [&](int rt, int ct, const f64x4& xr, const f64x4& xc) {
+        f64x4 c;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c[g] = Ls[(16 * rt + lr) * LP + 16 * ct + lk + 4 * g];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) c = mfma4(-xc[ks], xr[ks], c);
 #pragma unroll
         for (int g = 0; g < 4; ++g) Ls[(16 * rt + lr) * LP + 16 * ct + lk + 4 * g] = c[g];
     };
-#pragma unroll 1
-    for (int s = 0; s < 4; ++s) {
-        const int c0 = 16 * s;
-        PIORAN_STAMP(8 * s + 0);
-        if (wave == 0) {
-            const int ir0 = s == 3 ? 16 : 0, ic0 = s == 3 ? 32 : 16 * (s + 1);   // where inv(L_ss) is parked
-            const int t = s + lk;                 // tile carried in m by this DPP row (lk >= 1); t > 3: nothing
-            const bool has_m = lk == 0 || t < 4;
-            double r[16], m[16];
+    static_for16([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s < 4) {
+            constexpr int c0 = 16 * s;
+            constexpr int ir0 = s == 3 ? 16 : 0, ic0 = s == 3 ? 32 : 16 * (s + 1);   // where inv(C_ss) is parked
+            double* G = Gsh[s];
+            PIORAN_STAMP(8 * s + 0);
+            if (wave == 0) {
+                double m[16];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) r[p] = Ls[(c0 + lr) * LP + c0 + p];
-            const int mrow = (t < 4 ? 16 * t : c0) + lr;   // (rows past the block: re-read the diagonal tile, result unused)
+                for (int j = 0; j < 16; ++j) m[j] = Ls[(c0 + (j >= lr ? j : lr)) * LP + c0 + (j >= lr ? lr : j)];   // lower triangle only
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                double d0;
+                asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(d0) : "v"(m[0]));
+                asm volatile("s_nop 0");
+                double mult = gj_mult_of(d0, m[0]);
+                mult = lr == 0 ? -2.0 : mult;
+                gj_sweep<0>(m, mult, lr);
+                PIORAN_STAMP(8 * s + 1);
+                if (lk == 0) {
+                    typedef double d2 __attribute__((ext_vector_type(2)));
+                    d2* dst = reinterpret_cast<d2*>(G + lr * GS);
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const double v = Ls[mrow * LP + c0 + p];
-                m[p] = lk == 0 ? (lr == p ? 1.0 : 0.0) : v;
+                    for (int j = 0; j < 16; j += 2) dst[j / 2] = d2{m[j], m[j + 1]};
+                }
             }
-            chol_sweep16<0>(r, m, bad, c0);
-            // keep the compiler from sinking the m updates into the publish branches below
-#pragma unroll
-            for (int p = 0; p < 16; ++p) asm volatile("" : "+v"(m[p]));
-            PIORAN_STAMP(8 * s + 1);
-            // publish what the other waves wait for: the inverse (lane = column) into a 16 x 16 tile of the block's
-            // strictly-upper part, which the algorithm never touches, and X_t in place
-            if (has_m) {
-                const int base = lk == 0 ? ir0 * LP + ic0 + lr : (16 * t + lr) * LP + c0;
-                const int stride = lk == 0 ? LP : 1;   // X[p][lr] down a column of the parked tile | row lr of X_t
-#pragma unroll
-                for (int p = 0; p < 16; ++p) Ls[base + p * stride] = m[p];
-            }
-            __syncthreads();   // sub-panel s finished and visible; every update tile of the previous sub-panel finished
+            __syncthreads();      // round s: G[s] visible; every wave's work of round s-1 finished and visible
             PIORAN_STAMP(8 * s + 2);
-            // the L rows are read by nobody inside the block (only by the final write-back): store them while waves
-            // 1..3 update the next sub-panel's tiles (junk above the diagonal is never read)
-            if (lk == 0) {
+            if (wave == 0) {
+                if constexpr (s < 3) {
+                    constexpr int d0_ = 16 * (s + 1);
+                    // (both tiles were last written by the other wavefronts in round s-1: readable only after this round's barrier)
+                    f64x4 c;
 #pragma unroll
-                for (int p = 0; p < 16; ++p) Ls[(c0 + lr) * LP + c0 + p] = r[p];
-            }
-        } else {
-            __syncthreads();
-            // ---- in-block trailing update, first the tiles of the next sub-panel: (rt, s+1), rt = s+1 .. 3 -> wave rt-s
-            const int rt = s + wave;
-            if (s < 3 && rt < 4) update_tile(rt, s + 1, c0);
-        }
-        __syncthreads();
-        PIORAN_STAMP(8 * s + 3);
-        // ---- the rest, (rt, ct) with ct >= s+2, on waves 1..3 while wave 0 starts the next sweep ---------------------
-        if (wave > 0) {
-            int idx = 0;
-#pragma unroll
-            for (int rt = 2; rt < 4; ++rt)
-#pragma unroll
-                for (int ct = 2; ct <= rt; ++ct)
-                    if (ct >= s + 2) {   // wave-uniform
-                        if (wave == 1 + idx % 3) update_tile(rt, ct, c0);
-                        ++idx;
+                    for (int g = 0; g < 4; ++g) {
+                        const int cc = lk + 4 * g;                           // symmetric tile: the lower triangle is the valid one
+                        c[g] = Ls[(d0_ + (lr >= cc ? lr : cc)) * LP + d0_ + (lr >= cc ? cc : lr)];
                     }
+                    double bq[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) bq[ks] = Ls[(d0_ + lr) * LP + c0 + 4 * ks + lk];
+                    double li[4], idv[4], rs_[4], rsl_, dl_;
+                    load_linv(std::false_type{}, G, li, idv, rs_, rsl_, dl_);
+                    f64x4 y = f64x4{0.0, 0.0, 0.0, 0.0};                    // Y[c = lk + 4 g][r = lr] = (L^-1 A~(s+1, s)')
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) y = mfma4(li[ks], bq[ks], y);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) c = mfma4(-y[ks], y[ks] * idv[ks], c);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) Ls[(d0_ + lr) * LP + d0_ + lk + 4 * g] = c[g];    // both triangles valid from here on
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            } else {
+                if (s >= 1 && wave >= s) {                                   // X(wave, s-1) of the previous round, in place
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) Ls[(16 * wave + lr) * LP + (c0 - 16) + lk + 4 * g] = xown[g];
+                }
+                double li[4], idv[4], rs[4], aop[4], rsl, dl;
+                double ldv[4];                                               // (L D)[lr][lk + 4 g]: row lr of the factor before its scaling
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ldv[g] = G[lr * GS + lk + 4 * g];
+                load_linv(std::true_type{}, G, li, idv, rs, rsl, dl);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) aop[ks] = li[ks] * rsl;      // inv(C_ss)[lr][4 ks + lk]
+                if (wave == 1) {
+                    const unsigned long long neg = __ballot(!(dl > 0.0)) & 0xffffull;
+                    if (neg && !bad) bad = c0 + __ffsll((long long)neg);
+                }
+                if (wave == (s == 0 ? 3 : 1)) {                              // the sub-panel's own outputs
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) Ls[(ir0 + lr) * LP + ic0 + 4 * ks + lk] = aop[ks];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int j = lk + 4 * g;                            // C_ss[lr][j] = (L D)[lr][j] d_j^-1/2 (j < lr), d^1/2 (j = lr)
+                        if (j <= lr) Ls[(c0 + lr) * LP + c0 + j] = ldv[g] * rs[g];
+                    }
+                }
+                if constexpr (s == 0) {
+                    if (wave == 1) {
+                        const f64x4 x1 = solve_tile(1, c0, aop), x2 = solve_tile(2, c0, aop), x3 = solve_tile(3, c0, aop);
+                        update_tile(2, 1, x2, x1);
+                        update_tile(3, 1, x3, x1);
+                        xown = x1;
+                    } else if (wave == 2) {
+                        const f64x4 x2 = solve_tile(2, c0, aop), x3 = solve_tile(3, c0, aop);
+                        update_tile(2, 2, x2, x2);
+                        update_tile(3, 2, x3, x2);
+                        xown = x2;
+                    } else {
+                        const f64x4 x3 = solve_tile(3, c0, aop);
+                        update_tile(3, 3, x3, x3);
+                        xown = x3;
+                    }
+                } else if constexpr (s == 1) {
+                    if (wave == 2) {
+                        const f64x4 x2 = solve_tile(2, c0, aop), x3 = solve_tile(3, c0, aop);
+                        update_tile(3, 2, x3, x2);
+                        xown = x2;
+                    } else if (wave == 3) {
+                        const f64x4 x3 = solve_tile(3, c0, aop);
+                        update_tile(3, 3, x3, x3);
+                        xown = x3;
+                    }
+                } else if constexpr (s == 2) {
+                    if (wave == 3) xown = solve_tile(3, c0, aop);
+                }
+            }
+            PIORAN_STAMP(8 * s + 3);
         }
-    }
-    if (tid == 0) *flag = bad;
+    });
+    if (tid == 64) *flag = bad;
     __syncthreads();
     bad = *flag;
     // the four inverses -> workspace (row-major 16 x 16 each), 4 entries per thread, coalesced

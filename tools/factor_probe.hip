@@ -11,6 +11,7 @@ __device__ unsigned long long g_st[64];
         if (threadIdx.x == 0) g_st[i] = t_;                                                        \
     } while (0)
 #include "../pioran.jl_amd/csrc/dense.hip"
+#include <cmath>
 #include <cstdio>
 #include <vector>
 
@@ -42,7 +43,7 @@ int main()
     const int n = 64, ld = 128;
     std::vector<double> h(ld * n, 0.0);
     for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) h[i + j * ld] = (i == j ? 70.0 : 0.0) + 1.0 / (1.0 + abs(i - j));
+        for (int j = 0; j < n; ++j) h[i + j * ld] = i < j ? NAN : (i == j ? 70.0 : 0.0) + 1.0 / (1.0 + abs(i - j));   // (upper triangle poisoned: never read as data)
     double *dA, *dws; unsigned long long* dout;
     hipMalloc(&dA, sizeof(double) * ld * n); hipMalloc(&dws, sizeof(double) * 2048); hipMalloc(&dout, 64 * 8);
     unsigned long long st[64];
@@ -61,11 +62,24 @@ int main()
             for (int k = 0; k <= j; ++k) acc += L[i + k * ld] * L[j + k * ld];
             err = fmax(err, fabs(acc - h[i + j * ld]));
         }
+    // the four parked inverses (copied to ws): inv(C_ss) C_ss = I, exact zeros above the diagonal
+    std::vector<double> W(1024);
+    hipMemcpy(W.data(), dws, sizeof(double) * 1024, hipMemcpyDeviceToHost);
+    double ierr = 0.0, upper = 0.0;
+    for (int sb = 0; sb < 4; ++sb)
+        for (int i = 0; i < 16; ++i)
+            for (int j = 0; j < 16; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k < 16; ++k) acc += W[sb * 256 + i * 16 + k] * (k >= j ? L[(16 * sb + k) + (16 * sb + j) * ld] : 0.0);
+                ierr = fmax(ierr, fabs(acc - (i == j ? 1.0 : 0.0)));
+                if (j > i) upper = fmax(upper, fabs(W[sb * 256 + i * 16 + j]));
+            }
     auto d = [&](int a, int b) { return (long long)(st[b] - st[a]); };
-    printf("load->LDS %lld | factor %lld | writeback %lld  (shader clock cycles) bad=%llu  max|LL'-A|=%.3e\n", d(50, 51),
-           d(51, 52), d(52, 53), st[63], err);
+    printf("load->LDS %lld | factor %lld | writeback %lld  (shader clock cycles) bad=%llu  max|LL'-A|=%.3e  max|inv(C_ss) C_ss - I|=%.3e  max|upper of inv|=%.1e\n", d(50, 51),
+           d(51, 52), d(52, 53), st[63], err, ierr, upper);
     for (int s = 0; s < 4; ++s)
-        printf(" s=%d: sub-panel sweep (wave 0) %lld | publish + barrier %lld | next-sub-panel tiles + barrier %lld\n", s,
+        printf(" s=%d: tile load + Gauss-Jordan sweep (wave 0) %lld | raw result to LDS + barrier %lld | chain's solve + diagonal-tile update %lld\n", s,
                d(8 * s + 0, 8 * s + 1), d(8 * s + 1, 8 * s + 2), d(8 * s + 2, 8 * s + 3));
+    printf(" last round's end -> return (flag, inverses to the workspace) %lld\n", d(8 * 3 + 3, 40));
     return 0;
 }
