@@ -27,6 +27,17 @@
  *     _shift, pioran_logpdf_batch_theta, _predict, _logl_grad prepare their own tables and never change what
  *     pioran_dataset_prepare declared, so host-pointer and *_dev calls can be mixed freely on one data set.
  *
+ * Accuracy (which kernel family evaluates a draw depends on rows, batch size and per-draw inputs; the calling thread's last family:
+ *   pioran_celerite_config_name(-1)).  With ratio = nu min(sigma2) / sum(a) ~ 1 / cond(K) of a draw:
+ *   - ratio >= 1e-8: every family is within 4.5e-9 (relative) of the exact value of its fp64 inputs, <= 3e-11 from ratio 1e-5 on
+ *     (every stored chain of the reference sits there); families agree to 3e-10 over prior draws of the bench model;
+ *   - ratio < 1e-8: the reference's own recurrence in fp64 is up to 7.8e-9 from the exact value; the step-by-step kernels follow it
+ *     (6 .. 8e-9), the windowed kernels ("tile", "block": large and small batches from 5 rows on) reach 2 .. 3.2e-8 on single draws,
+ *     the time-parallel family ("tp") 1e-10.  Two families can therefore differ by up to 4e-8 on such a draw; no single stage of the
+ *     windowed form removes that within 1 % of its time (profiles/r06_window_precision_by_stage.txt).  A caller that needs one
+ *     family for every batch size pins it: options "no_tile", "no_block", "no_tp", "scan_config".
+ *   - draws flagged in `status` (below): the families agree only to ~1e-6 (which D_n crosses zero within rounding differs).
+ *
  * status[b]:  0 ok;  1 some D_n <= 0 (matrix not positive definite — the reference silently uses
  *             log(abs(D_n)) for n >= 2, src/celerite_solver.jl:140, and so does out[b]);
  *             2 non-finite result (the reference would throw DomainError from log(D_1 < 0), :126).

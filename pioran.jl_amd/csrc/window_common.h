@@ -51,21 +51,23 @@ __host__ __device__ inline int64_t block_rec_doubles(int NB, int J) { return ((3
 // which is the rank-1 update of Sigma for n > P, the row operation on the identity for n < P, and turns lane P's own
 // Sigma_jP = L_jP d_P into -L_jP d_P: column P of L^-1 SCALED BY d_P (exactly: the factor -2 is exact, and every later row
 // operation is linear in the column; -1/d_P - 1 instead would leave the unscaled column but rounds 1/d_P to the grid of 1).
-// One v_fmac_f64_dpp per (P, j): 120 in all.  At the end lane n holds d_n in m[n] and d_n (L^-1)_jn in m[j], j > n; m[j]_n
+// One v_fmac_f64_dpp per (P, j): 120 in all.  DPP hazard (two wait states between a VALU write of a register and a DPP read of it; not
+// interlocked): the DPP source of an update is the row's own register m[j], last written by the PREVIOUS step's update of that row — at least the
+// seven instructions of the multiplier chain earlier — so the updates carry no s_nop (up to round 5 every group of four had one: 168 s_nop per
+// window in the ISA); only the broadcast of the next pivot, which reads the register the instruction before it wrote, keeps its s_nop 1.  At the end lane n holds d_n in m[n] and d_n (L^-1)_jn in m[j], j > n; m[j]_n
 // with j < n is left-over Sigma (the readers mask it).
 #define PIORAN_BLK_DPP " row_newbcast:%c[p] row_mask:0xf bank_mask:0xf"
 template <int P, int J0, int CNT>
 __device__ __forceinline__ void ldl_rows(double (&m)[16], double mult)
 {
     if constexpr (CNT >= 4) {
-        asm volatile("s_nop 1\n\t"
-                     "v_fmac_f64_dpp %[c0], %[c0], %[t]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[c1], %[c1], %[t]" PIORAN_BLK_DPP "\n\t"
+        asm volatile("v_fmac_f64_dpp %[c0], %[c0], %[t]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[c1], %[c1], %[t]" PIORAN_BLK_DPP "\n\t"
                      "v_fmac_f64_dpp %[c2], %[c2], %[t]" PIORAN_BLK_DPP "\n\tv_fmac_f64_dpp %[c3], %[c3], %[t]" PIORAN_BLK_DPP
                      : [c0] "+v"(m[J0]), [c1] "+v"(m[J0 + 1]), [c2] "+v"(m[J0 + 2]), [c3] "+v"(m[J0 + 3])
                      : [t] "v"(mult), [p] "i"(P));
         ldl_rows<P, J0 + 4, CNT - 4>(m, mult);
     } else if constexpr (CNT >= 1) {
-        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %[c0], %[c0], %[t]" PIORAN_BLK_DPP : [c0] "+v"(m[J0]) : [t] "v"(mult), [p] "i"(P));
+        asm volatile("v_fmac_f64_dpp %[c0], %[c0], %[t]" PIORAN_BLK_DPP : [c0] "+v"(m[J0]) : [t] "v"(mult), [p] "i"(P));
         ldl_rows<P, J0 + 1, CNT - 1>(m, mult);
     }
 }
