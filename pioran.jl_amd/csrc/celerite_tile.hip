@@ -20,7 +20,7 @@
 // vector instructions, against ~1300 SIMD cycles of the register-resident step-by-step scan (celerite_scan.hip), whose every FMA is
 // a vector instruction.
 // The window's own covariance block A (kappa on the 120 pairs of the window: a contraction of the pair table E with the draw's
-// (a, b)) does not depend on the state: tile_pairs_kernel forms it for every (draw, window) of the launch beforehand — E in
+// (a, b)) does not depend on the state: tile_pairs_mfma_kernel forms it for every (draw, window) of the launch beforehand — E in
 // registers, 32 draws per workgroup — into a workspace of 1 KB per draw and window that the factorisation reads one window ahead
 // (first version: the contraction inside the window loop, 40 .. 80 dependent reads of E from L2 per window: a third of the time).
 // Restrictions: shared (c, d) without per-draw rows; 1 .. 95 active rows; the series shared or per draw (Y, S2: the shifted log-flux models).
@@ -64,89 +64,11 @@ struct TileWave {                  // LDS of one wavefront
                                                           // they are the upper tiles as B operands
 };
 
-// A_p = sum_t a_t E_t,p.cos + b_t E_t,p.sin for the 120 pairs p of every window and every draw of the launch (kappa, src/acvf.jl:138-140, on the
-// window's own pairs): out[(b * NW + k) * 128 + p].  Workgroup (k, chunk of DC draws): thread p reads E_t,p once per term and serves DC draws
-// from it; the coefficients of the chunk sit in LDS as [t][draw] (broadcast reads).
-constexpr int kPairDraws = 32;
-__global__ void __launch_bounds__(128) tile_pairs_kernel(const ScanParams p, const double* __restrict__ btab, int64_t rsb, int64_t tsp, double* __restrict__ out)
-{
-    constexpr int DC = kPairDraws;
-    __shared__ double2 cf[kTileMaxTerms * DC];
-    const int J = p.J;
-    const int64_t NW = (p.N + KW - 1) / KW;
-    const int64_t k = blockIdx.x, b0 = (int64_t)blockIdx.y * DC;
-    const int pp = threadIdx.x;
-    for (int it = threadIdx.x; it < DC * J; it += 128) {
-        const int i = it / J, t = it - i * J;
-        const int64_t b = b0 + i < p.B ? b0 + i : p.B - 1;
-        cf[t * DC + i] = double2{p.A[b * J + t], p.Bc[b * J + t]};
-    }
-    __syncthreads();
-    const double2* E = reinterpret_cast<const double2*>(btab + k * rsb + tsp) + pp;
-    double acc0[DC], acc1[DC];
-#pragma unroll
-    for (int i = 0; i < DC; ++i) { acc0[i] = 0.0; acc1[i] = 0.0; }
-    int t = 0;
-    for (; t + 3 < J; t += 4) {
-        double2 e[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = E[(t + u) * 128];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int i = 0; i < DC; ++i) {
-                const double2 c = cf[(t + u) * DC + i];
-                acc0[i] = fma(c.x, e[u].x, acc0[i]);
-                acc1[i] = fma(c.y, e[u].y, acc1[i]);
-            }
-    }
-    for (; t < J; ++t) {
-        const double2 e = E[t * 128];
-#pragma unroll
-        for (int i = 0; i < DC; ++i) {
-            const double2 c = cf[t * DC + i];
-            acc0[i] = fma(c.x, e.x, acc0[i]);
-            acc1[i] = fma(c.y, e.y, acc1[i]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < DC; ++i)
-        if (b0 + i < p.B) out[((b0 + i) * NW + k) * 128 + pp] = acc0[i] + acc1[i];
-}
-
-// The same with the pair table in REGISTERS and the coefficients as scalar operands (wave-uniform loads straight from A / Bc: no LDS, two FMAs per
-// term, draw and pair and nothing else): JC = number of terms, compile-time (the launch picks it for 20 terms — the approx model of the benchmark —
-// and falls back to the kernel above).  Workgroup (k, chunk of DCR draws) of two wavefronts.
-constexpr int kPairDrawsReg = 64;
-template <int JC>
-__global__ void __launch_bounds__(128) tile_pairs_reg_kernel(const ScanParams p, const double* __restrict__ btab, int64_t rsb, int64_t tsp, double* __restrict__ out)
-{
-    const int64_t NW = (p.N + KW - 1) / KW;
-    const int64_t k = blockIdx.x, b0 = (int64_t)blockIdx.y * kPairDrawsReg;
-    const int pp = threadIdx.x;
-    const double2* E = reinterpret_cast<const double2*>(btab + k * rsb + tsp) + pp;
-    double2 e[JC];
-#pragma unroll
-    for (int t = 0; t < JC; ++t) e[t] = E[t * 128];
-    const int64_t nb = p.B - b0 < kPairDrawsReg ? p.B - b0 : kPairDrawsReg;
-    for (int64_t i = 0; i < nb; ++i) {
-        const double* __restrict__ ar = p.A + (b0 + i) * JC;      // (uniform addresses: scalar loads)
-        const double* __restrict__ br = p.Bc + (b0 + i) * JC;
-        double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-        for (int t = 0; t < JC; ++t) {
-            acc0 = fma(ar[t], e[t].x, acc0);
-            acc1 = fma(br[t], e[t].y, acc1);
-        }
-        out[((b0 + i) * NW + k) * 128 + pp] = acc0 + acc1;
-    }
-}
-
-// The same contraction as what it is, a GEMM — out[draw][(window, pair)] = sum over (t, cos | sin) of coef[draw][(t, cos | sin)] E[(t, cos | sin)][(window, pair)],
+// The contraction is a GEMM — out[draw][(window, pair)] = sum over (t, cos | sin) of coef[draw][(t, cos | sin)] E[(t, cos | sin)][(window, pair)],
 // 4096 x 2 J x 80 000 at the bench shape — on v_mfma_f64_16x16x4_f64: a wavefront owns 16 draws (their coefficients as A operands in 2 JQ registers for
 // the whole launch) and walks kPairWin windows x 8 tiles of 16 pairs; per tile JQ 16-byte table reads per lane (cos and sin of one term: both halves feed a
-// matrix instruction), 2 JQ matrix instructions, four 8-byte stores per lane (128 contiguous bytes per draw).  JQ = ceil(J / 4), compile-time.
-// (Vector forms above: 0.93 ms per 4096 draws at 20 terms with the table in registers, 1.97 ms at 40 terms with the coefficients in LDS.)
+// matrix instruction), 2 JQ matrix instructions, one 32-byte store per lane (128 contiguous bytes per draw).  JQ = ceil(J / 4), compile-time.
+// (Vector forms of round 5, removed in round 6: 0.93 ms per 4096 draws at 20 terms with the table in registers, 1.97 ms at 40 terms with the coefficients in LDS.)
 constexpr int kPairWin = 5;
 template <int JQ>
 __global__ void __launch_bounds__(256) tile_pairs_mfma_kernel(const ScanParams p, const double* __restrict__ btab, int64_t rsb, int64_t tsp, double* __restrict__ out)
@@ -157,6 +79,9 @@ __global__ void __launch_bounds__(256) tile_pairs_mfma_kernel(const ScanParams p
     const int64_t b0 = ((int64_t)blockIdx.y * 4 + w) * 16;
     if (b0 >= p.B) return;                         // (no workgroup-level synchronisation in this kernel)
     const int64_t draw = b0 + li < p.B ? b0 + li : p.B - 1;
+    // The PAIRS are the rows of the product (table entries as A operands), the draws its columns (coefficients as B operands), and row r of a tile is
+    // pair 4 (r & 3) + (r >> 2): result register g of lane (lk, li) is then pair 4 lk + g of draw li — four ADJACENT pairs, one 32-byte store per
+    // lane and tile (up to round 5 the draws were the rows: four 8-byte stores per lane; the kernel is bound by its 2.6 GB of stores).
     double aop[JQ], bop[JQ];
     int toff[JQ];
 #pragma unroll
@@ -164,8 +89,10 @@ __global__ void __launch_bounds__(256) tile_pairs_mfma_kernel(const ScanParams p
         const int t = 4 * q + lk;
         aop[q] = t < J ? p.A[draw * J + t] : 0.0;
         bop[q] = t < J ? p.Bc[draw * J + t] : 0.0;
-        toff[q] = (t < J ? t : J - 1) * 128 + li;
+        toff[q] = (t < J ? t : J - 1) * 128 + 4 * (li & 3) + (li >> 2);
     }
+    const bool live = b0 + li < p.B;
+    double* orow = out + (b0 + li) * NW * 128 + 4 * lk;
     const int64_t k0 = (int64_t)blockIdx.x * kPairWin, k1 = k0 + kPairWin < NW ? k0 + kPairWin : NW;
     for (int64_t k = k0; k < k1; ++k) {
         const double2* E = reinterpret_cast<const double2*>(btab + k * rsb + tsp);
@@ -177,14 +104,10 @@ __global__ void __launch_bounds__(256) tile_pairs_mfma_kernel(const ScanParams p
             d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < JQ; ++q) {
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[q], e[q].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bop[q], e[q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e[q].x, aop[q], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e[q].y, bop[q], acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int64_t bd = b0 + 4 * g + lk;
-                if (bd < p.B) out[(bd * NW + k) * 128 + 16 * pt + li] = acc[g];
-            }
+            if (live) *reinterpret_cast<d4*>(orow + k * 128 + 16 * pt) = acc;
         }
     }
 }
@@ -193,8 +116,8 @@ template <typename... Args>
 static inline bool launch_pairs_mfma(const ScanParams& p, hipStream_t stream, Args... args)
 {
     const int64_t NW = (p.N + KW - 1) / KW;
+    if ((p.B + 63) / 64 > 65535 || p.J > kTileMaxTerms) return false;       // (more than 4 M draws per launch / 64 terms: the callers chunk / refuse)
     const dim3 gr((unsigned)((NW + kPairWin - 1) / kPairWin), (unsigned)((p.B + 63) / 64));
-    if (gr.y > 65535) return false;
     const int jq = (p.J + 3) / 4;
     if (jq <= 5) hipLaunchKernelGGL(tile_pairs_mfma_kernel<5>, gr, dim3(256), 0, stream, p, args...);
     else if (jq <= 10) hipLaunchKernelGGL(tile_pairs_mfma_kernel<10>, gr, dim3(256), 0, stream, p, args...);
@@ -284,7 +207,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
 #pragma unroll
         for (int i = 0; i < NCK; ++i) ckpre[i] = tile_bload(rs_tab, lane8, so + 512 * i);   // (past 16 NB + 16 doubles: padding / the pair table, not used)
     };
-    // A of window k, C/D order (row 4 g + q, column c16): the off-diagonal entries from the workspace of tile_pairs_kernel (pair p =
+    // A of window k, C/D order (row 4 g + q, column c16): the off-diagonal entries from the workspace of tile_pairs_mfma_kernel (pair p =
     // nn (nn - 1) / 2 + jj, jj < nn), fetched one window ahead; the diagonal sum(a) + nu sigma2_n here (:92)
     int pidx[4];
 #pragma unroll
@@ -1085,15 +1008,8 @@ int launch_tile(const ScanParams& p, const double* btab, double* pairs, hipStrea
     const int64_t groups = (p.B + kTileWaves - 1) / kTileWaves;
     if (groups > 0x7fffffffLL) return PIORAN_ERR_UNSUPPORTED;
     const int64_t NW = (p.N + KW - 1) / KW;
-    if (NW > 0x7fffffffLL || (p.B + kPairDraws - 1) / kPairDraws > 65535) return PIORAN_ERR_UNSUPPORTED;
-    const dim3 gr((unsigned)NW, (unsigned)((p.B + kPairDrawsReg - 1) / kPairDrawsReg));
-    // (measured, profiles/r05_*kernel_stats.csv: 20 terms 0.93 ms per 4096 draws at N = 1e4 against 1.11 ms on the LDS form; with 40 terms the 160
-    //  registers of table entries cost it its occupancy — 2.76 against 1.96 ms — so that count stays on the LDS form)
-    if (launch_pairs_mfma(p, stream, btab, (int64_t)block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs)) {}
-    else if (p.J == 20) hipLaunchKernelGGL(tile_pairs_reg_kernel<20>, gr, dim3(128), 0, stream, p, btab, block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs);
-    else
-    hipLaunchKernelGGL(tile_pairs_kernel, dim3((unsigned)NW, (unsigned)((p.B + kPairDraws - 1) / kPairDraws)), dim3(128), 0, stream, p, btab,
-                       block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs);
+    if (NW > 0x7fffffffLL) return PIORAN_ERR_UNSUPPORTED;
+    if (!launch_pairs_mfma(p, stream, btab, (int64_t)block_rec_doubles(NB, p.J), (int64_t)block_tile_doubles(NB), pairs)) return PIORAN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((celerite_tile_kernel<NB>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds, stream, p, btab, (const double*)pairs);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
@@ -1117,12 +1033,9 @@ int launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab
     }
     const int64_t groups = (p.B + kTileWaves - 1) / kTileWaves;
     const int64_t NW = (p.N + KW - 1) / KW;
-    if (groups > 0x7fffffffLL || NW > 0x7fffffffLL || (p.B + kPairDraws - 1) / kPairDraws > 65535) return PIORAN_ERR_UNSUPPORTED;
+    if (groups > 0x7fffffffLL || NW > 0x7fffffffLL) return PIORAN_ERR_UNSUPPORTED;
     const int64_t rsb = block_rec_doubles(NB, p.J), tsp = block_tile_doubles(NB);
-    const dim3 gr((unsigned)NW, (unsigned)((p.B + kPairDrawsReg - 1) / kPairDrawsReg));
-    if (launch_pairs_mfma(p, stream, btab, rsb, tsp, pairs)) {}
-    else if (p.J == 20) hipLaunchKernelGGL(tile_pairs_reg_kernel<20>, gr, dim3(128), 0, stream, p, btab, rsb, tsp, pairs);
-    else hipLaunchKernelGGL(tile_pairs_kernel, dim3((unsigned)NW, (unsigned)((p.B + kPairDraws - 1) / kPairDraws)), dim3(128), 0, stream, p, btab, rsb, tsp, pairs);
+    if (!launch_pairs_mfma(p, stream, btab, rsb, tsp, pairs)) return PIORAN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((celerite_tile_kernel<NB, true>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_f, stream, p, btab, (const double*)pairs);
     hipLaunchKernelGGL((celerite_tile_adjoint_kernel<NB>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_r, stream, p, btab, gtab, pairs, grad_a, grad_b,
                        grad_nu, grad_mu);
