@@ -27,6 +27,7 @@ int pioran_launch_predict_from_gy(ScanParams p, double* work, double* tau_work, 
 
 struct pioran_ctx {
     int device = 0;
+    int ncu = 0;                    // compute units of the device (read once, at creation: the dispatch functions must not call into the runtime per launch)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev[16] = {};
@@ -109,6 +110,16 @@ static size_t ws_allow(const pioran_ctx* ctx, size_t free_b)
 {
     const size_t cap = (size_t)(ctx->opt.workspace_limit_mb > 0 ? ctx->opt.workspace_limit_mb : 16384) << 20;
     return free_b / 2 < cap ? free_b / 2 : cap;
+}
+
+// May `b` hold `bytes` under the workspace budget?  The runtime is asked for the free memory only when the buffer would have to GROW: the
+// asynchronous *_dev entries run this on every launch, and a launch that fits what is already allocated must not block on the host.
+static bool ws_fits(pioran_ctx* ctx, const pioran_ctx::Buf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return true;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return bytes <= ws_allow(ctx, free_b) + b.cap;
 }
 
 int ensure(pioran_ctx* ctx, pioran_ctx::Buf& b, size_t bytes)
@@ -424,6 +435,9 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     rows.insert(rows.end(), kind.begin(), kind.end());
     int rc = upload(ctx, ctx->btprow, rows.data(), rows.size() * sizeof(int32_t));
     if (rc) return rc;
+    // (B N (6 RP + 5) doubles of records + 133 KB per (draw, segment): 25 GB for eight draws of 64 rows at N = 1e6 — under the same budget as every
+    //  other chunked workspace; over it the serial-chain kernels take the call)
+    if (!ws_fits(ctx, ctx->btp, pioran_tp_workspace_doubles(p.B, p.N, RP, nseg) * sizeof(double))) return PIORAN_ERR_UNSUPPORTED;
     rc = ensure(ctx, ctx->btp, pioran_tp_workspace_doubles(p.B, p.N, RP, nseg) * sizeof(double));
     if (rc) return rc == PIORAN_ERR_ALLOC ? PIORAN_ERR_UNSUPPORTED : rc;
     ScanParams q = p;
@@ -471,15 +485,11 @@ int tile_dispatch(pioran_ds* ds, const ScanParams& p)
     int rc = ensure_btab(ds, *s);
     if (rc) return rc;
     // workspace: 1 KB per draw and window (the windows' own covariance blocks); large batches in chunks of whole passes
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
-    int ncu = 0;
-    HIPCHK(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    const int64_t pass = pioran_tile_pass_draws(p.R, ncu);
+    const int64_t pass = pioran_tile_pass_draws(p.R, ctx->ncu);
     int64_t chunk = p.B;
-    while (chunk > pass && pioran_tile_workspace_doubles(chunk, p.N) * sizeof(double) > ws_allow(ctx, free_b) + ctx->bpair.cap)
+    while (chunk > pass && !ws_fits(ctx, ctx->bpair, pioran_tile_workspace_doubles(chunk, p.N) * sizeof(double)))
         chunk = ((chunk / 2 + pass - 1) / pass) * pass;
-    if (pioran_tile_workspace_doubles(chunk, p.N) * sizeof(double) > ws_allow(ctx, free_b) + ctx->bpair.cap) return PIORAN_ERR_UNSUPPORTED;
+    if (!ws_fits(ctx, ctx->bpair, pioran_tile_workspace_doubles(chunk, p.N) * sizeof(double))) return PIORAN_ERR_UNSUPPORTED;
     rc = ensure(ctx, ctx->bpair, pioran_tile_workspace_doubles(chunk, p.N) * sizeof(double));
     if (rc) return rc == PIORAN_ERR_ALLOC ? PIORAN_ERR_UNSUPPORTED : rc;
     g_last_kernel = "tile";
@@ -606,9 +616,7 @@ int pioran_ctx_fp64_probe(pioran_ctx* ctx, int waves_per_simd, double ms, double
 {
     if (!ctx || !tflops || waves_per_simd < 1 || waves_per_simd > 8 || !(ms > 0.0) || ms > 1000.0) return PIORAN_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int ncu = 0;
-    HIPCHK(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    const int blocks = ncu * waves_per_simd;
+    const int blocks = ctx->ncu * waves_per_simd;
     int rc = ensure(ctx, ctx->bscratch, (size_t)blocks * 256 * sizeof(double));
     if (rc) return rc;
     // 64 FMAs per trip at ~4.6 issue cycles each and `waves_per_simd` wavefronts sharing the SIMD, ~2 GHz
@@ -700,6 +708,7 @@ static int ctx_create_impl(int device, void* stream, bool own, pioran_ctx** out)
 #endif
     pioran_ctx_set_option(ctx, "no_wide2", std::getenv("PIORAN_NO_WIDE2"));
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
+    if (hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->ncu < 1) { delete ctx; return PIORAN_ERR_HIP; }
     if (own) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PIORAN_ERR_HIP; }
         ctx->own_stream = true;

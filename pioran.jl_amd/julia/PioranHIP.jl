@@ -20,7 +20,10 @@ const ABI_VERSION = 7
 
 # PIORAN_BACKEND=julia keeps every call on Pioran's own Julia code (the escape hatch a deployment wants when no GPU is
 # visible or for A/B comparisons); anything else (default "hip") routes Float64 calls to libpioran_hip.so.
-const USE_HIP = Ref(lowercase(get(ENV, "PIORAN_BACKEND", "hip")) != "julia")
+# (USE_HIP, MIN_ROWS, MIN_STEPS: read from ENV in __init__, i.e. when the package is LOADED — module-level initialisers run at precompile time
+#  and would bake the build machine's environment into the package cache.  LIB stays a const: ccall wants a constant library name; set
+#  PIORAN_HIP_LIB before precompiling, or put the library on the loader's path.)
+const USE_HIP = Ref(true)
 # A drop-in must not be slower than what it replaces.  One scalar evaluation on the GPU walks a short series as a serial chain at ~0.15 us per
 # step whatever the term count, Pioran.logl on one CPU core costs ~0.04 us per step and ROW (N = 8192: j = 2 terms 0.60 ms, j = 4 1.31 ms, j = 8
 # 2.6 ms on the bench host; the reference's own figure: 0.85 / 1.6 / 3.7 ms — benchmark/benchmarks.jl:76-91, bench.py
@@ -28,11 +31,16 @@ const USE_HIP = Ref(lowercase(get(ENV, "PIORAN_BACKEND", "hip")) != "julia")
 # stay on Pioran's own code — unless the series is long: from PIORAN_HIP_MIN_STEPS steps on (default 3072) the library's time-parallel
 # family (celerite_tp.hip, round 5: segments of the series on different CUs) is ahead of one core at every term count (N = 8192: j = 2
 # 0.27 ms, j = 4 0.47 ms).  Batched calls (logpdf_batch and friends) always use the GPU.  PIORAN_HIP_MIN_ROWS = 0 sends everything to the GPU.
-const MIN_ROWS = Ref(parse(Int, get(ENV, "PIORAN_HIP_MIN_ROWS", "9")))
-const MIN_STEPS = Ref(parse(Int, get(ENV, "PIORAN_HIP_MIN_STEPS", "3072")))
-use_hip_scalar(nterms::Integer, nsteps::Integer) = USE_HIP[] && (2 * nterms >= MIN_ROWS[] || nsteps >= MIN_STEPS[])
+const MIN_ROWS = Ref(9)
+const MIN_STEPS = Ref(3072)
+# rows the kernels execute: two per term, one for a term with b = d = 0 (Exp / DRW terms: src/Exp.jl:29-33, the DRW half of DRWCelerite src/psd.jl:270-273)
+active_rows(b, d) = 2 * length(b) - count(i -> iszero(b[i]) && iszero(d[i]), eachindex(b))
+use_hip_scalar(nrows::Integer, nsteps::Integer) = USE_HIP[] && (nrows >= MIN_ROWS[] || nsteps >= MIN_STEPS[])
 
 function __init__()
+    USE_HIP[] = lowercase(get(ENV, "PIORAN_BACKEND", "hip")) != "julia"
+    MIN_ROWS[] = parse(Int, get(ENV, "PIORAN_HIP_MIN_ROWS", "9"))
+    MIN_STEPS[] = parse(Int, get(ENV, "PIORAN_HIP_MIN_STEPS", "3072"))
     USE_HIP[] || return
     v = ccall((:pioran_abi_version, LIB), Cint, ())
     v == ABI_VERSION || error("libpioran_hip.so has ABI version $v, PioranHIP.jl was written for $ABI_VERSION")
@@ -110,7 +118,7 @@ end
 function log_likelihood(cov::SumOfCelerite, τ::Vector{Float64}, y::Vector{Float64}, σ2::Vector{Float64}; solver = :celerite)
     (solver == :celerite || solver == :celerite_matrix) ||
         error("solver $solver not recognised, use either :celerite or :celerite_matrix")
-    if use_hip_scalar(length(cov.a), length(τ)) && eltype(cov.a) === Float64
+    if use_hip_scalar(active_rows(cov.b, cov.d), length(τ)) && eltype(cov.a) === Float64
         return logl_hip(collect(cov.a), collect(cov.b), collect(cov.c), collect(cov.d), τ, y, σ2)
     end
     return Pioran.logl(cov.a, cov.b, cov.c, cov.d, τ, y, σ2)
@@ -121,7 +129,7 @@ function _log_likelihood_coefs(cov, τ::Vector{Float64}, y::Vector{Float64}, σ2
     (solver == :celerite || solver == :celerite_matrix) ||
         error("solver $solver not recognised, use either :celerite or :celerite_matrix")
     a, b, c, d = celerite_coefs(cov)
-    if use_hip_scalar(length(a), length(τ)) && all(v -> eltype(v) <: Union{Float64, ComplexF64}, (a, b, c, d)) && all(v -> all(iszero, imag.(v)), (a, b, c, d))
+    if use_hip_scalar(active_rows(b, d), length(τ)) && all(v -> eltype(v) <: Union{Float64, ComplexF64}, (a, b, c, d)) && all(v -> all(iszero, imag.(v)), (a, b, c, d))
         return logl_hip(collect(Float64, real.(a)), collect(Float64, real.(b)), collect(Float64, real.(c)), collect(Float64, real.(d)), τ, y, σ2)
     end
     return real(Pioran.logl(a, b, c, d, τ, y, σ2))
