@@ -263,6 +263,11 @@ int pioran_celerite_simulate(pioran_ctx* ctx, int64_t N, int64_t B, int64_t J, c
  * (latency layout), "scan" (throughput layouts), "fallback", "block (windowed gradient[, per-draw tables])",
  * "wide (step-by-step gradient)" (diagnostics). */
 const char* pioran_celerite_config_name(int64_t R);
+/* Diagnostics (no GPU needed): the automatic choice between the windowed form with one draw per wavefront (1, "tile") and the other families (0)
+ * for a shared-table batch of B draws with R active rows; `pass` = draws per pass of the step-by-step layout of these rows (0 = unknown:
+ * returns -1 where the choice depends on it), no_split != 0: option "no_split".  The thresholds come from one sweep (profiles/r05_tile_batch_sweep.txt);
+ * tests/test_host.py holds this function against that file, tools/retune_thresholds.py prints both side by side. */
+int pioran_tile_choice(int32_t R, int64_t B, int64_t pass, int no_split);
 /* Diagnostics: the FP64 FMA rate (TFLOP/s) the device sustains right now with `waves_per_simd` (1 .. 8) wavefronts on every SIMD — about
  * `ms` milliseconds of a pure stream of independent v_fma_f64, event-timed on the context's stream.  The measured ceiling of any FP64
  * vector kernel on this box at that occupancy (the 78.6 TFLOP/s vendor figure assumes one FMA per SIMD every 4 cycles at 2.4 GHz).

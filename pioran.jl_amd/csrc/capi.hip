@@ -447,6 +447,27 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     return pioran_launch_tp(q, RP, nseg, L, dr, dr + RP, (double*)ctx->btp.p, ctx->stream);
 }
 
+// The automatic choice between the windowed form with one draw per wavefront ("tile", 1) and the rest (0: step-by-step throughput layouts / the
+// small-batch windowed kernel) for a shared-table batch of B draws with R active rows — a PURE function of its arguments, exported so that
+// tests/test_host.py can hold it against the committed sweep (profiles/r05_tile_batch_sweep.txt: the choice must be within 5 % of the faster
+// family on every measured line) and tools/retune_thresholds.py can print where it is not.  pass = draws per pass of the step-by-step
+// layout that would take the batch (pioran_scan_pass_draws; 0 = not known: -1 is returned where the ladder needs it).
+static int tile_choice(int32_t R, int64_t B, int64_t pass, int no_split)
+{
+    if (R >= 49) return B > (R > pioran_block_supported_rows() ? 256 : 512) ? 1 : 0;
+    if (R < 17 || B <= 512) return 0;
+    if (B <= 1024) return 1;
+    if (R < 33) return B <= 2048 ? 1 : 0;   // one round of this kernel's workgroups (2048 draws): SHO-12 1536 / 2048 draws 3.5 / 3.6 against 4.3 / 4.4 ms,
+                                          // SHO-16 level (5.3 / 5.4 against 5.4); beyond, the step-by-step layouts' pass (8192 / 4096 draws) is ahead
+    if (R >= 39 && R <= 47) return 1;   // three block columns cost the same for 33 .. 47 rows, the step-by-step layouts ~R^2: from 39 rows on this
+                                        // kernel is ahead on whole passes too (SHO-20, 4096 draws: 10.7 against 11.4 .. 12.0 ms)
+    if (pass <= 0) return -1;
+    const int64_t r = B % pass;
+    // a remainder of up to one round of the small-batch kernel rides beside the scan (split_dispatch) where that kernel takes these rows
+    const bool split = B > pass && r > 0 && r <= (R <= 47 ? 512 : 256) && !no_split;
+    return r > 0 && 4 * r <= 3 * pass && !split ? 1 : 0;
+}
+
 // Large shared-table batches: the windowed form with one draw per wavefront (celerite_tile.hip, round 5).  Same table as the windowed
 // kernel for small batches.  scan_config = "tile" forces it for any batch size.
 int tile_dispatch(pioran_ds* ds, const ScanParams& p)
@@ -465,19 +486,9 @@ int tile_dispatch(pioran_ds* ds, const ScanParams& p)
     // SHO-12 / SHO-16 / SHO-24 at 1024 draws 2.9 / 3.9 / 6.2 against 4.2 / 5.6 / 8.2 ms).
     bool automatic = !o.scan_config[0] && !o.no_tile && !o.no_block && p.tab && p.npd_rows == 0;
     if (automatic) {
-        if (p.R >= 49) automatic = p.B > (p.R > pioran_block_supported_rows() ? 256 : 512);
-        else if (p.R < 17 || p.B <= 512) automatic = false;
-        else if (p.B <= 1024) automatic = true;
-        else if (p.R < 33) automatic = false;
-        else if (p.R >= 39 && p.R <= 47) automatic = true;   // three block columns cost the same for 33 .. 47 rows, the step-by-step layouts ~R^2: from 39
-                                                             // rows on this kernel is ahead on whole passes too (SHO-20, 4096 draws: 10.7 against 11.4 .. 12.0 ms)
-        else {
-            const int64_t pass = pioran_scan_pass_draws(p, nullptr);
-            const int64_t r = pass > 0 ? p.B % pass : 0;
-            // a remainder of up to one round of the small-batch kernel rides beside the scan (split_dispatch) where that kernel takes these rows
-            const bool split = p.B > pass && r > 0 && r <= (p.R <= 47 ? 512 : 256) && !o.no_split;
-            automatic = pass > 0 && r > 0 && 4 * r <= 3 * pass && !split;
-        }
+        int choice = tile_choice(p.R, p.B, 0, o.no_split ? 1 : 0);
+        if (choice < 0) choice = tile_choice(p.R, p.B, pioran_scan_pass_draws(p, nullptr), o.no_split ? 1 : 0);   // (the occupancy query only where the ladder needs it)
+        automatic = choice == 1;
     }
     if (!(force || automatic) || !p.tab || p.npd_rows != 0 || !pioran_tile_fits(p.R, p.J)) return PIORAN_ERR_UNSUPPORTED;
     PrepState* s = p.tab == ds->user.tab ? &ds->user : (p.tab == ds->host.tab ? &ds->host : nullptr);
@@ -591,6 +602,9 @@ int launch(pioran_ds* ds, ScanParams& p)
 }
 
 }  // namespace
+
+int pioran_tile_choice(int32_t R, int64_t B, int64_t pass, int no_split) { return tile_choice(R, B, pass, no_split); }
+
 
 extern "C" {
 

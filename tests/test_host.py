@@ -8,6 +8,9 @@ import numpy as np
 import pytest
 
 import pioran_jl_amd as pj
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
 from oracle import oracle as O
 
 
@@ -248,3 +251,17 @@ def test_julia_shim_matches_header():
                  "pioran_logpdf_batch_theta", "pioran_dense_nll", "pioran_celerite_predict", "pioran_farm_logl_batch"):
         assert must in seen, must
     assert "pioran_abi_version" in jl and "ABI_VERSION = 7" in jl
+
+
+def test_tile_dispatch_ladder_matches_the_committed_sweep():
+    """capi.hip's automatic choice between the windowed form with one draw per wavefront and the other families (pioran_tile_choice: a pure
+    function, no GPU) against the sweep it was tuned on (profiles/r05_tile_batch_sweep.txt, tools/ab_tile.py): on every measured (rows, batch
+    size) the family the library takes is within 5 % of the faster one.  (the ladder was hand-typed from one box's sweep and
+    nothing re-derived it; tools/retune_thresholds.py prints the table.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("retune_thresholds", ROOT / "tools" / "retune_thresholds.py")
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    lines = list(mod.sweep_lines(ROOT / "profiles" / "r05_tile_batch_sweep.txt"))
+    assert len(lines) >= 60
+    bad = mod.check(verbose=False)
+    assert not bad, [(r["model"], r["rows"], r["B"], round(loss, 3)) for r, loss in bad]
