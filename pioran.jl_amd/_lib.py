@@ -54,6 +54,7 @@ SIGNATURES = {
     "pioran_celerite_simulate": (ctypes.c_int, [c_void_p, i64, i64, i64] + [c_void_p] * 4 + [ctypes.c_int] + [c_void_p] * 4),
     "pioran_celerite_config_name": (ctypes.c_char_p, [i64]),
     "pioran_ctx_fp64_probe": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]),
+    "pioran_tile_choice": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
     "pioran_farm_create": (ctypes.c_int, [ctypes.c_int, c_void_p, i64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),
     "pioran_farm_destroy": (ctypes.c_int, [c_void_p]),
     "pioran_farm_size": (ctypes.c_int, [c_void_p]),
