@@ -1687,12 +1687,13 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
         if (rc == PIORAN_ERR_UNSUPPORTED) windowed = false;
         else if (rc) return rc;
     }
-    // Many chains (round 5): the one-draw-per-wavefront reverse mode (celerite_tile.hip) — value and d/d(a, b, mu, nu) only, shared series.  Its
+    // Many chains (round 5): the one-draw-per-wavefront reverse mode (celerite_tile.hip) — value and d/d(a, b, mu, nu), since round 6 also d/d(c, d) of the
+    // SHARED (c, d) (both or neither), shared series.  Its
     // forward pass keeps the lower tiles of T per window (12 KB at three block columns) and the reverse kernel recomputes the rest, where the
     // small-batch kernels keep 41 KB per window and chain and hold one chain per CU.  scan_config = "tile" forces it for any chain count.
     // From 513 chains on (measured, SHO-20 / SHO-12 at N = 1e4: 512 chains 15.1 / 9.3 ms against the small-batch kernels' 11.0 / 9.2; 640 chains 15.2 /
     // 9.4 against 16.6 / 14.0; 2048 chains 27 / 16 against 44 / 36).
-    const bool tilegrad = windowed && !grad_c && !grad_d && !grad_y && !grad_sigma2 && !shift && s.R <= pioran_tile_grad_supported_rows() &&
+    const bool tilegrad = windowed && (grad_c != nullptr) == (grad_d != nullptr) && !grad_y && !grad_sigma2 && !shift && s.R <= pioran_tile_grad_supported_rows() &&
                           (ctx->opt.force_tile || (!ctx->opt.no_tile && B > 512 && s.R >= 17));
     auto ws_doubles = [&](int64_t nb) {
         return tilegrad ? pioran_tile_grad_workspace_doubles(nb, ds->N, s.R)
@@ -1767,7 +1768,7 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
         if (tilegrad) {
             p.gw = (double*)ctx->bwork.p;
             g_last_kernel = "tile (windowed gradient, one draw per wavefront)";
-            rc = pioran_launch_tile_grad(p, s.btab, gtab, (double*)ctx->bpair.p, dga, dgb, dgn, dgm, ctx->stream);
+            rc = pioran_launch_tile_grad(p, s.btab, gtab, (double*)ctx->bpair.p, dga, dgb, dgn, dgm, grad_c ? dgc : nullptr, grad_d ? dgd : nullptr, ctx->stream);
         } else if (windowed) {
             p.gw = (double*)ctx->bwork.p;
             g_last_kernel = "block (windowed gradient)";

@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
 // recomputed from it (76 matrix instructions + the factorisation), then the adjoint's products run on tiles (144): ~2.6 forward windows per reverse window.
 // T_k is read twice as B operand (M' and U~-'): its lower tiles as fragments straight from the workspace (the second time from L2), its upper
 // tiles as transposed reads of LDS copies; T- lives like T in the forward kernel (lower tiles in registers, transposed LDS copies).
-template <int NB>
+template <int NB, bool CD = false>
 struct TileAdjWave {
     double scr[16 * 18];           // transposing scratch (blocks of M', Q', X-' ... in turn); D_k (L^-1)_ik
     double srm[16 * 16];           // S- row-major
@@ -453,13 +453,19 @@ struct TileAdjWave {
     double tk[NB * (NB + 1) / 2][16 * 18];                 // the lower tiles of T_k, [row][column]: read as they stand (tiles on and below the
                                                            // diagonal) and transposed (above it) — registers hold T_k only on its way here
     double upB[NB > 1 ? NB * (NB - 1) / 2 : 1][16 * 18];   // strictly lower tiles of T-
+    double mw[CD ? NB : 1][CD ? 256 : 1];                  // d/d(c, d): M' of the window, C/D order [register][lane] (x goes on to hold X', then Q')
 };
 
-template <int NB>
+// CD (round 6): also the ROW part of d/d(c_t, d_t) with (c, d) shared by the chains (the formulas of celerite_block_adjoint_kernel<.., CD>:
+//   d/dc_r -= sum_n U~-'[n][r] U~'[n][r] (t_n - t_b) + sum_n X-'[n][r] V^'[n][r] (t_e - t_n) + cK-_r cK_r (t_e - t_b),  cK-_r = 2 sum_j T-_jr cK_j T_jr - sum_n X-'[n][r] M'[n][r]
+//   d/dd_r += s_r sum_n t_n (U~-'[n][r] (al_r C x - be_r C v)[n][r] + X-'[n][r] ((C_K / C) x)[n][r]),  s_r = -1 (cos row), +1 (sin row));
+// the pair part (d/dc E = -tau E, d/dd (E.cos, E.sin) = tau (-E.sin, E.cos)) is the post-pass's second product (tile_pairs_grad_kernel<true>).
+template <int NB, bool CD = false>
 __global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kernel(const ScanParams p, const double* __restrict__ btab,
                                                                                                   const double* __restrict__ gtab, double* __restrict__ pairs,
                                                                                                   double* __restrict__ grad_a, double* __restrict__ grad_b,
-                                                                                                  double* __restrict__ grad_nu, double* __restrict__ grad_mu)
+                                                                                                  double* __restrict__ grad_nu, double* __restrict__ grad_mu,
+                                                                                                  double* __restrict__ grad_c, double* __restrict__ grad_d)
 {
     constexpr int TS = 3 * NB * 256 + 16 * NB + 16, TSP = (TS + 127) & ~127;
     constexpr int64_t GS = 4 * (int64_t)NB * 256 + 16 * NB + 16 + 24;     // block_gtab_doubles (celerite_block.hip): C o v | C o x (C/D order) | C_K | sigma2 | ...
@@ -474,7 +480,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kern
     const int J = p.J, R = p.R;
     const int64_t NW = (N + KW - 1) / KW;
     const int64_t RSB = TSP + 256 * (int64_t)J;
-    TileAdjWave<NB>& sw = reinterpret_cast<TileAdjWave<NB>*>(lds_)[w];
+    TileAdjWave<NB, CD>& sw = reinterpret_cast<TileAdjWave<NB, CD>*>(lds_)[w];
     const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(btab), 0, 0x7ffffffc, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_gt = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(gtab), 0, 0x7ffffffc, 0x00020000);
     double* const pw = pairs + b * NW * 128;
@@ -518,6 +524,10 @@ __global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kern
 #pragma unroll
     for (int Jc = 0; Jc < NB; ++Jc) { acc_al[Jc] = 0.0; acc_be[Jc] = 0.0; }
     double acc_mu = 0.0, acc_sa = 0.0, acc_nu = 0.0;
+    [[maybe_unused]] double acc_c[NB], acc_d[NB];
+#pragma unroll
+    for (int Jc = 0; Jc < NB; ++Jc) { acc_c[Jc] = 0.0; acc_d[Jc] = 0.0; }
+    [[maybe_unused]] constexpr int OFF_H = 2 * NB * 256 + 16 * NB + 16, OFF_TM = OFF_H + 2 * NB * 256;     // gtab: (C_K / C) o v | (C_K / C) o x | t_n x 16, t_b, t_e
     int pidx[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -632,6 +642,10 @@ __global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kern
         for (int Jc = 0; Jc < NB; ++Jc) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 18 + c16] = x[Jc][g];
+            if constexpr (CD) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sw.mw[Jc][g * 64 + lane] = x[Jc][g];
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             double mb[4];
 #pragma unroll
@@ -803,8 +817,25 @@ __global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kern
 #pragma unroll
             for (int g = 0; g < 4; ++g) uw[Jc][g] = fma(myab[Jc].x, cvs[Jc][g], myab[Jc].y * cxs[Jc][g]);
         double wa[NB][4];          // W' in A-operand order
+        // d/d(c, d), round 6: the three groups of terms sit where their factor is consumed anyway — X-' here, U~-' in phase D, T- o T_k in the update — so
+        // that no operand's life grows (all of them in phase D: 334 spilled registers, the reverse kernel twice as slow)
+        [[maybe_unused]] double tnw[4], tbw = 0.0, tew = 0.0;
+        if constexpr (CD) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) tnw[g] = tile_bload(rs_gt, (4 * g + q) * 8, gso + OFF_TM * 8);
+            tbw = tile_bload(rs_gt, 0, gso + (OFF_TM + 16) * 8);
+            tew = tile_bload(rs_gt, 0, gso + (OFF_TM + 17) * 8);
+        }
 #pragma unroll
         for (int Jc = 0; Jc < NB; ++Jc) {
+            [[maybe_unused]] double hvw[4], hxw[4];
+            if constexpr (CD) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    hvw[g] = tile_bload(rs_gt, lane8, gso + (OFF_H + (Jc * 4 + g) * 64) * 8);
+                    hxw[g] = tile_bload(rs_gt, lane8, gso + (OFF_H + NB * 256 + (Jc * 4 + g) * 64) * 8);
+                }
+            }
             d4 su = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) su = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[ks], uw[Jc][ks], su, 0, 0, 0);
@@ -818,6 +849,16 @@ __global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kern
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) wa[Jc][ks] = sw.scr[c16 * 18 + 4 * ks + q];
+            if constexpr (CD) {             // the X-' terms: -sum X-' V^' (t_e - t_n), + sum t_n X-' ((C_K / C) x), and cK-_r's  - sum X-' M'  times  -cK_r (t_e - t_b)
+                double xm = 0.0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    xm = fma(xb[Jc][g], sw.mw[Jc][g * 64 + lane], xm);
+                    acc_c[Jc] = fma(-xb[Jc][g] * hvw[g], tew - tnw[g], acc_c[Jc]);
+                    acc_d[Jc] = fma(tnw[g] * xb[Jc][g], hxw[g], acc_d[Jc]);
+                }
+                acc_c[Jc] = fma(xm * ckc, tew - tbw, acc_c[Jc]);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -847,6 +888,13 @@ __global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kern
                 acc_al[Jc] = fma(ub[g], cvs[Jc][g], acc_al[Jc]);
                 acc_be[Jc] = fma(ub[g], cxs[Jc][g], acc_be[Jc]);
             }
+            if constexpr (CD) {             // the U~-' terms of d/d(c, d) (the X-' terms: phase C; the T- o T_k term: the update below)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc_c[Jc] = fma(-ub[g] * uw[Jc][g], tnw[g] - tbw, acc_c[Jc]);
+                    acc_d[Jc] = fma(tnw[g] * ub[g], fma(myab[Jc].x, cxs[Jc][g], -myab[Jc].y * cvs[Jc][g]), acc_d[Jc]);
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         PIORAN_ASTAMP2(11);
@@ -860,6 +908,22 @@ __global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kern
             for (int ks = 0; ks < 4; ++ks) { hm[ks] = 0.5 * mbk[Jc][ks]; hu[ks] = 0.5 * uw[Jc][ks]; }
 #pragma unroll
             for (int I = Jc; I < NB; ++I) {
+                if constexpr (CD) {
+                    // cK-_r's  2 sum_j T-_jr cK_j T_jr  times  -cK_r (t_e - t_b), tile by tile, T- BEFORE this window's rescaling: this tile's entries for
+                    // the columns of block Jc (this lane: column c16, rows 4 g + q of block I), and — tiles below the diagonal — their mirror images for the
+                    // columns of block I, read transposed from the LDS copies (T- from the previous window's update, T_k from this window's head)
+                    double s1 = 0.0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) s1 = fma(Tb[tix(I, Jc)][g] * sw.ck[16 * I + 4 * g + q], sw.tk[tix(I, Jc)][(4 * g + q) * 18 + c16], s1);
+                    acc_c[Jc] = fma(-2.0 * s1 * ckc, tew - tbw, acc_c[Jc]);
+                    if (Jc < I) {
+                        double s2 = 0.0;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            s2 = fma(sw.upB[uix(I, Jc)][c16 * 18 + 4 * g + q] * sw.ck[16 * Jc + 4 * g + q], sw.tk[tix(I, Jc)][c16 * 18 + 4 * g + q], s2);
+                        acc_c[I] = fma(-2.0 * s2 * sw.ck[16 * I + c16], tew - tbw, acc_c[I]);
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) Tb[tix(I, Jc)][g] *= sw.ck[16 * I + 4 * g + q] * ckc;
 #pragma unroll
@@ -900,21 +964,42 @@ __global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kern
         s_sa += __shfl_xor(s_sa, off);
         s_nu += __shfl_xor(s_nu, off);
     }
-    // rows -> terms through LDS (scr as ra | rb, at most 64 terms... 16 x 18 doubles hold 2 x 64)
+    [[maybe_unused]] double row_c = 0.0, row_d = 0.0;
+    if constexpr (CD) {
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) sw.red[16 * Jc + c16][q] = acc_c[Jc];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 16 * NB) row_c = (sw.red[lane][0] + sw.red[lane][1]) + (sw.red[lane][2] + sw.red[lane][3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int Jc = 0; Jc < NB; ++Jc) sw.red[16 * Jc + c16][q] = acc_d[Jc];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 16 * NB) row_d = (sw.red[lane][0] + sw.red[lane][1]) + (sw.red[lane][2] + sw.red[lane][3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // rows -> terms through LDS (scr as ra | rb | rc | rd, at most 64 terms: 16 x 18 doubles hold 4 x 64)
     double* ra = sw.scr;
     double* rb = sw.scr + 64;
-    for (int t = lane; t < 128; t += 64) sw.scr[t] = 0.0;
+    for (int t = lane; t < 256; t += 64) sw.scr[t] = 0.0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane < R) {
         const int rm = p.rowmap[lane];
         const int term = rm & 0xfffff;
         atomicAdd(&ra[term], row_al);
         atomicAdd(&rb[term], ((rm >> 30) & 1) ? -row_be : row_be);
+        if constexpr (CD) {
+            atomicAdd(&sw.scr[128 + term], row_c);
+            atomicAdd(&sw.scr[192 + term], ((rm >> 30) & 1) ? row_d : -row_d);
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int t = lane; t < J; t += 64) {
         grad_a[b * J + t] = ra[t] + s_sa;
         grad_b[b * J + t] = rb[t];
+        if constexpr (CD) {
+            grad_c[b * J + t] = sw.scr[128 + t];
+            grad_d[b * J + t] = sw.scr[192 + t];
+        }
     }
     if (lane == 0) {
         if (grad_mu) grad_mu[b] = s_mu;
@@ -932,40 +1017,82 @@ __global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kern
 //  per two FMAs; lanes = pairs with the table from L2 14.5 ms; lanes = pairs with the table in LDS and 40 accumulators per lane ~5 ms, two draws per
 //  wavefront 247 spilled registers.)
 constexpr int kPairGradTiles = 6;      // 16-column tiles of (term, cos | sin): 2 J <= 94 columns at the 47 rows of three block columns
+// CD (round 6): the pair part of d/d(c_t, d_t) with shared (c, d) — d/dc E_t,p = -tau_p E_t,p, d/dd (E.cos, E.sin) = tau_p (-E.sin, E.cos), tau_p = t_n - t_j of
+// the pair — is the same product with the A operand scaled by tau_p:  G_t = sum (S-_nj + S-_jn) tau_p E_t,p  (cos | sin), then per chain
+//   d/dc_t -= a_t G_t.cos + b_t G_t.sin,   d/dd_t += b_t G_t.cos - a_t G_t.sin;
+// a second set of accumulators, twice the matrix instructions.  The window's 16 time stamps sit in LDS per wavefront.
+template <bool CD>
 __global__ void __launch_bounds__(512) tile_pairs_grad_kernel(const ScanParams p, const double* __restrict__ btab, int64_t rsb, int64_t tsp,
-                                                              const double* __restrict__ pairs, double* __restrict__ grad_a, double* __restrict__ grad_b)
+                                                              const double* __restrict__ pairs, double* __restrict__ grad_a, double* __restrict__ grad_b,
+                                                              double* __restrict__ grad_c, double* __restrict__ grad_d)
 {
     __shared__ double red[8][256];
+    __shared__ double tw[8][16];
+    __shared__ double fin[256];
     const int J = p.J, nct = (2 * J + 15) / 16;
     const int64_t NW = (p.N + KW - 1) / KW;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
     const int64_t b0 = (int64_t)blockIdx.x * 16;
     const int64_t draw = b0 + i < p.B ? b0 + i : p.B - 1;       // (rows past the batch: a live draw's values, never written)
     d4 acc[kPairGradTiles];
+    [[maybe_unused]] d4 acc2[CD ? kPairGradTiles : 1];
 #pragma unroll
     for (int ct = 0; ct < kPairGradTiles; ++ct) acc[ct] = d4{0.0, 0.0, 0.0, 0.0};
+    if constexpr (CD) {
+#pragma unroll
+        for (int ct = 0; ct < kPairGradTiles; ++ct) acc2[ct] = d4{0.0, 0.0, 0.0, 0.0};
+    }
     int toff[kPairGradTiles];
 #pragma unroll
     for (int ct = 0; ct < kPairGradTiles; ++ct) {               // (columns past the last term: the last term's entries, never written)
         const int t = 8 * ct + (i >> 1);
         toff[ct] = (t < J ? t : J - 1) * 128 + 4 * q;
     }
+    // the steps (n > j) of this lane's pairs 16 g + 4 q + s, packed n | j << 4 (pair p = n (n - 1) / 2 + j; pairs 120 .. 127: n = j = 0, tau = 0)
+    [[maybe_unused]] unsigned char nj[8][4];
+    if constexpr (CD) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const int pp = 16 * g + 4 * q + s_;
+                int n_ = 1;
+                while ((n_ + 1) * n_ / 2 <= pp) ++n_;
+                nj[g][s_] = pp < 120 ? (unsigned char)(n_ | ((pp - n_ * (n_ - 1) / 2) << 4)) : (unsigned char)0;
+            }
+    }
     const bool sine = i & 1;
     for (int64_t k = w; k < NW; k += 8) {
         const double* sv = pairs + (draw * NW + k) * 128 + 4 * q;
         const double2* E = reinterpret_cast<const double2*>(btab + k * rsb + tsp);
+        if constexpr (CD) {
+            if (lane < 16) { const int64_t n = k * KW + lane; tw[w][lane] = p.t[n < p.N ? n : p.N - 1]; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wavefront writes and reads its own row: LDS serves a wavefront in order)
+        }
 #pragma unroll 2
         for (int g = 0; g < 8; ++g) {                           // (pairs 120 .. 127: zeros from the reverse kernel, zeros in the table)
             const d4 a = *reinterpret_cast<const d4*>(sv + 16 * g);
+            [[maybe_unused]] d4 at;
+            if constexpr (CD) {
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) at[s_] = a[s_] * (tw[w][nj[g][s_] & 15] - tw[w][nj[g][s_] >> 4]);
+            }
 #pragma unroll
             for (int ct = 0; ct < kPairGradTiles; ++ct) {
                 if (ct < nct) {
                     const double2* e = E + toff[ct] + 16 * g;
                     const double2 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
-                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], sine ? e0.y : e0.x, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], sine ? e1.y : e1.x, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], sine ? e2.y : e2.x, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], sine ? e3.y : e3.x, acc[ct], 0, 0, 0);
+                    const double b0_ = sine ? e0.y : e0.x, b1_ = sine ? e1.y : e1.x, b2_ = sine ? e2.y : e2.x, b3_ = sine ? e3.y : e3.x;
+                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b0_, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b1_, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b2_, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b3_, acc[ct], 0, 0, 0);
+                    if constexpr (CD) {
+                        acc2[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[0], b0_, acc2[ct], 0, 0, 0);
+                        acc2[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[1], b1_, acc2[ct], 0, 0, 0);
+                        acc2[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[2], b2_, acc2[ct], 0, 0, 0);
+                        acc2[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[3], b3_, acc2[ct], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -986,6 +1113,29 @@ __global__ void __launch_bounds__(512) tile_pairs_grad_kernel(const ScanParams p
                 if (b < p.B && t < J) { double* o = (col & 1) ? grad_b : grad_a; o[b * J + t] += sum; }
             }
             __syncthreads();
+            if constexpr (CD) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) red[w][g * 64 + lane] = acc2[ct][g];
+                __syncthreads();
+                if (threadIdx.x < 256) {
+                    double sum = 0.0;
+#pragma unroll
+                    for (int ww = 0; ww < 8; ++ww) sum += red[ww][threadIdx.x];
+                    fin[threadIdx.x] = sum;
+                }
+                __syncthreads();
+                if (threadIdx.x < 256 && !(threadIdx.x & 1)) {                // the (cos, sin) columns of a term sit in neighbouring lanes
+                    const int gg = threadIdx.x >> 6, ll = threadIdx.x & 63;
+                    const int64_t b = b0 + 4 * gg + (ll >> 4);
+                    const int t = (16 * ct + (ll & 15)) >> 1;
+                    if (b < p.B && t < J) {
+                        const double gco = fin[threadIdx.x], gsi = fin[threadIdx.x + 1], a_ = p.A[b * J + t], b_ = p.Bc[b * J + t];
+                        grad_c[b * J + t] -= fma(a_, gco, b_ * gsi);
+                        grad_d[b * J + t] += fma(b_, gco, -a_ * gsi);
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
 }
@@ -1019,16 +1169,19 @@ constexpr size_t tile_adj_lds_bytes() { return kTileWaves * sizeof(TileAdjWave<N
 
 template <int NB>
 int launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab, double* pairs, double* grad_a, double* grad_b, double* grad_nu,
-                     double* grad_mu, hipStream_t stream)
+                     double* grad_mu, double* grad_c, double* grad_d, hipStream_t stream)
 {
-    constexpr size_t lds_f = tile_lds_bytes<NB>(), lds_r = tile_adj_lds_bytes<NB>();
-    static_assert(lds_f <= 160 * 1024 && lds_r <= 160 * 1024, "one workgroup must fit a CU");
+    constexpr size_t lds_f = tile_lds_bytes<NB>(), lds_r = tile_adj_lds_bytes<NB>(), lds_rc = kTileWaves * sizeof(TileAdjWave<NB, true>);
+    static_assert(lds_f <= 160 * 1024 && lds_r <= 160 * 1024 && lds_rc <= 160 * 1024, "one workgroup must fit a CU");
     static bool granted[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
+    const bool cd = grad_c && grad_d;
+    if ((grad_c != nullptr) != (grad_d != nullptr)) return PIORAN_ERR_ARG;
     if (!granted[dev]) {
         if (hipFuncSetAttribute((const void*)celerite_tile_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f) != hipSuccess) return PIORAN_ERR_HIP;
-        if (hipFuncSetAttribute((const void*)celerite_tile_adjoint_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r) != hipSuccess) return PIORAN_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)celerite_tile_adjoint_kernel<NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r) != hipSuccess) return PIORAN_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)celerite_tile_adjoint_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rc) != hipSuccess) return PIORAN_ERR_HIP;
         granted[dev] = true;
     }
     const int64_t groups = (p.B + kTileWaves - 1) / kTileWaves;
@@ -1037,9 +1190,17 @@ int launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab
     const int64_t rsb = block_rec_doubles(NB, p.J), tsp = block_tile_doubles(NB);
     if (!launch_pairs_mfma(p, stream, btab, rsb, tsp, pairs)) return PIORAN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((celerite_tile_kernel<NB, true>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_f, stream, p, btab, (const double*)pairs);
-    hipLaunchKernelGGL((celerite_tile_adjoint_kernel<NB>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_r, stream, p, btab, gtab, pairs, grad_a, grad_b,
-                       grad_nu, grad_mu);
-    hipLaunchKernelGGL(tile_pairs_grad_kernel, dim3((unsigned)((p.B + 15) / 16)), dim3(512), 0, stream, p, btab, rsb, tsp, (const double*)pairs, grad_a, grad_b);
+    if (cd) {
+        hipLaunchKernelGGL((celerite_tile_adjoint_kernel<NB, true>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_rc, stream, p, btab, gtab, pairs, grad_a, grad_b,
+                           grad_nu, grad_mu, grad_c, grad_d);
+        hipLaunchKernelGGL(tile_pairs_grad_kernel<true>, dim3((unsigned)((p.B + 15) / 16)), dim3(512), 0, stream, p, btab, rsb, tsp, (const double*)pairs, grad_a, grad_b,
+                           grad_c, grad_d);
+    } else {
+        hipLaunchKernelGGL((celerite_tile_adjoint_kernel<NB, false>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_r, stream, p, btab, gtab, pairs, grad_a, grad_b,
+                           grad_nu, grad_mu, (double*)nullptr, (double*)nullptr);
+        hipLaunchKernelGGL(tile_pairs_grad_kernel<false>, dim3((unsigned)((p.B + 15) / 16)), dim3(512), 0, stream, p, btab, rsb, tsp, (const double*)pairs, grad_a, grad_b,
+                           (double*)nullptr, (double*)nullptr);
+    }
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
@@ -1055,18 +1216,18 @@ size_t pioran_tile_grad_workspace_doubles(int64_t B, int64_t N, int32_t R)
     return (size_t)B * (size_t)((N + KW - 1) / KW) * (size_t)(NB * (NB + 1) / 2) * 256;
 }
 
-// log L and its gradient with respect to (a, b, mu, nu), shared (c, d), shared series; p.gw: pioran_tile_grad_workspace_doubles, pairs:
+// log L and its gradient with respect to (a, b, mu, nu) and — grad_c, grad_d both given — the shared (c, d), shared series; p.gw: pioran_tile_grad_workspace_doubles, pairs:
 // pioran_tile_workspace_doubles; btab / gtab: the tables of pioran_launch_block_table / pioran_launch_block_gtab for the same (N, R, J, rowmap)
 int pioran_launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab, double* pairs, double* grad_a, double* grad_b, double* grad_nu,
-                            double* grad_mu, hipStream_t stream)
+                            double* grad_mu, double* grad_c, double* grad_d, hipStream_t stream)
 {
     if (!btab || !gtab || !pairs || !p.gw || !grad_a || !grad_b || p.B < 1 || p.N < 1 || p.npd_rows != 0 || p.Y || p.S2 || p.J > kTileMaxTerms ||
         p.R < 1 || p.R > pioran_tile_grad_supported_rows())
         return PIORAN_ERR_UNSUPPORTED;
     switch ((p.R + 1 + 15) / 16) {
-        case 1: return launch_tile_grad<1>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, stream);
-        case 2: return launch_tile_grad<2>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, stream);
-        case 3: return launch_tile_grad<3>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, stream);
+        case 1: return launch_tile_grad<1>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, grad_c, grad_d, stream);
+        case 2: return launch_tile_grad<2>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, grad_c, grad_d, stream);
+        case 3: return launch_tile_grad<3>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, grad_c, grad_d, stream);
     }
     return PIORAN_ERR_UNSUPPORTED;
 }

@@ -175,7 +175,7 @@ size_t pioran_tp_workspace_doubles(int64_t B, int64_t N, int RP, int nseg);
 int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream);
 size_t pioran_tile_grad_workspace_doubles(int64_t B, int64_t N, int32_t R);
 int pioran_launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab, double* pairs, double* grad_a, double* grad_b, double* grad_nu,
-                            double* grad_mu, hipStream_t stream);
+                            double* grad_mu, double* grad_c, double* grad_d, hipStream_t stream);
 int pioran_launch_block_table_reference(int64_t N, int32_t R, int32_t J, const int32_t* rowmap, const double* t, const double* c,
                                         const double* d, const double* y, const double* s2, double* btab, hipStream_t stream);
 // celerite_predict.hip: posterior mean at new times (pred, src/celerite_solver.jl:363-483)

@@ -2105,14 +2105,22 @@ def test_tile_gradient_matches_complex_step(ctx, J, N, B, nreal):
         assert name() == TILE_GRAD
         val = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
         assert name() == "tile"
-        gc = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)               # d/d(c, d) asked for: not this kernel's, whatever is forced
-        assert name() == "block (windowed gradient)"
+        gt = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)               # with d/d(c, d) of the shared (c, d): round 6, the same kernels (CD instantiation)
+        assert name() == TILE_GRAD
     finally:
         ctx.set_option("scan_config", None)
-    assert (g["logl"] == val).all() and (g["status"] == 0).all()
+    gc = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)                   # the small-batch windowed reverse mode (the automatic choice at these chain counts)
+    assert name() == "block (windowed gradient)"
+    assert (g["logl"] == val).all() and (g["status"] == 0).all() and (gt["logl"] == val).all()
     assert relerr(g["logl"], O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu)) < 1e-11
     for key in ("grad_a", "grad_b", "grad_mu", "grad_nu"):
         assert np.max(np.abs(g[key] - gc[key])) <= 1e-11 * (1 + np.max(np.abs(gc[key]))), key
+    for key in ("grad_a", "grad_b", "grad_c", "grad_d", "grad_mu", "grad_nu"):
+        assert np.max(np.abs(gt[key] - gc[key])) <= 1e-11 * (1 + np.max(np.abs(gc[key]))), key
+    ref = O.logl_grad(A[0], Bc[0], C, Dd, t, y - mu[0], nu[0] * s2, cd=True)       # d/d(c, d) against complex steps of the oracle
+    live = Dd != 0.0                                                # (one-row terms: d is structurally zero, no derivative asked of it)
+    assert np.max(np.abs(gt["grad_c"][0] - ref["grad_c"])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_c"])))
+    assert np.max(np.abs(gt["grad_d"][0][live] - ref["grad_d"][live])) <= 1e-9 * (1 + np.max(np.abs(ref["grad_d"])))
     for i in range(min(B, 4)):
         ref = O.logl_grad(A[i], Bc[i], C, Dd, t, y - mu[i], nu[i] * s2)
         for key in ("grad_a", "grad_b"):
@@ -2134,7 +2142,8 @@ def test_tile_gradient_dispatch_chunks_and_flagged_draws(ctx):
     g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
     assert name() == TILE_GRAD and (g["status"] == 0).all()
     assert ds.logl_grad(A[:512], Bc[:512], C, Dd, mu=mu[:512], nu=nu[:512], cd_grad=False)["logl"].shape == (512,) and name() == "block (windowed gradient)"
-    assert ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)["grad_c"] is not None and name() == "block (windowed gradient)"
+    gcd = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)               # with d/d(c, d) (round 6): the same kernels
+    assert gcd["grad_c"] is not None and name() == TILE_GRAD
     assert ds.logl_grad(A[:, :8], Bc[:, :8], C[:8], Dd[:8], mu=mu, nu=nu, cd_grad=False)["logl"].shape == (B,) and name() == "block (windowed gradient)"   # 16 rows
     try:
         ctx.set_option("no_tile", True)
@@ -2145,6 +2154,14 @@ def test_tile_gradient_dispatch_chunks_and_flagged_draws(ctx):
     assert relerr(g["logl"], h["logl"]) < 1e-12
     for key in ("grad_a", "grad_b", "grad_mu", "grad_nu"):
         assert np.max(np.abs(g[key] - h[key])) <= 1e-11 * (1 + np.max(np.abs(h[key]))), key
+    try:
+        ctx.set_option("no_tile", True)
+        hcd = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert name() == "block (windowed gradient)"
+    finally:
+        ctx.set_option("no_tile", False)
+    for key in ("grad_a", "grad_b", "grad_c", "grad_d", "grad_mu", "grad_nu"):
+        assert np.max(np.abs(gcd[key] - hcd[key])) <= 1e-11 * (1 + np.max(np.abs(hcd[key]))), key
     try:       # 19 windows x 3 tiles x 2 KB = 114 KB of T per chain: 1 MB holds nine chains -> 700 -> 350 -> ... -> 5 per launch
         ctx.set_option("workspace_limit_mb", 1)
         gs = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
