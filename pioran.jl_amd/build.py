@@ -13,7 +13,7 @@ CSRC = PKG / "csrc"
 OBJ = PKG / "_obj"
 LIB = PKG / "libpioran_hip.so"
 SOURCES = ["celerite_scan.hip", "celerite_wide.hip", "celerite_block.hip", "celerite_tile.hip", "celerite_tp.hip", "celerite_predict.hip", "celerite_fallback.hip", "table.hip", "approx.hip", "dense.hip", "capi.hip"]
-HEADERS = [CSRC / "common.h", CSRC / "window_common.h", PKG.parent / "include" / "pioran_hip.h"]
+HEADERS = [CSRC / "common.h", CSRC / "window_common.h", CSRC / "ldl_steps.inc", PKG.parent / "include" / "pioran_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-source additions.  celerite_tile.hip: keep the operands and results of the matrix instructions in VGPRs where the allocator has the choice — the
 # kernels' vector work (rescaling the state, LDS copies, the adjoint's products) otherwise reaches them through v_accvgpr moves (2568 -> 1516 in the file)
