@@ -380,21 +380,6 @@ __device__ __forceinline__ double recip_f64d(double x)
 // is the row's own register m[j], last written by the PREVIOUS step's update of that row — at least the seven instructions of the
 // multiplier chain earlier — so the updates need no s_nop (window_common.h's form pays one per group of four: 168 s_nop per sweep in
 // the ISA); only the broadcast of the next pivot, which reads the register the instruction before it wrote, keeps its s_nop 1.
-#define PIORAN_GJ_DPP " row_newbcast:%c[p] row_mask:0xf bank_mask:0xf"
-template <int P, int J0, int CNT>
-__device__ __forceinline__ void gj_rows(double (&m)[16], double mult)
-{
-    if constexpr (CNT >= 4) {
-        asm volatile("v_fmac_f64_dpp %[c0], %[c0], %[t]" PIORAN_GJ_DPP "\n\tv_fmac_f64_dpp %[c1], %[c1], %[t]" PIORAN_GJ_DPP "\n\t"
-                     "v_fmac_f64_dpp %[c2], %[c2], %[t]" PIORAN_GJ_DPP "\n\tv_fmac_f64_dpp %[c3], %[c3], %[t]" PIORAN_GJ_DPP
-                     : [c0] "+v"(m[J0]), [c1] "+v"(m[J0 + 1]), [c2] "+v"(m[J0 + 2]), [c3] "+v"(m[J0 + 3])
-                     : [t] "v"(mult), [p] "i"(P));
-        gj_rows<P, J0 + 4, CNT - 4>(m, mult);
-    } else if constexpr (CNT >= 1) {
-        asm volatile("v_fmac_f64_dpp %[c0], %[c0], %[t]" PIORAN_GJ_DPP : [c0] "+v"(m[J0]) : [t] "v"(mult), [p] "i"(P));
-        gj_rows<P, J0 + 1, CNT - 1>(m, mult);
-    }
-}
 // multiplier -m / d without a finished reciprocal: r0 = v_rcp_f64(d), e = 1 - d r0, t0 = -m r0, mult = t0 (1 + e + e^2) (relative error e^3 < 1e-22)
 __device__ __forceinline__ double gj_mult_of(double dn, double mrow)
 {
@@ -405,34 +390,14 @@ __device__ __forceinline__ double gj_mult_of(double dn, double mrow)
     asm volatile("v_fma_f64 %0, %1, %2, %1" : "=v"(mn) : "v"(t0), "v"(pq));
     return mn;
 }
-template <int P>
-__device__ __forceinline__ void gj_step(double (&m)[16], double& mult, int c16)
-{
-    constexpr int NR = 15 - P;                       // rows below the pivot
-    constexpr int NA = NR >= 1 ? 1 : 0;              // the next pivot's row first
-    constexpr int NBk = NR - NA >= 4 ? 4 : NR - NA;
-    constexpr int NCk = NR - NA - NBk >= 4 ? 4 : NR - NA - NBk;
-    constexpr int NDk = NR - NA - NBk - NCk;
-    gj_rows<P, P + 1, NA>(m, mult);
-    if constexpr (P < 15) {
-        double dn, r0, e, t0, pq, mn;
-        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%c2 row_mask:0xf bank_mask:0xf" : "=v"(dn) : "v"(m[P + 1]), "i"(P + 1));
-        if constexpr (NBk == 0) asm volatile("s_nop 0");
-        asm volatile("v_rcp_f64 %0, %1" : "=v"(r0) : "v"(dn));
-        gj_rows<P, P + 1 + NA, NBk>(m, mult);
-        asm volatile("s_nop 0\n\tv_fma_f64 %0, -%2, %3, 1.0\n\tv_mul_f64 %1, -%4, %2" : "=&v"(e), "=&v"(t0) : "v"(r0), "v"(dn), "v"(m[P + 1]));
-        gj_rows<P, P + 1 + NA + NBk, NCk>(m, mult);
-        asm volatile("v_fma_f64 %0, %1, %1, %1" : "=v"(pq) : "v"(e));
-        gj_rows<P, P + 1 + NA + NBk + NCk, NDk>(m, mult);
-        asm volatile("v_fma_f64 %0, %1, %2, %1" : "=v"(mn) : "v"(t0), "v"(pq));
-        mult = c16 == P + 1 ? -2.0 : mn;
-    }
-}
+// one elimination step = ONE inline-assembly statement (ldl_steps.inc, generated by tools/gen_ldl_steps.py; shared with the windowed celerite kernels):
+// as separate statements per piece the compiler put an `s_nop 0` at most of their boundaries (111 s_nop per sweep, on a chain that waits for every one)
+#include "ldl_steps.inc"
 template <int P>
 __device__ __forceinline__ void gj_sweep(double (&m)[16], double& mult, int c16)
 {
     if constexpr (P < 16) {
-        gj_step<P>(m, mult, c16);
+        ldl_step_fused<P>(m, mult, c16);
         gj_sweep<P + 1>(m, mult, c16);
     }
 }
