@@ -675,6 +675,8 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     else if (!std::strcmp(key, "btab_reference")) o.btab_reference = on;
     else if (!std::strcmp(key, "block_emode")) o.block_emode = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "dense_quad_threshold")) o.dense.quad_threshold = (value && value[0]) ? std::atoi(value) : -1;
+    else if (!std::strcmp(key, "dense_pair_tiles")) o.dense.pair_tiles = (value && value[0]) ? std::atoi(value) : -1;
+    else if (!std::strcmp(key, "dense_half_tile_limit")) o.dense.half_tile_limit = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "dense_batch_pair_threshold")) o.dense.batch_pair_threshold = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "dense_old_chain")) {
         const int v = (value && value[0]) ? std::atoi(value) : 0;

@@ -19,6 +19,8 @@
 // dense path (dense.hip): diagnostics / tuning of the factorisation schedule, carried per context (-1 = the defaults of dense.hip)
 struct DenseOptions {
     int quad_threshold = -1;        // trailing tiles per side above which a batched launch takes its steps in fours
+    int pair_tiles = -1;            // dense_step_kernel: tiles of the trailing matrix above which the bulk goes in pairs of panels (-1: the measured default)
+    int half_tile_limit = -1;       // dense_step_kernel: tiles per launch up to which a tile is split over two wavefronts (-1: default)
     int batch_pair_threshold = -1;  // ... in pairs
     int old_chain = 0;              // 1: one matrix on the panel / update chain of rounds 1-3 (A/B and cross-check of dense_step_kernel);
                                     // 2 / 3 / 4: timing experiments of dense_step_kernel's roles (tools/dense_roles.py)

@@ -1416,8 +1416,9 @@ static int dense_nll_impl(unsigned nbatch, DenseBatch bt, int64_t N, int32_t J, 
             const int64_t nt = (int64_t)(nb - org) + 1;
             return nt >= 2 ? (nt - 1) * (nt + 2) / 2 : 0;
         };
-        constexpr int64_t kPairTiles = 900;
-        constexpr int kHalfTileLimit = 1024;      // tiles per launch up to which every tile is split over two wavefronts
+        const int64_t kPairTiles = dop.pair_tiles >= 0 ? dop.pair_tiles : 250;     // (900 up to round 5, with a chain of 15.1 us per step; at 13.3 us: tools/dense_sched_sweep.py,
+                                                                                      //  N = 3000 / 4096 / 6000: 0.728 / 1.130 / 2.453 ms against 0.767 / 1.156 / 2.498)
+        const int kHalfTileLimit = dop.half_tile_limit >= 0 ? dop.half_tile_limit : 1024;      // tiles per launch up to which every tile is split over two wavefronts
         int ks = 2;
         if (!dop.no_pairs) while (ks + 2 < nb && tiles_of(ks + 2) > kPairTiles) ks += 2;
         // prototype: the chain as one persistent workgroup on a second stream (see flag_wait above); the step launches start at DIAG2

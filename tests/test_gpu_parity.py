@@ -1064,7 +1064,7 @@ def test_dense_nll_vs_oracle(ctx, N, J):
     assert abs(got - ref) <= 1e-11 * abs(ref)
 
 
-@pytest.mark.parametrize("N", [129, 191, 192, 193, 257, 320, 1000, 2760, 2881, 3100])
+@pytest.mark.parametrize("N", [129, 191, 192, 193, 257, 320, 1000, 1472, 1536, 1700, 2760, 2881, 3100])
 def test_dense_one_launch_per_block_column_equals_the_panel_update_chain(ctx, N):
     """log_likelihood_direct (src/direct_solver.jl:6-21) for one matrix: the one-launch-per-block-column factorisation of round 4
     (dense_step_kernel: critical workgroup + strips + lagging bulk, paired / single-panel phases, half tiles) against the panel / update
