@@ -396,7 +396,16 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     for (int j = 0; j < J; ++j)
         if (s->real_host[j]) { term.push_back(j); kind.push_back(2); }
     if ((int)term.size() > pioran_tp_supported_rows() || p.N < 64) return PIORAN_ERR_UNSUPPORTED;
-    const int RP = pioran_tp_padded_rows((int)term.size());
+    // The boundary phase as a scan over the segments' elements (tp_combine_kernel, round 6: ceil(log2 nseg) launches of one workgroup per (draw, target)
+    // instead of nseg - 1 dependent boundary steps) — up to two draws (nseg targets per draw and level want a CU each), 5 .. 48 state rows (padded to
+    // a multiple of 8 for it) — moves every crossover (tools/tp_scan_sweep.py, profiles/r06_time_parallel_scan.txt; one scalar call, PCIe included):
+    // 8 / 16 rows from 1024 steps on (N = 1024: 0.146 / 0.172 against 0.159 / 0.211 ms on the serial chain; N = 8192: 0.23 / 0.27 against 1.08 / 1.50),
+    // 24 rows from 1536 (0.254 against 0.306), 32 from 2048 (0.32 against 0.42), 40 / 48 from 3072 (0.50 / 0.58 against 0.60 / 0.76; N = 1e4:
+    // 0.64 / 0.76 against 1.87 / 2.40; N = 65536: 1.19 / 1.35 against 12.0 / 16.4).
+    const int nrows = (int)term.size();
+    const bool scan_rows = nrows > 4 && nrows <= 48;
+    const bool scan = o.tp_scan != 0 && scan_rows && (o.tp_scan > 0 || p.B <= 2);
+    const int RP = scan ? (nrows + 7) & ~7 : pioran_tp_padded_rows(nrows);
     // measured (tools/ab_tp.py sweep, profiles/r05_time_parallel_gpu.txt): with up to 8 draws it beats the serial-chain kernels from 1024 steps on at
     // up to 4 state rows (N = 8192: one SHO term 0.17 against 1.16 ms, two 0.27 against 1.15; there also at 64 draws from 4096 steps on: 0.90
     // against 1.16 ms), from 2048 steps at up to 8 rows (four terms, N = 8192: 0.47 against 1.21), from 4096 at up to 12, from 6144 at up to 16
@@ -415,19 +424,30 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
         const int64_t nmin12 = RP <= 24 ? 4096 : (RP <= 32 ? 5120 : (RP <= 40 ? 8192 : (RP <= 48 ? 6144 : nwide)));
         const int64_t nmin8 = RP <= 24 ? 5120 : (RP <= 32 ? 6144 : (RP <= 40 ? 8192 : (RP <= 48 ? 8192 : nwide)));
         const bool many = RP > 16 && ((p.B <= 2 && p.N >= nmin12) || (p.B <= 8 && p.N >= nmin8));
-        if (!few && !mid && !many) return PIORAN_ERR_UNSUPPORTED;
+        const bool scanned = scan && p.N >= (RP <= 16 ? 1024 : (RP <= 24 ? 1536 : (RP <= 32 ? 2048 : 3072)));
+        if (!few && !mid && !many && !scanned) return PIORAN_ERR_UNSUPPORTED;
     }
     while ((int)term.size() < RP) { term.push_back(0); kind.push_back(3); }
     // segments: phases 1 + 3 cost tau ~ 0.7 + R / 8 us per step with one wavefront per segment (up to 16 rows), ~ 1 + R / 32 with four; phase 2 t2 per
     // boundary as below (measured at 2 .. 48 rows, tools/ab_tp.py): N / nseg tau + nseg t2 is least at sqrt(tau N / t2)
     int nseg = o.tp_segments;
+    if (nseg <= 0 && scan) {
+        // N / nseg tau + ceil(log2 nseg) t_c, t_c = one combination (measured, tools/ab_tp.py: see profiles/r06_time_parallel_scan.txt): powers of two
+        const double tau = RP <= 16 ? 0.7 + RP / 8.0 : 1.0 + RP / 32.0, tc = 8.0 + (double)RP * RP / 34.0;
+        double best = 1e300;
+        for (int cand = 8, lv = 3; cand <= 256; cand *= 2, ++lv) {
+            const double est = tau * (double)p.N / cand + lv * tc;
+            if (est < best && (int64_t)cand * 16 <= p.N) { best = est; nseg = cand; }
+        }
+        if (nseg <= 0) nseg = 1;
+    }
     if (nseg <= 0) {
         const double tau = RP <= 16 ? 0.7 + RP / 8.0 : 1.0 + RP / 32.0, t2 = RP == 2 ? 0.6 : (RP == 4 ? 2.0 : (RP <= 16 ? 1.3 + RP * RP / 21.0 : 5.0 + (double)RP * RP / 80.0));   // (2 / 4 rows: one thread per draw; up to 16: one wavefront, in registers;
                                                                                  //  above: four wavefronts, products on the matrix cores, four pivots per barrier)
         nseg = (int)std::lround(std::sqrt(tau * (double)p.N / t2));
     }
     if (nseg < 1) nseg = 1;
-    if (nseg > 128) nseg = 128;
+    if (nseg > (scan ? 256 : 128)) nseg = scan ? 256 : 128;
     if ((int64_t)nseg * 16 > p.N) nseg = (int)(p.N / 16);
     const int64_t L = (p.N + nseg - 1) / nseg;
     nseg = (int)((p.N + L - 1) / L);
@@ -441,10 +461,10 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     rc = ensure(ctx, ctx->btp, pioran_tp_workspace_doubles(p.B, p.N, RP, nseg) * sizeof(double));
     if (rc) return rc == PIORAN_ERR_ALLOC ? PIORAN_ERR_UNSUPPORTED : rc;
     ScanParams q = p;
-    q.C = s->dc; q.D = s->dd; q.J = J;
+    q.C = s->dc; q.D = s->dd; q.J = J; q.opt = &ctx->opt;
     g_last_kernel = "tp";
     const int32_t* dr = (const int32_t*)ctx->btprow.p;
-    return pioran_launch_tp(q, RP, nseg, L, dr, dr + RP, (double*)ctx->btp.p, ctx->stream);
+    return pioran_launch_tp(q, RP, nseg, L, dr, dr + RP, (double*)ctx->btp.p, ctx->stream, scan ? 1 : 0);
 }
 
 // The automatic choice between the windowed form with one draw per wavefront ("tile", 1) and the rest (0: step-by-step throughput layouts / the
@@ -662,6 +682,8 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
         o.force_tp = value && !std::strcmp(value, "tp");
         if (value && !o.force_tile && !o.force_tp) std::strcpy(o.scan_config, value);
     } else if (!std::strcmp(key, "no_tp")) o.no_tp = on; else if (!std::strcmp(key, "tp_segments")) o.tp_segments = (value && value[0]) ? std::atoi(value) : 0;
+    else if (!std::strcmp(key, "tp_scan")) o.tp_scan = (value && value[0]) ? std::atoi(value) : -1;
+    else if (!std::strcmp(key, "tp_scan_tol")) o.tp_scan_tol = (value && value[0]) ? std::atof(value) : 0.0;
     else if (!std::strcmp(key, "no_tile")) o.no_tile = on; else if (!std::strcmp(key, "no_wide")) o.no_wide = on;
     else if (!std::strcmp(key, "no_paired")) o.no_paired = on;
     else if (!std::strcmp(key, "no_mixed")) o.no_mixed = on;

@@ -28,6 +28,8 @@
 
 #include "common.h"
 
+int pioran_tp_scan_rows(int RP);
+
 namespace {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -47,6 +49,7 @@ struct __attribute__((aligned(32))) TpStep { double s, y, s2, yos; };           
 
 constexpr int TP_ELEM_DOUBLES = (3 * 64 + 2) * 64;     // A' | C | J (64 x 64 each, row-major, rows = lanes), b, eta
 constexpr int TP_BND_DOUBLES = 65 * 64;                // m | P (64 x 64 row-major)
+constexpr double kTpScanTol = 1e-6;                    // largest relative discrepancy between the scan's boundary states and the boundary steps from them (tp_combine_kernel)
 
 __device__ __forceinline__ double tp_readlane(double x, int l)
 {
@@ -491,8 +494,10 @@ __global__ void __launch_bounds__(64 * NWV) tp_element_kernel(int64_t N, int RP,
 template <int TW, int RT>      // wavefronts (4; 1: no barrier at all, LDS traffic of one wavefront is served in order); RT 16-row tiles: 16 (RT - 1) < RP <= 16 RT
 __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, int J, const int32_t* __restrict__ row_term, const int32_t* __restrict__ row_kind,
                                                           const double* __restrict__ A_, const double* __restrict__ Bc_, const double* __restrict__ elem,
-                                                          double* __restrict__ bnd)
+                                                          double* __restrict__ bnd, const double* __restrict__ disc, double tol)
 {
+    // (disc: behind the scan form of this phase, tp_combine_kernel — only the draws whose scan failed its check are walked)
+    if (disc && !(disc[blockIdx.x] > tol)) return;
     extern __shared__ double lds[];
     constexpr int R16 = 16 * RT;                       // the products run on 16 x 16 tiles: rows and columns RP .. R16 - 1 of every matrix stay zero
     constexpr int S1 = R16 + 1, LW = 2 * R16 + 3;      // odd strides
@@ -721,6 +726,288 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
     if (nseg > 1) publish(nseg - 1);
 }
 
+// ---- phase 2 as a SCAN (round 6) ---------------------------------------------------------------------------------------------------------------
+// The boundary walk above is sequential over the segments (25 us per boundary at 40 rows: 724 of SHO-20's 1450 us at N = 1e4) while the elements it
+// consumes are associative.  Here: a Kogge-Stone scan over the scan indices 0 (the prior, as the element A = 0, b = 0, C = P_inf) and p = 1 .. nseg-1
+// (the element of segment p-1): level l combines  out[p] = in[p - 2^l] (x) in[p]  for every p >= 2^l, one workgroup each on its own CU; after level l
+// the indices below 2^(l+1) are complete prefixes, and the (b, C) of a complete prefix IS the filtered state (m, P) at the boundary in front of segment
+// p (its A is 0).  ceil(log2 nseg) launches instead of nseg - 1 dependent steps.
+//   a_i (x) a_j (i the earlier):  M = (I + C_i J_j)^-1;  b = A_j M (b_i + C_i eta_j) + b_j;  C = A_j (M C_i) A_j' + C_j        <- the boundary step with (m, P) := (b_i, C_i)
+//                                 A = A_j (M A_i);  J = A_i' J_j (M A_i) + J_i  (M' J_j = J_j M);  eta = A_i' (v - J_j (M C_i) v) + eta_i,  v = eta_j - J_j b_i  (M' = I - J_j M C_i)
+// i.e. the solve of the boundary step with RP more right-hand sides (A_i), three more products and a few matrix-vector sums.  A complete prefix as the
+// left operand (its A is 0: "prefix mode") needs none of the extras and its result goes straight to the boundary states; its (b, C) are read from there.
+// One workgroup of four wavefronts per (draw, target); the pieces — products on the matrix cores tile by tile, Gauss-Jordan with partial pivoting without
+// row exchanges, four pivots per barrier, rank-4 updates on the matrix cores — are tp_boundary_kernel's.  16 RT >= RP, RP a multiple of 8, RT <= 3 (the
+// three-block right-hand side does not fit 160 KB of LDS at 64 rows: those stay on the walk).
+template <int RT>
+__global__ void __launch_bounds__(256) tp_combine_kernel(int RP, int nseg, int J, int stride, const int32_t* __restrict__ row_term,
+                                                         const int32_t* __restrict__ row_kind, const double* __restrict__ A_, const double* __restrict__ Bc_,
+                                                         const double* __restrict__ ein, double* __restrict__ eout, double* __restrict__ bnd,
+                                                         double* __restrict__ disc)
+{
+    // disc != nullptr ("verify", stride = 1 with every left operand taken as a complete prefix): the boundary step of the sequential walk from the SCAN's
+    // state at boundary p - 1 with the raw element of segment p - 1, compared with the scan's state at boundary p: a safety net under the scan's
+    // combinations of incomplete elements.  Measured (tools/tp_scan_tol.py, profiles/r06_time_parallel_scan.txt): over 130 positive definite prior draws
+    // of three bench models at N = 1e4 and 128 segments the scan's log L is as close to the oracle as the walk's (max 1.1e-10) although the boundary
+    // states differ by 1e-14 .. 1e-9 — the discrepancy is far more sensitive than log L — so the threshold (kTpScanTol, option "tp_scan_tol") only
+    // catches a scan that has gone wrong outright (a NaN, a blow-up): such a draw goes through the walk after all (tp_boundary_kernel's `disc`).
+    extern __shared__ double lds[];
+    constexpr int TW = 4, R16 = 16 * RT, S1 = R16 + 1, LW = 3 * R16 + 3, T = 256;
+    double* X = lds;                     // [R16][LW]: [W, later A_j Z | z (1), Z (RP), later J_j (M A_i) | A_i -> M A_i (RP)]
+    double* Pm = X + R16 * LW;           // [R16][S1]: C_i, later Z = M C_i, then C (unsymmetrised), then J (unsymmetrised)
+    double* JL = Pm + R16 * S1;          // J_j
+    double* AL = JL + R16 * S1;          // A_j' as stored: AL[k][r] = A_j[r][k]; at the end A_i' the same way
+    double* WA = AL + R16 * S1;          // M A_i
+    double* mv = WA + R16 * S1;          // [64] b_i, later z
+    double* ev = mv + 64;                // eta_j
+    double* bl = ev + 64;                // b_j
+    double* bi = bl + 64;                // b_i (kept)
+    double* vv = bi + 64;                // v = eta_j - J_j b_i
+    double* zz = vv + 64;                // Z v
+    double* w2 = zz + 64;                // v - J_j Z v
+    double* fneg = w2 + 64;              // [TW][4][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b = blockIdx.y;
+    const int p = (int)blockIdx.x + stride, i = p - stride;
+    const bool prior = i == 0, full = !disc && i >= stride;  // the left operand: the prior | a complete prefix (in bnd) | an incomplete element (in ein)
+    const double* ej = ein + (b * nseg + (p - 1)) * TP_ELEM_DOUBLES;
+    const double* ei_ = ein + (b * nseg + (i > 0 ? i - 1 : 0)) * TP_ELEM_DOUBLES;
+    double* bs = bnd + b * nseg * TP_BND_DOUBLES;
+    const double* bsi = bs + (int64_t)i * TP_BND_DOUBLES;
+    const int NC = full ? 3 * RP + 1 : 2 * RP + 1;          // live columns of [W | z | Z (| M A_i)]
+    for (int q = tid; q < R16 * LW + 4 * R16 * S1 + 7 * 64; q += T) lds[q] = 0.0;
+    const int li = lane & 15, lk = lane >> 4;
+    auto gemm = [&](auto aop, auto bop, auto store) __attribute__((always_inline)) {
+        for (int tI = w; tI < RT * RT; tI += TW) {
+            const int I = tI / RT, Jt = tI - I * RT;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            double av[RT][4], bv[RT][4];
+#pragma unroll
+            for (int k4 = 0; k4 < RT; ++k4)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    av[k4][q4] = aop(16 * I + li, 16 * k4 + 4 * q4 + lk);
+                    bv[k4][q4] = bop(16 * k4 + 4 * q4 + lk, 16 * Jt + li);
+                }
+#pragma unroll
+            for (int k4 = 0; k4 < RT; ++k4)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k4][q4], bv[k4][q4], acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = 16 * I + 4 * g + lk, c = 16 * Jt + li;
+                if (r < RP && c < RP) store(r, c, acc[g]);
+            }
+        }
+    };
+    TP_BARRIER();
+    // ---- operands -----------------------------------------------------------------------------------------------------------------------------
+    for (int q = tid; q < RP * RP; q += T) {
+        const int r = q / RP, c = q % RP;
+        double v;
+        if (prior) {                                         // P_inf (tp_boundary_kernel's prior)
+            v = 0.0;
+            const int kr = row_kind[r], kc = row_kind[c];
+            if (kr != 3 && kc != 3) {
+                if (r == c) v = A_[b * J + row_term[r]];
+                else if ((r ^ 1) == c && kr < 2 && kc < 2) v = -Bc_[b * J + row_term[r]];
+            }
+            if (p == 1 && !disc) bs[64 + r * 64 + c] = v;    // (level 0: the prior's boundary state, which the filter of segment 0 starts from)
+        } else {
+            v = full ? ei_[4096 + r * 64 + c] : bsi[64 + r * 64 + c];
+        }
+        Pm[r * S1 + c] = v;
+        JL[r * S1 + c] = ej[8192 + r * 64 + c];
+        AL[r * S1 + c] = ej[r * 64 + c];
+    }
+    if (tid < RP) {
+        const double m0 = prior ? 0.0 : (full ? ei_[12288 + tid] : bsi[tid]);
+        mv[tid] = m0; bi[tid] = m0;
+        ev[tid] = ej[12288 + 64 + tid];
+        bl[tid] = ej[12288 + tid];
+        if (prior && p == 1 && !disc) bs[tid] = 0.0;
+    }
+    TP_BARRIER();
+    // ---- W = I + C_i J_j, z = b_i + C_i eta_j, Z = C_i (, A_i) ----------------------------------------------------------------------------------
+    gemm([&](int r, int kk) { return Pm[r * S1 + kk]; }, [&](int kk, int c) { return JL[kk * S1 + c]; },
+         [&](int r, int c, double v) { X[r * LW + c] = v + (r == c ? 1.0 : 0.0); });
+    for (int q = tid; q < RP * RP; q += T) {
+        const int r = q / RP, c = q % RP;
+        X[r * LW + RP + 1 + c] = Pm[r * S1 + c];
+        if (full) X[r * LW + 2 * RP + 1 + c] = ei_[c * 64 + r];          // A_i[r][c] (stored transposed)
+    }
+    if (tid < RP) {
+        double acc = mv[tid];
+#pragma unroll 8
+        for (int k = 0; k < RP; ++k) acc = fma(Pm[tid * S1 + k], ev[k], acc);
+        X[tid * LW + RP] = acc;
+    }
+    TP_BARRIER();
+    // ---- Gauss-Jordan elimination, four pivots per barrier (tp_boundary_kernel) ------------------------------------------------------------------
+    bool used = lane >= RP;
+    int mycol = 0;
+    double mypiv = 1.0;
+    const int lr = lane < RP ? lane : 0;
+    for (int k0 = 0; k0 < RP; k0 += 4) {
+        double xp[4], f[4];
+        int pr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xp[j] = X[lr * LW + k0 + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned cand = used ? 0u : ((unsigned)__double2hiint(xp[j]) & 0x7fffffffu) + 1u;
+            const unsigned mx = tp_max_u32(cand);
+            const unsigned long long bal = __ballot(cand == mx);
+            pr[j] = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(bal));
+            const double ipv = tp_rcp(tp_readlane(xp[j], pr[j]));
+            f[j] = (lane == pr[j] || lane >= RP) ? 0.0 : xp[j] * ipv;
+            if (lane == pr[j]) { used = true; mycol = k0 + j; mypiv = ipv; }
+#pragma unroll
+            for (int jj = j + 1; jj < 4; ++jj) xp[jj] = fma(-f[j], tp_readlane(xp[jj], pr[j]), xp[jj]);
+        }
+        const double f01 = tp_readlane(f[0], pr[1]), f02 = tp_readlane(f[0], pr[2]), f03 = tp_readlane(f[0], pr[3]);
+        const double f12 = tp_readlane(f[1], pr[2]), f13 = tp_readlane(f[1], pr[3]), f23 = tp_readlane(f[2], pr[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fneg[(w * 4 + j) * 64 + lane] = -f[j];
+        for (int ct = w; k0 + 4 + 16 * ct < NC; ct += TW) {
+            const int c0 = k0 + 4 + 16 * ct, col = c0 + li, cc = col < NC ? col : NC - 1;
+            const double x0 = X[pr[0] * LW + cc], x1 = X[pr[1] * LW + cc], x2 = X[pr[2] * LW + cc], x3 = X[pr[3] * LW + cc];
+            const double u0 = x0, u1 = fma(-f01, u0, x1), u2 = fma(-f12, u1, fma(-f02, u0, x2)), u3 = fma(-f23, u2, fma(-f13, u1, fma(-f03, u0, x3)));
+            const double ub = lk == 0 ? u0 : (lk == 1 ? u1 : (lk == 2 ? u2 : u3));
+            f64x4 acc[RT];
+            double fa[RT];
+#pragma unroll
+            for (int It = 0; It < RT; ++It) {
+                fa[It] = fneg[(w * 4 + lk) * 64 + 16 * It + li];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[It][g] = X[(16 * It + 4 * g + lk) * LW + cc];
+            }
+#pragma unroll
+            for (int It = 0; It < RT; ++It) {
+                acc[It] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[It], ub, acc[It], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (col < NC && 16 * It + 4 * g + lk < RP) X[(16 * It + 4 * g + lk) * LW + col] = acc[It][g];
+            }
+        }
+        TP_BARRIER();
+    }
+    // row `lane` solved column mycol: Z into Pm (C_i is dead), z into mv, M A_i into WA
+    if (lane < RP) {
+        for (int c = w; c < RP; c += TW) {
+            Pm[mycol * S1 + c] = X[lane * LW + RP + 1 + c] * mypiv;
+            if (full) WA[mycol * S1 + c] = X[lane * LW + 2 * RP + 1 + c] * mypiv;
+        }
+        if (w == 0) mv[mycol] = X[lane * LW + RP] * mypiv;
+    }
+    TP_BARRIER();
+    // ---- vectors: b = A_j z + b_j;  v = eta_j - J_j b_i, Z v, v - J_j Z v (general mode) -----------------------------------------------------------
+    double mnew = 0.0;
+    if (tid < RP) {
+        double acc = bl[tid];
+#pragma unroll 8
+        for (int k = 0; k < RP; ++k) acc = fma(AL[k * S1 + tid], mv[k], acc);
+        mnew = acc;
+        if (full) {
+            double a2 = ev[tid];
+#pragma unroll 8
+            for (int k = 0; k < RP; ++k) a2 = fma(-JL[tid * S1 + k], bi[k], a2);
+            vv[tid] = a2;
+        }
+    }
+    // T = A_j Z (into X, columns 0 .. RP-1; W is dead)
+    gemm([&](int r, int kk) { return AL[kk * S1 + r]; }, [&](int kk, int c) { return Pm[kk * S1 + c]; },
+         [&](int r, int c, double v) { X[r * LW + c] = v; });
+    if (full) {
+        // J_j (M A_i) into X, columns RP+1 .. 2 RP (the copy of Z there is dead);  A = A_j (M A_i), stored transposed, straight to the output
+        gemm([&](int r, int kk) { return JL[r * S1 + kk]; }, [&](int kk, int c) { return WA[kk * S1 + c]; },
+             [&](int r, int c, double v) { X[r * LW + RP + 1 + c] = v; });
+        double* eo = eout + (b * nseg + (p - 1)) * TP_ELEM_DOUBLES;
+        gemm([&](int k, int s_) { return WA[s_ * S1 + k]; }, [&](int s_, int r) { return AL[s_ * S1 + r]; },
+             [&](int k, int r, double v) { eo[k * 64 + r] = v; });
+    }
+    TP_BARRIER();
+    if (full && tid < RP) {
+        double a2 = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < RP; ++k) a2 = fma(Pm[tid * S1 + k], vv[k], a2);
+        zz[tid] = a2;
+    }
+    TP_BARRIER();
+    if (full && tid < RP) {
+        double a2 = vv[tid];
+#pragma unroll 8
+        for (int k = 0; k < RP; ++k) a2 = fma(-JL[tid * S1 + k], zz[k], a2);
+        w2[tid] = a2;
+    }
+    TP_BARRIER();
+    // C = T A_j' + C_j (Z is dead: into Pm), symmetrised on the way out
+    gemm([&](int r, int kk) { return X[r * LW + kk]; }, [&](int kk, int c) { return kk < RP ? AL[kk * S1 + c] : 0.0; },
+         [&](int r, int c, double v) { Pm[r * S1 + c] = v; });
+    TP_BARRIER();
+    if (disc) {
+        // verify: |scan - step| over the state, relative to the state's largest entries
+        double* bo = bs + (int64_t)p * TP_BND_DOUBLES;
+        double dP = 0.0, sP = 0.0, dm = 0.0, sm = 0.0;
+        for (int q = tid; q < RP * RP; q += T) {
+            const int r = q / RP, c = q % RP;
+            const double v = 0.5 * (Pm[r * S1 + c] + Pm[c * S1 + r]) + ej[4096 + r * 64 + c], o = bo[64 + r * 64 + c];
+            dP = fmax(dP, fabs(v - o)); sP = fmax(sP, fabs(o));
+        }
+        if (tid < RP) { const double o = bo[tid]; dm = fabs(mnew - o); sm = fabs(o); }
+        dP = tp_max(dP); sP = tp_max(sP); dm = tp_max(dm); sm = tp_max(sm);
+        if (lane == 0) { fneg[w] = dP; fneg[4 + w] = sP; fneg[8 + w] = dm; fneg[12 + w] = sm; }
+        TP_BARRIER();
+        if (tid == 0) {
+            const double DP = fmax(fmax(fneg[0], fneg[1]), fmax(fneg[2], fneg[3])), SP = fmax(fmax(fneg[4], fneg[5]), fmax(fneg[6], fneg[7]));
+            const double DM = fmax(fmax(fneg[8], fneg[9]), fmax(fneg[10], fneg[11])), SM = fmax(fmax(fneg[12], fneg[13]), fmax(fneg[14], fneg[15]));
+            // (the mean is measured against its own scale and the standard deviation the covariance implies: a mean that is tiny by symmetry must not trip it)
+            double rel = DP / (SP > 0.0 ? SP : 1.0);
+            const double mscale = fmax(SM, sqrt(SP));
+            rel = fmax(rel, DM / (mscale > 0.0 ? mscale : 1.0));
+            if (!(rel >= 0.0)) rel = 1.0;                    // NaN: a draw that is not positive definite — the walk reports it the way it always did
+            atomicMax(reinterpret_cast<unsigned long long*>(disc + b), (unsigned long long)__double_as_longlong(rel));
+        }
+        return;
+    }
+    {
+        double* eo = eout + (b * nseg + (p - 1)) * TP_ELEM_DOUBLES;
+        double* bo = bs + (int64_t)p * TP_BND_DOUBLES;
+        for (int q = tid; q < RP * RP; q += T) {
+            const int r = q / RP, c = q % RP;
+            const double v = 0.5 * (Pm[r * S1 + c] + Pm[c * S1 + r]) + ej[4096 + r * 64 + c];
+            if (full) eo[4096 + r * 64 + c] = v; else bo[64 + r * 64 + c] = v;
+        }
+        if (tid < RP) { if (full) eo[12288 + tid] = mnew; else bo[tid] = mnew; }
+    }
+    if (!full) return;                                       // (workgroup-uniform)
+    TP_BARRIER();
+    // ---- J = A_i' (J_j M A_i) + J_i, eta = A_i' (v - J_j Z v) + eta_i: A_i' into AL (A_j is dead) ---------------------------------------------------
+    for (int q = tid; q < RP * RP; q += T) {
+        const int r = q / RP, c = q % RP;
+        AL[r * S1 + c] = ei_[r * 64 + c];
+    }
+    TP_BARRIER();
+    gemm([&](int r, int kk) { return AL[r * S1 + kk]; }, [&](int kk, int c) { return kk < RP ? X[kk * LW + RP + 1 + c] : 0.0; },
+         [&](int r, int c, double v) { Pm[r * S1 + c] = v; });
+    double enew = 0.0;
+    if (tid < RP) {
+        double a2 = ei_[12288 + 64 + tid];
+#pragma unroll 8
+        for (int k = 0; k < RP; ++k) a2 = fma(AL[tid * S1 + k], w2[k], a2);
+        enew = a2;
+    }
+    TP_BARRIER();
+    {
+        double* eo = eout + (b * nseg + (p - 1)) * TP_ELEM_DOUBLES;
+        for (int q = tid; q < RP * RP; q += T) {
+            const int r = q / RP, c = q % RP;
+            eo[8192 + r * 64 + c] = 0.5 * (Pm[r * S1 + c] + Pm[c * S1 + r]) + ei_[8192 + r * 64 + c];
+        }
+        if (tid < RP) eo[12288 + 64 + tid] = enew;
+    }
+}
+
 // The same for two or four state rows (the reference benchmark grid's j = 2: benchmark/benchmarks.jl:16-18), ONE THREAD per draw, everything in
 // registers, fully unrolled; partial pivoting by conditional row exchanges.  A boundary is ~550 dependent-chain-free instructions (1.3 us) where the
 // workgroup kernel spends 4.2 us in LDS round trips.
@@ -862,8 +1149,9 @@ __global__ void __launch_bounds__(64) tp_boundary_small_kernel(int nseg, int J, 
 template <int R>
 __global__ void __launch_bounds__(64) tp_boundary_wave_kernel(int nseg, int J, const int32_t* __restrict__ row_term, const int32_t* __restrict__ row_kind,
                                                               const double* __restrict__ A_, const double* __restrict__ Bc_, const double* __restrict__ elem,
-                                                              double* __restrict__ bnd)
+                                                              double* __restrict__ bnd, const double* __restrict__ disc, double tol)
 {
+    if (disc && !(disc[blockIdx.x] > tol)) return;
     __shared__ double tr[16][17];
     __shared__ int inv[16];
     const int lane = threadIdx.x;
@@ -982,15 +1270,18 @@ __global__ void __launch_bounds__(64) tp_boundary_wave_kernel(int nseg, int J, c
 }
 
 template <int NP, int NWV>
-int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream)
+int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream, int scan)
 {
     const int64_t B = p.B, N = p.N;
     TpRec* rec = reinterpret_cast<TpRec*>(work);
     TpStep* stp = reinterpret_cast<TpStep*>(work + (size_t)B * N * RP * 6);
     double* sval = work + (size_t)B * N * RP * 6 + (size_t)B * N * 4;
     double* elem = sval + (size_t)B * N;
-    double* bnd = elem + (size_t)B * nseg * TP_ELEM_DOUBLES;
+    double* elem2 = elem + (size_t)B * nseg * TP_ELEM_DOUBLES;       // the scan's two element buffers (its levels ping-pong; the raw elements stay for the check)
+    double* elem3 = elem2 + (size_t)B * nseg * TP_ELEM_DOUBLES;
+    double* bnd = elem3 + (size_t)B * nseg * TP_ELEM_DOUBLES;
     double* part = bnd + (size_t)B * nseg * TP_BND_DOUBLES;
+    double* disc = part + (size_t)B * nseg * 4;                      // [B] the scan's largest discrepancy per draw
     if (hipMemsetAsync(bnd, 0, (size_t)B * nseg * TP_BND_DOUBLES * sizeof(double), stream) != hipSuccess) return PIORAN_ERR_HIP;
     hipLaunchKernelGGL(tp_records_kernel, dim3((unsigned)N, (unsigned)B), dim3(64), 0, stream, N, RP, p.J, row_term, row_kind, p.t, p.y, p.s2, p.Y, p.S2, p.A,
                        p.Bc, p.C, p.D, p.mu, p.nu, rec, stp);
@@ -1001,12 +1292,53 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
     static size_t granted[8][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
-    if (RP == 2)
+    if (scan && nseg >= 2 && pioran_tp_scan_rows(RP)) {
+        // phase 2 as a scan: ceil(log2 nseg) launches of tp_combine_kernel, one workgroup per (draw, target)
+        const int rt = (RP + 15) / 16;
+        const size_t r16s = (size_t)rt * 16, ldsc = (r16s * (3 * r16s + 3) + 4 * r16s * (r16s + 1) + 7 * 64 + 1024) * sizeof(double);
+        const void* fnc = rt == 1 ? (const void*)tp_combine_kernel<1> : (rt == 2 ? (const void*)tp_combine_kernel<2> : (const void*)tp_combine_kernel<3>);
+        static size_t granted_c[4][64] = {};
+        if (ldsc > granted_c[rt][dev]) {
+            if (hipFuncSetAttribute(fnc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc) != hipSuccess) return PIORAN_ERR_HIP;
+            granted_c[rt][dev] = ldsc;
+        }
+        const double tol = p.opt && p.opt->tp_scan_tol > 0.0 ? p.opt->tp_scan_tol : kTpScanTol;
+        if (hipMemsetAsync(disc, 0, (size_t)B * sizeof(double), stream) != hipSuccess) return PIORAN_ERR_HIP;
+        auto combine = [&](const dim3& gr, int stride, const double* src, double* dst, double* dsc) {
+            if (rt == 1) hipLaunchKernelGGL((tp_combine_kernel<1>), gr, dim3(256), ldsc, stream, RP, nseg, p.J, stride, row_term, row_kind, p.A, p.Bc, src, dst, bnd, dsc);
+            else if (rt == 2) hipLaunchKernelGGL((tp_combine_kernel<2>), gr, dim3(256), ldsc, stream, RP, nseg, p.J, stride, row_term, row_kind, p.A, p.Bc, src, dst, bnd, dsc);
+            else hipLaunchKernelGGL((tp_combine_kernel<3>), gr, dim3(256), ldsc, stream, RP, nseg, p.J, stride, row_term, row_kind, p.A, p.Bc, src, dst, bnd, dsc);
+        };
+        const double* src = elem;
+        double* dst = elem2;
+        for (int stride = 1; stride < nseg; stride *= 2) {
+            combine(dim3((unsigned)(nseg - stride), (unsigned)B), stride, src, dst, nullptr);
+            src = dst;
+            dst = dst == elem2 ? elem3 : elem2;
+        }
+        // the check (one boundary step per boundary from the scan's states, all at once) and, for the draws that fail it, the walk
+        combine(dim3((unsigned)(nseg - 1), (unsigned)B), 1, elem, nullptr, disc);
+        if (RP <= 16) {
+#define TP_WAVE_CASE(RR) case RR: hipLaunchKernelGGL((tp_boundary_wave_kernel<RR>), dim3((unsigned)B), dim3(64), 0, stream, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)disc, tol); break;
+            switch (RP) { TP_WAVE_CASE(8) TP_WAVE_CASE(16) default: return PIORAN_ERR_UNSUPPORTED; }
+#undef TP_WAVE_CASE
+        } else {
+            const void* fn = rt == 2 ? (const void*)tp_boundary_kernel<4, 2> : (const void*)tp_boundary_kernel<4, 3>;
+            if (lds2 > granted[rt][dev]) {
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return PIORAN_ERR_HIP;
+                granted[rt][dev] = lds2;
+            }
+            if (rt == 2)
+                hipLaunchKernelGGL((tp_boundary_kernel<4, 2>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)disc, tol);
+            else
+                hipLaunchKernelGGL((tp_boundary_kernel<4, 3>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)disc, tol);
+        }
+    } else if (RP == 2)
         hipLaunchKernelGGL((tp_boundary_small_kernel<2>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, nseg, p.J, B, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
     else if (RP == 4)
         hipLaunchKernelGGL((tp_boundary_small_kernel<4>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, nseg, p.J, B, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
     else if (RP <= 16) {
-#define TP_WAVE_CASE(RR) case RR: hipLaunchKernelGGL((tp_boundary_wave_kernel<RR>), dim3((unsigned)B), dim3(64), 0, stream, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd); break;
+#define TP_WAVE_CASE(RR) case RR: hipLaunchKernelGGL((tp_boundary_wave_kernel<RR>), dim3((unsigned)B), dim3(64), 0, stream, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)nullptr, 0.0); break;
         switch (RP) {
             TP_WAVE_CASE(6) TP_WAVE_CASE(8) TP_WAVE_CASE(10) TP_WAVE_CASE(12) TP_WAVE_CASE(14) TP_WAVE_CASE(16)
             default: return PIORAN_ERR_UNSUPPORTED;
@@ -1021,11 +1353,11 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
             granted[rt][dev] = lds2;
         }
         if (rt == 2)
-            hipLaunchKernelGGL((tp_boundary_kernel<4, 2>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
+            hipLaunchKernelGGL((tp_boundary_kernel<4, 2>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)nullptr, 0.0);
         else if (rt == 3)
-            hipLaunchKernelGGL((tp_boundary_kernel<4, 3>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
+            hipLaunchKernelGGL((tp_boundary_kernel<4, 3>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)nullptr, 0.0);
         else
-            hipLaunchKernelGGL((tp_boundary_kernel<4, 4>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
+            hipLaunchKernelGGL((tp_boundary_kernel<4, 4>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)nullptr, 0.0);
     }
     hipLaunchKernelGGL((tp_filter_kernel<NP, NWV>), dim3((unsigned)nseg, (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
                        (const TpRec*)rec, (const TpStep*)stp, (const double*)bnd, part, sval);
@@ -1036,43 +1368,45 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
 }  // namespace
 
 int pioran_tp_supported_rows() { return 64; }     // (lane = state row in the element and filter kernels)
+// state rows (padded) whose boundary phase can run as a scan (tp_combine_kernel: a multiple of 8, up to three tiles of 16)
+int pioran_tp_scan_rows(int RP) { return RP >= 8 && RP <= 48 && RP % 8 == 0; }
 
 // state rows as the kernels want them: a multiple of 2 up to 12 rows (one wavefront per segment), of 8 above (four; at 16 rows four are 9 % ahead of one)
 int pioran_tp_padded_rows(int rows) { return rows <= 12 ? (rows + 1) & ~1 : (rows + 7) & ~7; }
 
 size_t pioran_tp_workspace_doubles(int64_t B, int64_t N, int RP, int nseg)
 {
-    return (size_t)B * N * RP * 6 + (size_t)B * N * 5 + (size_t)B * nseg * (TP_ELEM_DOUBLES + TP_BND_DOUBLES + 4);
+    return (size_t)B * N * RP * 6 + (size_t)B * N * 5 + (size_t)B * nseg * (3 * (size_t)TP_ELEM_DOUBLES + TP_BND_DOUBLES + 4) + (size_t)B;
 }
 
 // RP = pioran_tp_padded_rows(rows) state rows in the layout of row_term / row_kind (device arrays, [RP]; kind 3 = padding); nseg segments of L steps
 // (the last one shorter)
-int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream)
+int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream, int scan)
 {
     if (RP < 2 || RP > 64 || RP != pioran_tp_padded_rows(RP) || nseg < 1 || L < 2 || (int64_t)nseg * L < p.N || (int64_t)(nseg - 1) * L >= p.N || p.B < 1 ||
         p.B > 65535 || p.N > 0x7fffffffLL)
         return PIORAN_ERR_UNSUPPORTED;
     if (RP <= 12) {
         switch (RP / 2) {
-            case 1: return tp_launch<1, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
-            case 2: return tp_launch<2, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
-            case 3: return tp_launch<3, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
-            case 4: return tp_launch<4, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
-            case 5: return tp_launch<5, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
-            case 6: return tp_launch<6, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
-            case 7: return tp_launch<7, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
-            case 8: return tp_launch<8, 1>(p, RP, nseg, L, row_term, row_kind, work, stream);
+            case 1: return tp_launch<1, 1>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+            case 2: return tp_launch<2, 1>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+            case 3: return tp_launch<3, 1>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+            case 4: return tp_launch<4, 1>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+            case 5: return tp_launch<5, 1>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+            case 6: return tp_launch<6, 1>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+            case 7: return tp_launch<7, 1>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+            case 8: return tp_launch<8, 1>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
         }
         return PIORAN_ERR_UNSUPPORTED;
     }
     switch (RP / 8) {
-        case 2: return tp_launch<2, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
-        case 3: return tp_launch<3, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
-        case 4: return tp_launch<4, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
-        case 5: return tp_launch<5, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
-        case 6: return tp_launch<6, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
-        case 7: return tp_launch<7, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
-        case 8: return tp_launch<8, 4>(p, RP, nseg, L, row_term, row_kind, work, stream);
+        case 2: return tp_launch<2, 4>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+        case 3: return tp_launch<3, 4>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+        case 4: return tp_launch<4, 4>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+        case 5: return tp_launch<5, 4>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+        case 6: return tp_launch<6, 4>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+        case 7: return tp_launch<7, 4>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
+        case 8: return tp_launch<8, 4>(p, RP, nseg, L, row_term, row_kind, work, stream, scan);
     }
     return PIORAN_ERR_UNSUPPORTED;
 }

@@ -32,6 +32,8 @@ struct ScanOptions {
     bool no_wide, no_paired, no_mixed, force_fallback, no_block;
     bool force_tp, no_tp;       // celerite_tp.hip (time-parallel evaluation of a handful of draws): force (scan_config "tp") / forbid
     int tp_segments = 0;        // ... its segment count (0 = automatic)
+    int tp_scan = -1;           // ... its boundary phase: 1 the scan over the segments' elements (tp_combine_kernel, round 6), 0 the sequential walk, -1 automatic
+    double tp_scan_tol = 0.0;   // ... the scan's acceptance threshold (largest relative discrepancy of a boundary state; 0 = the default, celerite_tp.hip kTpScanTol)
     bool force_tile, no_tile;   // celerite_tile.hip (windowed form, one draw per wavefront; default from 49 rows on above the small-batch range): force / forbid
     bool no_split;        // never send the remainder of a multi-pass batch to the windowed kernel on the second stream (capi.hip split_dispatch)
     bool win3, no_win3;   // throughput layouts with two / three rows per lane: force / forbid the three-step form (celerite_scan.hip;
@@ -174,7 +176,8 @@ int pioran_tile_grad_supported_rows();
 int pioran_tp_supported_rows();
 int pioran_tp_padded_rows(int rows);
 size_t pioran_tp_workspace_doubles(int64_t B, int64_t N, int RP, int nseg);
-int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream);
+int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream, int scan = 0);
+int pioran_tp_scan_rows(int RP);
 size_t pioran_tile_grad_workspace_doubles(int64_t B, int64_t N, int32_t R);
 int pioran_launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab, double* pairs, double* grad_a, double* grad_b, double* grad_nu,
                             double* grad_mu, double* grad_c, double* grad_d, hipStream_t stream);

@@ -2036,9 +2036,12 @@ def test_time_parallel_dispatch_reference_values_and_flagged_draws(ctx, golden_d
     rng2 = np.random.default_rng(516)
     t8, y8, s8, A8, B8, C8, D8, mu8, nu8 = _random_case(rng2, 5000, 7, 2)      # fourteen state rows: from 6144 steps on
     ds3 = pj.Dataset(t8, y8, s8, ctx)
-    ds3.logl_batch(A8, B8, C8, D8)
-    assert name() != "tp"
-    g6 = ds3.logl_batch(A8[:, :6], B8[:, :6], C8[:6], D8[:6])
+    g14 = ds3.logl_batch(A8, B8, C8, D8)
+    assert name() == "tp"                                           # (up to two draws: the boundary phase as a scan, from 1024 steps on)
+    assert relerr(g14, O.logl_batch(A8, B8, C8, D8, t8, y8, s8, None, None)) < 1e-11
+    ds3.logl_batch(np.tile(A8, (2, 1)), np.tile(B8, (2, 1)), C8, D8)
+    assert name() != "tp"                                           # four draws: the boundary walk, from 6144 steps on
+    g6 = ds3.logl_batch(np.tile(A8[:, :6], (2, 1)), np.tile(B8[:, :6], (2, 1)), C8[:6], D8[:6])[:2]
     assert name() == "tp"                                           # twelve state rows: from 4096
     assert relerr(g6, O.logl_batch(A8[:, :6], B8[:, :6], C8[:6], D8[:6], t8, y8, s8, None, None)) < 1e-11
     # 17 .. 64 state rows: long series only (the boundary solves are R^3 each)
@@ -2081,6 +2084,73 @@ def test_time_parallel_dispatch_reference_values_and_flagged_draws(ctx, golden_d
             dsu.close()
     finally:
         ctx.set_option("scan_config", None)
+    assert worst < 1e-10, worst
+
+
+@pytest.mark.parametrize("J,N,B,nreal,nseg", [(3, 500, 1, 1, 2), (4, 640, 2, 0, 3), (8, 2000, 1, 0, 17), (8, 4096, 2, 0, 128), (12, 3000, 2, 3, 0), (11, 1500, 1, 1, 33),
+                                              (20, 10000, 1, 0, 0), (20, 4096, 2, 0, 256), (24, 3100, 1, 0, 64), (25, 1800, 2, 22, 9), (9, 1111, 4, 0, 16)])
+def test_time_parallel_boundary_scan_vs_walk_and_oracle(ctx, J, N, B, nreal, nseg):
+    """Round 6: the boundary phase as a Kogge-Stone scan over the segments' elements (tp_combine_kernel), 5 .. 48 state rows padded to a multiple of 8,
+    against the boundary walk (tp_scan = 0) and the oracle: segment counts that are not powers of two, 2 segments (one level), the cap of 256, one and
+    two draws, four when forced (tp_scan = 1), one-row terms, padded rows.  With tp_scan_tol tiny every prefix fails the verification launch and
+    the walk runs after the scan: bit-identical to the walk alone."""
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    rng = np.random.default_rng(6600 + J + N)
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    Dd = np.maximum(Dd, 0.05)
+    Bc[:, :nreal] = 0.0; Dd[:nreal] = 0.0
+    ds = pj.Dataset(t, y, s2, ctx)
+    ref = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, nthreads=8)
+    try:
+        ctx.set_option("scan_config", "tp"); ctx.set_option("tp_segments", nseg)
+        ctx.set_option("tp_scan", 1)
+        scan, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+        assert name() == "tp"
+        ctx.set_option("tp_scan", 0)
+        walk = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        ctx.set_option("tp_scan", 1); ctx.set_option("tp_scan_tol", 1e-300)
+        both = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+    finally:
+        ctx.set_option("scan_config", None); ctx.set_option("tp_segments", 0); ctx.set_option("tp_scan", -1); ctx.set_option("tp_scan_tol", 0)
+    assert (st == 0).all()
+    assert relerr(scan, ref) < 1e-11 and relerr(walk, ref) < 1e-11 and relerr(scan, walk) < 1e-11
+    rows = 2 * J - nreal
+    if 0 < nseg <= 128 and (rows + 7) & ~7 == ((rows + 1) & ~1 if rows <= 12 else (rows + 7) & ~7):
+        assert np.array_equal(both, walk)                  # (same segments, same padded layout: the walk after a failed verification is the walk)
+    else:
+        assert relerr(both, walk) < 1e-12
+
+
+def test_time_parallel_scan_flagged_draw_and_ill_conditioned_reference_points(ctx, golden_dir):
+    """(i) A draw that is not positive definite next to one that is, through the scan: status and value semantics of the other families.
+    (ii) Stored reference values at N = 242 (SHO-20, 40 rows) through the scan at 8 segments: 1e-10 against Julia's numbers."""
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    rng = np.random.default_rng(6715)
+    N, J, B = 3000, 6, 2
+    t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+    A[1, 0] = -40.0
+    ds = pj.Dataset(t, y, s2, ctx)
+    gb, sb = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
+    assert name() == "tp"
+    rb, rs = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu, nu, return_status=True)
+    assert sb[1] != 0 and rs[1] != 0 and sb[0] == 0
+    assert abs(gb[0] - rb[0]) <= 1e-11 * abs(rb[0])
+    assert (np.isnan(gb[1]) and np.isnan(rb[1])) or abs(gb[1] - rb[1]) <= 1e-6 * abs(rb[1])
+    un = np.load(golden_dir / "ultranest_points.npz")
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_oracle import _un_inputs
+    try:
+        ctx.set_option("scan_config", "tp"); ctx.set_option("tp_scan", 1); ctx.set_option("tp_segments", 8)
+        worst = 0.0
+        for i in np.linspace(0, len(un["logl"]) - 1, 40).astype(int):
+            a, b, c, d, tt, yy, ss = _un_inputs(un, i)
+            dsu = pj.Dataset(tt, yy, ss, ctx)
+            g = dsu.logl_batch(a[None, :], b[None, :], c, d)[0]
+            assert name() == "tp"
+            worst = max(worst, abs(g - un["logl"][i]) / abs(un["logl"][i]))
+            dsu.close()
+    finally:
+        ctx.set_option("scan_config", None); ctx.set_option("tp_scan", -1); ctx.set_option("tp_segments", 0)
     assert worst < 1e-10, worst
 
 
