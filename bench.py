@@ -683,8 +683,9 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
     out["single_evaluation_B1"] = single
     out["single_evaluation_B1"]["kernel"] = ("resident_launch_ms: what the automatic choice takes for one resident draw; scalar_entry_kernel names it for the "
                                              "scalar entry — 'block': celerite_block_kernel (windowed form, 16 steps per window on the fp64 matrix cores, a "
-                                             "serial chain of windows; celerite_block.hip), 'tp': the time-parallel family (celerite_tp.hip, round 5: "
-                                             "segments of the series on different CUs; up to 48 state rows on series that are long enough for their rows)")
+                                             "serial chain of windows; celerite_block.hip), 'tp': the time-parallel family (celerite_tp.hip: segments of the "
+                                             "series on different CUs, boundary phase as a log-depth scan over the segments' elements since round 6; up to 64 "
+                                             "state rows on series that are long enough for their rows)")
     # -- one evaluation of a LONG series (the reference grid goes to N = 65536, benchmark/benchmarks.jl:16-18): the time-parallel family (celerite_tp.hip,
     #    round 5) against the serial-chain kernel it replaces there ("no_tp"), scalar entry, PCIe included -------------------------------------------
     longs = {}

@@ -397,13 +397,13 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
         if (s->real_host[j]) { term.push_back(j); kind.push_back(2); }
     if ((int)term.size() > pioran_tp_supported_rows() || p.N < 64) return PIORAN_ERR_UNSUPPORTED;
     // The boundary phase as a scan over the segments' elements (tp_combine_kernel, round 6: ceil(log2 nseg) launches of one workgroup per (draw, target)
-    // instead of nseg - 1 dependent boundary steps) — up to two draws (nseg targets per draw and level want a CU each), 5 .. 48 state rows (padded to
+    // instead of nseg - 1 dependent boundary steps) — up to two draws (nseg targets per draw and level want a CU each), 5 .. 64 state rows (padded to
     // a multiple of 8 for it) — moves every crossover (tools/tp_scan_sweep.py, profiles/r06_time_parallel_scan.txt; one scalar call, PCIe included):
     // 8 / 16 rows from 1024 steps on (N = 1024: 0.146 / 0.172 against 0.159 / 0.211 ms on the serial chain; N = 8192: 0.23 / 0.27 against 1.08 / 1.50),
     // 24 rows from 1536 (0.254 against 0.306), 32 from 2048 (0.32 against 0.42), 40 / 48 from 3072 (0.50 / 0.58 against 0.60 / 0.76; N = 1e4:
     // 0.64 / 0.76 against 1.87 / 2.40; N = 65536: 1.19 / 1.35 against 12.0 / 16.4).
     const int nrows = (int)term.size();
-    const bool scan_rows = nrows > 4 && nrows <= 48;
+    const bool scan_rows = nrows > 4 && nrows <= 64;
     const bool scan = o.tp_scan != 0 && scan_rows && (o.tp_scan > 0 || p.B <= 2);
     const int RP = scan ? (nrows + 7) & ~7 : pioran_tp_padded_rows(nrows);
     // measured (tools/ab_tp.py sweep, profiles/r05_time_parallel_gpu.txt): with up to 8 draws it beats the serial-chain kernels from 1024 steps on at
@@ -424,7 +424,9 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
         const int64_t nmin12 = RP <= 24 ? 4096 : (RP <= 32 ? 5120 : (RP <= 40 ? 8192 : (RP <= 48 ? 6144 : nwide)));
         const int64_t nmin8 = RP <= 24 ? 5120 : (RP <= 32 ? 6144 : (RP <= 40 ? 8192 : (RP <= 48 ? 8192 : nwide)));
         const bool many = RP > 16 && ((p.B <= 2 && p.N >= nmin12) || (p.B <= 8 && p.N >= nmin8));
-        const bool scanned = scan && p.N >= (RP <= 16 ? 1024 : (RP <= 24 ? 1536 : (RP <= 32 ? 2048 : 3072)));
+        // (49 .. 64 rows, tp_combine_lean_kernel: 56 / 60 rows from 4096 steps on — 0.89 / 1.02 against 1.03 / 1.08 ms; N = 1e4: 1.10 / 1.21 against 2.46 / 2.58;
+        //  64 rows, five block columns on the serial chain, from 2048 — 0.89 against 0.98; N = 1e4: 1.21 against 4.6)
+        const bool scanned = scan && p.N >= (RP <= 16 ? 1024 : (RP <= 24 ? 1536 : (RP <= 32 ? 2048 : (RP <= 48 ? 3072 : (p.R + 1 > 64 ? 2048 : 4096)))));
         if (!few && !mid && !many && !scanned) return PIORAN_ERR_UNSUPPORTED;
     }
     while ((int)term.size() < RP) { term.push_back(0); kind.push_back(3); }
@@ -683,6 +685,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
         if (value && !o.force_tile && !o.force_tp) std::strcpy(o.scan_config, value);
     } else if (!std::strcmp(key, "no_tp")) o.no_tp = on; else if (!std::strcmp(key, "tp_segments")) o.tp_segments = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan")) o.tp_scan = (value && value[0]) ? std::atoi(value) : -1;
+    else if (!std::strcmp(key, "tp_scan_lean")) o.tp_scan_lean = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan_tol")) o.tp_scan_tol = (value && value[0]) ? std::atof(value) : 0.0;
     else if (!std::strcmp(key, "no_tile")) o.no_tile = on; else if (!std::strcmp(key, "no_wide")) o.no_wide = on;
     else if (!std::strcmp(key, "no_paired")) o.no_paired = on;

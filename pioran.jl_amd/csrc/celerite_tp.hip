@@ -1008,6 +1008,262 @@ __global__ void __launch_bounds__(256) tp_combine_kernel(int RP, int nseg, int J
     }
 }
 
+// The same combination for up to FOUR tiles of 16 rows (49 .. 64 state rows: DRWCelerite-20 is 60), where tp_combine_kernel's five matrices do not fit
+// 160 KB of LDS.  Only the right-hand-side block X and one matrix stay in LDS (142 KB at 64 rows); A_j, J_j, C_j, A_i come from the elements in global
+// memory straight into the matrix-core operands (32 KB each, L2-resident: they were written by the launch before), Z and M A_i stay where the elimination
+// left them — row l of X holds row mycol(l) of the solution — and are read through the inverse permutation `rowof`.  J_j is read as its transpose (it is
+// symmetric up to rounding) so that the lanes of a load run along a row.  Same three modes (prior / complete prefix / incomplete element) and the same
+// verification mode as tp_combine_kernel; tests hold the two against each other at 16 .. 48 rows (option tp_scan_lean).
+template <int RT>
+__global__ void __launch_bounds__(256) tp_combine_lean_kernel(int RP, int nseg, int J, int stride, const int32_t* __restrict__ row_term,
+                                                              const int32_t* __restrict__ row_kind, const double* __restrict__ A_, const double* __restrict__ Bc_,
+                                                              const double* __restrict__ ein, double* __restrict__ eout, double* __restrict__ bnd,
+                                                              double* __restrict__ disc)
+{
+    extern __shared__ double lds[];
+    constexpr int TW = 4, R16 = 16 * RT, S1 = R16 + 1, LW = 3 * R16 + 3, T = 256;
+    double* X = lds;                     // [R16][LW]: [W, later A_j Z, later J (unsymmetrised) | z (1) | C_i -> Z (RP), later C (unsymmetrised) | A_i -> M A_i (RP)]
+    double* Pm = X + R16 * LW;           // [R16][S1]: J_j (M A_i)
+    double* mv = Pm + R16 * S1;          // [64] b_i, later z
+    double* ev = mv + 64;                // eta_j
+    double* bl = ev + 64;                // b_j
+    double* bi = bl + 64;                // b_i (kept)
+    double* vv = bi + 64;                // v = eta_j - J_j b_i
+    double* zz = vv + 64;                // Z v
+    double* w2 = zz + 64;                // v - J_j Z v
+    int* rowof = reinterpret_cast<int*>(w2 + 64);   // [64] the row of X that holds row k of the solution
+    double* fneg = w2 + 64 + 32;         // [TW][4][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b = blockIdx.y;
+    const int p = (int)blockIdx.x + stride, i = p - stride;
+    const bool prior = i == 0, full = !disc && i >= stride;  // the left operand: the prior | a complete prefix (in bnd) | an incomplete element (in ein: "full" combination)
+    const double* ej = ein + (b * nseg + (p - 1)) * TP_ELEM_DOUBLES;
+    const double* ei_ = ein + (b * nseg + (i > 0 ? i - 1 : 0)) * TP_ELEM_DOUBLES;
+    double* bs = bnd + b * nseg * TP_BND_DOUBLES;
+    const double* bsi = bs + (int64_t)i * TP_BND_DOUBLES;
+    const int NC = full ? 3 * RP + 1 : 2 * RP + 1;          // live columns of [W | z | Z (| M A_i)]
+    const int ZC = RP + 1, MC = 2 * RP + 1;                  // first column of Z / of M A_i in X
+    for (int q = tid; q < R16 * LW + R16 * S1 + 7 * 64 + 32; q += T) lds[q] = 0.0;
+    const int li = lane & 15, lk = lane >> 4;
+    // one 16 x 16 tile of a product per wavefront and round; operands through aop(row, k) / bop(k, col), which return 0 outside RP themselves
+    auto gemm = [&](auto aop, auto bop, auto store) __attribute__((always_inline)) {
+        for (int tI = w; tI < RT * RT; tI += TW) {
+            const int I = tI / RT, Jt = tI - I * RT;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            double av[RT][4], bv[RT][4];
+#pragma unroll
+            for (int k4 = 0; k4 < RT; ++k4)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    av[k4][q4] = aop(16 * I + li, 16 * k4 + 4 * q4 + lk);
+                    bv[k4][q4] = bop(16 * k4 + 4 * q4 + lk, 16 * Jt + li);
+                }
+#pragma unroll
+            for (int k4 = 0; k4 < RT; ++k4)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k4][q4], bv[k4][q4], acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = 16 * I + 4 * g + lk, c = 16 * Jt + li;
+                if (r < RP && c < RP) store(r, c, acc[g]);
+            }
+        }
+    };
+    auto in = [&](int r, int c) { return r < RP && c < RP; };
+    TP_BARRIER();
+    // ---- operands: C_i into the Z block, A_i into the last block ------------------------------------------------------------------------------------
+    for (int q = tid; q < RP * RP; q += T) {
+        const int r = q / RP, c = q % RP;
+        double v;
+        if (prior) {                                         // P_inf (tp_boundary_kernel's prior)
+            v = 0.0;
+            const int kr = row_kind[r], kc = row_kind[c];
+            if (kr != 3 && kc != 3) {
+                if (r == c) v = A_[b * J + row_term[r]];
+                else if ((r ^ 1) == c && kr < 2 && kc < 2) v = -Bc_[b * J + row_term[r]];
+            }
+            if (p == 1 && !disc) bs[64 + r * 64 + c] = v;    // (level 0: the prior's boundary state, which the filter of segment 0 starts from)
+        } else {
+            v = full ? ei_[4096 + r * 64 + c] : bsi[64 + r * 64 + c];
+        }
+        X[r * LW + ZC + c] = v;
+        if (full) X[r * LW + MC + c] = ei_[c * 64 + r];      // A_i[r][c] (stored transposed)
+    }
+    if (tid < RP) {
+        const double m0 = prior ? 0.0 : (full ? ei_[12288 + tid] : bsi[tid]);
+        mv[tid] = m0; bi[tid] = m0;
+        ev[tid] = ej[12288 + 64 + tid];
+        bl[tid] = ej[12288 + tid];
+        if (prior && p == 1 && !disc) bs[tid] = 0.0;
+    }
+    TP_BARRIER();
+    // ---- W = I + C_i J_j, z = b_i + C_i eta_j ------------------------------------------------------------------------------------------------------
+    gemm([&](int r, int kk) { return in(r, kk) ? X[r * LW + ZC + kk] : 0.0; }, [&](int kk, int c) { return in(kk, c) ? ej[8192 + kk * 64 + c] : 0.0; },
+         [&](int r, int c, double v) { X[r * LW + c] = v + (r == c ? 1.0 : 0.0); });
+    if (tid < RP) {
+        double acc = mv[tid];
+#pragma unroll 8
+        for (int k = 0; k < RP; ++k) acc = fma(X[tid * LW + ZC + k], ev[k], acc);
+        X[tid * LW + RP] = acc;
+    }
+    TP_BARRIER();
+    // ---- Gauss-Jordan elimination, four pivots per barrier (tp_boundary_kernel) ------------------------------------------------------------------
+    bool used = lane >= RP;
+    int mycol = 0;
+    double mypiv = 1.0;
+    const int lr = lane < RP ? lane : 0;
+    for (int k0 = 0; k0 < RP; k0 += 4) {
+        double xp[4], f[4];
+        int pr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xp[j] = X[lr * LW + k0 + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned cand = used ? 0u : ((unsigned)__double2hiint(xp[j]) & 0x7fffffffu) + 1u;
+            const unsigned mx = tp_max_u32(cand);
+            const unsigned long long bal = __ballot(cand == mx);
+            pr[j] = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(bal));
+            const double ipv = tp_rcp(tp_readlane(xp[j], pr[j]));
+            f[j] = (lane == pr[j] || lane >= RP) ? 0.0 : xp[j] * ipv;
+            if (lane == pr[j]) { used = true; mycol = k0 + j; mypiv = ipv; }
+#pragma unroll
+            for (int jj = j + 1; jj < 4; ++jj) xp[jj] = fma(-f[j], tp_readlane(xp[jj], pr[j]), xp[jj]);
+        }
+        const double f01 = tp_readlane(f[0], pr[1]), f02 = tp_readlane(f[0], pr[2]), f03 = tp_readlane(f[0], pr[3]);
+        const double f12 = tp_readlane(f[1], pr[2]), f13 = tp_readlane(f[1], pr[3]), f23 = tp_readlane(f[2], pr[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fneg[(w * 4 + j) * 64 + lane] = -f[j];
+        for (int ct = w; k0 + 4 + 16 * ct < NC; ct += TW) {
+            const int c0 = k0 + 4 + 16 * ct, col = c0 + li, cc = col < NC ? col : NC - 1;
+            const double x0 = X[pr[0] * LW + cc], x1 = X[pr[1] * LW + cc], x2 = X[pr[2] * LW + cc], x3 = X[pr[3] * LW + cc];
+            const double u0 = x0, u1 = fma(-f01, u0, x1), u2 = fma(-f12, u1, fma(-f02, u0, x2)), u3 = fma(-f23, u2, fma(-f13, u1, fma(-f03, u0, x3)));
+            const double ub = lk == 0 ? u0 : (lk == 1 ? u1 : (lk == 2 ? u2 : u3));
+            f64x4 acc[RT];
+            double fa[RT];
+#pragma unroll
+            for (int It = 0; It < RT; ++It) {
+                fa[It] = fneg[(w * 4 + lk) * 64 + 16 * It + li];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[It][g] = X[(16 * It + 4 * g + lk) * LW + cc];
+            }
+#pragma unroll
+            for (int It = 0; It < RT; ++It) {
+                acc[It] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[It], ub, acc[It], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (col < NC && 16 * It + 4 * g + lk < RP) X[(16 * It + 4 * g + lk) * LW + col] = acc[It][g];
+            }
+        }
+        TP_BARRIER();
+    }
+    // row `lane` solved column mycol: scaled in place, found again through rowof; z into mv
+    if (lane < RP) {
+        for (int c = w; c < NC - RP; c += TW) X[lane * LW + RP + c] *= mypiv;
+        if (w == 0) rowof[mycol] = lane;
+    }
+    TP_BARRIER();
+    if (tid < RP) mv[tid] = X[rowof[tid] * LW + RP];
+    auto Zs = [&](int kk, int c) { return in(kk, c) ? X[rowof[kk] * LW + ZC + c] : 0.0; };        // Z = M C_i
+    auto MA = [&](int kk, int c) { return in(kk, c) ? X[rowof[kk] * LW + MC + c] : 0.0; };        // M A_i
+    TP_BARRIER();
+    // ---- vectors: b = A_j z + b_j;  v = eta_j - J_j b_i, Z v, v - J_j Z v (full combination) ---------------------------------------------------------
+    double mnew = 0.0;
+    if (tid < RP) {
+        double acc = bl[tid];
+#pragma unroll 8
+        for (int k = 0; k < RP; ++k) acc = fma(ej[k * 64 + tid], mv[k], acc);
+        mnew = acc;
+        if (full) {
+            double a2 = ev[tid];
+#pragma unroll 8
+            for (int k = 0; k < RP; ++k) a2 = fma(-ej[8192 + k * 64 + tid], bi[k], a2);
+            vv[tid] = a2;
+        }
+    }
+    // T = A_j Z (into X, columns 0 .. RP-1; W is dead)
+    gemm([&](int r, int kk) { return in(r, kk) ? ej[kk * 64 + r] : 0.0; }, Zs, [&](int r, int c, double v) { X[r * LW + c] = v; });
+    if (full) {
+        // J_j (M A_i) into Pm;  A = A_j (M A_i), stored transposed, straight to the output
+        gemm([&](int r, int kk) { return in(r, kk) ? ej[8192 + kk * 64 + r] : 0.0; }, MA, [&](int r, int c, double v) { Pm[r * S1 + c] = v; });
+        double* eo = eout + (b * nseg + (p - 1)) * TP_ELEM_DOUBLES;
+        gemm([&](int k, int s_) { return MA(s_, k); }, [&](int s_, int r) { return in(s_, r) ? ej[s_ * 64 + r] : 0.0; },
+             [&](int k, int r, double v) { eo[k * 64 + r] = v; });
+    }
+    TP_BARRIER();
+    if (full && tid < RP) {
+        double a2 = 0.0;
+        const int ro = rowof[tid];
+#pragma unroll 8
+        for (int k = 0; k < RP; ++k) a2 = fma(X[ro * LW + ZC + k], vv[k], a2);
+        zz[tid] = a2;
+    }
+    TP_BARRIER();
+    if (full && tid < RP) {
+        double a2 = vv[tid];
+#pragma unroll 8
+        for (int k = 0; k < RP; ++k) a2 = fma(-ej[8192 + k * 64 + tid], zz[k], a2);
+        w2[tid] = a2;
+    }
+    // C = T A_j' + C_j (Z is dead — every wavefront is past its last read of it: into its block), symmetrised on the way out
+    gemm([&](int r, int kk) { return in(r, kk) ? X[r * LW + kk] : 0.0; }, [&](int kk, int c) { return in(kk, c) ? ej[kk * 64 + c] : 0.0; },
+         [&](int r, int c, double v) { X[r * LW + ZC + c] = v; });
+    TP_BARRIER();
+    if (disc) {
+        // verify: |scan - step| over the state, relative to the state's largest entries
+        double* bo = bs + (int64_t)p * TP_BND_DOUBLES;
+        double dP = 0.0, sP = 0.0, dm = 0.0, sm = 0.0;
+        for (int q = tid; q < RP * RP; q += T) {
+            const int r = q / RP, c = q % RP;
+            const double v = 0.5 * (X[r * LW + ZC + c] + X[c * LW + ZC + r]) + ej[4096 + r * 64 + c], o = bo[64 + r * 64 + c];
+            dP = fmax(dP, fabs(v - o)); sP = fmax(sP, fabs(o));
+        }
+        if (tid < RP) { const double o = bo[tid]; dm = fabs(mnew - o); sm = fabs(o); }
+        dP = tp_max(dP); sP = tp_max(sP); dm = tp_max(dm); sm = tp_max(sm);
+        if (lane == 0) { fneg[w] = dP; fneg[4 + w] = sP; fneg[8 + w] = dm; fneg[12 + w] = sm; }
+        TP_BARRIER();
+        if (tid == 0) {
+            const double DP = fmax(fmax(fneg[0], fneg[1]), fmax(fneg[2], fneg[3])), SP = fmax(fmax(fneg[4], fneg[5]), fmax(fneg[6], fneg[7]));
+            const double DM = fmax(fmax(fneg[8], fneg[9]), fmax(fneg[10], fneg[11])), SM = fmax(fmax(fneg[12], fneg[13]), fmax(fneg[14], fneg[15]));
+            double rel = DP / (SP > 0.0 ? SP : 1.0);
+            const double mscale = fmax(SM, sqrt(SP));
+            rel = fmax(rel, DM / (mscale > 0.0 ? mscale : 1.0));
+            if (!(rel >= 0.0)) rel = 1.0;                    // (NaN: see tp_combine_kernel)
+            atomicMax(reinterpret_cast<unsigned long long*>(disc + b), (unsigned long long)__double_as_longlong(rel));
+        }
+        return;
+    }
+    {
+        double* eo = eout + (b * nseg + (p - 1)) * TP_ELEM_DOUBLES;
+        double* bo = bs + (int64_t)p * TP_BND_DOUBLES;
+        for (int q = tid; q < RP * RP; q += T) {
+            const int r = q / RP, c = q % RP;
+            const double v = 0.5 * (X[r * LW + ZC + c] + X[c * LW + ZC + r]) + ej[4096 + r * 64 + c];
+            if (full) eo[4096 + r * 64 + c] = v; else bo[64 + r * 64 + c] = v;
+        }
+        if (tid < RP) { if (full) eo[12288 + tid] = mnew; else bo[tid] = mnew; }
+    }
+    if (!full) return;                                       // (workgroup-uniform)
+    // ---- J = A_i' (J_j M A_i) + J_i, eta = A_i' (v - J_j Z v) + eta_i  (T is dead since the barrier above: into its block) ------------------------------
+    gemm([&](int r, int kk) { return in(r, kk) ? ei_[r * 64 + kk] : 0.0; }, [&](int kk, int c) { return in(kk, c) ? Pm[kk * S1 + c] : 0.0; },
+         [&](int r, int c, double v) { X[r * LW + c] = v; });
+    double enew = 0.0;
+    if (tid < RP) {
+        double a2 = ei_[12288 + 64 + tid];
+#pragma unroll 8
+        for (int k = 0; k < RP; ++k) a2 = fma(ei_[tid * 64 + k], w2[k], a2);
+        enew = a2;
+    }
+    TP_BARRIER();
+    {
+        double* eo = eout + (b * nseg + (p - 1)) * TP_ELEM_DOUBLES;
+        for (int q = tid; q < RP * RP; q += T) {
+            const int r = q / RP, c = q % RP;
+            eo[8192 + r * 64 + c] = 0.5 * (X[r * LW + c] + X[c * LW + r]) + ei_[8192 + r * 64 + c];
+        }
+        if (tid < RP) eo[12288 + 64 + tid] = enew;
+    }
+}
+
 // The same for two or four state rows (the reference benchmark grid's j = 2: benchmark/benchmarks.jl:16-18), ONE THREAD per draw, everything in
 // registers, fully unrolled; partial pivoting by conditional row exchanges.  A boundary is ~550 dependent-chain-free instructions (1.3 us) where the
 // workgroup kernel spends 4.2 us in LDS round trips.
@@ -1295,19 +1551,28 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
     if (scan && nseg >= 2 && pioran_tp_scan_rows(RP)) {
         // phase 2 as a scan: ceil(log2 nseg) launches of tp_combine_kernel, one workgroup per (draw, target)
         const int rt = (RP + 15) / 16;
-        const size_t r16s = (size_t)rt * 16, ldsc = (r16s * (3 * r16s + 3) + 4 * r16s * (r16s + 1) + 7 * 64 + 1024) * sizeof(double);
-        const void* fnc = rt == 1 ? (const void*)tp_combine_kernel<1> : (rt == 2 ? (const void*)tp_combine_kernel<2> : (const void*)tp_combine_kernel<3>);
-        static size_t granted_c[4][64] = {};
-        if (ldsc > granted_c[rt][dev]) {
+        const bool lean = rt == 4 || (p.opt && p.opt->tp_scan_lean);          // (four tiles of rows: only the lean form fits the LDS)
+        const size_t r16s = (size_t)rt * 16;
+        const size_t ldsc = lean ? (r16s * (3 * r16s + 3) + r16s * (r16s + 1) + 7 * 64 + 32 + 1024) * sizeof(double)
+                                 : (r16s * (3 * r16s + 3) + 4 * r16s * (r16s + 1) + 7 * 64 + 1024) * sizeof(double);
+        const void* fnc = lean ? (rt == 1 ? (const void*)tp_combine_lean_kernel<1> : (rt == 2 ? (const void*)tp_combine_lean_kernel<2> : (rt == 3 ? (const void*)tp_combine_lean_kernel<3> : (const void*)tp_combine_lean_kernel<4>)))
+                               : (rt == 1 ? (const void*)tp_combine_kernel<1> : (rt == 2 ? (const void*)tp_combine_kernel<2> : (const void*)tp_combine_kernel<3>));
+        static size_t granted_c[2][5][64] = {};
+        if (ldsc > granted_c[lean ? 1 : 0][rt][dev]) {
             if (hipFuncSetAttribute(fnc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc) != hipSuccess) return PIORAN_ERR_HIP;
-            granted_c[rt][dev] = ldsc;
+            granted_c[lean ? 1 : 0][rt][dev] = ldsc;
         }
         const double tol = p.opt && p.opt->tp_scan_tol > 0.0 ? p.opt->tp_scan_tol : kTpScanTol;
         if (hipMemsetAsync(disc, 0, (size_t)B * sizeof(double), stream) != hipSuccess) return PIORAN_ERR_HIP;
         auto combine = [&](const dim3& gr, int stride, const double* src, double* dst, double* dsc) {
-            if (rt == 1) hipLaunchKernelGGL((tp_combine_kernel<1>), gr, dim3(256), ldsc, stream, RP, nseg, p.J, stride, row_term, row_kind, p.A, p.Bc, src, dst, bnd, dsc);
-            else if (rt == 2) hipLaunchKernelGGL((tp_combine_kernel<2>), gr, dim3(256), ldsc, stream, RP, nseg, p.J, stride, row_term, row_kind, p.A, p.Bc, src, dst, bnd, dsc);
-            else hipLaunchKernelGGL((tp_combine_kernel<3>), gr, dim3(256), ldsc, stream, RP, nseg, p.J, stride, row_term, row_kind, p.A, p.Bc, src, dst, bnd, dsc);
+#define TP_COMBINE(KERNEL, RR) hipLaunchKernelGGL((KERNEL<RR>), gr, dim3(256), ldsc, stream, RP, nseg, p.J, stride, row_term, row_kind, p.A, p.Bc, src, dst, bnd, dsc)
+            if (lean) {
+                if (rt == 1) TP_COMBINE(tp_combine_lean_kernel, 1); else if (rt == 2) TP_COMBINE(tp_combine_lean_kernel, 2);
+                else if (rt == 3) TP_COMBINE(tp_combine_lean_kernel, 3); else TP_COMBINE(tp_combine_lean_kernel, 4);
+            } else {
+                if (rt == 1) TP_COMBINE(tp_combine_kernel, 1); else if (rt == 2) TP_COMBINE(tp_combine_kernel, 2); else TP_COMBINE(tp_combine_kernel, 3);
+            }
+#undef TP_COMBINE
         };
         const double* src = elem;
         double* dst = elem2;
@@ -1323,15 +1588,17 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
             switch (RP) { TP_WAVE_CASE(8) TP_WAVE_CASE(16) default: return PIORAN_ERR_UNSUPPORTED; }
 #undef TP_WAVE_CASE
         } else {
-            const void* fn = rt == 2 ? (const void*)tp_boundary_kernel<4, 2> : (const void*)tp_boundary_kernel<4, 3>;
+            const void* fn = rt == 2 ? (const void*)tp_boundary_kernel<4, 2> : (rt == 3 ? (const void*)tp_boundary_kernel<4, 3> : (const void*)tp_boundary_kernel<4, 4>);
             if (lds2 > granted[rt][dev]) {
                 if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return PIORAN_ERR_HIP;
                 granted[rt][dev] = lds2;
             }
             if (rt == 2)
                 hipLaunchKernelGGL((tp_boundary_kernel<4, 2>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)disc, tol);
-            else
+            else if (rt == 3)
                 hipLaunchKernelGGL((tp_boundary_kernel<4, 3>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)disc, tol);
+            else
+                hipLaunchKernelGGL((tp_boundary_kernel<4, 4>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)disc, tol);
         }
     } else if (RP == 2)
         hipLaunchKernelGGL((tp_boundary_small_kernel<2>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, nseg, p.J, B, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd);
@@ -1368,8 +1635,8 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
 }  // namespace
 
 int pioran_tp_supported_rows() { return 64; }     // (lane = state row in the element and filter kernels)
-// state rows (padded) whose boundary phase can run as a scan (tp_combine_kernel: a multiple of 8, up to three tiles of 16)
-int pioran_tp_scan_rows(int RP) { return RP >= 8 && RP <= 48 && RP % 8 == 0; }
+// state rows (padded) whose boundary phase can run as a scan (tp_combine_kernel up to three tiles of 16 rows, tp_combine_lean_kernel at four: a multiple of 8)
+int pioran_tp_scan_rows(int RP) { return RP >= 8 && RP <= 64 && RP % 8 == 0; }
 
 // state rows as the kernels want them: a multiple of 2 up to 12 rows (one wavefront per segment), of 8 above (four; at 16 rows four are 9 % ahead of one)
 int pioran_tp_padded_rows(int rows) { return rows <= 12 ? (rows + 1) & ~1 : (rows + 7) & ~7; }

@@ -2088,12 +2088,14 @@ def test_time_parallel_dispatch_reference_values_and_flagged_draws(ctx, golden_d
 
 
 @pytest.mark.parametrize("J,N,B,nreal,nseg", [(3, 500, 1, 1, 2), (4, 640, 2, 0, 3), (8, 2000, 1, 0, 17), (8, 4096, 2, 0, 128), (12, 3000, 2, 3, 0), (11, 1500, 1, 1, 33),
-                                              (20, 10000, 1, 0, 0), (20, 4096, 2, 0, 256), (24, 3100, 1, 0, 64), (25, 1800, 2, 22, 9), (9, 1111, 4, 0, 16)])
+                                              (20, 10000, 1, 0, 0), (20, 4096, 2, 0, 256), (24, 3100, 1, 0, 64), (25, 1800, 2, 22, 9), (9, 1111, 4, 0, 16),
+                                              (28, 900, 1, 0, 5), (30, 1500, 2, 0, 33), (32, 4200, 1, 0, 0), (40, 2000, 1, 20, 64), (36, 700, 2, 9, 2)])
 def test_time_parallel_boundary_scan_vs_walk_and_oracle(ctx, J, N, B, nreal, nseg):
     """Round 6: the boundary phase as a Kogge-Stone scan over the segments' elements (tp_combine_kernel), 5 .. 48 state rows padded to a multiple of 8,
     against the boundary walk (tp_scan = 0) and the oracle: segment counts that are not powers of two, 2 segments (one level), the cap of 256, one and
-    two draws, four when forced (tp_scan = 1), one-row terms, padded rows.  With tp_scan_tol tiny every prefix fails the verification launch and
-    the walk runs after the scan: bit-identical to the walk alone."""
+    two draws, four when forced (tp_scan = 1), one-row terms, padded rows; 49 .. 64 rows (DRWCelerite-20 is 60) on tp_combine_lean_kernel (operands from global
+    memory: the form that fits the LDS there), which tp_scan_lean = 1 also puts under the smaller shapes.  With tp_scan_tol tiny every prefix fails
+    the verification launch and the walk runs after the scan: bit-identical to the walk alone."""
     name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
     rng = np.random.default_rng(6600 + J + N)
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
@@ -2106,14 +2108,17 @@ def test_time_parallel_boundary_scan_vs_walk_and_oracle(ctx, J, N, B, nreal, nse
         ctx.set_option("tp_scan", 1)
         scan, st = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, return_status=True)
         assert name() == "tp"
+        ctx.set_option("tp_scan_lean", 1)
+        lean = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        ctx.set_option("tp_scan_lean", 0)
         ctx.set_option("tp_scan", 0)
         walk = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
         ctx.set_option("tp_scan", 1); ctx.set_option("tp_scan_tol", 1e-300)
         both = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
     finally:
-        ctx.set_option("scan_config", None); ctx.set_option("tp_segments", 0); ctx.set_option("tp_scan", -1); ctx.set_option("tp_scan_tol", 0)
+        ctx.set_option("scan_config", None); ctx.set_option("tp_segments", 0); ctx.set_option("tp_scan", -1); ctx.set_option("tp_scan_tol", 0); ctx.set_option("tp_scan_lean", 0)
     assert (st == 0).all()
-    assert relerr(scan, ref) < 1e-11 and relerr(walk, ref) < 1e-11 and relerr(scan, walk) < 1e-11
+    assert relerr(scan, ref) < 1e-11 and relerr(walk, ref) < 1e-11 and relerr(scan, walk) < 1e-11 and relerr(lean, scan) < 1e-12
     rows = 2 * J - nreal
     if 0 < nseg <= 128 and (rows + 7) & ~7 == ((rows + 1) & ~1 if rows <= 12 else (rows + 7) & ~7):
         assert np.array_equal(both, walk)                  # (same segments, same padded layout: the walk after a failed verification is the walk)

@@ -14,11 +14,12 @@ def timed(f):
     for _ in range(7):
         t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
     return min(ts) * 1e3
-for N in (512, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 10000, 16384, 65536):
+for N in (512, 1024, 1536, 2048, 3072, 4096, 5120, 6144, 8192, 10000, 16384, 65536):
     t, y, yerr = bench.synth_series(N)
     th, f_min, f_max = bench.synth_theta(4, t, y, seed=99)
     line = f"N={N}:"
-    for basis, nc in (("SHO", 4), ("SHO", 8), ("SHO", 12), ("SHO", 16), ("SHO", 20), ("SHO", 24)):
+    wide = len(sys.argv) > 1 and sys.argv[1] == "wide"          # 49 .. 64 state rows (tp_combine_lean_kernel)
+    for basis, nc in ((("SHO", 28), ("DRWCelerite", 20), ("SHO", 32)) if wide else (("SHO", 4), ("SHO", 8), ("SHO", 12), ("SHO", 16), ("SHO", 20), ("SHO", 24))):
         A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, th[:, :3], f_min, f_max, nc, th[:, 3], basis_function=basis)
         a, b, mu, nu = A[1], Bc[1], th[1, 5], th[1, 4]
         f = lambda: ctx.logl(a, b, C, Dd, t, y - mu, nu * yerr ** 2)
@@ -31,5 +32,5 @@ for N in (512, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 10000, 16384, 65536):
         except Exception: wk = float("nan")
         ctx.set_option("scan_config", None); ctx.set_option("tp_scan", -1)
         auto = timed(f); ka = name()
-        line += f"  {2 * nc}r: {ks} {ser:.3f} | scan {sc:.3f} | walk {wk:.3f} | auto[{ka}] {auto:.3f}"
+        line += f"  {len(C) * 2 - int((np.asarray(Dd) == 0).sum())}r: {ks} {ser:.3f} | scan {sc:.3f} | walk {wk:.3f} | auto[{ka}] {auto:.3f}"
     print(line, flush=True)
