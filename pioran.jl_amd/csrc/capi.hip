@@ -404,8 +404,14 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     // 0.64 / 0.76 against 1.87 / 2.40; N = 65536: 1.19 / 1.35 against 12.0 / 16.4).
     const int nrows = (int)term.size();
     const bool scan_rows = nrows > 4 && nrows <= 64;
-    const bool scan = o.tp_scan != 0 && scan_rows && (o.tp_scan > 0 || p.B <= 2);
-    const int RP = scan ? (nrows + 7) & ~7 : pioran_tp_padded_rows(nrows);
+    // Three to 32 draws (tools/tp_scan_batch_sweep.py, section 8 of the profile): the combinations of one level want a CU slot each — a CU holds kc = 4 / 2 / 1
+    // workgroups of tp_combine_kernel at up to 8 / up to 32 / more rows (its LDS) — so the segment count is the largest power of two with B nseg <= 256 kc
+    // (SHO-20, N = 1e4, 4 / 8 draws: 64 / 32 segments 0.76 / 1.06 ms against 1.50 / 1.53 on the walk and 1.85 on the serial chains; 128 segments 1.08 / 2.0).
+    const int RPs = (nrows + 7) & ~7, kc = RPs <= 8 ? 4 : (RPs <= 32 ? 2 : 1);
+    const bool scan = o.tp_scan != 0 && scan_rows && (o.tp_scan > 0 || p.B <= 2 || (p.B <= 32 && 16 * p.B <= 256 * kc));
+    int scan_cap = 256;
+    if (scan && p.B > 2) { scan_cap = 16; while (2 * scan_cap * p.B <= 256 * kc && scan_cap < 256) scan_cap *= 2; }
+    const int RP = scan ? RPs : pioran_tp_padded_rows(nrows);
     // measured (tools/ab_tp.py sweep, profiles/r05_time_parallel_gpu.txt): with up to 8 draws it beats the serial-chain kernels from 1024 steps on at
     // up to 4 state rows (N = 8192: one SHO term 0.17 against 1.16 ms, two 0.27 against 1.15; there also at 64 draws from 4096 steps on: 0.90
     // against 1.16 ms), from 2048 steps at up to 8 rows (four terms, N = 8192: 0.47 against 1.21), from 4096 at up to 12, from 6144 at up to 16
@@ -427,7 +433,21 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
         // (49 .. 64 rows, tp_combine_lean_kernel: 56 / 60 rows from 4096 steps on — 0.89 / 1.02 against 1.03 / 1.08 ms; N = 1e4: 1.10 / 1.21 against 2.46 / 2.58;
         //  64 rows, five block columns on the serial chain, from 2048 — 0.89 against 0.98; N = 1e4: 1.21 against 4.6)
         const bool scanned = scan && p.N >= (RP <= 16 ? 1024 : (RP <= 24 ? 1536 : (RP <= 32 ? 2048 : (RP <= 48 ? 3072 : (p.R + 1 > 64 ? 2048 : 4096)))));
-        if (!few && !mid && !many && !scanned) return PIORAN_ERR_UNSUPPORTED;
+        // three and more draws on the scan: a model of its time (records + two phases of N / nseg steps + one combination per level and the check, in us)
+        // against the serial chain's time per step (measured at N = 1e4, resident inputs), taken when it promises 15 % off (up to 8 rows, where the model is
+        // optimistic at 32 draws: a quarter) — profiles/r06_time_parallel_scan.txt section 8 has the sweep this was held against at N = 2048 / 4096 / 1e4
+        bool scanned_b = false;
+        if (scan && p.B > 2) {
+            const double tau = RP <= 16 ? 0.7 + RP / 8.0 : 1.0 + RP / 32.0, tc = 8.0 + (double)RP * RP / 34.0;
+            int lv = 0;
+            for (int c = scan_cap; c > 1; c >>= 1) ++lv;
+            // (17 .. 32 rows: two combinations and eight phase wavefronts share a CU at the cap — measured 1.5 x the steps' time there)
+            const double load = RP > 16 && RP <= 32 ? (double)p.B * scan_cap * 4.0 / 1024.0 : 1.0, rp = 1.0 + 0.5 * (load > 1.0 ? load - 1.0 : 0.0);
+            const double t_scan = 35.0 + rp * tau * (double)p.N / scan_cap + (lv + 1) * tc;
+            const double s_chain = RP <= 8 ? 0.127 : (RP <= 24 ? 0.178 : (RP <= 40 ? 0.19 : (RP <= 48 ? 0.24 : (p.R + 1 > 64 ? 0.46 : 0.25))));
+            scanned_b = (int64_t)scan_cap * 16 <= p.N && t_scan < (RP <= 8 ? 0.75 : 0.85) * s_chain * (double)p.N;
+        }
+        if (!few && !mid && !many && !(scanned && p.B <= 2) && !scanned_b) return PIORAN_ERR_UNSUPPORTED;
     }
     while ((int)term.size() < RP) { term.push_back(0); kind.push_back(3); }
     // segments: phases 1 + 3 cost tau ~ 0.7 + R / 8 us per step with one wavefront per segment (up to 16 rows), ~ 1 + R / 32 with four; phase 2 t2 per
@@ -437,7 +457,7 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
         // N / nseg tau + ceil(log2 nseg) t_c, t_c = one combination (measured, tools/ab_tp.py: see profiles/r06_time_parallel_scan.txt): powers of two
         const double tau = RP <= 16 ? 0.7 + RP / 8.0 : 1.0 + RP / 32.0, tc = 8.0 + (double)RP * RP / 34.0;
         double best = 1e300;
-        for (int cand = 8, lv = 3; cand <= 256; cand *= 2, ++lv) {
+        for (int cand = 8, lv = 3; cand <= scan_cap; cand *= 2, ++lv) {
             const double est = tau * (double)p.N / cand + lv * tc;
             if (est < best && (int64_t)cand * 16 <= p.N) { best = est; nseg = cand; }
         }
@@ -450,6 +470,7 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     }
     if (nseg < 1) nseg = 1;
     if (nseg > (scan ? 256 : 128)) nseg = scan ? 256 : 128;
+    if (scan && p.B > 2 && o.tp_segments <= 0) nseg = scan_cap;
     if ((int64_t)nseg * 16 > p.N) nseg = (int)(p.N / 16);
     const int64_t L = (p.N + nseg - 1) / nseg;
     nseg = (int)((p.N + L - 1) / L);
@@ -1721,7 +1742,9 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
     // From 513 chains on (measured, SHO-20 / SHO-12 at N = 1e4: 512 chains 15.1 / 9.3 ms against the small-batch kernels' 11.0 / 9.2; 640 chains 15.2 /
     // 9.4 against 16.6 / 14.0; 2048 chains 27 / 16 against 44 / 36).
     const bool tilegrad = windowed && (grad_c != nullptr) == (grad_d != nullptr) && !grad_y && !grad_sigma2 && !shift && s.R <= pioran_tile_grad_supported_rows() &&
-                          (ctx->opt.force_tile || (!ctx->opt.no_tile && B > 512 && s.R >= 17));
+                          (ctx->opt.force_tile || (!ctx->opt.no_tile && B > 512 && s.R >= 17 && s.R <= 47));
+    // (48 .. 63 rows — DRWCelerite-20 is 60 — run on it when forced: three draws per workgroup there, and 4096 chains take 188 ms (294 with d/d(c, d)) against
+    //  164 (174) in 512-chain launches of the small-batch kernels: tools/ab_tile_grad_nb4.py, profiles/r06_tile_grad_four_block_columns.txt)
     auto ws_doubles = [&](int64_t nb) {
         return tilegrad ? pioran_tile_grad_workspace_doubles(nb, ds->N, s.R)
                         : (windowed ? pioran_block_grad_workspace_doubles(nb, ds->N, s.R) : pioran_grad_workspace_doubles(nb, ds->N, s.R));

@@ -44,6 +44,9 @@ namespace {
 
 constexpr int kTileMaxTerms = 64;
 constexpr int kTileWaves = 4;      // wavefronts (= draws) per workgroup
+// ... of the reverse mode: T_k and T- of a draw are 45 KB (53 with d/d(c, d)) of LDS at four block columns — three draws fit a CU, not four
+template <int NB>
+constexpr int tile_adj_waves() { return NB <= 3 ? 4 : 3; }
 
 typedef unsigned int tile_u32x2 __attribute__((ext_vector_type(2)));
 // 8 bytes through a buffer resource: per-lane byte offset in a VGPR (constant over the kernel), everything that moves (window, block, register
@@ -461,7 +464,7 @@ struct TileAdjWave {
 //   d/dd_r += s_r sum_n t_n (U~-'[n][r] (al_r C x - be_r C v)[n][r] + X-'[n][r] ((C_K / C) x)[n][r]),  s_r = -1 (cos row), +1 (sin row));
 // the pair part (d/dc E = -tau E, d/dd (E.cos, E.sin) = tau (-E.sin, E.cos)) is the post-pass's second product (tile_pairs_grad_kernel<true>).
 template <int NB, bool CD = false>
-__global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kernel(const ScanParams p, const double* __restrict__ btab,
+__global__ void __launch_bounds__(64 * tile_adj_waves<NB>(), 1) celerite_tile_adjoint_kernel(const ScanParams p, const double* __restrict__ btab,
                                                                                                   const double* __restrict__ gtab, double* __restrict__ pairs,
                                                                                                   double* __restrict__ grad_a, double* __restrict__ grad_b,
                                                                                                   double* __restrict__ grad_nu, double* __restrict__ grad_mu,
@@ -474,7 +477,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, 1) celerite_tile_adjoint_kern
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, q = lane >> 4, c16 = lane & 15;
-    const int64_t b = (int64_t)blockIdx.x * kTileWaves + w;
+    const int64_t b = (int64_t)blockIdx.x * tile_adj_waves<NB>() + w;
     if (b >= p.B) return;
     const int64_t N = p.N;
     const int J = p.J, R = p.R;
@@ -1165,13 +1168,14 @@ int launch_tile(const ScanParams& p, const double* btab, double* pairs, hipStrea
 }
 
 template <int NB>
-constexpr size_t tile_adj_lds_bytes() { return kTileWaves * sizeof(TileAdjWave<NB>); }
+constexpr size_t tile_adj_lds_bytes() { return tile_adj_waves<NB>() * sizeof(TileAdjWave<NB>); }
 
 template <int NB>
 int launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab, double* pairs, double* grad_a, double* grad_b, double* grad_nu,
                      double* grad_mu, double* grad_c, double* grad_d, hipStream_t stream)
 {
-    constexpr size_t lds_f = tile_lds_bytes<NB>(), lds_r = tile_adj_lds_bytes<NB>(), lds_rc = kTileWaves * sizeof(TileAdjWave<NB, true>);
+    constexpr size_t lds_f = tile_lds_bytes<NB>(), lds_r = tile_adj_lds_bytes<NB>(), lds_rc = tile_adj_waves<NB>() * sizeof(TileAdjWave<NB, true>);
+    constexpr int AW = tile_adj_waves<NB>();
     static_assert(lds_f <= 160 * 1024 && lds_r <= 160 * 1024 && lds_rc <= 160 * 1024, "one workgroup must fit a CU");
     static bool granted[64] = {};
     int dev = 0;
@@ -1190,13 +1194,14 @@ int launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab
     const int64_t rsb = block_rec_doubles(NB, p.J), tsp = block_tile_doubles(NB);
     if (!launch_pairs_mfma(p, stream, btab, rsb, tsp, pairs)) return PIORAN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((celerite_tile_kernel<NB, true>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_f, stream, p, btab, (const double*)pairs);
+    const unsigned agroups = (unsigned)((p.B + AW - 1) / AW);
     if (cd) {
-        hipLaunchKernelGGL((celerite_tile_adjoint_kernel<NB, true>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_rc, stream, p, btab, gtab, pairs, grad_a, grad_b,
+        hipLaunchKernelGGL((celerite_tile_adjoint_kernel<NB, true>), dim3(agroups), dim3(64 * AW), lds_rc, stream, p, btab, gtab, pairs, grad_a, grad_b,
                            grad_nu, grad_mu, grad_c, grad_d);
         hipLaunchKernelGGL(tile_pairs_grad_kernel<true>, dim3((unsigned)((p.B + 15) / 16)), dim3(512), 0, stream, p, btab, rsb, tsp, (const double*)pairs, grad_a, grad_b,
                            grad_c, grad_d);
     } else {
-        hipLaunchKernelGGL((celerite_tile_adjoint_kernel<NB, false>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_r, stream, p, btab, gtab, pairs, grad_a, grad_b,
+        hipLaunchKernelGGL((celerite_tile_adjoint_kernel<NB, false>), dim3(agroups), dim3(64 * AW), lds_r, stream, p, btab, gtab, pairs, grad_a, grad_b,
                            grad_nu, grad_mu, (double*)nullptr, (double*)nullptr);
         hipLaunchKernelGGL(tile_pairs_grad_kernel<false>, dim3((unsigned)((p.B + 15) / 16)), dim3(512), 0, stream, p, btab, rsb, tsp, (const double*)pairs, grad_a, grad_b,
                            (double*)nullptr, (double*)nullptr);
@@ -1207,7 +1212,7 @@ int launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab
 }  // namespace
 
 int pioran_tile_supported_rows() { return 95; }
-int pioran_tile_grad_supported_rows() { return 47; }   // three block columns (four: T_k and T- of four draws do not fit a CU's LDS)
+int pioran_tile_grad_supported_rows() { return 63; }   // four block columns (DRWCelerite-20 is 60 rows; there three draws per workgroup: tile_adj_waves)
 
 // doubles of the state workspace of the reverse mode: the lower tiles of T at the start of every window, per draw
 size_t pioran_tile_grad_workspace_doubles(int64_t B, int64_t N, int32_t R)
@@ -1228,6 +1233,7 @@ int pioran_launch_tile_grad(const ScanParams& p, const double* btab, const doubl
         case 1: return launch_tile_grad<1>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, grad_c, grad_d, stream);
         case 2: return launch_tile_grad<2>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, grad_c, grad_d, stream);
         case 3: return launch_tile_grad<3>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, grad_c, grad_d, stream);
+        case 4: return launch_tile_grad<4>(p, btab, gtab, pairs, grad_a, grad_b, grad_nu, grad_mu, grad_c, grad_d, stream);
     }
     return PIORAN_ERR_UNSUPPORTED;
 }

@@ -2039,8 +2039,10 @@ def test_time_parallel_dispatch_reference_values_and_flagged_draws(ctx, golden_d
     g14 = ds3.logl_batch(A8, B8, C8, D8)
     assert name() == "tp"                                           # (up to two draws: the boundary phase as a scan, from 1024 steps on)
     assert relerr(g14, O.logl_batch(A8, B8, C8, D8, t8, y8, s8, None, None)) < 1e-11
-    ds3.logl_batch(np.tile(A8, (2, 1)), np.tile(B8, (2, 1)), C8, D8)
-    assert name() != "tp"                                           # four draws: the boundary walk, from 6144 steps on
+    g14b = ds3.logl_batch(np.tile(A8, (2, 1)), np.tile(B8, (2, 1)), C8, D8)
+    assert name() == "tp" and relerr(g14b[:2], g14) < 1e-11         # four draws: the scan at 64 segments (3 .. 32 draws: by the model of tp_dispatch)
+    ds3.logl_batch(np.tile(A8, (17, 1)), np.tile(B8, (17, 1)), C8, D8)
+    assert name() != "tp"                                           # 34 draws
     g6 = ds3.logl_batch(np.tile(A8[:, :6], (2, 1)), np.tile(B8[:, :6], (2, 1)), C8[:6], D8[:6])[:2]
     assert name() == "tp"                                           # twelve state rows: from 4096
     assert relerr(g6, O.logl_batch(A8[:, :6], B8[:, :6], C8[:6], D8[:6], t8, y8, s8, None, None)) < 1e-11
@@ -2049,8 +2051,10 @@ def test_time_parallel_dispatch_reference_values_and_flagged_draws(ctx, golden_d
     ds9 = pj.Dataset(t9, y9, s9, ctx)
     g9_ = ds9.logl_batch(A9_[:2, :12], B9_[:2, :12], C9[:12], D9[:12], mu=mu9[:2], nu=nu9[:2])       # 24 state rows: from 4096 steps on
     assert name() == "tp" and relerr(g9_, O.logl_batch(A9_[:2, :12], B9_[:2, :12], C9[:12], D9[:12], t9, y9, s9, mu9[:2], nu9[:2], nthreads=8)) < 1e-10
-    ds9.logl_batch(A9_, B9_, C9, D9)
-    assert name() != "tp"                                           # 40 state rows: from 8192 steps on
+    g40 = ds9.logl_batch(A9_, B9_, C9, D9)
+    assert name() == "tp" and relerr(g40, O.logl_batch(A9_, B9_, C9, D9, t9, y9, s9, None, None, nthreads=8)) < 1e-10   # 40 state rows, four draws: the scan
+    ds9.logl_batch(np.tile(A9_, (3, 1)), np.tile(B9_, (3, 1)), C9, D9)
+    assert name() != "tp"                                           # twelve draws of 40 rows: the serial chains
     ds9.logl_batch(A9_[:, :16], B9_[:, :16], C9[:16], D9[:16])
     assert name() == "tp"                                           # 32 state rows, four draws: from 6144
     ds9.close()
@@ -2163,12 +2167,14 @@ TILE_GRAD = "tile (windowed gradient, one draw per wavefront)"
 
 
 @pytest.mark.parametrize("J,N,B,nreal", [(1, 40, 3, 0), (3, 50, 5, 0), (5, 16, 2, 0), (8, 37, 6, 0), (8, 100, 3, 1), (10, 17, 4, 0), (12, 64, 4, 2), (15, 130, 5, 0),
-                                         (16, 33, 70, 0), (20, 257, 9, 0), (23, 48, 2, 0), (23, 95, 3, 5)])
+                                         (16, 33, 70, 0), (20, 257, 9, 0), (23, 48, 2, 0), (23, 95, 3, 5), (24, 50, 5, 0), (28, 40, 7, 2), (30, 97, 5, 3),
+                                         (31, 130, 4, 0), (40, 65, 4, 20)])
 def test_tile_gradient_matches_complex_step(ctx, J, N, B, nreal):
     """d log L / d(a_j, b_j, mu, nu) by the one-draw-per-wavefront reverse mode (celerite_tile_adjoint_kernel, round 5; what many chains of an
     approx-based model ask for), forced here at every batch size: against the complex-step derivatives of the oracle and the small-batch windowed
-    reverse mode; block columns NB = 1 .. 3 (up to 47 rows), ragged last windows, N = 16 and 17 (one window / one step in the second), one-row
-    terms, more draws than one workgroup holds; the value is bit-identical to the tile forward kernel's."""
+    reverse mode; block columns NB = 1 .. 4 (up to 63 rows; at four — DRWCelerite-20's 60 rows — three draws per workgroup, forced only: the small-batch
+    kernels are faster there), ragged last windows, N = 16 and 17 (one window / one step in the second), one-row terms, more draws than one workgroup
+    holds; the value is bit-identical to the tile forward kernel's."""
     rng = np.random.default_rng(7700 + J + N)
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
     Bc[:, :nreal] = 0.0; Dd[:nreal] = 0.0
@@ -2266,7 +2272,8 @@ def test_tile_gradient_dispatch_chunks_and_flagged_draws(ctx):
 def test_tile_gradient_full_size(ctx, full_size):
     """N = 1e4 (BASELINE shape), 1024 prior draws of SHO-20 (40 rows) and DRWCelerite-15 (45 rows, 15 of the 30 terms with one row): the
     one-draw-per-wavefront reverse mode against the small-batch windowed reverse mode on every chain both call positive definite, and against
-    complex steps of the oracle.  (DRWCelerite-20 has 60 rows: four block columns, which the reverse kernel's LDS does not hold — block.)"""
+    complex steps of the oracle.  (DRWCelerite-20 has 60 rows: four block columns, three draws per workgroup on the tile reverse kernel, which is slower than
+    the small-batch kernels there — block.)"""
     t, y, yerr = full_size
     th = O.synthetic_theta(1024, t, y, seed=77)
     ds = pj.Dataset(t, y, yerr ** 2, ctx)
