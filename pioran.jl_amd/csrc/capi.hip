@@ -438,7 +438,7 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
         // optimistic at 32 draws: a quarter) — profiles/r06_time_parallel_scan.txt section 8 has the sweep this was held against at N = 2048 / 4096 / 1e4
         bool scanned_b = false;
         if (scan && p.B > 2) {
-            const double tau = RP <= 16 ? 0.7 + RP / 8.0 : 1.0 + RP / 32.0, tc = 8.0 + (double)RP * RP / 34.0;
+            const double tau = RP <= 16 ? 0.7 + RP / 8.0 : 1.0 + RP / 32.0, tc = 8.0 + (double)RP * RP / 50.0;
             int lv = 0;
             for (int c = scan_cap; c > 1; c >>= 1) ++lv;
             // (17 .. 32 rows: two combinations and eight phase wavefronts share a CU at the cap — measured 1.5 x the steps' time there)
@@ -455,7 +455,7 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     int nseg = o.tp_segments;
     if (nseg <= 0 && scan) {
         // N / nseg tau + ceil(log2 nseg) t_c, t_c = one combination (measured, tools/ab_tp.py: see profiles/r06_time_parallel_scan.txt): powers of two
-        const double tau = RP <= 16 ? 0.7 + RP / 8.0 : 1.0 + RP / 32.0, tc = 8.0 + (double)RP * RP / 34.0;
+        const double tau = RP <= 16 ? 0.7 + RP / 8.0 : 1.0 + RP / 32.0, tc = 8.0 + (double)RP * RP / 50.0;
         double best = 1e300;
         for (int cand = 8, lv = 3; cand <= scan_cap; cand *= 2, ++lv) {
             const double est = tau * (double)p.N / cand + lv * tc;
@@ -706,6 +706,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
         if (value && !o.force_tile && !o.force_tp) std::strcpy(o.scan_config, value);
     } else if (!std::strcmp(key, "no_tp")) o.no_tp = on; else if (!std::strcmp(key, "tp_segments")) o.tp_segments = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan")) o.tp_scan = (value && value[0]) ? std::atoi(value) : -1;
+    else if (!std::strcmp(key, "tp_scan_waves")) o.tp_scan_waves = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan_lean")) o.tp_scan_lean = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan_tol")) o.tp_scan_tol = (value && value[0]) ? std::atof(value) : 0.0;
     else if (!std::strcmp(key, "no_tile")) o.no_tile = on; else if (!std::strcmp(key, "no_wide")) o.no_wide = on;

@@ -319,13 +319,20 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
 __global__ void __launch_bounds__(64) tp_finish_kernel(int64_t N, int nseg, int64_t B, const double* __restrict__ part, double* __restrict__ out,
                                                        int32_t* __restrict__ status)
 {
-    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (b >= B) return;
+    // one wavefront per draw (round 6: with up to 256 segments the one-thread loop was 34 us of a 600 us evaluation): lane l adds the segments l, l + 64, ...,
+    // then a butterfly over the lanes — the same order on every call
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
     double ld = 0.0, q = 0.0, bad = 0.0;
-    for (int s2 = 0; s2 < nseg; ++s2) {
+    for (int s2 = lane; s2 < nseg; s2 += 64) {
         const double* o = part + (b * nseg + s2) * 4;
         q += o[0]; ld += o[1]; bad += o[2];
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        q += __shfl_xor(q, off); ld += __shfl_xor(ld, off); bad += __shfl_xor(bad, off);
+    }
+    if (lane != 0) return;
     const double res = -0.5 * ld - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * q;
     out[b] = res;
     if (status) status[b] = !isfinite(res) ? 2 : (bad > 0.0 ? 1 : 0);
@@ -739,8 +746,8 @@ __global__ void __launch_bounds__(64 * TW) tp_boundary_kernel(int RP, int nseg, 
 // One workgroup of four wavefronts per (draw, target); the pieces — products on the matrix cores tile by tile, Gauss-Jordan with partial pivoting without
 // row exchanges, four pivots per barrier, rank-4 updates on the matrix cores — are tp_boundary_kernel's.  16 RT >= RP, RP a multiple of 8, RT <= 3 (the
 // three-block right-hand side does not fit 160 KB of LDS at 64 rows: those stay on the walk).
-template <int RT>
-__global__ void __launch_bounds__(256) tp_combine_kernel(int RP, int nseg, int J, int stride, const int32_t* __restrict__ row_term,
+template <int RT, int TW>
+__global__ void __launch_bounds__(64 * TW) tp_combine_kernel(int RP, int nseg, int J, int stride, const int32_t* __restrict__ row_term,
                                                          const int32_t* __restrict__ row_kind, const double* __restrict__ A_, const double* __restrict__ Bc_,
                                                          const double* __restrict__ ein, double* __restrict__ eout, double* __restrict__ bnd,
                                                          double* __restrict__ disc)
@@ -752,7 +759,7 @@ __global__ void __launch_bounds__(256) tp_combine_kernel(int RP, int nseg, int J
     // states differ by 1e-14 .. 1e-9 — the discrepancy is far more sensitive than log L — so the threshold (kTpScanTol, option "tp_scan_tol") only
     // catches a scan that has gone wrong outright (a NaN, a blow-up): such a draw goes through the walk after all (tp_boundary_kernel's `disc`).
     extern __shared__ double lds[];
-    constexpr int TW = 4, R16 = 16 * RT, S1 = R16 + 1, LW = 3 * R16 + 3, T = 256;
+    constexpr int R16 = 16 * RT, S1 = R16 + 1, LW = 3 * R16 + 3, T = 64 * TW;
     double* X = lds;                     // [R16][LW]: [W, later A_j Z | z (1), Z (RP), later J_j (M A_i) | A_i -> M A_i (RP)]
     double* Pm = X + R16 * LW;           // [R16][S1]: C_i, later Z = M C_i, then C (unsymmetrised), then J (unsymmetrised)
     double* JL = Pm + R16 * S1;          // J_j
@@ -952,15 +959,16 @@ __global__ void __launch_bounds__(256) tp_combine_kernel(int RP, int nseg, int J
         for (int q = tid; q < RP * RP; q += T) {
             const int r = q / RP, c = q % RP;
             const double v = 0.5 * (Pm[r * S1 + c] + Pm[c * S1 + r]) + ej[4096 + r * 64 + c], o = bo[64 + r * 64 + c];
-            dP = fmax(dP, fabs(v - o)); sP = fmax(sP, fabs(o));
+            const double dd = fabs(v - o);
+            dP = fmax(dP, dd >= 0.0 ? dd : __builtin_inf()); sP = fmax(sP, fabs(o));      // (fmax drops a NaN: a state that is not a number must fail the check)
         }
-        if (tid < RP) { const double o = bo[tid]; dm = fabs(mnew - o); sm = fabs(o); }
+        if (tid < RP) { const double o = bo[tid]; dm = fabs(mnew - o); dm = dm >= 0.0 ? dm : __builtin_inf(); sm = fabs(o); }
         dP = tp_max(dP); sP = tp_max(sP); dm = tp_max(dm); sm = tp_max(sm);
-        if (lane == 0) { fneg[w] = dP; fneg[4 + w] = sP; fneg[8 + w] = dm; fneg[12 + w] = sm; }
+        if (lane == 0) { fneg[w] = dP; fneg[TW + w] = sP; fneg[2 * TW + w] = dm; fneg[3 * TW + w] = sm; }
         TP_BARRIER();
         if (tid == 0) {
-            const double DP = fmax(fmax(fneg[0], fneg[1]), fmax(fneg[2], fneg[3])), SP = fmax(fmax(fneg[4], fneg[5]), fmax(fneg[6], fneg[7]));
-            const double DM = fmax(fmax(fneg[8], fneg[9]), fmax(fneg[10], fneg[11])), SM = fmax(fmax(fneg[12], fneg[13]), fmax(fneg[14], fneg[15]));
+            double DP = 0.0, SP = 0.0, DM = 0.0, SM = 0.0;
+            for (int x = 0; x < TW; ++x) { DP = fmax(DP, fneg[x]); SP = fmax(SP, fneg[TW + x]); DM = fmax(DM, fneg[2 * TW + x]); SM = fmax(SM, fneg[3 * TW + x]); }
             // (the mean is measured against its own scale and the standard deviation the covariance implies: a mean that is tiny by symmetry must not trip it)
             double rel = DP / (SP > 0.0 ? SP : 1.0);
             const double mscale = fmax(SM, sqrt(SP));
@@ -1014,14 +1022,14 @@ __global__ void __launch_bounds__(256) tp_combine_kernel(int RP, int nseg, int J
 // left them — row l of X holds row mycol(l) of the solution — and are read through the inverse permutation `rowof`.  J_j is read as its transpose (it is
 // symmetric up to rounding) so that the lanes of a load run along a row.  Same three modes (prior / complete prefix / incomplete element) and the same
 // verification mode as tp_combine_kernel; tests hold the two against each other at 16 .. 48 rows (option tp_scan_lean).
-template <int RT>
-__global__ void __launch_bounds__(256) tp_combine_lean_kernel(int RP, int nseg, int J, int stride, const int32_t* __restrict__ row_term,
+template <int RT, int TW>
+__global__ void __launch_bounds__(64 * TW) tp_combine_lean_kernel(int RP, int nseg, int J, int stride, const int32_t* __restrict__ row_term,
                                                               const int32_t* __restrict__ row_kind, const double* __restrict__ A_, const double* __restrict__ Bc_,
                                                               const double* __restrict__ ein, double* __restrict__ eout, double* __restrict__ bnd,
                                                               double* __restrict__ disc)
 {
     extern __shared__ double lds[];
-    constexpr int TW = 4, R16 = 16 * RT, S1 = R16 + 1, LW = 3 * R16 + 3, T = 256;
+    constexpr int R16 = 16 * RT, S1 = R16 + 1, LW = 3 * R16 + 3, T = 64 * TW;
     double* X = lds;                     // [R16][LW]: [W, later A_j Z, later J (unsymmetrised) | z (1) | C_i -> Z (RP), later C (unsymmetrised) | A_i -> M A_i (RP)]
     double* Pm = X + R16 * LW;           // [R16][S1]: J_j (M A_i)
     double* mv = Pm + R16 * S1;          // [64] b_i, later z
@@ -1215,15 +1223,16 @@ __global__ void __launch_bounds__(256) tp_combine_lean_kernel(int RP, int nseg, 
         for (int q = tid; q < RP * RP; q += T) {
             const int r = q / RP, c = q % RP;
             const double v = 0.5 * (X[r * LW + ZC + c] + X[c * LW + ZC + r]) + ej[4096 + r * 64 + c], o = bo[64 + r * 64 + c];
-            dP = fmax(dP, fabs(v - o)); sP = fmax(sP, fabs(o));
+            const double dd = fabs(v - o);
+            dP = fmax(dP, dd >= 0.0 ? dd : __builtin_inf()); sP = fmax(sP, fabs(o));      // (fmax drops a NaN: a state that is not a number must fail the check)
         }
-        if (tid < RP) { const double o = bo[tid]; dm = fabs(mnew - o); sm = fabs(o); }
+        if (tid < RP) { const double o = bo[tid]; dm = fabs(mnew - o); dm = dm >= 0.0 ? dm : __builtin_inf(); sm = fabs(o); }
         dP = tp_max(dP); sP = tp_max(sP); dm = tp_max(dm); sm = tp_max(sm);
-        if (lane == 0) { fneg[w] = dP; fneg[4 + w] = sP; fneg[8 + w] = dm; fneg[12 + w] = sm; }
+        if (lane == 0) { fneg[w] = dP; fneg[TW + w] = sP; fneg[2 * TW + w] = dm; fneg[3 * TW + w] = sm; }
         TP_BARRIER();
         if (tid == 0) {
-            const double DP = fmax(fmax(fneg[0], fneg[1]), fmax(fneg[2], fneg[3])), SP = fmax(fmax(fneg[4], fneg[5]), fmax(fneg[6], fneg[7]));
-            const double DM = fmax(fmax(fneg[8], fneg[9]), fmax(fneg[10], fneg[11])), SM = fmax(fmax(fneg[12], fneg[13]), fmax(fneg[14], fneg[15]));
+            double DP = 0.0, SP = 0.0, DM = 0.0, SM = 0.0;
+            for (int x = 0; x < TW; ++x) { DP = fmax(DP, fneg[x]); SP = fmax(SP, fneg[TW + x]); DM = fmax(DM, fneg[2 * TW + x]); SM = fmax(SM, fneg[3 * TW + x]); }
             double rel = DP / (SP > 0.0 ? SP : 1.0);
             const double mscale = fmax(SM, sqrt(SP));
             rel = fmax(rel, DM / (mscale > 0.0 ? mscale : 1.0));
@@ -1553,25 +1562,35 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
         const int rt = (RP + 15) / 16;
         const bool lean = rt == 4 || (p.opt && p.opt->tp_scan_lean);          // (four tiles of rows: only the lean form fits the LDS)
         const size_t r16s = (size_t)rt * 16;
-        const size_t ldsc = lean ? (r16s * (3 * r16s + 3) + r16s * (r16s + 1) + 7 * 64 + 32 + 1024) * sizeof(double)
-                                 : (r16s * (3 * r16s + 3) + 4 * r16s * (r16s + 1) + 7 * 64 + 1024) * sizeof(double);
-        const void* fnc = lean ? (rt == 1 ? (const void*)tp_combine_lean_kernel<1> : (rt == 2 ? (const void*)tp_combine_lean_kernel<2> : (rt == 3 ? (const void*)tp_combine_lean_kernel<3> : (const void*)tp_combine_lean_kernel<4>)))
-                               : (rt == 1 ? (const void*)tp_combine_kernel<1> : (rt == 2 ? (const void*)tp_combine_kernel<2> : (const void*)tp_combine_kernel<3>));
-        static size_t granted_c[2][5][64] = {};
-        if (ldsc > granted_c[lean ? 1 : 0][rt][dev]) {
+        // wavefronts per combination: eight from 17 rows on (three tiles of rows: nine product tiles and eight column tiles per elimination round — 48.9 -> 40.2 us;
+        // four tiles, lean: sixteen and twelve)
+        const int tw = rt >= 2 && !(p.opt && p.opt->tp_scan_waves == 4) ? 8 : 4;
+        const size_t ldsc = lean ? (r16s * (3 * r16s + 3) + r16s * (r16s + 1) + 7 * 64 + 32 + 256 * tw) * sizeof(double)
+                                 : (r16s * (3 * r16s + 3) + 4 * r16s * (r16s + 1) + 7 * 64 + 256 * tw) * sizeof(double);
+        const void* fnc = nullptr;
+#define TP_PICK(KERNEL) (rt == 1 ? (const void*)KERNEL<1, 4> : (rt == 2 ? (tw == 8 ? (const void*)KERNEL<2, 8> : (const void*)KERNEL<2, 4>) : (rt == 3 ? (tw == 8 ? (const void*)KERNEL<3, 8> : (const void*)KERNEL<3, 4>) : (tw == 8 ? (const void*)KERNEL<4, 8> : (const void*)KERNEL<4, 4>))))
+        if (lean) fnc = TP_PICK(tp_combine_lean_kernel);
+        else if (rt <= 3) fnc = rt == 1 ? (const void*)tp_combine_kernel<1, 4> : (rt == 2 ? (tw == 8 ? (const void*)tp_combine_kernel<2, 8> : (const void*)tp_combine_kernel<2, 4>) : (tw == 8 ? (const void*)tp_combine_kernel<3, 8> : (const void*)tp_combine_kernel<3, 4>));
+#undef TP_PICK
+        if (!fnc) return PIORAN_ERR_UNSUPPORTED;
+        static size_t granted_c[4][5][64] = {};
+        const int gi = (lean ? 2 : 0) + (tw == 8 ? 1 : 0);
+        if (ldsc > granted_c[gi][rt][dev]) {
             if (hipFuncSetAttribute(fnc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc) != hipSuccess) return PIORAN_ERR_HIP;
-            granted_c[lean ? 1 : 0][rt][dev] = ldsc;
+            granted_c[gi][rt][dev] = ldsc;
         }
         const double tol = p.opt && p.opt->tp_scan_tol > 0.0 ? p.opt->tp_scan_tol : kTpScanTol;
         if (hipMemsetAsync(disc, 0, (size_t)B * sizeof(double), stream) != hipSuccess) return PIORAN_ERR_HIP;
         auto combine = [&](const dim3& gr, int stride, const double* src, double* dst, double* dsc) {
-#define TP_COMBINE(KERNEL, RR) hipLaunchKernelGGL((KERNEL<RR>), gr, dim3(256), ldsc, stream, RP, nseg, p.J, stride, row_term, row_kind, p.A, p.Bc, src, dst, bnd, dsc)
+#define TP_COMBINE(KERNEL, WV) hipLaunchKernelGGL(KERNEL, gr, dim3(64 * WV), ldsc, stream, RP, nseg, p.J, stride, row_term, row_kind, p.A, p.Bc, src, dst, bnd, dsc)
+#define TP_COMBINE_RT(KERNEL, RR) do { if (tw == 8) TP_COMBINE((KERNEL<RR, 8>), 8); else TP_COMBINE((KERNEL<RR, 4>), 4); } while (0)
             if (lean) {
-                if (rt == 1) TP_COMBINE(tp_combine_lean_kernel, 1); else if (rt == 2) TP_COMBINE(tp_combine_lean_kernel, 2);
-                else if (rt == 3) TP_COMBINE(tp_combine_lean_kernel, 3); else TP_COMBINE(tp_combine_lean_kernel, 4);
+                if (rt == 1) TP_COMBINE((tp_combine_lean_kernel<1, 4>), 4); else if (rt == 2) TP_COMBINE_RT(tp_combine_lean_kernel, 2);
+                else if (rt == 3) TP_COMBINE_RT(tp_combine_lean_kernel, 3); else TP_COMBINE_RT(tp_combine_lean_kernel, 4);
             } else {
-                if (rt == 1) TP_COMBINE(tp_combine_kernel, 1); else if (rt == 2) TP_COMBINE(tp_combine_kernel, 2); else TP_COMBINE(tp_combine_kernel, 3);
+                if (rt == 1) TP_COMBINE((tp_combine_kernel<1, 4>), 4); else if (rt == 2) TP_COMBINE_RT(tp_combine_kernel, 2); else TP_COMBINE_RT(tp_combine_kernel, 3);
             }
+#undef TP_COMBINE_RT
 #undef TP_COMBINE
         };
         const double* src = elem;
@@ -1628,7 +1647,7 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
     }
     hipLaunchKernelGGL((tp_filter_kernel<NP, NWV>), dim3((unsigned)nseg, (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
                        (const TpRec*)rec, (const TpStep*)stp, (const double*)bnd, part, sval);
-    hipLaunchKernelGGL(tp_finish_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, N, nseg, B, (const double*)part, p.out, p.status);
+    hipLaunchKernelGGL(tp_finish_kernel, dim3((unsigned)B), dim3(64), 0, stream, N, nseg, B, (const double*)part, p.out, p.status);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 

@@ -33,6 +33,7 @@ struct ScanOptions {
     bool force_tp, no_tp;       // celerite_tp.hip (time-parallel evaluation of a handful of draws): force (scan_config "tp") / forbid
     int tp_segments = 0;        // ... its segment count (0 = automatic)
     int tp_scan = -1;           // ... its boundary phase: 1 the scan over the segments' elements (tp_combine_kernel, round 6), 0 the sequential walk, -1 automatic
+    int tp_scan_waves = 0;      // ... 4: four wavefronts per combination also at 33 .. 48 rows (default there: eight)
     int tp_scan_lean = 0;       // ... 1: the scan's combinations with operands from global memory (tp_combine_lean_kernel) also below 49 rows (tests)
     double tp_scan_tol = 0.0;   // ... the scan's acceptance threshold (largest relative discrepancy of a boundary state; 0 = the default, celerite_tp.hip kTpScanTol)
     bool force_tile, no_tile;   // celerite_tile.hip (windowed form, one draw per wavefront; default from 49 rows on above the small-batch range): force / forbid
