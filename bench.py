@@ -83,7 +83,7 @@ def pmc_traffic(basis: str, J: int, B: int, N: int, kernel_config: str):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary of this same command (bench.py cannot collect
     PMCs on itself).  Quoted only when the summary was taken on the SAME kernel: same configuration name and same
     source fingerprint; otherwise null with the reason."""
-    cands = [ROOT / "profiles" / f"{r}_pmc_{basis.lower()}{J}_b{B}.json" for r in ("r05", "r04", "r03", "r02")]
+    cands = [ROOT / "profiles" / f"{r}_pmc_{basis.lower()}{J}_b{B}.json" for r in ("r06", "r05", "r04", "r03", "r02")]
     f = next((c for c in cands if c.exists()), cands[0])
     if N != 10_000 or not f.exists():
         return None, f"no PMC summary for this workload ({f.name})"
@@ -152,7 +152,7 @@ def emit(result: dict) -> None:
             line[k] = result[k]
     line["full_form"] = "bench_full.json (notes, every secondary measurement); DESIGN.md section 7"
     if sec:
-        first = [k for k in sec if k.startswith(("drwcelerite", "sho", "dense_", "single_evaluation_B1", "small_batch_B256", "gradient_", "batch_sizes"))]
+        first = [k for k in sec if k.startswith(("drwcelerite", "sho", "dense_", "single_evaluation_B1", "few_draws", "small_batch_B256", "gradient_", "batch_sizes"))]
         sec = {**{k: sec[k] for k in first}, **{k: v for k, v in sec.items() if k not in first}}
         line["secondary"] = _numbers_only(sec)
         order = list(line["secondary"].keys())
@@ -752,6 +752,20 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
         msb, *_ = resident_batch(basis, N, 256, 11)
         small[f"{basis}{J}_N{N}_B256"] = {"resident_launch_ms": msb, "evals_per_s": 256 / (msb * 1e-3)}
     out["small_batch_B256"] = small
+    # -- a handful of draws (a few chains / walkers evaluated together): the time-parallel family with its boundary phase as a scan (round 6) against the
+    #    serial chains ("no_tp"), resident inputs -------------------------------------------------------------------------------------------------------
+    few = {}
+    for basis in ("SHO", "DRWCelerite"):
+        for nbf in (4, 8):
+            msf, *_rest = resident_batch(basis, N, nbf, 7)
+            kern_f = _rest[7]
+            try:
+                ctx.set_option("no_tp", True)
+                mss, *_ = resident_batch(basis, N, nbf, 7)
+            finally:
+                ctx.set_option("no_tp", False)
+            few[f"{basis}{J}_N{N}_B{nbf}"] = {"resident_launch_ms": msf, "kernel": kern_f, "serial_chains_ms": mss}
+    out["few_draws"] = few
 
     # -- small batches with per-draw (c, d): a QPO feature on the approx continuum (src/psd.jl:254-261) and (c, d) per draw in every
     #    term (free Celerite / CARMA terms, src/CARMA.jl:98-143) — host-pointer entry (PCIe included), 256 draws --------------------

@@ -487,7 +487,28 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     q.C = s->dc; q.D = s->dd; q.J = J; q.opt = &ctx->opt;
     g_last_kernel = "tp";
     const int32_t* dr = (const int32_t*)ctx->btprow.p;
-    return pioran_launch_tp(q, RP, nseg, L, dr, dr + RP, (double*)ctx->btp.p, ctx->stream, scan ? 1 : 0);
+    // A draw whose scan fails its check (tp_combine_kernel's verification launch: ~5 % of the prior draws of DRWCelerite-20, whose scan alone is off by up to
+    // 1e-5 there; none of 96 at SHO-20 / SHO-28 — tools/tp_scan_tol2.py) is evaluated again.  By the family's own boundary walk that costs 15 ms at 128
+    // segments; the serial-chain windowed kernel does it in 2.5 (celerite_block_kernel with ScanParams::only_if: its workgroups leave at once for every draw
+    // that passed), so that is the repair pass wherever that kernel takes the rows; the walk stays for the rest (option tp_walk_repair forces it).
+    bool repair = scan && nseg >= 2 && !o.tp_walk_repair && !o.no_block && p.R >= 5 && pioran_block_fits_value(p.R, p.J) &&
+                  p.rec_stride == 3 * (int64_t)(s->R + 2) + 2 && (p.Y == nullptr) == (p.S2 == nullptr);
+    if (repair) {
+        rc = ensure_btab(ds, *s);
+        if (rc == PIORAN_ERR_UNSUPPORTED) repair = false;
+        else if (rc) return rc;
+    }
+    rc = pioran_launch_tp(q, RP, nseg, L, dr, dr + RP, (double*)ctx->btp.p, ctx->stream, scan ? (repair ? 2 : 1) : 0);
+    if (rc || !repair) return rc;
+    ScanParams qr = p;
+    qr.only_if = pioran_tp_disc((const double*)ctx->btp.p, p.B, p.N, RP, nseg);
+    qr.only_if_tol = pioran_tp_scan_tol(&ctx->opt);
+    rc = pioran_launch_scan_block(qr, s->btab, ctx->stream);
+    if (rc == PIORAN_ERR_UNSUPPORTED) {
+        ctx->last_err = "time-parallel scan: the serial-chain repair pass refused a launch its own conditions admit";
+        return PIORAN_ERR_HIP;
+    }
+    return rc;
 }
 
 // The automatic choice between the windowed form with one draw per wavefront ("tile", 1) and the rest (0: step-by-step throughput layouts / the
@@ -706,6 +727,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
         if (value && !o.force_tile && !o.force_tp) std::strcpy(o.scan_config, value);
     } else if (!std::strcmp(key, "no_tp")) o.no_tp = on; else if (!std::strcmp(key, "tp_segments")) o.tp_segments = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan")) o.tp_scan = (value && value[0]) ? std::atoi(value) : -1;
+    else if (!std::strcmp(key, "tp_walk_repair")) o.tp_walk_repair = on;
     else if (!std::strcmp(key, "tp_scan_waves")) o.tp_scan_waves = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan_lean")) o.tp_scan_lean = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan_tol")) o.tp_scan_tol = (value && value[0]) ? std::atof(value) : 0.0;

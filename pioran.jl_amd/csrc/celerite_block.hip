@@ -308,6 +308,9 @@ __global__ void __launch_bounds__(NB < 4 ? (PDM == 1 ? 320 : 256) : 512, (NB < 4
     constexpr int CH = NCW - 1;             // the chain wavefront
     constexpr int TS = 3 * NB * 256 + 16 * NB + 16, TSP = (TS + 127) & ~127;
     extern __shared__ double lds_[];
+    if constexpr (ST == 0) {
+        if (p.only_if && !(p.only_if[blockIdx.x] > p.only_if_tol)) return;     // (the repair pass behind the time-parallel scan: workgroup-uniform, before any barrier)
+    }
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be
     const int lane = tid & 63, q = lane >> 4, c16 = lane & 15;

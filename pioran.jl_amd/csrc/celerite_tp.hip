@@ -29,6 +29,7 @@
 #include "common.h"
 
 int pioran_tp_scan_rows(int RP);
+double pioran_tp_scan_tol(const ScanOptions* opt);
 
 namespace {
 
@@ -1579,7 +1580,7 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
             if (hipFuncSetAttribute(fnc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc) != hipSuccess) return PIORAN_ERR_HIP;
             granted_c[gi][rt][dev] = ldsc;
         }
-        const double tol = p.opt && p.opt->tp_scan_tol > 0.0 ? p.opt->tp_scan_tol : kTpScanTol;
+        const double tol = pioran_tp_scan_tol(p.opt);
         if (hipMemsetAsync(disc, 0, (size_t)B * sizeof(double), stream) != hipSuccess) return PIORAN_ERR_HIP;
         auto combine = [&](const dim3& gr, int stride, const double* src, double* dst, double* dsc) {
 #define TP_COMBINE(KERNEL, WV) hipLaunchKernelGGL(KERNEL, gr, dim3(64 * WV), ldsc, stream, RP, nseg, p.J, stride, row_term, row_kind, p.A, p.Bc, src, dst, bnd, dsc)
@@ -1602,7 +1603,9 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
         }
         // the check (one boundary step per boundary from the scan's states, all at once) and, for the draws that fail it, the walk
         combine(dim3((unsigned)(nseg - 1), (unsigned)B), 1, elem, nullptr, disc);
-        if (RP <= 16) {
+        if (scan == 2) {
+            // (the caller repairs the draws that fail the check itself: capi.hip tp_dispatch, the serial-chain kernel with ScanParams::only_if)
+        } else if (RP <= 16) {
 #define TP_WAVE_CASE(RR) case RR: hipLaunchKernelGGL((tp_boundary_wave_kernel<RR>), dim3((unsigned)B), dim3(64), 0, stream, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)disc, tol); break;
             switch (RP) { TP_WAVE_CASE(8) TP_WAVE_CASE(16) default: return PIORAN_ERR_UNSUPPORTED; }
 #undef TP_WAVE_CASE
@@ -1652,6 +1655,12 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
 }
 
 }  // namespace
+
+const double* pioran_tp_disc(const double* work, int64_t B, int64_t N, int RP, int nseg)
+{
+    return work + (size_t)B * N * RP * 6 + (size_t)B * N * 5 + (size_t)B * nseg * (3 * (size_t)TP_ELEM_DOUBLES + TP_BND_DOUBLES + 4);
+}
+double pioran_tp_scan_tol(const ScanOptions* opt) { return opt && opt->tp_scan_tol != 0.0 ? opt->tp_scan_tol : kTpScanTol; }   // (negative: every draw is repaired — tests)
 
 int pioran_tp_supported_rows() { return 64; }     // (lane = state row in the element and filter kernels)
 // state rows (padded) whose boundary phase can run as a scan (tp_combine_kernel up to three tiles of 16 rows, tp_combine_lean_kernel at four: a multiple of 8)

@@ -33,9 +33,10 @@ struct ScanOptions {
     bool force_tp, no_tp;       // celerite_tp.hip (time-parallel evaluation of a handful of draws): force (scan_config "tp") / forbid
     int tp_segments = 0;        // ... its segment count (0 = automatic)
     int tp_scan = -1;           // ... its boundary phase: 1 the scan over the segments' elements (tp_combine_kernel, round 6), 0 the sequential walk, -1 automatic
+    bool tp_walk_repair = false; // ... draws whose scan fails its check go through the family's own boundary walk instead of the serial-chain kernel
     int tp_scan_waves = 0;      // ... 4: four wavefronts per combination also at 33 .. 48 rows (default there: eight)
     int tp_scan_lean = 0;       // ... 1: the scan's combinations with operands from global memory (tp_combine_lean_kernel) also below 49 rows (tests)
-    double tp_scan_tol = 0.0;   // ... the scan's acceptance threshold (largest relative discrepancy of a boundary state; 0 = the default, celerite_tp.hip kTpScanTol)
+    double tp_scan_tol = 0.0;   // ... the scan's acceptance threshold (largest relative discrepancy of a boundary state; 0 = the default, celerite_tp.hip kTpScanTol; negative: every draw is repaired)
     bool force_tile, no_tile;   // celerite_tile.hip (windowed form, one draw per wavefront; default from 49 rows on above the small-batch range): force / forbid
     bool no_split;        // never send the remainder of a multi-pass batch to the windowed kernel on the second stream (capi.hip split_dispatch)
     bool win3, no_win3;   // throughput layouts with two / three rows per lane: force / forbid the three-step form (celerite_scan.hip;
@@ -120,6 +121,10 @@ struct ScanParams {
     double* g_scal;
     double* g_y;
     double* g_s2;
+    // celerite_block_kernel as the repair pass behind the time-parallel scan (round 6): a workgroup runs only if only_if[draw] > only_if_tol
+    // (only_if = nullptr: every draw) — the draws whose scan failed its check are evaluated again on the serial chain, into the same out / status
+    const double* only_if;
+    double only_if_tol;
 };
 
 // celerite_scan.hip
@@ -180,6 +185,9 @@ int pioran_tp_padded_rows(int rows);
 size_t pioran_tp_workspace_doubles(int64_t B, int64_t N, int RP, int nseg);
 int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream, int scan = 0);
 int pioran_tp_scan_rows(int RP);
+// where pioran_launch_tp(.., scan != 0) leaves the scan's largest discrepancy per draw ([B], inside `work`), and the threshold it is held against
+const double* pioran_tp_disc(const double* work, int64_t B, int64_t N, int RP, int nseg);
+double pioran_tp_scan_tol(const ScanOptions* opt);
 size_t pioran_tile_grad_workspace_doubles(int64_t B, int64_t N, int32_t R);
 int pioran_launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab, double* pairs, double* grad_a, double* grad_b, double* grad_nu,
                             double* grad_mu, double* grad_c, double* grad_d, hipStream_t stream);

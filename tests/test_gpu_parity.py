@@ -2098,8 +2098,9 @@ def test_time_parallel_boundary_scan_vs_walk_and_oracle(ctx, J, N, B, nreal, nse
     """Round 6: the boundary phase as a Kogge-Stone scan over the segments' elements (tp_combine_kernel), 5 .. 48 state rows padded to a multiple of 8,
     against the boundary walk (tp_scan = 0) and the oracle: segment counts that are not powers of two, 2 segments (one level), the cap of 256, one and
     two draws, four when forced (tp_scan = 1), one-row terms, padded rows; 49 .. 64 rows (DRWCelerite-20 is 60) on tp_combine_lean_kernel (operands from global
-    memory: the form that fits the LDS there), which tp_scan_lean = 1 also puts under the smaller shapes.  With tp_scan_tol tiny every prefix fails
-    the verification launch and the walk runs after the scan: bit-identical to the walk alone."""
+    memory: the form that fits the LDS there), which tp_scan_lean = 1 also puts under the smaller shapes.  With tp_scan_tol negative every draw counts as
+    having failed the verification launch and is repaired: by the serial-chain windowed kernel (bit-identical to "no_tp") or, with tp_walk_repair, by the
+    family's boundary walk (bit-identical to the walk alone)."""
     name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
     rng = np.random.default_rng(6600 + J + N)
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
@@ -2117,10 +2118,18 @@ def test_time_parallel_boundary_scan_vs_walk_and_oracle(ctx, J, N, B, nreal, nse
         ctx.set_option("tp_scan_lean", 0)
         ctx.set_option("tp_scan", 0)
         walk = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
-        ctx.set_option("tp_scan", 1); ctx.set_option("tp_scan_tol", 1e-300)
+        ctx.set_option("tp_scan", 1); ctx.set_option("tp_scan_tol", -1.0)    # (negative: every draw counts as failed — well-conditioned draws pass with discrepancy 0)
+        repaired = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert name() == "tp"
+        ctx.set_option("tp_walk_repair", True)
         both = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        ctx.set_option("scan_config", None); ctx.set_option("no_tp", True)
+        chain = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
+        assert name() == "block"
     finally:
         ctx.set_option("scan_config", None); ctx.set_option("tp_segments", 0); ctx.set_option("tp_scan", -1); ctx.set_option("tp_scan_tol", 0); ctx.set_option("tp_scan_lean", 0)
+        ctx.set_option("tp_walk_repair", False); ctx.set_option("no_tp", False)
+    assert np.array_equal(repaired, chain)                 # (every draw through the repair pass: the serial-chain kernel's own values)
     assert (st == 0).all()
     assert relerr(scan, ref) < 1e-11 and relerr(walk, ref) < 1e-11 and relerr(scan, walk) < 1e-11 and relerr(lean, scan) < 1e-12
     rows = 2 * J - nreal

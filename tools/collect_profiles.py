@@ -11,7 +11,7 @@ root = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(root))
 import bench  # noqa: E402  (scan_source_hash)
 
-ROUND = sys.argv[2] if len(sys.argv) > 2 else "r05"
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "r06"
 src = Path(sys.argv[1]) if len(sys.argv) > 1 else root / "gpurun_out" / ROUND
 prof = root / "profiles"
 for tag, basis in (("sho", "SHO"), ("drwcelerite", "DRWCelerite")):

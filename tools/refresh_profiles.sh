@@ -4,7 +4,7 @@
 # tools/collect_profiles.py + a plain cp of extra/*.  ROUND defaults to r03.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r06}
 X=$ROOT/gpurun_out/$ROUND/extra
 mkdir -p "$X"
 cd "$ROOT"

@@ -4,7 +4,7 @@
 # writes the summaries the judge reads into profiles/.  The program sits directly after `--` (no env/bash hop).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
