@@ -443,8 +443,11 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
             for (int c = scan_cap; c > 1; c >>= 1) ++lv;
             // (17 .. 32 rows: two combinations and eight phase wavefronts share a CU at the cap — measured 1.5 x the steps' time there)
             const double load = RP > 16 && RP <= 32 ? (double)p.B * scan_cap * 4.0 / 1024.0 : 1.0, rp = 1.0 + 0.5 * (load > 1.0 ? load - 1.0 : 0.0);
-            const double t_scan = 35.0 + rp * tau * (double)p.N / scan_cap + (lv + 1) * tc;
+            double t_scan = 35.0 + rp * tau * (double)p.N / scan_cap + (lv + 1) * tc;
             const double s_chain = RP <= 8 ? 0.127 : (RP <= 24 ? 0.178 : (RP <= 40 ? 0.19 : (RP <= 48 ? 0.24 : (p.R + 1 > 64 ? 0.46 : 0.25))));
+            // models with one-row terms (DRWCelerite): 3 .. 4 % of their prior draws fail the scan's check (profiles/r06_time_parallel_scan.txt section 11) and one
+            // failing draw sends the launch through the serial chain as well — its expected share
+            if (nrows != 2 * J) t_scan += (1.0 - std::pow(0.96, (double)p.B)) * s_chain * (double)p.N;
             scanned_b = (int64_t)scan_cap * 16 <= p.N && t_scan < (RP <= 8 ? 0.75 : 0.85) * s_chain * (double)p.N;
         }
         if (!few && !mid && !many && !(scanned && p.B <= 2) && !scanned_b) return PIORAN_ERR_UNSUPPORTED;

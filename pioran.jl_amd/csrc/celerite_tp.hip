@@ -194,7 +194,7 @@ struct TpStage {
 template <int NP, int NWV>     // NWV wavefronts per workgroup (1: up to 16 rows, no barrier at all; 4: up to 64), NP column pairs per wavefront: RP = 2 NP NWV
 __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, int nseg, int64_t L, const int32_t* __restrict__ row_kind,
                                                              const TpRec* __restrict__ rec, const TpStep* __restrict__ stp, const double* __restrict__ bnd,
-                                                             double* __restrict__ part, double* __restrict__ sval)
+                                                             double* __restrict__ part, double* __restrict__ sval, double* __restrict__ disc)
 {
     using Stage = TpStage<NWV>;
     constexpr int CH = Stage::CH;
@@ -313,6 +313,42 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
     if (threadIdx.x == 0) {
         double* o = part + (b * nseg + seg) * 4;
         o[0] = quad; o[1] = ldsum; o[2] = (double)bad; o[3] = 0.0;
+    }
+    // The scan's check, for free (round 6; disc != nullptr behind the scan form of phase 2): the filter has just carried the scan's state at boundary `seg`
+    // through the segment — that IS the state at boundary seg + 1, by the sequential arithmetic.  Its distance from the scan's own state there, relative to the
+    // state's largest entries (the mean against its own scale and the standard deviation the covariance implies), goes to the draw's maximum: what
+    // tp_combine_kernel's verification launch measured with one boundary step per boundary, without that launch (40 / 84 us at 40 / 60 rows).
+    if (disc && seg + 1 < nseg) {
+        const double* b2 = bs + TP_BND_DOUBLES;
+        double dP = 0.0, sP = 0.0, dm = 0.0, sm = 0.0;
+        if (lane < RP) {
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                const int c0 = 2 * (NWV * s + w);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const double o = b2[64 + lane * 64 + c0 + k], dd = fabs(P[s][k] - o);
+                    dP = fmax(dP, dd >= 0.0 ? dd : __builtin_inf()); sP = fmax(sP, fabs(o));       // (fmax drops a NaN: a state that is not a number must fail)
+                }
+            }
+            const double o = b2[lane];
+            dm = fabs(m - o); dm = dm >= 0.0 ? dm : __builtin_inf(); sm = fabs(o);
+        }
+        dP = tp_max(dP); sP = tp_max(sP); dm = tp_max(dm); sm = tp_max(sm);
+        if constexpr (NWV > 1) {
+            TP_BARRIER();
+            if (lane == 0) { red[0][w][0] = dP; red[0][w][1] = sP; red[0][w][2] = dm; red[0][w][3] = sm; }
+            TP_BARRIER();
+            dP = fmax(fmax(red[0][0][0], red[0][1][0]), fmax(red[0][2][0], red[0][3][0])); sP = fmax(fmax(red[0][0][1], red[0][1][1]), fmax(red[0][2][1], red[0][3][1]));
+            dm = fmax(fmax(red[0][0][2], red[0][1][2]), fmax(red[0][2][2], red[0][3][2])); sm = fmax(fmax(red[0][0][3], red[0][1][3]), fmax(red[0][2][3], red[0][3][3]));
+        }
+        if (threadIdx.x == 0) {
+            double rel = dP / (sP > 0.0 ? sP : 1.0);
+            const double mscale = fmax(sm, sqrt(sP));
+            rel = fmax(rel, dm / (mscale > 0.0 ? mscale : 1.0));
+            if (!(rel >= 0.0)) rel = 1.0;
+            atomicMax(reinterpret_cast<unsigned long long*>(disc + b), (unsigned long long)__double_as_longlong(rel));
+        }
     }
 }
 
@@ -1558,6 +1594,7 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
     static size_t granted[8][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PIORAN_ERR_HIP;
+    double* filter_disc = nullptr;
     if (scan && nseg >= 2 && pioran_tp_scan_rows(RP)) {
         // phase 2 as a scan: ceil(log2 nseg) launches of tp_combine_kernel, one workgroup per (draw, target)
         const int rt = (RP + 15) / 16;
@@ -1601,15 +1638,19 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
             src = dst;
             dst = dst == elem2 ? elem3 : elem2;
         }
-        // the check (one boundary step per boundary from the scan's states, all at once) and, for the draws that fail it, the walk
-        combine(dim3((unsigned)(nseg - 1), (unsigned)B), 1, elem, nullptr, disc);
+        // the check and what happens to the draws that fail it
         if (scan == 2) {
-            // (the caller repairs the draws that fail the check itself: capi.hip tp_dispatch, the serial-chain kernel with ScanParams::only_if)
+            // the caller repairs the draws that fail the check itself (capi.hip tp_dispatch: the serial-chain kernel with ScanParams::only_if), so the check can
+            // wait for the filter, which makes it on its way (tp_filter_kernel's `disc`) — no verification launch.  Otherwise: one boundary step per boundary
+            // from the scan's states, all at once (tp_combine_kernel's verify mode), and the walk for the draws that fail it, before the filter runs
+            filter_disc = disc;
         } else if (RP <= 16) {
+            combine(dim3((unsigned)(nseg - 1), (unsigned)B), 1, elem, nullptr, disc);
 #define TP_WAVE_CASE(RR) case RR: hipLaunchKernelGGL((tp_boundary_wave_kernel<RR>), dim3((unsigned)B), dim3(64), 0, stream, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)disc, tol); break;
             switch (RP) { TP_WAVE_CASE(8) TP_WAVE_CASE(16) default: return PIORAN_ERR_UNSUPPORTED; }
 #undef TP_WAVE_CASE
         } else {
+            combine(dim3((unsigned)(nseg - 1), (unsigned)B), 1, elem, nullptr, disc);
             const void* fn = rt == 2 ? (const void*)tp_boundary_kernel<4, 2> : (rt == 3 ? (const void*)tp_boundary_kernel<4, 3> : (const void*)tp_boundary_kernel<4, 4>);
             if (lds2 > granted[rt][dev]) {
                 if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return PIORAN_ERR_HIP;
@@ -1649,7 +1690,7 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
             hipLaunchKernelGGL((tp_boundary_kernel<4, 4>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)nullptr, 0.0);
     }
     hipLaunchKernelGGL((tp_filter_kernel<NP, NWV>), dim3((unsigned)nseg, (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
-                       (const TpRec*)rec, (const TpStep*)stp, (const double*)bnd, part, sval);
+                       (const TpRec*)rec, (const TpStep*)stp, (const double*)bnd, part, sval, filter_disc);
     hipLaunchKernelGGL(tp_finish_kernel, dim3((unsigned)B), dim3(64), 0, stream, N, nseg, B, (const double*)part, p.out, p.status);
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
