@@ -45,8 +45,8 @@ namespace {
 constexpr int kTileMaxTerms = 64;
 constexpr int kTileWaves = 4;      // wavefronts (= draws) per workgroup
 // ... of the reverse mode: T_k and T- of a draw are 45 KB (53 with d/d(c, d)) of LDS at four block columns — three draws fit a CU, not four
-template <int NB>
-constexpr int tile_adj_waves() { return NB <= 3 ? 4 : 3; }
+template <int NB, bool CD = false>
+constexpr int tile_adj_waves() { return NB <= 3 ? 4 : (CD ? 2 : 3); }
 
 typedef unsigned int tile_u32x2 __attribute__((ext_vector_type(2)));
 // 8 bytes through a buffer resource: per-lane byte offset in a VGPR (constant over the kernel), everything that moves (window, block, register
@@ -457,6 +457,10 @@ struct TileAdjWave {
                                                            // diagonal) and transposed (above it) — registers hold T_k only on its way here
     double upB[NB > 1 ? NB * (NB - 1) / 2 : 1][16 * 18];   // strictly lower tiles of T-
     double mw[CD ? NB : 1][CD ? 256 : 1];                  // d/d(c, d): M' of the window, C/D order [register][lane] (x goes on to hold X', then Q')
+    double accd[CD ? 2 * NB : 1][CD ? 64 : 1];             // ... its per-lane sums (d/dc rows | d/dd rows of block column Jc) and the window's time stamps t_n, t_b, t_e:
+    double tm[CD ? 24 : 1];                                //     in LDS, not in registers (24 live registers less: 175 -> 90 spilled, 4096 chains of SHO-20 84 -> 69 ms)
+    double acab[2 * NB][64];                               // per-lane sums of d/dal | d/dbe of block column Jc, the same move for both instantiations: 43 -> 1 spilled
+                                                           // registers without d/d(c, d), 90 -> 4 with (53.7 -> 49.9 ms, 69 -> 57 ms per 4096 chains of SHO-20)
 };
 
 // CD (round 6): also the ROW part of d/d(c_t, d_t) with (c, d) shared by the chains (the formulas of celerite_block_adjoint_kernel<.., CD>:
@@ -464,7 +468,7 @@ struct TileAdjWave {
 //   d/dd_r += s_r sum_n t_n (U~-'[n][r] (al_r C x - be_r C v)[n][r] + X-'[n][r] ((C_K / C) x)[n][r]),  s_r = -1 (cos row), +1 (sin row));
 // the pair part (d/dc E = -tau E, d/dd (E.cos, E.sin) = tau (-E.sin, E.cos)) is the post-pass's second product (tile_pairs_grad_kernel<true>).
 template <int NB, bool CD = false>
-__global__ void __launch_bounds__(64 * tile_adj_waves<NB>(), 1) celerite_tile_adjoint_kernel(const ScanParams p, const double* __restrict__ btab,
+__global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_tile_adjoint_kernel(const ScanParams p, const double* __restrict__ btab,
                                                                                                   const double* __restrict__ gtab, double* __restrict__ pairs,
                                                                                                   double* __restrict__ grad_a, double* __restrict__ grad_b,
                                                                                                   double* __restrict__ grad_nu, double* __restrict__ grad_mu,
@@ -477,7 +481,7 @@ __global__ void __launch_bounds__(64 * tile_adj_waves<NB>(), 1) celerite_tile_ad
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, q = lane >> 4, c16 = lane & 15;
-    const int64_t b = (int64_t)blockIdx.x * tile_adj_waves<NB>() + w;
+    const int64_t b = (int64_t)blockIdx.x * tile_adj_waves<NB, CD>() + w;
     if (b >= p.B) return;
     const int64_t N = p.N;
     const int J = p.J, R = p.R;
@@ -523,13 +527,15 @@ __global__ void __launch_bounds__(64 * tile_adj_waves<NB>(), 1) celerite_tile_ad
     d4 Tb[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) Tb[i] = d4{0.0, 0.0, 0.0, 0.0};
-    double acc_al[NB], acc_be[NB];
 #pragma unroll
-    for (int Jc = 0; Jc < NB; ++Jc) { acc_al[Jc] = 0.0; acc_be[Jc] = 0.0; }
+    for (int Jc = 0; Jc < 2 * NB; ++Jc) sw.acab[Jc][lane] = 0.0;
     double acc_mu = 0.0, acc_sa = 0.0, acc_nu = 0.0;
-    [[maybe_unused]] double acc_c[NB], acc_d[NB];
+    if constexpr (CD) {
 #pragma unroll
-    for (int Jc = 0; Jc < NB; ++Jc) { acc_c[Jc] = 0.0; acc_d[Jc] = 0.0; }
+        for (int Jc = 0; Jc < 2 * NB; ++Jc) sw.accd[Jc][lane] = 0.0;
+    }
+    [[maybe_unused]] auto add_c = [&](int Jc, double v) __attribute__((always_inline)) { sw.accd[Jc][lane] += v; };
+    [[maybe_unused]] auto add_d = [&](int Jc, double v) __attribute__((always_inline)) { sw.accd[NB + Jc][lane] += v; };
     [[maybe_unused]] constexpr int OFF_H = 2 * NB * 256 + 16 * NB + 16, OFF_TM = OFF_H + 2 * NB * 256;     // gtab: (C_K / C) o v | (C_K / C) o x | t_n x 16, t_b, t_e
     int pidx[4];
 #pragma unroll
@@ -822,12 +828,9 @@ __global__ void __launch_bounds__(64 * tile_adj_waves<NB>(), 1) celerite_tile_ad
         double wa[NB][4];          // W' in A-operand order
         // d/d(c, d), round 6: the three groups of terms sit where their factor is consumed anyway — X-' here, U~-' in phase D, T- o T_k in the update — so
         // that no operand's life grows (all of them in phase D: 334 spilled registers, the reverse kernel twice as slow)
-        [[maybe_unused]] double tnw[4], tbw = 0.0, tew = 0.0;
         if constexpr (CD) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) tnw[g] = tile_bload(rs_gt, (4 * g + q) * 8, gso + OFF_TM * 8);
-            tbw = tile_bload(rs_gt, 0, gso + (OFF_TM + 16) * 8);
-            tew = tile_bload(rs_gt, 0, gso + (OFF_TM + 17) * 8);
+            if (lane < 18) sw.tm[lane] = tile_bload(rs_gt, lane8, gso + OFF_TM * 8);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
 #pragma unroll
         for (int Jc = 0; Jc < NB; ++Jc) {
@@ -853,14 +856,17 @@ __global__ void __launch_bounds__(64 * tile_adj_waves<NB>(), 1) celerite_tile_ad
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) wa[Jc][ks] = sw.scr[c16 * 18 + 4 * ks + q];
             if constexpr (CD) {             // the X-' terms: -sum X-' V^' (t_e - t_n), + sum t_n X-' ((C_K / C) x), and cK-_r's  - sum X-' M'  times  -cK_r (t_e - t_b)
-                double xm = 0.0;
+                double xm = 0.0, pc = 0.0, pd = 0.0;
+                const double tbw = sw.tm[16], tew = sw.tm[17];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+                    const double tn = sw.tm[4 * g + q];
                     xm = fma(xb[Jc][g], sw.mw[Jc][g * 64 + lane], xm);
-                    acc_c[Jc] = fma(-xb[Jc][g] * hvw[g], tew - tnw[g], acc_c[Jc]);
-                    acc_d[Jc] = fma(tnw[g] * xb[Jc][g], hxw[g], acc_d[Jc]);
+                    pc = fma(-xb[Jc][g] * hvw[g], tew - tn, pc);
+                    pd = fma(tn * xb[Jc][g], hxw[g], pd);
                 }
-                acc_c[Jc] = fma(xm * ckc, tew - tbw, acc_c[Jc]);
+                add_c(Jc, fma(xm * ckc, tew - tbw, pc));
+                add_d(Jc, pd);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -886,17 +892,27 @@ __global__ void __launch_bounds__(64 * tile_adj_waves<NB>(), 1) celerite_tile_ad
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) ub = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[I][ks], bt[ks], ub, 0, 0, 0);
             }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                acc_al[Jc] = fma(ub[g], cvs[Jc][g], acc_al[Jc]);
-                acc_be[Jc] = fma(ub[g], cxs[Jc][g], acc_be[Jc]);
-            }
-            if constexpr (CD) {             // the U~-' terms of d/d(c, d) (the X-' terms: phase C; the T- o T_k term: the update below)
+            {
+                double pa = 0.0, pb = 0.0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    acc_c[Jc] = fma(-ub[g] * uw[Jc][g], tnw[g] - tbw, acc_c[Jc]);
-                    acc_d[Jc] = fma(tnw[g] * ub[g], fma(myab[Jc].x, cxs[Jc][g], -myab[Jc].y * cvs[Jc][g]), acc_d[Jc]);
+                    pa = fma(ub[g], cvs[Jc][g], pa);
+                    pb = fma(ub[g], cxs[Jc][g], pb);
                 }
+                sw.acab[Jc][lane] += pa;
+                sw.acab[NB + Jc][lane] += pb;
+            }
+            if constexpr (CD) {             // the U~-' terms of d/d(c, d) (the X-' terms: phase C; the T- o T_k term: the update below)
+                double pc = 0.0, pd = 0.0;
+                const double tbw = sw.tm[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const double tn = sw.tm[4 * g + q];
+                    pc = fma(-ub[g] * uw[Jc][g], tn - tbw, pc);
+                    pd = fma(tn * ub[g], fma(myab[Jc].x, cxs[Jc][g], -myab[Jc].y * cvs[Jc][g]), pd);
+                }
+                add_c(Jc, pc);
+                add_d(Jc, pd);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -918,13 +934,14 @@ __global__ void __launch_bounds__(64 * tile_adj_waves<NB>(), 1) celerite_tile_ad
                     double s1 = 0.0;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) s1 = fma(Tb[tix(I, Jc)][g] * sw.ck[16 * I + 4 * g + q], sw.tk[tix(I, Jc)][(4 * g + q) * 18 + c16], s1);
-                    acc_c[Jc] = fma(-2.0 * s1 * ckc, tew - tbw, acc_c[Jc]);
+                    const double tspan = sw.tm[17] - sw.tm[16];
+                    add_c(Jc, -2.0 * s1 * ckc * tspan);
                     if (Jc < I) {
                         double s2 = 0.0;
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
                             s2 = fma(sw.upB[uix(I, Jc)][c16 * 18 + 4 * g + q] * sw.ck[16 * Jc + 4 * g + q], sw.tk[tix(I, Jc)][c16 * 18 + 4 * g + q], s2);
-                        acc_c[I] = fma(-2.0 * s2 * sw.ck[16 * I + c16], tew - tbw, acc_c[I]);
+                        add_c(I, -2.0 * s2 * sw.ck[16 * I + c16] * tspan);
                     }
                 }
 #pragma unroll
@@ -948,14 +965,14 @@ __global__ void __launch_bounds__(64 * tile_adj_waves<NB>(), 1) celerite_tile_ad
     // ---- reductions: steps -> rows -> terms --------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int Jc = 0; Jc < NB; ++Jc) {
-        sw.red[16 * Jc + c16][q] = acc_al[Jc];
+        sw.red[16 * Jc + c16][q] = sw.acab[Jc][lane];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     double row_al = 0.0, row_be = 0.0;     // lane r < 16 NB (two rounds when NB > 4 is not reached here: 16 NB <= 64)
     if (lane < 16 * NB) row_al = (sw.red[lane][0] + sw.red[lane][1]) + (sw.red[lane][2] + sw.red[lane][3]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int Jc = 0; Jc < NB; ++Jc) sw.red[16 * Jc + c16][q] = acc_be[Jc];
+    for (int Jc = 0; Jc < NB; ++Jc) sw.red[16 * Jc + c16][q] = sw.acab[NB + Jc][lane];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane < 16 * NB) row_be = (sw.red[lane][0] + sw.red[lane][1]) + (sw.red[lane][2] + sw.red[lane][3]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -970,12 +987,12 @@ __global__ void __launch_bounds__(64 * tile_adj_waves<NB>(), 1) celerite_tile_ad
     [[maybe_unused]] double row_c = 0.0, row_d = 0.0;
     if constexpr (CD) {
 #pragma unroll
-        for (int Jc = 0; Jc < NB; ++Jc) sw.red[16 * Jc + c16][q] = acc_c[Jc];
+        for (int Jc = 0; Jc < NB; ++Jc) sw.red[16 * Jc + c16][q] = sw.accd[Jc][lane];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane < 16 * NB) row_c = (sw.red[lane][0] + sw.red[lane][1]) + (sw.red[lane][2] + sw.red[lane][3]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int Jc = 0; Jc < NB; ++Jc) sw.red[16 * Jc + c16][q] = acc_d[Jc];
+        for (int Jc = 0; Jc < NB; ++Jc) sw.red[16 * Jc + c16][q] = sw.accd[NB + Jc][lane];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane < 16 * NB) row_d = (sw.red[lane][0] + sw.red[lane][1]) + (sw.red[lane][2] + sw.red[lane][3]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1174,8 +1191,8 @@ template <int NB>
 int launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab, double* pairs, double* grad_a, double* grad_b, double* grad_nu,
                      double* grad_mu, double* grad_c, double* grad_d, hipStream_t stream)
 {
-    constexpr size_t lds_f = tile_lds_bytes<NB>(), lds_r = tile_adj_lds_bytes<NB>(), lds_rc = tile_adj_waves<NB>() * sizeof(TileAdjWave<NB, true>);
-    constexpr int AW = tile_adj_waves<NB>();
+    constexpr size_t lds_f = tile_lds_bytes<NB>(), lds_r = tile_adj_lds_bytes<NB>(), lds_rc = tile_adj_waves<NB, true>() * sizeof(TileAdjWave<NB, true>);
+    constexpr int AW = tile_adj_waves<NB>(), AWC = tile_adj_waves<NB, true>();
     static_assert(lds_f <= 160 * 1024 && lds_r <= 160 * 1024 && lds_rc <= 160 * 1024, "one workgroup must fit a CU");
     static bool granted[64] = {};
     int dev = 0;
@@ -1196,7 +1213,7 @@ int launch_tile_grad(const ScanParams& p, const double* btab, const double* gtab
     hipLaunchKernelGGL((celerite_tile_kernel<NB, true>), dim3((unsigned)groups), dim3(64 * kTileWaves), lds_f, stream, p, btab, (const double*)pairs);
     const unsigned agroups = (unsigned)((p.B + AW - 1) / AW);
     if (cd) {
-        hipLaunchKernelGGL((celerite_tile_adjoint_kernel<NB, true>), dim3(agroups), dim3(64 * AW), lds_rc, stream, p, btab, gtab, pairs, grad_a, grad_b,
+        hipLaunchKernelGGL((celerite_tile_adjoint_kernel<NB, true>), dim3((unsigned)((p.B + AWC - 1) / AWC)), dim3(64 * AWC), lds_rc, stream, p, btab, gtab, pairs, grad_a, grad_b,
                            grad_nu, grad_mu, grad_c, grad_d);
         hipLaunchKernelGGL(tile_pairs_grad_kernel<true>, dim3((unsigned)((p.B + 15) / 16)), dim3(512), 0, stream, p, btab, rsb, tsp, (const double*)pairs, grad_a, grad_b,
                            grad_c, grad_d);

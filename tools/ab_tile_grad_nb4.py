@@ -41,7 +41,7 @@ for basis, nc in (("DRWCelerite", 20), ("SHO", 28), ("SHO", 20)):
     for cd in (False, True):
         res = {}
         for label, opt in (("tile", False), ("small-batch", True)):
-            ctx.set_option("no_tile", opt)
+            ctx.set_option("no_tile", opt); ctx.set_option("scan_config", None if opt else "tile")      # (the tile reverse mode forced: not the automatic choice past 47 rows)
             nb = 4096 if not opt else 1024
             g = ds.logl_grad(A[:nb], Bc[:nb], C, Dd, mu=mu[:nb], nu=nu[:nb], cd_grad=cd); k = name()
             w = []
@@ -49,7 +49,7 @@ for basis, nc in (("DRWCelerite", 20), ("SHO", 28), ("SHO", 20)):
                 t0 = time.perf_counter(); g = ds.logl_grad(A[:nb], Bc[:nb], C, Dd, mu=mu[:nb], nu=nu[:nb], cd_grad=cd); w.append(time.perf_counter() - t0)
             res[label] = g
             print(f"{basis}-{nc}: {nb} chains d/d(c,d)={cd} [{k}] {min(w) * 1e3:.1f} ms" + (f" = {min(w) * 1e3 / val:.2f} x the values" if not opt else f" (x 4 = {4 * min(w) * 1e3:.1f})"), flush=True)
-        ctx.set_option("no_tile", False)
+        ctx.set_option("no_tile", False); ctx.set_option("scan_config", None)
         gt, h = res["tile"], res["small-batch"]
         ok = (h["status"] == 0) & (gt["status"][:1024] == 0)
         for key in ("grad_a", "grad_c", "grad_d") if cd else ("grad_a",):
