@@ -403,7 +403,8 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     // 24 rows from 1536 (0.254 against 0.306), 32 from 2048 (0.32 against 0.42), 40 / 48 from 3072 (0.50 / 0.58 against 0.60 / 0.76; N = 1e4:
     // 0.64 / 0.76 against 1.87 / 2.40; N = 65536: 1.19 / 1.35 against 12.0 / 16.4).
     const int nrows = (int)term.size();
-    const bool scan_rows = nrows > 4 && nrows <= 64;
+    // (three and four rows — the reference grid's j = 2 — padded to eight: N = 8192 0.19 ms against 0.28 on the one-thread boundary walk; from 2048 steps on)
+    const bool scan_rows = (nrows > 4 || (nrows > 2 && p.B <= 2 && (p.N >= 2048 || o.tp_scan > 0))) && nrows <= 64;
     // Three to 32 draws (tools/tp_scan_batch_sweep.py, section 8 of the profile): the combinations of one level want a CU slot each — a CU holds kc = 4 / 2 / 1
     // workgroups of tp_combine_kernel at up to 8 / up to 32 / more rows (its LDS) — so the segment count is the largest power of two with B nseg <= 256 kc
     // (SHO-20, N = 1e4, 4 / 8 draws: 64 / 32 segments 0.76 / 1.06 ms against 1.50 / 1.53 on the walk and 1.85 on the serial chains; 128 segments 1.08 / 2.0).
@@ -432,7 +433,7 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
         const bool many = RP > 16 && ((p.B <= 2 && p.N >= nmin12) || (p.B <= 8 && p.N >= nmin8));
         // (49 .. 64 rows, tp_combine_lean_kernel: 56 / 60 rows from 4096 steps on — 0.89 / 1.02 against 1.03 / 1.08 ms; N = 1e4: 1.10 / 1.21 against 2.46 / 2.58;
         //  64 rows, five block columns on the serial chain, from 2048 — 0.89 against 0.98; N = 1e4: 1.21 against 4.6)
-        const bool scanned = scan && p.N >= (RP <= 16 ? 1024 : (RP <= 24 ? 1536 : (RP <= 32 ? 2048 : (RP <= 48 ? 3072 : (p.R + 1 > 64 ? 2048 : 4096)))));
+        const bool scanned = scan && p.N >= (nrows <= 4 ? 2048 : RP <= 16 ? 1024 : (RP <= 24 ? 1536 : (RP <= 32 ? 2048 : (RP <= 48 ? 3072 : (p.R + 1 > 64 ? 2048 : 4096)))));
         // three and more draws on the scan: a model of its time (records + two phases of N / nseg steps + one combination per level and the check, in us)
         // against the serial chain's time per step (measured at N = 1e4, resident inputs), taken when it promises 15 % off (up to 8 rows, where the model is
         // optimistic at 32 draws: a quarter) — profiles/r06_time_parallel_scan.txt section 8 has the sweep this was held against at N = 2048 / 4096 / 1e4
