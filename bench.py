@@ -123,6 +123,24 @@ def _numbers_only(o, depth=0):
     return o
 
 
+_FIGURES = ("ms", "ratio", "frac", "evals_per_s", "per_s", "rel", "speedup", "tflops")
+
+
+def _figures_only(o):
+    """A secondary section for the compact line: numbers whose key names a time, a rate, a ratio, a fraction or a deviation; sub-objects that keep none go."""
+    if not isinstance(o, dict):
+        return o
+    out = {}
+    for k, v in o.items():
+        if isinstance(v, dict):
+            sub = _figures_only(v)
+            if sub:
+                out[k] = sub
+        elif isinstance(v, (int, float)) and not isinstance(v, bool) and any(f in k for f in _FIGURES):
+            out[k] = v
+    return out
+
+
 def emit(result: dict) -> None:
     """Rank 0's output: the LONG form (every note and secondary measurement) to bench_full.json beside this file (and to
     $PIORAN_BENCH_FULL if set), ONE compact line of at most LINE_LIMIT bytes to stdout — the contract's keys first, then `roofline`, `cpu_baseline`,
@@ -152,9 +170,13 @@ def emit(result: dict) -> None:
             line[k] = result[k]
     line["full_form"] = "bench_full.json (notes, every secondary measurement); DESIGN.md section 7"
     if sec:
-        first = [k for k in sec if k.startswith(("drwcelerite", "sho", "dense_", "single_evaluation_B1", "few_draws", "small_batch_B256", "gradient_", "batch_sizes"))]
+        # BASELINE's other configurations first, in this order (whatever order the sections were measured in), then the rest; per section only the figures
+        # (times, rates, ratios, fractions, deviations) — counts, flop totals and kernel names are in bench_full.json
+        prio = ("drwcelerite", "sho", "dense_", "single_evaluation_B1", "gradient_", "few_draws", "small_batch_B256", "batch_sizes", "single_evaluation_long", "reference_benchmark")
+        first = [k for pre in prio for k in sec if k.startswith(pre)]
+        first = list(dict.fromkeys(first))
         sec = {**{k: sec[k] for k in first}, **{k: v for k, v in sec.items() if k not in first}}
-        line["secondary"] = _numbers_only(sec)
+        line["secondary"] = _figures_only(_numbers_only(sec))
         order = list(line["secondary"].keys())
         while len(json.dumps(line)) > LINE_LIMIT and order:
             line["secondary"].pop(order.pop())          # from the end: the least BASELINE-relevant sections are last

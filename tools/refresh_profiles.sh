@@ -26,7 +26,7 @@ BASIS=DRWCelerite run small_batch_latency_drw20.json python3 tools/bench_small_b
 run host_api_pcie_inclusive.json python3 tools/bench_host_api.py
 run dense_n4096_j40.json python3 tools/bench_dense.py
 run dense_batched_launches.txt python3 tools/sweep_dense_streams.py
-run bench_default_full_line.json python3 bench.py
+PIORAN_BENCH_FULL=$X/bench_full.json run bench_default_full_line.json python3 bench.py
 fi
 if [[ $PART == all || $PART == 2 ]]; then
 timeout -k 10 900 python3 tools/bench_grid.py > "$X/grid.json" 2> "$X/grid.json.err" || echo "grid failed" >&2
