@@ -90,12 +90,21 @@ int pioran_ctx_trim(pioran_ctx* ctx);
  *   "no_tile"         value "1": never the windowed form with one draw per wavefront (celerite_tile.hip); "scan_config" = "tile" forces it for
  *                     every launch it can take
  *   "no_tp"           value "1": never the time-parallel evaluation (celerite_tp.hip: segments of the series on different CUs, for a handful of
- *                     draws of a long series — automatic for up to 8 draws with up to 4 / 8 / 12 / 16 state rows from 1024 / 2048 / 4096 / 6144 steps on, up to 64 draws at up to 4 rows from 4096, up to 8 draws with up to 24 / 32 / 40 / 48 / 64 rows from 5120 / 6144 / 8192 / 8192 / 12288);
+ *                     draws of a long series).  Automatic choice, round 6 (its boundary phase as a scan over the segments' elements): one or two draws with
+ *                     3-4 / 5-16 / 24 / 32 / 40-48 / 56-64 state rows from 2048 / 1024 / 1536 / 2048 / 3072 / 4096 steps on, 3 .. 32 draws where a model of its
+ *                     time promises 15 % against the serial chains; with the boundary walk of round 5: up to 8 draws with up to 4 / 8 / 12 / 16 state rows
+ *                     from 1024 / 2048 / 4096 / 6144 steps on, up to 64 draws at up to 4 rows from 4096, up to 8 draws with up to 24 / 32 / 40 / 48 / 64 rows from
+ *                     5120 / 6144 / 8192 / 8192 / 12288;
  *                     "scan_config" = "tp" forces it wherever it applies (shared (c, d), up to 64 state rows, up to 64 draws);
- *                     "tp_segments" its segment count (0 / NULL = automatic)
+ *                     "tp_segments" its segment count (0 / NULL = automatic);
+ *                     "tp_scan" -1 (default) automatic, 0 the boundary walk, 1 the scan wherever the rows allow (3 .. 64);
+ *                     "tp_scan_tol" the scan's acceptance threshold: a draw whose boundary states differ from the sequential filter's by more (relative) is
+ *                     evaluated again on the serial chain (0 / NULL = 1e-6; negative: every draw — tests); "tp_walk_repair" = "1": by the family's own
+ *                     boundary walk instead; "tp_scan_lean" = "1", "tp_scan_waves" = "4": the forms of the combination kernel that are the default only at
+ *                     49 .. 64 rows / up to 16 rows (tests, tools)
  *   "dense_old_chain" 0 one launch per block column (default), 1 the panel / update chain of rounds 1-3 (2 .. 8: timing experiments, only in
  *                     builds with -DPIORAN_EXPERIMENTS; PIORAN_ERR_ARG otherwise);
- *                     "dense_no_pairs", "dense_no_halves", "dense_quad_threshold", "dense_batch_pair_threshold", "dense_streams": schedule knobs
+ *                     "dense_no_pairs", "dense_no_halves", "dense_pair_tiles", "dense_half_tile_limit", "dense_quad_threshold", "dense_batch_pair_threshold", "dense_streams": schedule knobs
  *   "block_emode", "gsum", "exp"   tuning / experiment selectors of single kernels (tools/ only; "exp" can make results meaningless)
  * Initial values come from the environment variables PIORAN_SCAN_CONFIG, PIORAN_NO_WIDE, PIORAN_NO_BLOCK, PIORAN_NO_TILE, PIORAN_NO_TP, PIORAN_NO_PAIRED,
  * PIORAN_NO_MIXED, PIORAN_FORCE_FALLBACK, PIORAN_WIN2, PIORAN_NO_WIN2, PIORAN_GSUM, PIORAN_WIDE2, read once when the context is created. */
