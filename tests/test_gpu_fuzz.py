@@ -296,3 +296,48 @@ def test_fuzz_64_to_143_rows_gradient_prediction_simulation_vs_oracle(capsys):
     with capsys.disabled():
         print(f"\n64..143-row fuzz: 40 cases, worst deviations from the oracle {worst}", file=sys.stderr)
     assert worst["grad"] < 1e-8 and worst["pred"] < 1e-8 and worst["sim"] < 1e-9, worst
+
+
+def test_fuzz_time_parallel_scan_vs_oracle(capsys):
+    """Round 6: the time-parallel family with its boundary phase as a scan (forced: scan_config "tp", tp_scan 1) on 300 seeded random shapes — 2 .. 32 terms, some of
+    them one-row terms (3 .. 64 state rows, padded to a multiple of 8; 49 .. 64 rows on tp_combine_lean_kernel), N = 64 .. 3000 with occasional long gaps, 1 .. 4 draws, segment
+    counts 2 .. 40 or automatic, optional mu / nu — against the oracle: 1e-8 relative to max(1, |log L|) (observed ~1e-12), statuses equal; the check + repair pass is part of the
+    path (a draw the scan gets wrong must come back right)."""
+    import numpy as np
+    import pioran_jl_amd as pj
+    from oracle import oracle as O
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_gpu_parity import _random_case
+    ctx = pj.Context(0)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    worst, worst_case, ncases = 0.0, None, 300
+    try:
+        ctx.set_option("scan_config", "tp"); ctx.set_option("tp_scan", 1)
+        for idx in range(ncases):
+            rng = np.random.default_rng(991000 + idx)
+            J = int(rng.integers(2, 33)); nreal = int(rng.integers(0, J // 2 + 1)) if rng.random() < 0.5 else 0
+            N = int(rng.integers(64, 3001)); B = int(rng.integers(1, 5))
+            nseg = int(rng.integers(2, 41)) if rng.random() < 0.6 else 0
+            t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
+            if rng.random() < 0.3:                                   # a few long gaps
+                gaps = rng.integers(1, N, size=3)
+                dt = np.diff(t, prepend=t[0]); dt[gaps] *= rng.uniform(20.0, 200.0, 3); t = np.cumsum(dt)
+            Dd = np.maximum(Dd, 0.05)
+            Bc[:, :nreal] = 0.0; Dd[:nreal] = 0.0
+            use_mu = rng.random() < 0.7
+            ds = pj.Dataset(t, y, s2, ctx)
+            ctx.set_option("tp_segments", nseg)
+            got, st = ds.logl_batch(A, Bc, C, Dd, mu=mu if use_mu else None, nu=nu if use_mu else None, return_status=True)
+            assert name() == "tp", (idx, J, N, B, nreal, nseg, name())
+            ref, rst = O.logl_batch(A, Bc, C, Dd, t, y, s2, mu if use_mu else None, nu if use_mu else None, return_status=True)
+            ds.close()
+            assert np.array_equal(st != 0, rst != 0), (idx, st, rst)
+            ok = rst == 0
+            if ok.any():
+                dev = float(np.max(np.abs(got[ok] - ref[ok]) / np.maximum(1.0, np.abs(ref[ok]))))
+                if dev > worst: worst, worst_case = dev, (idx, J, N, B, nreal, nseg)
+    finally:
+        ctx.set_option("scan_config", None); ctx.set_option("tp_scan", -1); ctx.set_option("tp_segments", 0)
+    with capsys.disabled():
+        print(f"\nfuzz, time-parallel scan: {ncases} cases, worst deviation {worst:.2e} at (case, J, N, B, one-row terms, segments) = {worst_case}", file=sys.stderr)
+    assert worst < 1e-8

@@ -2176,6 +2176,38 @@ def test_time_parallel_scan_flagged_draw_and_ill_conditioned_reference_points(ct
     assert worst < 1e-10, worst
 
 
+def test_time_parallel_scan_check_and_repair_on_prior_draws(ctx, full_size):
+    """BASELINE configs[1] as the product runs it (one draw, N = 1e4, automatic choice: the scan, its check by the filter, the repair pass on the serial chain) on 160 prior
+    draws of DRWCelerite-20 (60 rows: tp_combine_lean_kernel) and DRWCelerite-10 — the models on which the scan ALONE is wrong for a few per cent of the prior
+    (profiles/r06_time_parallel_scan.txt sections 10, 11): every positive definite draw within the north star's 1e-8 of the oracle, statuses the oracle's.  With the check
+    switched off (tp_scan_tol huge) the same draws are evaluated again: where that result is off by more than 1e-8 the product path must have repaired it — the check is
+    what stands between the scan and the bar."""
+    t, y, yerr = full_size
+    th = O.synthetic_theta(160, t, y, seed=909)
+    ds = pj.Dataset(t, y, yerr ** 2, ctx)
+    name = lambda: pj._lib.lib().pioran_celerite_config_name(-1).decode()
+    caught = 0
+    for ncomp in (20, 10):
+        A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, ncomp, "DRWCelerite")
+        ref, rst = O.logl_batch(A, Bc, C, Dd, t, y, yerr ** 2, mu, nu, nthreads=8, return_status=True)
+        got = np.empty(len(th)); st = np.empty(len(th), int); alone = np.empty(len(th))
+        for i in range(len(th)):
+            g, s_ = ds.logl_batch(A[i:i + 1], Bc[i:i + 1], C, Dd, mu=mu[i:i + 1], nu=nu[i:i + 1], return_status=True)
+            assert name() == "tp"
+            got[i], st[i] = g[0], s_[0]
+        try:
+            ctx.set_option("tp_scan_tol", 1e30)
+            for i in range(len(th)):
+                alone[i] = ds.logl_batch(A[i:i + 1], Bc[i:i + 1], C, Dd, mu=mu[i:i + 1], nu=nu[i:i + 1])[0]
+        finally:
+            ctx.set_option("tp_scan_tol", 0)
+        ok = rst == 0
+        assert np.array_equal(st != 0, rst != 0)
+        assert relerr(got[ok], ref[ok]) < 1e-8, (ncomp, relerr(got[ok], ref[ok]))
+        caught += int((np.abs(alone[ok] - ref[ok]) / np.abs(ref[ok]) > 1e-8).sum())
+    print(f"draws the scan alone gets wrong by more than 1e-8 (all repaired): {caught}")
+
+
 TILE_GRAD = "tile (windowed gradient, one draw per wavefront)"
 
 
