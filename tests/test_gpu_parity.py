@@ -2158,6 +2158,22 @@ def test_time_parallel_scan_flagged_draw_and_ill_conditioned_reference_points(ct
     assert sb[1] != 0 and rs[1] != 0 and sb[0] == 0
     assert abs(gb[0] - rb[0]) <= 1e-11 * abs(rb[0])
     assert (np.isnan(gb[1]) and np.isnan(rb[1])) or abs(gb[1] - rb[1]) <= 1e-6 * abs(rb[1])
+    # per-draw series (Y, S2) through the scan, and through its repair pass (every draw repaired: the serial-chain kernel's values)
+    A[1, 0] = 1.3
+    Y = y[None, :] + 0.01 * rng.standard_normal((B, N)); S2 = s2[None, :] * rng.uniform(0.8, 1.2, (B, 1))
+    gy = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+    assert name() == "tp"
+    ry = np.array([O.logl(A[i], Bc[i], C, Dd, t, Y[i] - mu[i], nu[i] * S2[i]) for i in range(B)])
+    assert relerr(gy, ry) < 1e-11
+    try:
+        ctx.set_option("tp_scan_tol", -1.0)
+        gr = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+        assert name() == "tp"
+        ctx.set_option("no_tp", True)
+        gc_ = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu, Y=Y, S2=S2)
+    finally:
+        ctx.set_option("tp_scan_tol", 0); ctx.set_option("no_tp", False)
+    assert np.array_equal(gr, gc_) and relerr(gr, ry) < 1e-11
     un = np.load(golden_dir / "ultranest_points.npz")
     sys.path.insert(0, str(Path(__file__).resolve().parent))
     from test_oracle import _un_inputs
