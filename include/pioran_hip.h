@@ -99,7 +99,7 @@ int pioran_ctx_trim(pioran_ctx* ctx);
  *                     "tp_segments" its segment count (0 / NULL = automatic);
  *                     "tp_scan" -1 (default) automatic, 0 the boundary walk, 1 the scan wherever the rows allow (3 .. 64);
  *                     "tp_scan_tol" the scan's acceptance threshold: a draw whose boundary states differ from the sequential filter's by more (relative) is
- *                     evaluated again on the serial chain (0 / NULL = 1e-6; negative: every draw — tests); "tp_walk_repair" = "1": by the family's own
+ *                     evaluated again on the serial chain (0 / NULL = 1e-5; negative: every draw — tests); "tp_walk_repair" = "1": by the family's own
  *                     boundary walk instead; "tp_scan_lean" = "1", "tp_scan_waves" = "4": the forms of the combination kernel that are the default only at
  *                     49 .. 64 rows / up to 16 rows (tests, tools)
  *   "dense_old_chain" 0 one launch per block column (default), 1 the panel / update chain of rounds 1-3 (2 .. 8: timing experiments, only in

@@ -446,9 +446,9 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
             const double load = RP > 16 && RP <= 32 ? (double)p.B * scan_cap * 4.0 / 1024.0 : 1.0, rp = 1.0 + 0.5 * (load > 1.0 ? load - 1.0 : 0.0);
             double t_scan = 35.0 + rp * tau * (double)p.N / scan_cap + (lv + 1) * tc;
             const double s_chain = RP <= 8 ? 0.127 : (RP <= 24 ? 0.178 : (RP <= 40 ? 0.19 : (RP <= 48 ? 0.24 : (p.R + 1 > 64 ? 0.46 : 0.25))));
-            // models with one-row terms (DRWCelerite): 3 .. 4 % of their prior draws fail the scan's check (profiles/r06_time_parallel_scan.txt section 11) and one
+            // models with one-row terms (DRWCelerite): 1.5 % of their prior draws fail the scan's check at its default threshold (profiles/r06_time_parallel_scan.txt section 11) and one
             // failing draw sends the launch through the serial chain as well — its expected share
-            if (nrows != 2 * J) t_scan += (1.0 - std::pow(0.96, (double)p.B)) * s_chain * (double)p.N;
+            if (nrows != 2 * J) t_scan += (1.0 - std::pow(0.985, (double)p.B)) * s_chain * (double)p.N;
             scanned_b = (int64_t)scan_cap * 16 <= p.N && t_scan < (RP <= 8 ? 0.75 : 0.85) * s_chain * (double)p.N;
         }
         if (!few && !mid && !many && !(scanned && p.B <= 2) && !scanned_b) return PIORAN_ERR_UNSUPPORTED;
@@ -491,8 +491,8 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     q.C = s->dc; q.D = s->dd; q.J = J; q.opt = &ctx->opt;
     g_last_kernel = "tp";
     const int32_t* dr = (const int32_t*)ctx->btprow.p;
-    // A draw whose scan fails its check (tp_combine_kernel's verification launch: ~5 % of the prior draws of DRWCelerite-20, whose scan alone is off by up to
-    // 1e-5 there; none of 96 at SHO-20 / SHO-28 — tools/tp_scan_tol2.py) is evaluated again.  By the family's own boundary walk that costs 15 ms at 128
+    // A draw whose scan fails its check (made by the filter on its way: tp_filter_kernel's `disc`; 1.5 % of the prior draws of the DRWCelerite models, whose scan
+    // alone is off by 1e-6 .. O(1) on a few of them; none of 1500 draws of the SHO models — tools/tp_scan_accept.py) is evaluated again.  By the family's own boundary walk that costs 15 ms at 128
     // segments; the serial-chain windowed kernel does it in 2.5 (celerite_block_kernel with ScanParams::only_if: its workgroups leave at once for every draw
     // that passed), so that is the repair pass wherever that kernel takes the rows; the walk stays for the rest (option tp_walk_repair forces it).
     bool repair = scan && nseg >= 2 && !o.tp_walk_repair && !o.no_block && p.R >= 5 && pioran_block_fits_value(p.R, p.J) &&
