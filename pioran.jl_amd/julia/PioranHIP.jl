@@ -29,8 +29,8 @@ const USE_HIP = Ref(true)
 # 2.6 ms on the bench host; the reference's own figure: 0.85 / 1.6 / 3.7 ms — benchmark/benchmarks.jl:76-91, bench.py
 # "reference_benchmark_grid_N8192").  So scalar calls with fewer than PIORAN_HIP_MIN_ROWS rows (R = 2 J; default 9, i.e. up to four terms)
 # stay on Pioran's own code — unless the series is long: from PIORAN_HIP_MIN_STEPS steps on (default 3072) the library's time-parallel
-# family (celerite_tp.hip, round 5: segments of the series on different CUs) is ahead of one core at every term count (N = 8192: j = 2
-# 0.27 ms, j = 4 0.47 ms).  Batched calls (logpdf_batch and friends) always use the GPU.  PIORAN_HIP_MIN_ROWS = 0 sends everything to the GPU.
+# family (celerite_tp.hip: segments of the series on different CUs; round 6: boundary phase as a scan) is ahead of one core at every term count
+# (N = 8192: j = 2 0.19 ms, j = 4 0.18 ms; N = 4096: 0.21 / 0.17 ms against 0.29 / 0.60 on one core).  Batched calls (logpdf_batch and friends) always use the GPU.  PIORAN_HIP_MIN_ROWS = 0 sends everything to the GPU.
 const MIN_ROWS = Ref(9)
 const MIN_STEPS = Ref(3072)
 # rows the kernels execute: two per term, one for a term with b = d = 0 (Exp / DRW terms: src/Exp.jl:29-33, the DRW half of DRWCelerite src/psd.jl:270-273)
