@@ -51,6 +51,14 @@ struct __attribute__((aligned(32))) TpStep { double s, y, s2, yos; };           
 constexpr int TP_ELEM_DOUBLES = (3 * 64 + 2) * 64;     // A' | C | J (64 x 64 each, row-major, rows = lanes), b, eta
 constexpr int TP_BND_DOUBLES = 65 * 64;                // m | P (64 x 64 row-major)
 constexpr double kTpScanTol = 1e-5;                    // largest relative discrepancy between the scan's boundary states and the boundary steps from them (tp_combine_kernel)
+// Experiment builds only (-DPIORAN_TP_STAMP, tools/tp_combine_stamps.sh; never in the product library): s_memtime stamps of the phases of one combination
+// (the workgroup of target blockIdx.x == gridDim.x - 1, draw 0), read back through pioran_tp_read_stamps.
+#ifdef PIORAN_TP_STAMP
+__device__ unsigned long long tp_stamp_buf[32];
+#define TP_STAMP(i) do { if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && threadIdx.x == 0) tp_stamp_buf[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TP_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ double tp_readlane(double x, int l)
 {
@@ -847,7 +855,9 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_kernel(int RP, int nseg, i
             }
         }
     };
+    TP_STAMP(0);
     TP_BARRIER();
+    TP_STAMP(1);
     // ---- operands -----------------------------------------------------------------------------------------------------------------------------
     for (int q = tid; q < RP * RP; q += T) {
         const int r = q / RP, c = q % RP;
@@ -875,6 +885,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_kernel(int RP, int nseg, i
         if (prior && p == 1 && !disc) bs[tid] = 0.0;
     }
     TP_BARRIER();
+    TP_STAMP(2);
     // ---- W = I + C_i J_j, z = b_i + C_i eta_j, Z = C_i (, A_i) ----------------------------------------------------------------------------------
     gemm([&](int r, int kk) { return Pm[r * S1 + kk]; }, [&](int kk, int c) { return JL[kk * S1 + c]; },
          [&](int r, int c, double v) { X[r * LW + c] = v + (r == c ? 1.0 : 0.0); });
@@ -890,6 +901,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_kernel(int RP, int nseg, i
         X[tid * LW + RP] = acc;
     }
     TP_BARRIER();
+    TP_STAMP(3);
     // ---- Gauss-Jordan elimination, four pivots per barrier (tp_boundary_kernel) ------------------------------------------------------------------
     bool used = lane >= RP;
     int mycol = 0;
@@ -912,10 +924,12 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_kernel(int RP, int nseg, i
 #pragma unroll
             for (int jj = j + 1; jj < 4; ++jj) xp[jj] = fma(-f[j], tp_readlane(xp[jj], pr[j]), xp[jj]);
         }
+        if (k0 == 0) TP_STAMP(10);
         const double f01 = tp_readlane(f[0], pr[1]), f02 = tp_readlane(f[0], pr[2]), f03 = tp_readlane(f[0], pr[3]);
         const double f12 = tp_readlane(f[1], pr[2]), f13 = tp_readlane(f[1], pr[3]), f23 = tp_readlane(f[2], pr[3]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fneg[(w * 4 + j) * 64 + lane] = -f[j];
+        if (k0 == 0) TP_STAMP(11);
         for (int ct = w; k0 + 4 + 16 * ct < NC; ct += TW) {
             const int c0 = k0 + 4 + 16 * ct, col = c0 + li, cc = col < NC ? col : NC - 1;
             const double x0 = X[pr[0] * LW + cc], x1 = X[pr[1] * LW + cc], x2 = X[pr[2] * LW + cc], x3 = X[pr[3] * LW + cc];
@@ -937,8 +951,11 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_kernel(int RP, int nseg, i
                     if (col < NC && 16 * It + 4 * g + lk < RP) X[(16 * It + 4 * g + lk) * LW + col] = acc[It][g];
             }
         }
+        if (k0 == 0) TP_STAMP(12);
         TP_BARRIER();
+        if (k0 == 0) TP_STAMP(13);
     }
+    TP_STAMP(4);
     // row `lane` solved column mycol: Z into Pm (C_i is dead), z into mv, M A_i into WA
     if (lane < RP) {
         for (int c = w; c < RP; c += TW) {
@@ -948,6 +965,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_kernel(int RP, int nseg, i
         if (w == 0) mv[mycol] = X[lane * LW + RP] * mypiv;
     }
     TP_BARRIER();
+    TP_STAMP(5);
     // ---- vectors: b = A_j z + b_j;  v = eta_j - J_j b_i, Z v, v - J_j Z v (general mode) -----------------------------------------------------------
     double mnew = 0.0;
     if (tid < RP) {
@@ -988,6 +1006,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_kernel(int RP, int nseg, i
         w2[tid] = a2;
     }
     TP_BARRIER();
+    TP_STAMP(6);
     // C = T A_j' + C_j (Z is dead: into Pm), symmetrised on the way out
     gemm([&](int r, int kk) { return X[r * LW + kk]; }, [&](int kk, int c) { return kk < RP ? AL[kk * S1 + c] : 0.0; },
          [&](int r, int c, double v) { Pm[r * S1 + c] = v; });
@@ -1028,6 +1047,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_kernel(int RP, int nseg, i
         }
         if (tid < RP) { if (full) eo[12288 + tid] = mnew; else bo[tid] = mnew; }
     }
+    TP_STAMP(7);
     if (!full) return;                                       // (workgroup-uniform)
     TP_BARRIER();
     // ---- J = A_i' (J_j M A_i) + J_i, eta = A_i' (v - J_j Z v) + eta_i: A_i' into AL (A_j is dead) ---------------------------------------------------
@@ -1054,6 +1074,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_kernel(int RP, int nseg, i
         }
         if (tid < RP) eo[12288 + 64 + tid] = enew;
     }
+    TP_STAMP(8);
 }
 
 // The same combination for up to FOUR tiles of 16 rows (49 .. 64 state rows: DRWCelerite-20 is 60), where tp_combine_kernel's five matrices do not fit
@@ -1118,7 +1139,9 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_lean_kernel(int RP, int ns
         }
     };
     auto in = [&](int r, int c) { return r < RP && c < RP; };
+    TP_STAMP(0);
     TP_BARRIER();
+    TP_STAMP(1);
     // ---- operands: C_i into the Z block, A_i into the last block ------------------------------------------------------------------------------------
     for (int q = tid; q < RP * RP; q += T) {
         const int r = q / RP, c = q % RP;
@@ -1145,6 +1168,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_lean_kernel(int RP, int ns
         if (prior && p == 1 && !disc) bs[tid] = 0.0;
     }
     TP_BARRIER();
+    TP_STAMP(2);
     // ---- W = I + C_i J_j, z = b_i + C_i eta_j ------------------------------------------------------------------------------------------------------
     gemm([&](int r, int kk) { return in(r, kk) ? X[r * LW + ZC + kk] : 0.0; }, [&](int kk, int c) { return in(kk, c) ? ej[8192 + kk * 64 + c] : 0.0; },
          [&](int r, int c, double v) { X[r * LW + c] = v + (r == c ? 1.0 : 0.0); });
@@ -1155,6 +1179,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_lean_kernel(int RP, int ns
         X[tid * LW + RP] = acc;
     }
     TP_BARRIER();
+    TP_STAMP(3);
     // ---- Gauss-Jordan elimination, four pivots per barrier (tp_boundary_kernel) ------------------------------------------------------------------
     bool used = lane >= RP;
     int mycol = 0;
@@ -1204,6 +1229,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_lean_kernel(int RP, int ns
         }
         TP_BARRIER();
     }
+    TP_STAMP(4);
     // row `lane` solved column mycol: scaled in place, found again through rowof; z into mv
     if (lane < RP) {
         for (int c = w; c < NC - RP; c += TW) X[lane * LW + RP + c] *= mypiv;
@@ -1214,6 +1240,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_lean_kernel(int RP, int ns
     auto Zs = [&](int kk, int c) { return in(kk, c) ? X[rowof[kk] * LW + ZC + c] : 0.0; };        // Z = M C_i
     auto MA = [&](int kk, int c) { return in(kk, c) ? X[rowof[kk] * LW + MC + c] : 0.0; };        // M A_i
     TP_BARRIER();
+    TP_STAMP(5);
     // ---- vectors: b = A_j z + b_j;  v = eta_j - J_j b_i, Z v, v - J_j Z v (full combination) ---------------------------------------------------------
     double mnew = 0.0;
     if (tid < RP) {
@@ -1252,6 +1279,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_lean_kernel(int RP, int ns
         for (int k = 0; k < RP; ++k) a2 = fma(-ej[8192 + k * 64 + tid], zz[k], a2);
         w2[tid] = a2;
     }
+    TP_STAMP(6);
     // C = T A_j' + C_j (Z is dead — every wavefront is past its last read of it: into its block), symmetrised on the way out
     gemm([&](int r, int kk) { return in(r, kk) ? X[r * LW + kk] : 0.0; }, [&](int kk, int c) { return in(kk, c) ? ej[kk * 64 + c] : 0.0; },
          [&](int r, int c, double v) { X[r * LW + ZC + c] = v; });
@@ -1291,6 +1319,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_lean_kernel(int RP, int ns
         }
         if (tid < RP) { if (full) eo[12288 + tid] = mnew; else bo[tid] = mnew; }
     }
+    TP_STAMP(7);
     if (!full) return;                                       // (workgroup-uniform)
     // ---- J = A_i' (J_j M A_i) + J_i, eta = A_i' (v - J_j Z v) + eta_i  (T is dead since the barrier above: into its block) ------------------------------
     gemm([&](int r, int kk) { return in(r, kk) ? ei_[r * 64 + kk] : 0.0; }, [&](int kk, int c) { return in(kk, c) ? Pm[kk * S1 + c] : 0.0; },
@@ -1311,6 +1340,7 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_lean_kernel(int RP, int ns
         }
         if (tid < RP) eo[12288 + 64 + tid] = enew;
     }
+    TP_STAMP(8);
 }
 
 // The same for two or four state rows (the reference benchmark grid's j = 2: benchmark/benchmarks.jl:16-18), ONE THREAD per draw, everything in
@@ -1705,6 +1735,13 @@ const double* pioran_tp_disc(const double* work, int64_t B, int64_t N, int RP, i
     return work + (size_t)B * N * RP * 6 + (size_t)B * N * 5 + (size_t)B * nseg * (3 * (size_t)TP_ELEM_DOUBLES + TP_BND_DOUBLES + 4);
 }
 double pioran_tp_scan_tol(const ScanOptions* opt) { return opt && opt->tp_scan_tol != 0.0 ? opt->tp_scan_tol : kTpScanTol; }   // (negative: every draw is repaired — tests)
+
+#ifdef PIORAN_TP_STAMP
+extern "C" int pioran_tp_read_stamps(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tp_stamp_buf), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int pioran_tp_supported_rows() { return 64; }     // (lane = state row in the element and filter kernels)
 // state rows (padded) whose boundary phase can run as a scan (tp_combine_kernel up to three tiles of 16 rows, tp_combine_lean_kernel at four: a multiple of 8)
