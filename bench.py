@@ -702,6 +702,19 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
             single[f"{basis}{J}_N{n}"] = {"resident_launch_ms": ms1, "scalar_entry_ms_incl_pcie": med(wall) * 1e3,
                                          "cpu_one_core_ms": med(cpu) * 1e3, "rows_executed": R1, "scalar_entry_kernel": kern1,
                                          "rel_dlogl_vs_oracle": abs(v - r) / abs(r)}
+            if kern1 == "tp":
+                # the time-parallel scan is checked per draw and a draw that fails is evaluated again on the serial chain: the MEAN over 32 prior draws, and the share
+                # of them that took the repair pass (a call 1.6 x the fastest or slower), beside the one draw above
+                A32, B32, C32, D32 = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:32, :3], f_min if n == N else 1.0 / (tt[-1] - tt[0]),
+                                                     f_max if n == N else 1.0 / (2 * np.min(np.diff(tt))), J, theta[:32, 3], basis_function=basis)
+                w32 = []
+                for i32 in range(32):
+                    ys32, ss32 = yy - mu[i32], nu[i32] * ee ** 2
+                    ctx.logl(A32[i32], B32[i32], C32, D32, tt, ys32, ss32)
+                    t0 = time.perf_counter(); ctx.logl(A32[i32], B32[i32], C32, D32, tt, ys32, ss32); w32.append(time.perf_counter() - t0)
+                w32 = np.array(w32)
+                single[f"{basis}{J}_N{n}"]["scalar_entry_ms_mean_of_32_prior_draws"] = float(w32.mean() * 1e3)
+                single[f"{basis}{J}_N{n}"]["repaired_share_of_32_prior_draws"] = float((w32 > 1.6 * w32.min()).mean())
     out["single_evaluation_B1"] = single
     out["single_evaluation_B1"]["kernel"] = ("resident_launch_ms: what the automatic choice takes for one resident draw; scalar_entry_kernel names it for the "
                                              "scalar entry — 'block': celerite_block_kernel (windowed form, 16 steps per window on the fp64 matrix cores, a "
@@ -870,6 +883,23 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
         grad[f"sho{Jg}_rows{2 * Jg}_chains_1"] = {"value_and_gradient_abcd_mu_nu_ms_incl_pcie": min(wall) * 1e3, "value_ms_incl_pcie": min(wv) * 1e3, "kernel": kern}
     dsg.close()
     out[f"gradient_sho{J}_N{N}"] = grad
+    # -- the same for BASELINE's literal model, DRWCelerite-20 (60 executed rows: four block columns — the small-batch windowed reverse mode in launches of 512
+    #    chains; the one-draw-per-wavefront reverse mode exists there but is slower), against the cost of a VALUE of the same model -------------
+    msv, Ad_, Bd_, Cd_, Dd_, *_ = resident_batch("DRWCelerite", N, nch, 3)
+    dsd = pj.Dataset(t, y, s2, ctx)
+    gradd = {"value_ms_per_launch_of_the_same_chains": msv}
+    for key, nb_, cd in (("chains_1", 1, True), (f"chains_{nch}", nch, False), (f"chains_{nch}_with_cd", nch, True)):
+        dsd.logl_grad(Ad_[:nb_], Bd_[:nb_], Cd_, Dd_, mu=mu[:nb_], nu=nu[:nb_], cd_grad=cd)
+        wall = []
+        for _ in range(2):
+            t0 = time.perf_counter(); gd_ = dsd.logl_grad(Ad_[:nb_], Bd_[:nb_], Cd_, Dd_, mu=mu[:nb_], nu=nu[:nb_], cd_grad=cd); wall.append(time.perf_counter() - t0)
+        wg = min(wall)
+        gradd[key] = {"value_and_gradient_ms_incl_pcie": wg * 1e3, "kernel": pj._lib.lib().pioran_celerite_config_name(-1).decode(),
+                      "all_finite_frac": float(np.isfinite(gd_["grad_a"]).all(axis=1).mean())}
+        if nb_ == nch:
+            gradd[key]["ratio_to_value_cost_of_this_model"] = wg * 1e3 / msv
+    dsd.close()
+    out[f"gradient_drwcelerite{J}_N{N}"] = gradd
 
     # -- posterior mean and simulation for a set of posterior draws (the callers after sampling:
     #    src/celerite_solver.jl:363-483, 515-549) — windowed factorisation, host entries (transfers included) -----------------

@@ -91,15 +91,16 @@ int pioran_ctx_trim(pioran_ctx* ctx);
  *                     every launch it can take
  *   "no_tp"           value "1": never the time-parallel evaluation (celerite_tp.hip: segments of the series on different CUs, for a handful of
  *                     draws of a long series).  Automatic choice, round 6 (its boundary phase as a scan over the segments' elements): one or two draws with
- *                     3-4 / 5-16 / 24 / 32 / 40-48 / 56-64 state rows from 2048 / 1024 / 1536 / 2048 / 3072 / 4096 steps on, 3 .. 32 draws where a model of its
+ *                     3-4 / 5-16 / 24 / 32 / 40-48 / 56-64 state rows from 3072 / 1536 / 2048 / 3072 / 4096 / 6144 steps on, 3 .. 32 draws where a model of its
  *                     time promises 15 % against the serial chains; with the boundary walk of round 5: up to 8 draws with up to 4 / 8 / 12 / 16 state rows
  *                     from 1024 / 2048 / 4096 / 6144 steps on, up to 64 draws at up to 4 rows from 4096, up to 8 draws with up to 24 / 32 / 40 / 48 / 64 rows from
  *                     5120 / 6144 / 8192 / 8192 / 12288;
  *                     "scan_config" = "tp" forces it wherever it applies (shared (c, d), up to 64 state rows, up to 64 draws);
  *                     "tp_segments" its segment count (0 / NULL = automatic);
  *                     "tp_scan" -1 (default) automatic, 0 the boundary walk, 1 the scan wherever the rows allow (3 .. 64);
- *                     "tp_scan_tol" the scan's acceptance threshold: a draw whose boundary states differ from the sequential filter's by more (relative) is
- *                     evaluated again on the serial chain (0 / NULL = 1e-5; negative: every draw — tests); "tp_walk_repair" = "1": by the family's own
+ *                     "tp_scan_tol" the scan's acceptance threshold: the filter measures how far the scan's boundary states are from the sequential ones (on the scale of the
+ *                     innovation variance) and a draw whose estimated relative error of log L exceeds it is evaluated again on the serial chain — one in ten of the
+ *                     prior draws of the SHO models, one in five of DRWCelerite's (0 / NULL = 1e-8; negative: every draw — tests); "tp_walk_repair" = "1": by the family's own
  *                     boundary walk instead; "tp_scan_lean" = "1", "tp_scan_waves" = "4": the forms of the combination kernel that are the default only at
  *                     49 .. 64 rows / up to 16 rows (tests, tools)
  *   "dense_old_chain" 0 one launch per block column (default), 1 the panel / update chain of rounds 1-3 (2 .. 8: timing experiments, only in

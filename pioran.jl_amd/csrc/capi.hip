@@ -404,7 +404,7 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     // 0.64 / 0.76 against 1.87 / 2.40; N = 65536: 1.19 / 1.35 against 12.0 / 16.4).
     const int nrows = (int)term.size();
     // (three and four rows — the reference grid's j = 2 — padded to eight: N = 8192 0.19 ms against 0.28 on the one-thread boundary walk; from 2048 steps on)
-    const bool scan_rows = (nrows > 4 || (nrows > 2 && p.B <= 2 && (p.N >= 2048 || o.tp_scan > 0))) && nrows <= 64;
+    const bool scan_rows = (nrows > 4 || (nrows > 2 && p.B <= 2 && (p.N >= 3072 || o.tp_scan > 0))) && nrows <= 64;
     // Three to 32 draws (tools/tp_scan_batch_sweep.py, section 8 of the profile): the combinations of one level want a CU slot each — a CU holds kc = 4 / 2 / 1
     // workgroups of tp_combine_kernel at up to 8 / up to 32 / more rows (its LDS) — so the segment count is the largest power of two with B nseg <= 256 kc
     // (SHO-20, N = 1e4, 4 / 8 draws: 64 / 32 segments 0.76 / 1.06 ms against 1.50 / 1.53 on the walk and 1.85 on the serial chains; 128 segments 1.08 / 2.0).
@@ -433,7 +433,9 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
         const bool many = RP > 16 && ((p.B <= 2 && p.N >= nmin12) || (p.B <= 8 && p.N >= nmin8));
         // (49 .. 64 rows, tp_combine_lean_kernel: 56 / 60 rows from 4096 steps on — 0.89 / 1.02 against 1.03 / 1.08 ms; N = 1e4: 1.10 / 1.21 against 2.46 / 2.58;
         //  64 rows, five block columns on the serial chain, from 2048 — 0.89 against 0.98; N = 1e4: 1.21 against 4.6)
-        const bool scanned = scan && p.N >= (nrows <= 4 ? 2048 : RP <= 16 ? 1024 : (RP <= 24 ? 1536 : (RP <= 32 ? 2048 : (RP <= 48 ? 3072 : (p.R + 1 > 64 ? 2048 : 4096)))));
+        // (one notch above the measured break-even: 7 .. 10 % of the prior draws of the SHO models and ~20 % of the DRWCelerite models fail the scan's check and are
+        //  evaluated again on the serial chain — tools/tp_scan_accept.py — so the scan has to be ahead by that share of the serial chain's time)
+        const bool scanned = scan && p.N >= (nrows <= 4 ? 3072 : RP <= 16 ? 1536 : (RP <= 24 ? 2048 : (RP <= 32 ? 3072 : (RP <= 48 ? 4096 : (p.R + 1 > 64 ? 3072 : 6144)))));
         // three and more draws on the scan: a model of its time (records + two phases of N / nseg steps + one combination per level and the check, in us)
         // against the serial chain's time per step (measured at N = 1e4, resident inputs), taken when it promises 15 % off (up to 8 rows, where the model is
         // optimistic at 32 draws: a quarter) — profiles/r06_time_parallel_scan.txt section 8 has the sweep this was held against at N = 2048 / 4096 / 1e4
@@ -446,9 +448,9 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
             const double load = RP > 16 && RP <= 32 ? (double)p.B * scan_cap * 4.0 / 1024.0 : 1.0, rp = 1.0 + 0.5 * (load > 1.0 ? load - 1.0 : 0.0);
             double t_scan = 35.0 + rp * tau * (double)p.N / scan_cap + (lv + 1) * tc;
             const double s_chain = RP <= 8 ? 0.127 : (RP <= 24 ? 0.178 : (RP <= 40 ? 0.19 : (RP <= 48 ? 0.24 : (p.R + 1 > 64 ? 0.46 : 0.25))));
-            // models with one-row terms (DRWCelerite): 1.5 % of their prior draws fail the scan's check at its default threshold (profiles/r06_time_parallel_scan.txt section 11) and one
-            // failing draw sends the launch through the serial chain as well — its expected share
-            if (nrows != 2 * J) t_scan += (1.0 - std::pow(0.985, (double)p.B)) * s_chain * (double)p.N;
+            // ~8 % of the prior draws of the SHO models and ~20 % of the models with one-row terms (DRWCelerite) fail the scan's check (profiles/r06_time_parallel_scan.txt
+            // section 11), and one failing draw sends the launch through the serial chain as well — its expected share
+            t_scan += (1.0 - std::pow(nrows != 2 * J ? 0.8 : 0.92, (double)p.B)) * s_chain * (double)p.N;
             scanned_b = (int64_t)scan_cap * 16 <= p.N && t_scan < (RP <= 8 ? 0.75 : 0.85) * s_chain * (double)p.N;
         }
         if (!few && !mid && !many && !(scanned && p.B <= 2) && !scanned_b) return PIORAN_ERR_UNSUPPORTED;
@@ -491,10 +493,11 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     q.C = s->dc; q.D = s->dd; q.J = J; q.opt = &ctx->opt;
     g_last_kernel = "tp";
     const int32_t* dr = (const int32_t*)ctx->btprow.p;
-    // A draw whose scan fails its check (made by the filter on its way: tp_filter_kernel's `disc`; 1.5 % of the prior draws of the DRWCelerite models, whose scan
-    // alone is off by 1e-6 .. O(1) on a few of them; none of 1500 draws of the SHO models — tools/tp_scan_accept.py) is evaluated again.  By the family's own boundary walk that costs 15 ms at 128
-    // segments; the serial-chain windowed kernel does it in 2.5 (celerite_block_kernel with ScanParams::only_if: its workgroups leave at once for every draw
-    // that passed), so that is the repair pass wherever that kernel takes the rows; the walk stays for the rest (option tp_walk_repair forces it).
+    // A draw whose scan fails its check (made by the filter on its way, tp_filter_kernel / tp_finish_kernel: one in ten of the prior draws of the SHO models, one in
+    // five of the DRWCelerite models; the scan ALONE is wrong by 1e-8 .. 2e-4 on 0.9 % of them — tools/tp_scan_metrics.py, tp_scan_accept.py) is evaluated again.  By the
+    // family's own boundary walk that costs 15 ms at 128 segments; the serial-chain windowed kernel does it in 2.5 (celerite_block_kernel with ScanParams::only_if: its
+    // workgroups leave at once for every draw that passed), so that is the repair pass wherever that kernel takes the rows; the walk stays for the rest (option
+    // tp_walk_repair forces it, with the verification launch of tp_combine_kernel as its check).
     bool repair = scan && nseg >= 2 && !o.tp_walk_repair && !o.no_block && p.R >= 5 && pioran_block_fits_value(p.R, p.J) &&
                   p.rec_stride == 3 * (int64_t)(s->R + 2) + 2 && (p.Y == nullptr) == (p.S2 == nullptr);
     if (repair) {
@@ -732,6 +735,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     } else if (!std::strcmp(key, "no_tp")) o.no_tp = on; else if (!std::strcmp(key, "tp_segments")) o.tp_segments = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan")) o.tp_scan = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "tp_walk_repair")) o.tp_walk_repair = on;
+    else if (!std::strcmp(key, "tp_check")) o.tp_check = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan_waves")) o.tp_scan_waves = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan_lean")) o.tp_scan_lean = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan_tol")) o.tp_scan_tol = (value && value[0]) ? std::atof(value) : 0.0;

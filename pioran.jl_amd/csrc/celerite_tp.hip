@@ -50,7 +50,7 @@ struct __attribute__((aligned(32))) TpStep { double s, y, s2, yos; };           
 
 constexpr int TP_ELEM_DOUBLES = (3 * 64 + 2) * 64;     // A' | C | J (64 x 64 each, row-major, rows = lanes), b, eta
 constexpr int TP_BND_DOUBLES = 65 * 64;                // m | P (64 x 64 row-major)
-constexpr double kTpScanTol = 1e-5;                    // largest relative discrepancy between the scan's boundary states and the boundary steps from them (tp_combine_kernel)
+constexpr double kTpScanTol = 1e-8;                    // largest accepted estimate of log L's relative error from the scan's check (tp_filter_kernel, tp_finish_kernel); walk-repair mode: of the state discrepancy
 // Experiment builds only (-DPIORAN_TP_STAMP, tools/tp_combine_stamps.sh; never in the product library): s_memtime stamps of the phases of one combination
 // (the workgroup of target blockIdx.x == gridDim.x - 1, draw 0), read back through pioran_tp_read_stamps.
 #ifdef PIORAN_TP_STAMP
@@ -202,7 +202,7 @@ struct TpStage {
 template <int NP, int NWV>     // NWV wavefronts per workgroup (1: up to 16 rows, no barrier at all; 4: up to 64), NP column pairs per wavefront: RP = 2 NP NWV
 __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, int nseg, int64_t L, const int32_t* __restrict__ row_kind,
                                                              const TpRec* __restrict__ rec, const TpStep* __restrict__ stp, const double* __restrict__ bnd,
-                                                             double* __restrict__ part, double* __restrict__ sval, double* __restrict__ disc)
+                                                             double* __restrict__ part, double* __restrict__ sval, double* __restrict__ disc, int check)
 {
     using Stage = TpStage<NWV>;
     constexpr int CH = Stage::CH;
@@ -244,6 +244,7 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
     }
     TP_BARRIER();
     double quad = 0.0;
+    double Slast = 1.0;                  // the innovation variance of the segment's last step: the scale of the scan's check below
     for (int k = 0; k < len; ++k) {
         const int ci = k / CH, si = k % CH, buf = ci & 1;
         const double2* rr = rbuf[buf] + si * RP * 3;
@@ -285,6 +286,7 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
         tp_sum2<NWV == 1>(sS, sm);
         const double S = sbuf[buf][si * 2 + 1].x + sS, v = s0.y - sm;
         const double iS = tp_rcp(S);
+        Slast = S;
         if (threadIdx.x == 0) sring[k & 255] = S;
         quad = fma(v * v, iS, quad);
         const double K = Ph * iS;
@@ -322,10 +324,17 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
         double* o = part + (b * nseg + seg) * 4;
         o[0] = quad; o[1] = ldsum; o[2] = (double)bad; o[3] = 0.0;
     }
-    // The scan's check, for free (round 6; disc != nullptr behind the scan form of phase 2): the filter has just carried the scan's state at boundary `seg`
-    // through the segment — that IS the state at boundary seg + 1, by the sequential arithmetic.  Its distance from the scan's own state there, relative to the
-    // state's largest entries (the mean against its own scale and the standard deviation the covariance implies), goes to the draw's maximum: what
-    // tp_combine_kernel's verification launch measured with one boundary step per boundary, without that launch (40 / 84 us at 40 / 60 rows).
+    // The scan's check (round 6; disc != nullptr behind the scan form of phase 2).  The filter has just carried the scan's state at boundary `seg` through the
+    // segment: that is the state at boundary seg + 1 by the sequential arithmetic.  Its distance from the scan's own state there goes to the draw's maximum, on the
+    // scale that log L feels — the INNOVATION VARIANCE S of the segment's last step (a step's term of log L moves by ~ dS / S and dv^2 / S, with dS, dv sums of
+    // entries of dP, dm): |dP| / S and |dm| / sqrt(S), absolute differences.  If every boundary's distance is below tol the scan's states are within nseg tol of the
+    // sequential ones (induction from the exact prior): a residual, not a guess.  tp_finish_kernel turns the maximum into an estimate of log L's RELATIVE error
+    // (x sqrt(N) / |log L|: the terms' errors have random signs), which is what the caller's repair pass goes by.
+    // History (tools/tp_scan_metrics.py, profiles/r06_time_parallel_scan.txt sections 11 - 13): combining incomplete elements is NOT stable — 0.8 % of 2300 draws come
+    // out of the scan alone wrong by 1e-8 .. 1e-3, SHO models included, at any segment count.  The first form of this check divided by the state's largest entry: a slow
+    // component of large variance hides errors that are O(1) of S (11 of 18 bad draws passed it at 1e-6; option tp_check = 1 keeps it for that tool).  A SECOND
+    // sweep of this kernel from the propagated states — one Jacobi step of the sequential recursion — was measured and does not help: the errors sit in
+    // components the filter does not forget within a segment.
     if (disc && seg + 1 < nseg) {
         const double* b2 = bs + TP_BND_DOUBLES;
         double dP = 0.0, sP = 0.0, dm = 0.0, sm = 0.0;
@@ -351,10 +360,13 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
             dm = fmax(fmax(red[0][0][2], red[0][1][2]), fmax(red[0][2][2], red[0][3][2])); sm = fmax(fmax(red[0][0][3], red[0][1][3]), fmax(red[0][2][3], red[0][3][3]));
         }
         if (threadIdx.x == 0) {
-            double rel = dP / (sP > 0.0 ? sP : 1.0);
-            const double mscale = fmax(sm, sqrt(sP));
-            rel = fmax(rel, dm / (mscale > 0.0 ? mscale : 1.0));
-            if (!(rel >= 0.0)) rel = 1.0;
+            const double Sa = fabs(Slast);
+            double rel = fmax(dP / (Sa > 0.0 ? Sa : 1.0), dm / (Sa > 0.0 ? sqrt(Sa) : 1.0));
+            if (check == 1) {            // (the first form: relative to the state's largest entries; tools/tp_scan_metrics.py holds the two against each other)
+                const double mscale = fmax(sm, sqrt(sP));
+                rel = fmax(dP / (sP > 0.0 ? sP : 1.0), dm / (mscale > 0.0 ? mscale : 1.0));
+            }
+            if (!(rel >= 0.0)) rel = __builtin_inf();
             atomicMax(reinterpret_cast<unsigned long long*>(disc + b), (unsigned long long)__double_as_longlong(rel));
         }
     }
@@ -362,7 +374,7 @@ __global__ void __launch_bounds__(64 * NWV) tp_filter_kernel(int64_t N, int RP, 
 
 // log L = -1/2 sum log |D_n| - N/2 log 2 pi - 1/2 sum z_n^2 / D_n from the segments' sums, in a fixed order
 __global__ void __launch_bounds__(64) tp_finish_kernel(int64_t N, int nseg, int64_t B, const double* __restrict__ part, double* __restrict__ out,
-                                                       int32_t* __restrict__ status)
+                                                       int32_t* __restrict__ status, double* __restrict__ disc, int mode)
 {
     // one wavefront per draw (round 6: with up to 256 segments the one-thread loop was 34 us of a 600 us evaluation): lane l adds the segments l, l + 64, ...,
     // then a butterfly over the lanes — the same order on every call
@@ -381,6 +393,11 @@ __global__ void __launch_bounds__(64) tp_finish_kernel(int64_t N, int nseg, int6
     const double res = -0.5 * ld - 0.5 * (double)N * 1.8378770664093454836 - 0.5 * q;
     out[b] = res;
     if (status) status[b] = !isfinite(res) ? 2 : (bad > 0.0 ? 1 : 0);
+    // the scan's check (tp_filter_kernel): the largest state distance on the innovation scale becomes an estimate of log L's relative error
+    //   est = distance x sqrt(N) / |log L|  (the terms' errors have random signs), accepted up to tol together with distance <= 1e3 tol — on 1920 draws of four
+    //   models at N = 1e4 .. 65536 (tools/tp_scan_metrics.py) tol = 1e-8 accepts no draw that is off by more than 5e-10 and sends 13.5 % to the repair pass
+    //   (est alone: 10 %, worst accepted 5.4e-9; the distance alone at 1e-6: 18 %, 5e-10)
+    if (disc) disc[b] = mode == 2 ? disc[b] : fmax(disc[b] * sqrt((double)N) / fmax(fabs(res), 1.0), mode == 3 ? 0.0 : 1e-3 * disc[b]);
 }
 
 // ---- phase 1 ---------------------------------------------------------------------------------------------------------------------------------
@@ -799,13 +816,10 @@ __global__ void __launch_bounds__(64 * TW) tp_combine_kernel(int RP, int nseg, i
 {
     // disc != nullptr ("verify", stride = 1 with every left operand taken as a complete prefix): the boundary step of the sequential walk from the SCAN's
     // state at boundary p - 1 with the raw element of segment p - 1, compared with the scan's state at boundary p: a safety net under the scan's
-    // combinations of incomplete elements, which are NOT as stable as the sequential filter.  Measured (tools/tp_scan_accept.py, profiles/r06_time_parallel_scan.txt
-    // section 11, 2500 prior draws of five models at N = 1e4, 630 at N = 65536): on the SHO models the scan's log L is as close to the oracle as the walk's on every
-    // draw; on the DRWCelerite models a few draws per hundred come out wrong by 1e-8 .. O(1), and every one of those has a discrepancy above 1e-4 (the first draw
-    // accepted with an error above 1e-8 appears at a threshold of 1e-3).  kTpScanTol = 1e-5 (option "tp_scan_tol") rejects 1.5 % of the DRWCelerite draws, all bad ones
-    // among them; a rejected draw is evaluated again — by the serial-chain kernel (capi.hip tp_dispatch) or, in this launch sequence, by the walk (tp_boundary_kernel's
-    // `disc`).  Since late round 6 the product path makes this comparison in tp_filter_kernel (the filter arrives at the next boundary's state anyway); this
-    // launch remains behind the walk-repair mode.
+    // combinations of incomplete elements, which are NOT as stable as the sequential filter (0.8 % of 2300 draws of four models come out of the scan alone wrong by
+    // 1e-8 .. 1e-3: tools/tp_scan_metrics.py).  This launch is the check of the WALK-REPAIR mode (option tp_walk_repair; discrepancy relative to the state's largest
+    // entries, the draws above the threshold are walked by tp_boundary_kernel).  The product path does not use it: there the filter kernel checks AND corrects
+    // (tp_filter_kernel: two sweeps, distances on the scale of the innovation variance) and what still fails goes to the serial-chain kernel (capi.hip tp_dispatch).
     extern __shared__ double lds[];
     constexpr int R16 = 16 * RT, S1 = R16 + 1, LW = 3 * R16 + 3, T = 64 * TW;
     double* X = lds;                     // [R16][LW]: [W, later A_j Z | z (1), Z (RP), later J_j (M A_i) | A_i -> M A_i (RP)]
@@ -1616,7 +1630,7 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
     double* elem3 = elem2 + (size_t)B * nseg * TP_ELEM_DOUBLES;
     double* bnd = elem3 + (size_t)B * nseg * TP_ELEM_DOUBLES;
     double* part = bnd + (size_t)B * nseg * TP_BND_DOUBLES;
-    double* disc = part + (size_t)B * nseg * 4;                      // [B] the scan's largest discrepancy per draw
+    double* disc = part + (size_t)B * nseg * 4;                      // [B] per draw: the scan's check (product path: the estimate of log L's relative error; walk-repair mode: the state discrepancy)
     if (hipMemsetAsync(bnd, 0, (size_t)B * nseg * TP_BND_DOUBLES * sizeof(double), stream) != hipSuccess) return PIORAN_ERR_HIP;
     hipLaunchKernelGGL(tp_records_kernel, dim3((unsigned)N, (unsigned)B), dim3(64), 0, stream, N, RP, p.J, row_term, row_kind, p.t, p.y, p.s2, p.Y, p.S2, p.A,
                        p.Bc, p.C, p.D, p.mu, p.nu, rec, stp);
@@ -1650,7 +1664,7 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
             if (hipFuncSetAttribute(fnc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc) != hipSuccess) return PIORAN_ERR_HIP;
             granted_c[gi][rt][dev] = ldsc;
         }
-        const double tol = pioran_tp_scan_tol(p.opt);
+        const double tol = p.opt && p.opt->tp_scan_tol != 0.0 ? p.opt->tp_scan_tol : 1e-6;      // (walk-repair mode: of the verification launch's state discrepancy)
         if (hipMemsetAsync(disc, 0, (size_t)B * sizeof(double), stream) != hipSuccess) return PIORAN_ERR_HIP;
         auto combine = [&](const dim3& gr, int stride, const double* src, double* dst, double* dsc) {
 #define TP_COMBINE(KERNEL, WV) hipLaunchKernelGGL(KERNEL, gr, dim3(64 * WV), ldsc, stream, RP, nseg, p.J, stride, row_term, row_kind, p.A, p.Bc, src, dst, bnd, dsc)
@@ -1722,9 +1736,10 @@ int tp_launch(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* r
         else
             hipLaunchKernelGGL((tp_boundary_kernel<4, 4>), dim3((unsigned)B), dim3(256), lds2, stream, RP, nseg, p.J, row_term, row_kind, p.A, p.Bc, (const double*)elem, bnd, (const double*)nullptr, 0.0);
     }
+    const int check = p.opt ? p.opt->tp_check : 0;
     hipLaunchKernelGGL((tp_filter_kernel<NP, NWV>), dim3((unsigned)nseg, (unsigned)B), dim3(64 * NWV), 0, stream, N, RP, nseg, L, row_kind,
-                       (const TpRec*)rec, (const TpStep*)stp, (const double*)bnd, part, sval, filter_disc);
-    hipLaunchKernelGGL(tp_finish_kernel, dim3((unsigned)B), dim3(64), 0, stream, N, nseg, B, (const double*)part, p.out, p.status);
+                       (const TpRec*)rec, (const TpStep*)stp, (const double*)bnd, part, sval, filter_disc, check);
+    hipLaunchKernelGGL(tp_finish_kernel, dim3((unsigned)B), dim3(64), 0, stream, N, nseg, B, (const double*)part, p.out, p.status, check != 1 ? filter_disc : (double*)nullptr, check);      // (tp_check = 2 / 3: the raw distance on the innovation scale / the estimate alone: tools)
     return hipGetLastError() == hipSuccess ? PIORAN_OK : PIORAN_ERR_HIP;
 }
 
