@@ -33,7 +33,9 @@
  *     (every stored chain of the reference sits there); families agree to 3e-10 over prior draws of the bench model;
  *   - ratio < 1e-8: the reference's own recurrence in fp64 is up to 7.8e-9 from the exact value; the step-by-step kernels follow it
  *     (6 .. 8e-9), the windowed kernels ("tile", "block": large and small batches from 5 rows on) reach 2 .. 3.2e-8 on single draws,
- *     the time-parallel family ("tp") 1e-10.  Two families can therefore differ by up to 4e-8 on such a draw; no single stage of the
+ *     the time-parallel family ("tp") 1e-10 — for a draw that passes its check: a draw of a long series whose boundary scan fails the check (one in ten
+ *     of the prior draws of the SHO models, one in five of DRWCelerite's; option "tp_scan_tol") is evaluated again by the windowed kernel and has ITS
+ *     accuracy, under the same name "tp".  Two families can therefore differ by up to 4e-8 on such a draw; no single stage of the
  *     windowed form removes that within 1 % of its time (profiles/r06_window_precision_by_stage.txt).  A caller that needs one
  *     family for every batch size pins it: options "no_tile", "no_block", "no_tp", "scan_config".
  *   - draws flagged in `status` (below): the families agree only to ~1e-6 (which D_n crosses zero within rounding differs).
