@@ -498,14 +498,18 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     // family's own boundary walk that costs 15 ms at 128 segments; the serial-chain windowed kernel does it in 2.5 (celerite_block_kernel with ScanParams::only_if: its
     // workgroups leave at once for every draw that passed), so that is the repair pass wherever that kernel takes the rows; the walk stays for the rest (option
     // tp_walk_repair forces it, with the verification launch of tp_combine_kernel as its check).
-    bool repair = scan && nseg >= 2 && !o.tp_walk_repair && !o.no_block && p.R >= 5 && pioran_block_fits_value(p.R, p.J) &&
+    bool repair = scan && nseg >= 2 && !o.tp_walk_repair && !o.no_block && pioran_block_fits_value(p.R, p.J) &&
                   p.rec_stride == 3 * (int64_t)(s->R + 2) + 2 && (p.Y == nullptr) == (p.S2 == nullptr);
     if (repair) {
         rc = ensure_btab(ds, *s);
         if (rc == PIORAN_ERR_UNSUPPORTED) repair = false;
         else if (rc) return rc;
     }
-    rc = pioran_launch_tp(q, RP, nseg, L, dr, dr + RP, (double*)ctx->btp.p, ctx->stream, scan ? (repair ? 2 : 1) : 0);
+    // (no repair pass available — the windowed kernel's table does not fit, "no_block" — and the walk-repair mode not asked for: the boundary walk instead of the
+    //  scan; the walk-repair mode's own check, a state discrepancy relative to the state's largest entry, lets bad draws through: tools/tp_scan_metrics.py)
+    const int mode = !scan ? 0 : (repair ? 2 : (o.tp_walk_repair ? 1 : 0));
+    if (scan && mode == 0 && nseg > 128) return PIORAN_ERR_UNSUPPORTED;      // (the segment count was chosen for the scan; the walk's kernels take up to 128)
+    rc = pioran_launch_tp(q, RP, nseg, L, dr, dr + RP, (double*)ctx->btp.p, ctx->stream, mode);
     if (rc || !repair) return rc;
     ScanParams qr = p;
     qr.only_if = pioran_tp_disc((const double*)ctx->btp.p, p.B, p.N, RP, nseg);

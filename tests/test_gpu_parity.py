@@ -2130,16 +2130,13 @@ def test_time_parallel_boundary_scan_vs_walk_and_oracle(ctx, J, N, B, nreal, nse
         assert name() == "tp"
         ctx.set_option("tp_walk_repair", True)
         both = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
-        ctx.set_option("scan_config", None); ctx.set_option("no_tp", True)
+        ctx.set_option("scan_config", "block" if 2 * J - nreal < 5 else None); ctx.set_option("no_tp", True)       # (fewer than five rows: the windowed kernel only when asked)
         chain = ds.logl_batch(A, Bc, C, Dd, mu=mu, nu=nu)
-        assert name() == ("block" if 2 * J - nreal >= 5 else "scan")
+        assert name() == "block"
     finally:
         ctx.set_option("scan_config", None); ctx.set_option("tp_segments", 0); ctx.set_option("tp_scan", -1); ctx.set_option("tp_scan_tol", 0); ctx.set_option("tp_scan_lean", 0)
         ctx.set_option("tp_walk_repair", False); ctx.set_option("no_tp", False)
-    if 2 * J - nreal >= 5:
-        assert np.array_equal(repaired, chain)             # (every draw through the repair pass: the serial-chain kernel's own values)
-    else:
-        assert np.array_equal(repaired, both)              # (three and four rows, padded to eight: the windowed kernel does not take them — the walk repairs)
+    assert np.array_equal(repaired, chain)                 # (every draw through the repair pass: the serial-chain windowed kernel's own values)
     assert (st == 0).all()
     assert relerr(scan, ref) < 1e-11 and relerr(walk, ref) < 1e-11 and relerr(scan, walk) < 1e-11 and relerr(lean, scan) < 1e-12
     rows = 2 * J - nreal
