@@ -265,3 +265,37 @@ def test_tile_dispatch_ladder_matches_the_committed_sweep():
     assert len(lines) >= 60
     bad = mod.check(verbose=False)
     assert not bad, [(r["model"], r["rows"], r["B"], round(loss, 3)) for r, loss in bad]
+
+
+def test_bench_final_line_is_compact_and_ordered(capsys, tmp_path, monkeypatch):
+    """bench.py's contract with the driver (which keeps an 8 KB tail of stdout): ONE final line of at most bench.LINE_LIMIT bytes whatever the size of the
+    secondary measurements; the contract's keys, `roofline`, `cpu_baseline` and the parity figures always present; `secondary` in BASELINE's order (the other
+    basis, dense, single evaluation, gradient, ...) with prose and counts dropped, cut from the END when too long; the long form in the file named by
+    PIORAN_BENCH_FULL."""
+    import json
+    import sys
+    sys.path.insert(0, str(ROOT))
+    import bench
+    full = tmp_path / "full.json"
+    monkeypatch.setenv("PIORAN_BENCH_FULL", str(full))
+    big = {f"zz_section_{i}": {"note": "x" * 500, **{f"entry_{j}": {"time_ms": 1.0 + j, "kernel": "k" * 60, "count": j} for j in range(12)}} for i in range(30)}
+    result = {"metric": "m", "value": 1.0, "unit": "evals/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 10.9, "higher_is_better": True, "scaling": "weak",
+              "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": "w"}, "roofline": {"bound": "mfma", "frac": 0.45, "note": "n" * 3000},
+              "cpu_baseline": {"value": 1.0, "unit": "evals/s", "cores": 32, "kind": "port", "sample": "s", "sample_detail": "d" * 2000},
+              "max_rel_dlogl_vs_oracle": 1e-10, "max_abs_dlogl_vs_oracle_kept": 1e-8, "status_ok_frac": 0.9,
+              "secondary": {**big, "gradient_sho20_N10000": {"chains_4096": {"value_and_gradient_ms": 50.0, "kernel": "tile"}},
+                            "dense_n4096_j40": {"factor_ms": 1.13, "roofline": {"frac": 0.26, "peak": 78.6}},
+                            "drwcelerite20_b4096": {"evals_per_s": 2.4e5, "roofline_frac_executed_rows": 0.63, "rows_executed": 60, "max_rel_dlogl_vs_oracle": 1e-11}}}
+    bench.emit(result)
+    line = capsys.readouterr().out.strip().splitlines()
+    assert len(line) == 1 and len(line[0].encode()) <= bench.LINE_LIMIT
+    d = json.loads(line[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+              "cpu_baseline", "max_rel_dlogl_vs_oracle", "max_abs_dlogl_vs_oracle_kept", "status_ok_frac", "other_basis"):
+        assert k in d, k
+    assert "note" not in d["roofline"] and "sample_detail" not in d["cpu_baseline"]
+    keys = list(d["secondary"].keys())
+    assert keys[:3] == ["drwcelerite20_b4096", "dense_n4096_j40", "gradient_sho20_N10000"] and d.get("secondary_truncated") is True
+    assert d["secondary"]["dense_n4096_j40"] == {"factor_ms": 1.13, "roofline": {"frac": 0.26}}
+    assert json.loads(full.read_text())["roofline"]["note"] == "n" * 3000
+    (ROOT / "bench_full.json").unlink(missing_ok=True)
