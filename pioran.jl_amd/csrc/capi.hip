@@ -409,18 +409,19 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     // workgroups of tp_combine_kernel at up to 8 / up to 32 / more rows (its LDS) — so the segment count is the largest power of two with B nseg <= 256 kc
     // (SHO-20, N = 1e4, 4 / 8 draws: 64 / 32 segments 0.76 / 1.06 ms against 1.50 / 1.53 on the walk and 1.85 on the serial chains; 128 segments 1.08 / 2.0).
     const int RPs = (nrows + 7) & ~7, kc = RPs <= 8 ? 4 : (RPs <= 32 ? 2 : 1);
-    const bool scan = o.tp_scan != 0 && scan_rows && (o.tp_scan > 0 || p.B <= 2 || (p.B <= 32 && 16 * p.B <= 256 * kc));
+    const bool scan_ok = o.tp_scan != 0 && scan_rows && (o.tp_scan > 0 || p.B <= 2 || (p.B <= 32 && 16 * p.B <= 256 * kc));      // the scan is possible
+    bool scan = scan_ok;                                                                                                                      // ... and chosen (below)
     int scan_cap = 256;
-    if (scan && p.B > 2) { scan_cap = 16; while (2 * scan_cap * p.B <= 256 * kc && scan_cap < 256) scan_cap *= 2; }
-    const int RP = scan ? RPs : pioran_tp_padded_rows(nrows);
+    if (scan_ok && p.B > 2) { scan_cap = 16; while (2 * scan_cap * p.B <= 256 * kc && scan_cap < 256) scan_cap *= 2; }
+    const int RPw = pioran_tp_padded_rows(nrows);        // rows as the boundary walk pads them (RPs: as the scan does)
     // measured (tools/ab_tp.py sweep, profiles/r05_time_parallel_gpu.txt): with up to 8 draws it beats the serial-chain kernels from 1024 steps on at
     // up to 4 state rows (N = 8192: one SHO term 0.17 against 1.16 ms, two 0.27 against 1.15; there also at 64 draws from 4096 steps on: 0.90
     // against 1.16 ms), from 2048 steps at up to 8 rows (four terms, N = 8192: 0.47 against 1.21), from 4096 at up to 12, from 6144 at up to 16
     // (eight terms: 0.96 against 1.47 ms); with more rows the boundary solves (R^3 each, one after the other) eat the gain (20 terms, N = 1e4:
     // 2.6 against 1.83 ms).
     if (!o.force_tp) {
-        const bool few = RP <= 4 && ((p.B <= 8 && p.N >= 1024) || p.N >= 4096);
-        const bool mid = RP > 4 && p.B <= 8 && p.N >= (RP <= 8 ? 2048 : (RP <= 12 ? 4096 : 6144)) && RP <= 16;
+        const bool few = RPw <= 4 && ((p.B <= 8 && p.N >= 1024) || p.N >= 4096);
+        const bool mid = RPw > 4 && p.B <= 8 && p.N >= (RPw <= 8 ? 2048 : (RPw <= 12 ? 4096 : 6144)) && RPw <= 16;
         // 17 .. 64 state rows: the boundary solves cost 14 .. 47 us each (four wavefronts, products and rank-4 updates on the matrix cores, four pivots per barrier), and
         // the gain comes with the length of the series (its time grows like sqrt(N), the serial chain's like N): SHO-12 (24 rows) N = 8192 / 1e4 /
         // 65536 0.84 / 0.93 / 2.4 against 1.45 / 1.77 / 11.6 ms; SHO-20 (40 rows) N = 8192 / 1e4 / 65536 1.39 / 1.54 / 3.9 against 1.50 / 1.83 / 11.9;
@@ -428,19 +429,20 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
         // 49 .. 64 state rows: DRWCelerite-20 (60 rows; four block columns on the serial chain) N = 1e4 2.71 against 2.61 (not chosen), N = 16384 / 65536
         // 3.5 / 7.0 against 4.3 / 19.1 ms; SHO-32 (64 rows; FIVE block columns on the serial chain) N = 8192 / 65536 2.45 / 7.0 against 3.7 / 34.4 ms
         const int64_t nwide = p.R + 1 > 64 ? 6144 : 12288;
-        const int64_t nmin12 = RP <= 24 ? 4096 : (RP <= 32 ? 5120 : (RP <= 40 ? 8192 : (RP <= 48 ? 6144 : nwide)));
-        const int64_t nmin8 = RP <= 24 ? 5120 : (RP <= 32 ? 6144 : (RP <= 40 ? 8192 : (RP <= 48 ? 8192 : nwide)));
-        const bool many = RP > 16 && ((p.B <= 2 && p.N >= nmin12) || (p.B <= 8 && p.N >= nmin8));
+        const int64_t nmin12 = RPw <= 24 ? 4096 : (RPw <= 32 ? 5120 : (RPw <= 40 ? 8192 : (RPw <= 48 ? 6144 : nwide)));
+        const int64_t nmin8 = RPw <= 24 ? 5120 : (RPw <= 32 ? 6144 : (RPw <= 40 ? 8192 : (RPw <= 48 ? 8192 : nwide)));
+        const bool many = RPw > 16 && ((p.B <= 2 && p.N >= nmin12) || (p.B <= 8 && p.N >= nmin8));
         // (49 .. 64 rows, tp_combine_lean_kernel: 56 / 60 rows from 4096 steps on — 0.89 / 1.02 against 1.03 / 1.08 ms; N = 1e4: 1.10 / 1.21 against 2.46 / 2.58;
         //  64 rows, five block columns on the serial chain, from 2048 — 0.89 against 0.98; N = 1e4: 1.21 against 4.6)
         // (one notch above the measured break-even: 7 .. 10 % of the prior draws of the SHO models and ~20 % of the DRWCelerite models fail the scan's check and are
         //  evaluated again on the serial chain — tools/tp_scan_accept.py — so the scan has to be ahead by that share of the serial chain's time)
-        const bool scanned = scan && p.N >= (nrows <= 4 ? 3072 : RP <= 16 ? 1536 : (RP <= 24 ? 2048 : (RP <= 32 ? 3072 : (RP <= 48 ? 4096 : (p.R + 1 > 64 ? 3072 : 6144)))));
+        const bool scanned = scan_ok && p.N >= (nrows <= 4 ? 3072 : RPs <= 16 ? 1536 : (RPs <= 24 ? 2048 : (RPs <= 32 ? 3072 : (RPs <= 48 ? 4096 : (p.R + 1 > 64 ? 3072 : 6144)))));
         // three and more draws on the scan: a model of its time (records + two phases of N / nseg steps + one combination per level and the check, in us)
         // against the serial chain's time per step (measured at N = 1e4, resident inputs), taken when it promises 15 % off (up to 8 rows, where the model is
         // optimistic at 32 draws: a quarter) — profiles/r06_time_parallel_scan.txt section 8 has the sweep this was held against at N = 2048 / 4096 / 1e4
         bool scanned_b = false;
-        if (scan && p.B > 2) {
+        if (scan_ok && p.B > 2) {
+            const int RP = RPs;
             const double tau = RP <= 16 ? 0.7 + RP / 8.0 : 1.0 + RP / 32.0, tc = 8.0 + (double)RP * RP / 50.0;
             int lv = 0;
             for (int c = scan_cap; c > 1; c >>= 1) ++lv;
@@ -450,11 +452,15 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
             const double s_chain = RP <= 8 ? 0.127 : (RP <= 24 ? 0.178 : (RP <= 40 ? 0.19 : (RP <= 48 ? 0.24 : (p.R + 1 > 64 ? 0.46 : 0.25))));
             // ~8 % of the prior draws of the SHO models and ~20 % of the models with one-row terms (DRWCelerite) fail the scan's check (profiles/r06_time_parallel_scan.txt
             // section 11), and one failing draw sends the launch through the serial chain as well — its expected share
-            t_scan += (1.0 - std::pow(nrows != 2 * J ? 0.8 : 0.92, (double)p.B)) * s_chain * (double)p.N;
+            t_scan += (1.0 - std::pow(nrows != 2 * J ? 0.78 : 0.9, (double)p.B)) * s_chain * (double)p.N;
             scanned_b = (int64_t)scan_cap * 16 <= p.N && t_scan < (RP <= 8 ? 0.75 : 0.85) * s_chain * (double)p.N;
         }
-        if (!few && !mid && !many && !(scanned && p.B <= 2) && !scanned_b) return PIORAN_ERR_UNSUPPORTED;
+        // the scan where ITS rule says so (o.tp_scan > 0: wherever possible); else the boundary walk where its rules say so — a batch of 8 draws of SHO-20 that the
+        // walk's rule admits is better off there (1.53 ms) than on the scan with its expected repair (0.98 + 57 % x 1.86)
+        if (o.tp_scan < 0) scan = p.B <= 2 ? scanned : scanned_b;
+        if (!scan && !few && !mid && !many) return PIORAN_ERR_UNSUPPORTED;
     }
+    const int RP = scan ? RPs : RPw;
     while ((int)term.size() < RP) { term.push_back(0); kind.push_back(3); }
     // segments: phases 1 + 3 cost tau ~ 0.7 + R / 8 us per step with one wavefront per segment (up to 16 rows), ~ 1 + R / 32 with four; phase 2 t2 per
     // boundary as below (measured at 2 .. 48 rows, tools/ab_tp.py): N / nseg tau + nseg t2 is least at sqrt(tau N / t2)
@@ -493,8 +499,8 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     q.C = s->dc; q.D = s->dd; q.J = J; q.opt = &ctx->opt;
     g_last_kernel = "tp";
     const int32_t* dr = (const int32_t*)ctx->btprow.p;
-    // A draw whose scan fails its check (made by the filter on its way, tp_filter_kernel / tp_finish_kernel: one in ten of the prior draws of the SHO models, one in
-    // five of the DRWCelerite models; the scan ALONE is wrong by 1e-8 .. 2e-4 on 0.9 % of them — tools/tp_scan_metrics.py, tp_scan_accept.py) is evaluated again.  By the
+    // A draw whose scan fails its check (made by the filter on its way, tp_filter_kernel: one in eight of the prior draws of the SHO models, one in
+    // four of the DRWCelerite models; the scan ALONE is wrong by 1e-8 .. 2e-4 on 0.9 % of them — tools/tp_scan_metrics.py, tp_scan_accept.py) is evaluated again.  By the
     // family's own boundary walk that costs 15 ms at 128 segments; the serial-chain windowed kernel does it in 2.5 (celerite_block_kernel with ScanParams::only_if: its
     // workgroups leave at once for every draw that passed), so that is the repair pass wherever that kernel takes the rows; the walk stays for the rest (option
     // tp_walk_repair forces it, with the verification launch of tp_combine_kernel as its check).

@@ -33,7 +33,7 @@ struct ScanOptions {
     bool force_tp, no_tp;       // celerite_tp.hip (time-parallel evaluation of a handful of draws): force (scan_config "tp") / forbid
     int tp_segments = 0;        // ... its segment count (0 = automatic)
     int tp_scan = -1;           // ... its boundary phase: 1 the scan over the segments' elements (tp_combine_kernel, round 6), 0 the sequential walk, -1 automatic
-    int tp_check = 0;           // ... what the scan's check goes by: 0 (default) the estimate of log L's relative error together with the state distance on the innovation scale; tools: 1 the state discrepancy relative to its largest entry, 2 the distance alone, 3 the estimate alone
+    int tp_check = 0;           // ... what the scan's check goes by: 0 (default) the state distance on the scale of the innovation variance; tools: 1 the state discrepancy relative to its largest entry, 3 an estimate of log L's relative error from the distance
     bool tp_walk_repair = false; // ... draws whose scan fails its check go through the family's own boundary walk instead of the serial-chain kernel
     int tp_scan_waves = 0;      // ... 4: four wavefronts per combination also at 33 .. 48 rows (default there: eight)
     int tp_scan_lean = 0;       // ... 1: the scan's combinations with operands from global memory (tp_combine_lean_kernel) also below 49 rows (tests)

@@ -2,7 +2,7 @@
 """GPU: the scan's check with one filter sweep (the scan's states as they are) and with two (the second corrects them: the product's form) on many draws, scalar
 entry (series already mean-subtracted and scaled on the host, as bench.py's and the Julia shim's scalar calls do): per draw the error of the scan ALONE against the family's boundary
 walk (trusted to 1e-10: quad truth) and the smallest threshold of a ladder at which each measure accepts it.  For each measure and threshold: how many draws it accepts and the worst
-scan-alone error among them.  usage: tp_scan_metrics.py [draws = 192]"""
+scan-alone error among them.  usage: tp_scan_metrics.py [draws = 192] [seed = 4321] [other: DRWCelerite-15, SHO-12, SHO-24, SHO-4 instead of DRWCelerite-20, SHO-20, DRWCelerite-10, SHO-8]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,14 +11,15 @@ import bench, pioran_jl_amd as pj
 ctx = pj.Context(0)
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 192
 t0_, y0_, e0_ = bench.synth_series(10000)
-theta, _, _ = bench.synth_theta(4096, t0_, y0_, seed=4321)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 4321
+theta, _, _ = bench.synth_theta(4096, t0_, y0_, seed=seed)
 ladder = (1e-11, 1e-10, 1e-9, 3e-9, 1e-8, 3e-8, 1e-7, 1e-6, 1e-5)
 ladder_raw = (1e-8, 1e-7, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 1e-3, 1e-2)
 allrows = {0: [], 1: []}
 for NL in (10000, 30000, 65536):
     tL, yL, eL = bench.synth_series(NL)
     fm, fM = 1.0 / (tL[-1] - tL[0]), 1.0 / (2 * np.min(np.diff(tL)))
-    for basis, nc in (("DRWCelerite", 20), ("SHO", 20), ("DRWCelerite", 10), ("SHO", 8)):
+    for basis, nc in ((("DRWCelerite", 20), ("SHO", 20), ("DRWCelerite", 10), ("SHO", 8)) if len(sys.argv) <= 3 else (("DRWCelerite", 15), ("SHO", 12), ("SHO", 24), ("SHO", 4))):
         A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:nd, :3], fm, fM, nc, theta[:nd, 3], basis_function=basis)
         call = lambda i: ctx.logl(A[i], Bc[i], C, Dd, tL, yL - theta[i, 5], theta[i, 4] * eL ** 2)
         ctx.set_option("tp_scan_tol", 1e30); call(1); ts = []
@@ -36,7 +37,7 @@ for NL in (10000, 30000, 65536):
             ctx.set_option("tp_scan_tol", None); vp = call(i)                                             # the product path
             es, ep = abs(vs - vw) / abs(vw), abs(vp - vw) / abs(vw)
             needs = []
-            for chk, lad in ((3, ladder), (2, ladder_raw)):
+            for chk, lad in ((3, ladder), (0, ladder_raw)):
                 ctx.set_option("tp_check", chk)
                 need = float("inf")
                 for tol in lad:
@@ -49,12 +50,12 @@ for NL in (10000, 30000, 65536):
         es = np.array([r[0] for r in rows[0]]); ep = np.array([r[2] for r in rows[0]])
         print(f"{basis}-{nc} N={NL}: {len(es)} draws; scan alone off by more than 1e-8 on {(es > 1e-8).sum()} (max {es.max():.1e}); product path max {ep.max():.1e}", flush=True)
 r = np.array(allrows[0])
-print(f"# the check's estimate of log L's relative error (state distance on the innovation scale x sqrt(N) / |log L|); all {len(r)} draws:")
+print(f"# an estimate of log L's relative error from it (distance x sqrt(N) / |log L|; tp_check = 3); all {len(r)} draws:")
 for tol in ladder:
     acc = r[:, 1] <= tol
     print(f"     threshold {tol:g}: {int(acc.sum())} accepted ({100 * (1 - acc.mean()):.1f} % repaired), worst error among the accepted {r[acc, 0].max() if acc.any() else 0:.1e}; "
           f"draws off by more than 1e-8: {int((r[acc, 0] > 1e-8).sum())} accepted, {int((r[~acc, 0] > 1e-8).sum())} rejected", flush=True)
-print("# the raw distance on the innovation scale (tp_check = 2):")
+print("# the distance on the innovation scale itself (the product's measure, tp_check = 0):")
 for tol in ladder_raw:
     acc = r[:, 3] <= tol
     print(f"     threshold {tol:g}: {int(acc.sum())} accepted ({100 * (1 - acc.mean()):.1f} % repaired), worst error among the accepted {r[acc, 0].max() if acc.any() else 0:.1e}; "
