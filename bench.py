@@ -550,15 +550,30 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
     def med(xs):
         return float(np.median(xs))
 
-    def resident_batch(basis, n, nb, reps):
-        """event-timed launches of the device-pointer entry on the first n time stamps / first nb draws"""
+    def first_pd(basis, tt, yy, ee, fm, fM):
+        """index of the first of the first 16 prior draws that is positive definite on this series (status 0 on the serial chain): the single-evaluation sections time
+        a draw the reference would evaluate without its abs() — on a flagged draw the kernel families agree only loosely (include/pioran_hip.h) and the time-parallel
+        family's check sends it to the repair pass"""
+        A16, B16, C16, D16 = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:16, :3], fm, fM, J, theta[:16, 3], basis_function=basis)
+        dsf = pj.Dataset(tt, yy, ee ** 2, ctx)
+        try:
+            ctx.set_option("no_tp", True)
+            _, st16 = dsf.logl_batch(A16, B16, C16, D16, mu=mu[:16].copy(), nu=nu[:16].copy(), return_status=True)
+        finally:
+            ctx.set_option("no_tp", False)
+            dsf.close()
+        ok16 = np.flatnonzero(st16 == 0)
+        return int(ok16[0]) if len(ok16) else 0
+
+    def resident_batch(basis, n, nb, reps, first=0):
+        """event-timed launches of the device-pointer entry on the first n time stamps / nb draws from draw `first` on"""
         tt, yy, ee = t[:n], y[:n], yerr[:n]
         fm, fM = (f_min, f_max) if n == N else (1.0 / (tt[-1] - tt[0]), 1.0 / (2 * np.min(np.diff(tt))))
-        A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:nb, :3], fm, fM, J, theta[:nb, 3], basis_function=basis)
+        A, Bc, C, Dd = pj.approx_batch(pj.SingleBendingPowerLaw, theta[first:first + nb, :3], fm, fM, J, theta[first:first + nb, 3], basis_function=basis)
         real = (Dd == 0.0) & (Bc == 0.0).all(axis=0)
         ds = pj.Dataset(tt, yy, ee ** 2, ctx)
         ds.prepare(C, Dd, real.astype(np.int32))
-        d = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (A, Bc, mu[:nb].copy(), nu[:nb].copy())]
+        d = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (A, Bc, mu[first:first + nb].copy(), nu[first:first + nb].copy())]
         do = torch.empty(nb, dtype=torch.float64, device=dev); dsx = torch.zeros(nb, dtype=torch.int32, device=dev)
 
         def go():
@@ -689,8 +704,10 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
     single = {}
     for basis in ("SHO", "DRWCelerite"):
         for n in (N, max(2, N // 10)):
-            ms1, A1, B1, C1, D1, R1, got1, st1, _, (tt, yy, ee) = resident_batch(basis, n, 1, 7)
-            ys, ss = yy - mu[0], nu[0] * ee ** 2
+            ttn, yyn, een = t[:n], y[:n], yerr[:n]
+            i0 = first_pd(basis, ttn, yyn, een, *((f_min, f_max) if n == N else (1.0 / (ttn[-1] - ttn[0]), 1.0 / (2 * np.min(np.diff(ttn))))))
+            ms1, A1, B1, C1, D1, R1, got1, st1, _, (tt, yy, ee) = resident_batch(basis, n, 1, 7, first=i0)
+            ys, ss = yy - mu[i0], nu[i0] * ee ** 2
             ctx.logl(A1[0], B1[0], C1, D1, tt, ys, ss)
             kern1 = pj._lib.lib().pioran_celerite_config_name(-1).decode()
             wall = []
@@ -701,7 +718,7 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
                 t0 = time.perf_counter(); r = O.logl(A1[0], B1[0], C1, D1, tt, ys, ss); cpu.append(time.perf_counter() - t0)
             single[f"{basis}{J}_N{n}"] = {"resident_launch_ms": ms1, "scalar_entry_ms_incl_pcie": med(wall) * 1e3,
                                          "cpu_one_core_ms": med(cpu) * 1e3, "rows_executed": R1, "scalar_entry_kernel": kern1,
-                                         "rel_dlogl_vs_oracle": abs(v - r) / abs(r)}
+                                         "rel_dlogl_vs_oracle": abs(v - r) / abs(r), "prior_draw": i0}
             if kern1 == "tp":
                 # the time-parallel scan is checked per draw and a draw that fails is evaluated again on the serial chain: the MEAN over 32 prior draws, and the share
                 # of them that took the repair pass (a call 1.6 x the fastest or slower), beside the one draw above
@@ -728,9 +745,10 @@ def secondary_configs(pj, torch, O, dev, stream, ctx, t, y, yerr, theta, f_min, 
     tL, yL, eL = synth_series(NL)
     fmL, fML = 1.0 / (tL[-1] - tL[0]), 1.0 / (2 * np.min(np.diff(tL)))
     for basis in ("SHO", "DRWCelerite"):
-        AL_, BL_, CL_, DL_ = pj.approx_batch(pj.SingleBendingPowerLaw, theta[:1, :3], fmL, fML, J, theta[:1, 3], basis_function=basis)
-        ysL, ssL = yL - mu[0], nu[0] * eL ** 2
-        entry = {}
+        iL = first_pd(basis, tL, yL, eL, fmL, fML)
+        AL_, BL_, CL_, DL_ = pj.approx_batch(pj.SingleBendingPowerLaw, theta[iL:iL + 1, :3], fmL, fML, J, theta[iL:iL + 1, 3], basis_function=basis)
+        ysL, ssL = yL - mu[iL], nu[iL] * eL ** 2
+        entry = {"prior_draw": iL}
         for key, off in (("ms_incl_pcie", False), ("serial_chain_ms_incl_pcie", True)):
             ctx.set_option("no_tp", off)
             try:

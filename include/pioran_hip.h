@@ -33,8 +33,8 @@
  *     (every stored chain of the reference sits there); families agree to 3e-10 over prior draws of the bench model;
  *   - ratio < 1e-8: the reference's own recurrence in fp64 is up to 7.8e-9 from the exact value; the step-by-step kernels follow it
  *     (6 .. 8e-9), the windowed kernels ("tile", "block": large and small batches from 5 rows on) reach 2 .. 3.2e-8 on single draws,
- *     the time-parallel family ("tp") 1e-10 — for a draw that passes its check: a draw of a long series whose boundary scan fails the check (one in eight
- *     of the prior draws of the SHO models, one in four of DRWCelerite's; option "tp_scan_tol") is evaluated again by the windowed kernel and has ITS
+ *     the time-parallel family ("tp") 1e-10 — for a draw that passes its check: a draw of a long series whose boundary scan fails the check (0.3 .. 2 %
+ *     of the prior draws of the SHO models, 6 .. 15 % of DRWCelerite's; option "tp_scan_tol") is evaluated again by the windowed kernel and has ITS
  *     accuracy, under the same name "tp".  Two families can therefore differ by up to 4e-8 on such a draw; no single stage of the
  *     windowed form removes that within 1 % of its time (profiles/r06_window_precision_by_stage.txt).  A caller that needs one
  *     family for every batch size pins it: options "no_tile", "no_block", "no_tp", "scan_config".
@@ -93,7 +93,7 @@ int pioran_ctx_trim(pioran_ctx* ctx);
  *                     every launch it can take
  *   "no_tp"           value "1": never the time-parallel evaluation (celerite_tp.hip: segments of the series on different CUs, for a handful of
  *                     draws of a long series).  Automatic choice, round 6 (its boundary phase as a scan over the segments' elements): one or two draws with
- *                     3-4 / 5-16 / 24 / 32 / 40-48 / 56-64 state rows from 3072 / 1536 / 2048 / 3072 / 4096 / 6144 steps on, 3 .. 32 draws where a model of its
+ *                     3-4 / 5-16 / 24 / 32 / 40-48 / 56-64 state rows from 2048 / 1024 / 1536 / 2048 / 3072 / 4096 steps on, 3 .. 32 draws where a model of its
  *                     time promises 15 % against the serial chains; with the boundary walk of round 5: up to 8 draws with up to 4 / 8 / 12 / 16 state rows
  *                     from 1024 / 2048 / 4096 / 6144 steps on, up to 64 draws at up to 4 rows from 4096, up to 8 draws with up to 24 / 32 / 40 / 48 / 64 rows from
  *                     5120 / 6144 / 8192 / 8192 / 12288;
@@ -101,8 +101,9 @@ int pioran_ctx_trim(pioran_ctx* ctx);
  *                     "tp_segments" its segment count (0 / NULL = automatic);
  *                     "tp_scan" -1 (default) automatic, 0 the boundary walk, 1 the scan wherever the rows allow (3 .. 64);
  *                     "tp_scan_tol" the scan's acceptance threshold: the filter measures how far the scan's boundary states are from the sequential ones (on the scale of the
- *                     innovation variance) and a draw whose largest distance exceeds it is evaluated again on the serial chain — one in eight of the
- *                     prior draws of the SHO models, one in four of DRWCelerite's (0 / NULL = 1e-6; negative: every draw — tests); "tp_walk_repair" = "1": by the family's own
+ *                     innovation variance) and a draw whose largest distance exceeds it is evaluated again on the serial chain — 0.3 .. 2 % of the
+ *                     prior draws of the SHO models, 6 .. 15 % of DRWCelerite's (0 / NULL = 1e-3; negative: every draw — tests); the boundary walk is checked the
+ *                     same way; "tp_unchecked" = "1" (with "scan_config" = "tp"): the family's own arithmetic, no check, no repair (tests, tools); "tp_walk_repair" = "1": by the family's own
  *                     boundary walk instead; "tp_scan_lean" = "1", "tp_scan_waves" = "4": the forms of the combination kernel that are the default only at
  *                     49 .. 64 rows / up to 16 rows (tests, tools)
  *   "dense_old_chain" 0 one launch per block column (default), 1 the panel / update chain of rounds 1-3 (2 .. 8: timing experiments, only in

@@ -404,7 +404,7 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     // 0.64 / 0.76 against 1.87 / 2.40; N = 65536: 1.19 / 1.35 against 12.0 / 16.4).
     const int nrows = (int)term.size();
     // (three and four rows — the reference grid's j = 2 — padded to eight: N = 8192 0.19 ms against 0.28 on the one-thread boundary walk; from 2048 steps on)
-    const bool scan_rows = (nrows > 4 || (nrows > 2 && p.B <= 2 && (p.N >= 3072 || o.tp_scan > 0))) && nrows <= 64;
+    const bool scan_rows = (nrows > 4 || (nrows > 2 && p.B <= 2 && (p.N >= 2048 || o.tp_scan > 0))) && nrows <= 64;
     // Three to 32 draws (tools/tp_scan_batch_sweep.py, section 8 of the profile): the combinations of one level want a CU slot each — a CU holds kc = 4 / 2 / 1
     // workgroups of tp_combine_kernel at up to 8 / up to 32 / more rows (its LDS) — so the segment count is the largest power of two with B nseg <= 256 kc
     // (SHO-20, N = 1e4, 4 / 8 draws: 64 / 32 segments 0.76 / 1.06 ms against 1.50 / 1.53 on the walk and 1.85 on the serial chains; 128 segments 1.08 / 2.0).
@@ -434,9 +434,7 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
         const bool many = RPw > 16 && ((p.B <= 2 && p.N >= nmin12) || (p.B <= 8 && p.N >= nmin8));
         // (49 .. 64 rows, tp_combine_lean_kernel: 56 / 60 rows from 4096 steps on — 0.89 / 1.02 against 1.03 / 1.08 ms; N = 1e4: 1.10 / 1.21 against 2.46 / 2.58;
         //  64 rows, five block columns on the serial chain, from 2048 — 0.89 against 0.98; N = 1e4: 1.21 against 4.6)
-        // (one notch above the measured break-even: 7 .. 10 % of the prior draws of the SHO models and ~20 % of the DRWCelerite models fail the scan's check and are
-        //  evaluated again on the serial chain — tools/tp_scan_accept.py — so the scan has to be ahead by that share of the serial chain's time)
-        const bool scanned = scan_ok && p.N >= (nrows <= 4 ? 3072 : RPs <= 16 ? 1536 : (RPs <= 24 ? 2048 : (RPs <= 32 ? 3072 : (RPs <= 48 ? 4096 : (p.R + 1 > 64 ? 3072 : 6144)))));
+        const bool scanned = scan_ok && p.N >= (nrows <= 4 ? 2048 : RPs <= 16 ? 1024 : (RPs <= 24 ? 1536 : (RPs <= 32 ? 2048 : (RPs <= 48 ? 3072 : (p.R + 1 > 64 ? 2048 : 4096)))));
         // three and more draws on the scan: a model of its time (records + two phases of N / nseg steps + one combination per level and the check, in us)
         // against the serial chain's time per step (measured at N = 1e4, resident inputs), taken when it promises 15 % off (up to 8 rows, where the model is
         // optimistic at 32 draws: a quarter) — profiles/r06_time_parallel_scan.txt section 8 has the sweep this was held against at N = 2048 / 4096 / 1e4
@@ -450,9 +448,9 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
             const double load = RP > 16 && RP <= 32 ? (double)p.B * scan_cap * 4.0 / 1024.0 : 1.0, rp = 1.0 + 0.5 * (load > 1.0 ? load - 1.0 : 0.0);
             double t_scan = 35.0 + rp * tau * (double)p.N / scan_cap + (lv + 1) * tc;
             const double s_chain = RP <= 8 ? 0.127 : (RP <= 24 ? 0.178 : (RP <= 40 ? 0.19 : (RP <= 48 ? 0.24 : (p.R + 1 > 64 ? 0.46 : 0.25))));
-            // ~8 % of the prior draws of the SHO models and ~20 % of the models with one-row terms (DRWCelerite) fail the scan's check (profiles/r06_time_parallel_scan.txt
+            // ~2 % of the prior draws of the SHO models and ~7 % of the models with one-row terms (DRWCelerite) fail the check (profiles/r06_time_parallel_scan.txt
             // section 11), and one failing draw sends the launch through the serial chain as well — its expected share
-            t_scan += (1.0 - std::pow(nrows != 2 * J ? 0.78 : 0.9, (double)p.B)) * s_chain * (double)p.N;
+            t_scan += (1.0 - std::pow(nrows != 2 * J ? 0.93 : 0.98, (double)p.B)) * s_chain * (double)p.N;
             scanned_b = (int64_t)scan_cap * 16 <= p.N && t_scan < (RP <= 8 ? 0.75 : 0.85) * s_chain * (double)p.N;
         }
         // the scan where ITS rule says so (o.tp_scan > 0: wherever possible); else the boundary walk where its rules say so — a batch of 8 draws of SHO-20 that the
@@ -499,12 +497,10 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     q.C = s->dc; q.D = s->dd; q.J = J; q.opt = &ctx->opt;
     g_last_kernel = "tp";
     const int32_t* dr = (const int32_t*)ctx->btprow.p;
-    // A draw whose scan fails its check (made by the filter on its way, tp_filter_kernel: one in eight of the prior draws of the SHO models, one in
-    // four of the DRWCelerite models; the scan ALONE is wrong by 1e-8 .. 2e-4 on 0.9 % of them — tools/tp_scan_metrics.py, tp_scan_accept.py) is evaluated again.  By the
-    // family's own boundary walk that costs 15 ms at 128 segments; the serial-chain windowed kernel does it in 2.5 (celerite_block_kernel with ScanParams::only_if: its
-    // workgroups leave at once for every draw that passed), so that is the repair pass wherever that kernel takes the rows; the walk stays for the rest (option
-    // tp_walk_repair forces it, with the verification launch of tp_combine_kernel as its check).
-    bool repair = scan && nseg >= 2 && !o.tp_walk_repair && !o.no_block && pioran_block_fits_value(p.R, p.J) &&
+    // A draw whose boundary states fail the filter's check (tp_filter_kernel: 1 .. 3 % of the prior draws of the SHO models, 6 .. 8 % of the DRWCelerite models; the scan
+    // or the walk ALONE is wrong by more than 1e-8 on a few per thousand of the latter — tools/tp_scan_accept.py, tp_walk_accuracy.py) is evaluated again by the
+    // serial-chain windowed kernel (celerite_block_kernel with ScanParams::only_if: its workgroups leave at once for every draw that passed).
+    bool repair = !o.tp_walk_repair && !o.tp_unchecked && !o.no_block && pioran_block_fits_value(p.R, p.J) &&
                   p.rec_stride == 3 * (int64_t)(s->R + 2) + 2 && (p.Y == nullptr) == (p.S2 == nullptr);
     if (repair) {
         rc = ensure_btab(ds, *s);
@@ -513,7 +509,11 @@ int tp_dispatch(pioran_ds* ds, const ScanParams& p)
     }
     // (no repair pass available — the windowed kernel's table does not fit, "no_block" — and the walk-repair mode not asked for: the boundary walk instead of the
     //  scan; the walk-repair mode's own check, a state discrepancy relative to the state's largest entry, lets bad draws through: tools/tp_scan_metrics.py)
-    const int mode = !scan ? 0 : (repair ? 2 : (o.tp_walk_repair ? 1 : 0));
+    // Late round 6: the boundary WALK is checked and repaired the same way (mode 4) — a long segment's element is no better conditioned than a composite of the scan:
+    // on prior draws of DRWCelerite-10 the walk alone is off by up to 8e-7 where the serial chain holds 4e-10 (tools/tp_walk_accuracy.py).  Without a repair pass the
+    // family is not an AUTOMATIC choice any more; forced (scan_config "tp"; options tp_unchecked / tp_walk_repair: tools) it runs unchecked as in round 5.
+    if (!repair && !o.force_tp) return PIORAN_ERR_UNSUPPORTED;
+    const int mode = repair ? (scan ? 2 : 4) : (scan && o.tp_walk_repair ? 1 : 0);
     if (scan && mode == 0 && nseg > 128) return PIORAN_ERR_UNSUPPORTED;      // (the segment count was chosen for the scan; the walk's kernels take up to 128)
     rc = pioran_launch_tp(q, RP, nseg, L, dr, dr + RP, (double*)ctx->btp.p, ctx->stream, mode);
     if (rc || !repair) return rc;
@@ -745,6 +745,7 @@ int pioran_ctx_set_option(pioran_ctx* ctx, const char* key, const char* value)
     } else if (!std::strcmp(key, "no_tp")) o.no_tp = on; else if (!std::strcmp(key, "tp_segments")) o.tp_segments = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan")) o.tp_scan = (value && value[0]) ? std::atoi(value) : -1;
     else if (!std::strcmp(key, "tp_walk_repair")) o.tp_walk_repair = on;
+    else if (!std::strcmp(key, "tp_unchecked")) o.tp_unchecked = on;
     else if (!std::strcmp(key, "tp_check")) o.tp_check = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan_waves")) o.tp_scan_waves = (value && value[0]) ? std::atoi(value) : 0;
     else if (!std::strcmp(key, "tp_scan_lean")) o.tp_scan_lean = (value && value[0]) ? std::atoi(value) : 0;

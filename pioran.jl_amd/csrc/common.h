@@ -34,6 +34,7 @@ struct ScanOptions {
     int tp_segments = 0;        // ... its segment count (0 = automatic)
     int tp_scan = -1;           // ... its boundary phase: 1 the scan over the segments' elements (tp_combine_kernel, round 6), 0 the sequential walk, -1 automatic
     int tp_check = 0;           // ... what the scan's check goes by: 0 (default) the state distance on the scale of the innovation variance; tools: 1 the state discrepancy relative to its largest entry, 3 an estimate of log L's relative error from the distance
+    bool tp_unchecked = false;  // ... no check, no repair: the family's own values whatever they are (tools, tests of the family's arithmetic; with scan_config "tp")
     bool tp_walk_repair = false; // ... draws whose scan fails its check go through the family's own boundary walk instead of the serial-chain kernel
     int tp_scan_waves = 0;      // ... 4: four wavefronts per combination also at 33 .. 48 rows (default there: eight)
     int tp_scan_lean = 0;       // ... 1: the scan's combinations with operands from global memory (tp_combine_lean_kernel) also below 49 rows (tests)
@@ -184,6 +185,8 @@ int pioran_tile_grad_supported_rows();
 int pioran_tp_supported_rows();
 int pioran_tp_padded_rows(int rows);
 size_t pioran_tp_workspace_doubles(int64_t B, int64_t N, int RP, int nseg);
+// scan: 0 boundary walk, unchecked (tools); 1 scan + verification launch + walk for the draws that fail (tools); 2 scan, checked by the filter, the caller repairs the draws whose
+// discrepancy (pioran_tp_disc) exceeds the threshold; 4 boundary walk, checked and repaired the same way
 int pioran_launch_tp(const ScanParams& p, int RP, int nseg, int64_t L, const int32_t* row_term, const int32_t* row_kind, double* work, hipStream_t stream, int scan = 0);
 int pioran_tp_scan_rows(int RP);
 // where pioran_launch_tp(.., scan != 0) leaves the scan's largest discrepancy per draw ([B], inside `work`), and the threshold it is held against

@@ -858,13 +858,13 @@ def test_ill_conditioned_draws_vs_quad_truth(ctx, golden_dir):
             ctx.set_option("scan_config", "tp")
             tpv, tpa = np.empty(len(truth)), np.empty(len(truth))
             for mode, dst in ((0, tpv), (-1, tpa)):
-                ctx.set_option("tp_scan", mode)
+                ctx.set_option("tp_scan", mode); ctx.set_option("tp_unchecked", mode == 0)         # (the family's own arithmetic | the product: checked, repaired)
                 for b0 in range(0, len(truth), 16):
                     sl = slice(b0, min(len(truth), b0 + 16))
                     dst[sl], st = ds.logl_batch(A[sl], Bc[sl], C, Dd, mu=mu[sl], nu=nu[sl], return_status=True)
                     assert name() == "tp" and (st == 0).all()
         finally:
-            ctx.set_option("scan_config", None); ctx.set_option("no_block", False); ctx.set_option("no_wide", False); ctx.set_option("tp_scan", -1)
+            ctx.set_option("scan_config", None); ctx.set_option("no_block", False); ctx.set_option("no_wide", False); ctx.set_option("tp_scan", -1); ctx.set_option("tp_unchecked", False)
         etp = np.abs(tpv - truth) / np.abs(truth)
         assert etp.max() < 5e-10 and np.median(etp) < 5e-12, (N, "tp", etp.max(), np.median(etp))
         eta = np.abs(tpa - truth) / np.abs(truth)

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """GPU: the scan's check with one filter sweep (the scan's states as they are) and with two (the second corrects them: the product's form) on many draws, scalar
-entry (series already mean-subtracted and scaled on the host, as bench.py's and the Julia shim's scalar calls do): per draw the error of the scan ALONE against the family's boundary
-walk (trusted to 1e-10: quad truth) and the smallest threshold of a ladder at which each measure accepts it.  For each measure and threshold: how many draws it accepts and the worst
+entry (series already mean-subtracted and scaled on the host, as bench.py's and the Julia shim's scalar calls do): per draw the error of the scan ALONE against the ORACLE and the smallest threshold of a ladder at which each measure accepts it.  For each measure and threshold: how many draws it accepts and the worst
 scan-alone error among them.  usage: tp_scan_metrics.py [draws = 192] [seed = 4321] [other: DRWCelerite-15, SHO-12, SHO-24, SHO-4 instead of DRWCelerite-20, SHO-20, DRWCelerite-10, SHO-8]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch; torch.cuda.init()
 import bench, pioran_jl_amd as pj
+from oracle import oracle as O
 ctx = pj.Context(0)
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 192
 t0_, y0_, e0_ = bench.synth_series(10000)
@@ -27,12 +27,10 @@ for NL in (10000, 30000, 65536):
             tt = time.perf_counter(); call(1); ts.append(time.perf_counter() - tt)
         fast = min(ts)
         rows = {0: [], 1: []}
+        refs, rsts = O.logl_batch(A, Bc, C, Dd, tL, yL, eL ** 2, theta[:nd, 5].copy(), theta[:nd, 4].copy(), nthreads=16, return_status=True)
         for i in range(nd):
-            ctx.set_option("scan_config", "tp"); ctx.set_option("tp_scan", 0)
-            try: vw = call(i)
-            except Exception: continue
-            finally: ctx.set_option("scan_config", None); ctx.set_option("tp_scan", -1)
-            if not np.isfinite(vw): continue
+            if rsts[i] or not np.isfinite(refs[i]): continue
+            vw = refs[i]                                                                                   # reference: the ORACLE (the walk is not one: tools/tp_walk_accuracy.py)
             ctx.set_option("tp_scan_tol", 1e30); vs = call(i)                                              # the scan alone
             ctx.set_option("tp_scan_tol", None); vp = call(i)                                             # the product path
             es, ep = abs(vs - vw) / abs(vw), abs(vp - vw) / abs(vw)
