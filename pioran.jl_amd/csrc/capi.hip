@@ -1784,9 +1784,10 @@ static int logl_grad_shared(pioran_ds* ds, int64_t B, int64_t J, const double* A
     // From 513 chains on (measured, SHO-20 / SHO-12 at N = 1e4: 512 chains 15.1 / 9.3 ms against the small-batch kernels' 11.0 / 9.2; 640 chains 15.2 /
     // 9.4 against 16.6 / 14.0; 2048 chains 27 / 16 against 44 / 36).
     const bool tilegrad = windowed && (grad_c != nullptr) == (grad_d != nullptr) && !grad_y && !grad_sigma2 && !shift && s.R <= pioran_tile_grad_supported_rows() &&
-                          (ctx->opt.force_tile || (!ctx->opt.no_tile && B > 512 && s.R >= 17 && s.R <= 47));
-    // (48 .. 63 rows — DRWCelerite-20 is 60 — run on it when forced: three draws per workgroup there (two with d/d(c, d)), and 4096 chains take 177 ms (208 with
-    //  d/d(c, d)) against 164 (174) in 512-chain launches of the small-batch kernels: tools/ab_tile_grad_nb4.py, profiles/r06_tile_grad_four_block_columns.txt)
+                          (ctx->opt.force_tile || (!ctx->opt.no_tile && B > 512 && s.R >= 17));
+    // (48 .. 63 rows — DRWCelerite-20 is 60: three draws per workgroup there (two with d/d(c, d)); 4096 chains take 126 ms (163 with d/d(c, d)) against 166 (175)
+    //  in 512-chain launches of the small-batch kernels: tools/ab_tile_grad_nb4.py, profiles/r06_tile_grad_four_block_columns.txt.  Until the reverse kernel
+    //  stopped spilling at four block columns — T_k and the window's U operands loaded at the head of their own window instead of a window ahead — it was 177 (208).)
     auto ws_doubles = [&](int64_t nb) {
         return tilegrad ? pioran_tile_grad_workspace_doubles(nb, ds->N, s.R)
                         : (windowed ? pioran_block_grad_workspace_doubles(nb, ds->N, s.R) : pioran_grad_workspace_doubles(nb, ds->N, s.R));

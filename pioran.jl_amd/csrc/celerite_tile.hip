@@ -45,6 +45,9 @@ namespace {
 constexpr int kTileMaxTerms = 64;
 constexpr int kTileWaves = 4;      // wavefronts (= draws) per workgroup
 // ... of the reverse mode: T_k and T- of a draw are 45 KB (53 with d/d(c, d)) of LDS at four block columns — three draws fit a CU, not four
+// Between a wavefront's LDS writes and its own reads of the same addresses no counter wait is needed — the LDS executes a wavefront's instructions in order —
+// only the compiler has to keep the order:
+#define PIORAN_LDS_ORDER() asm volatile("" ::: "memory")
 template <int NB, bool CD = false>
 constexpr int tile_adj_waves() { return NB <= 3 ? 4 : (CD ? 2 : 3); }
 
@@ -459,6 +462,8 @@ struct TileAdjWave {
     double mw[CD ? NB : 1][CD ? 256 : 1];                  // d/d(c, d): M' of the window, C/D order [register][lane] (x goes on to hold X', then Q')
     double accd[CD ? 2 * NB : 1][CD ? 64 : 1];             // ... its per-lane sums (d/dc rows | d/dd rows of block column Jc) and the window's time stamps t_n, t_b, t_e:
     double tm[CD ? 24 : 1];                                //     in LDS, not in registers (24 live registers less: 175 -> 90 spilled, 4096 chains of SHO-20 84 -> 69 ms)
+    double scrb[(NB <= 3 && !CD) ? NB : 1][(NB <= 3 && !CD) ? 16 * 18 : 1];   // one transposing scratch per block column where LDS has room (tile_adj_batched): the
+                                                           // window's 15 LDS round trips (write a block, wait, read it transposed, wait) become 5
     double acab[2 * NB][64];                               // per-lane sums of d/dal | d/dbe of block column Jc, the same move for both instantiations: 43 -> 1 spilled
                                                            // registers without d/d(c, d), 90 -> 4 with (53.7 -> 49.9 ms, 69 -> 57 ms per 4096 chains of SHO-20)
 };
@@ -467,6 +472,8 @@ struct TileAdjWave {
 //   d/dc_r -= sum_n U~-'[n][r] U~'[n][r] (t_n - t_b) + sum_n X-'[n][r] V^'[n][r] (t_e - t_n) + cK-_r cK_r (t_e - t_b),  cK-_r = 2 sum_j T-_jr cK_j T_jr - sum_n X-'[n][r] M'[n][r]
 //   d/dd_r += s_r sum_n t_n (U~-'[n][r] (al_r C x - be_r C v)[n][r] + X-'[n][r] ((C_K / C) x)[n][r]),  s_r = -1 (cos row), +1 (sin row));
 // the pair part (d/dc E = -tau E, d/dd (E.cos, E.sin) = tau (-E.sin, E.cos)) is the post-pass's second product (tile_pairs_grad_kernel<true>).
+template <int NB, bool CD>
+constexpr bool tile_adj_batched() { return NB <= 3 && !CD; }
 template <int NB, bool CD = false>
 __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_tile_adjoint_kernel(const ScanParams p, const double* __restrict__ btab,
                                                                                                   const double* __restrict__ gtab, double* __restrict__ pairs,
@@ -477,6 +484,7 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
     constexpr int TS = 3 * NB * 256 + 16 * NB + 16, TSP = (TS + 127) & ~127;
     constexpr int64_t GS = 4 * (int64_t)NB * 256 + 16 * NB + 16 + 24;     // block_gtab_doubles (celerite_block.hip): C o v | C o x (C/D order) | C_K | sigma2 | ...
     constexpr int NT = NB * (NB + 1) / 2, NU = NB * (NB - 1) / 2;
+    constexpr bool BT = tile_adj_batched<NB, CD>();
     extern __shared__ double lds_[];
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -534,8 +542,14 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
 #pragma unroll
         for (int Jc = 0; Jc < 2 * NB; ++Jc) sw.accd[Jc][lane] = 0.0;
     }
-    [[maybe_unused]] auto add_c = [&](int Jc, double v) __attribute__((always_inline)) { sw.accd[Jc][lane] += v; };
-    [[maybe_unused]] auto add_d = [&](int Jc, double v) __attribute__((always_inline)) { sw.accd[NB + Jc][lane] += v; };
+    // per-lane sums in LDS: ds_add_f64 without a return value — nothing to wait for
+    // (with d/d(c, d) the plain read - add - write stays: there the atomic form costs 19 more spilled registers, 57 -> 60 ms per 4096 chains of SHO-20)
+    auto lds_add = [](double* slot, double v) __attribute__((always_inline)) {
+        if constexpr (CD) *slot += v;
+        else (void)__hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    };
+    [[maybe_unused]] auto add_c = [&](int Jc, double v) __attribute__((always_inline)) { lds_add(&sw.accd[Jc][lane], v); };
+    [[maybe_unused]] auto add_d = [&](int Jc, double v) __attribute__((always_inline)) { lds_add(&sw.accd[NB + Jc][lane], v); };
     [[maybe_unused]] constexpr int OFF_H = 2 * NB * 256 + 16 * NB + 16, OFF_TM = OFF_H + 2 * NB * 256;     // gtab: (C_K / C) o v | (C_K / C) o x | t_n x 16, t_b, t_e
     int pidx[4];
 #pragma unroll
@@ -562,24 +576,39 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
     //   (C_K / C) o v at the head of the window (used after M'), C o v / C o x in C/D order before phase A (used in C and D).
     // T_k itself sits in LDS for the window (lower tiles, read as they stand or transposed): registers hold it only on its way there.
     constexpr int NCK = (16 * NB + 16 + 63) / 64;
+    constexpr int NWARM = (NT * 2048 + 8191) / 8192;
+    constexpr bool PFT = NB <= 3;       // T_k a window ahead in registers; four block columns: 80 registers the kernel does not have (253 spilled: a window
+                                        // took four times the cycles of three block columns) — there T_k is loaded at the head of its own window, in two halves
     struct WinIn {
-        d4 T[NT];
-        double cva[NB][4], cxa[NB][4];      // C o v, C o x, A-operand order (btab)
+        d4 T[PFT ? NT : 1];
+        double cva[PFT ? NB : 1][4], cxa[PFT ? NB : 1][4];      // C o v, C o x, A-operand order (btab)
         double ckp[NCK];
         double ap[4];
+        float warm[PFT ? 1 : NWARM];        // four block columns: one word of every 128-byte line of the next T_k, so that the head's loads find it in L2
     };
     auto fetch_win = [&](int64_t kk, WinIn& wi) __attribute__((always_inline)) {
         const int wso = (int)kk * rsb8;
         const d4* tk = reinterpret_cast<const d4*>(gtb + kk * NT * 256);
+        if constexpr (PFT) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i) wi.T[i] = tk[i * 64 + lane];
+            for (int i = 0; i < NT; ++i) wi.T[i] = tk[i * 64 + lane];
+        } else {
+            const float* tw = reinterpret_cast<const float*>(tk);
 #pragma unroll
-        for (int I = 0; I < NB; ++I)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                wi.cva[I][ks] = tile_bload(rs_tab, lane8, wso + (I * 4 + ks) * 512);
-                wi.cxa[I][ks] = tile_bload(rs_tab, lane8, wso + (NB * 256 + (I * 4 + ks) * 64) * 8);
+            for (int j = 0; j < NWARM; ++j) {
+                const int line = j * 64 + lane;
+                wi.warm[j] = tw[(line < NT * 16 ? line : NT * 16 - 1) * 32];
             }
+        }
+        if constexpr (PFT) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    wi.cva[I][ks] = tile_bload(rs_tab, lane8, wso + (I * 4 + ks) * 512);
+                    wi.cxa[I][ks] = tile_bload(rs_tab, lane8, wso + (NB * 256 + (I * 4 + ks) * 64) * 8);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < NCK; ++i) wi.ckp[i] = tile_bload(rs_tab, lane8, wso + 3 * NB * 256 * 8 + 512 * i);
 #pragma unroll
@@ -592,6 +621,24 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
     for (int64_t k = NW - 1; k >= 0; --k) {
         PIORAN_ASTAMP2(0);
         const int wso = (int)k * rsb8, gso = (int)k * gs8;
+        [[maybe_unused]] d4 tnow[PFT ? 1 : NT];      // four block columns: T_k of this window, first in the queue (warmed into L2 a window ago)
+        [[maybe_unused]] double cvh[PFT ? 1 : NB][4], cxh[PFT ? 1 : NB][4];
+        if constexpr (!PFT) {
+#pragma unroll
+            for (int j = 0; j < NWARM; ++j) asm volatile("" ::"v"(cur.warm[j]));
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    cvh[I][ks] = tile_bload(rs_tab, lane8, wso + (I * 4 + ks) * 512);
+                    cxh[I][ks] = tile_bload(rs_tab, lane8, wso + (NB * 256 + (I * 4 + ks) * 64) * 8);
+                }
+            const d4* tkg = reinterpret_cast<const d4*>(gtb + k * NT * 256);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) tnow[i] = tkg[i * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);      // (all of them in flight together: left to itself the compiler issues them pair by pair next to their uses,
+                                                    //  sixteen memory round trips in a row — 14 000 of a window's 57 000 cycles)
+        }
         double vhs[NB][4];
 #pragma unroll
         for (int I = 0; I < NB; ++I)
@@ -610,14 +657,22 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const double2 cf = sw.albe[16 * I + 4 * ks + q];
-                Uf[I][ks] = fma(cf.x, cur.cva[I][ks], cf.y * cur.cxa[I][ks]);
+                if constexpr (PFT) Uf[I][ks] = fma(cf.x, cur.cva[I][ks], cf.y * cur.cxa[I][ks]);
+                else Uf[I][ks] = fma(cf.x, cvh[I][ks], cf.y * cxh[I][ks]);
             }
         // the lower tiles of T_k -> LDS
+        if constexpr (PFT) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+            for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) sw.tk[i][(4 * g + q) * 18 + c16] = cur.T[i][g];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int g = 0; g < 4; ++g) sw.tk[i][(4 * g + q) * 18 + c16] = cur.T[i][g];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sw.tk[i][(4 * g + q) * 18 + c16] = tnow[i][g];
+        }
+        PIORAN_LDS_ORDER();
         __builtin_amdgcn_sched_barrier(0);
         PIORAN_ASTAMP2(1);
         // ---- forward window again: M' = U~' T_k ----------------------------------------------------------------------------------
@@ -647,6 +702,34 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
         PIORAN_ASTAMP2(2);
         // ---- G = U~' M, X' = V^' - C_K o M' ----------------------------------------------------------------------------------------
         d4 G = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (BT) {
+            double mb[NB][4], ckc[NB];
+#pragma unroll
+            for (int Jc = 0; Jc < NB; ++Jc)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sw.scrb[Jc][(4 * g + q) * 18 + c16] = x[Jc][g];
+            PIORAN_LDS_ORDER();
+#pragma unroll
+            for (int Jc = 0; Jc < NB; ++Jc) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) mb[Jc][ks] = sw.scrb[Jc][c16 * 18 + 4 * ks + q];
+                ckc[Jc] = sw.ck[16 * Jc + c16];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int Jc = 0; Jc < NB; ++Jc)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) G = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[Jc][ks], mb[Jc][ks], G, 0, 0, 0);
+#pragma unroll
+            for (int Jc = 0; Jc < NB; ++Jc)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    double v = vhs[Jc][g] - mu_sel[Jc];
+                    if (k == k_ragged && k * KW + 4 * g + q >= N) v = 0.0;
+                    x[Jc][g] = fma(-ckc[Jc], x[Jc][g], v);
+                    asm volatile("" : "+v"(x[Jc][g]));
+                }
+        } else {
 #pragma unroll
         for (int Jc = 0; Jc < NB; ++Jc) {
 #pragma unroll
@@ -655,7 +738,7 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
 #pragma unroll
                 for (int g = 0; g < 4; ++g) sw.mw[Jc][g * 64 + lane] = x[Jc][g];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PIORAN_LDS_ORDER();
             double mb[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) mb[ks] = sw.scr[c16 * 18 + 4 * ks + q];
@@ -671,6 +754,7 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
                 asm volatile("" : "+v"(x[Jc][g]));
             }
         }
+        }
         __builtin_amdgcn_sched_barrier(0);
         PIORAN_ASTAMP2(3);
         // ---- Sigma = A - G, LDL', L^-1 ---------------------------------------------------------------------------------------------
@@ -681,7 +765,7 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
 #pragma unroll
             for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 16 + c16] = ((on_diag && g == gd) ? dg : apre[g]) - G[g];
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIORAN_LDS_ORDER();
         double m[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) m[j] = sw.scr[j * 16 + c16];
@@ -695,7 +779,7 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
 #pragma unroll
             for (int j = 0; j < 16; j += 2) dst[j / 2] = double2{m[j], m[j + 1]};
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIORAN_LDS_ORDER();
         // operands: L^-1 (A operand of Y^' = L^-1 X'), L^-T D^-1 (A operand of Q' = L^-T D^-1 Y^'), and K = L^-T D^-1 L^-1
         double li[4], lt[4], la[4], lb[4];
         {
@@ -718,14 +802,30 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
         for (int ks = 0; ks < 4; ++ks) Kv = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], lb[ks], Kv, 0, 0, 0);
         PIORAN_ASTAMP2(6);
         // ---- Q' = Sigma^-1 X' ---------------------------------------------------------------------------------------------------------
+        if constexpr (BT) {      // the block columns' chains side by side: a product waits for the one that feeds its B operand, not for its accumulator
+            d4 yt[NB], qv[NB];
 #pragma unroll
-        for (int Jc = 0; Jc < NB; ++Jc) {
-            d4 yt = {0.0, 0.0, 0.0, 0.0}, qv = {0.0, 0.0, 0.0, 0.0};
+            for (int Jc = 0; Jc < NB; ++Jc) { yt[Jc] = d4{0.0, 0.0, 0.0, 0.0}; qv[Jc] = d4{0.0, 0.0, 0.0, 0.0}; }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) yt = __builtin_amdgcn_mfma_f64_16x16x4f64(li[ks], x[Jc][ks], yt, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qv = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[ks], yt[ks], qv, 0, 0, 0);
-            x[Jc] = qv;                                            // from here on x holds Q'
+                for (int Jc = 0; Jc < NB; ++Jc) yt[Jc] = __builtin_amdgcn_mfma_f64_16x16x4f64(li[ks], x[Jc][ks], yt[Jc], 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int Jc = 0; Jc < NB; ++Jc) qv[Jc] = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[ks], yt[Jc][ks], qv[Jc], 0, 0, 0);
+#pragma unroll
+            for (int Jc = 0; Jc < NB; ++Jc) x[Jc] = qv[Jc];
+        } else {
+#pragma unroll
+            for (int Jc = 0; Jc < NB; ++Jc) {
+                d4 yt = {0.0, 0.0, 0.0, 0.0}, qv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) yt = __builtin_amdgcn_mfma_f64_16x16x4f64(li[ks], x[Jc][ks], yt, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qv = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[ks], yt[ks], qv, 0, 0, 0);
+                x[Jc] = qv;                                            // from here on x holds Q'
+            }
         }
         if (c16 == ry) {                                            // q_y: the y column of Q' (block Jy), by step
             static_for<0, NB>([&](auto Ic) __attribute__((always_inline)) {
@@ -749,17 +849,65 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
         __builtin_amdgcn_sched_barrier(0);
         // ---- A: Q in A-operand order; X-' = 2 Q' T- (- q_y in the y column); P = Q' T- Q -----------------------------------------------
         double qf[NB][4];
+        d4 xb[NB];
+        d4 P = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (BT) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sw.scrb[I][(4 * g + q) * 18 + c16] = x[I][g];
+            PIORAN_LDS_ORDER();
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qf[I][ks] = sw.scrb[I][c16 * 18 + 4 * ks + q];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            d4 qt[NB];
+#pragma unroll
+            for (int Jc = 0; Jc < NB; ++Jc) {
+                qt[Jc] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int I = 0; I < Jc; ++I) {
+                    double bt[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) bt[ks] = sw.upB[uix(Jc, I)][c16 * 18 + 4 * ks + q];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) qt[Jc] = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[I][ks], bt[ks], qt[Jc], 0, 0, 0);
+                }
+#pragma unroll
+                for (int I = Jc; I < NB; ++I)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) qt[Jc] = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[I][ks], Tb[tix(I, Jc)][ks], qt[Jc], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sw.scrb[Jc][(4 * g + q) * 18 + c16] = qt[Jc][g];
+            }
+            PIORAN_LDS_ORDER();
+            double qtT[NB][4];
+#pragma unroll
+            for (int Jc = 0; Jc < NB; ++Jc)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qtT[Jc][ks] = sw.scrb[Jc][c16 * 18 + 4 * ks + q];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int Jc = 0; Jc < NB; ++Jc) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) P = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[Jc][ks], qtT[Jc][ks], P, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    xb[Jc][g] = fma(-ymask[Jc], x[Jc][g], 2.0 * qt[Jc][g]);
+                    acc_mu = fma(-ymask[Jc], xb[Jc][g], acc_mu);      // (padded steps: Q' = 0 there, nothing to mask)
+                }
+            }
+        } else {
 #pragma unroll
         for (int I = 0; I < NB; ++I) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 18 + c16] = x[I][g];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PIORAN_LDS_ORDER();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qf[I][ks] = sw.scr[c16 * 18 + 4 * ks + q];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        d4 xb[NB];
-        d4 P = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int Jc = 0; Jc < NB; ++Jc) {
             d4 qt = {0.0, 0.0, 0.0, 0.0};
@@ -777,7 +925,7 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
                 for (int ks = 0; ks < 4; ++ks) qt = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[I][ks], Tb[tix(I, Jc)][ks], qt, 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 18 + c16] = qt[g];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PIORAN_LDS_ORDER();
             double qtT[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qtT[ks] = sw.scr[c16 * 18 + 4 * ks + q];
@@ -789,6 +937,7 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
                 xb[Jc][g] = fma(-ymask[Jc], x[Jc][g], 2.0 * qt[g]);
                 acc_mu = fma(-ymask[Jc], xb[Jc][g], acc_mu);      // (padded steps: Q' = 0 there, nothing to mask)
             }
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         PIORAN_ASTAMP2(8);
@@ -805,7 +954,7 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIORAN_LDS_ORDER();
         double sA[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) sA[ks] = 0.5 * (sw.srm[c16 * 16 + 4 * ks + q] + sw.srm[(4 * ks + q) * 16 + c16]);   // symmetrised
@@ -832,6 +981,31 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
             if (lane < 18) sw.tm[lane] = tile_bload(rs_gt, lane8, gso + OFF_TM * 8);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
+        if constexpr (BT) {      // (never with d/d(c, d): tile_adj_batched)
+            d4 su[NB];
+#pragma unroll
+            for (int Jc = 0; Jc < NB; ++Jc) su[Jc] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int Jc = 0; Jc < NB; ++Jc) su[Jc] = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[ks], uw[Jc][ks], su[Jc], 0, 0, 0);
+#pragma unroll
+            for (int Jc = 0; Jc < NB; ++Jc) {
+                const double ckc = sw.ck[16 * Jc + c16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const double cx_ = -ckc * xb[Jc][g];
+                    mbk[Jc][g] = cx_ - su[Jc][g];
+                    sw.scrb[Jc][(4 * g + q) * 18 + c16] = cx_ - 2.0 * su[Jc][g];
+                }
+            }
+            PIORAN_LDS_ORDER();
+#pragma unroll
+            for (int Jc = 0; Jc < NB; ++Jc)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wa[Jc][ks] = sw.scrb[Jc][c16 * 18 + 4 * ks + q];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
 #pragma unroll
         for (int Jc = 0; Jc < NB; ++Jc) {
             [[maybe_unused]] double hvw[4], hxw[4];
@@ -852,7 +1026,7 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
                 mbk[Jc][g] = cx_ - su[g];
                 sw.scr[(4 * g + q) * 18 + c16] = cx_ - 2.0 * su[g];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PIORAN_LDS_ORDER();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) wa[Jc][ks] = sw.scr[c16 * 18 + 4 * ks + q];
             if constexpr (CD) {             // the X-' terms: -sum X-' V^' (t_e - t_n), + sum t_n X-' ((C_K / C) x), and cK-_r's  - sum X-' M'  times  -cK_r (t_e - t_b)
@@ -869,6 +1043,7 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
                 add_d(Jc, pd);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         PIORAN_ASTAMP2(10);
@@ -899,8 +1074,8 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
                     pa = fma(ub[g], cvs[Jc][g], pa);
                     pb = fma(ub[g], cxs[Jc][g], pb);
                 }
-                sw.acab[Jc][lane] += pa;
-                sw.acab[NB + Jc][lane] += pb;
+                lds_add(&sw.acab[Jc][lane], pa);
+                lds_add(&sw.acab[NB + Jc][lane], pb);
             }
             if constexpr (CD) {             // the U~-' terms of d/d(c, d) (the X-' terms: phase C; the T- o T_k term: the update below)
                 double pc = 0.0, pd = 0.0;
@@ -919,9 +1094,23 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
         PIORAN_ASTAMP2(11);
         if (k > 0) fetch_win(k - 1, cur);          // T_k has had its last use: window k - 1's inputs, straight into the same registers
         __builtin_amdgcn_sched_barrier(0);
+        // C_K of the tiles' rows and columns read once, in front of the tiles (a read and a wait per tile before).  Not with d/d(c, d): 20 more registers
+        // there are 20 .. 30 more spilled ones (57 -> 59 ms per 4096 chains of SHO-20).  (Also measured, round 6: all rescalings, then the matrix instructions of
+        // all tiles back to back, then the LDS copies — no faster, 45.9 -> 47.1 ms at three block columns.)
+        [[maybe_unused]] double ckrow[CD ? 1 : NB][4], ckcol[CD ? 1 : NB];
+        if constexpr (!CD) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ckrow[I][g] = sw.ck[16 * I + 4 * g + q];
+                ckcol[I] = sw.ck[16 * I + c16];
+            }
+        }
+        auto ck_row = [&](int I, int g) __attribute__((always_inline)) -> double { if constexpr (CD) return sw.ck[16 * I + 4 * g + q]; else return ckrow[I][g]; };
+        auto ck_col = [&](int I) __attribute__((always_inline)) -> double { if constexpr (CD) return sw.ck[16 * I + c16]; else return ckcol[I]; };
 #pragma unroll
         for (int Jc = 0; Jc < NB; ++Jc) {
-            const double ckc = sw.ck[16 * Jc + c16];
+            const double ckc = ck_col(Jc);
             double hm[4], hu[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { hm[ks] = 0.5 * mbk[Jc][ks]; hu[ks] = 0.5 * uw[Jc][ks]; }
@@ -933,19 +1122,19 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
                     // columns of block I, read transposed from the LDS copies (T- from the previous window's update, T_k from this window's head)
                     double s1 = 0.0;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) s1 = fma(Tb[tix(I, Jc)][g] * sw.ck[16 * I + 4 * g + q], sw.tk[tix(I, Jc)][(4 * g + q) * 18 + c16], s1);
+                    for (int g = 0; g < 4; ++g) s1 = fma(Tb[tix(I, Jc)][g] * ck_row(I, g), sw.tk[tix(I, Jc)][(4 * g + q) * 18 + c16], s1);
                     const double tspan = sw.tm[17] - sw.tm[16];
                     add_c(Jc, -2.0 * s1 * ckc * tspan);
                     if (Jc < I) {
                         double s2 = 0.0;
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            s2 = fma(sw.upB[uix(I, Jc)][c16 * 18 + 4 * g + q] * sw.ck[16 * Jc + 4 * g + q], sw.tk[tix(I, Jc)][c16 * 18 + 4 * g + q], s2);
-                        add_c(I, -2.0 * s2 * sw.ck[16 * I + c16] * tspan);
+                            s2 = fma(sw.upB[uix(I, Jc)][c16 * 18 + 4 * g + q] * ck_row(Jc, g), sw.tk[tix(I, Jc)][c16 * 18 + 4 * g + q], s2);
+                        add_c(I, -2.0 * s2 * ck_col(I) * tspan);
                     }
                 }
 #pragma unroll
-                for (int g = 0; g < 4; ++g) Tb[tix(I, Jc)][g] *= sw.ck[16 * I + 4 * g + q] * ckc;
+                for (int g = 0; g < 4; ++g) Tb[tix(I, Jc)][g] *= ck_row(I, g) * ckc;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     Tb[tix(I, Jc)] = __builtin_amdgcn_mfma_f64_16x16x4f64(uw[I][ks], hm[ks], Tb[tix(I, Jc)], 0, 0, 0);
@@ -957,7 +1146,7 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIORAN_LDS_ORDER();
         PIORAN_ASTAMP2(12);
     }
     PIORAN_ASTAMP2_FLUSH

@@ -2236,8 +2236,8 @@ TILE_GRAD = "tile (windowed gradient, one draw per wavefront)"
 def test_tile_gradient_matches_complex_step(ctx, J, N, B, nreal):
     """d log L / d(a_j, b_j, mu, nu) by the one-draw-per-wavefront reverse mode (celerite_tile_adjoint_kernel, round 5; what many chains of an
     approx-based model ask for), forced here at every batch size: against the complex-step derivatives of the oracle and the small-batch windowed
-    reverse mode; block columns NB = 1 .. 4 (up to 63 rows; at four — DRWCelerite-20's 60 rows — three draws per workgroup, forced only: the small-batch
-    kernels are faster there), ragged last windows, N = 16 and 17 (one window / one step in the second), one-row terms, more draws than one workgroup
+    reverse mode; block columns NB = 1 .. 4 (up to 63 rows; at four — DRWCelerite-20's 60 rows — three draws per workgroup and T_k loaded at the head of
+    its own window), ragged last windows, N = 16 and 17 (one window / one step in the second), one-row terms, more draws than one workgroup
     holds; the value is bit-identical to the tile forward kernel's."""
     rng = np.random.default_rng(7700 + J + N)
     t, y, s2, A, Bc, C, Dd, mu, nu = _random_case(rng, N, J, B)
@@ -2276,7 +2276,7 @@ def test_tile_gradient_matches_complex_step(ctx, J, N, B, nreal):
 
 
 def test_tile_gradient_dispatch_chunks_and_flagged_draws(ctx):
-    """The automatic choice (more than 512 chains, 17 .. 47 rows, d/d(a, b, mu, nu) only), "no_tile", a workspace limit that forces several
+    """The automatic choice (more than 512 chains, 17 .. 63 rows, with or without d/d(c, d) of shared (c, d)), "no_tile", a workspace limit that forces several
     launches (the chunk is cut by 1024 chains, then halved), optional outputs left out, and a draw that is not positive definite: its status
     is the forward kernel's and the other chains are untouched."""
     rng = np.random.default_rng(4242)
@@ -2336,8 +2336,8 @@ def test_tile_gradient_dispatch_chunks_and_flagged_draws(ctx):
 def test_tile_gradient_full_size(ctx, full_size):
     """N = 1e4 (BASELINE shape), 1024 prior draws of SHO-20 (40 rows) and DRWCelerite-15 (45 rows, 15 of the 30 terms with one row): the
     one-draw-per-wavefront reverse mode against the small-batch windowed reverse mode on every chain both call positive definite, and against
-    complex steps of the oracle.  (DRWCelerite-20 has 60 rows: four block columns, three draws per workgroup on the tile reverse kernel, which is slower than
-    the small-batch kernels there — block.)"""
+    complex steps of the oracle; DRWCelerite-20 (60 rows: four block columns, three draws per workgroup — automatic since the reverse kernel stopped
+    spilling there, round 6) likewise.  Up to 512 chains: the small-batch kernels."""
     t, y, yerr = full_size
     th = O.synthetic_theta(1024, t, y, seed=77)
     ds = pj.Dataset(t, y, yerr ** 2, ctx)
@@ -2346,7 +2346,7 @@ def test_tile_gradient_full_size(ctx, full_size):
     A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th[:300], t, 20, "DRWCelerite")
     ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
     assert name() == "block (windowed gradient)"
-    for basis, ncomp in (("SHO", 20), ("DRWCelerite", 15)):
+    for basis, ncomp in (("SHO", 20), ("DRWCelerite", 15), ("DRWCelerite", 20)):
         A, Bc, C, Dd, mu, nu = O.theta_to_coefs(th, t, ncomp, basis)
         g = ds.logl_grad(A, Bc, C, Dd, mu=mu, nu=nu, cd_grad=False)
         assert name() == TILE_GRAD

@@ -80,7 +80,7 @@ int main(int argc, char** argv)
         p.gw = gw;
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0, 0);
-            int rc = pioran_launch_tile_grad(p, btab, gtab, work, ga, gb, gn, gm, 0);
+            int rc = pioran_launch_tile_grad(p, btab, gtab, work, ga, gb, gn, gm, nullptr, nullptr, 0);
             hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
             if (rc) { printf("grad launch rc %d\n", rc); return 1; }
         }
@@ -93,6 +93,7 @@ int main(int argc, char** argv)
         unsigned long long tot = 0; for (int i = 0; i < 13; ++i) tot += aacc[0][i];
         printf("reverse kernel, wavefront 0: %.0f cycles per window\n", (double)tot / nw);
         for (int i = 1; i < 13; ++i) printf("  %-58s %8.1f\n", an[i], (double)aacc[0][i] / nw);
+
     }
     return 0;
 }
