@@ -385,6 +385,20 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
             yt[Jc] = a;
         }
         PIORAN_TSTAMP(7);
+        // C_K of the tiles' rows and columns: up to three block columns read once, in front of the tiles (round 6: left at its uses, every tile starts with an
+        // LDS read and a wait for it; SHO-20 10.18 -> 9.97 ms per 4096 draws).  With four block columns the 20 values cost spilled registers (DRWCelerite-20
+        // 15.99 -> 16.33 ms): read per tile there, as before.
+        constexpr bool CKP = NB <= 3;
+        [[maybe_unused]] double ckrow[CKP ? NB : 1][4], ckcol[CKP ? NB : 1];
+        if constexpr (CKP) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ckrow[I][g] = sw.ck[16 * I + 4 * g + q];
+                ckcol[I] = sw.ck[16 * I + c16];
+            }
+        }
+        auto ck_row = [&](int I, int g) __attribute__((always_inline)) -> double { if constexpr (CKP) return ckrow[I][g]; else return sw.ck[16 * I + 4 * g + q]; };
         // ---- T <- (C_K C_K') o T + Y^ D^-1 Y^', lower tiles, one block column at a time; the off-diagonal ones are copied to LDS for the
         //      next window's M'; U~ of the next window is formed on the way ------------------------------------------------------
 #pragma unroll
@@ -394,7 +408,8 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
                 if (Jc + 1 < NB) fetch_u(k + 1, Jc + 1);
             }
             double ysc[4];
-            const double ckc = sw.ck[16 * Jc + c16];
+            double ckc;
+            if constexpr (CKP) ckc = ckcol[Jc]; else ckc = sw.ck[16 * Jc + c16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 ysc[g] = yt[Jc][g] * idv[g];
@@ -403,7 +418,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
 #pragma unroll
             for (int I = Jc; I < NB; ++I) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) T[tix(I, Jc)][g] *= sw.ck[16 * I + 4 * g + q] * ckc;
+                for (int g = 0; g < 4; ++g) T[tix(I, Jc)][g] *= ck_row(I, g) * ckc;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) T[tix(I, Jc)] = __builtin_amdgcn_mfma_f64_16x16x4f64(yt[I][ks], ysc[ks], T[tix(I, Jc)], 0, 0, 0);
                 if (Jc < I) {
