@@ -199,11 +199,12 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
         }
     };
     auto form_u = [&](int I) __attribute__((always_inline)) {
+        double2 cf[4];          // the four (al, be) reads together, one wait (left to the compiler: read, wait, two FMAs, four times in a row)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const double2 cf = sw.albe[16 * I + 4 * ks + q];
-            Uf[I][ks] = fma(cf.x, cvn[ks], cf.y * cxn[ks]);
-        }
+        for (int ks = 0; ks < 4; ++ks) cf[ks] = sw.albe[16 * I + 4 * ks + q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) Uf[I][ks] = fma(cf[ks].x, cvn[ks], cf[ks].y * cxn[ks]);
     };
     // C_K and sigma2 of window k: fetched a window ahead, staged in LDS at the start of the window
     constexpr int NCK = (16 * NB + 16 + 63) / 64;
@@ -301,6 +302,11 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
         double vh[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) vh[g] = tile_bload(rs_tab, lane8, wso + (2 * NB * 256 + g * 64) * 8);
+        double ysv[4] = {0.0, 0.0, 0.0, 0.0};     // per-draw series: read here, under the wave-uniform test (inside the block-column loop the compiler turns the
+        if (has_series) {                         // test into a select and reads sw.ys for every block column, a wait each — also when there is no series)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ysv[g] = sw.ys[4 * g + q];
+        }
 #pragma unroll
         for (int Jc = 0; Jc < NB; ++Jc) {
 #pragma unroll
@@ -316,7 +322,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 double v = vh[g];
-                if (has_series && Jc == Jy && c16 == ry) v = sw.ys[4 * g + q];     // (the table's y row holds the shared series)
+                if (has_series && Jc == Jy && c16 == ry) v = ysv[g];     // (the table's y row holds the shared series)
                 v -= mu_sel[Jc];
                 if (k == k_ragged && k * KW + 4 * g + q >= N) v = 0.0;     // (wave-uniform test first: only the last, ragged window pays for the mask)
                 x[Jc][g] = fma(-ckc, x[Jc][g], v);
