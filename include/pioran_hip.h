@@ -241,11 +241,12 @@ int pioran_celerite_predict(pioran_ds* ds, int64_t B, int64_t J, const double* A
  * grad_c / grad_d).  With 64 .. 143 rows (and as a cross-check: context option "no_block") the STEP-BY-STEP reverse mode runs
  * (celerite_wide.hip: forward pass with checkpoints, replayed segments, lean adjoint kernel since round 4): 40 .. 45 ms at 64 .. 95 rows,
  * 62 .. 157 ms at 96 .. 143 (the reference benchmark grid's j = 64 is 128 rows) at N = 1e4.  More than 143 rows: PIORAN_ERR_UNSUPPORTED.
- * Many chains (round 5): with more than 512 chains, 17 .. 47 rows, shared (c, d), grad_c = grad_d = grad_y = grad_sigma2 = NULL (value and
- * d/d(a, b, mu, nu): what the approx-based models' samplers ask for — (c, d) shared by the chains are fixed by the spectral grid) the reverse mode
+ * Many chains (round 5): with more than 512 chains, 17 .. 63 rows (round 6: four block columns), shared (c, d), grad_y = grad_sigma2 = NULL (value and
+ * d/d(a, b, mu, nu) — what the approx-based models' samplers ask for: (c, d) shared by the chains are fixed by the spectral grid — and, round 6, d/d(c, d) of
+ * the shared (c, d): grad_c and grad_d both or neither) the reverse mode
  * with ONE DRAW PER WAVEFRONT runs (celerite_tile.hip): its forward pass keeps only the lower tiles of T per window (7.5 MB per chain at N = 1e4,
- * chunks of 2048 chains under the default workspace limit) and the reverse kernel recomputes the rest — 4096 chains 54 ms (100 ms on the
- * small-batch kernels).  Context option "no_tile" keeps every chain count on the small-batch kernels, "scan_config" = "tile" forces the new
+ * chunks of 2048 chains under the default workspace limit) and the reverse kernel recomputes the rest — 4096 chains of SHO-20 45.7 ms (56.0 with d/d(c, d);
+ * 88 / 100 ms on the small-batch kernels), of DRWCelerite-20 (60 rows) 125 / 154 ms (166 / 175).  Context option "no_tile" keeps every chain count on the small-batch kernels, "scan_config" = "tile" forces the new
  * family from one chain on; config name "tile (windowed gradient, one draw per wavefront)".
  * Memory (step-by-step mode): the forward pass keeps the R x R state only at checkpoints (every ~2 sqrt(N) steps) and the reverse pass replays one
  * segment at a time: ~15 MB of workspace per draw at N = 1e4, J = 20 (two replayed segments + checkpoints 11 MB, stored m / D 4 MB: pioran_grad_workspace_doubles;
