@@ -42,6 +42,26 @@
 
 namespace {
 
+#ifndef PIORAN_TILE_FWD_NOWAIT
+#define PIORAN_TILE_FWD_NOWAIT 1      // no counter wait between a wavefront's LDS writes and its own reads of them (the LDS serves a wavefront in order): -0.3 %, same box
+#endif
+#if PIORAN_TILE_FWD_NOWAIT
+#define PIORAN_TILE_FWD_ORDER() asm volatile("" ::: "memory")
+#else
+#define PIORAN_TILE_FWD_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+#ifndef PIORAN_TILE_QUADALL
+#define PIORAN_TILE_QUADALL 1     // a quadratic-form accumulator per block column, the y row's picked after the loop: -0.8 %, same box
+#endif
+#ifndef PIORAN_TILE_RAGFIX
+#define PIORAN_TILE_RAGFIX 1      // the ragged window's mask once per window under its wave-uniform test: -0.9 %, same box
+#endif
+#ifndef PIORAN_TILE_YSFIX
+#define PIORAN_TILE_YSFIX 1       // the per-draw series as a fix-up of X' under its wave-uniform test instead of a select per block column and step: -0.7 %, same box
+#endif
+#ifndef PIORAN_TILE_VHA      // compile-time switches of measured choices (tools/ab_variant_lib.py builds the other side for a same-box A/B)
+#define PIORAN_TILE_VHA 1
+#endif
 constexpr int kTileMaxTerms = 64;
 constexpr int kTileWaves = 4;      // wavefronts (= draws) per workgroup
 // ... of the reverse mode: T_k and T- of a draw are 45 KB (53 with d/d(c, d)) of LDS at four block columns — three draws fit a CU, not four
@@ -254,6 +274,11 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
     for (int Jc = 0; Jc < NB; ++Jc) mu_sel[Jc] = (Jc == Jy && c16 == ry) ? mu : 0.0;
     const int64_t k_ragged = (N % KW) ? NW - 1 : NW;   // the window whose steps past N are padding (none if N is a multiple of 16)
     double quad = 0.0;                 // meaningful in the y-row lanes
+#if PIORAN_TILE_QUADALL
+    double quadb[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) quadb[I] = 0.0;
+#endif
     double Pm = 1.0;                   // per lane (step c16 of every window): running product of |D| (sign of D_1 kept: :126)
     int Pe = 0;
     bool nonpd = false;
@@ -275,6 +300,27 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
             d4* gtk = reinterpret_cast<d4*>(p.gw + ((b * NW + k) * NT) * 256);      // [tile][lane][register]: 32 bytes per lane, two 16-byte stores
 #pragma unroll
             for (int i = 0; i < NT; ++i) gtk[i * 64 + lane] = T[i];
+        }
+        // (C_K / C) o v of the window: up to three block columns all of it now, behind the matrix instructions of M' (round 6: fetched a block ahead inside the
+        // G phase before, its wait stood right behind the issue); more block columns: a block ahead as before (registers)
+        constexpr bool VHA = PIORAN_TILE_VHA && NB <= 3;
+        [[maybe_unused]] double vha[VHA ? NB : 1][4];
+        if constexpr (VHA) {
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) vha[I][g] = tile_bload(rs_tab, lane8, wso + (2 * NB * 256 + (I * 4 + g) * 64) * 8);
+#if PIORAN_TILE_RAGFIX
+            // the padded steps of the last, ragged window: V^' - mu = 0 there.  Once, under the wave-uniform test, on the loaded values (as a select inside the
+            // block-column loop: four v_cndmask per block column and step in EVERY window, 48 of the ~520 vector instructions)
+            if (k == k_ragged) {
+#pragma unroll
+                for (int I = 0; I < NB; ++I)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (k * KW + 4 * g + q >= N) vha[I][g] = mu_sel[I];
+            }
+#endif
         }
         // ---- M' = U~' T: the lower tiles from registers, the upper ones as transposed reads of their LDS copies -------------------
         d4 x[NB];
@@ -300,8 +346,10 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
         //      (C_K / C) o v is fetched a block ahead) ------------------------------------------------------------------------
         d4 G = {0.0, 0.0, 0.0, 0.0};
         double vh[4];
+        if constexpr (!VHA) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) vh[g] = tile_bload(rs_tab, lane8, wso + (2 * NB * 256 + g * 64) * 8);
+            for (int g = 0; g < 4; ++g) vh[g] = tile_bload(rs_tab, lane8, wso + (2 * NB * 256 + g * 64) * 8);
+        }
         double ysv[4] = {0.0, 0.0, 0.0, 0.0};     // per-draw series: read here, under the wave-uniform test (inside the block-column loop the compiler turns the
         if (has_series) {                         // test into a select and reads sw.ys for every block column, a wait each — also when there is no series)
 #pragma unroll
@@ -311,7 +359,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
         for (int Jc = 0; Jc < NB; ++Jc) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 18 + c16] = x[Jc][g];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PIORAN_TILE_FWD_ORDER();
             double mb[4];   // M [row 16 Jc + 4 ks + q][step c16]
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) mb[ks] = sw.scr[c16 * 18 + 4 * ks + q];
@@ -321,19 +369,45 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
             for (int ks = 0; ks < 4; ++ks) G = __builtin_amdgcn_mfma_f64_16x16x4f64(Uf[Jc][ks], mb[ks], G, 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                double v = vh[g];
+                double v;
+                if constexpr (VHA) v = vha[Jc][g]; else v = vh[g];
+#if !PIORAN_TILE_YSFIX
                 if (has_series && Jc == Jy && c16 == ry) v = ysv[g];     // (the table's y row holds the shared series)
+#endif
                 v -= mu_sel[Jc];
-                if (k == k_ragged && k * KW + 4 * g + q >= N) v = 0.0;     // (wave-uniform test first: only the last, ragged window pays for the mask)
+#if PIORAN_TILE_RAGFIX
+                if constexpr (!VHA)      // (four block columns and more: (C_K / C) o v arrives a block ahead; a forced branch per block there costs more than the selects — 16.7 -> 21.9 ms)
+#endif
+                if (k == k_ragged && k * KW + 4 * g + q >= N) v = 0.0;
                 x[Jc][g] = fma(-ckc, x[Jc][g], v);
                 asm volatile("" : "+v"(x[Jc][g]));   // formed HERE: left to itself the compiler sinks these FMAs below the LDL' and keeps (C_K / C) o v live across it
             }
-            if (Jc + 1 < NB) {
+            if constexpr (!VHA) {
+                if (Jc + 1 < NB) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) vh[g] = tile_bload(rs_tab, lane8, wso + (2 * NB * 256 + ((Jc + 1) * 4 + g) * 64) * 8);
+                    for (int g = 0; g < 4; ++g) vh[g] = tile_bload(rs_tab, lane8, wso + (2 * NB * 256 + ((Jc + 1) * 4 + g) * 64) * 8);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#if PIORAN_TILE_YSFIX
+        // per-draw series: X' = V^' - C_K o M' took the table's (shared) series in the y row; the draw's own replaces it here, under the wave-uniform test — as a
+        // select inside the block-column loop it cost 24 v_cndmask per window whether there is a series or not
+        if (has_series) {
+            static_for<0, NB>([&](auto Jcc) __attribute__((always_inline)) {
+                constexpr int Jc = decltype(Jcc)::value;
+                if (Jc == Jy) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        double vt;
+                        if constexpr (VHA) vt = vha[Jc][g]; else vt = tile_bload(rs_tab, lane8, wso + (2 * NB * 256 + (Jc * 4 + g) * 64) * 8);
+                        const bool pad = k == k_ragged && k * KW + 4 * g + q >= N;
+                        if (c16 == ry && !pad) x[Jc][g] += ysv[g] - vt;
+                    }
+                }
+            });
+        }
+#endif
         PIORAN_TSTAMP(2);
         PIORAN_TSTAMP(3);
         // ---- Sigma = A - G, Sigma = L D L', L^-1 ----------------------------------------------------------------------------
@@ -344,7 +418,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
             for (int g = 0; g < 4; ++g) sw.scr[(4 * g + q) * 16 + c16] = ((on_diag && g == gd) ? dg : apre[g]) - G[g];
         }
         if (k + 1 < NW) fetch_A(k + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIORAN_TILE_FWD_ORDER();
         double m[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) m[j] = sw.scr[j * 16 + c16];
@@ -360,7 +434,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
 #pragma unroll
             for (int j = 0; j < 16; j += 2) dst[j / 2] = double2{m[j], m[j + 1]};
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIORAN_TILE_FWD_ORDER();
         double li[4], idv[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -419,7 +493,11 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 ysc[g] = yt[Jc][g] * idv[g];
+#if PIORAN_TILE_QUADALL
+                quadb[Jc] = fma(yt[Jc][g], ysc[g], quadb[Jc]);         // z_n^2 / D_n (== y'K^-1 y, :333) of EVERY block column; the y row's is picked after the loop
+#else                                                                  // (picked here — `if (Jc == Jy)` — it is an FMA and two v_cndmask per block column and step)
                 if (Jc == Jy) quad = fma(yt[Jc][g], ysc[g], quad);     // z_n^2 / D_n (== y'K^-1 y, :333), in the y-row lanes
+#endif
             }
 #pragma unroll
             for (int I = Jc; I < NB; ++I) {
@@ -435,12 +513,17 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
             __builtin_amdgcn_sched_barrier(0);
         }
         PIORAN_TSTAMP(8);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIORAN_TILE_FWD_ORDER();
     }
 
     PIORAN_TSTAMP_FLUSH
     // ---- result ------------------------------------------------------------------------------------------------------------
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if PIORAN_TILE_QUADALL
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+        if (I == Jy) quad = quadb[I];
+#endif
     if (c16 == ry) sw.scr[q] = quad;
     if (q == 0) sw.scr[16 + c16] = log(Pm) + (double)Pe * 0.6931471805599453094;
     const bool any_nonpd = __builtin_amdgcn_ballot_w64(nonpd) != 0;
