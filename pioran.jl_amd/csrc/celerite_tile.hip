@@ -50,6 +50,9 @@ namespace {
 #else
 #define PIORAN_TILE_FWD_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #endif
+#ifndef PIORAN_TILE_RAGFIX4
+#define PIORAN_TILE_RAGFIX4 1     // ... at four block columns and more as a fix-up after the loop with the values loaded again: DRWCelerite-20 -1.5 %, same box
+#endif
 #ifndef PIORAN_TILE_QUADALL
 #define PIORAN_TILE_QUADALL 1     // a quadratic-form accumulator per block column, the y row's picked after the loop: -0.8 %, same box
 #endif
@@ -375,10 +378,12 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
                 if (has_series && Jc == Jy && c16 == ry) v = ysv[g];     // (the table's y row holds the shared series)
 #endif
                 v -= mu_sel[Jc];
-#if PIORAN_TILE_RAGFIX
+#if PIORAN_TILE_RAGFIX && !PIORAN_TILE_RAGFIX4
                 if constexpr (!VHA)      // (four block columns and more: (C_K / C) o v arrives a block ahead; a forced branch per block there costs more than the selects — 16.7 -> 21.9 ms)
 #endif
+#if !PIORAN_TILE_RAGFIX4
                 if (k == k_ragged && k * KW + 4 * g + q >= N) v = 0.0;
+#endif
                 x[Jc][g] = fma(-ckc, x[Jc][g], v);
                 asm volatile("" : "+v"(x[Jc][g]));   // formed HERE: left to itself the compiler sinks these FMAs below the LDL' and keeps (C_K / C) o v live across it
             }
@@ -390,6 +395,21 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#if PIORAN_TILE_RAGFIX4
+        // four block columns and more: the padded steps of the last, ragged window took V^' - mu like the others; taken back here, once, with the table's values
+        // loaded again (a load cannot be speculated: this stays a branch)
+        if constexpr (!VHA) {
+            if (k == k_ragged) {
+#pragma unroll
+                for (int Jc = 0; Jc < NB; ++Jc)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const double vt = tile_bload(rs_tab, lane8, wso + (2 * NB * 256 + (Jc * 4 + g) * 64) * 8);
+                        if (k * KW + 4 * g + q >= N) x[Jc][g] -= vt - mu_sel[Jc];
+                    }
+            }
+        }
+#endif
 #if PIORAN_TILE_YSFIX
         // per-draw series: X' = V^' - C_K o M' took the table's (shared) series in the y row; the draw's own replaces it here, under the wave-uniform test — as a
         // select inside the block-column loop it cost 24 v_cndmask per window whether there is a series or not
