@@ -50,6 +50,9 @@ namespace {
 #else
 #define PIORAN_TILE_FWD_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #endif
+#ifndef PIORAN_TILE_ADJ_RAGFIX
+#define PIORAN_TILE_ADJ_RAGFIX 1   // the same in the reverse kernel: 4096 chains of SHO-20 45.60 -> 45.33 ms, same box
+#endif
 #ifndef PIORAN_TILE_RAGFIX4
 #define PIORAN_TILE_RAGFIX4 1     // ... at four block columns and more as a fix-up after the loop with the values loaded again: DRWCelerite-20 -1.5 %, same box
 #endif
@@ -768,6 +771,15 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
         for (int I = 0; I < NB; ++I)
 #pragma unroll
             for (int g = 0; g < 4; ++g) vhs[I][g] = tile_bload(rs_tab, lane8, wso + (2 * NB * 256 + (I * 4 + g) * 64) * 8);
+#if PIORAN_TILE_ADJ_RAGFIX
+        if (k == k_ragged) {        // the padded steps of the last, ragged window: V^' - mu = 0 there — once, on the loaded values (celerite_tile_kernel, PIORAN_TILE_RAGFIX)
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (k * KW + 4 * g + q >= N) vhs[I][g] = mu_sel[I];
+        }
+#endif
         // ---- this window's inputs ---------------------------------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < NCK; ++i)
@@ -849,7 +861,9 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     double v = vhs[Jc][g] - mu_sel[Jc];
+#if !PIORAN_TILE_ADJ_RAGFIX
                     if (k == k_ragged && k * KW + 4 * g + q >= N) v = 0.0;
+#endif
                     x[Jc][g] = fma(-ckc[Jc], x[Jc][g], v);
                     asm volatile("" : "+v"(x[Jc][g]));
                 }
@@ -873,7 +887,9 @@ __global__ void __launch_bounds__((64 * tile_adj_waves<NB, CD>()), 1) celerite_t
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 double v = vhs[Jc][g] - mu_sel[Jc];
+#if !PIORAN_TILE_ADJ_RAGFIX
                 if (k == k_ragged && k * KW + 4 * g + q >= N) v = 0.0;
+#endif
                 x[Jc][g] = fma(-ckc, x[Jc][g], v);
                 asm volatile("" : "+v"(x[Jc][g]));
             }
