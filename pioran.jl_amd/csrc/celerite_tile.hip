@@ -65,6 +65,12 @@ namespace {
 #ifndef PIORAN_TILE_YSFIX
 #define PIORAN_TILE_YSFIX 1       // the per-draw series as a fix-up of X' under its wave-uniform test instead of a select per block column and step: -0.7 %, same box
 #endif
+#ifndef PIORAN_TILE_BIG_VHA
+#define PIORAN_TILE_BIG_VHA 1      // five and six block columns (one wavefront per SIMD, 512 registers): both preloads, SHO-40 38.0 -> 32.4 ms per 4096 draws, same box
+#endif
+#ifndef PIORAN_TILE_BIG_CKP
+#define PIORAN_TILE_BIG_CKP 1
+#endif
 #ifndef PIORAN_TILE_VHA      // compile-time switches of measured choices (tools/ab_variant_lib.py builds the other side for a same-box A/B)
 #define PIORAN_TILE_VHA 1
 #endif
@@ -309,7 +315,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
         }
         // (C_K / C) o v of the window: up to three block columns all of it now, behind the matrix instructions of M' (round 6: fetched a block ahead inside the
         // G phase before, its wait stood right behind the issue); more block columns: a block ahead as before (registers)
-        constexpr bool VHA = PIORAN_TILE_VHA && NB <= 3;
+        constexpr bool VHA = PIORAN_TILE_VHA && (NB <= 3 || (PIORAN_TILE_BIG_VHA && NB >= 5));
         [[maybe_unused]] double vha[VHA ? NB : 1][4];
         if constexpr (VHA) {
 #pragma unroll
@@ -491,7 +497,7 @@ __global__ void __launch_bounds__(64 * kTileWaves, NB <= 4 ? 2 : 1) celerite_til
         // C_K of the tiles' rows and columns: up to three block columns read once, in front of the tiles (round 6: left at its uses, every tile starts with an
         // LDS read and a wait for it; SHO-20 10.18 -> 9.97 ms per 4096 draws).  With four block columns the 20 values cost spilled registers (DRWCelerite-20
         // 15.99 -> 16.33 ms): read per tile there, as before.
-        constexpr bool CKP = NB <= 3;
+        constexpr bool CKP = NB <= 3 || (PIORAN_TILE_BIG_CKP && NB >= 5);
         [[maybe_unused]] double ckrow[CKP ? NB : 1][4], ckcol[CKP ? NB : 1];
         if constexpr (CKP) {
 #pragma unroll
